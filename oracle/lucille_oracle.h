@@ -1,0 +1,117 @@
+/*
+ * lucille_oracle.h -- CPU restatement of lucille's BVH build / traversal /
+ * ray-triangle hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The product (lucille_amd, the
+ * C-ABI library liblucille_hip.so) never links, loads or calls anything here.
+ *
+ * Parity status: PINNED.  The restatement is checked bit-for-bit against the
+ * compiled reference (oracle/_ref, built from /root/reference by
+ * oracle/Makefile) in tests/test_oracle_vs_ref.py, and against the golden
+ * fixtures the compiled reference produced (tests/golden/, generator
+ * tests/golden/make_golden.py) in tests/test_oracle_golden.py.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the lucille source tree).
+ */
+#ifndef LUCILLE_ORACLE_H
+#define LUCILLE_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LO_MISS 0xFFFFFFFFu
+
+typedef struct lo_scene lo_scene_t;
+
+/* per-batch traversal counters, same definitions as ri_bvh_stat_traversal_t
+ * (src/render/bvh.h:117-129, incremented at bvh.c:460,829-831,845,1129,1149) */
+typedef struct lo_counters {
+    uint64_t ninner_node_traversals;
+    uint64_t nleaf_node_traversals;
+    uint64_t ntested_triangles;
+    uint64_t nactually_hit_triangles;
+    uint64_t nrays;
+} lo_counters_t;
+
+typedef struct lo_tree_stats {
+    uint64_t ninner;
+    uint64_t nleaf;
+    uint64_t max_depth;
+    uint64_t max_leaf_tris;
+    uint64_t ntriangles;
+} lo_tree_stats_t;
+
+lo_scene_t *lo_scene_new(void);
+void        lo_scene_free(lo_scene_t *scene);
+
+/* One call == one ri_geom_t appended to scene->geom_list
+ * (src/render/scene.c:144-148).  positions are xyz triples (the reference
+ * stores double[4]; w is never read on this path). */
+int lo_scene_add_mesh(lo_scene_t *scene, uint32_t npositions,
+                      const double *positions_xyz, uint32_t nindices,
+                      const uint32_t *indices);
+
+/* ri_bvh_build (src/render/bvh.c:276-379).  leaf_size<=0 -> BVH_NTRIS_LEAF=16 */
+int lo_scene_build(lo_scene_t *scene);
+
+uint64_t lo_scene_ntriangles(const lo_scene_t *scene);
+void     lo_scene_tree_stats(const lo_scene_t *scene, lo_tree_stats_t *out);
+/* scene bbox after margin (bvh->bmin/bmax, bvh.c:325-340) */
+void     lo_scene_bbox(const lo_scene_t *scene, double bmin[3], double bmax[3]);
+
+/* Flattened triangle list in reference primID order (create_triangle_list,
+ * bvh.c:1736-1826): 9 doubles per triangle (v0 v1 v2), plus (geom ordinal,
+ * index=3*i) per triangle. */
+void lo_scene_get_triangles(const lo_scene_t *scene, double *v9,
+                            uint32_t *geom_ord, uint32_t *index);
+
+/*
+ * ri_bvh_intersect minus the ri_intersection_state_build epilogue
+ * (bvh.c:430-542): closest hit over a ray batch.  prim = global primitive id
+ * in create_triangle_list order, LO_MISS on miss; t=1e38,u=v=0 on miss.
+ * nthreads>1 slices the batch contiguously over pthreads.
+ * counters may be NULL.
+ */
+void lo_intersect_batch(const lo_scene_t *scene, size_t n,
+                        const double *org_xyz, const double *dir_xyz,
+                        uint32_t *prim, double *t, double *u, double *v,
+                        lo_counters_t *counters, int nthreads);
+
+/* brute force arg-min over ALL triangles with the triangle_isect arithmetic
+ * (bvh.c:730-791); ties: last equal-t triangle in primID order wins (same
+ * rule as within a reference leaf, bvh.c:780). */
+void lo_brute_force_batch(const lo_scene_t *scene, size_t n,
+                          const double *org_xyz, const double *dir_xyz,
+                          uint32_t *prim, double *t, double *u, double *v,
+                          int nthreads);
+
+/* the S-soup generator of SURVEY.md Appendix C (xorshift64 13/7/17).
+ * state is in/out so the ray stream continues after the triangles. */
+void lo_soup_triangles(uint64_t *state, uint32_t ntri, double half_extent,
+                       double *positions_xyz /* 9*ntri */,
+                       uint32_t *indices /* 3*ntri */);
+void lo_soup_rays(uint64_t *state, size_t nrays, double *org_xyz,
+                  double *dir_xyz);
+
+/* ------------------------------------------------------------------ */
+/* AO transport / camera restatement (see lucille_oracle_ao.c)        */
+/* ------------------------------------------------------------------ */
+
+typedef struct lo_camera {
+    int    width, height;
+    double fov;              /* degrees */
+    int    rh;               /* Orientation "rh" => 1 */
+    double cam2world[16];    /* row-major 4x4, row-vector convention */
+} lo_camera_t;
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,230 @@
+"""ctypes bindings for the CHECKERS under oracle/ (test infrastructure only).
+
+  Oracle  -> oracle/liblucille_oracle.so   this repo's CPU restatement
+  RefLib  -> oracle/_ref/liblucille_ref*.so the compiled reference (built only
+             where /root/reference exists; the .so travels to the GPU box)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module.  Nothing under lucille_amd/ does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MISS = 0xFFFFFFFF
+
+_dp = C.POINTER(C.c_double)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(ty) if a is not None else None
+
+
+def build_oracle(force=False):
+    so = os.path.join(HERE, "liblucille_oracle.so")
+    srcs = [os.path.join(HERE, f) for f in ("lucille_oracle.c", "lucille_oracle_ao.c", "lucille_oracle.h")]
+    stale = (not os.path.exists(so)) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", HERE, "liblucille_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def build_ref():
+    """(Re)build oracle/_ref from /root/reference when that tree is present."""
+    if os.path.isdir(os.environ.get("LUCILLE_REF", "/root/reference") + "/src/render"):
+        subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
+        return True
+    return False
+
+
+def ref_available(stat=False):
+    return os.path.exists(os.path.join(HERE, "_ref", "liblucille_ref_stat.so" if stat else "liblucille_ref.so"))
+
+
+class Counters(C.Structure):
+    _fields_ = [("ninner", C.c_uint64), ("nleaf", C.c_uint64), ("ntested", C.c_uint64),
+                ("nhit", C.c_uint64), ("nrays", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class TreeStats(C.Structure):
+    _fields_ = [("ninner", C.c_uint64), ("nleaf", C.c_uint64), ("max_depth", C.c_uint64),
+                ("max_leaf_tris", C.c_uint64), ("ntriangles", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build_oracle())
+        L.lo_scene_new.restype = C.c_void_p
+        L.lo_scene_free.argtypes = [C.c_void_p]
+        L.lo_scene_add_mesh.argtypes = [C.c_void_p, C.c_uint32, _dp, C.c_uint32, _u32p]
+        L.lo_scene_build.argtypes = [C.c_void_p]
+        L.lo_scene_ntriangles.argtypes = [C.c_void_p]
+        L.lo_scene_ntriangles.restype = C.c_uint64
+        L.lo_scene_tree_stats.argtypes = [C.c_void_p, C.POINTER(TreeStats)]
+        L.lo_scene_bbox.argtypes = [C.c_void_p, _dp, _dp]
+        L.lo_scene_get_triangles.argtypes = [C.c_void_p, _dp, _u32p, _u32p]
+        L.lo_intersect_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _u32p, _dp, _dp, _dp,
+                                         C.POINTER(Counters), C.c_int]
+        L.lo_brute_force_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _u32p, _dp, _dp, _dp, C.c_int]
+        L.lo_soup_triangles.argtypes = [_u64p, C.c_uint32, C.c_double, _dp, _u32p]
+        L.lo_soup_rays.argtypes = [_u64p, C.c_size_t, _dp, _dp]
+        _lib = L
+    return _lib
+
+
+SOUP_SEED = 88172645463325252
+
+
+def soup(ntri, nrays, half_extent=0.005, seed=SOUP_SEED):
+    """S-soup generator: triangles then rays from ONE
+    xorshift64 stream.  Returns (positions[3*ntri,3], indices[3*ntri], org[n,3], dir[n,3])."""
+    L = lib()
+    st = C.c_uint64(seed)
+    P = np.empty((3 * ntri, 3), np.float64)
+    idx = np.empty(3 * ntri, np.uint32)
+    L.lo_soup_triangles(C.byref(st), ntri, half_extent, _p(P, _dp), _p(idx, _u32p))
+    org = np.empty((nrays, 3), np.float64)
+    dr = np.empty((nrays, 3), np.float64)
+    L.lo_soup_rays(C.byref(st), nrays, _p(org, _dp), _p(dr, _dp))
+    return P, idx, org, dr
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class Oracle:
+    """The CPU restatement (oracle/lucille_oracle.c)."""
+
+    def __init__(self):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.lo_scene_new())
+
+    def __del__(self):
+        try:
+            self.L.lo_scene_free(self.h)
+        except Exception:
+            pass
+
+    def add_mesh(self, positions, indices):
+        P = _c(positions, np.float64).reshape(-1, 3)
+        I = _c(indices, np.uint32).reshape(-1)
+        self.L.lo_scene_add_mesh(self.h, P.shape[0], _p(P, _dp), I.shape[0], _p(I, _u32p))
+
+    def build(self):
+        self.L.lo_scene_build(self.h)
+
+    @property
+    def ntriangles(self):
+        return int(self.L.lo_scene_ntriangles(self.h))
+
+    def tree_stats(self):
+        s = TreeStats()
+        self.L.lo_scene_tree_stats(self.h, C.byref(s))
+        return s.as_dict()
+
+    def bbox(self):
+        a = np.empty(3); b = np.empty(3)
+        self.L.lo_scene_bbox(self.h, _p(a, _dp), _p(b, _dp))
+        return a, b
+
+    def triangles(self):
+        n = self.ntriangles
+        v9 = np.empty((n, 9), np.float64); g = np.empty(n, np.uint32); ix = np.empty(n, np.uint32)
+        self.L.lo_scene_get_triangles(self.h, _p(v9, _dp), _p(g, _u32p), _p(ix, _u32p))
+        return v9, g, ix
+
+    def _run(self, fn, org, dr, counters, nthreads):
+        org = _c(org, np.float64).reshape(-1, 3); dr = _c(dr, np.float64).reshape(-1, 3)
+        n = org.shape[0]
+        prim = np.empty(n, np.uint32); t = np.empty(n); u = np.empty(n); v = np.empty(n)
+        if fn is self.L.lo_intersect_batch:
+            c = Counters() if counters else None
+            fn(self.h, n, _p(org, _dp), _p(dr, _dp), _p(prim, _u32p), _p(t, _dp), _p(u, _dp), _p(v, _dp),
+               C.byref(c) if c is not None else None, nthreads)
+            return (prim, t, u, v, c.as_dict()) if counters else (prim, t, u, v)
+        fn(self.h, n, _p(org, _dp), _p(dr, _dp), _p(prim, _u32p), _p(t, _dp), _p(u, _dp), _p(v, _dp), nthreads)
+        return prim, t, u, v
+
+    def intersect(self, org, dr, counters=False, nthreads=1):
+        return self._run(self.L.lo_intersect_batch, org, dr, counters, nthreads)
+
+    def brute_force(self, org, dr, nthreads=1):
+        return self._run(self.L.lo_brute_force_batch, org, dr, False, nthreads)
+
+
+class RefLib:
+    """The compiled reference (oracle/_ref).  One global scene per process."""
+
+    def __init__(self, stat=False):
+        name = "liblucille_ref_stat.so" if stat else "liblucille_ref.so"
+        path = os.path.join(HERE, "_ref", name)
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        L = C.CDLL(path)
+        L.lref_scene_add_mesh.argtypes = [C.c_uint32, _dp, C.c_uint32, _u32p]
+        L.lref_intersect_batch.argtypes = [C.c_size_t, _dp, _dp, _u32p, _dp, _dp, _dp, _dp]
+        L.lref_tree_stats.argtypes = [_u64p]
+        L.lref_counters_get.argtypes = [_u64p]
+        L.lref_scene_bbox.argtypes = [_dp, _dp]
+        L.lref_record_stop.restype = C.c_size_t
+        L.lref_record_size.restype = C.c_size_t
+        L.lref_record_copy.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+        self.L = L
+        L.lref_init()
+        L.lref_scene_reset()
+
+    def reset(self):
+        self.L.lref_scene_reset()
+
+    def add_mesh(self, positions, indices):
+        P = _c(positions, np.float64).reshape(-1, 3)
+        I = _c(indices, np.uint32).reshape(-1)
+        self.L.lref_scene_add_mesh(P.shape[0], _p(P, _dp), I.shape[0], _p(I, _u32p))
+
+    def build(self):
+        assert self.L.lref_scene_build() == 0
+
+    def tree_stats(self):
+        o = np.zeros(5, np.uint64)
+        self.L.lref_tree_stats(_p(o, _u64p))
+        return dict(zip(("ninner", "nleaf", "max_depth", "max_leaf_tris", "ntriangles"), map(int, o)))
+
+    def bbox(self):
+        a = np.empty(3); b = np.empty(3)
+        self.L.lref_scene_bbox(_p(a, _dp), _p(b, _dp))
+        return a, b
+
+    def intersect(self, org, dr, state=False, counters=False):
+        org = _c(org, np.float64).reshape(-1, 3); dr = _c(dr, np.float64).reshape(-1, 3)
+        n = org.shape[0]
+        prim = np.empty(n, np.uint32); t = np.empty(n); u = np.empty(n); v = np.empty(n)
+        st = np.empty((n, 9)) if state else None
+        if counters:
+            self.L.lref_counters_clear()
+        self.L.lref_intersect_batch(n, _p(org, _dp), _p(dr, _dp), _p(prim, _u32p), _p(t, _dp), _p(u, _dp),
+                                    _p(v, _dp), _p(st, _dp))
+        out = [prim, t, u, v]
+        if state:
+            out.append(st)
+        if counters:
+            o = np.zeros(5, np.uint64)
+            self.L.lref_counters_get(_p(o, _u64p))
+            out.append(dict(zip(("ninner", "nleaf", "ntested", "nhit", "nrays"), map(int, o))))
+        return tuple(out)

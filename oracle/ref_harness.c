@@ -1,0 +1,267 @@
+/*
+ * ref_harness.c -- thin ctypes-friendly driver around the COMPILED REFERENCE.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is this repository's own code; it is
+ * compiled by oracle/Makefile together with the reference's sources *where
+ * they lie* under /root/reference (never copied) into
+ * oracle/_ref/liblucille_ref.so.  It includes the reference's public headers
+ * at build time and calls the reference's own entry points:
+ *
+ *   ri_parallel_init / ri_render_init / ri_render_get   (base/parallel.h, render/render.h:104-105)
+ *   ri_geom_new / ri_geom_add_positions / _add_indices  (render/geom.h)
+ *   ri_scene_new / ri_scene_add_geom / ri_scene_build_accel (render/scene.h:60-96)
+ *   ri_accel_bind(RI_ACCEL_BVH)                          (render/accel.h)
+ *   ri_raytrace                                          (render/raytrace.h:46-49)
+ *
+ * It replaces exactly one reference object, render/accel.o, with the
+ * ri_accel_new/free/bind below so that the accelerator's intersect() can be
+ * wrapped by a recorder (the (org,dir)->(hit) stream the reference's own AO
+ * transport produces is what tests/golden/ao_c1_* holds).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+
+#include "ri.h"
+#include "parallel.h"
+#include "log.h"
+#include "memory.h"
+#include "render.h"
+#include "scene.h"
+#include "geom.h"
+#include "accel.h"
+#include "bvh.h"
+#include "ugrid.h"
+#include "raytrace.h"
+#include "ray.h"
+#include "intersection_state.h"
+
+#define LREF_MISS 0xFFFFFFFFu
+
+/* ---------------------------------------------------------------------- */
+/* replacement for render/accel.c (ri_accel_new/free/bind, accel.c:28-109) */
+/* with a recording wrapper around ri_bvh_intersect                        */
+/* ---------------------------------------------------------------------- */
+
+typedef struct {
+    double   org[3], dir[3];
+    double   t, u, v;
+    uint32_t hit, geom, index, pad;
+} lref_record_t;   /* 88 bytes */
+
+static lref_record_t *g_rec      = NULL;
+static size_t         g_rec_n    = 0, g_rec_cap = 0;
+static int            g_rec_on   = 0;
+
+#define LREF_MAX_GEOMS 4096
+static ri_geom_t *g_geoms[LREF_MAX_GEOMS];
+static uint32_t   g_geom_base[LREF_MAX_GEOMS + 1];
+static uint32_t   g_ngeoms = 0;
+
+static uint32_t geom_ordinal(const ri_geom_t *g)
+{
+    uint32_t i;
+    for (i = 0; i < g_ngeoms; i++) if (g_geoms[i] == g) return i;
+    return LREF_MISS;
+}
+
+static int recording_intersect(void *accel, ri_ray_t *ray,
+                               ri_intersection_state_t *state, void *user)
+{
+    double o[3], d[3];
+    int hit;
+    o[0] = ray->org[0]; o[1] = ray->org[1]; o[2] = ray->org[2];
+    d[0] = ray->dir[0]; d[1] = ray->dir[1]; d[2] = ray->dir[2];
+    hit = ri_bvh_intersect(accel, ray, state, user);
+    if (g_rec_on) {
+        lref_record_t *r;
+        if (g_rec_n == g_rec_cap) {
+            g_rec_cap = g_rec_cap ? g_rec_cap * 2 : (1u << 16);
+            g_rec = (lref_record_t *)realloc(g_rec, g_rec_cap * sizeof(*g_rec));
+        }
+        r = &g_rec[g_rec_n++];
+        memcpy(r->org, o, sizeof(o)); memcpy(r->dir, d, sizeof(d));
+        r->hit = (uint32_t)hit; r->pad = 0;
+        if (hit) { r->t = state->t; r->u = state->u; r->v = state->v;
+                   r->geom = geom_ordinal(state->geom); r->index = state->index; }
+        else     { r->t = 1.0e38; r->u = r->v = 0.0; r->geom = LREF_MISS; r->index = 0; }
+    }
+    return hit;
+}
+
+ri_accel_t *ri_accel_new()
+{
+    ri_accel_t *p = (ri_accel_t *)ri_mem_alloc(sizeof(ri_accel_t));
+    memset(p, 0, sizeof(ri_accel_t));
+    return p;
+}
+
+void ri_accel_free(ri_accel_t *accel)
+{
+    if (accel) {
+        if (accel->free) accel->free(accel->data);
+        ri_mem_free(accel);
+    }
+}
+
+int ri_accel_bind(ri_accel_t *accel, int method)
+{
+    switch (method) {
+    case RI_ACCEL_UGRID:
+        accel->build = ri_ugrid_build; accel->free = ri_ugrid_free;
+        accel->intersect = ri_ugrid_intersect;
+        break;
+    case RI_ACCEL_BVH:
+        accel->build = ri_bvh_build; accel->free = ri_bvh_free;
+        accel->intersect = recording_intersect;
+        break;
+    default:
+        return -1;
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------- */
+/* direct-scene driver (pattern of src/testbed/main.cpp:53-65)             */
+/* ---------------------------------------------------------------------- */
+
+static int g_inited = 0;
+
+int lref_init(void)
+{
+    if (!g_inited) {
+        int argc = 1; char *argv0 = (char *)"lref"; char **argv = &argv0;
+        ri_parallel_init(&argc, &argv);
+        ri_render_init();
+        ri_log_set_level(RI_LOG_LEVEL_ERROR);
+        g_inited = 1;
+    }
+    return 0;
+}
+
+/* start a fresh scene on the global renderer (old one is leaked on purpose:
+ * ri_bvh_free only frees the header, bvh.c:381-387) */
+int lref_scene_reset(void)
+{
+    lref_init();
+    ri_render_get()->scene = ri_scene_new();
+    g_ngeoms = 0; g_geom_base[0] = 0;
+    return 0;
+}
+
+int lref_scene_add_mesh(uint32_t npos, const double *pos_xyz, uint32_t nidx,
+                        const uint32_t *idx)
+{
+    ri_geom_t *g; ri_vector_t *P; uint32_t i;
+    if (g_ngeoms >= LREF_MAX_GEOMS) return -1;
+    g = ri_geom_new();
+    P = (ri_vector_t *)malloc(sizeof(ri_vector_t) * (npos ? npos : 1));
+    for (i = 0; i < npos; i++) {
+        P[i][0] = pos_xyz[3 * i + 0]; P[i][1] = pos_xyz[3 * i + 1];
+        P[i][2] = pos_xyz[3 * i + 2]; P[i][3] = 0.0;
+    }
+    if (npos) ri_geom_add_positions(g, npos, (const ri_vector_t *)P);
+    if (nidx) ri_geom_add_indices(g, nidx, idx);
+    free(P);
+    ri_scene_add_geom(ri_render_get()->scene, g);
+    g_geoms[g_ngeoms] = g;
+    g_geom_base[g_ngeoms + 1] = g_geom_base[g_ngeoms] + nidx / 3;
+    g_ngeoms++;
+    return 0;
+}
+
+int lref_scene_build(void)
+{
+    ri_scene_t *scene = ri_render_get()->scene;
+    if (ri_accel_bind(scene->accel, RI_ACCEL_BVH) != 0) return -1;
+    return ri_scene_build_accel(scene);
+}
+
+/* closest hit through the reference's own façade ri_raytrace().
+ * state9 (optional): P, Ng, Ns of the hit (9 doubles per ray) as produced by
+ * ri_intersection_state_build. */
+void lref_intersect_batch(size_t n, const double *org, const double *dir,
+                          uint32_t *prim, double *t, double *u, double *v,
+                          double *state9)
+{
+    size_t i; ri_render_t *render = ri_render_get();
+    for (i = 0; i < n; i++) {
+        ri_ray_t ray; ri_intersection_state_t st; int hit;
+        memset(&ray, 0, sizeof(ray)); memset(&st, 0, sizeof(st));
+        ray.org[0] = org[3 * i]; ray.org[1] = org[3 * i + 1]; ray.org[2] = org[3 * i + 2];
+        ray.dir[0] = dir[3 * i]; ray.dir[1] = dir[3 * i + 1]; ray.dir[2] = dir[3 * i + 2];
+        ray.thread_num = 0;
+        hit = ri_raytrace(render, &ray, &st);
+        if (hit) {
+            uint32_t g = geom_ordinal(st.geom);
+            prim[i] = g_geom_base[g] + st.index / 3;
+            t[i] = st.t; u[i] = st.u; v[i] = st.v;
+            if (state9) {
+                int k;
+                for (k = 0; k < 3; k++) {
+                    state9[9 * i + k] = st.P[k]; state9[9 * i + 3 + k] = st.Ng[k];
+                    state9[9 * i + 6 + k] = st.Ns[k];
+                }
+            }
+        } else {
+            prim[i] = LREF_MISS; t[i] = 1.0e38; u[i] = 0.0; v[i] = 0.0;
+            if (state9) memset(&state9[9 * i], 0, 9 * sizeof(double));
+        }
+    }
+}
+
+/* tree shape by walking the reference's own node structs (bvh.h:73-94) */
+static void walk(const ri_qbvh_node_t *n, uint64_t depth, uint64_t out[5])
+{
+    if (depth > out[2]) out[2] = depth;
+    if (n->is_leaf) {
+        uint32_t cnt = *((const uint32_t *)&n->bbox[0]);
+        out[1]++; if (cnt > out[3]) out[3] = cnt; out[4] += cnt;
+    } else {
+        out[0]++;
+        walk(n->child[0], depth + 1, out); walk(n->child[1], depth + 1, out);
+    }
+}
+
+/* out = {ninner, nleaf, max_depth, max_leaf_tris, ntriangles} */
+void lref_tree_stats(uint64_t out[5])
+{
+    ri_bvh_t *bvh = (ri_bvh_t *)ri_render_get()->scene->accel->data;
+    memset(out, 0, 5 * sizeof(uint64_t));
+    if (!bvh || bvh->empty) return;
+    walk(bvh->root, 0, out);
+}
+
+void lref_scene_bbox(double bmin[3], double bmax[3])
+{
+    ri_bvh_t *bvh = (ri_bvh_t *)ri_render_get()->scene->accel->data;
+    int k; for (k = 0; k < 3; k++) { bmin[k] = bvh->bmin[k]; bmax[k] = bvh->bmax[k]; }
+}
+
+/* traversal counters: meaningful only in the -DRI_BVH_TRACE_STATISTICS build
+ * (liblucille_ref_stat.so); g_stattrav is the reference's global (bvh.c:146) */
+#ifdef RI_BVH_TRACE_STATISTICS
+extern ri_bvh_stat_traversal_t g_stattrav;
+void lref_counters_clear(void) { memset(&g_stattrav, 0, sizeof(g_stattrav)); }
+void lref_counters_get(uint64_t out[5])
+{
+    out[0] = g_stattrav.ninner_node_traversals; out[1] = g_stattrav.nleaf_node_traversals;
+    out[2] = g_stattrav.ntested_triangles; out[3] = g_stattrav.nactually_hit_triangles;
+    out[4] = g_stattrav.nrays;
+}
+int lref_has_counters(void) { return 1; }
+#else
+void lref_counters_clear(void) {}
+void lref_counters_get(uint64_t out[5]) { memset(out, 0, 5 * sizeof(uint64_t)); }
+int lref_has_counters(void) { return 0; }
+#endif
+
+/* recorder control */
+void   lref_record_start(void) { g_rec_n = 0; g_rec_on = 1; }
+size_t lref_record_stop(void)  { g_rec_on = 0; return g_rec_n; }
+size_t lref_record_size(void)  { return sizeof(lref_record_t); }
+void   lref_record_copy(void *dst, size_t first, size_t count)
+{
+    memcpy(dst, g_rec + first, count * sizeof(lref_record_t));
+}
