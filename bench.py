@@ -1,0 +1,223 @@
+#!/usr/bin/env python
+"""bench.py -- the driver's benchmark contract for the lucille hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is ONE pass of the hot path (BVH traversal + ray/triangle intersection,
+closest-hit records prim/t/u/v) over one synthetic ray batch that is already
+resident in HBM.  Workload (BASELINE.json config 3, the one the north-star target
+"~1M-tri scene" is quoted on): S-soup-1M = 1,000,000 random triangles
+(SURVEY.md Appendix C generator, seed 88172645463325252), --rays incoherent rays
+per GPU (default 100M).  Weak scaling: every rank traces its own ray batch against
+a replicated BVH; no data-path collective (rays are independent).  Rank 0's batch
+is the canonical Appendix C ray stream; rank r>0 continues from a rank-derived
+xorshift state.
+
+One JSON line on rank 0: value = total Mrays/s over all ranks (max-over-ranks
+time), plus `roofline` (algorithmic bytes of the dominant kernel / its HIP-event
+duration vs the 8 TB/s HBM peak) and `cpu_baseline` (the compiled reference, or
+the oracle port, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
+B_IN, B_OUT, B_NODE, B_TRI = 32, 16, 64, 40   # SURVEY.md 8(d) algorithmic bytes
+
+
+def hip_event_timer():
+    """HIP events on an explicit stream, straight from libamdhip64 (torch.cuda.Event only
+    sees torch's current stream; the kernel is launched on the stream we pass)."""
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+    hip.hipEventSynchronize.argtypes = [C.c_void_p]
+    hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+    return hip
+
+
+def rank_state(seed_after_tris, rank):
+    if rank == 0:
+        return seed_after_tris
+    x = (seed_after_tris ^ (0x9E3779B97F4A7C15 * (rank + 1))) & 0xFFFFFFFFFFFFFFFF
+    x ^= (x >> 30); x = (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x ^= (x >> 27); x = (x * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    x ^= (x >> 31)
+    return x or 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rays", type=int, default=100_000_000, help="rays per GPU per step")
+    ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--half-extent", type=float, default=0.005)
+    ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--mode", choices=["closest", "any"], default="closest")
+    ap.add_argument("--cpu-rays", type=int, default=1_500_000, help="cpu_baseline sample size")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import lucille_amd as la
+    from lucille_amd import shard
+    # bench needs the synthetic generator, which lives with the checkers; it is used
+    # here only to MAKE inputs and (cpu_baseline leg) to time the CPU path
+    from oracle import pyoracle as po
+
+    rank, world, local = shard.init_process_group()
+    assert world == args.gpus, "launch with --nproc-per-node == --gpus"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # ---- synthetic inputs (host) -> HBM -----------------------------------------
+    L = po.lib()
+    st = C.c_uint64(po.SOUP_SEED)
+    P = np.empty((3 * args.tris, 3), np.float64); idx = np.empty(3 * args.tris, np.uint32)
+    L.lo_soup_triangles(C.byref(st), args.tris, args.half_extent, P.ctypes.data_as(C.POINTER(C.c_double)),
+                        idx.ctypes.data_as(C.POINTER(C.c_uint32)))
+    st = C.c_uint64(rank_state(st.value, rank))
+    n = args.rays
+    d_org = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    d_dir = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    chunk = 10_000_000
+    ho = np.empty((min(chunk, n), 3)); hd = np.empty((min(chunk, n), 3))
+    first_org = first_dir = None
+    for b in range(0, n, chunk):
+        m = min(chunk, n - b)
+        L.lo_soup_rays(C.byref(st), m, ho.ctypes.data_as(C.POINTER(C.c_double)), hd.ctypes.data_as(C.POINTER(C.c_double)))
+        d_org[b:b + m].copy_(torch.from_numpy(ho[:m])); d_dir[b:b + m].copy_(torch.from_numpy(hd[:m]))
+        if b == 0:
+            first_org = ho[:min(m, args.cpu_rays)].copy(); first_dir = hd[:min(m, args.cpu_rays)].copy()
+
+    acc = la.HipAccel(local)
+    acc.add_mesh(P, idx)
+    info = acc.commit()
+
+    mode = la.MODE_CLOSEST if args.mode == "closest" else la.MODE_ANY
+    out = acc.intersect_device(d_org, d_dir, mode=mode, variant=args.variant)   # allocates outputs (untimed)
+    torch.cuda.synchronize(dev)
+
+    # ---- algorithmic bytes per ray: counted launch on a sample (untimed) ---------
+    ns = min(n, 4_000_000)
+    _, cnt = acc.intersect_device(d_org[:ns], d_dir[:ns], mode=mode, variant=args.variant, counters=True)
+    n_nodes = cnt["nodes"] / ns; n_tris = cnt["tris"] / ns
+    b_out = B_OUT if mode == la.MODE_CLOSEST else 4
+    b_ray = B_IN + b_out + B_NODE * n_nodes + B_TRI * n_tris
+
+    # ---- timed region -------------------------------------------------------------
+    hip = hip_event_timer()
+    stream = torch.cuda.current_stream(dev)
+    sptr = C.c_void_p(stream.cuda_stream)
+    ev = [(C.c_void_p(), C.c_void_p()) for _ in range(args.steps)]
+    for a, b in ev:
+        hip.hipEventCreate(C.byref(a)); hip.hipEventCreate(C.byref(b))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        acc.intersect_device(d_org, d_dir, out=out, mode=mode, variant=args.variant)
+    barrier(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        hip.hipEventRecord(ev[k][0], sptr)
+        acc.intersect_device(d_org, d_dir, out=out, mode=mode, variant=args.variant)
+        hip.hipEventRecord(ev[k][1], sptr)
+    torch.cuda.synchronize(dev); barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kms = []
+    for a, b in ev:
+        ms = C.c_float(); hip.hipEventElapsedTime(C.byref(ms), a, b); kms.append(ms.value)
+    kernel_ms = float(np.mean(kms))
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        total_rays = n * world * args.steps
+        value = total_rays / elapsed / 1e6
+        achieved = b_ray * n / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                j = json.load(open(pmc))
+                if j.get("rays_per_launch") == n and j.get("mode") == args.mode:
+                    traffic = j.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "Mrays/s (primary+AO)", "value": round(value, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 filter + f64 resolve (hit records f64)",
+            "data": "synthetic",
+            "config": {"workload": "S-soup-1M ray dump (BASELINE config 3): %d random triangles, %d incoherent rays per GPU, %s-hit"
+                                   % (args.tris, n, args.mode),
+                       "rays_per_gpu": n, "triangles": args.tris, "mode": args.mode,
+                       "variant": args.variant, "parallelism": "replicated BVH, ray slices x%d" % world,
+                       "bvh": {"nodes": info["nnodes"], "depth": info["max_depth"], "device_bytes": info["device_bytes"],
+                               "build_s": round(info["build_seconds"], 3)}},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "kernel": "k_trace_persist_lane" if args.variant in (-1, 2) else "k_trace_v%d" % args.variant,
+                         "kernel_ms": round(kernel_ms, 3), "bytes_per_ray": round(b_ray, 1),
+                         "nodes_per_ray": round(n_nodes, 3), "tris_per_ray": round(n_tris, 3)},
+        }
+        if not args.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(po, P, idx, first_org, first_dir)
+        print(json.dumps(res), flush=True)
+    acc.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(po, P, idx, org, dr):
+    """The reference's CPU path on this box's host cores, bounded sample of the SAME
+    workload (first rays of rank 0's batch).  kind "reference": the compiled reference
+    itself (oracle/_ref, scalar double, single thread -- its own threading is a racy
+    bucket queue that scales 1.36x on 8 cores); else kind "port": the
+    bit-identical oracle.  Also reports the port on all host cores."""
+    ncores = os.cpu_count() or 1
+    out = {}
+    if po.ref_available():
+        ref = po.RefLib()
+        ref.add_mesh(P, idx); ref.build()
+        t0 = time.perf_counter(); ref.intersect(org, dr); dt = time.perf_counter() - t0
+        out = {"value": round(org.shape[0] / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "reference",
+               "sample": "first %d rays of the same S-soup ray dump, ri_raytrace() per ray, %.1f s" % (org.shape[0], dt)}
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    if not out:
+        t0 = time.perf_counter(); o.intersect(org, dr, nthreads=1); dt = time.perf_counter() - t0
+        out = {"value": round(org.shape[0] / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+               "sample": "first %d rays of the same S-soup ray dump, %.1f s" % (org.shape[0], dt)}
+    reps = max(1, min(8, ncores // 8))
+    big_o = np.concatenate([org] * reps); big_d = np.concatenate([dr] * reps)
+    t0 = time.perf_counter(); o.intersect(big_o, big_d, nthreads=ncores); dt = time.perf_counter() - t0
+    out["port_all_cores"] = {"value": round(big_o.shape[0] / dt / 1e6, 3), "unit": "Mrays/s", "cores": ncores,
+                             "sample": "%d rays, contiguous slices per thread, %.1f s" % (big_o.shape[0], dt)}
+    return out
+
+
+if __name__ == "__main__":
+    main()

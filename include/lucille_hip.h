@@ -1,0 +1,117 @@
+/*
+ * lucille_hip.h -- C ABI of liblucille_hip.so: the MI355X (gfx950) accelerator
+ * for lucille's ray-query hot path.  Plain C, plain pointers and sizes; no
+ * C++/torch types cross this boundary.  Every function returns 0 on success
+ * and -1 on failure (lh_last_error() holds a message); nothing throws.
+ *
+ * Each entry point names the reference interface it stands in for (paths are
+ * relative to the lucille source tree).  The reference-side glue a lucille
+ * maintainer adds (a new RI_ACCEL_HIP case in ri_accel_bind that forwards to
+ * these functions) is shown in INTEGRATION.md and lives, compilable against
+ * the reference's own headers, in integration/ri_accel_hip.c.
+ */
+#ifndef LUCILLE_HIP_H
+#define LUCILLE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LH_MISS      0xFFFFFFFFu     /* prim id of a miss                     */
+#define LH_INFINITY  1.0e38          /* t of a miss == RI_INFINITY (include/ri.h:47) */
+
+/* query modes */
+#define LH_MODE_CLOSEST 0            /* ri_bvh_intersect semantics            */
+#define LH_MODE_ANY     1            /* boolean occlusion: the value calculate_occlusion
+                                        actually consumes (ambientocclusion.c:123-129) */
+
+/* kernel variants; LH_VARIANT_DEFAULT picks the tuned one */
+#define LH_VARIANT_DEFAULT (-1)
+
+typedef struct lh_accel lh_accel_t;  /* opaque: host BVH + device SoA copies  */
+
+typedef struct lh_accel_info {
+    uint32_t ntriangles;
+    uint32_t nnodes;
+    uint32_t nleaves;
+    uint32_t max_depth;
+    uint64_t device_bytes;           /* HBM footprint of the scene            */
+    double   build_seconds;          /* host BVH build                        */
+    double   upload_seconds;
+    int      device;
+} lh_accel_info_t;
+
+/* ---- runtime ----------------------------------------------------------- */
+int         lh_device_count(void);
+const char *lh_last_error(void);
+
+/* ---- accelerator lifetime: accel_build_func / accel_free_func ----------
+ * reference: src/render/accel.h:24-28; ri_bvh_build src/render/bvh.c:276-379;
+ * ri_bvh_free bvh.c:381-387.  The reference's build() walks scene->geom_list;
+ * across the C ABI the same walk is three calls: create, add_mesh per
+ * ri_geom_t in list order (this fixes primitive ids exactly as
+ * create_triangle_list does, bvh.c:1736-1826), commit. */
+int  lh_accel_create(lh_accel_t **out, int device);
+/* positions: first double of vertex 0; stride_bytes between vertices
+ * (32 for lucille's ri_vector_t = double[4], 24 for packed xyz).  The data is
+ * copied (the reference copies too, bvh.c:320-321). */
+int  lh_accel_add_mesh(lh_accel_t *accel, uint32_t npositions, const double *positions,
+                       size_t stride_bytes, uint32_t nindices, const uint32_t *indices);
+/* builds the BVH on the host (build_threads <= 0: all cores) and uploads the
+ * SoA scene to the device.  An empty scene commits to an always-miss accel
+ * (bvh.c:311-315,446-449). */
+int  lh_accel_commit(lh_accel_t *accel, int build_threads);
+void lh_accel_destroy(lh_accel_t *accel);
+int  lh_accel_info(const lh_accel_t *accel, lh_accel_info_t *out);
+
+/* primitive id -> (mesh ordinal in add order, index = 3*i into that mesh's
+ * index list): what state->geom / state->index carry in the reference
+ * (bvh.c:855-860), so the host can run ri_intersection_state_build. */
+int  lh_accel_prim_lookup(const lh_accel_t *accel, uint32_t prim, uint32_t *mesh,
+                          uint32_t *index);
+
+/* ---- queries: accel_intersect_func (src/render/accel.h:30-34) ----------
+ * Rays are fp64 xyz triples exactly as ri_ray_t.org/.dir (src/render/ray.h:
+ * 24-25); dir need not be normalised, t is in units of |dir|.
+ * Closest mode writes prim (LH_MISS on miss), t (1e38 on miss), u, v as the
+ * reference does (bvh.c:850-861,1187).  Any mode writes occluded[i] in {0,1}.
+ * Unused outputs may be NULL. */
+
+/* one synchronous ray: the reference's calling convention, kept correct (a
+ * batch of one through the same kernel). Returns 1 hit / 0 miss / -1 error. */
+int  lh_accel_intersect1(lh_accel_t *accel, const double org[3], const double dir[3],
+                         uint32_t *prim, double *t, double *u, double *v);
+
+/* host-resident batch: H2D, kernel, D2H on the accel's own stream */
+int  lh_accel_intersect_host(lh_accel_t *accel, size_t n, const double *org_xyz,
+                             const double *dir_xyz, uint32_t *prim, double *t, double *u,
+                             double *v, uint8_t *occluded, int mode);
+
+/* device-resident batch on a caller stream (hipStream_t as void*; NULL =
+ * default stream).  Asynchronous: returns after enqueue. */
+int  lh_accel_intersect_device(lh_accel_t *accel, size_t n, const void *d_org_xyz,
+                               const void *d_dir_xyz, void *d_prim, void *d_t, void *d_u,
+                               void *d_v, void *d_occluded, int mode, int variant,
+                               void *stream);
+
+/* same launch with traversal statistics: counters[4] (host) receives
+ * {inner-node visits, triangle tests, fp64 resolves, rays}; synchronous. */
+int  lh_accel_intersect_device_counted(lh_accel_t *accel, size_t n, const void *d_org_xyz,
+                                       const void *d_dir_xyz, void *d_prim, void *d_t,
+                                       void *d_u, void *d_v, void *d_occluded, int mode,
+                                       int variant, uint64_t counters[4]);
+
+/* number of persistent workgroups the persistent variants launch */
+int  lh_accel_set_grid(lh_accel_t *accel, int blocks);
+
+/* copy of the flattened BVH for cross-checks (tests): sizes via lh_accel_info.
+ * nodes: nnodes*64 bytes, tri32: ntriangles*48 bytes; either may be NULL. */
+int  lh_accel_export(const lh_accel_t *accel, void *nodes, void *tri32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,16 @@
+"""lucille_amd -- MI355X (gfx950) accelerator for lucille's ray-query hot path.
+
+The product is the C-ABI shared library ``lucille_amd/csrc/liblucille_hip.so``
+(declared in ``include/lucille_hip.h``); this package is the thin Python
+plumbing used by the tests, ``bench.py`` and the multi-GPU driver:
+
+  lucille_amd.binding   ctypes view of the C ABI (+ torch device-pointer helpers)
+  lucille_amd.accel     ri_accel_* / ri_raytrace host mirror (via lh_host.c)
+  lucille_amd.shard     image-space / ray-slice sharding over torch.distributed
+
+There is no CPU fallback: loading fails loudly when the library is missing and
+every query fails loudly when no HIP device is visible.
+"""
+from .binding import (HipAccel, LucilleHipError, MISS, MODE_ANY, MODE_CLOSEST,  # noqa: F401
+                      VARIANT_DEFAULT, VARIANT_DIRECT, VARIANT_PERSIST_LANE,
+                      VARIANT_PERSIST_WAVE, build_library, device_count, library_path)

@@ -1,0 +1,229 @@
+"""ctypes binding of include/lucille_hip.h (the drop-in C ABI).
+
+Reference interface mirrored: accel_build_func / accel_free_func /
+accel_intersect_func (lucille src/render/accel.h:24-34) -- see the header for
+the per-function mapping.  No compute happens in Python.
+"""
+import atexit
+import ctypes as C
+import os
+import subprocess
+import weakref
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+
+MISS = 0xFFFFFFFF
+T_INF = 1.0e38
+MODE_CLOSEST, MODE_ANY = 0, 1
+VARIANT_DEFAULT, VARIANT_DIRECT, VARIANT_PERSIST_WAVE, VARIANT_PERSIST_LANE = -1, 0, 1, 2
+
+
+class LucilleHipError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(CSRC, "liblucille_hip.so")
+
+
+def build_library(force=False):
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC]
+    if force:
+        subprocess.check_call(args + ["clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(args + ["liblucille_hip.so"], stdout=subprocess.DEVNULL)
+    return library_path()
+
+
+class AccelInfo(C.Structure):
+    _fields_ = [("ntriangles", C.c_uint32), ("nnodes", C.c_uint32), ("nleaves", C.c_uint32),
+                ("max_depth", C.c_uint32), ("device_bytes", C.c_uint64), ("build_seconds", C.c_double),
+                ("upload_seconds", C.c_double), ("device", C.c_int)]
+
+
+# every symbol include/lucille_hip.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "lh_device_count", "lh_last_error", "lh_accel_create", "lh_accel_add_mesh", "lh_accel_commit",
+    "lh_accel_destroy", "lh_accel_info", "lh_accel_prim_lookup", "lh_accel_intersect1",
+    "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted",
+    "lh_accel_set_grid", "lh_accel_export",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise LucilleHipError(
+            "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C %s` "
+            "(there is no CPU fallback)" % (path, CSRC))
+    L = C.CDLL(path)
+    vp, sz, i32, u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
+    L.lh_device_count.restype = i32
+    L.lh_last_error.restype = C.c_char_p
+    L.lh_accel_create.argtypes = [C.POINTER(vp), i32]
+    L.lh_accel_add_mesh.argtypes = [vp, u32, vp, sz, u32, vp]
+    L.lh_accel_commit.argtypes = [vp, i32]
+    L.lh_accel_destroy.argtypes = [vp]
+    L.lh_accel_destroy.restype = None
+    L.lh_accel_info.argtypes = [vp, C.POINTER(AccelInfo)]
+    L.lh_accel_prim_lookup.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(u32)]
+    L.lh_accel_intersect1.argtypes = [vp, vp, vp, C.POINTER(u32), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.lh_accel_intersect_host.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32]
+    L.lh_accel_intersect_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.lh_accel_intersect_device_counted.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, i32,
+                                                    C.POINTER(C.c_uint64)]
+    L.lh_accel_set_grid.argtypes = [vp, i32]
+    L.lh_accel_export.argtypes = [vp, vp, vp]
+    _lib = L
+    return L
+
+
+def device_count():
+    return int(lib().lh_device_count())
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise LucilleHipError("%s: %s" % (what, lib().lh_last_error().decode()))
+    return rc
+
+
+def _np(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _dptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+_live = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    # device memory must be released while the HIP runtime is still alive
+    for a in list(_live):
+        a.close()
+
+
+class HipAccel:
+    """One committed accelerator == the `void *accel` the reference's vtable carries."""
+
+    def __init__(self, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        _check(self.L.lh_accel_create(C.byref(self.h), int(device)), "lh_accel_create")
+        self.device = int(device)
+        self.committed = False
+        _live.add(self)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.lh_accel_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- build ------------------------------------------------------------
+    def add_mesh(self, positions, indices):
+        """positions: [npos,3] (packed xyz) or [npos,4] (lucille's ri_vector_t) float64"""
+        P = _np(positions, np.float64)
+        if P.ndim != 2 or P.shape[1] not in (3, 4):
+            raise ValueError("positions must be [n,3] or [n,4]")
+        I = _np(indices, np.uint32).reshape(-1)
+        _check(self.L.lh_accel_add_mesh(self.h, P.shape[0], P.ctypes.data, P.shape[1] * 8, I.shape[0],
+                                        I.ctypes.data), "lh_accel_add_mesh")
+
+    def commit(self, build_threads=0):
+        _check(self.L.lh_accel_commit(self.h, int(build_threads)), "lh_accel_commit")
+        self.committed = True
+        return self.info()
+
+    def info(self):
+        s = AccelInfo()
+        _check(self.L.lh_accel_info(self.h, C.byref(s)), "lh_accel_info")
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def prim_lookup(self, prim):
+        m, i = C.c_uint32(), C.c_uint32()
+        _check(self.L.lh_accel_prim_lookup(self.h, int(prim), C.byref(m), C.byref(i)), "lh_accel_prim_lookup")
+        return int(m.value), int(i.value)
+
+    def set_grid(self, blocks):
+        _check(self.L.lh_accel_set_grid(self.h, int(blocks)), "lh_accel_set_grid")
+
+    def export(self):
+        inf = self.info()
+        nodes = np.zeros((inf["nnodes"], 16), np.float32)
+        tri32 = np.zeros((inf["ntriangles"], 12), np.float32)
+        _check(self.L.lh_accel_export(self.h, nodes.ctypes.data, tri32.ctypes.data), "lh_accel_export")
+        return nodes, tri32
+
+    # ---- queries ----------------------------------------------------------
+    def intersect1(self, org, dr):
+        o = _np(org, np.float64).reshape(3); d = _np(dr, np.float64).reshape(3)
+        p = C.c_uint32(); t = C.c_double(); u = C.c_double(); v = C.c_double()
+        hit = _check(self.L.lh_accel_intersect1(self.h, o.ctypes.data, d.ctypes.data, C.byref(p), C.byref(t),
+                                                C.byref(u), C.byref(v)), "lh_accel_intersect1")
+        return hit, int(p.value), t.value, u.value, v.value
+
+    def intersect_host(self, org, dr, mode=MODE_CLOSEST):
+        o = _np(org, np.float64).reshape(-1, 3); d = _np(dr, np.float64).reshape(-1, 3)
+        n = o.shape[0]
+        if mode == MODE_CLOSEST:
+            prim = np.empty(n, np.uint32); t = np.empty(n); u = np.empty(n); v = np.empty(n)
+            _check(self.L.lh_accel_intersect_host(self.h, n, o.ctypes.data, d.ctypes.data, prim.ctypes.data,
+                                                  t.ctypes.data, u.ctypes.data, v.ctypes.data, None, mode),
+                   "lh_accel_intersect_host")
+            return prim, t, u, v
+        occ = np.empty(n, np.uint8)
+        _check(self.L.lh_accel_intersect_host(self.h, n, o.ctypes.data, d.ctypes.data, None, None, None, None,
+                                              occ.ctypes.data, mode), "lh_accel_intersect_host")
+        return occ
+
+    def intersect_device(self, org, dr, out=None, mode=MODE_CLOSEST, variant=VARIANT_DEFAULT, stream=None,
+                         counters=False):
+        """org, dr: CUDA(HIP) float64 tensors [n,3], contiguous.  Enqueues on `stream`
+        (default: torch's current stream) and returns the output tensors."""
+        import torch
+        assert org.is_cuda and dr.is_cuda and org.dtype == torch.float64 and dr.dtype == torch.float64
+        assert org.is_contiguous() and dr.is_contiguous()
+        n = org.shape[0]
+        dev = org.device
+        if out is None:
+            if mode == MODE_CLOSEST:
+                out = (torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.float64, device=dev),
+                       torch.empty(n, dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev))
+            else:
+                out = (torch.empty(n, dtype=torch.uint8, device=dev),)
+        if mode == MODE_CLOSEST:
+            prim, t, u, v = out; occ = None
+        else:
+            prim = t = u = v = None; occ = out[0]
+        if counters:
+            torch.cuda.synchronize(dev)
+            c = (C.c_uint64 * 4)()
+            _check(self.L.lh_accel_intersect_device_counted(self.h, n, _dptr(org), _dptr(dr), _dptr(prim), _dptr(t),
+                                                            _dptr(u), _dptr(v), _dptr(occ), mode, variant, c),
+                   "lh_accel_intersect_device_counted")
+            return out, {"nodes": int(c[0]), "tris": int(c[1]), "exact": int(c[2]), "rays": int(c[3])}
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(self.L.lh_accel_intersect_device(self.h, n, _dptr(org), _dptr(dr), _dptr(prim), _dptr(t), _dptr(u),
+                                                _dptr(v), _dptr(occ), mode, variant, C.c_void_p(stream)),
+               "lh_accel_intersect_device")
+        return out

@@ -1,0 +1,344 @@
+/*
+ * lh_api.hip -- implementation of the C ABI in include/lucille_hip.h over the
+ * HIP runtime.  Owns the host BVH (lh_bvh.c), its device copies, and a small
+ * amount of per-accel device scratch (work cursor, counters, staging for the
+ * host-batch entry point).
+ */
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#include "../../include/lucille_hip.h"
+#include "lh_bvh.h"
+#include "lh_device.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return -1;
+}
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+    return fail("%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
+
+struct lh_mesh_copy { uint32_t npos, nidx; double *pos; uint32_t *idx; };
+
+struct lh_accel {
+    int device;
+    int committed;
+    /* staged meshes (host copies, packed xyz) */
+    lh_mesh_copy *meshes; uint32_t nmeshes;
+    /* host BVH */
+    lh_bvh_t bvh;
+    /* device */
+    lh_dev_scene_t dev;
+    void *d_nodes, *d_tri32, *d_tri64;
+    unsigned long long *d_cursor, *d_counters;
+    hipStream_t stream;
+    uint64_t device_bytes;
+    double upload_seconds;
+    int grid_blocks;
+    int default_variant;
+    /* staging for host batches */
+    void *d_stage; size_t stage_bytes;
+};
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+extern "C" const char *lh_last_error(void) { return g_err; }
+
+extern "C" int lh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int lh_accel_create(lh_accel_t **out, int device)
+{
+    if (!out) return fail("lh_accel_create: out is NULL");
+    int n = lh_device_count();
+    if (n <= 0) return fail("lh_accel_create: no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail("lh_accel_create: device %d out of range [0,%d)", device, n);
+    lh_accel_t *a = (lh_accel_t *)calloc(1, sizeof(*a));
+    if (!a) return fail("out of memory");
+    a->device = device;
+    a->default_variant = LH_VARIANT_PERSIST_LANE;
+    const char *env = getenv("LH_VARIANT");
+    if (env) a->default_variant = atoi(env);
+    *out = a;
+    return 0;
+}
+
+extern "C" int lh_accel_add_mesh(lh_accel_t *a, uint32_t npos, const double *pos, size_t stride,
+                                 uint32_t nidx, const uint32_t *idx)
+{
+    if (!a) return fail("lh_accel_add_mesh: accel is NULL");
+    if (a->committed) return fail("lh_accel_add_mesh: accel already committed");
+    if ((npos && !pos) || (nidx && !idx)) return fail("lh_accel_add_mesh: NULL array");
+    if (stride < 3 * sizeof(double) || (stride % sizeof(double)) != 0) return fail("lh_accel_add_mesh: bad stride %zu", stride);
+    for (uint32_t i = 0; i < nidx - (nidx % 3); i++)
+        if (idx[i] >= npos) return fail("lh_accel_add_mesh: index %u out of range (npositions %u)", idx[i], npos);
+    lh_mesh_copy *nm = (lh_mesh_copy *)realloc(a->meshes, sizeof(lh_mesh_copy) * (a->nmeshes + 1));
+    if (!nm) return fail("out of memory");
+    a->meshes = nm;
+    lh_mesh_copy *m = &a->meshes[a->nmeshes];
+    m->npos = npos; m->nidx = nidx;
+    m->pos = (double *)malloc(sizeof(double) * 3 * (size_t)(npos ? npos : 1));
+    m->idx = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nidx ? nidx : 1));
+    if (!m->pos || !m->idx) return fail("out of memory");
+    for (uint32_t i = 0; i < npos; i++) {
+        const double *p = (const double *)((const char *)pos + (size_t)i * stride);
+        m->pos[3 * (size_t)i] = p[0]; m->pos[3 * (size_t)i + 1] = p[1]; m->pos[3 * (size_t)i + 2] = p[2];
+    }
+    memcpy(m->idx, idx, sizeof(uint32_t) * nidx);
+    a->nmeshes++;
+    return 0;
+}
+
+static void release_device(lh_accel_t *a)
+{
+    if (a->d_nodes) (void)hipFree(a->d_nodes);
+    if (a->d_tri32) (void)hipFree(a->d_tri32);
+    if (a->d_tri64) (void)hipFree(a->d_tri64);
+    if (a->d_cursor) (void)hipFree(a->d_cursor);
+    if (a->d_counters) (void)hipFree(a->d_counters);
+    if (a->d_stage) (void)hipFree(a->d_stage);
+    if (a->stream) (void)hipStreamDestroy(a->stream);
+    a->d_nodes = a->d_tri32 = a->d_tri64 = NULL; a->d_cursor = a->d_counters = NULL;
+    a->d_stage = NULL; a->stage_bytes = 0; a->stream = NULL;
+}
+
+extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
+{
+    if (!a) return fail("lh_accel_commit: accel is NULL");
+    if (a->committed) return fail("lh_accel_commit: already committed");
+    if (build_threads <= 0) {
+        long nc = sysconf(_SC_NPROCESSORS_ONLN);
+        build_threads = nc > 0 ? (int)nc : 1;
+    }
+    lh_mesh_view_t *views = (lh_mesh_view_t *)calloc(a->nmeshes ? a->nmeshes : 1, sizeof(*views));
+    for (uint32_t g = 0; g < a->nmeshes; g++) {
+        views[g].npositions = a->meshes[g].npos; views[g].positions = a->meshes[g].pos;
+        views[g].stride_bytes = 3 * sizeof(double);
+        views[g].nindices = a->meshes[g].nidx; views[g].indices = a->meshes[g].idx;
+    }
+    int rc = lh_bvh_build(&a->bvh, views, a->nmeshes, build_threads);
+    free(views);
+    if (rc != 0) return fail("lh_accel_commit: BVH build failed (bad input or out of memory)");
+    /* the packed mesh copies are no longer needed: the BVH holds tri64 */
+    for (uint32_t g = 0; g < a->nmeshes; g++) { free(a->meshes[g].pos); free(a->meshes[g].idx); }
+    free(a->meshes); a->meshes = NULL;
+
+    HIPCHK(hipSetDevice(a->device));
+    double t0 = now_s();
+    HIPCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&a->d_counters, sizeof(unsigned long long) * LH_CNT_N));
+    a->device_bytes = 0;
+    if (a->bvh.ntris) {
+        size_t nb = sizeof(lh_node_t) * (size_t)a->bvh.nnodes;
+        size_t t32 = sizeof(lh_tri32_t) * (size_t)a->bvh.ntris;
+        size_t t64 = sizeof(lh_tri64_t) * (size_t)a->bvh.ntris;
+        HIPCHK(hipMalloc(&a->d_nodes, nb));
+        HIPCHK(hipMalloc(&a->d_tri32, t32));
+        HIPCHK(hipMalloc(&a->d_tri64, t64));
+        HIPCHK(hipMemcpy(a->d_nodes, a->bvh.nodes, nb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(a->d_tri32, a->bvh.tri32, t32, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(a->d_tri64, a->bvh.tri64, t64, hipMemcpyHostToDevice));
+        a->device_bytes = nb + t32 + t64;
+        float r = 0.0f;
+        for (int k = 0; k < 3; k++) { r = fmaxf(r, fabsf(a->bvh.bmin[k])); r = fmaxf(r, fabsf(a->bvh.bmax[k])); }
+        a->dev.nodes = a->d_nodes; a->dev.tri32 = a->d_tri32; a->dev.tri64 = a->d_tri64;
+        a->dev.ntris = a->bvh.ntris; a->dev.nnodes = a->bvh.nnodes;
+        a->dev.max_depth = a->bvh.max_depth; a->dev.scene_r = r;
+        if (a->bvh.max_depth + 1 > 64) return fail("lh_accel_commit: tree depth %u exceeds the kernel stack", a->bvh.max_depth);
+    }
+    a->upload_seconds = now_s() - t0;
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, a->device));
+        int per_cu = (a->bvh.max_depth + 1 <= 32) ? 5 : 2;   /* LDS stack bound */
+        a->grid_blocks = prop.multiProcessorCount * per_cu;
+        const char *env = getenv("LH_GRID_BLOCKS");
+        if (env && atoi(env) > 0) a->grid_blocks = atoi(env);
+    }
+    a->committed = 1;
+    return 0;
+}
+
+extern "C" void lh_accel_destroy(lh_accel_t *a)
+{
+    if (!a) return;
+    if (a->committed) { (void)hipSetDevice(a->device); release_device(a); }
+    for (uint32_t g = 0; g < a->nmeshes; g++) { free(a->meshes[g].pos); free(a->meshes[g].idx); }
+    free(a->meshes);
+    lh_bvh_release(&a->bvh);
+    free(a);
+}
+
+extern "C" int lh_accel_info(const lh_accel_t *a, lh_accel_info_t *o)
+{
+    if (!a || !o) return fail("lh_accel_info: NULL argument");
+    if (!a->committed) return fail("lh_accel_info: accel not committed");
+    o->ntriangles = a->bvh.ntris; o->nnodes = a->bvh.nnodes; o->nleaves = a->bvh.nleaves;
+    o->max_depth = a->bvh.max_depth; o->device_bytes = a->device_bytes;
+    o->build_seconds = a->bvh.build_seconds; o->upload_seconds = a->upload_seconds;
+    o->device = a->device;
+    return 0;
+}
+
+extern "C" int lh_accel_prim_lookup(const lh_accel_t *a, uint32_t prim, uint32_t *mesh, uint32_t *index)
+{
+    if (!a || !a->committed) return fail("lh_accel_prim_lookup: accel not committed");
+    if (prim >= a->bvh.ntris) return fail("lh_accel_prim_lookup: prim %u out of range", prim);
+    if (mesh) *mesh = a->bvh.prim_geom[prim];
+    if (index) *index = a->bvh.prim_index[prim];
+    return 0;
+}
+
+extern "C" int lh_accel_set_grid(lh_accel_t *a, int blocks)
+{
+    if (!a || blocks <= 0) return fail("lh_accel_set_grid: bad argument");
+    a->grid_blocks = blocks;
+    return 0;
+}
+
+extern "C" int lh_accel_export(const lh_accel_t *a, void *nodes, void *tri32)
+{
+    if (!a || !a->committed) return fail("lh_accel_export: accel not committed");
+    if (nodes && a->bvh.nnodes) memcpy(nodes, a->bvh.nodes, sizeof(lh_node_t) * (size_t)a->bvh.nnodes);
+    if (tri32 && a->bvh.ntris) memcpy(tri32, a->bvh.tri32, sizeof(lh_tri32_t) * (size_t)a->bvh.ntris);
+    return 0;
+}
+
+/* fill miss results without touching the scene (empty accel) */
+__global__ void k_fill_miss(size_t n, uint32_t *prim, double *t, double *u, double *v, uint8_t *occ)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (prim) prim[i] = LH_MISS_PRIM;
+    if (t) t[i] = LH_T_INF;
+    if (u) u[i] = 0.0;
+    if (v) v[i] = 0.0;
+    if (occ) occ[i] = 0;
+}
+
+static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, void *d_prim,
+                  void *d_t, void *d_u, void *d_v, void *d_occ, int mode, int variant,
+                  unsigned long long *d_counters, hipStream_t s)
+{
+    if (!a || !a->committed) return fail("intersect: accel not committed");
+    if (n == 0) return 0;
+    if (!d_org || !d_dir) return fail("intersect: NULL ray arrays");
+    if (mode == LH_MODE_CLOSEST && (!d_prim || !d_t || !d_u || !d_v)) return fail("intersect: closest mode needs prim,t,u,v outputs");
+    if (mode == LH_MODE_ANY && !d_occ) return fail("intersect: any mode needs the occluded output");
+    if (mode != LH_MODE_CLOSEST && mode != LH_MODE_ANY) return fail("intersect: unknown mode %d", mode);
+    HIPCHK(hipSetDevice(a->device));
+    if (a->bvh.ntris == 0) {
+        size_t blocks = (n + 255) / 256;
+        hipLaunchKernelGGL(k_fill_miss, dim3((unsigned)blocks), dim3(256), 0, s, n,
+                           mode == LH_MODE_CLOSEST ? (uint32_t *)d_prim : NULL, (double *)(mode == LH_MODE_CLOSEST ? d_t : NULL),
+                           (double *)(mode == LH_MODE_CLOSEST ? d_u : NULL), (double *)(mode == LH_MODE_CLOSEST ? d_v : NULL),
+                           mode == LH_MODE_ANY ? (uint8_t *)d_occ : NULL);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    if (variant == LH_VARIANT_DEFAULT) variant = a->default_variant;
+    if (variant < 0 || variant > LH_VARIANT_PERSIST_LANE) return fail("intersect: unknown variant %d", variant);
+    int rc = lh_launch_trace(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim,
+                             (double *)d_t, (double *)d_u, (double *)d_v, mode == LH_MODE_ANY,
+                             (uint8_t *)d_occ, d_counters, a->d_cursor, variant, a->grid_blocks, (void *)s);
+    if (rc != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+extern "C" int lh_accel_intersect_device(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
+                                         void *d_prim, void *d_t, void *d_u, void *d_v, void *d_occ,
+                                         int mode, int variant, void *stream)
+{
+    return launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, variant, NULL, (hipStream_t)stream);
+}
+
+extern "C" int lh_accel_intersect_device_counted(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
+                                                 void *d_prim, void *d_t, void *d_u, void *d_v, void *d_occ,
+                                                 int mode, int variant, uint64_t counters[4])
+{
+    if (!a || !a->committed) return fail("intersect: accel not committed");
+    if (!counters) return fail("intersect_counted: counters is NULL");
+    HIPCHK(hipSetDevice(a->device));
+    HIPCHK(hipMemsetAsync(a->d_counters, 0, sizeof(unsigned long long) * LH_CNT_N, a->stream));
+    HIPCHK(hipDeviceSynchronize());
+    if (a->bvh.ntris == 0) { counters[0] = counters[1] = counters[2] = 0; counters[3] = n; }
+    int rc = launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, variant, a->d_counters, a->stream);
+    if (rc != 0) return rc;
+    HIPCHK(hipStreamSynchronize(a->stream));
+    if (a->bvh.ntris) {
+        unsigned long long h[LH_CNT_N];
+        HIPCHK(hipMemcpy(h, a->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+        for (int k = 0; k < LH_CNT_N; k++) counters[k] = h[k];
+    }
+    return 0;
+}
+
+static int ensure_stage(lh_accel_t *a, size_t bytes)
+{
+    if (a->stage_bytes >= bytes) return 0;
+    if (a->d_stage) { (void)hipFree(a->d_stage); a->d_stage = NULL; a->stage_bytes = 0; }
+    HIPCHK(hipMalloc(&a->d_stage, bytes));
+    a->stage_bytes = bytes;
+    return 0;
+}
+
+extern "C" int lh_accel_intersect_host(lh_accel_t *a, size_t n, const double *org, const double *dir,
+                                       uint32_t *prim, double *t, double *u, double *v, uint8_t *occ, int mode)
+{
+    if (!a || !a->committed) return fail("intersect: accel not committed");
+    if (n == 0) return 0;
+    if (!org || !dir) return fail("intersect: NULL ray arrays");
+    HIPCHK(hipSetDevice(a->device));
+    /* layout of the staging block: org | dir | t | u | v | prim | occ */
+    const size_t b_ray = sizeof(double) * 3 * n, b_d = sizeof(double) * n;
+    const size_t total = 2 * b_ray + 3 * b_d + sizeof(uint32_t) * n + n + 64;
+    if (ensure_stage(a, total) != 0) return -1;
+    char *base = (char *)a->d_stage;
+    double *d_org = (double *)base, *d_dir = (double *)(base + b_ray);
+    double *d_t = (double *)(base + 2 * b_ray), *d_u = d_t + n, *d_v = d_u + n;
+    uint32_t *d_prim = (uint32_t *)(d_v + n);
+    uint8_t *d_occ = (uint8_t *)(d_prim + n);
+    HIPCHK(hipMemcpyAsync(d_org, org, b_ray, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_dir, dir, b_ray, hipMemcpyHostToDevice, a->stream));
+    int rc = launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, LH_VARIANT_DEFAULT, NULL, a->stream);
+    if (rc != 0) return rc;
+    if (mode == LH_MODE_CLOSEST) {
+        if (prim) HIPCHK(hipMemcpyAsync(prim, d_prim, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, a->stream));
+        if (t) HIPCHK(hipMemcpyAsync(t, d_t, b_d, hipMemcpyDeviceToHost, a->stream));
+        if (u) HIPCHK(hipMemcpyAsync(u, d_u, b_d, hipMemcpyDeviceToHost, a->stream));
+        if (v) HIPCHK(hipMemcpyAsync(v, d_v, b_d, hipMemcpyDeviceToHost, a->stream));
+    } else {
+        if (occ) HIPCHK(hipMemcpyAsync(occ, d_occ, n, hipMemcpyDeviceToHost, a->stream));
+    }
+    HIPCHK(hipStreamSynchronize(a->stream));
+    return 0;
+}
+
+extern "C" int lh_accel_intersect1(lh_accel_t *a, const double org[3], const double dir[3],
+                                   uint32_t *prim, double *t, double *u, double *v)
+{
+    uint32_t p = LH_MISS_PRIM; double tt = LH_T_INF, uu = 0.0, vv = 0.0;
+    if (!org || !dir) return fail("lh_accel_intersect1: NULL ray");
+    if (lh_accel_intersect_host(a, 1, org, dir, &p, &tt, &uu, &vv, NULL, LH_MODE_CLOSEST) != 0) return -1;
+    if (prim) *prim = p;
+    if (t) *t = tt;
+    if (u) *u = uu;
+    if (v) *v = vv;
+    return p != LH_MISS_PRIM;
+}

@@ -1,0 +1,417 @@
+/*
+ * lh_bvh.c -- host BVH builder for the gfx950 traversal kernels.
+ *
+ * Role in the drop-in: this is what accel->build() runs for RI_ACCEL_HIP, in
+ * place of ri_bvh_build (reference src/render/bvh.c:276-379).  Input is the
+ * scene's geom list flattened exactly like create_triangle_list
+ * (bvh.c:1736-1826) so primitive ids agree with the reference; output is the
+ * SoA form described in lh_bvh.h / DESIGN.md.
+ *
+ * Algorithm (this project's own): top-down binned SAH over centroid bounds
+ * (32 bins x 3 axes), leaves of <= 4 triangles, boxes stored as fp32 rounded
+ * OUTWARD from the fp64 vertices so that fp32 culling is conservative with
+ * respect to the reference's fp64 geometry.  Large inputs are built in
+ * parallel: the main thread splits the top of the tree, subtrees below a size
+ * threshold become tasks for a pthread pool, and a final DFS pass flattens
+ * the pointer tree so that sibling inner nodes are adjacent in memory (one
+ * 128-byte line when both are visited).
+ */
+#include "lh_bvh.h"
+
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define NBINS 32
+
+typedef struct tnode {
+    float lo[3], hi[3];
+    struct tnode *c[2];
+    uint32_t first, count;   /* leaf range in order[] (count>0 => leaf) */
+    int axis;
+} tnode_t;
+
+/* chunked arena so tnode pointers stay valid */
+typedef struct arena_chunk { struct arena_chunk *next; size_t used, cap; tnode_t *nodes; } arena_chunk_t;
+typedef struct { arena_chunk_t *head; } arena_t;
+
+static tnode_t *arena_new(arena_t *a)
+{
+    if (!a->head || a->head->used == a->head->cap) {
+        arena_chunk_t *c = (arena_chunk_t *)malloc(sizeof(*c));
+        c->cap = 1 << 14; c->used = 0;
+        c->nodes = (tnode_t *)malloc(sizeof(tnode_t) * c->cap);
+        c->next = a->head; a->head = c;
+    }
+    tnode_t *n = &a->head->nodes[a->head->used++];
+    memset(n, 0, sizeof(*n));
+    return n;
+}
+
+static void arena_free(arena_t *a)
+{
+    arena_chunk_t *c = a->head;
+    while (c) { arena_chunk_t *nx = c->next; free(c->nodes); free(c); c = nx; }
+    a->head = NULL;
+}
+
+typedef struct {
+    uint32_t  n;
+    float    *plo, *phi;    /* per-primitive fp32 outward box, [n][3] */
+    float    *cen;          /* centroids [n][3] */
+    uint32_t *order;        /* permutation being partitioned */
+    float     ci, ct;       /* SAH constants */
+    uint32_t  task_threshold;
+    /* deferred subtree tasks */
+    struct task { tnode_t *node; uint32_t first, count; int depth; } *tasks;
+    size_t ntasks, captasks;
+    int collecting;
+} build_ctx_t;
+
+static inline float down32(double d) { float f = (float)d; if ((double)f > d) f = nextafterf(f, -INFINITY); return f; }
+static inline float up32(double d)   { float f = (float)d; if ((double)f < d) f = nextafterf(f,  INFINITY); return f; }
+
+static inline float half_area(const float lo[3], const float hi[3])
+{
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+static void range_bounds(const build_ctx_t *b, uint32_t first, uint32_t count,
+                         float lo[3], float hi[3], float clo[3], float chi[3])
+{
+    int k; uint32_t i;
+    for (k = 0; k < 3; k++) { lo[k] = clo[k] = INFINITY; hi[k] = chi[k] = -INFINITY; }
+    for (i = first; i < first + count; i++) {
+        uint32_t p = b->order[i];
+        for (k = 0; k < 3; k++) {
+            float l = b->plo[3 * (size_t)p + k], h = b->phi[3 * (size_t)p + k], c = b->cen[3 * (size_t)p + k];
+            if (l < lo[k]) lo[k] = l;
+            if (h > hi[k]) hi[k] = h;
+            if (c < clo[k]) clo[k] = c;
+            if (c > chi[k]) chi[k] = c;
+        }
+    }
+}
+
+static void build_range(build_ctx_t *b, arena_t *ar, tnode_t *node, uint32_t first,
+                        uint32_t count, int depth);
+
+static void make_leaf(tnode_t *node, uint32_t first, uint32_t count)
+{
+    node->first = first; node->count = count; node->c[0] = node->c[1] = NULL;
+}
+
+static void split_children(build_ctx_t *b, arena_t *ar, tnode_t *node, uint32_t first,
+                           uint32_t nl, uint32_t count, int depth)
+{
+    node->count = 0;
+    node->c[0] = arena_new(ar); node->c[1] = arena_new(ar);
+    build_range(b, ar, node->c[0], first, nl, depth + 1);
+    build_range(b, ar, node->c[1], first + nl, count - nl, depth + 1);
+}
+
+static void build_range(build_ctx_t *b, arena_t *ar, tnode_t *node, uint32_t first,
+                        uint32_t count, int depth)
+{
+    float clo[3], chi[3];
+    int k, axis, best_axis = -1, best_bin = -1;
+    float best_cost = INFINITY;
+    uint32_t i;
+
+    if (b->collecting && count <= b->task_threshold && count > LH_MAX_LEAF_TRIS) {
+        if (b->ntasks == b->captasks) {
+            b->captasks = b->captasks ? b->captasks * 2 : 256;
+            b->tasks = (struct task *)realloc(b->tasks, sizeof(*b->tasks) * b->captasks);
+        }
+        b->tasks[b->ntasks].node = node; b->tasks[b->ntasks].first = first;
+        b->tasks[b->ntasks].count = count; b->tasks[b->ntasks].depth = depth;
+        b->ntasks++;
+        return;
+    }
+
+    range_bounds(b, first, count, node->lo, node->hi, clo, chi);
+
+    if (count == 1) { make_leaf(node, first, count); return; }
+
+    if (depth >= 48) {   /* degenerate input guard: bounded depth */
+        if (count <= LH_MAX_LEAF_TRIS) { make_leaf(node, first, count); return; }
+        node->axis = 0;
+        split_children(b, ar, node, first, count / 2, count, depth);
+        return;
+    }
+
+    /* binned SAH */
+    {
+        float parent_area = half_area(node->lo, node->hi);
+        for (axis = 0; axis < 3; axis++) {
+            uint32_t cnt[NBINS]; float blo[NBINS][3], bhi[NBINS][3];
+            float ext = chi[axis] - clo[axis];
+            float scale;
+            float rarea[NBINS]; uint32_t rcnt[NBINS];
+            float lo[3], hi[3]; uint32_t n;
+            int j;
+            if (!(ext > 0.0f)) continue;
+            scale = (float)NBINS * (1.0f - 1e-6f) / ext;
+            for (j = 0; j < NBINS; j++) {
+                cnt[j] = 0;
+                for (k = 0; k < 3; k++) { blo[j][k] = INFINITY; bhi[j][k] = -INFINITY; }
+            }
+            for (i = first; i < first + count; i++) {
+                uint32_t p = b->order[i];
+                int bin = (int)((b->cen[3 * (size_t)p + axis] - clo[axis]) * scale);
+                if (bin < 0) bin = 0;
+                if (bin >= NBINS) bin = NBINS - 1;
+                cnt[bin]++;
+                for (k = 0; k < 3; k++) {
+                    float l = b->plo[3 * (size_t)p + k], h = b->phi[3 * (size_t)p + k];
+                    if (l < blo[bin][k]) blo[bin][k] = l;
+                    if (h > bhi[bin][k]) bhi[bin][k] = h;
+                }
+            }
+            /* right-to-left sweep */
+            for (k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+            n = 0;
+            for (j = NBINS - 1; j >= 1; j--) {
+                n += cnt[j];
+                for (k = 0; k < 3; k++) { if (blo[j][k] < lo[k]) lo[k] = blo[j][k]; if (bhi[j][k] > hi[k]) hi[k] = bhi[j][k]; }
+                rcnt[j] = n; rarea[j] = n ? half_area(lo, hi) : 0.0f;
+            }
+            for (k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+            n = 0;
+            for (j = 0; j < NBINS - 1; j++) {
+                float cost;
+                n += cnt[j];
+                for (k = 0; k < 3; k++) { if (blo[j][k] < lo[k]) lo[k] = blo[j][k]; if (bhi[j][k] > hi[k]) hi[k] = bhi[j][k]; }
+                if (n == 0 || rcnt[j + 1] == 0) continue;
+                cost = half_area(lo, hi) * (float)n + rarea[j + 1] * (float)rcnt[j + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = j; }
+            }
+        }
+
+        if (best_axis >= 0 && count <= LH_MAX_LEAF_TRIS) {
+            float split_cost = b->ci + b->ct * best_cost / (parent_area > 0.0f ? parent_area : 1e-30f);
+            if ((float)count * b->ct <= split_cost) { make_leaf(node, first, count); return; }
+        }
+    }
+
+    if (best_axis < 0) {
+        /* all centroids coincide: cannot separate spatially */
+        if (count <= LH_MAX_LEAF_TRIS) { make_leaf(node, first, count); return; }
+        node->axis = 0;
+        split_children(b, ar, node, first, count / 2, count, depth);
+        return;
+    }
+
+    /* partition order[first, first+count) by bin <= best_bin */
+    {
+        float ext = chi[best_axis] - clo[best_axis];
+        float scale = (float)NBINS * (1.0f - 1e-6f) / ext;
+        uint32_t l = first, r = first + count;
+        while (l < r) {
+            uint32_t p = b->order[l];
+            int bin = (int)((b->cen[3 * (size_t)p + best_axis] - clo[best_axis]) * scale);
+            if (bin < 0) bin = 0;
+            if (bin >= NBINS) bin = NBINS - 1;
+            if (bin <= best_bin) l++;
+            else { r--; b->order[l] = b->order[r]; b->order[r] = p; }
+        }
+        node->axis = best_axis;
+        {
+            uint32_t nl = l - first;
+            if (nl == 0 || nl == count) nl = count / 2;   /* cannot happen; guard */
+            split_children(b, ar, node, first, nl, count, depth);
+        }
+    }
+}
+
+typedef struct { build_ctx_t *b; arena_t arena; volatile uint32_t *next; } worker_t;
+
+static void *worker_main(void *arg)
+{
+    worker_t *w = (worker_t *)arg;
+    for (;;) {
+        uint32_t t = __sync_fetch_and_add(w->next, 1);
+        if (t >= w->b->ntasks) break;
+        build_range(w->b, &w->arena, w->b->tasks[t].node, w->b->tasks[t].first,
+                    w->b->tasks[t].count, w->b->tasks[t].depth);
+    }
+    return NULL;
+}
+
+/* ------------------------------------------------------------- flatten */
+
+typedef struct {
+    const build_ctx_t *b; lh_bvh_t *out; const lh_tri64_t *tri64;
+    uint32_t next_node, next_tri, max_depth, nleaves;
+} flat_t;
+
+static int32_t emit_leaf(flat_t *f, const tnode_t *n)
+{
+    uint32_t first = f->next_tri, i; int k;
+    for (i = 0; i < n->count; i++) {
+        uint32_t p = f->b->order[n->first + i];
+        const lh_tri64_t *t = &f->tri64[p];
+        lh_tri32_t *o = &f->out->tri32[f->next_tri++];
+        double e1[3], e2[3], n1, n2;
+        for (k = 0; k < 3; k++) {
+            e1[k] = t->v[1][k] - t->v[0][k]; e2[k] = t->v[2][k] - t->v[0][k];
+            o->v0[k] = (float)t->v[0][k];
+        }
+        o->e1x = (float)e1[0]; o->e1y = (float)e1[1]; o->e1z = (float)e1[2];
+        o->e2x = (float)e2[0]; o->e2y = (float)e2[1]; o->e2z = (float)e2[2];
+        n1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+        n2 = sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+        o->prim = p;
+        o->ne1 = up32(n1 * (1.0 + 1e-6));
+        o->ne2 = up32(n2 * (1.0 + 1e-6));
+    }
+    f->nleaves++;
+    return ~(int32_t)((first << 2) | (n->count - 1));
+}
+
+static void emit_inner(flat_t *f, const tnode_t *n, uint32_t idx, uint32_t depth)
+{
+    lh_node_t *o = &f->out->nodes[idx];
+    const tnode_t *c0 = n->c[0], *c1 = n->c[1];
+    uint32_t k0 = 0, k1 = 0; int k;
+    if (depth > f->max_depth) f->max_depth = depth;
+    for (k = 0; k < 3; k++) { o->lo0[k] = c0->lo[k]; o->hi0[k] = c0->hi[k]; o->lo1[k] = c1->lo[k]; o->hi1[k] = c1->hi[k]; }
+    o->axis = n->axis; o->pad = 0;
+    if (c0->count == 0) k0 = f->next_node++;
+    if (c1->count == 0) k1 = f->next_node++;
+    if (c0->count) o->ref0 = emit_leaf(f, c0); else { o->ref0 = (int32_t)k0; }
+    if (c1->count) o->ref1 = emit_leaf(f, c1); else { o->ref1 = (int32_t)k1; }
+    if (c0->count == 0) emit_inner(f, c0, k0, depth + 1);
+    if (c1->count == 0) emit_inner(f, c1, k1, depth + 1);
+}
+
+static uint32_t count_inner(const tnode_t *n) { return n->count ? 0 : 1 + count_inner(n->c[0]) + count_inner(n->c[1]); }
+
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
+int lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, int nthreads)
+{
+    uint64_t n64 = 0; uint32_t g, i, n; int k, c;
+    build_ctx_t b; arena_t main_arena; tnode_t *root;
+    double t0 = now_s();
+    const char *env;
+
+    memset(out, 0, sizeof(*out));
+    for (g = 0; g < nmeshes; g++) {
+        const lh_mesh_view_t *m = &meshes[g];
+        if (m->nindices && (!m->indices || !m->positions)) return -1;
+        n64 += m->nindices / 3;
+    }
+    if (n64 >= (1u << 29)) return -1;   /* leaf reference encoding limit */
+    n = (uint32_t)n64;
+    out->ntris = n;
+    if (n == 0) return 0;                /* empty scene: always-miss accel (bvh.c:311-315) */
+
+    out->tri64 = (lh_tri64_t *)malloc(sizeof(lh_tri64_t) * n);
+    out->tri32 = (lh_tri32_t *)malloc(sizeof(lh_tri32_t) * n);
+    out->prim_geom = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    out->prim_index = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    memset(&b, 0, sizeof(b));
+    b.n = n;
+    b.plo = (float *)malloc(sizeof(float) * 3 * (size_t)n);
+    b.phi = (float *)malloc(sizeof(float) * 3 * (size_t)n);
+    b.cen = (float *)malloc(sizeof(float) * 3 * (size_t)n);
+    b.order = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    if (!out->tri64 || !out->tri32 || !out->prim_geom || !out->prim_index || !b.plo || !b.phi || !b.cen || !b.order) {
+        free(b.plo); free(b.phi); free(b.cen); free(b.order); lh_bvh_release(out); return -1;
+    }
+
+    /* flatten in create_triangle_list order: primitive id = running index */
+    {
+        uint32_t p = 0;
+        for (g = 0; g < nmeshes; g++) {
+            const lh_mesh_view_t *m = &meshes[g];
+            for (i = 0; i < m->nindices / 3; i++, p++) {
+                lh_tri64_t *t = &out->tri64[p];
+                for (c = 0; c < 3; c++) {
+                    uint32_t vi = m->indices[3 * i + c];
+                    const double *P;
+                    if (vi >= m->npositions) { free(b.plo); free(b.phi); free(b.cen); free(b.order); lh_bvh_release(out); return -1; }
+                    P = (const double *)((const char *)m->positions + (size_t)vi * m->stride_bytes);
+                    for (k = 0; k < 3; k++) t->v[c][k] = P[k];
+                }
+                out->prim_geom[p] = g; out->prim_index[p] = 3 * i;
+                for (k = 0; k < 3; k++) {
+                    double lo = t->v[0][k], hi = t->v[0][k];
+                    if (t->v[1][k] < lo) lo = t->v[1][k];
+                    if (t->v[2][k] < lo) lo = t->v[2][k];
+                    if (t->v[1][k] > hi) hi = t->v[1][k];
+                    if (t->v[2][k] > hi) hi = t->v[2][k];
+                    b.plo[3 * (size_t)p + k] = down32(lo); b.phi[3 * (size_t)p + k] = up32(hi);
+                    b.cen[3 * (size_t)p + k] = (float)(0.5 * (lo + hi));
+                }
+                b.order[p] = p;
+            }
+        }
+    }
+
+    b.ci = 1.0f; b.ct = 1.0f;
+    if ((env = getenv("LH_BVH_CI")) != NULL) b.ci = (float)atof(env);
+    if ((env = getenv("LH_BVH_CT")) != NULL) b.ct = (float)atof(env);
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+
+    memset(&main_arena, 0, sizeof(main_arena));
+    root = arena_new(&main_arena);
+    if (nthreads > 1 && n > 100000) {
+        b.collecting = 1;
+        b.task_threshold = n / (uint32_t)(nthreads * 8);
+        if (b.task_threshold < 4096) b.task_threshold = 4096;
+    }
+    build_range(&b, &main_arena, root, 0, n, 0);
+    b.collecting = 0;
+
+    {
+        worker_t *w = NULL; pthread_t *th = NULL; volatile uint32_t next = 0; int t;
+        if (b.ntasks) {
+            w = (worker_t *)calloc((size_t)nthreads, sizeof(*w));
+            th = (pthread_t *)calloc((size_t)nthreads, sizeof(*th));
+            for (t = 0; t < nthreads; t++) { w[t].b = &b; w[t].next = &next; pthread_create(&th[t], NULL, worker_main, &w[t]); }
+            for (t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+        }
+
+        /* flatten */
+        {
+            flat_t f; uint32_t ninner;
+            memset(&f, 0, sizeof(f));
+            f.b = &b; f.out = out; f.tri64 = out->tri64;
+            if (root->count) {   /* single-leaf scene: synthesize an inner root */
+                out->nodes = (lh_node_t *)calloc(1, sizeof(lh_node_t));
+                out->nnodes = 1;
+                for (k = 0; k < 3; k++) { out->nodes[0].lo0[k] = root->lo[k]; out->nodes[0].hi0[k] = root->hi[k]; out->nodes[0].lo1[k] = INFINITY; out->nodes[0].hi1[k] = -INFINITY; }
+                out->nodes[0].ref0 = emit_leaf(&f, root);
+                out->nodes[0].ref1 = LH_REF_EMPTY;
+            } else {
+                ninner = count_inner(root);
+                out->nodes = (lh_node_t *)calloc(ninner, sizeof(lh_node_t));
+                out->nnodes = ninner;
+                f.next_node = 1;
+                emit_inner(&f, root, 0, 0);
+            }
+            out->max_depth = f.max_depth + 1; out->nleaves = f.nleaves;
+            for (k = 0; k < 3; k++) { out->bmin[k] = root->lo[k]; out->bmax[k] = root->hi[k]; }
+        }
+
+        if (w) { int t2; for (t2 = 0; t2 < nthreads; t2++) arena_free(&w[t2].arena); }
+        free(w); free(th);
+    }
+    arena_free(&main_arena);
+    free(b.tasks); free(b.plo); free(b.phi); free(b.cen); free(b.order);
+    out->build_seconds = now_s() - t0;
+    return 0;
+}
+
+void lh_bvh_release(lh_bvh_t *bvh)
+{
+    free(bvh->nodes); free(bvh->tri32); free(bvh->tri64); free(bvh->prim_geom); free(bvh->prim_index);
+    memset(bvh, 0, sizeof(*bvh));
+}

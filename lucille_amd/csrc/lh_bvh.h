@@ -1,0 +1,83 @@
+/*
+ * lh_bvh.h -- host-side builder that turns lucille geometry into the
+ * structure-of-arrays BVH the gfx950 kernels traverse.
+ *
+ * Replaces, for the HIP accelerator, what ri_bvh_build does for the CPU one
+ * (reference: src/render/bvh.c:276-379 ri_bvh_build, :1736-1826
+ * create_triangle_list, :1328-1564 bvh_construct).  The primitive numbering
+ * is the reference's (running index of create_triangle_list: geom-list order,
+ * then triangle order); the tree itself is this project's own, because hit
+ * records are tree-independent while GPU traversal wants
+ * small leaves, 64-byte nodes and fp32 boxes.
+ */
+#ifndef LH_BVH_H
+#define LH_BVH_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LH_MAX_LEAF_TRIS 4
+#define LH_MAX_DEPTH     60      /* builder falls back to median splits past 48 */
+
+/* 64-byte inner node: boxes of BOTH children + their references.
+ *   ref >= 0 : index of an inner node
+ *   ref <  0 : leaf, x = ~ref, first = x >> 2, count = (x & 3) + 1
+ *   LH_REF_EMPTY : no child (box is inverted, never hit)                   */
+typedef struct lh_node {
+    float   lo0[3], hi0[3];
+    float   lo1[3], hi1[3];
+    int32_t ref0, ref1;
+    int32_t axis;      /* split axis (diagnostics only) */
+    int32_t pad;
+} lh_node_t;
+
+#define LH_REF_EMPTY ((int32_t)0x80000000)
+
+/* 48-byte leaf triangle record (fp32 filter form): v0, e1=v1-v0, e2=v2-v0
+ * rounded from the fp64 differences, the primitive id and two precomputed
+ * norms used by the conservative-filter tolerances.                        */
+typedef struct lh_tri32 {
+    float    v0[3];  float e1x;
+    float    e1y, e1z, e2x, e2y;
+    float    e2z;    uint32_t prim;
+    float    ne1, ne2;                            /* |e1|_2, |e2|_2 rounded up */
+} lh_tri32_t;
+
+/* 72-byte exact triangle (fp64), indexed by primitive id */
+typedef struct lh_tri64 { double v[3][3]; } lh_tri64_t;
+
+typedef struct lh_bvh {
+    uint32_t    ntris;
+    uint32_t    nnodes;
+    uint32_t    max_depth;
+    uint32_t    nleaves;
+    lh_node_t  *nodes;     /* nnodes (>=1 when ntris>0)                     */
+    lh_tri32_t *tri32;     /* ntris, leaf order                             */
+    lh_tri64_t *tri64;     /* ntris, primitive-id order                     */
+    uint32_t   *prim_geom; /* ntris: mesh ordinal of primitive              */
+    uint32_t   *prim_index;/* ntris: 3*i offset into that mesh's indices    */
+    float       bmin[3], bmax[3];  /* scene box, fp32 outward               */
+    double      build_seconds;
+} lh_bvh_t;
+
+typedef struct lh_mesh_view {
+    uint32_t        npositions;
+    const double   *positions;       /* first component of position 0       */
+    size_t          stride_bytes;    /* 24 for xyz, 32 for lucille's double[4] */
+    uint32_t        nindices;
+    const uint32_t *indices;
+} lh_mesh_view_t;
+
+/* returns 0 on success, -1 on bad input / out of memory */
+int  lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes,
+                  int nthreads);
+void lh_bvh_release(lh_bvh_t *bvh);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

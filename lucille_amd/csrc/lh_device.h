@@ -1,0 +1,51 @@
+/*
+ * lh_device.h -- shared host/device declarations for the gfx950 kernels.
+ * Internal to liblucille_hip.so (the public C-ABI is include/lucille_hip.h).
+ */
+#ifndef LH_DEVICE_H
+#define LH_DEVICE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#define LH_BLOCK      256          /* 4 wavefronts of 64 lanes              */
+#define LH_MISS_PRIM  0xFFFFFFFFu
+#define LH_T_INF      1.0e38       /* RI_INFINITY, include/ri.h:47          */
+
+/* device-resident scene (all pointers are HBM addresses) */
+typedef struct lh_dev_scene {
+    const void *nodes;     /* lh_node_t[nnodes]  (64 B each)                 */
+    const void *tri32;     /* lh_tri32_t[ntris]  (48 B each, leaf order)     */
+    const void *tri64;     /* lh_tri64_t[ntris]  (72 B each, prim-id order)  */
+    uint32_t    ntris;
+    uint32_t    nnodes;
+    uint32_t    max_depth;
+    float       scene_r;   /* max |coordinate| of the scene box              */
+} lh_dev_scene_t;
+
+/* traversal statistics accumulated by the COUNT variants (u64 each) */
+enum { LH_CNT_NODES = 0, LH_CNT_TRIS = 1, LH_CNT_EXACT = 2, LH_CNT_RAYS = 3, LH_CNT_N = 4 };
+
+/* kernel variants (A/B-testable in one process) */
+enum {
+    LH_VARIANT_DIRECT      = 0,   /* one ray per lane, grid covers the batch  */
+    LH_VARIANT_PERSIST_WAVE = 1,  /* persistent waves, 64-ray chunks          */
+    LH_VARIANT_PERSIST_LANE = 2   /* persistent waves, ballot-compacted refill */
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* launchers implemented in lh_kernels.hip; stream is a hipStream_t */
+int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double *d_org,
+                    const double *d_dir, uint32_t *d_prim, double *d_t,
+                    double *d_u, double *d_v, int anyhit, uint8_t *d_occluded,
+                    unsigned long long *d_counters /* LH_CNT_N or NULL */,
+                    unsigned long long *d_workq /* persistent cursor */,
+                    int variant, int grid_blocks, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,381 @@
+/*
+ * lh_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for lucille's
+ * BVH traversal + ray/triangle intersection hot path.
+ *
+ * What this replaces (reference, CPU, one ray at a time, all fp64):
+ *   ri_bvh_intersect          src/render/bvh.c:430-542
+ *   bvh_traverse              src/render/bvh.c:1092-1188
+ *   test_ray_node/aabb        src/render/bvh.c:869-1083
+ *   bvh_intersect_leaf_node   src/render/bvh.c:793-864
+ *   triangle_isect            src/render/bvh.c:730-791
+ *
+ * Design (see DESIGN.md for the full argument):
+ *
+ *  - one ray per lane, 64-lane wavefronts, 256-thread workgroups; each lane
+ *    owns a column of a [STACK][256] int stack in LDS (bank = lane % 32, so
+ *    pushes and pops are conflict-free whatever the per-lane depth);
+ *  - 64-byte SoA nodes holding BOTH children's fp32 boxes (4 x dwordx4 per
+ *    visit) and 48-byte fp32 triangle records (3 x dwordx4 per test);
+ *  - traversal and the Moeller-Trumbore test run in fp32 as a CONSERVATIVE
+ *    FILTER: boxes are rounded outward at build time, every slab interval is
+ *    widened by a per-ray slack that bounds the fp32 perturbation of the ray,
+ *    and every barycentric/t comparison carries a per-test tolerance.  A
+ *    triangle the filter cannot reject is queued (a 4-deep per-lane pending
+ *    list in registers);
+ *  - the queued candidates are resolved in fp64 with the reference's exact
+ *    operation order and no FMA contraction (exact_isect below == bvh.c:
+ *    730-791), wave-coherently when the lane's traversal has finished, so
+ *    (prim, t, u, v) are the reference's bits whenever no exact-t tie occurs;
+ *  - "certain" fp32 hits (inside by more than the tolerance) shrink the
+ *    culling bound for closest-hit and terminate any-hit rays at once, so AO
+ *    rays almost never touch fp64;
+ *  - persistent variants pull work from a global cursor: whole 64-ray chunks
+ *    (PERSIST_WAVE) or, ballot/popcount-compacted, just enough rays to refill
+ *    the lanes that have finished (PERSIST_LANE).
+ *
+ * No MFMA: this is branchy gather work bounded by the memory system.
+ * Compiled with -ffp-contract=off; fp32 code uses explicit fmaf().
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lh_device.h"
+#include "lh_filter.h"
+
+namespace {
+
+constexpr int   kDone  = (int)0x80000000; /* stack-bottom sentinel == LH_REF_EMPTY */
+constexpr int   kPend  = 4;
+
+struct Best {            /* exact (fp64) closest hit so far */
+    double   t, u, v;
+    uint32_t prim;
+};
+
+/* resolve one queued candidate against the running exact best.
+ * Tie rule (exact-equal t): larger primitive id wins -- the rule of a
+ * brute-force sweep with the reference's `t > t_best` reject (bvh.c:780). */
+__device__ __forceinline__ void resolve(const double *__restrict__ tri64, uint32_t prim,
+                                        double ox, double oy, double oz,
+                                        double dx, double dy, double dz, Best &b)
+{
+    double t, u, v;
+    if (lh_exact_isect(tri64 + 9 * (size_t)prim, ox, oy, oz, dx, dy, dz, &t, &u, &v)) {
+        if ((t < b.t) || (t == b.t && b.prim != LH_MISS_PRIM && prim > b.prim)) {
+            if (t < LH_T_INF) { b.t = t; b.u = u; b.v = v; b.prim = prim; }
+        }
+    }
+}
+
+struct Lane {
+    lh_ray32_t r;          /* fp32 ray + slab/filter constants */
+    float tb;              /* culling bound (fp32, rounded up) */
+    int   cur, sp;         /* traversal cursor, stack pointer  */
+    uint32_t p0, p1, p2, p3;   /* pending fp64 candidates      */
+    int   np;
+    bool  certain;         /* any-hit: a certain fp32 hit was found */
+};
+
+__device__ __forceinline__ void lane_init(Lane &L, const lh_dev_scene_t &sc,
+                                          double ox, double oy, double oz,
+                                          double dx, double dy, double dz)
+{
+    lh_ray_setup(&L.r, ox, oy, oz, dx, dy, dz, sc.scene_r);
+    L.tb = 1.0e38f;
+    L.cur = 0; L.sp = 1;
+    L.p0 = L.p1 = L.p2 = L.p3 = LH_MISS_PRIM; L.np = 0;
+    L.certain = false;
+}
+
+/* the per-lane traversal body; runs while the lane has work, leaves when
+ * `stop()` says the wave should regroup.  Returns with L.cur == kDone when the
+ * ray is finished. */
+template <int STACK, bool ANYHIT, bool COUNT, bool BURST>
+__device__ __forceinline__ void traverse(Lane &L, const lh_dev_scene_t &sc,
+                                         int (*stk)[LH_BLOCK], const int tid,
+                                         double ox, double oy, double oz,
+                                         double dx, double dy, double dz, Best &best,
+                                         uint32_t &c_nodes, uint32_t &c_tris, uint32_t &c_exact,
+                                         const int min_active)
+{
+    const float4 *__restrict__ nodes = (const float4 *)sc.nodes;
+    const float4 *__restrict__ tris  = (const float4 *)sc.tri32;
+    const double *__restrict__ tri64 = (const double *)sc.tri64;
+
+    while (L.cur != kDone) {
+        /* ---- inner nodes ------------------------------------------------ */
+        while (L.cur >= 0) {
+            const float4 *np = nodes + 4 * (size_t)L.cur;
+            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            if (COUNT) c_nodes++;
+            /* child0: lo (n0.x n0.y n0.z) hi (n0.w n1.x n1.y)
+             * child1: lo (n1.z n1.w n2.x) hi (n2.y n2.z n2.w) */
+            float tn0, tn1;
+            const bool h0 = lh_slab(&L.r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, L.tb, &tn0);
+            const bool h1 = lh_slab(&L.r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, L.tb, &tn1);
+            const int r0 = __float_as_int(n3.x), r1 = __float_as_int(n3.y);
+            if (h0 | h1) {
+                const bool second = h1 && (!h0 || tn1 < tn0);
+                L.cur = second ? r1 : r0;
+                if (h0 & h1) { stk[L.sp][tid] = second ? r0 : r1; L.sp++; }
+            } else {
+                L.sp--; L.cur = stk[L.sp][tid];
+            }
+        }
+        if (L.cur == kDone) break;
+
+        /* ---- leaf: fp32 conservative Moeller-Trumbore filter ------------ */
+        {
+            const uint32_t x = ~(uint32_t)L.cur;
+            const uint32_t first = x >> 2, cnt = (x & 3u) + 1u;
+            bool finished = false;
+            for (uint32_t i = 0; i < cnt; i++) {
+                const float4 *tp = tris + 3 * (size_t)(first + i);
+                const float4 ta = tp[0], tb_ = tp[1], tc = tp[2];
+                if (COUNT) c_tris++;
+                float t_hi;
+                const int cls = lh_tri_filter(&L.r, ta.x, ta.y, ta.z, ta.w, tb_.x, tb_.y,
+                                              tb_.z, tb_.w, tc.x, tc.z, tc.w, L.tb, &t_hi);
+                if (cls != LH_TRI_REJECT) {
+                    const bool sure = (cls == LH_TRI_CERTAIN);
+                    if (ANYHIT && sure) { L.certain = true; finished = true; break; }
+                    if (sure) L.tb = fminf(L.tb, t_hi);
+                    const uint32_t prim = __float_as_uint(tc.y);
+                    if (L.np == kPend) {
+                        /* pending list full: resolve it now (rare) */
+                        if (COUNT) c_exact += kPend;
+                        resolve(tri64, L.p0, ox, oy, oz, dx, dy, dz, best);
+                        resolve(tri64, L.p1, ox, oy, oz, dx, dy, dz, best);
+                        resolve(tri64, L.p2, ox, oy, oz, dx, dy, dz, best);
+                        resolve(tri64, L.p3, ox, oy, oz, dx, dy, dz, best);
+                        L.np = 0;
+                        if (ANYHIT && best.prim != LH_MISS_PRIM) { finished = true; break; }
+                    }
+                    L.p3 = L.p2; L.p2 = L.p1; L.p1 = L.p0; L.p0 = prim; L.np++;
+                }
+            }
+            if (finished) { L.cur = kDone; break; }
+            L.sp--; L.cur = stk[L.sp][tid];
+        }
+
+        if (BURST) {
+            /* wave regroup point: leave when too few lanes are still walking */
+            if (__popcll(__ballot(1)) < min_active) break;
+        }
+    }
+}
+
+/* resolve whatever is still queued; afterwards `best` is the exact answer */
+template <bool ANYHIT, bool COUNT>
+__device__ __forceinline__ void finish(Lane &L, const lh_dev_scene_t &sc,
+                                       double ox, double oy, double oz,
+                                       double dx, double dy, double dz, Best &best,
+                                       uint32_t &c_exact)
+{
+    const double *__restrict__ tri64 = (const double *)sc.tri64;
+    if (ANYHIT && (L.certain || best.prim != LH_MISS_PRIM)) return;
+    if (COUNT) c_exact += (uint32_t)L.np;
+    if (L.np > 0) resolve(tri64, L.p0, ox, oy, oz, dx, dy, dz, best);
+    if (L.np > 1) resolve(tri64, L.p1, ox, oy, oz, dx, dy, dz, best);
+    if (L.np > 2) resolve(tri64, L.p2, ox, oy, oz, dx, dy, dz, best);
+    if (L.np > 3) resolve(tri64, L.p3, ox, oy, oz, dx, dy, dz, best);
+    L.np = 0;
+}
+
+template <bool ANYHIT>
+__device__ __forceinline__ void write_out(size_t i, const Lane &L, const Best &best,
+                                          uint32_t *__restrict__ prim, double *__restrict__ t,
+                                          double *__restrict__ u, double *__restrict__ v,
+                                          uint8_t *__restrict__ occ)
+{
+    if (ANYHIT) {
+        occ[i] = (L.certain || best.prim != LH_MISS_PRIM) ? 1 : 0;
+    } else {
+        prim[i] = best.prim; t[i] = best.t; u[i] = best.u; v[i] = best.v;
+    }
+}
+
+__device__ __forceinline__ void add_counters(unsigned long long *c, uint32_t nodes, uint32_t tris,
+                                             uint32_t exact, uint32_t rays)
+{
+    /* COUNT builds are diagnostic: plain atomics are fine */
+    atomicAdd(&c[LH_CNT_NODES], (unsigned long long)nodes);
+    atomicAdd(&c[LH_CNT_TRIS], (unsigned long long)tris);
+    atomicAdd(&c[LH_CNT_EXACT], (unsigned long long)exact);
+    atomicAdd(&c[LH_CNT_RAYS], (unsigned long long)rays);
+}
+
+/* ------------------------------------------------------------------------ */
+/* variant 0: one ray per lane                                              */
+/* ------------------------------------------------------------------------ */
+template <int STACK, bool ANYHIT, bool COUNT>
+__global__ __launch_bounds__(LH_BLOCK) void k_trace_direct(
+    lh_dev_scene_t sc, size_t n, const double *__restrict__ org, const double *__restrict__ dir,
+    uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
+    double *__restrict__ v, uint8_t *__restrict__ occ, unsigned long long *counters)
+{
+    __shared__ int stk[STACK][LH_BLOCK];
+    const int tid = threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * LH_BLOCK + tid;
+    if (i >= n) return;
+    const double ox = org[3 * i], oy = org[3 * i + 1], oz = org[3 * i + 2];
+    const double dx = dir[3 * i], dy = dir[3 * i + 1], dz = dir[3 * i + 2];
+    Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM};
+    uint32_t cn = 0, ct = 0, ce = 0;
+    lane_init(L, sc, ox, oy, oz, dx, dy, dz);
+    stk[0][tid] = kDone;
+    traverse<STACK, ANYHIT, COUNT, false>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, 0);
+    finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
+    write_out<ANYHIT>(i, L, best, prim, t, u, v, occ);
+    if (COUNT) add_counters(counters, cn, ct, ce, 1);
+}
+
+/* ------------------------------------------------------------------------ */
+/* variant 1: persistent wavefronts, 64-ray chunks from a global cursor     */
+/* ------------------------------------------------------------------------ */
+template <int STACK, bool ANYHIT, bool COUNT>
+__global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_wave(
+    lh_dev_scene_t sc, size_t n, const double *__restrict__ org, const double *__restrict__ dir,
+    uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
+    double *__restrict__ v, uint8_t *__restrict__ occ, unsigned long long *counters,
+    unsigned long long *cursor)
+{
+    __shared__ int stk[STACK][LH_BLOCK];
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint32_t cn = 0, ct = 0, ce = 0, cr = 0;
+    for (;;) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(cursor, 64ull);
+        base = __shfl(base, 0);
+        if (base >= n) break;
+        const size_t i = base + lane;
+        if (i < n) {
+            const double ox = org[3 * i], oy = org[3 * i + 1], oz = org[3 * i + 2];
+            const double dx = dir[3 * i], dy = dir[3 * i + 1], dz = dir[3 * i + 2];
+            Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM};
+            lane_init(L, sc, ox, oy, oz, dx, dy, dz);
+            stk[0][tid] = kDone;
+            traverse<STACK, ANYHIT, COUNT, false>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, 0);
+            finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
+            write_out<ANYHIT>(i, L, best, prim, t, u, v, occ);
+            if (COUNT) cr++;
+        }
+    }
+    if (COUNT) add_counters(counters, cn, ct, ce, cr);
+}
+
+/* ------------------------------------------------------------------------ */
+/* variant 2: persistent wavefronts with ballot-compacted lane refill       */
+/* ------------------------------------------------------------------------ */
+template <int STACK, bool ANYHIT, bool COUNT>
+__global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
+    lh_dev_scene_t sc, size_t n, const double *__restrict__ org, const double *__restrict__ dir,
+    uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
+    double *__restrict__ v, uint8_t *__restrict__ occ, unsigned long long *counters,
+    unsigned long long *cursor, int min_active)
+{
+    __shared__ int stk[STACK][LH_BLOCK];
+    const int tid = threadIdx.x;
+    uint32_t cn = 0, ct = 0, ce = 0, cr = 0;
+    Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM};
+    size_t my = (size_t)-1;          /* ray this lane is working on */
+    double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
+    L.cur = kDone; L.sp = 1; L.np = 0; L.certain = false;
+    bool exhausted = false;          /* wave-uniform: cursor ran past n */
+
+    for (;;) {
+        /* ---- regroup: retire finished lanes, refill them ----------------- */
+        const bool idle = (L.cur == kDone);
+        const unsigned long long idle_mask = __ballot(idle);
+        if (idle) {
+            if (my != (size_t)-1) {
+                finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
+                write_out<ANYHIT>(my, L, best, prim, t, u, v, occ);
+                if (COUNT) cr++;
+                my = (size_t)-1;
+            }
+            if (!exhausted) {
+                const int need = __popcll(idle_mask);
+                const int rank = __popcll(idle_mask & ((1ull << (tid & 63)) - 1ull));
+                unsigned long long base = 0;
+                if (rank == 0) base = atomicAdd(cursor, (unsigned long long)need);
+                base = __shfl(base, __ffsll((long long)idle_mask) - 1);
+                const size_t i = base + rank;
+                if (i < n) {
+                    my = i;
+                    ox = org[3 * i]; oy = org[3 * i + 1]; oz = org[3 * i + 2];
+                    dx = dir[3 * i]; dy = dir[3 * i + 1]; dz = dir[3 * i + 2];
+                    lane_init(L, sc, ox, oy, oz, dx, dy, dz);
+                    best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM;
+                    stk[0][tid] = kDone;
+                }
+                if (base + need >= n) exhausted = true;
+            }
+        }
+        exhausted = __any(exhausted);
+        const unsigned long long work = __ballot(L.cur != kDone);
+        if (work == 0ull) break;
+        /* ---- walk until too few lanes remain active ---------------------- */
+        const int thresh = exhausted ? 1 : min_active;
+        if (L.cur != kDone)
+            traverse<STACK, ANYHIT, COUNT, true>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
+    }
+    if (COUNT) add_counters(counters, cn, ct, ce, cr);
+}
+
+template <int STACK, bool ANYHIT, bool COUNT>
+int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const double *dir,
+               uint32_t *prim, double *t, double *u, double *v, uint8_t *occ,
+               unsigned long long *counters, unsigned long long *cursor, int variant,
+               int grid_blocks, hipStream_t s)
+{
+    if (variant == LH_VARIANT_DIRECT) {
+        const size_t blocks = (n + LH_BLOCK - 1) / LH_BLOCK;
+        if (blocks > 0x7fffffffull) return -1;
+        hipLaunchKernelGGL((k_trace_direct<STACK, ANYHIT, COUNT>), dim3((unsigned)blocks), dim3(LH_BLOCK), 0, s,
+                           sc, n, org, dir, prim, t, u, v, occ, counters);
+    } else {
+        if (hipMemsetAsync(cursor, 0, sizeof(unsigned long long), s) != hipSuccess) return -1;
+        if (variant == LH_VARIANT_PERSIST_WAVE)
+            hipLaunchKernelGGL((k_trace_persist_wave<STACK, ANYHIT, COUNT>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor);
+        else
+            hipLaunchKernelGGL((k_trace_persist_lane<STACK, ANYHIT, COUNT>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, 40);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int STACK>
+int launch_stack(const lh_dev_scene_t &sc, size_t n, const double *org, const double *dir,
+                 uint32_t *prim, double *t, double *u, double *v, int anyhit, uint8_t *occ,
+                 unsigned long long *counters, unsigned long long *cursor, int variant,
+                 int grid_blocks, hipStream_t s)
+{
+    if (anyhit) {
+        if (counters) return launch_one<STACK, true, true>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, s);
+        return launch_one<STACK, true, false>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, s);
+    }
+    if (counters) return launch_one<STACK, false, true>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, s);
+    return launch_one<STACK, false, false>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, s);
+}
+
+} /* namespace */
+
+extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double *d_org,
+                               const double *d_dir, uint32_t *d_prim, double *d_t, double *d_u,
+                               double *d_v, int anyhit, uint8_t *d_occluded,
+                               unsigned long long *d_counters, unsigned long long *d_workq,
+                               int variant, int grid_blocks, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) return 0;
+    /* stack entries needed <= tree depth + 1 (sentinel) */
+    if (sc->max_depth + 1 <= 32)
+        return launch_stack<32>(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
+                                d_counters, d_workq, variant, grid_blocks, s);
+    if (sc->max_depth + 1 <= 64)
+        return launch_stack<64>(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
+                                d_counters, d_workq, variant, grid_blocks, s);
+    return -1;
+}

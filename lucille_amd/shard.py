@@ -1,0 +1,81 @@
+"""Sharding of the hot path over the GPUs of one node.
+
+The reference decomposes a frame into independent 32x32 buckets pulled from a
+queue by worker threads (lucille src/render/render.c:582-710,1043-1105) and its
+(compiled-out) MPI design is "every rank renders, rank 0 owns the display"
+(render.c:468-514, src/base/parallel.c:101-119).  Here: one process per GPU
+(torch.distributed, backend "nccl" == RCCL over xGMI), the BVH replicated in
+every GPU's HBM (each rank builds the same deterministic tree; no broadcast
+needed), units sharded with NO per-ray communication:
+
+  * ray dumps   -> contiguous slices            (ray_slice)
+  * image tiles -> tile_id % world == rank      (tiles_of_rank)
+
+and ONE exchange step: the gather of finished tiles to rank 0 (gather_tiles).
+"""
+import os
+
+
+def ray_slice(n, rank, world):
+    """contiguous [begin, end) of an n-ray dump owned by `rank`"""
+    return n * rank // world, n * (rank + 1) // world
+
+
+def tile_grid(width, height, tile):
+    """row-major list of (x0, y0, w, h) tiles covering the image (ragged edges kept)"""
+    out = []
+    for y0 in range(0, height, tile):
+        for x0 in range(0, width, tile):
+            out.append((x0, y0, min(tile, width - x0), min(tile, height - y0)))
+    return out
+
+
+def tiles_of_rank(ntiles, rank, world):
+    """interleaved assignment (load balance): tile_id % world == rank"""
+    return list(range(rank, ntiles, world))
+
+
+def init_process_group(backend=None):
+    """env:// rendezvous as launched by torch.distributed.run; returns (rank, world, local_rank)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def gather_tiles(image_shards, tile_ids, width, height, tile, channels, rank, world, dst=0):
+    """The exchange step.  image_shards: tensor [ntiles_local, tile*tile*channels] of this
+    rank's finished tiles (ragged tiles zero-padded), tile_ids: their ids.  Returns the
+    assembled [height, width, channels] image on rank `dst`, None elsewhere.
+    Equal-sized slabs -> one all_gather (RCCL: 7 point-to-point xGMI peers in parallel)."""
+    import torch
+    import torch.distributed as dist
+    tiles = tile_grid(width, height, tile)
+    per_rank = (len(tiles) + world - 1) // world
+    slab = torch.zeros((per_rank, tile * tile * channels), dtype=image_shards.dtype, device=image_shards.device)
+    if image_shards.shape[0]:
+        slab[:image_shards.shape[0]] = image_shards
+    if world > 1:
+        out = [torch.empty_like(slab) for _ in range(world)] if True else None
+        dist.all_gather(out, slab)
+    else:
+        out = [slab]
+    if rank != dst:
+        return None
+    img = torch.zeros((height, width, channels), dtype=image_shards.dtype, device=image_shards.device)
+    for r in range(world):
+        for k, tid in enumerate(tiles_of_rank(len(tiles), r, world)):
+            x0, y0, w, h = tiles[tid]
+            t = out[r][k].view(tile, tile, channels)
+            img[y0:y0 + h, x0:x0 + w] = t[:h, :w]
+    return img

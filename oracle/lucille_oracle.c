@@ -562,6 +562,23 @@ void lo_brute_force_batch(const lo_scene_t *s, size_t n, const double *org, cons
     run_batch(s, n, org, dir, prim, t, u, v, NULL, nthreads, 1);
 }
 
+/* number of triangles whose triangle_isect hit has EXACTLY t == t_ref[i]:
+ * >= 2 means the reference's winner depends on its traversal order (leaf
+ * order / first-visited-leaf rule, bvh.c:780,850), i.e. an exact-t tie. */
+void lo_count_equal_t_batch(const lo_scene_t *s, size_t n, const double *org, const double *dir,
+                            const double *t_ref, uint32_t *count)
+{
+    size_t i; uint64_t k;
+    for (i = 0; i < n; i++) {
+        uint32_t c = 0;
+        for (k = 0; k < s->ntris; k++) {
+            double t = LO_INFINITY, u = 0.0, v = 0.0; uint32_t tid = 0;
+            if (tri_isect(&tid, &t, &u, &v, &s->tris_orig[k], &org[3 * i], &dir[3 * i], 0) && t == t_ref[i]) c++;
+        }
+        count[i] = c;
+    }
+}
+
 /* ------------------------------------------------------ synthetic inputs */
 
 /* SURVEY.md Appendix C generator (the build's own tooling, not reference code) */

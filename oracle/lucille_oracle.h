@@ -91,6 +91,11 @@ void lo_brute_force_batch(const lo_scene_t *scene, size_t n,
                           uint32_t *prim, double *t, double *u, double *v,
                           int nthreads);
 
+/* brute force: how many triangles hit with exactly t == t_ref[i] (>= 2: an
+ * exact-t tie, where the reference's winner is traversal-order dependent) */
+void lo_count_equal_t_batch(const lo_scene_t *scene, size_t n, const double *org_xyz,
+                            const double *dir_xyz, const double *t_ref, uint32_t *count);
+
 /* the S-soup generator of SURVEY.md Appendix C (xorshift64 13/7/17).
  * state is in/out so the ray stream continues after the triangles. */
 void lo_soup_triangles(uint64_t *state, uint32_t ntri, double half_extent,

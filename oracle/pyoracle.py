@@ -82,6 +82,7 @@ def lib():
         L.lo_intersect_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _u32p, _dp, _dp, _dp,
                                          C.POINTER(Counters), C.c_int]
         L.lo_brute_force_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _u32p, _dp, _dp, _dp, C.c_int]
+        L.lo_count_equal_t_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _dp, _u32p]
         L.lo_soup_triangles.argtypes = [_u64p, C.c_uint32, C.c_double, _dp, _u32p]
         L.lo_soup_rays.argtypes = [_u64p, C.c_size_t, _dp, _dp]
         _lib = L
@@ -164,6 +165,14 @@ class Oracle:
 
     def intersect(self, org, dr, counters=False, nthreads=1):
         return self._run(self.L.lo_intersect_batch, org, dr, counters, nthreads)
+
+    def count_equal_t(self, org, dr, t_ref):
+        """per ray: number of triangles hit at exactly t_ref (brute force, small scenes)"""
+        org = _c(org, np.float64).reshape(-1, 3); dr = _c(dr, np.float64).reshape(-1, 3)
+        t_ref = _c(t_ref, np.float64)
+        cnt = np.zeros(org.shape[0], np.uint32)
+        self.L.lo_count_equal_t_batch(self.h, org.shape[0], _p(org, _dp), _p(dr, _dp), _p(t_ref, _dp), _p(cnt, _u32p))
+        return cnt
 
     def brute_force(self, org, dr, nthreads=1):
         return self._run(self.L.lo_brute_force_batch, org, dr, False, nthreads)

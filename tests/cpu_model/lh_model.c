@@ -1,0 +1,135 @@
+/*
+ * lh_model.c -- HOST MODEL of the gfx950 traversal kernel (test infrastructure).
+ *
+ * Not part of the product and never loaded by it.  It runs, on the CPU, the
+ * same algorithm as lucille_amd/csrc/lh_kernels.hip over the SAME flattened
+ * BVH (lh_bvh.c) with the SAME arithmetic (lh_filter.h is shared source):
+ * fp32 conservative slab test, fp32 tolerance-carrying Moeller-Trumbore
+ * filter, pending list, certain-hit bound shrinking, fp64 resolve.  The
+ * not-gpu tests use it to show, without a GPU, that the filter never loses a
+ * hit the fp64 oracle finds, and to count node visits / triangle tests of the
+ * product's own BVH for the roofline formula.
+ */
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "lh_bvh.h"
+#include "lh_filter.h"
+
+#define MISS 0xFFFFFFFFu
+#define DONE ((int32_t)0x80000000)
+#define T_INF 1.0e38
+#define PEND 4
+
+typedef struct { double t, u, v; uint32_t prim; } best_t;
+
+static void resolve(const lh_bvh_t *b, uint32_t prim, const double *o, const double *d, best_t *best)
+{
+    double t, u, v;
+    if (lh_exact_isect(&b->tri64[prim].v[0][0], o[0], o[1], o[2], d[0], d[1], d[2], &t, &u, &v)) {
+        if ((t < best->t) || (t == best->t && best->prim != MISS && prim > best->prim)) {
+            if (t < T_INF) { best->t = t; best->u = u; best->v = v; best->prim = prim; }
+        }
+    }
+}
+
+typedef struct {
+    const lh_bvh_t *b; size_t begin, end; const double *org, *dir;
+    uint32_t *prim; double *t, *u, *v; uint8_t *occ; int anyhit;
+    uint64_t c[4];
+} job_t;
+
+static void trace_one(job_t *j, size_t i)
+{
+    const lh_bvh_t *b = j->b;
+    const double *o = &j->org[3 * i], *d = &j->dir[3 * i];
+    best_t best = { T_INF, 0.0, 0.0, MISS };
+    int certain = 0;
+    j->c[3]++;
+    if (b->ntris) {
+        lh_ray32_t r; float tb = 1.0e38f, scene_r = 0.0f;
+        int32_t stack[LH_MAX_DEPTH + 8]; int sp = 1, cur = 0, np = 0, k;
+        uint32_t pend[PEND];
+        for (k = 0; k < 3; k++) { scene_r = fmaxf(scene_r, fabsf(b->bmin[k])); scene_r = fmaxf(scene_r, fabsf(b->bmax[k])); }
+        lh_ray_setup(&r, o[0], o[1], o[2], d[0], d[1], d[2], scene_r);
+        stack[0] = DONE;
+        while (cur != DONE) {
+            while (cur >= 0) {
+                const lh_node_t *n = &b->nodes[cur]; float tn0, tn1;
+                int h0, h1;
+                j->c[0]++;
+                h0 = lh_slab(&r, n->lo0[0], n->lo0[1], n->lo0[2], n->hi0[0], n->hi0[1], n->hi0[2], tb, &tn0);
+                h1 = lh_slab(&r, n->lo1[0], n->lo1[1], n->lo1[2], n->hi1[0], n->hi1[1], n->hi1[2], tb, &tn1);
+                if (h0 | h1) {
+                    int second = h1 && (!h0 || tn1 < tn0);
+                    cur = second ? n->ref1 : n->ref0;
+                    if (h0 & h1) stack[sp++] = second ? n->ref0 : n->ref1;
+                } else cur = stack[--sp];
+            }
+            if (cur == DONE) break;
+            {
+                uint32_t x = ~(uint32_t)cur, first = x >> 2, cnt = (x & 3u) + 1u, q; int finished = 0;
+                for (q = 0; q < cnt; q++) {
+                    const lh_tri32_t *T = &b->tri32[first + q]; float t_hi; int cls;
+                    j->c[1]++;
+                    cls = lh_tri_filter(&r, T->v0[0], T->v0[1], T->v0[2], T->e1x, T->e1y, T->e1z,
+                                        T->e2x, T->e2y, T->e2z, T->ne1, T->ne2, tb, &t_hi);
+                    if (cls != LH_TRI_REJECT) {
+                        int sure = (cls == LH_TRI_CERTAIN);
+                        if (j->anyhit && sure) { certain = 1; finished = 1; break; }
+                        if (sure) tb = fminf(tb, t_hi);
+                        if (np == PEND) {
+                            for (k = 0; k < PEND; k++) resolve(b, pend[k], o, d, &best);
+                            j->c[2] += PEND; np = 0;
+                            if (j->anyhit && best.prim != MISS) { finished = 1; break; }
+                        }
+                        pend[np++] = T->prim;
+                    }
+                }
+                if (finished) { cur = DONE; break; }
+                cur = stack[--sp];
+            }
+        }
+        if (!(j->anyhit && (certain || best.prim != MISS))) {
+            for (k = 0; k < np; k++) resolve(b, pend[k], o, d, &best);
+            j->c[2] += (uint64_t)np;
+        }
+    }
+    if (j->anyhit) j->occ[i] = (certain || best.prim != MISS) ? 1 : 0;
+    else { j->prim[i] = best.prim; j->t[i] = best.t; j->u[i] = best.u; j->v[i] = best.v; }
+}
+
+static void *run(void *arg) { job_t *j = (job_t *)arg; size_t i; for (i = j->begin; i < j->end; i++) trace_one(j, i); return NULL; }
+
+int lhm_trace(const lh_bvh_t *b, size_t n, const double *org, const double *dir, uint32_t *prim,
+              double *t, double *u, double *v, uint8_t *occ, int anyhit, uint64_t counters[4], int nthreads)
+{
+    int i; job_t *jobs; pthread_t *th;
+    if (nthreads < 1) nthreads = 1;
+    jobs = (job_t *)calloc((size_t)nthreads, sizeof(*jobs)); th = (pthread_t *)calloc((size_t)nthreads, sizeof(*th));
+    for (i = 0; i < nthreads; i++) {
+        jobs[i].b = b; jobs[i].begin = n * (size_t)i / (size_t)nthreads; jobs[i].end = n * (size_t)(i + 1) / (size_t)nthreads;
+        jobs[i].org = org; jobs[i].dir = dir; jobs[i].prim = prim; jobs[i].t = t; jobs[i].u = u; jobs[i].v = v;
+        jobs[i].occ = occ; jobs[i].anyhit = anyhit;
+    }
+    if (nthreads == 1) run(&jobs[0]);
+    else { for (i = 0; i < nthreads; i++) pthread_create(&th[i], NULL, run, &jobs[i]); for (i = 0; i < nthreads; i++) pthread_join(th[i], NULL); }
+    if (counters) { int k; for (k = 0; k < 4; k++) { counters[k] = 0; for (i = 0; i < nthreads; i++) counters[k] += jobs[i].c[k]; } }
+    free(jobs); free(th);
+    return 0;
+}
+
+/* host-only construction of the product's BVH (no device needed) */
+lh_bvh_t *lhm_build(uint32_t npos, const double *pos_xyz, uint32_t nidx, const uint32_t *idx, int nthreads)
+{
+    lh_bvh_t *b = (lh_bvh_t *)calloc(1, sizeof(*b)); lh_mesh_view_t m;
+    m.npositions = npos; m.positions = pos_xyz; m.stride_bytes = 24; m.nindices = nidx; m.indices = idx;
+    if (lh_bvh_build(b, &m, 1, nthreads) != 0) { free(b); return NULL; }
+    return b;
+}
+void lhm_free(lh_bvh_t *b) { if (b) { lh_bvh_release(b); free(b); } }
+void lhm_info(const lh_bvh_t *b, uint32_t out[4]) { out[0] = b->ntris; out[1] = b->nnodes; out[2] = b->max_depth; out[3] = b->nleaves; }
+double lhm_build_seconds(const lh_bvh_t *b) { return b->build_seconds; }
+const void *lhm_nodes(const lh_bvh_t *b) { return b->nodes; }
+const void *lhm_tri32(const lh_bvh_t *b) { return b->tri32; }

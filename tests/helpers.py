@@ -1,0 +1,134 @@
+"""Shared test helpers (test infrastructure)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+MODEL_DIR = os.path.join(ROOT, "tests", "cpu_model")
+CSRC = os.path.join(ROOT, "lucille_amd", "csrc")
+
+_dp = C.POINTER(C.c_double)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def _fma_flag():
+    try:
+        return ["-mfma"] if " fma " in open("/proc/cpuinfo").read() else []
+    except OSError:
+        return []
+
+
+def build_model():
+    """tests/cpu_model/liblh_model.so: host model of the kernel algorithm over
+    the product's own BVH builder (lh_bvh.c) and arithmetic (lh_filter.h)."""
+    so = os.path.join(MODEL_DIR, "liblh_model.so")
+    srcs = [os.path.join(MODEL_DIR, "lh_model.c"), os.path.join(CSRC, "lh_bvh.c"),
+            os.path.join(CSRC, "lh_bvh.h"), os.path.join(CSRC, "lh_filter.h")]
+    if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-shared"] + _fma_flag() +
+                              ["-I" + CSRC, srcs[0], srcs[1], "-o", so, "-lm", "-lpthread"])
+    return so
+
+
+class Model:
+    """Host model of the HIP kernel (see tests/cpu_model/lh_model.c)."""
+    _L = None
+
+    @classmethod
+    def lib(cls):
+        if cls._L is None:
+            L = C.CDLL(build_model())
+            L.lhm_build.restype = C.c_void_p
+            L.lhm_build.argtypes = [C.c_uint32, _dp, C.c_uint32, _u32p, C.c_int]
+            L.lhm_free.argtypes = [C.c_void_p]
+            L.lhm_info.argtypes = [C.c_void_p, _u32p]
+            L.lhm_nodes.restype = C.c_void_p
+            L.lhm_nodes.argtypes = [C.c_void_p]
+            L.lhm_tri32.restype = C.c_void_p
+            L.lhm_tri32.argtypes = [C.c_void_p]
+            L.lhm_trace.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _u32p, _dp, _dp, _dp,
+                                    C.POINTER(C.c_uint8), C.c_int, C.POINTER(C.c_uint64), C.c_int]
+            cls._L = L
+        return cls._L
+
+    def __init__(self, positions, indices, nthreads=4):
+        L = self.lib()
+        P = np.ascontiguousarray(positions, np.float64).reshape(-1, 3)
+        I = np.ascontiguousarray(indices, np.uint32).reshape(-1)
+        self.h = L.lhm_build(P.shape[0], P.ctypes.data_as(_dp), I.shape[0], I.ctypes.data_as(_u32p), nthreads)
+        assert self.h, "lh_bvh_build failed"
+        info = np.zeros(4, np.uint32)
+        L.lhm_info(self.h, info.ctypes.data_as(_u32p))
+        self.ntris, self.nnodes, self.max_depth, self.nleaves = map(int, info)
+
+    def __del__(self):
+        try:
+            self.lib().lhm_free(self.h)
+        except Exception:
+            pass
+
+    def nodes(self):
+        if self.nnodes == 0:
+            return np.zeros((0, 16), np.float32)
+        buf = (C.c_float * (16 * self.nnodes)).from_address(self.lib().lhm_nodes(self.h))
+        return np.frombuffer(buf, np.float32).reshape(-1, 16).copy()
+
+    def tri32(self):
+        if self.ntris == 0:
+            return np.zeros((0, 12), np.float32)
+        buf = (C.c_float * (12 * self.ntris)).from_address(self.lib().lhm_tri32(self.h))
+        return np.frombuffer(buf, np.float32).reshape(-1, 12).copy()
+
+    def trace(self, org, dr, anyhit=False, nthreads=4):
+        org = np.ascontiguousarray(org, np.float64).reshape(-1, 3)
+        dr = np.ascontiguousarray(dr, np.float64).reshape(-1, 3)
+        n = org.shape[0]
+        cnt = np.zeros(4, np.uint64)
+        cp = cnt.ctypes.data_as(C.POINTER(C.c_uint64))
+        if anyhit:
+            occ = np.empty(n, np.uint8)
+            self.lib().lhm_trace(self.h, n, org.ctypes.data_as(_dp), dr.ctypes.data_as(_dp), None, None, None, None,
+                                 occ.ctypes.data_as(C.POINTER(C.c_uint8)), 1, cp, nthreads)
+            return occ, dict(zip(("nodes", "tris", "exact", "rays"), map(int, cnt)))
+        prim = np.empty(n, np.uint32); t = np.empty(n); u = np.empty(n); v = np.empty(n)
+        self.lib().lhm_trace(self.h, n, org.ctypes.data_as(_dp), dr.ctypes.data_as(_dp), prim.ctypes.data_as(_u32p),
+                             t.ctypes.data_as(_dp), u.ctypes.data_as(_dp), v.ctypes.data_as(_dp), None, 0, cp, nthreads)
+        return (prim, t, u, v), dict(zip(("nodes", "tris", "exact", "rays"), map(int, cnt)))
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def random_rays(rng, n, lo=-0.2, hi=1.2):
+    org = rng.uniform(lo, hi, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return org, d
+
+
+def grid_mesh(nx, ny, z=0.0, size=1.0):
+    """axis-aligned quad grid split 0-1-2 / 0-2-3 like polygon.c; shared vertices,
+    so rays through vertices/edges/diagonals exercise the tolerance band"""
+    xs = np.linspace(0.0, size, nx + 1); ys = np.linspace(0.0, size, ny + 1)
+    P = np.array([[x, y, z] for y in ys for x in xs], np.float64)
+    idx = []
+    for j in range(ny):
+        for i in range(nx):
+            a = j * (nx + 1) + i; b = a + 1; c = a + nx + 2; d = a + nx + 1
+            idx += [a, b, c, a, c, d]
+    return P, np.array(idx, np.uint32)
+
+
+def assert_hits_equal(got, exp, what=""):
+    names = ("prim", "t", "u", "v")
+    for k in range(4):
+        g = np.asarray(got[k]); e = np.asarray(exp[k])
+        if k == 0:
+            g = g.view(np.uint32) if g.dtype == np.int32 else g
+        bad = np.nonzero(g != e)[0]
+        assert bad.size == 0, "%s: %s differs at %d rays, first %s: got %r expected %r" % (
+            what, names[k], bad.size, bad[:5], g[bad[:5]], e[bad[:5]])

@@ -1,0 +1,196 @@
+"""Parity tests proper: the HIP path (through the C ABI, liblucille_hip.so) against
+the oracle on the same seeded inputs, against the committed reference goldens,
+and -- at BASELINE sizes -- through size-independent properties.
+Bit-exact for prim ids AND for t/u/v (stronger than the 1e-5 the north star asks)."""
+import numpy as np
+import pytest
+
+import lucille_amd as la
+from oracle import pyoracle as po
+from tests.helpers import Model, assert_hits_equal, grid_mesh, load_golden, random_rays
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [la.VARIANT_DIRECT, la.VARIANT_PERSIST_WAVE, la.VARIANT_PERSIST_LANE]
+
+
+def torch_rays(org, dr):
+    import torch
+    return (torch.from_numpy(np.ascontiguousarray(org, np.float64)).cuda(),
+            torch.from_numpy(np.ascontiguousarray(dr, np.float64)).cuda())
+
+
+def gpu_closest(acc, org, dr, variant):
+    import torch
+    o, d = torch_rays(org, dr)
+    out = acc.intersect_device(o, d, variant=variant)
+    torch.cuda.synchronize()
+    return (out[0].cpu().numpy().view(np.uint32), out[1].cpu().numpy(), out[2].cpu().numpy(), out[3].cpu().numpy())
+
+
+def gpu_any(acc, org, dr, variant):
+    import torch
+    o, d = torch_rays(org, dr)
+    out = acc.intersect_device(o, d, mode=la.MODE_ANY, variant=variant)
+    torch.cuda.synchronize()
+    return out[0].cpu().numpy()
+
+
+def make_accel(P, idx):
+    acc = la.HipAccel(0)
+    acc.add_mesh(P, idx)
+    acc.commit()
+    return acc
+
+
+@pytest.mark.parametrize("name", ["soup_20k", "soup_3k_fat"])
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_reference_goldens(name, variant):
+    g = load_golden(name)
+    P, idx, org, dr = po.soup(int(g["ntri"]), int(g["nrays"]), float(g["half_extent"]), int(g["seed"]))
+    acc = make_accel(P, idx)
+    assert_hits_equal(gpu_closest(acc, org, dr, variant), (g["prim"], g["t"], g["u"], g["v"]), name)
+    assert np.array_equal(gpu_any(acc, org, dr, variant).astype(bool), g["prim"] != po.MISS)
+
+
+@pytest.mark.parametrize("ntri,nrays,he,seed", [(200000, 300000, 0.005, 21), (50000, 100000, 0.0007, 22), (7, 30001, 0.4, 23)])
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_oracle_parity_seeded(ntri, nrays, he, seed, variant):
+    P, idx, org, dr = po.soup(ntri, nrays, he, seed)
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr, nthreads=16)
+    acc = make_accel(P, idx)
+    assert_hits_equal(gpu_closest(acc, org, dr, variant), exp, "soup %d v%d" % (ntri, variant))
+    assert np.array_equal(gpu_any(acc, org, dr, variant).astype(bool), exp[0] != po.MISS)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 255, 256, 257, 1000])
+def test_ragged_batch_sizes(n):
+    P, idx, org, dr = po.soup(5000, 1000, 0.03, 31)
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org[:n], dr[:n])
+    acc = make_accel(P, idx)
+    for variant in VARIANTS:
+        assert_hits_equal(gpu_closest(acc, org[:n], dr[:n], variant), exp, "n=%d v%d" % (n, variant))
+
+
+def test_empty_scene_and_empty_batch():
+    import torch
+    acc = la.HipAccel(0); acc.add_mesh(np.zeros((0, 3)), np.zeros(0, np.uint32)); acc.commit()
+    org, dr = random_rays(np.random.default_rng(0), 100)
+    prim, t, u, v = gpu_closest(acc, org, dr, la.VARIANT_DEFAULT)
+    assert (prim == la.MISS).all() and (t == 1.0e38).all() and (u == 0).all() and (v == 0).all()
+    assert (gpu_any(acc, org, dr, la.VARIANT_DEFAULT) == 0).all()
+    P, idx, _, _ = po.soup(100, 1, 0.1, 1)
+    acc2 = make_accel(P, idx)
+    e = torch.empty((0, 3), dtype=torch.float64, device="cuda")
+    out = acc2.intersect_device(e, e)
+    assert out[0].numel() == 0
+    # accel with no meshes at all
+    acc3 = la.HipAccel(0); acc3.commit()
+    assert (acc3.intersect_host(org, dr)[0] == la.MISS).all()
+
+
+def test_host_batch_and_single_ray_entry_points():
+    """lh_accel_intersect_host / lh_accel_intersect1 == accel_intersect_func semantics"""
+    P, idx, org, dr = po.soup(3000, 2000, 0.05, 41)
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr)
+    acc = make_accel(P, idx)
+    assert_hits_equal(acc.intersect_host(org, dr), exp, "host batch")
+    assert np.array_equal(acc.intersect_host(org, dr, mode=la.MODE_ANY).astype(bool), exp[0] != po.MISS)
+    for i in range(25):
+        hit, prim, t, u, v = acc.intersect1(org[i], dr[i])
+        assert hit == int(exp[0][i] != po.MISS) and prim == exp[0][i] and t == exp[1][i] and u == exp[2][i] and v == exp[3][i]
+
+
+def test_multi_mesh_prim_lookup():
+    P1, i1, org, dr = po.soup(300, 5000, 0.1, 11)
+    P2, i2, _, _ = po.soup(500, 1, 0.1, 22)
+    P2w = np.concatenate([P2, np.ones((P2.shape[0], 1))], 1)      # lucille's double[4] stride
+    acc = la.HipAccel(0); acc.add_mesh(P1, i1); acc.add_mesh(P2w, i2); acc.commit()
+    o = po.Oracle(); o.add_mesh(P1, i1); o.add_mesh(P2, i2); o.build()
+    exp = o.intersect(org, dr)
+    assert_hits_equal(acc.intersect_host(org, dr), exp, "two meshes")
+    assert acc.prim_lookup(299) == (0, 3 * 299) and acc.prim_lookup(300) == (1, 0) and acc.prim_lookup(799) == (1, 3 * 499)
+    with pytest.raises(la.LucilleHipError):
+        acc.prim_lookup(800)
+
+
+def test_tolerance_band_geometry():
+    """axis-aligned shared-vertex grid, rays through vertices/edges/diagonals, far
+    origins, AO-style origins 1e-6 above the surface: the fp32 filter's band cases"""
+    P, idx = grid_mesh(8, 8)
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    acc = make_accel(P, idx)
+    xs = np.linspace(0.0, 1.0, 33); tx, ty = np.meshgrid(xs, xs)
+    tgt = np.stack([tx.ravel(), ty.ravel(), np.zeros(tx.size)], 1)
+    rng = np.random.default_rng(0)
+    for oz in (1.0, 37.5, 1e-3):
+        org = np.tile(np.array([[0.3, 0.45, oz]]), (tgt.shape[0], 1)) + rng.uniform(-0.2, 0.2, (tgt.shape[0], 3)) * [1, 1, 0]
+        dr = tgt - org
+        exp = o.intersect(org, dr)
+        tie = o.count_equal_t(org, dr, exp[1]) >= 2
+        bf = o.brute_force(org, dr)
+        for variant in VARIANTS:
+            got = gpu_closest(acc, org, dr, variant)
+            assert np.array_equal(got[1], exp[1])                      # t bit-exact even on ties
+            assert np.array_equal(got[0][tie], bf[0][tie])             # documented tie rule
+            assert_hits_equal(tuple(g[~tie] for g in got), tuple(e[~tie] for e in exp), "grid oz=%g" % oz)
+            assert np.array_equal(gpu_any(acc, org, dr, variant).astype(bool), exp[0] != po.MISS)
+    n = 50000
+    org = np.stack([rng.uniform(0, 1, n), rng.uniform(0, 1, n), np.full(n, 1e-6)], 1)
+    d = rng.normal(size=(n, 3)); d[:, 2] = np.abs(d[:, 2]); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    for z in (1e-6, 0.0, -1e-9):
+        org[:, 2] = z
+        exp = o.intersect(org, d, nthreads=8)
+        assert_hits_equal(gpu_closest(acc, org, d, la.VARIANT_PERSIST_LANE), exp, "surface z=%g" % z)
+        assert np.array_equal(gpu_any(acc, org, d, la.VARIANT_PERSIST_LANE).astype(bool), exp[0] != po.MISS)
+
+
+def test_counters_match_host_model():
+    """the COUNT kernel variant reports the node visits / triangle tests the roofline
+    formula uses; the host model of the same algorithm must count the same"""
+    import torch
+    P, idx, org, dr = po.soup(30000, 20000, 0.005, 61)
+    acc = make_accel(P, idx)
+    o_, d_ = torch_rays(org, dr)
+    _, cnt = acc.intersect_device(o_, d_, counters=True, variant=la.VARIANT_DIRECT)
+    m = Model(P, idx)
+    _, mc = m.trace(org, dr)
+    assert cnt["rays"] == mc["rays"] == 20000
+    # v_rcp_f32 vs 1/x may move a handful of band decisions: counts agree to 1e-4
+    for k in ("nodes", "tris"):
+        assert abs(cnt[k] - mc[k]) <= 1e-4 * mc[k] + 4, (k, cnt[k], mc[k])
+
+
+def test_full_size_properties_soup_1m():
+    """BASELINE config 3 scale (1M triangles): properties that need no CPU reference:
+    any-hit == (closest hit exists); variants agree bit for bit; t >= 0; the hit point
+    lies inside the hit triangle's box; first 200k rays bit-exact vs the oracle."""
+    import torch
+    ntri, nrays = 1000000, 4000000
+    P, idx, org, dr = po.soup(ntri, nrays)
+    acc = make_accel(P, idx)
+    o_, d_ = torch_rays(org, dr)
+    res = {}
+    for variant in VARIANTS:
+        out = acc.intersect_device(o_, d_, variant=variant)
+        occ = acc.intersect_device(o_, d_, mode=la.MODE_ANY, variant=variant)[0]
+        torch.cuda.synchronize()
+        res[variant] = [x.clone() for x in out]
+        hit = out[0] != -1
+        assert torch.equal(hit, occ.bool())
+        assert (out[1][hit] >= 0).all() and (out[1][~hit] == 1.0e38).all()
+    for variant in VARIANTS[1:]:
+        for a, b in zip(res[VARIANTS[0]], res[variant]):
+            assert torch.equal(a, b)
+    prim = res[0][0].cpu().numpy().view(np.uint32); t = res[0][1].cpu().numpy()
+    hit = prim != la.MISS
+    tri = P[idx].reshape(-1, 3, 3)[prim[hit]]
+    X = org[hit] + dr[hit] * t[hit][:, None]
+    assert (X >= tri.min(1) - 1e-9).all() and (X <= tri.max(1) + 1e-9).all()
+    n = 200000
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org[:n], dr[:n], nthreads=32)
+    assert_hits_equal(tuple(x.cpu().numpy()[:n] for x in res[2]), exp, "soup-1M prefix")
