@@ -136,7 +136,7 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
     if (rc != 0) return fail("lh_accel_commit: BVH build failed (bad input or out of memory)");
     /* the packed mesh copies are no longer needed: the BVH holds tri64 */
     for (uint32_t g = 0; g < a->nmeshes; g++) { free(a->meshes[g].pos); free(a->meshes[g].idx); }
-    free(a->meshes); a->meshes = NULL;
+    free(a->meshes); a->meshes = NULL; a->nmeshes = 0;
 
     HIPCHK(hipSetDevice(a->device));
     double t0 = now_s();
