@@ -1,0 +1,142 @@
+/*
+ * lucille_accel.h -- host-side (plain C) mirror of lucille's accelerator plugin
+ * interface for the ray-query path, with the HIP accelerator as a new method.
+ *
+ * Same names, argument meaning and error behaviour as the reference:
+ *
+ *   ri_accel_t, accel_*_func, ri_accel_new/free/bind   src/render/accel.h:24-92, accel.c:28-109
+ *   ri_raytrace                                        src/render/raytrace.h:46-49, raytrace.c:31-69
+ *   ri_geom_new / _add_positions / _add_indices ...    src/render/geom.h:67-131
+ *   ri_scene_new / _add_geom / _build_accel            src/render/scene.h:60-96, scene.c:84-167
+ *   ri_intersection_state_build                        src/render/intersection_state.c:99-248
+ *   ri_render_init / ri_render_get                     src/render/render.h:104-105
+ *
+ * so that code written against lucille's API for THIS path (build a scene of
+ * ri_geom_t, bind an accelerator, call ri_raytrace per ray) compiles and runs
+ * against liblucille_hip.so, and parity tests read like lucille programs.
+ * Structs carry only the members this path reads or writes; they are this
+ * library's own layout (inside lucille itself the glue in
+ * integration/ri_accel_hip.c adapts lucille's real structs to the flat C ABI of
+ * lucille_hip.h -- see INTEGRATION.md).
+ *
+ * New relative to the reference, because a one-ray-synchronous vtable cannot
+ * feed a GPU: RI_ACCEL_HIP, ri_raytrace_batch(), ri_accel_intersect_batch().
+ */
+#ifndef LUCILLE_ACCEL_H
+#define LUCILLE_ACCEL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef double ri_float_t;          /* src/base/common.h:24-27 */
+typedef double ri_vector_t[4];      /* src/base/vector.h:61    */
+
+#define RI_ACCEL_UGRID 0            /* accel.h:20 (lives in lucille; not provided here) */
+#define RI_ACCEL_BVH   1            /* accel.h:21 (lives in lucille; not provided here) */
+#define RI_ACCEL_HIP   2            /* new: MI355X accelerator, option string "hip"     */
+
+/* ---- geometry: the BVH's input (geom.h:29-65) -------------------------- */
+typedef struct _ri_geom_t {
+    ri_vector_t  *positions;   unsigned int npositions;
+    ri_vector_t  *normals;     unsigned int nnormals;
+    unsigned int *indices;     unsigned int nindices;
+    int           two_side;
+} ri_geom_t;
+
+ri_geom_t *ri_geom_new(void);
+void       ri_geom_free(ri_geom_t *geom);
+void       ri_geom_add_positions(ri_geom_t *geom, unsigned int npositions, const ri_vector_t *positions);
+void       ri_geom_add_normals(ri_geom_t *geom, unsigned int nnormals, const ri_vector_t *normals);
+void       ri_geom_add_indices(ri_geom_t *geom, unsigned int nindices, const unsigned int *indices);
+
+/* ---- ray / hit state (ray.h:22-68, intersection_state.h:34-61) --------- */
+typedef struct _ri_ray_t {
+    ri_vector_t org;           /* [in]  position                              */
+    ri_vector_t dir;           /* [in]  direction, need not be normalised     */
+    float       t;             /* reset to 0 by ri_raytrace (raytrace.c:49)   */
+    int         dir_sign[3];   /* [out] scratch the reference writes (bvh.c:473-497) */
+    ri_vector_t invdir;        /* [out] idem                                  */
+    int         thread_num;
+} ri_ray_t;
+
+typedef struct _ri_intersection_state_t {
+    ri_vector_t  P, Ng, Ns, E, I;
+    double       t;
+    char         inside;
+    ri_geom_t   *geom;         /* borrowed pointer to the hit geometry        */
+    uint32_t     index;        /* 3*i offset into geom->indices (bvh.c:1813)  */
+    ri_vector_t  color, tangent, binormal, stqr;
+    ri_float_t   u, v;
+} ri_intersection_state_t;
+
+void ri_intersection_state_build(ri_intersection_state_t *state_inout,
+                                 const ri_vector_t eye, const ri_vector_t dir);
+
+/* ---- accelerator plugin (accel.h:24-75) --------------------------------- */
+typedef void *(*accel_build_func)(const void *data /* const ri_scene_t* */);
+typedef void  (*accel_free_func)(void *accel);
+typedef int   (*accel_intersect_func)(void *accel, ri_ray_t *ray,
+                                      ri_intersection_state_t *state, void *user);
+
+typedef struct _ri_accel_t {
+    accel_build_func     build;
+    accel_free_func      free;
+    accel_intersect_func intersect;
+    void                *data;
+} ri_accel_t;
+
+ri_accel_t *ri_accel_new(void);
+void        ri_accel_free(ri_accel_t *accel);
+/* 0 on success, -1 on unknown/unavailable method (accel.c:102-106) */
+int         ri_accel_bind(ri_accel_t *accel, int method);
+
+/* the HIP implementation of the three vtable entries */
+void *ri_hipbvh_build(const void *scene);
+void  ri_hipbvh_free(void *accel);
+int   ri_hipbvh_intersect(void *accel, ri_ray_t *ray, ri_intersection_state_t *state, void *user);
+
+/* ---- scene / render (scene.h:31-96, render.h:104-105) ------------------- */
+typedef struct _ri_scene_t {
+    ri_geom_t  **geom_list;  unsigned int ngeoms;     /* geoms in list order */
+    ri_accel_t  *accel;
+} ri_scene_t;
+
+ri_scene_t *ri_scene_new(void);
+void        ri_scene_free(ri_scene_t *scene);
+void        ri_scene_add_geom(ri_scene_t *scene, const ri_geom_t *geom);
+int         ri_scene_build_accel(ri_scene_t *scene);     /* 0 / -1 (scene.c:153-167) */
+
+typedef struct _ri_render_t {
+    ri_scene_t *scene;
+    struct { uint64_t nrays; } stat;                     /* raytrace.c:43 */
+    int         device;                                  /* HIP device for RI_ACCEL_HIP */
+} ri_render_t;
+
+void         ri_render_init(void);
+ri_render_t *ri_render_get(void);
+void         ri_render_free(void);
+
+/* ---- queries ------------------------------------------------------------- */
+/* 1 hit / 0 miss; state_out written only on a hit (raytrace.c:56-66) */
+int ri_raytrace(ri_render_t *render, ri_ray_t *ray, ri_intersection_state_t *state_out);
+
+/* n rays in one device launch; hit[i] in {0,1}; states[i] written on hit exactly as
+ * ri_raytrace would.  Returns number of hits, -1 on error. */
+long ri_raytrace_batch(ri_render_t *render, size_t n, ri_ray_t *rays,
+                       ri_intersection_state_t *states, int *hit);
+
+/* SoA batch straight on the accelerator: mode 0 closest (prim,t,u,v), 1 any (occluded) */
+int ri_accel_intersect_batch(void *accel, size_t n, const double *org_xyz, const double *dir_xyz,
+                             uint32_t *prim, double *t, double *u, double *v,
+                             uint8_t *occluded, int mode);
+/* primitive id -> (geom, index), the pair state->geom/state->index carry */
+int ri_accel_prim_lookup(void *accel, uint32_t prim, ri_geom_t **geom, uint32_t *index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,115 @@
+/*
+ * ri_accel_hip.c -- the reference-side glue a lucille maintainer adds to make
+ * the MI355X accelerator a third accel method next to RI_ACCEL_UGRID/BVH.
+ *
+ * This file is compiled INSIDE lucille (it includes lucille's own headers:
+ * src/render/accel.h, scene.h, geom.h, intersection_state.h, src/base/list.h)
+ * and talks to liblucille_hip.so only through the flat C ABI of
+ * include/lucille_hip.h.  Together with a three-line case in ri_accel_bind
+ * (accel.c:72-109) and an "hip" string in the Option "raytrace" "accel_method"
+ * parser (src/ri/option.c:453-462) it is the whole integration -- see
+ * INTEGRATION.md.  oracle/Makefile builds it against the real reference
+ * (oracle/_ref/liblucille_ref_hip.so) so tests can drive the reference's OWN
+ * renderer through the GPU accelerator.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "accel.h"
+#include "scene.h"
+#include "geom.h"
+#include "list.h"
+#include "log.h"
+#include "intersection_state.h"
+
+#include "lucille_hip.h"
+
+#ifndef RI_ACCEL_HIP
+#define RI_ACCEL_HIP 2
+#endif
+
+typedef struct {
+    lh_accel_t *lh;
+    ri_geom_t **geoms;          /* back-pointers in geom_list order (cf. bvh.c:1808) */
+    unsigned    ngeoms;
+} ri_hipbvh_t;
+
+static int g_ri_hip_device = 0;
+void ri_hipbvh_set_device(int device) { g_ri_hip_device = device; }
+
+/* accel_build_func: walks scene->geom_list exactly like create_triangle_list
+ * (bvh.c:1758-1821) so primitive ids match the CPU BVH's numbering */
+void *ri_hipbvh_build(const void *data)
+{
+    const ri_scene_t *scene = (const ri_scene_t *)data;
+    ri_hipbvh_t *h;
+    ri_list_t *itr;
+    unsigned n = 0;
+
+    for (itr = ri_list_first((ri_list_t *)scene->geom_list); itr != NULL; itr = ri_list_next(itr)) n++;
+
+    h = (ri_hipbvh_t *)calloc(1, sizeof(*h));
+    h->geoms = (ri_geom_t **)calloc(n ? n : 1, sizeof(ri_geom_t *));
+    if (lh_accel_create(&h->lh, g_ri_hip_device) != 0) {
+        ri_log(LOG_ERROR, "(HIPBVH) %s", lh_last_error());
+        free(h->geoms); free(h);
+        return NULL;
+    }
+    for (itr = ri_list_first((ri_list_t *)scene->geom_list); itr != NULL; itr = ri_list_next(itr)) {
+        ri_geom_t *geom = (ri_geom_t *)itr->data;
+        h->geoms[h->ngeoms++] = geom;
+        /* positions are ri_vector_t = double[4]: stride 32 bytes */
+        if (lh_accel_add_mesh(h->lh, geom->npositions, (const double *)geom->positions,
+                              sizeof(ri_vector_t), geom->nindices, geom->indices) != 0) {
+            ri_log(LOG_ERROR, "(HIPBVH) %s", lh_last_error());
+        }
+    }
+    if (lh_accel_commit(h->lh, 0) != 0) {
+        ri_log(LOG_ERROR, "(HIPBVH) %s", lh_last_error());
+        lh_accel_destroy(h->lh); free(h->geoms); free(h);
+        return NULL;
+    }
+    return h;
+}
+
+/* accel_free_func */
+void ri_hipbvh_free(void *accel)
+{
+    ri_hipbvh_t *h = (ri_hipbvh_t *)accel;
+    if (!h) return;
+    lh_accel_destroy(h->lh);
+    free(h->geoms);
+    free(h);
+}
+
+/* accel_intersect_func: one synchronous ray (the reference's calling
+ * convention); transports that batch use lh_accel_intersect_host/_device */
+int ri_hipbvh_intersect(void *accel, ri_ray_t *ray, ri_intersection_state_t *state, void *user)
+{
+    ri_hipbvh_t *h = (ri_hipbvh_t *)accel;
+    uint32_t prim, mesh, index;
+    double t, u, v;
+    int hit;
+    (void)user;
+
+    hit = lh_accel_intersect1(h->lh, ray->org, ray->dir, &prim, &t, &u, &v);
+    if (hit <= 0) return 0;
+
+    lh_accel_prim_lookup(h->lh, prim, &mesh, &index);
+    state->t = t; state->u = u; state->v = v;
+    state->geom = h->geoms[mesh];
+    state->index = index;
+    ri_intersection_state_build(state, ray->org, ray->dir);   /* as bvh.c:537-539 */
+    return 1;
+}
+
+/* what ri_accel_bind's new case does */
+int ri_accel_bind_hip(ri_accel_t *accel)
+{
+    ri_log(LOG_DEBUG, "(Accel ) Use HIP (MI355X) accelerator");
+    accel->build     = ri_hipbvh_build;
+    accel->free      = ri_hipbvh_free;
+    accel->intersect = ri_hipbvh_intersect;
+    return 0;
+}

@@ -1,0 +1,339 @@
+/*
+ * lh_host.c -- host side (plain C) above the C ABI: the reference's plugin
+ * interface for the ray-query path, bound to the HIP accelerator.
+ * See include/lucille_accel.h for the reference file:line of every function.
+ */
+#include "lucille_accel.h"
+#include "lucille_hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- geom ---- */
+
+ri_geom_t *ri_geom_new(void) { return (ri_geom_t *)calloc(1, sizeof(ri_geom_t)); }
+
+void ri_geom_free(ri_geom_t *g)
+{
+    if (!g) return;
+    free(g->positions); free(g->normals); free(g->indices); free(g);
+}
+
+static void *dup_bytes(const void *src, size_t n)
+{
+    void *p = malloc(n ? n : 1);
+    if (p && n) memcpy(p, src, n);
+    return p;
+}
+
+/* geom.c:78-99: silently ignores empty input */
+void ri_geom_add_positions(ri_geom_t *g, unsigned int n, const ri_vector_t *p)
+{
+    if (!g || n == 0 || !p) return;
+    free(g->positions);
+    g->positions = (ri_vector_t *)dup_bytes(p, sizeof(ri_vector_t) * n); g->npositions = n;
+}
+
+void ri_geom_add_normals(ri_geom_t *g, unsigned int n, const ri_vector_t *p)
+{
+    if (!g || n == 0 || !p) return;
+    free(g->normals);
+    g->normals = (ri_vector_t *)dup_bytes(p, sizeof(ri_vector_t) * n); g->nnormals = n;
+}
+
+void ri_geom_add_indices(ri_geom_t *g, unsigned int n, const unsigned int *idx)
+{
+    if (!g || n == 0 || !idx) return;
+    free(g->indices);
+    g->indices = (unsigned int *)dup_bytes(idx, sizeof(unsigned int) * n); g->nindices = n;
+}
+
+/* --------------------------------------------------------------- scene ---- */
+
+ri_scene_t *ri_scene_new(void)
+{
+    ri_scene_t *s = (ri_scene_t *)calloc(1, sizeof(ri_scene_t));
+    if (s) s->accel = ri_accel_new();            /* scene.c:43 */
+    return s;
+}
+
+void ri_scene_free(ri_scene_t *s)
+{
+    if (!s) return;
+    ri_accel_free(s->accel);                     /* scene.c:73 */
+    free(s->geom_list);
+    free(s);
+}
+
+void ri_scene_add_geom(ri_scene_t *s, const ri_geom_t *g)
+{
+    ri_geom_t **nl;
+    if (!s || !g) return;
+    nl = (ri_geom_t **)realloc(s->geom_list, sizeof(ri_geom_t *) * (s->ngeoms + 1));
+    if (!nl) return;
+    s->geom_list = nl;
+    s->geom_list[s->ngeoms++] = (ri_geom_t *)g;
+}
+
+int ri_scene_build_accel(ri_scene_t *s)
+{
+    if (!s || !s->accel || !s->accel->build) {
+        fprintf(stderr, "[lucille_hip] FATAL : No spatial accelerator is assigned to the scene.\n");
+        return -1;                               /* scene.c:158-161 */
+    }
+    s->accel->data = s->accel->build((const void *)s);
+    return s->accel->data ? 0 : -1;
+}
+
+/* --------------------------------------------------------------- accel ---- */
+
+ri_accel_t *ri_accel_new(void) { return (ri_accel_t *)calloc(1, sizeof(ri_accel_t)); }
+
+void ri_accel_free(ri_accel_t *a)
+{
+    if (!a) return;
+    if (a->free && a->data) a->free(a->data);    /* accel.c:45-50 */
+    free(a);
+}
+
+int ri_accel_bind(ri_accel_t *a, int method)
+{
+    if (!a) return -1;
+    switch (method) {
+    case RI_ACCEL_HIP:
+        a->build = ri_hipbvh_build; a->free = ri_hipbvh_free; a->intersect = ri_hipbvh_intersect;
+        return 0;
+    case RI_ACCEL_UGRID:
+    case RI_ACCEL_BVH:
+        fprintf(stderr, "[lucille_hip] ERROR : (Accel ) CPU accel method %d lives in lucille itself; "
+                        "this library provides RI_ACCEL_HIP only (no CPU fallback)\n", method);
+        return -1;
+    default:
+        fprintf(stderr, "[lucille_hip] ERROR : (Accel ) Unknown accel method\n");   /* accel.c:104 */
+        return -1;
+    }
+}
+
+/* what `void *accel` points to for RI_ACCEL_HIP */
+typedef struct {
+    lh_accel_t  *lh;
+    ri_geom_t  **geoms; unsigned int ngeoms;     /* borrowed back-pointers, as in bvh.c:1808 */
+} hipbvh_t;
+
+static int g_device = 0;
+
+void *ri_hipbvh_build(const void *data)
+{
+    const ri_scene_t *scene = (const ri_scene_t *)data;
+    hipbvh_t *h; unsigned int g;
+    if (!scene) return NULL;
+    h = (hipbvh_t *)calloc(1, sizeof(*h));
+    if (!h) return NULL;
+    if (lh_accel_create(&h->lh, g_device) != 0) {
+        fprintf(stderr, "[lucille_hip] ERROR : (HIPBVH) %s\n", lh_last_error());
+        free(h); return NULL;
+    }
+    h->ngeoms = scene->ngeoms;
+    h->geoms = (ri_geom_t **)dup_bytes(scene->geom_list, sizeof(ri_geom_t *) * scene->ngeoms);
+    for (g = 0; g < scene->ngeoms; g++) {
+        const ri_geom_t *geom = scene->geom_list[g];
+        if (lh_accel_add_mesh(h->lh, geom->npositions, (const double *)geom->positions,
+                              sizeof(ri_vector_t), geom->nindices, geom->indices) != 0) {
+            fprintf(stderr, "[lucille_hip] ERROR : (HIPBVH) %s\n", lh_last_error());
+            ri_hipbvh_free(h); return NULL;
+        }
+    }
+    if (lh_accel_commit(h->lh, 0) != 0) {
+        fprintf(stderr, "[lucille_hip] ERROR : (HIPBVH) %s\n", lh_last_error());
+        ri_hipbvh_free(h); return NULL;
+    }
+    return h;
+}
+
+void ri_hipbvh_free(void *accel)
+{
+    hipbvh_t *h = (hipbvh_t *)accel;
+    if (!h) return;
+    lh_accel_destroy(h->lh);
+    free(h->geoms);
+    free(h);
+}
+
+static void fill_state(hipbvh_t *h, ri_intersection_state_t *st, uint32_t prim, double t, double u, double v,
+                       const ri_vector_t org, const ri_vector_t dir)
+{
+    uint32_t mesh = 0, index = 0;
+    lh_accel_prim_lookup(h->lh, prim, &mesh, &index);
+    st->t = t; st->u = u; st->v = v;
+    st->geom = h->geoms[mesh]; st->index = index;
+    ri_intersection_state_build(st, org, dir);   /* bvh.c:537-539 */
+}
+
+int ri_hipbvh_intersect(void *accel, ri_ray_t *ray, ri_intersection_state_t *state, void *user)
+{
+    hipbvh_t *h = (hipbvh_t *)accel;
+    uint32_t prim; double t, u, v; int hit, k;
+    (void)user;
+    if (!h || !ray || !state) return 0;
+    /* the scratch members the reference writes into the caller's ray (bvh.c:473-497) */
+    for (k = 0; k < 3; k++) {
+        ray->dir_sign[k] = (ray->dir[k] < 0.0) ? 1 : 0;
+        ray->invdir[k] = (fabs(ray->dir[k]) > 1.0e-14) ? 1.0 / ray->dir[k]
+                                                       : ((ray->dir[k] < 0.0) ? -1.7976931348623157e308 : 1.7976931348623157e308);
+    }
+    hit = lh_accel_intersect1(h->lh, ray->org, ray->dir, &prim, &t, &u, &v);
+    if (hit < 0) { fprintf(stderr, "[lucille_hip] ERROR : (HIPBVH) %s\n", lh_last_error()); return 0; }
+    /* bvh_traverse initialises these whether or not there is a hit (bvh.c:1111-1115) */
+    state->t = 1.0e38; state->u = 0.0; state->v = 0.0; state->geom = NULL; state->index = 0;
+    if (hit) fill_state(h, state, prim, t, u, v, ray->org, ray->dir);
+    return hit;
+}
+
+/* -------------------------------------------------------------- render ---- */
+
+static ri_render_t *g_render = NULL;
+
+void ri_render_init(void)
+{
+    if (g_render) return;                        /* render.c:177-179 */
+    g_render = (ri_render_t *)calloc(1, sizeof(ri_render_t));
+    g_render->scene = ri_scene_new();
+    g_render->device = g_device;
+}
+
+ri_render_t *ri_render_get(void) { return g_render; }
+
+void ri_render_free(void)
+{
+    if (!g_render) return;
+    ri_scene_free(g_render->scene);
+    free(g_render); g_render = NULL;
+}
+
+/* ------------------------------------------------------------- queries ---- */
+
+int ri_raytrace(ri_render_t *render, ri_ray_t *ray, ri_intersection_state_t *state_out)
+{
+    int hit; ri_intersection_state_t state;
+    if (!render || !render->scene || !render->scene->accel || !render->scene->accel->intersect) return 0;
+    render->stat.nrays++;                        /* raytrace.c:43 */
+    memset(&state, 0, sizeof(state));
+    state.inside = 0; ray->t = 0.0f;             /* raytrace.c:48-49 */
+    hit = render->scene->accel->intersect(render->scene->accel->data, ray, &state, NULL);
+    if (hit) memcpy(state_out, &state, sizeof(state));   /* raytrace.c:64-66 */
+    return hit;
+}
+
+int ri_accel_intersect_batch(void *accel, size_t n, const double *org, const double *dir, uint32_t *prim,
+                             double *t, double *u, double *v, uint8_t *occluded, int mode)
+{
+    hipbvh_t *h = (hipbvh_t *)accel;
+    if (!h) return -1;
+    if (lh_accel_intersect_host(h->lh, n, org, dir, prim, t, u, v, occluded, mode) != 0) {
+        fprintf(stderr, "[lucille_hip] ERROR : (HIPBVH) %s\n", lh_last_error());
+        return -1;
+    }
+    return 0;
+}
+
+int ri_accel_prim_lookup(void *accel, uint32_t prim, ri_geom_t **geom, uint32_t *index)
+{
+    hipbvh_t *h = (hipbvh_t *)accel; uint32_t mesh = 0, idx = 0;
+    if (!h || lh_accel_prim_lookup(h->lh, prim, &mesh, &idx) != 0) return -1;
+    if (geom) *geom = h->geoms[mesh];
+    if (index) *index = idx;
+    return 0;
+}
+
+long ri_raytrace_batch(ri_render_t *render, size_t n, ri_ray_t *rays, ri_intersection_state_t *states, int *hit)
+{
+    hipbvh_t *h; double *org, *dir, *t, *u, *v; uint32_t *prim; size_t i; long nhit = 0; int k;
+    if (!render || !render->scene || !render->scene->accel) return -1;
+    if (render->scene->accel->intersect != ri_hipbvh_intersect) {
+        /* any other accelerator: the reference's own per-ray loop */
+        for (i = 0; i < n; i++) { hit[i] = ri_raytrace(render, &rays[i], &states[i]); nhit += hit[i]; }
+        return nhit;
+    }
+    h = (hipbvh_t *)render->scene->accel->data;
+    if (!h) return -1;
+    if (n == 0) return 0;
+    org = (double *)malloc(sizeof(double) * 3 * n); dir = (double *)malloc(sizeof(double) * 3 * n);
+    t = (double *)malloc(sizeof(double) * n); u = (double *)malloc(sizeof(double) * n); v = (double *)malloc(sizeof(double) * n);
+    prim = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    if (!org || !dir || !t || !u || !v || !prim) { nhit = -1; goto done; }
+    for (i = 0; i < n; i++)
+        for (k = 0; k < 3; k++) { org[3 * i + k] = rays[i].org[k]; dir[3 * i + k] = rays[i].dir[k]; }
+    if (ri_accel_intersect_batch(h, n, org, dir, prim, t, u, v, NULL, LH_MODE_CLOSEST) != 0) { nhit = -1; goto done; }
+    render->stat.nrays += n;
+    for (i = 0; i < n; i++) {
+        rays[i].t = 0.0f;
+        hit[i] = prim[i] != LH_MISS;
+        if (hit[i]) {
+            memset(&states[i], 0, sizeof(states[i]));
+            fill_state(h, &states[i], prim[i], t[i], u[i], v[i], rays[i].org, rays[i].dir);
+            nhit++;
+        }
+    }
+done:
+    free(org); free(dir); free(t); free(u); free(v); free(prim);
+    return nhit;
+}
+
+/* --------------------------------------------------- hit epilogue (host) ---- */
+
+static void vnormalize(ri_vector_t d)
+{   /* ri_vector_normalize, src/base/vector.h:75-86 (threshold is the FLOAT 1.0e-17f) */
+    double norm2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    if (norm2 > 1.0e-17f) { double rsq = 1.0 / sqrt(norm2); d[0] *= rsq; d[1] *= rsq; d[2] *= rsq; }
+}
+
+static void vcross(ri_vector_t d, const ri_vector_t a, const ri_vector_t b)
+{
+    d[0] = a[1] * b[2] - a[2] * b[1]; d[1] = a[2] * b[0] - a[0] * b[2]; d[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* ri_ortho_basis, src/render/reflection.c:311-333 */
+static void ortho_basis(ri_vector_t basis[3], const ri_vector_t n)
+{
+    int i;
+    memcpy(basis[2], n, sizeof(ri_vector_t));
+    basis[1][0] = basis[1][1] = basis[1][2] = basis[1][3] = 0.0;
+    for (i = 0; i < 3; i++) if (basis[2][i] < 0.6 && basis[2][i] > -0.6) break;
+    if (i >= 3) i = 0;
+    basis[1][i] = 1.0;
+    vcross(basis[0], basis[1], basis[2]); vnormalize(basis[0]);
+    vcross(basis[1], basis[2], basis[0]); vnormalize(basis[1]);
+}
+
+/* intersection_state.c:99-248, for the members this struct carries */
+void ri_intersection_state_build(ri_intersection_state_t *st, const ri_vector_t eye, const ri_vector_t dir)
+{
+    const ri_geom_t *geom = st->geom; uint32_t index = st->index;
+    const double t = st->t, u = st->u, v = st->v;
+    uint32_t i0, i1, i2; ri_vector_t v01, v02, basis[3]; int k;
+    st->P[0] = eye[0] + dir[0] * t; st->P[1] = eye[1] + dir[1] * t; st->P[2] = eye[2] + dir[2] * t; st->P[3] = 0.0;
+    memcpy(st->I, dir, sizeof(ri_vector_t)); vnormalize(st->I);
+    memcpy(st->E, eye, sizeof(ri_vector_t));
+    i0 = geom->indices[index + 0]; i1 = geom->indices[index + 1]; i2 = geom->indices[index + 2];
+    /* ri_normal_of_triangle, src/base/geometric.c:31-44 */
+    for (k = 0; k < 3; k++) { v01[k] = geom->positions[i1][k] - geom->positions[i0][k]; v02[k] = geom->positions[i2][k] - geom->positions[i0][k]; }
+    vcross(st->Ng, v01, v02); vnormalize(st->Ng);
+    if (geom->normals) {
+        /* ri_lerp_vector, geometric.c:51-72: (1-u-v) n0 + u n1 + v n2, in that order */
+        const double w = 1.0 - u - v;
+        for (k = 0; k < 3; k++) {
+            double a = geom->normals[i0][k] * w, b = geom->normals[i1][k] * u, c = geom->normals[i2][k] * v;
+            st->Ns[k] = (a + b) + c;
+        }
+    } else {
+        memcpy(st->Ns, st->Ng, sizeof(ri_vector_t));
+    }
+    ortho_basis(basis, st->Ng);
+    memcpy(st->tangent, basis[0], sizeof(ri_vector_t));
+    memcpy(st->binormal, basis[1], sizeof(ri_vector_t));
+    st->color[0] = st->color[1] = st->color[2] = 1.0; st->color[3] = 0.0;
+    st->stqr[0] = st->stqr[1] = 0.0;
+    st->inside = (geom->two_side && index >= geom->nindices / 2) ? 1 : 0;
+}

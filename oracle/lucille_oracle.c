@@ -71,6 +71,8 @@ typedef struct {
     uint32_t npos, nidx;
     double  *pos;   /* xyz */
     uint32_t *idx;
+    double  *nrm;   /* optional vertex normals xyz (geom->normals) */
+    int      two_side;
 } lo_mesh_t;
 
 struct lo_scene {
@@ -106,7 +108,7 @@ void lo_scene_free(lo_scene_t *s)
 {
     uint32_t i;
     if (!s) return;
-    for (i = 0; i < s->nmeshes; i++) { free(s->meshes[i].pos); free(s->meshes[i].idx); }
+    for (i = 0; i < s->nmeshes; i++) { free(s->meshes[i].pos); free(s->meshes[i].idx); free(s->meshes[i].nrm); }
     free(s->meshes);
     free_tree(s);
     free(s);
@@ -118,11 +120,25 @@ int lo_scene_add_mesh(lo_scene_t *s, uint32_t npos, const double *pos,
     lo_mesh_t *m;
     s->meshes = (lo_mesh_t *)realloc(s->meshes, sizeof(lo_mesh_t) * (s->nmeshes + 1));
     m = &s->meshes[s->nmeshes++];
-    m->npos = npos; m->nidx = nidx;
+    m->npos = npos; m->nidx = nidx; m->nrm = NULL; m->two_side = 0;
     m->pos = (double *)malloc(sizeof(double) * 3 * (npos ? npos : 1));
     m->idx = (uint32_t *)malloc(sizeof(uint32_t) * (nidx ? nidx : 1));
     memcpy(m->pos, pos, sizeof(double) * 3 * npos);
     memcpy(m->idx, idx, sizeof(uint32_t) * nidx);
+    return 0;
+}
+
+int lo_scene_set_normals(lo_scene_t *s, uint32_t mesh, const double *normals_xyz, int two_side)
+{
+    lo_mesh_t *m;
+    if (mesh >= s->nmeshes) return -1;
+    m = &s->meshes[mesh];
+    free(m->nrm); m->nrm = NULL;
+    if (normals_xyz) {
+        m->nrm = (double *)malloc(sizeof(double) * 3 * (m->npos ? m->npos : 1));
+        memcpy(m->nrm, normals_xyz, sizeof(double) * 3 * m->npos);
+    }
+    m->two_side = two_side;
     return 0;
 }
 
@@ -560,6 +576,36 @@ void lo_brute_force_batch(const lo_scene_t *s, size_t n, const double *org, cons
                           uint32_t *prim, double *t, double *u, double *v, int nthreads)
 {
     run_batch(s, n, org, dir, prim, t, u, v, NULL, nthreads, 1);
+}
+
+/* ---- accessors for lucille_oracle_ao.c ---------------------------------- */
+
+int lo_priv_intersect1(const lo_scene_t *s, const double *org, const double *dir,
+                       uint32_t *prim, double *t, double *u, double *v)
+{
+    lo_hit_t h; lo_ray_t r; double tmin, tmax, b[6]; int k;
+    h.t = LO_INFINITY; h.u = 0.0; h.v = 0.0; h.prim = LO_MISS;
+    if (!s->empty) {
+        ray_setup(&r, org, dir);
+        for (k = 0; k < 3; k++) { b[k] = s->bmin[k]; b[3 + k] = s->bmax[k]; }
+        if (ray_aabb(&tmin, &tmax, b, &r)) traverse(s, &r, &h, NULL);
+    }
+    *prim = h.prim; *t = h.t; *u = h.u; *v = h.v;
+    return h.prim != LO_MISS;
+}
+
+/* vertex positions / normals of primitive `prim`: v[3][3]; n may come back NULL */
+void lo_priv_prim_vertices(const lo_scene_t *s, uint32_t prim, const double **v0, const double **v1,
+                           const double **v2, const double **n0, const double **n1, const double **n2,
+                           int *inside_flag_two_side, uint32_t *index, uint32_t *nindices)
+{
+    const lo_tri_t *t = &s->tris_orig[prim];
+    const lo_mesh_t *m = &s->meshes[t->geom];
+    uint32_t i0 = m->idx[t->index], i1 = m->idx[t->index + 1], i2 = m->idx[t->index + 2];
+    *v0 = &m->pos[3 * (size_t)i0]; *v1 = &m->pos[3 * (size_t)i1]; *v2 = &m->pos[3 * (size_t)i2];
+    if (m->nrm) { *n0 = &m->nrm[3 * (size_t)i0]; *n1 = &m->nrm[3 * (size_t)i1]; *n2 = &m->nrm[3 * (size_t)i2]; }
+    else { *n0 = *n1 = *n2 = NULL; }
+    *inside_flag_two_side = m->two_side; *index = t->index; *nindices = m->nidx;
 }
 
 /* number of triangles whose triangle_isect hit has EXACTLY t == t_ref[i]:

@@ -104,16 +104,36 @@ void lo_soup_triangles(uint64_t *state, uint32_t ntri, double half_extent,
 void lo_soup_rays(uint64_t *state, size_t nrays, double *org_xyz,
                   double *dir_xyz);
 
+/* optional per-vertex normals / two_side flag of mesh `mesh` (geom->normals,
+ * geom->two_side; consumed by ri_intersection_state_build) */
+int lo_scene_set_normals(lo_scene_t *scene, uint32_t mesh, const double *normals_xyz, int two_side);
+
 /* ------------------------------------------------------------------ */
-/* AO transport / camera restatement (see lucille_oracle_ao.c)        */
+/* callers on either side of the ray query (lucille_oracle_ao.c)       */
 /* ------------------------------------------------------------------ */
 
 typedef struct lo_camera {
     int    width, height;
-    double fov;              /* degrees */
-    int    rh;               /* Orientation "rh" => 1 */
-    double cam2world[16];    /* row-major 4x4, row-vector convention */
+    int    rh;               /* Orientation "rh" => 1 (camera->is_rh)        */
+    int    pad;
+    double flength;          /* 1/tan(fov/2), camera.c:219                   */
+    double cam2world[16];    /* camera_to_world, row-major, row-vector conv. */
 } lo_camera_t;
+
+void lo_camera_ray(const lo_camera_t *cam, double x, double y, double org[3], double dir[3]);
+void lo_subpixel_jitter(int xs, int ys, int xsamples, int ysamples, double jitter[2]);
+int  lo_bucket_order(int width, int height, int bucket_size, unsigned int *out_xy);
+void lo_ortho_basis(double basis[3][3], const double n[3]);
+void lo_state_build(const lo_scene_t *scene, uint32_t prim, double t, double u, double v,
+                    const double org[3], const double dir[3],
+                    double P[3], double Ng[3], double Ns[3], int *inside);
+void lo_ao_rays(const double P[3], const double Ns[3], uint32_t ntheta, uint32_t nphi,
+                const double *rnd, double *org_xyz, double *dir_xyz);
+void lo_mt_stream(unsigned long seed, size_t n, double *out);
+size_t lo_render_ao(const lo_scene_t *scene, const lo_camera_t *cam, int xsamples, int ysamples,
+                    int gather_nsamples, int bucket_size, float *image,
+                    double *rec_org, double *rec_dir, uint32_t *rec_prim, double *rec_t,
+                    double *rec_u, double *rec_v, size_t rec_cap);
 
 #ifdef __cplusplus
 }

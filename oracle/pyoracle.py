@@ -63,6 +63,23 @@ class TreeStats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class Camera(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("rh", C.c_int), ("pad", C.c_int),
+                ("flength", C.c_double), ("cam2world", C.c_double * 16)]
+
+    @classmethod
+    def from_ref(cls, cam20, width=None, height=None):
+        """from the 20 doubles lref_camera_get captures: c2w[16], flength, w, h, is_rh"""
+        c = cls()
+        for i in range(16):
+            c.cam2world[i] = float(cam20[i])
+        c.flength = float(cam20[16])
+        c.width = int(cam20[17]) if width is None else width
+        c.height = int(cam20[18]) if height is None else height
+        c.rh = int(cam20[19])
+        return c
+
+
 _lib = None
 
 
@@ -83,6 +100,16 @@ def lib():
                                          C.POINTER(Counters), C.c_int]
         L.lo_brute_force_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _u32p, _dp, _dp, _dp, C.c_int]
         L.lo_count_equal_t_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _dp, _u32p]
+        L.lo_scene_set_normals.argtypes = [C.c_void_p, C.c_uint32, _dp, C.c_int]
+        L.lo_camera_ray.argtypes = [C.POINTER(Camera), C.c_double, C.c_double, _dp, _dp]
+        L.lo_state_build.argtypes = [C.c_void_p, C.c_uint32, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp, _dp, _dp,
+                                     C.POINTER(C.c_int)]
+        L.lo_ao_rays.argtypes = [_dp, _dp, C.c_uint32, C.c_uint32, _dp, _dp, _dp]
+        L.lo_mt_stream.argtypes = [C.c_ulong, C.c_size_t, _dp]
+        L.lo_bucket_order.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint)]
+        L.lo_render_ao.restype = C.c_size_t
+        L.lo_render_ao.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.POINTER(C.c_float), _dp, _dp, _u32p, _dp, _dp, _dp, C.c_size_t]
         L.lo_soup_triangles.argtypes = [_u64p, C.c_uint32, C.c_double, _dp, _u32p]
         L.lo_soup_rays.argtypes = [_u64p, C.c_size_t, _dp, _dp]
         _lib = L
@@ -128,8 +155,29 @@ class Oracle:
         I = _c(indices, np.uint32).reshape(-1)
         self.L.lo_scene_add_mesh(self.h, P.shape[0], _p(P, _dp), I.shape[0], _p(I, _u32p))
 
+    def set_normals(self, mesh, normals, two_side=0):
+        N = _c(normals, np.float64).reshape(-1, 3) if normals is not None else None
+        self.L.lo_scene_set_normals(self.h, mesh, _p(N, _dp), int(two_side))
+
     def build(self):
         self.L.lo_scene_build(self.h)
+
+    def render_ao(self, cam, pixel_samples, gather_nsamples, record=True, bucket_size=32):
+        """the reference's frame loop + AO transport, single thread (lo_render_ao)"""
+        W, H = cam.width, cam.height
+        img = np.zeros((H, W, 3), np.float32)
+        n_ao = int(np.sqrt(gather_nsamples)) ** 2
+        cap = W * H * pixel_samples * pixel_samples * (1 + n_ao) if record else 0
+        ro = np.empty((cap, 3)); rd = np.empty((cap, 3)); rp = np.empty(cap, np.uint32)
+        rt = np.empty(cap); ru = np.empty(cap); rv = np.empty(cap)
+        n = self.L.lo_render_ao(self.h, C.byref(cam), pixel_samples, pixel_samples, gather_nsamples, bucket_size,
+                                img.ctypes.data_as(C.POINTER(C.c_float)), _p(ro, _dp) if record else None,
+                                _p(rd, _dp) if record else None, _p(rp, _u32p) if record else None,
+                                _p(rt, _dp) if record else None, _p(ru, _dp) if record else None,
+                                _p(rv, _dp) if record else None, cap)
+        if not record:
+            return img, n
+        return img, {"org": ro[:n], "dir": rd[:n], "prim": rp[:n], "t": rt[:n], "u": ru[:n], "v": rv[:n]}
 
     @property
     def ntriangles(self):

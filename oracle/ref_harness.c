@@ -36,8 +36,18 @@
 #include "raytrace.h"
 #include "ray.h"
 #include "intersection_state.h"
+#include "context.h"
+#include "option.h"
+#include "camera.h"
+#include "display.h"
+#include "hash.h"
+#include "list.h"
 
 #define LREF_MISS 0xFFFFFFFFu
+
+#ifdef LREF_WITH_HIP
+extern int ri_accel_bind_hip(ri_accel_t *accel);   /* integration/ri_accel_hip.c */
+#endif
 
 /* ---------------------------------------------------------------------- */
 /* replacement for render/accel.c (ri_accel_new/free/bind, accel.c:28-109) */
@@ -66,14 +76,31 @@ static uint32_t geom_ordinal(const ri_geom_t *g)
     return LREF_MISS;
 }
 
+/* camera of the frame being rendered, captured at the first query (it is set up
+ * after the accelerator is built, render.c:335-336) */
+static double g_cam[16 + 4];   /* camera_to_world row-major, flength, w, h, is_rh */
+static int    g_cam_valid = 0;
+static accel_intersect_func g_inner_intersect = NULL;
+
+static void capture_camera(void)
+{
+    ri_camera_t *c = ri_render_get()->context->option->camera;
+    int i, j;
+    for (i = 0; i < 4; i++) for (j = 0; j < 4; j++) g_cam[4 * i + j] = c->camera_to_world.f[i][j];
+    g_cam[16] = c->flength; g_cam[17] = c->horizontal_resolution; g_cam[18] = c->vertical_resolution;
+    g_cam[19] = c->is_rh;
+    g_cam_valid = 1;
+}
+
 static int recording_intersect(void *accel, ri_ray_t *ray,
                                ri_intersection_state_t *state, void *user)
 {
     double o[3], d[3];
     int hit;
+    if (!g_cam_valid) capture_camera();
     o[0] = ray->org[0]; o[1] = ray->org[1]; o[2] = ray->org[2];
     d[0] = ray->dir[0]; d[1] = ray->dir[1]; d[2] = ray->dir[2];
-    hit = ri_bvh_intersect(accel, ray, state, user);
+    hit = g_inner_intersect(accel, ray, state, user);
     if (g_rec_on) {
         lref_record_t *r;
         if (g_rec_n == g_rec_cap) {
@@ -89,6 +116,46 @@ static int recording_intersect(void *accel, ri_ray_t *ray,
     }
     return hit;
 }
+
+/* geometry of the scene the renderer hands to build(): captured so fixtures can
+ * hold the triangles the reference actually traced (after its own RIB ingest,
+ * polygon.c:494-1001) */
+static void capture_scene(const ri_scene_t *scene)
+{
+    ri_list_t *itr;
+    g_ngeoms = 0; g_geom_base[0] = 0;
+    for (itr = ri_list_first((ri_list_t *)scene->geom_list); itr != NULL; itr = ri_list_next(itr)) {
+        ri_geom_t *g = (ri_geom_t *)itr->data;
+        if (g_ngeoms >= LREF_MAX_GEOMS) break;
+        g_geoms[g_ngeoms] = g;
+        g_geom_base[g_ngeoms + 1] = g_geom_base[g_ngeoms] + g->nindices / 3;
+        g_ngeoms++;
+    }
+}
+
+static accel_build_func g_inner_build = NULL;
+static void *capturing_build(const void *data)
+{
+    capture_scene((const ri_scene_t *)data);
+    g_cam_valid = 0;
+    return g_inner_build(data);
+}
+
+uint32_t lref_scene_ngeoms(void) { return g_ngeoms; }
+void lref_scene_geom_sizes(uint32_t g, uint32_t *npos, uint32_t *nidx, uint32_t *has_normals, uint32_t *two_side)
+{
+    *npos = g_geoms[g]->npositions; *nidx = g_geoms[g]->nindices;
+    *has_normals = g_geoms[g]->normals != NULL; *two_side = (uint32_t)g_geoms[g]->two_side;
+}
+void lref_scene_geom_copy(uint32_t g, double *pos_xyz, uint32_t *idx, double *nrm_xyz)
+{
+    uint32_t i; ri_geom_t *G = g_geoms[g];
+    for (i = 0; i < G->npositions; i++) { pos_xyz[3*i] = G->positions[i][0]; pos_xyz[3*i+1] = G->positions[i][1]; pos_xyz[3*i+2] = G->positions[i][2]; }
+    memcpy(idx, G->indices, sizeof(uint32_t) * G->nindices);
+    if (nrm_xyz && G->normals)
+        for (i = 0; i < G->nnormals; i++) { nrm_xyz[3*i] = G->normals[i][0]; nrm_xyz[3*i+1] = G->normals[i][1]; nrm_xyz[3*i+2] = G->normals[i][2]; }
+}
+int lref_camera_get(double out[20]) { memcpy(out, g_cam, sizeof(g_cam)); return g_cam_valid; }
 
 ri_accel_t *ri_accel_new()
 {
@@ -114,11 +181,19 @@ int ri_accel_bind(ri_accel_t *accel, int method)
         break;
     case RI_ACCEL_BVH:
         accel->build = ri_bvh_build; accel->free = ri_bvh_free;
-        accel->intersect = recording_intersect;
+        accel->intersect = ri_bvh_intersect;
         break;
+#ifdef LREF_WITH_HIP
+    case 2:   /* RI_ACCEL_HIP: the glue of integration/ri_accel_hip.c */
+        if (ri_accel_bind_hip(accel) != 0) return -1;
+        break;
+#endif
     default:
         return -1;
     }
+    /* wrap whatever was bound with the scene/camera capture and the ray recorder */
+    g_inner_build = accel->build;         accel->build = capturing_build;
+    g_inner_intersect = accel->intersect; accel->intersect = recording_intersect;
     return 0;
 }
 
@@ -256,6 +331,50 @@ void lref_counters_clear(void) {}
 void lref_counters_get(uint64_t out[5]) { memset(out, 0, 5 * sizeof(uint64_t)); }
 int lref_has_counters(void) { return 0; }
 #endif
+
+/* ---------------------------------------------------------------------- */
+/* frame capture: replaces the functions of the "file" display driver      */
+/* (render.c:259-268, driver interface src/ri/display.h:72-81) so a        */
+/* Display "x.hdr" "file" "rgb" render lands in memory as float RGB        */
+/* ---------------------------------------------------------------------- */
+static float *g_img = NULL; static int g_img_w = 0, g_img_h = 0;
+static int cap_open(const char *name, int w, int h, int bits, RtToken comp, const char *fmt)
+{
+    (void)name; (void)bits; (void)comp; (void)fmt;
+    free(g_img); g_img = (float *)calloc((size_t)w * h * 3, sizeof(float)); g_img_w = w; g_img_h = h;
+    return 1;
+}
+static int cap_write(int x, int y, const void *pixel)
+{
+    const float *p = (const float *)pixel; size_t i;
+    if (x < 0 || y < 0 || x >= g_img_w || y >= g_img_h) return 0;
+    i = 3 * ((size_t)x + (size_t)y * g_img_w);
+    g_img[i] += p[0] < 0 ? 0 : p[0]; g_img[i + 1] += p[1] < 0 ? 0 : p[1]; g_img[i + 2] += p[2] < 0 ? 0 : p[2];  /* hdrdrv.c:84-96 */
+    return 1;
+}
+static int cap_close(void) { return 1; }
+static int cap_progress(void) { return 1; }
+
+int lref_capture_display(void)
+{
+    ri_display_drv_t *drv;
+    lref_init();
+    drv = (ri_display_drv_t *)ri_hash_lookup(ri_render_get()->display_drvs, RI_FILE);
+    if (!drv) return -1;
+    drv->open = cap_open; drv->write = cap_write; drv->close = cap_close; drv->progress = cap_progress;
+    return 0;
+}
+int lref_image_size(int *w, int *h) { *w = g_img_w; *h = g_img_h; return g_img != NULL; }
+void lref_image_copy(float *dst) { memcpy(dst, g_img, sizeof(float) * 3 * (size_t)g_img_w * g_img_h); }
+
+/* option overrides the lsh CLI would apply (lsh/main.c:213-241) */
+void lref_set_options(int accel_method, int nthreads, int gather_nsamples)
+{
+    ri_option_t *o = ri_render_get()->context->option;
+    if (accel_method >= 0) o->accel_method = accel_method;
+    if (nthreads > 0) o->nthreads = nthreads;
+    if (gather_nsamples > 0) o->gather_nsamples = gather_nsamples;
+}
 
 /* recorder control */
 void   lref_record_start(void) { g_rec_n = 0; g_rec_on = 1; }

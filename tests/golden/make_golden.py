@@ -42,10 +42,53 @@ def soup_fixture(name, ntri, nrays, half_extent):
     print(name, "hits", int((prim != po.MISS).sum()), "of", nrays, "sum t", float(t[prim != po.MISS].sum()), cnt, tree)
 
 
+def ao_fixture(name, rib, width, height, gather_nsamples, pixel_samples=1):
+    """The reference's own AO render of one of its example scenes (single thread, Ri C API
+    driven by oracle/ref_rib.py): the triangles it actually traced (after its RIB ingest),
+    its camera, every ray it issued IN ORDER with the hit record, and the float image.
+    Rays are not stored: the oracle regenerates them bit for bit (checked here) and the
+    fixture pins their SHA-256."""
+    import hashlib
+    from oracle import ref_rib
+    tmp = os.path.join("/tmp", name + "_ref.npz")
+    r = ref_rib.render_rib_subprocess(rib, tmp, width=width, height=height, gather_nsamples=gather_nsamples,
+                                      pixel_samples=pixel_samples)
+    R = r["records"]
+    ng = int(r["ngeoms"])
+    base = np.cumsum([0] + [len(r["idx%d" % g]) // 3 for g in range(ng)])
+    prim = np.where(R["hit"] == 1, base[np.minimum(R["geom"], ng - 1)] + R["index"] // 3, po.MISS).astype(np.uint32)
+    o = po.Oracle()
+    for g in range(ng):
+        o.add_mesh(r["pos%d" % g], r["idx%d" % g])
+        if ("nrm%d" % g) in r.files:
+            o.set_normals(g, r["nrm%d" % g], int(r["two_side%d" % g]))
+    o.build()
+    cam = po.Camera.from_ref(r["camera"])
+    img, rec = o.render_ao(cam, pixel_samples, gather_nsamples)
+    assert np.array_equal(rec["org"], R["org"]) and np.array_equal(rec["dir"], R["dir"]), "oracle ray stream != reference"
+    assert np.array_equal(rec["prim"], prim) and np.array_equal(rec["t"], R["t"])
+    assert np.array_equal(img, r["image"])
+    hit = prim != po.MISS
+    ties = int((o.count_equal_t(R["org"][hit], R["dir"][hit], R["t"][hit]) >= 2).sum())
+    d = {"width": width, "height": height, "gather_nsamples": gather_nsamples, "pixel_samples": pixel_samples,
+         "camera": r["camera"], "ngeoms": ng, "image": r["image"], "prim": prim,
+         "t_hit": R["t"][hit], "u_hit": R["u"][hit], "v_hit": R["v"][hit], "nrays": len(R),
+         "rays_sha256": hashlib.sha256(R["org"].tobytes() + R["dir"].tobytes()).hexdigest(), "exact_t_ties": ties}
+    for g in range(ng):
+        d["pos%d" % g] = r["pos%d" % g]; d["idx%d" % g] = r["idx%d" % g]; d["two_side%d" % g] = r["two_side%d" % g]
+        if ("nrm%d" % g) in r.files:
+            d["nrm%d" % g] = r["nrm%d" % g]
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(name, "rays", len(R), "hits", int(hit.sum()), "tris", int(base[-1]), "exact-t ties among hits", ties,
+          "image mean", float(r["image"].mean()))
+
+
 if __name__ == "__main__":
     if not po.ref_available(stat=True):
         po.build_ref()
     soup_fixture("soup_20k", 20000, 20000, 0.005)
     soup_fixture("soup_3k_fat", 3000, 10000, 0.05)
+    # BASELINE config 1: examples/ambient_occlusion.rib, 256x256, 16 AO samples, 1 thread
+    ao_fixture("ao_c1", "/root/reference/examples/ambient_occlusion/ambient_occlusion.rib", 256, 256, 16)
     # check values of the full S-soup-1M (SURVEY.md Appendix C) are pinned in
     # tests/test_oracle_vs_ref.py against the live reference, not stored here.

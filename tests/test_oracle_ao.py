@@ -1,0 +1,85 @@
+"""The oracle's restatement of the CALLERS of the ray query -- camera rays, tile loop,
+hit epilogue, AO ray producer (oracle/lucille_oracle_ao.c) -- against the reference's own
+single-thread AO render of examples/ambient_occlusion.rib (BASELINE config 1):
+every ray in order, every hit record and the float image, bit for bit."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests.helpers import load_golden
+
+RIB = "/root/reference/examples/ambient_occlusion/ambient_occlusion.rib"
+
+
+def oracle_from_fixture(g):
+    o = po.Oracle()
+    for k in range(int(g["ngeoms"])):
+        o.add_mesh(g["pos%d" % k], g["idx%d" % k])
+        if ("nrm%d" % k) in g.files:
+            o.set_normals(k, g["nrm%d" % k], int(g["two_side%d" % k]))
+    o.build()
+    return o
+
+
+def test_ao_c1_golden():
+    g = load_golden("ao_c1")
+    o = oracle_from_fixture(g)
+    assert o.ntriangles == 322
+    cam = po.Camera.from_ref(g["camera"])
+    img, rec = o.render_ao(cam, int(g["pixel_samples"]), int(g["gather_nsamples"]))
+    assert len(rec["prim"]) == int(g["nrays"]) == 499168           # 65 536 primary + 27 102 hits x 16
+    assert hashlib.sha256(rec["org"].tobytes() + rec["dir"].tobytes()).hexdigest() == str(g["rays_sha256"])
+    assert np.array_equal(rec["prim"], g["prim"])
+    hit = rec["prim"] != po.MISS
+    assert int(hit.sum()) == 87620
+    assert np.array_equal(rec["t"][hit], g["t_hit"]) and np.array_equal(rec["u"][hit], g["u_hit"]) \
+        and np.array_equal(rec["v"][hit], g["v_hit"])
+    assert np.array_equal(img, g["image"])
+    assert int(g["exact_t_ties"]) == 0
+
+
+def test_mt19937_reference_stream():
+    """randomMT2 (src/base/random.c:211-250): seed 4357, 1998-style seeding.  Known answers
+    recorded from the compiled reference (randomMT2 called 2000 times on a fresh thread id)."""
+    out = np.empty(2000)
+    po.lib().lo_mt_stream(4357, 2000, out.ctypes.data_as(po._dp))
+    assert [float(x) for x in out[:4]] == [0.8173300598282367, 0.9990608994849026, 0.510354372439906, 0.13153290981426835]
+    assert float(out[1999]) == 0.19620114658027887
+    if po.ref_available():
+        L = po.C.CDLL(os.path.join(po.HERE, "_ref", "liblucille_ref.so"))
+        L.randomMT2.restype = po.C.c_double; L.randomMT2.argtypes = [po.C.c_int]
+        assert [L.randomMT2(5) for _ in range(2000)] == out.tolist()
+
+
+def test_spiral_visits_every_bucket_once():
+    for w, h in ((256, 256), (1024, 1024), (100, 70), (33, 257)):
+        nx, ny = -(-w // 32), -(-h // 32)
+        xy = np.zeros(2 * nx * ny, np.uint32)
+        n = po.lib().lo_bucket_order(w, h, 32, xy.ctypes.data_as(po.C.POINTER(po.C.c_uint)))
+        assert n == nx * ny
+        pts = set(map(tuple, xy.reshape(-1, 2).tolist()))
+        # the reference's spiral (spiral.c) only covers the image for square-ish bucket grids;
+        # what matters here is that it is reproduced, which test_ao_live_reference checks
+        if nx == ny:
+            assert pts == {(i, j) for i in range(nx) for j in range(ny)}
+
+
+@pytest.mark.skipif(not po.ref_available() or not os.path.exists(RIB), reason="needs oracle/_ref and /root/reference")
+@pytest.mark.parametrize("w,h,ns,ps", [(64, 64, 9, 2), (96, 96, 64, 1)])
+def test_ao_live_reference(tmp_path, w, h, ns, ps):
+    """other sizes / sample counts than the golden, against a fresh reference render"""
+    from oracle import ref_rib
+    r = ref_rib.render_rib_subprocess(RIB, str(tmp_path / "r.npz"), width=w, height=h, gather_nsamples=ns, pixel_samples=ps)
+    o = po.Oracle()
+    for k in range(int(r["ngeoms"])):
+        o.add_mesh(r["pos%d" % k], r["idx%d" % k])
+    o.build()
+    img, rec = o.render_ao(po.Camera.from_ref(r["camera"]), ps, ns)
+    R = r["records"]
+    assert len(R) == len(rec["prim"])
+    assert np.array_equal(R["org"], rec["org"]) and np.array_equal(R["dir"], rec["dir"])
+    assert np.array_equal(R["t"], rec["t"]) and np.array_equal(R["u"], rec["u"]) and np.array_equal(R["v"], rec["v"])
+    assert np.array_equal(img, r["image"])
