@@ -107,6 +107,54 @@ int  lh_accel_intersect_device_counted(lh_accel_t *accel, size_t n, const void *
 /* number of persistent workgroups the persistent variants launch */
 int  lh_accel_set_grid(lh_accel_t *accel, int blocks);
 
+/* ---- tile rendering: the callers on either side of the query, on the device ----
+ * reference: subsample / render_bucket / bucket_write (src/render/render.c:715-823,
+ * 1107-1166, 919-983), ri_camera_get_pos_and_dir (src/ri/camera.c:248-318),
+ * ri_intersection_state_build (src/render/intersection_state.c:99-248),
+ * ri_transport_ambientocclusion + calculate_occlusion
+ * (src/transport/ambientocclusion.c:42-151,332-415). */
+
+typedef struct lh_camera {
+    int    width, height;       /* camera->horizontal/vertical_resolution             */
+    int    rh;                  /* Orientation "rh" (camera->is_rh)                   */
+    int    pad;
+    double flength;             /* 1/tan(fov/2) (camera.c:219)                         */
+    double cam2world[16];       /* camera->camera_to_world, row-major, row vectors     */
+} lh_camera_t;
+
+typedef struct lh_tile_stats {
+    uint64_t primary_rays;      /* w*h*pixel_samples^2                                 */
+    uint64_t primary_hits;
+    uint64_t ao_rays;           /* primary_hits * floor(sqrt(gather_nsamples))^2       */
+    uint64_t ao_occluded;
+} lh_tile_stats_t;
+
+/* optional per-vertex normals of mesh `mesh` (add order), before commit:
+ * geom->normals / geom->two_side as ri_intersection_state_build reads them */
+int  lh_accel_set_normals(lh_accel_t *accel, uint32_t mesh, const double *normals,
+                          size_t stride_bytes, int two_side);
+
+/* camera rays of the tile [x0,x0+w) x [y0,y0+h), pixel_samples^2 per pixel, written to
+ * device arrays of w*h*pixel_samples^2 xyz triples (sample id = ((ly*w+lx)*ps+sy)*ps+sx) */
+int  lh_render_primary_rays(lh_accel_t *accel, const lh_camera_t *cam, int x0, int y0, int w, int h,
+                            int pixel_samples, void *d_org_xyz, void *d_dir_xyz, void *stream);
+
+/* one AO tile entirely on the device: camera rays -> closest hit -> hit epilogue ->
+ * gather_nsamples AO rays per hit -> any-hit -> radiance.  d_rgb: float[h][w][3] in image
+ * orientation (row 0 = the tile's TOP row of the output image, as bucket_write flips y).
+ * d_uniforms: NULL for the built-in counter-based RNG (seed), or 2 doubles per AO ray in
+ * (hit slot, j, i) order -- how a caller replays the reference's MT19937 stream.
+ * Synchronous on `stream` (one 8-byte read-back of the hit count). */
+int  lh_render_ao_tile(lh_accel_t *accel, const lh_camera_t *cam, int x0, int y0, int w, int h,
+                       int pixel_samples, int gather_nsamples, uint64_t seed,
+                       const void *d_uniforms, void *d_rgb, lh_tile_stats_t *stats, void *stream);
+
+/* device scratch of the last lh_render_ao_tile call (for tests / pipelines):
+ * which: 0 primary org, 1 primary dir, 2 prim, 3 t, 4 u, 5 v, 6 slot_of_sample,
+ *        7 hit records (12 doubles: AO origin, tangent, binormal, Ns), 8 AO org, 9 AO dir,
+ *        10 AO occluded */
+int  lh_render_scratch(lh_accel_t *accel, int which, void **d_ptr, size_t *count);
+
 /* copy of the flattened BVH for cross-checks (tests): sizes via lh_accel_info.
  * nodes: nnodes*64 bytes, tri32: ntriangles*48 bytes; either may be NULL. */
 int  lh_accel_export(const lh_accel_t *accel, void *nodes, void *tri32);

@@ -11,6 +11,6 @@ plumbing used by the tests, ``bench.py`` and the multi-GPU driver:
 There is no CPU fallback: loading fails loudly when the library is missing and
 every query fails loudly when no HIP device is visible.
 """
-from .binding import (HipAccel, LucilleHipError, MISS, MODE_ANY, MODE_CLOSEST,  # noqa: F401
+from .binding import (Camera, HipAccel, LucilleHipError, MISS, MODE_ANY, MODE_CLOSEST,  # noqa: F401
                       VARIANT_DEFAULT, VARIANT_DIRECT, VARIANT_PERSIST_LANE,
                       VARIANT_PERSIST_WAVE, build_library, device_count, library_path)

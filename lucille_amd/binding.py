@@ -44,12 +44,32 @@ class AccelInfo(C.Structure):
                 ("upload_seconds", C.c_double), ("device", C.c_int)]
 
 
+class Camera(C.Structure):
+    """lh_camera_t: the members of ri_camera_t the ray generator reads (camera.c:248-318)"""
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("rh", C.c_int), ("pad", C.c_int),
+                ("flength", C.c_double), ("cam2world", C.c_double * 16)]
+
+    @classmethod
+    def make(cls, width, height, flength, cam2world, rh=1):
+        c = cls(); c.width = int(width); c.height = int(height); c.rh = int(rh); c.flength = float(flength)
+        m = np.asarray(cam2world, np.float64).reshape(16)
+        for i in range(16):
+            c.cam2world[i] = float(m[i])
+        return c
+
+
+class TileStats(C.Structure):
+    _fields_ = [("primary_rays", C.c_uint64), ("primary_hits", C.c_uint64), ("ao_rays", C.c_uint64),
+                ("ao_occluded", C.c_uint64)]
+
+
 # every symbol include/lucille_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "lh_device_count", "lh_last_error", "lh_accel_create", "lh_accel_add_mesh", "lh_accel_commit",
     "lh_accel_destroy", "lh_accel_info", "lh_accel_prim_lookup", "lh_accel_intersect1",
     "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted",
-    "lh_accel_set_grid", "lh_accel_export",
+    "lh_accel_set_grid", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
+    "lh_render_ao_tile", "lh_render_scratch",
 ]
 
 _lib = None
@@ -83,6 +103,11 @@ def lib():
                                                     C.POINTER(C.c_uint64)]
     L.lh_accel_set_grid.argtypes = [vp, i32]
     L.lh_accel_export.argtypes = [vp, vp, vp]
+    L.lh_accel_set_normals.argtypes = [vp, u32, vp, sz, i32]
+    L.lh_render_primary_rays.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, vp, vp, vp]
+    L.lh_render_ao_tile.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, C.c_uint64, vp, vp,
+                                    C.POINTER(TileStats), vp]
+    L.lh_render_scratch.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz)]
     _lib = L
     return L
 
@@ -147,6 +172,12 @@ class HipAccel:
         I = _np(indices, np.uint32).reshape(-1)
         _check(self.L.lh_accel_add_mesh(self.h, P.shape[0], P.ctypes.data, P.shape[1] * 8, I.shape[0],
                                         I.ctypes.data), "lh_accel_add_mesh")
+
+    def set_normals(self, mesh, normals, two_side=0):
+        N = _np(normals, np.float64) if normals is not None else None
+        _check(self.L.lh_accel_set_normals(self.h, int(mesh), N.ctypes.data if N is not None else None,
+                                           (N.shape[1] * 8) if N is not None else 24, int(two_side)),
+               "lh_accel_set_normals")
 
     def commit(self, build_threads=0):
         _check(self.L.lh_accel_commit(self.h, int(build_threads)), "lh_accel_commit")
@@ -227,3 +258,42 @@ class HipAccel:
                                                 _dptr(v), _dptr(occ), mode, variant, C.c_void_p(stream)),
                "lh_accel_intersect_device")
         return out
+
+    # ---- tile rendering (device-resident pipeline) ---------------------------
+    def primary_rays(self, cam, x0, y0, w, h, pixel_samples=1, stream=None):
+        import torch
+        n = w * h * pixel_samples * pixel_samples
+        dev = torch.device("cuda", self.device)
+        org = torch.empty((n, 3), dtype=torch.float64, device=dev); dr = torch.empty((n, 3), dtype=torch.float64, device=dev)
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(self.L.lh_render_primary_rays(self.h, C.byref(cam), x0, y0, w, h, pixel_samples, _dptr(org), _dptr(dr),
+                                             C.c_void_p(stream)), "lh_render_primary_rays")
+        return org, dr
+
+    def render_ao_tile(self, cam, x0, y0, w, h, pixel_samples, gather_nsamples, seed=1, uniforms=None, out=None,
+                       stream=None):
+        """-> (rgb float32 [h,w,3] CUDA tensor in image orientation, stats dict)"""
+        import torch
+        dev = torch.device("cuda", self.device)
+        if out is None:
+            out = torch.empty((h, w, 3), dtype=torch.float32, device=dev)
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        st = TileStats()
+        _check(self.L.lh_render_ao_tile(self.h, C.byref(cam), x0, y0, w, h, pixel_samples, gather_nsamples, int(seed),
+                                        _dptr(uniforms), _dptr(out), C.byref(st), C.c_void_p(stream)),
+               "lh_render_ao_tile")
+        return out, {k: int(getattr(st, k)) for k, _ in st._fields_}
+
+    def scratch(self, which, dtype, width):
+        """view (copy to host) of a scratch buffer of the last render_ao_tile call"""
+        p = C.c_void_p(); n = C.c_size_t()
+        _check(self.L.lh_render_scratch(self.h, which, C.byref(p), C.byref(n)), "lh_render_scratch")
+        count = n.value * width
+        host = np.empty(count, dtype)
+        if count:
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            assert hip.hipMemcpy(host.ctypes.data, p, host.nbytes, 2) == 0
+        return host.reshape(n.value, width) if width > 1 else host

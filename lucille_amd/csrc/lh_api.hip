@@ -29,7 +29,25 @@ static int fail(const char *fmt, ...)
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
     return fail("%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
 
-struct lh_mesh_copy { uint32_t npos, nidx; double *pos; uint32_t *idx; };
+struct lh_mesh_copy { uint32_t npos, nidx; double *pos; uint32_t *idx; double *nrm; int two_side; };
+
+/* launchers in lh_render.hip */
+extern "C" int lh_render_launch_primary(const lh_camera_t *cam, int x0, int y0, int w, int h, int xs, int ys,
+                                        double *d_org, double *d_dir, void *stream);
+extern "C" int lh_render_launch_compact(const lh_dev_scene_t *sc, const double *d_nrm9, size_t n, const double *d_org,
+                                        const double *d_dir, const uint32_t *d_prim, const double *d_t,
+                                        const double *d_u, const double *d_v, uint32_t *d_block_counts,
+                                        uint32_t *d_slot_of_sample, double *d_hitrec,
+                                        unsigned long long *d_slot_key, int x0, int y0, int w, int spp, int full_width,
+                                        unsigned long long *d_total, void *stream);
+extern "C" int lh_render_launch_ao_rays(size_t nslots, int ntheta, int nphi, unsigned long long seed,
+                                        const double *d_hitrec, const double *d_rnd,
+                                        const unsigned long long *d_slot_key, double *d_org, double *d_dir, void *stream);
+extern "C" int lh_render_launch_resolve(int w, int h, int xs, int ys, int N, const uint32_t *d_slot_of_sample,
+                                        const uint8_t *d_occ, float *d_rgb, unsigned long long *d_occ_total,
+                                        void *stream);
+
+struct lh_buf { void *p; size_t cap; };
 
 struct lh_accel {
     int device;
@@ -49,6 +67,12 @@ struct lh_accel {
     int default_variant;
     /* staging for host batches */
     void *d_stage; size_t stage_bytes;
+    /* per-primitive vertex normals (9 doubles, NaN = none), only if some mesh has normals */
+    double *h_nrm9; void *d_nrm9;
+    /* tile-render scratch (lh_render_ao_tile) */
+    lh_buf r_org, r_dir, r_prim, r_t, r_u, r_v, r_slot, r_hitrec, r_aorg, r_adir, r_occ, r_blocks, r_key;
+    unsigned long long *d_total;
+    size_t r_nsamples, r_nslots, r_nao;
 };
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -91,7 +115,7 @@ extern "C" int lh_accel_add_mesh(lh_accel_t *a, uint32_t npos, const double *pos
     if (!nm) return fail("out of memory");
     a->meshes = nm;
     lh_mesh_copy *m = &a->meshes[a->nmeshes];
-    m->npos = npos; m->nidx = nidx;
+    m->npos = npos; m->nidx = nidx; m->nrm = NULL; m->two_side = 0;
     m->pos = (double *)malloc(sizeof(double) * 3 * (size_t)(npos ? npos : 1));
     m->idx = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nidx ? nidx : 1));
     if (!m->pos || !m->idx) return fail("out of memory");
@@ -104,8 +128,35 @@ extern "C" int lh_accel_add_mesh(lh_accel_t *a, uint32_t npos, const double *pos
     return 0;
 }
 
+extern "C" int lh_accel_set_normals(lh_accel_t *a, uint32_t mesh, const double *nrm, size_t stride, int two_side)
+{
+    if (!a) return fail("lh_accel_set_normals: accel is NULL");
+    if (a->committed) return fail("lh_accel_set_normals: accel already committed");
+    if (mesh >= a->nmeshes) return fail("lh_accel_set_normals: mesh %u out of range", mesh);
+    if (nrm && (stride < 3 * sizeof(double) || (stride % sizeof(double)) != 0)) return fail("lh_accel_set_normals: bad stride");
+    lh_mesh_copy *m = &a->meshes[mesh];
+    free(m->nrm); m->nrm = NULL; m->two_side = two_side;
+    if (nrm) {
+        m->nrm = (double *)malloc(sizeof(double) * 3 * (size_t)(m->npos ? m->npos : 1));
+        if (!m->nrm) return fail("out of memory");
+        for (uint32_t i = 0; i < m->npos; i++) {
+            const double *p = (const double *)((const char *)nrm + (size_t)i * stride);
+            m->nrm[3 * (size_t)i] = p[0]; m->nrm[3 * (size_t)i + 1] = p[1]; m->nrm[3 * (size_t)i + 2] = p[2];
+        }
+    }
+    return 0;
+}
+
+static void free_buf(lh_buf *b) { if (b->p) (void)hipFree(b->p); b->p = NULL; b->cap = 0; }
+
 static void release_device(lh_accel_t *a)
 {
+    lh_buf *bufs[] = {&a->r_org, &a->r_dir, &a->r_prim, &a->r_t, &a->r_u, &a->r_v, &a->r_slot, &a->r_hitrec,
+                      &a->r_aorg, &a->r_adir, &a->r_occ, &a->r_blocks, &a->r_key};
+    for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) free_buf(bufs[i]);
+    if (a->d_total) (void)hipFree(a->d_total);
+    if (a->d_nrm9) (void)hipFree(a->d_nrm9);
+    a->d_total = NULL; a->d_nrm9 = NULL;
     if (a->d_nodes) (void)hipFree(a->d_nodes);
     if (a->d_tri32) (void)hipFree(a->d_tri32);
     if (a->d_tri64) (void)hipFree(a->d_tri64);
@@ -134,8 +185,26 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
     int rc = lh_bvh_build(&a->bvh, views, a->nmeshes, build_threads);
     free(views);
     if (rc != 0) return fail("lh_accel_commit: BVH build failed (bad input or out of memory)");
+    /* per-primitive normals in primitive-id order, if any mesh carries normals */
+    {
+        bool any = false;
+        for (uint32_t g = 0; g < a->nmeshes; g++) any = any || a->meshes[g].nrm != NULL;
+        if (any && a->bvh.ntris) {
+            a->h_nrm9 = (double *)malloc(sizeof(double) * 9 * (size_t)a->bvh.ntris);
+            if (!a->h_nrm9) return fail("out of memory");
+            for (uint32_t p = 0; p < a->bvh.ntris; p++) {
+                const lh_mesh_copy *m = &a->meshes[a->bvh.prim_geom[p]];
+                double *o = a->h_nrm9 + 9 * (size_t)p;
+                if (!m->nrm) { for (int k = 0; k < 9; k++) o[k] = NAN; continue; }
+                for (int c = 0; c < 3; c++) {
+                    uint32_t vi = m->idx[a->bvh.prim_index[p] + c];
+                    for (int k = 0; k < 3; k++) o[3 * c + k] = m->nrm[3 * (size_t)vi + k];
+                }
+            }
+        }
+    }
     /* the packed mesh copies are no longer needed: the BVH holds tri64 */
-    for (uint32_t g = 0; g < a->nmeshes; g++) { free(a->meshes[g].pos); free(a->meshes[g].idx); }
+    for (uint32_t g = 0; g < a->nmeshes; g++) { free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm); }
     free(a->meshes); a->meshes = NULL; a->nmeshes = 0;
 
     HIPCHK(hipSetDevice(a->device));
@@ -143,6 +212,12 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
     HIPCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&a->d_counters, sizeof(unsigned long long) * LH_CNT_N));
+    HIPCHK(hipMalloc((void **)&a->d_total, sizeof(unsigned long long)));
+    if (a->h_nrm9) {
+        HIPCHK(hipMalloc(&a->d_nrm9, sizeof(double) * 9 * (size_t)a->bvh.ntris));
+        HIPCHK(hipMemcpy(a->d_nrm9, a->h_nrm9, sizeof(double) * 9 * (size_t)a->bvh.ntris, hipMemcpyHostToDevice));
+        free(a->h_nrm9); a->h_nrm9 = NULL;
+    }
     a->device_bytes = 0;
     if (a->bvh.ntris) {
         size_t nb = sizeof(lh_node_t) * (size_t)a->bvh.nnodes;
@@ -179,8 +254,8 @@ extern "C" void lh_accel_destroy(lh_accel_t *a)
 {
     if (!a) return;
     if (a->committed) { (void)hipSetDevice(a->device); release_device(a); }
-    for (uint32_t g = 0; g < a->nmeshes; g++) { free(a->meshes[g].pos); free(a->meshes[g].idx); }
-    free(a->meshes);
+    for (uint32_t g = 0; g < a->nmeshes; g++) { free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm); }
+    free(a->meshes); free(a->h_nrm9);
     lh_bvh_release(&a->bvh);
     free(a);
 }
@@ -341,4 +416,103 @@ extern "C" int lh_accel_intersect1(lh_accel_t *a, const double org[3], const dou
     if (u) *u = uu;
     if (v) *v = vv;
     return p != LH_MISS_PRIM;
+}
+
+/* ------------------------------------------------------------------------ */
+/* tile rendering                                                           */
+/* ------------------------------------------------------------------------ */
+
+static int ensure_buf(lh_buf *b, size_t bytes)
+{
+    if (b->cap >= bytes && b->p) return 0;
+    if (b->p) { (void)hipFree(b->p); b->p = NULL; b->cap = 0; }
+    if (bytes == 0) bytes = 16;
+    HIPCHK(hipMalloc(&b->p, bytes));
+    b->cap = bytes;
+    return 0;
+}
+
+extern "C" int lh_render_primary_rays(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h,
+                                      int ps, void *d_org, void *d_dir, void *stream)
+{
+    if (!a || !a->committed) return fail("lh_render_primary_rays: accel not committed");
+    if (!cam || !d_org || !d_dir) return fail("lh_render_primary_rays: NULL argument");
+    if (w < 0 || h < 0 || ps < 1) return fail("lh_render_primary_rays: bad tile");
+    HIPCHK(hipSetDevice(a->device));
+    if (lh_render_launch_primary(cam, x0, y0, w, h, ps, ps, (double *)d_org, (double *)d_dir, stream) != 0)
+        return fail("primary ray kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+extern "C" int lh_render_ao_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int ps,
+                                 int gather_nsamples, uint64_t seed, const void *d_uniforms, void *d_rgb,
+                                 lh_tile_stats_t *stats, void *stream)
+{
+    if (!a || !a->committed) return fail("lh_render_ao_tile: accel not committed");
+    if (!cam || !d_rgb) return fail("lh_render_ao_tile: NULL argument");
+    if (w <= 0 || h <= 0 || ps < 1 || gather_nsamples < 1) return fail("lh_render_ao_tile: bad tile/sample counts");
+    HIPCHK(hipSetDevice(a->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int nphi = (int)sqrt((double)gather_nsamples), ntheta = nphi, N = nphi * ntheta;   /* ambientocclusion.c:378-380 */
+    const size_t S = (size_t)w * h * ps * ps;
+    const unsigned nb = (unsigned)((S + 255) / 256);
+    if (ensure_buf(&a->r_org, S * 24) || ensure_buf(&a->r_dir, S * 24) || ensure_buf(&a->r_prim, S * 4) ||
+        ensure_buf(&a->r_t, S * 8) || ensure_buf(&a->r_u, S * 8) || ensure_buf(&a->r_v, S * 8) ||
+        ensure_buf(&a->r_slot, S * 4) || ensure_buf(&a->r_blocks, (size_t)nb * 4)) return -1;
+    /* 1. camera rays */
+    if (lh_render_launch_primary(cam, x0, y0, w, h, ps, ps, (double *)a->r_org.p, (double *)a->r_dir.p, s) != 0)
+        return fail("primary ray kernel launch failed");
+    /* 2. closest hit */
+    if (launch(a, S, a->r_org.p, a->r_dir.p, a->r_prim.p, a->r_t.p, a->r_u.p, a->r_v.p, NULL, LH_MODE_CLOSEST,
+               LH_VARIANT_DEFAULT, NULL, s) != 0) return -1;
+    /* 3. count hits (deterministic compaction needs the total before sizing the AO batch) */
+    unsigned long long nhit = 0;
+    if (a->bvh.ntris) {
+        if (ensure_buf(&a->r_hitrec, S * 96) || ensure_buf(&a->r_key, S * 8)) return -1;   /* worst case: every sample hits */
+        if (lh_render_launch_compact(&a->dev, (const double *)a->d_nrm9, S, (const double *)a->r_org.p,
+                                     (const double *)a->r_dir.p, (const uint32_t *)a->r_prim.p, (const double *)a->r_t.p,
+                                     (const double *)a->r_u.p, (const double *)a->r_v.p, (uint32_t *)a->r_blocks.p,
+                                     (uint32_t *)a->r_slot.p, (double *)a->r_hitrec.p, (unsigned long long *)a->r_key.p,
+                                     x0, y0, w, ps * ps, cam->width, a->d_total, s) != 0)
+            return fail("compaction kernels failed: %s", hipGetErrorString(hipGetLastError()));
+        HIPCHK(hipMemcpyAsync(&nhit, a->d_total, sizeof(nhit), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    } else {
+        HIPCHK(hipMemsetAsync(a->r_slot.p, 0xFF, S * 4, s));
+    }
+    const size_t nao = (size_t)nhit * N;
+    unsigned long long nocc = 0;
+    if (nao) {
+        if (ensure_buf(&a->r_aorg, nao * 24) || ensure_buf(&a->r_adir, nao * 24) || ensure_buf(&a->r_occ, nao)) return -1;
+        /* 4. AO rays */
+        if (lh_render_launch_ao_rays(nhit, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const double *)d_uniforms,
+                                     (const unsigned long long *)a->r_key.p, (double *)a->r_aorg.p, (double *)a->r_adir.p, s) != 0)
+            return fail("AO ray kernel launch failed");
+        /* 5. any-hit */
+        if (launch(a, nao, a->r_aorg.p, a->r_adir.p, NULL, NULL, NULL, NULL, a->r_occ.p, LH_MODE_ANY,
+                   LH_VARIANT_DEFAULT, NULL, s) != 0) return -1;
+    }
+    /* 6. radiance */
+    HIPCHK(hipMemsetAsync(a->d_total, 0, sizeof(unsigned long long), s));
+    if (lh_render_launch_resolve(w, h, ps, ps, N, (const uint32_t *)a->r_slot.p, (const uint8_t *)a->r_occ.p,
+                                 (float *)d_rgb, a->d_total, s) != 0) return fail("resolve kernel launch failed");
+    HIPCHK(hipMemcpyAsync(&nocc, a->d_total, sizeof(nocc), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    a->r_nsamples = S; a->r_nslots = (size_t)nhit; a->r_nao = nao;
+    if (stats) {
+        stats->primary_rays = S; stats->primary_hits = nhit; stats->ao_rays = nao; stats->ao_occluded = nocc;
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int lh_render_scratch(lh_accel_t *a, int which, void **d_ptr, size_t *count)
+{
+    if (!a || !a->committed || !d_ptr || !count) return fail("lh_render_scratch: bad argument");
+    lh_buf *b[] = {&a->r_org, &a->r_dir, &a->r_prim, &a->r_t, &a->r_u, &a->r_v, &a->r_slot, &a->r_hitrec,
+                   &a->r_aorg, &a->r_adir, &a->r_occ};
+    if (which < 0 || which > 10) return fail("lh_render_scratch: unknown buffer %d", which);
+    *d_ptr = b[which]->p;
+    *count = which <= 6 ? a->r_nsamples : (which == 7 ? a->r_nslots : a->r_nao);
+    return 0;
 }

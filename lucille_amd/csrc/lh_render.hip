@@ -1,0 +1,324 @@
+/*
+ * lh_render.hip -- the callers on either side of the ray query, batched per tile
+ * and kept on the device: camera rays, hit epilogue, ambient-occlusion ray
+ * producer and the radiance reduction.
+ *
+ * Reference (CPU, one pixel / one ray at a time):
+ *   subsample + sample_subpixel        src/render/render.c:715-861
+ *   ri_camera_get_pos_and_dir          src/ri/camera.c:248-318
+ *   ri_intersection_state_build        src/render/intersection_state.c:99-248
+ *   ri_ortho_basis                     src/render/reflection.c:311-333
+ *   calculate_occlusion,
+ *     ri_transport_ambientocclusion    src/transport/ambientocclusion.c:42-151,332-415
+ *   render_bucket / bucket_write       src/render/render.c:1107-1166,919-983
+ *
+ * Wavefront pipeline of one tile (all buffers resident in HBM, no host round trip
+ * except one 8-byte hit count):
+ *
+ *   k_primary_rays  -> [trace closest] -> k_hit_count / k_scan_blocks / k_ao_setup
+ *                   -> k_ao_rays -> [trace any] -> k_ao_resolve
+ *
+ * All geometry arithmetic is fp64 with the reference's operation order and no FMA
+ * contraction, so primary rays, P, Ng, Ns and the basis equal the oracle's bits;
+ * AO directions use a counter-based RNG by default (the reference's MT19937 stream
+ * is order-dependent) or caller-supplied uniforms (parity replay), and the device
+ * libm's sin/cos.
+ */
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/lucille_hip.h"
+#include "lh_device.h"
+
+namespace {
+
+#define LH_NC _Pragma("clang fp contract(off)")
+
+struct DevCamera {
+    double c2w[16];
+    double flength;
+    int width, height, rh;
+};
+
+__device__ __forceinline__ void vnormalize(double d[3])
+{   /* ri_vector_normalize (vector.h:75-86): FLOAT threshold literal */
+    LH_NC
+    const double norm2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    if (norm2 > (double)1.0e-17f) { const double rsq = 1.0 / sqrt(norm2); d[0] *= rsq; d[1] *= rsq; d[2] *= rsq; }
+}
+
+__device__ __forceinline__ void vcross(double d[3], const double a[3], const double b[3])
+{
+    LH_NC
+    d[0] = a[1] * b[2] - a[2] * b[1]; d[1] = a[2] * b[0] - a[0] * b[2]; d[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* radical inverse permutation of init_sigma (render.c:870-917) */
+__device__ __forceinline__ unsigned sigma_of(unsigned i, unsigned period)
+{
+    unsigned digit = period, inverse = 0;
+    for (unsigned bits = i; bits; bits >>= 1) { digit >>= 1; if (bits & 1) inverse += digit; }
+    return inverse;
+}
+
+/* one thread per pixel sub-sample: sample id = ((ly*w + lx)*ys + sy)*xs + sx */
+__global__ void k_primary_rays(DevCamera cam, int x0, int y0, int w, int h, int xs, int ys,
+                               double *__restrict__ org, double *__restrict__ dir)
+{
+    LH_NC
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)w * h * xs * ys;
+    if (id >= total) return;
+    const int sx = (int)(id % xs), sy = (int)((id / xs) % ys);
+    const size_t pix = id / ((size_t)xs * ys);
+    const int px = x0 + (int)(pix % w), py = y0 + (int)(pix / w);
+    /* sample_subpixel (render.c:830-861) */
+    const unsigned j = (unsigned)sx & ((unsigned)xs - 1), k = (unsigned)sy & ((unsigned)xs - 1);
+    double jx = (double)sx + (double)sigma_of(k, (unsigned)xs) / (double)xs;
+    double jy = (double)sy + (double)sigma_of(j, (unsigned)ys) / (double)ys;
+    jx /= (double)xs; jy /= (double)ys;
+    jx += 0.5 / (xs * xs); jy += 0.5 / (ys * ys);
+    /* ri_camera_get_pos_and_dir (camera.c:248-318) */
+    const double x = (double)(px + jx), y = (double)(py + jy);
+    const double W = cam.width, H = cam.height;
+    const float sign = cam.rh ? -1.0f : 1.0f;
+    double v[4], o[4] = {0.0, 0.0, 0.0, 1.0}, pos[4], dp[4];
+    v[0] = (2.0f * x - W) / W; v[1] = (2.0f * y - H) / H; v[2] = sign * cam.flength; v[3] = 1.0;
+    for (int c = 0; c < 4; c++) {
+        pos[c] = 0.0; dp[c] = 0.0;
+        for (int r = 0; r < 4; r++) { pos[c] += o[r] * cam.c2w[4 * r + c]; dp[c] += v[r] * cam.c2w[4 * r + c]; }
+    }
+    double d[3] = {dp[0] - pos[0], dp[1] - pos[1], dp[2] - pos[2]};
+    vnormalize(d);
+    org[3 * id] = pos[0]; org[3 * id + 1] = pos[1]; org[3 * id + 2] = pos[2];
+    dir[3 * id] = d[0]; dir[3 * id + 1] = d[1]; dir[3 * id + 2] = d[2];
+}
+
+/* ---- deterministic compaction of the primary hits (sample order) ---------- */
+__global__ void k_hit_count(size_t n, const uint32_t *__restrict__ prim, uint32_t *__restrict__ block_counts)
+{
+    __shared__ uint32_t wsum[4];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool hit = (i < n) && (prim[i] != LH_MISS_PRIM);
+    const unsigned long long m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+/* exclusive scan of block_counts in place (one workgroup); total -> *total_out */
+__global__ void k_scan_blocks(uint32_t nblocks, uint32_t *__restrict__ block_counts, unsigned long long *total_out)
+{
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = (i < nblocks) ? block_counts[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            uint32_t t = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nblocks) block_counts[i] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+struct DevNormals { const double *nrm; };   /* 9 doubles per prim (n0 n1 n2), NaN n0.x => none */
+
+/* one thread per primary sample: slot = exclusive scan of the hit flags; writes the
+ * per-hit record {org(3), basis(9)} (12 doubles) and slot_of_sample */
+__global__ void k_ao_setup(size_t n, const lh_dev_scene_t sc, const double *__restrict__ nrm9,
+                           const double *__restrict__ org, const double *__restrict__ dir,
+                           const uint32_t *__restrict__ prim, const double *__restrict__ t,
+                           const double *__restrict__ u, const double *__restrict__ v,
+                           const uint32_t *__restrict__ block_offsets, uint32_t *__restrict__ slot_of_sample,
+                           double *__restrict__ hitrec, unsigned long long *__restrict__ slot_key,
+                           int x0, int y0, int w, int spp, int full_width)
+{
+    LH_NC
+    __shared__ uint32_t wsum[4];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool hit = (i < n) && (prim[i] != LH_MISS_PRIM);
+    const unsigned long long m = __ballot(hit);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wsum[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < wv; k++) woff += wsum[k];
+    if (i < n) slot_of_sample[i] = LH_MISS_PRIM;
+    if (!hit) return;
+    const uint32_t slot = block_offsets[blockIdx.x] + woff + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    slot_of_sample[i] = slot;
+    {   /* absolute sample key (frame position, not tile position): keeps the built-in
+         * RNG independent of how the frame is tiled or sharded */
+        const size_t pix = i / (size_t)spp;
+        const unsigned long long px = (unsigned long long)(x0 + (int)(pix % (size_t)w));
+        const unsigned long long py = (unsigned long long)(y0 + (int)(pix / (size_t)w));
+        slot_key[slot] = (py * (unsigned long long)full_width + px) * (unsigned long long)spp + (i % (size_t)spp);
+    }
+
+    /* ri_intersection_state_build (intersection_state.c:99-248): P, Ng, Ns */
+    const uint32_t p = prim[i];
+    const double *tv = (const double *)sc.tri64 + 9 * (size_t)p;
+    const double tt = t[i], uu = u[i], vv = v[i];
+    double P[3], Ng[3], Ns[3], v01[3], v02[3];
+    for (int k = 0; k < 3; k++) P[k] = org[3 * i + k] + dir[3 * i + k] * tt;
+    for (int k = 0; k < 3; k++) { v01[k] = tv[3 + k] - tv[k]; v02[k] = tv[6 + k] - tv[k]; }
+    vcross(Ng, v01, v02); vnormalize(Ng);
+    bool has_n = false;
+    if (nrm9) { const double n0x = nrm9[9 * (size_t)p]; has_n = (n0x == n0x); }
+    if (has_n) {
+        const double *nn = nrm9 + 9 * (size_t)p; const double w = 1.0 - uu - vv;
+        for (int k = 0; k < 3; k++) { const double a = nn[k] * w, b = nn[3 + k] * uu, c = nn[6 + k] * vv; Ns[k] = (a + b) + c; }
+    } else {
+        Ns[0] = Ng[0]; Ns[1] = Ng[1]; Ns[2] = Ng[2];
+    }
+    /* ri_ortho_basis(basis, Ns) (reflection.c:311-333) and the 1e-6 offset (ambientocclusion.c:65-73) */
+    double b0[3], b1[3] = {0.0, 0.0, 0.0};
+    int ax = 3;
+    for (int k = 0; k < 3; k++) if (Ns[k] < 0.6 && Ns[k] > -0.6) { ax = k; break; }
+    if (ax >= 3) ax = 0;
+    b1[ax] = 1.0;
+    vcross(b0, b1, Ns); vnormalize(b0);
+    vcross(b1, Ns, b0); vnormalize(b1);
+    double *r = hitrec + 12 * (size_t)slot;
+    const double eps = 1.0e-6;
+    for (int k = 0; k < 3; k++) { r[k] = P[k] + Ns[k] * eps; r[3 + k] = b0[k]; r[6 + k] = b1[k]; r[9 + k] = Ns[k]; }
+}
+
+/* counter-based uniforms in [0,1) with 32-bit resolution (like randomMT2's y*2^-32) */
+__device__ __forceinline__ uint32_t mix32(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return (uint32_t)(x >> 16);
+}
+
+/* one thread per AO ray: ray id = slot*N + (j*ntheta + i) (calculate_occlusion's loop order) */
+__global__ void k_ao_rays(size_t nslots, int ntheta, int nphi, unsigned long long seed,
+                          const double *__restrict__ hitrec, const double *__restrict__ rnd /* 2 per ray or NULL */,
+                          const unsigned long long *__restrict__ slot_key, double *__restrict__ org, double *__restrict__ dir)
+{
+    LH_NC
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = ntheta * nphi;
+    if (id >= nslots * (size_t)N) return;
+    const size_t slot = id / N; const int r = (int)(id % N);
+    const int i = r % ntheta, j = r / ntheta;
+    double r0, r1;
+    if (rnd) { r0 = rnd[2 * id]; r1 = rnd[2 * id + 1]; }
+    else {
+        const uint64_t key = (seed * 0x9E3779B97F4A7C15ULL) ^ ((slot_key[slot] * (uint64_t)N + (uint64_t)r) * 2ull);
+        r0 = (double)mix32(key) * 2.3283064365386963e-10;
+        r1 = (double)mix32(key + 1ull) * 2.3283064365386963e-10;
+    }
+    const double z0 = ((double)(uint32_t)i + r0) / (double)(uint32_t)ntheta;
+    const double z1 = ((double)(uint32_t)j + r1) / (double)(uint32_t)nphi;
+    const double cos_theta = sqrt(z0), phi = 2.0 * 3.14159265358979323846 * z1;
+    double sp, cp;
+    sincos(phi, &sp, &cp);
+    const double d0 = cp * cos_theta, d1 = sp * cos_theta, d2 = sqrt(1.0 - cos_theta * cos_theta);
+    const double *h = hitrec + 12 * slot;
+    for (int k = 0; k < 3; k++) {
+        org[3 * id + k] = h[k];
+        dir[3 * id + k] = d0 * h[3 + k] + d1 * h[6 + k] + d2 * h[9 + k];
+    }
+}
+
+/* one thread per pixel: accumulates its sub-samples exactly like subsample()
+ * (render.c:749-822) and bucket_write (:962-975): rgb[(h-1-ly)*w + lx] */
+__global__ void k_ao_resolve(int w, int h, int xs, int ys, int N, const uint32_t *__restrict__ slot_of_sample,
+                             const uint8_t *__restrict__ occ, float *__restrict__ rgb,
+                             unsigned long long *__restrict__ occ_total)
+{
+    LH_NC
+    const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (size_t)w * h) return;
+    const int lx = (int)(pix % w), ly = (int)(pix / w);
+    double accum = 0.0;
+    unsigned int nocc = 0;
+    const int S = xs * ys;
+    for (int s = 0; s < S; s++) {
+        const uint32_t slot = slot_of_sample[pix * S + s];
+        double rad = 0.0;
+        if (slot != LH_MISS_PRIM) {
+            double occlusion = 0.0;
+            const uint8_t *o = occ + (size_t)slot * N;
+            for (int r = 0; r < N; r++) if (o[r]) { occlusion += 1.0; nocc++; }
+            const double ns = (double)(uint32_t)N;
+            rad = 1.0 * (ns - occlusion) / ns;
+        }
+        accum = accum + rad;
+    }
+    const double val = accum * ((double)1.0 / (xs * ys));
+    float f = (float)val;
+    if (f < 0.0f) f = 0.0f;
+    float *o = rgb + 3 * ((size_t)(h - 1 - ly) * w + lx);
+    o[0] = f; o[1] = f; o[2] = f;
+    if (occ_total && nocc) atomicAdd(occ_total, (unsigned long long)nocc);
+}
+
+} /* namespace */
+
+/* ---- host side -------------------------------------------------------------- */
+
+extern "C" int lh_render_launch_primary(const lh_camera_t *cam, int x0, int y0, int w, int h, int xs, int ys,
+                                        double *d_org, double *d_dir, void *stream)
+{
+    DevCamera c;
+    for (int i = 0; i < 16; i++) c.c2w[i] = cam->cam2world[i];
+    c.flength = cam->flength; c.width = cam->width; c.height = cam->height; c.rh = cam->rh;
+    const size_t total = (size_t)w * h * xs * ys;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(k_primary_rays, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       c, x0, y0, w, h, xs, ys, d_org, d_dir);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int lh_render_launch_compact(const lh_dev_scene_t *sc, const double *d_nrm9, size_t n, const double *d_org,
+                                        const double *d_dir, const uint32_t *d_prim, const double *d_t,
+                                        const double *d_u, const double *d_v, uint32_t *d_block_counts,
+                                        uint32_t *d_slot_of_sample, double *d_hitrec,
+                                        unsigned long long *d_slot_key, int x0, int y0, int w, int spp, int full_width,
+                                        unsigned long long *d_total, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) return 0;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_hit_count, dim3(nb), dim3(256), 0, s, n, d_prim, d_block_counts);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, nb, d_block_counts, d_total);
+    hipLaunchKernelGGL(k_ao_setup, dim3(nb), dim3(256), 0, s, n, *sc, d_nrm9, d_org, d_dir, d_prim, d_t, d_u, d_v,
+                       d_block_counts, d_slot_of_sample, d_hitrec, d_slot_key, x0, y0, w, spp, full_width);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int lh_render_launch_ao_rays(size_t nslots, int ntheta, int nphi, unsigned long long seed,
+                                        const double *d_hitrec, const double *d_rnd,
+                                        const unsigned long long *d_slot_key, double *d_org, double *d_dir, void *stream)
+{
+    const size_t total = nslots * (size_t)(ntheta * nphi);
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(k_ao_rays, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       nslots, ntheta, nphi, seed, d_hitrec, d_rnd, d_slot_key, d_org, d_dir);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int lh_render_launch_resolve(int w, int h, int xs, int ys, int N, const uint32_t *d_slot_of_sample,
+                                        const uint8_t *d_occ, float *d_rgb, unsigned long long *d_occ_total,
+                                        void *stream)
+{
+    const size_t total = (size_t)w * h;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(k_ao_resolve, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       w, h, xs, ys, N, d_slot_of_sample, d_occ, d_rgb, d_occ_total);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

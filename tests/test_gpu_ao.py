@@ -1,0 +1,136 @@
+"""GPU parity for the callers on either side of the query:
+camera rays, hit epilogue, AO ray producer, tile loop -- against the oracle and the
+reference's own C1 render (tests/golden/ao_c1.npz)."""
+import numpy as np
+import pytest
+
+import lucille_amd as la
+from lucille_amd import render
+from oracle import pyoracle as po
+from tests.helpers import assert_hits_equal, load_golden
+from tests.test_oracle_ao import oracle_from_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c1():
+    g = load_golden("ao_c1")
+    o = oracle_from_fixture(g)
+    acc = la.HipAccel(0)
+    for k in range(int(g["ngeoms"])):
+        acc.add_mesh(g["pos%d" % k], g["idx%d" % k])
+    acc.commit()
+    ocam = po.Camera.from_ref(g["camera"])
+    cam = la.Camera.make(ocam.width, ocam.height, ocam.flength, list(ocam.cam2world), ocam.rh)
+    img, rec = o.render_ao(ocam, 1, 16)
+    return {"g": g, "oracle": o, "acc": acc, "ocam": ocam, "cam": cam, "img": img, "rec": rec}
+
+
+def test_c1_ray_dump_hit_records(c1):
+    """BASELINE config 1's exact ray batch (499 168 rays, the reference's own primary +
+    AO rays in its own order) -> hit records equal the reference's, bit for bit"""
+    import torch
+    g, rec, acc = c1["g"], c1["rec"], c1["acc"]
+    o_ = torch.from_numpy(rec["org"]).cuda(); d_ = torch.from_numpy(rec["dir"]).cuda()
+    hit = g["prim"] != po.MISS
+    for variant in (0, 1, 2):
+        out = acc.intersect_device(o_, d_, variant=variant)
+        torch.cuda.synchronize()
+        prim = out[0].cpu().numpy().view(np.uint32)
+        assert np.array_equal(prim, g["prim"])
+        assert np.array_equal(out[1].cpu().numpy()[hit], g["t_hit"])
+        assert np.array_equal(out[2].cpu().numpy()[hit], g["u_hit"])
+        assert np.array_equal(out[3].cpu().numpy()[hit], g["v_hit"])
+        assert (out[1].cpu().numpy()[~hit] == 1.0e38).all()
+        occ = acc.intersect_device(o_, d_, mode=la.MODE_ANY, variant=variant)[0]
+        torch.cuda.synchronize()
+        assert np.array_equal(occ.cpu().numpy().astype(bool), hit)
+
+
+@pytest.mark.parametrize("ps", [1, 2, 4])
+def test_primary_rays_bit_exact(c1, ps):
+    """device camera rays == ri_camera_get_pos_and_dir + Hammersley jitter, every bit"""
+    import torch
+    acc, cam, ocam = c1["acc"], c1["cam"], c1["ocam"]
+    x0, y0, w, h = 37, 101, 50, 23
+    org, dr = acc.primary_rays(cam, x0, y0, w, h, ps)
+    torch.cuda.synchronize()
+    org = org.cpu().numpy(); dr = dr.cpu().numpy()
+    L = po.lib()
+    eo = np.empty(3); ed = np.empty(3); jit = (po.C.c_double * 2)()
+    L.lo_subpixel_jitter.argtypes = [po.C.c_int] * 4 + [po.C.c_double * 2]
+    k = 0
+    for ly in range(h):
+        for lx in range(w):
+            for sy in range(ps):
+                for sx in range(ps):
+                    L.lo_subpixel_jitter(sx, sy, ps, ps, jit)
+                    L.lo_camera_ray(po.C.byref(ocam), float(x0 + lx + jit[0]), float(y0 + ly + jit[1]),
+                                    eo.ctypes.data_as(po._dp), ed.ctypes.data_as(po._dp))
+                    assert np.array_equal(org[k], eo) and np.array_equal(dr[k], ed), (lx, ly, sx, sy)
+                    k += 1
+
+
+def test_tile_pipeline_replays_reference_frame(c1):
+    """bucket by bucket in the reference's spiral order, feeding the reference's MT19937
+    uniforms: hit epilogue records bit-exact, image == the reference's except where the
+    device libm's sin/cos moved an AO direction across an occlusion boundary"""
+    import torch
+    g, acc, cam, ocam, o = c1["g"], c1["acc"], c1["cam"], c1["ocam"], c1["oracle"]
+    W = H = 256; N = 16
+    order = np.zeros(2 * 64, np.uint32)
+    nb = po.lib().lo_bucket_order(W, H, 32, order.ctypes.data_as(po.C.POINTER(po.C.c_uint)))
+    assert nb == 64
+    mt = np.empty(2 * N * 27102 + 64); po.lib().lo_mt_stream(4357, mt.size, mt.ctypes.data_as(po._dp))
+    img = np.zeros((H, W, 3), np.float32)
+    used = 0; nhits = 0
+    first = True
+    for b in range(nb):
+        bx, by = int(order[2 * b]) * 32, int(order[2 * b + 1]) * 32
+        uni = torch.from_numpy(mt[used:used + 2 * N * 1024].copy()).cuda()     # at most 1024 hits per bucket
+        rgb, st = acc.render_ao_tile(cam, bx, by, 32, 32, 1, N, uniforms=uni)
+        used += 2 * N * st["primary_hits"]; nhits += st["primary_hits"]
+        img[H - (by + 32):H - by, bx:bx + 32] = rgb.cpu().numpy()
+        if first and st["primary_hits"]:
+            first = False
+            rec = acc.scratch(7, np.float64, 12)               # AO origin, tangent, binormal, Ns
+            prim = acc.scratch(2, np.uint32, 1); t = acc.scratch(3, np.float64, 1)
+            u = acc.scratch(4, np.float64, 1); v = acc.scratch(5, np.float64, 1)
+            po_ = acc.scratch(0, np.float64, 3); pd_ = acc.scratch(1, np.float64, 3)
+            slot = 0
+            for i in np.nonzero(prim != po.MISS)[0]:
+                P = np.empty(3); Ng = np.empty(3); Ns = np.empty(3); B = np.empty((3, 3))
+                po.lib().lo_state_build(o.h, int(prim[i]), float(t[i]), float(u[i]), float(v[i]),
+                                        po_[i].ctypes.data_as(po._dp), pd_[i].ctypes.data_as(po._dp),
+                                        P.ctypes.data_as(po._dp), Ng.ctypes.data_as(po._dp), Ns.ctypes.data_as(po._dp), None)
+                po.lib().lo_ortho_basis.argtypes = [po._dp, po._dp]
+                po.lib().lo_ortho_basis(B.ctypes.data_as(po._dp), Ns.ctypes.data_as(po._dp))
+                exp = np.concatenate([P + Ns * 1.0e-6, B[0], B[1], Ns])
+                assert np.array_equal(rec[slot], exp), (i, rec[slot], exp)
+                slot += 1
+    assert nhits == 27102                                     # the reference's primary hit count
+    ref = g["image"]
+    diff = np.abs(img - ref)
+    nbad = int((diff[..., 0] > 0).sum())
+    assert nbad <= 20, "pixels differing from the reference image: %d" % nbad
+    assert diff.max() <= 2.0 / 16 + 1e-6
+    assert np.array_equal(img[..., 0] == 0, ref[..., 0] == 0) or nbad > 0
+
+
+def test_whole_frame_builtin_rng_statistics(c1):
+    """throughput mode (counter-based RNG, one tile = whole frame): same coverage mask,
+    radiance statistically equal to the reference's image"""
+    g, acc, cam = c1["g"], c1["acc"], c1["cam"]
+    img, st = render.render_ao_frame(acc, cam, 1, 16, tile=256)
+    img = img.cpu().numpy(); ref = g["image"]
+    assert st["primary_rays"] == 65536 and st["primary_hits"] == 27102 and st["ao_rays"] == 27102 * 16
+    assert abs(img.mean() - ref.mean()) < 2e-3
+    hitmask = np.zeros((256, 256), bool)
+    # pixels the reference shaded (radiance > 0 somewhere) vs missed: misses are exactly 0
+    assert ((img[..., 0] == 0) & (ref[..., 0] > 0.5)).sum() == 0
+    rms = np.sqrt(((img - ref) ** 2).mean())
+    assert rms < 0.06, rms
+    # tiled == untiled (the RNG is keyed by absolute sample position, not by tile)
+    img2, _ = render.render_ao_frame(acc, cam, 1, 16, tile=64)
+    assert np.array_equal(img, img2.cpu().numpy())
