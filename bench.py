@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--mode", choices=["closest", "any"], default="closest")
     ap.add_argument("--cpu-rays", type=int, default=1_500_000, help="cpu_baseline sample size")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-ao", action="store_true", help="skip the secondary AO-frame leg")
+    ap.add_argument("--ao-size", type=int, default=1024)
+    ap.add_argument("--ao-samples", type=int, default=64)
     args = ap.parse_args()
 
     import torch
@@ -153,6 +156,11 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    ao = None
+    if not args.no_ao:
+        ao = ao_frame_leg(la, acc_device=local, rank=rank, world=world, size=args.ao_size, nsamples=args.ao_samples,
+                          steps=max(2, args.steps), dev=dev)
+
     if rank == 0:
         total_rays = n * world * args.steps
         value = total_rays / elapsed / 1e6
@@ -184,12 +192,57 @@ def main():
                          "kernel_ms": round(kernel_ms, 3), "bytes_per_ray": round(b_ray, 1),
                          "nodes_per_ray": round(n_nodes, 3), "tris_per_ray": round(n_tris, 3)},
         }
+        if ao is not None:
+            res["ao_render"] = ao
         if not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(po, P, idx, first_org, first_dir)
         print(json.dumps(res), flush=True)
     acc.close()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev):
+    """Secondary leg (BASELINE config 2): the reference's AO example scene (the 322
+    triangles its own RIB ingest produced, tests/golden/ao_c1.npz), size x size pixels,
+    `nsamples` AO rays per primary hit, whole pipeline on the device, tiles sharded
+    tile_id % world with one all-gather of tile slabs (strong scaling: the frame is fixed)."""
+    import torch
+    from lucille_amd import render
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ao_c1.npz"))
+    acc = la.HipAccel(acc_device)
+    for k in range(int(g["ngeoms"])):
+        acc.add_mesh(g["pos%d" % k], g["idx%d" % k])
+    acc.commit()
+    c = g["camera"]
+    cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
+    tile = max(64, size // 8)
+    times = []; st = None; img = None
+    for it in range(steps + 1):
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+        if world > 1:
+            img, st = render.render_ao_frame_sharded(acc, cam, 1, nsamples, rank, world, tile=tile)
+        else:
+            img, st = render.render_ao_frame(acc, cam, 1, nsamples, tile=size)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    rays = torch.tensor([st["primary_rays"] + st["ao_rays"]], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([min(times)], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(rays); torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    acc.close()
+    if rank != 0:
+        return None
+    return {"workload": "examples/ambient_occlusion scene (322 tris), %dx%d, %d AO samples, frame wall incl. ray gen + tile gather"
+                        % (size, size, nsamples),
+            "rays_per_frame": int(rays.item()), "frame_ms": round(tmax.item() * 1e3, 3),
+            "value": round(rays.item() / tmax.item() / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
+            "image_mean": float(img.mean().item())}
 
 
 def cpu_baseline(po, P, idx, org, dr):

@@ -51,31 +51,3 @@ def init_process_group(backend=None):
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
-
-
-def gather_tiles(image_shards, tile_ids, width, height, tile, channels, rank, world, dst=0):
-    """The exchange step.  image_shards: tensor [ntiles_local, tile*tile*channels] of this
-    rank's finished tiles (ragged tiles zero-padded), tile_ids: their ids.  Returns the
-    assembled [height, width, channels] image on rank `dst`, None elsewhere.
-    Equal-sized slabs -> one all_gather (RCCL: 7 point-to-point xGMI peers in parallel)."""
-    import torch
-    import torch.distributed as dist
-    tiles = tile_grid(width, height, tile)
-    per_rank = (len(tiles) + world - 1) // world
-    slab = torch.zeros((per_rank, tile * tile * channels), dtype=image_shards.dtype, device=image_shards.device)
-    if image_shards.shape[0]:
-        slab[:image_shards.shape[0]] = image_shards
-    if world > 1:
-        out = [torch.empty_like(slab) for _ in range(world)] if True else None
-        dist.all_gather(out, slab)
-    else:
-        out = [slab]
-    if rank != dst:
-        return None
-    img = torch.zeros((height, width, channels), dtype=image_shards.dtype, device=image_shards.device)
-    for r in range(world):
-        for k, tid in enumerate(tiles_of_rank(len(tiles), r, world)):
-            x0, y0, w, h = tiles[tid]
-            t = out[r][k].view(tile, tile, channels)
-            img[y0:y0 + h, x0:x0 + w] = t[:h, :w]
-    return img

@@ -1,0 +1,89 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the sharding and the one
+exchange step (all-gather of tile slabs to the display owner) used by
+lucille_amd.render / bench.py on RCCL."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lucille_amd import render, shard
+
+
+def test_ray_slices_partition_exactly():
+    for n in (0, 1, 7, 64, 1000003):
+        for world in (1, 2, 3, 8):
+            sl = [shard.ray_slice(n, r, world) for r in range(world)]
+            assert sl[0][0] == 0 and sl[-1][1] == n
+            assert all(sl[i][1] == sl[i + 1][0] for i in range(world - 1))
+            assert max(e - b for b, e in sl) - min(e - b for b, e in sl) <= 1
+
+
+def test_tiles_cover_image_once():
+    for (W, H, T) in ((256, 256, 64), (100, 70, 32), (33, 257, 16), (1024, 1024, 256)):
+        tiles = shard.tile_grid(W, H, T)
+        cover = np.zeros((H, W), int)
+        for x0, y0, w, h in tiles:
+            cover[y0:y0 + h, x0:x0 + w] += 1
+        assert (cover == 1).all()
+        for world in (1, 2, 8):
+            ids = sorted(sum((shard.tiles_of_rank(len(tiles), r, world) for r in range(world)), []))
+            assert ids == list(range(len(tiles)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, W, H, T, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = shard.init_process_group(backend="gloo")
+    assert (r, w) == (rank, world)
+    tiles = shard.tile_grid(W, H, T)
+    mine = shard.tiles_of_rank(len(tiles), rank, world)
+    # "render": pixel value encodes its frame position (bottom-up y like the renderer's tiles)
+    slab = torch.zeros((len(mine), T * T * 3))
+    for k, tid in enumerate(mine):
+        x0, y0, w_, h_ = tiles[tid]
+        t = torch.zeros((T, T, 3))
+        for ly in range(h_):
+            for lx in range(w_):
+                py = y0 + (h_ - 1 - ly)           # tile row 0 = top row of the tile in image orientation
+                t[ly, lx] = torch.tensor([x0 + lx, py, rank], dtype=torch.float32)
+        slab[k] = t.view(-1)
+    img = render.assemble(slab, W, H, T, rank, world)
+    # max-over-ranks timing reduction as bench.py does
+    tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    assert tt.item() == world
+    if rank == 0:
+        q.put(img.numpy())
+    else:
+        assert img is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("W,H,T", [(64, 48, 16), (50, 35, 16)])
+def test_tile_gather_world2_gloo(W, H, T):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, W, H, T, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    img = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    assert np.array_equal(img[..., 0], xs)
+    assert np.array_equal(img[..., 1], H - 1 - ys)          # image row r shows frame line H-1-r (bucket_write's flip)
+    tiles = shard.tile_grid(W, H, T)
+    owner = np.zeros((H, W))
+    for tid, (x0, y0, w_, h_) in enumerate(tiles):
+        owner[H - (y0 + h_):H - y0, x0:x0 + w_] = tid % 2
+    assert np.array_equal(img[..., 2], owner)
