@@ -32,7 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
-B_IN, B_OUT, B_NODE, B_TRI = 32, 16, 64, 40   # SURVEY.md 8(d) algorithmic bytes
+B_IN, B_OUT, B_TRI = 32, 16, 40   # SURVEY.md 8(d) algorithmic bytes per ray / per triangle test
+B_NODE = {"f32": 64, "q16": 32}       # per inner-node visit: SURVEY's 64-B fp32 node, or this build's 32-B 16-bit grid node
 
 
 def hip_event_timer():
@@ -121,7 +122,8 @@ def main():
     _, cnt = acc.intersect_device(d_org[:ns], d_dir[:ns], mode=mode, variant=args.variant, counters=True)
     n_nodes = cnt["nodes"] / ns; n_tris = cnt["tris"] / ns
     b_out = B_OUT if mode == la.MODE_CLOSEST else 4
-    b_ray = B_IN + b_out + B_NODE * n_nodes + B_TRI * n_tris
+    node_fmt = "f32" if os.environ.get("LH_NODE_FORMAT") == "f32" else "q16"
+    b_ray = B_IN + b_out + B_NODE[node_fmt] * n_nodes + B_TRI * n_tris
 
     # ---- timed region -------------------------------------------------------------
     hip = hip_event_timer()
@@ -188,7 +190,8 @@ def main():
                                "build_s": round(info["build_seconds"], 3)}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "k_trace_persist_lane" if args.variant in (-1, 2) else "k_trace_v%d" % args.variant,
+                         "kernel": "k_trace_persist_lane<walk=spec,%s nodes>" % node_fmt if args.variant in (-1, 4) else "k_trace_v%d" % args.variant,
+                         "node_bytes": B_NODE[node_fmt],
                          "kernel_ms": round(kernel_ms, 3), "bytes_per_ray": round(b_ray, 1),
                          "nodes_per_ray": round(n_nodes, 3), "tris_per_ray": round(n_tris, 3)},
         }

@@ -58,12 +58,14 @@ struct lh_accel {
     lh_bvh_t bvh;
     /* device */
     lh_dev_scene_t dev;
-    void *d_nodes, *d_tri32, *d_tri64;
+    void *d_nodes, *d_tri32, *d_tri64, *d_qnodes;
     unsigned long long *d_cursor, *d_counters;
     hipStream_t stream;
     uint64_t device_bytes;
     double upload_seconds;
     int grid_blocks;
+    int min_active;
+    int tri_batch;
     int default_variant;
     /* staging for host batches */
     void *d_stage; size_t stage_bytes;
@@ -95,9 +97,15 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     lh_accel_t *a = (lh_accel_t *)calloc(1, sizeof(*a));
     if (!a) return fail("out of memory");
     a->device = device;
-    a->default_variant = LH_VARIANT_PERSIST_LANE;
+    a->default_variant = LH_VARIANT_SPEC;
     const char *env = getenv("LH_VARIANT");
     if (env) a->default_variant = atoi(env);
+    a->min_active = 16;
+    a->tri_batch = 4;
+    env = getenv("LH_TRI_BATCH");
+    if (env && atoi(env) > 0 && atoi(env) <= 64) a->tri_batch = atoi(env);
+    env = getenv("LH_MIN_ACTIVE");
+    if (env && atoi(env) > 0 && atoi(env) <= 64) a->min_active = atoi(env);
     *out = a;
     return 0;
 }
@@ -160,6 +168,8 @@ static void release_device(lh_accel_t *a)
     if (a->d_nodes) (void)hipFree(a->d_nodes);
     if (a->d_tri32) (void)hipFree(a->d_tri32);
     if (a->d_tri64) (void)hipFree(a->d_tri64);
+    if (a->d_qnodes) (void)hipFree(a->d_qnodes);
+    a->d_qnodes = NULL;
     if (a->d_cursor) (void)hipFree(a->d_cursor);
     if (a->d_counters) (void)hipFree(a->d_counters);
     if (a->d_stage) (void)hipFree(a->d_stage);
@@ -224,17 +234,24 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
         size_t t32 = sizeof(lh_tri32_t) * (size_t)a->bvh.ntris;
         size_t t64 = sizeof(lh_tri64_t) * (size_t)a->bvh.ntris;
         HIPCHK(hipMalloc(&a->d_nodes, nb));
-        HIPCHK(hipMalloc(&a->d_tri32, t32));
+        HIPCHK(hipMalloc(&a->d_tri32, t32 + 64));   /* the unified walk reads 16 B past a record */
         HIPCHK(hipMalloc(&a->d_tri64, t64));
         HIPCHK(hipMemcpy(a->d_nodes, a->bvh.nodes, nb, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(a->d_tri32, a->bvh.tri32, t32, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(a->d_tri64, a->bvh.tri64, t64, hipMemcpyHostToDevice));
-        a->device_bytes = nb + t32 + t64;
+        size_t qb = sizeof(lh_qnode_t) * (size_t)a->bvh.nnodes;
+        HIPCHK(hipMalloc(&a->d_qnodes, qb));
+        HIPCHK(hipMemcpy(a->d_qnodes, a->bvh.qnodes, qb, hipMemcpyHostToDevice));
+        a->device_bytes = nb + t32 + t64 + qb;
         float r = 0.0f;
         for (int k = 0; k < 3; k++) { r = fmaxf(r, fabsf(a->bvh.bmin[k])); r = fmaxf(r, fabsf(a->bvh.bmax[k])); }
         a->dev.nodes = a->d_nodes; a->dev.tri32 = a->d_tri32; a->dev.tri64 = a->d_tri64;
         a->dev.ntris = a->bvh.ntris; a->dev.nnodes = a->bvh.nnodes;
         a->dev.max_depth = a->bvh.max_depth; a->dev.scene_r = r;
+        a->dev.qnodes = a->d_qnodes;
+        for (int k = 0; k < 3; k++) { a->dev.grid_lo[k] = a->bvh.grid_lo[k]; a->dev.grid_step[k] = a->bvh.grid_step[k]; }
+        a->dev.use_qnodes = 1;
+        { const char *fmt = getenv("LH_NODE_FORMAT"); if (fmt && strcmp(fmt, "f32") == 0) a->dev.use_qnodes = 0; }
         if (a->bvh.max_depth + 1 > 64) return fail("lh_accel_commit: tree depth %u exceeds the kernel stack", a->bvh.max_depth);
     }
     a->upload_seconds = now_s() - t0;
@@ -328,10 +345,10 @@ static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
         return 0;
     }
     if (variant == LH_VARIANT_DEFAULT) variant = a->default_variant;
-    if (variant < 0 || variant > LH_VARIANT_PERSIST_LANE) return fail("intersect: unknown variant %d", variant);
+    if (variant < 0 || variant > LH_VARIANT_SPEC) return fail("intersect: unknown variant %d", variant);
     int rc = lh_launch_trace(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim,
                              (double *)d_t, (double *)d_u, (double *)d_v, mode == LH_MODE_ANY,
-                             (uint8_t *)d_occ, d_counters, a->d_cursor, variant, a->grid_blocks, (void *)s);
+                             (uint8_t *)d_occ, d_counters, a->d_cursor, variant, a->grid_blocks, a->min_active, a->tri_batch, (void *)s);
     if (rc != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     return 0;
 }

@@ -289,6 +289,42 @@ static void emit_inner(flat_t *f, const tnode_t *n, uint32_t idx, uint32_t depth
     if (c1->count == 0) emit_inner(f, c1, k1, depth + 1);
 }
 
+/* derive the 16-bit grid nodes from the fp32 nodes (see lh_qnode_t) */
+static int quantize_nodes(lh_bvh_t *o)
+{
+    uint32_t i; int k, c;
+    o->qnodes = (lh_qnode_t *)malloc(sizeof(lh_qnode_t) * (size_t)(o->nnodes ? o->nnodes : 1));
+    if (!o->qnodes) return -1;
+    for (k = 0; k < 3; k++) {
+        double ext = (double)o->bmax[k] - (double)o->bmin[k];
+        o->grid_lo[k] = o->bmin[k];
+        o->grid_step[k] = up32(ext > 0.0 ? ext / 65535.0 * (1.0 + 1e-6) : 1e-30);
+    }
+    for (i = 0; i < o->nnodes; i++) {
+        const lh_node_t *n = &o->nodes[i]; lh_qnode_t *q = &o->qnodes[i];
+        const float *lo[2] = { n->lo0, n->lo1 }, *hi[2] = { n->hi0, n->hi1 };
+        int32_t ref[2] = { n->ref0, n->ref1 };
+        if (ref[1] == LH_REF_EMPTY) {       /* single-leaf scene: no empty boxes on a grid -> visit the leaf twice */
+            ref[1] = ref[0]; lo[1] = lo[0]; hi[1] = hi[0];
+        }
+        for (c = 0; c < 2; c++)
+            for (k = 0; k < 3; k++) {
+                const double g = o->grid_lo[k], st = o->grid_step[k];
+                double ql = floor(((double)lo[c][k] - g) / st), qh = ceil(((double)hi[c][k] - g) / st);
+                if (ql < 0.0) ql = 0.0;
+                if (ql > 65535.0) ql = 65535.0;
+                if (qh < 0.0) qh = 0.0;
+                if (qh > 65535.0) qh = 65535.0;
+                while (ql > 0.0 && g + ql * st > (double)lo[c][k]) ql -= 1.0;
+                while (qh < 65535.0 && g + qh * st < (double)hi[c][k]) qh += 1.0;
+                if (g + ql * st > (double)lo[c][k] || g + qh * st < (double)hi[c][k]) return -1;   /* grid does not cover: bug */
+                q->q[6 * c + k] = (uint16_t)ql; q->q[6 * c + 3 + k] = (uint16_t)qh;
+            }
+        q->ref0 = ref[0]; q->ref1 = ref[1];
+    }
+    return 0;
+}
+
 static uint32_t count_inner(const tnode_t *n) { return n->count ? 0 : 1 + count_inner(n->c[0]) + count_inner(n->c[1]); }
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -406,12 +442,13 @@ int lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, 
     }
     arena_free(&main_arena);
     free(b.tasks); free(b.plo); free(b.phi); free(b.cen); free(b.order);
+    if (quantize_nodes(out) != 0) { lh_bvh_release(out); return -1; }
     out->build_seconds = now_s() - t0;
     return 0;
 }
 
 void lh_bvh_release(lh_bvh_t *bvh)
 {
-    free(bvh->nodes); free(bvh->tri32); free(bvh->tri64); free(bvh->prim_geom); free(bvh->prim_index);
+    free(bvh->nodes); free(bvh->qnodes); free(bvh->tri32); free(bvh->tri64); free(bvh->prim_geom); free(bvh->prim_index);
     memset(bvh, 0, sizeof(*bvh));
 }

@@ -37,6 +37,17 @@ typedef struct lh_node {
 
 #define LH_REF_EMPTY ((int32_t)0x80000000)
 
+/* 32-byte quantised inner node: the same two child boxes on a 16-bit grid spanning the
+ * scene box (x = grid_lo + q * grid_step, lo rounded down / hi rounded up, so the decoded
+ * box CONTAINS the fp32 box).  Halves the 16-byte lane-loads per visit (2 instead of 4)
+ * -- the traversal kernel is bound by the texture-addresser's per-lane request rate, not
+ * by bytes (profiles/r01_pmc_diag.md) -- and doubles the nodes an L2 holds.
+ *   q[0..2] lo0 xyz, q[3..5] hi0 xyz, q[6..8] lo1 xyz, q[9..11] hi1 xyz               */
+typedef struct lh_qnode {
+    uint16_t q[12];
+    int32_t  ref0, ref1;
+} lh_qnode_t;
+
 /* 48-byte leaf triangle record (fp32 filter form): v0, e1=v1-v0, e2=v2-v0
  * rounded from the fp64 differences, the primitive id and two precomputed
  * norms used by the conservative-filter tolerances.                        */
@@ -61,6 +72,8 @@ typedef struct lh_bvh {
     uint32_t   *prim_geom; /* ntris: mesh ordinal of primitive              */
     uint32_t   *prim_index;/* ntris: 3*i offset into that mesh's indices    */
     float       bmin[3], bmax[3];  /* scene box, fp32 outward               */
+    lh_qnode_t *qnodes;            /* nnodes, same indexing as nodes         */
+    float       grid_lo[3], grid_step[3];   /* quantisation grid of qnodes   */
     double      build_seconds;
 } lh_bvh_t;
 

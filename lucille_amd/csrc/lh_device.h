@@ -17,6 +17,9 @@ typedef struct lh_dev_scene {
     const void *nodes;     /* lh_node_t[nnodes]  (64 B each)                 */
     const void *tri32;     /* lh_tri32_t[ntris]  (48 B each, leaf order)     */
     const void *tri64;     /* lh_tri64_t[ntris]  (72 B each, prim-id order)  */
+    const void *qnodes;    /* lh_qnode_t[nnodes] (32 B each, 16-bit grid)     */
+    float       grid_lo[3], grid_step[3];
+    int         use_qnodes;
     uint32_t    ntris;
     uint32_t    nnodes;
     uint32_t    max_depth;
@@ -30,7 +33,9 @@ enum { LH_CNT_NODES = 0, LH_CNT_TRIS = 1, LH_CNT_EXACT = 2, LH_CNT_RAYS = 3, LH_
 enum {
     LH_VARIANT_DIRECT      = 0,   /* one ray per lane, grid covers the batch  */
     LH_VARIANT_PERSIST_WAVE = 1,  /* persistent waves, 64-ray chunks          */
-    LH_VARIANT_PERSIST_LANE = 2   /* persistent waves, ballot-compacted refill */
+    LH_VARIANT_PERSIST_LANE = 2,  /* persistent waves, ballot-compacted refill */
+    LH_VARIANT_UNIFIED      = 3,  /* + single-loop walk: one record per lane per iteration */
+    LH_VARIANT_SPEC         = 4   /* + speculative walk, leaves parked and tested in batches */
 };
 
 #ifdef __cplusplus
@@ -43,7 +48,7 @@ int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double *d_org,
                     double *d_u, double *d_v, int anyhit, uint8_t *d_occluded,
                     unsigned long long *d_counters /* LH_CNT_N or NULL */,
                     unsigned long long *d_workq /* persistent cursor */,
-                    int variant, int grid_blocks, void *stream);
+                    int variant, int grid_blocks, int min_active, int tri_batch, void *stream);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,8 @@ typedef struct lh_ray32 {
     float ix, iy, iz;                 /* 1/dir (|dir_k| clamped to 1e-30)   */
     float cnx, cny, cnz;              /* -org*idir - slack                   */
     float cfx, cfy, cfz;              /* -org*idir + slack                   */
+    /* 16-bit grid nodes: t = q*qa + qbn/qbf  (qa = step*idir, qb = (grid_lo-org)*idir -/+ slack) */
+    float qax, qay, qaz, qbnx, qbny, qbnz, qbfx, qbfy, qbfz;
     float keps;                       /* KTRI*2^-24*(|org|_inf+R)            */
     float dn;                         /* |dir|_2 rounded up                  */
     int   ngx, ngy, ngz;              /* dir_k < 0                           */
@@ -58,6 +60,24 @@ typedef struct lh_ray32 {
 LH_HD float lh_safe_dir(float d)
 {
     return (fabsf(d) < 1e-30f) ? copysignf(1e-30f, d) : d;
+}
+
+typedef struct lh_grid { float lo[3], step[3]; } lh_grid_t;
+
+/* grid constants; scene_r as in lh_ray_setup.  The grid adds one rounding of (grid_lo-org)
+ * and of step*idir per axis: both are inside the KBOX margin. */
+LH_HD void lh_ray_setup_grid(lh_ray32_t *r, const float glo[3], const float gstep[3], float scene_r)
+{
+    const float omax = fmaxf(fabsf(r->ox), fmaxf(fabsf(r->oy), fabsf(r->oz)));
+    const float pe = LH_KBOX * LH_EPS24 * (omax + scene_r);
+    const float sx = pe * fabsf(r->ix), sy = pe * fabsf(r->iy), sz = pe * fabsf(r->iz);
+    r->qax = gstep[0] * r->ix; r->qay = gstep[1] * r->iy; r->qaz = gstep[2] * r->iz;
+    {
+        const float bx = (glo[0] - r->ox) * r->ix, by = (glo[1] - r->oy) * r->iy, bz = (glo[2] - r->oz) * r->iz;
+        r->qbnx = bx - sx; r->qbfx = bx + sx;
+        r->qbny = by - sy; r->qbfy = by + sy;
+        r->qbnz = bz - sz; r->qbfz = bz + sz;
+    }
 }
 
 LH_HD void lh_ray_setup(lh_ray32_t *r, double ox, double oy, double oz,
@@ -78,6 +98,7 @@ LH_HD void lh_ray_setup(lh_ray32_t *r, double ox, double oy, double oz,
     r->cnz = fmaf(-r->oz, r->iz, -sz); r->cfz = fmaf(-r->oz, r->iz, sz);
     r->ngx = r->dx < 0.0f; r->ngy = r->dy < 0.0f; r->ngz = r->dz < 0.0f;
     r->keps = LH_KTRI * LH_EPS24 * scale;
+    r->qax = r->qay = r->qaz = 0.0f; r->qbnx = r->qbny = r->qbnz = 0.0f; r->qbfx = r->qbfy = r->qbfz = 0.0f;
     r->dn = sqrtf(fmaf(r->dx, r->dx, fmaf(r->dy, r->dy, r->dz * r->dz))) * 1.000001f;
 }
 
@@ -95,6 +116,21 @@ LH_HD int lh_slab(const lh_ray32_t *r, float lox, float loy, float loz,
                            fmaxf(fmaf(az, r->iz, r->cnz), 0.0f));
     const float tf = fminf(fminf(fmaf(bx, r->ix, r->cfx), fmaf(by, r->iy, r->cfy)),
                            fminf(fmaf(bz, r->iz, r->cfz), tb));
+    *tn_out = tn;
+    return tn <= tf;
+}
+
+/* the same test on a 16-bit grid box (lh_qnode_t): qlo/qhi already converted to float */
+LH_HD int lh_slab_q(const lh_ray32_t *r, float lox, float loy, float loz,
+                    float hix, float hiy, float hiz, float tb, float *tn_out)
+{
+    const float ax = r->ngx ? hix : lox, bx = r->ngx ? lox : hix;
+    const float ay = r->ngy ? hiy : loy, by = r->ngy ? loy : hiy;
+    const float az = r->ngz ? hiz : loz, bz = r->ngz ? loz : hiz;
+    const float tn = fmaxf(fmaxf(fmaf(ax, r->qax, r->qbnx), fmaf(ay, r->qay, r->qbny)),
+                           fmaxf(fmaf(az, r->qaz, r->qbnz), 0.0f));
+    const float tf = fminf(fminf(fmaf(bx, r->qax, r->qbfx), fmaf(by, r->qay, r->qbfy)),
+                           fminf(fmaf(bz, r->qaz, r->qbfz), tb));
     *tn_out = tn;
     return tn <= tf;
 }

@@ -67,6 +67,30 @@ __device__ __forceinline__ void resolve(const double *__restrict__ tri64, uint32
     }
 }
 
+/* fetch one inner node and test both child boxes: fp32 nodes (4 x dwordx4) or 16-bit grid
+ * nodes (2 x dwordx4) */
+template <bool QN>
+__device__ __forceinline__ void node_test(const lh_dev_scene_t &sc, const lh_ray32_t &r, float tb, int cur,
+                                          bool &h0, bool &h1, float &tn0, float &tn1, int &r0, int &r1)
+{
+    if (QN) {
+        const uint4 *p = (const uint4 *)sc.qnodes + 2 * (size_t)cur;
+        const uint4 a = p[0], b = p[1];
+        h0 = lh_slab_q(&r, (float)(a.x & 0xffffu), (float)(a.x >> 16), (float)(a.y & 0xffffu),
+                       (float)(a.y >> 16), (float)(a.z & 0xffffu), (float)(a.z >> 16), tb, &tn0);
+        h1 = lh_slab_q(&r, (float)(a.w & 0xffffu), (float)(a.w >> 16), (float)(b.x & 0xffffu),
+                       (float)(b.x >> 16), (float)(b.y & 0xffffu), (float)(b.y >> 16), tb, &tn1);
+        r0 = (int)b.z; r1 = (int)b.w;
+    } else {
+        const float4 *p = (const float4 *)sc.nodes + 4 * (size_t)cur;
+        const float4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3];
+        /* child0: lo (n0.x n0.y n0.z) hi (n0.w n1.x n1.y); child1: lo (n1.z n1.w n2.x) hi (n2.y n2.z n2.w) */
+        h0 = lh_slab(&r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, tb, &tn0);
+        h1 = lh_slab(&r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, tb, &tn1);
+        r0 = __float_as_int(n3.x); r1 = __float_as_int(n3.y);
+    }
+}
+
 struct Lane {
     lh_ray32_t r;          /* fp32 ray + slab/filter constants */
     float tb;              /* culling bound (fp32, rounded up) */
@@ -81,6 +105,7 @@ __device__ __forceinline__ void lane_init(Lane &L, const lh_dev_scene_t &sc,
                                           double dx, double dy, double dz)
 {
     lh_ray_setup(&L.r, ox, oy, oz, dx, dy, dz, sc.scene_r);
+    if (sc.use_qnodes) lh_ray_setup_grid(&L.r, sc.grid_lo, sc.grid_step, sc.scene_r);
     L.tb = 1.0e38f;
     L.cur = 0; L.sp = 1;
     L.p0 = L.p1 = L.p2 = L.p3 = LH_MISS_PRIM; L.np = 0;
@@ -90,7 +115,7 @@ __device__ __forceinline__ void lane_init(Lane &L, const lh_dev_scene_t &sc,
 /* the per-lane traversal body; runs while the lane has work, leaves when
  * `stop()` says the wave should regroup.  Returns with L.cur == kDone when the
  * ray is finished. */
-template <int STACK, bool ANYHIT, bool COUNT, bool BURST>
+template <int STACK, bool ANYHIT, bool COUNT, bool BURST, bool QN>
 __device__ __forceinline__ void traverse(Lane &L, const lh_dev_scene_t &sc,
                                          int (*stk)[LH_BLOCK], const int tid,
                                          double ox, double oy, double oz,
@@ -98,22 +123,15 @@ __device__ __forceinline__ void traverse(Lane &L, const lh_dev_scene_t &sc,
                                          uint32_t &c_nodes, uint32_t &c_tris, uint32_t &c_exact,
                                          const int min_active)
 {
-    const float4 *__restrict__ nodes = (const float4 *)sc.nodes;
     const float4 *__restrict__ tris  = (const float4 *)sc.tri32;
     const double *__restrict__ tri64 = (const double *)sc.tri64;
 
     while (L.cur != kDone) {
         /* ---- inner nodes ------------------------------------------------ */
         while (L.cur >= 0) {
-            const float4 *np = nodes + 4 * (size_t)L.cur;
-            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             if (COUNT) c_nodes++;
-            /* child0: lo (n0.x n0.y n0.z) hi (n0.w n1.x n1.y)
-             * child1: lo (n1.z n1.w n2.x) hi (n2.y n2.z n2.w) */
-            float tn0, tn1;
-            const bool h0 = lh_slab(&L.r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, L.tb, &tn0);
-            const bool h1 = lh_slab(&L.r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, L.tb, &tn1);
-            const int r0 = __float_as_int(n3.x), r1 = __float_as_int(n3.y);
+            float tn0, tn1; bool h0, h1; int r0, r1;
+            node_test<QN>(sc, L.r, L.tb, L.cur, h0, h1, tn0, tn1, r0, r1);
             if (h0 | h1) {
                 const bool second = h1 && (!h0 || tn1 < tn0);
                 L.cur = second ? r1 : r0;
@@ -165,6 +183,166 @@ __device__ __forceinline__ void traverse(Lane &L, const lh_dev_scene_t &sc,
     }
 }
 
+/* Single-loop ("if-if") walk: every iteration every active lane consumes exactly ONE
+ * record -- an inner node (64 B) or one leaf triangle (48 B) -- fetched with the same
+ * four dwordx4 loads from a per-lane pointer, so lanes that reach a leaf do not idle
+ * while their neighbours are still descending (the while-while walk above measured
+ * 21 % VALU lane utilisation on incoherent rays: rocprofv3 SQ_THREAD_CYCLES_VALU /
+ * (SQ_ACTIVE_INST_VALU*64), profiles/r01_pmc_diag.md).  A leaf with k triangles is k
+ * iterations: the leaf reference carries (first, count-1) and is advanced in place. */
+template <int STACK, bool ANYHIT, bool COUNT>
+__device__ __forceinline__ void traverse_unified(Lane &L, const lh_dev_scene_t &sc,
+                                                 int (*stk)[LH_BLOCK], const int tid,
+                                                 double ox, double oy, double oz,
+                                                 double dx, double dy, double dz, Best &best,
+                                                 uint32_t &c_nodes, uint32_t &c_tris, uint32_t &c_exact,
+                                                 const int min_active)
+{
+    const float4 *__restrict__ nodes = (const float4 *)sc.nodes;
+    const float4 *__restrict__ tris  = (const float4 *)sc.tri32;
+    const double *__restrict__ tri64 = (const double *)sc.tri64;
+
+    while (L.cur != kDone) {
+        const bool is_node = L.cur >= 0;
+        const uint32_t x = ~(uint32_t)L.cur;
+        const float4 *p = is_node ? nodes + 4 * (size_t)L.cur : tris + 3 * (size_t)(x >> 2);
+        const float4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3];   /* tri32 is padded by 16 B */
+        if (is_node) {
+            if (COUNT) c_nodes++;
+            float tn0, tn1;
+            const bool h0 = lh_slab(&L.r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, L.tb, &tn0);
+            const bool h1 = lh_slab(&L.r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, L.tb, &tn1);
+            const int r0 = __float_as_int(n3.x), r1 = __float_as_int(n3.y);
+            if (h0 | h1) {
+                const bool second = h1 && (!h0 || tn1 < tn0);
+                L.cur = second ? r1 : r0;
+                if (h0 & h1) { stk[L.sp][tid] = second ? r0 : r1; L.sp++; }
+            } else {
+                L.sp--; L.cur = stk[L.sp][tid];
+            }
+        } else {
+            if (COUNT) c_tris++;
+            float t_hi;
+            bool finished = false;
+            const int cls = lh_tri_filter(&L.r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y,
+                                          n1.z, n1.w, n2.x, n2.z, n2.w, L.tb, &t_hi);
+            if (cls != LH_TRI_REJECT) {
+                const bool sure = (cls == LH_TRI_CERTAIN);
+                if (ANYHIT && sure) { L.certain = true; finished = true; }
+                else {
+                    if (sure) L.tb = fminf(L.tb, t_hi);
+                    const uint32_t prim = __float_as_uint(n2.y);
+                    if (L.np == kPend) {
+                        if (COUNT) c_exact += kPend;
+                        resolve(tri64, L.p0, ox, oy, oz, dx, dy, dz, best);
+                        resolve(tri64, L.p1, ox, oy, oz, dx, dy, dz, best);
+                        resolve(tri64, L.p2, ox, oy, oz, dx, dy, dz, best);
+                        resolve(tri64, L.p3, ox, oy, oz, dx, dy, dz, best);
+                        L.np = 0;
+                        if (ANYHIT && best.prim != LH_MISS_PRIM) finished = true;
+                    }
+                    L.p3 = L.p2; L.p2 = L.p1; L.p1 = L.p0; L.p0 = prim; L.np++;
+                }
+            }
+            if (finished) L.cur = kDone;
+            else if (x & 3u) L.cur = (int)~(((x >> 2) + 1u) << 2 | ((x & 3u) - 1u));   /* next triangle of this leaf */
+            else { L.sp--; L.cur = stk[L.sp][tid]; }
+        }
+        /* wave regroup point: leave when too few lanes are still walking */
+        if (__popcll(__ballot(L.cur != kDone)) < min_active) break;
+    }
+}
+
+/* Speculative walk with one postponed leaf per lane (variant 4).
+ *
+ * The unified walk still executes the ~75-instruction triangle path on every iteration
+ * for the ~6 % of lanes that hold a leaf (rocprofv3: SIMDs ~90 % issue-busy, VALU lane
+ * utilisation 29 %).  Here a lane that reaches a leaf parks it in `pend` and keeps
+ * descending from its stack; the triangle path runs only when at least `tri_batch` lanes
+ * hold a parked leaf (or nobody has an inner node left), one triangle per parked lane per
+ * pass.  A lane that meets a second leaf while one is parked waits for the next pass.
+ * The node step is branch-free: unconditional LDS push (slot sp is free space), pop read
+ * of slot sp-1 (slot 0 holds the sentinel), selects for everything else. */
+template <int STACK, bool ANYHIT, bool COUNT, bool QN>
+__device__ __forceinline__ void traverse_spec(Lane &L, int &pend, const lh_dev_scene_t &sc,
+                                              int (*stk)[LH_BLOCK], const int tid,
+                                              double ox, double oy, double oz,
+                                              double dx, double dy, double dz, Best &best,
+                                              uint32_t &c_nodes, uint32_t &c_tris, uint32_t &c_exact,
+                                              const int min_active, const int tri_batch)
+{
+    const float4 *__restrict__ tris  = (const float4 *)sc.tri32;
+    const double *__restrict__ tri64 = (const double *)sc.tri64;
+    constexpr int kNoLeaf = 0;   /* never a valid leaf reference (leaf refs are negative) */
+
+    for (;;) {
+        /* ---- node step for every lane that holds an inner node ------------------ */
+        if (L.cur >= 0) {
+            if (COUNT) c_nodes++;
+            float tn0, tn1; bool h0, h1; int r0, r1;
+            node_test<QN>(sc, L.r, L.tb, L.cur, h0, h1, tn0, tn1, r0, r1);
+            const bool any = h0 | h1, both = h0 & h1;
+            const bool second = h1 && (!h0 || tn1 < tn0);
+            stk[L.sp][tid] = second ? r0 : r1;                 /* far child; kept only if `both` */
+            L.sp += both ? 1 : 0;
+            const int popped = stk[L.sp - 1][tid];
+            int nxt = any ? (second ? r1 : r0) : popped;
+            L.sp -= any ? 0 : 1;
+            /* park the leaf and keep walking if the parking slot is free */
+            const bool is_leaf = (nxt < 0) & (nxt != kDone);
+            const bool park = is_leaf & (pend == kNoLeaf);
+            pend = park ? nxt : pend;
+            const int popped2 = stk[L.sp - 1][tid];
+            L.cur = park ? popped2 : nxt;
+            L.sp -= park ? 1 : 0;
+        }
+        /* ---- triangle pass when enough leaves are parked ------------------------- */
+        const unsigned long long m_node = __ballot(L.cur >= 0);
+        const unsigned long long m_pend = __ballot(pend != kNoLeaf);
+        if (m_pend != 0ull && (__popcll(m_pend) >= tri_batch || m_node == 0ull)) {
+            if (pend != kNoLeaf) {
+                const uint32_t x = ~(uint32_t)pend;
+                const float4 *tp = tris + 3 * (size_t)(x >> 2);
+                const float4 ta = tp[0], tb_ = tp[1], tc = tp[2];
+                if (COUNT) c_tris++;
+                float t_hi;
+                bool finished = false;
+                const int cls = lh_tri_filter(&L.r, ta.x, ta.y, ta.z, ta.w, tb_.x, tb_.y,
+                                              tb_.z, tb_.w, tc.x, tc.z, tc.w, L.tb, &t_hi);
+                if (cls != LH_TRI_REJECT) {
+                    const bool sure = (cls == LH_TRI_CERTAIN);
+                    if (ANYHIT && sure) { L.certain = true; finished = true; }
+                    else {
+                        if (sure) L.tb = fminf(L.tb, t_hi);
+                        const uint32_t prim = __float_as_uint(tc.y);
+                        if (L.np == kPend) {
+                            if (COUNT) c_exact += kPend;
+                            resolve(tri64, L.p0, ox, oy, oz, dx, dy, dz, best);
+                            resolve(tri64, L.p1, ox, oy, oz, dx, dy, dz, best);
+                            resolve(tri64, L.p2, ox, oy, oz, dx, dy, dz, best);
+                            resolve(tri64, L.p3, ox, oy, oz, dx, dy, dz, best);
+                            L.np = 0;
+                            if (ANYHIT && best.prim != LH_MISS_PRIM) finished = true;
+                        }
+                        L.p3 = L.p2; L.p2 = L.p1; L.p1 = L.p0; L.p0 = prim; L.np++;
+                    }
+                }
+                if (finished) { L.cur = kDone; pend = kNoLeaf; }
+                else if (x & 3u) pend = (int)~(((x >> 2) + 1u) << 2 | ((x & 3u) - 1u));   /* next triangle */
+                else {
+                    /* leaf finished: a lane that was waiting with a second leaf parks it now */
+                    const bool waiting = (L.cur < 0) & (L.cur != kDone);
+                    pend = waiting ? L.cur : kNoLeaf;
+                    if (waiting) { L.sp--; L.cur = stk[L.sp][tid]; }
+                }
+            }
+        }
+        /* ---- regroup when too few lanes still have work --------------------------- */
+        const unsigned long long m_work = __ballot((L.cur != kDone) | (pend != kNoLeaf));
+        if (__popcll(m_work) < min_active) break;
+    }
+}
+
 /* resolve whatever is still queued; afterwards `best` is the exact answer */
 template <bool ANYHIT, bool COUNT>
 __device__ __forceinline__ void finish(Lane &L, const lh_dev_scene_t &sc,
@@ -208,7 +386,7 @@ __device__ __forceinline__ void add_counters(unsigned long long *c, uint32_t nod
 /* ------------------------------------------------------------------------ */
 /* variant 0: one ray per lane                                              */
 /* ------------------------------------------------------------------------ */
-template <int STACK, bool ANYHIT, bool COUNT>
+template <int STACK, bool ANYHIT, bool COUNT, bool QN>
 __global__ __launch_bounds__(LH_BLOCK) void k_trace_direct(
     lh_dev_scene_t sc, size_t n, const double *__restrict__ org, const double *__restrict__ dir,
     uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
@@ -224,7 +402,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_direct(
     uint32_t cn = 0, ct = 0, ce = 0;
     lane_init(L, sc, ox, oy, oz, dx, dy, dz);
     stk[0][tid] = kDone;
-    traverse<STACK, ANYHIT, COUNT, false>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, 0);
+    traverse<STACK, ANYHIT, COUNT, false, QN>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, 0);
     finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
     write_out<ANYHIT>(i, L, best, prim, t, u, v, occ);
     if (COUNT) add_counters(counters, cn, ct, ce, 1);
@@ -233,7 +411,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_direct(
 /* ------------------------------------------------------------------------ */
 /* variant 1: persistent wavefronts, 64-ray chunks from a global cursor     */
 /* ------------------------------------------------------------------------ */
-template <int STACK, bool ANYHIT, bool COUNT>
+template <int STACK, bool ANYHIT, bool COUNT, bool QN>
 __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_wave(
     lh_dev_scene_t sc, size_t n, const double *__restrict__ org, const double *__restrict__ dir,
     uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
@@ -255,7 +433,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_wave(
             Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM};
             lane_init(L, sc, ox, oy, oz, dx, dy, dz);
             stk[0][tid] = kDone;
-            traverse<STACK, ANYHIT, COUNT, false>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, 0);
+            traverse<STACK, ANYHIT, COUNT, false, QN>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, 0);
             finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
             write_out<ANYHIT>(i, L, best, prim, t, u, v, occ);
             if (COUNT) cr++;
@@ -267,17 +445,18 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_wave(
 /* ------------------------------------------------------------------------ */
 /* variant 2: persistent wavefronts with ballot-compacted lane refill       */
 /* ------------------------------------------------------------------------ */
-template <int STACK, bool ANYHIT, bool COUNT>
+template <int STACK, bool ANYHIT, bool COUNT, int WALK, bool QN>
 __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
     lh_dev_scene_t sc, size_t n, const double *__restrict__ org, const double *__restrict__ dir,
     uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
     double *__restrict__ v, uint8_t *__restrict__ occ, unsigned long long *counters,
-    unsigned long long *cursor, int min_active)
+    unsigned long long *cursor, int min_active, int tri_batch)
 {
     __shared__ int stk[STACK][LH_BLOCK];
     const int tid = threadIdx.x;
     uint32_t cn = 0, ct = 0, ce = 0, cr = 0;
     Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM};
+    int pend = 0;                    /* WALK 2: parked leaf reference (0 = none) */
     size_t my = (size_t)-1;          /* ray this lane is working on */
     double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
     L.cur = kDone; L.sp = 1; L.np = 0; L.certain = false;
@@ -285,7 +464,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
 
     for (;;) {
         /* ---- regroup: retire finished lanes, refill them ----------------- */
-        const bool idle = (L.cur == kDone);
+        const bool idle = (L.cur == kDone) && (pend == 0);
         const unsigned long long idle_mask = __ballot(idle);
         if (idle) {
             if (my != (size_t)-1) {
@@ -313,51 +492,74 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
             }
         }
         exhausted = __any(exhausted);
-        const unsigned long long work = __ballot(L.cur != kDone);
+        const unsigned long long work = __ballot((L.cur != kDone) | (pend != 0));
         if (work == 0ull) break;
         /* ---- walk until too few lanes remain active ---------------------- */
         const int thresh = exhausted ? 1 : min_active;
-        if (L.cur != kDone)
-            traverse<STACK, ANYHIT, COUNT, true>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
+        if (WALK == 2) {
+            /* every lane enters (idle lanes just vote in the ballots) */
+            traverse_spec<STACK, ANYHIT, COUNT, QN>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch);
+        } else if (L.cur != kDone) {
+            if (WALK == 1) traverse_unified<STACK, ANYHIT, COUNT>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
+            else traverse<STACK, ANYHIT, COUNT, true, QN>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
+        }
     }
     if (COUNT) add_counters(counters, cn, ct, ce, cr);
 }
 
-template <int STACK, bool ANYHIT, bool COUNT>
+template <int STACK, bool ANYHIT, bool COUNT, bool QN>
 int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const double *dir,
                uint32_t *prim, double *t, double *u, double *v, uint8_t *occ,
                unsigned long long *counters, unsigned long long *cursor, int variant,
-               int grid_blocks, hipStream_t s)
+               int grid_blocks, int min_active, int tri_batch, hipStream_t s)
 {
     if (variant == LH_VARIANT_DIRECT) {
         const size_t blocks = (n + LH_BLOCK - 1) / LH_BLOCK;
         if (blocks > 0x7fffffffull) return -1;
-        hipLaunchKernelGGL((k_trace_direct<STACK, ANYHIT, COUNT>), dim3((unsigned)blocks), dim3(LH_BLOCK), 0, s,
+        hipLaunchKernelGGL((k_trace_direct<STACK, ANYHIT, COUNT, QN>), dim3((unsigned)blocks), dim3(LH_BLOCK), 0, s,
                            sc, n, org, dir, prim, t, u, v, occ, counters);
     } else {
         if (hipMemsetAsync(cursor, 0, sizeof(unsigned long long), s) != hipSuccess) return -1;
         if (variant == LH_VARIANT_PERSIST_WAVE)
-            hipLaunchKernelGGL((k_trace_persist_wave<STACK, ANYHIT, COUNT>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
+            hipLaunchKernelGGL((k_trace_persist_wave<STACK, ANYHIT, COUNT, QN>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor);
+        else if (variant == LH_VARIANT_PERSIST_LANE)
+            hipLaunchKernelGGL((k_trace_persist_lane<STACK, ANYHIT, COUNT, 0, QN>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
+        else if (variant == LH_VARIANT_UNIFIED)
+            hipLaunchKernelGGL((k_trace_persist_lane<STACK, ANYHIT, COUNT, 1, false>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
         else
-            hipLaunchKernelGGL((k_trace_persist_lane<STACK, ANYHIT, COUNT>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
-                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, 40);
+            hipLaunchKernelGGL((k_trace_persist_lane<STACK, ANYHIT, COUNT, 2, QN>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int STACK, bool QN>
+int launch_fmt(const lh_dev_scene_t &sc, size_t n, const double *org, const double *dir,
+               uint32_t *prim, double *t, double *u, double *v, int anyhit, uint8_t *occ,
+               unsigned long long *counters, unsigned long long *cursor, int variant,
+               int grid_blocks, int min_active, int tri_batch, hipStream_t s)
+{
+    if (anyhit) {
+        if (counters) return launch_one<STACK, true, true, QN>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, s);
+        return launch_one<STACK, true, false, QN>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, s);
+    }
+    if (counters) return launch_one<STACK, false, true, QN>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, s);
+    return launch_one<STACK, false, false, QN>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, s);
 }
 
 template <int STACK>
 int launch_stack(const lh_dev_scene_t &sc, size_t n, const double *org, const double *dir,
                  uint32_t *prim, double *t, double *u, double *v, int anyhit, uint8_t *occ,
                  unsigned long long *counters, unsigned long long *cursor, int variant,
-                 int grid_blocks, hipStream_t s)
+                 int grid_blocks, int min_active, int tri_batch, hipStream_t s)
 {
-    if (anyhit) {
-        if (counters) return launch_one<STACK, true, true>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, s);
-        return launch_one<STACK, true, false>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, s);
-    }
-    if (counters) return launch_one<STACK, false, true>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, s);
-    return launch_one<STACK, false, false>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, s);
+    /* the unified walk (variant 3) reads fp32 nodes only */
+    if (sc.use_qnodes && variant != LH_VARIANT_UNIFIED)
+        return launch_fmt<STACK, true>(sc, n, org, dir, prim, t, u, v, anyhit, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, s);
+    return launch_fmt<STACK, false>(sc, n, org, dir, prim, t, u, v, anyhit, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, s);
 }
 
 } /* namespace */
@@ -366,16 +568,16 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
                                const double *d_dir, uint32_t *d_prim, double *d_t, double *d_u,
                                double *d_v, int anyhit, uint8_t *d_occluded,
                                unsigned long long *d_counters, unsigned long long *d_workq,
-                               int variant, int grid_blocks, void *stream)
+                               int variant, int grid_blocks, int min_active, int tri_batch, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) return 0;
     /* stack entries needed <= tree depth + 1 (sentinel) */
     if (sc->max_depth + 1 <= 32)
         return launch_stack<32>(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
-                                d_counters, d_workq, variant, grid_blocks, s);
+                                d_counters, d_workq, variant, grid_blocks, min_active, tri_batch, s);
     if (sc->max_depth + 1 <= 64)
         return launch_stack<64>(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
-                                d_counters, d_workq, variant, grid_blocks, s);
+                                d_counters, d_workq, variant, grid_blocks, min_active, tri_batch, s);
     return -1;
 }

@@ -36,7 +36,7 @@ static void resolve(const lh_bvh_t *b, uint32_t prim, const double *o, const dou
 
 typedef struct {
     const lh_bvh_t *b; size_t begin, end; const double *org, *dir;
-    uint32_t *prim; double *t, *u, *v; uint8_t *occ; int anyhit;
+    uint32_t *prim; double *t, *u, *v; uint8_t *occ; int anyhit; int qnodes;
     uint64_t c[4];
 } job_t;
 
@@ -53,18 +53,27 @@ static void trace_one(job_t *j, size_t i)
         uint32_t pend[PEND];
         for (k = 0; k < 3; k++) { scene_r = fmaxf(scene_r, fabsf(b->bmin[k])); scene_r = fmaxf(scene_r, fabsf(b->bmax[k])); }
         lh_ray_setup(&r, o[0], o[1], o[2], d[0], d[1], d[2], scene_r);
+        if (j->qnodes) lh_ray_setup_grid(&r, b->grid_lo, b->grid_step, scene_r);
         stack[0] = DONE;
         while (cur != DONE) {
             while (cur >= 0) {
-                const lh_node_t *n = &b->nodes[cur]; float tn0, tn1;
-                int h0, h1;
+                float tn0, tn1; int h0, h1; int32_t r0, r1;
                 j->c[0]++;
-                h0 = lh_slab(&r, n->lo0[0], n->lo0[1], n->lo0[2], n->hi0[0], n->hi0[1], n->hi0[2], tb, &tn0);
-                h1 = lh_slab(&r, n->lo1[0], n->lo1[1], n->lo1[2], n->hi1[0], n->hi1[1], n->hi1[2], tb, &tn1);
+                if (j->qnodes) {
+                    const lh_qnode_t *n = &b->qnodes[cur];
+                    h0 = lh_slab_q(&r, n->q[0], n->q[1], n->q[2], n->q[3], n->q[4], n->q[5], tb, &tn0);
+                    h1 = lh_slab_q(&r, n->q[6], n->q[7], n->q[8], n->q[9], n->q[10], n->q[11], tb, &tn1);
+                    r0 = n->ref0; r1 = n->ref1;
+                } else {
+                    const lh_node_t *n = &b->nodes[cur];
+                    h0 = lh_slab(&r, n->lo0[0], n->lo0[1], n->lo0[2], n->hi0[0], n->hi0[1], n->hi0[2], tb, &tn0);
+                    h1 = lh_slab(&r, n->lo1[0], n->lo1[1], n->lo1[2], n->hi1[0], n->hi1[1], n->hi1[2], tb, &tn1);
+                    r0 = n->ref0; r1 = n->ref1;
+                }
                 if (h0 | h1) {
                     int second = h1 && (!h0 || tn1 < tn0);
-                    cur = second ? n->ref1 : n->ref0;
-                    if (h0 & h1) stack[sp++] = second ? n->ref0 : n->ref1;
+                    cur = second ? r1 : r0;
+                    if (h0 & h1) stack[sp++] = second ? r0 : r1;
                 } else cur = stack[--sp];
             }
             if (cur == DONE) break;
@@ -111,7 +120,7 @@ int lhm_trace(const lh_bvh_t *b, size_t n, const double *org, const double *dir,
     for (i = 0; i < nthreads; i++) {
         jobs[i].b = b; jobs[i].begin = n * (size_t)i / (size_t)nthreads; jobs[i].end = n * (size_t)(i + 1) / (size_t)nthreads;
         jobs[i].org = org; jobs[i].dir = dir; jobs[i].prim = prim; jobs[i].t = t; jobs[i].u = u; jobs[i].v = v;
-        jobs[i].occ = occ; jobs[i].anyhit = anyhit;
+        jobs[i].occ = occ; jobs[i].anyhit = anyhit & 1; jobs[i].qnodes = (anyhit >> 1) & 1;
     }
     if (nthreads == 1) run(&jobs[0]);
     else { for (i = 0; i < nthreads; i++) pthread_create(&th[i], NULL, run, &jobs[i]); for (i = 0; i < nthreads; i++) pthread_join(th[i], NULL); }
@@ -133,3 +142,5 @@ void lhm_info(const lh_bvh_t *b, uint32_t out[4]) { out[0] = b->ntris; out[1] = 
 double lhm_build_seconds(const lh_bvh_t *b) { return b->build_seconds; }
 const void *lhm_nodes(const lh_bvh_t *b) { return b->nodes; }
 const void *lhm_tri32(const lh_bvh_t *b) { return b->tri32; }
+const void *lhm_qnodes(const lh_bvh_t *b) { return b->qnodes; }
+void lhm_grid(const lh_bvh_t *b, float out[6]) { int k; for (k = 0; k < 3; k++) { out[k] = b->grid_lo[k]; out[3 + k] = b->grid_step[k]; } }

@@ -82,7 +82,17 @@ class Model:
         buf = (C.c_float * (12 * self.ntris)).from_address(self.lib().lhm_tri32(self.h))
         return np.frombuffer(buf, np.float32).reshape(-1, 12).copy()
 
-    def trace(self, org, dr, anyhit=False, nthreads=4):
+    def qnodes(self):
+        L = self.lib()
+        L.lhm_qnodes.restype = C.c_void_p; L.lhm_qnodes.argtypes = [C.c_void_p]
+        L.lhm_grid.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        grid = np.zeros(6, np.float32); L.lhm_grid(self.h, grid.ctypes.data_as(C.POINTER(C.c_float)))
+        if self.nnodes == 0:
+            return np.zeros((0, 16), np.uint16), grid
+        buf = (C.c_uint16 * (16 * self.nnodes)).from_address(L.lhm_qnodes(self.h))
+        return np.frombuffer(buf, np.uint16).reshape(-1, 16).copy(), grid
+
+    def trace(self, org, dr, anyhit=False, nthreads=4, qnodes=True):
         org = np.ascontiguousarray(org, np.float64).reshape(-1, 3)
         dr = np.ascontiguousarray(dr, np.float64).reshape(-1, 3)
         n = org.shape[0]
@@ -91,11 +101,11 @@ class Model:
         if anyhit:
             occ = np.empty(n, np.uint8)
             self.lib().lhm_trace(self.h, n, org.ctypes.data_as(_dp), dr.ctypes.data_as(_dp), None, None, None, None,
-                                 occ.ctypes.data_as(C.POINTER(C.c_uint8)), 1, cp, nthreads)
+                                 occ.ctypes.data_as(C.POINTER(C.c_uint8)), 1 | (2 if qnodes else 0), cp, nthreads)
             return occ, dict(zip(("nodes", "tris", "exact", "rays"), map(int, cnt)))
         prim = np.empty(n, np.uint32); t = np.empty(n); u = np.empty(n); v = np.empty(n)
         self.lib().lhm_trace(self.h, n, org.ctypes.data_as(_dp), dr.ctypes.data_as(_dp), prim.ctypes.data_as(_u32p),
-                             t.ctypes.data_as(_dp), u.ctypes.data_as(_dp), v.ctypes.data_as(_dp), None, 0, cp, nthreads)
+                             t.ctypes.data_as(_dp), u.ctypes.data_as(_dp), v.ctypes.data_as(_dp), None, 2 if qnodes else 0, cp, nthreads)
         return (prim, t, u, v), dict(zip(("nodes", "tris", "exact", "rays"), map(int, cnt)))
 
 

@@ -1,0 +1,132 @@
+// Microbenchmark: dependent random 64-byte "node" gathers, the access pattern of BVH traversal.
+//   mode 0: one chain per LANE, 4 x dwordx4 per step (current kernel's pattern)
+//   mode 1: one chain per QUAD of lanes, 1 x dwordx4 per lane per step (cooperative fetch)
+//   mode 2: one chain per lane, 2 x dwordx4 (32-byte nodes)
+//   mode 3: one chain per PAIR of lanes, 2 x dwordx4 per lane (64-byte nodes)
+//   mode 4: one chain per lane, 1 x dwordx4 (16-byte nodes)
+// Each step's next index comes from the loaded data (dependent chain, like traversal).
+// Usage: gather <array MB> <steps> <blocks> <mode...>
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cstdint>
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ nodes, uint32_t nnodes, int steps, uint32_t *out)
+{
+    const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+    uint32_t acc = 0;
+    if (MODE == 0) {
+        uint32_t cur = (gid * 2654435761u) % nnodes;
+        for (int s = 0; s < steps; s++) {
+            const uint4 *p = nodes + 4 * (size_t)cur;
+            uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+            acc += a.y + b.y + c.y + d.y;
+            cur = (a.x ^ (acc & 1)) % nnodes;
+        }
+    } else if (MODE == 1) {
+        const uint32_t chain = gid >> 2, sub = gid & 3;
+        uint32_t cur = (chain * 2654435761u) % nnodes;
+        for (int s = 0; s < steps; s++) {
+            uint4 a = nodes[4 * (size_t)cur + sub];
+            acc += a.y;
+            uint32_t nx = __shfl(a.x, (threadIdx.x & 63) & ~3);       // lane 0 of the quad holds the link
+            cur = (nx ^ (acc & 1 & 0)) % nnodes;
+        }
+    } else if (MODE == 2) {
+        uint32_t cur = (gid * 2654435761u) % (nnodes * 2);
+        for (int s = 0; s < steps; s++) {
+            const uint4 *p = nodes + 2 * (size_t)cur;
+            uint4 a = p[0], b = p[1];
+            acc += a.y + b.y;
+            cur = (a.x ^ (acc & 1)) % (nnodes * 2);
+        }
+    } else if (MODE == 3) {
+        const uint32_t chain = gid >> 1, sub = gid & 1;
+        uint32_t cur = (chain * 2654435761u) % nnodes;
+        for (int s = 0; s < steps; s++) {
+            const uint4 *p = nodes + 4 * (size_t)cur + 2 * sub;
+            uint4 a = p[0], b = p[1];
+            acc += a.y + b.y;
+            uint32_t nx = __shfl(a.x, (threadIdx.x & 63) & ~1);
+            cur = nx % nnodes;
+        }
+    } else if (MODE == 5) {          /* 128-byte nodes, one chain per lane, 8 x dwordx4 */
+        uint32_t cur = (gid * 2654435761u) % (nnodes / 2);
+        for (int s = 0; s < steps; s++) {
+            const uint4 *p = nodes + 8 * (size_t)cur;
+            uint4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], g = p[6], h = p[7];
+            acc += a.y + b.y + c.y + d.y + e.y + f.y + g.y + h.y;
+            cur = (a.x ^ (acc & 1)) % (nnodes / 2);
+        }
+    } else if (MODE == 6) {          /* 128-byte nodes, one chain per QUAD, 2 x dwordx4 per lane */
+        const uint32_t chain = gid >> 2, sub = gid & 3;
+        uint32_t cur = (chain * 2654435761u) % (nnodes / 2);
+        for (int s = 0; s < steps; s++) {
+            const uint4 *p = nodes + 8 * (size_t)cur + 2 * sub;
+            uint4 a = p[0], b = p[1];
+            acc += a.y + b.y;
+            uint32_t nx = __shfl(a.x, (threadIdx.x & 63) & ~3);
+            cur = nx % (nnodes / 2);
+        }
+    } else if (MODE == 7) {          /* 256-byte nodes (2 lines), one chain per lane, first 5 x dwordx4 (80 B used) */
+        uint32_t cur = (gid * 2654435761u) % (nnodes / 4);
+        for (int s = 0; s < steps; s++) {
+            const uint4 *p = nodes + 16 * (size_t)cur;
+            uint4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+            acc += a.y + b.y + c.y + d.y + e.y;
+            cur = (a.x ^ (acc & 1)) % (nnodes / 4);
+        }
+    } else {
+        uint32_t cur = (gid * 2654435761u) % (nnodes * 4);
+        for (int s = 0; s < steps; s++) {
+            uint4 a = nodes[cur];
+            acc += a.y;
+            cur = (a.x ^ (acc & 1)) % (nnodes * 4);
+        }
+    }
+    out[gid] = acc;
+}
+
+int main(int argc, char **argv)
+{
+    const size_t mb = argc > 1 ? atol(argv[1]) : 64;
+    const int steps = argc > 2 ? atoi(argv[2]) : 200;
+    const int blocks = argc > 3 ? atoi(argv[3]) : 1024;
+    const uint32_t nnodes = (uint32_t)(mb * 1024 * 1024 / 64);
+    std::vector<uint32_t> h((size_t)nnodes * 16);
+    uint64_t x = 88172645463325252ULL;
+    for (size_t i = 0; i < h.size(); i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; h[i] = (uint32_t)(x >> 20); }
+    uint4 *d; uint32_t *out;
+    CHK(hipMalloc(&d, h.size() * 4)); CHK(hipMalloc(&out, (size_t)blocks * 256 * 4));
+    CHK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    for (int a = 4; a < argc; a++) {
+        const int mode = atoi(argv[a]);
+        float best = 1e30f;
+        for (int rep = 0; rep < 4; rep++) {
+            CHK(hipEventRecord(e0));
+            switch (mode) {
+            case 0: hipLaunchKernelGGL(k_gather<0>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
+            case 1: hipLaunchKernelGGL(k_gather<1>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
+            case 2: hipLaunchKernelGGL(k_gather<2>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
+            case 3: hipLaunchKernelGGL(k_gather<3>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
+            case 5: hipLaunchKernelGGL(k_gather<5>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
+            case 6: hipLaunchKernelGGL(k_gather<6>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
+            case 7: hipLaunchKernelGGL(k_gather<7>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
+            default: hipLaunchKernelGGL(k_gather<4>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
+            }
+            CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+            float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if (rep > 0 && ms < best) best = ms;
+        }
+        const double chains = (double)blocks * 256 / ((mode == 1 || mode == 6) ? 4 : (mode == 3 ? 2 : 1));
+        const double bytes_per_step = (mode == 2) ? 32 : (mode == 4 ? 16 : ((mode == 5 || mode == 6) ? 128 : (mode == 7 ? 80 : 64)));
+        const double gsteps = chains * steps / (best * 1e-3) / 1e9;
+        printf("array %4zu MB blocks %5d mode %d: %.3f ms  %.2f G chain-steps/s  %.2f TB/s useful\n", mb, blocks, mode, best, gsteps,
+               gsteps * bytes_per_step / 1e3);
+    }
+    return 0;
+}
