@@ -92,6 +92,27 @@ def _params(args):
 
 def render_rib(path, width, height, gather_nsamples, pixel_samples=1, accel_method=1, nthreads=1,
                lib="liblucille_ref.so", record=True):
+    return render_verbs(parse(path), width, height, gather_nsamples, pixel_samples, accel_method, nthreads, lib, record)
+
+
+def scene_verbs(geoms, world_to_camera, fov=45.0, rh=True):
+    """RIB verbs for a scene given as triangle meshes (positions [n,3], indices) + camera:
+    how tests feed the reference's renderer without a RIB file (no /root/reference needed)"""
+    v = [("Display", ["out.hdr", "file", "rgb"]), ("Projection", ["perspective", "fov", [fov]])]
+    if rh:
+        v.append(("Orientation", ["rh"]))
+    v.append(("ConcatTransform", [[float(x) for x in np.asarray(world_to_camera).reshape(16)]]))
+    v.append(("WorldBegin", []))
+    for P, I in geoms:
+        I = np.asarray(I).reshape(-1)
+        v.append(("PointsPolygons", [[3] * (len(I) // 3), [int(i) for i in I], "P",
+                                     [float(x) for x in np.asarray(P, np.float64).reshape(-1)]]))
+    v.append(("WorldEnd", []))
+    return v
+
+
+def render_verbs(verbs, width, height, gather_nsamples, pixel_samples=1, accel_method=1, nthreads=1,
+                 lib="liblucille_ref.so", record=True):
     L = C.CDLL(os.path.join(HERE, "_ref", lib))
     L.lref_init(); L.lref_capture_display()
     L.RiFormat.argtypes = [C.c_int, C.c_int, C.c_float]
@@ -103,7 +124,7 @@ def render_rib(path, width, height, gather_nsamples, pixel_samples=1, accel_meth
     cwd = os.getcwd(); tmp = tempfile.mkdtemp(); os.chdir(tmp)
     try:
         L.RiBegin(None)
-        for verb, a in parse(path):
+        for verb, a in verbs:
             if verb == "Display":
                 n, T, V, keep = _params(a[3:])
                 L.RiDisplayV(a[0].encode(), b"file", a[2].encode(), n, T, V)
@@ -173,6 +194,18 @@ def render_rib(path, width, height, gather_nsamples, pixel_samples=1, accel_meth
         geoms.append({"positions": P, "indices": I, "normals": N, "two_side": int(ts.value)})
     out["geoms"] = geoms
     return out
+
+
+def render_scene_subprocess(scene_npz, outfile, **kw):
+    """like render_rib_subprocess for a scene stored as .npz {ngeoms, pos%d, idx%d, w2c, fov}"""
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np; from oracle import ref_rib as r; "
+            "g = np.load(%r); "
+            "verbs = r.scene_verbs([(g['pos%%d' %% i], g['idx%%d' %% i]) for i in range(int(g['ngeoms']))], g['w2c'], float(g['fov'])); "
+            "o = r.render_verbs(verbs, **%r); "
+            "np.savez(%r, image=o['image'], camera=o['camera'], records=o['records'])") % (
+                os.path.dirname(HERE), scene_npz, kw, outfile)
+    subprocess.check_call([sys.executable, "-c", code], stdout=subprocess.DEVNULL)
+    return np.load(outfile)
 
 
 def render_rib_subprocess(path, outfile, **kw):
