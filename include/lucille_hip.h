@@ -155,6 +155,23 @@ int  lh_render_ao_tile(lh_accel_t *accel, const lh_camera_t *cam, int x0, int y0
  *        10 AO occluded */
 int  lh_render_scratch(lh_accel_t *accel, int which, void **d_ptr, size_t *count);
 
+/* ---- beam (frustum) visibility: ri_beam_set + ri_bvh_intersect_beam_visibility ----
+ * reference: src/render/beam.c:331-465, src/render/bvh.c:612-667 (+ :1997-2281, :2435-2542,
+ * :2648-2746), constants src/render/beam.h:27-29.  A beam is a common origin and 4 corner
+ * directions (n x 4 x 3 doubles).  result[i]: LH_BEAM_MISS_COMPLETELY / _HIT_COMPLETELY /
+ * _HIT_PARTIALLY exactly as the reference returns them (the answer depends on ITS tree, so the
+ * query runs on the reference-order tree kept beside the traversal tree), or LH_BEAM_INVALID
+ * where ri_beam_set returns -1 (corner directions straddle an octant, beam.c:352-376). */
+#define LH_BEAM_MISS_COMPLETELY 0
+#define LH_BEAM_HIT_COMPLETELY  1
+#define LH_BEAM_HIT_PARTIALLY   2
+#define LH_BEAM_INVALID        (-1)
+
+int  lh_accel_beam_visibility_host(lh_accel_t *accel, size_t n, const double *org_xyz,
+                                   const double *corner_dirs_xyz, int32_t *result);
+int  lh_accel_beam_visibility_device(lh_accel_t *accel, size_t n, const void *d_org_xyz,
+                                     const void *d_corner_dirs_xyz, void *d_result, void *stream);
+
 /* copy of the flattened BVH for cross-checks (tests): sizes via lh_accel_info.
  * nodes: nnodes*64 bytes, tri32: ntriangles*48 bytes; either may be NULL. */
 int  lh_accel_export(const lh_accel_t *accel, void *nodes, void *tri32);

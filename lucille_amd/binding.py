@@ -69,7 +69,7 @@ ABI_SYMBOLS = [
     "lh_accel_destroy", "lh_accel_info", "lh_accel_prim_lookup", "lh_accel_intersect1",
     "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted",
     "lh_accel_set_grid", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
-    "lh_render_ao_tile", "lh_render_scratch",
+    "lh_render_ao_tile", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device",
 ]
 
 _lib = None
@@ -108,6 +108,8 @@ def lib():
     L.lh_render_ao_tile.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, C.c_uint64, vp, vp,
                                     C.POINTER(TileStats), vp]
     L.lh_render_scratch.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz)]
+    L.lh_accel_beam_visibility_host.argtypes = [vp, sz, vp, vp, vp]
+    L.lh_accel_beam_visibility_device.argtypes = [vp, sz, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -258,6 +260,15 @@ class HipAccel:
                                                 _dptr(v), _dptr(occ), mode, variant, C.c_void_p(stream)),
                "lh_accel_intersect_device")
         return out
+
+    def beam_visibility(self, org, corner_dirs):
+        """ri_beam_set + ri_bvh_intersect_beam_visibility for n beams: org [n,3], corner_dirs [n,4,3]
+        -> int32 [n] in {0 miss, 1 hit completely, 2 hit partially, -1 invalid beam}"""
+        o = _np(org, np.float64).reshape(-1, 3); d = _np(corner_dirs, np.float64).reshape(-1, 4, 3)
+        res = np.empty(o.shape[0], np.int32)
+        _check(self.L.lh_accel_beam_visibility_host(self.h, o.shape[0], o.ctypes.data, d.ctypes.data, res.ctypes.data),
+               "lh_accel_beam_visibility_host")
+        return res
 
     # ---- tile rendering (device-resident pipeline) ---------------------------
     def primary_rays(self, cam, x0, y0, w, h, pixel_samples=1, stream=None):

@@ -16,6 +16,7 @@
 
 #include "../../include/lucille_hip.h"
 #include "lh_bvh.h"
+#include "lh_refbvh.h"
 #include "lh_device.h"
 
 static thread_local char g_err[512] = "";
@@ -56,6 +57,9 @@ struct lh_accel {
     lh_mesh_copy *meshes; uint32_t nmeshes;
     /* host BVH */
     lh_bvh_t bvh;
+    lh_refbvh_t ref;          /* reference-order tree (ties, beams) */
+    int have_ref;
+    void *d_ref_lca, *d_prim_leafpos, *d_ref_nodes, *d_ref_leaf_prims;
     /* device */
     lh_dev_scene_t dev;
     void *d_nodes, *d_tri32, *d_tri64, *d_qnodes;
@@ -170,6 +174,11 @@ static void release_device(lh_accel_t *a)
     if (a->d_tri64) (void)hipFree(a->d_tri64);
     if (a->d_qnodes) (void)hipFree(a->d_qnodes);
     a->d_qnodes = NULL;
+    if (a->d_ref_lca) (void)hipFree(a->d_ref_lca);
+    if (a->d_prim_leafpos) (void)hipFree(a->d_prim_leafpos);
+    if (a->d_ref_nodes) (void)hipFree(a->d_ref_nodes);
+    if (a->d_ref_leaf_prims) (void)hipFree(a->d_ref_leaf_prims);
+    a->d_ref_lca = a->d_prim_leafpos = a->d_ref_nodes = a->d_ref_leaf_prims = NULL;
     if (a->d_cursor) (void)hipFree(a->d_cursor);
     if (a->d_counters) (void)hipFree(a->d_counters);
     if (a->d_stage) (void)hipFree(a->d_stage);
@@ -195,6 +204,14 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
     int rc = lh_bvh_build(&a->bvh, views, a->nmeshes, build_threads);
     free(views);
     if (rc != 0) return fail("lh_accel_commit: BVH build failed (bad input or out of memory)");
+    /* the reference-order tree: exact-t tie winners + beam visibility (LH_REFTREE=0 skips it:
+     * ties then fall back to "larger primitive id wins" and beam queries are refused) */
+    {
+        const char *e = getenv("LH_REFTREE");
+        a->have_ref = !(e && atoi(e) == 0);
+        if (a->have_ref && lh_refbvh_build(&a->ref, a->bvh.tri64, a->bvh.ntris, build_threads) != 0)
+            return fail("lh_accel_commit: reference-order tree build failed (out of memory)");
+    }
     /* per-primitive normals in primitive-id order, if any mesh carries normals */
     {
         bool any = false;
@@ -250,6 +267,34 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
         a->dev.max_depth = a->bvh.max_depth; a->dev.scene_r = r;
         a->dev.qnodes = a->d_qnodes;
         for (int k = 0; k < 3; k++) { a->dev.grid_lo[k] = a->bvh.grid_lo[k]; a->dev.grid_step[k] = a->bvh.grid_step[k]; }
+        if (a->have_ref) {
+            const uint32_t rn = a->ref.nnodes;
+            int *lca = (int *)malloc(sizeof(int) * 4 * (size_t)rn);
+            uint32_t *lp = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (size_t)a->bvh.ntris);
+            if (!lca || !lp) { free(lca); free(lp); return fail("out of memory"); }
+            for (uint32_t i = 0; i < rn; i++) {
+                lca[4 * i] = a->ref.nodes[i].parent; lca[4 * i + 1] = a->ref.nodes[i].depth;
+                lca[4 * i + 2] = a->ref.nodes[i].axis; lca[4 * i + 3] = a->ref.nodes[i].child[0];
+            }
+            for (uint32_t p = 0; p < a->bvh.ntris; p++) { lp[2 * p] = a->ref.prim_leaf[p]; lp[2 * p + 1] = a->ref.prim_pos[p]; }
+            hipError_t e1 = hipMalloc(&a->d_ref_lca, sizeof(int) * 4 * (size_t)rn);
+            hipError_t e2 = hipMalloc(&a->d_prim_leafpos, sizeof(uint32_t) * 2 * (size_t)a->bvh.ntris);
+            hipError_t e3 = hipMalloc(&a->d_ref_nodes, sizeof(lh_refnode_t) * (size_t)rn);
+            hipError_t e4 = hipMalloc(&a->d_ref_leaf_prims, sizeof(uint32_t) * (size_t)a->bvh.ntris);
+            if (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess) {
+                e1 = hipMemcpy(a->d_ref_lca, lca, sizeof(int) * 4 * (size_t)rn, hipMemcpyHostToDevice);
+                e2 = hipMemcpy(a->d_prim_leafpos, lp, sizeof(uint32_t) * 2 * (size_t)a->bvh.ntris, hipMemcpyHostToDevice);
+                e3 = hipMemcpy(a->d_ref_nodes, a->ref.nodes, sizeof(lh_refnode_t) * (size_t)rn, hipMemcpyHostToDevice);
+                e4 = hipMemcpy(a->d_ref_leaf_prims, a->ref.leaf_prims, sizeof(uint32_t) * (size_t)a->bvh.ntris, hipMemcpyHostToDevice);
+            }
+            free(lca); free(lp);
+            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) return fail("reference-order tree upload failed");
+            a->dev.ref_lca = a->d_ref_lca; a->dev.prim_leafpos = a->d_prim_leafpos;
+            a->dev.ref_nodes = a->d_ref_nodes; a->dev.ref_leaf_prims = a->d_ref_leaf_prims;
+            a->dev.ref_nnodes = rn; a->dev.ref_empty = a->ref.empty;
+            for (int k = 0; k < 3; k++) { a->dev.ref_bmin[k] = a->ref.bmin[k]; a->dev.ref_bmax[k] = a->ref.bmax[k]; }
+            a->device_bytes += sizeof(int) * 4 * (size_t)rn + sizeof(uint32_t) * 3 * (size_t)a->bvh.ntris + sizeof(lh_refnode_t) * (size_t)rn;
+        }
         a->dev.use_qnodes = 1;
         { const char *fmt = getenv("LH_NODE_FORMAT"); if (fmt && strcmp(fmt, "f32") == 0) a->dev.use_qnodes = 0; }
         if (a->bvh.max_depth + 1 > 64) return fail("lh_accel_commit: tree depth %u exceeds the kernel stack", a->bvh.max_depth);
@@ -274,6 +319,7 @@ extern "C" void lh_accel_destroy(lh_accel_t *a)
     for (uint32_t g = 0; g < a->nmeshes; g++) { free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm); }
     free(a->meshes); free(a->h_nrm9);
     lh_bvh_release(&a->bvh);
+    lh_refbvh_release(&a->ref);
     free(a);
 }
 
@@ -531,5 +577,49 @@ extern "C" int lh_render_scratch(lh_accel_t *a, int which, void **d_ptr, size_t 
     if (which < 0 || which > 10) return fail("lh_render_scratch: unknown buffer %d", which);
     *d_ptr = b[which]->p;
     *count = which <= 6 ? a->r_nsamples : (which == 7 ? a->r_nslots : a->r_nao);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* beam visibility                                                          */
+/* ------------------------------------------------------------------------ */
+extern "C" int lh_launch_beam_visibility(const lh_dev_scene_t *sc, size_t n, const double *d_org, const double *d_dirs,
+                                         int32_t *d_result, void *stream);
+
+__global__ void k_fill_i32(size_t n, int32_t *p, int32_t v)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+extern "C" int lh_accel_beam_visibility_device(lh_accel_t *a, size_t n, const void *d_org, const void *d_dirs,
+                                               void *d_result, void *stream)
+{
+    if (!a || !a->committed) return fail("beam_visibility: accel not committed");
+    if (n == 0) return 0;
+    if (!d_org || !d_dirs || !d_result) return fail("beam_visibility: NULL argument");
+    if (!a->have_ref) return fail("beam_visibility: the reference-order tree was disabled (LH_REFTREE=0)");
+    HIPCHK(hipSetDevice(a->device));
+    lh_dev_scene_t sc = a->dev;
+    if (a->bvh.ntris == 0) { sc.ref_empty = 1; }
+    if (lh_launch_beam_visibility(&sc, n, (const double *)d_org, (const double *)d_dirs, (int32_t *)d_result, stream) != 0)
+        return fail("beam kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+extern "C" int lh_accel_beam_visibility_host(lh_accel_t *a, size_t n, const double *org, const double *dirs, int32_t *result)
+{
+    if (!a || !a->committed) return fail("beam_visibility: accel not committed");
+    if (n == 0) return 0;
+    if (!org || !dirs || !result) return fail("beam_visibility: NULL argument");
+    HIPCHK(hipSetDevice(a->device));
+    const size_t bo = sizeof(double) * 3 * n, bd = sizeof(double) * 12 * n, br = sizeof(int32_t) * n;
+    if (ensure_stage(a, bo + bd + br + 64) != 0) return -1;
+    char *base = (char *)a->d_stage;
+    HIPCHK(hipMemcpyAsync(base, org, bo, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(base + bo, dirs, bd, hipMemcpyHostToDevice, a->stream));
+    if (lh_accel_beam_visibility_device(a, n, base, base + bo, base + bo + bd, a->stream) != 0) return -1;
+    HIPCHK(hipMemcpyAsync(result, base + bo + bd, br, hipMemcpyDeviceToHost, a->stream));
+    HIPCHK(hipStreamSynchronize(a->stream));
     return 0;
 }

@@ -1,0 +1,187 @@
+/*
+ * lh_beam.hip -- beam (frustum) visibility on the GPU: SURVEY.md 8a row a14.
+ *
+ * Reference (CPU, fp64):
+ *   ri_beam_set                              src/render/beam.c:331-465
+ *   ri_bvh_intersect_beam_visibility         src/render/bvh.c:612-667
+ *   test_beam_aabb / get_n_point             src/render/bvh.c:1997-2089
+ *   test_beam_node                           src/render/bvh.c:2097-2126
+ *   test_beam_triangle                       src/render/bvh.c:2139-2281
+ *   leaf / traversal                         src/render/bvh.c:2435-2542, 2648-2746
+ *
+ * The answer (0 miss / 1 hit completely / 2 hit partially) is the class of the FIRST
+ * non-missing triangle in the reference's own traversal order and depends on which leaves
+ * its plane tests let through, so this kernel walks the reference-order tree (lh_refbvh.c)
+ * with the reference's fp64 arithmetic, operation order and comparisons (no FMA
+ * contraction): one beam per lane, private stack, 128-byte fp64 nodes.  It is a
+ * low-volume query (the reference's only caller issues (W/64)^2 root beams), bounded by
+ * dependent 128-byte gathers like the ray kernel; there is nothing for MFMA here.
+ */
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "lh_device.h"
+#include "lh_refbvh.h"
+
+namespace {
+
+#define LH_NC _Pragma("clang fp contract(off)")
+constexpr double kEps = 1.0e-14;    /* RI_EPS */
+constexpr double kTInf = 1.0e38;    /* RI_INFINITY */
+
+struct Beam {
+    double org[3], dir[4][3], normal[4][3];
+    int dominant_axis, dirsign[3];
+};
+
+__device__ __forceinline__ void cross3(double d[3], const double a[3], const double b[3])
+{
+    LH_NC
+    d[0] = a[1] * b[2] - a[2] * b[1]; d[1] = a[2] * b[0] - a[0] * b[2]; d[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ double dot3(const double a[3], const double b[3])
+{
+    LH_NC
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+/* ri_beam_set (beam.c:331-465), including the maxval re-assignment at :387-390 */
+__device__ int beam_set(Beam &b, const double *org, const double *dir /* 4x3 */)
+{
+    LH_NC
+    for (int i = 0; i < 3; i++) {
+        int zeros = 0, mask = 0;
+        for (int j = 0; j < 4; j++) {
+            if (fabs(dir[3 * j + i]) < kEps) zeros++;
+            else mask += (dir[3 * j + i] < 0.0) ? 1 : -1;
+        }
+        if ((mask != -(4 - zeros)) && (mask != (4 - zeros))) return -1;
+    }
+    for (int i = 0; i < 3; i++) b.org[i] = org[i];
+    double maxval = fabs(dir[0]); int dom = 0;
+    if (maxval < fabs(dir[1])) { maxval = fabs(dir[0]); dom = 1; }
+    if (maxval < fabs(dir[2])) { maxval = fabs(dir[2]); dom = 2; }
+    b.dominant_axis = dom;
+    for (int i = 0; i < 3; i++) b.dirsign[i] = (dir[i] < 0.0) ? 1 : 0;
+    double normal[3] = {0.0, 0.0, 0.0};
+    normal[dom] = 1.0;
+    if (b.dirsign[dom]) { normal[0] = -normal[0]; normal[1] = -normal[1]; normal[2] = -normal[2]; }
+    for (int i = 0; i < 4; i++) {
+        const double d3[3] = {dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]};
+        const double t = dot3(d3, normal);
+        const double k = (fabs(t) > kEps) ? 1024.0 / t : 1.0;
+        b.dir[i][0] = k * d3[0]; b.dir[i][1] = k * d3[1]; b.dir[i][2] = k * d3[2];
+    }
+    cross3(b.normal[0], b.dir[1], b.dir[0]);
+    cross3(b.normal[1], b.dir[2], b.dir[1]);
+    cross3(b.normal[2], b.dir[3], b.dir[2]);
+    cross3(b.normal[3], b.dir[0], b.dir[3]);
+    return 0;
+}
+
+/* test_beam_aabb (bvh.c:2053-2089): 1 = the box may be hit */
+__device__ __forceinline__ int beam_aabb(const double *box, const Beam &b)
+{
+    LH_NC
+    for (int i = 0; i < 4; i++) {
+        double no[3];
+        for (int k = 0; k < 3; k++) {
+            const double np = (b.normal[i][k] > 0.0) ? box[k] : box[3 + k];
+            no[k] = np - b.org[k];
+        }
+        if (dot3(no, b.normal[i]) > 0.0) return 0;
+    }
+    return 1;
+}
+
+/* test_beam_triangle (bvh.c:2139-2281) */
+__device__ int beam_triangle(const double *tv, const Beam &b)
+{
+    LH_NC
+    double u[4], v[4], t[4], e1[3], e2[3];
+    int mask = 0;
+    for (int i = 0; i < 3; i++) { e1[i] = tv[3 + i] - tv[i]; e2[i] = tv[6 + i] - tv[i]; }
+    for (int i = 0; i < 4; i++) {
+        double p[3], q[3], s[3];
+        cross3(p, b.dir[i], e2);
+        const double a = dot3(e1, p);
+        const double inva = (fabs(a) > kEps) ? 1.0 / a : 0.0;
+        s[0] = b.org[0] - tv[0]; s[1] = b.org[1] - tv[1]; s[2] = b.org[2] - tv[2];
+        cross3(q, s, e1);
+        u[i] = dot3(s, p) * inva; v[i] = dot3(q, b.dir[i]) * inva; t[i] = dot3(e2, q) * inva;
+        if ((u[i] < 0.0) || (u[i] > 1.0)) continue;
+        if ((v[i] < 0.0) || ((u[i] + v[i]) > 1.0)) continue;
+        if ((t[i] < 0.0) || (t[i] > kTInf)) continue;
+        mask |= (1 << i);
+    }
+    if (mask == 0) {
+        int cnt = 0;
+        for (int i = 0; i < 4; i++) if (t[i] < 0.0) cnt++;
+        if (cnt == 4) return 0;
+        cnt = 0; for (int i = 0; i < 4; i++) if (u[i] < 0.0) cnt++;
+        if ((cnt != 0) && (cnt != 4)) return 2;
+        cnt = 0; for (int i = 0; i < 4; i++) if (u[i] > 1.0) cnt++;
+        if ((cnt != 0) && (cnt != 4)) return 2;
+        cnt = 0; for (int i = 0; i < 4; i++) if (v[i] < 0.0) cnt++;
+        if ((cnt != 0) && (cnt != 4)) return 2;
+        cnt = 0; for (int i = 0; i < 4; i++) if ((u[i] + v[i]) >= 1.0) cnt++;
+        if ((cnt != 0) && (cnt != 4)) return 2;
+        return 0;
+    }
+    return (mask == 0xf) ? 1 : 2;
+}
+
+__global__ __launch_bounds__(128) void k_beam_visibility(lh_dev_scene_t sc, size_t n, const double *__restrict__ org,
+                                                         const double *__restrict__ dirs, int32_t *__restrict__ result)
+{
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    Beam b;
+    if (beam_set(b, org + 3 * r, dirs + 12 * r) != 0) { result[r] = -1; return; }
+    if (sc.ref_empty) { result[r] = 0; return; }
+    {
+        const double sb[6] = {sc.ref_bmin[0], sc.ref_bmin[1], sc.ref_bmin[2], sc.ref_bmax[0], sc.ref_bmax[1], sc.ref_bmax[2]};
+        if (!beam_aabb(sb, b)) { result[r] = 0; return; }
+    }
+    const lh_refnode_t *nodes = (const lh_refnode_t *)sc.ref_nodes;
+    const uint32_t *leaf_prims = (const uint32_t *)sc.ref_leaf_prims;
+    const double *tri64 = (const double *)sc.tri64;
+    int stack[104];           /* BVH_MAXDEPTH + 1 (bvh.c:80,124-129) */
+    int depth = 0, node = 0, ret = 0;
+    for (;;) {
+        const lh_refnode_t *nd = &nodes[node];
+        if (nd->is_leaf) {
+            int cls = 0;
+            for (uint32_t q = 0; q < nd->count; q++) {
+                cls = beam_triangle(tri64 + 9 * (size_t)leaf_prims[nd->first + q], b);
+                if (cls != 0) break;
+            }
+            if (cls != 0) { ret = cls; break; }
+            if (depth < 1) { ret = 0; break; }
+            node = stack[--depth];
+        } else {
+            const int hit = beam_aabb(nd->box[0], b) | (beam_aabb(nd->box[1], b) << 1);
+            if (hit == 0) { if (depth < 1) { ret = 0; break; } node = stack[--depth]; }
+            else if (hit == 1) node = nd->child[0];
+            else if (hit == 2) node = nd->child[1];
+            else {
+                const int order = b.dirsign[b.dominant_axis];
+                if (depth < 103) stack[depth++] = nd->child[1 - order];
+                node = nd->child[order];
+            }
+        }
+    }
+    result[r] = ret;
+}
+
+} /* namespace */
+
+extern "C" int lh_launch_beam_visibility(const lh_dev_scene_t *sc, size_t n, const double *d_org, const double *d_dirs,
+                                         int32_t *d_result, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_beam_visibility, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
+                       *sc, n, d_org, d_dirs, d_result);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -20,6 +20,14 @@ typedef struct lh_dev_scene {
     const void *qnodes;    /* lh_qnode_t[nnodes] (32 B each, 16-bit grid)     */
     float       grid_lo[3], grid_step[3];
     int         use_qnodes;
+    /* reference-order tree (lh_refbvh.c), for exact-t tie winners and beam queries; may be NULL */
+    const void *ref_lca;      /* int4[ref_nnodes]: parent, depth, axis0, child[0]            */
+    const void *prim_leafpos; /* uint2[ntris]: leaf node of the primitive, position in leaf  */
+    const void *ref_nodes;    /* lh_refnode_t[ref_nnodes] (128 B each)                       */
+    const void *ref_leaf_prims; /* uint32[ntris]: primitive ids in the reference's leaf order */
+    uint32_t    ref_nnodes;
+    int         ref_empty;
+    double      ref_bmin[3], ref_bmax[3];
     uint32_t    ntris;
     uint32_t    nnodes;
     uint32_t    max_depth;

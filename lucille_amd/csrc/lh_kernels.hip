@@ -52,18 +52,39 @@ struct Best {            /* exact (fp64) closest hit so far */
     uint32_t prim;
 };
 
-/* resolve one queued candidate against the running exact best.
- * Tie rule (exact-equal t): larger primitive id wins -- the rule of a
- * brute-force sweep with the reference's `t > t_best` reject (bvh.c:780). */
-__device__ __forceinline__ void resolve(const double *__restrict__ tri64, uint32_t prim,
+/* The reference's winner between two primitives hit at bit-equal t (lh_refbvh.c):
+ * same leaf -> the later triangle (bvh.c:780 rejects only t > t_best); different leaves ->
+ * the leaf the reference visits first (bvh.c:850 strict <), i.e. the one under
+ * child[dir_sign[axis0]] of their lowest common ancestor (bvh.c:1080,1171-1178). */
+__device__ __noinline__ bool tie_takes_new(const lh_dev_scene_t &sc, uint32_t pnew, uint32_t pold,
+                                           double dx, double dy, double dz)
+{
+    if (!sc.ref_lca) return pnew > pold;          /* no reference-order tree: documented fallback */
+    const uint2 *lp = (const uint2 *)sc.prim_leafpos;
+    const int4 *nd = (const int4 *)sc.ref_lca;
+    const uint2 a = lp[pnew], b = lp[pold];
+    if (a.x == b.x) return a.y > b.y;
+    int ca = (int)a.x, cb = (int)b.x;
+    int4 na = nd[ca], nb = nd[cb];
+    while (na.y > nb.y) { ca = na.x; na = nd[ca]; }
+    while (nb.y > na.y) { cb = nb.x; nb = nd[cb]; }
+    while (na.x != nb.x) { ca = na.x; na = nd[ca]; cb = nb.x; nb = nd[cb]; }
+    const int4 l = nd[na.x];
+    const int order = (l.z == 0 ? dx : (l.z == 1 ? dy : dz)) < 0.0 ? 1 : 0;
+    const int first_child = order == 0 ? l.w : l.w + 1;     /* children are allocated adjacently */
+    return first_child == ca;
+}
+
+/* resolve one queued candidate against the running exact best */
+__device__ __forceinline__ void resolve(const lh_dev_scene_t &sc, uint32_t prim,
                                         double ox, double oy, double oz,
                                         double dx, double dy, double dz, Best &b)
 {
     double t, u, v;
-    if (lh_exact_isect(tri64 + 9 * (size_t)prim, ox, oy, oz, dx, dy, dz, &t, &u, &v)) {
-        if ((t < b.t) || (t == b.t && b.prim != LH_MISS_PRIM && prim > b.prim)) {
-            if (t < LH_T_INF) { b.t = t; b.u = u; b.v = v; b.prim = prim; }
-        }
+    if (lh_exact_isect((const double *)sc.tri64 + 9 * (size_t)prim, ox, oy, oz, dx, dy, dz, &t, &u, &v)) {
+        bool take = t < b.t;
+        if (!take && t == b.t && b.prim != LH_MISS_PRIM && prim != b.prim) take = tie_takes_new(sc, prim, b.prim, dx, dy, dz);
+        if (take && t < LH_T_INF) { b.t = t; b.u = u; b.v = v; b.prim = prim; }
     }
 }
 
@@ -124,7 +145,6 @@ __device__ __forceinline__ void traverse(Lane &L, const lh_dev_scene_t &sc,
                                          const int min_active)
 {
     const float4 *__restrict__ tris  = (const float4 *)sc.tri32;
-    const double *__restrict__ tri64 = (const double *)sc.tri64;
 
     while (L.cur != kDone) {
         /* ---- inner nodes ------------------------------------------------ */
@@ -162,10 +182,10 @@ __device__ __forceinline__ void traverse(Lane &L, const lh_dev_scene_t &sc,
                     if (L.np == kPend) {
                         /* pending list full: resolve it now (rare) */
                         if (COUNT) c_exact += kPend;
-                        resolve(tri64, L.p0, ox, oy, oz, dx, dy, dz, best);
-                        resolve(tri64, L.p1, ox, oy, oz, dx, dy, dz, best);
-                        resolve(tri64, L.p2, ox, oy, oz, dx, dy, dz, best);
-                        resolve(tri64, L.p3, ox, oy, oz, dx, dy, dz, best);
+                        resolve(sc, L.p0, ox, oy, oz, dx, dy, dz, best);
+                        resolve(sc, L.p1, ox, oy, oz, dx, dy, dz, best);
+                        resolve(sc, L.p2, ox, oy, oz, dx, dy, dz, best);
+                        resolve(sc, L.p3, ox, oy, oz, dx, dy, dz, best);
                         L.np = 0;
                         if (ANYHIT && best.prim != LH_MISS_PRIM) { finished = true; break; }
                     }
@@ -200,7 +220,6 @@ __device__ __forceinline__ void traverse_unified(Lane &L, const lh_dev_scene_t &
 {
     const float4 *__restrict__ nodes = (const float4 *)sc.nodes;
     const float4 *__restrict__ tris  = (const float4 *)sc.tri32;
-    const double *__restrict__ tri64 = (const double *)sc.tri64;
 
     while (L.cur != kDone) {
         const bool is_node = L.cur >= 0;
@@ -234,10 +253,10 @@ __device__ __forceinline__ void traverse_unified(Lane &L, const lh_dev_scene_t &
                     const uint32_t prim = __float_as_uint(n2.y);
                     if (L.np == kPend) {
                         if (COUNT) c_exact += kPend;
-                        resolve(tri64, L.p0, ox, oy, oz, dx, dy, dz, best);
-                        resolve(tri64, L.p1, ox, oy, oz, dx, dy, dz, best);
-                        resolve(tri64, L.p2, ox, oy, oz, dx, dy, dz, best);
-                        resolve(tri64, L.p3, ox, oy, oz, dx, dy, dz, best);
+                        resolve(sc, L.p0, ox, oy, oz, dx, dy, dz, best);
+                        resolve(sc, L.p1, ox, oy, oz, dx, dy, dz, best);
+                        resolve(sc, L.p2, ox, oy, oz, dx, dy, dz, best);
+                        resolve(sc, L.p3, ox, oy, oz, dx, dy, dz, best);
                         L.np = 0;
                         if (ANYHIT && best.prim != LH_MISS_PRIM) finished = true;
                     }
@@ -272,7 +291,6 @@ __device__ __forceinline__ void traverse_spec(Lane &L, int &pend, const lh_dev_s
                                               const int min_active, const int tri_batch)
 {
     const float4 *__restrict__ tris  = (const float4 *)sc.tri32;
-    const double *__restrict__ tri64 = (const double *)sc.tri64;
     constexpr int kNoLeaf = 0;   /* never a valid leaf reference (leaf refs are negative) */
 
     for (;;) {
@@ -317,10 +335,10 @@ __device__ __forceinline__ void traverse_spec(Lane &L, int &pend, const lh_dev_s
                         const uint32_t prim = __float_as_uint(tc.y);
                         if (L.np == kPend) {
                             if (COUNT) c_exact += kPend;
-                            resolve(tri64, L.p0, ox, oy, oz, dx, dy, dz, best);
-                            resolve(tri64, L.p1, ox, oy, oz, dx, dy, dz, best);
-                            resolve(tri64, L.p2, ox, oy, oz, dx, dy, dz, best);
-                            resolve(tri64, L.p3, ox, oy, oz, dx, dy, dz, best);
+                            resolve(sc, L.p0, ox, oy, oz, dx, dy, dz, best);
+                            resolve(sc, L.p1, ox, oy, oz, dx, dy, dz, best);
+                            resolve(sc, L.p2, ox, oy, oz, dx, dy, dz, best);
+                            resolve(sc, L.p3, ox, oy, oz, dx, dy, dz, best);
                             L.np = 0;
                             if (ANYHIT && best.prim != LH_MISS_PRIM) finished = true;
                         }
@@ -350,13 +368,12 @@ __device__ __forceinline__ void finish(Lane &L, const lh_dev_scene_t &sc,
                                        double dx, double dy, double dz, Best &best,
                                        uint32_t &c_exact)
 {
-    const double *__restrict__ tri64 = (const double *)sc.tri64;
     if (ANYHIT && (L.certain || best.prim != LH_MISS_PRIM)) return;
     if (COUNT) c_exact += (uint32_t)L.np;
-    if (L.np > 0) resolve(tri64, L.p0, ox, oy, oz, dx, dy, dz, best);
-    if (L.np > 1) resolve(tri64, L.p1, ox, oy, oz, dx, dy, dz, best);
-    if (L.np > 2) resolve(tri64, L.p2, ox, oy, oz, dx, dy, dz, best);
-    if (L.np > 3) resolve(tri64, L.p3, ox, oy, oz, dx, dy, dz, best);
+    if (L.np > 0) resolve(sc, L.p0, ox, oy, oz, dx, dy, dz, best);
+    if (L.np > 1) resolve(sc, L.p1, ox, oy, oz, dx, dy, dz, best);
+    if (L.np > 2) resolve(sc, L.p2, ox, oy, oz, dx, dy, dz, best);
+    if (L.np > 3) resolve(sc, L.p3, ox, oy, oz, dx, dy, dz, best);
     L.np = 0;
 }
 

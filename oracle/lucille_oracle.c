@@ -578,6 +578,18 @@ void lo_brute_force_batch(const lo_scene_t *s, size_t n, const double *org, cons
     run_batch(s, n, org, dir, prim, t, u, v, NULL, nthreads, 1);
 }
 
+/* primitive ids in the reference's leaf order (the order gather_triangles leaves them in,
+ * bvh.c:1897-1917) and, per primitive, a leaf ordinal (first-triangle offset of its leaf) */
+void lo_scene_leaf_order(const lo_scene_t *s, uint32_t *leaf_prims, uint32_t *prim_leaf_first)
+{
+    uint64_t i, k;
+    for (i = 0; i < s->ntris; i++) leaf_prims[i] = s->tris[i].prim;
+    for (i = 0; i < s->nnodes; i++)
+        if (s->nodes[i].is_leaf)
+            for (k = 0; k < s->nodes[i].count; k++)
+                prim_leaf_first[s->tris[s->nodes[i].first + k].prim] = s->nodes[i].first;
+}
+
 /* ---- accessors for lucille_oracle_ao.c ---------------------------------- */
 
 int lo_priv_intersect1(const lo_scene_t *s, const double *org, const double *dir,
@@ -606,6 +618,25 @@ void lo_priv_prim_vertices(const lo_scene_t *s, uint32_t prim, const double **v0
     if (m->nrm) { *n0 = &m->nrm[3 * (size_t)i0]; *n1 = &m->nrm[3 * (size_t)i1]; *n2 = &m->nrm[3 * (size_t)i2]; }
     else { *n0 = *n1 = *n2 = NULL; }
     *inside_flag_two_side = m->two_side; *index = t->index; *nindices = m->nidx;
+}
+
+/* ---- accessors for lucille_oracle_beam.c --------------------------------- */
+int lo_priv_empty(const lo_scene_t *s) { return s->empty; }
+
+/* returns is_leaf */
+int lo_priv_node(const lo_scene_t *s, int32_t idx, const double **box0, const double **box1, int32_t child[2],
+                 uint32_t *first, uint32_t *count)
+{
+    const lo_node_t *n = &s->nodes[idx];
+    *box0 = n->box[0]; *box1 = n->box[1]; child[0] = n->child[0]; child[1] = n->child[1];
+    *first = n->first; *count = n->count;
+    return n->is_leaf;
+}
+
+void lo_priv_leaf_tri(const lo_scene_t *s, uint32_t sorted_index, const double **v0, const double **v1, const double **v2)
+{
+    const lo_tri_t *t = &s->tris[sorted_index];
+    *v0 = t->v[0]; *v1 = t->v[1]; *v2 = t->v[2];
 }
 
 /* number of triangles whose triangle_isect hit has EXACTLY t == t_ref[i]:

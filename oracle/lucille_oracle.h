@@ -91,6 +91,8 @@ void lo_brute_force_batch(const lo_scene_t *scene, size_t n,
                           uint32_t *prim, double *t, double *u, double *v,
                           int nthreads);
 
+void lo_scene_leaf_order(const lo_scene_t *scene, uint32_t *leaf_prims, uint32_t *prim_leaf_first);
+
 /* brute force: how many triangles hit with exactly t == t_ref[i] (>= 2: an
  * exact-t tie, where the reference's winner is traversal-order dependent) */
 void lo_count_equal_t_batch(const lo_scene_t *scene, size_t n, const double *org_xyz,
@@ -134,6 +136,12 @@ size_t lo_render_ao(const lo_scene_t *scene, const lo_camera_t *cam, int xsample
                     int gather_nsamples, int bucket_size, float *image,
                     double *rec_org, double *rec_dir, uint32_t *rec_prim, double *rec_t,
                     double *rec_u, double *rec_v, size_t rec_cap);
+
+/* beam (frustum) visibility: ri_beam_set + ri_bvh_intersect_beam_visibility
+ * (lucille_oracle_beam.c).  dirs_xyz: n x 4 corner directions.  result: 0 miss, 1 hit
+ * completely, 2 hit partially (beam.h:27-29), -1 where ri_beam_set returns -1 */
+void lo_beam_visibility_batch(const lo_scene_t *scene, size_t n, const double *org_xyz,
+                              const double *dirs_xyz, int32_t *result);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ def _p(a, ty):
 
 def build_oracle(force=False):
     so = os.path.join(HERE, "liblucille_oracle.so")
-    srcs = [os.path.join(HERE, f) for f in ("lucille_oracle.c", "lucille_oracle_ao.c", "lucille_oracle.h")]
+    srcs = [os.path.join(HERE, f) for f in ("lucille_oracle.c", "lucille_oracle_ao.c", "lucille_oracle_beam.c", "lucille_oracle.h")]
     stale = (not os.path.exists(so)) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
@@ -99,6 +99,8 @@ def lib():
         L.lo_intersect_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _u32p, _dp, _dp, _dp,
                                          C.POINTER(Counters), C.c_int]
         L.lo_brute_force_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _u32p, _dp, _dp, _dp, C.c_int]
+        L.lo_beam_visibility_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, C.POINTER(C.c_int32)]
+        L.lo_scene_leaf_order.argtypes = [C.c_void_p, _u32p, _u32p]
         L.lo_count_equal_t_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _dp, _u32p]
         L.lo_scene_set_normals.argtypes = [C.c_void_p, C.c_uint32, _dp, C.c_int]
         L.lo_camera_ray.argtypes = [C.POINTER(Camera), C.c_double, C.c_double, _dp, _dp]
@@ -214,6 +216,18 @@ class Oracle:
     def intersect(self, org, dr, counters=False, nthreads=1):
         return self._run(self.L.lo_intersect_batch, org, dr, counters, nthreads)
 
+    def beam_visibility(self, org, dirs):
+        org = _c(org, np.float64).reshape(-1, 3); dirs = _c(dirs, np.float64).reshape(-1, 4, 3)
+        res = np.empty(org.shape[0], np.int32)
+        self.L.lo_beam_visibility_batch(self.h, org.shape[0], _p(org, _dp), _p(dirs, _dp), res.ctypes.data_as(C.POINTER(C.c_int32)))
+        return res
+
+    def leaf_order(self):
+        n = self.ntriangles
+        lp = np.empty(n, np.uint32); pf = np.empty(n, np.uint32)
+        self.L.lo_scene_leaf_order(self.h, _p(lp, _u32p), _p(pf, _u32p))
+        return lp, pf
+
     def count_equal_t(self, org, dr, t_ref):
         """per ray: number of triangles hit at exactly t_ref (brute force, small scenes)"""
         org = _c(org, np.float64).reshape(-1, 3); dr = _c(dr, np.float64).reshape(-1, 3)
@@ -243,6 +257,7 @@ class RefLib:
         L.lref_record_stop.restype = C.c_size_t
         L.lref_record_size.restype = C.c_size_t
         L.lref_record_copy.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+        L.lref_beam_visibility_batch.argtypes = [C.c_size_t, _dp, _dp, C.POINTER(C.c_int32)]
         self.L = L
         L.lref_init()
         L.lref_scene_reset()
@@ -267,6 +282,12 @@ class RefLib:
         a = np.empty(3); b = np.empty(3)
         self.L.lref_scene_bbox(_p(a, _dp), _p(b, _dp))
         return a, b
+
+    def beam_visibility(self, org, dirs):
+        org = _c(org, np.float64).reshape(-1, 3); dirs = _c(dirs, np.float64).reshape(-1, 4, 3)
+        res = np.empty(org.shape[0], np.int32)
+        self.L.lref_beam_visibility_batch(org.shape[0], _p(org, _dp), _p(dirs, _dp), res.ctypes.data_as(C.POINTER(C.c_int32)))
+        return res
 
     def intersect(self, org, dr, state=False, counters=False):
         org = _c(org, np.float64).reshape(-1, 3); dr = _c(dr, np.float64).reshape(-1, 3)

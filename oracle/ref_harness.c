@@ -36,6 +36,7 @@
 #include "raytrace.h"
 #include "ray.h"
 #include "intersection_state.h"
+#include "beam.h"
 #include "context.h"
 #include "option.h"
 #include "camera.h"
@@ -374,6 +375,26 @@ void lref_set_options(int accel_method, int nthreads, int gather_nsamples)
     if (accel_method >= 0) o->accel_method = accel_method;
     if (nthreads > 0) o->nthreads = nthreads;
     if (gather_nsamples > 0) o->gather_nsamples = gather_nsamples;
+}
+
+/* beam visibility through the reference's own ri_beam_set + ri_bvh_intersect_beam_visibility
+ * (beam.c:331-465, bvh.c:612-667); dirs: n x 4 x 3; -1 where ri_beam_set refuses */
+void lref_beam_visibility_batch(size_t n, const double *org, const double *dirs, int32_t *result)
+{
+    size_t r; void *accel = ri_render_get()->scene->accel->data;
+    FILE *saved = stderr;
+    for (r = 0; r < n; r++) {
+        ri_beam_t beam; ri_vector_t o, d[4]; int i, k;
+        memset(&beam, 0, sizeof(beam));
+        for (k = 0; k < 3; k++) o[k] = org[3 * r + k];
+        o[3] = 0.0;
+        for (i = 0; i < 4; i++) { for (k = 0; k < 3; k++) d[i][k] = dirs[12 * r + 3 * i + k]; d[i][3] = 0.0; }
+        stderr = fopen("/dev/null", "w");          /* ri_beam_set prints a TODO message on refusal */
+        i = ri_beam_set(&beam, o, d);
+        fclose(stderr); stderr = saved;
+        if (i != 0) { result[r] = -1; continue; }
+        result[r] = ri_bvh_intersect_beam_visibility(accel, &beam, NULL);
+    }
 }
 
 /* recorder control */

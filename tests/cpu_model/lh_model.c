@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "lh_bvh.h"
+#include "lh_refbvh.h"
 #include "lh_filter.h"
 
 #define MISS 0xFFFFFFFFu
@@ -24,13 +25,18 @@
 
 typedef struct { double t, u, v; uint32_t prim; } best_t;
 
+static const lh_refbvh_t *g_ref = NULL;    /* reference-order tree for exact-t ties (optional) */
+
 static void resolve(const lh_bvh_t *b, uint32_t prim, const double *o, const double *d, best_t *best)
 {
     double t, u, v;
     if (lh_exact_isect(&b->tri64[prim].v[0][0], o[0], o[1], o[2], d[0], d[1], d[2], &t, &u, &v)) {
-        if ((t < best->t) || (t == best->t && best->prim != MISS && prim > best->prim)) {
-            if (t < T_INF) { best->t = t; best->u = u; best->v = v; best->prim = prim; }
+        int take = t < best->t;
+        if (!take && t == best->t && best->prim != MISS && prim != best->prim) {
+            if (g_ref) { int sg[3] = { d[0] < 0.0, d[1] < 0.0, d[2] < 0.0 }; take = lh_refbvh_tie_winner(g_ref, prim, best->prim, sg) == prim; }
+            else take = prim > best->prim;
         }
+        if (take && t < T_INF) { best->t = t; best->u = u; best->v = v; best->prim = prim; }
     }
 }
 
@@ -144,3 +150,26 @@ const void *lhm_nodes(const lh_bvh_t *b) { return b->nodes; }
 const void *lhm_tri32(const lh_bvh_t *b) { return b->tri32; }
 const void *lhm_qnodes(const lh_bvh_t *b) { return b->qnodes; }
 void lhm_grid(const lh_bvh_t *b, float out[6]) { int k; for (k = 0; k < 3; k++) { out[k] = b->grid_lo[k]; out[3 + k] = b->grid_step[k]; } }
+
+/* reference-order tree of the same scene */
+lh_refbvh_t *lhm_ref_build(const lh_bvh_t *b, int nthreads)
+{
+    lh_refbvh_t *r = (lh_refbvh_t *)calloc(1, sizeof(*r));
+    if (lh_refbvh_build(r, b->tri64, b->ntris, nthreads) != 0) { free(r); return NULL; }
+    return r;
+}
+void lhm_ref_free(lh_refbvh_t *r) { if (r) { lh_refbvh_release(r); free(r); } }
+void lhm_ref_use(const lh_refbvh_t *r) { g_ref = r; }
+void lhm_ref_info(const lh_refbvh_t *r, uint32_t out[4])
+{
+    uint32_t i, ninner = 0, nleaf = 0;
+    for (i = 0; i < r->nnodes; i++) { if (r->nodes[i].is_leaf) nleaf++; else ninner++; }
+    out[0] = ninner; out[1] = nleaf; out[2] = r->max_depth; out[3] = r->ntris;
+}
+void lhm_ref_leaf_order(const lh_refbvh_t *r, uint32_t *leaf_prims, uint32_t *prim_leaf_first)
+{
+    uint32_t i;
+    memcpy(leaf_prims, r->leaf_prims, sizeof(uint32_t) * r->ntris);
+    for (i = 0; i < r->ntris; i++) prim_leaf_first[i] = r->nodes[r->prim_leaf[i]].first;
+}
+void lhm_ref_bbox(const lh_refbvh_t *r, double out[6]) { int k; for (k = 0; k < 3; k++) { out[k] = r->bmin[k]; out[3 + k] = r->bmax[k]; } }

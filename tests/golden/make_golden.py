@@ -83,11 +83,27 @@ def ao_fixture(name, rib, width, height, gather_nsamples, pixel_samples=1):
           "image mean", float(r["image"].mean()))
 
 
+def beam_fixture(name, ntri, half_extent, seed, nbeams):
+    """ri_beam_set + ri_bvh_intersect_beam_visibility of the compiled reference on seeded beams
+    (tests.helpers.random_beams) over a seeded S-soup: expected classes only."""
+    from tests.helpers import random_beams
+    P, idx, _, _ = po.soup(ntri, 1, half_extent, seed)
+    ref = po.RefLib(); ref.add_mesh(P, idx); ref.build()
+    out = {}
+    for spread in (0.001, 0.01, 0.05):
+        org, d = random_beams(np.random.default_rng(int(spread * 1e6) + seed), nbeams, spread)
+        out["res_%g" % spread] = ref.beam_visibility(org, d)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), ntri=ntri, half_extent=half_extent, seed=seed, nbeams=nbeams, **out)
+    print(name, {k: np.bincount(v + 1, minlength=4).tolist() for k, v in out.items()})
+
+
 if __name__ == "__main__":
     if not po.ref_available(stat=True):
         po.build_ref()
     soup_fixture("soup_20k", 20000, 20000, 0.005)
     soup_fixture("soup_3k_fat", 3000, 10000, 0.05)
+    beam_fixture("beams_2k", 2000, 0.03, 77, 4000)
+    beam_fixture("beams_300", 300, 0.1, 78, 4000)
     # BASELINE config 1: examples/ambient_occlusion.rib, 256x256, 16 AO samples, 1 thread
     ao_fixture("ao_c1", "/root/reference/examples/ambient_occlusion/ambient_occlusion.rib", 256, 256, 16)
     # check values of the full S-soup-1M (SURVEY.md Appendix C) are pinned in

@@ -25,11 +25,11 @@ def build_model():
     """tests/cpu_model/liblh_model.so: host model of the kernel algorithm over
     the product's own BVH builder (lh_bvh.c) and arithmetic (lh_filter.h)."""
     so = os.path.join(MODEL_DIR, "liblh_model.so")
-    srcs = [os.path.join(MODEL_DIR, "lh_model.c"), os.path.join(CSRC, "lh_bvh.c"),
-            os.path.join(CSRC, "lh_bvh.h"), os.path.join(CSRC, "lh_filter.h")]
+    srcs = [os.path.join(MODEL_DIR, "lh_model.c"), os.path.join(CSRC, "lh_bvh.c"), os.path.join(CSRC, "lh_refbvh.c"),
+            os.path.join(CSRC, "lh_bvh.h"), os.path.join(CSRC, "lh_filter.h"), os.path.join(CSRC, "lh_refbvh.h")]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-shared"] + _fma_flag() +
-                              ["-I" + CSRC, srcs[0], srcs[1], "-o", so, "-lm", "-lpthread"])
+                              ["-I" + CSRC, srcs[0], srcs[1], srcs[2], "-o", so, "-lm", "-lpthread"])
     return so
 
 
@@ -69,6 +69,30 @@ class Model:
             self.lib().lhm_free(self.h)
         except Exception:
             pass
+
+    # ---- reference-order tree (lh_refbvh.c) ------------------------------------
+    def ref_build(self, nthreads=4, use_for_ties=True):
+        L = self.lib()
+        L.lhm_ref_build.restype = C.c_void_p; L.lhm_ref_build.argtypes = [C.c_void_p, C.c_int]
+        L.lhm_ref_use.argtypes = [C.c_void_p]; L.lhm_ref_info.argtypes = [C.c_void_p, _u32p]
+        L.lhm_ref_leaf_order.argtypes = [C.c_void_p, _u32p, _u32p]; L.lhm_ref_bbox.argtypes = [C.c_void_p, _dp]
+        self.ref = L.lhm_ref_build(self.h, nthreads)
+        assert self.ref
+        L.lhm_ref_use(self.ref if use_for_ties else None)
+        info = np.zeros(4, np.uint32); L.lhm_ref_info(self.ref, info.ctypes.data_as(_u32p))
+        return dict(zip(("ninner", "nleaf", "max_depth", "ntriangles"), map(int, info)))
+
+    def ref_leaf_order(self):
+        lp = np.empty(self.ntris, np.uint32); pf = np.empty(self.ntris, np.uint32)
+        self.lib().lhm_ref_leaf_order(self.ref, lp.ctypes.data_as(_u32p), pf.ctypes.data_as(_u32p))
+        return lp, pf
+
+    def ref_bbox(self):
+        b = np.empty(6); self.lib().lhm_ref_bbox(self.ref, b.ctypes.data_as(_dp)); return b[:3], b[3:]
+
+    @classmethod
+    def ref_off(cls):
+        cls.lib().lhm_ref_use.argtypes = [C.c_void_p]; cls.lib().lhm_ref_use(None)
 
     def nodes(self):
         if self.nnodes == 0:
@@ -142,3 +166,16 @@ def assert_hits_equal(got, exp, what=""):
         bad = np.nonzero(g != e)[0]
         assert bad.size == 0, "%s: %s differs at %d rays, first %s: got %r expected %r" % (
             what, names[k], bad.size, bad[:5], g[bad[:5]], e[bad[:5]])
+
+
+def random_beams(rng, n, spread, lo=-0.5, hi=1.5):
+    """n beams: origin, 4 corner directions around an axis aimed into the unit cube
+    (a small share straddles an octant, which ri_beam_set refuses with -1)"""
+    org = rng.uniform(lo, hi, (n, 3))
+    c = rng.uniform(0, 1, (n, 3)) - org
+    c /= np.linalg.norm(c, axis=1, keepdims=True)
+    a = np.cross(c, rng.normal(size=(n, 3))); a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = np.cross(c, a)
+    d = np.stack([c - spread * a - spread * b, c + spread * a - spread * b, c + spread * a + spread * b,
+                  c - spread * a + spread * b], 1)
+    return org, d

@@ -130,13 +130,10 @@ def test_tolerance_band_geometry():
         org = np.tile(np.array([[0.3, 0.45, oz]]), (tgt.shape[0], 1)) + rng.uniform(-0.2, 0.2, (tgt.shape[0], 3)) * [1, 1, 0]
         dr = tgt - org
         exp = o.intersect(org, dr)
-        tie = o.count_equal_t(org, dr, exp[1]) >= 2
-        bf = o.brute_force(org, dr)
         for variant in VARIANTS:
             got = gpu_closest(acc, org, dr, variant)
-            assert np.array_equal(got[1], exp[1])                      # t bit-exact even on ties
-            assert np.array_equal(got[0][tie], bf[0][tie])             # documented tie rule
-            assert_hits_equal(tuple(g[~tie] for g in got), tuple(e[~tie] for e in exp), "grid oz=%g" % oz)
+            # exact-t ties included: the reference-order tree on the device picks the reference's winner
+            assert_hits_equal(got, exp, "grid oz=%g v%d" % (oz, variant))
             assert np.array_equal(gpu_any(acc, org, dr, variant).astype(bool), exp[0] != po.MISS)
     n = 50000
     org = np.stack([rng.uniform(0, 1, n), rng.uniform(0, 1, n), np.full(n, 1e-6)], 1)
