@@ -71,8 +71,12 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=1_500_000, help="cpu_baseline sample size")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ao", action="store_true", help="skip the secondary AO-frame leg")
-    ap.add_argument("--ao-size", type=int, default=1024)
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--device-override", type=int, default=None,
+                    help="testing only: put every rank on this device (2 ranks on a 1-GPU box, use with --backend gloo)")
+    ap.add_argument("--ao-size", type=int, default=2048)
     ap.add_argument("--ao-samples", type=int, default=64)
+    ap.add_argument("--ao-tess", type=int, default=6, help="midpoint-subdivision levels of the example scene (4^n x 322 triangles)")
     args = ap.parse_args()
 
     import torch
@@ -82,10 +86,14 @@ def main():
     # here only to MAKE inputs and (cpu_baseline leg) to time the CPU path
     from oracle import pyoracle as po
 
-    rank, world, local = shard.init_process_group()
+    if args.device_override is not None:
+        os.environ["LH_DEVICE_OVERRIDE"] = str(args.device_override)
+    rank, world, local = shard.init_process_group(backend=args.backend)
     assert world == args.gpus, "launch with --nproc-per-node == --gpus"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    if args.device_override is not None:
+        local = args.device_override
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -154,14 +162,15 @@ def main():
     kernel_ms = float(np.mean(kms))
 
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = dev if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     ao = None
     if not args.no_ao:
         ao = ao_frame_leg(la, acc_device=local, rank=rank, world=world, size=args.ao_size, nsamples=args.ao_samples,
-                          steps=max(2, args.steps), dev=dev)
+                          steps=max(2, args.steps), dev=dev, tess=args.ao_tess)
 
     if rank == 0:
         total_rays = n * world * args.steps
@@ -205,17 +214,20 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev):
-    """Secondary leg (BASELINE config 2): the reference's AO example scene (the 322
-    triangles its own RIB ingest produced, tests/golden/ao_c1.npz), size x size pixels,
-    `nsamples` AO rays per primary hit, whole pipeline on the device, tiles sharded
+def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
+    """Secondary leg (BASELINE configs 2/5): the reference's AO example scene (the 322 triangles
+    its own RIB ingest produced, tests/golden/ao_c1.npz), midpoint-tessellated `tess` times,
+    size x size pixels, `nsamples` AO rays per primary hit, whole pipeline on the device
+    (camera rays, hits, epilogue, AO rays, occlusion, radiance), tiles sharded
     tile_id % world with one all-gather of tile slabs (strong scaling: the frame is fixed)."""
     import torch
-    from lucille_amd import render
+    from lucille_amd import render, scenes
     g = np.load(os.path.join(ROOT, "tests", "golden", "ao_c1.npz"))
     acc = la.HipAccel(acc_device)
+    ntri = 0
     for k in range(int(g["ngeoms"])):
-        acc.add_mesh(g["pos%d" % k], g["idx%d" % k])
+        P_, I_ = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess)
+        acc.add_mesh(P_, I_); ntri += I_.shape[0] // 3
     acc.commit()
     c = g["camera"]
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
@@ -234,15 +246,16 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev):
             torch.distributed.barrier()
         if it > 0:
             times.append(time.perf_counter() - t0)
-    rays = torch.tensor([st["primary_rays"] + st["ao_rays"]], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([min(times)], dtype=torch.float64, device=dev)
+    rdev = dev if (world == 1 or torch.distributed.get_backend() == "nccl") else torch.device("cpu")
+    rays = torch.tensor([st["primary_rays"] + st["ao_rays"]], dtype=torch.float64, device=rdev)
+    tmax = torch.tensor([min(times)], dtype=torch.float64, device=rdev)
     if world > 1:
         torch.distributed.all_reduce(rays); torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     acc.close()
     if rank != 0:
         return None
-    return {"workload": "examples/ambient_occlusion scene (322 tris), %dx%d, %d AO samples, frame wall incl. ray gen + tile gather"
-                        % (size, size, nsamples),
+    return {"workload": "examples/ambient_occlusion scene tessellated to %d tris, %dx%d, %d AO samples, frame wall incl. ray gen + tile gather"
+                        % (ntri, size, size, nsamples), "triangles": ntri, "tile": tile,
             "rays_per_frame": int(rays.item()), "frame_ms": round(tmax.item() * 1e3, 3),
             "value": round(rays.item() / tmax.item() / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
             "image_mean": float(img.mean().item())}

@@ -62,8 +62,13 @@ def assemble(slab, W, H, tile, rank, world):
     pad = torch.zeros((per_rank, tile * tile * 3), dtype=slab.dtype, device=slab.device)
     pad[:slab.shape[0]] = slab
     if world > 1:
-        out = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(out, pad)
+        if dist.get_backend() != "nccl" and pad.is_cuda:      # gloo (tests): stage through the host
+            hp = pad.cpu(); ho = [torch.empty_like(hp) for _ in range(world)]
+            dist.all_gather(ho, hp)
+            out = [t.to(pad.device) for t in ho]
+        else:
+            out = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(out, pad)
     else:
         out = [pad]
     if rank != 0:

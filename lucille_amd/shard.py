@@ -48,6 +48,6 @@ def init_process_group(backend=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(int(os.environ.get("LH_DEVICE_OVERRIDE", local)))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
