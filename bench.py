@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 B_IN, B_OUT, B_TRI = 32, 16, 40   # SURVEY.md 8(d) algorithmic bytes per ray / per triangle test
-B_NODE = {"f32": 64, "q16": 32}       # per inner-node visit: SURVEY's 64-B fp32 node, or this build's 32-B 16-bit grid node
+B_NODE = {"f32": 64, "q16": 32, "q16x4": 64}   # per node visit: SURVEY's 64-B fp32 2-wide node, 32-B 16-bit grid 2-wide, 64-B 16-bit grid 4-wide
 
 
 def hip_event_timer():
@@ -130,7 +130,7 @@ def main():
     _, cnt = acc.intersect_device(d_org[:ns], d_dir[:ns], mode=mode, variant=args.variant, counters=True)
     n_nodes = cnt["nodes"] / ns; n_tris = cnt["tris"] / ns
     b_out = B_OUT if mode == la.MODE_CLOSEST else 4
-    node_fmt = "f32" if os.environ.get("LH_NODE_FORMAT") == "f32" else "q16"
+    node_fmt = {"f32": "f32", "q16": "q16"}.get(os.environ.get("LH_NODE_FORMAT", ""), "q16x4")
     b_ray = B_IN + b_out + B_NODE[node_fmt] * n_nodes + B_TRI * n_tris
 
     # ---- timed region -------------------------------------------------------------
@@ -181,7 +181,8 @@ def main():
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("rays_per_launch") == n and j.get("mode") == args.mode:
+                if j.get("rays_per_launch") == n and j.get("mode") == args.mode and j.get("kernel_tag") == node_fmt \
+                        and args.variant in (-1, 4):
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None

@@ -62,7 +62,7 @@ struct lh_accel {
     void *d_ref_lca, *d_prim_leafpos, *d_ref_nodes, *d_ref_leaf_prims;
     /* device */
     lh_dev_scene_t dev;
-    void *d_nodes, *d_tri32, *d_tri64, *d_qnodes;
+    void *d_nodes, *d_tri32, *d_tri64, *d_qnodes, *d_q4nodes;
     unsigned long long *d_cursor, *d_counters;
     hipStream_t stream;
     uint64_t device_bytes;
@@ -104,8 +104,8 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     a->default_variant = LH_VARIANT_SPEC;
     const char *env = getenv("LH_VARIANT");
     if (env) a->default_variant = atoi(env);
-    a->min_active = 16;
-    a->tri_batch = 4;
+    a->min_active = 32;
+    a->tri_batch = 8;
     env = getenv("LH_TRI_BATCH");
     if (env && atoi(env) > 0 && atoi(env) <= 64) a->tri_batch = atoi(env);
     env = getenv("LH_MIN_ACTIVE");
@@ -174,6 +174,8 @@ static void release_device(lh_accel_t *a)
     if (a->d_tri64) (void)hipFree(a->d_tri64);
     if (a->d_qnodes) (void)hipFree(a->d_qnodes);
     a->d_qnodes = NULL;
+    if (a->d_q4nodes) (void)hipFree(a->d_q4nodes);
+    a->d_q4nodes = NULL;
     if (a->d_ref_lca) (void)hipFree(a->d_ref_lca);
     if (a->d_prim_leafpos) (void)hipFree(a->d_prim_leafpos);
     if (a->d_ref_nodes) (void)hipFree(a->d_ref_nodes);
@@ -259,7 +261,10 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
         size_t qb = sizeof(lh_qnode_t) * (size_t)a->bvh.nnodes;
         HIPCHK(hipMalloc(&a->d_qnodes, qb));
         HIPCHK(hipMemcpy(a->d_qnodes, a->bvh.qnodes, qb, hipMemcpyHostToDevice));
-        a->device_bytes = nb + t32 + t64 + qb;
+        size_t q4b = sizeof(lh_q4node_t) * (size_t)a->bvh.nq4nodes;
+        HIPCHK(hipMalloc(&a->d_q4nodes, q4b));
+        HIPCHK(hipMemcpy(a->d_q4nodes, a->bvh.q4nodes, q4b, hipMemcpyHostToDevice));
+        a->device_bytes = nb + t32 + t64 + qb + q4b;
         float r = 0.0f;
         for (int k = 0; k < 3; k++) { r = fmaxf(r, fabsf(a->bvh.bmin[k])); r = fmaxf(r, fabsf(a->bvh.bmax[k])); }
         a->dev.nodes = a->d_nodes; a->dev.tri32 = a->d_tri32; a->dev.tri64 = a->d_tri64;
@@ -295,15 +300,26 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
             for (int k = 0; k < 3; k++) { a->dev.ref_bmin[k] = a->ref.bmin[k]; a->dev.ref_bmax[k] = a->ref.bmax[k]; }
             a->device_bytes += sizeof(int) * 4 * (size_t)rn + sizeof(uint32_t) * 3 * (size_t)a->bvh.ntris + sizeof(lh_refnode_t) * (size_t)rn;
         }
-        a->dev.use_qnodes = 1;
-        { const char *fmt = getenv("LH_NODE_FORMAT"); if (fmt && strcmp(fmt, "f32") == 0) a->dev.use_qnodes = 0; }
+        a->dev.q4nodes = a->d_q4nodes; a->dev.nq4nodes = a->bvh.nq4nodes; a->dev.q4_depth = a->bvh.q4_depth;
+        a->dev.use_qnodes = 2;
+        {
+            const char *fmt = getenv("LH_NODE_FORMAT");
+            if (fmt && strcmp(fmt, "f32") == 0) a->dev.use_qnodes = 0;
+            if (fmt && strcmp(fmt, "q16") == 0) a->dev.use_qnodes = 1;
+            if (3 * a->bvh.q4_depth + 5 > 64) a->dev.use_qnodes = 1;     /* pathological depth: 2-wide walk */
+        }
         if (a->bvh.max_depth + 1 > 64) return fail("lh_accel_commit: tree depth %u exceeds the kernel stack", a->bvh.max_depth);
     }
     a->upload_seconds = now_s() - t0;
     {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, a->device));
-        int per_cu = (a->bvh.max_depth + 1 <= 32) ? 5 : 2;   /* LDS stack bound */
+        uint32_t need = a->bvh.max_depth + 1;
+        if (a->dev.use_qnodes == 2) need = 3 * a->bvh.q4_depth + 5;
+        const uint32_t stack = need <= 32 ? 32 : (need <= 48 ? 48 : 64);
+        int per_cu = (int)(160u / stack);                     /* LDS: stack KiB per 256-thread workgroup */
+        if (per_cu > 5) per_cu = 5;
+        if (per_cu < 1) per_cu = 1;
         a->grid_blocks = prop.multiProcessorCount * per_cu;
         const char *env = getenv("LH_GRID_BLOCKS");
         if (env && atoi(env) > 0) a->grid_blocks = atoi(env);

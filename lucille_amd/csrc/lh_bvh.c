@@ -325,6 +325,78 @@ static int quantize_nodes(lh_bvh_t *o)
     return 0;
 }
 
+/* ---- 4-wide collapse of the flat binary tree (see lh_q4node_t) ------------------------- */
+typedef struct { const float *lo, *hi; int32_t ref; } child4_t;
+
+static float area3(const float *lo, const float *hi)
+{
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+static void quant_box(const lh_bvh_t *o, const float *lo, const float *hi, uint16_t q[6])
+{
+    int k;
+    for (k = 0; k < 3; k++) {
+        const double g = o->grid_lo[k], st = o->grid_step[k];
+        double ql = floor(((double)lo[k] - g) / st), qh = ceil(((double)hi[k] - g) / st);
+        if (ql < 0.0) ql = 0.0;
+        if (ql > 65535.0) ql = 65535.0;
+        if (qh < 0.0) qh = 0.0;
+        if (qh > 65535.0) qh = 65535.0;
+        while (ql > 0.0 && g + ql * st > (double)lo[k]) ql -= 1.0;
+        while (qh < 65535.0 && g + qh * st < (double)hi[k]) qh += 1.0;
+        q[k] = (uint16_t)ql; q[3 + k] = (uint16_t)qh;
+    }
+}
+
+static void build4(lh_bvh_t *o, uint32_t i2, uint32_t k4, uint32_t depth, uint32_t *next)
+{
+    child4_t ch[4]; int n = 2, c, k; uint32_t kid[4];
+    const lh_node_t *nd = &o->nodes[i2];
+    ch[0].lo = nd->lo0; ch[0].hi = nd->hi0; ch[0].ref = nd->ref0;
+    ch[1].lo = nd->lo1; ch[1].hi = nd->hi1; ch[1].ref = nd->ref1;
+    if (ch[1].ref == LH_REF_EMPTY) n = 1;
+    while (n < 4) {
+        int best = -1; float ba = -1.0f;
+        for (c = 0; c < n; c++)
+            if (ch[c].ref >= 0) { float a = area3(ch[c].lo, ch[c].hi); if (a > ba) { ba = a; best = c; } }
+        if (best < 0) break;
+        {
+            const lh_node_t *g = &o->nodes[ch[best].ref];
+            ch[best].lo = g->lo0; ch[best].hi = g->hi0; ch[best].ref = g->ref0;
+            ch[n].lo = g->lo1; ch[n].hi = g->hi1; ch[n].ref = g->ref1;
+            n++;
+        }
+    }
+    if (depth + 1 > o->q4_depth) o->q4_depth = depth + 1;
+    for (c = 0; c < n; c++) if (ch[c].ref >= 0) kid[c] = (*next)++;     /* inner children adjacent */
+    {
+        lh_q4node_t *q = &o->q4nodes[k4];
+        for (c = 0; c < 4; c++) {
+            if (c < n) {
+                quant_box(o, ch[c].lo, ch[c].hi, q->q[c]);
+                q->ref[c] = (ch[c].ref >= 0) ? (int32_t)kid[c] : ch[c].ref;
+            } else {
+                for (k = 0; k < 3; k++) { q->q[c][k] = 65535; q->q[c][3 + k] = 0; }
+                q->ref[c] = LH_REF_EMPTY;
+            }
+        }
+    }
+    for (c = 0; c < n; c++) if (ch[c].ref >= 0) build4(o, (uint32_t)ch[c].ref, kid[c], depth + 1, next);
+}
+
+static int collapse4(lh_bvh_t *o)
+{
+    uint32_t next = 1;
+    o->q4nodes = (lh_q4node_t *)calloc(o->nnodes ? o->nnodes : 1, sizeof(lh_q4node_t));   /* <= nnodes records */
+    if (!o->q4nodes) return -1;
+    o->q4_depth = 0;
+    build4(o, 0, 0, 0, &next);
+    o->nq4nodes = next;
+    return 0;
+}
+
 static uint32_t count_inner(const tnode_t *n) { return n->count ? 0 : 1 + count_inner(n->c[0]) + count_inner(n->c[1]); }
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -442,13 +514,13 @@ int lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, 
     }
     arena_free(&main_arena);
     free(b.tasks); free(b.plo); free(b.phi); free(b.cen); free(b.order);
-    if (quantize_nodes(out) != 0) { lh_bvh_release(out); return -1; }
+    if (quantize_nodes(out) != 0 || collapse4(out) != 0) { lh_bvh_release(out); return -1; }
     out->build_seconds = now_s() - t0;
     return 0;
 }
 
 void lh_bvh_release(lh_bvh_t *bvh)
 {
-    free(bvh->nodes); free(bvh->qnodes); free(bvh->tri32); free(bvh->tri64); free(bvh->prim_geom); free(bvh->prim_index);
+    free(bvh->nodes); free(bvh->qnodes); free(bvh->q4nodes); free(bvh->tri32); free(bvh->tri64); free(bvh->prim_geom); free(bvh->prim_index);
     memset(bvh, 0, sizeof(*bvh));
 }

@@ -61,6 +61,17 @@ typedef struct lh_tri32 {
 /* 72-byte exact triangle (fp64), indexed by primitive id */
 typedef struct lh_tri64 { double v[3][3]; } lh_tri64_t;
 
+/* 64-byte 4-wide node on the same 16-bit grid: the binary tree collapsed (largest-area
+ * inner child opened first) so that one 64-byte record -- one L2 request -- decides four
+ * children.  The traversal kernel runs at the L2 request-rate ceiling of its footprint
+ * (profiles/README.md), so halving the records per ray is what raises rays/s.
+ *   q[c][0..2] lo xyz, q[c][3..5] hi xyz of child c; ref[c] as in lh_node_t
+ *   (LH_REF_EMPTY for unused slots, whose box is inverted)                              */
+typedef struct lh_q4node {
+    uint16_t q[4][6];
+    int32_t  ref[4];
+} lh_q4node_t;
+
 typedef struct lh_bvh {
     uint32_t    ntris;
     uint32_t    nnodes;
@@ -73,6 +84,8 @@ typedef struct lh_bvh {
     uint32_t   *prim_index;/* ntris: 3*i offset into that mesh's indices    */
     float       bmin[3], bmax[3];  /* scene box, fp32 outward               */
     lh_qnode_t *qnodes;            /* nnodes, same indexing as nodes         */
+    lh_q4node_t *q4nodes;          /* nq4nodes: 4-wide collapse of the same tree */
+    uint32_t    nq4nodes, q4_depth;
     float       grid_lo[3], grid_step[3];   /* quantisation grid of qnodes   */
     double      build_seconds;
 } lh_bvh_t;

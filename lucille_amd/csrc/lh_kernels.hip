@@ -361,6 +361,106 @@ __device__ __forceinline__ void traverse_spec(Lane &L, int &pend, const lh_dev_s
     }
 }
 
+/* Speculative walk over the 4-wide 16-bit grid nodes (lh_q4node_t): one 64-byte record --
+ * one L2 request -- decides four children.  The node step is branch-free: the four slab
+ * tests give (hit, entry distance); ranks by entry distance come from six key comparisons
+ * (key = distance bits with the slot number in the two low bits, misses = max); every child
+ * writes its reference to the LDS stack at a rank-derived slot (hits: farthest at the bottom,
+ * nearest on top; misses: above the new top, i.e. into free space) and the next reference
+ * is read back from the new top -- which is the nearest hit, or the previous top when
+ * nothing was hit (a pop).  Leaves are parked and tested in batches as in traverse_spec. */
+template <int STACK, bool ANYHIT, bool COUNT>
+__device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_scene_t &sc,
+                                               int (*stk)[LH_BLOCK], const int tid,
+                                               double ox, double oy, double oz,
+                                               double dx, double dy, double dz, Best &best,
+                                               uint32_t &c_nodes, uint32_t &c_tris, uint32_t &c_exact,
+                                               const int min_active, const int tri_batch)
+{
+    const float4 *__restrict__ tris  = (const float4 *)sc.tri32;
+    constexpr int kNoLeaf = 0;
+
+    for (;;) {
+        if (L.cur >= 0) {
+            const uint4 *p = (const uint4 *)sc.q4nodes + 4 * (size_t)L.cur;
+            const uint4 a = p[0], b = p[1], c = p[2], r = p[3];
+            if (COUNT) c_nodes++;
+            float t0, t1, t2, t3;
+            const bool h0 = lh_slab_q(&L.r, (float)(a.x & 0xffffu), (float)(a.x >> 16), (float)(a.y & 0xffffu),
+                                      (float)(a.y >> 16), (float)(a.z & 0xffffu), (float)(a.z >> 16), L.tb, &t0) & ((int)r.x != kDone);
+            const bool h1 = lh_slab_q(&L.r, (float)(a.w & 0xffffu), (float)(a.w >> 16), (float)(b.x & 0xffffu),
+                                      (float)(b.x >> 16), (float)(b.y & 0xffffu), (float)(b.y >> 16), L.tb, &t1) & ((int)r.y != kDone);
+            const bool h2 = lh_slab_q(&L.r, (float)(b.z & 0xffffu), (float)(b.z >> 16), (float)(b.w & 0xffffu),
+                                      (float)(b.w >> 16), (float)(c.x & 0xffffu), (float)(c.x >> 16), L.tb, &t2) & ((int)r.z != kDone);
+            const bool h3 = lh_slab_q(&L.r, (float)(c.y & 0xffffu), (float)(c.y >> 16), (float)(c.z & 0xffffu),
+                                      (float)(c.z >> 16), (float)(c.w & 0xffffu), (float)(c.w >> 16), L.tb, &t3) & ((int)r.w != kDone);
+            /* entry distances are >= 0, so their bit patterns order like unsigned integers */
+            const uint32_t k0 = h0 ? ((__float_as_uint(t0) & ~3u) | 0u) : 0xFFFFFFFCu;
+            const uint32_t k1 = h1 ? ((__float_as_uint(t1) & ~3u) | 1u) : 0xFFFFFFFDu;
+            const uint32_t k2 = h2 ? ((__float_as_uint(t2) & ~3u) | 2u) : 0xFFFFFFFEu;
+            const uint32_t k3 = h3 ? ((__float_as_uint(t3) & ~3u) | 3u) : 0xFFFFFFFFu;
+            const int b10 = k1 < k0, b20 = k2 < k0, b30 = k3 < k0, b21 = k2 < k1, b31 = k3 < k1, b32 = k3 < k2;
+            const int rk0 = b10 + b20 + b30, rk1 = (1 - b10) + b21 + b31;
+            const int rk2 = (2 - b20 - b21) + b32, rk3 = 3 - b30 - b31 - b32;
+            const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+            const int base = L.sp + nh - 1;
+            stk[h0 ? base - rk0 : L.sp + rk0][tid] = (int)r.x;
+            stk[h1 ? base - rk1 : L.sp + rk1][tid] = (int)r.y;
+            stk[h2 ? base - rk2 : L.sp + rk2][tid] = (int)r.z;
+            stk[h3 ? base - rk3 : L.sp + rk3][tid] = (int)r.w;
+            L.sp = base;
+            const int nxt = stk[base][tid];
+            const bool is_leaf = (nxt < 0) & (nxt != kDone);
+            const bool park = is_leaf & (pend == kNoLeaf);
+            pend = park ? nxt : pend;
+            const int popped2 = stk[L.sp - 1][tid];
+            L.cur = park ? popped2 : nxt;
+            L.sp -= park ? 1 : 0;
+        }
+        const unsigned long long m_node = __ballot(L.cur >= 0);
+        const unsigned long long m_pend = __ballot(pend != kNoLeaf);
+        if (m_pend != 0ull && (__popcll(m_pend) >= tri_batch || m_node == 0ull)) {
+            if (pend != kNoLeaf) {
+                const uint32_t x = ~(uint32_t)pend;
+                const float4 *tp = tris + 3 * (size_t)(x >> 2);
+                const float4 ta = tp[0], tb_ = tp[1], tc = tp[2];
+                if (COUNT) c_tris++;
+                float t_hi;
+                bool finished = false;
+                const int cls = lh_tri_filter(&L.r, ta.x, ta.y, ta.z, ta.w, tb_.x, tb_.y,
+                                              tb_.z, tb_.w, tc.x, tc.z, tc.w, L.tb, &t_hi);
+                if (cls != LH_TRI_REJECT) {
+                    const bool sure = (cls == LH_TRI_CERTAIN);
+                    if (ANYHIT && sure) { L.certain = true; finished = true; }
+                    else {
+                        if (sure) L.tb = fminf(L.tb, t_hi);
+                        const uint32_t prim = __float_as_uint(tc.y);
+                        if (L.np == kPend) {
+                            if (COUNT) c_exact += kPend;
+                            resolve(sc, L.p0, ox, oy, oz, dx, dy, dz, best);
+                            resolve(sc, L.p1, ox, oy, oz, dx, dy, dz, best);
+                            resolve(sc, L.p2, ox, oy, oz, dx, dy, dz, best);
+                            resolve(sc, L.p3, ox, oy, oz, dx, dy, dz, best);
+                            L.np = 0;
+                            if (ANYHIT && best.prim != LH_MISS_PRIM) finished = true;
+                        }
+                        L.p3 = L.p2; L.p2 = L.p1; L.p1 = L.p0; L.p0 = prim; L.np++;
+                    }
+                }
+                if (finished) { L.cur = kDone; pend = kNoLeaf; }
+                else if (x & 3u) pend = (int)~(((x >> 2) + 1u) << 2 | ((x & 3u) - 1u));
+                else {
+                    const bool waiting = (L.cur < 0) & (L.cur != kDone);
+                    pend = waiting ? L.cur : kNoLeaf;
+                    if (waiting) { L.sp--; L.cur = stk[L.sp][tid]; }
+                }
+            }
+        }
+        const unsigned long long m_work = __ballot((L.cur != kDone) | (pend != kNoLeaf));
+        if (__popcll(m_work) < min_active) break;
+    }
+}
+
 /* resolve whatever is still queued; afterwards `best` is the exact answer */
 template <bool ANYHIT, bool COUNT>
 __device__ __forceinline__ void finish(Lane &L, const lh_dev_scene_t &sc,
@@ -513,7 +613,9 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         if (work == 0ull) break;
         /* ---- walk until too few lanes remain active ---------------------- */
         const int thresh = exhausted ? 1 : min_active;
-        if (WALK == 2) {
+        if (WALK == 3) {
+            traverse_spec4<STACK, ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch);
+        } else if (WALK == 2) {
             /* every lane enters (idle lanes just vote in the ballots) */
             traverse_spec<STACK, ANYHIT, COUNT, QN>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch);
         } else if (L.cur != kDone) {
@@ -546,6 +648,9 @@ int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const doub
         else if (variant == LH_VARIANT_UNIFIED)
             hipLaunchKernelGGL((k_trace_persist_lane<STACK, ANYHIT, COUNT, 1, false>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
+        else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2)
+            hipLaunchKernelGGL((k_trace_persist_lane<STACK, ANYHIT, COUNT, 3, true>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
         else
             hipLaunchKernelGGL((k_trace_persist_lane<STACK, ANYHIT, COUNT, 2, QN>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
@@ -574,7 +679,7 @@ int launch_stack(const lh_dev_scene_t &sc, size_t n, const double *org, const do
                  int grid_blocks, int min_active, int tri_batch, hipStream_t s)
 {
     /* the unified walk (variant 3) reads fp32 nodes only */
-    if (sc.use_qnodes && variant != LH_VARIANT_UNIFIED)
+    if (sc.use_qnodes != 0 && variant != LH_VARIANT_UNIFIED)
         return launch_fmt<STACK, true>(sc, n, org, dir, prim, t, u, v, anyhit, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, s);
     return launch_fmt<STACK, false>(sc, n, org, dir, prim, t, u, v, anyhit, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, s);
 }
@@ -589,11 +694,17 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
 {
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) return 0;
-    /* stack entries needed <= tree depth + 1 (sentinel) */
-    if (sc->max_depth + 1 <= 32)
+    /* stack entries needed: 2-wide walks <= tree depth + 1 (sentinel); the 4-wide walk pushes
+     * up to 3 per level and writes up to 3 slots above its top */
+    uint32_t need = sc->max_depth + 1;
+    if (variant == LH_VARIANT_SPEC && sc->use_qnodes == 2) need = 3 * sc->q4_depth + 5;
+    if (need <= 32)
         return launch_stack<32>(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
                                 d_counters, d_workq, variant, grid_blocks, min_active, tri_batch, s);
-    if (sc->max_depth + 1 <= 64)
+    if (need <= 48)
+        return launch_stack<48>(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
+                                d_counters, d_workq, variant, grid_blocks, min_active, tri_batch, s);
+    if (need <= 64)
         return launch_stack<64>(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
                                 d_counters, d_workq, variant, grid_blocks, min_active, tri_batch, s);
     return -1;

@@ -55,13 +55,30 @@ static void trace_one(job_t *j, size_t i)
     j->c[3]++;
     if (b->ntris) {
         lh_ray32_t r; float tb = 1.0e38f, scene_r = 0.0f;
-        int32_t stack[LH_MAX_DEPTH + 8]; int sp = 1, cur = 0, np = 0, k;
+        int32_t stack[3 * LH_MAX_DEPTH + 8]; int sp = 1, cur = 0, np = 0, k;
         uint32_t pend[PEND];
         for (k = 0; k < 3; k++) { scene_r = fmaxf(scene_r, fabsf(b->bmin[k])); scene_r = fmaxf(scene_r, fabsf(b->bmax[k])); }
         lh_ray_setup(&r, o[0], o[1], o[2], d[0], d[1], d[2], scene_r);
         if (j->qnodes) lh_ray_setup_grid(&r, b->grid_lo, b->grid_step, scene_r);
         stack[0] = DONE;
         while (cur != DONE) {
+            while (cur >= 0 && j->qnodes == 2) {      /* 4-wide 16-bit grid nodes */
+                const lh_q4node_t *n = &b->q4nodes[cur]; float tn[4]; int h[4], c, nh = 0, order[4], m;
+                j->c[0]++;
+                for (c = 0; c < 4; c++) {
+                    h[c] = lh_slab_q(&r, n->q[c][0], n->q[c][1], n->q[c][2], n->q[c][3], n->q[c][4], n->q[c][5], tb, &tn[c])
+                           && n->ref[c] != DONE;
+                    if (h[c]) order[nh++] = c;
+                }
+                for (c = 1; c < nh; c++) {                 /* nearest first (same key as the kernel: low 2 bits = slot) */
+                    int x = order[c]; uint32_t kx, km; union { float f; uint32_t u; } cv;
+                    cv.f = tn[x]; kx = (cv.u & ~3u) | (uint32_t)x;
+                    for (m = c - 1; m >= 0; m--) { cv.f = tn[order[m]]; km = (cv.u & ~3u) | (uint32_t)order[m]; if (km <= kx) break; order[m + 1] = order[m]; }
+                    order[m + 1] = x;
+                }
+                if (nh == 0) cur = stack[--sp];
+                else { for (c = nh - 1; c >= 1; c--) stack[sp++] = n->ref[order[c]]; cur = n->ref[order[0]]; }
+            }
             while (cur >= 0) {
                 float tn0, tn1; int h0, h1; int32_t r0, r1;
                 j->c[0]++;
@@ -126,7 +143,7 @@ int lhm_trace(const lh_bvh_t *b, size_t n, const double *org, const double *dir,
     for (i = 0; i < nthreads; i++) {
         jobs[i].b = b; jobs[i].begin = n * (size_t)i / (size_t)nthreads; jobs[i].end = n * (size_t)(i + 1) / (size_t)nthreads;
         jobs[i].org = org; jobs[i].dir = dir; jobs[i].prim = prim; jobs[i].t = t; jobs[i].u = u; jobs[i].v = v;
-        jobs[i].occ = occ; jobs[i].anyhit = anyhit & 1; jobs[i].qnodes = (anyhit >> 1) & 1;
+        jobs[i].occ = occ; jobs[i].anyhit = anyhit & 1; jobs[i].qnodes = (anyhit >> 1) & 3;
     }
     if (nthreads == 1) run(&jobs[0]);
     else { for (i = 0; i < nthreads; i++) pthread_create(&th[i], NULL, run, &jobs[i]); for (i = 0; i < nthreads; i++) pthread_join(th[i], NULL); }
@@ -145,6 +162,8 @@ lh_bvh_t *lhm_build(uint32_t npos, const double *pos_xyz, uint32_t nidx, const u
 }
 void lhm_free(lh_bvh_t *b) { if (b) { lh_bvh_release(b); free(b); } }
 void lhm_info(const lh_bvh_t *b, uint32_t out[4]) { out[0] = b->ntris; out[1] = b->nnodes; out[2] = b->max_depth; out[3] = b->nleaves; }
+void lhm_info4(const lh_bvh_t *b, uint32_t out[2]) { out[0] = b->nq4nodes; out[1] = b->q4_depth; }
+const void *lhm_q4nodes(const lh_bvh_t *b) { return b->q4nodes; }
 double lhm_build_seconds(const lh_bvh_t *b) { return b->build_seconds; }
 const void *lhm_nodes(const lh_bvh_t *b) { return b->nodes; }
 const void *lhm_tri32(const lh_bvh_t *b) { return b->tri32; }

@@ -106,6 +106,17 @@ class Model:
         buf = (C.c_float * (12 * self.ntris)).from_address(self.lib().lhm_tri32(self.h))
         return np.frombuffer(buf, np.float32).reshape(-1, 12).copy()
 
+    def q4info(self):
+        L = self.lib(); o = np.zeros(2, np.uint32)
+        L.lhm_info4.argtypes = [C.c_void_p, _u32p]; L.lhm_info4(self.h, o.ctypes.data_as(_u32p))
+        return int(o[0]), int(o[1])
+
+    def q4nodes(self):
+        L = self.lib(); n, _ = self.q4info()
+        L.lhm_q4nodes.restype = C.c_void_p; L.lhm_q4nodes.argtypes = [C.c_void_p]
+        buf = (C.c_uint16 * (32 * n)).from_address(L.lhm_q4nodes(self.h))
+        return np.frombuffer(buf, np.uint16).reshape(-1, 32).copy()
+
     def qnodes(self):
         L = self.lib()
         L.lhm_qnodes.restype = C.c_void_p; L.lhm_qnodes.argtypes = [C.c_void_p]
@@ -116,7 +127,9 @@ class Model:
         buf = (C.c_uint16 * (16 * self.nnodes)).from_address(L.lhm_qnodes(self.h))
         return np.frombuffer(buf, np.uint16).reshape(-1, 16).copy(), grid
 
-    def trace(self, org, dr, anyhit=False, nthreads=4, qnodes=True):
+    def trace(self, org, dr, anyhit=False, nthreads=4, qnodes=2):
+        """qnodes: 0 fp32 2-wide nodes, 1 16-bit grid 2-wide, 2 16-bit grid 4-wide (the kernel's default)"""
+        qnodes = int(qnodes)
         org = np.ascontiguousarray(org, np.float64).reshape(-1, 3)
         dr = np.ascontiguousarray(dr, np.float64).reshape(-1, 3)
         n = org.shape[0]
@@ -125,11 +138,11 @@ class Model:
         if anyhit:
             occ = np.empty(n, np.uint8)
             self.lib().lhm_trace(self.h, n, org.ctypes.data_as(_dp), dr.ctypes.data_as(_dp), None, None, None, None,
-                                 occ.ctypes.data_as(C.POINTER(C.c_uint8)), 1 | (2 if qnodes else 0), cp, nthreads)
+                                 occ.ctypes.data_as(C.POINTER(C.c_uint8)), 1 | (qnodes << 1), cp, nthreads)
             return occ, dict(zip(("nodes", "tris", "exact", "rays"), map(int, cnt)))
         prim = np.empty(n, np.uint32); t = np.empty(n); u = np.empty(n); v = np.empty(n)
         self.lib().lhm_trace(self.h, n, org.ctypes.data_as(_dp), dr.ctypes.data_as(_dp), prim.ctypes.data_as(_u32p),
-                             t.ctypes.data_as(_dp), u.ctypes.data_as(_dp), v.ctypes.data_as(_dp), None, 2 if qnodes else 0, cp, nthreads)
+                             t.ctypes.data_as(_dp), u.ctypes.data_as(_dp), v.ctypes.data_as(_dp), None, qnodes << 1, cp, nthreads)
         return (prim, t, u, v), dict(zip(("nodes", "tris", "exact", "rays"), map(int, cnt)))
 
 

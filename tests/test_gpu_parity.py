@@ -152,13 +152,20 @@ def test_counters_match_host_model():
     P, idx, org, dr = po.soup(30000, 20000, 0.005, 61)
     acc = make_accel(P, idx)
     o_, d_ = torch_rays(org, dr)
-    _, cnt = acc.intersect_device(o_, d_, counters=True, variant=la.VARIANT_DIRECT)
+    _, cnt = acc.intersect_device(o_, d_, counters=True, variant=la.VARIANT_DIRECT)     # 2-wide 16-bit grid nodes
     m = Model(P, idx)
-    _, mc = m.trace(org, dr)
+    _, mc = m.trace(org, dr, qnodes=1)
     assert cnt["rays"] == mc["rays"] == 20000
     # v_rcp_f32 vs 1/x may move a handful of band decisions: counts agree to 1e-4
     for k in ("nodes", "tris"):
         assert abs(cnt[k] - mc[k]) <= 1e-4 * mc[k] + 4, (k, cnt[k], mc[k])
+    # default kernel: 4-wide nodes, leaves parked and tested in batches (the culling bound
+    # shrinks a little later than in the sequential model): same order of work, within 5 %
+    _, c4 = acc.intersect_device(o_, d_, counters=True)
+    _, m4 = m.trace(org, dr, qnodes=2)
+    for k in ("nodes", "tris"):
+        assert abs(c4[k] - m4[k]) <= 0.05 * m4[k], (k, c4[k], m4[k])
+    assert c4["nodes"] < 0.6 * cnt["nodes"]          # the 4-wide walk visits about half the records
 
 
 def test_full_size_properties_soup_1m():
