@@ -39,11 +39,24 @@ def tokenize(text):
                 yield ("w", tok)
 
 
-def parse(path, _depth=0):
+def _find_archive(name, base, root):
+    """Option "searchpath" "archive" of the example scenes lists sub-directories of the scene
+    directory: look next to the including file, then anywhere under the top-level RIB's directory"""
+    cand = os.path.join(base, name)
+    if os.path.exists(cand):
+        return cand
+    for dp, _, files in os.walk(root):
+        if name in files:
+            return os.path.join(dp, name)
+    raise FileNotFoundError(name)
+
+
+def parse(path, _depth=0, _root=None):
     """-> list of (verb, args) with arrays as python lists; ReadArchive is inlined"""
     toks = list(tokenize(open(path).read()))
     out, i = [], 0
     base = os.path.dirname(path)
+    root = _root or base
     while i < len(toks):
         kind, val = toks[i]
         assert kind == "w", "expected a RIB verb, got %r" % (toks[i],)
@@ -59,7 +72,7 @@ def parse(path, _depth=0):
             else:
                 args.append(toks[i][1]); i += 1
         if verb == "ReadArchive":
-            out += parse(os.path.join(base, args[0]), _depth + 1)
+            out += parse(_find_archive(args[0], base, root), _depth + 1, root)
         else:
             out.append((verb, args))
     return out
@@ -127,7 +140,7 @@ def render_verbs(verbs, width, height, gather_nsamples, pixel_samples=1, accel_m
         for verb, a in verbs:
             if verb == "Display":
                 n, T, V, keep = _params(a[3:])
-                L.RiDisplayV(a[0].encode(), b"file", a[2].encode(), n, T, V)
+                L.RiDisplayV(b"capture.hdr", b"file", b"rgb", n, T, V)   # .hdr name keeps the type "file" (display.c:148-185) = our capture driver
             elif verb == "Format":
                 pass                                   # overridden below (lsh applies CLI overrides the same way)
             elif verb == "PixelSamples":

@@ -106,5 +106,8 @@ if __name__ == "__main__":
     beam_fixture("beams_300", 300, 0.1, 78, 4000)
     # BASELINE config 1: examples/ambient_occlusion.rib, 256x256, 16 AO samples, 1 thread
     ao_fixture("ao_c1", "/root/reference/examples/ambient_occlusion/ambient_occlusion.rib", 256, 256, 16)
+    # examples/plane_sphere (BASELINE config 4's scene): 1 986 triangles, vertex normals (Ns is
+    # interpolated), ReadArchive, lh orientation; small frame, 2x2 pixel samples
+    ao_fixture("ao_ps", "/root/reference/examples/plane_sphere/Scene_DEFAULT_Set0.rib", 96, 96, 9, pixel_samples=2)
     # check values of the full S-soup-1M are pinned in
     # tests/test_oracle_vs_ref.py against the live reference, not stored here.

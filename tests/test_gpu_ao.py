@@ -13,18 +13,75 @@ from tests.test_oracle_ao import oracle_from_fixture
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def c1():
-    g = load_golden("ao_c1")
+def load_case(name):
+    g = load_golden(name)
     o = oracle_from_fixture(g)
     acc = la.HipAccel(0)
     for k in range(int(g["ngeoms"])):
         acc.add_mesh(g["pos%d" % k], g["idx%d" % k])
+        if ("nrm%d" % k) in g.files:
+            acc.set_normals(k, g["nrm%d" % k], int(g["two_side%d" % k]))
     acc.commit()
     ocam = po.Camera.from_ref(g["camera"])
     cam = la.Camera.make(ocam.width, ocam.height, ocam.flength, list(ocam.cam2world), ocam.rh)
-    img, rec = o.render_ao(ocam, 1, 16)
+    img, rec = o.render_ao(ocam, int(g["pixel_samples"]), int(g["gather_nsamples"]))
     return {"g": g, "oracle": o, "acc": acc, "ocam": ocam, "cam": cam, "img": img, "rec": rec}
+
+
+@pytest.fixture(scope="module")
+def c1():
+    return load_case("ao_c1")
+
+
+@pytest.fixture(scope="module")
+def ps():
+    return load_case("ao_ps")
+
+
+def test_plane_sphere_ray_dump_and_normals_pipeline(ps):
+    """examples/plane_sphere (interpolated vertex normals, lh camera, 2x2 pixel samples):
+    the reference's ray dump -> bit-exact hit records; the device tile pipeline replayed bucket by
+    bucket with the reference's MT19937 stream -> hit epilogue (Ns lerp, basis) bit-exact, frame equal
+    up to libm sin/cos ulps"""
+    import torch
+    g, rec, acc, cam, o = ps["g"], ps["rec"], ps["acc"], ps["cam"], ps["oracle"]
+    o_ = torch.from_numpy(rec["org"]).cuda(); d_ = torch.from_numpy(rec["dir"]).cuda()
+    out = acc.intersect_device(o_, d_); torch.cuda.synchronize()
+    assert np.array_equal(out[0].cpu().numpy().view(np.uint32), g["prim"])
+    hit = g["prim"] != po.MISS
+    assert np.array_equal(out[1].cpu().numpy()[hit], g["t_hit"]) and np.array_equal(out[3].cpu().numpy()[hit], g["v_hit"])
+    W, H, PS, NS = int(g["width"]), int(g["height"]), int(g["pixel_samples"]), int(g["gather_nsamples"])
+    N = int(np.sqrt(NS)) ** 2
+    nbx = -(-W // 32); nby = -(-H // 32)
+    order = np.zeros(2 * nbx * nby, np.uint32)
+    nb = po.lib().lo_bucket_order(W, H, 32, order.ctypes.data_as(po.C.POINTER(po.C.c_uint)))
+    mt = np.empty(2 * N * W * H * PS * PS + 64); po.lib().lo_mt_stream(4357, mt.size, mt.ctypes.data_as(po._dp))
+    img = np.zeros((H, W, 3), np.float32); used = 0; checked = False
+    po.lib().lo_ortho_basis.argtypes = [po._dp, po._dp]
+    for b in range(nb):
+        bx, by = int(order[2 * b]) * 32, int(order[2 * b + 1]) * 32
+        bw, bh = min(32, W - bx), min(32, H - by)
+        uni = torch.from_numpy(mt[used:used + 2 * N * bw * bh * PS * PS].copy()).cuda()
+        rgb, st = acc.render_ao_tile(cam, bx, by, bw, bh, PS, NS, uniforms=uni)
+        used += 2 * N * st["primary_hits"]
+        img[H - (by + bh):H - by, bx:bx + bw] = rgb.cpu().numpy()
+        if not checked and st["primary_hits"] > 50:
+            checked = True
+            recs = acc.scratch(7, np.float64, 12); prim = acc.scratch(2, np.uint32, 1)
+            t = acc.scratch(3, np.float64, 1); u = acc.scratch(4, np.float64, 1); v = acc.scratch(5, np.float64, 1)
+            po_ = acc.scratch(0, np.float64, 3); pd_ = acc.scratch(1, np.float64, 3)
+            slot = 0
+            for i in np.nonzero(prim != po.MISS)[0]:
+                P = np.empty(3); Ng = np.empty(3); Ns = np.empty(3); B = np.empty((3, 3))
+                po.lib().lo_state_build(o.h, int(prim[i]), float(t[i]), float(u[i]), float(v[i]),
+                                        po_[i].ctypes.data_as(po._dp), pd_[i].ctypes.data_as(po._dp),
+                                        P.ctypes.data_as(po._dp), Ng.ctypes.data_as(po._dp), Ns.ctypes.data_as(po._dp), None)
+                po.lib().lo_ortho_basis(B.ctypes.data_as(po._dp), Ns.ctypes.data_as(po._dp))
+                assert np.array_equal(recs[slot], np.concatenate([P + Ns * 1.0e-6, B[0], B[1], Ns])), i
+                slot += 1
+    assert checked
+    diff = np.abs(img - g["image"])
+    assert int((diff[..., 0] > 0).sum()) <= 12 and diff.max() <= 0.15
 
 
 def test_c1_ray_dump_hit_records(c1):

@@ -41,6 +41,21 @@ def test_ao_c1_golden():
     assert int(g["exact_t_ties"]) == 0
 
 
+def test_ao_plane_sphere_golden():
+    """examples/plane_sphere: vertex normals (Ns = (1-u-v)n0+u n1+v n2), "lh" orientation,
+    ReadArchive, 2x2 Hammersley pixel samples, 9 AO samples"""
+    g = load_golden("ao_ps")
+    o = oracle_from_fixture(g)
+    assert o.ntriangles == 1986
+    img, rec = o.render_ao(po.Camera.from_ref(g["camera"]), int(g["pixel_samples"]), int(g["gather_nsamples"]))
+    assert len(rec["prim"]) == int(g["nrays"])
+    assert hashlib.sha256(rec["org"].tobytes() + rec["dir"].tobytes()).hexdigest() == str(g["rays_sha256"])
+    assert np.array_equal(rec["prim"], g["prim"])
+    hit = rec["prim"] != po.MISS
+    assert np.array_equal(rec["t"][hit], g["t_hit"]) and np.array_equal(rec["u"][hit], g["u_hit"])
+    assert np.array_equal(img, g["image"])
+
+
 def test_mt19937_reference_stream():
     """randomMT2 (src/base/random.c:211-250): seed 4357, 1998-style seeding.  Known answers
     recorded from the compiled reference (randomMT2 called 2000 times on a fresh thread id)."""
