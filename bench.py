@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=1_500_000, help="cpu_baseline sample size")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ao", action="store_true", help="skip the secondary AO-frame leg")
+    ap.add_argument("--no-pt", action="store_true", help="skip the secondary path-traced leg")
+    ap.add_argument("--pt-size", type=int, default=1024)
+    ap.add_argument("--pt-spp", type=int, default=64)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--device-override", type=int, default=None,
                     help="testing only: put every rank on this device (2 ranks on a 1-GPU box, use with --backend gloo)")
@@ -172,6 +175,10 @@ def main():
         ao = ao_frame_leg(la, acc_device=local, rank=rank, world=world, size=args.ao_size, nsamples=args.ao_samples,
                           steps=max(2, args.steps), dev=dev, tess=args.ao_tess)
 
+    pt = None
+    if not args.no_pt:
+        pt = pt_frame_leg(la, acc_device=local, rank=rank, world=world, size=args.pt_size, spp=args.pt_spp, dev=dev)
+
     if rank == 0:
         total_rays = n * world * args.steps
         value = total_rays / elapsed / 1e6
@@ -207,6 +214,8 @@ def main():
         }
         if ao is not None:
             res["ao_render"] = ao
+        if pt is not None:
+            res["pt_render"] = pt
         if not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(po, P, idx, first_org, first_dir)
         print(json.dumps(res), flush=True)
@@ -257,6 +266,48 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
         return None
     return {"workload": "examples/ambient_occlusion scene tessellated to %d tris, %dx%d, %d AO samples, frame wall incl. ray gen + tile gather"
                         % (ntri, size, size, nsamples), "triangles": ntri, "tile": tile,
+            "rays_per_frame": int(rays.item()), "frame_ms": round(tmax.item() * 1e3, 3),
+            "value": round(rays.item() / tmax.item() / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
+            "image_mean": float(img.mean().item())}
+
+
+def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
+    """Secondary leg (BASELINE config 4): examples/plane_sphere (the 1 986 triangles + vertex normals
+    the reference's RIB ingest produced, tests/golden/ao_ps.npz), size x size, spp paths per pixel,
+    diffuse wavefront path tracer, tiles sharded tile_id % world + all-gather of tile slabs."""
+    import torch
+    from lucille_amd import render
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ao_ps.npz"))
+    acc = la.HipAccel(acc_device)
+    for k in range(int(g["ngeoms"])):
+        acc.add_mesh(g["pos%d" % k], g["idx%d" % k])
+        if ("nrm%d" % k) in g.files:
+            acc.set_normals(k, g["nrm%d" % k], int(g["two_side%d" % k]))
+    acc.commit()
+    c = g["camera"]
+    cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
+    times = []; st = None; img = None
+    for it in range(3):
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+        img, st = render.render_pt_frame_sharded(acc, cam, spp, rank, world, tile=max(64, size // 8), spp_chunk=16,
+                                                 kd=0.8, env=(1.0, 1.0, 1.0), max_vertices=8, seed=7)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    rdev = dev if (world == 1 or torch.distributed.get_backend() == "nccl") else torch.device("cpu")
+    rays = torch.tensor([float(st["rays"])], dtype=torch.float64, device=rdev)
+    tmax = torch.tensor([min(times)], dtype=torch.float64, device=rdev)
+    if world > 1:
+        torch.distributed.all_reduce(rays); torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    acc.close()
+    if rank != 0:
+        return None
+    return {"workload": "examples/plane_sphere (1986 tris, vertex normals), %dx%d, %d spp, <=8 path vertices, kd 0.8, frame wall incl. ray gen, shading, compaction, tile gather"
+                        % (size, size, spp),
             "rays_per_frame": int(rays.item()), "frame_ms": round(tmax.item() * 1e3, 3),
             "value": round(rays.item() / tmax.item() / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
             "image_mean": float(img.mean().item())}

@@ -149,6 +149,20 @@ int  lh_render_ao_tile(lh_accel_t *accel, const lh_camera_t *cam, int x0, int y0
                        int pixel_samples, int gather_nsamples, uint64_t seed,
                        const void *d_uniforms, void *d_rgb, lh_tile_stats_t *stats, void *stream);
 
+/* one path-traced tile on the device (BASELINE config 4: the reference's pathtrace.c is dead
+ * code; its documented structure -- camera sample, Russian roulette on the reflectance,
+ * cosine-sampled diffuse bounces to a vertex limit, environment radiance on escape -- re-expressed
+ * as closest-hit batches, every bounce through the same kernel as ri_raytrace).  Adds
+ * spp_count samples (numbered spp_begin...) of spp_total to d_rgb (float[h][w][3], image
+ * orientation; the caller zeroes it before the first pass).  kd: diffuse reflectance in (0,1];
+ * env_rgb: constant environment radiance.  stats: rays traced / paths. */
+typedef struct lh_pt_stats { uint64_t paths, rays, max_depth_reached; } lh_pt_stats_t;
+
+int  lh_render_pt_tile(lh_accel_t *accel, const lh_camera_t *cam, int x0, int y0, int w, int h,
+                       int spp_begin, int spp_count, int spp_total, int max_path_vertices,
+                       float kd, const float env_rgb[3], uint64_t seed, void *d_rgb,
+                       lh_pt_stats_t *stats, void *stream);
+
 /* device scratch of the last lh_render_ao_tile call (for tests / pipelines):
  * which: 0 primary org, 1 primary dir, 2 prim, 3 t, 4 u, 5 v, 6 slot_of_sample,
  *        7 hit records (12 doubles: AO origin, tangent, binormal, Ns), 8 AO org, 9 AO dir,

@@ -58,6 +58,10 @@ class Camera(C.Structure):
         return c
 
 
+class PtStats(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("max_depth_reached", C.c_uint64)]
+
+
 class TileStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("primary_hits", C.c_uint64), ("ao_rays", C.c_uint64),
                 ("ao_occluded", C.c_uint64)]
@@ -69,7 +73,7 @@ ABI_SYMBOLS = [
     "lh_accel_destroy", "lh_accel_info", "lh_accel_prim_lookup", "lh_accel_intersect1",
     "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted",
     "lh_accel_set_grid", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
-    "lh_render_ao_tile", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device",
+    "lh_render_ao_tile", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device", "lh_render_pt_tile",
 ]
 
 _lib = None
@@ -108,6 +112,8 @@ def lib():
     L.lh_render_ao_tile.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, C.c_uint64, vp, vp,
                                     C.POINTER(TileStats), vp]
     L.lh_render_scratch.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz)]
+    L.lh_render_pt_tile.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, i32, i32, C.c_float,
+                                    C.POINTER(C.c_float * 3), C.c_uint64, vp, C.POINTER(PtStats), vp]
     L.lh_accel_beam_visibility_host.argtypes = [vp, sz, vp, vp, vp]
     L.lh_accel_beam_visibility_device.argtypes = [vp, sz, vp, vp, vp, vp]
     _lib = L
@@ -295,6 +301,21 @@ class HipAccel:
         _check(self.L.lh_render_ao_tile(self.h, C.byref(cam), x0, y0, w, h, pixel_samples, gather_nsamples, int(seed),
                                         _dptr(uniforms), _dptr(out), C.byref(st), C.c_void_p(stream)),
                "lh_render_ao_tile")
+        return out, {k: int(getattr(st, k)) for k, _ in st._fields_}
+
+    def render_pt_tile(self, cam, x0, y0, w, h, spp_begin, spp_count, spp_total, max_vertices=8, kd=0.8,
+                       env=(1.0, 1.0, 1.0), seed=1, out=None, stream=None):
+        """adds spp_count path-traced samples to `out` (float32 [h,w,3] CUDA, zeroed if None) -> (out, stats)"""
+        import torch
+        dev = torch.device("cuda", self.device)
+        if out is None:
+            out = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        st = PtStats(); e = (C.c_float * 3)(*[float(x) for x in env])
+        _check(self.L.lh_render_pt_tile(self.h, C.byref(cam), x0, y0, w, h, spp_begin, spp_count, spp_total, max_vertices,
+                                        float(kd), C.byref(e), int(seed), _dptr(out), C.byref(st), C.c_void_p(stream)),
+               "lh_render_pt_tile")
         return out, {k: int(getattr(st, k)) for k, _ in st._fields_}
 
     def scratch(self, which, dtype, width):

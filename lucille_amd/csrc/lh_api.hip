@@ -77,6 +77,7 @@ struct lh_accel {
     double *h_nrm9; void *d_nrm9;
     /* tile-render scratch (lh_render_ao_tile) */
     lh_buf r_org, r_dir, r_prim, r_t, r_u, r_v, r_slot, r_hitrec, r_aorg, r_adir, r_occ, r_blocks, r_key;
+    lh_buf p_org2, p_dir2, p_path, p_path2, p_thr, p_thr2, p_rad, p_alive;   /* path tracer */
     unsigned long long *d_total;
     size_t r_nsamples, r_nslots, r_nao;
 };
@@ -164,7 +165,8 @@ static void free_buf(lh_buf *b) { if (b->p) (void)hipFree(b->p); b->p = NULL; b-
 static void release_device(lh_accel_t *a)
 {
     lh_buf *bufs[] = {&a->r_org, &a->r_dir, &a->r_prim, &a->r_t, &a->r_u, &a->r_v, &a->r_slot, &a->r_hitrec,
-                      &a->r_aorg, &a->r_adir, &a->r_occ, &a->r_blocks, &a->r_key};
+                      &a->r_aorg, &a->r_adir, &a->r_occ, &a->r_blocks, &a->r_key,
+                      &a->p_org2, &a->p_dir2, &a->p_path, &a->p_path2, &a->p_thr, &a->p_thr2, &a->p_rad, &a->p_alive};
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) free_buf(bufs[i]);
     if (a->d_total) (void)hipFree(a->d_total);
     if (a->d_nrm9) (void)hipFree(a->d_nrm9);
@@ -637,5 +639,69 @@ extern "C" int lh_accel_beam_visibility_host(lh_accel_t *a, size_t n, const doub
     if (lh_accel_beam_visibility_device(a, n, base, base + bo, base + bo + bd, a->stream) != 0) return -1;
     HIPCHK(hipMemcpyAsync(result, base + bo + bd, br, hipMemcpyDeviceToHost, a->stream));
     HIPCHK(hipStreamSynchronize(a->stream));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* wavefront path tracer                                                    */
+/* ------------------------------------------------------------------------ */
+extern "C" int lh_pt_launch_primary(const lh_camera_t *cam, int x0, int y0, int w, int h, int spp, int s0,
+                                    unsigned long long seed, double *d_org, double *d_dir, uint32_t *d_path_of,
+                                    float *d_thr, void *stream);
+extern "C" int lh_pt_launch_shade(size_t n, const lh_dev_scene_t *sc, const double *d_nrm9, int depth, int max_depth,
+                                  float kd, unsigned long long seed, int s0, int spp, int x0, int y0, int w,
+                                  int full_width, double *d_org, double *d_dir, const uint32_t *d_prim,
+                                  const double *d_t, const double *d_u, const double *d_v, const uint32_t *d_path_of,
+                                  float *d_thr, float *d_radiance, uint8_t *d_alive, uint32_t *d_blocks,
+                                  unsigned long long *d_total, double *d_org2, double *d_dir2, uint32_t *d_path_of2,
+                                  float *d_thr2, void *stream);
+extern "C" int lh_pt_launch_resolve(int w, int h, int spp, float inv_total_spp, const float env[3],
+                                    const float *d_radiance, float *d_rgb, void *stream);
+
+extern "C" int lh_render_pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int s0, int spp,
+                                 int spp_total, int max_vertices, float kd, const float env[3], uint64_t seed,
+                                 void *d_rgb, lh_pt_stats_t *stats, void *stream)
+{
+    if (!a || !a->committed) return fail("lh_render_pt_tile: accel not committed");
+    if (!cam || !d_rgb || !env) return fail("lh_render_pt_tile: NULL argument");
+    if (w <= 0 || h <= 0 || spp < 1 || spp_total < spp || max_vertices < 2 || !(kd > 0.0f) || kd > 1.0f)
+        return fail("lh_render_pt_tile: bad arguments");
+    HIPCHK(hipSetDevice(a->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t S = (size_t)w * h * spp;
+    const unsigned nb = (unsigned)((S + 255) / 256);
+    if (ensure_buf(&a->r_org, S * 24) || ensure_buf(&a->r_dir, S * 24) || ensure_buf(&a->p_org2, S * 24) ||
+        ensure_buf(&a->p_dir2, S * 24) || ensure_buf(&a->r_prim, S * 4) || ensure_buf(&a->r_t, S * 8) ||
+        ensure_buf(&a->r_u, S * 8) || ensure_buf(&a->r_v, S * 8) || ensure_buf(&a->p_path, S * 4) ||
+        ensure_buf(&a->p_path2, S * 4) || ensure_buf(&a->p_thr, S * 4) || ensure_buf(&a->p_thr2, S * 4) ||
+        ensure_buf(&a->p_rad, S * 4) || ensure_buf(&a->p_alive, S) || ensure_buf(&a->r_blocks, (size_t)nb * 4)) return -1;
+    HIPCHK(hipMemsetAsync(a->p_rad.p, 0, S * 4, s));
+    double *org = (double *)a->r_org.p, *dir = (double *)a->r_dir.p, *org2 = (double *)a->p_org2.p, *dir2 = (double *)a->p_dir2.p;
+    uint32_t *path = (uint32_t *)a->p_path.p, *path2 = (uint32_t *)a->p_path2.p;
+    float *thr = (float *)a->p_thr.p, *thr2 = (float *)a->p_thr2.p;
+    if (lh_pt_launch_primary(cam, x0, y0, w, h, spp, s0, seed, org, dir, path, thr, s) != 0) return fail("pt primary launch failed");
+    size_t n = S; uint64_t rays = 0; int depth = 0;
+    while (n > 0) {
+        if (launch(a, n, org, dir, a->r_prim.p, a->r_t.p, a->r_u.p, a->r_v.p, NULL, LH_MODE_CLOSEST, LH_VARIANT_DEFAULT, NULL, s) != 0) return -1;
+        rays += n;
+        if (a->bvh.ntris == 0) {
+            /* empty scene: every path escapes at once */
+        }
+        if (lh_pt_launch_shade(n, &a->dev, (const double *)a->d_nrm9, depth, max_vertices, kd, seed, s0, spp, x0, y0, w,
+                               cam->width, org, dir, (const uint32_t *)a->r_prim.p, (const double *)a->r_t.p,
+                               (const double *)a->r_u.p, (const double *)a->r_v.p, path, thr, (float *)a->p_rad.p,
+                               (uint8_t *)a->p_alive.p, (uint32_t *)a->r_blocks.p, a->d_total, org2, dir2, path2, thr2, s) != 0)
+            return fail("pt shade launch failed: %s", hipGetErrorString(hipGetLastError()));
+        unsigned long long alive = 0;
+        HIPCHK(hipMemcpyAsync(&alive, a->d_total, sizeof(alive), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        n = (size_t)alive; depth++;
+        { double *t1 = org; org = org2; org2 = t1; t1 = dir; dir = dir2; dir2 = t1; }
+        { uint32_t *t2 = path; path = path2; path2 = t2; float *t3 = thr; thr = thr2; thr2 = t3; }
+    }
+    if (lh_pt_launch_resolve(w, h, spp, 1.0f / (float)spp_total, env, (const float *)a->p_rad.p, (float *)d_rgb, s) != 0)
+        return fail("pt resolve launch failed");
+    HIPCHK(hipStreamSynchronize(s));
+    if (stats) { stats->paths = S; stats->rays = rays; stats->max_depth_reached = (uint64_t)depth; }
     return 0;
 }

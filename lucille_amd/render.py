@@ -80,3 +80,26 @@ def assemble(slab, W, H, tile, rank, world):
             t = out[r][k].view(tile, tile, 3)
             img[H - (y0 + h):H - y0, x0:x0 + w] = t[:h, :w]
     return img
+
+
+def render_pt_frame_sharded(acc, cam, spp, rank, world, tile=256, spp_chunk=16, **kw):
+    """Path-traced frame (BASELINE config 4): tiles `tile_id % world == rank`, samples in passes
+    of `spp_chunk` per tile (bounded device memory), one all-gather of tile slabs.
+    Returns (image on rank 0 | None, local stats)."""
+    import torch
+    W, H = cam.width, cam.height
+    tiles = shard.tile_grid(W, H, tile)
+    mine = shard.tiles_of_rank(len(tiles), rank, world)
+    dev = torch.device("cuda", acc.device)
+    slab = torch.zeros((len(mine), tile * tile * 3), dtype=torch.float32, device=dev)
+    tot = {"paths": 0, "rays": 0}
+    for k, tid in enumerate(mine):
+        x0, y0, w, h = tiles[tid]
+        out = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+        for s0 in range(0, spp, spp_chunk):
+            _, st = acc.render_pt_tile(cam, x0, y0, w, h, s0, min(spp_chunk, spp - s0), spp, out=out, **kw)
+            tot["paths"] += st["paths"]; tot["rays"] += st["rays"]
+        t = torch.zeros((tile, tile, 3), dtype=torch.float32, device=dev)
+        t[:h, :w] = out
+        slab[k] = t.view(-1)
+    return assemble(slab, W, H, tile, rank, world), tot
