@@ -291,7 +291,7 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev); t0 = time.perf_counter()
-        img, st = render.render_pt_frame_sharded(acc, cam, spp, rank, world, tile=max(64, size // 8), spp_chunk=16,
+        img, st = render.render_pt_frame_sharded(acc, cam, spp, rank, world, tile=(size if world == 1 else max(128, size // 4)), spp_chunk=16,
                                                  kd=0.8, env=(1.0, 1.0, 1.0), max_vertices=8, seed=7)
         torch.cuda.synchronize(dev)
         if world > 1:
