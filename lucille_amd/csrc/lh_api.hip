@@ -318,7 +318,8 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
         HIPCHK(hipGetDeviceProperties(&prop, a->device));
         uint32_t need = a->bvh.max_depth + 1;
         if (a->dev.use_qnodes == 2) need = 3 * a->bvh.q4_depth + 5;
-        const uint32_t stack = need <= 32 ? 32 : (need <= 48 ? 48 : 64);
+        uint32_t stack = (need + 1u) & ~1u;
+        if (stack < 16) stack = 16;
         int per_cu = (int)(160u / stack);                     /* LDS: stack KiB per 256-thread workgroup */
         if (per_cu > 5) per_cu = 5;
         if (per_cu < 1) per_cu = 1;

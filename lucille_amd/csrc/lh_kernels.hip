@@ -136,7 +136,7 @@ __device__ __forceinline__ void lane_init(Lane &L, const lh_dev_scene_t &sc,
 /* the per-lane traversal body; runs while the lane has work, leaves when
  * `stop()` says the wave should regroup.  Returns with L.cur == kDone when the
  * ray is finished. */
-template <int STACK, bool ANYHIT, bool COUNT, bool BURST, bool QN>
+template <bool ANYHIT, bool COUNT, bool BURST, bool QN>
 __device__ __forceinline__ void traverse(Lane &L, const lh_dev_scene_t &sc,
                                          int (*stk)[LH_BLOCK], const int tid,
                                          double ox, double oy, double oz,
@@ -210,7 +210,7 @@ __device__ __forceinline__ void traverse(Lane &L, const lh_dev_scene_t &sc,
  * 21 % VALU lane utilisation on incoherent rays: rocprofv3 SQ_THREAD_CYCLES_VALU /
  * (SQ_ACTIVE_INST_VALU*64), profiles/r01_pmc_diag.md).  A leaf with k triangles is k
  * iterations: the leaf reference carries (first, count-1) and is advanced in place. */
-template <int STACK, bool ANYHIT, bool COUNT>
+template <bool ANYHIT, bool COUNT>
 __device__ __forceinline__ void traverse_unified(Lane &L, const lh_dev_scene_t &sc,
                                                  int (*stk)[LH_BLOCK], const int tid,
                                                  double ox, double oy, double oz,
@@ -282,7 +282,7 @@ __device__ __forceinline__ void traverse_unified(Lane &L, const lh_dev_scene_t &
  * pass.  A lane that meets a second leaf while one is parked waits for the next pass.
  * The node step is branch-free: unconditional LDS push (slot sp is free space), pop read
  * of slot sp-1 (slot 0 holds the sentinel), selects for everything else. */
-template <int STACK, bool ANYHIT, bool COUNT, bool QN>
+template <bool ANYHIT, bool COUNT, bool QN>
 __device__ __forceinline__ void traverse_spec(Lane &L, int &pend, const lh_dev_scene_t &sc,
                                               int (*stk)[LH_BLOCK], const int tid,
                                               double ox, double oy, double oz,
@@ -369,7 +369,7 @@ __device__ __forceinline__ void traverse_spec(Lane &L, int &pend, const lh_dev_s
  * nearest on top; misses: above the new top, i.e. into free space) and the next reference
  * is read back from the new top -- which is the nearest hit, or the previous top when
  * nothing was hit (a pop).  Leaves are parked and tested in batches as in traverse_spec. */
-template <int STACK, bool ANYHIT, bool COUNT>
+template <bool ANYHIT, bool COUNT>
 __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_scene_t &sc,
                                                int (*stk)[LH_BLOCK], const int tid,
                                                double ox, double oy, double oz,
@@ -503,13 +503,14 @@ __device__ __forceinline__ void add_counters(unsigned long long *c, uint32_t nod
 /* ------------------------------------------------------------------------ */
 /* variant 0: one ray per lane                                              */
 /* ------------------------------------------------------------------------ */
-template <int STACK, bool ANYHIT, bool COUNT, bool QN>
+template <bool ANYHIT, bool COUNT, bool QN>
 __global__ __launch_bounds__(LH_BLOCK) void k_trace_direct(
     lh_dev_scene_t sc, size_t n, const double *__restrict__ org, const double *__restrict__ dir,
     uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
     double *__restrict__ v, uint8_t *__restrict__ occ, unsigned long long *counters)
 {
-    __shared__ int stk[STACK][LH_BLOCK];
+    extern __shared__ int lh_stack_lds[];          /* [stack entries][LH_BLOCK], sized at launch */
+    int (*stk)[LH_BLOCK] = (int (*)[LH_BLOCK])lh_stack_lds;
     const int tid = threadIdx.x;
     const size_t i = (size_t)blockIdx.x * LH_BLOCK + tid;
     if (i >= n) return;
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_direct(
     uint32_t cn = 0, ct = 0, ce = 0;
     lane_init(L, sc, ox, oy, oz, dx, dy, dz);
     stk[0][tid] = kDone;
-    traverse<STACK, ANYHIT, COUNT, false, QN>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, 0);
+    traverse<ANYHIT, COUNT, false, QN>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, 0);
     finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
     write_out<ANYHIT>(i, L, best, prim, t, u, v, occ);
     if (COUNT) add_counters(counters, cn, ct, ce, 1);
@@ -528,14 +529,15 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_direct(
 /* ------------------------------------------------------------------------ */
 /* variant 1: persistent wavefronts, 64-ray chunks from a global cursor     */
 /* ------------------------------------------------------------------------ */
-template <int STACK, bool ANYHIT, bool COUNT, bool QN>
+template <bool ANYHIT, bool COUNT, bool QN>
 __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_wave(
     lh_dev_scene_t sc, size_t n, const double *__restrict__ org, const double *__restrict__ dir,
     uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
     double *__restrict__ v, uint8_t *__restrict__ occ, unsigned long long *counters,
     unsigned long long *cursor)
 {
-    __shared__ int stk[STACK][LH_BLOCK];
+    extern __shared__ int lh_stack_lds[];          /* [stack entries][LH_BLOCK], sized at launch */
+    int (*stk)[LH_BLOCK] = (int (*)[LH_BLOCK])lh_stack_lds;
     const int tid = threadIdx.x, lane = tid & 63;
     uint32_t cn = 0, ct = 0, ce = 0, cr = 0;
     for (;;) {
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_wave(
             Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM};
             lane_init(L, sc, ox, oy, oz, dx, dy, dz);
             stk[0][tid] = kDone;
-            traverse<STACK, ANYHIT, COUNT, false, QN>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, 0);
+            traverse<ANYHIT, COUNT, false, QN>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, 0);
             finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
             write_out<ANYHIT>(i, L, best, prim, t, u, v, occ);
             if (COUNT) cr++;
@@ -562,14 +564,15 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_wave(
 /* ------------------------------------------------------------------------ */
 /* variant 2: persistent wavefronts with ballot-compacted lane refill       */
 /* ------------------------------------------------------------------------ */
-template <int STACK, bool ANYHIT, bool COUNT, int WALK, bool QN>
+template <bool ANYHIT, bool COUNT, int WALK, bool QN>
 __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
     lh_dev_scene_t sc, size_t n, const double *__restrict__ org, const double *__restrict__ dir,
     uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
     double *__restrict__ v, uint8_t *__restrict__ occ, unsigned long long *counters,
     unsigned long long *cursor, int min_active, int tri_batch)
 {
-    __shared__ int stk[STACK][LH_BLOCK];
+    extern __shared__ int lh_stack_lds[];          /* [stack entries][LH_BLOCK], sized at launch */
+    int (*stk)[LH_BLOCK] = (int (*)[LH_BLOCK])lh_stack_lds;
     const int tid = threadIdx.x;
     uint32_t cn = 0, ct = 0, ce = 0, cr = 0;
     Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM};
@@ -614,74 +617,73 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         /* ---- walk until too few lanes remain active ---------------------- */
         const int thresh = exhausted ? 1 : min_active;
         if (WALK == 3) {
-            traverse_spec4<STACK, ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch);
+            traverse_spec4<ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch);
         } else if (WALK == 2) {
             /* every lane enters (idle lanes just vote in the ballots) */
-            traverse_spec<STACK, ANYHIT, COUNT, QN>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch);
+            traverse_spec<ANYHIT, COUNT, QN>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch);
         } else if (L.cur != kDone) {
-            if (WALK == 1) traverse_unified<STACK, ANYHIT, COUNT>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
-            else traverse<STACK, ANYHIT, COUNT, true, QN>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
+            if (WALK == 1) traverse_unified<ANYHIT, COUNT>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
+            else traverse<ANYHIT, COUNT, true, QN>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
         }
     }
     if (COUNT) add_counters(counters, cn, ct, ce, cr);
 }
 
-template <int STACK, bool ANYHIT, bool COUNT, bool QN>
+template <bool ANYHIT, bool COUNT, bool QN>
 int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const double *dir,
                uint32_t *prim, double *t, double *u, double *v, uint8_t *occ,
                unsigned long long *counters, unsigned long long *cursor, int variant,
-               int grid_blocks, int min_active, int tri_batch, hipStream_t s)
+               int grid_blocks, int min_active, int tri_batch, size_t lds_bytes, hipStream_t s)
 {
     if (variant == LH_VARIANT_DIRECT) {
         const size_t blocks = (n + LH_BLOCK - 1) / LH_BLOCK;
         if (blocks > 0x7fffffffull) return -1;
-        hipLaunchKernelGGL((k_trace_direct<STACK, ANYHIT, COUNT, QN>), dim3((unsigned)blocks), dim3(LH_BLOCK), 0, s,
+        hipLaunchKernelGGL((k_trace_direct<ANYHIT, COUNT, QN>), dim3((unsigned)blocks), dim3(LH_BLOCK), lds_bytes, s,
                            sc, n, org, dir, prim, t, u, v, occ, counters);
     } else {
         if (hipMemsetAsync(cursor, 0, sizeof(unsigned long long), s) != hipSuccess) return -1;
         if (variant == LH_VARIANT_PERSIST_WAVE)
-            hipLaunchKernelGGL((k_trace_persist_wave<STACK, ANYHIT, COUNT, QN>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
+            hipLaunchKernelGGL((k_trace_persist_wave<ANYHIT, COUNT, QN>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor);
         else if (variant == LH_VARIANT_PERSIST_LANE)
-            hipLaunchKernelGGL((k_trace_persist_lane<STACK, ANYHIT, COUNT, 0, QN>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 0, QN>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
         else if (variant == LH_VARIANT_UNIFIED)
-            hipLaunchKernelGGL((k_trace_persist_lane<STACK, ANYHIT, COUNT, 1, false>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 1, false>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
         else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2)
-            hipLaunchKernelGGL((k_trace_persist_lane<STACK, ANYHIT, COUNT, 3, true>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 3, true>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
         else
-            hipLaunchKernelGGL((k_trace_persist_lane<STACK, ANYHIT, COUNT, 2, QN>), dim3(grid_blocks), dim3(LH_BLOCK), 0, s,
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 2, QN>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <int STACK, bool QN>
+template <bool QN>
 int launch_fmt(const lh_dev_scene_t &sc, size_t n, const double *org, const double *dir,
                uint32_t *prim, double *t, double *u, double *v, int anyhit, uint8_t *occ,
                unsigned long long *counters, unsigned long long *cursor, int variant,
-               int grid_blocks, int min_active, int tri_batch, hipStream_t s)
+               int grid_blocks, int min_active, int tri_batch, size_t lds_bytes, hipStream_t s)
 {
     if (anyhit) {
-        if (counters) return launch_one<STACK, true, true, QN>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, s);
-        return launch_one<STACK, true, false, QN>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, s);
+        if (counters) return launch_one<true, true, QN>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, lds_bytes, s);
+        return launch_one<true, false, QN>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, lds_bytes, s);
     }
-    if (counters) return launch_one<STACK, false, true, QN>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, s);
-    return launch_one<STACK, false, false, QN>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, s);
+    if (counters) return launch_one<false, true, QN>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, lds_bytes, s);
+    return launch_one<false, false, QN>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, lds_bytes, s);
 }
 
-template <int STACK>
 int launch_stack(const lh_dev_scene_t &sc, size_t n, const double *org, const double *dir,
                  uint32_t *prim, double *t, double *u, double *v, int anyhit, uint8_t *occ,
                  unsigned long long *counters, unsigned long long *cursor, int variant,
-                 int grid_blocks, int min_active, int tri_batch, hipStream_t s)
+                 int grid_blocks, int min_active, int tri_batch, size_t lds_bytes, hipStream_t s)
 {
     /* the unified walk (variant 3) reads fp32 nodes only */
     if (sc.use_qnodes != 0 && variant != LH_VARIANT_UNIFIED)
-        return launch_fmt<STACK, true>(sc, n, org, dir, prim, t, u, v, anyhit, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, s);
-    return launch_fmt<STACK, false>(sc, n, org, dir, prim, t, u, v, anyhit, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, s);
+        return launch_fmt<true>(sc, n, org, dir, prim, t, u, v, anyhit, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, lds_bytes, s);
+    return launch_fmt<false>(sc, n, org, dir, prim, t, u, v, anyhit, occ, counters, cursor, variant, grid_blocks, min_active, tri_batch, lds_bytes, s);
 }
 
 } /* namespace */
@@ -695,17 +697,14 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) return 0;
     /* stack entries needed: 2-wide walks <= tree depth + 1 (sentinel); the 4-wide walk pushes
-     * up to 3 per level and writes up to 3 slots above its top */
+     * up to 3 per level and writes up to 3 slots above its top.  The LDS stack is dynamic
+     * shared memory of exactly that many rows (2-row granularity). */
     uint32_t need = sc->max_depth + 1;
     if (variant == LH_VARIANT_SPEC && sc->use_qnodes == 2) need = 3 * sc->q4_depth + 5;
-    if (need <= 32)
-        return launch_stack<32>(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
-                                d_counters, d_workq, variant, grid_blocks, min_active, tri_batch, s);
-    if (need <= 48)
-        return launch_stack<48>(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
-                                d_counters, d_workq, variant, grid_blocks, min_active, tri_batch, s);
-    if (need <= 64)
-        return launch_stack<64>(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
-                                d_counters, d_workq, variant, grid_blocks, min_active, tri_batch, s);
-    return -1;
+    need = (need + 1u) & ~1u;
+    if (need < 16) need = 16;
+    if (need > 64) return -1;
+    const size_t lds_bytes = (size_t)need * LH_BLOCK * sizeof(int);
+    return launch_stack(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
+                        d_counters, d_workq, variant, grid_blocks, min_active, tri_batch, lds_bytes, s);
 }
