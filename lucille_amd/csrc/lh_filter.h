@@ -165,11 +165,13 @@ LH_HD int lh_tri_filter(const lh_ray32_t *r, float v0x, float v0y, float v0z,
                        (u + v > 1.0f + tolu + tolv) | (t < -tolt) | (t - tolt > tb);
     if (reject) return LH_TRI_REJECT;
     {
-        /* relative uncertainty of the determinant itself */
+        /* relative uncertainty of the determinant itself.  The reference also drops
+         * |det| <= 1e-14 as an ABSOLUTE threshold (bvh.c:754): a hit is only certain when
+         * the fp64 determinant (within 25 % of a) clears it, else the fp64 resolve decides. */
         const float rela = (LH_KTRI * LH_EPS24) * ne1 * ne2 * r->dn * fabsf(inva);
         const int sure = (u >= tolu) & (u <= 1.0f - tolu) & (v >= tolv) &
                          (u + v <= 1.0f - tolu - tolv) & (t >= tolt) & (rela < 0.25f) &
-                         (t + tolt < 1.0e37f);
+                         (fabsf(a) > 2.0e-14f) & (t + tolt < 1.0e37f);
         *t_hi = (t + tolt) * 1.000001f;
         return sure ? LH_TRI_CERTAIN : LH_TRI_CANDIDATE;
     }

@@ -198,3 +198,28 @@ def test_full_size_properties_soup_1m():
     o = po.Oracle(); o.add_mesh(P, idx); o.build()
     exp = o.intersect(org[:n], dr[:n], nthreads=32)
     assert_hits_equal(tuple(x.cpu().numpy()[:n] for x in res[2]), exp, "soup-1M prefix")
+
+
+@pytest.mark.parametrize("kind,log_scale,off", [("soup", -3, 0.0), ("soup", 3, -800.0), ("slivers", 0, 10.0), ("axis", 2, 500.0),
+                                                ("degenerate", -1, -3.0), ("slivers", -2, 0.5)])
+def test_scaled_translated_degenerate_scenes(kind, log_scale, off):
+    """magnitude robustness of the conservative filter on the device: tiny / huge / far-from-origin
+    scenes, sliver and degenerate triangles, axis-parallel and unnormalised rays (same generator as
+    the CPU fuzz test, tests/test_filter_fuzz.py)"""
+    from tests.test_filter_fuzz import make_scene
+    rng = np.random.default_rng(1234)
+    scale = 10.0 ** log_scale; offset = np.array([off, -0.5 * off, 0.25 * off])
+    P, idx = make_scene(rng, 300, scale, offset, kind)
+    n = 20000
+    tgt = rng.uniform(-0.1, 1.1, (n, 3)) * scale + offset
+    org = tgt + rng.normal(size=(n, 3)) * scale * 3.0
+    dr = tgt - org
+    dr[::11, 0] = 0.0; dr[1::13, 1] = 1e-3 * scale; dr[2::17] *= 1e-3; dr[3::19, 2] = 1e-20
+    ok = np.abs(dr[:, 1]) > 1e-14
+    org, dr = np.ascontiguousarray(org[ok]), np.ascontiguousarray(dr[ok])
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr, nthreads=8)
+    acc = make_accel(P, idx)
+    for variant in VARIANTS:
+        assert_hits_equal(gpu_closest(acc, org, dr, variant), exp, "%s 1e%d v%d" % (kind, log_scale, variant))
+    assert np.array_equal(gpu_any(acc, org, dr, la.VARIANT_DEFAULT).astype(bool), exp[0] != po.MISS)
