@@ -136,6 +136,47 @@ int ri_accel_intersect_batch(void *accel, size_t n, const double *org_xyz, const
 /* primitive id -> (geom, index), the pair state->geom/state->index carry */
 int ri_accel_prim_lookup(void *accel, uint32_t prim, ri_geom_t **geom, uint32_t *index);
 
+/* ---- BVH extras of the boundary (bvh.h:194-227) ---------------------------- */
+
+/* beam = frustum of 4 corner rays with a common origin (beam.h:45-84).  Only the members the
+ * visibility query reads are kept; `corner` remembers the caller's un-normalised directions,
+ * which is what the device query (which repeats ri_beam_set in fp64) is fed with. */
+#define RI_BEAM_MISS_COMPLETELY 0     /* beam.h:27-29 */
+#define RI_BEAM_HIT_COMPLETELY  1
+#define RI_BEAM_HIT_PARTIALLY   2
+
+typedef struct _ri_beam_t {
+    ri_vector_t org;
+    ri_vector_t dir[4];               /* scaled onto the axis plane at distance d (beam.c:417-440) */
+    ri_float_t  d, t_max;
+    ri_vector_t invdir[4];
+    int         dominant_axis;
+    int         dirsign[3];
+    ri_vector_t normal[4];
+    ri_vector_t corner[4];            /* as given to ri_beam_set */
+} ri_beam_t;
+
+/* 0, or -1 when the corner directions straddle an octant (beam.c:352-376) */
+int ri_beam_set(ri_beam_t *beam, ri_vector_t org, ri_vector_t dir[4]);
+
+/* ri_bvh_intersect_beam_visibility (bvh.c:612-667): RI_BEAM_* class, `user` ignored */
+int  ri_hipbvh_intersect_beam_visibility(void *accel, ri_beam_t *beam, void *user);
+/* n beams in one launch; result[i] = RI_BEAM_* or -1 where ri_beam_set refuses the beam */
+int  ri_hipbvh_intersect_beam_visibility_batch(void *accel, size_t n, const double *org_xyz,
+                                               const double *corner_dirs_xyz, int32_t *result);
+/* ri_bvh_invalidate_cache (bvh.c:389-428) frees the lazily built per-leaf 2-D triangle caches of
+ * the beam-raster path; this accelerator has none: a no-op kept for source compatibility. */
+void ri_hipbvh_invalidate_cache(void *accel);
+
+/* ri_bvh_clear_stat_traversal / ri_bvh_report_stat_traversal (bvh.c:669-706).  The reference
+ * fills its globals only when compiled with -DRI_BVH_TRACE_STATISTICS; here the switch is a
+ * run-time one (or the environment variable RI_BVH_TRACE_STATISTICS=1 at build time of the accel). */
+void ri_hipbvh_trace_statistics(int enable);
+void ri_hipbvh_clear_stat_traversal(void);
+void ri_hipbvh_report_stat_traversal(void);
+/* the same totals as numbers: nrays, node visits, filter tests, fp64 tests, hits */
+void ri_hipbvh_get_stat_traversal(uint64_t out[5]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,7 @@ ABI_SYMBOLS = [
     "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted",
     "lh_accel_set_grid", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
     "lh_render_ao_tile", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device", "lh_render_pt_tile",
+    "lh_accel_trace_statistics", "lh_accel_statistics",
 ]
 
 _lib = None
@@ -106,6 +107,8 @@ def lib():
     L.lh_accel_intersect_device_counted.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, i32,
                                                     C.POINTER(C.c_uint64)]
     L.lh_accel_set_grid.argtypes = [vp, i32]
+    L.lh_accel_trace_statistics.argtypes = [vp, i32]
+    L.lh_accel_statistics.argtypes = [vp, C.POINTER(C.c_uint64), i32]
     L.lh_accel_export.argtypes = [vp, vp, vp]
     L.lh_accel_set_normals.argtypes = [vp, u32, vp, sz, i32]
     L.lh_render_primary_rays.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, vp, vp, vp]

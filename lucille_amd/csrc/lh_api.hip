@@ -5,6 +5,7 @@
  * host-batch entry point).
  */
 #include <hip/hip_runtime.h>
+#include <vector>
 
 #include <math.h>
 #include <stdarg.h>
@@ -64,6 +65,8 @@ struct lh_accel {
     lh_dev_scene_t dev;
     void *d_nodes, *d_tri32, *d_tri64, *d_qnodes, *d_q4nodes;
     unsigned long long *d_cursor, *d_counters;
+    int stat_on;                       /* lh_accel_trace_statistics */
+    unsigned long long stat[5];        /* nodes, filter tests, fp64 tests, rays, hits */
     hipStream_t stream;
     uint64_t device_bytes;
     double upload_seconds;
@@ -473,8 +476,24 @@ extern "C" int lh_accel_intersect_host(lh_accel_t *a, size_t n, const double *or
     uint8_t *d_occ = (uint8_t *)(d_prim + n);
     HIPCHK(hipMemcpyAsync(d_org, org, b_ray, hipMemcpyHostToDevice, a->stream));
     HIPCHK(hipMemcpyAsync(d_dir, dir, b_ray, hipMemcpyHostToDevice, a->stream));
-    int rc = launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, LH_VARIANT_DEFAULT, NULL, a->stream);
+    if (a->stat_on) HIPCHK(hipMemsetAsync(a->d_counters, 0, sizeof(unsigned long long) * LH_CNT_N, a->stream));
+    int rc = launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, LH_VARIANT_DEFAULT,
+                    a->stat_on ? a->d_counters : NULL, a->stream);
     if (rc != 0) return rc;
+    if (a->stat_on) {
+        /* hits are counted from the device outputs whatever the caller asked to copy back */
+        std::vector<uint32_t> hp; std::vector<uint8_t> ho; unsigned long long h[LH_CNT_N] = {0, 0, 0, 0}, nh = 0;
+        if (mode == LH_MODE_CLOSEST) {
+            hp.resize(n); HIPCHK(hipMemcpyAsync(hp.data(), d_prim, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, a->stream));
+        } else {
+            ho.resize(n); HIPCHK(hipMemcpyAsync(ho.data(), d_occ, n, hipMemcpyDeviceToHost, a->stream));
+        }
+        if (a->bvh.ntris) HIPCHK(hipMemcpyAsync(h, a->d_counters, sizeof(h), hipMemcpyDeviceToHost, a->stream));
+        HIPCHK(hipStreamSynchronize(a->stream));
+        for (size_t i = 0; i < n; i++) nh += (mode == LH_MODE_CLOSEST) ? (hp[i] != LH_MISS_PRIM) : (ho[i] != 0);
+        a->stat[0] += h[LH_CNT_NODES]; a->stat[1] += h[LH_CNT_TRIS]; a->stat[2] += h[LH_CNT_EXACT];
+        a->stat[3] += n; a->stat[4] += nh;
+    }
     if (mode == LH_MODE_CLOSEST) {
         if (prim) HIPCHK(hipMemcpyAsync(prim, d_prim, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, a->stream));
         if (t) HIPCHK(hipMemcpyAsync(t, d_t, b_d, hipMemcpyDeviceToHost, a->stream));
@@ -484,6 +503,21 @@ extern "C" int lh_accel_intersect_host(lh_accel_t *a, size_t n, const double *or
         if (occ) HIPCHK(hipMemcpyAsync(occ, d_occ, n, hipMemcpyDeviceToHost, a->stream));
     }
     HIPCHK(hipStreamSynchronize(a->stream));
+    return 0;
+}
+
+extern "C" int lh_accel_trace_statistics(lh_accel_t *a, int enable)
+{
+    if (!a) return fail("lh_accel_trace_statistics: NULL accel");
+    a->stat_on = enable != 0;
+    return 0;
+}
+
+extern "C" int lh_accel_statistics(lh_accel_t *a, uint64_t counters[5], int clear)
+{
+    if (!a) return fail("lh_accel_statistics: NULL accel");
+    if (counters) for (int k = 0; k < 5; k++) counters[k] = a->stat[k];
+    if (clear) for (int k = 0; k < 5; k++) a->stat[k] = 0;
     return 0;
 }
 

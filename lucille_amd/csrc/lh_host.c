@@ -11,6 +11,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+static void vcross(ri_vector_t d, const ri_vector_t a, const ri_vector_t b);
+
 /* ---------------------------------------------------------------- geom ---- */
 
 ri_geom_t *ri_geom_new(void) { return (ri_geom_t *)calloc(1, sizeof(ri_geom_t)); }
@@ -83,6 +85,9 @@ int ri_scene_build_accel(ri_scene_t *s)
         fprintf(stderr, "[lucille_hip] FATAL : No spatial accelerator is assigned to the scene.\n");
         return -1;                               /* scene.c:158-161 */
     }
+    /* the reference overwrites ->data and leaks the old tree when a scene is rebuilt
+     * (scene.c:97,164); device memory is not something to leak: release it first */
+    if (s->accel->data && s->accel->free) { s->accel->free(s->accel->data); s->accel->data = NULL; }
     s->accel->data = s->accel->build((const void *)s);
     return s->accel->data ? 0 : -1;
 }
@@ -161,6 +166,56 @@ void ri_hipbvh_free(void *accel)
     free(h);
 }
 
+/* -------------------------------------------- traversal statistics ---- */
+/* ri_bvh_clear_stat_traversal / ri_bvh_report_stat_traversal (bvh.c:669-706): process-wide
+ * totals like the reference's g_stattrav; filled from the accelerator's counting kernel. */
+static int      g_trace_stats = -1;          /* -1: read RI_BVH_TRACE_STATISTICS on first use */
+static uint64_t g_stat[5];                   /* node visits, filter tests, fp64 tests, rays, hits */
+
+static int trace_stats_on(void)
+{
+    if (g_trace_stats < 0) {
+        const char *e = getenv("RI_BVH_TRACE_STATISTICS");
+        g_trace_stats = (e && e[0] && e[0] != '0') ? 1 : 0;
+    }
+    return g_trace_stats;
+}
+
+static void stat_before(hipbvh_t *h) { lh_accel_trace_statistics(h->lh, trace_stats_on()); }
+
+static void stat_after(hipbvh_t *h)
+{
+    uint64_t c[5]; int k;
+    if (!trace_stats_on()) return;
+    if (lh_accel_statistics(h->lh, c, 1) == 0) for (k = 0; k < 5; k++) g_stat[k] += c[k];
+}
+
+void ri_hipbvh_trace_statistics(int enable) { g_trace_stats = enable != 0; }
+void ri_hipbvh_clear_stat_traversal(void) { memset(g_stat, 0, sizeof(g_stat)); }
+void ri_hipbvh_get_stat_traversal(uint64_t out[5])
+{
+    out[0] = g_stat[3]; out[1] = g_stat[0]; out[2] = g_stat[1]; out[3] = g_stat[2]; out[4] = g_stat[4];
+}
+
+void ri_hipbvh_report_stat_traversal(void)
+{   /* the reference's layout (bvh.c:681-706); leaf visits are not a unit of this kernel
+     * (leaves are parked and drained in batches), fp64 re-tests are listed instead */
+    const double nrays = (double)g_stat[3];
+    const double tested = g_stat[1] / nrays, hit = g_stat[4] / nrays;
+    printf("== BVH traversal statistiscs ==================================================\n");
+    printf("# of rays                    %llu\n", (unsigned long long)g_stat[3]);
+    printf("# of inner node travs        %llu\n", (unsigned long long)g_stat[0]);
+    printf("  Per ray                    %f\n", g_stat[0] / nrays);
+    printf("# of tested triangles        %llu\n", (unsigned long long)g_stat[1]);
+    printf("  Per ray                    %f\n", tested);
+    printf("# of fp64 re-tested tris     %llu\n", (unsigned long long)g_stat[2]);
+    printf("  Per ray                    %f\n", g_stat[2] / nrays);
+    printf("# of actually hit triangles  %llu\n", (unsigned long long)g_stat[4]);
+    printf("  Per ray                    %f\n", hit);
+    printf("  Hit rate                   %f %%\n", 100.0 * (hit / tested));
+    printf("===============================================================================\n");
+}
+
 static void fill_state(hipbvh_t *h, ri_intersection_state_t *st, uint32_t prim, double t, double u, double v,
                        const ri_vector_t org, const ri_vector_t dir)
 {
@@ -183,7 +238,9 @@ int ri_hipbvh_intersect(void *accel, ri_ray_t *ray, ri_intersection_state_t *sta
         ray->invdir[k] = (fabs(ray->dir[k]) > 1.0e-14) ? 1.0 / ray->dir[k]
                                                        : ((ray->dir[k] < 0.0) ? -1.7976931348623157e308 : 1.7976931348623157e308);
     }
+    stat_before(h);
     hit = lh_accel_intersect1(h->lh, ray->org, ray->dir, &prim, &t, &u, &v);
+    stat_after(h);
     if (hit < 0) { fprintf(stderr, "[lucille_hip] ERROR : (HIPBVH) %s\n", lh_last_error()); return 0; }
     /* bvh_traverse initialises these whether or not there is a hit (bvh.c:1111-1115) */
     state->t = 1.0e38; state->u = 0.0; state->v = 0.0; state->geom = NULL; state->index = 0;
@@ -231,12 +288,81 @@ int ri_accel_intersect_batch(void *accel, size_t n, const double *org, const dou
 {
     hipbvh_t *h = (hipbvh_t *)accel;
     if (!h) return -1;
+    stat_before(h);
     if (lh_accel_intersect_host(h->lh, n, org, dir, prim, t, u, v, occluded, mode) != 0) {
+        fprintf(stderr, "[lucille_hip] ERROR : (HIPBVH) %s\n", lh_last_error());
+        return -1;
+    }
+    stat_after(h);
+    return 0;
+}
+
+/* ---------------------------------------------------------------- beams ---- */
+
+/* ri_beam_set, src/render/beam.c:331-465 (incl. the maxval re-assignment at :387-390) */
+int ri_beam_set(ri_beam_t *beam, ri_vector_t org, ri_vector_t dir[4])
+{
+    int i, j, dom; double maxval, normal[3] = {0.0, 0.0, 0.0};
+    if (!beam || !org || !dir) return -1;
+    beam->d = 1024.0; beam->t_max = 1.0e38;
+    for (i = 0; i < 3; i++) {
+        int zeros = 0, mask = 0;
+        for (j = 0; j < 4; j++) {
+            if (fabs(dir[j][i]) < 1.0e-14) zeros++;
+            else mask += (dir[j][i] < 0.0) ? 1 : -1;
+        }
+        if ((mask != -(4 - zeros)) && (mask != (4 - zeros))) {
+            fprintf(stderr, "TODO: Beam's dir does not have same sign.\n");
+            return -1;
+        }
+    }
+    for (j = 0; j < 4; j++) memcpy(beam->corner[j], dir[j], sizeof(ri_vector_t));
+    memcpy(beam->org, org, sizeof(ri_vector_t));
+    maxval = fabs(dir[0][0]); dom = 0;
+    if (maxval < fabs(dir[0][1])) { maxval = fabs(dir[0][0]); dom = 1; }
+    if (maxval < fabs(dir[0][2])) { maxval = fabs(dir[0][2]); dom = 2; }
+    beam->dominant_axis = dom;
+    for (i = 0; i < 3; i++) beam->dirsign[i] = (dir[0][i] < 0.0) ? 1 : 0;
+    normal[dom] = beam->dirsign[dom] ? -1.0 : 1.0;
+    for (i = 0; i < 4; i++) {
+        const double t = dir[i][0] * normal[0] + dir[i][1] * normal[1] + dir[i][2] * normal[2];
+        const double k = (fabs(t) > 1.0e-14) ? beam->d / t : 1.0;
+        for (j = 0; j < 3; j++) {
+            beam->dir[i][j] = k * dir[i][j];
+            beam->invdir[i][j] = (fabs(beam->dir[i][j]) > 1.0e-14) ? 1.0 / beam->dir[i][j] : 1.7976931348623157e308;
+        }
+    }
+    vcross(beam->normal[0], beam->dir[1], beam->dir[0]);
+    vcross(beam->normal[1], beam->dir[2], beam->dir[1]);
+    vcross(beam->normal[2], beam->dir[3], beam->dir[2]);
+    vcross(beam->normal[3], beam->dir[0], beam->dir[3]);
+    return 0;
+}
+
+int ri_hipbvh_intersect_beam_visibility_batch(void *accel, size_t n, const double *org, const double *dirs, int32_t *result)
+{
+    hipbvh_t *h = (hipbvh_t *)accel;
+    if (!h) return -1;
+    if (lh_accel_beam_visibility_host(h->lh, n, org, dirs, result) != 0) {
         fprintf(stderr, "[lucille_hip] ERROR : (HIPBVH) %s\n", lh_last_error());
         return -1;
     }
     return 0;
 }
+
+/* ri_bvh_intersect_beam_visibility, bvh.c:612-667: the beam was accepted by ri_beam_set */
+int ri_hipbvh_intersect_beam_visibility(void *accel, ri_beam_t *beam, void *user)
+{
+    double org[3], dirs[12]; int32_t cls = 0; int i, k;
+    (void)user;
+    if (!accel || !beam) return 0;
+    for (k = 0; k < 3; k++) org[k] = beam->org[k];
+    for (i = 0; i < 4; i++) for (k = 0; k < 3; k++) dirs[3 * i + k] = beam->corner[i][k];
+    if (ri_hipbvh_intersect_beam_visibility_batch(accel, 1, org, dirs, &cls) != 0) return 0;
+    return cls < 0 ? 0 : (int)cls;
+}
+
+void ri_hipbvh_invalidate_cache(void *accel) { (void)accel; }
 
 int ri_accel_prim_lookup(void *accel, uint32_t prim, ri_geom_t **geom, uint32_t *index)
 {
