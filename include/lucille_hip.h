@@ -126,7 +126,8 @@ int  lh_accel_set_grid(lh_accel_t *accel, int blocks);
 typedef struct lh_camera {
     int    width, height;       /* camera->horizontal/vertical_resolution             */
     int    rh;                  /* Orientation "rh" (camera->is_rh)                   */
-    int    pad;
+    int    ortho;               /* 1: Projection "orthographic" (the reference's default when no
+                                 * "fov" is given, camera.c:100,428); 0: perspective        */
     double flength;             /* 1/tan(fov/2) (camera.c:219)                         */
     double cam2world[16];       /* camera->camera_to_world, row-major, row vectors     */
 } lh_camera_t;
@@ -194,6 +195,58 @@ int  lh_accel_beam_visibility_host(lh_accel_t *accel, size_t n, const double *or
                                    const double *corner_dirs_xyz, int32_t *result);
 int  lh_accel_beam_visibility_device(lh_accel_t *accel, size_t n, const void *d_org_xyz,
                                      const void *d_corner_dirs_xyz, void *d_result, void *stream);
+
+/* whole AO frame into HOST memory: the tile loop of render_frame_controller + bucket_write
+ * (src/render/render.c:1168-1207, 919-983) over lh_render_ao_tile.  rgb: height rows of width RGB
+ * float triples, top row first (bucket_write's y flip applied) -- what the reference hands its
+ * display driver.  tile = tile edge in pixels (0: 256).  stats may be NULL. */
+int  lh_render_ao_frame_host(lh_accel_t *accel, const lh_camera_t *cam, int pixel_samples,
+                             int gather_nsamples, uint64_t seed, int tile, float *rgb,
+                             lh_tile_stats_t *stats);
+
+/* ---- RIB-subset reader + Radiance .hdr writer: `lsh scene.rib` without flex/bison ----
+ * reference: the RenderMan front end for the verbs its example scenes use --
+ * src/ri/transform.c, context.c, attribute.c, camera.c:209-240,360-438, display.c:70-200,
+ * option.c:430-560, src/render/polygon.c:39-262,495-640, src/base/matrix.c, quaternion.c; numbers
+ * are C floats as in src/lsh/lexrib.l:213 / parserib.y:119.  The result is what lucille's renderer
+ * is handed: the ri_geom_t list (world-space double[4] positions / normals, triangle indices,
+ * two_side) in RIB order -- same global primitive ids -- and the camera.  Verbs outside the
+ * ray-query path (shaders, lights, colours, quadrics ...) are skipped and counted. */
+typedef struct lh_rib_scene lh_rib_scene_t;
+
+typedef struct lh_rib_info {
+    uint32_t    nmeshes;
+    uint64_t    ntriangles;
+    lh_camera_t camera;           /* ri_camera_setup (camera.c:209-240) of the parsed state       */
+    int         perspective;      /* 0: no Projection "perspective" "fov" seen (reference: ortho)  */
+    float       fov;
+    int         pixel_samples[2]; /* PixelSamples (context.c:210-222)                              */
+    int         gather_nsamples;  /* Option "gather" "nsamples" (option.c:545-549), default 64     */
+    int         accel_method;     /* Option "raytrace" "accel_method": 0 grid, 1 bvh, 2 hip        */
+    int         nthreads;
+    int         world_complete;   /* WorldBegin ... WorldEnd seen                                  */
+    uint32_t    nskipped, nrequests;  /* requests outside the ray-query path / all requests      */
+    uint32_t    nunknown;             /* of the skipped: not RenderMan requests at all           */
+    char        display_name[1024];   /* after display.c's extension rule (".hdr")                */
+    char        display_type[64];
+} lh_rib_info_t;
+
+int  lh_rib_load(const char *path, lh_rib_scene_t **scene_out);   /* 0 / -1 (lh_rib_last_error) */
+void lh_rib_free(lh_rib_scene_t *scene);
+const char *lh_rib_last_error(void);
+int  lh_rib_info(const lh_rib_scene_t *scene, lh_rib_info_t *info);
+/* parse diagnostics, one per line, as `lsh` prints them to stdout ("Unknown RIB command: X") */
+const char *lh_rib_messages(const lh_rib_scene_t *scene);
+/* borrowed pointers into the scene: positions/normals are npositions x double[4] (normals may be
+ * NULL), indices are triangle corners (3 per primitive) */
+int  lh_rib_mesh(const lh_rib_scene_t *scene, uint32_t mesh, uint32_t *npositions,
+                 const double **positions, uint32_t *nindices, const uint32_t **indices,
+                 const double **normals, int *two_side);
+/* meshes (+ normals) of a parsed scene into an accelerator, in order; the caller commits */
+int  lh_accel_add_rib_scene(lh_accel_t *accel, const lh_rib_scene_t *scene);
+/* Radiance RGBE, run-length coded, byte-compatible with the reference's "file" display driver
+ * (src/display/hdrdrv.c:38-121, src/imageio/rgbe.c:78-96,118-140,241-345); rgb as above */
+int  lh_hdr_write(const char *path, int width, int height, const float *rgb);
 
 /* copy of the flattened BVH for cross-checks (tests): sizes via lh_accel_info.
  * nodes: nnodes*64 bytes, tri32: ntriangles*48 bytes; either may be NULL. */

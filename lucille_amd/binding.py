@@ -46,7 +46,7 @@ class AccelInfo(C.Structure):
 
 class Camera(C.Structure):
     """lh_camera_t: the members of ri_camera_t the ray generator reads (camera.c:248-318)"""
-    _fields_ = [("width", C.c_int), ("height", C.c_int), ("rh", C.c_int), ("pad", C.c_int),
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("rh", C.c_int), ("ortho", C.c_int),
                 ("flength", C.c_double), ("cam2world", C.c_double * 16)]
 
     @classmethod
@@ -75,6 +75,8 @@ ABI_SYMBOLS = [
     "lh_accel_set_grid", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
     "lh_render_ao_tile", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device", "lh_render_pt_tile",
     "lh_accel_trace_statistics", "lh_accel_statistics",
+    "lh_render_ao_frame_host", "lh_rib_load", "lh_rib_free", "lh_rib_last_error", "lh_rib_info", "lh_rib_messages",
+    "lh_rib_mesh", "lh_accel_add_rib_scene", "lh_hdr_write",
 ]
 
 _lib = None

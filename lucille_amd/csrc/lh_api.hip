@@ -79,7 +79,7 @@ struct lh_accel {
     /* per-primitive vertex normals (9 doubles, NaN = none), only if some mesh has normals */
     double *h_nrm9; void *d_nrm9;
     /* tile-render scratch (lh_render_ao_tile) */
-    lh_buf r_org, r_dir, r_prim, r_t, r_u, r_v, r_slot, r_hitrec, r_aorg, r_adir, r_occ, r_blocks, r_key;
+    lh_buf r_org, r_dir, r_prim, r_t, r_u, r_v, r_slot, r_hitrec, r_aorg, r_adir, r_occ, r_blocks, r_key, r_frame;
     lh_buf p_org2, p_dir2, p_path, p_path2, p_thr, p_thr2, p_rad, p_alive;   /* path tracer */
     unsigned long long *d_total;
     size_t r_nsamples, r_nslots, r_nao;
@@ -168,7 +168,7 @@ static void free_buf(lh_buf *b) { if (b->p) (void)hipFree(b->p); b->p = NULL; b-
 static void release_device(lh_accel_t *a)
 {
     lh_buf *bufs[] = {&a->r_org, &a->r_dir, &a->r_prim, &a->r_t, &a->r_u, &a->r_v, &a->r_slot, &a->r_hitrec,
-                      &a->r_aorg, &a->r_adir, &a->r_occ, &a->r_blocks, &a->r_key,
+                      &a->r_aorg, &a->r_adir, &a->r_occ, &a->r_blocks, &a->r_key, &a->r_frame,
                       &a->p_org2, &a->p_dir2, &a->p_path, &a->p_path2, &a->p_thr, &a->p_thr2, &a->p_rad, &a->p_alive};
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) free_buf(bufs[i]);
     if (a->d_total) (void)hipFree(a->d_total);
@@ -560,6 +560,21 @@ extern "C" int lh_render_primary_rays(lh_accel_t *a, const lh_camera_t *cam, int
     return 0;
 }
 
+extern "C" int lh_accel_add_rib_scene(lh_accel_t *a, const lh_rib_scene_t *scene)
+{
+    lh_rib_info_t info;
+    if (!a || !scene) return fail("lh_accel_add_rib_scene: NULL argument");
+    if (lh_rib_info(scene, &info) != 0) return fail("lh_accel_add_rib_scene: %s", lh_rib_last_error());
+    for (uint32_t m = 0; m < info.nmeshes; m++) {
+        uint32_t npos = 0, nidx = 0; const double *pos = NULL, *nrm = NULL; const uint32_t *idx = NULL; int two = 0;
+        if (lh_rib_mesh(scene, m, &npos, &pos, &nidx, &idx, &nrm, &two) != 0) return fail("lh_accel_add_rib_scene: %s", lh_rib_last_error());
+        const int id = lh_accel_add_mesh(a, npos, pos, 4 * sizeof(double), nidx, idx);
+        if (id < 0) return -1;
+        if (nrm && lh_accel_set_normals(a, (uint32_t)id, nrm, 4 * sizeof(double), two) != 0) return -1;
+    }
+    return 0;
+}
+
 extern "C" int lh_render_ao_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int ps,
                                  int gather_nsamples, uint64_t seed, const void *d_uniforms, void *d_rgb,
                                  lh_tile_stats_t *stats, void *stream)
@@ -738,5 +753,38 @@ extern "C" int lh_render_pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
         return fail("pt resolve launch failed");
     HIPCHK(hipStreamSynchronize(s));
     if (stats) { stats->paths = S; stats->rays = rays; stats->max_depth_reached = (uint64_t)depth; }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* whole frame into host memory (render_frame_controller + bucket_write)     */
+/* ------------------------------------------------------------------------ */
+
+extern "C" int lh_render_ao_frame_host(lh_accel_t *a, const lh_camera_t *cam, int ps, int gather_nsamples,
+                                       uint64_t seed, int tile, float *rgb, lh_tile_stats_t *stats)
+{
+    if (!a || !a->committed) return fail("lh_render_ao_frame_host: accel not committed");
+    if (!cam || !rgb) return fail("lh_render_ao_frame_host: NULL argument");
+    if (cam->width <= 0 || cam->height <= 0) return fail("lh_render_ao_frame_host: bad resolution");
+    if (tile <= 0) tile = 256;
+    HIPCHK(hipSetDevice(a->device));
+    const int W = cam->width, H = cam->height;
+    if (ensure_buf(&a->r_frame, (size_t)tile * tile * 3 * sizeof(float))) return -1;
+    std::vector<float> host((size_t)tile * tile * 3);
+    lh_tile_stats_t tot = {0, 0, 0, 0};
+    for (int y0 = 0; y0 < H; y0 += tile)
+        for (int x0 = 0; x0 < W; x0 += tile) {
+            const int w = (x0 + tile <= W) ? tile : W - x0, h = (y0 + tile <= H) ? tile : H - y0;
+            lh_tile_stats_t st;
+            if (lh_render_ao_tile(a, cam, x0, y0, w, h, ps, gather_nsamples, seed, NULL, a->r_frame.p, &st, a->stream) != 0) return -1;
+            HIPCHK(hipMemcpyAsync(host.data(), a->r_frame.p, (size_t)w * h * 3 * sizeof(float), hipMemcpyDeviceToHost, a->stream));
+            HIPCHK(hipStreamSynchronize(a->stream));
+            /* the tile comes back with its rows already flipped (row 0 = pixel row y0+h-1) */
+            for (int r = 0; r < h; r++)
+                memcpy(rgb + ((size_t)(H - (y0 + h) + r) * W + x0) * 3, host.data() + (size_t)r * w * 3, (size_t)w * 3 * sizeof(float));
+            tot.primary_rays += st.primary_rays; tot.primary_hits += st.primary_hits;
+            tot.ao_rays += st.ao_rays; tot.ao_occluded += st.ao_occluded;
+        }
+    if (stats) *stats = tot;
     return 0;
 }

@@ -38,7 +38,7 @@ namespace {
 struct DevCamera {
     double c2w[16];
     double flength;
-    int width, height, rh;
+    int width, height, rh, ortho;
 };
 
 __device__ __forceinline__ void vnormalize(double d[3])
@@ -85,6 +85,7 @@ __global__ void k_primary_rays(DevCamera cam, int x0, int y0, int w, int h, int 
     const float sign = cam.rh ? -1.0f : 1.0f;
     double v[4], o[4] = {0.0, 0.0, 0.0, 1.0}, pos[4], dp[4];
     v[0] = (2.0f * x - W) / W; v[1] = (2.0f * y - H) / H; v[2] = sign * cam.flength; v[3] = 1.0;
+    if (cam.ortho) { o[0] = v[0]; o[1] = v[1]; v[2] = sign * 1.0; }      /* camera.c:285-301 */
     for (int c = 0; c < 4; c++) {
         pos[c] = 0.0; dp[c] = 0.0;
         for (int r = 0; r < 4; r++) { pos[c] += o[r] * cam.c2w[4 * r + c]; dp[c] += v[r] * cam.c2w[4 * r + c]; }
@@ -303,6 +304,7 @@ __global__ void k_pt_primary(DevCamera cam, int x0, int y0, int w, int h, int sp
     const float sign = cam.rh ? -1.0f : 1.0f;
     double v[4], o[4] = {0.0, 0.0, 0.0, 1.0}, pos[4], dp[4];
     v[0] = (2.0f * x - W) / W; v[1] = (2.0f * y - H) / H; v[2] = sign * cam.flength; v[3] = 1.0;
+    if (cam.ortho) { o[0] = v[0]; o[1] = v[1]; v[2] = sign * 1.0; }      /* camera.c:285-301 */
     for (int c = 0; c < 4; c++) {
         pos[c] = 0.0; dp[c] = 0.0;
         for (int r = 0; r < 4; r++) { pos[c] += o[r] * cam.c2w[4 * r + c]; dp[c] += v[r] * cam.c2w[4 * r + c]; }
@@ -427,7 +429,7 @@ extern "C" int lh_render_launch_primary(const lh_camera_t *cam, int x0, int y0, 
 {
     DevCamera c;
     for (int i = 0; i < 16; i++) c.c2w[i] = cam->cam2world[i];
-    c.flength = cam->flength; c.width = cam->width; c.height = cam->height; c.rh = cam->rh;
+    c.flength = cam->flength; c.width = cam->width; c.height = cam->height; c.rh = cam->rh; c.ortho = cam->ortho;
     const size_t total = (size_t)w * h * xs * ys;
     if (total == 0) return 0;
     hipLaunchKernelGGL(k_primary_rays, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -480,7 +482,7 @@ extern "C" int lh_pt_launch_primary(const lh_camera_t *cam, int x0, int y0, int 
 {
     DevCamera c;
     for (int i = 0; i < 16; i++) c.c2w[i] = cam->cam2world[i];
-    c.flength = cam->flength; c.width = cam->width; c.height = cam->height; c.rh = cam->rh;
+    c.flength = cam->flength; c.width = cam->width; c.height = cam->height; c.rh = cam->rh; c.ortho = cam->ortho;
     const size_t total = (size_t)w * h * spp;
     if (total == 0) return 0;
     hipLaunchKernelGGL(k_pt_primary, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

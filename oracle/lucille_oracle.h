@@ -117,7 +117,7 @@ int lo_scene_set_normals(lo_scene_t *scene, uint32_t mesh, const double *normals
 typedef struct lo_camera {
     int    width, height;
     int    rh;               /* Orientation "rh" => 1 (camera->is_rh)        */
-    int    pad;
+    int    ortho;      /* camera_projection == RI_ORTHOGRAPHIC (camera.c:276,285-301) */
     double flength;          /* 1/tan(fov/2), camera.c:219                   */
     double cam2world[16];    /* camera_to_world, row-major, row-vector conv. */
 } lo_camera_t;

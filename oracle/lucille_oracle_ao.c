@@ -123,6 +123,10 @@ void lo_camera_ray(const lo_camera_t *c, double x, double y, double org[3], doub
     v[2] = sign * c->flength;
     v[3] = 1.0;
     o[0] = o[1] = o[2] = 0.0; o[3] = 1.0;
+    if (c->ortho) {                                /* camera.c:285-301 */
+        o[0] = v[0]; o[1] = v[1];
+        v[2] = sign * 1.0;
+    }
     for (j = 0; j < 4; j++) {
         pos[j] = 0.0; dp[j] = 0.0;
         for (i = 0; i < 4; i++) { pos[j] += o[i] * c->cam2world[4 * i + j]; dp[j] += v[i] * c->cam2world[4 * i + j]; }

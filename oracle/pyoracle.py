@@ -64,7 +64,7 @@ class TreeStats(C.Structure):
 
 
 class Camera(C.Structure):
-    _fields_ = [("width", C.c_int), ("height", C.c_int), ("rh", C.c_int), ("pad", C.c_int),
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("rh", C.c_int), ("ortho", C.c_int),
                 ("flength", C.c_double), ("cam2world", C.c_double * 16)]
 
     @classmethod

@@ -79,6 +79,7 @@ static uint32_t geom_ordinal(const ri_geom_t *g)
 
 /* camera of the frame being rendered, captured at the first query (it is set up
  * after the accelerator is built, render.c:335-336) */
+static int g_cam_ortho;
 static double g_cam[16 + 4];   /* camera_to_world row-major, flength, w, h, is_rh */
 static int    g_cam_valid = 0;
 static accel_intersect_func g_inner_intersect = NULL;
@@ -90,6 +91,7 @@ static void capture_camera(void)
     for (i = 0; i < 4; i++) for (j = 0; j < 4; j++) g_cam[4 * i + j] = c->camera_to_world.f[i][j];
     g_cam[16] = c->flength; g_cam[17] = c->horizontal_resolution; g_cam[18] = c->vertical_resolution;
     g_cam[19] = c->is_rh;
+    g_cam_ortho = (c->camera_projection == RI_ORTHOGRAPHIC);
     g_cam_valid = 1;
 }
 
@@ -157,6 +159,7 @@ void lref_scene_geom_copy(uint32_t g, double *pos_xyz, uint32_t *idx, double *nr
         for (i = 0; i < G->nnormals; i++) { nrm_xyz[3*i] = G->normals[i][0]; nrm_xyz[3*i+1] = G->normals[i][1]; nrm_xyz[3*i+2] = G->normals[i][2]; }
 }
 int lref_camera_get(double out[20]) { memcpy(out, g_cam, sizeof(g_cam)); return g_cam_valid; }
+int lref_camera_is_ortho(void) { return g_cam_ortho; }
 
 ri_accel_t *ri_accel_new()
 {

@@ -170,8 +170,23 @@ def render_verbs(verbs, width, height, gather_nsamples, pixel_samples=1, accel_m
                 nverts, verts = _iarr(a[0]), _iarr(a[1])
                 n, T, V, keep = _params(a[2:])
                 L.RiPointsPolygonsV(len(a[0]), nverts, verts, n, T, V)
+            elif verb == "Polygon":
+                n, T, V, keep = _params(a)
+                p_arr = [a[k + 1] for k in range(0, len(a) - 1, 2) if a[k] == "P"][0]
+                L.RiPolygonV(len(p_arr) // 3, n, T, V)
+            elif verb == "Identity":
+                L.RiIdentity()
+            elif verb in ("Translate", "Scale"):
+                f = getattr(L, "Ri" + verb); f.argtypes = [C.c_float] * 3
+                f(*[float(x) for x in (a[0] if isinstance(a[0], list) else a[:3])])
+            elif verb == "Rotate":
+                L.RiRotate.argtypes = [C.c_float] * 4
+                L.RiRotate(*[float(x) for x in (a[0] if isinstance(a[0], list) else a[:4])])
+            elif verb == "Sides":
+                L.RiSides.argtypes = [C.c_int]
+                L.RiSides(int(a[0]))
             elif verb in ("Surface", "ShadingInterpolation", "Atmosphere", "Imager", "ShadingRate", "Option",
-                          "Attribute", "Sides", "Color", "Opacity", "Declare", "FrameBegin", "FrameEnd",
+                          "Attribute", "Color", "Opacity", "Declare", "FrameBegin", "FrameEnd",
                           "Exposure", "Quantize", "Clipping", "ScreenWindow", "LightSource", "version"):
                 pass                                   # no effect on the ray-query path
             else:
@@ -196,6 +211,7 @@ def render_verbs(verbs, width, height, gather_nsamples, pixel_samples=1, accel_m
     out["image"] = img
     cam = np.zeros(20); L.lref_camera_get.argtypes = [C.c_void_p]; L.lref_camera_get(cam.ctypes.data)
     out["camera"] = cam
+    out["ortho"] = int(L.lref_camera_is_ortho())
     geoms = []
     L.lref_scene_geom_sizes.argtypes = [C.c_uint32] + [C.POINTER(C.c_uint32)] * 4
     L.lref_scene_geom_copy.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -225,7 +241,7 @@ def render_rib_subprocess(path, outfile, **kw):
     """fresh process per render; result saved as .npz at outfile"""
     code = ("import sys; sys.path.insert(0, %r); import numpy as np; from oracle import ref_rib as r; "
             "o = r.render_rib(%r, **%r); "
-            "d = {'image': o['image'], 'camera': o['camera'], 'records': o['records'], 'ngeoms': len(o['geoms'])}; "
+            "d = {'image': o['image'], 'camera': o['camera'], 'ortho': o['ortho'], 'records': o['records'], 'ngeoms': len(o['geoms'])}; "
             "[d.update({'pos%%d' %% i: g['positions'], 'idx%%d' %% i: g['indices'], 'two_side%%d' %% i: g['two_side']}) for i, g in enumerate(o['geoms'])]; "
             "[d.update({'nrm%%d' %% i: g['normals']}) for i, g in enumerate(o['geoms']) if g['normals'] is not None]; "
             "np.savez(%r, **d)") % (os.path.dirname(HERE), path, kw, outfile)

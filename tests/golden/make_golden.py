@@ -97,7 +97,55 @@ def beam_fixture(name, ntri, half_extent, seed, nbeams):
     print(name, {k: np.bincount(v + 1, minlength=4).tolist() for k, v in out.items()})
 
 
+def rib_fixture():
+    """What the reference's RenderMan front end makes of the RIB files under tests/golden/rib/
+    (its geoms after ingest, in order, and its camera), captured through its own Ri C API
+    (oracle/ref_rib.py): the expected output of the product's RIB reader (lh_rib.c).
+    The .rib files are scene DATA: the reference's parser-test inputs (tests/ribparse/), two of
+    its example scenes, and synth.rib written for this repo."""
+    from oracle import ref_rib
+    d = {}
+    for name in ("ambient_occlusion", "synth", "tut1"):
+        tmp = os.path.join("/tmp", "rib_" + name + ".npz")
+        r = ref_rib.render_rib_subprocess(os.path.join(OUT, "rib", name + ".rib"), tmp, width=8, height=8, gather_nsamples=1,
+                                          pixel_samples=1, record=False)
+        ng = int(r["ngeoms"]); d[name + "_ngeoms"] = ng
+        d[name + "_camera"] = np.append(r["camera"][[*range(17), 19]], float(r["ortho"]))   # c2w[16], flength, is_rh, ortho
+        for g in range(ng):
+            d["%s_pos%d" % (name, g)] = r["pos%d" % g]; d["%s_idx%d" % (name, g)] = r["idx%d" % g]
+            d["%s_two%d" % (name, g)] = r["two_side%d" % g]
+            if "nrm%d" % g in r:
+                d["%s_nrm%d" % (name, g)] = r["nrm%d" % g]
+        print("rib", name, ng, "geoms", sum(len(r["idx%d" % g]) // 3 for g in range(ng)), "triangles")
+    np.savez_compressed(os.path.join(OUT, "rib_parse.npz"), **d)
+
+
+def hdr_fixture():
+    """Bytes the reference's "file" display driver (hdrdrv.c -> rgbe.c, run-length coded) writes for
+    seeded float frames: inputs are reproducible from the recipe in tests/test_rib.py::hdr_frames."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_rib import hdr_frames
+    R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "liblucille_ref.so"))
+    R.hdr_dd_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+    R.hdr_dd_write.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    d = {}
+    for name, img in hdr_frames():
+        h, w, _ = img.shape
+        path = os.path.join("/tmp", "golden_%s.hdr" % name)
+        assert R.hdr_dd_open(path.encode(), w, h, 32, b"rgb", b"float") == 1
+        for y in range(h):
+            for x in range(w):
+                px = np.ascontiguousarray(img[y, x]); R.hdr_dd_write(x, y, px.ctypes.data)
+        R.hdr_dd_close()
+        d[name] = np.frombuffer(open(path, "rb").read(), np.uint8)
+        print("hdr", name, img.shape, len(d[name]), "bytes")
+    np.savez_compressed(os.path.join(OUT, "hdr_bytes.npz"), **d)
+
+
 if __name__ == "__main__":
+    if "--rib" in sys.argv:
+        rib_fixture(); hdr_fixture(); sys.exit(0)
     if not po.ref_available(stat=True):
         po.build_ref()
     soup_fixture("soup_20k", 20000, 20000, 0.005)
@@ -109,5 +157,7 @@ if __name__ == "__main__":
     # examples/plane_sphere (BASELINE config 4's scene): 1 986 triangles, vertex normals (Ns is
     # interpolated), ReadArchive, lh orientation; small frame, 2x2 pixel samples
     ao_fixture("ao_ps", "/root/reference/examples/plane_sphere/Scene_DEFAULT_Set0.rib", 96, 96, 9, pixel_samples=2)
+    rib_fixture()
+    hdr_fixture()
     # check values of the full S-soup-1M are pinned in
     # tests/test_oracle_vs_ref.py against the live reference, not stored here.

@@ -105,11 +105,15 @@ def test_c1_ray_dump_hit_records(c1):
         assert np.array_equal(occ.cpu().numpy().astype(bool), hit)
 
 
+@pytest.mark.parametrize("ortho", [0, 1])
 @pytest.mark.parametrize("ps", [1, 2, 4])
-def test_primary_rays_bit_exact(c1, ps):
-    """device camera rays == ri_camera_get_pos_and_dir + Hammersley jitter, every bit"""
+def test_primary_rays_bit_exact(c1, ps, ortho):
+    """device camera rays == ri_camera_get_pos_and_dir + Hammersley jitter, every bit; the
+    orthographic branch (camera.c:285-301, the reference's default projection) as well"""
+    import copy
     import torch
-    acc, cam, ocam = c1["acc"], c1["cam"], c1["ocam"]
+    acc, cam, ocam = c1["acc"], copy.copy(c1["cam"]), copy.copy(c1["ocam"])
+    cam.ortho = ocam.ortho = ortho
     x0, y0, w, h = 37, 101, 50, 23
     org, dr = acc.primary_rays(cam, x0, y0, w, h, ps)
     torch.cuda.synchronize()

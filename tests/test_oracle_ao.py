@@ -98,3 +98,23 @@ def test_ao_live_reference(tmp_path, w, h, ns, ps):
     assert np.array_equal(R["org"], rec["org"]) and np.array_equal(R["dir"], rec["dir"])
     assert np.array_equal(R["t"], rec["t"]) and np.array_equal(R["u"], rec["u"]) and np.array_equal(R["v"], rec["v"])
     assert np.array_equal(img, r["image"])
+
+
+@pytest.mark.skipif(not po.ref_available(), reason="compiled reference not built (no /root/reference)")
+def test_orthographic_camera_rays_live_reference(tmp_path):
+    """tests/golden/rib/tut1.rib has no Projection: the reference's default orthographic camera
+    (camera.c:100,285-301).  Its rays are axis-parallel, i.e. inside the |dir.y| <= 1e-14 case where
+    the reference's traversal reads an unset invdir (bvh.c:483-487) and misses everything: the
+    camera rays are compared (bit for bit), the hits are outside the contract."""
+    import os
+    from oracle import ref_rib
+    from tests.helpers import GOLDEN
+    r = ref_rib.render_rib_subprocess(os.path.join(GOLDEN, "rib", "tut1.rib"), str(tmp_path / "t1.npz"), width=24, height=16,
+                                      gather_nsamples=4, pixel_samples=2)
+    R = r["records"]
+    assert int(r["ortho"]) == 1 and len(R) == 24 * 16 * 4
+    o = po.Oracle(); o.add_mesh(r["pos0"], r["idx0"]); o.build()
+    cam = po.Camera.from_ref(r["camera"]); cam.ortho = 1
+    _, rec = o.render_ao(cam, 2, 4)
+    primary = (rec["org"][:, 2] == 0) & (rec["dir"][:, 2] == 1)
+    assert np.array_equal(rec["org"][primary], R["org"]) and np.array_equal(rec["dir"][primary], R["dir"])
