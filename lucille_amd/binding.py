@@ -26,7 +26,8 @@ class LucilleHipError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(CSRC, "liblucille_hip.so")
+    """LH_LIBRARY overrides the path (A/B runs of differently built kernels in tools/)"""
+    return os.environ.get("LH_LIBRARY") or os.path.join(CSRC, "liblucille_hip.so")
 
 
 def build_library(force=False):

@@ -375,10 +375,12 @@ static void build4(lh_bvh_t *o, uint32_t i2, uint32_t k4, uint32_t depth, uint32
         lh_q4node_t *q = &o->q4nodes[k4];
         for (c = 0; c < 4; c++) {
             if (c < n) {
-                quant_box(o, ch[c].lo, ch[c].hi, q->q[c]);
+                uint16_t qb[6];
+                quant_box(o, ch[c].lo, ch[c].hi, qb);
+                for (k = 0; k < 3; k++) q->w[c][k] = (uint32_t)qb[k] | ((uint32_t)qb[3 + k] << 16);
                 q->ref[c] = (ch[c].ref >= 0) ? (int32_t)kid[c] : ch[c].ref;
             } else {
-                for (k = 0; k < 3; k++) { q->q[c][k] = 65535; q->q[c][3 + k] = 0; }
+                for (k = 0; k < 3; k++) q->w[c][k] = 65535u;          /* lo = 65535, hi = 0: inverted */
                 q->ref[c] = LH_REF_EMPTY;
             }
         }

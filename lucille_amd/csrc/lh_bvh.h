@@ -65,10 +65,12 @@ typedef struct lh_tri64 { double v[3][3]; } lh_tri64_t;
  * inner child opened first) so that one 64-byte record -- one L2 request -- decides four
  * children.  The traversal kernel runs at the L2 request-rate ceiling of its footprint
  * (profiles/README.md), so halving the records per ray is what raises rays/s.
- *   q[c][0..2] lo xyz, q[c][3..5] hi xyz of child c; ref[c] as in lh_node_t
- *   (LH_REF_EMPTY for unused slots, whose box is inverted)                              */
+ *   w[c][k] = lo | hi << 16 of child c on axis k: one dword holds both planes of an axis, so
+ *   the kernel picks (near, far) for the ray's direction sign with ONE rotate
+ *   (v_alignbit_b32 by 0 or 16) instead of two selects, then converts the halves (SDWA);
+ *   ref[c] as in lh_node_t (LH_REF_EMPTY for unused slots, whose box is inverted)       */
 typedef struct lh_q4node {
-    uint16_t q[4][6];
+    uint32_t w[4][3];
     int32_t  ref[4];
 } lh_q4node_t;
 

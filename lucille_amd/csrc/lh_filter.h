@@ -135,6 +135,20 @@ LH_HD int lh_slab_q(const lh_ray32_t *r, float lox, float loy, float loz,
     return tn <= tf;
 }
 
+/* the same test on lh_q4node_t's packing: w = lo | hi << 16 per axis */
+LH_HD int lh_slab_w(const lh_ray32_t *r, uint32_t wx, uint32_t wy, uint32_t wz, float tb, float *tn_out)
+{
+    const uint32_t sx = r->ngx ? ((wx >> 16) | (wx << 16)) : wx;
+    const uint32_t sy = r->ngy ? ((wy >> 16) | (wy << 16)) : wy;
+    const uint32_t sz = r->ngz ? ((wz >> 16) | (wz << 16)) : wz;
+    const float tn = fmaxf(fmaxf(fmaf((float)(sx & 0xffffu), r->qax, r->qbnx), fmaf((float)(sy & 0xffffu), r->qay, r->qbny)),
+                           fmaxf(fmaf((float)(sz & 0xffffu), r->qaz, r->qbnz), 0.0f));
+    const float tf = fminf(fminf(fmaf((float)(sx >> 16), r->qax, r->qbfx), fmaf((float)(sy >> 16), r->qay, r->qbfy)),
+                           fminf(fmaf((float)(sz >> 16), r->qaz, r->qbfz), tb));
+    *tn_out = tn;
+    return tn <= tf;
+}
+
 #define LH_TRI_REJECT    0
 #define LH_TRI_CANDIDATE 1   /* cannot be decided in fp32: resolve in fp64   */
 #define LH_TRI_CERTAIN   2   /* inside by more than the tolerance: a hit in

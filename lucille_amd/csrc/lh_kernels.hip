@@ -114,6 +114,7 @@ __device__ __forceinline__ void node_test(const lh_dev_scene_t &sc, const lh_ray
 
 struct Lane {
     lh_ray32_t r;          /* fp32 ray + slab/filter constants */
+    uint32_t sh[3];        /* 16 where the direction is negative: rotate lo|hi<<16 into (near, far) */
     float tb;              /* culling bound (fp32, rounded up) */
     int   cur, sp;         /* traversal cursor, stack pointer  */
     uint32_t p0, p1, p2, p3;   /* pending fp64 candidates      */
@@ -127,10 +128,30 @@ __device__ __forceinline__ void lane_init(Lane &L, const lh_dev_scene_t &sc,
 {
     lh_ray_setup(&L.r, ox, oy, oz, dx, dy, dz, sc.scene_r);
     if (sc.use_qnodes) lh_ray_setup_grid(&L.r, sc.grid_lo, sc.grid_step, sc.scene_r);
+    L.sh[0] = L.r.ngx ? 16u : 0u; L.sh[1] = L.r.ngy ? 16u : 0u; L.sh[2] = L.r.ngz ? 16u : 0u;
     L.tb = 1.0e38f;
     L.cur = 0; L.sp = 1;
     L.p0 = L.p1 = L.p2 = L.p3 = LH_MISS_PRIM; L.np = 0;
     L.certain = false;
+}
+
+/* lh_slab_w (lh_filter.h) written for the VALU: per axis one rotate (v_alignbit_b32 by 0 or 16)
+ * puts (near, far) into the (low, high) halves, two SDWA converts, two FMAs: 136 VALU ops per
+ * 4-wide node step instead of 161 with per-plane selects.  Measured (A/B, 50 M rays): +1.5 %;
+ * v_pk_fma_f32 for the two FMAs is 2 % SLOWER, reading the stack top before the slab tests
+ * instead of after the pushes changes nothing -- the step is not VALU- or LDS-latency-bound
+ * (profiles/README.md, r01d). */
+__device__ __forceinline__ bool slab_w(const Lane &L, uint32_t wx, uint32_t wy, uint32_t wz, float &tn_out)
+{
+    const uint32_t sx = __builtin_amdgcn_alignbit(wx, wx, L.sh[0]);
+    const uint32_t sy = __builtin_amdgcn_alignbit(wy, wy, L.sh[1]);
+    const uint32_t sz = __builtin_amdgcn_alignbit(wz, wz, L.sh[2]);
+    const float tn = fmaxf(fmaxf(fmaf((float)(sx & 0xffffu), L.r.qax, L.r.qbnx), fmaf((float)(sy & 0xffffu), L.r.qay, L.r.qbny)),
+                           fmaxf(fmaf((float)(sz & 0xffffu), L.r.qaz, L.r.qbnz), 0.0f));
+    const float tf = fminf(fminf(fmaf((float)(sx >> 16), L.r.qax, L.r.qbfx), fmaf((float)(sy >> 16), L.r.qay, L.r.qbfy)),
+                           fminf(fmaf((float)(sz >> 16), L.r.qaz, L.r.qbfz), L.tb));
+    tn_out = tn;
+    return tn <= tf;
 }
 
 /* the per-lane traversal body; runs while the lane has work, leaves when
@@ -386,14 +407,10 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
             const uint4 a = p[0], b = p[1], c = p[2], r = p[3];
             if (COUNT) c_nodes++;
             float t0, t1, t2, t3;
-            const bool h0 = lh_slab_q(&L.r, (float)(a.x & 0xffffu), (float)(a.x >> 16), (float)(a.y & 0xffffu),
-                                      (float)(a.y >> 16), (float)(a.z & 0xffffu), (float)(a.z >> 16), L.tb, &t0) & ((int)r.x != kDone);
-            const bool h1 = lh_slab_q(&L.r, (float)(a.w & 0xffffu), (float)(a.w >> 16), (float)(b.x & 0xffffu),
-                                      (float)(b.x >> 16), (float)(b.y & 0xffffu), (float)(b.y >> 16), L.tb, &t1) & ((int)r.y != kDone);
-            const bool h2 = lh_slab_q(&L.r, (float)(b.z & 0xffffu), (float)(b.z >> 16), (float)(b.w & 0xffffu),
-                                      (float)(b.w >> 16), (float)(c.x & 0xffffu), (float)(c.x >> 16), L.tb, &t2) & ((int)r.z != kDone);
-            const bool h3 = lh_slab_q(&L.r, (float)(c.y & 0xffffu), (float)(c.y >> 16), (float)(c.z & 0xffffu),
-                                      (float)(c.z >> 16), (float)(c.w & 0xffffu), (float)(c.w >> 16), L.tb, &t3) & ((int)r.w != kDone);
+            const bool h0 = slab_w(L, a.x, a.y, a.z, t0) & ((int)r.x != kDone);
+            const bool h1 = slab_w(L, a.w, b.x, b.y, t1) & ((int)r.y != kDone);
+            const bool h2 = slab_w(L, b.z, b.w, c.x, t2) & ((int)r.z != kDone);
+            const bool h3 = slab_w(L, c.y, c.z, c.w, t3) & ((int)r.w != kDone);
             /* entry distances are >= 0, so their bit patterns order like unsigned integers */
             const uint32_t k0 = h0 ? ((__float_as_uint(t0) & ~3u) | 0u) : 0xFFFFFFFCu;
             const uint32_t k1 = h1 ? ((__float_as_uint(t1) & ~3u) | 1u) : 0xFFFFFFFDu;
@@ -410,10 +427,10 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
             stk[h3 ? base - rk3 : L.sp + rk3][tid] = (int)r.w;
             L.sp = base;
             const int nxt = stk[base][tid];
+            const int popped2 = stk[L.sp - 1][tid];
             const bool is_leaf = (nxt < 0) & (nxt != kDone);
             const bool park = is_leaf & (pend == kNoLeaf);
             pend = park ? nxt : pend;
-            const int popped2 = stk[L.sp - 1][tid];
             L.cur = park ? popped2 : nxt;
             L.sp -= park ? 1 : 0;
         }

@@ -66,8 +66,7 @@ static void trace_one(job_t *j, size_t i)
                 const lh_q4node_t *n = &b->q4nodes[cur]; float tn[4]; int h[4], c, nh = 0, order[4], m;
                 j->c[0]++;
                 for (c = 0; c < 4; c++) {
-                    h[c] = lh_slab_q(&r, n->q[c][0], n->q[c][1], n->q[c][2], n->q[c][3], n->q[c][4], n->q[c][5], tb, &tn[c])
-                           && n->ref[c] != DONE;
+                    h[c] = lh_slab_w(&r, n->w[c][0], n->w[c][1], n->w[c][2], tb, &tn[c]) && n->ref[c] != DONE;
                     if (h[c]) order[nh++] = c;
                 }
                 for (c = 1; c < nh; c++) {                 /* nearest first (same key as the kernel: low 2 bits = slot) */

@@ -46,7 +46,7 @@ elif what == "bvh":
         acc.close()
 elif what == "sort":
     acc, info = mk()
-    base = timeit(acc, 0, 2)
+    base = timeit(acc, 0, 4)
     # coherence potential: sort rays by a Morton key of the origin (+ direction octant) with torch (experiment only)
     def morton(o, bits):
         q = (o.clamp(0, 0.999999) * (1 << bits)).long()
@@ -55,11 +55,11 @@ elif what == "sort":
             for k in range(3):
                 key |= ((q[:, k] >> b) & 1) << (3 * b + k)
         return key
-    for bits in (4, 6, 8):
+    for bits in (3, 4, 5, 6, 8):
         key = morton(d_org, bits) * 8 + ((d_dir[:, 0] < 0).long() | ((d_dir[:, 1] < 0).long() << 1) | ((d_dir[:, 2] < 0).long() << 2))
         perm = torch.argsort(key)
         so = d_org[perm].contiguous(); sd = d_dir[perm].contiguous()
-        print("sorted bits", bits, "closest %.1f (unsorted %.1f) any %.1f Mrays/s" % (timeit(acc, 0, 2, o=so, d=sd), base, timeit(acc, 1, 2, o=so, d=sd)), flush=True)
+        print("sorted bits", bits, "closest %.1f (unsorted %.1f) any %.1f Mrays/s" % (timeit(acc, 0, 4, o=so, d=sd), base, timeit(acc, 1, 4, o=so, d=sd)), flush=True)
         key2 = ((d_dir[:, 0] < 0).long() | ((d_dir[:, 1] < 0).long() << 1) | ((d_dir[:, 2] < 0).long() << 2)) * (1 << (3 * bits)) + morton(d_org, bits)
         perm = torch.argsort(key2); so = d_org[perm].contiguous(); sd = d_dir[perm].contiguous()
-        print("  octant-major bits", bits, "closest %.1f any %.1f" % (timeit(acc, 0, 2, o=so, d=sd), timeit(acc, 1, 2, o=so, d=sd)), flush=True)
+        print("  octant-major bits", bits, "closest %.1f any %.1f" % (timeit(acc, 0, 4, o=so, d=sd), timeit(acc, 1, 4, o=so, d=sd)), flush=True)

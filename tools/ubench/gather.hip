@@ -80,6 +80,34 @@ __global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ nodes,
             acc += a.y + b.y + c.y + d.y + e.y;
             cur = (a.x ^ (acc & 1)) % (nnodes / 4);
         }
+    } else if (MODE == 8) {          /* 64-byte nodes, one chain per LANE, quad-transposed fetch: in phase p every lane
+                                      * of a quad loads one 16-byte piece of quad-lane p's node (4 lanes -> one 64-byte
+                                      * contiguous request), then the quad transposes the pieces with DPP */
+        const int j = threadIdx.x & 3;
+        uint32_t cur = (gid * 2654435761u) % nnodes;
+        for (int s = 0; s < steps; s++) {
+            uint4 R[4];
+#define QB(v, P) (uint32_t)__builtin_amdgcn_mov_dpp((int)(v), (P) * 0x55, 0xf, 0xf, true)
+            R[0] = nodes[4 * (size_t)QB(cur, 0) + j];
+            R[1] = nodes[4 * (size_t)QB(cur, 1) + j];
+            R[2] = nodes[4 * (size_t)QB(cur, 2) + j];
+            R[3] = nodes[4 * (size_t)QB(cur, 3) + j];
+            /* butterfly transpose of the 4x4 (lane x register) matrix of 16-byte pieces */
+#define XSWAP(A, B, CTRL, BIT) { \
+                const bool hi = (j & (BIT)) != 0; \
+                uint4 snd = hi ? A : B, rcv; \
+                rcv.x = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd.x, CTRL, 0xf, 0xf, true); \
+                rcv.y = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd.y, CTRL, 0xf, 0xf, true); \
+                rcv.z = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd.z, CTRL, 0xf, 0xf, true); \
+                rcv.w = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd.w, CTRL, 0xf, 0xf, true); \
+                if (hi) A = rcv; else B = rcv; }
+            XSWAP(R[0], R[1], 0xB1, 1)       /* quad_perm [1,0,3,2] */
+            XSWAP(R[2], R[3], 0xB1, 1)
+            XSWAP(R[0], R[2], 0x4E, 2)       /* quad_perm [2,3,0,1] */
+            XSWAP(R[1], R[3], 0x4E, 2)
+            acc += R[0].y + R[1].y + R[2].y + R[3].y;
+            cur = (R[0].x ^ (acc & 1)) % nnodes;
+        }
     } else {
         uint32_t cur = (gid * 2654435761u) % (nnodes * 4);
         for (int s = 0; s < steps; s++) {
@@ -116,6 +144,7 @@ int main(int argc, char **argv)
             case 3: hipLaunchKernelGGL(k_gather<3>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
             case 5: hipLaunchKernelGGL(k_gather<5>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
             case 6: hipLaunchKernelGGL(k_gather<6>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
+            case 8: hipLaunchKernelGGL(k_gather<8>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
             case 7: hipLaunchKernelGGL(k_gather<7>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
             default: hipLaunchKernelGGL(k_gather<4>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
             }
