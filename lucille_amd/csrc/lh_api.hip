@@ -72,6 +72,7 @@ struct lh_accel {
     double upload_seconds;
     int grid_blocks;
     int min_active;
+    uint32_t ray_chunk;                /* rays reserved per cursor atomic (LH_RAY_CHUNK) */
     int tri_batch;
     int default_variant;
     /* staging for host batches */
@@ -114,6 +115,10 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     if (env && atoi(env) > 0 && atoi(env) <= 64) a->tri_batch = atoi(env);
     env = getenv("LH_MIN_ACTIVE");
     if (env && atoi(env) > 0 && atoi(env) <= 64) a->min_active = atoi(env);
+    a->ray_chunk = 256;
+    env = getenv("LH_RAY_CHUNK");
+    if (env && atoi(env) > 0 && atoi(env) <= (1 << 20)) a->ray_chunk = (uint32_t)atoi(env);
+    a->dev.ray_chunk = a->ray_chunk;
     *out = a;
     return 0;
 }
@@ -245,7 +250,7 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
     double t0 = now_s();
     HIPCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(unsigned long long)));
-    HIPCHK(hipMalloc((void **)&a->d_counters, sizeof(unsigned long long) * LH_CNT_N));
+    HIPCHK(hipMalloc((void **)&a->d_counters, sizeof(unsigned long long) * LH_CNT_DEV));
     HIPCHK(hipMalloc((void **)&a->d_total, sizeof(unsigned long long)));
     if (a->h_nrm9) {
         HIPCHK(hipMalloc(&a->d_nrm9, sizeof(double) * 9 * (size_t)a->bvh.ntris));
@@ -274,7 +279,7 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
         for (int k = 0; k < 3; k++) { r = fmaxf(r, fabsf(a->bvh.bmin[k])); r = fmaxf(r, fabsf(a->bvh.bmax[k])); }
         a->dev.nodes = a->d_nodes; a->dev.tri32 = a->d_tri32; a->dev.tri64 = a->d_tri64;
         a->dev.ntris = a->bvh.ntris; a->dev.nnodes = a->bvh.nnodes;
-        a->dev.max_depth = a->bvh.max_depth; a->dev.scene_r = r;
+        a->dev.max_depth = a->bvh.max_depth; a->dev.scene_r = r; a->dev.ray_chunk = a->ray_chunk;
         a->dev.qnodes = a->d_qnodes;
         for (int k = 0; k < 3; k++) { a->dev.grid_lo[k] = a->bvh.grid_lo[k]; a->dev.grid_step[k] = a->bvh.grid_step[k]; }
         if (a->have_ref) {
@@ -435,16 +440,19 @@ extern "C" int lh_accel_intersect_device_counted(lh_accel_t *a, size_t n, const 
     if (!a || !a->committed) return fail("intersect: accel not committed");
     if (!counters) return fail("intersect_counted: counters is NULL");
     HIPCHK(hipSetDevice(a->device));
-    HIPCHK(hipMemsetAsync(a->d_counters, 0, sizeof(unsigned long long) * LH_CNT_N, a->stream));
+    HIPCHK(hipMemsetAsync(a->d_counters, 0, sizeof(unsigned long long) * LH_CNT_DEV, a->stream));
     HIPCHK(hipDeviceSynchronize());
     if (a->bvh.ntris == 0) { counters[0] = counters[1] = counters[2] = 0; counters[3] = n; }
     int rc = launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, variant, a->d_counters, a->stream);
     if (rc != 0) return rc;
     HIPCHK(hipStreamSynchronize(a->stream));
     if (a->bvh.ntris) {
-        unsigned long long h[LH_CNT_N];
+        unsigned long long h[LH_CNT_DEV];
         HIPCHK(hipMemcpy(h, a->d_counters, sizeof(h), hipMemcpyDeviceToHost));
         for (int k = 0; k < LH_CNT_N; k++) counters[k] = h[k];
+        if (getenv("LH_DEBUG_COUNTERS"))
+            fprintf(stderr, "[lucille_hip] lane slots: node steps %llu of %llu, triangle steps %llu of %llu, regroup iterations %llu\n",
+                    h[LH_CNT_NODES], h[LH_CNT_NODE_SLOTS], h[LH_CNT_TRIS], h[LH_CNT_TRI_SLOTS], h[LH_CNT_REGROUP_SLOTS]);
     }
     return 0;
 }
@@ -476,7 +484,7 @@ extern "C" int lh_accel_intersect_host(lh_accel_t *a, size_t n, const double *or
     uint8_t *d_occ = (uint8_t *)(d_prim + n);
     HIPCHK(hipMemcpyAsync(d_org, org, b_ray, hipMemcpyHostToDevice, a->stream));
     HIPCHK(hipMemcpyAsync(d_dir, dir, b_ray, hipMemcpyHostToDevice, a->stream));
-    if (a->stat_on) HIPCHK(hipMemsetAsync(a->d_counters, 0, sizeof(unsigned long long) * LH_CNT_N, a->stream));
+    if (a->stat_on) HIPCHK(hipMemsetAsync(a->d_counters, 0, sizeof(unsigned long long) * LH_CNT_DEV, a->stream));
     int rc = launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, LH_VARIANT_DEFAULT,
                     a->stat_on ? a->d_counters : NULL, a->stream);
     if (rc != 0) return rc;

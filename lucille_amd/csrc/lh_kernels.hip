@@ -396,12 +396,14 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
                                                double ox, double oy, double oz,
                                                double dx, double dy, double dz, Best &best,
                                                uint32_t &c_nodes, uint32_t &c_tris, uint32_t &c_exact,
-                                               const int min_active, const int tri_batch)
+                                               const int min_active, const int tri_batch,
+                                               uint32_t &c_nslots, uint32_t &c_tslots)
 {
     const float4 *__restrict__ tris  = (const float4 *)sc.tri32;
     constexpr int kNoLeaf = 0;
 
     for (;;) {
+        if (COUNT) { if (__ballot(L.cur >= 0) != 0ull) c_nslots++; }
         if (L.cur >= 0) {
             const uint4 *p = (const uint4 *)sc.q4nodes + 4 * (size_t)L.cur;
             const uint4 a = p[0], b = p[1], c = p[2], r = p[3];
@@ -437,6 +439,7 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
         const unsigned long long m_node = __ballot(L.cur >= 0);
         const unsigned long long m_pend = __ballot(pend != kNoLeaf);
         if (m_pend != 0ull && (__popcll(m_pend) >= tri_batch || m_node == 0ull)) {
+            if (COUNT) c_tslots++;
             if (pend != kNoLeaf) {
                 const uint32_t x = ~(uint32_t)pend;
                 const float4 *tp = tris + 3 * (size_t)(x >> 2);
@@ -591,18 +594,20 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
     extern __shared__ int lh_stack_lds[];          /* [stack entries][LH_BLOCK], sized at launch */
     int (*stk)[LH_BLOCK] = (int (*)[LH_BLOCK])lh_stack_lds;
     const int tid = threadIdx.x;
-    uint32_t cn = 0, ct = 0, ce = 0, cr = 0;
+    uint32_t cn = 0, ct = 0, ce = 0, cr = 0, cns = 0, cts = 0, crs = 0;
     Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM};
     int pend = 0;                    /* WALK 2: parked leaf reference (0 = none) */
     size_t my = (size_t)-1;          /* ray this lane is working on */
     double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
     L.cur = kDone; L.sp = 1; L.np = 0; L.certain = false;
     bool exhausted = false;          /* wave-uniform: cursor ran past n */
+    unsigned long long wbase = 0, wend = 0;   /* wave-uniform: this wave's reserved ray range */
 
     for (;;) {
         /* ---- regroup: retire finished lanes, refill them ----------------- */
         const bool idle = (L.cur == kDone) && (pend == 0);
         const unsigned long long idle_mask = __ballot(idle);
+        if (COUNT) crs++;
         if (idle) {
             if (my != (size_t)-1) {
                 finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
@@ -610,31 +615,40 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
                 if (COUNT) cr++;
                 my = (size_t)-1;
             }
-            if (!exhausted) {
-                const int need = __popcll(idle_mask);
-                const int rank = __popcll(idle_mask & ((1ull << (tid & 63)) - 1ull));
-                unsigned long long base = 0;
-                if (rank == 0) base = atomicAdd(cursor, (unsigned long long)need);
-                base = __shfl(base, __ffsll((long long)idle_mask) - 1);
-                const size_t i = base + rank;
-                if (i < n) {
-                    my = i;
-                    ox = org[3 * i]; oy = org[3 * i + 1]; oz = org[3 * i + 2];
-                    dx = dir[3 * i]; dy = dir[3 * i + 1]; dz = dir[3 * i + 2];
-                    lane_init(L, sc, ox, oy, oz, dx, dy, dz);
-                    best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM;
-                    stk[0][tid] = kDone;
-                }
-                if (base + need >= n) exhausted = true;
-            }
         }
-        exhausted = __any(exhausted);
+        /* refill from the wave's private range [wbase, wend); one atomic on the global cursor reserves
+         * sc.ray_chunk rays (the cursor is ONE address: at a refill per ~33 rays it serialised the whole
+         * grid -- 64 M same-address atomics/s for 2.1 Grays/s, profiles/README.md r01e) */
+        if (idle_mask != 0ull && !exhausted) {
+            if (wbase == wend) {
+                unsigned long long b = 0;
+                if ((tid & 63) == 0) b = atomicAdd(cursor, (unsigned long long)sc.ray_chunk);
+                b = __shfl(b, 0);
+                wbase = b < n ? b : n;
+                wend = (b + sc.ray_chunk < n) ? b + sc.ray_chunk : n;
+            }
+            const int need = __popcll(idle_mask);
+            const unsigned long long avail = wend - wbase;
+            const int take = avail < (unsigned long long)need ? (int)avail : need;
+            const int rank = __popcll(idle_mask & ((1ull << (tid & 63)) - 1ull));
+            if (idle && rank < take) {
+                const size_t i = wbase + rank;
+                my = i;
+                ox = org[3 * i]; oy = org[3 * i + 1]; oz = org[3 * i + 2];
+                dx = dir[3 * i]; dy = dir[3 * i + 1]; dz = dir[3 * i + 2];
+                lane_init(L, sc, ox, oy, oz, dx, dy, dz);
+                best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM;
+                stk[0][tid] = kDone;
+            }
+            wbase += take;
+            if (wbase >= n) exhausted = true;          /* the grid has handed out every ray */
+        }
         const unsigned long long work = __ballot((L.cur != kDone) | (pend != 0));
         if (work == 0ull) break;
         /* ---- walk until too few lanes remain active ---------------------- */
         const int thresh = exhausted ? 1 : min_active;
         if (WALK == 3) {
-            traverse_spec4<ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch);
+            traverse_spec4<ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts);
         } else if (WALK == 2) {
             /* every lane enters (idle lanes just vote in the ballots) */
             traverse_spec<ANYHIT, COUNT, QN>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch);
@@ -643,7 +657,12 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
             else traverse<ANYHIT, COUNT, true, QN>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
         }
     }
-    if (COUNT) add_counters(counters, cn, ct, ce, cr);
+    if (COUNT) {
+        add_counters(counters, cn, ct, ce, cr);
+        atomicAdd(&counters[LH_CNT_NODE_SLOTS], (unsigned long long)cns);
+        atomicAdd(&counters[LH_CNT_TRI_SLOTS], (unsigned long long)cts);
+        atomicAdd(&counters[LH_CNT_REGROUP_SLOTS], (unsigned long long)crs);
+    }
 }
 
 template <bool ANYHIT, bool COUNT, bool QN>
