@@ -8,6 +8,7 @@
 #include <vector>
 
 #include <math.h>
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -64,7 +65,9 @@ struct lh_accel {
     /* device */
     lh_dev_scene_t dev;
     void *d_nodes, *d_tri32, *d_tri64, *d_qnodes, *d_q4nodes;
-    unsigned long long *d_cursor, *d_counters;
+    unsigned long long *d_cursor, *d_counters;   /* d_cursor: LH_NCURSOR slots, one per launch in flight */
+    unsigned cursor_next;
+    pthread_mutex_t mu;                /* serialises the entry points of ONE accelerator (recursive) */
     int stat_on;                       /* lh_accel_trace_statistics */
     unsigned long long stat[5];        /* nodes, filter tests, fp64 tests, rays, hits */
     hipStream_t stream;
@@ -84,6 +87,16 @@ struct lh_accel {
     lh_buf p_org2, p_dir2, p_path, p_path2, p_thr, p_thr2, p_rad, p_alive;   /* path tracer */
     unsigned long long *d_total;
     size_t r_nsamples, r_nslots, r_nao;
+};
+
+#define LH_NCURSOR 64
+
+/* lucille calls accel->intersect from up to 16 render threads at once (render.c:1043-1105): every
+ * entry point that touches the accelerator's buffers holds its lock */
+struct lh_guard {
+    pthread_mutex_t *m;
+    explicit lh_guard(const lh_accel_t *a) : m(a ? (pthread_mutex_t *)&a->mu : NULL) { if (m) pthread_mutex_lock(m); }
+    ~lh_guard() { if (m) pthread_mutex_unlock(m); }
 };
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -106,6 +119,10 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     lh_accel_t *a = (lh_accel_t *)calloc(1, sizeof(*a));
     if (!a) return fail("out of memory");
     a->device = device;
+    {
+        pthread_mutexattr_t at; pthread_mutexattr_init(&at); pthread_mutexattr_settype(&at, PTHREAD_MUTEX_RECURSIVE);
+        pthread_mutex_init(&a->mu, &at); pthread_mutexattr_destroy(&at);
+    }
     a->default_variant = LH_VARIANT_SPEC;
     const char *env = getenv("LH_VARIANT");
     if (env) a->default_variant = atoi(env);
@@ -126,6 +143,7 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
 extern "C" int lh_accel_add_mesh(lh_accel_t *a, uint32_t npos, const double *pos, size_t stride,
                                  uint32_t nidx, const uint32_t *idx)
 {
+    lh_guard guard(a);
     if (!a) return fail("lh_accel_add_mesh: accel is NULL");
     if (a->committed) return fail("lh_accel_add_mesh: accel already committed");
     if ((npos && !pos) || (nidx && !idx)) return fail("lh_accel_add_mesh: NULL array");
@@ -151,6 +169,7 @@ extern "C" int lh_accel_add_mesh(lh_accel_t *a, uint32_t npos, const double *pos
 
 extern "C" int lh_accel_set_normals(lh_accel_t *a, uint32_t mesh, const double *nrm, size_t stride, int two_side)
 {
+    lh_guard guard(a);
     if (!a) return fail("lh_accel_set_normals: accel is NULL");
     if (a->committed) return fail("lh_accel_set_normals: accel already committed");
     if (mesh >= a->nmeshes) return fail("lh_accel_set_normals: mesh %u out of range", mesh);
@@ -201,6 +220,7 @@ static void release_device(lh_accel_t *a)
 
 extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
 {
+    lh_guard guard(a);
     if (!a) return fail("lh_accel_commit: accel is NULL");
     if (a->committed) return fail("lh_accel_commit: already committed");
     if (build_threads <= 0) {
@@ -249,7 +269,7 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
     HIPCHK(hipSetDevice(a->device));
     double t0 = now_s();
     HIPCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
-    HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(unsigned long long) * LH_NCURSOR));
     HIPCHK(hipMalloc((void **)&a->d_counters, sizeof(unsigned long long) * LH_CNT_DEV));
     HIPCHK(hipMalloc((void **)&a->d_total, sizeof(unsigned long long)));
     if (a->h_nrm9) {
@@ -347,6 +367,7 @@ extern "C" void lh_accel_destroy(lh_accel_t *a)
     free(a->meshes); free(a->h_nrm9);
     lh_bvh_release(&a->bvh);
     lh_refbvh_release(&a->ref);
+    pthread_mutex_destroy(&a->mu);
     free(a);
 }
 
@@ -372,6 +393,7 @@ extern "C" int lh_accel_prim_lookup(const lh_accel_t *a, uint32_t prim, uint32_t
 
 extern "C" int lh_accel_set_grid(lh_accel_t *a, int blocks)
 {
+    lh_guard guard(a);
     if (!a || blocks <= 0) return fail("lh_accel_set_grid: bad argument");
     a->grid_blocks = blocks;
     return 0;
@@ -421,7 +443,7 @@ static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
     if (variant < 0 || variant > LH_VARIANT_SPEC) return fail("intersect: unknown variant %d", variant);
     int rc = lh_launch_trace(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim,
                              (double *)d_t, (double *)d_u, (double *)d_v, mode == LH_MODE_ANY,
-                             (uint8_t *)d_occ, d_counters, a->d_cursor, variant, a->grid_blocks, a->min_active, a->tri_batch, (void *)s);
+                             (uint8_t *)d_occ, d_counters, a->d_cursor + (a->cursor_next++ % LH_NCURSOR), variant, a->grid_blocks, a->min_active, a->tri_batch, (void *)s);
     if (rc != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     return 0;
 }
@@ -430,6 +452,7 @@ extern "C" int lh_accel_intersect_device(lh_accel_t *a, size_t n, const void *d_
                                          void *d_prim, void *d_t, void *d_u, void *d_v, void *d_occ,
                                          int mode, int variant, void *stream)
 {
+    lh_guard guard(a);
     return launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, variant, NULL, (hipStream_t)stream);
 }
 
@@ -437,6 +460,7 @@ extern "C" int lh_accel_intersect_device_counted(lh_accel_t *a, size_t n, const 
                                                  void *d_prim, void *d_t, void *d_u, void *d_v, void *d_occ,
                                                  int mode, int variant, uint64_t counters[4])
 {
+    lh_guard guard(a);
     if (!a || !a->committed) return fail("intersect: accel not committed");
     if (!counters) return fail("intersect_counted: counters is NULL");
     HIPCHK(hipSetDevice(a->device));
@@ -469,6 +493,7 @@ static int ensure_stage(lh_accel_t *a, size_t bytes)
 extern "C" int lh_accel_intersect_host(lh_accel_t *a, size_t n, const double *org, const double *dir,
                                        uint32_t *prim, double *t, double *u, double *v, uint8_t *occ, int mode)
 {
+    lh_guard guard(a);
     if (!a || !a->committed) return fail("intersect: accel not committed");
     if (n == 0) return 0;
     if (!org || !dir) return fail("intersect: NULL ray arrays");
@@ -516,6 +541,7 @@ extern "C" int lh_accel_intersect_host(lh_accel_t *a, size_t n, const double *or
 
 extern "C" int lh_accel_trace_statistics(lh_accel_t *a, int enable)
 {
+    lh_guard guard(a);
     if (!a) return fail("lh_accel_trace_statistics: NULL accel");
     a->stat_on = enable != 0;
     return 0;
@@ -523,6 +549,7 @@ extern "C" int lh_accel_trace_statistics(lh_accel_t *a, int enable)
 
 extern "C" int lh_accel_statistics(lh_accel_t *a, uint64_t counters[5], int clear)
 {
+    lh_guard guard(a);
     if (!a) return fail("lh_accel_statistics: NULL accel");
     if (counters) for (int k = 0; k < 5; k++) counters[k] = a->stat[k];
     if (clear) for (int k = 0; k < 5; k++) a->stat[k] = 0;
@@ -559,6 +586,7 @@ static int ensure_buf(lh_buf *b, size_t bytes)
 extern "C" int lh_render_primary_rays(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h,
                                       int ps, void *d_org, void *d_dir, void *stream)
 {
+    lh_guard guard(a);
     if (!a || !a->committed) return fail("lh_render_primary_rays: accel not committed");
     if (!cam || !d_org || !d_dir) return fail("lh_render_primary_rays: NULL argument");
     if (w < 0 || h < 0 || ps < 1) return fail("lh_render_primary_rays: bad tile");
@@ -570,6 +598,7 @@ extern "C" int lh_render_primary_rays(lh_accel_t *a, const lh_camera_t *cam, int
 
 extern "C" int lh_accel_add_rib_scene(lh_accel_t *a, const lh_rib_scene_t *scene)
 {
+    lh_guard guard(a);
     lh_rib_info_t info;
     if (!a || !scene) return fail("lh_accel_add_rib_scene: NULL argument");
     if (lh_rib_info(scene, &info) != 0) return fail("lh_accel_add_rib_scene: %s", lh_rib_last_error());
@@ -587,6 +616,7 @@ extern "C" int lh_render_ao_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
                                  int gather_nsamples, uint64_t seed, const void *d_uniforms, void *d_rgb,
                                  lh_tile_stats_t *stats, void *stream)
 {
+    lh_guard guard(a);
     if (!a || !a->committed) return fail("lh_render_ao_tile: accel not committed");
     if (!cam || !d_rgb) return fail("lh_render_ao_tile: NULL argument");
     if (w <= 0 || h <= 0 || ps < 1 || gather_nsamples < 1) return fail("lh_render_ao_tile: bad tile/sample counts");
@@ -647,6 +677,7 @@ extern "C" int lh_render_ao_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
 
 extern "C" int lh_render_scratch(lh_accel_t *a, int which, void **d_ptr, size_t *count)
 {
+    lh_guard guard(a);
     if (!a || !a->committed || !d_ptr || !count) return fail("lh_render_scratch: bad argument");
     lh_buf *b[] = {&a->r_org, &a->r_dir, &a->r_prim, &a->r_t, &a->r_u, &a->r_v, &a->r_slot, &a->r_hitrec,
                    &a->r_aorg, &a->r_adir, &a->r_occ};
@@ -671,6 +702,7 @@ __global__ void k_fill_i32(size_t n, int32_t *p, int32_t v)
 extern "C" int lh_accel_beam_visibility_device(lh_accel_t *a, size_t n, const void *d_org, const void *d_dirs,
                                                void *d_result, void *stream)
 {
+    lh_guard guard(a);
     if (!a || !a->committed) return fail("beam_visibility: accel not committed");
     if (n == 0) return 0;
     if (!d_org || !d_dirs || !d_result) return fail("beam_visibility: NULL argument");
@@ -685,6 +717,7 @@ extern "C" int lh_accel_beam_visibility_device(lh_accel_t *a, size_t n, const vo
 
 extern "C" int lh_accel_beam_visibility_host(lh_accel_t *a, size_t n, const double *org, const double *dirs, int32_t *result)
 {
+    lh_guard guard(a);
     if (!a || !a->committed) return fail("beam_visibility: accel not committed");
     if (n == 0) return 0;
     if (!org || !dirs || !result) return fail("beam_visibility: NULL argument");
@@ -720,6 +753,7 @@ extern "C" int lh_render_pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
                                  int spp_total, int max_vertices, float kd, const float env[3], uint64_t seed,
                                  void *d_rgb, lh_pt_stats_t *stats, void *stream)
 {
+    lh_guard guard(a);
     if (!a || !a->committed) return fail("lh_render_pt_tile: accel not committed");
     if (!cam || !d_rgb || !env) return fail("lh_render_pt_tile: NULL argument");
     if (w <= 0 || h <= 0 || spp < 1 || spp_total < spp || max_vertices < 2 || !(kd > 0.0f) || kd > 1.0f)
@@ -771,6 +805,7 @@ extern "C" int lh_render_pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
 extern "C" int lh_render_ao_frame_host(lh_accel_t *a, const lh_camera_t *cam, int ps, int gather_nsamples,
                                        uint64_t seed, int tile, float *rgb, lh_tile_stats_t *stats)
 {
+    lh_guard guard(a);
     if (!a || !a->committed) return fail("lh_render_ao_frame_host: accel not committed");
     if (!cam || !rgb) return fail("lh_render_ao_frame_host: NULL argument");
     if (cam->width <= 0 || cam->height <= 0) return fail("lh_render_ao_frame_host: bad resolution");

@@ -104,6 +104,40 @@ def test_host_batch_and_single_ray_entry_points():
         assert hit == int(exp[0][i] != po.MISS) and prim == exp[0][i] and t == exp[1][i] and u == exp[2][i] and v == exp[3][i]
 
 
+def test_concurrent_host_threads_like_the_reference_render_threads():
+    """lucille calls accel->intersect from up to 16 pthreads at once (render.c:1043-1105): batches of
+    different sizes and single rays from 12 threads through ONE accelerator, every record exact"""
+    import threading
+    P, idx, org, dr = po.soup(20000, 60000, 0.02, 77)
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr, nthreads=8)
+    acc = make_accel(P, idx)
+    errors = []
+
+    def worker(k):
+        try:
+            rng = np.random.default_rng(k)
+            for it in range(6):
+                n = int(rng.integers(1, 9000)); a = int(rng.integers(0, len(org) - n))
+                got = acc.intersect_host(org[a:a + n], dr[a:a + n])
+                for c in range(4):
+                    if not np.array_equal(got[c], exp[c][a:a + n]):
+                        errors.append("thread %d batch %d field %d" % (k, it, c)); return
+                occ = acc.intersect_host(org[a:a + n], dr[a:a + n], mode=la.MODE_ANY)
+                if not np.array_equal(occ.astype(bool), exp[0][a:a + n] != po.MISS):
+                    errors.append("thread %d any-hit %d" % (k, it)); return
+                for i in rng.integers(0, len(org), 15):
+                    hit, prim, t, u, v = acc.intersect1(org[i], dr[i])
+                    if not (prim == exp[0][i] and t == exp[1][i] and u == exp[2][i] and v == exp[3][i]):
+                        errors.append("thread %d single ray %d" % (k, i)); return
+        except Exception as e:                                   # noqa: BLE001
+            errors.append("thread %d: %r" % (k, e))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(12)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errors, errors[:3]
+
+
 def test_multi_mesh_prim_lookup():
     P1, i1, org, dr = po.soup(300, 5000, 0.1, 11)
     P2, i2, _, _ = po.soup(500, 1, 0.1, 22)
