@@ -170,6 +170,26 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- context figures (rank 0, untimed for `value`): the box's copy bandwidth and the host path ----
+    copy_gbps = host_path = None
+    if rank == 0 and not args.no_cpu:
+        big = torch.empty(1 << 30, dtype=torch.uint8, device=dev); dst = torch.empty_like(big)
+        dst.copy_(big); torch.cuda.synchronize(dev)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(big)
+        e1.record(); torch.cuda.synchronize(dev)
+        copy_gbps = 10 * 2 * big.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9       # read + write
+        del big, dst
+        nh = min(n, 10_000_000)
+        h_org = d_org[:nh].cpu().numpy(); h_dir = d_dir[:nh].cpu().numpy()
+        acc.intersect_host(h_org[:1000], h_dir[:1000])
+        th = time.perf_counter(); acc.intersect_host(h_org, h_dir); th = time.perf_counter() - th
+        host_path = {"value": round(nh / th / 1e6, 1), "unit": "Mrays/s",
+                     "sample": "%d rays through lh_accel_intersect_host: pageable host arrays, 48 B/ray up + 28 B/ray down over PCIe, "
+                               "one launch; never the headline value" % nh}
+
     ao = None
     if not args.no_ao:
         ao = ao_frame_leg(la, acc_device=local, rank=rank, world=world, size=args.ao_size, nsamples=args.ao_samples,
@@ -212,6 +232,12 @@ def main():
                          "kernel_ms": round(kernel_ms, 3), "bytes_per_ray": round(b_ray, 1),
                          "nodes_per_ray": round(n_nodes, 3), "tris_per_ray": round(n_tris, 3)},
         }
+        if copy_gbps is not None:
+            # the box's own device-to-device copy rate next to the 8 TB/s datasheet peak
+            res["roofline"]["measured_copy_GBps"] = round(copy_gbps, 1)
+            res["roofline"]["frac_of_measured_copy"] = round(achieved / copy_gbps, 4)
+        if host_path is not None:
+            res["host_path"] = host_path
         if ao is not None:
             res["ao_render"] = ao
         if pt is not None:

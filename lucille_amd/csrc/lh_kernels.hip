@@ -741,6 +741,17 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
     if (need < 16) need = 16;
     if (need > 64) return -1;
     const size_t lds_bytes = (size_t)need * LH_BLOCK * sizeof(int);
+    /* rays per cursor atomic: the scene's setting, but never so large that a wave gets fewer than
+     * ~4 ranges of a small batch (tail imbalance: late path-tracing bounces, small tiles) */
+    lh_dev_scene_t scl = *sc;
+    {
+        const size_t waves = (size_t)(grid_blocks > 0 ? grid_blocks : 1) * (LH_BLOCK / 64);
+        size_t c = n / (waves * 4);
+        if (c < 64) c = 64;
+        if (c < scl.ray_chunk) scl.ray_chunk = (uint32_t)c;
+        if (scl.ray_chunk == 0) scl.ray_chunk = 64;
+    }
+    sc = &scl;
     return launch_stack(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
                         d_counters, d_workq, variant, grid_blocks, min_active, tri_batch, lds_bytes, s);
 }

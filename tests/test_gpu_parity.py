@@ -234,6 +234,38 @@ def test_full_size_properties_soup_1m():
     assert_hits_equal(tuple(x.cpu().numpy()[:n] for x in res[2]), exp, "soup-1M prefix")
 
 
+def test_full_size_properties_soup_10m():
+    """BASELINE config 5 scale (S-soup-10M: 10 M triangles, half-extent 0.002): properties over 8 M
+    rays, and the first 200 k rays bit for bit against the oracle (its single-threaded build of this
+    scene is what takes most of this test's ~45 s)"""
+    import torch
+    ntri, nrays = 10000000, 8000000
+    P, idx, org, dr = po.soup(ntri, nrays, 0.002)
+    acc = make_accel(P, idx)
+    info = acc.info()
+    assert info["ntriangles"] == ntri
+    o_, d_ = torch_rays(org, dr)
+    out = acc.intersect_device(o_, d_)
+    occ = acc.intersect_device(o_, d_, mode=la.MODE_ANY)[0]
+    out0 = acc.intersect_device(o_[:500000].contiguous(), d_[:500000].contiguous(), variant=0)
+    torch.cuda.synchronize()
+    hit_t = out[0] != -1
+    assert torch.equal(hit_t, occ.bool())
+    assert (out[1][hit_t] >= 0).all() and (out[1][~hit_t] == 1.0e38).all()
+    for a, b in zip(out, out0):
+        assert torch.equal(a[:500000], b)                       # 4-wide speculative walk == 2-wide direct walk
+    prim = out[0].cpu().numpy().view(np.uint32); t = out[1].cpu().numpy()
+    hit = prim != la.MISS
+    assert 0.5 < hit.mean() < 0.999
+    tri = P[idx].reshape(-1, 3, 3)[prim[hit]]
+    X = org[hit] + dr[hit] * t[hit][:, None]
+    assert (X >= tri.min(1) - 1e-9).all() and (X <= tri.max(1) + 1e-9).all()
+    n = 200000
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org[:n], dr[:n], nthreads=32)
+    assert_hits_equal(tuple(x.cpu().numpy()[:n] for x in out), exp, "soup-10M prefix")
+
+
 @pytest.mark.parametrize("kind,log_scale,off", [("soup", -3, 0.0), ("soup", 3, -800.0), ("slivers", 0, 10.0), ("axis", 2, 500.0),
                                                 ("degenerate", -1, -3.0), ("slivers", -2, 0.5)])
 def test_scaled_translated_degenerate_scenes(kind, log_scale, off):
