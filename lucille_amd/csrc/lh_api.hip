@@ -475,8 +475,9 @@ extern "C" int lh_accel_intersect_device_counted(lh_accel_t *a, size_t n, const 
         HIPCHK(hipMemcpy(h, a->d_counters, sizeof(h), hipMemcpyDeviceToHost));
         for (int k = 0; k < LH_CNT_N; k++) counters[k] = h[k];
         if (getenv("LH_DEBUG_COUNTERS"))
-            fprintf(stderr, "[lucille_hip] lane slots: node steps %llu of %llu, triangle steps %llu of %llu, regroup iterations %llu\n",
-                    h[LH_CNT_NODES], h[LH_CNT_NODE_SLOTS], h[LH_CNT_TRIS], h[LH_CNT_TRI_SLOTS], h[LH_CNT_REGROUP_SLOTS]);
+            fprintf(stderr, "[lucille_hip] lane slots: node steps %llu of %llu, triangle steps %llu of %llu, regroup iterations %llu; "
+                            "rays through the reference walk %llu\n",
+                    h[LH_CNT_NODES], h[LH_CNT_NODE_SLOTS], h[LH_CNT_TRIS], h[LH_CNT_TRI_SLOTS], h[LH_CNT_REGROUP_SLOTS], h[LH_CNT_RETRACED]);
     }
     return 0;
 }

@@ -41,7 +41,9 @@ typedef struct lh_dev_scene {
 enum { LH_CNT_NODES = 0, LH_CNT_TRIS = 1, LH_CNT_EXACT = 2, LH_CNT_RAYS = 3, LH_CNT_N = 4,
        /* diagnostics of the COUNT build (LH_DEBUG_COUNTERS=1 prints them): lane slots offered by wave
         * iterations that ran a node step / a triangle step (64 per iteration), regroup iterations x 64 */
-       LH_CNT_NODE_SLOTS = 4, LH_CNT_TRI_SLOTS = 5, LH_CNT_REGROUP_SLOTS = 6, LH_CNT_DEV = 8 };
+       LH_CNT_NODE_SLOTS = 4, LH_CNT_TRI_SLOTS = 5, LH_CNT_REGROUP_SLOTS = 6,
+       LH_CNT_RETRACED = 7,      /* rays sent through the reference's own walk (lh_reftrace.h) */
+       LH_CNT_DEV = 8 };
 
 /* kernel variants (A/B-testable in one process) */
 enum {

@@ -174,15 +174,20 @@ LH_HD int lh_tri_filter(const lh_ray32_t *r, float v0x, float v0y, float v0z,
     const float t = fmaf(e2x, qx, fmaf(e2y, qy, e2z * qz)) * inva;
     const float g = r->keps * fabsf(inva);
     const float tolu = g * r->dn * ne2, tolv = g * r->dn * ne1, tolt = g * ne1 * ne2;
+    /* relative uncertainty of the determinant itself: when the fp32 determinant is noise (zero-area or
+     * edge-on triangle), so is the reference's -- and ITS noise can clear the |det| > 1e-14 test and
+     * yield an accepted "hit" (t = u = v = -0.0 on a triangle with two equal vertices was seen).
+     * Nothing can be concluded in fp32: fp64 decides.  (NaN-safe: !(x < c) is true for NaN.) */
+    const float rela = (LH_KTRI * LH_EPS24) * ne1 * ne2 * r->dn * fabsf(inva);
+    if (!(rela < 0.5f)) { *t_hi = 3.0e38f; return LH_TRI_CANDIDATE; }
     /* NaN-safe: a comparison with NaN is false => not rejected */
     const int reject = (u < -tolu) | (u > 1.0f + tolu) | (v < -tolv) |
                        (u + v > 1.0f + tolu + tolv) | (t < -tolt) | (t - tolt > tb);
     if (reject) return LH_TRI_REJECT;
     {
-        /* relative uncertainty of the determinant itself.  The reference also drops
+        /* The reference also drops
          * |det| <= 1e-14 as an ABSOLUTE threshold (bvh.c:754): a hit is only certain when
          * the fp64 determinant (within 25 % of a) clears it, else the fp64 resolve decides. */
-        const float rela = (LH_KTRI * LH_EPS24) * ne1 * ne2 * r->dn * fabsf(inva);
         const int sure = (u >= tolu) & (u <= 1.0f - tolu) & (v >= tolv) &
                          (u + v <= 1.0f - tolu - tolv) & (t >= tolt) & (rela < 0.25f) &
                          (fabsf(a) > 2.0e-14f) & (t + tolt < 1.0e37f);

@@ -41,6 +41,7 @@
 
 #include "lh_device.h"
 #include "lh_filter.h"
+#include "lh_reftrace.h"
 
 namespace {
 
@@ -50,6 +51,8 @@ constexpr int   kPend  = 4;
 struct Best {            /* exact (fp64) closest hit so far */
     double   t, u, v;
     uint32_t prim;
+    uint32_t frag;       /* bit 0: this hit is within rounding reach of a box face of the reference's tree
+                          * (lh_hit_fragile); bit 1 (sticky): two different triangles at almost equal t */
 };
 
 /* The reference's winner between two primitives hit at bit-equal t (lh_refbvh.c):
@@ -81,10 +84,16 @@ __device__ __forceinline__ void resolve(const lh_dev_scene_t &sc, uint32_t prim,
                                         double dx, double dy, double dz, Best &b)
 {
     double t, u, v;
-    if (lh_exact_isect((const double *)sc.tri64 + 9 * (size_t)prim, ox, oy, oz, dx, dy, dz, &t, &u, &v)) {
+    const double *tv = (const double *)sc.tri64 + 9 * (size_t)prim;
+    if (lh_exact_isect(tv, ox, oy, oz, dx, dy, dz, &t, &u, &v)) {
         bool take = t < b.t;
         if (!take && t == b.t && b.prim != LH_MISS_PRIM && prim != b.prim) take = tie_takes_new(sc, prim, b.prim, dx, dy, dz);
-        if (take && t < LH_T_INF) { b.t = t; b.u = u; b.v = v; b.prim = prim; }
+        /* almost-equal t of two triangles: which one the reference keeps can hinge on one box test */
+        if (b.prim != LH_MISS_PRIM && prim != b.prim && t != b.t && fabs(t - b.t) <= LH_FRAGILE_REL * fabs(t)) b.frag |= 2u;
+        if (take && t < LH_T_INF) {
+            b.t = t; b.u = u; b.v = v; b.prim = prim;
+            b.frag = (b.frag & 2u) | (uint32_t)lh_hit_fragile(tv, ox, oy, oz, dx, dy, dz, t);
+        }
     }
 }
 
@@ -501,12 +510,15 @@ template <bool ANYHIT>
 __device__ __forceinline__ void write_out(size_t i, const Lane &L, const Best &best,
                                           uint32_t *__restrict__ prim, double *__restrict__ t,
                                           double *__restrict__ u, double *__restrict__ v,
-                                          uint8_t *__restrict__ occ)
+                                          uint8_t *__restrict__ occ, const bool retrace_on)
 {
+    /* a hit the reference may not reach goes through the reference's own walk (k_ref_retrace);
+     * a certain fp32 hit is strictly inside its triangle, hence inside every box: never fragile */
+    const bool retrace = retrace_on && best.prim != LH_MISS_PRIM && best.frag != 0u && !(ANYHIT && L.certain);
     if (ANYHIT) {
-        occ[i] = (L.certain || best.prim != LH_MISS_PRIM) ? 1 : 0;
+        occ[i] = retrace ? (uint8_t)LH_OCC_RETRACE : ((L.certain || best.prim != LH_MISS_PRIM) ? 1 : 0);
     } else {
-        prim[i] = best.prim; t[i] = best.t; u[i] = best.u; v[i] = best.v;
+        prim[i] = retrace ? LH_PRIM_RETRACE : best.prim; t[i] = best.t; u[i] = best.u; v[i] = best.v;
     }
 }
 
@@ -536,13 +548,13 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_direct(
     if (i >= n) return;
     const double ox = org[3 * i], oy = org[3 * i + 1], oz = org[3 * i + 2];
     const double dx = dir[3 * i], dy = dir[3 * i + 1], dz = dir[3 * i + 2];
-    Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM};
+    Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM, 0u};
     uint32_t cn = 0, ct = 0, ce = 0;
     lane_init(L, sc, ox, oy, oz, dx, dy, dz);
     stk[0][tid] = kDone;
     traverse<ANYHIT, COUNT, false, QN>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, 0);
     finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
-    write_out<ANYHIT>(i, L, best, prim, t, u, v, occ);
+    write_out<ANYHIT>(i, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL);
     if (COUNT) add_counters(counters, cn, ct, ce, 1);
 }
 
@@ -569,12 +581,12 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_wave(
         if (i < n) {
             const double ox = org[3 * i], oy = org[3 * i + 1], oz = org[3 * i + 2];
             const double dx = dir[3 * i], dy = dir[3 * i + 1], dz = dir[3 * i + 2];
-            Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM};
+            Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM, 0u};
             lane_init(L, sc, ox, oy, oz, dx, dy, dz);
             stk[0][tid] = kDone;
             traverse<ANYHIT, COUNT, false, QN>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, 0);
             finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
-            write_out<ANYHIT>(i, L, best, prim, t, u, v, occ);
+            write_out<ANYHIT>(i, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL);
             if (COUNT) cr++;
         }
     }
@@ -595,7 +607,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
     int (*stk)[LH_BLOCK] = (int (*)[LH_BLOCK])lh_stack_lds;
     const int tid = threadIdx.x;
     uint32_t cn = 0, ct = 0, ce = 0, cr = 0, cns = 0, cts = 0, crs = 0;
-    Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM};
+    Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM, 0u};
     int pend = 0;                    /* WALK 2: parked leaf reference (0 = none) */
     size_t my = (size_t)-1;          /* ray this lane is working on */
     double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
@@ -611,7 +623,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         if (idle) {
             if (my != (size_t)-1) {
                 finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
-                write_out<ANYHIT>(my, L, best, prim, t, u, v, occ);
+                write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL);
                 if (COUNT) cr++;
                 my = (size_t)-1;
             }
@@ -637,7 +649,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
                 ox = org[3 * i]; oy = org[3 * i + 1]; oz = org[3 * i + 2];
                 dx = dir[3 * i]; dy = dir[3 * i + 1]; dz = dir[3 * i + 2];
                 lane_init(L, sc, ox, oy, oz, dx, dy, dz);
-                best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM;
+                best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM; best.frag = 0u;
                 stk[0][tid] = kDone;
             }
             wbase += take;
@@ -663,6 +675,26 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         atomicAdd(&counters[LH_CNT_TRI_SLOTS], (unsigned long long)cts);
         atomicAdd(&counters[LH_CNT_REGROUP_SLOTS], (unsigned long long)crs);
     }
+}
+
+/* ------------------------------------------------------------------------ */
+/* rays flagged by write_out: the reference's own walk on its own tree       */
+/* ------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_ref_retrace(lh_dev_scene_t sc, size_t n, const double *__restrict__ org,
+                                                     const double *__restrict__ dir, uint32_t *__restrict__ prim,
+                                                     double *__restrict__ t, double *__restrict__ u, double *__restrict__ v,
+                                                     uint8_t *__restrict__ occ, int anyhit, unsigned long long *counters)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (anyhit ? (occ[i] != LH_OCC_RETRACE) : (prim[i] != LH_PRIM_RETRACE)) return;
+    uint32_t p; double tt, uu, vv;
+    const int hit = lh_ref_trace((const lh_refnode_t *)sc.ref_nodes, (const uint32_t *)sc.ref_leaf_prims, (const double *)sc.tri64,
+                                 sc.ref_empty, sc.ref_bmin, sc.ref_bmax, org[3 * i], org[3 * i + 1], org[3 * i + 2],
+                                 dir[3 * i], dir[3 * i + 1], dir[3 * i + 2], &p, &tt, &uu, &vv);
+    if (anyhit) occ[i] = hit ? 1 : 0;
+    else { prim[i] = p; t[i] = tt; u[i] = uu; v[i] = vv; }
+    if (counters) atomicAdd(&counters[LH_CNT_RETRACED], 1ull);
 }
 
 template <bool ANYHIT, bool COUNT, bool QN>
@@ -735,15 +767,20 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
     /* stack entries needed: 2-wide walks <= tree depth + 1 (sentinel); the 4-wide walk pushes
      * up to 3 per level and writes up to 3 slots above its top.  The LDS stack is dynamic
      * shared memory of exactly that many rows (2-row granularity). */
+    lh_dev_scene_t scl = *sc;
     uint32_t need = sc->max_depth + 1;
-    if (variant == LH_VARIANT_SPEC && sc->use_qnodes == 2) need = 3 * sc->q4_depth + 5;
+    if (variant == LH_VARIANT_SPEC && sc->use_qnodes == 2) {
+        need = 3 * sc->q4_depth + 5;
+        /* a very deep tree (chains of nested geometry): the 4-wide walk's worst case does not fit the
+         * 64-row LDS stack; the 2-wide walk over the same tree (<= LH_MAX_DEPTH + 1 rows) always does */
+        if (need > 64) { scl.use_qnodes = 1; need = sc->max_depth + 1; }
+    }
     need = (need + 1u) & ~1u;
     if (need < 16) need = 16;
     if (need > 64) return -1;
     const size_t lds_bytes = (size_t)need * LH_BLOCK * sizeof(int);
     /* rays per cursor atomic: the scene's setting, but never so large that a wave gets fewer than
      * ~4 ranges of a small batch (tail imbalance: late path-tracing bounces, small tiles) */
-    lh_dev_scene_t scl = *sc;
     {
         const size_t waves = (size_t)(grid_blocks > 0 ? grid_blocks : 1) * (LH_BLOCK / 64);
         size_t c = n / (waves * 4);
@@ -752,6 +789,14 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
         if (scl.ray_chunk == 0) scl.ray_chunk = 64;
     }
     sc = &scl;
+    if (sc->ref_nodes) {
+        const int rc = launch_stack(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
+                                    d_counters, d_workq, variant, grid_blocks, min_active, tri_batch, lds_bytes, s);
+        if (rc != 0) return rc;
+        hipLaunchKernelGGL(k_ref_retrace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, *sc, n, d_org, d_dir,
+                           d_prim, d_t, d_u, d_v, d_occluded, anyhit, d_counters);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     return launch_stack(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
                         d_counters, d_workq, variant, grid_blocks, min_active, tri_batch, lds_bytes, s);
 }

@@ -17,13 +17,14 @@
 #include "lh_bvh.h"
 #include "lh_refbvh.h"
 #include "lh_filter.h"
+#include "lh_reftrace.h"
 
 #define MISS 0xFFFFFFFFu
 #define DONE ((int32_t)0x80000000)
 #define T_INF 1.0e38
 #define PEND 4
 
-typedef struct { double t, u, v; uint32_t prim; } best_t;
+typedef struct { double t, u, v; uint32_t prim; uint32_t frag; } best_t;
 
 static const lh_refbvh_t *g_ref = NULL;    /* reference-order tree for exact-t ties (optional) */
 
@@ -32,11 +33,15 @@ static void resolve(const lh_bvh_t *b, uint32_t prim, const double *o, const dou
     double t, u, v;
     if (lh_exact_isect(&b->tri64[prim].v[0][0], o[0], o[1], o[2], d[0], d[1], d[2], &t, &u, &v)) {
         int take = t < best->t;
+        if (best->prim != MISS && prim != best->prim && t != best->t && fabs(t - best->t) <= LH_FRAGILE_REL * fabs(t)) best->frag |= 2u;
         if (!take && t == best->t && best->prim != MISS && prim != best->prim) {
             if (g_ref) { int sg[3] = { d[0] < 0.0, d[1] < 0.0, d[2] < 0.0 }; take = lh_refbvh_tie_winner(g_ref, prim, best->prim, sg) == prim; }
             else take = prim > best->prim;
         }
-        if (take && t < T_INF) { best->t = t; best->u = u; best->v = v; best->prim = prim; }
+        if (take && t < T_INF) {
+            best->t = t; best->u = u; best->v = v; best->prim = prim;
+            best->frag = (best->frag & 2u) | (uint32_t)lh_hit_fragile(&b->tri64[prim].v[0][0], o[0], o[1], o[2], d[0], d[1], d[2], t);
+        }
     }
 }
 
@@ -50,7 +55,7 @@ static void trace_one(job_t *j, size_t i)
 {
     const lh_bvh_t *b = j->b;
     const double *o = &j->org[3 * i], *d = &j->dir[3 * i];
-    best_t best = { T_INF, 0.0, 0.0, MISS };
+    best_t best = { T_INF, 0.0, 0.0, MISS, 0u };
     int certain = 0;
     j->c[3]++;
     if (b->ntris) {
@@ -126,6 +131,16 @@ static void trace_one(job_t *j, size_t i)
             for (k = 0; k < np; k++) resolve(b, pend[k], o, d, &best);
             j->c[2] += (uint64_t)np;
         }
+    }
+    if (g_ref && best.prim != MISS && best.frag != 0u && !(j->anyhit && certain)) {
+        /* the kernel's retrace pass (k_ref_retrace): the reference's own walk decides */
+        uint32_t p; double tt, uu, vv;
+        const int hit = lh_ref_trace(g_ref->nodes, g_ref->leaf_prims, &b->tri64[0].v[0][0], g_ref->empty, g_ref->bmin, g_ref->bmax,
+                                     o[0], o[1], o[2], d[0], d[1], d[2], &p, &tt, &uu, &vv);
+        j->c[2]++;
+        if (j->anyhit) j->occ[i] = hit ? 1 : 0;
+        else { j->prim[i] = p; j->t[i] = tt; j->u[i] = uu; j->v[i] = vv; }
+        return;
     }
     if (j->anyhit) j->occ[i] = (certain || best.prim != MISS) ? 1 : 0;
     else { j->prim[i] = best.prim; j->t[i] = best.t; j->u[i] = best.u; j->v[i] = best.v; }

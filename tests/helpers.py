@@ -26,7 +26,8 @@ def build_model():
     the product's own BVH builder (lh_bvh.c) and arithmetic (lh_filter.h)."""
     so = os.path.join(MODEL_DIR, "liblh_model.so")
     srcs = [os.path.join(MODEL_DIR, "lh_model.c"), os.path.join(CSRC, "lh_bvh.c"), os.path.join(CSRC, "lh_refbvh.c"),
-            os.path.join(CSRC, "lh_bvh.h"), os.path.join(CSRC, "lh_filter.h"), os.path.join(CSRC, "lh_refbvh.h")]
+            os.path.join(CSRC, "lh_bvh.h"), os.path.join(CSRC, "lh_filter.h"), os.path.join(CSRC, "lh_refbvh.h"),
+            os.path.join(CSRC, "lh_reftrace.h")]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-shared"] + _fma_flag() +
                               ["-I" + CSRC, srcs[0], srcs[1], srcs[2], "-o", so, "-lm", "-lpthread"])
@@ -192,3 +193,25 @@ def random_beams(rng, n, spread, lo=-0.5, hi=1.5):
     d = np.stack([c - spread * a - spread * b, c + spread * a - spread * b, c + spread * a + spread * b,
                   c - spread * a + spread * b], 1)
     return org, d
+
+
+def chain_scene(n, ratio=0.5 ** 0.5):
+    """n triangles of geometrically shrinking size along a line: SAH peels them off one by one, so the
+    tree is about as deep as it can get (4-wide depth 26+ from n = 120), and every triangle is isolated
+    (a ray aimed at one of its vertices grazes box corners of the reference's tree)"""
+    k = np.arange(n); s_ = ratio ** k
+    base = np.stack([s_, s_ * 0.3, s_ * 0.1], 1)
+    P = np.concatenate([base, base + np.stack([s_ * 0.4, 0 * s_, 0 * s_], 1), base + np.stack([0 * s_, s_ * 0.4, s_ * 0.1], 1)], 1).reshape(-1, 3)
+    return P, np.arange(3 * n, dtype=np.uint32)
+
+
+def vertex_aimed_rays(rng, P, idx, n, spread=1.2):
+    """origins around the scene, targets EXACTLY on vertices / edge midpoints / centroids of triangles"""
+    T = P[idx].reshape(-1, 3, 3)
+    lo, hi = P.min(0), P.max(0)
+    org = rng.uniform(lo - (spread - 1) * (hi - lo) - 0.1, hi + (spread - 1) * (hi - lo) + 0.1, (n, 3))
+    pick = rng.integers(0, T.shape[0], n)
+    tgt = T[pick, rng.integers(0, 3, n)].copy()
+    tgt[1::3] = 0.5 * (T[pick[1::3], 0] + T[pick[1::3], 1])
+    tgt[2::5] = T[pick[2::5]].mean(axis=1)
+    return org, tgt - org
