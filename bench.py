@@ -172,7 +172,7 @@ def main():
 
     # ---- context figures (rank 0, untimed for `value`): the box's copy bandwidth and the host path ----
     copy_gbps = host_path = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:
         big = torch.empty(1 << 30, dtype=torch.uint8, device=dev); dst = torch.empty_like(big)
         dst.copy_(big); torch.cuda.synchronize(dev)
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -242,7 +242,7 @@ def main():
             res["ao_render"] = ao
         if pt is not None:
             res["pt_render"] = pt
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:            # rank 0 at N = 1 only (the contract)
             res["cpu_baseline"] = cpu_baseline(po, P, idx, first_org, first_dir)
         print(json.dumps(res), flush=True)
     acc.close()
