@@ -440,7 +440,7 @@ static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
         return 0;
     }
     if (variant == LH_VARIANT_DEFAULT) variant = a->default_variant;
-    if (variant < 0 || variant > LH_VARIANT_SPEC) return fail("intersect: unknown variant %d", variant);
+    if (variant < 0 || variant > LH_VARIANT_UNIFIED4) return fail("intersect: unknown variant %d", variant);
     int rc = lh_launch_trace(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim,
                              (double *)d_t, (double *)d_u, (double *)d_v, mode == LH_MODE_ANY,
                              (uint8_t *)d_occ, d_counters, a->d_cursor + (a->cursor_next++ % LH_NCURSOR), variant, a->grid_blocks, a->min_active, a->tri_batch, (void *)s);

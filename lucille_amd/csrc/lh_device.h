@@ -51,7 +51,8 @@ enum {
     LH_VARIANT_PERSIST_WAVE = 1,  /* persistent waves, 64-ray chunks          */
     LH_VARIANT_PERSIST_LANE = 2,  /* persistent waves, ballot-compacted refill */
     LH_VARIANT_UNIFIED      = 3,  /* + single-loop walk: one record per lane per iteration */
-    LH_VARIANT_SPEC         = 4   /* + speculative walk, leaves parked and tested in batches */
+    LH_VARIANT_SPEC         = 4,  /* + speculative walk, leaves parked and tested in batches */
+    LH_VARIANT_UNIFIED4     = 5   /* single-loop walk over the 4-wide nodes: one record per lane per iteration */
 };
 
 #ifdef __cplusplus

@@ -490,6 +490,81 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
     }
 }
 
+/* Single-loop walk over the 4-wide nodes (variant 5): every iteration every active lane consumes ONE
+ * record -- a 4-wide node (64 B) or one leaf triangle (48 B, padded) -- fetched by the same four
+ * dwordx4 loads, so a wave pays one memory round trip per iteration for both kinds of work.  The node
+ * step is traverse_spec4's (rank-derived stack writes); nothing is parked. */
+template <bool ANYHIT, bool COUNT>
+__device__ __forceinline__ void traverse_unified4(Lane &L, const lh_dev_scene_t &sc,
+                                                  int (*stk)[LH_BLOCK], const int tid,
+                                                  double ox, double oy, double oz,
+                                                  double dx, double dy, double dz, Best &best,
+                                                  uint32_t &c_nodes, uint32_t &c_tris, uint32_t &c_exact,
+                                                  const int min_active)
+{
+    const uint4 *__restrict__ nodes = (const uint4 *)sc.q4nodes;
+    const uint4 *__restrict__ tris  = (const uint4 *)sc.tri32;
+
+    while (L.cur != kDone) {
+        const bool is_node = L.cur >= 0;
+        const uint32_t x = ~(uint32_t)L.cur;
+        const uint4 *p = is_node ? nodes + 4 * (size_t)L.cur : tris + 3 * (size_t)(x >> 2);
+        const uint4 a = p[0], b = p[1], c = p[2], r = p[3];          /* tri32 is padded by 16 B */
+        if (is_node) {
+            if (COUNT) c_nodes++;
+            float t0, t1, t2, t3;
+            const bool h0 = slab_w(L, a.x, a.y, a.z, t0) & ((int)r.x != kDone);
+            const bool h1 = slab_w(L, a.w, b.x, b.y, t1) & ((int)r.y != kDone);
+            const bool h2 = slab_w(L, b.z, b.w, c.x, t2) & ((int)r.z != kDone);
+            const bool h3 = slab_w(L, c.y, c.z, c.w, t3) & ((int)r.w != kDone);
+            const uint32_t k0 = h0 ? ((__float_as_uint(t0) & ~3u) | 0u) : 0xFFFFFFFCu;
+            const uint32_t k1 = h1 ? ((__float_as_uint(t1) & ~3u) | 1u) : 0xFFFFFFFDu;
+            const uint32_t k2 = h2 ? ((__float_as_uint(t2) & ~3u) | 2u) : 0xFFFFFFFEu;
+            const uint32_t k3 = h3 ? ((__float_as_uint(t3) & ~3u) | 3u) : 0xFFFFFFFFu;
+            const int b10 = k1 < k0, b20 = k2 < k0, b30 = k3 < k0, b21 = k2 < k1, b31 = k3 < k1, b32 = k3 < k2;
+            const int rk0 = b10 + b20 + b30, rk1 = (1 - b10) + b21 + b31;
+            const int rk2 = (2 - b20 - b21) + b32, rk3 = 3 - b30 - b31 - b32;
+            const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+            const int base = L.sp + nh - 1;
+            stk[h0 ? base - rk0 : L.sp + rk0][tid] = (int)r.x;
+            stk[h1 ? base - rk1 : L.sp + rk1][tid] = (int)r.y;
+            stk[h2 ? base - rk2 : L.sp + rk2][tid] = (int)r.z;
+            stk[h3 ? base - rk3 : L.sp + rk3][tid] = (int)r.w;
+            L.sp = base;
+            L.cur = stk[base][tid];
+        } else {
+            if (COUNT) c_tris++;
+            float t_hi;
+            bool finished = false;
+            const int cls = lh_tri_filter(&L.r, __uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                                          __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w),
+                                          __uint_as_float(c.x), __uint_as_float(c.z), __uint_as_float(c.w), L.tb, &t_hi);
+            if (cls != LH_TRI_REJECT) {
+                const bool sure = (cls == LH_TRI_CERTAIN);
+                if (ANYHIT && sure) { L.certain = true; finished = true; }
+                else {
+                    if (sure) L.tb = fminf(L.tb, t_hi);
+                    const uint32_t prim = c.y;
+                    if (L.np == kPend) {
+                        if (COUNT) c_exact += kPend;
+                        resolve(sc, L.p0, ox, oy, oz, dx, dy, dz, best);
+                        resolve(sc, L.p1, ox, oy, oz, dx, dy, dz, best);
+                        resolve(sc, L.p2, ox, oy, oz, dx, dy, dz, best);
+                        resolve(sc, L.p3, ox, oy, oz, dx, dy, dz, best);
+                        L.np = 0;
+                        if (ANYHIT && best.prim != LH_MISS_PRIM) finished = true;
+                    }
+                    L.p3 = L.p2; L.p2 = L.p1; L.p1 = L.p0; L.p0 = prim; L.np++;
+                }
+            }
+            if (finished) L.cur = kDone;
+            else if (x & 3u) L.cur = (int)~(((x >> 2) + 1u) << 2 | ((x & 3u) - 1u));
+            else { L.sp--; L.cur = stk[L.sp][tid]; }
+        }
+        if (__popcll(__ballot(L.cur != kDone)) < min_active) break;
+    }
+}
+
 /* resolve whatever is still queued; afterwards `best` is the exact answer */
 template <bool ANYHIT, bool COUNT>
 __device__ __forceinline__ void finish(Lane &L, const lh_dev_scene_t &sc,
@@ -659,7 +734,9 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         if (work == 0ull) break;
         /* ---- walk until too few lanes remain active ---------------------- */
         const int thresh = exhausted ? 1 : min_active;
-        if (WALK == 3) {
+        if (WALK == 4) {
+            if (L.cur != kDone) traverse_unified4<ANYHIT, COUNT>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
+        } else if (WALK == 3) {
             traverse_spec4<ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts);
         } else if (WALK == 2) {
             /* every lane enters (idle lanes just vote in the ballots) */
@@ -719,6 +796,9 @@ int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const doub
         else if (variant == LH_VARIANT_UNIFIED)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 1, false>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
+        else if (variant == LH_VARIANT_UNIFIED4 && sc.use_qnodes == 2)
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 4, true>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
         else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 3, true>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
@@ -769,7 +849,7 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
      * shared memory of exactly that many rows (2-row granularity). */
     lh_dev_scene_t scl = *sc;
     uint32_t need = sc->max_depth + 1;
-    if (variant == LH_VARIANT_SPEC && sc->use_qnodes == 2) {
+    if ((variant == LH_VARIANT_SPEC || variant == LH_VARIANT_UNIFIED4) && sc->use_qnodes == 2) {
         need = 3 * sc->q4_depth + 5;
         /* a very deep tree (chains of nested geometry): the 4-wide walk's worst case does not fit the
          * 64-row LDS stack; the 2-wide walk over the same tree (<= LH_MAX_DEPTH + 1 rows) always does */
