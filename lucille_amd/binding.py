@@ -88,6 +88,10 @@ def lib():
     if _lib is not None:
         return _lib
     path = library_path()
+    try:                      # torch ships its own HIP runtime: let it initialise first when both live in one process
+        import torch          # noqa: F401
+    except Exception:         # noqa: BLE001 -- the library itself does not need torch
+        pass
     if not os.path.exists(path):
         raise LucilleHipError(
             "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C %s` "
