@@ -64,7 +64,7 @@ struct lh_accel {
     void *d_ref_lca, *d_prim_leafpos, *d_ref_nodes, *d_ref_leaf_prims;
     /* device */
     lh_dev_scene_t dev;
-    void *d_nodes, *d_tri32, *d_tri64, *d_qnodes, *d_q4nodes;
+    void *d_nodes, *d_tri32, *d_tri64, *d_qnodes, *d_q4nodes, *d_c8nodes, *d_tri32_c8;
     unsigned long long *d_cursor, *d_counters;   /* d_cursor: LH_NCURSOR slots, one per launch in flight */
     unsigned cursor_next;
     pthread_mutex_t mu;                /* serialises the entry points of ONE accelerator (recursive) */
@@ -205,6 +205,9 @@ static void release_device(lh_accel_t *a)
     a->d_qnodes = NULL;
     if (a->d_q4nodes) (void)hipFree(a->d_q4nodes);
     a->d_q4nodes = NULL;
+    if (a->d_c8nodes) (void)hipFree(a->d_c8nodes);
+    if (a->d_tri32_c8) (void)hipFree(a->d_tri32_c8);
+    a->d_c8nodes = a->d_tri32_c8 = NULL;
     if (a->d_ref_lca) (void)hipFree(a->d_ref_lca);
     if (a->d_prim_leafpos) (void)hipFree(a->d_prim_leafpos);
     if (a->d_ref_nodes) (void)hipFree(a->d_ref_nodes);
@@ -295,6 +298,18 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
         HIPCHK(hipMalloc(&a->d_q4nodes, q4b));
         HIPCHK(hipMemcpy(a->d_q4nodes, a->bvh.q4nodes, q4b, hipMemcpyHostToDevice));
         a->device_bytes = nb + t32 + t64 + qb + q4b;
+        {   /* the 8-wide compressed tree is an experiment (slower: its node step is VALU-bound,
+             * profiles/README.md r01d): resident only when asked for */
+            const char *fmt = getenv("LH_NODE_FORMAT");
+            if (fmt && strcmp(fmt, "c8") == 0) {
+                size_t c8b = sizeof(lh_c8node_t) * (size_t)a->bvh.nc8nodes;
+                HIPCHK(hipMalloc(&a->d_c8nodes, c8b + 64));
+                HIPCHK(hipMalloc(&a->d_tri32_c8, t32 + 64));
+                HIPCHK(hipMemcpy(a->d_c8nodes, a->bvh.c8nodes, c8b, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(a->d_tri32_c8, a->bvh.tri32_c8, t32, hipMemcpyHostToDevice));
+                a->device_bytes += c8b + t32;
+            }
+        }
         float r = 0.0f;
         for (int k = 0; k < 3; k++) { r = fmaxf(r, fabsf(a->bvh.bmin[k])); r = fmaxf(r, fabsf(a->bvh.bmax[k])); }
         a->dev.nodes = a->d_nodes; a->dev.tri32 = a->d_tri32; a->dev.tri64 = a->d_tri64;
@@ -331,12 +346,15 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
             a->device_bytes += sizeof(int) * 4 * (size_t)rn + sizeof(uint32_t) * 3 * (size_t)a->bvh.ntris + sizeof(lh_refnode_t) * (size_t)rn;
         }
         a->dev.q4nodes = a->d_q4nodes; a->dev.nq4nodes = a->bvh.nq4nodes; a->dev.q4_depth = a->bvh.q4_depth;
+        a->dev.c8nodes = a->d_c8nodes; a->dev.tri32_c8 = a->d_tri32_c8; a->dev.nc8nodes = a->bvh.nc8nodes; a->dev.c8_depth = a->bvh.c8_depth;
         a->dev.use_qnodes = 2;
         {
             const char *fmt = getenv("LH_NODE_FORMAT");
             if (fmt && strcmp(fmt, "f32") == 0) a->dev.use_qnodes = 0;
             if (fmt && strcmp(fmt, "q16") == 0) a->dev.use_qnodes = 1;
             if (3 * a->bvh.q4_depth + 5 > 64) a->dev.use_qnodes = 1;     /* pathological depth: 2-wide walk */
+            /* 8-wide compressed nodes: stack overflow is handed to the reference walk, so that tree is needed */
+            if (fmt && strcmp(fmt, "c8") == 0 && a->have_ref && a->d_c8nodes) a->dev.use_qnodes = 3;
         }
         if (a->bvh.max_depth + 1 > 64) return fail("lh_accel_commit: tree depth %u exceeds the kernel stack", a->bvh.max_depth);
     }

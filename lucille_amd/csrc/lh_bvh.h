@@ -74,6 +74,25 @@ typedef struct lh_q4node {
     int32_t  ref[4];
 } lh_q4node_t;
 
+/* 80-byte 8-wide node, boxes on an 8-bit grid LOCAL to the node (Ylitie, Karras, Laine: "Efficient
+ * Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", HPG 2017 -- the layout, not their
+ * code): child s has box [p + qlo[k][s] * 2^(e[k]-127) , p + qhi[k][s] * 2^(e[k]-127)] per axis k
+ * (lo rounded down, hi rounded up: the decoded box contains the fp32 box).  Inner children are
+ * adjacent: index = child_base + popcount(imask & ((1 << s) - 1)).  Leaf children index a triangle
+ * array kept in THIS tree's order (tri32_c8): meta = 0x80 | (count-1) << 5 | offset, triangles
+ * [tri_base + offset, + count).  Children sit in octant order: slot s = (x high) | (y high) << 1 |
+ * (z high) << 2 relative to the node centre (greedy assignment), so visiting slots in order of
+ * s ^ (ray octant) is front to back without sorting distances.  Empty slot: meta 0, imask bit 0. */
+typedef struct lh_c8node {
+    float    p[3];
+    uint8_t  e[3];
+    uint8_t  imask;
+    uint32_t child_base, tri_base;
+    uint8_t  meta[8];
+    uint8_t  qlo[3][8];
+    uint8_t  qhi[3][8];
+} lh_c8node_t;
+
 typedef struct lh_bvh {
     uint32_t    ntris;
     uint32_t    nnodes;
@@ -88,6 +107,9 @@ typedef struct lh_bvh {
     lh_qnode_t *qnodes;            /* nnodes, same indexing as nodes         */
     lh_q4node_t *q4nodes;          /* nq4nodes: 4-wide collapse of the same tree */
     uint32_t    nq4nodes, q4_depth;
+    lh_c8node_t *c8nodes;          /* nc8nodes: 8-wide collapse of the same tree (lh_c8node_t) */
+    lh_tri32_t  *tri32_c8;         /* ntris, in the 8-wide tree's leaf order */
+    uint32_t    nc8nodes, c8_depth;
     float       grid_lo[3], grid_step[3];   /* quantisation grid of qnodes   */
     double      build_seconds;
 } lh_bvh_t;

@@ -129,6 +129,7 @@ struct Lane {
     uint32_t p0, p1, p2, p3;   /* pending fp64 candidates      */
     int   np;
     bool  certain;         /* any-hit: a certain fp32 hit was found */
+    bool  over;            /* 8-wide walk: the LDS stack would overflow; the ray goes to the reference walk */
 };
 
 __device__ __forceinline__ void lane_init(Lane &L, const lh_dev_scene_t &sc,
@@ -141,7 +142,7 @@ __device__ __forceinline__ void lane_init(Lane &L, const lh_dev_scene_t &sc,
     L.tb = 1.0e38f;
     L.cur = 0; L.sp = 1;
     L.p0 = L.p1 = L.p2 = L.p3 = LH_MISS_PRIM; L.np = 0;
-    L.certain = false;
+    L.certain = false; L.over = false;
 }
 
 /* lh_slab_w (lh_filter.h) written for the VALU: per axis one rotate (v_alignbit_b32 by 0 or 16)
@@ -490,6 +491,123 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
     }
 }
 
+/* Speculative walk over the 8-wide compressed nodes (lh_c8node_t, use_qnodes == 3): 80-byte records,
+ * five dwordx4 loads, eight children per visit in octant order -- no distance sort: child s has
+ * priority s ^ oct (0 = nearest) and hit children are written to the stack by rank among the hits
+ * (popcount of nearer hits), nearest on top.  Leaves are parked and tested in batches exactly as in
+ * traverse_spec4; their triangles come from tri32_c8.  If the stack would overflow (rows are capped
+ * so that three workgroups fit a CU) the ray is handed to the reference walk (write_out). */
+template <bool ANYHIT, bool COUNT>
+__device__ __forceinline__ void traverse_c8(Lane &L, int &pend, const lh_dev_scene_t &sc,
+                                            int (*stk)[LH_BLOCK], const int tid,
+                                            double ox, double oy, double oz,
+                                            double dx, double dy, double dz, Best &best,
+                                            uint32_t &c_nodes, uint32_t &c_tris, uint32_t &c_exact,
+                                            const int min_active, const int tri_batch)
+{
+    const float4 *__restrict__ tris = (const float4 *)sc.tri32_c8;
+    constexpr int kNoLeaf = 0;
+    const uint32_t oct = (uint32_t)L.r.ngx | ((uint32_t)L.r.ngy << 1) | ((uint32_t)L.r.ngz << 2);
+    const int rows = (int)sc.stack_rows;
+
+    for (;;) {
+        if (L.cur >= 0) {
+            const uint4 *p = (const uint4 *)((const char *)sc.c8nodes + 80 * (size_t)L.cur);
+            const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
+            if (COUNT) c_nodes++;
+            if (L.sp + 9 > rows) { L.over = true; L.cur = kDone; pend = kNoLeaf; }
+            else {
+                lh_c8frame_t f;
+                lh_c8_frame(&L.r, __uint_as_float(n0.x), __uint_as_float(n0.y), __uint_as_float(n0.z),
+                            n0.w & 255u, (n0.w >> 8) & 255u, (n0.w >> 16) & 255u, &f);
+                const uint32_t imask = n0.w >> 24;
+                /* near / far plane bytes for the ray's direction signs: 4 children per dword */
+                const uint32_t nxA = L.r.ngx ? n3.z : n2.x, nxB = L.r.ngx ? n3.w : n2.y, fxA = L.r.ngx ? n2.x : n3.z, fxB = L.r.ngx ? n2.y : n3.w;
+                const uint32_t nyA = L.r.ngy ? n4.x : n2.z, nyB = L.r.ngy ? n4.y : n2.w, fyA = L.r.ngy ? n2.z : n4.x, fyB = L.r.ngy ? n2.w : n4.y;
+                const uint32_t nzA = L.r.ngz ? n4.z : n3.x, nzB = L.r.ngz ? n4.w : n3.y, fzA = L.r.ngz ? n3.x : n4.z, fzB = L.r.ngz ? n3.y : n4.w;
+                uint32_t hp = 0u;                 /* hits, bit position = priority (0 nearest) */
+                int ref[8];
+#define LH_C8_CHILD(S, NX, NY, NZ, FX, FY, FZ, META) { \
+                    const uint32_t m_ = ((META) >> (8 * ((S) & 3))) & 255u; \
+                    const bool inner_ = (imask >> (S)) & 1u; \
+                    float tn_; \
+                    const bool hit_ = lh_slab_c8(&f, (float)(((NX) >> (8 * ((S) & 3))) & 255u), (float)(((NY) >> (8 * ((S) & 3))) & 255u), \
+                                                 (float)(((NZ) >> (8 * ((S) & 3))) & 255u), (float)(((FX) >> (8 * ((S) & 3))) & 255u), \
+                                                 (float)(((FY) >> (8 * ((S) & 3))) & 255u), (float)(((FZ) >> (8 * ((S) & 3))) & 255u), L.tb, &tn_) \
+                                      & (inner_ | (m_ != 0u)); \
+                    hp |= (hit_ ? 1u : 0u) << ((uint32_t)(S) ^ oct); \
+                    ref[S] = inner_ ? (int)(n1.x + (uint32_t)__popc(imask & ((1u << (S)) - 1u))) \
+                                    : (int)~(((n1.y + (m_ & 31u)) << 2) | ((m_ >> 5) & 3u)); }
+                LH_C8_CHILD(0, nxA, nyA, nzA, fxA, fyA, fzA, n1.z)
+                LH_C8_CHILD(1, nxA, nyA, nzA, fxA, fyA, fzA, n1.z)
+                LH_C8_CHILD(2, nxA, nyA, nzA, fxA, fyA, fzA, n1.z)
+                LH_C8_CHILD(3, nxA, nyA, nzA, fxA, fyA, fzA, n1.z)
+                LH_C8_CHILD(4, nxB, nyB, nzB, fxB, fyB, fzB, n1.w)
+                LH_C8_CHILD(5, nxB, nyB, nzB, fxB, fyB, fzB, n1.w)
+                LH_C8_CHILD(6, nxB, nyB, nzB, fxB, fyB, fzB, n1.w)
+                LH_C8_CHILD(7, nxB, nyB, nzB, fxB, fyB, fzB, n1.w)
+#undef LH_C8_CHILD
+                const int nh = __popc(hp);
+                const int base = L.sp + nh - 1;
+#pragma unroll
+                for (int sl = 0; sl < 8; sl++) {
+                    const uint32_t pr = (uint32_t)sl ^ oct;
+                    if ((hp >> pr) & 1u) stk[base - __popc(hp & ((1u << pr) - 1u))][tid] = ref[sl];
+                }
+                L.sp = base;
+                const int nxt = stk[base][tid];
+                const bool is_leaf = (nxt < 0) & (nxt != kDone);
+                const bool park = is_leaf & (pend == kNoLeaf);
+                pend = park ? nxt : pend;
+                const int popped2 = stk[L.sp - 1][tid];
+                L.cur = park ? popped2 : nxt;
+                L.sp -= park ? 1 : 0;
+            }
+        }
+        const unsigned long long m_node = __ballot(L.cur >= 0);
+        const unsigned long long m_pend = __ballot(pend != kNoLeaf);
+        if (m_pend != 0ull && (__popcll(m_pend) >= tri_batch || m_node == 0ull)) {
+            if (pend != kNoLeaf) {
+                const uint32_t x = ~(uint32_t)pend;
+                const float4 *tp = tris + 3 * (size_t)(x >> 2);
+                const float4 ta = tp[0], tb_ = tp[1], tc = tp[2];
+                if (COUNT) c_tris++;
+                float t_hi;
+                bool finished = false;
+                const int cls = lh_tri_filter(&L.r, ta.x, ta.y, ta.z, ta.w, tb_.x, tb_.y,
+                                              tb_.z, tb_.w, tc.x, tc.z, tc.w, L.tb, &t_hi);
+                if (cls != LH_TRI_REJECT) {
+                    const bool sure = (cls == LH_TRI_CERTAIN);
+                    if (ANYHIT && sure) { L.certain = true; finished = true; }
+                    else {
+                        if (sure) L.tb = fminf(L.tb, t_hi);
+                        const uint32_t prim = __float_as_uint(tc.y);
+                        if (L.np == kPend) {
+                            if (COUNT) c_exact += kPend;
+                            resolve(sc, L.p0, ox, oy, oz, dx, dy, dz, best);
+                            resolve(sc, L.p1, ox, oy, oz, dx, dy, dz, best);
+                            resolve(sc, L.p2, ox, oy, oz, dx, dy, dz, best);
+                            resolve(sc, L.p3, ox, oy, oz, dx, dy, dz, best);
+                            L.np = 0;
+                            if (ANYHIT && best.prim != LH_MISS_PRIM) finished = true;
+                        }
+                        L.p3 = L.p2; L.p2 = L.p1; L.p1 = L.p0; L.p0 = prim; L.np++;
+                    }
+                }
+                if (finished) { L.cur = kDone; pend = kNoLeaf; }
+                else if (x & 3u) pend = (int)~(((x >> 2) + 1u) << 2 | ((x & 3u) - 1u));
+                else {
+                    const bool waiting = (L.cur < 0) & (L.cur != kDone);
+                    pend = waiting ? L.cur : kNoLeaf;
+                    if (waiting) { L.sp--; L.cur = stk[L.sp][tid]; }
+                }
+            }
+        }
+        const unsigned long long m_work = __ballot((L.cur != kDone) | (pend != kNoLeaf));
+        if (__popcll(m_work) < min_active) break;
+    }
+}
+
 /* Single-loop walk over the 4-wide nodes (variant 5): every iteration every active lane consumes ONE
  * record -- a 4-wide node (64 B) or one leaf triangle (48 B, padded) -- fetched by the same four
  * dwordx4 loads, so a wave pays one memory round trip per iteration for both kinds of work.  The node
@@ -589,7 +707,7 @@ __device__ __forceinline__ void write_out(size_t i, const Lane &L, const Best &b
 {
     /* a hit the reference may not reach goes through the reference's own walk (k_ref_retrace);
      * a certain fp32 hit is strictly inside its triangle, hence inside every box: never fragile */
-    const bool retrace = retrace_on && best.prim != LH_MISS_PRIM && best.frag != 0u && !(ANYHIT && L.certain);
+    const bool retrace = retrace_on && (L.over || (best.prim != LH_MISS_PRIM && best.frag != 0u && !(ANYHIT && L.certain)));
     if (ANYHIT) {
         occ[i] = retrace ? (uint8_t)LH_OCC_RETRACE : ((L.certain || best.prim != LH_MISS_PRIM) ? 1 : 0);
     } else {
@@ -686,7 +804,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
     int pend = 0;                    /* WALK 2: parked leaf reference (0 = none) */
     size_t my = (size_t)-1;          /* ray this lane is working on */
     double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
-    L.cur = kDone; L.sp = 1; L.np = 0; L.certain = false;
+    L.cur = kDone; L.sp = 1; L.np = 0; L.certain = false; L.over = false;
     bool exhausted = false;          /* wave-uniform: cursor ran past n */
     unsigned long long wbase = 0, wend = 0;   /* wave-uniform: this wave's reserved ray range */
 
@@ -734,7 +852,9 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         if (work == 0ull) break;
         /* ---- walk until too few lanes remain active ---------------------- */
         const int thresh = exhausted ? 1 : min_active;
-        if (WALK == 4) {
+        if (WALK == 5) {
+            traverse_c8<ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch);
+        } else if (WALK == 4) {
             if (L.cur != kDone) traverse_unified4<ANYHIT, COUNT>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
         } else if (WALK == 3) {
             traverse_spec4<ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts);
@@ -796,6 +916,9 @@ int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const doub
         else if (variant == LH_VARIANT_UNIFIED)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 1, false>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
+        else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 3)
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 5, true>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
         else if (variant == LH_VARIANT_UNIFIED4 && sc.use_qnodes == 2)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 4, true>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
@@ -849,7 +972,16 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
      * shared memory of exactly that many rows (2-row granularity). */
     lh_dev_scene_t scl = *sc;
     uint32_t need = sc->max_depth + 1;
-    if ((variant == LH_VARIANT_SPEC || variant == LH_VARIANT_UNIFIED4) && sc->use_qnodes == 2) {
+    if (sc->use_qnodes == 3) {
+        if (variant == LH_VARIANT_SPEC) {
+            /* worst case 7 per level + slack; capped at 48 rows (three workgroups per CU): a ray that would go
+             * deeper is handed to the reference walk */
+            need = 7 * sc->c8_depth + 10;
+            if (need > 48) need = 48;
+        } else if (variant == LH_VARIANT_UNIFIED4) scl.use_qnodes = 2;
+        else scl.use_qnodes = 1;                 /* the 2-wide walks read the 16-bit grid nodes */
+    }
+    if ((variant == LH_VARIANT_SPEC || variant == LH_VARIANT_UNIFIED4) && scl.use_qnodes == 2) {
         need = 3 * sc->q4_depth + 5;
         /* a very deep tree (chains of nested geometry): the 4-wide walk's worst case does not fit the
          * 64-row LDS stack; the 2-wide walk over the same tree (<= LH_MAX_DEPTH + 1 rows) always does */
@@ -858,6 +990,7 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
     need = (need + 1u) & ~1u;
     if (need < 16) need = 16;
     if (need > 64) return -1;
+    scl.stack_rows = need;
     const size_t lds_bytes = (size_t)need * LH_BLOCK * sizeof(int);
     /* rays per cursor atomic: the scene's setting, but never so large that a wave gets fewer than
      * ~4 ranges of a small batch (tail imbalance: late path-tracing bounces, small tiles) */

@@ -60,13 +60,33 @@ static void trace_one(job_t *j, size_t i)
     j->c[3]++;
     if (b->ntris) {
         lh_ray32_t r; float tb = 1.0e38f, scene_r = 0.0f;
-        int32_t stack[3 * LH_MAX_DEPTH + 8]; int sp = 1, cur = 0, np = 0, k;
+        int32_t stack[7 * LH_MAX_DEPTH + 16]; int sp = 1, cur = 0, np = 0, k;
         uint32_t pend[PEND];
         for (k = 0; k < 3; k++) { scene_r = fmaxf(scene_r, fabsf(b->bmin[k])); scene_r = fmaxf(scene_r, fabsf(b->bmax[k])); }
         lh_ray_setup(&r, o[0], o[1], o[2], d[0], d[1], d[2], scene_r);
         if (j->qnodes) lh_ray_setup_grid(&r, b->grid_lo, b->grid_step, scene_r);
         stack[0] = DONE;
         while (cur != DONE) {
+            while (cur >= 0 && j->qnodes == 3) {      /* 8-wide compressed nodes, octant order */
+                const lh_c8node_t *n = &b->c8nodes[cur]; lh_c8frame_t f; int pr, pushed = 0;
+                const int oct = r.ngx | (r.ngy << 1) | (r.ngz << 2);
+                j->c[0]++;
+                lh_c8_frame(&r, n->p[0], n->p[1], n->p[2], n->e[0], n->e[1], n->e[2], &f);
+                for (pr = 7; pr >= 0; pr--) {              /* far to near: the nearest ends on top */
+                    const int s = pr ^ oct; float tn; int hit; int32_t ref;
+                    const int inner = (n->imask >> s) & 1;
+                    if (!inner && n->meta[s] == 0) continue;
+                    hit = lh_slab_c8(&f, r.ngx ? n->qhi[0][s] : n->qlo[0][s], r.ngy ? n->qhi[1][s] : n->qlo[1][s],
+                                     r.ngz ? n->qhi[2][s] : n->qlo[2][s], r.ngx ? n->qlo[0][s] : n->qhi[0][s],
+                                     r.ngy ? n->qlo[1][s] : n->qhi[1][s], r.ngz ? n->qlo[2][s] : n->qhi[2][s], tb, &tn);
+                    if (!hit) continue;
+                    if (inner) ref = (int32_t)(n->child_base + (uint32_t)__builtin_popcount(n->imask & ((1u << s) - 1u)));
+                    else ref = (int32_t)~(((n->tri_base + (n->meta[s] & 31u)) << 2) | ((n->meta[s] >> 5) & 3u));
+                    stack[sp++] = ref; pushed++;
+                }
+                cur = stack[--sp];
+                (void)pushed;
+            }
             while (cur >= 0 && j->qnodes == 2) {      /* 4-wide 16-bit grid nodes */
                 const lh_q4node_t *n = &b->q4nodes[cur]; float tn[4]; int h[4], c, nh = 0, order[4], m;
                 j->c[0]++;
@@ -107,7 +127,7 @@ static void trace_one(job_t *j, size_t i)
             {
                 uint32_t x = ~(uint32_t)cur, first = x >> 2, cnt = (x & 3u) + 1u, q; int finished = 0;
                 for (q = 0; q < cnt; q++) {
-                    const lh_tri32_t *T = &b->tri32[first + q]; float t_hi; int cls;
+                    const lh_tri32_t *T = (j->qnodes == 3) ? &b->tri32_c8[first + q] : &b->tri32[first + q]; float t_hi; int cls;
                     j->c[1]++;
                     cls = lh_tri_filter(&r, T->v0[0], T->v0[1], T->v0[2], T->e1x, T->e1y, T->e1z,
                                         T->e2x, T->e2y, T->e2z, T->ne1, T->ne2, tb, &t_hi);
@@ -177,6 +197,7 @@ lh_bvh_t *lhm_build(uint32_t npos, const double *pos_xyz, uint32_t nidx, const u
 void lhm_free(lh_bvh_t *b) { if (b) { lh_bvh_release(b); free(b); } }
 void lhm_info(const lh_bvh_t *b, uint32_t out[4]) { out[0] = b->ntris; out[1] = b->nnodes; out[2] = b->max_depth; out[3] = b->nleaves; }
 void lhm_info4(const lh_bvh_t *b, uint32_t out[2]) { out[0] = b->nq4nodes; out[1] = b->q4_depth; }
+void lhm_info8(const lh_bvh_t *b, uint32_t out[2]) { out[0] = b->nc8nodes; out[1] = b->c8_depth; }
 const void *lhm_q4nodes(const lh_bvh_t *b) { return b->q4nodes; }
 double lhm_build_seconds(const lh_bvh_t *b) { return b->build_seconds; }
 const void *lhm_nodes(const lh_bvh_t *b) { return b->nodes; }

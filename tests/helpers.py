@@ -112,6 +112,11 @@ class Model:
         L.lhm_info4.argtypes = [C.c_void_p, _u32p]; L.lhm_info4(self.h, o.ctypes.data_as(_u32p))
         return int(o[0]), int(o[1])
 
+    def c8info(self):
+        L = self.lib(); o = np.zeros(2, np.uint32)
+        L.lhm_info8.argtypes = [C.c_void_p, _u32p]; L.lhm_info8(self.h, o.ctypes.data_as(_u32p))
+        return int(o[0]), int(o[1])
+
     def q4nodes(self):
         L = self.lib(); n, _ = self.q4info()
         L.lhm_q4nodes.restype = C.c_void_p; L.lhm_q4nodes.argtypes = [C.c_void_p]

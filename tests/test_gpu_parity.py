@@ -64,6 +64,25 @@ def test_oracle_parity_seeded(ntri, nrays, he, seed, variant):
     assert np.array_equal(gpu_any(acc, org, dr, variant).astype(bool), exp[0] != po.MISS)
 
 
+@pytest.mark.parametrize("fmt", ["f32", "q16", "q16x4", "c8"])
+def test_node_formats(fmt, monkeypatch):
+    """every node format the kernels can walk (LH_NODE_FORMAT is read at commit): fp32 2-wide, 16-bit grid
+    2-wide, 16-bit grid 4-wide (default), 8-wide compressed (experiment) -- same records"""
+    monkeypatch.setenv("LH_NODE_FORMAT", fmt)
+    P, idx, org, dr = po.soup(60000, 120000, 0.01, 8)
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr, nthreads=16)
+    acc = make_accel(P, idx)
+    for variant in VARIANTS:
+        assert_hits_equal(gpu_closest(acc, org, dr, variant), exp, "format %s variant %d" % (fmt, variant))
+        assert np.array_equal(gpu_any(acc, org, dr, variant).astype(bool), exp[0] != po.MISS)
+    P, idx = grid_mesh(8, 8)                      # shared vertices / edges: exact-t ties
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    acc = make_accel(P, idx)
+    org, dr = random_rays(np.random.default_rng(3), 20000)
+    assert_hits_equal(gpu_closest(acc, org, dr, la.VARIANT_DEFAULT), o.intersect(org, dr), "format %s grid" % fmt)
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 255, 256, 257, 1000])
 def test_ragged_batch_sizes(n):
     P, idx, org, dr = po.soup(5000, 1000, 0.03, 31)

@@ -24,7 +24,7 @@ def test_model_answers_what_the_reference_answers_on_box_corner_hits(n):
     lost = int(((bf[0] != po.MISS) & (exp[0] == po.MISS)).sum())
     m = Model(P, idx, nthreads=1); m.ref_build(nthreads=1, use_for_ties=True)
     try:
-        for q in (2, 1, 0):
+        for q in (3, 2, 1, 0):
             got, _ = m.trace(org, dr, qnodes=q, nthreads=1)
             assert_hits_equal(got, exp, "chain %d fmt %d" % (n, q))
             occ, _ = m.trace(org, dr, anyhit=True, qnodes=q, nthreads=1)
