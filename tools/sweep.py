@@ -31,18 +31,18 @@ if what == "grid":
     acc, info = mk()
     for g in (256, 512, 768, 1024, 1280, 1536, 2048, 2560):
         acc.set_grid(g)
-        print("grid", g, "closest %.1f any %.1f Mrays/s" % (timeit(acc, 0, 2), timeit(acc, 1, 2)), flush=True)
+        print("grid", g, "closest %.1f any %.1f Mrays/s" % (timeit(acc, 0, 4), timeit(acc, 1, 4)), flush=True)
 elif what == "minact":
     for m in (8, 16, 24, 32, 40, 48, 56, 62):
         acc, info = mk({"LH_MIN_ACTIVE": m})
-        print("min_active", m, "closest %.1f any %.1f Mrays/s" % (timeit(acc, 0, 2), timeit(acc, 1, 2)), flush=True)
+        print("min_active", m, "closest %.1f any %.1f Mrays/s" % (timeit(acc, 0, 4), timeit(acc, 1, 4)), flush=True)
         acc.close()
 elif what == "bvh":
     for ci, ct in ((1, 1), (1, 0.5), (1, 0.25), (1, 2), (2, 1), (0.5, 1)):
         acc, info = mk({"LH_BVH_CI": ci, "LH_BVH_CT": ct})
         _, cnt = acc.intersect_device(d_org[:2000000].contiguous(), d_dir[:2000000].contiguous(), counters=True, variant=0)
         print("ci", ci, "ct", ct, "nodes", info["nnodes"], "depth", info["max_depth"], "nodes/ray %.2f tris/ray %.2f" % (cnt["nodes"] / 2e6, cnt["tris"] / 2e6),
-              "closest %.1f any %.1f Mrays/s" % (timeit(acc, 0, 2), timeit(acc, 1, 2)), flush=True)
+              "closest %.1f any %.1f Mrays/s" % (timeit(acc, 0, 4), timeit(acc, 1, 4)), flush=True)
         acc.close()
 elif what == "sort":
     acc, info = mk()
