@@ -298,8 +298,20 @@ def test_scaled_translated_degenerate_scenes(kind, log_scale, off):
     n = 20000
     tgt = rng.uniform(-0.1, 1.1, (n, 3)) * scale + offset
     org = tgt + rng.normal(size=(n, 3)) * scale * 3.0
+    # rays aimed exactly at vertices / edge midpoints / centroids of proper triangles, origins on triangles
+    T = P[idx].reshape(-1, 3, 3)
+    area = np.linalg.norm(np.cross(T[:, 1] - T[:, 0], T[:, 2] - T[:, 0]), axis=1)
+    proper = np.nonzero(area > 1e-9 * scale * scale)[0]
+    pick = proper[rng.integers(0, len(proper), n)]
+    tgt[::5] = T[pick[::5], rng.integers(0, 3, len(pick[::5]))]
+    tgt[1::7] = 0.5 * (T[pick[1::7], 0] + T[pick[1::7], 1])
+    tgt[2::9] = T[pick[2::9]].mean(axis=1)
+    org[3::23] = T[pick[3::23], 2]
+    org[4::29] = T[pick[4::29]].mean(axis=1)
     dr = tgt - org
     dr[::11, 0] = 0.0; dr[1::13, 1] = 1e-3 * scale; dr[2::17] *= 1e-3; dr[3::19, 2] = 1e-20
+    keep = np.linalg.norm(dr, axis=1) > 0
+    org, dr = org[keep], dr[keep]
     ok = np.abs(dr[:, 1]) > 1e-14
     org, dr = np.ascontiguousarray(org[ok]), np.ascontiguousarray(dr[ok])
     o = po.Oracle(); o.add_mesh(P, idx); o.build()
