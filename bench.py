@@ -72,14 +72,14 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ao", action="store_true", help="skip the secondary AO-frame leg")
     ap.add_argument("--no-pt", action="store_true", help="skip the secondary path-traced leg")
-    ap.add_argument("--pt-size", type=int, default=1024)
-    ap.add_argument("--pt-spp", type=int, default=64)
+    ap.add_argument("--pt-size", type=int, default=2048)      # BASELINE config 4: 2048 x 2048, 256 spp
+    ap.add_argument("--pt-spp", type=int, default=256)
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--device-override", type=int, default=None,
                     help="testing only: put every rank on this device (2 ranks on a 1-GPU box, use with --backend gloo)")
-    ap.add_argument("--ao-size", type=int, default=2048)
+    ap.add_argument("--ao-size", type=int, default=4096)
     ap.add_argument("--ao-samples", type=int, default=64)
-    ap.add_argument("--ao-tess", type=int, default=6, help="midpoint-subdivision levels of the example scene (4^n x 322 triangles)")
+    ap.add_argument("--ao-tess", type=int, default=7, help="midpoint-subdivision levels of the example scene (4^n x 322 triangles; 7 -> 5.3 M, 8 -> 21 M)")
     args = ap.parse_args()
 
     import torch
@@ -251,7 +251,8 @@ def main():
 
 
 def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
-    """Secondary leg (BASELINE configs 2/5): the reference's AO example scene (the 322 triangles
+    """Secondary leg (BASELINE config 5's shape by default: 4096 x 4096, 64 AO samples, the example scene
+    tessellated to 5.3 M triangles; --ao-size 1024 --ao-tess 0 is config 2): the reference's AO example scene (the 322 triangles
     its own RIB ingest produced, tests/golden/ao_c1.npz), midpoint-tessellated `tess` times,
     size x size pixels, `nsamples` AO rays per primary hit, whole pipeline on the device
     (camera rays, hits, epilogue, AO rays, occlusion, radiance), tiles sharded
@@ -267,7 +268,7 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
     acc.commit()
     c = g["camera"]
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
-    tile = max(64, size // 8)
+    tile = max(64, size // 8) if world > 1 else min(size, 1024)
     times = []; st = None; img = None
     for it in range(steps + 1):
         if world > 1:
@@ -276,7 +277,7 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
         if world > 1:
             img, st = render.render_ao_frame_sharded(acc, cam, 1, nsamples, rank, world, tile=tile)
         else:
-            img, st = render.render_ao_frame(acc, cam, 1, nsamples, tile=size)
+            img, st = render.render_ao_frame(acc, cam, 1, nsamples, tile=tile)
         torch.cuda.synchronize(dev)
         if world > 1:
             torch.distributed.barrier()
