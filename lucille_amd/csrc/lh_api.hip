@@ -828,7 +828,7 @@ extern "C" int lh_render_ao_frame_host(lh_accel_t *a, const lh_camera_t *cam, in
     if (!a || !a->committed) return fail("lh_render_ao_frame_host: accel not committed");
     if (!cam || !rgb) return fail("lh_render_ao_frame_host: NULL argument");
     if (cam->width <= 0 || cam->height <= 0) return fail("lh_render_ao_frame_host: bad resolution");
-    if (tile <= 0) tile = 256;
+    if (tile <= 0) tile = 1024;
     HIPCHK(hipSetDevice(a->device));
     const int W = cam->width, H = cam->height;
     if (ensure_buf(&a->r_frame, (size_t)tile * tile * 3 * sizeof(float))) return -1;
