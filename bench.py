@@ -320,7 +320,10 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev); t0 = time.perf_counter()
-        img, st = render.render_pt_frame_sharded(acc, cam, spp, rank, world, tile=(size if world == 1 else max(128, size // 4)), spp_chunk=16,
+        pt_tile = size if world == 1 else max(128, size // 4)
+        # paths per pass ~ 64 M (about 10 GB of path state): fewer, larger wavefronts -> fewer host syncs per tile
+        chunk = max(1, min(spp, (64 << 20) // (pt_tile * pt_tile)))
+        img, st = render.render_pt_frame_sharded(acc, cam, spp, rank, world, tile=pt_tile, spp_chunk=chunk,
                                                  kd=0.8, env=(1.0, 1.0, 1.0), max_vertices=8, seed=7)
         torch.cuda.synchronize(dev)
         if world > 1:
