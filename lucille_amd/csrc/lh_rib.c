@@ -33,6 +33,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 /* ------------------------------------------------------------------ errors -- */
@@ -454,8 +455,11 @@ static int do_points_polygons(lh_rib_scene_t *s, const arglist_t *L)
             free(idx); rib_log(s, "warning: PointsPolygons: %s, primitive ignored", "vertex index list shorter than the face list"); return 0;
         }
         for (k = 0; k < (size_t)(n > 0 ? n : 0); k++) {
-            const uint32_t v = (uint32_t)(int)vs->num[j + k];
-            if (nvertices < v) nvertices = v;
+            const float fv = vs->num[j + k];
+            if (!(fv >= 0.0f) || fv > 1.0e9f) {          /* negative / absurd / NaN vertex index */
+                free(idx); rib_log(s, "warning: PointsPolygons: %s, primitive ignored", "vertex index out of range"); return 0;
+            }
+            if (nvertices < (uint32_t)fv) nvertices = (uint32_t)fv;
         }
         if (n == 3) { for (k = 0; k < 3; k++) idx[nidx + k] = (uint32_t)(int)vs->num[j + order[k]]; nidx += 3; }
         else {
@@ -583,7 +587,11 @@ static void do_option(lh_rib_scene_t *s, const arglist_t *L)
 
 static int parse_file(lh_rib_scene_t *s, const char *path, int depth);
 
-static int file_exists(const char *p) { return access(p, R_OK) == 0; }
+static int file_exists(const char *p)
+{
+    struct stat st;
+    return access(p, R_OK) == 0 && stat(p, &st) == 0 && S_ISREG(st.st_mode);
+}
 
 static void dir_of(const char *path, char *out, size_t n)
 {
@@ -725,7 +733,9 @@ static int parse_file(lh_rib_scene_t *s, const char *path, int depth)
 {
     FILE *fp = fopen(path, "rb"); long size; char *buf; lexer_t lx; arglist_t L; int rc = 0; char *verb = NULL;
     if (!fp) RIB_FAIL("cannot open \"%s\"", path);
-    fseek(fp, 0, SEEK_END); size = ftell(fp); fseek(fp, 0, SEEK_SET);
+    if (fseek(fp, 0, SEEK_END) != 0 || (size = ftell(fp)) < 0 || size > (1L << 40) || fseek(fp, 0, SEEK_SET) != 0) {
+        fclose(fp); RIB_FAIL("\"%s\" is not a readable regular file", path);       /* e.g. a directory */
+    }
     buf = (char *)malloc((size_t)size + 1);
     if (!buf) { fclose(fp); RIB_FAIL("out of memory"); }
     if (size > 0 && fread(buf, 1, (size_t)size, fp) != (size_t)size) { fclose(fp); free(buf); RIB_FAIL("short read on \"%s\"", path); }
