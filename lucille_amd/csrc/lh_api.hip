@@ -238,6 +238,7 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
     }
     int rc = lh_bvh_build(&a->bvh, views, a->nmeshes, build_threads);
     free(views);
+    if (rc == -2) return fail("lh_accel_commit: a vertex coordinate is NaN, infinite or beyond 1e30");
     if (rc != 0) return fail("lh_accel_commit: BVH build failed (bad input or out of memory)");
     /* the reference-order tree: exact-t tie winners + beam visibility (LH_REFTREE=0 skips it:
      * ties then fall back to "larger primitive id wins" and beam queries are refused) */

@@ -557,7 +557,11 @@ int lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, 
                     const double *P;
                     if (vi >= m->npositions) { free(b.plo); free(b.phi); free(b.cen); free(b.order); lh_bvh_release(out); return -1; }
                     P = (const double *)((const char *)m->positions + (size_t)vi * m->stride_bytes);
-                    for (k = 0; k < 3; k++) t->v[c][k] = P[k];
+                    for (k = 0; k < 3; k++) {
+                        /* NaN, inf or beyond what the fp32 filter can bound: refuse the scene (return -2) */
+                        if (!(fabs(P[k]) <= 1.0e30)) { free(b.plo); free(b.phi); free(b.cen); free(b.order); lh_bvh_release(out); return -2; }
+                        t->v[c][k] = P[k];
+                    }
                 }
                 out->prim_geom[p] = g; out->prim_index[p] = 3 * i;
                 for (k = 0; k < 3; k++) {

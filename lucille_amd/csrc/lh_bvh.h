@@ -122,7 +122,7 @@ typedef struct lh_mesh_view {
     const uint32_t *indices;
 } lh_mesh_view_t;
 
-/* returns 0 on success, -1 on bad input / out of memory */
+/* returns 0 on success, -1 on bad input / out of memory, -2 on a NaN / infinite / > 1e30 vertex coordinate */
 int  lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes,
                   int nthreads);
 void lh_bvh_release(lh_bvh_t *bvh);

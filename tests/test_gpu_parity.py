@@ -157,6 +157,30 @@ def test_concurrent_host_threads_like_the_reference_render_threads():
     assert not errors, errors[:3]
 
 
+def test_bad_input_is_refused_or_harmless():
+    """a NaN / infinite vertex is refused at commit with a message (the fp32 filter cannot bound it);
+    NaN / infinite / zero rays inside a batch come back as misses and do not disturb their neighbours"""
+    P, idx, org, dr = po.soup(5000, 4000, 0.03, 12)
+    for bad in (np.nan, np.inf, -1e300):
+        Q = P.copy(); Q[101, 2] = bad
+        acc = la.HipAccel(0); acc.add_mesh(Q, idx)
+        with pytest.raises(la.LucilleHipError, match="NaN, infinite"):
+            acc.commit()
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr)
+    org2, dr2 = org.copy(), dr.copy()
+    weird = np.arange(0, len(org), 37)
+    dr2[weird[0::4]] = np.nan; org2[weird[1::4]] = np.inf; dr2[weird[2::4]] = 0.0; dr2[weird[3::4], 0] = -np.inf
+    acc = make_accel(P, idx)
+    for variant in (la.VARIANT_DEFAULT, la.VARIANT_DIRECT):
+        got = gpu_closest(acc, org2, dr2, variant)
+        keep = np.ones(len(org), bool); keep[weird] = False
+        assert_hits_equal(tuple(g[keep] for g in got), tuple(e[keep] for e in exp), "neighbours of bad rays")
+        assert (got[0][weird[0::4]] == la.MISS).all() and (got[0][weird[1::4]] == la.MISS).all()
+        occ = gpu_any(acc, org2, dr2, variant)
+        assert np.array_equal(occ[keep].astype(bool), exp[0][keep] != po.MISS)
+
+
 def test_multi_mesh_prim_lookup():
     P1, i1, org, dr = po.soup(300, 5000, 0.1, 11)
     P2, i2, _, _ = po.soup(500, 1, 0.1, 22)
