@@ -62,7 +62,10 @@ int  lh_accel_add_mesh(lh_accel_t *accel, uint32_t npositions, const double *pos
                        size_t stride_bytes, uint32_t nindices, const uint32_t *indices);
 /* builds the BVH on the host (build_threads <= 0: all cores) and uploads the
  * SoA scene to the device.  An empty scene commits to an always-miss accel
- * (bvh.c:311-315,446-449). */
+ * (bvh.c:311-315,446-449).  Fails (-1, lh_last_error) on an out-of-range vertex index, on a NaN /
+ * infinite / > 1e30 vertex coordinate (the fp32 filter cannot bound it) and on >= 2^29 triangles.
+ * Every entry point taking an accelerator holds its lock: calls from several threads are safe and
+ * serialised (lucille's render threads call accel->intersect concurrently, render.c:1043-1105). */
 int  lh_accel_commit(lh_accel_t *accel, int build_threads);
 void lh_accel_destroy(lh_accel_t *accel);
 int  lh_accel_info(const lh_accel_t *accel, lh_accel_info_t *out);
