@@ -5,8 +5,13 @@ The product is the C-ABI shared library ``lucille_amd/csrc/liblucille_hip.so``
 plumbing used by the tests, ``bench.py`` and the multi-GPU driver:
 
   lucille_amd.binding   ctypes view of the C ABI (+ torch device-pointer helpers)
-  lucille_amd.accel     ri_accel_* / ri_raytrace host mirror (via lh_host.c)
+  lucille_amd.render    frame loops over the tile entry points (AO, path-traced), sharded or not
   lucille_amd.shard     image-space / ray-slice sharding over torch.distributed
+  lucille_amd.rib       RIB-subset reader / .hdr writer entry points, lsh_hip path
+  lucille_amd.scenes    test / bench scene helpers (tessellation, fixtures)
+
+The host mirror of lucille's own plugin API (ri_geom_*, ri_accel_*, ri_raytrace ...,
+include/lucille_accel.h, lh_host.c) is C and is exercised by the C program in tests/c/.
 
 There is no CPU fallback: loading fails loudly when the library is missing and
 every query fails loudly when no HIP device is visible.
