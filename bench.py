@@ -256,7 +256,7 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
     its own RIB ingest produced, tests/golden/ao_c1.npz), midpoint-tessellated `tess` times,
     size x size pixels, `nsamples` AO rays per primary hit, whole pipeline on the device
     (camera rays, hits, epilogue, AO rays, occlusion, radiance), tiles sharded
-    tile_id % world with one all-gather of tile slabs (strong scaling: the frame is fixed)."""
+    tile_id % world with one gather of tile slabs to rank 0 (strong scaling: the frame is fixed)."""
     import torch
     from lucille_amd import render, scenes
     g = np.load(os.path.join(ROOT, "tests", "golden", "ao_c1.npz"))
@@ -303,7 +303,7 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
 def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
     """Secondary leg (BASELINE config 4): examples/plane_sphere (the 1 986 triangles + vertex normals
     the reference's RIB ingest produced, tests/golden/ao_ps.npz), size x size, spp paths per pixel,
-    diffuse wavefront path tracer, tiles sharded tile_id % world + all-gather of tile slabs."""
+    diffuse wavefront path tracer, tiles sharded tile_id % world + gather of tile slabs to rank 0."""
     import torch
     from lucille_amd import render
     g = np.load(os.path.join(ROOT, "tests", "golden", "ao_ps.npz"))

@@ -4,7 +4,7 @@ sharded in image space over the GPUs of a node.
 
   render_ao_frame(acc, cam, ...)   one process: all tiles of the frame (or this rank's)
   render_ao_frame_sharded(...)     torch.distributed: tiles `tile_id % world == rank`,
-                                   replicated BVH, one all-gather of tile slabs to rank 0
+                                   replicated BVH, one gather of tile slabs to rank 0
 
 All pixel arithmetic happens in liblucille_hip.so (lh_render_ao_tile); this module only
 decides which tile goes where.
@@ -32,7 +32,7 @@ def render_ao_frame(acc, cam, pixel_samples, gather_nsamples, tile=256, seed=1, 
 
 
 def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, world, tile=256, seed=1):
-    """Each rank renders its interleaved tiles; one all-gather of equal-sized tile slabs
+    """Each rank renders its interleaved tiles; one gather of equal-sized tile slabs
     assembles the frame on rank 0 (None elsewhere).  Returns (image|None, local stats)."""
     import torch
     W, H = cam.width, cam.height
@@ -62,13 +62,16 @@ def assemble(slab, W, H, tile, rank, world):
     pad = torch.zeros((per_rank, tile * tile * 3), dtype=slab.dtype, device=slab.device)
     pad[:slab.shape[0]] = slab
     if world > 1:
+        # the display owner is rank 0 (the reference's compiled-out MPI design: "everyone renders, rank 0
+        # owns the display", render.c:468-514): a GATHER -- seven point-to-point xGMI transfers landing on
+        # rank 0 in parallel -- not an all-gather whose ring would carry every slab past every GPU
         if dist.get_backend() != "nccl" and pad.is_cuda:      # gloo (tests): stage through the host
-            hp = pad.cpu(); ho = [torch.empty_like(hp) for _ in range(world)]
-            dist.all_gather(ho, hp)
-            out = [t.to(pad.device) for t in ho]
+            hp = pad.cpu(); ho = [torch.empty_like(hp) for _ in range(world)] if rank == 0 else None
+            dist.gather(hp, ho, dst=0)
+            out = [t.to(pad.device) for t in ho] if rank == 0 else None
         else:
-            out = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(out, pad)
+            out = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+            dist.gather(pad, out, dst=0)
     else:
         out = [pad]
     if rank != 0:
@@ -84,7 +87,7 @@ def assemble(slab, W, H, tile, rank, world):
 
 def render_pt_frame_sharded(acc, cam, spp, rank, world, tile=256, spp_chunk=16, **kw):
     """Path-traced frame (BASELINE config 4): tiles `tile_id % world == rank`, samples in passes
-    of `spp_chunk` per tile (bounded device memory), one all-gather of tile slabs.
+    of `spp_chunk` per tile (bounded device memory), one gather of tile slabs.
     Returns (image on rank 0 | None, local stats)."""
     import torch
     W, H = cam.width, cam.height
