@@ -109,6 +109,16 @@ def test_reference_parser_tests_parse_clean(name, tmp_path):
         assert "Unknown RIB command: TheWorld" in r.stdout
 
 
+def test_lsh_hip_fails_loudly_without_a_gpu(tmp_path):
+    """no CPU fallback in the driver either: parsing works, rendering needs the device"""
+    import lucille_amd as la
+    if la.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    r = _lsh([os.path.join(RIB, "tut1.rib")], str(tmp_path))
+    assert r.returncode != 0 and "no HIP device" in r.stderr
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".hdr")]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(f for f in os.listdir(RIB) if f[-12:-4].isdigit()))
 def test_reference_parser_tests_render_clean(name, tmp_path):
