@@ -182,13 +182,21 @@ def main():
         e1.record(); torch.cuda.synchronize(dev)
         copy_gbps = 10 * 2 * big.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9       # read + write
         del big, dst
-        nh = min(n, 10_000_000)
-        h_org = d_org[:nh].cpu().numpy(); h_dir = d_dir[:nh].cpu().numpy()
-        acc.intersect_host(h_org[:1000], h_dir[:1000])
-        th = time.perf_counter(); acc.intersect_host(h_org, h_dir); th = time.perf_counter() - th
-        host_path = {"value": round(nh / th / 1e6, 1), "unit": "Mrays/s",
-                     "sample": "%d rays through lh_accel_intersect_host: pageable host arrays, 48 B/ray up + 28 B/ray down over PCIe, "
-                               "one launch; never the headline value" % nh}
+        nh = min(n, 20_000_000)
+        h_org = np.ascontiguousarray(d_org[:nh].cpu().numpy()); h_dir = np.ascontiguousarray(d_dir[:nh].cpu().numpy())
+        # caller-owned, already-touched result arrays (a fresh allocation would time page faults, not the path)
+        hp = np.zeros(nh, np.uint32); ht = np.zeros(nh); hu = np.zeros(nh); hv = np.zeros(nh)
+        best = None
+        for _ in range(2):
+            th = time.perf_counter()
+            rc = acc.L.lh_accel_intersect_host(acc.h, nh, h_org.ctypes.data, h_dir.ctypes.data, hp.ctypes.data, ht.ctypes.data,
+                                               hu.ctypes.data, hv.ctypes.data, None, 0)
+            th = time.perf_counter() - th
+            assert rc == 0
+            best = th if best is None else min(best, th)
+        host_path = {"value": round(nh / best / 1e6, 1), "unit": "Mrays/s", "link_GBps": round(nh * 76 / best / 1e9, 1),
+                     "sample": "%d rays through lh_accel_intersect_host: pageable host arrays -> pinned staging in 2 M-ray chunks on two "
+                               "streams, 48 B/ray up + 28 B/ray down over PCIe; never the headline value" % nh}
 
     ao = None
     if not args.no_ao:

@@ -5,6 +5,7 @@
  * host-batch entry point).
  */
 #include <hip/hip_runtime.h>
+#include <thread>
 #include <vector>
 
 #include <math.h>
@@ -80,6 +81,8 @@ struct lh_accel {
     int default_variant;
     /* staging for host batches */
     void *d_stage; size_t stage_bytes;
+    /* pipelined host batches: two pinned in/out staging pairs, two device pairs, two streams */
+    struct { void *h_in[2], *h_out[2], *d_in[2], *d_out[2]; hipStream_t s[2]; hipEvent_t done[2]; size_t cap; int ready; } pipe;
     /* per-primitive vertex normals (9 doubles, NaN = none), only if some mesh has normals */
     double *h_nrm9; void *d_nrm9;
     /* tile-render scratch (lh_render_ao_tile) */
@@ -215,6 +218,14 @@ static void release_device(lh_accel_t *a)
     a->d_ref_lca = a->d_prim_leafpos = a->d_ref_nodes = a->d_ref_leaf_prims = NULL;
     if (a->d_cursor) (void)hipFree(a->d_cursor);
     if (a->d_counters) (void)hipFree(a->d_counters);
+    if (a->pipe.ready) {
+        for (int b = 0; b < 2; b++) {
+            (void)hipHostFree(a->pipe.h_in[b]); (void)hipHostFree(a->pipe.h_out[b]);
+            (void)hipFree(a->pipe.d_in[b]); (void)hipFree(a->pipe.d_out[b]);
+            (void)hipStreamDestroy(a->pipe.s[b]); (void)hipEventDestroy(a->pipe.done[b]);
+        }
+        a->pipe.ready = 0;
+    }
     if (a->d_stage) (void)hipFree(a->d_stage);
     if (a->stream) (void)hipStreamDestroy(a->stream);
     a->d_nodes = a->d_tri32 = a->d_tri64 = NULL; a->d_cursor = a->d_counters = NULL;
@@ -510,6 +521,87 @@ static int ensure_stage(lh_accel_t *a, size_t bytes)
     return 0;
 }
 
+/* ---- large host batches: chunks pipelined through pinned staging -----------------------------------
+ * A pageable hipMemcpy moves ~12 GB/s; the link does ~50.  Rays are cut into chunks of LH_PIPE_CHUNK;
+ * chunk k is copied into pinned memory by a few host threads, sent, traced and brought back on stream
+ * k & 1 while the host stages chunk k+1 and un-stages chunk k-1. */
+#define LH_PIPE_CHUNK ((size_t)1 << 21)
+#define LH_PIPE_MIN   ((size_t)1 << 20)
+
+static void par_copy(void *dst, const void *src, size_t bytes)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nt = bytes < ((size_t)8 << 20) ? 1 : (hw >= 16 ? 8 : (hw >= 4 ? 4 : 1));
+    if (nt == 1) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
+    for (size_t k = 0; k < nt; k++) {
+        const size_t b = k * per; if (b >= bytes) break;
+        const size_t e = (b + per < bytes) ? b + per : bytes;
+        th.emplace_back([=] { memcpy((char *)dst + b, (const char *)src + b, e - b); });
+    }
+    for (auto &t : th) t.join();
+}
+
+static int pipe_init(lh_accel_t *a)
+{
+    if (a->pipe.ready) return 0;
+    const size_t C = LH_PIPE_CHUNK;
+    const size_t in_b = sizeof(double) * 6 * C, out_b = (sizeof(double) * 3 + sizeof(uint32_t)) * C;
+    for (int b = 0; b < 2; b++) {
+        HIPCHK(hipHostMalloc(&a->pipe.h_in[b], in_b, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&a->pipe.h_out[b], out_b, hipHostMallocDefault));
+        HIPCHK(hipMalloc(&a->pipe.d_in[b], in_b));
+        HIPCHK(hipMalloc(&a->pipe.d_out[b], out_b));
+        HIPCHK(hipStreamCreateWithFlags(&a->pipe.s[b], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&a->pipe.done[b], hipEventDisableTiming));
+    }
+    a->pipe.cap = C; a->pipe.ready = 1;
+    return 0;
+}
+
+static int intersect_host_pipelined(lh_accel_t *a, size_t n, const double *org, const double *dir,
+                                    uint32_t *prim, double *t, double *u, double *v, uint8_t *occ, int mode)
+{
+    if (pipe_init(a) != 0) return -1;
+    const size_t C = a->pipe.cap, nchunks = (n + C - 1) / C;
+    auto unstage = [&](size_t k) {
+        const int b = (int)(k & 1); const size_t first = k * C, m = (first + C <= n) ? C : n - first;
+        const char *ho = (const char *)a->pipe.h_out[b];
+        if (mode == LH_MODE_CLOSEST) {
+            if (t) par_copy(t + first, ho, sizeof(double) * m);
+            if (u) par_copy(u + first, ho + sizeof(double) * C, sizeof(double) * m);
+            if (v) par_copy(v + first, ho + 2 * sizeof(double) * C, sizeof(double) * m);
+            if (prim) par_copy(prim + first, ho + 3 * sizeof(double) * C, sizeof(uint32_t) * m);
+        } else if (occ) par_copy(occ + first, ho, m);
+    };
+    for (size_t k = 0; k < nchunks; k++) {
+        const int b = (int)(k & 1); const size_t first = k * C, m = (first + C <= n) ? C : n - first;
+        if (k >= 2) { HIPCHK(hipEventSynchronize(a->pipe.done[b])); unstage(k - 2); }
+        char *hi = (char *)a->pipe.h_in[b], *di = (char *)a->pipe.d_in[b], *dout = (char *)a->pipe.d_out[b];
+        par_copy(hi, org + 3 * first, sizeof(double) * 3 * m);
+        par_copy(hi + sizeof(double) * 3 * C, dir + 3 * first, sizeof(double) * 3 * m);
+        hipStream_t s = a->pipe.s[b];
+        HIPCHK(hipMemcpyAsync(di, hi, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(di + sizeof(double) * 3 * C, hi + sizeof(double) * 3 * C, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
+        double *d_t = (double *)dout, *d_u = d_t + C, *d_v = d_u + C; uint32_t *d_prim = (uint32_t *)(d_v + C);
+        const int rc = launch(a, m, di, di + sizeof(double) * 3 * C, d_prim, d_t, d_u, d_v, (uint8_t *)dout, mode, LH_VARIANT_DEFAULT, NULL, s);
+        if (rc != 0) return rc;
+        char *ho = (char *)a->pipe.h_out[b];
+        if (mode == LH_MODE_CLOSEST) {
+            if (t) HIPCHK(hipMemcpyAsync(ho, d_t, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+            if (u) HIPCHK(hipMemcpyAsync(ho + sizeof(double) * C, d_u, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+            if (v) HIPCHK(hipMemcpyAsync(ho + 2 * sizeof(double) * C, d_v, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+            if (prim) HIPCHK(hipMemcpyAsync(ho + 3 * sizeof(double) * C, d_prim, sizeof(uint32_t) * m, hipMemcpyDeviceToHost, s));
+        } else if (occ) HIPCHK(hipMemcpyAsync(ho, dout, m, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(a->pipe.done[b], s));
+    }
+    for (size_t k = (nchunks >= 2 ? nchunks - 2 : 0); k < nchunks; k++) {
+        HIPCHK(hipEventSynchronize(a->pipe.done[k & 1])); unstage(k);
+    }
+    return 0;
+}
+
 extern "C" int lh_accel_intersect_host(lh_accel_t *a, size_t n, const double *org, const double *dir,
                                        uint32_t *prim, double *t, double *u, double *v, uint8_t *occ, int mode)
 {
@@ -517,7 +609,10 @@ extern "C" int lh_accel_intersect_host(lh_accel_t *a, size_t n, const double *or
     if (!a || !a->committed) return fail("intersect: accel not committed");
     if (n == 0) return 0;
     if (!org || !dir) return fail("intersect: NULL ray arrays");
+    if (mode != LH_MODE_CLOSEST && mode != LH_MODE_ANY) return fail("intersect: unknown mode %d", mode);
     HIPCHK(hipSetDevice(a->device));
+    if (n >= LH_PIPE_MIN && !a->stat_on && !getenv("LH_HOST_SIMPLE"))
+        return intersect_host_pipelined(a, n, org, dir, prim, t, u, v, occ, mode);
     /* layout of the staging block: org | dir | t | u | v | prim | occ */
     const size_t b_ray = sizeof(double) * 3 * n, b_d = sizeof(double) * n;
     const size_t total = 2 * b_ray + 3 * b_d + sizeof(uint32_t) * n + n + 64;

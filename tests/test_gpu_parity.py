@@ -123,6 +123,27 @@ def test_host_batch_and_single_ray_entry_points():
         assert hit == int(exp[0][i] != po.MISS) and prim == exp[0][i] and t == exp[1][i] and u == exp[2][i] and v == exp[3][i]
 
 
+def test_large_host_batches_are_pipelined_in_chunks():
+    """>= 1 M rays from host arrays go through pinned staging in 2 M-ray chunks on two streams: same records
+    as the device path, ragged last chunk, both modes, optional outputs left out"""
+    import torch
+    P, idx, org, dr = po.soup(200000, 5 * (1 << 20) + 12345, 0.005, 4)
+    acc = make_accel(P, idx)
+    o_, d_ = torch_rays(org, dr)
+    dev = acc.intersect_device(o_, d_); occ_dev = acc.intersect_device(o_, d_, mode=la.MODE_ANY)[0]
+    torch.cuda.synchronize()
+    got = acc.intersect_host(org, dr)
+    assert np.array_equal(got[0], dev[0].cpu().numpy().view(np.uint32))
+    for k in (1, 2, 3):
+        assert np.array_equal(got[k], dev[k].cpu().numpy())
+    assert np.array_equal(acc.intersect_host(org, dr, mode=la.MODE_ANY), occ_dev.cpu().numpy())
+    n = len(org); prim = np.empty(n, np.uint32)                      # only prim requested
+    rc = acc.L.lh_accel_intersect_host(acc.h, n, org.ctypes.data, dr.ctypes.data, prim.ctypes.data, None, None, None, None, 0)
+    assert rc == 0 and np.array_equal(prim, got[0])
+    ex = po.Oracle(); ex.add_mesh(P, idx); ex.build()
+    assert_hits_equal(tuple(g[:100000] for g in got), ex.intersect(org[:100000], dr[:100000], nthreads=16), "pipelined host path prefix")
+
+
 def test_concurrent_host_threads_like_the_reference_render_threads():
     """lucille calls accel->intersect from up to 16 pthreads at once (render.c:1043-1105): batches of
     different sizes and single rays from 12 threads through ONE accelerator, every record exact"""
