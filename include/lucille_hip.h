@@ -38,10 +38,15 @@ typedef struct lh_accel_info {
     uint32_t nnodes;
     uint32_t nleaves;
     uint32_t max_depth;
-    uint64_t device_bytes;           /* HBM footprint of the scene            */
-    double   build_seconds;          /* host BVH build                        */
+    uint64_t device_bytes;           /* HBM footprint of the scene: the node format the default
+                                        kernel walks + triangles + the reference-order tree;
+                                        other node formats are uploaded when a variant first asks */
+    double   build_seconds;          /* host build of the traversal tree      */
     double   upload_seconds;
     int      device;
+    double   ref_build_seconds;      /* host build of the reference-order tree (lucille's own tree,
+                                        kept for ties / fragile hits / beams): part of every commit */
+    uint32_t nnodes_traversal;       /* 4-wide nodes the default kernel walks  */
 } lh_accel_info_t;
 
 /* ---- runtime ----------------------------------------------------------- */
@@ -250,6 +255,17 @@ int  lh_accel_add_rib_scene(lh_accel_t *accel, const lh_rib_scene_t *scene);
 /* Radiance RGBE, run-length coded, byte-compatible with the reference's "file" display driver
  * (src/display/hdrdrv.c:38-121, src/imageio/rgbe.c:78-96,118-140,241-345); rgb as above */
 int  lh_hdr_write(const char *path, int width, int height, const float *rgb);
+
+/* ---- synthetic workloads (BASELINE configs 3 and 5): input generation only ----
+ * One xorshift64 stream (*state; shifts 13/7/17; seed 88172645463325252): triangles first, the ray
+ * dump continues it.  positions_xyz: 9 doubles per triangle (packed xyz), indices: identity.
+ * lh_synth_tessellate: midpoint subdivision, triangle i -> 4i..4i+3, tri_out holds
+ * ntriangles * 4^levels * 9 doubles. */
+#define LH_SYNTH_SEED 88172645463325252ULL
+void lh_synth_soup_triangles(uint64_t *state, uint32_t ntriangles, double half_extent,
+                             double *positions_xyz, uint32_t *indices);
+void lh_synth_soup_rays(uint64_t *state, size_t n, double *org_xyz, double *dir_xyz);
+void lh_synth_tessellate(const double *tri_in, size_t ntriangles, int levels, double *tri_out);
 
 /* copy of the flattened BVH for cross-checks (tests): sizes via lh_accel_info.
  * nodes: nnodes*64 bytes, tri32: ntriangles*48 bytes; either may be NULL. */

@@ -42,7 +42,8 @@ def build_library(force=False):
 class AccelInfo(C.Structure):
     _fields_ = [("ntriangles", C.c_uint32), ("nnodes", C.c_uint32), ("nleaves", C.c_uint32),
                 ("max_depth", C.c_uint32), ("device_bytes", C.c_uint64), ("build_seconds", C.c_double),
-                ("upload_seconds", C.c_double), ("device", C.c_int)]
+                ("upload_seconds", C.c_double), ("device", C.c_int), ("ref_build_seconds", C.c_double),
+                ("nnodes_traversal", C.c_uint32)]
 
 
 class Camera(C.Structure):
@@ -78,6 +79,7 @@ ABI_SYMBOLS = [
     "lh_accel_trace_statistics", "lh_accel_statistics",
     "lh_render_ao_frame_host", "lh_rib_load", "lh_rib_free", "lh_rib_last_error", "lh_rib_info", "lh_rib_messages",
     "lh_rib_mesh", "lh_accel_add_rib_scene", "lh_hdr_write",
+    "lh_synth_soup_triangles", "lh_synth_soup_rays", "lh_synth_tessellate",
 ]
 
 _lib = None
@@ -126,6 +128,12 @@ def lib():
                                     C.POINTER(C.c_float * 3), C.c_uint64, vp, C.POINTER(PtStats), vp]
     L.lh_accel_beam_visibility_host.argtypes = [vp, sz, vp, vp, vp]
     L.lh_accel_beam_visibility_device.argtypes = [vp, sz, vp, vp, vp, vp]
+    L.lh_synth_soup_triangles.argtypes = [C.POINTER(C.c_uint64), u32, C.c_double, vp, vp]
+    L.lh_synth_soup_triangles.restype = None
+    L.lh_synth_soup_rays.argtypes = [C.POINTER(C.c_uint64), sz, vp, vp]
+    L.lh_synth_soup_rays.restype = None
+    L.lh_synth_tessellate.argtypes = [vp, sz, i32, vp]
+    L.lh_synth_tessellate.restype = None
     _lib = L
     return L
 
@@ -168,6 +176,7 @@ class HipAccel:
         _check(self.L.lh_accel_create(C.byref(self.h), int(device)), "lh_accel_create")
         self.device = int(device)
         self.committed = False
+        self._npos = []            # vertex count per added mesh (set_normals validates against it)
         _live.add(self)
 
     def close(self):
@@ -190,9 +199,16 @@ class HipAccel:
         I = _np(indices, np.uint32).reshape(-1)
         _check(self.L.lh_accel_add_mesh(self.h, P.shape[0], P.ctypes.data, P.shape[1] * 8, I.shape[0],
                                         I.ctypes.data), "lh_accel_add_mesh")
+        self._npos.append(P.shape[0])
 
     def set_normals(self, mesh, normals, two_side=0):
         N = _np(normals, np.float64) if normals is not None else None
+        if int(mesh) < 0 or int(mesh) >= len(self._npos):
+            raise ValueError("set_normals: mesh %d was not added" % int(mesh))
+        if N is not None and (N.ndim != 2 or N.shape[1] not in (3, 4) or N.shape[0] != self._npos[int(mesh)]):
+            # the C ABI reads one normal per vertex of the mesh: a short array would be read past its end
+            raise ValueError("normals must be [%d,3] or [%d,4] (one per vertex of mesh %d)"
+                             % (self._npos[int(mesh)], self._npos[int(mesh)], int(mesh)))
         _check(self.L.lh_accel_set_normals(self.h, int(mesh), N.ctypes.data if N is not None else None,
                                            (N.shape[1] * 8) if N is not None else 24, int(two_side)),
                "lh_accel_set_normals")

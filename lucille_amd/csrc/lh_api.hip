@@ -53,15 +53,25 @@ extern "C" int lh_render_launch_resolve(int w, int h, int xs, int ys, int N, con
 
 struct lh_buf { void *p; size_t cap; };
 
+/* the host side of a committed scene: ONE build, any number of device replicas (lh_multi.hip
+ * uploads it to every GPU of the node; SURVEY.md 8e "replicated BVH") */
+struct lh_host_scene {
+    int refs;                 /* guarded by g_scene_mu */
+    lh_bvh_t bvh;
+    lh_refbvh_t ref;          /* reference-order tree (ties, beams, the reference walk) */
+    int have_ref;
+    double ref_build_seconds;
+    double *nrm9;             /* per-primitive vertex normals (9 doubles, NaN = none) or NULL */
+};
+static pthread_mutex_t g_scene_mu = PTHREAD_MUTEX_INITIALIZER;
+
 struct lh_accel {
     int device;
     int committed;
+    int commit_failed;        /* a commit that failed half-way: device memory is released by destroy, a retry is refused */
     /* staged meshes (host copies, packed xyz) */
     lh_mesh_copy *meshes; uint32_t nmeshes;
-    /* host BVH */
-    lh_bvh_t bvh;
-    lh_refbvh_t ref;          /* reference-order tree (ties, beams) */
-    int have_ref;
+    lh_host_scene *hs;        /* never NULL after create */
     void *d_ref_lca, *d_prim_leafpos, *d_ref_nodes, *d_ref_leaf_prims;
     /* device */
     lh_dev_scene_t dev;
@@ -83,8 +93,7 @@ struct lh_accel {
     void *d_stage; size_t stage_bytes;
     /* pipelined host batches: two pinned in/out staging pairs, two device pairs, two streams */
     struct { void *h_in[2], *h_out[2], *d_in[2], *d_out[2]; hipStream_t s[2]; hipEvent_t done[2]; size_t cap; int ready; } pipe;
-    /* per-primitive vertex normals (9 doubles, NaN = none), only if some mesh has normals */
-    double *h_nrm9; void *d_nrm9;
+    void *d_nrm9;                      /* hs->nrm9 on the device */
     /* tile-render scratch (lh_render_ao_tile) */
     lh_buf r_org, r_dir, r_prim, r_t, r_u, r_v, r_slot, r_hitrec, r_aorg, r_adir, r_occ, r_blocks, r_key, r_frame;
     lh_buf p_org2, p_dir2, p_path, p_path2, p_thr, p_thr2, p_rad, p_alive;   /* path tracer */
@@ -121,6 +130,9 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     if (device < 0 || device >= n) return fail("lh_accel_create: device %d out of range [0,%d)", device, n);
     lh_accel_t *a = (lh_accel_t *)calloc(1, sizeof(*a));
     if (!a) return fail("out of memory");
+    a->hs = (lh_host_scene *)calloc(1, sizeof(lh_host_scene));
+    if (!a->hs) { free(a); return fail("out of memory"); }
+    a->hs->refs = 1;
     a->device = device;
     {
         pthread_mutexattr_t at; pthread_mutexattr_init(&at); pthread_mutexattr_settype(&at, PTHREAD_MUTEX_RECURSIVE);
@@ -232,46 +244,52 @@ static void release_device(lh_accel_t *a)
     a->d_stage = NULL; a->stage_bytes = 0; a->stream = NULL;
 }
 
-extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
+/* ---- host build (once per scene) ------------------------------------------------------------ */
+static int host_build(lh_accel_t *a, int build_threads)
 {
-    lh_guard guard(a);
-    if (!a) return fail("lh_accel_commit: accel is NULL");
-    if (a->committed) return fail("lh_accel_commit: already committed");
+    lh_host_scene *hs = a->hs;
     if (build_threads <= 0) {
-        long nc = sysconf(_SC_NPROCESSORS_ONLN);
+        /* LH_BUILD_THREADS: how a multi-process launcher (one rank per GPU) keeps N ranks from
+         * oversubscribing the host N times over (lucille_amd/shard.py sets cores / world) */
+        const char *e = getenv("LH_BUILD_THREADS");
+        long nc = (e && atoi(e) > 0) ? atoi(e) : sysconf(_SC_NPROCESSORS_ONLN);
         build_threads = nc > 0 ? (int)nc : 1;
     }
     lh_mesh_view_t *views = (lh_mesh_view_t *)calloc(a->nmeshes ? a->nmeshes : 1, sizeof(*views));
+    if (!views) return fail("out of memory");
     for (uint32_t g = 0; g < a->nmeshes; g++) {
         views[g].npositions = a->meshes[g].npos; views[g].positions = a->meshes[g].pos;
         views[g].stride_bytes = 3 * sizeof(double);
         views[g].nindices = a->meshes[g].nidx; views[g].indices = a->meshes[g].idx;
     }
-    int rc = lh_bvh_build(&a->bvh, views, a->nmeshes, build_threads);
+    int rc = lh_bvh_build(&hs->bvh, views, a->nmeshes, build_threads);
     free(views);
     if (rc == -2) return fail("lh_accel_commit: a vertex coordinate is NaN, infinite or beyond 1e30");
     if (rc != 0) return fail("lh_accel_commit: BVH build failed (bad input or out of memory)");
-    /* the reference-order tree: exact-t tie winners + beam visibility (LH_REFTREE=0 skips it:
-     * ties then fall back to "larger primitive id wins" and beam queries are refused) */
+    /* the reference-order tree: exact-t tie winners, the reference walk for fragile hits, beam
+     * visibility (LH_REFTREE=0 skips it: ties then fall back to "larger primitive id wins",
+     * fragile hits are not re-traced and beam queries are refused) */
     {
         const char *e = getenv("LH_REFTREE");
-        a->have_ref = !(e && atoi(e) == 0);
-        if (a->have_ref && lh_refbvh_build(&a->ref, a->bvh.tri64, a->bvh.ntris, build_threads) != 0)
+        hs->have_ref = !(e && atoi(e) == 0);
+        const double t0 = now_s();
+        if (hs->have_ref && lh_refbvh_build(&hs->ref, hs->bvh.tri64, hs->bvh.ntris, build_threads) != 0)
             return fail("lh_accel_commit: reference-order tree build failed (out of memory)");
+        hs->ref_build_seconds = now_s() - t0;
     }
     /* per-primitive normals in primitive-id order, if any mesh carries normals */
     {
         bool any = false;
         for (uint32_t g = 0; g < a->nmeshes; g++) any = any || a->meshes[g].nrm != NULL;
-        if (any && a->bvh.ntris) {
-            a->h_nrm9 = (double *)malloc(sizeof(double) * 9 * (size_t)a->bvh.ntris);
-            if (!a->h_nrm9) return fail("out of memory");
-            for (uint32_t p = 0; p < a->bvh.ntris; p++) {
-                const lh_mesh_copy *m = &a->meshes[a->bvh.prim_geom[p]];
-                double *o = a->h_nrm9 + 9 * (size_t)p;
+        if (any && hs->bvh.ntris) {
+            hs->nrm9 = (double *)malloc(sizeof(double) * 9 * (size_t)hs->bvh.ntris);
+            if (!hs->nrm9) return fail("out of memory");
+            for (uint32_t p = 0; p < hs->bvh.ntris; p++) {
+                const lh_mesh_copy *m = &a->meshes[hs->bvh.prim_geom[p]];
+                double *o = hs->nrm9 + 9 * (size_t)p;
                 if (!m->nrm) { for (int k = 0; k < 9; k++) o[k] = NAN; continue; }
                 for (int c = 0; c < 3; c++) {
-                    uint32_t vi = m->idx[a->bvh.prim_index[p] + c];
+                    uint32_t vi = m->idx[hs->bvh.prim_index[p] + c];
                     for (int k = 0; k < 3; k++) o[3 * c + k] = m->nrm[3 * (size_t)vi + k];
                 }
             }
@@ -280,102 +298,130 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
     /* the packed mesh copies are no longer needed: the BVH holds tri64 */
     for (uint32_t g = 0; g < a->nmeshes; g++) { free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm); }
     free(a->meshes); a->meshes = NULL; a->nmeshes = 0;
+    if (hs->bvh.ntris && hs->bvh.max_depth + 1 > 64) return fail("lh_accel_commit: tree depth %u exceeds the kernel stack", hs->bvh.max_depth);
+    return 0;
+}
 
+/* node formats a walk can read; only the one the default kernel uses is uploaded at commit, the
+ * others (A/B variants, the deep-tree fallback) on first use */
+enum { LH_FMT_F32 = 1, LH_FMT_Q16 = 2, LH_FMT_Q16X4 = 4, LH_FMT_C8 = 8 };
+extern "C" int lh_trace_formats_needed(const lh_dev_scene_t *sc, int variant);      /* lh_kernels.hip */
+
+static int ensure_formats(lh_accel_t *a, int mask)
+{
+    const lh_bvh_t *b = &a->hs->bvh;
+    if ((mask & LH_FMT_F32) && !a->d_nodes) {
+        const size_t nb = sizeof(lh_node_t) * (size_t)b->nnodes;
+        HIPCHK(hipMalloc(&a->d_nodes, nb));
+        HIPCHK(hipMemcpy(a->d_nodes, b->nodes, nb, hipMemcpyHostToDevice));
+        a->dev.nodes = a->d_nodes; a->device_bytes += nb;
+    }
+    if ((mask & LH_FMT_Q16) && !a->d_qnodes) {
+        const size_t qb = sizeof(lh_qnode_t) * (size_t)b->nnodes;
+        HIPCHK(hipMalloc(&a->d_qnodes, qb));
+        HIPCHK(hipMemcpy(a->d_qnodes, b->qnodes, qb, hipMemcpyHostToDevice));
+        a->dev.qnodes = a->d_qnodes; a->device_bytes += qb;
+    }
+    if ((mask & LH_FMT_Q16X4) && !a->d_q4nodes) {
+        const size_t q4b = sizeof(lh_q4node_t) * (size_t)b->nq4nodes;
+        HIPCHK(hipMalloc(&a->d_q4nodes, q4b));
+        HIPCHK(hipMemcpy(a->d_q4nodes, b->q4nodes, q4b, hipMemcpyHostToDevice));
+        a->dev.q4nodes = a->d_q4nodes; a->device_bytes += q4b;
+    }
+    if ((mask & LH_FMT_C8) && !a->d_c8nodes) {
+        pthread_mutex_lock(&g_scene_mu);
+        const int rc8 = lh_bvh_ensure_c8(&a->hs->bvh);
+        pthread_mutex_unlock(&g_scene_mu);
+        if (rc8 != 0) return fail("building the 8-wide compressed tree failed (out of memory)");
+        a->dev.nc8nodes = b->nc8nodes; a->dev.c8_depth = b->c8_depth;
+        const size_t c8b = sizeof(lh_c8node_t) * (size_t)b->nc8nodes, t32 = sizeof(lh_tri32_t) * (size_t)b->ntris;
+        HIPCHK(hipMalloc(&a->d_c8nodes, c8b + 64));
+        HIPCHK(hipMalloc(&a->d_tri32_c8, t32 + 64));
+        HIPCHK(hipMemcpy(a->d_c8nodes, b->c8nodes, c8b, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(a->d_tri32_c8, b->tri32_c8, t32, hipMemcpyHostToDevice));
+        a->dev.c8nodes = a->d_c8nodes; a->dev.tri32_c8 = a->d_tri32_c8; a->device_bytes += c8b + t32;
+    }
+    return 0;
+}
+
+/* ---- device replica of the host scene (once per GPU) ---------------------------------------- */
+static int device_upload(lh_accel_t *a)
+{
+    lh_host_scene *hs = a->hs;
     HIPCHK(hipSetDevice(a->device));
     double t0 = now_s();
     HIPCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(unsigned long long) * LH_NCURSOR));
     HIPCHK(hipMalloc((void **)&a->d_counters, sizeof(unsigned long long) * LH_CNT_DEV));
-    HIPCHK(hipMalloc((void **)&a->d_total, sizeof(unsigned long long)));
-    if (a->h_nrm9) {
-        HIPCHK(hipMalloc(&a->d_nrm9, sizeof(double) * 9 * (size_t)a->bvh.ntris));
-        HIPCHK(hipMemcpy(a->d_nrm9, a->h_nrm9, sizeof(double) * 9 * (size_t)a->bvh.ntris, hipMemcpyHostToDevice));
-        free(a->h_nrm9); a->h_nrm9 = NULL;
-    }
+    HIPCHK(hipMalloc((void **)&a->d_total, sizeof(unsigned long long) * 4));
     a->device_bytes = 0;
-    if (a->bvh.ntris) {
-        size_t nb = sizeof(lh_node_t) * (size_t)a->bvh.nnodes;
-        size_t t32 = sizeof(lh_tri32_t) * (size_t)a->bvh.ntris;
-        size_t t64 = sizeof(lh_tri64_t) * (size_t)a->bvh.ntris;
-        HIPCHK(hipMalloc(&a->d_nodes, nb));
+    if (hs->nrm9) {
+        HIPCHK(hipMalloc(&a->d_nrm9, sizeof(double) * 9 * (size_t)hs->bvh.ntris));
+        HIPCHK(hipMemcpy(a->d_nrm9, hs->nrm9, sizeof(double) * 9 * (size_t)hs->bvh.ntris, hipMemcpyHostToDevice));
+        a->device_bytes += sizeof(double) * 9 * (size_t)hs->bvh.ntris;
+    }
+    if (hs->bvh.ntris) {
+        size_t t32 = sizeof(lh_tri32_t) * (size_t)hs->bvh.ntris;
+        size_t t64 = sizeof(lh_tri64_t) * (size_t)hs->bvh.ntris;
         HIPCHK(hipMalloc(&a->d_tri32, t32 + 64));   /* the unified walk reads 16 B past a record */
         HIPCHK(hipMalloc(&a->d_tri64, t64));
-        HIPCHK(hipMemcpy(a->d_nodes, a->bvh.nodes, nb, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(a->d_tri32, a->bvh.tri32, t32, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(a->d_tri64, a->bvh.tri64, t64, hipMemcpyHostToDevice));
-        size_t qb = sizeof(lh_qnode_t) * (size_t)a->bvh.nnodes;
-        HIPCHK(hipMalloc(&a->d_qnodes, qb));
-        HIPCHK(hipMemcpy(a->d_qnodes, a->bvh.qnodes, qb, hipMemcpyHostToDevice));
-        size_t q4b = sizeof(lh_q4node_t) * (size_t)a->bvh.nq4nodes;
-        HIPCHK(hipMalloc(&a->d_q4nodes, q4b));
-        HIPCHK(hipMemcpy(a->d_q4nodes, a->bvh.q4nodes, q4b, hipMemcpyHostToDevice));
-        a->device_bytes = nb + t32 + t64 + qb + q4b;
-        {   /* the 8-wide compressed tree is an experiment (slower: its node step is VALU-bound,
-             * profiles/README.md r01d): resident only when asked for */
-            const char *fmt = getenv("LH_NODE_FORMAT");
-            if (fmt && strcmp(fmt, "c8") == 0) {
-                size_t c8b = sizeof(lh_c8node_t) * (size_t)a->bvh.nc8nodes;
-                HIPCHK(hipMalloc(&a->d_c8nodes, c8b + 64));
-                HIPCHK(hipMalloc(&a->d_tri32_c8, t32 + 64));
-                HIPCHK(hipMemcpy(a->d_c8nodes, a->bvh.c8nodes, c8b, hipMemcpyHostToDevice));
-                HIPCHK(hipMemcpy(a->d_tri32_c8, a->bvh.tri32_c8, t32, hipMemcpyHostToDevice));
-                a->device_bytes += c8b + t32;
-            }
-        }
+        HIPCHK(hipMemcpy(a->d_tri32, hs->bvh.tri32, t32, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(a->d_tri64, hs->bvh.tri64, t64, hipMemcpyHostToDevice));
+        a->device_bytes += t32 + t64;
         float r = 0.0f;
-        for (int k = 0; k < 3; k++) { r = fmaxf(r, fabsf(a->bvh.bmin[k])); r = fmaxf(r, fabsf(a->bvh.bmax[k])); }
-        a->dev.nodes = a->d_nodes; a->dev.tri32 = a->d_tri32; a->dev.tri64 = a->d_tri64;
-        a->dev.ntris = a->bvh.ntris; a->dev.nnodes = a->bvh.nnodes;
-        a->dev.max_depth = a->bvh.max_depth; a->dev.scene_r = r; a->dev.ray_chunk = a->ray_chunk;
-        a->dev.qnodes = a->d_qnodes;
-        for (int k = 0; k < 3; k++) { a->dev.grid_lo[k] = a->bvh.grid_lo[k]; a->dev.grid_step[k] = a->bvh.grid_step[k]; }
-        if (a->have_ref) {
-            const uint32_t rn = a->ref.nnodes;
+        for (int k = 0; k < 3; k++) { r = fmaxf(r, fabsf(hs->bvh.bmin[k])); r = fmaxf(r, fabsf(hs->bvh.bmax[k])); }
+        a->dev.tri32 = a->d_tri32; a->dev.tri64 = a->d_tri64;
+        a->dev.ntris = hs->bvh.ntris; a->dev.nnodes = hs->bvh.nnodes;
+        a->dev.max_depth = hs->bvh.max_depth; a->dev.scene_r = r; a->dev.ray_chunk = a->ray_chunk;
+        for (int k = 0; k < 3; k++) { a->dev.grid_lo[k] = hs->bvh.grid_lo[k]; a->dev.grid_step[k] = hs->bvh.grid_step[k]; }
+        if (hs->have_ref) {
+            const uint32_t rn = hs->ref.nnodes;
             int *lca = (int *)malloc(sizeof(int) * 4 * (size_t)rn);
-            uint32_t *lp = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (size_t)a->bvh.ntris);
+            uint32_t *lp = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (size_t)hs->bvh.ntris);
             if (!lca || !lp) { free(lca); free(lp); return fail("out of memory"); }
             for (uint32_t i = 0; i < rn; i++) {
-                lca[4 * i] = a->ref.nodes[i].parent; lca[4 * i + 1] = a->ref.nodes[i].depth;
-                lca[4 * i + 2] = a->ref.nodes[i].axis; lca[4 * i + 3] = a->ref.nodes[i].child[0];
+                lca[4 * i] = hs->ref.nodes[i].parent; lca[4 * i + 1] = hs->ref.nodes[i].depth;
+                lca[4 * i + 2] = hs->ref.nodes[i].axis; lca[4 * i + 3] = hs->ref.nodes[i].child[0];
             }
-            for (uint32_t p = 0; p < a->bvh.ntris; p++) { lp[2 * p] = a->ref.prim_leaf[p]; lp[2 * p + 1] = a->ref.prim_pos[p]; }
+            for (uint32_t p = 0; p < hs->bvh.ntris; p++) { lp[2 * p] = hs->ref.prim_leaf[p]; lp[2 * p + 1] = hs->ref.prim_pos[p]; }
             hipError_t e1 = hipMalloc(&a->d_ref_lca, sizeof(int) * 4 * (size_t)rn);
-            hipError_t e2 = hipMalloc(&a->d_prim_leafpos, sizeof(uint32_t) * 2 * (size_t)a->bvh.ntris);
+            hipError_t e2 = hipMalloc(&a->d_prim_leafpos, sizeof(uint32_t) * 2 * (size_t)hs->bvh.ntris);
             hipError_t e3 = hipMalloc(&a->d_ref_nodes, sizeof(lh_refnode_t) * (size_t)rn);
-            hipError_t e4 = hipMalloc(&a->d_ref_leaf_prims, sizeof(uint32_t) * (size_t)a->bvh.ntris);
+            hipError_t e4 = hipMalloc(&a->d_ref_leaf_prims, sizeof(uint32_t) * (size_t)hs->bvh.ntris);
             if (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess) {
                 e1 = hipMemcpy(a->d_ref_lca, lca, sizeof(int) * 4 * (size_t)rn, hipMemcpyHostToDevice);
-                e2 = hipMemcpy(a->d_prim_leafpos, lp, sizeof(uint32_t) * 2 * (size_t)a->bvh.ntris, hipMemcpyHostToDevice);
-                e3 = hipMemcpy(a->d_ref_nodes, a->ref.nodes, sizeof(lh_refnode_t) * (size_t)rn, hipMemcpyHostToDevice);
-                e4 = hipMemcpy(a->d_ref_leaf_prims, a->ref.leaf_prims, sizeof(uint32_t) * (size_t)a->bvh.ntris, hipMemcpyHostToDevice);
+                e2 = hipMemcpy(a->d_prim_leafpos, lp, sizeof(uint32_t) * 2 * (size_t)hs->bvh.ntris, hipMemcpyHostToDevice);
+                e3 = hipMemcpy(a->d_ref_nodes, hs->ref.nodes, sizeof(lh_refnode_t) * (size_t)rn, hipMemcpyHostToDevice);
+                e4 = hipMemcpy(a->d_ref_leaf_prims, hs->ref.leaf_prims, sizeof(uint32_t) * (size_t)hs->bvh.ntris, hipMemcpyHostToDevice);
             }
             free(lca); free(lp);
             if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) return fail("reference-order tree upload failed");
             a->dev.ref_lca = a->d_ref_lca; a->dev.prim_leafpos = a->d_prim_leafpos;
             a->dev.ref_nodes = a->d_ref_nodes; a->dev.ref_leaf_prims = a->d_ref_leaf_prims;
-            a->dev.ref_nnodes = rn; a->dev.ref_empty = a->ref.empty;
-            for (int k = 0; k < 3; k++) { a->dev.ref_bmin[k] = a->ref.bmin[k]; a->dev.ref_bmax[k] = a->ref.bmax[k]; }
-            a->device_bytes += sizeof(int) * 4 * (size_t)rn + sizeof(uint32_t) * 3 * (size_t)a->bvh.ntris + sizeof(lh_refnode_t) * (size_t)rn;
+            a->dev.ref_nnodes = rn; a->dev.ref_empty = hs->ref.empty;
+            for (int k = 0; k < 3; k++) { a->dev.ref_bmin[k] = hs->ref.bmin[k]; a->dev.ref_bmax[k] = hs->ref.bmax[k]; }
+            a->device_bytes += sizeof(int) * 4 * (size_t)rn + sizeof(uint32_t) * 3 * (size_t)hs->bvh.ntris + sizeof(lh_refnode_t) * (size_t)rn;
         }
-        a->dev.q4nodes = a->d_q4nodes; a->dev.nq4nodes = a->bvh.nq4nodes; a->dev.q4_depth = a->bvh.q4_depth;
-        a->dev.c8nodes = a->d_c8nodes; a->dev.tri32_c8 = a->d_tri32_c8; a->dev.nc8nodes = a->bvh.nc8nodes; a->dev.c8_depth = a->bvh.c8_depth;
+        a->dev.nq4nodes = hs->bvh.nq4nodes; a->dev.q4_depth = hs->bvh.q4_depth;
+        a->dev.nc8nodes = hs->bvh.nc8nodes; a->dev.c8_depth = hs->bvh.c8_depth;
         a->dev.use_qnodes = 2;
         {
             const char *fmt = getenv("LH_NODE_FORMAT");
             if (fmt && strcmp(fmt, "f32") == 0) a->dev.use_qnodes = 0;
             if (fmt && strcmp(fmt, "q16") == 0) a->dev.use_qnodes = 1;
-            if (3 * a->bvh.q4_depth + 5 > 64) a->dev.use_qnodes = 1;     /* pathological depth: 2-wide walk */
+            if (3 * hs->bvh.q4_depth + 5 > 64) a->dev.use_qnodes = 1;     /* pathological depth: 2-wide walk */
             /* 8-wide compressed nodes: stack overflow is handed to the reference walk, so that tree is needed */
-            if (fmt && strcmp(fmt, "c8") == 0 && a->have_ref && a->d_c8nodes) a->dev.use_qnodes = 3;
+            if (fmt && strcmp(fmt, "c8") == 0 && hs->have_ref) a->dev.use_qnodes = 3;
         }
-        if (a->bvh.max_depth + 1 > 64) return fail("lh_accel_commit: tree depth %u exceeds the kernel stack", a->bvh.max_depth);
+        /* resident from the start: what the default kernel reads (everything else on first use) */
+        if (ensure_formats(a, lh_trace_formats_needed(&a->dev, a->default_variant)) != 0) return -1;
     }
     a->upload_seconds = now_s() - t0;
     {
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, a->device));
-        uint32_t need = a->bvh.max_depth + 1;
-        if (a->dev.use_qnodes == 2) need = 3 * a->bvh.q4_depth + 5;
+        uint32_t need = hs->bvh.max_depth + 1;
+        if (a->dev.use_qnodes == 2) need = 3 * hs->bvh.q4_depth + 5;
         uint32_t stack = (need + 1u) & ~1u;
         if (stack < 16) stack = 16;
         int per_cu = (int)(160u / stack);                     /* LDS: stack KiB per 256-thread workgroup */
@@ -389,14 +435,51 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
     return 0;
 }
 
+extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
+{
+    lh_guard guard(a);
+    if (!a) return fail("lh_accel_commit: accel is NULL");
+    if (a->committed) return fail("lh_accel_commit: already committed");
+    if (a->commit_failed) return fail("lh_accel_commit: an earlier commit of this accelerator failed; create a new one");
+    a->commit_failed = 1;                       /* cleared on success */
+    if (host_build(a, build_threads) != 0) return -1;
+    if (device_upload(a) != 0) return -1;
+    a->commit_failed = 0;
+    return 0;
+}
+
+/* lh_multi.hip: `dst` (created, nothing added) becomes a replica of `src`'s committed scene on its own device */
+extern "C" int lh_accel_commit_replica(lh_accel_t *dst, lh_accel_t *src)
+{
+    if (!dst || !src || !src->committed) return fail("lh_accel_commit_replica: source not committed");
+    lh_guard guard(dst);
+    if (dst->committed || dst->commit_failed || dst->nmeshes) return fail("lh_accel_commit_replica: destination is not a fresh accelerator");
+    pthread_mutex_lock(&g_scene_mu);
+    lh_host_scene *old = dst->hs;
+    dst->hs = src->hs; dst->hs->refs++;
+    pthread_mutex_unlock(&g_scene_mu);
+    free(old);                                  /* a fresh accelerator's scene holds nothing */
+    dst->commit_failed = 1;
+    if (device_upload(dst) != 0) return -1;
+    dst->commit_failed = 0;
+    return 0;
+}
+
 extern "C" void lh_accel_destroy(lh_accel_t *a)
 {
     if (!a) return;
-    if (a->committed) { (void)hipSetDevice(a->device); release_device(a); }
+    if (a->committed || a->commit_failed) { (void)hipSetDevice(a->device); release_device(a); }
     for (uint32_t g = 0; g < a->nmeshes; g++) { free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm); }
-    free(a->meshes); free(a->h_nrm9);
-    lh_bvh_release(&a->bvh);
-    lh_refbvh_release(&a->ref);
+    free(a->meshes);
+    pthread_mutex_lock(&g_scene_mu);
+    const int last = (--a->hs->refs == 0);
+    pthread_mutex_unlock(&g_scene_mu);
+    if (last) {
+        free(a->hs->nrm9);
+        lh_bvh_release(&a->hs->bvh);
+        lh_refbvh_release(&a->hs->ref);
+        free(a->hs);
+    }
     pthread_mutex_destroy(&a->mu);
     free(a);
 }
@@ -405,19 +488,21 @@ extern "C" int lh_accel_info(const lh_accel_t *a, lh_accel_info_t *o)
 {
     if (!a || !o) return fail("lh_accel_info: NULL argument");
     if (!a->committed) return fail("lh_accel_info: accel not committed");
-    o->ntriangles = a->bvh.ntris; o->nnodes = a->bvh.nnodes; o->nleaves = a->bvh.nleaves;
-    o->max_depth = a->bvh.max_depth; o->device_bytes = a->device_bytes;
-    o->build_seconds = a->bvh.build_seconds; o->upload_seconds = a->upload_seconds;
+    o->ntriangles = a->hs->bvh.ntris; o->nnodes = a->hs->bvh.nnodes; o->nleaves = a->hs->bvh.nleaves;
+    o->max_depth = a->hs->bvh.max_depth; o->device_bytes = a->device_bytes;
+    o->build_seconds = a->hs->bvh.build_seconds; o->upload_seconds = a->upload_seconds;
     o->device = a->device;
+    o->ref_build_seconds = a->hs->ref_build_seconds;
+    o->nnodes_traversal = a->hs->bvh.nq4nodes;
     return 0;
 }
 
 extern "C" int lh_accel_prim_lookup(const lh_accel_t *a, uint32_t prim, uint32_t *mesh, uint32_t *index)
 {
     if (!a || !a->committed) return fail("lh_accel_prim_lookup: accel not committed");
-    if (prim >= a->bvh.ntris) return fail("lh_accel_prim_lookup: prim %u out of range", prim);
-    if (mesh) *mesh = a->bvh.prim_geom[prim];
-    if (index) *index = a->bvh.prim_index[prim];
+    if (prim >= a->hs->bvh.ntris) return fail("lh_accel_prim_lookup: prim %u out of range", prim);
+    if (mesh) *mesh = a->hs->bvh.prim_geom[prim];
+    if (index) *index = a->hs->bvh.prim_index[prim];
     return 0;
 }
 
@@ -432,8 +517,8 @@ extern "C" int lh_accel_set_grid(lh_accel_t *a, int blocks)
 extern "C" int lh_accel_export(const lh_accel_t *a, void *nodes, void *tri32)
 {
     if (!a || !a->committed) return fail("lh_accel_export: accel not committed");
-    if (nodes && a->bvh.nnodes) memcpy(nodes, a->bvh.nodes, sizeof(lh_node_t) * (size_t)a->bvh.nnodes);
-    if (tri32 && a->bvh.ntris) memcpy(tri32, a->bvh.tri32, sizeof(lh_tri32_t) * (size_t)a->bvh.ntris);
+    if (nodes && a->hs->bvh.nnodes) memcpy(nodes, a->hs->bvh.nodes, sizeof(lh_node_t) * (size_t)a->hs->bvh.nnodes);
+    if (tri32 && a->hs->bvh.ntris) memcpy(tri32, a->hs->bvh.tri32, sizeof(lh_tri32_t) * (size_t)a->hs->bvh.ntris);
     return 0;
 }
 
@@ -460,7 +545,7 @@ static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
     if (mode == LH_MODE_ANY && !d_occ) return fail("intersect: any mode needs the occluded output");
     if (mode != LH_MODE_CLOSEST && mode != LH_MODE_ANY) return fail("intersect: unknown mode %d", mode);
     HIPCHK(hipSetDevice(a->device));
-    if (a->bvh.ntris == 0) {
+    if (a->hs->bvh.ntris == 0) {
         size_t blocks = (n + 255) / 256;
         hipLaunchKernelGGL(k_fill_miss, dim3((unsigned)blocks), dim3(256), 0, s, n,
                            mode == LH_MODE_CLOSEST ? (uint32_t *)d_prim : NULL, (double *)(mode == LH_MODE_CLOSEST ? d_t : NULL),
@@ -471,6 +556,7 @@ static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
     }
     if (variant == LH_VARIANT_DEFAULT) variant = a->default_variant;
     if (variant < 0 || variant > LH_VARIANT_UNIFIED4) return fail("intersect: unknown variant %d", variant);
+    if (ensure_formats(a, lh_trace_formats_needed(&a->dev, variant)) != 0) return -1;     /* A/B formats: uploaded on first use */
     int rc = lh_launch_trace(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim,
                              (double *)d_t, (double *)d_u, (double *)d_v, mode == LH_MODE_ANY,
                              (uint8_t *)d_occ, d_counters, a->d_cursor + (a->cursor_next++ % LH_NCURSOR), variant, a->grid_blocks, a->min_active, a->tri_batch, (void *)s);
@@ -496,11 +582,11 @@ extern "C" int lh_accel_intersect_device_counted(lh_accel_t *a, size_t n, const 
     HIPCHK(hipSetDevice(a->device));
     HIPCHK(hipMemsetAsync(a->d_counters, 0, sizeof(unsigned long long) * LH_CNT_DEV, a->stream));
     HIPCHK(hipDeviceSynchronize());
-    if (a->bvh.ntris == 0) { counters[0] = counters[1] = counters[2] = 0; counters[3] = n; }
+    if (a->hs->bvh.ntris == 0) { counters[0] = counters[1] = counters[2] = 0; counters[3] = n; }
     int rc = launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, variant, a->d_counters, a->stream);
     if (rc != 0) return rc;
     HIPCHK(hipStreamSynchronize(a->stream));
-    if (a->bvh.ntris) {
+    if (a->hs->bvh.ntris) {
         unsigned long long h[LH_CNT_DEV];
         HIPCHK(hipMemcpy(h, a->d_counters, sizeof(h), hipMemcpyDeviceToHost));
         for (int k = 0; k < LH_CNT_N; k++) counters[k] = h[k];
@@ -636,7 +722,7 @@ extern "C" int lh_accel_intersect_host(lh_accel_t *a, size_t n, const double *or
         } else {
             ho.resize(n); HIPCHK(hipMemcpyAsync(ho.data(), d_occ, n, hipMemcpyDeviceToHost, a->stream));
         }
-        if (a->bvh.ntris) HIPCHK(hipMemcpyAsync(h, a->d_counters, sizeof(h), hipMemcpyDeviceToHost, a->stream));
+        if (a->hs->bvh.ntris) HIPCHK(hipMemcpyAsync(h, a->d_counters, sizeof(h), hipMemcpyDeviceToHost, a->stream));
         HIPCHK(hipStreamSynchronize(a->stream));
         for (size_t i = 0; i < n; i++) nh += (mode == LH_MODE_CLOSEST) ? (hp[i] != LH_MISS_PRIM) : (ho[i] != 0);
         a->stat[0] += h[LH_CNT_NODES]; a->stat[1] += h[LH_CNT_TRIS]; a->stat[2] += h[LH_CNT_EXACT];
@@ -720,9 +806,9 @@ extern "C" int lh_accel_add_rib_scene(lh_accel_t *a, const lh_rib_scene_t *scene
     for (uint32_t m = 0; m < info.nmeshes; m++) {
         uint32_t npos = 0, nidx = 0; const double *pos = NULL, *nrm = NULL; const uint32_t *idx = NULL; int two = 0;
         if (lh_rib_mesh(scene, m, &npos, &pos, &nidx, &idx, &nrm, &two) != 0) return fail("lh_accel_add_rib_scene: %s", lh_rib_last_error());
-        const int id = lh_accel_add_mesh(a, npos, pos, 4 * sizeof(double), nidx, idx);
-        if (id < 0) return -1;
-        if (nrm && lh_accel_set_normals(a, (uint32_t)id, nrm, 4 * sizeof(double), two) != 0) return -1;
+        const uint32_t ord = a->nmeshes;          /* add_mesh returns 0 / -1, not the ordinal */
+        if (lh_accel_add_mesh(a, npos, pos, 4 * sizeof(double), nidx, idx) != 0) return -1;
+        if (nrm && lh_accel_set_normals(a, ord, nrm, 4 * sizeof(double), two) != 0) return -1;
     }
     return 0;
 }
@@ -751,7 +837,7 @@ extern "C" int lh_render_ao_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
                LH_VARIANT_DEFAULT, NULL, s) != 0) return -1;
     /* 3. count hits (deterministic compaction needs the total before sizing the AO batch) */
     unsigned long long nhit = 0;
-    if (a->bvh.ntris) {
+    if (a->hs->bvh.ntris) {
         if (ensure_buf(&a->r_hitrec, S * 96) || ensure_buf(&a->r_key, S * 8)) return -1;   /* worst case: every sample hits */
         if (lh_render_launch_compact(&a->dev, (const double *)a->d_nrm9, S, (const double *)a->r_org.p,
                                      (const double *)a->r_dir.p, (const uint32_t *)a->r_prim.p, (const double *)a->r_t.p,
@@ -821,10 +907,10 @@ extern "C" int lh_accel_beam_visibility_device(lh_accel_t *a, size_t n, const vo
     if (!a || !a->committed) return fail("beam_visibility: accel not committed");
     if (n == 0) return 0;
     if (!d_org || !d_dirs || !d_result) return fail("beam_visibility: NULL argument");
-    if (!a->have_ref) return fail("beam_visibility: the reference-order tree was disabled (LH_REFTREE=0)");
+    if (!a->hs->have_ref) return fail("beam_visibility: the reference-order tree was disabled (LH_REFTREE=0)");
     HIPCHK(hipSetDevice(a->device));
     lh_dev_scene_t sc = a->dev;
-    if (a->bvh.ntris == 0) { sc.ref_empty = 1; }
+    if (a->hs->bvh.ntris == 0) { sc.ref_empty = 1; }
     if (lh_launch_beam_visibility(&sc, n, (const double *)d_org, (const double *)d_dirs, (int32_t *)d_result, stream) != 0)
         return fail("beam kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     return 0;
@@ -891,7 +977,7 @@ extern "C" int lh_render_pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
     while (n > 0) {
         if (launch(a, n, org, dir, a->r_prim.p, a->r_t.p, a->r_u.p, a->r_v.p, NULL, LH_MODE_CLOSEST, LH_VARIANT_DEFAULT, NULL, s) != 0) return -1;
         rays += n;
-        if (a->bvh.ntris == 0) {
+        if (a->hs->bvh.ntris == 0) {
             /* empty scene: every path escapes at once */
         }
         if (lh_pt_launch_shade(n, &a->dev, (const double *)a->d_nrm9, depth, max_vertices, kd, seed, s0, spp, x0, y0, w,

@@ -21,6 +21,7 @@
 #include <float.h>
 #include <math.h>
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -591,8 +592,10 @@ int lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, 
         b.task_threshold = n / (uint32_t)(nthreads * 8);
         if (b.task_threshold < 4096) b.task_threshold = 4096;
     }
+    double t_prep = now_s();
     build_range(&b, &main_arena, root, 0, n, 0);
     b.collecting = 0;
+    double t_top = now_s();
 
     {
         worker_t *w = NULL; pthread_t *th = NULL; volatile uint32_t next = 0; int t;
@@ -603,6 +606,8 @@ int lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, 
             for (t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
         }
 
+        double t_par = now_s();
+        if (getenv("LH_BUILD_TIMING")) fprintf(stderr, "[lh_bvh] prep %.3f top %.3f subtrees %.3f (tasks %zu)\n", t_prep - t0, t_top - t_prep, t_par - t_top, b.ntasks);
         /* flatten */
         {
             flat_t f; uint32_t ninner;
@@ -630,8 +635,24 @@ int lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, 
     }
     arena_free(&main_arena);
     free(b.tasks); free(b.plo); free(b.phi); free(b.cen); free(b.order);
-    if (quantize_nodes(out) != 0 || collapse4(out) != 0 || collapse8(out) != 0) { lh_bvh_release(out); return -1; }
+    {
+        double t1 = now_s(), t2, t3;
+        if (quantize_nodes(out) != 0) { lh_bvh_release(out); return -1; }
+        t2 = now_s();
+        if (collapse4(out) != 0) { lh_bvh_release(out); return -1; }
+        t3 = now_s();
+        /* the 8-wide compressed tree is an opt-in experiment (slower: profiles/README.md r01d): lh_bvh_ensure_c8 */
+        if (getenv("LH_BUILD_TIMING")) fprintf(stderr, "[lh_bvh] flatten+free ..%.3f quantize %.3f collapse4 %.3f \n", t1 - t0, t2 - t1, t3 - t2);
+    }
     out->build_seconds = now_s() - t0;
+    return 0;
+}
+
+/* the 8-wide compressed collapse, built the first time something asks for it (not thread-safe: callers lock) */
+int lh_bvh_ensure_c8(lh_bvh_t *bvh)
+{
+    if (bvh->c8nodes || bvh->ntris == 0) return 0;
+    if (collapse8(bvh) != 0) { free(bvh->c8nodes); free(bvh->tri32_c8); bvh->c8nodes = NULL; bvh->tri32_c8 = NULL; return -1; }
     return 0;
 }
 

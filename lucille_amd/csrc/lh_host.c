@@ -200,7 +200,7 @@ void ri_hipbvh_get_stat_traversal(uint64_t out[5])
 void ri_hipbvh_report_stat_traversal(void)
 {   /* the reference's layout (bvh.c:681-706); leaf visits are not a unit of this kernel
      * (leaves are parked and drained in batches), fp64 re-tests are listed instead */
-    const double nrays = (double)g_stat[3];
+    const double nrays = g_stat[3] ? (double)g_stat[3] : 1.0;     /* no rays traced yet: print zeros, not NaN */
     const double tested = g_stat[1] / nrays, hit = g_stat[4] / nrays;
     printf("== BVH traversal statistiscs ==================================================\n");
     printf("# of rays                    %llu\n", (unsigned long long)g_stat[3]);
@@ -212,7 +212,7 @@ void ri_hipbvh_report_stat_traversal(void)
     printf("  Per ray                    %f\n", g_stat[2] / nrays);
     printf("# of actually hit triangles  %llu\n", (unsigned long long)g_stat[4]);
     printf("  Per ray                    %f\n", hit);
-    printf("  Hit rate                   %f %%\n", 100.0 * (hit / tested));
+    printf("  Hit rate                   %f %%\n", tested > 0.0 ? 100.0 * (hit / tested) : 0.0);
     printf("===============================================================================\n");
 }
 

@@ -959,6 +959,25 @@ int launch_stack(const lh_dev_scene_t &sc, size_t n, const double *org, const do
 
 } /* namespace */
 
+/* the node formats (bit mask: 1 fp32 2-wide, 2 16-bit grid 2-wide, 4 16-bit grid 4-wide, 8 8-wide
+ * compressed) the launch below reads for this scene and variant -- the same decisions, so that
+ * lh_api.hip can upload a format the first time a variant asks for it */
+extern "C" int lh_trace_formats_needed(const lh_dev_scene_t *sc, int variant)
+{
+    int uq = sc->use_qnodes;
+    if (variant == LH_VARIANT_UNIFIED) return 1;
+    if (uq == 3) {
+        if (variant == LH_VARIANT_SPEC) return 8;          /* rays whose stack would overflow go through the reference walk */
+        uq = (variant == LH_VARIANT_UNIFIED4) ? 2 : 1;
+    }
+    if ((variant == LH_VARIANT_SPEC || variant == LH_VARIANT_UNIFIED4) && uq == 2) {
+        if (3 * sc->q4_depth + 5 > 64) return 2;
+        return 4;
+    }
+    if (uq == 0) return 1;
+    return 2;
+}
+
 extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double *d_org,
                                const double *d_dir, uint32_t *d_prim, double *d_t, double *d_u,
                                double *d_v, int anyhit, uint8_t *d_occluded,
