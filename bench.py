@@ -5,19 +5,32 @@
   (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is ONE pass of the hot path (BVH traversal + ray/triangle intersection,
-closest-hit records prim/t/u/v) over one synthetic ray batch that is already
+closest-hit records prim/t/u/v) over one synthetic ray dump that is already
 resident in HBM.  Workload (BASELINE.json config 3, the one the north-star target
 "~1M-tri scene" is quoted on): S-soup-1M = 1,000,000 random triangles
-(SURVEY.md Appendix C generator, seed 88172645463325252), --rays incoherent rays
-per GPU (default 100M).  Weak scaling: every rank traces its own ray batch against
-a replicated BVH; no data-path collective (rays are independent).  Rank 0's batch
-is the canonical Appendix C ray stream; rank r>0 continues from a rank-derived
-xorshift state.
+(SURVEY.md Appendix C generator, seed 88172645463325252) and the canonical dump of
+--rays incoherent rays (default 100 M) that continues the same stream.
 
-One JSON line on rank 0: value = total Mrays/s over all ranks (max-over-ranks
-time), plus `roofline` (algorithmic bytes of the dominant kernel / its HIP-event
-duration vs the 8 TB/s HBM peak) and `cpu_baseline` (the compiled reference, or
-the oracle port, timed on this box's host cores on a bounded sample).
+STRONG scaling: the dump is fixed.  Rank r owns the contiguous slice
+[n r / N, n (r+1) / N) (it jump-aheads the generator to its first ray), traces it against
+its replica of the BVH in a few chunks, and the hit records (prim u32 + t, u, v f64 =
+28 B/ray) are gathered to rank 0 -- the display / dump owner, as in lucille's "every rank
+renders, rank 0 owns the display" design (render.c:468-514) -- chunk by chunk, overlapped
+with the tracing of the next chunk, INSIDE the timed region.  value = n x steps / max-over-
+ranks time.  At N = 1 there is nothing to gather and the dump is one launch.
+
+One JSON line on rank 0, with
+  roofline      the dominant kernel on the headline workload: algorithmic bytes / HIP-event
+                duration vs the 8 TB/s peak.  Its hot set (76 MB) lives in L2 + the 256 MiB
+                Infinity Cache: `residency` says so -- this is NOT an HBM measurement;
+  roofline_hbm  the same kernel on S-soup-10M (0.8 GB hot set, cannot live in the
+                Infinity Cache): the HBM figure (N = 1 only);
+  ao_render     BASELINE config 5 as stated: the AO example scene tessellated to 21.1 M
+                triangles (4.8 GB of trees + triangles), 4096 x 4096, 64 AO samples, tiles sharded
+                over the ranks, frame gathered to rank 0 (strong scaling);
+  pt_render     BASELINE config 4 (plane_sphere, 2048^2, 256 spp);
+  cpu_baseline  the compiled reference / the bit-identical port on this box's host cores.
+Every timed launch is validated in-run (`validation`).
 """
 import argparse
 import ctypes as C
@@ -34,12 +47,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 B_IN, B_OUT, B_TRI = 32, 16, 40   # SURVEY.md 8(d) algorithmic bytes per ray / per triangle test
 B_NODE = {"f32": 64, "q16": 32, "q16x4": 64}   # per node visit: SURVEY's 64-B fp32 2-wide node, 32-B 16-bit grid 2-wide, 64-B 16-bit grid 4-wide
+# check values of the canonical S-soup-1M dump on the UNMODIFIED reference
+SOUP1M_CHECK = {1_000_000: (821_596, 87998.6606), 2_000_000: (1_644_156, 176110.93)}
 
 
-def hip_event_timer():
+def hip_events():
     """HIP events on an explicit stream, straight from libamdhip64 (torch.cuda.Event only
     sees torch's current stream; the kernel is launched on the stream we pass)."""
-    import torch
     hip = C.CDLL("libamdhip64.so")
     hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
     hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
@@ -48,14 +62,48 @@ def hip_event_timer():
     return hip
 
 
-def rank_state(seed_after_tris, rank):
-    if rank == 0:
-        return seed_after_tris
-    x = (seed_after_tris ^ (0x9E3779B97F4A7C15 * (rank + 1))) & 0xFFFFFFFFFFFFFFFF
-    x ^= (x >> 30); x = (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
-    x ^= (x >> 27); x = (x * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
-    x ^= (x >> 31)
-    return x or 1
+class EventPairs:
+    def __init__(self, hip, n):
+        self.hip = hip
+        self.ev = [(C.c_void_p(), C.c_void_p()) for _ in range(n)]
+        for a, b in self.ev:
+            hip.hipEventCreate(C.byref(a)); hip.hipEventCreate(C.byref(b))
+        self.k = 0
+
+    def begin(self, sptr):
+        self.hip.hipEventRecord(self.ev[self.k][0], sptr)
+
+    def end(self, sptr):
+        self.hip.hipEventRecord(self.ev[self.k][1], sptr); self.k += 1
+
+    def ms(self):
+        out = []
+        for a, b in self.ev[:self.k]:
+            v = C.c_float(); self.hip.hipEventElapsedTime(C.byref(v), a, b); out.append(v.value)
+        return out
+
+
+def upload_rays(scenes, torch, dev, state, n, keep_first=0):
+    """n rays of the stream starting at `state` -> HBM (generated on the host in 10 M-ray pieces)"""
+    d_org = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    d_dir = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    chunk = 10_000_000
+    ho = np.empty((min(chunk, max(n, 1)), 3)); hd = np.empty((min(chunk, max(n, 1)), 3))
+    first = None
+    for b in range(0, n, chunk):
+        m = min(chunk, n - b)
+        _, _, state = scenes.soup_rays(m, state, ho, hd)
+        d_org[b:b + m].copy_(torch.from_numpy(ho[:m])); d_dir[b:b + m].copy_(torch.from_numpy(hd[:m]))
+        if b == 0 and keep_first:
+            first = (ho[:min(m, keep_first)].copy(), hd[:min(m, keep_first)].copy())
+    return d_org, d_dir, first
+
+
+def record_views(torch, buf, m):
+    """SoA views (prim i32, t, u, v f64) over one byte buffer of m * 28 bytes: t | u | v | prim"""
+    t = buf[0:8 * m].view(torch.float64); u = buf[8 * m:16 * m].view(torch.float64)
+    v = buf[16 * m:24 * m].view(torch.float64); p = buf[24 * m:28 * m].view(torch.int32)
+    return (p, t, u, v)
 
 
 def main():
@@ -63,13 +111,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rays", type=int, default=100_000_000, help="rays per GPU per step")
+    ap.add_argument("--rays", type=int, default=100_000_000, help="rays of the dump (all GPUs together)")
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--half-extent", type=float, default=0.005)
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--mode", choices=["closest", "any"], default="closest")
+    ap.add_argument("--chunks", type=int, default=4, help="N>1: trace/gather pipeline depth per rank")
     ap.add_argument("--cpu-rays", type=int, default=1_500_000, help="cpu_baseline sample size")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-hbm", action="store_true", help="skip the S-soup-10M HBM-roofline leg")
+    ap.add_argument("--hbm-tris", type=int, default=10_000_000)
+    ap.add_argument("--hbm-rays", type=int, default=50_000_000)
     ap.add_argument("--no-ao", action="store_true", help="skip the secondary AO-frame leg")
     ap.add_argument("--no-pt", action="store_true", help="skip the secondary path-traced leg")
     ap.add_argument("--pt-size", type=int, default=2048)      # BASELINE config 4: 2048 x 2048, 256 spp
@@ -79,15 +131,17 @@ def main():
                     help="testing only: put every rank on this device (2 ranks on a 1-GPU box, use with --backend gloo)")
     ap.add_argument("--ao-size", type=int, default=4096)
     ap.add_argument("--ao-samples", type=int, default=64)
-    ap.add_argument("--ao-tess", type=int, default=7, help="midpoint-subdivision levels of the example scene (4^n x 322 triangles; 7 -> 5.3 M, 8 -> 21 M)")
+    ap.add_argument("--ao-tess", type=int, default=8, help="midpoint-subdivision levels of the example scene (4^n x 322 triangles; 8 -> 21.1 M = BASELINE config 5's '>= 10 M', 7 -> 5.3 M)")
+    ap.add_argument("--only", choices=["hbm", "ao", "pt"], default=None,
+                    help="profiling aid: run one secondary leg (the headline shrinks to a 1 M-ray smoke pass)")
     args = ap.parse_args()
+    if args.only:
+        args.rays = 1_000_000; args.steps = max(1, min(args.steps, 2)); args.no_cpu = True
+        args.no_hbm = args.only != "hbm"; args.no_ao = args.only != "ao"; args.no_pt = args.only != "pt"
 
     import torch
     import lucille_amd as la
-    from lucille_amd import shard
-    # bench needs the synthetic generator, which lives with the checkers; it is used
-    # here only to MAKE inputs and (cpu_baseline leg) to time the CPU path
-    from oracle import pyoracle as po
+    from lucille_amd import scenes, shard
 
     if args.device_override is not None:
         os.environ["LH_DEVICE_OVERRIDE"] = str(args.device_override)
@@ -99,104 +153,111 @@ def main():
         local = args.device_override
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    nccl = world > 1 and torch.distributed.get_backend() == "nccl"
 
-    # ---- synthetic inputs (host) -> HBM -----------------------------------------
-    L = po.lib()
-    st = C.c_uint64(po.SOUP_SEED)
-    P = np.empty((3 * args.tris, 3), np.float64); idx = np.empty(3 * args.tris, np.uint32)
-    L.lo_soup_triangles(C.byref(st), args.tris, args.half_extent, P.ctypes.data_as(C.POINTER(C.c_double)),
-                        idx.ctypes.data_as(C.POINTER(C.c_uint32)))
-    st = C.c_uint64(rank_state(st.value, rank))
-    n = args.rays
-    d_org = torch.empty((n, 3), dtype=torch.float64, device=dev)
-    d_dir = torch.empty((n, 3), dtype=torch.float64, device=dev)
-    chunk = 10_000_000
-    ho = np.empty((min(chunk, n), 3)); hd = np.empty((min(chunk, n), 3))
-    first_org = first_dir = None
-    for b in range(0, n, chunk):
-        m = min(chunk, n - b)
-        L.lo_soup_rays(C.byref(st), m, ho.ctypes.data_as(C.POINTER(C.c_double)), hd.ctypes.data_as(C.POINTER(C.c_double)))
-        d_org[b:b + m].copy_(torch.from_numpy(ho[:m])); d_dir[b:b + m].copy_(torch.from_numpy(hd[:m]))
-        if b == 0:
-            first_org = ho[:min(m, args.cpu_rays)].copy(); first_dir = hd[:min(m, args.cpu_rays)].copy()
+    # ---- synthetic inputs: the scene on every rank, this rank's slice of the dump -> HBM ----
+    P, idx, st_after_tris = scenes.soup_triangles(args.tris, args.half_extent)
+    n_total = args.rays
+    b0, b1 = shard.ray_slice(n_total, rank, world)
+    n = b1 - b0
+    d_org, d_dir, first = upload_rays(scenes, torch, dev, scenes.skip(st_after_tris, 5 * b0), n,
+                                      keep_first=args.cpu_rays if rank == 0 else 0)
 
     acc = la.HipAccel(local)
     acc.add_mesh(P, idx)
     info = acc.commit()
 
     mode = la.MODE_CLOSEST if args.mode == "closest" else la.MODE_ANY
-    out = acc.intersect_device(d_org, d_dir, mode=mode, variant=args.variant)   # allocates outputs (untimed)
+    rec_bytes = 28 if mode == la.MODE_CLOSEST else 1
+
+    # chunks of this rank's slice (N = 1: one launch); record buffers; rank 0's gather destination
+    nchunks = 1 if world == 1 else max(1, args.chunks)
+    per = shard.chunk_capacity(n_total, world, nchunks)     # equal chunk capacity on every rank
+    cb = [(c * per, min(n, (c + 1) * per)) for c in range(nchunks)]
+    bufs = [torch.empty(per * rec_bytes, dtype=torch.uint8, device=dev) for _ in range(nchunks)]
+
+    def outs_of(c):
+        m = cb[c][1] - cb[c][0]
+        return record_views(torch, bufs[c], per)[:4] if mode == la.MODE_CLOSEST else (bufs[c][:per],), max(m, 0)
+
+    gathered = None
+    if world > 1 and rank == 0:
+        gathered = [[torch.empty(per * rec_bytes, dtype=torch.uint8, device=dev if nccl else "cpu") for _ in range(world)]
+                    for _ in range(nchunks)]
+
+    hip = hip_events()
+    stream = torch.cuda.current_stream(dev)
+    sptr = C.c_void_p(stream.cuda_stream)
+    evp = EventPairs(hip, (args.steps + args.warmup + 2) * nchunks)
+
+    def one_step(timed):
+        works = []
+        for c in range(nchunks):
+            (o, m) = outs_of(c)
+            if m > 0:
+                if timed:
+                    evp.begin(sptr)
+                sl = slice(cb[c][0], cb[c][1])
+                full = tuple(x[:m] for x in o)
+                acc.intersect_device(d_org[sl], d_dir[sl], out=full, mode=mode, variant=args.variant)
+                if timed:
+                    evp.end(sptr)
+            if world > 1:
+                works.append(shard.gather_bytes(bufs[c], gathered[c] if rank == 0 else None, async_op=True))
+        for w in works:
+            shard.wait(w)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    one_step(False)                                   # allocations, lazy uploads (untimed)
     torch.cuda.synchronize(dev)
 
     # ---- algorithmic bytes per ray: counted launch on a sample (untimed) ---------
     ns = min(n, 4_000_000)
-    _, cnt = acc.intersect_device(d_org[:ns], d_dir[:ns], mode=mode, variant=args.variant, counters=True)
+    cnt_out, cnt = acc.intersect_device(d_org[:ns], d_dir[:ns], mode=mode, variant=args.variant, counters=True)
     n_nodes = cnt["nodes"] / ns; n_tris = cnt["tris"] / ns
     b_out = B_OUT if mode == la.MODE_CLOSEST else 4
     node_fmt = {"f32": "f32", "q16": "q16"}.get(os.environ.get("LH_NODE_FORMAT", ""), "q16x4")
     b_ray = B_IN + b_out + B_NODE[node_fmt] * n_nodes + B_TRI * n_tris
 
     # ---- timed region -------------------------------------------------------------
-    hip = hip_event_timer()
-    stream = torch.cuda.current_stream(dev)
-    sptr = C.c_void_p(stream.cuda_stream)
-    ev = [(C.c_void_p(), C.c_void_p()) for _ in range(args.steps)]
-    for a, b in ev:
-        hip.hipEventCreate(C.byref(a)); hip.hipEventCreate(C.byref(b))
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-
     for _ in range(args.warmup):
-        acc.intersect_device(d_org, d_dir, out=out, mode=mode, variant=args.variant)
+        one_step(False)
     barrier(); torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        hip.hipEventRecord(ev[k][0], sptr)
-        acc.intersect_device(d_org, d_dir, out=out, mode=mode, variant=args.variant)
-        hip.hipEventRecord(ev[k][1], sptr)
+        one_step(True)
     torch.cuda.synchronize(dev); barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    kms = []
-    for a, b in ev:
-        ms = C.c_float(); hip.hipEventElapsedTime(C.byref(ms), a, b); kms.append(ms.value)
-    kernel_ms = float(np.mean(kms))
+    kms = evp.ms()
+    launches_per_step = sum(1 for c in range(nchunks) if cb[c][1] > cb[c][0])
+    kernel_ms = float(np.sum(kms)) / max(1, args.steps)            # per step, this rank's launches together
 
     if world > 1:
-        rdev = dev if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
+        rdev = dev if nccl else torch.device("cpu")
         tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- context figures (rank 0, untimed for `value`): the box's copy bandwidth and the host path ----
+    # ---- validation of the timed launches (rank 0) --------------------------------
+    validation = None
+    if rank == 0:
+        validation = validate_dump(torch, la, args, mode, outs_of, cb, cnt_out, ns, gathered, world, per, n_total, bufs)
+
+    # ---- context figures (rank 0, N = 1, untimed for `value`) ----------------------
     copy_gbps = host_path = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        big = torch.empty(1 << 30, dtype=torch.uint8, device=dev); dst = torch.empty_like(big)
-        dst.copy_(big); torch.cuda.synchronize(dev)
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            dst.copy_(big)
-        e1.record(); torch.cuda.synchronize(dev)
-        copy_gbps = 10 * 2 * big.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9       # read + write
-        del big, dst
-        nh = min(n, 20_000_000)
-        h_org = np.ascontiguousarray(d_org[:nh].cpu().numpy()); h_dir = np.ascontiguousarray(d_dir[:nh].cpu().numpy())
-        # caller-owned, already-touched result arrays (a fresh allocation would time page faults, not the path)
-        hp = np.zeros(nh, np.uint32); ht = np.zeros(nh); hu = np.zeros(nh); hv = np.zeros(nh)
-        best = None
-        for _ in range(2):
-            th = time.perf_counter()
-            rc = acc.L.lh_accel_intersect_host(acc.h, nh, h_org.ctypes.data, h_dir.ctypes.data, hp.ctypes.data, ht.ctypes.data,
-                                               hu.ctypes.data, hv.ctypes.data, None, 0)
-            th = time.perf_counter() - th
-            assert rc == 0
-            best = th if best is None else min(best, th)
-        host_path = {"value": round(nh / best / 1e6, 1), "unit": "Mrays/s", "link_GBps": round(nh * 76 / best / 1e9, 1),
-                     "sample": "%d rays through lh_accel_intersect_host: pageable host arrays -> pinned staging in 2 M-ray chunks on two "
-                               "streams, 48 B/ray up + 28 B/ray down over PCIe; never the headline value" % nh}
+        copy_gbps = copy_rate(torch, dev)
+        host_path = host_path_leg(acc, d_org, d_dir, n)
+
+    hbm = None
+    if rank == 0 and world == 1 and not args.no_hbm:
+        del d_org, d_dir
+        torch.cuda.empty_cache()
+        hbm = hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt)
 
     ao = None
     if not args.no_ao:
@@ -208,12 +269,11 @@ def main():
         pt = pt_frame_leg(la, acc_device=local, rank=rank, world=world, size=args.pt_size, spp=args.pt_spp, dev=dev)
 
     if rank == 0:
-        total_rays = n * world * args.steps
-        value = total_rays / elapsed / 1e6
+        value = n_total * args.steps / elapsed / 1e6
         achieved = b_ray * n / (kernel_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and world == 1:
             try:
                 j = json.load(open(pmc))
                 if j.get("rays_per_launch") == n and j.get("mode") == args.mode and j.get("kernel_tag") == node_fmt \
@@ -221,29 +281,39 @@ def main():
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        hot_mb = (info["nnodes_traversal"] * 64 + info["ntriangles"] * 48) / 1e6
         res = {
             "metric": "Mrays/s (primary+AO)", "value": round(value, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 filter + f64 resolve (hit records f64)",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32 filter + f64 resolve (hit records f64)",
             "data": "synthetic",
-            "config": {"workload": "S-soup-1M ray dump (BASELINE config 3): %d random triangles, %d incoherent rays per GPU, %s-hit"
-                                   % (args.tris, n, args.mode),
-                       "rays_per_gpu": n, "triangles": args.tris, "mode": args.mode,
-                       "variant": args.variant, "parallelism": "replicated BVH, ray slices x%d" % world,
-                       "bvh": {"nodes": info["nnodes"], "depth": info["max_depth"], "device_bytes": info["device_bytes"],
-                               "build_s": round(info["build_seconds"], 3)}},
+            "config": {"workload": "S-soup-1M ray dump (BASELINE config 3): %d random triangles, one dump of %d incoherent rays cut into %d "
+                                   "contiguous slice(s), %s-hit%s" % (args.tris, n_total, world, args.mode,
+                                                                      "" if world == 1 else ", 28-B hit records gathered to rank 0 inside the timed region"),
+                       "rays": n_total, "rays_per_gpu": n, "triangles": args.tris, "mode": args.mode,
+                       "variant": args.variant, "parallelism": "replicated BVH, ray slices x%d%s" % (world, "" if world == 1 else ", %d-chunk trace/gather pipeline" % nchunks),
+                       "bvh": {"nodes": info["nnodes_traversal"], "depth": info["max_depth"], "device_bytes": info["device_bytes"],
+                               "build_s": round(info["build_seconds"], 3), "ref_tree_build_s": round(info["ref_build_seconds"], 3)}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "residency": "hot set %.0f MB (4-wide nodes + tri32) < 256 MiB Infinity Cache: served by L2 + MALL, "
+                                      "NOT an HBM measurement; see roofline_hbm" % hot_mb,
                          "kernel": "k_trace_persist_lane<walk=spec,%s nodes>" % node_fmt if args.variant in (-1, 4) else "k_trace_v%d" % args.variant,
-                         "node_bytes": B_NODE[node_fmt],
+                         "node_bytes": B_NODE[node_fmt], "launches_per_step": launches_per_step,
                          "kernel_ms": round(kernel_ms, 3), "bytes_per_ray": round(b_ray, 1),
                          "nodes_per_ray": round(n_nodes, 3), "tris_per_ray": round(n_tris, 3)},
+            "validation": validation,
         }
         if copy_gbps is not None:
             # the box's own device-to-device copy rate next to the 8 TB/s datasheet peak
             res["roofline"]["measured_copy_GBps"] = round(copy_gbps, 1)
             res["roofline"]["frac_of_measured_copy"] = round(achieved / copy_gbps, 4)
+        if hbm is not None:
+            if copy_gbps is not None:
+                hbm["measured_copy_GBps"] = round(copy_gbps, 1)
+                hbm["frac_of_measured_copy"] = round(hbm["achieved"] / copy_gbps, 4)
+            res["roofline_hbm"] = hbm
         if host_path is not None:
             res["host_path"] = host_path
         if ao is not None:
@@ -251,20 +321,130 @@ def main():
         if pt is not None:
             res["pt_render"] = pt
         if not args.no_cpu and world == 1:            # rank 0 at N = 1 only (the contract)
-            res["cpu_baseline"] = cpu_baseline(po, P, idx, first_org, first_dir)
+            res["cpu_baseline"] = cpu_baseline(P, idx, first[0], first[1])
         print(json.dumps(res), flush=True)
     acc.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 
 
+def validate_dump(torch, la, args, mode, outs_of, cb, cnt_out, ns, gathered, world, per, n_total, bufs):
+    """the timed launches' own outputs: (1) bit-equal to the counted launch on the sample, (2) hits and
+    sum(t) of the first 1 M / 2 M rays against the reference's check values for the canonical dump,
+    (3) N > 1: the gathered records on rank 0 == the ranks' slices (own slice checked bit for bit,
+    every slice by hit-rate bounds)"""
+    v = {"ok": True}
+    (o, m) = outs_of(0)
+    k = min(ns, m)
+    if mode == la.MODE_CLOSEST:
+        same = all(torch.equal(a[:k], b[:k]) for a, b in zip(o, cnt_out))
+        v["timed_equals_counted_launch"] = bool(same); v["ok"] &= bool(same)
+        canonical = (args.tris == 1_000_000 and abs(args.half_extent - 0.005) < 1e-12 and args.variant in (-1, 4))
+        for nn, (hits, sumt) in SOUP1M_CHECK.items():
+            if canonical and m >= nn:
+                hit = o[0][:nn] != -1
+                h = int(hit.sum().item()); s = float(o[1][:nn][hit].sum().item())
+                good = (h == hits) and abs(s - sumt) < 5e-3
+                v["first_%dM" % (nn // 1_000_000)] = {"hits": h, "sum_t": round(s, 4), "reference_hits": hits, "reference_sum_t": sumt, "ok": good}
+                v["ok"] &= good
+        total_hits = int(sum(int((outs_of(c)[0][0][:outs_of(c)[1]] != -1).sum().item()) for c in range(len(cb))))
+        v["hits_this_rank"] = total_hits
+    else:
+        same = torch.equal(o[0][:k], cnt_out[0][:k])
+        v["timed_equals_counted_launch"] = bool(same); v["ok"] &= bool(same)
+    if world > 1:
+        ok = True
+        for c in range(len(cb)):
+            own = gathered[c][0].to(bufs[c].device)
+            ok &= bool(torch.equal(own, bufs[c]))
+            if mode == la.MODE_CLOSEST:
+                for r in range(world):
+                    p = gathered[c][r][24 * per:28 * per].view(torch.int32)
+                    frac = float((p != -1).float().mean().item())
+                    ok &= (0.5 < frac < 0.99)
+        v["gathered_records_ok"] = ok; v["ok"] &= ok
+    return v
+
+
+def copy_rate(torch, dev):
+    big = torch.empty(1 << 30, dtype=torch.uint8, device=dev); dst = torch.empty_like(big)
+    dst.copy_(big); torch.cuda.synchronize(dev)
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        dst.copy_(big)
+    e1.record(); torch.cuda.synchronize(dev)
+    return 10 * 2 * big.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9       # read + write
+
+
+def host_path_leg(acc, d_org, d_dir, n):
+    nh = min(n, 20_000_000)
+    h_org = np.ascontiguousarray(d_org[:nh].cpu().numpy()); h_dir = np.ascontiguousarray(d_dir[:nh].cpu().numpy())
+    # caller-owned, already-touched result arrays (a fresh allocation would time page faults, not the path)
+    hp = np.zeros(nh, np.uint32); ht = np.zeros(nh); hu = np.zeros(nh); hv = np.zeros(nh)
+    best = None
+    for _ in range(2):
+        th = time.perf_counter()
+        rc = acc.L.lh_accel_intersect_host(acc.h, nh, h_org.ctypes.data, h_dir.ctypes.data, hp.ctypes.data, ht.ctypes.data,
+                                           hu.ctypes.data, hv.ctypes.data, None, 0)
+        th = time.perf_counter() - th
+        assert rc == 0
+        best = th if best is None else min(best, th)
+    return {"value": round(nh / best / 1e6, 1), "unit": "Mrays/s", "link_GBps": round(nh * 76 / best / 1e9, 1),
+            "sample": "%d rays through lh_accel_intersect_host: pageable host arrays -> pinned staging in 2 M-ray chunks on two "
+                      "streams, 48 B/ray up + 28 B/ray down over PCIe; never the headline value" % nh}
+
+
+def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
+    """the HBM roofline: the same closest-hit kernel on S-soup-10M (10 M triangles, half-extent 0.002: the
+    SURVEY's config-5 stress soup).  Hot set = 4-wide nodes + tri32 ~ 0.8 GB >> the 256 MiB Infinity Cache."""
+    P, idx, st = scenes.soup_triangles(args.hbm_tris, 0.002)
+    n = args.hbm_rays
+    d_org, d_dir, _ = upload_rays(scenes, torch, dev, st, n)
+    acc = la.HipAccel(local); acc.add_mesh(P, idx); info = acc.commit()
+    del P, idx
+    out = acc.intersect_device(d_org, d_dir); torch.cuda.synchronize(dev)
+    ns = min(n, 4_000_000)
+    cnt_out, cnt = acc.intersect_device(d_org[:ns], d_dir[:ns], counters=True)
+    n_nodes = cnt["nodes"] / ns; n_tris = cnt["tris"] / ns
+    b_ray = B_IN + B_OUT + B_NODE[node_fmt] * n_nodes + B_TRI * n_tris
+    steps = 3
+    evp = EventPairs(hip, steps)
+    acc.intersect_device(d_org, d_dir, out=out); torch.cuda.synchronize(dev)
+    for _ in range(steps):
+        evp.begin(sptr); acc.intersect_device(d_org, d_dir, out=out); evp.end(sptr)
+    torch.cuda.synchronize(dev)
+    ms = float(np.mean(evp.ms()))
+    ok = all(torch.equal(a[:ns], b) for a, b in zip(out, cnt_out))
+    hit = float((out[0] != -1).float().mean().item())
+    achieved = b_ray * n / (ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest_hbm.json")
+    if os.path.exists(pmc):
+        try:
+            j = json.load(open(pmc))
+            if j.get("rays_per_launch") == n and j.get("triangles") == args.hbm_tris and j.get("kernel_tag") == node_fmt:
+                traffic = j.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    hot = info["nnodes_traversal"] * 64 + info["ntriangles"] * 48
+    acc.close()
+    return {"workload": "S-soup-10M ray dump: %d random triangles (half-extent 0.002), %d incoherent rays, closest-hit" % (args.hbm_tris, n),
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": traffic, "residency": "hot set %.0f MB (4-wide nodes + tri32) >> 256 MiB Infinity Cache: HBM" % (hot / 1e6),
+            "value": round(n / (ms * 1e-3) / 1e6, 1), "value_unit": "Mrays/s", "kernel_ms": round(ms, 3),
+            "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(n_nodes, 3), "tris_per_ray": round(n_tris, 3),
+            "hit_rate": round(hit, 4), "device_bytes": info["device_bytes"],
+            "build_s": round(info["build_seconds"], 3), "ref_tree_build_s": round(info["ref_build_seconds"], 3),
+            "validation": {"timed_equals_counted_launch": bool(ok), "ok": bool(ok) and 0.5 < hit < 0.999}}
+
+
 def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
-    """Secondary leg (BASELINE config 5's shape by default: 4096 x 4096, 64 AO samples, the example scene
-    tessellated to 5.3 M triangles; --ao-size 1024 --ao-tess 0 is config 2): the reference's AO example scene (the 322 triangles
-    its own RIB ingest produced, tests/golden/ao_c1.npz), midpoint-tessellated `tess` times,
-    size x size pixels, `nsamples` AO rays per primary hit, whole pipeline on the device
-    (camera rays, hits, epilogue, AO rays, occlusion, radiance), tiles sharded
-    tile_id % world with one gather of tile slabs to rank 0 (strong scaling: the frame is fixed)."""
+    """Secondary leg = BASELINE config 5 as stated (4096 x 4096, 64 AO samples, the AO example scene -- the
+    322 triangles the reference's own RIB ingest produced, tests/golden/ao_c1.npz -- midpoint-tessellated
+    `tess` = 8 times: 21.1 M triangles >= 10 M); --ao-size 1024 --ao-tess 0 is config 2.  Whole pipeline on
+    the device (camera rays, hits, epilogue, AO rays, occlusion, radiance), tiles sharded over the ranks
+    with one gather of tile slabs to rank 0 (strong scaling: the frame is fixed)."""
     import torch
     from lucille_amd import render, scenes
     g = np.load(os.path.join(ROOT, "tests", "golden", "ao_c1.npz"))
@@ -273,13 +453,13 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
     for k in range(int(g["ngeoms"])):
         P_, I_ = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess)
         acc.add_mesh(P_, I_); ntri += I_.shape[0] // 3
-    acc.commit()
+        del P_, I_
+    info = acc.commit()
     c = g["camera"]
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
-    # one GPU: the whole frame as one tile (HBM holds it: 460 M rays x 49 B = 22 GB at 4096^2 x 64);
-    # sharded: 64 tiles, tile_id % world
+    # one GPU: the whole frame as one tile; sharded: 64 tiles, tile_id % world
     tile = max(64, size // 8) if world > 1 else min(size, 4096)
-    times = []; st = None; img = None
+    times = []; st = None; img = None; stats = []
     for it in range(steps + 1):
         if world > 1:
             torch.distributed.barrier()
@@ -291,21 +471,34 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
         torch.cuda.synchronize(dev)
         if world > 1:
             torch.distributed.barrier()
+        stats.append(dict(st))
         if it > 0:
             times.append(time.perf_counter() - t0)
+    # in-run validation: every timed frame produced the same counts; a differently tiled render of the
+    # same frame (untimed) is bit-equal -- the RNG is keyed by absolute sample position
+    ok = all(s == stats[0] for s in stats)
+    if world == 1:
+        img2, st2 = render.render_ao_frame(acc, cam, 1, nsamples, tile=max(256, size // 4))
+        ok = ok and bool(torch.equal(img, img2)) and st2 == stats[0]
     rdev = dev if (world == 1 or torch.distributed.get_backend() == "nccl") else torch.device("cpu")
     rays = torch.tensor([st["primary_rays"] + st["ao_rays"]], dtype=torch.float64, device=rdev)
     tmax = torch.tensor([min(times)], dtype=torch.float64, device=rdev)
+    okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=rdev)
     if world > 1:
         torch.distributed.all_reduce(rays); torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(okt, op=torch.distributed.ReduceOp.MIN)
     acc.close()
     if rank != 0:
         return None
-    return {"workload": "examples/ambient_occlusion scene tessellated to %d tris, %dx%d, %d AO samples, frame wall incl. ray gen + tile gather"
+    return {"workload": "BASELINE config 5: examples/ambient_occlusion scene tessellated to %d tris, %dx%d, %d AO samples, frame wall incl. ray gen + tile gather"
                         % (ntri, size, size, nsamples), "triangles": ntri, "tile": tile,
+            "device_bytes": info["device_bytes"], "build_s": round(info["build_seconds"], 3),
+            "ref_tree_build_s": round(info["ref_build_seconds"], 3),
             "rays_per_frame": int(rays.item()), "frame_ms": round(tmax.item() * 1e3, 3),
             "value": round(rays.item() / tmax.item() / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
-            "image_mean": float(img.mean().item())}
+            "image_mean": float(img.mean().item()),
+            "validation": {"frames_repeat": bool(okt.item() > 0.5), "retiled_frame_bit_equal": bool(ok) if world == 1 else None,
+                           "primary_hits": int(stats[0]["primary_hits"]) if world == 1 else None, "ok": bool(okt.item() > 0.5)}}
 
 
 def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
@@ -353,12 +546,14 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
             "image_mean": float(img.mean().item())}
 
 
-def cpu_baseline(po, P, idx, org, dr):
+def cpu_baseline(P, idx, org, dr):
     """The reference's CPU path on this box's host cores, bounded sample of the SAME
-    workload (first rays of rank 0's batch).  kind "reference": the compiled reference
+    workload (first rays of the dump).  kind "reference": the compiled reference
     itself (oracle/_ref, scalar double, single thread -- its own threading is a racy
     bucket queue that scales 1.36x on 8 cores); else kind "port": the
-    bit-identical oracle.  Also reports the port on all host cores."""
+    bit-identical oracle.  Also reports the port on all host cores.  The only place bench.py
+    touches oracle/: the checker timed as the CPU baseline."""
+    from oracle import pyoracle as po
     ncores = os.cpu_count() or 1
     out = {}
     if po.ref_available():

@@ -265,6 +265,9 @@ int  lh_hdr_write(const char *path, int width, int height, const float *rgb);
 void lh_synth_soup_triangles(uint64_t *state, uint32_t ntriangles, double half_extent,
                              double *positions_xyz, uint32_t *indices);
 void lh_synth_soup_rays(uint64_t *state, size_t n, double *org_xyz, double *dir_xyz);
+/* advance the stream by ndraws uniforms without producing them (a triangle is 12 draws, a ray 5):
+ * how a rank that owns a slice of a ray dump reaches its first ray */
+void lh_synth_skip(uint64_t *state, uint64_t ndraws);
 void lh_synth_tessellate(const double *tri_in, size_t ntriangles, int levels, double *tri_out);
 
 /* copy of the flattened BVH for cross-checks (tests): sizes via lh_accel_info.

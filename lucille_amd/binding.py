@@ -79,7 +79,7 @@ ABI_SYMBOLS = [
     "lh_accel_trace_statistics", "lh_accel_statistics",
     "lh_render_ao_frame_host", "lh_rib_load", "lh_rib_free", "lh_rib_last_error", "lh_rib_info", "lh_rib_messages",
     "lh_rib_mesh", "lh_accel_add_rib_scene", "lh_hdr_write",
-    "lh_synth_soup_triangles", "lh_synth_soup_rays", "lh_synth_tessellate",
+    "lh_synth_soup_triangles", "lh_synth_soup_rays", "lh_synth_tessellate", "lh_synth_skip",
 ]
 
 _lib = None
@@ -132,6 +132,8 @@ def lib():
     L.lh_synth_soup_triangles.restype = None
     L.lh_synth_soup_rays.argtypes = [C.POINTER(C.c_uint64), sz, vp, vp]
     L.lh_synth_soup_rays.restype = None
+    L.lh_synth_skip.argtypes = [C.POINTER(C.c_uint64), C.c_uint64]
+    L.lh_synth_skip.restype = None
     L.lh_synth_tessellate.argtypes = [vp, sz, i32, vp]
     L.lh_synth_tessellate.restype = None
     _lib = L

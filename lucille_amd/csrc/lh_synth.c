@@ -25,6 +25,40 @@ static inline double xs_next(uint64_t *s)
     return (double)(x >> 11) * (1.0 / 9007199254740992.0);
 }
 
+/* jump-ahead: xorshift64 is linear over GF(2), x_{k+1} = T x_k with T a 64x64 bit matrix, so
+ * `ndraws` steps are one product with T^ndraws (square-and-multiply, columns as uint64 words).  A rank
+ * that owns rays [b, e) of a dump skips 5 b draws instead of generating b rays (ray dumps
+ * are cut into contiguous slices). */
+static uint64_t mat_apply(const uint64_t m[64], uint64_t x)
+{
+    uint64_t y = 0; int j;
+    for (j = 0; j < 64; j++) if ((x >> j) & 1u) y ^= m[j];        /* m[j] = image of basis vector j */
+    return y;
+}
+
+static void mat_mul(uint64_t out[64], const uint64_t a[64], const uint64_t b[64])
+{
+    uint64_t t[64]; int j;
+    for (j = 0; j < 64; j++) t[j] = mat_apply(a, b[j]);           /* (a b) e_j = a (b e_j) */
+    for (j = 0; j < 64; j++) out[j] = t[j];
+}
+
+void lh_synth_skip(uint64_t *state, uint64_t ndraws)
+{
+    uint64_t T[64], R[64]; int j;
+    for (j = 0; j < 64; j++) {
+        uint64_t x = (uint64_t)1 << j;
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        T[j] = x; R[j] = (uint64_t)1 << j;
+    }
+    while (ndraws) {
+        if (ndraws & 1u) mat_mul(R, T, R);
+        mat_mul(T, T, T);
+        ndraws >>= 1;
+    }
+    *state = mat_apply(R, *state);
+}
+
 void lh_synth_soup_triangles(uint64_t *state, uint32_t ntriangles, double half_extent, double *positions_xyz,
                              uint32_t *indices)
 {

@@ -30,6 +30,14 @@ def soup_rays(n, state, org=None, dr=None):
     return org[:n], dr[:n], int(st.value)
 
 
+def skip(state, ndraws):
+    """the stream state after `ndraws` more uniforms (lh_synth_skip; a ray is 5 draws, a triangle 12)"""
+    from . import binding
+    st = C.c_uint64(int(state))
+    binding.lib().lh_synth_skip(C.byref(st), int(ndraws))
+    return int(st.value)
+
+
 def soup(ntriangles, nrays, half_extent, state=SOUP_SEED):
     P, idx, st = soup_triangles(ntriangles, half_extent, state)
     org, dr, _ = soup_rays(nrays, st)

@@ -21,6 +21,13 @@ def ray_slice(n, rank, world):
     return n * rank // world, n * (rank + 1) // world
 
 
+def chunk_capacity(n, world, nchunks):
+    """rays per chunk when every rank cuts its slice of an n-ray dump into nchunks equal-capacity chunks
+    (the largest slice decides; gathers need the same size on every rank)"""
+    largest = -(-n // world)
+    return max(1, -(-largest // nchunks))
+
+
 def tile_grid(width, height, tile):
     """row-major list of (x0, y0, w, h) tiles covering the image (ragged edges kept)"""
     out = []
@@ -42,6 +49,10 @@ def init_process_group(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        # N ranks on one host: each builds its BVH replica with its share of the cores, not all of them
+        # (lh_accel_commit reads LH_BUILD_THREADS when build_threads <= 0)
+        os.environ.setdefault("LH_BUILD_THREADS", str(max(1, (os.cpu_count() or 1) // world)))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -51,3 +62,25 @@ def init_process_group(backend=None):
             torch.cuda.set_device(int(os.environ.get("LH_DEVICE_OVERRIDE", local)))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def gather_bytes(buf, dst_list, async_op=False):
+    """the exchange step: every rank's `buf` (same size everywhere) lands in rank 0's dst_list[r]
+    (None on the other ranks).  RCCL: seven point-to-point transfers into rank 0 (xGMI is a full mesh:
+    they run in parallel, one link each), enqueued behind the work already on the current stream;
+    with async_op the caller keeps tracing the next chunk while this one is on the links.
+    gloo (CPU tests, 2 ranks on one GPU): staged through the host, synchronous.
+    Returns a handle for wait()."""
+    import torch.distributed as dist
+    if dist.get_world_size() == 1:
+        return None
+    if dist.get_backend() == "nccl":
+        return dist.gather(buf, dst_list, dst=0, async_op=async_op)
+    hb = buf.cpu() if buf.is_cuda else buf
+    dist.gather(hb, dst_list, dst=0)
+    return None
+
+
+def wait(work):
+    if work is not None:
+        work.wait()

@@ -87,3 +87,49 @@ def test_tile_gather_world2_gloo(W, H, T):
     for tid, (x0, y0, w_, h_) in enumerate(tiles):
         owner[H - (y0 + h_):H - y0, x0:x0 + w_] = tid % 2
     assert np.array_equal(img[..., 2], owner)
+
+
+def _dump_worker(rank, world, port, n, nchunks, q):
+    """the strong-scaling ray-dump exchange of bench.py on gloo: every rank produces 'hit records' for its
+    slice of one dump (here: a function of the absolute ray id), chunk by chunk, and rank 0 gathers them"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    shard.init_process_group(backend="gloo")
+    assert os.environ["LH_BUILD_THREADS"] == str(max(1, (os.cpu_count() or 1) // world))
+    b0, b1 = shard.ray_slice(n, rank, world)
+    per = shard.chunk_capacity(n, world, nchunks)
+    got = [[torch.zeros(per * 4, dtype=torch.uint8) for _ in range(world)] for _ in range(nchunks)] if rank == 0 else None
+    works = []
+    for c in range(nchunks):
+        lo, hi = b0 + c * per, min(b1, b0 + (c + 1) * per)
+        rec = torch.full((per,), -1, dtype=torch.int32)
+        if hi > lo:
+            rec[:hi - lo] = torch.arange(lo, hi, dtype=torch.int32) * 3 + 1
+        works.append(shard.gather_bytes(rec.view(torch.uint8), got[c] if rank == 0 else None, async_op=True))
+    for w in works:
+        shard.wait(w)
+    if rank == 0:
+        out = np.full(n, -7, np.int64)
+        for r in range(world):
+            rb0, rb1 = shard.ray_slice(n, r, world)
+            for c in range(nchunks):
+                lo, hi = rb0 + c * per, min(rb1, rb0 + (c + 1) * per)
+                if hi > lo:
+                    out[lo:hi] = got[c][r].view(torch.int32).numpy()[:hi - lo]
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,nchunks", [(1000, 4), (1003, 3), (5, 4)])
+def test_ray_dump_gather_world2_gloo(n, nchunks):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dump_worker, args=(r, 2, port, n, nchunks, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(out, np.arange(n) * 3 + 1)
