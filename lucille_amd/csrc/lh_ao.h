@@ -1,0 +1,56 @@
+/*
+ * lh_ao.h -- the ambient-occlusion ray producer, written once for the two places that run it on the
+ * device: k_ao_rays (lh_render.hip: rays materialised in HBM -- the parity-replay path, and what
+ * lh_render_scratch shows) and the refill of the any-hit traversal kernel (lh_trace2.hip: the ray is a
+ * function of (hit slot, sample index) and never touches HBM).
+ *
+ * Reference: calculate_occlusion, src/transport/ambientocclusion.c:42-151 -- origin P + 1e-6 Ns (in the
+ * hit record), for j < nphi, i < ntheta: z0 = (i + xi) / ntheta, z1 = (j + xi') / nphi, cos(theta) =
+ * sqrt(z0), phi = 2 pi z1, local direction (cos phi cos theta, sin phi cos theta, sqrt(1 - cos^2 theta))
+ * taken to world space through the basis rows (tangent, binormal, Ns).
+ *
+ *   replay   (rnd != NULL): xi, xi' supplied by the caller (the reference's MT19937 stream), everything
+ *            in fp64 with the reference's operation order -- the parity path;
+ *   built-in (rnd == NULL): xi, xi' from a counter-based generator keyed by the ABSOLUTE sample position
+ *            (frame pixel, sub-sample, AO index), so a frame does not depend on tiling or sharding; the
+ *            local direction is computed in fp32 with the hardware sin/cos (v_sin_f32 / v_cos_f32 take
+ *            revolutions: exactly z1), then combined with the fp64 basis.  The traced ray IS that fp64
+ *            ray; its occlusion answer has the reference's semantics for it.
+ */
+#ifndef LH_AO_H
+#define LH_AO_H
+
+#include <stdint.h>
+
+/* counter-based uniforms with 32-bit resolution (like randomMT2's y * 2^-32) */
+__device__ __forceinline__ uint32_t lh_mix32(uint64_t x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return (uint32_t)(x >> 16);
+}
+
+/* hit record of one primary hit: AO origin (P + 1e-6 Ns), tangent, binormal, Ns -- 12 doubles */
+#define LH_HITREC_DOUBLES 12
+
+/* built-in generator: AO ray r (= j * ntheta + i) of the hit whose absolute sample key is `key` */
+__device__ __forceinline__ void lh_ao_ray_builtin(const double *__restrict__ h, unsigned long long key, unsigned long long seed,
+                                                  int ntheta, int nphi, int r,
+                                                  double &ox, double &oy, double &oz, double &dx, double &dy, double &dz)
+{
+#pragma clang fp contract(off)
+    const int N = ntheta * nphi;
+    const int i = r % ntheta, j = r / ntheta;
+    const uint64_t k = (seed * 0x9E3779B97F4A7C15ULL) ^ ((key * (uint64_t)N + (uint64_t)r) * 2ull);
+    const float r0 = (float)(lh_mix32(k) >> 8) * 5.9604645e-8f;            /* 24 bits: stays below 1 in fp32 */
+    const float r1 = (float)(lh_mix32(k + 1ull) >> 8) * 5.9604645e-8f;
+    const float z0 = ((float)i + r0) / (float)ntheta;
+    const float z1 = ((float)j + r1) / (float)nphi;
+    const float ct = __builtin_sqrtf(z0), st = __builtin_sqrtf(fmaxf(1.0f - z0, 0.0f));
+    const double d0 = (double)(__builtin_amdgcn_cosf(z1) * ct), d1 = (double)(__builtin_amdgcn_sinf(z1) * ct), d2 = (double)st;
+    ox = h[0]; oy = h[1]; oz = h[2];
+    dx = d0 * h[3] + d1 * h[6] + d2 * h[9];
+    dy = d0 * h[4] + d1 * h[7] + d2 * h[10];
+    dz = d0 * h[5] + d1 * h[8] + d2 * h[11];
+}
+
+#endif

@@ -52,6 +52,7 @@ extern "C" int lh_render_launch_resolve(int w, int h, int xs, int ys, int N, con
                                         void *stream);
 
 struct lh_buf { void *p; size_t cap; };
+#define LH_T2_SLOTS 4
 
 /* the host side of a committed scene: ONE build, any number of device replicas (lh_multi.hip
  * uploads it to every GPU of the node; SURVEY.md 8e "replicated BVH") */
@@ -89,6 +90,9 @@ struct lh_accel {
     uint32_t ray_chunk;                /* rays reserved per cursor atomic (LH_RAY_CHUNK) */
     int tri_batch;
     int default_variant;
+    /* lean walk (lh_trace2.hip): persistent grid + per-stream scratch (spill strips, pending queue) */
+    int t2_grid;
+    struct { hipStream_t stream; int used; int *spill; uint32_t *queue; uint32_t *qcount; } t2[LH_T2_SLOTS];
     /* staging for host batches */
     void *d_stage; size_t stage_bytes;
     /* pipelined host batches: two pinned in/out staging pairs, two device pairs, two streams */
@@ -102,6 +106,7 @@ struct lh_accel {
 };
 
 #define LH_NCURSOR 64
+#define LH_T2_QCAP  (1u << 20)       /* pending any-hit rays per launch (24 B each); beyond: the reference walk */
 
 /* lucille calls accel->intersect from up to 16 render threads at once (render.c:1043-1105): every
  * entry point that touches the accelerator's buffers holds its lock */
@@ -138,7 +143,7 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
         pthread_mutexattr_t at; pthread_mutexattr_init(&at); pthread_mutexattr_settype(&at, PTHREAD_MUTEX_RECURSIVE);
         pthread_mutex_init(&a->mu, &at); pthread_mutexattr_destroy(&at);
     }
-    a->default_variant = LH_VARIANT_SPEC;
+    a->default_variant = LH_VARIANT_LEAN;
     const char *env = getenv("LH_VARIANT");
     if (env) a->default_variant = atoi(env);
     a->min_active = 32;
@@ -230,6 +235,11 @@ static void release_device(lh_accel_t *a)
     a->d_ref_lca = a->d_prim_leafpos = a->d_ref_nodes = a->d_ref_leaf_prims = NULL;
     if (a->d_cursor) (void)hipFree(a->d_cursor);
     if (a->d_counters) (void)hipFree(a->d_counters);
+    for (int k = 0; k < LH_T2_SLOTS; k++) {
+        if (a->t2[k].spill) (void)hipFree(a->t2[k].spill);
+        if (a->t2[k].queue) (void)hipFree(a->t2[k].queue);
+        a->t2[k].spill = NULL; a->t2[k].queue = NULL; a->t2[k].qcount = NULL; a->t2[k].used = 0;
+    }
     if (a->pipe.ready) {
         for (int b = 0; b < 2; b++) {
             (void)hipHostFree(a->pipe.h_in[b]); (void)hipHostFree(a->pipe.h_out[b]);
@@ -430,6 +440,9 @@ static int device_upload(lh_accel_t *a)
         a->grid_blocks = prop.multiProcessorCount * per_cu;
         const char *env = getenv("LH_GRID_BLOCKS");
         if (env && atoi(env) > 0) a->grid_blocks = atoi(env);
+        a->t2_grid = prop.multiProcessorCount * lh_trace2_blocks_per_cu();
+        env = getenv("LH_T2_GRID_BLOCKS");
+        if (env && atoi(env) > 0) a->t2_grid = atoi(env);
     }
     a->committed = 1;
     return 0;
@@ -534,6 +547,31 @@ __global__ void k_fill_miss(size_t n, uint32_t *prim, double *t, double *u, doub
     if (occ) occ[i] = 0;
 }
 
+/* scratch of the lean walk for launches on `s`: launches on one stream are ordered, so they share a slot;
+ * different streams (the two pipeline streams of large host batches) get their own */
+static int t2_slot(lh_accel_t *a, hipStream_t s)
+{
+    int k, free_k = -1;
+    for (k = 0; k < LH_T2_SLOTS; k++) {
+        if (a->t2[k].used && a->t2[k].stream == s) return k;
+        if (!a->t2[k].used && free_k < 0) free_k = k;
+    }
+    if (free_k < 0) {
+        /* more concurrent streams than slots: wait for the device, then recycle slot 0 */
+        HIPCHK(hipDeviceSynchronize());
+        free_k = 0;
+    }
+    k = free_k;
+    if (!a->t2[k].spill) {
+        const size_t lanes = (size_t)a->t2_grid * LH_BLOCK;
+        HIPCHK(hipMalloc((void **)&a->t2[k].spill, lanes * 64 * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&a->t2[k].queue, (size_t)LH_T2_QCAP * 6 * sizeof(uint32_t) + 2 * sizeof(uint32_t)));
+        a->t2[k].qcount = a->t2[k].queue + (size_t)LH_T2_QCAP * 6;
+    }
+    a->t2[k].stream = s; a->t2[k].used = 1;
+    return k;
+}
+
 static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, void *d_prim,
                   void *d_t, void *d_u, void *d_v, void *d_occ, int mode, int variant,
                   unsigned long long *d_counters, hipStream_t s)
@@ -555,7 +593,22 @@ static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
         return 0;
     }
     if (variant == LH_VARIANT_DEFAULT) variant = a->default_variant;
-    if (variant < 0 || variant > LH_VARIANT_UNIFIED4) return fail("intersect: unknown variant %d", variant);
+    if (variant < 0 || variant > LH_VARIANT_LEAN) return fail("intersect: unknown variant %d", variant);
+    if (variant == LH_VARIANT_LEAN) {
+        /* the lean walk reads the 4-wide 16-bit-grid nodes; scenes it cannot take (another format forced by
+         * LH_NODE_FORMAT, a tree too deep for its 64-entry logical stack) go through the r01 walk */
+        if (a->dev.use_qnodes != 2 || 3 * a->dev.q4_depth + 5 > 64) variant = LH_VARIANT_SPEC;
+        else {
+            int k = t2_slot(a, s);
+            if (k < 0) return -1;
+            int rc = lh_launch_trace2(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim, (double *)d_t,
+                                      (double *)d_u, (double *)d_v, mode == LH_MODE_ANY, (uint8_t *)d_occ, d_counters,
+                                      a->d_cursor + (a->cursor_next++ % LH_NCURSOR), a->t2_grid, a->min_active, a->tri_batch,
+                                      a->t2[k].spill, a->t2[k].queue, a->t2[k].qcount, LH_T2_QCAP, (void *)s);
+            if (rc != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+            return 0;
+        }
+    }
     if (ensure_formats(a, lh_trace_formats_needed(&a->dev, variant)) != 0) return -1;     /* A/B formats: uploaded on first use */
     int rc = lh_launch_trace(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim,
                              (double *)d_t, (double *)d_u, (double *)d_v, mode == LH_MODE_ANY,

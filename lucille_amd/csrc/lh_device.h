@@ -55,8 +55,14 @@ enum {
     LH_VARIANT_PERSIST_LANE = 2,  /* persistent waves, ballot-compacted refill */
     LH_VARIANT_UNIFIED      = 3,  /* + single-loop walk: one record per lane per iteration */
     LH_VARIANT_SPEC         = 4,  /* + speculative walk, leaves parked and tested in batches */
-    LH_VARIANT_UNIFIED4     = 5   /* single-loop walk over the 4-wide nodes: one record per lane per iteration */
+    LH_VARIANT_UNIFIED4     = 5,  /* single-loop walk over the 4-wide nodes: one record per lane per iteration */
+    LH_VARIANT_LEAN         = 6   /* lh_trace2.hip: the speculative 4-wide walk without fp64 state, 16-row LDS ring
+                                     stack, candidates resolved by a separate fp64 pass */
 };
+
+#define LH_T2_ROWS        16           /* LDS ring rows per lane of the lean walk */
+#define LH_PRIM_PENDING   0xFFFFFFF0u  /* | candidate count: the slot holds unresolved candidates (not a valid id: ids < 2^29) */
+#define LH_OCC_PENDING    3u           /* any-hit: the ray waits in the pending queue */
 
 #ifdef __cplusplus
 extern "C" {
@@ -69,6 +75,19 @@ int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double *d_org,
                     unsigned long long *d_counters /* LH_CNT_N or NULL */,
                     unsigned long long *d_workq /* persistent cursor */,
                     int variant, int grid_blocks, int min_active, int tri_batch, void *stream);
+
+/* launchers implemented in lh_trace2.hip */
+int lh_trace2_blocks_per_cu(void);
+int lh_launch_trace2(const lh_dev_scene_t *sc, size_t n, const double *d_org, const double *d_dir,
+                     uint32_t *d_prim, double *d_t, double *d_u, double *d_v, int anyhit, uint8_t *d_occluded,
+                     unsigned long long *d_counters, unsigned long long *d_cursor, int grid_blocks,
+                     int min_active, int tri_batch, int *d_spill, uint32_t *d_queue, uint32_t *d_qcount,
+                     uint32_t qcap, void *stream);
+int lh_launch_trace2_ao(const lh_dev_scene_t *sc, size_t nslots, int ntheta, int nphi, unsigned long long seed,
+                        const double *d_hitrec, const unsigned long long *d_slot_key, unsigned int *d_occ_count,
+                        unsigned long long *d_counters, unsigned long long *d_cursor, int grid_blocks,
+                        int min_active, int tri_batch, int *d_spill, uint32_t *d_queue, uint32_t *d_qcount,
+                        uint32_t qcap, void *stream);
 
 #ifdef __cplusplus
 }

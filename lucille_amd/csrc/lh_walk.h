@@ -1,0 +1,136 @@
+/*
+ * lh_walk.h -- device-side pieces shared by the traversal kernels (lh_kernels.hip: the r01 walks kept
+ * for A/B; lh_trace2.hip: the lean walk + resolve pass): the exact-hit record, the reference's tie
+ * rule, the fp64 resolve of one candidate, the per-lane walk state and the 16-bit-grid slab test.
+ * Device code only (included inside the including file's anonymous namespace).
+ */
+#ifndef LH_WALK_H
+#define LH_WALK_H
+
+constexpr int   kDone  = (int)0x80000000; /* stack-bottom sentinel == LH_REF_EMPTY */
+constexpr int   kPend  = 4;
+
+struct Best {            /* exact (fp64) closest hit so far */
+    double   t, u, v;
+    uint32_t prim;
+    uint32_t frag;       /* bit 0: this hit is within rounding reach of a box face of the reference's tree
+                          * (lh_hit_fragile); bit 1 (sticky): two different triangles at almost equal t */
+};
+
+/* The reference's winner between two primitives hit at bit-equal t (lh_refbvh.c):
+ * same leaf -> the later triangle (bvh.c:780 rejects only t > t_best); different leaves ->
+ * the leaf the reference visits first (bvh.c:850 strict <), i.e. the one under
+ * child[dir_sign[axis0]] of their lowest common ancestor (bvh.c:1080,1171-1178). */
+__device__ __noinline__ bool tie_takes_new(const lh_dev_scene_t &sc, uint32_t pnew, uint32_t pold,
+                                           double dx, double dy, double dz)
+{
+    if (!sc.ref_lca) return pnew > pold;          /* no reference-order tree: documented fallback */
+    const uint2 *lp = (const uint2 *)sc.prim_leafpos;
+    const int4 *nd = (const int4 *)sc.ref_lca;
+    const uint2 a = lp[pnew], b = lp[pold];
+    if (a.x == b.x) return a.y > b.y;
+    int ca = (int)a.x, cb = (int)b.x;
+    int4 na = nd[ca], nb = nd[cb];
+    while (na.y > nb.y) { ca = na.x; na = nd[ca]; }
+    while (nb.y > na.y) { cb = nb.x; nb = nd[cb]; }
+    while (na.x != nb.x) { ca = na.x; na = nd[ca]; cb = nb.x; nb = nd[cb]; }
+    const int4 l = nd[na.x];
+    const int order = (l.z == 0 ? dx : (l.z == 1 ? dy : dz)) < 0.0 ? 1 : 0;
+    const int first_child = order == 0 ? l.w : l.w + 1;     /* children are allocated adjacently */
+    return first_child == ca;
+}
+
+/* resolve one queued candidate against the running exact best */
+__device__ __forceinline__ void resolve(const lh_dev_scene_t &sc, uint32_t prim,
+                                        double ox, double oy, double oz,
+                                        double dx, double dy, double dz, Best &b)
+{
+    double t, u, v;
+    const double *tv = (const double *)sc.tri64 + 9 * (size_t)prim;
+    if (lh_exact_isect(tv, ox, oy, oz, dx, dy, dz, &t, &u, &v)) {
+        bool take = t < b.t;
+        if (!take && t == b.t && b.prim != LH_MISS_PRIM && prim != b.prim) take = tie_takes_new(sc, prim, b.prim, dx, dy, dz);
+        /* almost-equal t of two triangles: which one the reference keeps can hinge on one box test */
+        if (b.prim != LH_MISS_PRIM && prim != b.prim && t != b.t && fabs(t - b.t) <= LH_FRAGILE_REL * fabs(t)) b.frag |= 2u;
+        if (take && t < LH_T_INF) {
+            b.t = t; b.u = u; b.v = v; b.prim = prim;
+            b.frag = (b.frag & 2u) | (uint32_t)lh_hit_fragile(tv, ox, oy, oz, dx, dy, dz, t);
+        }
+    }
+}
+
+struct Lane {
+    lh_ray32_t r;          /* fp32 ray + slab/filter constants */
+    uint32_t sh[3];        /* 16 where the direction is negative: rotate lo|hi<<16 into (near, far) */
+    float tb;              /* culling bound (fp32, rounded up) */
+    int   cur, sp;         /* traversal cursor, stack pointer  */
+    uint32_t p0, p1, p2, p3;   /* pending fp64 candidates      */
+    int   np;
+    bool  certain;         /* any-hit: a certain fp32 hit was found */
+    bool  over;            /* 8-wide walk: the LDS stack would overflow; the ray goes to the reference walk */
+};
+
+__device__ __forceinline__ void lane_init(Lane &L, const lh_dev_scene_t &sc,
+                                          double ox, double oy, double oz,
+                                          double dx, double dy, double dz)
+{
+    lh_ray_setup(&L.r, ox, oy, oz, dx, dy, dz, sc.scene_r);
+    if (sc.use_qnodes) lh_ray_setup_grid(&L.r, sc.grid_lo, sc.grid_step, sc.scene_r);
+    L.sh[0] = L.r.ngx ? 16u : 0u; L.sh[1] = L.r.ngy ? 16u : 0u; L.sh[2] = L.r.ngz ? 16u : 0u;
+    L.tb = 1.0e38f;
+    L.cur = 0; L.sp = 1;
+    L.p0 = L.p1 = L.p2 = L.p3 = LH_MISS_PRIM; L.np = 0;
+    L.certain = false; L.over = false;
+}
+
+/* lh_slab_w (lh_filter.h) written for the VALU: per axis one rotate (v_alignbit_b32 by 0 or 16)
+ * puts (near, far) into the (low, high) halves, two SDWA converts, two FMAs: 136 VALU ops per
+ * 4-wide node step instead of 161 with per-plane selects.  Measured (A/B, 50 M rays): +1.5 %;
+ * v_pk_fma_f32 for the two FMAs is 2 % SLOWER, reading the stack top before the slab tests
+ * instead of after the pushes changes nothing -- the step is not VALU- or LDS-latency-bound
+ * (profiles/README.md, r01d). */
+__device__ __forceinline__ bool slab_w(const Lane &L, uint32_t wx, uint32_t wy, uint32_t wz, float &tn_out)
+{
+    const uint32_t sx = __builtin_amdgcn_alignbit(wx, wx, L.sh[0]);
+    const uint32_t sy = __builtin_amdgcn_alignbit(wy, wy, L.sh[1]);
+    const uint32_t sz = __builtin_amdgcn_alignbit(wz, wz, L.sh[2]);
+    const float tn = fmaxf(fmaxf(fmaf((float)(sx & 0xffffu), L.r.qax, L.r.qbnx), fmaf((float)(sy & 0xffffu), L.r.qay, L.r.qbny)),
+                           fmaxf(fmaf((float)(sz & 0xffffu), L.r.qaz, L.r.qbnz), 0.0f));
+    const float tf = fminf(fminf(fmaf((float)(sx >> 16), L.r.qax, L.r.qbfx), fmaf((float)(sy >> 16), L.r.qay, L.r.qbfy)),
+                           fminf(fmaf((float)(sz >> 16), L.r.qaz, L.r.qbfz), L.tb));
+    tn_out = tn;
+    return tn <= tf;
+}
+
+/* one triangle record through the fp32 filter (lh_tri_filter): the bookkeeping every walk shares.
+ * Rejected: nothing.  Certain hit: ends an any-hit ray at once, shrinks the closest-hit culling bound.
+ * Anything not rejected joins the pending list (resolved in fp64 now if the list is full).
+ * Returns true when the ray is finished (any-hit only). */
+template <bool ANYHIT, bool COUNT>
+__device__ __forceinline__ bool tri_step(Lane &L, const lh_dev_scene_t &sc, float v0x, float v0y, float v0z,
+                                         float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
+                                         float ne1, float ne2, uint32_t prim,
+                                         double ox, double oy, double oz, double dx, double dy, double dz,
+                                         Best &best, uint32_t &c_exact)
+{
+    float t_hi;
+    const int cls = lh_tri_filter(&L.r, v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, ne1, ne2, L.tb, &t_hi);
+    if (cls == LH_TRI_REJECT) return false;
+    const bool sure = (cls == LH_TRI_CERTAIN);
+    if (ANYHIT && sure) { L.certain = true; return true; }
+    if (sure) L.tb = fminf(L.tb, t_hi);
+    if (L.np == kPend) {
+        /* pending list full: resolve it now (rare) */
+        if (COUNT) c_exact += kPend;
+        resolve(sc, L.p0, ox, oy, oz, dx, dy, dz, best);
+        resolve(sc, L.p1, ox, oy, oz, dx, dy, dz, best);
+        resolve(sc, L.p2, ox, oy, oz, dx, dy, dz, best);
+        resolve(sc, L.p3, ox, oy, oz, dx, dy, dz, best);
+        L.np = 0;
+        if (ANYHIT && best.prim != LH_MISS_PRIM) return true;
+    }
+    L.p3 = L.p2; L.p2 = L.p1; L.p1 = L.p0; L.p0 = prim; L.np++;
+    return false;
+}
+
+#endif

@@ -47,8 +47,21 @@ def test_window_ray_dumps_bit_exact(c5):
     middle of the 4096^2 frame (silhouettes + floor + background) against the oracle"""
     import torch
     acc, o, cam = c5["acc"], c5["oracle"], c5["cam"]
-    x0, y0, w, h = 1900, 1630, 160, 96
+    w, h = 160, 96
     N = 64
+    # a window that straddles a silhouette: scan the frame's middle rows at coarse steps for mixed hit / miss
+    x0 = y0 = None
+    for yy in range(1024, 3072, 256):
+        for xx in range(512, 3584, 160):
+            po_, pd_ = acc.primary_rays(cam, xx, yy, w, h, 1)
+            pr = acc.intersect_device(po_, pd_)[0]
+            frac = float((pr != -1).float().mean().item())
+            if 0.3 < frac < 0.8:
+                x0, y0 = xx, yy
+                break
+        if x0 is not None:
+            break
+    assert x0 is not None, "no window with a silhouette found"
     rng = np.random.default_rng(11)
     uni = torch.from_numpy(rng.random(2 * N * w * h)).cuda()
     rgb, st = acc.render_ao_tile(cam, x0, y0, w, h, 1, NS, uniforms=uni)

@@ -11,7 +11,7 @@ from tests.helpers import Model, assert_hits_equal, grid_mesh, load_golden, rand
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [la.VARIANT_DIRECT, la.VARIANT_PERSIST_WAVE, la.VARIANT_PERSIST_LANE, la.VARIANT_UNIFIED, la.VARIANT_SPEC, la.VARIANT_UNIFIED4]
+VARIANTS = [la.VARIANT_DIRECT, la.VARIANT_PERSIST_WAVE, la.VARIANT_PERSIST_LANE, la.VARIANT_UNIFIED, la.VARIANT_SPEC, la.VARIANT_UNIFIED4, la.VARIANT_LEAN]
 
 
 def torch_rays(org, dr):

@@ -21,5 +21,7 @@ for LEG in $LEGS; do
     [ -n "$F" ] && { head -1 $F > $OUT/$P.csv; grep -E "k_trace|k_ref_retrace|k_ao|k_pt|k_primary|k_resolve" $F >> $OUT/$P.csv; rm -rf $OUT/$P; }
   done
   K=$(ls $OUT/trace/*/*kernel_stats.csv 2>/dev/null | head -1)
+  T=$(ls $OUT/trace/*/*kernel_trace.csv 2>/dev/null | head -1)
+  [ -n "$T" ] && { head -1 $T > $OUT/kernel_trace_rayquery.csv; grep -E "k_trace|k_resolve" $T >> $OUT/kernel_trace_rayquery.csv; }
   [ -n "$K" ] && { cp $K $OUT/kernel_stats.csv; rm -rf $OUT/trace; }
 done
