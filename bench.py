@@ -277,7 +277,7 @@ def main():
             try:
                 j = json.load(open(pmc))
                 if j.get("rays_per_launch") == n and j.get("mode") == args.mode and j.get("kernel_tag") == node_fmt \
-                        and args.variant in (-1, 6):
+                        and args.variant in (-1, 4):
                     traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -299,7 +299,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "residency": "hot set %.0f MB (4-wide nodes + tri32) < 256 MiB Infinity Cache: served by L2 + MALL, "
                                       "NOT an HBM measurement; see roofline_hbm" % hot_mb,
-                         "kernel": ("k_trace2<closest, ray arrays> (+ k_resolve2, k_ref_retrace2 inside the timed launch)" if args.variant in (-1, 6) and node_fmt == "q16x4"
+                         "kernel": ("k_trace2<closest, ray arrays> (+ k_resolve2, k_ref_retrace2 inside the timed launch)" if args.variant == 6 and node_fmt == "q16x4"
                                     else "k_trace_persist_lane<walk=spec,%s nodes>" % node_fmt if args.variant in (-1, 4) else "k_trace_v%d" % args.variant),
                          "node_bytes": B_NODE[node_fmt], "launches_per_step": launches_per_step,
                          "kernel_ms": round(kernel_ms, 3), "bytes_per_ray": round(b_ray, 1),

@@ -123,6 +123,8 @@ int  lh_accel_statistics(lh_accel_t *accel, uint64_t counters[5], int clear);
 
 /* number of persistent workgroups the persistent variants launch */
 int  lh_accel_set_grid(lh_accel_t *accel, int blocks);
+/* tuning knobs by name (sweeps): "grid", "t2_grid", "min_active", "tri_batch", "ray_chunk", "variant" */
+int  lh_accel_set_param(lh_accel_t *accel, const char *name, int value);
 
 /* ---- tile rendering: the callers on either side of the query, on the device ----
  * reference: subsample / render_bucket / bucket_write (src/render/render.c:715-823,

@@ -74,7 +74,7 @@ ABI_SYMBOLS = [
     "lh_device_count", "lh_last_error", "lh_accel_create", "lh_accel_add_mesh", "lh_accel_commit",
     "lh_accel_destroy", "lh_accel_info", "lh_accel_prim_lookup", "lh_accel_intersect1",
     "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted",
-    "lh_accel_set_grid", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
+    "lh_accel_set_grid", "lh_accel_set_param", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
     "lh_render_ao_tile", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device", "lh_render_pt_tile",
     "lh_accel_trace_statistics", "lh_accel_statistics",
     "lh_render_ao_frame_host", "lh_rib_load", "lh_rib_free", "lh_rib_last_error", "lh_rib_info", "lh_rib_messages",
@@ -116,6 +116,7 @@ def lib():
     L.lh_accel_intersect_device_counted.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, i32,
                                                     C.POINTER(C.c_uint64)]
     L.lh_accel_set_grid.argtypes = [vp, i32]
+    L.lh_accel_set_param.argtypes = [vp, C.c_char_p, i32]
     L.lh_accel_trace_statistics.argtypes = [vp, i32]
     L.lh_accel_statistics.argtypes = [vp, C.POINTER(C.c_uint64), i32]
     L.lh_accel_export.argtypes = [vp, vp, vp]
@@ -229,6 +230,9 @@ class HipAccel:
         m, i = C.c_uint32(), C.c_uint32()
         _check(self.L.lh_accel_prim_lookup(self.h, int(prim), C.byref(m), C.byref(i)), "lh_accel_prim_lookup")
         return int(m.value), int(i.value)
+
+    def set_param(self, name, value):
+        _check(self.L.lh_accel_set_param(self.h, name.encode(), int(value)), "lh_accel_set_param")
 
     def set_grid(self, blocks):
         _check(self.L.lh_accel_set_grid(self.h, int(blocks)), "lh_accel_set_grid")

@@ -13,9 +13,9 @@
  *            in fp64 with the reference's operation order -- the parity path;
  *   built-in (rnd == NULL): xi, xi' from a counter-based generator keyed by the ABSOLUTE sample position
  *            (frame pixel, sub-sample, AO index), so a frame does not depend on tiling or sharding; the
- *            local direction is computed in fp32 with the hardware sin/cos (v_sin_f32 / v_cos_f32 take
- *            revolutions: exactly z1), then combined with the fp64 basis.  The traced ray IS that fp64
- *            ray; its occlusion answer has the reference's semantics for it.
+ *            local direction is computed in fp32 (sincospif: phi = 2 pi z1 needs no argument reduction), then
+ *            combined with the fp64 basis.  The traced ray IS that fp64 ray; its occlusion answer has the
+ *            reference's semantics for it.
  */
 #ifndef LH_AO_H
 #define LH_AO_H
@@ -46,7 +46,9 @@ __device__ __forceinline__ void lh_ao_ray_builtin(const double *__restrict__ h, 
     const float z0 = ((float)i + r0) / (float)ntheta;
     const float z1 = ((float)j + r1) / (float)nphi;
     const float ct = __builtin_sqrtf(z0), st = __builtin_sqrtf(fmaxf(1.0f - z0, 0.0f));
-    const double d0 = (double)(__builtin_amdgcn_cosf(z1) * ct), d1 = (double)(__builtin_amdgcn_sinf(z1) * ct), d2 = (double)st;
+    float sphi, cphi;
+    sincospif(2.0f * z1, &sphi, &cphi);                /* phi = 2 pi z1: no argument reduction beyond the exact 2 z1 */
+    const double d0 = (double)(cphi * ct), d1 = (double)(sphi * ct), d2 = (double)st;
     ox = h[0]; oy = h[1]; oz = h[2];
     dx = d0 * h[3] + d1 * h[6] + d2 * h[9];
     dy = d0 * h[4] + d1 * h[7] + d2 * h[10];

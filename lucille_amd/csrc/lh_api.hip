@@ -48,8 +48,8 @@ extern "C" int lh_render_launch_ao_rays(size_t nslots, int ntheta, int nphi, uns
                                         const double *d_hitrec, const double *d_rnd,
                                         const unsigned long long *d_slot_key, double *d_org, double *d_dir, void *stream);
 extern "C" int lh_render_launch_resolve(int w, int h, int xs, int ys, int N, const uint32_t *d_slot_of_sample,
-                                        const uint8_t *d_occ, float *d_rgb, unsigned long long *d_occ_total,
-                                        void *stream);
+                                        const uint8_t *d_occ, const unsigned int *d_occ_count, float *d_rgb,
+                                        unsigned long long *d_occ_total, void *stream);
 
 struct lh_buf { void *p; size_t cap; };
 #define LH_T2_SLOTS 4
@@ -99,7 +99,8 @@ struct lh_accel {
     struct { void *h_in[2], *h_out[2], *d_in[2], *d_out[2]; hipStream_t s[2]; hipEvent_t done[2]; size_t cap; int ready; } pipe;
     void *d_nrm9;                      /* hs->nrm9 on the device */
     /* tile-render scratch (lh_render_ao_tile) */
-    lh_buf r_org, r_dir, r_prim, r_t, r_u, r_v, r_slot, r_hitrec, r_aorg, r_adir, r_occ, r_blocks, r_key, r_frame;
+    lh_buf r_org, r_dir, r_prim, r_t, r_u, r_v, r_slot, r_hitrec, r_aorg, r_adir, r_occ, r_blocks, r_key, r_frame, r_occcount;
+    int ao_fused;                      /* AO rays generated inside the any-hit kernel (default); 0: materialised in HBM */
     lh_buf p_org2, p_dir2, p_path, p_path2, p_thr, p_thr2, p_rad, p_alive;   /* path tracer */
     unsigned long long *d_total;
     size_t r_nsamples, r_nslots, r_nao;
@@ -143,7 +144,9 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
         pthread_mutexattr_t at; pthread_mutexattr_init(&at); pthread_mutexattr_settype(&at, PTHREAD_MUTEX_RECURSIVE);
         pthread_mutex_init(&a->mu, &at); pthread_mutexattr_destroy(&at);
     }
-    a->default_variant = LH_VARIANT_LEAN;
+    a->default_variant = LH_VARIANT_SPEC;
+    a->ao_fused = 1;
+    { const char *e = getenv("LH_AO_FUSED"); if (e) a->ao_fused = atoi(e) != 0; }
     const char *env = getenv("LH_VARIANT");
     if (env) a->default_variant = atoi(env);
     a->min_active = 32;
@@ -212,7 +215,7 @@ static void free_buf(lh_buf *b) { if (b->p) (void)hipFree(b->p); b->p = NULL; b-
 static void release_device(lh_accel_t *a)
 {
     lh_buf *bufs[] = {&a->r_org, &a->r_dir, &a->r_prim, &a->r_t, &a->r_u, &a->r_v, &a->r_slot, &a->r_hitrec,
-                      &a->r_aorg, &a->r_adir, &a->r_occ, &a->r_blocks, &a->r_key, &a->r_frame,
+                      &a->r_aorg, &a->r_adir, &a->r_occ, &a->r_blocks, &a->r_key, &a->r_frame, &a->r_occcount,
                       &a->p_org2, &a->p_dir2, &a->p_path, &a->p_path2, &a->p_thr, &a->p_thr2, &a->p_rad, &a->p_alive};
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) free_buf(bufs[i]);
     if (a->d_total) (void)hipFree(a->d_total);
@@ -527,6 +530,34 @@ extern "C" int lh_accel_set_grid(lh_accel_t *a, int blocks)
     return 0;
 }
 
+/* tuning knobs of the traversal kernels (A/B sweeps, tools/): "grid" / "t2_grid" persistent workgroups of the
+ * r01 / lean walk, "min_active" regroup threshold, "tri_batch" parked leaves per triangle pass, "ray_chunk"
+ * rays per cursor atomic, "variant" default kernel variant */
+extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
+{
+    lh_guard guard(a);
+    if (!a || !name) return fail("lh_accel_set_param: NULL argument");
+    if (!strcmp(name, "grid") && value > 0) a->grid_blocks = value;
+    else if (!strcmp(name, "t2_grid") && value > 0) {
+        if (value > a->t2_grid) {            /* spill strips are sized by the grid: drop them, they are re-made */
+            HIPCHK(hipSetDevice(a->device)); HIPCHK(hipDeviceSynchronize());
+            for (int k = 0; k < LH_T2_SLOTS; k++) {
+                if (a->t2[k].spill) (void)hipFree(a->t2[k].spill);
+                if (a->t2[k].queue) (void)hipFree(a->t2[k].queue);
+                a->t2[k].spill = NULL; a->t2[k].queue = NULL; a->t2[k].qcount = NULL; a->t2[k].used = 0;
+            }
+        }
+        a->t2_grid = value;
+    }
+    else if (!strcmp(name, "min_active") && value > 0 && value <= 64) a->min_active = value;
+    else if (!strcmp(name, "tri_batch") && value > 0 && value <= 64) a->tri_batch = value;
+    else if (!strcmp(name, "ray_chunk") && value > 0 && value <= (1 << 20)) { a->ray_chunk = (uint32_t)value; a->dev.ray_chunk = (uint32_t)value; }
+    else if (!strcmp(name, "variant") && value >= 0 && value <= LH_VARIANT_LEAN) a->default_variant = value;
+    else if (!strcmp(name, "ao_fused")) a->ao_fused = value != 0;
+    else return fail("lh_accel_set_param: unknown parameter or bad value: %s = %d", name, value);
+    return 0;
+}
+
 extern "C" int lh_accel_export(const lh_accel_t *a, void *nodes, void *tri32)
 {
     if (!a || !a->committed) return fail("lh_accel_export: accel not committed");
@@ -549,7 +580,7 @@ __global__ void k_fill_miss(size_t n, uint32_t *prim, double *t, double *u, doub
 
 /* scratch of the lean walk for launches on `s`: launches on one stream are ordered, so they share a slot;
  * different streams (the two pipeline streams of large host batches) get their own */
-static int t2_slot(lh_accel_t *a, hipStream_t s)
+static int t2_slot(lh_accel_t *a, hipStream_t s, bool need_spill)
 {
     int k, free_k = -1;
     for (k = 0; k < LH_T2_SLOTS; k++) {
@@ -562,9 +593,11 @@ static int t2_slot(lh_accel_t *a, hipStream_t s)
         free_k = 0;
     }
     k = free_k;
-    if (!a->t2[k].spill) {
+    if (need_spill && !a->t2[k].spill) {
         const size_t lanes = (size_t)a->t2_grid * LH_BLOCK;
         HIPCHK(hipMalloc((void **)&a->t2[k].spill, lanes * 64 * sizeof(int)));
+    }
+    if (!a->t2[k].queue) {
         HIPCHK(hipMalloc((void **)&a->t2[k].queue, (size_t)LH_T2_QCAP * 6 * sizeof(uint32_t) + 2 * sizeof(uint32_t)));
         a->t2[k].qcount = a->t2[k].queue + (size_t)LH_T2_QCAP * 6;
     }
@@ -599,7 +632,7 @@ static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
          * LH_NODE_FORMAT, a tree too deep for its 64-entry logical stack) go through the r01 walk */
         if (a->dev.use_qnodes != 2 || 3 * a->dev.q4_depth + 5 > 64) variant = LH_VARIANT_SPEC;
         else {
-            int k = t2_slot(a, s);
+            int k = t2_slot(a, s, true);
             if (k < 0) return -1;
             int rc = lh_launch_trace2(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim, (double *)d_t,
                                       (double *)d_u, (double *)d_v, mode == LH_MODE_ANY, (uint8_t *)d_occ, d_counters,
@@ -905,7 +938,33 @@ extern "C" int lh_render_ao_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
     }
     const size_t nao = (size_t)nhit * N;
     unsigned long long nocc = 0;
-    if (nao) {
+    /* AO stage.  Fused (default): the any-hit kernel generates ray (slot, r) in its refill (lh_ao.h) and counts
+     * the occluded rays per slot -- nothing per AO ray goes through HBM.  Materialised: caller uniforms (the parity
+     * replay), LH_AO_FUSED=0, a scene the lean walk cannot take, or a pending-queue overflow of the fused launch. */
+    bool fused = a->ao_fused && !d_uniforms && nao && nao < ((size_t)1 << 32) && a->dev.use_qnodes == 2 && 3 * a->dev.q4_depth + 5 <= 64;
+    if (fused) {
+        if (ensure_buf(&a->r_occcount, (size_t)nhit * sizeof(unsigned int))) return -1;
+        const int k = t2_slot(a, s, a->default_variant == LH_VARIANT_LEAN);
+        if (k < 0) return -1;
+        int rcf;
+        if (a->default_variant == LH_VARIANT_LEAN)      /* A/B: the lean walk's AO source (its pending queue fills up on large tiles) */
+            rcf = lh_launch_trace2_ao(&a->dev, (size_t)nhit, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const unsigned long long *)a->r_key.p,
+                                      (unsigned int *)a->r_occcount.p, NULL, a->d_cursor + (a->cursor_next++ % LH_NCURSOR), a->t2_grid,
+                                      a->min_active, a->tri_batch, a->t2[k].spill, a->t2[k].queue, a->t2[k].qcount, LH_T2_QCAP, (void *)s);
+        else {
+            rcf = lh_launch_trace_ao(&a->dev, (size_t)nhit, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const unsigned long long *)a->r_key.p,
+                                     (unsigned int *)a->r_occcount.p, NULL, a->d_cursor + (a->cursor_next++ % LH_NCURSOR), a->grid_blocks,
+                                     a->min_active, a->tri_batch, a->t2[k].queue, a->t2[k].qcount, LH_T2_QCAP, (void *)s);
+            if (rcf == 0) rcf = lh_launch_ao_queue(&a->dev, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const unsigned long long *)a->r_key.p,
+                                                   (unsigned int *)a->r_occcount.p, NULL, a->t2[k].queue, a->t2[k].qcount, LH_T2_QCAP, (void *)s);
+        }
+        if (rcf != 0) return fail("fused AO launch failed: %s", hipGetErrorString(hipGetLastError()));
+        uint32_t qc[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(qc, a->t2[k].qcount, sizeof(qc), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (qc[1] != 0) fused = false;             /* more than LH_T2_QCAP uncertain AO rays: redo the stage materialised */
+    }
+    if (nao && !fused) {
         if (ensure_buf(&a->r_aorg, nao * 24) || ensure_buf(&a->r_adir, nao * 24) || ensure_buf(&a->r_occ, nao)) return -1;
         /* 4. AO rays */
         if (lh_render_launch_ao_rays(nhit, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const double *)d_uniforms,
@@ -918,10 +977,11 @@ extern "C" int lh_render_ao_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
     /* 6. radiance */
     HIPCHK(hipMemsetAsync(a->d_total, 0, sizeof(unsigned long long), s));
     if (lh_render_launch_resolve(w, h, ps, ps, N, (const uint32_t *)a->r_slot.p, (const uint8_t *)a->r_occ.p,
-                                 (float *)d_rgb, a->d_total, s) != 0) return fail("resolve kernel launch failed");
+                                 fused ? (const unsigned int *)a->r_occcount.p : NULL, (float *)d_rgb, a->d_total, s) != 0)
+        return fail("resolve kernel launch failed");
     HIPCHK(hipMemcpyAsync(&nocc, a->d_total, sizeof(nocc), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    a->r_nsamples = S; a->r_nslots = (size_t)nhit; a->r_nao = nao;
+    a->r_nsamples = S; a->r_nslots = (size_t)nhit; a->r_nao = fused ? 0 : nao;
     if (stats) {
         stats->primary_rays = S; stats->primary_hits = nhit; stats->ao_rays = nao; stats->ao_occluded = nocc;
     }

@@ -76,6 +76,14 @@ int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double *d_org,
                     unsigned long long *d_workq /* persistent cursor */,
                     int variant, int grid_blocks, int min_active, int tri_batch, void *stream);
 
+int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int ntheta, int nphi, unsigned long long seed,
+                       const double *d_hitrec, const unsigned long long *d_slot_key, unsigned int *d_occ_count,
+                       unsigned long long *d_counters, unsigned long long *d_cursor, int grid_blocks, int min_active,
+                       int tri_batch, uint32_t *d_queue, uint32_t *d_qcount, uint32_t qcap, void *stream);
+int lh_launch_ao_queue(const lh_dev_scene_t *sc, int ntheta, int nphi, unsigned long long seed,
+                       const double *d_hitrec, const unsigned long long *d_slot_key, unsigned int *d_occ_count,
+                       unsigned long long *d_counters, uint32_t *d_queue, uint32_t *d_qcount, uint32_t qcap, void *stream);
+
 /* launchers implemented in lh_trace2.hip */
 int lh_trace2_blocks_per_cu(void);
 int lh_launch_trace2(const lh_dev_scene_t *sc, size_t n, const double *d_org, const double *d_dir,

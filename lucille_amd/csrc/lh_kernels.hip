@@ -42,6 +42,7 @@
 #include "lh_device.h"
 #include "lh_filter.h"
 #include "lh_reftrace.h"
+#include "lh_ao.h"
 
 namespace {
 
@@ -571,12 +572,23 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_wave(
 /* ------------------------------------------------------------------------ */
 /* variant 2: persistent wavefronts with ballot-compacted lane refill       */
 /* ------------------------------------------------------------------------ */
-template <bool ANYHIT, bool COUNT, int WALK, bool QN>
+/* SRC 0: rays from the fp64 org/dir arrays.  SRC 1 (any-hit, WALK 3): the work items are the ambient-occlusion
+ * rays of a tile -- item i = (hit slot i / N, sample i % N) -- generated in the refill by lh_ao.h from the hit
+ * record; an occluded ray adds one to its slot's counter, nothing per ray goes through HBM (round 1 wrote and
+ * re-read 49 bytes per AO ray: 22 GB per 4096^2 x 64 frame).  A fragile hit (lh_reftrace.h; rare) is queued for
+ * the reference's own walk. */
+struct AoSrc {
+    const double *hitrec; const unsigned long long *slot_key; unsigned int *occ_count;
+    unsigned long long seed; int ntheta, nphi;
+    uint32_t *queue, *qcount; uint32_t qcap;
+};
+
+template <bool ANYHIT, bool COUNT, int WALK, bool QN, int SRC>
 __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
     lh_dev_scene_t sc, size_t n, const double *__restrict__ org, const double *__restrict__ dir,
     uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
     double *__restrict__ v, uint8_t *__restrict__ occ, unsigned long long *counters,
-    unsigned long long *cursor, int min_active, int tri_batch)
+    unsigned long long *cursor, int min_active, int tri_batch, const AoSrc ao)
 {
     extern __shared__ int lh_stack_lds[];          /* [stack entries][LH_BLOCK], sized at launch */
     int (*stk)[LH_BLOCK] = (int (*)[LH_BLOCK])lh_stack_lds;
@@ -598,7 +610,16 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         if (idle) {
             if (my != (size_t)-1) {
                 finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
-                write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL);
+                if (SRC == 0) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL);
+                else {
+                    const bool hit = L.certain || best.prim != LH_MISS_PRIM;
+                    const bool retrace = sc.ref_nodes != NULL && (L.over || (best.prim != LH_MISS_PRIM && best.frag != 0u && !L.certain));
+                    if (retrace) {
+                        const uint32_t k = atomicAdd(ao.qcount, 1u);
+                        if (k < ao.qcap) { ao.queue[6 * (size_t)k] = (uint32_t)my; ao.queue[6 * (size_t)k + 1] = 5u; }   /* 5: the reference walk decides */
+                        else atomicOr(ao.qcount + 1, 1u);
+                    } else if (hit) atomicAdd(&ao.occ_count[(uint32_t)my / (uint32_t)(ao.ntheta * ao.nphi)], 1u);
+                }
                 if (COUNT) cr++;
                 my = (size_t)-1;
             }
@@ -621,8 +642,14 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
             if (idle && rank < take) {
                 const size_t i = wbase + rank;
                 my = i;
-                ox = org[3 * i]; oy = org[3 * i + 1]; oz = org[3 * i + 2];
-                dx = dir[3 * i]; dy = dir[3 * i + 1]; dz = dir[3 * i + 2];
+                if (SRC == 0) {
+                    ox = org[3 * i]; oy = org[3 * i + 1]; oz = org[3 * i + 2];
+                    dx = dir[3 * i]; dy = dir[3 * i + 1]; dz = dir[3 * i + 2];
+                } else {
+                    const uint32_t N = (uint32_t)(ao.ntheta * ao.nphi), slot = (uint32_t)i / N;
+                    lh_ao_ray_builtin(ao.hitrec + LH_HITREC_DOUBLES * (size_t)slot, ao.slot_key[slot], ao.seed, ao.ntheta, ao.nphi,
+                                      (int)((uint32_t)i - slot * N), ox, oy, oz, dx, dy, dz);
+                }
                 lane_init(L, sc, ox, oy, oz, dx, dy, dz);
                 best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM; best.frag = 0u;
                 stk[0][tid] = kDone;
@@ -693,23 +720,23 @@ int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const doub
             hipLaunchKernelGGL((k_trace_persist_wave<ANYHIT, COUNT, QN>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor);
         else if (variant == LH_VARIANT_PERSIST_LANE)
-            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 0, QN>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 0, QN, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
         else if (variant == LH_VARIANT_UNIFIED)
-            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 1, false>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 1, false, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
         else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 3)
-            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 5, true>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 5, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
         else if (variant == LH_VARIANT_UNIFIED4 && sc.use_qnodes == 2)
-            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 4, true>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 4, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
         else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2)
-            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 3, true>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 3, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
         else
-            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 2, QN>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch);
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 2, QN, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -740,6 +767,48 @@ int launch_stack(const lh_dev_scene_t &sc, size_t n, const double *org, const do
 }
 
 } /* namespace */
+
+/* the AO stage of a tile with the rays generated inside the any-hit kernel (SRC 1 above): nslots primary hits,
+ * N = ntheta * nphi rays each, occluded rays counted per slot in d_occ_count (zeroed here).  Fragile hits go to
+ * d_queue (6 words per entry, count + overflow flag in d_qcount[0..1]); lh_launch_ao_queue (lh_trace2.hip) runs
+ * the reference walk for them.  Needs the 4-wide nodes (use_qnodes == 2) and a tree the LDS stack holds. */
+extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int ntheta, int nphi, unsigned long long seed,
+                                  const double *d_hitrec, const unsigned long long *d_slot_key, unsigned int *d_occ_count,
+                                  unsigned long long *d_counters, unsigned long long *d_cursor, int grid_blocks, int min_active,
+                                  int tri_batch, uint32_t *d_queue, uint32_t *d_qcount, uint32_t qcap, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = nslots * (size_t)(ntheta * nphi);
+    if (n == 0) return 0;
+    if (n >= ((size_t)1 << 32) || sc->use_qnodes != 2) return -1;
+    lh_dev_scene_t scl = *sc;
+    uint32_t need = 3 * sc->q4_depth + 5;
+    if (need > 64) return -1;
+    need = (need + 1u) & ~1u;
+    if (need < 16) need = 16;
+    scl.stack_rows = need;
+    const size_t lds_bytes = (size_t)need * LH_BLOCK * sizeof(int);
+    {
+        const size_t waves = (size_t)(grid_blocks > 0 ? grid_blocks : 1) * (LH_BLOCK / 64);
+        size_t c = n / (waves * 4);
+        if (c < 64) c = 64;
+        if (c < scl.ray_chunk) scl.ray_chunk = (uint32_t)c;
+        if (scl.ray_chunk == 0) scl.ray_chunk = 64;
+    }
+    AoSrc ao = {d_hitrec, d_slot_key, d_occ_count, seed, ntheta, nphi, d_queue, d_qcount, qcap};
+    if (hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), s) != hipSuccess) return -1;
+    if (hipMemsetAsync(d_qcount, 0, 2 * sizeof(uint32_t), s) != hipSuccess) return -1;
+    if (hipMemsetAsync(d_occ_count, 0, sizeof(unsigned int) * nslots, s) != hipSuccess) return -1;
+    if (d_counters)
+        hipLaunchKernelGGL((k_trace_persist_lane<true, true, 3, true, 1>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                           scl, n, (const double *)NULL, (const double *)NULL, (uint32_t *)NULL, (double *)NULL, (double *)NULL,
+                           (double *)NULL, (uint8_t *)NULL, d_counters, d_cursor, min_active, tri_batch, ao);
+    else
+        hipLaunchKernelGGL((k_trace_persist_lane<true, false, 3, true, 1>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                           scl, n, (const double *)NULL, (const double *)NULL, (uint32_t *)NULL, (double *)NULL, (double *)NULL,
+                           (double *)NULL, (uint8_t *)NULL, d_counters, d_cursor, min_active, tri_batch, ao);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 /* the node formats (bit mask: 1 fp32 2-wide, 2 16-bit grid 2-wide, 4 16-bit grid 4-wide, 8 8-wide
  * compressed) the launch below reads for this scene and variant -- the same decisions, so that

@@ -30,6 +30,7 @@
 
 #include "../../include/lucille_hip.h"
 #include "lh_device.h"
+#include "lh_ao.h"
 
 namespace {
 
@@ -197,14 +198,13 @@ __global__ void k_ao_setup(size_t n, const lh_dev_scene_t sc, const double *__re
     for (int k = 0; k < 3; k++) { r[k] = P[k] + Ns[k] * eps; r[3 + k] = b0[k]; r[6 + k] = b1[k]; r[9 + k] = Ns[k]; }
 }
 
-/* counter-based uniforms in [0,1) with 32-bit resolution (like randomMT2's y*2^-32) */
-__device__ __forceinline__ uint32_t mix32(uint64_t x)
-{
-    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
-    return (uint32_t)(x >> 16);
-}
+/* counter-based uniforms in [0,1) with 32-bit resolution (like randomMT2's y*2^-32): lh_ao.h */
+__device__ __forceinline__ uint32_t mix32(uint64_t x) { return lh_mix32(x); }
 
-/* one thread per AO ray: ray id = slot*N + (j*ntheta + i) (calculate_occlusion's loop order) */
+/* one thread per AO ray: ray id = slot*N + (j*ntheta + i) (calculate_occlusion's loop order).
+ * rnd != NULL: the caller's uniforms (2 per ray), fp64 throughout -- the parity replay of the reference's
+ * MT19937 stream.  rnd == NULL: the built-in generator of lh_ao.h -- bit for bit the rays the any-hit kernel
+ * generates in its refill when the tile runs fused (this kernel is then only used to show them). */
 __global__ void k_ao_rays(size_t nslots, int ntheta, int nphi, unsigned long long seed,
                           const double *__restrict__ hitrec, const double *__restrict__ rnd /* 2 per ray or NULL */,
                           const unsigned long long *__restrict__ slot_key, double *__restrict__ org, double *__restrict__ dir)
@@ -214,21 +214,22 @@ __global__ void k_ao_rays(size_t nslots, int ntheta, int nphi, unsigned long lon
     const int N = ntheta * nphi;
     if (id >= nslots * (size_t)N) return;
     const size_t slot = id / N; const int r = (int)(id % N);
-    const int i = r % ntheta, j = r / ntheta;
-    double r0, r1;
-    if (rnd) { r0 = rnd[2 * id]; r1 = rnd[2 * id + 1]; }
-    else {
-        const uint64_t key = (seed * 0x9E3779B97F4A7C15ULL) ^ ((slot_key[slot] * (uint64_t)N + (uint64_t)r) * 2ull);
-        r0 = (double)mix32(key) * 2.3283064365386963e-10;
-        r1 = (double)mix32(key + 1ull) * 2.3283064365386963e-10;
+    const double *h = hitrec + 12 * slot;
+    if (!rnd) {
+        double ox, oy, oz, dx, dy, dz;
+        lh_ao_ray_builtin(h, slot_key[slot], seed, ntheta, nphi, r, ox, oy, oz, dx, dy, dz);
+        org[3 * id] = ox; org[3 * id + 1] = oy; org[3 * id + 2] = oz;
+        dir[3 * id] = dx; dir[3 * id + 1] = dy; dir[3 * id + 2] = dz;
+        return;
     }
+    const int i = r % ntheta, j = r / ntheta;
+    const double r0 = rnd[2 * id], r1 = rnd[2 * id + 1];
     const double z0 = ((double)(uint32_t)i + r0) / (double)(uint32_t)ntheta;
     const double z1 = ((double)(uint32_t)j + r1) / (double)(uint32_t)nphi;
     const double cos_theta = sqrt(z0), phi = 2.0 * 3.14159265358979323846 * z1;
     double sp, cp;
     sincos(phi, &sp, &cp);
     const double d0 = cp * cos_theta, d1 = sp * cos_theta, d2 = sqrt(1.0 - cos_theta * cos_theta);
-    const double *h = hitrec + 12 * slot;
     for (int k = 0; k < 3; k++) {
         org[3 * id + k] = h[k];
         dir[3 * id + k] = d0 * h[3 + k] + d1 * h[6 + k] + d2 * h[9 + k];
@@ -238,8 +239,8 @@ __global__ void k_ao_rays(size_t nslots, int ntheta, int nphi, unsigned long lon
 /* one thread per pixel: accumulates its sub-samples exactly like subsample()
  * (render.c:749-822) and bucket_write (:962-975): rgb[(h-1-ly)*w + lx] */
 __global__ void k_ao_resolve(int w, int h, int xs, int ys, int N, const uint32_t *__restrict__ slot_of_sample,
-                             const uint8_t *__restrict__ occ, float *__restrict__ rgb,
-                             unsigned long long *__restrict__ occ_total)
+                             const uint8_t *__restrict__ occ, const unsigned int *__restrict__ occ_count,
+                             float *__restrict__ rgb, unsigned long long *__restrict__ occ_total)
 {
     LH_NC
     const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -253,8 +254,13 @@ __global__ void k_ao_resolve(int w, int h, int xs, int ys, int N, const uint32_t
         double rad = 0.0;
         if (slot != LH_MISS_PRIM) {
             double occlusion = 0.0;
-            const uint8_t *o = occ + (size_t)slot * N;
-            for (int r = 0; r < N; r++) if (o[r]) { occlusion += 1.0; nocc++; }
+            if (occ_count) {                       /* fused AO stage: occluded rays were counted per slot */
+                const unsigned int c = occ_count[slot];
+                occlusion = (double)c; nocc += c;
+            } else {
+                const uint8_t *o = occ + (size_t)slot * N;
+                for (int r = 0; r < N; r++) if (o[r]) { occlusion += 1.0; nocc++; }
+            }
             const double ns = (double)(uint32_t)N;
             rad = 1.0 * (ns - occlusion) / ns;
         }
@@ -466,13 +472,13 @@ extern "C" int lh_render_launch_ao_rays(size_t nslots, int ntheta, int nphi, uns
 }
 
 extern "C" int lh_render_launch_resolve(int w, int h, int xs, int ys, int N, const uint32_t *d_slot_of_sample,
-                                        const uint8_t *d_occ, float *d_rgb, unsigned long long *d_occ_total,
-                                        void *stream)
+                                        const uint8_t *d_occ, const unsigned int *d_occ_count, float *d_rgb,
+                                        unsigned long long *d_occ_total, void *stream)
 {
     const size_t total = (size_t)w * h;
     if (total == 0) return 0;
     hipLaunchKernelGGL(k_ao_resolve, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       w, h, xs, ys, N, d_slot_of_sample, d_occ, d_rgb, d_occ_total);
+                       w, h, xs, ys, N, d_slot_of_sample, d_occ, d_occ_count, d_rgb, d_occ_total);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -422,6 +422,20 @@ extern "C" int lh_launch_trace2(const lh_dev_scene_t *sc, size_t n, const double
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+/* the queued AO rays of lh_launch_trace_ao (lh_kernels.hip): regenerated, decided by the reference walk,
+ * added to their slot's count */
+extern "C" int lh_launch_ao_queue(const lh_dev_scene_t *sc, int ntheta, int nphi, unsigned long long seed,
+                                  const double *d_hitrec, const unsigned long long *d_slot_key, unsigned int *d_occ_count,
+                                  unsigned long long *d_counters, uint32_t *d_queue, uint32_t *d_qcount, uint32_t qcap, void *stream)
+{
+    T2Args a;
+    memset(&a, 0, sizeof(a));
+    a.counters = d_counters; a.queue = d_queue; a.qcount = d_qcount; a.qcap = qcap;
+    a.hitrec = d_hitrec; a.slot_key = d_slot_key; a.occ_count = d_occ_count; a.seed = seed; a.ntheta = ntheta; a.nphi = nphi;
+    hipLaunchKernelGGL((k_resolve_queue<SRC_AO>), dim3(64), dim3(256), 0, (hipStream_t)stream, *sc, a);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 /* the AO stage of a tile with the rays generated inside the any-hit kernel: nslots primary hits (hit
  * records + absolute sample keys), N = ntheta * nphi rays each, occlusion counted per slot in
  * d_occ_count (zeroed here).  d_qcount[1] != 0 afterwards: the pending queue overflowed and the caller

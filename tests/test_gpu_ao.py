@@ -195,3 +195,29 @@ def test_whole_frame_builtin_rng_statistics(c1):
     # tiled == untiled (the RNG is keyed by absolute sample position, not by tile)
     img2, _ = render.render_ao_frame(acc, cam, 1, 16, tile=64)
     assert np.array_equal(img, img2.cpu().numpy())
+
+
+def test_fused_ao_stage_equals_materialised_rays(c1, ps):
+    """the AO stage with rays generated inside the any-hit kernel (default) == the same stage with the rays
+    written to HBM first: same generator (lh_ao.h), same frame bit for bit, same counts; and the materialised
+    rays' occlusion equals the oracle's answer for them"""
+    import torch
+    for case, pxs in ((c1, 1), (ps, 2)):
+        acc, cam, o = case["acc"], case["cam"], case["oracle"]
+        W, H = cam.width, cam.height
+        acc.set_param("ao_fused", 1)
+        img_f, st_f = acc.render_ao_tile(cam, 0, 0, W, H, pxs, 16, seed=5)
+        assert acc.scratch(8, np.float64, 3).shape[0] == 0               # nothing was materialised
+        acc.set_param("ao_fused", 0)
+        img_m, st_m = acc.render_ao_tile(cam, 0, 0, W, H, pxs, 16, seed=5)
+        aorg = acc.scratch(8, np.float64, 3); adir = acc.scratch(9, np.float64, 3); occ = acc.scratch(10, np.uint8, 1)
+        acc.set_param("ao_fused", 1)
+        torch.cuda.synchronize()
+        assert st_f == st_m and st_f["ao_rays"] == aorg.shape[0] > 0
+        assert torch.equal(img_f, img_m)
+        exp = o.intersect(aorg, adir, nthreads=8)
+        assert np.array_equal(occ.astype(bool), exp[0] != po.MISS)
+        assert st_f["ao_occluded"] == int((exp[0] != po.MISS).sum())
+        if case is c1:                                                    # flat-shaded scene: orthonormal basis
+            n = np.linalg.norm(adir, axis=1)
+            assert np.all(np.abs(n - 1.0) < 1e-6)                         # fp32 trigonometry, fp64 basis
