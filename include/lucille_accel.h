@@ -45,6 +45,12 @@ typedef struct _ri_geom_t {
     ri_vector_t  *normals;     unsigned int nnormals;
     unsigned int *indices;     unsigned int nindices;
     int           two_side;
+    ri_vector_t  *tangents;    unsigned int ntangents;      /* geom.h:34-39: looked at only next to normals */
+    ri_vector_t  *binormals;   unsigned int nbinormals;
+    ri_vector_t  *colors;      unsigned int ncolors;        /* vertex colour (Cs) */
+    ri_float_t   *texcoords;                                /* st per vertex (geom.h:42-48) */
+    ri_float_t   *texcoords_unshared;                       /* st per index */
+    unsigned int  ntexcoords;
 } ri_geom_t;
 
 ri_geom_t *ri_geom_new(void);
@@ -52,6 +58,11 @@ void       ri_geom_free(ri_geom_t *geom);
 void       ri_geom_add_positions(ri_geom_t *geom, unsigned int npositions, const ri_vector_t *positions);
 void       ri_geom_add_normals(ri_geom_t *geom, unsigned int nnormals, const ri_vector_t *normals);
 void       ri_geom_add_indices(ri_geom_t *geom, unsigned int nindices, const unsigned int *indices);
+void       ri_geom_add_tangents(ri_geom_t *geom, unsigned int ntangents, const ri_vector_t *tangents);
+void       ri_geom_add_binormals(ri_geom_t *geom, unsigned int nbinormals, const ri_vector_t *binormals);
+void       ri_geom_add_colors(ri_geom_t *geom, unsigned int ncolors, const ri_vector_t *colors);
+void       ri_geom_add_texcoords(ri_geom_t *geom, unsigned int ntexcoords, const ri_float_t *texcoords);
+void       ri_geom_add_texcoords_unshared(ri_geom_t *geom, unsigned int ntexcoords, const ri_float_t *texcoords);
 
 /* ---- ray / hit state (ray.h:22-68, intersection_state.h:34-61) --------- */
 typedef struct _ri_ray_t {

@@ -32,6 +32,7 @@ extern "C" {
 #define LH_VARIANT_DEFAULT (-1)
 
 typedef struct lh_accel lh_accel_t;  /* opaque: host BVH + device SoA copies  */
+typedef struct lh_rib_scene lh_rib_scene_t;   /* a parsed RIB (below)         */
 
 typedef struct lh_accel_info {
     uint32_t ntriangles;
@@ -183,6 +184,69 @@ int  lh_render_pt_tile(lh_accel_t *accel, const lh_camera_t *cam, int x0, int y0
                        float kd, const float env_rgb[3], uint64_t seed, void *d_rgb,
                        lh_pt_stats_t *stats, void *stream);
 
+/* ---- path tracer with the reference's three reflection types (src/transport/pathtrace.c:189-314,407-537) ----
+ * Per-mesh material = ri_material_t (src/render/material.h:21-30; defaults of ri_material_new: kd 1, ks 0, kt 0,
+ * ior 1): diffuse / specular / transmission reflectances (their averages d, s, t drive the Russian roulette and the
+ * choice of reflection type: d + s + t <= 1) and the index of refraction.  Environment = the light source of
+ * light_sample / ri_texture_ibl_fetch (src/render/texture.c:238-276): an angular-map light probe (RGBA float rows,
+ * bilinear), scaled by rgb; map NULL: the constant radiance rgb. */
+typedef struct lh_material { float kd[3], ks[3], kt[3]; float ior; } lh_material_t;
+typedef struct lh_environment { float rgb[3]; const float *map_rgba; int width, height; } lh_environment_t;
+#define LH_ALL_MESHES 0xFFFFFFFFu
+#define LH_PT_REFERENCE_WEIGHTS 1     /* throughput *= the reference's brdf() value (kd / pi, ks, kt) instead of the
+                                         unbiased weight of the same sampling scheme */
+int  lh_accel_set_material(lh_accel_t *accel, uint32_t mesh /* or LH_ALL_MESHES */, const lh_material_t *material);
+int  lh_accel_set_environment(lh_accel_t *accel, const lh_environment_t *environment);   /* after commit; the map is copied */
+/* as lh_render_pt_tile, with the accelerator's materials and environment */
+int  lh_render_pt_tile2(lh_accel_t *accel, const lh_camera_t *cam, int x0, int y0, int w, int h,
+                        int spp_begin, int spp_count, int spp_total, int max_path_vertices, int flags,
+                        uint64_t seed, void *d_rgb, lh_pt_stats_t *stats, void *stream);
+
+/* ---- the whole hit epilogue: ri_intersection_state_build (src/render/intersection_state.c:99-248) ----
+ * Optional per-vertex attributes of mesh `mesh`, before commit (geom.h:34-48): colours, tangents, binormals
+ * (xyz, `count` = vertices), texture coordinates (s, t per vertex) or texcoords_unshared (s, t per INDEX: `count` =
+ * indices).  lh_accel_state_build_*: for n rays and their hit records, LH_STATE_DOUBLES per ray --
+ * P[3] Ng[3] Ns[3] tangent[3] binormal[3] color[3] st[2] I[3] inside -- in the reference's operation order (fp64,
+ * no contraction); records of misses are left as they are (device) / zero (host). */
+#define LH_ATTR_COLOR 0
+#define LH_ATTR_TANGENT 1
+#define LH_ATTR_BINORMAL 2
+#define LH_ATTR_TEXCOORD 3
+#define LH_ATTR_TEXCOORD_UNSHARED 4
+#define LH_STATE_DOUBLES 24
+int  lh_accel_set_attribute(lh_accel_t *accel, uint32_t mesh, int kind, const double *data, size_t stride_bytes, uint32_t count);
+int  lh_accel_state_build_device(lh_accel_t *accel, size_t n, const void *d_org_xyz, const void *d_dir_xyz, const void *d_prim,
+                                 const void *d_t, const void *d_u, const void *d_v, void *d_state, void *stream);
+int  lh_accel_state_build_host(lh_accel_t *accel, size_t n, const double *org_xyz, const double *dir_xyz, const uint32_t *prim,
+                               const double *t, const double *u, const double *v, double *state);
+
+/* ---- the G GPUs of one node from ONE process ----
+ * reference role: the bucket queue drained by render threads (src/render/render.c:1043-1207) and the compiled-out MPI
+ * design "every rank renders, rank 0 owns the display" (render.c:468-514, src/base/parallel.c:62-232).  One host build,
+ * replicated to every device; frames: a dynamic queue of tiles, one host thread per device, finished tile slabs copied
+ * device-to-device (hipMemcpyPeerAsync, one xGMI link per peer) to device 0 = the display owner, which places them
+ * (bucket_write's row order) and delivers the frame; ray dumps: contiguous slices.  `devices` may list a device more
+ * than once (replicas on one GPU: how the sharded path is tested on a one-GPU box); NULL: devices 0 .. n-1
+ * (ndevices <= 0: all).  device_seconds (ndevices doubles, may be NULL): busy time of each replica's tile loop. */
+typedef struct lh_multi lh_multi_t;
+int  lh_multi_create(lh_multi_t **out, int ndevices, const int *devices);
+void lh_multi_destroy(lh_multi_t *multi);
+int  lh_multi_ndevices(const lh_multi_t *multi);
+lh_accel_t *lh_multi_accel(lh_multi_t *multi, int replica);          /* borrowed: queries on one replica */
+int  lh_multi_add_mesh(lh_multi_t *multi, uint32_t npositions, const double *positions, size_t stride_bytes,
+                       uint32_t nindices, const uint32_t *indices);
+int  lh_multi_set_normals(lh_multi_t *multi, uint32_t mesh, const double *normals, size_t stride_bytes, int two_side);
+int  lh_multi_add_rib_scene(lh_multi_t *multi, const lh_rib_scene_t *scene);
+int  lh_multi_commit(lh_multi_t *multi, int build_threads);
+int  lh_multi_set_material(lh_multi_t *multi, uint32_t mesh, const lh_material_t *material);
+int  lh_multi_set_environment(lh_multi_t *multi, const lh_environment_t *environment);
+int  lh_multi_intersect_host(lh_multi_t *multi, size_t n, const double *org_xyz, const double *dir_xyz, uint32_t *prim,
+                             double *t, double *u, double *v, uint8_t *occluded, int mode);
+int  lh_multi_render_ao_frame_host(lh_multi_t *multi, const lh_camera_t *cam, int pixel_samples, int gather_nsamples,
+                                   uint64_t seed, int tile, float *rgb, lh_tile_stats_t *stats, double *device_seconds);
+int  lh_multi_render_pt_frame_host(lh_multi_t *multi, const lh_camera_t *cam, int spp, int spp_chunk, int max_path_vertices,
+                                   int flags, uint64_t seed, int tile, float *rgb, lh_pt_stats_t *stats, double *device_seconds);
+
 /* device scratch of the last lh_render_ao_tile call (for tests / pipelines):
  * which: 0 primary org, 1 primary dir, 2 prim, 3 t, 4 u, 5 v, 6 slot_of_sample,
  *        7 hit records (12 doubles: AO origin, tangent, binormal, Ns), 8 AO org, 9 AO dir,
@@ -222,8 +286,6 @@ int  lh_render_ao_frame_host(lh_accel_t *accel, const lh_camera_t *cam, int pixe
  * is handed: the ri_geom_t list (world-space double[4] positions / normals, triangle indices,
  * two_side) in RIB order -- same global primitive ids -- and the camera.  Verbs outside the
  * ray-query path (shaders, lights, colours, quadrics ...) are skipped and counted. */
-typedef struct lh_rib_scene lh_rib_scene_t;
-
 typedef struct lh_rib_info {
     uint32_t    nmeshes;
     uint64_t    ntriangles;

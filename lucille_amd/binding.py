@@ -60,6 +60,29 @@ class Camera(C.Structure):
         return c
 
 
+class Material(C.Structure):
+    """lh_material_t = ri_material_t's kd, ks, kt, ior (src/render/material.h:21-30)"""
+    _fields_ = [("kd", C.c_float * 3), ("ks", C.c_float * 3), ("kt", C.c_float * 3), ("ior", C.c_float)]
+
+    @classmethod
+    def make(cls, kd=(1, 1, 1), ks=(0, 0, 0), kt=(0, 0, 0), ior=1.0):
+        m = cls()
+        for k in range(3):
+            m.kd[k] = float(kd[k]); m.ks[k] = float(ks[k]); m.kt[k] = float(kt[k])
+        m.ior = float(ior)
+        return m
+
+
+class Environment(C.Structure):
+    _fields_ = [("rgb", C.c_float * 3), ("map_rgba", C.c_void_p), ("width", C.c_int), ("height", C.c_int)]
+
+
+ALL_MESHES = 0xFFFFFFFF
+PT_REFERENCE_WEIGHTS = 1
+ATTR_COLOR, ATTR_TANGENT, ATTR_BINORMAL, ATTR_TEXCOORD, ATTR_TEXCOORD_UNSHARED = 0, 1, 2, 3, 4
+STATE_DOUBLES = 24
+
+
 class PtStats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("max_depth_reached", C.c_uint64)]
 
@@ -79,6 +102,11 @@ ABI_SYMBOLS = [
     "lh_accel_trace_statistics", "lh_accel_statistics",
     "lh_render_ao_frame_host", "lh_rib_load", "lh_rib_free", "lh_rib_last_error", "lh_rib_info", "lh_rib_messages",
     "lh_rib_mesh", "lh_accel_add_rib_scene", "lh_hdr_write",
+    "lh_accel_set_material", "lh_accel_set_environment", "lh_render_pt_tile2", "lh_accel_set_attribute",
+    "lh_accel_state_build_device", "lh_accel_state_build_host",
+    "lh_multi_create", "lh_multi_destroy", "lh_multi_ndevices", "lh_multi_accel", "lh_multi_add_mesh", "lh_multi_set_normals",
+    "lh_multi_add_rib_scene", "lh_multi_commit", "lh_multi_set_material", "lh_multi_set_environment", "lh_multi_intersect_host",
+    "lh_multi_render_ao_frame_host", "lh_multi_render_pt_frame_host",
     "lh_synth_soup_triangles", "lh_synth_soup_rays", "lh_synth_tessellate", "lh_synth_skip",
 ]
 
@@ -129,6 +157,26 @@ def lib():
                                     C.POINTER(C.c_float * 3), C.c_uint64, vp, C.POINTER(PtStats), vp]
     L.lh_accel_beam_visibility_host.argtypes = [vp, sz, vp, vp, vp]
     L.lh_accel_beam_visibility_device.argtypes = [vp, sz, vp, vp, vp, vp]
+    L.lh_accel_set_material.argtypes = [vp, u32, C.POINTER(Material)]
+    L.lh_accel_set_environment.argtypes = [vp, C.POINTER(Environment)]
+    L.lh_render_pt_tile2.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, i32, i32, i32, C.c_uint64, vp,
+                                     C.POINTER(PtStats), vp]
+    L.lh_accel_set_attribute.argtypes = [vp, u32, i32, vp, sz, u32]
+    L.lh_accel_state_build_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.lh_accel_state_build_host.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp]
+    L.lh_multi_create.argtypes = [C.POINTER(vp), i32, C.POINTER(i32)]
+    L.lh_multi_destroy.argtypes = [vp]; L.lh_multi_destroy.restype = None
+    L.lh_multi_ndevices.argtypes = [vp]
+    L.lh_multi_accel.argtypes = [vp, i32]; L.lh_multi_accel.restype = vp
+    L.lh_multi_add_mesh.argtypes = [vp, u32, vp, sz, u32, vp]
+    L.lh_multi_set_normals.argtypes = [vp, u32, vp, sz, i32]
+    L.lh_multi_add_rib_scene.argtypes = [vp, vp]
+    L.lh_multi_commit.argtypes = [vp, i32]
+    L.lh_multi_set_material.argtypes = [vp, u32, C.POINTER(Material)]
+    L.lh_multi_set_environment.argtypes = [vp, C.POINTER(Environment)]
+    L.lh_multi_intersect_host.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32]
+    L.lh_multi_render_ao_frame_host.argtypes = [vp, C.POINTER(Camera), i32, i32, C.c_uint64, i32, vp, C.POINTER(TileStats), vp]
+    L.lh_multi_render_pt_frame_host.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, C.c_uint64, i32, vp, C.POINTER(PtStats), vp]
     L.lh_synth_soup_triangles.argtypes = [C.POINTER(C.c_uint64), u32, C.c_double, vp, vp]
     L.lh_synth_soup_triangles.restype = None
     L.lh_synth_soup_rays.argtypes = [C.POINTER(C.c_uint64), sz, vp, vp]
@@ -350,6 +398,51 @@ class HipAccel:
                "lh_render_pt_tile")
         return out, {k: int(getattr(st, k)) for k, _ in st._fields_}
 
+    def render_pt_tile2(self, cam, x0, y0, w, h, spp_begin, spp_count, spp_total, max_vertices=8, flags=0, seed=1, out=None,
+                        stream=None):
+        """as render_pt_tile, with the accelerator's per-mesh materials and environment (set_material / set_environment)"""
+        import torch
+        dev = torch.device("cuda", self.device)
+        if out is None:
+            out = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        st = PtStats()
+        _check(self.L.lh_render_pt_tile2(self.h, C.byref(cam), x0, y0, w, h, spp_begin, spp_count, spp_total, max_vertices,
+                                         int(flags), int(seed), _dptr(out), C.byref(st), C.c_void_p(stream)), "lh_render_pt_tile2")
+        return out, {k: int(getattr(st, k)) for k, _ in st._fields_}
+
+    def set_material(self, mesh, material):
+        _check(self.L.lh_accel_set_material(self.h, int(mesh), C.byref(material)), "lh_accel_set_material")
+
+    def set_environment(self, rgb=(1.0, 1.0, 1.0), envmap=None):
+        """envmap: [H,W,4] float32 angular-map light probe or None (constant radiance rgb)"""
+        e = Environment()
+        for k in range(3):
+            e.rgb[k] = float(rgb[k])
+        m = None
+        if envmap is not None:
+            m = np.ascontiguousarray(envmap, np.float32)
+            assert m.ndim == 3 and m.shape[2] == 4
+            e.map_rgba = m.ctypes.data; e.height, e.width = m.shape[0], m.shape[1]
+        _check(self.L.lh_accel_set_environment(self.h, C.byref(e)), "lh_accel_set_environment")
+
+    def set_attribute(self, mesh, kind, data):
+        D = _np(data, np.float64)
+        if D.ndim != 2:
+            raise ValueError("attribute data must be [n, components]")
+        _check(self.L.lh_accel_set_attribute(self.h, int(mesh), int(kind), D.ctypes.data, D.shape[1] * 8, D.shape[0]),
+               "lh_accel_set_attribute")
+
+    def state_build(self, org, dr, prim, t, u, v):
+        """host arrays -> [n, 24] ri_intersection_state_build records (zeros for misses)"""
+        o = _np(org, np.float64).reshape(-1, 3); d = _np(dr, np.float64).reshape(-1, 3)
+        p = _np(prim, np.uint32); tt = _np(t, np.float64); uu = _np(u, np.float64); vv = _np(v, np.float64)
+        st = np.zeros((o.shape[0], STATE_DOUBLES))
+        _check(self.L.lh_accel_state_build_host(self.h, o.shape[0], o.ctypes.data, d.ctypes.data, p.ctypes.data, tt.ctypes.data,
+                                                uu.ctypes.data, vv.ctypes.data, st.ctypes.data), "lh_accel_state_build_host")
+        return st
+
     def scratch(self, which, dtype, width):
         """view (copy to host) of a scratch buffer of the last render_ao_tile call"""
         p = C.c_void_p(); n = C.c_size_t()
@@ -361,3 +454,96 @@ class HipAccel:
             hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
             assert hip.hipMemcpy(host.ctypes.data, p, host.nbytes, 2) == 0
         return host.reshape(n.value, width) if width > 1 else host
+
+
+class _AccelView(HipAccel):
+    """a replica of a HipMulti as a HipAccel (borrowed handle: closing it does nothing)"""
+
+    def __init__(self, handle, device):        # noqa: D401 -- no lh_accel_create here
+        self.L = lib(); self.h = C.c_void_p(handle); self.device = int(device); self.committed = True; self._npos = []
+
+    def close(self):
+        self.h = None
+
+
+class HipMulti:
+    """lh_multi_t: the G GPUs of one node from one process -- one host build, replicated; frames through a tile
+    queue with the slabs gathered on device 0; ray dumps in contiguous slices."""
+
+    def __init__(self, devices=None):
+        self.L = lib()
+        self.h = C.c_void_p()
+        if devices is None:
+            _check(self.L.lh_multi_create(C.byref(self.h), 0, None), "lh_multi_create")
+        else:
+            arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            _check(self.L.lh_multi_create(C.byref(self.h), len(devices), arr), "lh_multi_create")
+        self.n = int(self.L.lh_multi_ndevices(self.h))
+        self.devices = list(devices) if devices is not None else list(range(self.n))
+        _live.add(self)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.lh_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_mesh(self, positions, indices):
+        P = _np(positions, np.float64); I = _np(indices, np.uint32).reshape(-1)
+        _check(self.L.lh_multi_add_mesh(self.h, P.shape[0], P.ctypes.data, P.shape[1] * 8, I.shape[0], I.ctypes.data), "lh_multi_add_mesh")
+
+    def set_normals(self, mesh, normals, two_side=0):
+        N = _np(normals, np.float64) if normals is not None else None
+        _check(self.L.lh_multi_set_normals(self.h, int(mesh), N.ctypes.data if N is not None else None,
+                                           (N.shape[1] * 8) if N is not None else 24, int(two_side)), "lh_multi_set_normals")
+
+    def commit(self, build_threads=0):
+        _check(self.L.lh_multi_commit(self.h, int(build_threads)), "lh_multi_commit")
+
+    def accel(self, k):
+        return _AccelView(self.L.lh_multi_accel(self.h, int(k)), self.devices[k])
+
+    def set_material(self, mesh, material):
+        _check(self.L.lh_multi_set_material(self.h, int(mesh), C.byref(material)), "lh_multi_set_material")
+
+    def set_environment(self, rgb=(1.0, 1.0, 1.0), envmap=None):
+        e = Environment()
+        for k in range(3):
+            e.rgb[k] = float(rgb[k])
+        m = None
+        if envmap is not None:
+            m = np.ascontiguousarray(envmap, np.float32)
+            e.map_rgba = m.ctypes.data; e.height, e.width = m.shape[0], m.shape[1]
+        _check(self.L.lh_multi_set_environment(self.h, C.byref(e)), "lh_multi_set_environment")
+
+    def intersect_host(self, org, dr, mode=MODE_CLOSEST):
+        o = _np(org, np.float64).reshape(-1, 3); d = _np(dr, np.float64).reshape(-1, 3)
+        n = o.shape[0]
+        if mode == MODE_CLOSEST:
+            prim = np.empty(n, np.uint32); t = np.empty(n); u = np.empty(n); v = np.empty(n)
+            _check(self.L.lh_multi_intersect_host(self.h, n, o.ctypes.data, d.ctypes.data, prim.ctypes.data, t.ctypes.data,
+                                                  u.ctypes.data, v.ctypes.data, None, mode), "lh_multi_intersect_host")
+            return prim, t, u, v
+        occ = np.empty(n, np.uint8)
+        _check(self.L.lh_multi_intersect_host(self.h, n, o.ctypes.data, d.ctypes.data, None, None, None, None, occ.ctypes.data, mode),
+               "lh_multi_intersect_host")
+        return occ
+
+    def render_ao_frame(self, cam, pixel_samples, gather_nsamples, seed=1, tile=512):
+        """-> (rgb [H,W,3] float32 host array, stats, per-replica busy seconds)"""
+        rgb = np.empty((cam.height, cam.width, 3), np.float32); st = TileStats(); secs = (C.c_double * self.n)()
+        _check(self.L.lh_multi_render_ao_frame_host(self.h, C.byref(cam), pixel_samples, gather_nsamples, int(seed), int(tile),
+                                                    rgb.ctypes.data, C.byref(st), secs), "lh_multi_render_ao_frame_host")
+        return rgb, {k: int(getattr(st, k)) for k, _ in st._fields_}, list(secs)
+
+    def render_pt_frame(self, cam, spp, spp_chunk=0, max_vertices=8, flags=0, seed=1, tile=512):
+        rgb = np.empty((cam.height, cam.width, 3), np.float32); st = PtStats(); secs = (C.c_double * self.n)()
+        _check(self.L.lh_multi_render_pt_frame_host(self.h, C.byref(cam), int(spp), int(spp_chunk), int(max_vertices), int(flags),
+                                                    int(seed), int(tile), rgb.ctypes.data, C.byref(st), secs),
+               "lh_multi_render_pt_frame_host")
+        return rgb, {k: int(getattr(st, k)) for k, _ in st._fields_}, list(secs)

@@ -24,6 +24,8 @@
 
 static thread_local char g_err[512] = "";
 
+extern "C" void lh_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }
+
 static int fail(const char *fmt, ...)
 {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
@@ -33,7 +35,10 @@ static int fail(const char *fmt, ...)
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
     return fail("%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
 
-struct lh_mesh_copy { uint32_t npos, nidx; double *pos; uint32_t *idx; double *nrm; int two_side; };
+/* attribute kinds of lh_accel_set_attribute: per-vertex xyz (colour, tangent, binormal), per-vertex st,
+ * per-index st (texcoords_unshared) -- the optional members of ri_geom_t that ri_intersection_state_build reads */
+struct lh_mesh_copy { uint32_t npos, nidx; double *pos; uint32_t *idx; double *nrm; int two_side;
+                      double *attr[5]; };
 
 /* launchers in lh_render.hip */
 extern "C" int lh_render_launch_primary(const lh_camera_t *cam, int x0, int y0, int w, int h, int xs, int ys,
@@ -63,6 +68,10 @@ struct lh_host_scene {
     int have_ref;
     double ref_build_seconds;
     double *nrm9;             /* per-primitive vertex normals (9 doubles, NaN = none) or NULL */
+    double *attr9[3];         /* colour / tangent / binormal per primitive (9 doubles, NaN = none) or NULL */
+    double *st6;              /* texture coordinates per primitive (6 doubles, NaN = none) or NULL */
+    uint8_t *inside;          /* per primitive: the back half of a two-sided mesh (intersection_state.c:233-241) or NULL */
+    uint32_t nmeshes;         /* meshes the scene was committed with */
 };
 static pthread_mutex_t g_scene_mu = PTHREAD_MUTEX_INITIALIZER;
 
@@ -98,6 +107,11 @@ struct lh_accel {
     /* pipelined host batches: two pinned in/out staging pairs, two device pairs, two streams */
     struct { void *h_in[2], *h_out[2], *d_in[2], *d_out[2]; hipStream_t s[2]; hipEvent_t done[2]; size_t cap; int ready; } pipe;
     void *d_nrm9;                      /* hs->nrm9 on the device */
+    void *d_attr9[3], *d_st6, *d_inside;            /* colour / tangent / binormal, st, inside flags (uploaded at commit if present) */
+    void *d_prim_mesh;                 /* mesh ordinal per primitive (materials; uploaded on first use) */
+    lh_material_t *materials; uint32_t nmaterials; void *d_materials; int materials_dirty;
+    lh_environment_t env; void *d_env_map;
+    lh_buf r_state;                    /* lh_accel_state_build_host staging */
     /* tile-render scratch (lh_render_ao_tile) */
     lh_buf r_org, r_dir, r_prim, r_t, r_u, r_v, r_slot, r_hitrec, r_aorg, r_adir, r_occ, r_blocks, r_key, r_frame, r_occcount;
     int ao_fused;                      /* AO rays generated inside the any-hit kernel (default); 0: materialised in HBM */
@@ -178,6 +192,7 @@ extern "C" int lh_accel_add_mesh(lh_accel_t *a, uint32_t npos, const double *pos
     a->meshes = nm;
     lh_mesh_copy *m = &a->meshes[a->nmeshes];
     m->npos = npos; m->nidx = nidx; m->nrm = NULL; m->two_side = 0;
+    for (int k = 0; k < 5; k++) m->attr[k] = NULL;
     m->pos = (double *)malloc(sizeof(double) * 3 * (size_t)(npos ? npos : 1));
     m->idx = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nidx ? nidx : 1));
     if (!m->pos || !m->idx) return fail("out of memory");
@@ -210,6 +225,30 @@ extern "C" int lh_accel_set_normals(lh_accel_t *a, uint32_t mesh, const double *
     return 0;
 }
 
+extern "C" int lh_accel_set_attribute(lh_accel_t *a, uint32_t mesh, int kind, const double *data, size_t stride, uint32_t count)
+{
+    lh_guard guard(a);
+    if (!a) return fail("lh_accel_set_attribute: accel is NULL");
+    if (a->committed) return fail("lh_accel_set_attribute: accel already committed");
+    if (mesh >= a->nmeshes) return fail("lh_accel_set_attribute: mesh %u out of range", mesh);
+    if (kind < LH_ATTR_COLOR || kind > LH_ATTR_TEXCOORD_UNSHARED) return fail("lh_accel_set_attribute: unknown attribute kind %d", kind);
+    lh_mesh_copy *m = &a->meshes[mesh];
+    const int ncomp = kind <= LH_ATTR_BINORMAL ? 3 : 2;
+    const uint32_t need = kind == LH_ATTR_TEXCOORD_UNSHARED ? m->nidx : m->npos;
+    free(m->attr[kind]); m->attr[kind] = NULL;
+    if (!data) return 0;
+    if (count != need) return fail("lh_accel_set_attribute: %u values given, the mesh needs %u (one per %s)", count, need,
+                                   kind == LH_ATTR_TEXCOORD_UNSHARED ? "index" : "vertex");
+    if (stride < (size_t)ncomp * sizeof(double) || (stride % sizeof(double)) != 0) return fail("lh_accel_set_attribute: bad stride %zu", stride);
+    m->attr[kind] = (double *)malloc(sizeof(double) * ncomp * (size_t)(need ? need : 1));
+    if (!m->attr[kind]) return fail("out of memory");
+    for (uint32_t i = 0; i < need; i++) {
+        const double *q = (const double *)((const char *)data + (size_t)i * stride);
+        for (int k = 0; k < ncomp; k++) m->attr[kind][(size_t)ncomp * i + k] = q[k];
+    }
+    return 0;
+}
+
 static void free_buf(lh_buf *b) { if (b->p) (void)hipFree(b->p); b->p = NULL; b->cap = 0; }
 
 static void release_device(lh_accel_t *a)
@@ -220,6 +259,14 @@ static void release_device(lh_accel_t *a)
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) free_buf(bufs[i]);
     if (a->d_total) (void)hipFree(a->d_total);
     if (a->d_nrm9) (void)hipFree(a->d_nrm9);
+    for (int k = 0; k < 3; k++) { if (a->d_attr9[k]) (void)hipFree(a->d_attr9[k]); a->d_attr9[k] = NULL; }
+    if (a->d_st6) (void)hipFree(a->d_st6);
+    if (a->d_inside) (void)hipFree(a->d_inside);
+    if (a->d_prim_mesh) (void)hipFree(a->d_prim_mesh);
+    if (a->d_materials) (void)hipFree(a->d_materials);
+    if (a->d_env_map) (void)hipFree(a->d_env_map);
+    a->d_st6 = a->d_inside = a->d_prim_mesh = a->d_materials = a->d_env_map = NULL;
+    free_buf(&a->r_state);
     a->d_total = NULL; a->d_nrm9 = NULL;
     if (a->d_nodes) (void)hipFree(a->d_nodes);
     if (a->d_tri32) (void)hipFree(a->d_tri32);
@@ -309,7 +356,55 @@ static int host_build(lh_accel_t *a, int build_threads)
         }
     }
     /* the packed mesh copies are no longer needed: the BVH holds tri64 */
-    for (uint32_t g = 0; g < a->nmeshes; g++) { free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm); }
+    /* the other per-vertex attributes ri_intersection_state_build reads, flattened the same way */
+    {
+        const uint32_t n = hs->bvh.ntris;
+        hs->nmeshes = a->nmeshes;
+        for (int kind = 0; kind < 3 && n; kind++) {
+            bool anyk = false;
+            for (uint32_t g = 0; g < a->nmeshes; g++) anyk = anyk || a->meshes[g].attr[kind] != NULL;
+            if (!anyk) continue;
+            hs->attr9[kind] = (double *)malloc(sizeof(double) * 9 * (size_t)n);
+            if (!hs->attr9[kind]) return fail("out of memory");
+            for (uint32_t p = 0; p < n; p++) {
+                const lh_mesh_copy *m = &a->meshes[hs->bvh.prim_geom[p]];
+                double *o = hs->attr9[kind] + 9 * (size_t)p;
+                if (!m->attr[kind]) { for (int k = 0; k < 9; k++) o[k] = NAN; continue; }
+                for (int c = 0; c < 3; c++) {
+                    const uint32_t vi = m->idx[hs->bvh.prim_index[p] + c];
+                    for (int k = 0; k < 3; k++) o[3 * c + k] = m->attr[kind][3 * (size_t)vi + k];
+                }
+            }
+        }
+        bool any_st = false, any_two = false;
+        for (uint32_t g = 0; g < a->nmeshes; g++) { any_st = any_st || a->meshes[g].attr[3] || a->meshes[g].attr[4]; any_two = any_two || a->meshes[g].two_side; }
+        if (any_st && n) {
+            hs->st6 = (double *)malloc(sizeof(double) * 6 * (size_t)n);
+            if (!hs->st6) return fail("out of memory");
+            for (uint32_t p = 0; p < n; p++) {
+                const lh_mesh_copy *m = &a->meshes[hs->bvh.prim_geom[p]];
+                double *o = hs->st6 + 6 * (size_t)p;
+                const uint32_t first = hs->bvh.prim_index[p];
+                if (m->attr[3]) {                 /* shared: geom->texcoords[2 * i_c] (intersection_state.c:210-216) */
+                    for (int c = 0; c < 3; c++) { const uint32_t vi = m->idx[first + c]; o[2 * c] = m->attr[3][2 * (size_t)vi]; o[2 * c + 1] = m->attr[3][2 * (size_t)vi + 1]; }
+                } else if (m->attr[4]) {          /* unshared: geom->texcoords_unshared[2 * (index + c)] (:218-224) */
+                    for (int c = 0; c < 3; c++) { o[2 * c] = m->attr[4][2 * (size_t)(first + c)]; o[2 * c + 1] = m->attr[4][2 * (size_t)(first + c) + 1]; }
+                } else for (int k = 0; k < 6; k++) o[k] = NAN;
+            }
+        }
+        if (any_two && n) {
+            hs->inside = (uint8_t *)calloc(n, 1);
+            if (!hs->inside) return fail("out of memory");
+            for (uint32_t p = 0; p < n; p++) {
+                const lh_mesh_copy *m = &a->meshes[hs->bvh.prim_geom[p]];
+                hs->inside[p] = (m->two_side && hs->bvh.prim_index[p] >= m->nidx / 2) ? 1 : 0;
+            }
+        }
+    }
+    for (uint32_t g = 0; g < a->nmeshes; g++) {
+        free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm);
+        for (int k = 0; k < 5; k++) free(a->meshes[g].attr[k]);
+    }
     free(a->meshes); a->meshes = NULL; a->nmeshes = 0;
     if (hs->bvh.ntris && hs->bvh.max_depth + 1 > 64) return fail("lh_accel_commit: tree depth %u exceeds the kernel stack", hs->bvh.max_depth);
     return 0;
@@ -372,6 +467,21 @@ static int device_upload(lh_accel_t *a)
         HIPCHK(hipMalloc(&a->d_nrm9, sizeof(double) * 9 * (size_t)hs->bvh.ntris));
         HIPCHK(hipMemcpy(a->d_nrm9, hs->nrm9, sizeof(double) * 9 * (size_t)hs->bvh.ntris, hipMemcpyHostToDevice));
         a->device_bytes += sizeof(double) * 9 * (size_t)hs->bvh.ntris;
+    }
+    for (int kind = 0; kind < 3; kind++) if (hs->attr9[kind]) {
+        const size_t b = sizeof(double) * 9 * (size_t)hs->bvh.ntris;
+        HIPCHK(hipMalloc(&a->d_attr9[kind], b));
+        HIPCHK(hipMemcpy(a->d_attr9[kind], hs->attr9[kind], b, hipMemcpyHostToDevice));
+        a->device_bytes += b;
+    }
+    if (hs->st6) {
+        const size_t b = sizeof(double) * 6 * (size_t)hs->bvh.ntris;
+        HIPCHK(hipMalloc(&a->d_st6, b)); HIPCHK(hipMemcpy(a->d_st6, hs->st6, b, hipMemcpyHostToDevice));
+        a->device_bytes += b;
+    }
+    if (hs->inside) {
+        HIPCHK(hipMalloc(&a->d_inside, hs->bvh.ntris)); HIPCHK(hipMemcpy(a->d_inside, hs->inside, hs->bvh.ntris, hipMemcpyHostToDevice));
+        a->device_bytes += hs->bvh.ntris;
     }
     if (hs->bvh.ntris) {
         size_t t32 = sizeof(lh_tri32_t) * (size_t)hs->bvh.ntris;
@@ -485,13 +595,16 @@ extern "C" void lh_accel_destroy(lh_accel_t *a)
 {
     if (!a) return;
     if (a->committed || a->commit_failed) { (void)hipSetDevice(a->device); release_device(a); }
-    for (uint32_t g = 0; g < a->nmeshes; g++) { free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm); }
+    for (uint32_t g = 0; g < a->nmeshes; g++) {
+        free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm);
+        for (int k = 0; k < 5; k++) free(a->meshes[g].attr[k]);
+    }
     free(a->meshes);
     pthread_mutex_lock(&g_scene_mu);
     const int last = (--a->hs->refs == 0);
     pthread_mutex_unlock(&g_scene_mu);
     if (last) {
-        free(a->hs->nrm9);
+        free(a->hs->nrm9); free(a->hs->attr9[0]); free(a->hs->attr9[1]); free(a->hs->attr9[2]); free(a->hs->st6); free(a->hs->inside);
         lh_bvh_release(&a->hs->bvh);
         lh_refbvh_release(&a->hs->ref);
         free(a->hs);
@@ -1002,6 +1115,125 @@ extern "C" int lh_render_scratch(lh_accel_t *a, int which, void **d_ptr, size_t 
 }
 
 /* ------------------------------------------------------------------------ */
+/* hit epilogue for a batch (ri_intersection_state_build)                   */
+/* ------------------------------------------------------------------------ */
+extern "C" int lh_render_launch_state_build(size_t n, const lh_dev_scene_t *sc, const double *d_nrm9, const double *d_col9,
+                                            const double *d_tan9, const double *d_bin9, const double *d_st6, const uint8_t *d_inside,
+                                            const double *d_org, const double *d_dir, const uint32_t *d_prim, const double *d_t,
+                                            const double *d_u, const double *d_v, double *d_state, void *stream);
+
+extern "C" int lh_accel_state_build_device(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, const void *d_prim,
+                                           const void *d_t, const void *d_u, const void *d_v, void *d_state, void *stream)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_accel_state_build_device: accel not committed");
+    if (n == 0 || a->hs->bvh.ntris == 0) return 0;
+    if (!d_org || !d_dir || !d_prim || !d_t || !d_u || !d_v || !d_state) return fail("lh_accel_state_build_device: NULL argument");
+    HIPCHK(hipSetDevice(a->device));
+    if (lh_render_launch_state_build(n, &a->dev, (const double *)a->d_nrm9, (const double *)a->d_attr9[0], (const double *)a->d_attr9[1],
+                                     (const double *)a->d_attr9[2], (const double *)a->d_st6, (const uint8_t *)a->d_inside,
+                                     (const double *)d_org, (const double *)d_dir, (const uint32_t *)d_prim, (const double *)d_t,
+                                     (const double *)d_u, (const double *)d_v, (double *)d_state, stream) != 0)
+        return fail("state-build kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+extern "C" int lh_accel_state_build_host(lh_accel_t *a, size_t n, const double *org, const double *dir, const uint32_t *prim,
+                                         const double *t, const double *u, const double *v, double *state)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_accel_state_build_host: accel not committed");
+    if (n == 0) return 0;
+    if (!org || !dir || !prim || !t || !u || !v || !state) return fail("lh_accel_state_build_host: NULL argument");
+    HIPCHK(hipSetDevice(a->device));
+    const size_t b_ray = sizeof(double) * 3 * n, b_d = sizeof(double) * n, b_state = sizeof(double) * LH_STATE_DOUBLES * n;
+    if (ensure_buf(&a->r_state, 2 * b_ray + 3 * b_d + sizeof(uint32_t) * n + 8 + b_state)) return -1;
+    char *base = (char *)a->r_state.p;
+    double *d_state = (double *)base, *d_org = (double *)(base + b_state), *d_dir = d_org + 3 * n, *d_t = d_dir + 3 * n, *d_u = d_t + n, *d_v = d_u + n;
+    uint32_t *d_prim = (uint32_t *)(d_v + n);
+    HIPCHK(hipMemcpyAsync(d_org, org, b_ray, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_dir, dir, b_ray, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_t, t, b_d, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_u, u, b_d, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_v, v, b_d, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_prim, prim, sizeof(uint32_t) * n, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemsetAsync(d_state, 0, b_state, a->stream));
+    if (lh_accel_state_build_device(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_state, a->stream) != 0) return -1;
+    HIPCHK(hipMemcpyAsync(state, d_state, b_state, hipMemcpyDeviceToHost, a->stream));
+    HIPCHK(hipStreamSynchronize(a->stream));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* materials / environment of the path tracer                               */
+/* ------------------------------------------------------------------------ */
+extern "C" int lh_accel_set_material(lh_accel_t *a, uint32_t mesh, const lh_material_t *mat)
+{
+    lh_guard guard(a);
+    if (!a || !mat) return fail("lh_accel_set_material: NULL argument");
+    const uint32_t nm = a->committed ? a->hs->nmeshes : a->nmeshes;
+    if (mesh != LH_ALL_MESHES && mesh >= nm) return fail("lh_accel_set_material: mesh %u out of range", mesh);
+    for (int k = 0; k < 3; k++) {
+        if (!(mat->kd[k] >= 0.0f && mat->ks[k] >= 0.0f && mat->kt[k] >= 0.0f)) return fail("lh_accel_set_material: negative or NaN reflectance");
+    }
+    const double sum = (mat->kd[0] + mat->kd[1] + mat->kd[2] + mat->ks[0] + mat->ks[1] + mat->ks[2] + mat->kt[0] + mat->kt[1] + mat->kt[2]) / 3.0;
+    if (sum > 1.0 + 1e-6) return fail("lh_accel_set_material: kd + ks + kt averages exceed 1 (pathtrace.c:419 asserts d + s + t <= 1)");
+    if (!(mat->ior > 0.0f)) return fail("lh_accel_set_material: ior must be positive");
+    if (a->nmaterials < nm) {
+        lh_material_t *nmats = (lh_material_t *)realloc(a->materials, sizeof(lh_material_t) * (nm ? nm : 1));
+        if (!nmats) return fail("out of memory");
+        for (uint32_t k = a->nmaterials; k < nm; k++) {        /* ri_material_new (material.c:20-40): kd 1, ks 0, kt 0, ior 1 */
+            memset(&nmats[k], 0, sizeof(lh_material_t));
+            nmats[k].kd[0] = nmats[k].kd[1] = nmats[k].kd[2] = 1.0f; nmats[k].ior = 1.0f;
+        }
+        a->materials = nmats; a->nmaterials = nm;
+    }
+    for (uint32_t k = 0; k < a->nmaterials; k++) if (mesh == LH_ALL_MESHES || mesh == k) a->materials[k] = *mat;
+    a->materials_dirty = 1;
+    return 0;
+}
+
+extern "C" int lh_accel_set_environment(lh_accel_t *a, const lh_environment_t *env)
+{
+    lh_guard guard(a);
+    if (!a || !env) return fail("lh_accel_set_environment: NULL argument");
+    if (!a->committed) return fail("lh_accel_set_environment: accel not committed");
+    if (env->map_rgba && (env->width < 1 || env->height < 1)) return fail("lh_accel_set_environment: bad map size");
+    HIPCHK(hipSetDevice(a->device));
+    if (a->d_env_map) { (void)hipFree(a->d_env_map); a->d_env_map = NULL; }
+    a->env = *env; a->env.map_rgba = NULL;
+    if (env->map_rgba) {
+        const size_t b = sizeof(float) * 4 * (size_t)env->width * env->height;
+        HIPCHK(hipMalloc(&a->d_env_map, b));
+        HIPCHK(hipMemcpy(a->d_env_map, env->map_rgba, b, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+static int sync_materials(lh_accel_t *a)
+{
+    const uint32_t nm = a->hs->nmeshes ? a->hs->nmeshes : 1;
+    if (a->nmaterials < nm) {
+        lh_material_t def; memset(&def, 0, sizeof(def)); def.kd[0] = def.kd[1] = def.kd[2] = 1.0f; def.ior = 1.0f;
+        lh_material_t *nmats = (lh_material_t *)realloc(a->materials, sizeof(lh_material_t) * nm);
+        if (!nmats) return fail("out of memory");
+        for (uint32_t k = a->nmaterials; k < nm; k++) nmats[k] = def;
+        a->materials = nmats; a->nmaterials = nm; a->materials_dirty = 1;
+    }
+    if (a->materials_dirty || !a->d_materials) {
+        if (a->d_materials) { (void)hipFree(a->d_materials); a->d_materials = NULL; }
+        HIPCHK(hipMalloc(&a->d_materials, sizeof(lh_material_t) * a->nmaterials));
+        HIPCHK(hipMemcpy(a->d_materials, a->materials, sizeof(lh_material_t) * a->nmaterials, hipMemcpyHostToDevice));
+        a->materials_dirty = 0;
+    }
+    if (!a->d_prim_mesh && a->hs->bvh.ntris) {
+        HIPCHK(hipMalloc(&a->d_prim_mesh, sizeof(uint32_t) * (size_t)a->hs->bvh.ntris));
+        HIPCHK(hipMemcpy(a->d_prim_mesh, a->hs->bvh.prim_geom, sizeof(uint32_t) * (size_t)a->hs->bvh.ntris, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* beam visibility                                                          */
 /* ------------------------------------------------------------------------ */
 extern "C" int lh_launch_beam_visibility(const lh_dev_scene_t *sc, size_t n, const double *d_org, const double *d_dirs,
@@ -1053,35 +1285,34 @@ extern "C" int lh_accel_beam_visibility_host(lh_accel_t *a, size_t n, const doub
 extern "C" int lh_pt_launch_primary(const lh_camera_t *cam, int x0, int y0, int w, int h, int spp, int s0,
                                     unsigned long long seed, double *d_org, double *d_dir, uint32_t *d_path_of,
                                     float *d_thr, void *stream);
-extern "C" int lh_pt_launch_shade(size_t n, const lh_dev_scene_t *sc, const double *d_nrm9, int depth, int max_depth,
-                                  float kd, unsigned long long seed, int s0, int spp, int x0, int y0, int w,
+extern "C" int lh_pt_launch_shade(size_t n, const lh_dev_scene_t *sc, const double *d_nrm9, const double *d_col9,
+                                  const uint32_t *d_prim_mesh, const void *d_materials, const lh_material_t *override_mat,
+                                  const float env_rgb[3], const void *d_env_map, int env_w, int env_h, int ref_weights,
+                                  int depth, int max_depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w,
                                   int full_width, double *d_org, double *d_dir, const uint32_t *d_prim,
-                                  const double *d_t, const double *d_u, const double *d_v, const uint32_t *d_path_of,
+                                  const double *d_t, const double *d_u, const double *d_v, uint32_t *d_path_of,
                                   float *d_thr, float *d_radiance, uint8_t *d_alive, uint32_t *d_blocks,
                                   unsigned long long *d_total, double *d_org2, double *d_dir2, uint32_t *d_path_of2,
                                   float *d_thr2, void *stream);
-extern "C" int lh_pt_launch_resolve(int w, int h, int spp, float inv_total_spp, const float env[3],
-                                    const float *d_radiance, float *d_rgb, void *stream);
+extern "C" int lh_pt_launch_resolve(int w, int h, int spp, float inv_total_spp, const float *d_radiance, float *d_rgb, void *stream);
 
-extern "C" int lh_render_pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int s0, int spp,
-                                 int spp_total, int max_vertices, float kd, const float env[3], uint64_t seed,
-                                 void *d_rgb, lh_pt_stats_t *stats, void *stream)
+static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int s0, int spp, int spp_total, int max_vertices,
+                   const lh_material_t *override_mat, const float env_rgb[3], const void *d_env_map, int env_w, int env_h, int flags,
+                   uint64_t seed, void *d_rgb, lh_pt_stats_t *stats, void *stream)
 {
-    lh_guard guard(a);
-    if (!a || !a->committed) return fail("lh_render_pt_tile: accel not committed");
-    if (!cam || !d_rgb || !env) return fail("lh_render_pt_tile: NULL argument");
-    if (w <= 0 || h <= 0 || spp < 1 || spp_total < spp || max_vertices < 2 || !(kd > 0.0f) || kd > 1.0f)
-        return fail("lh_render_pt_tile: bad arguments");
+    if (w <= 0 || h <= 0 || spp < 1 || spp_total < spp || max_vertices < 2) return fail("lh_render_pt_tile: bad arguments");
     HIPCHK(hipSetDevice(a->device));
+    if (sync_materials(a) != 0) return -1;
     hipStream_t s = (hipStream_t)stream;
     const size_t S = (size_t)w * h * spp;
+    if (S >= ((size_t)1 << 31)) return fail("lh_render_pt_tile: more than 2^31 paths in one pass; lower spp_count or the tile size");
     const unsigned nb = (unsigned)((S + 255) / 256);
     if (ensure_buf(&a->r_org, S * 24) || ensure_buf(&a->r_dir, S * 24) || ensure_buf(&a->p_org2, S * 24) ||
         ensure_buf(&a->p_dir2, S * 24) || ensure_buf(&a->r_prim, S * 4) || ensure_buf(&a->r_t, S * 8) ||
         ensure_buf(&a->r_u, S * 8) || ensure_buf(&a->r_v, S * 8) || ensure_buf(&a->p_path, S * 4) ||
-        ensure_buf(&a->p_path2, S * 4) || ensure_buf(&a->p_thr, S * 4) || ensure_buf(&a->p_thr2, S * 4) ||
-        ensure_buf(&a->p_rad, S * 4) || ensure_buf(&a->p_alive, S) || ensure_buf(&a->r_blocks, (size_t)nb * 4)) return -1;
-    HIPCHK(hipMemsetAsync(a->p_rad.p, 0, S * 4, s));
+        ensure_buf(&a->p_path2, S * 4) || ensure_buf(&a->p_thr, S * 12) || ensure_buf(&a->p_thr2, S * 12) ||
+        ensure_buf(&a->p_rad, S * 12) || ensure_buf(&a->p_alive, S) || ensure_buf(&a->r_blocks, (size_t)nb * 4)) return -1;
+    HIPCHK(hipMemsetAsync(a->p_rad.p, 0, S * 12, s));
     double *org = (double *)a->r_org.p, *dir = (double *)a->r_dir.p, *org2 = (double *)a->p_org2.p, *dir2 = (double *)a->p_dir2.p;
     uint32_t *path = (uint32_t *)a->p_path.p, *path2 = (uint32_t *)a->p_path2.p;
     float *thr = (float *)a->p_thr.p, *thr2 = (float *)a->p_thr2.p;
@@ -1090,12 +1321,10 @@ extern "C" int lh_render_pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
     while (n > 0) {
         if (launch(a, n, org, dir, a->r_prim.p, a->r_t.p, a->r_u.p, a->r_v.p, NULL, LH_MODE_CLOSEST, LH_VARIANT_DEFAULT, NULL, s) != 0) return -1;
         rays += n;
-        if (a->hs->bvh.ntris == 0) {
-            /* empty scene: every path escapes at once */
-        }
-        if (lh_pt_launch_shade(n, &a->dev, (const double *)a->d_nrm9, depth, max_vertices, kd, seed, s0, spp, x0, y0, w,
-                               cam->width, org, dir, (const uint32_t *)a->r_prim.p, (const double *)a->r_t.p,
-                               (const double *)a->r_u.p, (const double *)a->r_v.p, path, thr, (float *)a->p_rad.p,
+        if (lh_pt_launch_shade(n, &a->dev, (const double *)a->d_nrm9, (const double *)a->d_attr9[0], (const uint32_t *)a->d_prim_mesh,
+                               a->d_materials, override_mat, env_rgb, d_env_map, env_w, env_h, (flags & LH_PT_REFERENCE_WEIGHTS) != 0,
+                               depth, max_vertices, seed, s0, spp, x0, y0, w, cam->width, org, dir, (const uint32_t *)a->r_prim.p,
+                               (const double *)a->r_t.p, (const double *)a->r_u.p, (const double *)a->r_v.p, path, thr, (float *)a->p_rad.p,
                                (uint8_t *)a->p_alive.p, (uint32_t *)a->r_blocks.p, a->d_total, org2, dir2, path2, thr2, s) != 0)
             return fail("pt shade launch failed: %s", hipGetErrorString(hipGetLastError()));
         unsigned long long alive = 0;
@@ -1105,11 +1334,37 @@ extern "C" int lh_render_pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
         { double *t1 = org; org = org2; org2 = t1; t1 = dir; dir = dir2; dir2 = t1; }
         { uint32_t *t2 = path; path = path2; path2 = t2; float *t3 = thr; thr = thr2; thr2 = t3; }
     }
-    if (lh_pt_launch_resolve(w, h, spp, 1.0f / (float)spp_total, env, (const float *)a->p_rad.p, (float *)d_rgb, s) != 0)
+    if (lh_pt_launch_resolve(w, h, spp, 1.0f / (float)spp_total, (const float *)a->p_rad.p, (float *)d_rgb, s) != 0)
         return fail("pt resolve launch failed");
     HIPCHK(hipStreamSynchronize(s));
     if (stats) { stats->paths = S; stats->rays = rays; stats->max_depth_reached = (uint64_t)depth; }
     return 0;
+}
+
+/* round-1 entry point: one diffuse reflectance for every mesh, constant environment */
+extern "C" int lh_render_pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int s0, int spp,
+                                 int spp_total, int max_vertices, float kd, const float env[3], uint64_t seed,
+                                 void *d_rgb, lh_pt_stats_t *stats, void *stream)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_render_pt_tile: accel not committed");
+    if (!cam || !d_rgb || !env) return fail("lh_render_pt_tile: NULL argument");
+    if (!(kd > 0.0f) || kd > 1.0f) return fail("lh_render_pt_tile: bad arguments");
+    lh_material_t m; memset(&m, 0, sizeof(m)); m.kd[0] = m.kd[1] = m.kd[2] = kd; m.ior = 1.0f;
+    return pt_tile(a, cam, x0, y0, w, h, s0, spp, spp_total, max_vertices, &m, env, NULL, 0, 0, 0, seed, d_rgb, stats, stream);
+}
+
+/* per-mesh materials (lh_accel_set_material) and the accelerator's environment (lh_accel_set_environment) */
+extern "C" int lh_render_pt_tile2(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int s0, int spp,
+                                  int spp_total, int max_vertices, int flags, uint64_t seed, void *d_rgb, lh_pt_stats_t *stats, void *stream)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_render_pt_tile2: accel not committed");
+    if (!cam || !d_rgb) return fail("lh_render_pt_tile2: NULL argument");
+    float one[3] = {1.0f, 1.0f, 1.0f};
+    const float *rgb = (a->env.rgb[0] != 0.0f || a->env.rgb[1] != 0.0f || a->env.rgb[2] != 0.0f || a->d_env_map) ? a->env.rgb : one;
+    return pt_tile(a, cam, x0, y0, w, h, s0, spp, spp_total, max_vertices, NULL, rgb, a->d_env_map, a->env.width, a->env.height, flags,
+                   seed, d_rgb, stats, stream);
 }
 
 /* ------------------------------------------------------------------------ */

@@ -20,7 +20,9 @@ ri_geom_t *ri_geom_new(void) { return (ri_geom_t *)calloc(1, sizeof(ri_geom_t));
 void ri_geom_free(ri_geom_t *g)
 {
     if (!g) return;
-    free(g->positions); free(g->normals); free(g->indices); free(g);
+    free(g->positions); free(g->normals); free(g->indices);
+    free(g->tangents); free(g->binormals); free(g->colors); free(g->texcoords); free(g->texcoords_unshared);
+    free(g);
 }
 
 static void *dup_bytes(const void *src, size_t n)
@@ -43,6 +45,42 @@ void ri_geom_add_normals(ri_geom_t *g, unsigned int n, const ri_vector_t *p)
     if (!g || n == 0 || !p) return;
     free(g->normals);
     g->normals = (ri_vector_t *)dup_bytes(p, sizeof(ri_vector_t) * n); g->nnormals = n;
+}
+
+/* geom.c:123-290: the optional attributes ri_intersection_state_build interpolates */
+void ri_geom_add_tangents(ri_geom_t *g, unsigned int n, const ri_vector_t *p)
+{
+    if (!g || n == 0 || !p) return;
+    free(g->tangents);
+    g->tangents = (ri_vector_t *)dup_bytes(p, sizeof(ri_vector_t) * n); g->ntangents = n;
+}
+
+void ri_geom_add_binormals(ri_geom_t *g, unsigned int n, const ri_vector_t *p)
+{
+    if (!g || n == 0 || !p) return;
+    free(g->binormals);
+    g->binormals = (ri_vector_t *)dup_bytes(p, sizeof(ri_vector_t) * n); g->nbinormals = n;
+}
+
+void ri_geom_add_colors(ri_geom_t *g, unsigned int n, const ri_vector_t *p)
+{
+    if (!g || n == 0 || !p) return;
+    free(g->colors);
+    g->colors = (ri_vector_t *)dup_bytes(p, sizeof(ri_vector_t) * n); g->ncolors = n;
+}
+
+void ri_geom_add_texcoords(ri_geom_t *g, unsigned int n, const ri_float_t *st)
+{
+    if (!g || n == 0 || !st) return;
+    free(g->texcoords);
+    g->texcoords = (ri_float_t *)dup_bytes(st, sizeof(ri_float_t) * 2 * n); g->ntexcoords = n;
+}
+
+void ri_geom_add_texcoords_unshared(ri_geom_t *g, unsigned int n, const ri_float_t *st)
+{
+    if (!g || n == 0 || !st) return;
+    free(g->texcoords_unshared);
+    g->texcoords_unshared = (ri_float_t *)dup_bytes(st, sizeof(ri_float_t) * 2 * n); g->ntexcoords = n;
 }
 
 void ri_geom_add_indices(ri_geom_t *g, unsigned int n, const unsigned int *idx)
@@ -149,6 +187,14 @@ void *ri_hipbvh_build(const void *data)
             fprintf(stderr, "[lucille_hip] ERROR : (HIPBVH) %s\n", lh_last_error());
             ri_hipbvh_free(h); return NULL;
         }
+        /* the attributes of the geom go along, so that the device-side epilogue (lh_accel_state_build_*, the tile
+         * pipelines) interpolates what ri_intersection_state_build would */
+        if (geom->normals || geom->two_side) lh_accel_set_normals(h->lh, g, (const double *)geom->normals, sizeof(ri_vector_t), geom->two_side);
+        if (geom->colors) lh_accel_set_attribute(h->lh, g, LH_ATTR_COLOR, (const double *)geom->colors, sizeof(ri_vector_t), geom->ncolors);
+        if (geom->tangents) lh_accel_set_attribute(h->lh, g, LH_ATTR_TANGENT, (const double *)geom->tangents, sizeof(ri_vector_t), geom->ntangents);
+        if (geom->binormals) lh_accel_set_attribute(h->lh, g, LH_ATTR_BINORMAL, (const double *)geom->binormals, sizeof(ri_vector_t), geom->nbinormals);
+        if (geom->texcoords) lh_accel_set_attribute(h->lh, g, LH_ATTR_TEXCOORD, geom->texcoords, 2 * sizeof(ri_float_t), geom->npositions);
+        else if (geom->texcoords_unshared) lh_accel_set_attribute(h->lh, g, LH_ATTR_TEXCOORD_UNSHARED, geom->texcoords_unshared, 2 * sizeof(ri_float_t), geom->nindices);
     }
     if (lh_accel_commit(h->lh, 0) != 0) {
         fprintf(stderr, "[lucille_hip] ERROR : (HIPBVH) %s\n", lh_last_error());
@@ -456,10 +502,31 @@ void ri_intersection_state_build(ri_intersection_state_t *st, const ri_vector_t 
     } else {
         memcpy(st->Ns, st->Ng, sizeof(ri_vector_t));
     }
-    ortho_basis(basis, st->Ng);
-    memcpy(st->tangent, basis[0], sizeof(ri_vector_t));
-    memcpy(st->binormal, basis[1], sizeof(ri_vector_t));
-    st->color[0] = st->color[1] = st->color[2] = 1.0; st->color[3] = 0.0;
-    st->stqr[0] = st->stqr[1] = 0.0;
+    if (geom->normals && geom->tangents && geom->binormals) {     /* :161-176: only looked at next to normals */
+        const double w = 1.0 - u - v;
+        for (k = 0; k < 3; k++) {
+            double a = geom->tangents[i0][k] * w, b = geom->tangents[i1][k] * u, c = geom->tangents[i2][k] * v;
+            st->tangent[k] = (a + b) + c;
+            a = geom->binormals[i0][k] * w; b = geom->binormals[i1][k] * u; c = geom->binormals[i2][k] * v;
+            st->binormal[k] = (a + b) + c;
+        }
+    } else {
+        ortho_basis(basis, st->Ng);
+        memcpy(st->tangent, basis[0], sizeof(ri_vector_t));
+        memcpy(st->binormal, basis[1], sizeof(ri_vector_t));
+    }
+    if (geom->colors) {                                            /* :188-200 */
+        const double w = 1.0 - u - v;
+        for (k = 0; k < 3; k++) { double a = geom->colors[i0][k] * w, b = geom->colors[i1][k] * u, c = geom->colors[i2][k] * v; st->color[k] = (a + b) + c; }
+    } else { st->color[0] = st->color[1] = st->color[2] = 1.0; }
+    st->color[3] = geom->colors ? 0.0 : 1.0;                       /* ri_vector_set1(defcol, 1.0) sets all four */
+    if (geom->texcoords) {                                         /* :210-231, lerp_uv :266-280 */
+        const ri_float_t *a = &geom->texcoords[2 * i0], *b = &geom->texcoords[2 * i1], *c = &geom->texcoords[2 * i2];
+        st->stqr[0] = (1 - u - v) * a[0] + u * b[0] + v * c[0]; st->stqr[1] = (1 - u - v) * a[1] + u * b[1] + v * c[1];
+    } else if (geom->texcoords_unshared) {
+        const ri_float_t *a = &geom->texcoords_unshared[2 * (index + 0)], *b = &geom->texcoords_unshared[2 * (index + 1)],
+                         *c = &geom->texcoords_unshared[2 * (index + 2)];
+        st->stqr[0] = (1 - u - v) * a[0] + u * b[0] + v * c[0]; st->stqr[1] = (1 - u - v) * a[1] + u * b[1] + v * c[1];
+    } else st->stqr[0] = st->stqr[1] = 0.0;
     st->inside = (geom->two_side && index >= geom->nindices / 2) ? 1 : 0;
 }

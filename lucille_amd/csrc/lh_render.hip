@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/lucille_hip.h"
 #include "lh_device.h"
@@ -275,21 +276,121 @@ __global__ void k_ao_resolve(int w, int h, int xs, int ys, int N, const uint32_t
 }
 
 
+/* ---- the whole hit epilogue for a batch of hit records --------------------------------------
+ * ri_intersection_state_build (intersection_state.c:99-248), every member a shader reads: P, Ng, Ns, tangent,
+ * binormal, colour, st, I (normalised direction), inside.  Attributes are per-primitive SoA arrays in
+ * primitive-id order (9 doubles = 3 corners x xyz; st: 6 doubles; first value NaN = the mesh has none):
+ * one thread per ray, LH_STATE_DOUBLES per record, misses are left untouched. */
+__global__ void k_state_build(size_t n, const lh_dev_scene_t sc, const double *__restrict__ nrm9, const double *__restrict__ col9,
+                              const double *__restrict__ tan9, const double *__restrict__ bin9, const double *__restrict__ st6,
+                              const uint8_t *__restrict__ inside_of_prim,
+                              const double *__restrict__ org, const double *__restrict__ dir, const uint32_t *__restrict__ prim,
+                              const double *__restrict__ t, const double *__restrict__ u, const double *__restrict__ v,
+                              double *__restrict__ state)
+{
+    LH_NC
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = prim[i];
+    if (p == LH_MISS_PRIM) return;
+    const double *tv = (const double *)sc.tri64 + 9 * (size_t)p;
+    const double tt = t[i], uu = u[i], vv = v[i], w = 1.0 - uu - vv;
+    double *o = state + LH_STATE_DOUBLES * i;
+    double Ng[3], v01[3], v02[3], I[3];
+    for (int k = 0; k < 3; k++) { o[k] = org[3 * i + k] + dir[3 * i + k] * tt; I[k] = dir[3 * i + k]; }
+    vnormalize(I);
+    for (int k = 0; k < 3; k++) { v01[k] = tv[3 + k] - tv[k]; v02[k] = tv[6 + k] - tv[k]; }
+    vcross(Ng, v01, v02); vnormalize(Ng);
+    bool has_n = false, has_tb = false;
+    if (nrm9) { const double x = nrm9[9 * (size_t)p]; has_n = (x == x); }
+    if (has_n && tan9 && bin9) { const double x = tan9[9 * (size_t)p], y = bin9[9 * (size_t)p]; has_tb = (x == x) && (y == y); }
+#define LH_LERP9(A, dst) { const double *q_ = (A) + 9 * (size_t)p; \
+        for (int k = 0; k < 3; k++) { const double a_ = q_[k] * w, b_ = q_[3 + k] * uu, c_ = q_[6 + k] * vv; (dst)[k] = (a_ + b_) + c_; } }
+    for (int k = 0; k < 3; k++) o[3 + k] = Ng[k];
+    if (has_n) LH_LERP9(nrm9, o + 6) else for (int k = 0; k < 3; k++) o[6 + k] = Ng[k];
+    if (has_tb) { LH_LERP9(tan9, o + 9) LH_LERP9(bin9, o + 12) }
+    else {
+        /* ri_ortho_basis(tmpbasis, Ng) (reflection.c:311-333) */
+        double b0[3], b1[3] = {0.0, 0.0, 0.0};
+        int ax = 3;
+        for (int k = 0; k < 3; k++) if (Ng[k] < 0.6 && Ng[k] > -0.6) { ax = k; break; }
+        if (ax >= 3) ax = 0;
+        b1[ax] = 1.0;
+        vcross(b0, b1, Ng); vnormalize(b0);
+        vcross(b1, Ng, b0); vnormalize(b1);
+        for (int k = 0; k < 3; k++) { o[9 + k] = b0[k]; o[12 + k] = b1[k]; }
+    }
+    bool has_c = false, has_st = false;
+    if (col9) { const double x = col9[9 * (size_t)p]; has_c = (x == x); }
+    if (has_c) LH_LERP9(col9, o + 15) else { o[15] = 1.0; o[16] = 1.0; o[17] = 1.0; }
+    if (st6) { const double x = st6[6 * (size_t)p]; has_st = (x == x); }
+    if (has_st) {
+        /* lerp_uv (intersection_state.c:58-76): (1-u-v) st0 + u st1 + v st2 */
+        const double *q = st6 + 6 * (size_t)p;
+        o[18] = (w * q[0] + uu * q[2]) + vv * q[4];
+        o[19] = (w * q[1] + uu * q[3]) + vv * q[5];
+    } else { o[18] = 0.0; o[19] = 0.0; }
+    for (int k = 0; k < 3; k++) o[20 + k] = I[k];
+    o[23] = (inside_of_prim && inside_of_prim[p]) ? 1.0 : 0.0;
+#undef LH_LERP9
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* wavefront path tracer (BASELINE config 4)                                */
 /*                                                                                       */
-/* The reference's Kajiya path tracer (src/transport/pathtrace.c:131-314,407-537) is dead */
-/* code that no longer compiles; what is kept from it is its documented structure:       */
-/* camera sample -> ri_raytrace; miss -> background radiance; hit -> Russian roulette on   */
-/* the material's reflectance, cosine-sampled diffuse bounce from P (offset along the      */
-/* normal), throughput *= bsdf/pdf, repeat to a vertex limit; a path that leaves the       */
-/* scene collects the environment radiance.  Materials: one diffuse reflectance kd;        */
-/* environment: constant radiance.  Parity for this row is at the ri_raytrace level (every */
-/* bounce goes through the same closest-hit kernel and fp64 resolve); the image is checked */
-/* by a furnace test and convergence, not against the reference.                           */
+/* The reference's Kajiya path tracer (src/transport/pathtrace.c) is dead code that no     */
+/* longer compiles; what is kept is its documented algorithm (pathtrace.c:189-314,407-537) */
+/* re-expressed as closest-hit batches:                                                    */
+/*   camera sample through a random sub-pixel position (sample_pixel :316-352);            */
+/*   miss -> the IBL radiance in the ray's direction (ri_texture_ibl_fetch, texture.c:     */
+/*   238-276: angular map, bilinear) or a constant environment;                            */
+/*   hit  -> Russian roulette on d + s + t = the averages of the material's kd, ks, kt     */
+/*   (russian_roulette :407-430), reflection type D / S / T drawn in those proportions     */
+/*   (sample_reflection_type :432-459), next direction: cosine-weighted about the normal   */
+/*   (sample_cosweight :500-531), mirror reflection (ri_reflect) or refraction with the    */
+/*   material's ior, entering / leaving tracked per path, total internal reflection turns  */
+/*   T into S (sample_outdir :461-498, ri_refract reflection.c:69-128); throughput *=      */
+/*   reflectance x the interpolated vertex colour (brdf :533-565), to a vertex limit.      */
+/* Two departures, both stated in DESIGN.md: (1) the reference multiplies the BRDF value    */
+/* (kd / pi ...) without the cosine / pdf factor and never compensates the roulette: the    */
+/* default here is the unbiased estimator of the same sampling scheme (a furnace renders    */
+/* white), LH_PT_REFERENCE_WEIGHTS reproduces the reference's factors; (2) its final        */
+/* "connect" step (one more sampled direction + visibility ray, light_sample :354-382) is   */
+/* what the extension ray already is in wavefront form: a path that leaves the scene        */
+/* collects the environment in the direction it left.  Parity for this row is at the        */
+/* ri_raytrace level (every bounce goes through the closest-hit kernel and fp64 resolve).   */
 /* ------------------------------------------------------------------------------------ */
 
 __device__ __forceinline__ double rnd01(uint64_t key) { return (double)mix32(key) * 2.3283064365386963e-10; }
+
+struct DevMaterial { float kd[3], ks[3], kt[3], ior; };
+struct DevEnv { float rgb[3]; const float4 *map; int w, h; };
+
+/* ri_texture_ibl_fetch (texture.c:238-276) + ri_texture_fetch's bilinear filter (:86-180) */
+__device__ __forceinline__ void env_fetch(const DevEnv &e, double dx, double dy, double dz, float out[3])
+{
+    if (!e.map) { out[0] = e.rgb[0]; out[1] = e.rgb[1]; out[2] = e.rgb[2]; return; }
+    double d[3] = {dx, dy, dz};
+    vnormalize(d);
+    const double pi = 3.1415926535;
+    double r = (d[2] >= -1.0 && d[2] < 1.0) ? (1.0 / pi) * acos(d[2]) : 0.0;
+    const double n2 = d[0] * d[0] + d[1] * d[1];
+    if (n2 > 1.0e-6) r /= sqrt(n2);
+    double u = 0.5 * (d[0] * r) + 0.5, v = 0.5 - 0.5 * (d[1] * r);
+    u -= floor(u); v -= floor(v);
+    if (u < 0.0) u = 0.0; if (u >= 1.0) u = 1.0;
+    if (v < 0.0) v = 0.0; if (v >= 1.0) v = 1.0;
+    const double px = u * (e.w - 1), py = v * (e.h - 1);
+    int x = (int)px, y = (int)py;
+    const double fx = px - x, fy = py - y;
+    const int x1 = x < e.w - 1 ? x + 1 : x, y1 = y < e.h - 1 ? y + 1 : y;
+    const float4 t00 = e.map[(size_t)y * e.w + x], t01 = e.map[(size_t)y1 * e.w + x];
+    const float4 t10 = e.map[(size_t)y * e.w + x1], t11 = e.map[(size_t)y1 * e.w + x1];
+    const double w0 = (1.0 - fx) * (1.0 - fy), w1 = (1.0 - fx) * fy, w2 = fx * (1.0 - fy), w3 = fx * fy;
+    out[0] = (float)(w0 * t00.x + w1 * t01.x + w2 * t10.x + w3 * t11.x) * e.rgb[0];
+    out[1] = (float)(w0 * t00.y + w1 * t01.y + w2 * t10.y + w3 * t11.y) * e.rgb[1];
+    out[2] = (float)(w0 * t00.z + w1 * t01.z + w2 * t10.z + w3 * t11.z) * e.rgb[2];
+}
 
 /* one thread per path: path id = (pixel * spp + s); primary camera ray through a random
  * sub-pixel position (sample_pixel, pathtrace.c:316-352) */
@@ -319,64 +420,124 @@ __global__ void k_pt_primary(DevCamera cam, int x0, int y0, int w, int h, int sp
     vnormalize(d);
     org[3 * id] = pos[0]; org[3 * id + 1] = pos[1]; org[3 * id + 2] = pos[2];
     dir[3 * id] = d[0]; dir[3 * id + 1] = d[1]; dir[3 * id + 2] = d[2];
-    path_of[id] = (uint32_t)id;
-    thr[id] = 1.0f;
+    path_of[id] = (uint32_t)id;                      /* bit 31: the path is inside a refractive object */
+    thr[3 * id] = 1.0f; thr[3 * id + 1] = 1.0f; thr[3 * id + 2] = 1.0f;
 }
 
+#define LH_PT_INTERIOR 0x80000000u
+
 /* one thread per live path after the closest-hit launch of bounce `depth`:
- *   miss            -> radiance[path] = throughput (x environment, applied at resolve); path ends
- *   hit, depth/RR   -> path ends with 0
- *   hit, survives   -> next ray: cosine-sampled about the shading normal facing the viewer   */
-__global__ void k_pt_shade(size_t n, const lh_dev_scene_t sc, const double *__restrict__ nrm9, int depth, int max_depth,
-                           float kd, unsigned long long seed, int s0, int spp, int x0, int y0, int w, int full_width,
+ *   miss            -> radiance[path] = throughput x environment(dir); the path ends
+ *   hit, depth/RR   -> the path ends with 0
+ *   hit, survives   -> next ray by the sampled reflection type D / S / T */
+__global__ void k_pt_shade(size_t n, const lh_dev_scene_t sc, const double *__restrict__ nrm9, const double *__restrict__ col9,
+                           const uint32_t *__restrict__ prim_mesh, const DevMaterial *__restrict__ materials,
+                           const DevMaterial override_mat, int use_override, const DevEnv env, int ref_weights,
+                           int depth, int max_depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w, int full_width,
                            double *__restrict__ org, double *__restrict__ dir,
                            const uint32_t *__restrict__ prim, const double *__restrict__ t, const double *__restrict__ u,
-                           const double *__restrict__ v, const uint32_t *__restrict__ path_of, float *__restrict__ thr,
+                           const double *__restrict__ v, uint32_t *__restrict__ path_of, float *__restrict__ thr,
                            float *__restrict__ radiance, uint8_t *__restrict__ alive)
 {
     LH_NC
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t path = path_of[i];
+    const uint32_t pword = path_of[i];
+    const uint32_t path = pword & ~LH_PT_INTERIOR;
     const uint32_t p = prim[i];
-    if (p == LH_MISS_PRIM) { radiance[path] = thr[i]; alive[i] = 0; return; }
+    float G[3] = {thr[3 * i], thr[3 * i + 1], thr[3 * i + 2]};
+    double D[3] = {dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]};
+    if (p == LH_MISS_PRIM) {
+        float e[3];
+        env_fetch(env, D[0], D[1], D[2], e);
+        radiance[3 * (size_t)path] = G[0] * e[0]; radiance[3 * (size_t)path + 1] = G[1] * e[1]; radiance[3 * (size_t)path + 2] = G[2] * e[2];
+        alive[i] = 0; return;
+    }
     const size_t pix = path / (uint32_t)spp;
     const uint64_t gx = (uint64_t)(x0 + (int)(pix % (size_t)w)), gy = (uint64_t)(y0 + (int)(pix / (size_t)w));
     const uint64_t key = (seed * 0x9E3779B97F4A7C15ULL) ^ (((gy * (uint64_t)full_width + gx) << 20) + (uint64_t)(s0 + (int)(path % (uint32_t)spp))) * 64ull
                          + 4ull * (uint64_t)(depth + 1);
-    /* Russian roulette on the reflectance (russian_roulette, pathtrace.c:407-430); with survival
-     * probability kd and a cosine pdf the diffuse throughput is unchanged */
-    if (depth + 2 >= max_depth || rnd01(key) >= (double)kd) { radiance[path] = 0.0f; alive[i] = 0; return; }
+    const DevMaterial M = use_override ? override_mat : materials[prim_mesh[p]];
+    const double kd_ = (M.kd[0] + M.kd[1] + M.kd[2]) / 3.0, ks_ = (M.ks[0] + M.ks[1] + M.ks[2]) / 3.0, kt_ = (M.kt[0] + M.kt[1] + M.kt[2]) / 3.0;
+    const double ksum = kd_ + ks_ + kt_;
+    /* vertex limit, then Russian roulette on d + s + t (russian_roulette, pathtrace.c:407-430) */
+    if (depth + 2 >= max_depth || !(ksum > 0.0) || rnd01(key) > ksum) {
+        radiance[3 * (size_t)path] = 0.0f; radiance[3 * (size_t)path + 1] = 0.0f; radiance[3 * (size_t)path + 2] = 0.0f;
+        alive[i] = 0; return;
+    }
+    /* ri_intersection_state_build subset: P, Ng, Ns, colour */
     const double *tv = (const double *)sc.tri64 + 9 * (size_t)p;
-    const double tt = t[i], uu = u[i], vv = v[i];
-    double P[3], Ng[3], Ns[3], v01[3], v02[3], D[3];
-    for (int k = 0; k < 3; k++) { D[k] = dir[3 * i + k]; P[k] = org[3 * i + k] + D[k] * tt; }
+    const double tt = t[i], uu = u[i], vv = v[i], wgt = 1.0 - uu - vv;
+    double P[3], Ng[3], Ns[3], v01[3], v02[3];
+    for (int k = 0; k < 3; k++) P[k] = org[3 * i + k] + D[k] * tt;
     for (int k = 0; k < 3; k++) { v01[k] = tv[3 + k] - tv[k]; v02[k] = tv[6 + k] - tv[k]; }
     vcross(Ng, v01, v02); vnormalize(Ng);
     bool has_n = false;
     if (nrm9) { const double n0x = nrm9[9 * (size_t)p]; has_n = (n0x == n0x); }
     if (has_n) {
-        const double *nn = nrm9 + 9 * (size_t)p; const double wgt = 1.0 - uu - vv;
+        const double *nn = nrm9 + 9 * (size_t)p;
         for (int k = 0; k < 3; k++) { const double a = nn[k] * wgt, b = nn[3 + k] * uu, c = nn[6 + k] * vv; Ns[k] = (a + b) + c; }
         vnormalize(Ns);
     } else { Ns[0] = Ng[0]; Ns[1] = Ng[1]; Ns[2] = Ng[2]; }
-    if (Ns[0] * D[0] + Ns[1] * D[1] + Ns[2] * D[2] > 0.0) { Ns[0] = -Ns[0]; Ns[1] = -Ns[1]; Ns[2] = -Ns[2]; }
-    double b0[3], b1[3] = {0.0, 0.0, 0.0};
-    int ax = 3;
-    for (int k = 0; k < 3; k++) if (Ns[k] < 0.6 && Ns[k] > -0.6) { ax = k; break; }
-    if (ax >= 3) ax = 0;
-    b1[ax] = 1.0;
-    vcross(b0, b1, Ns); vnormalize(b0);
-    vcross(b1, Ns, b0); vnormalize(b1);
-    const double z0 = rnd01(key + 1), z1 = rnd01(key + 2);
-    const double ct = sqrt(z0), phi = 2.0 * 3.14159265358979323846 * z1;
-    double sp, cp;
-    sincos(phi, &sp, &cp);
-    const double d0 = cp * ct, d1 = sp * ct, d2 = sqrt(1.0 - ct * ct);     /* cosine lobe, as calculate_occlusion samples it */
-    for (int k = 0; k < 3; k++) {
-        org[3 * i + k] = P[k] + Ns[k] * 1.0e-6;
-        dir[3 * i + k] = d0 * b0[k] + d1 * b1[k] + d2 * Ns[k];
+    float col[3] = {1.0f, 1.0f, 1.0f};
+    if (col9) {
+        const double *cc = col9 + 9 * (size_t)p;
+        if (cc[0] == cc[0]) for (int k = 0; k < 3; k++) { const double a = cc[k] * wgt, b = cc[3 + k] * uu, c = cc[6 + k] * vv; col[k] = (float)((a + b) + c); }
     }
+    /* the normal facing the incoming ray */
+    const bool back = Ns[0] * D[0] + Ns[1] * D[1] + Ns[2] * D[2] > 0.0;
+    double N[3] = {back ? -Ns[0] : Ns[0], back ? -Ns[1] : Ns[1], back ? -Ns[2] : Ns[2]};
+    /* reflection type (sample_reflection_type, pathtrace.c:432-459) */
+    const double rt = rnd01(key + 3) * ksum;
+    int type = rt < kd_ ? 0 : (rt < kd_ + ks_ ? 1 : 2);
+    uint32_t interior = pword & LH_PT_INTERIOR;
+    double O[3];
+    double side = 1.0;                          /* which side of the surface the next ray starts on */
+    if (type == 2) {
+        /* ri_refract (reflection.c:69-128) with the unit direction: eta = ior when leaving, 1 / ior when entering */
+        double In[3] = {D[0], D[1], D[2]};
+        vnormalize(In);
+        const double e = interior ? (double)M.ior : 1.0 / (double)M.ior;
+        const double cos1 = -(In[0] * N[0] + In[1] * N[1] + In[2] * N[2]);
+        const double coeff = 1.0 - (e * e) * (1.0 - cos1 * cos1);
+        if (coeff <= 0.0) type = 1;             /* total internal reflection */
+        else {
+            const double c2 = e * cos1 - sqrt(coeff);
+            for (int k = 0; k < 3; k++) O[k] = c2 * N[k] + e * In[k];
+            vnormalize(O);
+            side = -1.0;
+            interior ^= LH_PT_INTERIOR;
+        }
+    }
+    if (type == 1) {                            /* ri_reflect (reflection.c:26-50): r = in - 2 n (in . n) */
+        const double dn = D[0] * N[0] + D[1] * N[1] + D[2] * N[2];
+        for (int k = 0; k < 3; k++) O[k] = D[k] - 2.0 * dn * N[k];
+    } else if (type == 0) {                     /* sample_cosweight (pathtrace.c:500-531) about the facing normal */
+        double b0[3], b1[3] = {0.0, 0.0, 0.0};
+        int ax = 3;
+        for (int k = 0; k < 3; k++) if (N[k] < 0.6 && N[k] > -0.6) { ax = k; break; }
+        if (ax >= 3) ax = 0;
+        b1[ax] = 1.0;
+        vcross(b0, b1, N); vnormalize(b0);
+        vcross(b1, N, b0); vnormalize(b1);
+        const double z0 = rnd01(key + 1), z1 = rnd01(key + 2);
+        const double ct = sqrt(z0), phi = 2.0 * 3.14159265358979323846 * z1;
+        double sp, cp;
+        sincos(phi, &sp, &cp);
+        const double d0 = cp * ct, d1 = sp * ct, d2 = sqrt(1.0 - ct * ct);
+        for (int k = 0; k < 3; k++) O[k] = d0 * b0[k] + d1 * b1[k] + d2 * N[k];
+    }
+    /* throughput (brdf, pathtrace.c:533-565) */
+    const float *kk = type == 0 ? M.kd : (type == 1 ? M.ks : M.kt);
+    const double pk = type == 0 ? kd_ : (type == 1 ? ks_ : kt_);
+    const float wsel = ref_weights ? (type == 0 ? 0.318309886f : 1.0f) : (float)(1.0 / pk);     /* unbiased: / (P(type) x survival) */
+    for (int k = 0; k < 3; k++) {
+        G[k] *= kk[k] * col[k] * wsel;
+        thr[3 * i + k] = G[k];
+        org[3 * i + k] = P[k] + side * N[k] * 1.0e-6;
+        dir[3 * i + k] = O[k];
+    }
+    path_of[i] = path | interior;
     alive[i] = 1;
 }
 
@@ -409,21 +570,20 @@ __global__ void k_pt_compact(size_t n, const uint8_t *__restrict__ flag, const u
     uint32_t woff = 0;
     for (int k = 0; k < wv; k++) woff += wsum[k];
     const size_t j = block_offsets[blockIdx.x] + woff + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    for (int k = 0; k < 3; k++) { org2[3 * j + k] = org[3 * i + k]; dir2[3 * j + k] = dir[3 * i + k]; }
-    path_of2[j] = path_of[i]; thr2[j] = thr[i];
+    for (int k = 0; k < 3; k++) { org2[3 * j + k] = org[3 * i + k]; dir2[3 * j + k] = dir[3 * i + k]; thr2[3 * j + k] = thr[3 * i + k]; }
+    path_of2[j] = path_of[i];
 }
 
-/* per pixel: add the mean of this pass's samples (in sample order) times the environment */
-__global__ void k_pt_resolve(int w, int h, int spp, float inv_total_spp, float er, float eg, float eb,
-                             const float *__restrict__ radiance, float *__restrict__ rgb)
+/* per pixel: add the mean of this pass's samples (in sample order) */
+__global__ void k_pt_resolve(int w, int h, int spp, float inv_total_spp, const float *__restrict__ radiance, float *__restrict__ rgb)
 {
     const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= (size_t)w * h) return;
     const int lx = (int)(pix % w), ly = (int)(pix / w);
-    float sum = 0.0f;
-    for (int s = 0; s < spp; s++) sum += radiance[pix * spp + s];
+    float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+    for (int s = 0; s < spp; s++) { const float *r = radiance + 3 * (pix * spp + s); sr += r[0]; sg += r[1]; sb += r[2]; }
     float *o = rgb + 3 * ((size_t)(h - 1 - ly) * w + lx);
-    o[0] += sum * inv_total_spp * er; o[1] += sum * inv_total_spp * eg; o[2] += sum * inv_total_spp * eb;
+    o[0] += sr * inv_total_spp; o[1] += sg * inv_total_spp; o[2] += sb * inv_total_spp;
 }
 
 } /* namespace */
@@ -496,10 +656,12 @@ extern "C" int lh_pt_launch_primary(const lh_camera_t *cam, int x0, int y0, int 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-extern "C" int lh_pt_launch_shade(size_t n, const lh_dev_scene_t *sc, const double *d_nrm9, int depth, int max_depth,
-                                  float kd, unsigned long long seed, int s0, int spp, int x0, int y0, int w,
+extern "C" int lh_pt_launch_shade(size_t n, const lh_dev_scene_t *sc, const double *d_nrm9, const double *d_col9,
+                                  const uint32_t *d_prim_mesh, const void *d_materials, const lh_material_t *override_mat,
+                                  const float env_rgb[3], const void *d_env_map, int env_w, int env_h, int ref_weights,
+                                  int depth, int max_depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w,
                                   int full_width, double *d_org, double *d_dir, const uint32_t *d_prim,
-                                  const double *d_t, const double *d_u, const double *d_v, const uint32_t *d_path_of,
+                                  const double *d_t, const double *d_u, const double *d_v, uint32_t *d_path_of,
                                   float *d_thr, float *d_radiance, uint8_t *d_alive, uint32_t *d_blocks,
                                   unsigned long long *d_total, double *d_org2, double *d_dir2, uint32_t *d_path_of2,
                                   float *d_thr2, void *stream)
@@ -507,7 +669,14 @@ extern "C" int lh_pt_launch_shade(size_t n, const lh_dev_scene_t *sc, const doub
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) return 0;
     const unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_pt_shade, dim3(nb), dim3(256), 0, s, n, *sc, d_nrm9, depth, max_depth, kd, seed, s0, spp, x0, y0, w,
+    DevMaterial om;
+    memset(&om, 0, sizeof(om));
+    if (override_mat) { for (int k = 0; k < 3; k++) { om.kd[k] = override_mat->kd[k]; om.ks[k] = override_mat->ks[k]; om.kt[k] = override_mat->kt[k]; } om.ior = override_mat->ior; }
+    DevEnv env;
+    env.rgb[0] = env_rgb[0]; env.rgb[1] = env_rgb[1]; env.rgb[2] = env_rgb[2];
+    env.map = (const float4 *)d_env_map; env.w = env_w; env.h = env_h;
+    hipLaunchKernelGGL(k_pt_shade, dim3(nb), dim3(256), 0, s, n, *sc, d_nrm9, d_col9, d_prim_mesh, (const DevMaterial *)d_materials, om,
+                       override_mat != NULL, env, ref_weights, depth, max_depth, seed, s0, spp, x0, y0, w,
                        full_width, d_org, d_dir, d_prim, d_t, d_u, d_v, d_path_of, d_thr, d_radiance, d_alive);
     hipLaunchKernelGGL(k_flag_count, dim3(nb), dim3(256), 0, s, n, d_alive, d_blocks);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, nb, d_blocks, d_total);
@@ -516,12 +685,22 @@ extern "C" int lh_pt_launch_shade(size_t n, const lh_dev_scene_t *sc, const doub
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-extern "C" int lh_pt_launch_resolve(int w, int h, int spp, float inv_total_spp, const float env[3],
-                                    const float *d_radiance, float *d_rgb, void *stream)
+extern "C" int lh_pt_launch_resolve(int w, int h, int spp, float inv_total_spp, const float *d_radiance, float *d_rgb, void *stream)
 {
     const size_t total = (size_t)w * h;
     if (total == 0) return 0;
     hipLaunchKernelGGL(k_pt_resolve, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       w, h, spp, inv_total_spp, env[0], env[1], env[2], d_radiance, d_rgb);
+                       w, h, spp, inv_total_spp, d_radiance, d_rgb);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int lh_render_launch_state_build(size_t n, const lh_dev_scene_t *sc, const double *d_nrm9, const double *d_col9,
+                                            const double *d_tan9, const double *d_bin9, const double *d_st6, const uint8_t *d_inside,
+                                            const double *d_org, const double *d_dir, const uint32_t *d_prim, const double *d_t,
+                                            const double *d_u, const double *d_v, double *d_state, void *stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_state_build, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, *sc, d_nrm9, d_col9,
+                       d_tan9, d_bin9, d_st6, d_inside, d_org, d_dir, d_prim, d_t, d_u, d_v, d_state);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

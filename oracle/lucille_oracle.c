@@ -73,6 +73,8 @@ typedef struct {
     uint32_t *idx;
     double  *nrm;   /* optional vertex normals xyz (geom->normals) */
     int      two_side;
+    double  *attr[5]; /* optional: colors, tangents, binormals (xyz per vertex), texcoords (st per vertex),
+                         texcoords_unshared (st per index) -- geom.h:34-48 */
 } lo_mesh_t;
 
 struct lo_scene {
@@ -108,7 +110,11 @@ void lo_scene_free(lo_scene_t *s)
 {
     uint32_t i;
     if (!s) return;
-    for (i = 0; i < s->nmeshes; i++) { free(s->meshes[i].pos); free(s->meshes[i].idx); free(s->meshes[i].nrm); }
+    for (i = 0; i < s->nmeshes; i++) {
+        int k;
+        free(s->meshes[i].pos); free(s->meshes[i].idx); free(s->meshes[i].nrm);
+        for (k = 0; k < 5; k++) free(s->meshes[i].attr[k]);
+    }
     free(s->meshes);
     free_tree(s);
     free(s);
@@ -121,6 +127,7 @@ int lo_scene_add_mesh(lo_scene_t *s, uint32_t npos, const double *pos,
     s->meshes = (lo_mesh_t *)realloc(s->meshes, sizeof(lo_mesh_t) * (s->nmeshes + 1));
     m = &s->meshes[s->nmeshes++];
     m->npos = npos; m->nidx = nidx; m->nrm = NULL; m->two_side = 0;
+    memset(m->attr, 0, sizeof(m->attr));
     m->pos = (double *)malloc(sizeof(double) * 3 * (npos ? npos : 1));
     m->idx = (uint32_t *)malloc(sizeof(uint32_t) * (nidx ? nidx : 1));
     memcpy(m->pos, pos, sizeof(double) * 3 * npos);
@@ -140,6 +147,37 @@ int lo_scene_set_normals(lo_scene_t *s, uint32_t mesh, const double *normals_xyz
     }
     m->two_side = two_side;
     return 0;
+}
+
+/* optional attributes of a mesh (ri_geom_add_colors / _tangents / _binormals / _texcoords /
+ * _texcoords_unshared, geom.c:123-290).  kind 0..2: xyz per vertex; 3: st per vertex; 4: st per index. */
+int lo_scene_set_attribute(lo_scene_t *s, uint32_t mesh, int kind, const double *data)
+{
+    lo_mesh_t *m; size_t n;
+    if (mesh >= s->nmeshes || kind < 0 || kind > 4) return -1;
+    m = &s->meshes[mesh];
+    free(m->attr[kind]); m->attr[kind] = NULL;
+    if (!data) return 0;
+    n = (kind <= 2) ? 3 * (size_t)m->npos : (kind == 3 ? 2 * (size_t)m->npos : 2 * (size_t)m->nidx);
+    m->attr[kind] = (double *)malloc(sizeof(double) * (n ? n : 1));
+    memcpy(m->attr[kind], data, sizeof(double) * n);
+    return 0;
+}
+
+/* the corners' attribute values of primitive `prim` (NULL where the mesh has none) */
+void lo_priv_prim_attributes(const lo_scene_t *s, uint32_t prim, const double *a[5][3])
+{
+    const lo_tri_t *t = &s->tris_orig[prim];
+    const lo_mesh_t *m = &s->meshes[t->geom];
+    uint32_t i[3]; int k, c;
+    for (c = 0; c < 3; c++) i[c] = m->idx[t->index + c];
+    for (k = 0; k < 5; k++)
+        for (c = 0; c < 3; c++) {
+            if (!m->attr[k]) a[k][c] = NULL;
+            else if (k <= 2) a[k][c] = &m->attr[k][3 * (size_t)i[c]];
+            else if (k == 3) a[k][c] = &m->attr[k][2 * (size_t)i[c]];
+            else a[k][c] = &m->attr[k][2 * (size_t)(t->index + c)];
+        }
 }
 
 /* ---------------------------------------------------------------- build */

@@ -129,6 +129,10 @@ void lo_ortho_basis(double basis[3][3], const double n[3]);
 void lo_state_build(const lo_scene_t *scene, uint32_t prim, double t, double u, double v,
                     const double org[3], const double dir[3],
                     double P[3], double Ng[3], double Ns[3], int *inside);
+int  lo_scene_set_attribute(lo_scene_t *scene, uint32_t mesh, int kind, const double *data);
+void lo_state_build_full(const lo_scene_t *scene, uint32_t prim, double t, double u, double v,
+                         const double org[3], const double dir[3], double state24[24]);
+void lo_state_batch(const lo_scene_t *scene, size_t n, const double *org_xyz, const double *dir_xyz, uint32_t *prim, double *state24);
 void lo_ao_rays(const double P[3], const double Ns[3], uint32_t ntheta, uint32_t nphi,
                 const double *rnd, double *org_xyz, double *dir_xyz);
 void lo_mt_stream(unsigned long seed, size_t n, double *out);

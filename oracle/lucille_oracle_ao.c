@@ -210,6 +210,56 @@ void lo_state_build(const lo_scene_t *s, uint32_t prim, double t, double u, doub
     if (inside) *inside = (two_side && index >= nindices / 2) ? 1 : 0;
 }
 
+void lo_priv_prim_attributes(const lo_scene_t *s, uint32_t prim, const double *a[5][3]);
+
+/* the whole ri_intersection_state_build (intersection_state.c:99-248): state24 = P[3] Ng[3] Ns[3] tangent[3]
+ * binormal[3] color[3] st[2] I[3] inside -- the layout of the product's LH_STATE_DOUBLES record */
+void lo_state_build_full(const lo_scene_t *s, uint32_t prim, double t, double u, double v,
+                         const double org[3], const double dir[3], double state24[24])
+{
+    const double *a[5][3]; double P[3], Ng[3], Ns[3], I[3], basis[3][3]; int inside, k;
+    const double w = 1.0 - u - v;
+    lo_state_build(s, prim, t, u, v, org, dir, P, Ng, Ns, &inside);
+    lo_priv_prim_attributes(s, prim, a);
+    for (k = 0; k < 3; k++) { state24[k] = P[k]; state24[3 + k] = Ng[k]; state24[6 + k] = Ns[k]; I[k] = dir[k]; }
+    vnormalize(I);
+    {
+        const double *n0, *n1, *n2, *v0, *v1, *v2; int two; uint32_t index, nind;
+        lo_priv_prim_vertices(s, prim, &v0, &v1, &v2, &n0, &n1, &n2, &two, &index, &nind);
+        if (n0 && a[1][0] && a[2][0]) {          /* tangents AND binormals, only looked at when normals exist (:161-176) */
+            for (k = 0; k < 3; k++) {
+                double x = a[1][0][k] * w, y = a[1][1][k] * u, z = a[1][2][k] * v; state24[9 + k] = (x + y) + z;
+                x = a[2][0][k] * w; y = a[2][1][k] * u; z = a[2][2][k] * v; state24[12 + k] = (x + y) + z;
+            }
+        } else {
+            lo_ortho_basis(basis, Ng);
+            for (k = 0; k < 3; k++) { state24[9 + k] = basis[0][k]; state24[12 + k] = basis[1][k]; }
+        }
+    }
+    if (a[0][0]) for (k = 0; k < 3; k++) { double x = a[0][0][k] * w, y = a[0][1][k] * u, z = a[0][2][k] * v; state24[15 + k] = (x + y) + z; }
+    else { state24[15] = 1.0; state24[16] = 1.0; state24[17] = 1.0; }
+    if (a[3][0] || a[4][0]) {                    /* shared texcoords win over unshared (:210-224); lerp_uv :266-280 */
+        const int kk = a[3][0] ? 3 : 4;
+        state24[18] = (1 - u - v) * a[kk][0][0] + u * a[kk][1][0] + v * a[kk][2][0];
+        state24[19] = (1 - u - v) * a[kk][0][1] + u * a[kk][1][1] + v * a[kk][2][1];
+    } else { state24[18] = 0.0; state24[19] = 0.0; }
+    for (k = 0; k < 3; k++) state24[20 + k] = I[k];
+    state24[23] = (double)inside;
+}
+
+/* closest hit + full state of n rays; misses leave zeros */
+void lo_state_batch(const lo_scene_t *s, size_t n, const double *org, const double *dir, uint32_t *prim, double *state24)
+{
+    size_t i;
+    for (i = 0; i < n; i++) {
+        uint32_t p; double t, u, v;
+        memset(state24 + 24 * i, 0, 24 * sizeof(double));
+        lo_intersect_batch(s, 1, org + 3 * i, dir + 3 * i, &p, &t, &u, &v, NULL, 1);
+        prim[i] = p;
+        if (p != 0xFFFFFFFFu) lo_state_build_full(s, p, t, u, v, org + 3 * i, dir + 3 * i, state24 + 24 * i);
+    }
+}
+
 /* AO rays of one shading point (calculate_occlusion, ambientocclusion.c:42-151).
  * rnd = 2*ntheta*nphi numbers in consumption order (z0 then z1, i fastest). */
 void lo_ao_rays(const double P[3], const double Ns[3], uint32_t ntheta, uint32_t nphi,

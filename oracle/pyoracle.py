@@ -112,6 +112,8 @@ def lib():
         L.lo_render_ao.restype = C.c_size_t
         L.lo_render_ao.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.POINTER(C.c_float), _dp, _dp, _u32p, _dp, _dp, _dp, C.c_size_t]
+        L.lo_scene_set_attribute.argtypes = [C.c_void_p, C.c_uint32, C.c_int, _dp]
+        L.lo_state_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _u32p, _dp]
         L.lo_soup_triangles.argtypes = [_u64p, C.c_uint32, C.c_double, _dp, _u32p]
         L.lo_soup_rays.argtypes = [_u64p, C.c_size_t, _dp, _dp]
         _lib = L
@@ -160,6 +162,18 @@ class Oracle:
     def set_normals(self, mesh, normals, two_side=0):
         N = _c(normals, np.float64).reshape(-1, 3) if normals is not None else None
         self.L.lo_scene_set_normals(self.h, mesh, _p(N, _dp), int(two_side))
+
+    def set_attribute(self, mesh, kind, data):
+        """kind 0 colors, 1 tangents, 2 binormals ([npos,3]); 3 texcoords ([npos,2]); 4 texcoords_unshared ([nidx,2])"""
+        D = _c(data, np.float64)
+        assert self.L.lo_scene_set_attribute(self.h, int(mesh), int(kind), _p(D, _dp)) == 0
+
+    def state_batch(self, org, dr):
+        """closest hit + the whole ri_intersection_state_build record (24 doubles, LH_STATE_DOUBLES layout)"""
+        org = _c(org, np.float64).reshape(-1, 3); dr = _c(dr, np.float64).reshape(-1, 3)
+        prim = np.empty(org.shape[0], np.uint32); st = np.zeros((org.shape[0], 24))
+        self.L.lo_state_batch(self.h, org.shape[0], _p(org, _dp), _p(dr, _dp), _p(prim, _u32p), _p(st, _dp))
+        return prim, st
 
     def build(self):
         self.L.lo_scene_build(self.h)
@@ -258,6 +272,8 @@ class RefLib:
         L.lref_record_size.restype = C.c_size_t
         L.lref_record_copy.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
         L.lref_beam_visibility_batch.argtypes = [C.c_size_t, _dp, _dp, C.POINTER(C.c_int32)]
+        L.lref_scene_set_attribute.argtypes = [C.c_uint32, C.c_int, _dp, C.c_uint32, C.c_int]
+        L.lref_state_batch.argtypes = [C.c_size_t, _dp, _dp, _u32p, _dp]
         self.L = L
         L.lref_init()
         L.lref_scene_reset()
@@ -269,6 +285,18 @@ class RefLib:
         P = _c(positions, np.float64).reshape(-1, 3)
         I = _c(indices, np.uint32).reshape(-1)
         self.L.lref_scene_add_mesh(P.shape[0], _p(P, _dp), I.shape[0], _p(I, _u32p))
+
+    def set_attribute(self, mesh, kind, data, two_side=0):
+        """kind -1 normals (+ two_side), 0 colors, 1 tangents, 2 binormals, 3 texcoords, 4 texcoords_unshared"""
+        D = _c(data, np.float64) if data is not None else None
+        n = 0 if D is None else D.shape[0]
+        assert self.L.lref_scene_set_attribute(int(mesh), int(kind), _p(D, _dp), n, int(two_side)) == 0
+
+    def state_batch(self, org, dr):
+        org = _c(org, np.float64).reshape(-1, 3); dr = _c(dr, np.float64).reshape(-1, 3)
+        prim = np.empty(org.shape[0], np.uint32); st = np.zeros((org.shape[0], 24))
+        self.L.lref_state_batch(org.shape[0], _p(org, _dp), _p(dr, _dp), _p(prim, _u32p), _p(st, _dp))
+        return prim, st
 
     def build(self):
         assert self.L.lref_scene_build() == 0

@@ -250,6 +250,53 @@ int lref_scene_add_mesh(uint32_t npos, const double *pos_xyz, uint32_t nidx,
     return 0;
 }
 
+/* optional attributes of geom `mesh`, through the reference's own ri_geom_add_* (geom.c:102-290).
+ * kind -1: normals (+ two_side); 0 colors, 1 tangents, 2 binormals (xyz per vertex); 3 texcoords (st per vertex);
+ * 4 texcoords_unshared (st per index). */
+int lref_scene_set_attribute(uint32_t mesh, int kind, const double *data, uint32_t count, int two_side)
+{
+    ri_geom_t *g; ri_vector_t *V; uint32_t i;
+    if (mesh >= g_ngeoms) return -1;
+    g = g_geoms[mesh];
+    if (kind == -1) g->two_side = two_side;
+    if (!data) return 0;
+    if (kind >= 3) {
+        if (kind == 3) ri_geom_add_texcoords(g, count, data);
+        else ri_geom_add_texcoords_unshared(g, count, data);
+        return 0;
+    }
+    V = (ri_vector_t *)malloc(sizeof(ri_vector_t) * (count ? count : 1));
+    for (i = 0; i < count; i++) { V[i][0] = data[3 * i]; V[i][1] = data[3 * i + 1]; V[i][2] = data[3 * i + 2]; V[i][3] = 0.0; }
+    if (kind == -1) ri_geom_add_normals(g, count, (const ri_vector_t *)V);
+    else if (kind == 0) ri_geom_add_colors(g, count, (const ri_vector_t *)V);
+    else if (kind == 1) ri_geom_add_tangents(g, count, (const ri_vector_t *)V);
+    else if (kind == 2) ri_geom_add_binormals(g, count, (const ri_vector_t *)V);
+    free(V);
+    return 0;
+}
+
+/* ri_raytrace + the whole ri_intersection_state_t of every hit: state24 = P Ng Ns tangent binormal color(3)
+ * st(2) I inside; zeros for a miss */
+void lref_state_batch(size_t n, const double *org, const double *dir, uint32_t *prim, double *state24)
+{
+    size_t i; ri_render_t *render = ri_render_get();
+    for (i = 0; i < n; i++) {
+        ri_ray_t ray; ri_intersection_state_t st; int hit, k; double *o = state24 + 24 * i;
+        memset(&ray, 0, sizeof(ray)); memset(&st, 0, sizeof(st));
+        for (k = 0; k < 3; k++) { ray.org[k] = org[3 * i + k]; ray.dir[k] = dir[3 * i + k]; }
+        ray.thread_num = 0;
+        hit = ri_raytrace(render, &ray, &st);
+        memset(o, 0, 24 * sizeof(double));
+        if (!hit) { prim[i] = LREF_MISS; continue; }
+        prim[i] = g_geom_base[geom_ordinal(st.geom)] + st.index / 3;
+        for (k = 0; k < 3; k++) {
+            o[k] = st.P[k]; o[3 + k] = st.Ng[k]; o[6 + k] = st.Ns[k]; o[9 + k] = st.tangent[k]; o[12 + k] = st.binormal[k];
+            o[15 + k] = st.color[k]; o[20 + k] = st.I[k];
+        }
+        o[18] = st.stqr[0]; o[19] = st.stqr[1]; o[23] = (double)st.inside;
+    }
+}
+
 int lref_scene_build(void)
 {
     ri_scene_t *scene = ri_render_get()->scene;

@@ -42,6 +42,59 @@ def soup_fixture(name, ntri, nrays, half_extent):
     print(name, "hits", int((prim != po.MISS).sum()), "of", nrays, "sum t", float(t[prim != po.MISS].sum()), cnt, tree)
 
 
+def state_scene(seed=2024):
+    """three small meshes exercising every branch of ri_intersection_state_build (intersection_state.c:99-248):
+    0: normals + tangents + binormals + colours + shared texcoords, two_side; 1: normals only + unshared texcoords;
+    2: nothing but positions (+ colours).  Inputs are reproducible from the seed."""
+    rng = np.random.default_rng(seed)
+    meshes = []
+    for k, (ntri, off) in enumerate(((60, 0.0), (50, 0.7), (40, -0.6))):
+        c = rng.uniform(-0.5, 0.5, (ntri, 1, 3)) + np.array([off, 0.1 * k, 0.0])
+        tri = c + rng.uniform(-0.15, 0.15, (ntri, 3, 3))
+        npos = 3 * ntri // 2                               # shared vertices: indices point into a smaller pool
+        P = tri.reshape(-1, 3)[:npos].copy()
+        idx = rng.integers(0, npos, 3 * ntri).astype(np.uint32)
+        m = {"P": P, "idx": idx, "two_side": 0}
+        unit = lambda a: a / np.linalg.norm(a, axis=1, keepdims=True)
+        if k == 0:
+            idx2 = np.concatenate([idx, idx[::-1]]).astype(np.uint32)      # two_side: second half = back faces
+            m.update(idx=idx2, two_side=1, N=unit(rng.normal(size=(npos, 3))), T=unit(rng.normal(size=(npos, 3))),
+                     B=unit(rng.normal(size=(npos, 3))), C=rng.uniform(0, 1, (npos, 3)), ST=rng.uniform(0, 4, (npos, 2)))
+        elif k == 1:
+            m.update(N=unit(rng.normal(size=(npos, 3))), STU=rng.uniform(-1, 1, (idx.shape[0], 2)))
+        else:
+            m.update(C=rng.uniform(0, 1, (npos, 3)))
+        meshes.append(m)
+    n = 6000
+    org = rng.uniform(-2.5, 2.5, (n, 3)); tgt = rng.uniform(-0.6, 0.9, (n, 3)); tgt[:, 0] += rng.choice([0.0, 0.7, -0.6], n)
+    return meshes, org, tgt - org
+
+
+def apply_state_scene(target, meshes, is_ref):
+    for k, m in enumerate(meshes):
+        target.add_mesh(m["P"], m["idx"])
+        if is_ref:
+            target.set_attribute(k, -1, m.get("N"), two_side=m["two_side"])
+        elif "N" in m or m["two_side"]:
+            target.set_normals(k, m.get("N"), m["two_side"])
+        for kind, key in ((0, "C"), (1, "T"), (2, "B"), (3, "ST"), (4, "STU")):
+            if key in m:
+                target.set_attribute(k, kind, m[key])
+
+
+def state_fixture(name="state_attr"):
+    """the whole hit record of the compiled reference (ri_raytrace -> ri_intersection_state_build) for a scene with
+    colours / tangents / binormals / texture coordinates: prim + 24 doubles per ray"""
+    meshes, org, dr = state_scene()
+    ref = po.RefLib(); apply_state_scene(ref, meshes, True); ref.build()
+    prim, st = ref.state_batch(org, dr)
+    o = po.Oracle(); apply_state_scene(o, meshes, False); o.build()
+    op, ost = o.state_batch(org, dr)
+    assert np.array_equal(op, prim) and np.array_equal(ost, st), "oracle restatement != compiled reference"
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=2024, prim=prim, state=st)
+    print(name, "hits", int((prim != po.MISS).sum()), "of", org.shape[0], "inside", int(st[:, 23].sum()))
+
+
 def ao_fixture(name, rib, width, height, gather_nsamples, pixel_samples=1):
     """The reference's own AO render of one of its example scenes (single thread, Ri C API
     driven by oracle/ref_rib.py): the triangles it actually traced (after its RIB ingest),
@@ -146,6 +199,8 @@ def hdr_fixture():
 if __name__ == "__main__":
     if "--rib" in sys.argv:
         rib_fixture(); hdr_fixture(); sys.exit(0)
+    if "--state" in sys.argv:
+        state_fixture(); sys.exit(0)
     if not po.ref_available(stat=True):
         po.build_ref()
     soup_fixture("soup_20k", 20000, 20000, 0.005)
@@ -159,5 +214,6 @@ if __name__ == "__main__":
     ao_fixture("ao_ps", "/root/reference/examples/plane_sphere/Scene_DEFAULT_Set0.rib", 96, 96, 9, pixel_samples=2)
     rib_fixture()
     hdr_fixture()
+    state_fixture()
     # check values of the full S-soup-1M are pinned in
     # tests/test_oracle_vs_ref.py against the live reference, not stored here.
