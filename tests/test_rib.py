@@ -174,16 +174,21 @@ def test_add_rib_scene_hands_every_mesh_its_own_normals():
         if m["normals"] is not None:
             b.set_normals(k, m["normals"], m["two_side"])
     b.commit()
-    c = sc.camera
-    cam = la.Camera.make(96, 96, c.flength, list(c.cam2world), c.rh); cam.ortho = c.ortho
-    ra, sa = a.render_ao_tile(cam, 0, 0, 96, 96, 2, 16, seed=3)
-    Ns_a = a.scratch(7, np.float64, 12)
-    rb, sb = b.render_ao_tile(cam, 0, 0, 96, 96, 2, 16, seed=3)
-    Ns_b = b.scratch(7, np.float64, 12)
-    torch.cuda.synchronize()
-    assert sa == sb and sa["primary_hits"] > 0
-    assert np.array_equal(Ns_a, Ns_b)                    # AO origin, tangent, binormal, Ns of every hit
-    assert torch.equal(ra, rb)
+    # rays aimed at the geometry (the synthetic scene is not framed by its own camera): hit records + epilogue
+    rng = np.random.default_rng(8)
+    allP = np.concatenate([m["positions"][:, :3] for m in meshes])
+    tgt = allP[rng.integers(0, allP.shape[0], 20000)] + rng.normal(scale=0.02, size=(20000, 3))
+    org = allP.mean(0) + rng.normal(size=(20000, 3)) * 4.0 * allP.std(0).max()
+    dr = tgt - org
+    ha = a.intersect_host(org, dr); hb = b.intersect_host(org, dr)
+    for x, y in zip(ha, hb):
+        assert np.array_equal(x, y)
+    sa = a.state_build(org, dr, *ha); sb = b.state_build(org, dr, *hb)
+    assert np.array_equal(sa, sb)                          # incl. Ns of every hit
+    hit_mesh = np.array([a.prim_lookup(int(p))[0] for p in ha[0][ha[0] != la.MISS][:4000]])
+    assert any((hit_mesh == k).any() for k in with_n if k > 0), "no hit on a later mesh that carries normals"
+    lerped = np.abs(sa[:, 6:9] - sa[:, 3:6]).max(1) > 1e-9           # Ns != Ng: interpolated normals were used
+    assert lerped.any()
     with pytest.raises(ValueError):
         b2 = la.HipAccel(0); b2.add_mesh(meshes[0]["positions"], meshes[0]["indices"])
         b2.set_normals(0, np.zeros((1, 3)))              # short normals array: refused before the C ABI reads it
