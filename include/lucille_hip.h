@@ -170,6 +170,14 @@ int  lh_render_ao_tile(lh_accel_t *accel, const lh_camera_t *cam, int x0, int y0
                        int pixel_samples, int gather_nsamples, uint64_t seed,
                        const void *d_uniforms, void *d_rgb, lh_tile_stats_t *stats, void *stream);
 
+/* the same tile for a plain-C host (the batched frame loop inside lucille, integration/ri_render_hip.c): rgb is
+ * HOST memory (h rows of w RGB floats, image orientation); uniforms (HOST, may be NULL) as d_uniforms above --
+ * nuniforms must cover the worst case 2 * floor(sqrt(gather_nsamples))^2 * w * h * pixel_samples^2; the tile
+ * consumes the first 2 * N * stats->primary_hits of them. */
+int  lh_render_ao_tile_host(lh_accel_t *accel, const lh_camera_t *cam, int x0, int y0, int w, int h,
+                            int pixel_samples, int gather_nsamples, uint64_t seed, const double *uniforms,
+                            size_t nuniforms, float *rgb, lh_tile_stats_t *stats);
+
 /* one path-traced tile on the device (BASELINE config 4: the reference's pathtrace.c is dead
  * code; its documented structure -- camera sample, Russian roulette on the reflectance,
  * cosine-sampled diffuse bounces to a vertex limit, environment radiance on escape -- re-expressed

@@ -29,7 +29,10 @@
 #define RI_ACCEL_HIP 2
 #endif
 
+#define RI_HIPBVH_MAGIC 0x48495042u   /* "HIPB": ri_hipbvh_handle is also asked about CPU accelerators */
+
 typedef struct {
+    unsigned    magic;
     lh_accel_t *lh;
     ri_geom_t **geoms;          /* back-pointers in geom_list order (cf. bvh.c:1808) */
     unsigned    ngeoms;
@@ -50,6 +53,7 @@ void *ri_hipbvh_build(const void *data)
     for (itr = ri_list_first((ri_list_t *)scene->geom_list); itr != NULL; itr = ri_list_next(itr)) n++;
 
     h = (ri_hipbvh_t *)calloc(1, sizeof(*h));
+    h->magic = RI_HIPBVH_MAGIC;
     h->geoms = (ri_geom_t **)calloc(n ? n : 1, sizeof(ri_geom_t *));
     if (lh_accel_create(&h->lh, g_ri_hip_device) != 0) {
         ri_log(LOG_ERROR, "(HIPBVH) %s", lh_last_error());
@@ -63,6 +67,20 @@ void *ri_hipbvh_build(const void *data)
         if (lh_accel_add_mesh(h->lh, geom->npositions, (const double *)geom->positions,
                               sizeof(ri_vector_t), geom->nindices, geom->indices) != 0) {
             ri_log(LOG_ERROR, "(HIPBVH) %s", lh_last_error());
+            continue;
+        }
+        /* what ri_intersection_state_build reads besides positions (geom.h:29-65): used by the device-side
+         * epilogue of the batched frame loop (integration/ri_render_hip.c); the one-ray path below keeps calling
+         * lucille's own ri_intersection_state_build on the host */
+        {
+            const uint32_t m = h->ngeoms - 1;
+            if (geom->normals || geom->two_side)
+                lh_accel_set_normals(h->lh, m, (const double *)geom->normals, sizeof(ri_vector_t), geom->two_side);
+            if (geom->colors) lh_accel_set_attribute(h->lh, m, LH_ATTR_COLOR, (const double *)geom->colors, sizeof(ri_vector_t), geom->ncolors);
+            if (geom->tangents) lh_accel_set_attribute(h->lh, m, LH_ATTR_TANGENT, (const double *)geom->tangents, sizeof(ri_vector_t), geom->ntangents);
+            if (geom->binormals) lh_accel_set_attribute(h->lh, m, LH_ATTR_BINORMAL, (const double *)geom->binormals, sizeof(ri_vector_t), geom->nbinormals);
+            if (geom->texcoords) lh_accel_set_attribute(h->lh, m, LH_ATTR_TEXCOORD, geom->texcoords, 2 * sizeof(ri_float_t), geom->npositions);
+            else if (geom->texcoords_unshared) lh_accel_set_attribute(h->lh, m, LH_ATTR_TEXCOORD_UNSHARED, geom->texcoords_unshared, 2 * sizeof(ri_float_t), geom->nindices);
         }
     }
     if (lh_accel_commit(h->lh, 0) != 0) {
@@ -71,6 +89,13 @@ void *ri_hipbvh_build(const void *data)
         return NULL;
     }
     return h;
+}
+
+/* the C-ABI handle behind a RI_ACCEL_HIP accelerator: for callers that batch (integration/ri_render_hip.c) */
+lh_accel_t *ri_hipbvh_handle(void *accel)
+{
+    ri_hipbvh_t *h = (ri_hipbvh_t *)accel;
+    return (h && h->magic == RI_HIPBVH_MAGIC) ? h->lh : NULL;
 }
 
 /* accel_free_func */

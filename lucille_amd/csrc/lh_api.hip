@@ -112,6 +112,7 @@ struct lh_accel {
     lh_material_t *materials; uint32_t nmaterials; void *d_materials; int materials_dirty;
     lh_environment_t env; void *d_env_map;
     lh_buf r_state;                    /* lh_accel_state_build_host staging */
+    lh_buf r_uni;                      /* lh_render_ao_tile_host: caller uniforms on the device */
     /* tile-render scratch (lh_render_ao_tile) */
     lh_buf r_org, r_dir, r_prim, r_t, r_u, r_v, r_slot, r_hitrec, r_aorg, r_adir, r_occ, r_blocks, r_key, r_frame, r_occcount;
     int ao_fused;                      /* AO rays generated inside the any-hit kernel (default); 0: materialised in HBM */
@@ -266,7 +267,7 @@ static void release_device(lh_accel_t *a)
     if (a->d_materials) (void)hipFree(a->d_materials);
     if (a->d_env_map) (void)hipFree(a->d_env_map);
     a->d_st6 = a->d_inside = a->d_prim_mesh = a->d_materials = a->d_env_map = NULL;
-    free_buf(&a->r_state);
+    free_buf(&a->r_state); free_buf(&a->r_uni);
     a->d_total = NULL; a->d_nrm9 = NULL;
     if (a->d_nodes) (void)hipFree(a->d_nodes);
     if (a->d_tri32) (void)hipFree(a->d_tri32);
@@ -1099,6 +1100,33 @@ extern "C" int lh_render_ao_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
         stats->primary_rays = S; stats->primary_hits = nhit; stats->ao_rays = nao; stats->ao_occluded = nocc;
     }
     HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+/* the same tile for a plain-C host program: uniforms (optional) come from and the tile goes to HOST memory */
+extern "C" int lh_render_ao_tile_host(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int ps,
+                                      int gather_nsamples, uint64_t seed, const double *uniforms, size_t nuniforms,
+                                      float *rgb, lh_tile_stats_t *stats)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_render_ao_tile_host: accel not committed");
+    if (!cam || !rgb) return fail("lh_render_ao_tile_host: NULL argument");
+    if (w <= 0 || h <= 0) return fail("lh_render_ao_tile_host: bad tile");
+    HIPCHK(hipSetDevice(a->device));
+    const size_t fb = (size_t)w * h * 3 * sizeof(float);
+    if (ensure_buf(&a->r_frame, fb)) return -1;
+    void *d_uni = NULL;
+    if (uniforms) {
+        const int nphi = (int)sqrt((double)gather_nsamples);
+        const size_t need = (size_t)2 * nphi * nphi * w * h * ps * ps;       /* worst case: every sample hits */
+        if (nuniforms < need) return fail("lh_render_ao_tile_host: %zu uniforms given, the tile may consume %zu", nuniforms, need);
+        if (ensure_buf(&a->r_uni, need * sizeof(double))) return -1;
+        HIPCHK(hipMemcpyAsync(a->r_uni.p, uniforms, need * sizeof(double), hipMemcpyHostToDevice, a->stream));
+        d_uni = a->r_uni.p;
+    }
+    if (lh_render_ao_tile(a, cam, x0, y0, w, h, ps, gather_nsamples, seed, d_uni, a->r_frame.p, stats, a->stream) != 0) return -1;
+    HIPCHK(hipMemcpyAsync(rgb, a->r_frame.p, fb, hipMemcpyDeviceToHost, a->stream));
+    HIPCHK(hipStreamSynchronize(a->stream));
     return 0;
 }
 

@@ -225,15 +225,18 @@ def render_verbs(verbs, width, height, gather_nsamples, pixel_samples=1, accel_m
     return out
 
 
-def render_scene_subprocess(scene_npz, outfile, **kw):
-    """like render_rib_subprocess for a scene stored as .npz {ngeoms, pos%d, idx%d, w2c, fov}"""
+def render_scene_subprocess(scene_npz, outfile, env=None, **kw):
+    """like render_rib_subprocess for a scene stored as .npz {ngeoms, pos%d, idx%d, w2c, fov};
+    env: extra environment variables of the child (RI_HIP_RENDER ...)"""
     code = ("import sys; sys.path.insert(0, %r); import numpy as np; from oracle import ref_rib as r; "
             "g = np.load(%r); "
             "verbs = r.scene_verbs([(g['pos%%d' %% i], g['idx%%d' %% i]) for i in range(int(g['ngeoms']))], g['w2c'], float(g['fov'])); "
             "o = r.render_verbs(verbs, **%r); "
             "np.savez(%r, image=o['image'], camera=o['camera'], records=o['records'])") % (
                 os.path.dirname(HERE), scene_npz, kw, outfile)
-    subprocess.check_call([sys.executable, "-c", code], stdout=subprocess.DEVNULL)
+    e = dict(os.environ)
+    e.update(env or {})
+    subprocess.check_call([sys.executable, "-c", code], stdout=subprocess.DEVNULL, env=e)
     return np.load(outfile)
 
 

@@ -30,8 +30,9 @@ def test_reference_renderer_on_hip_accel(tmp_path):
     sp = str(tmp_path / "scene.npz")
     np.savez(sp, **scene)
     kw = dict(width=40, height=40, gather_nsamples=4, pixel_samples=1, lib="liblucille_ref_hip.so")
-    cpu = ref_rib.render_scene_subprocess(sp, str(tmp_path / "cpu.npz"), accel_method=1, **kw)
-    hip = ref_rib.render_scene_subprocess(sp, str(tmp_path / "hip.npz"), accel_method=2, **kw)
+    rays = {"RI_HIP_RENDER": "rays"}          # the one-ray vtable path (the batched frame loop is tested below)
+    cpu = ref_rib.render_scene_subprocess(sp, str(tmp_path / "cpu.npz"), accel_method=1, env=rays, **kw)
+    hip = ref_rib.render_scene_subprocess(sp, str(tmp_path / "hip.npz"), accel_method=2, env=rays, **kw)
     assert len(cpu["records"]) == len(hip["records"]) > 1600
     for f in ("org", "dir", "hit", "geom", "index", "t", "u", "v"):
         assert np.array_equal(cpu["records"][f], hip["records"][f]), f
@@ -54,9 +55,51 @@ def test_reference_renderer_with_render_threads_on_hip_accel(tmp_path):
     sp = str(tmp_path / "scene.npz")
     np.savez(sp, **scene)
     kw = dict(width=64, height=64, gather_nsamples=16, pixel_samples=1, lib="liblucille_ref_hip.so", record=False)
-    one = ref_rib.render_scene_subprocess(sp, str(tmp_path / "t1.npz"), accel_method=2, nthreads=1, **kw)
-    four = ref_rib.render_scene_subprocess(sp, str(tmp_path / "t4.npz"), accel_method=2, nthreads=4, **kw)
+    rays = {"RI_HIP_RENDER": "rays"}
+    one = ref_rib.render_scene_subprocess(sp, str(tmp_path / "t1.npz"), accel_method=2, nthreads=1, env=rays, **kw)
+    four = ref_rib.render_scene_subprocess(sp, str(tmp_path / "t4.npz"), accel_method=2, nthreads=4, env=rays, **kw)
     a, b = one["image"], four["image"]
     assert a.shape == b.shape and b.max() > 0
     assert np.array_equal(a.sum(axis=2) == 0, b.sum(axis=2) == 0)          # same pixels see geometry
     assert abs(float(a.mean()) - float(b.mean())) < 0.01                  # 16 AO samples per pixel, 4 096 pixels
+
+
+def _c1_scene(tmp_path):
+    g = load_golden("ao_c1")
+    c2w = np.asarray(g["camera"][:16]).reshape(4, 4)
+    w2c = np.linalg.inv(c2w @ np.linalg.inv(np.diag([1.0, 1.0, -1.0, 1.0])))
+    scene = {"ngeoms": int(g["ngeoms"]), "w2c": w2c, "fov": 45.0}
+    for k in range(int(g["ngeoms"])):
+        scene["pos%d" % k] = g["pos%d" % k]; scene["idx%d" % k] = g["idx%d" % k]
+    sp = str(tmp_path / "scene.npz")
+    np.savez(sp, **scene)
+    return g, sp
+
+
+def test_reference_renderer_batched_frame_loop(tmp_path):
+    """BASELINE config 1 (256 x 256, 16 AO samples) rendered by the REFERENCE's Ri API / frame set-up / bucket queue /
+    bucket_write / display driver, with the per-pixel work done by the device tile pipeline through the batched frame
+    controller of integration/ri_render_hip.c (compiled into oracle/_ref/liblucille_ref_hip.so in place of render.c):
+      replay   the reference's own MT19937 stream fed bucket by bucket -> its frame (tests/golden/ao_c1.npz) up to
+               <= 20 pixels (device vs glibc sin/cos), no ray through ri_raytrace;
+      batched  the whole frame in one go with the built-in sample stream -> same coverage, same radiance statistics."""
+    import time
+    from oracle import ref_rib
+    g, sp = _c1_scene(tmp_path)
+    ref = g["image"]
+    kw = dict(width=256, height=256, gather_nsamples=16, pixel_samples=1, lib="liblucille_ref_hip.so", accel_method=2)
+    rep = ref_rib.render_scene_subprocess(sp, str(tmp_path / "replay.npz"), env={"RI_HIP_RENDER": "replay"}, **kw)
+    assert len(rep["records"]) == 0                              # no ray went through the one-ray vtable
+    diff = np.abs(rep["image"] - ref)
+    nbad = int((diff[..., 0] > 0).sum())
+    assert nbad <= 20, "pixels differing from the reference's frame: %d" % nbad
+    assert diff.max() <= 2.0 / 16 + 1e-6
+    t0 = time.time()
+    bat = ref_rib.render_scene_subprocess(sp, str(tmp_path / "batched.npz"), env={"RI_HIP_RENDER": "batched"}, record=False, **kw)
+    img = bat["image"]
+    assert np.array_equal(img.sum(axis=2) == 0, ref.sum(axis=2) == 0)      # the same pixels see geometry
+    assert abs(float(img.mean()) - float(ref.mean())) < 2e-3
+    assert float(np.sqrt(((img - ref) ** 2).mean())) < 0.06
+    # the default mode is the batched one
+    dflt = ref_rib.render_scene_subprocess(sp, str(tmp_path / "default.npz"), record=False, **kw)
+    assert np.array_equal(dflt["image"], img)
