@@ -74,6 +74,10 @@ void *ri_hipbvh_build(const void *data)
          * lucille's own ri_intersection_state_build on the host */
         {
             const uint32_t m = h->ngeoms - 1;
+            if (getenv("RI_HIP_DEBUG"))
+                fprintf(stderr, "(HIPBVH) geom %u: %u positions, %u indices, normals %p (%u), two_side %d, colors %p, tangents %p, texcoords %p / %p\n", m,
+                        geom->npositions, geom->nindices, (void *)geom->normals, geom->nnormals, geom->two_side, (void *)geom->colors,
+                        (void *)geom->tangents, (void *)geom->texcoords, (void *)geom->texcoords_unshared);
             if (geom->normals || geom->two_side)
                 lh_accel_set_normals(h->lh, m, (const double *)geom->normals, sizeof(ri_vector_t), geom->two_side);
             if (geom->colors) lh_accel_set_attribute(h->lh, m, LH_ATTR_COLOR, (const double *)geom->colors, sizeof(ri_vector_t), geom->ncolors);

@@ -4,10 +4,11 @@
  * pipeline instead of one synchronous GPU launch per ri_raytrace() call.
  *
  * In lucille this is an edit INSIDE render.c (it needs that file's private bucket_t and bucket_write): the frame
- * controller render_frame_controller (render.c:1168-1207) gets a GPU branch.  To build it here without touching the
- * reference, this translation unit pulls render.c in unchanged from the include path with the CPU controller
- * renamed, and defines the controller below it; oracle/Makefile compiles this file IN PLACE OF render.c for
- * _ref/liblucille_ref_hip.so.  INTEGRATION.md section 3 shows the same change as a patch to render.c.
+ * controller render_frame_controller (render.c:1168-1207) gets a GPU branch in front of its thread launch.  To
+ * build it here without touching the reference, this translation unit pulls render.c in unchanged from the
+ * include path and hooks the branch in through the bucket queue (see "The hook" below); oracle/Makefile compiles
+ * this file IN PLACE OF render.c for _ref/liblucille_ref_hip.so.  INTEGRATION.md section 3 shows the same change
+ * as a patch to render.c.
  *
  * What the GPU branch replaces (all per-pixel work of a frame):
  *   render_bucket -> subsample -> ri_camera_get_pos_and_dir -> ri_transport_ambientocclusion -> ri_raytrace x (1 + N)
@@ -26,9 +27,20 @@
  * Anything the tile pipeline does not cover (sunsky light, xsamples != ysamples, a material texture on a geom)
  * falls back to the CPU controller, which still traces through the HIP accelerator.
  */
-#define render_frame_controller render_frame_controller_cpu
+#include <stdint.h>
+#include <pthread.h>
+#include "queue.h"
+
+/* The hook.  In lucille the GPU branch below sits at the top of render_frame_controller (render.c:1168-1207);
+ * render.c is read-only here and that function is static, so this build interposes on the ONE place the frame's
+ * worker threads take work -- ri_mt_queue_pop in render_bucket_thread_func (render.c:1057-1061): the first pop
+ * of a frame (the bucket queue is still full) renders the whole frame on the device and drains the queue, after
+ * which every worker finds it empty and returns; if the GPU branch declines, the pops go through unchanged and
+ * the reference's own threads render the frame (still tracing through the HIP accelerator, one ray per call). */
+static int hip_queue_pop(ri_mt_queue_t *queue, void **data, uint32_t *size);
+#define ri_mt_queue_pop hip_queue_pop
 #include "render.c"                 /* lucille's own src/render/render.c, found through -I src/render */
-#undef render_frame_controller
+#undef ri_mt_queue_pop
 
 #include "random.h"
 #include "material.h"
@@ -82,7 +94,8 @@ static void hip_emit_bucket(bucket_t *bucket, const float *img, int img_w, int i
     bucket->pixels = NULL;
 }
 
-void render_frame_controller(ri_render_t *render)
+/* 1: the frame was rendered on the device and the queue is drained; 0: declined, the CPU threads do it */
+static int hip_render_frame(ri_render_t *render)
 {
     const char *mode = getenv("RI_HIP_RENDER");
     lh_accel_t *lh; lh_camera_t cam; lh_tile_stats_t st;
@@ -91,10 +104,8 @@ void render_frame_controller(ri_render_t *render)
 
     if (!render->scene || !render->scene->accel || render->scene->accel->intersect == NULL ||
         (mode && strcmp(mode, "rays") == 0) || !hip_frame_supported(render, &ps) ||
-        (lh = ri_hipbvh_handle(render->scene->accel->data)) == NULL) {
-        render_frame_controller_cpu(render);
-        return;
-    }
+        (lh = ri_hipbvh_handle(render->scene->accel->data)) == NULL)
+        return 0;
     hip_camera(&cam, render->context->option->camera);
     W = cam.width; H = cam.height;
     N = render->context->option->gather_nsamples;
@@ -105,13 +116,17 @@ void render_frame_controller(ri_render_t *render)
         const int nphi = (int)sqrt((double)N), NN = nphi * nphi;
         double *fifo = NULL; size_t have = 0, cap = 0;
         float *rgb = NULL; size_t rgb_cap = 0;
-        while (ri_mt_queue_pop(render->bucket_queue, (void **)&bucket, &data_size) == 0) {
+        while ((ri_mt_queue_pop)(render->bucket_queue, (void **)&bucket, &data_size) == 0) {
             const size_t need = (size_t)2 * NN * bucket->w * bucket->h * ps * ps;
             if (need > cap) { fifo = (double *)realloc(fifo, sizeof(double) * need); cap = need; }
             while (have < need) fifo[have++] = randomMT2(0);
             if ((size_t)bucket->w * bucket->h * 3 > rgb_cap) { rgb_cap = (size_t)bucket->w * bucket->h * 3; rgb = (float *)realloc(rgb, sizeof(float) * rgb_cap); }
             ret = lh_render_ao_tile_host(lh, &cam, bucket->x, bucket->y, bucket->w, bucket->h, ps, N, 0, fifo, have, rgb, &st);
-            if (ret != 0) { ri_log(LOG_ERROR, "(HIPBVH) %s", lh_last_error()); break; }
+            if (ret != 0) {       /* put nothing back: this bucket stays black, the rest go to the CPU threads */
+                ri_log(LOG_ERROR, "(HIPBVH) %s", lh_last_error());
+                free(fifo); free(rgb);
+                return 0;
+            }
             {   /* keep what the bucket did not consume for the next one */
                 const size_t used = (size_t)2 * NN * st.primary_hits;
                 memmove(fifo, fifo + used, sizeof(double) * (have - used));
@@ -120,23 +135,38 @@ void render_frame_controller(ri_render_t *render)
             hip_emit_bucket(bucket, rgb, bucket->w, 0, 0);
         }
         free(fifo); free(rgb);
-        return;
+        return 1;
     }
 
     {   /* batched: the frame on the device (tiles sized by its scratch budget), then bucket by bucket to the display */
         float *img = (float *)malloc(sizeof(float) * 3 * (size_t)W * H);
-        if (!img) { render_frame_controller_cpu(render); return; }
+        if (!img) return 0;
         ret = lh_render_ao_frame_host(lh, &cam, ps, N, 1, 0, img, &st);
         if (ret != 0) {
             ri_log(LOG_ERROR, "(HIPBVH) %s -- falling back to the one-ray path", lh_last_error());
             free(img);
-            render_frame_controller_cpu(render);
-            return;
+            return 0;
         }
-        while (ri_mt_queue_pop(render->bucket_queue, (void **)&bucket, &data_size) == 0)
+        while ((ri_mt_queue_pop)(render->bucket_queue, (void **)&bucket, &data_size) == 0)
             hip_emit_bucket(bucket, img, W, bucket->x, H - (bucket->y + bucket->h));
         free(img);
         ri_log(LOG_INFO, "(HIPBVH) frame on the device: %llu primary + %llu AO rays",
                (unsigned long long)st.primary_rays, (unsigned long long)st.ao_rays);
     }
+    return 1;
+}
+
+static pthread_mutex_t g_hip_frame_mu = PTHREAD_MUTEX_INITIALIZER;
+static int             g_hip_declined = 0;
+
+static int hip_queue_pop(ri_mt_queue_t *queue, void **data, uint32_t *size)
+{
+    ri_render_t *render = ri_render_get();
+    if (render && queue == render->bucket_queue) {
+        pthread_mutex_lock(&g_hip_frame_mu);
+        if (ri_mt_queue_len(queue) != render->nbuckets) g_hip_declined = 0;      /* the frame is under way */
+        else if (!g_hip_declined && !hip_render_frame(render)) g_hip_declined = 1; /* first pop of a frame */
+        pthread_mutex_unlock(&g_hip_frame_mu);
+    }
+    return (ri_mt_queue_pop)(queue, data, size);
 }

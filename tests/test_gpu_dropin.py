@@ -77,29 +77,30 @@ def _c1_scene(tmp_path):
 
 
 def test_reference_renderer_batched_frame_loop(tmp_path):
-    """BASELINE config 1 (256 x 256, 16 AO samples) rendered by the REFERENCE's Ri API / frame set-up / bucket queue /
-    bucket_write / display driver, with the per-pixel work done by the device tile pipeline through the batched frame
-    controller of integration/ri_render_hip.c (compiled into oracle/_ref/liblucille_ref_hip.so in place of render.c):
-      replay   the reference's own MT19937 stream fed bucket by bucket -> its frame (tests/golden/ao_c1.npz) up to
-               <= 20 pixels (device vs glibc sin/cos), no ray through ri_raytrace;
+    """BASELINE config 1's shape (256 x 256, 16 AO samples) rendered by the REFERENCE's Ri API / frame set-up / bucket
+    queue / bucket_write / display driver, with the per-pixel work done by the device tile pipeline through the batched
+    frame loop of integration/ri_render_hip.c (compiled into oracle/_ref/liblucille_ref_hip.so in place of render.c):
+      replay   the reference's own MT19937 stream fed bucket by bucket -> the frame its CPU path renders (same library,
+               accel_method "bvh", one thread) up to <= 20 pixels (device vs glibc sin/cos); no ray through ri_raytrace;
       batched  the whole frame in one go with the built-in sample stream -> same coverage, same radiance statistics."""
-    import time
     from oracle import ref_rib
     g, sp = _c1_scene(tmp_path)
-    ref = g["image"]
-    kw = dict(width=256, height=256, gather_nsamples=16, pixel_samples=1, lib="liblucille_ref_hip.so", accel_method=2)
-    rep = ref_rib.render_scene_subprocess(sp, str(tmp_path / "replay.npz"), env={"RI_HIP_RENDER": "replay"}, **kw)
+    kw = dict(width=256, height=256, gather_nsamples=16, pixel_samples=1, lib="liblucille_ref_hip.so")
+    cpu = ref_rib.render_scene_subprocess(sp, str(tmp_path / "cpu.npz"), accel_method=1, record=False, **kw)
+    ref = cpu["image"]
+    assert ref.max() > 0 and (ref.sum(axis=2) > 0).mean() > 0.2
+    rep = ref_rib.render_scene_subprocess(sp, str(tmp_path / "replay.npz"), accel_method=2, env={"RI_HIP_RENDER": "replay"}, **kw)
     assert len(rep["records"]) == 0                              # no ray went through the one-ray vtable
     diff = np.abs(rep["image"] - ref)
     nbad = int((diff[..., 0] > 0).sum())
-    assert nbad <= 20, "pixels differing from the reference's frame: %d" % nbad
+    assert nbad <= 20, "pixels differing from the reference's CPU frame: %d" % nbad
     assert diff.max() <= 2.0 / 16 + 1e-6
-    t0 = time.time()
-    bat = ref_rib.render_scene_subprocess(sp, str(tmp_path / "batched.npz"), env={"RI_HIP_RENDER": "batched"}, record=False, **kw)
+    bat = ref_rib.render_scene_subprocess(sp, str(tmp_path / "batched.npz"), accel_method=2, env={"RI_HIP_RENDER": "batched"},
+                                          record=False, **kw)
     img = bat["image"]
     assert np.array_equal(img.sum(axis=2) == 0, ref.sum(axis=2) == 0)      # the same pixels see geometry
     assert abs(float(img.mean()) - float(ref.mean())) < 2e-3
     assert float(np.sqrt(((img - ref) ** 2).mean())) < 0.06
     # the default mode is the batched one
-    dflt = ref_rib.render_scene_subprocess(sp, str(tmp_path / "default.npz"), record=False, **kw)
+    dflt = ref_rib.render_scene_subprocess(sp, str(tmp_path / "default.npz"), accel_method=2, record=False, **kw)
     assert np.array_equal(dflt["image"], img)
