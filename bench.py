@@ -458,15 +458,15 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
     info = acc.commit()
     c = g["camera"]
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
-    # one GPU: the whole frame as one tile; sharded: 64 tiles, tile_id % world
-    tile = max(64, size // 8) if world > 1 else min(size, 4096)
+    # one GPU: the whole frame as one tile; sharded: full-width bands, 8 per rank, band_id % world (render.bands_for)
+    tile = None if world > 1 else min(size, 4096)
     times = []; st = None; img = None; stats = []
     for it in range(steps + 1):
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev); t0 = time.perf_counter()
         if world > 1:
-            img, st = render.render_ao_frame_sharded(acc, cam, 1, nsamples, rank, world, tile=tile)
+            img, st = render.render_ao_frame_sharded(acc, cam, 1, nsamples, rank, world)
         else:
             img, st = render.render_ao_frame(acc, cam, 1, nsamples, tile=tile)
         torch.cuda.synchronize(dev)
@@ -492,7 +492,8 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
     if rank != 0:
         return None
     return {"workload": "BASELINE config 5: examples/ambient_occlusion scene tessellated to %d tris, %dx%d, %d AO samples, frame wall incl. ray gen + tile gather"
-                        % (ntri, size, size, nsamples), "triangles": ntri, "tile": tile,
+                        % (ntri, size, size, nsamples), "triangles": ntri,
+            "tile": tile if tile is not None else "%d full-width bands, band_id %% %d" % (len(render.bands_for(size, size, world)), world),
             "device_bytes": info["device_bytes"], "build_s": round(info["build_seconds"], 3),
             "ref_tree_build_s": round(info["ref_build_seconds"], 3),
             "rays_per_frame": int(rays.item()), "frame_ms": round(tmax.item() * 1e3, 3),

@@ -31,49 +31,61 @@ def render_ao_frame(acc, cam, pixel_samples, gather_nsamples, tile=256, seed=1, 
     return img, tot
 
 
-def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, world, tile=256, seed=1):
-    """Each rank renders its interleaved tiles; one gather of equal-sized tile slabs
-    assembles the frame on rank 0 (None elsewhere).  Returns (image|None, local stats)."""
+def bands_for(width, height, world, per_rank=8, min_rows=16):
+    """image-space shards for `world` ranks: full-width bands of equal height, `per_rank` of them for every rank,
+    interleaved (band_id % world == rank) so that sky / floor / silhouettes are spread over the ranks.  A band is one
+    device batch (one lh_render_ao_tile call: ~10 kernel launches + 2 small read-backs), so per_rank bounds the host
+    overhead per frame while the interleave bounds the imbalance.  -> list of (x0, y0, w, h)"""
+    n = max(1, world * per_rank)
+    rows = max(min_rows, -(-height // n))
+    return [(0, y0, width, min(rows, height - y0)) for y0 in range(0, height, rows)]
+
+
+def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, world, tile=None, seed=1, per_rank=8):
+    """Each rank renders its interleaved shards straight into its slab; ONE gather of the equal-sized slabs assembles
+    the frame on rank 0 (None elsewhere).  tile=None: full-width bands (bands_for); an int: square tiles as before.
+    Returns (image|None, local stats)."""
     import torch
     W, H = cam.width, cam.height
-    tiles = shard.tile_grid(W, H, tile)
-    mine = shard.tiles_of_rank(len(tiles), rank, world)
+    shards = bands_for(W, H, world, per_rank) if tile is None else shard.tile_grid(W, H, tile)
+    mine = shard.tiles_of_rank(len(shards), rank, world)
     dev = torch.device("cuda", acc.device)
-    slab = torch.zeros((len(mine), tile * tile * 3), dtype=torch.float32, device=dev)
+    cap = max(w * h for (_, _, w, h) in shards) * 3
+    per = (len(shards) + world - 1) // world
+    slab = torch.zeros((per, cap), dtype=torch.float32, device=dev)      # one allocation per frame; padding stays zero
     tot = {"primary_rays": 0, "primary_hits": 0, "ao_rays": 0, "ao_occluded": 0}
     for k, tid in enumerate(mine):
-        x0, y0, w, h = tiles[tid]
-        rgb, st = acc.render_ao_tile(cam, x0, y0, w, h, pixel_samples, gather_nsamples, seed=seed)
-        t = torch.zeros((tile, tile, 3), dtype=torch.float32, device=dev)
-        t[:h, :w] = rgb
-        slab[k] = t.view(-1)
+        x0, y0, w, h = shards[tid]
+        out = slab[k, :w * h * 3].view(h, w, 3)                          # the tile renders in place
+        _, st = acc.render_ao_tile(cam, x0, y0, w, h, pixel_samples, gather_nsamples, seed=seed, out=out)
         for kk in tot:
             tot[kk] += st[kk]
-    img = assemble(slab, W, H, tile, rank, world)
-    return img, tot
+    return assemble_shards(slab, shards, W, H, rank, world), tot
+
+
+def assemble_shards(slab, shards, W, H, rank, world):
+    """the exchange step (one gather of [per_rank, cap] slabs to rank 0) + placement with the reference's y flip
+    (bucket_write, render.c:962-964)"""
+    import torch
+    out = shard.gather_slabs(slab, rank, world)
+    if rank != 0:
+        return None
+    img = torch.zeros((H, W, 3), dtype=slab.dtype, device=slab.device)
+    for r in range(world):
+        for k, tid in enumerate(shard.tiles_of_rank(len(shards), r, world)):
+            x0, y0, w, h = shards[tid]
+            img[H - (y0 + h):H - y0, x0:x0 + w] = out[r][k, :w * h * 3].view(h, w, 3)
+    return img
 
 
 def assemble(slab, W, H, tile, rank, world):
-    """the exchange step + placement with the reference's y flip"""
+    """square-tile slabs [n, tile*tile*3] (rows of `tile` pixels, ragged tiles top-left aligned) -> frame on rank 0"""
     import torch
-    import torch.distributed as dist
     tiles = shard.tile_grid(W, H, tile)
     per_rank = (len(tiles) + world - 1) // world
     pad = torch.zeros((per_rank, tile * tile * 3), dtype=slab.dtype, device=slab.device)
     pad[:slab.shape[0]] = slab
-    if world > 1:
-        # the display owner is rank 0 (the reference's compiled-out MPI design: "everyone renders, rank 0
-        # owns the display", render.c:468-514): a GATHER -- seven point-to-point xGMI transfers landing on
-        # rank 0 in parallel -- not an all-gather whose ring would carry every slab past every GPU
-        if dist.get_backend() != "nccl" and pad.is_cuda:      # gloo (tests): stage through the host
-            hp = pad.cpu(); ho = [torch.empty_like(hp) for _ in range(world)] if rank == 0 else None
-            dist.gather(hp, ho, dst=0)
-            out = [t.to(pad.device) for t in ho] if rank == 0 else None
-        else:
-            out = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
-            dist.gather(pad, out, dst=0)
-    else:
-        out = [pad]
+    out = shard.gather_slabs(pad, rank, world)
     if rank != 0:
         return None
     img = torch.zeros((H, W, 3), dtype=slab.dtype, device=slab.device)

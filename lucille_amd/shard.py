@@ -84,3 +84,21 @@ def gather_bytes(buf, dst_list, async_op=False):
 def wait(work):
     if work is not None:
         work.wait()
+
+
+def gather_slabs(slab, rank, world):
+    """every rank's slab tensor (same shape everywhere) -> list of `world` tensors on rank 0, None elsewhere.
+    The display owner is rank 0 (the reference's compiled-out MPI design: "everyone renders, rank 0 owns the display",
+    render.c:468-514): a GATHER -- seven point-to-point xGMI transfers landing on rank 0 in parallel -- not an
+    all-gather whose ring would carry every slab past every GPU."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return [slab]
+    if dist.get_backend() != "nccl" and slab.is_cuda:          # gloo (tests): stage through the host
+        hp = slab.cpu(); ho = [torch.empty_like(hp) for _ in range(world)] if rank == 0 else None
+        dist.gather(hp, ho, dst=0)
+        return [t.to(slab.device) for t in ho] if rank == 0 else None
+    out = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
+    dist.gather(slab, out, dst=0)
+    return out

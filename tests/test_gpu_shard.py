@@ -1,0 +1,93 @@
+"""N > 1 on a ONE-GPU box, the torch.distributed way (one process per rank, as bench.py / the driver launch it): two
+ranks share cuda:0 (gloo for the exchange step), each with its own replica of the BVH.  The sharded AO and path-traced
+frames gathered on rank 0 must equal the unsharded frame bit for bit, and bench.py's own N = 2 code path (strong-scaling
+ray dump with the hit-record gather inside the timed region, sharded AO / PT legs) must validate itself."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      LH_DEVICE_OVERRIDE="0")
+    import torch
+    import torch.distributed as dist
+    import lucille_amd as la
+    from lucille_amd import render, shard
+    from tests.helpers import load_golden
+    shard.init_process_group(backend="gloo")
+    torch.cuda.set_device(0)
+    g = load_golden("ao_ps")
+    acc = la.HipAccel(0)
+    for k in range(int(g["ngeoms"])):
+        acc.add_mesh(g["pos%d" % k], g["idx%d" % k])
+        if ("nrm%d" % k) in g.files:
+            acc.set_normals(k, g["nrm%d" % k], int(g["two_side%d" % k]))
+    acc.commit()
+    c = g["camera"]
+    cam = la.Camera.make(200, 150, c[16], c[:16], int(c[19]))
+    out = {}
+    for name, kw in (("bands", {}), ("tiles", {"tile": 64})):
+        img, st = render.render_ao_frame_sharded(acc, cam, 2, 16, rank, world, seed=3, **kw)
+        stt = torch.tensor([st["primary_rays"], st["primary_hits"], st["ao_rays"], st["ao_occluded"]], dtype=torch.int64)
+        dist.all_reduce(stt)
+        if rank == 0:
+            ref, st1 = render.render_ao_frame(acc, cam, 2, 16, tile=200, seed=3)
+            out[name] = bool(torch.equal(img, ref)) and [int(x) for x in stt] == [st1[k] for k in ("primary_rays", "primary_hits", "ao_rays", "ao_occluded")]
+    pimg, pst = render.render_pt_frame_sharded(acc, cam, 12, rank, world, tile=64, spp_chunk=6, kd=0.7, env=(1.0, 0.9, 0.8), max_vertices=5, seed=2)
+    if rank == 0:
+        ref = torch.zeros((150, 200, 3), dtype=torch.float32, device="cuda")
+        for s0 in (0, 6):
+            acc.render_pt_tile(cam, 0, 0, 200, 150, s0, 6, 12, kd=0.7, env=(1.0, 0.9, 0.8), max_vertices=5, seed=2, out=ref)
+        torch.cuda.synchronize()
+        out["pt"] = bool(torch.allclose(pimg, ref, rtol=0, atol=1e-6))
+        q.put(out)
+    dist.barrier()
+    acc.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_the_unsharded_frames():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    assert out == {"bands": True, "tiles": True, "pt": True}, out
+
+
+def test_bench_n2_code_path_on_one_gpu():
+    """bench.py exactly as the driver launches it for N = 2, both ranks on device 0 (gloo): the JSON line must carry a
+    passing validation of the strong-scaling ray dump (rank 0's own records + the gathered slices) and of the legs"""
+    env = dict(os.environ)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--device-override", "0", "--rays", "3000001", "--tris", "200000", "--half-extent", "0.01",
+           "--no-cpu", "--no-hbm", "--ao-size", "256", "--ao-tess", "2", "--ao-samples", "16", "--pt-size", "128", "--pt-spp", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["rays"] == 3000001
+    assert j["validation"]["ok"] and j["validation"]["gathered_records_ok"] and j["validation"]["timed_equals_counted_launch"]
+    assert j["ao_render"]["validation"]["ok"] and j["ao_render"]["rays_per_frame"] > 0
+    assert j["pt_render"]["rays_per_frame"] > 0 and j["value"] > 0
