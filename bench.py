@@ -458,7 +458,7 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
     info = acc.commit()
     c = g["camera"]
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
-    # one GPU: the whole frame as one tile; sharded: full-width bands, 8 per rank, band_id % world (render.bands_for)
+    # one GPU: the whole frame as one tile; sharded: full-width bands, ~16 per rank, band_id % world, ONE device batch per rank (render.bands_for / lh_render_ao_bands)
     tile = None if world > 1 else min(size, 4096)
     times = []; st = None; img = None; stats = []
     for it in range(steps + 1):
@@ -493,7 +493,8 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
         return None
     return {"workload": "BASELINE config 5: examples/ambient_occlusion scene tessellated to %d tris, %dx%d, %d AO samples, frame wall incl. ray gen + tile gather"
                         % (ntri, size, size, nsamples), "triangles": ntri,
-            "tile": tile if tile is not None else "%d full-width bands, band_id %% %d" % (len(render.bands_for(size, size, world)), world),
+            "tile": tile if tile is not None else "%d full-width bands of %d rows, band_id %% %d, one device batch per rank" % (
+                len(render.bands_for(size, world)[1]), render.bands_for(size, world)[0], world),
             "device_bytes": info["device_bytes"], "build_s": round(info["build_seconds"], 3),
             "ref_tree_build_s": round(info["ref_build_seconds"], 3),
             "rays_per_frame": int(rays.item()), "frame_ms": round(tmax.item() * 1e3, 3),

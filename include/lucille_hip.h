@@ -170,6 +170,15 @@ int  lh_render_ao_tile(lh_accel_t *accel, const lh_camera_t *cam, int x0, int y0
                        int pixel_samples, int gather_nsamples, uint64_t seed,
                        const void *d_uniforms, void *d_rgb, lh_tile_stats_t *stats, void *stream);
 
+/* nbands full-width bands of band_rows lines each (band b = frame lines band_y0[b] .. + band_rows, clipped at the frame)
+ * as ONE device batch -- how a rank renders ALL of its interleaved shards of a frame (image space sharded
+ * over the GPUs) with one set of kernel launches: every launch of the persistent traversal kernel ends with a drain
+ * as long as its slowest ray (~1.7 ms on BASELINE config 5), paid once per batch instead of once per shard.
+ * band_y0: nbands ints (HOST).  d_rgb: float[nbands][band_rows][width][3], every band in image orientation. */
+int  lh_render_ao_bands(lh_accel_t *accel, const lh_camera_t *cam, int nbands, const int *band_y0, int band_rows,
+                        int pixel_samples, int gather_nsamples, uint64_t seed, void *d_rgb, lh_tile_stats_t *stats,
+                        void *stream);
+
 /* the same tile for a plain-C host (the batched frame loop inside lucille, integration/ri_render_hip.c): rgb is
  * HOST memory (h rows of w RGB floats, image orientation); uniforms (HOST, may be NULL) as d_uniforms above --
  * nuniforms must cover the worst case 2 * floor(sqrt(gather_nsamples))^2 * w * h * pixel_samples^2; the tile

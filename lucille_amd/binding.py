@@ -98,7 +98,7 @@ ABI_SYMBOLS = [
     "lh_accel_destroy", "lh_accel_info", "lh_accel_prim_lookup", "lh_accel_intersect1",
     "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted",
     "lh_accel_set_grid", "lh_accel_set_param", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
-    "lh_render_ao_tile", "lh_render_ao_tile_host", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device", "lh_render_pt_tile",
+    "lh_render_ao_tile", "lh_render_ao_tile_host", "lh_render_ao_bands", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device", "lh_render_pt_tile",
     "lh_accel_trace_statistics", "lh_accel_statistics",
     "lh_render_ao_frame_host", "lh_rib_load", "lh_rib_free", "lh_rib_last_error", "lh_rib_info", "lh_rib_messages",
     "lh_rib_mesh", "lh_accel_add_rib_scene", "lh_hdr_write",
@@ -152,6 +152,7 @@ def lib():
     L.lh_render_primary_rays.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, vp, vp, vp]
     L.lh_render_ao_tile.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, C.c_uint64, vp, vp,
                                     C.POINTER(TileStats), vp]
+    L.lh_render_ao_bands.argtypes = [vp, C.POINTER(Camera), i32, C.POINTER(i32), i32, i32, i32, C.c_uint64, vp, C.POINTER(TileStats), vp]
     L.lh_render_scratch.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz)]
     L.lh_render_pt_tile.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, i32, i32, C.c_float,
                                     C.POINTER(C.c_float * 3), C.c_uint64, vp, C.POINTER(PtStats), vp]
@@ -381,6 +382,21 @@ class HipAccel:
         _check(self.L.lh_render_ao_tile(self.h, C.byref(cam), x0, y0, w, h, pixel_samples, gather_nsamples, int(seed),
                                         _dptr(uniforms), _dptr(out), C.byref(st), C.c_void_p(stream)),
                "lh_render_ao_tile")
+        return out, {k: int(getattr(st, k)) for k, _ in st._fields_}
+
+    def render_ao_bands(self, cam, band_y0, band_rows, pixel_samples, gather_nsamples, seed=1, out=None, stream=None):
+        """full-width bands (first lines band_y0, band_rows lines each) as ONE device batch ->
+        (float32 [nbands, band_rows, W, 3] CUDA tensor, every band in image orientation, stats)"""
+        import torch
+        dev = torch.device("cuda", self.device)
+        nb = len(band_y0)
+        if out is None:
+            out = torch.zeros((nb, band_rows, cam.width, 3), dtype=torch.float32, device=dev)
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        st = TileStats(); arr = (C.c_int * max(nb, 1))(*[int(y) for y in band_y0])
+        _check(self.L.lh_render_ao_bands(self.h, C.byref(cam), nb, arr, int(band_rows), pixel_samples, gather_nsamples, int(seed),
+                                         _dptr(out), C.byref(st), C.c_void_p(stream)), "lh_render_ao_bands")
         return out, {k: int(getattr(st, k)) for k, _ in st._fields_}
 
     def render_pt_tile(self, cam, x0, y0, w, h, spp_begin, spp_count, spp_total, max_vertices=8, kd=0.8,

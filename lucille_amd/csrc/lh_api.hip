@@ -47,12 +47,15 @@ extern "C" int lh_render_launch_compact(const lh_dev_scene_t *sc, const double *
                                         const double *d_dir, const uint32_t *d_prim, const double *d_t,
                                         const double *d_u, const double *d_v, uint32_t *d_block_counts,
                                         uint32_t *d_slot_of_sample, double *d_hitrec,
-                                        unsigned long long *d_slot_key, int x0, int y0, int w, int spp, int full_width,
+                                        unsigned long long *d_slot_key, int x0, int w, int nbands, int band_rows,
+                                        const int *d_band_y0, int y0, int spp, int full_width,
                                         unsigned long long *d_total, void *stream);
+extern "C" int lh_render_launch_primary_region(const lh_camera_t *cam, int x0, int w, int nbands, int band_rows, const int *d_band_y0,
+                                               int y0, int height_limit, int xs, int ys, double *d_org, double *d_dir, void *stream);
 extern "C" int lh_render_launch_ao_rays(size_t nslots, int ntheta, int nphi, unsigned long long seed,
                                         const double *d_hitrec, const double *d_rnd,
                                         const unsigned long long *d_slot_key, double *d_org, double *d_dir, void *stream);
-extern "C" int lh_render_launch_resolve(int w, int h, int xs, int ys, int N, const uint32_t *d_slot_of_sample,
+extern "C" int lh_render_launch_resolve(int w, int h, int band_rows, int xs, int ys, int N, const uint32_t *d_slot_of_sample,
                                         const uint8_t *d_occ, const unsigned int *d_occ_count, float *d_rgb,
                                         unsigned long long *d_occ_total, void *stream);
 
@@ -113,6 +116,7 @@ struct lh_accel {
     lh_environment_t env; void *d_env_map;
     lh_buf r_state;                    /* lh_accel_state_build_host staging */
     lh_buf r_uni;                      /* lh_render_ao_tile_host: caller uniforms on the device */
+    lh_buf r_bands;                    /* lh_render_ao_bands: first line of every band */
     /* tile-render scratch (lh_render_ao_tile) */
     lh_buf r_org, r_dir, r_prim, r_t, r_u, r_v, r_slot, r_hitrec, r_aorg, r_adir, r_occ, r_blocks, r_key, r_frame, r_occcount;
     int ao_fused;                      /* AO rays generated inside the any-hit kernel (default); 0: materialised in HBM */
@@ -267,7 +271,7 @@ static void release_device(lh_accel_t *a)
     if (a->d_materials) (void)hipFree(a->d_materials);
     if (a->d_env_map) (void)hipFree(a->d_env_map);
     a->d_st6 = a->d_inside = a->d_prim_mesh = a->d_materials = a->d_env_map = NULL;
-    free_buf(&a->r_state); free_buf(&a->r_uni);
+    free_buf(&a->r_state); free_buf(&a->r_uni); free_buf(&a->r_bands);
     a->d_total = NULL; a->d_nrm9 = NULL;
     if (a->d_nodes) (void)hipFree(a->d_nodes);
     if (a->d_tri32) (void)hipFree(a->d_tri32);
@@ -1013,14 +1017,12 @@ extern "C" int lh_accel_add_rib_scene(lh_accel_t *a, const lh_rib_scene_t *scene
     return 0;
 }
 
-extern "C" int lh_render_ao_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int ps,
-                                 int gather_nsamples, uint64_t seed, const void *d_uniforms, void *d_rgb,
-                                 lh_tile_stats_t *stats, void *stream)
+/* one device batch of the AO pipeline over a Region (lh_render.hip): a rectangle, or nbands full-width bands */
+static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int nbands, int band_rows, const int *d_band_y0, int y0,
+                     uint64_t valid_pixels, int ps, int gather_nsamples, uint64_t seed, const void *d_uniforms, void *d_rgb,
+                     lh_tile_stats_t *stats, void *stream)
 {
-    lh_guard guard(a);
-    if (!a || !a->committed) return fail("lh_render_ao_tile: accel not committed");
-    if (!cam || !d_rgb) return fail("lh_render_ao_tile: NULL argument");
-    if (w <= 0 || h <= 0 || ps < 1 || gather_nsamples < 1) return fail("lh_render_ao_tile: bad tile/sample counts");
+    const int h = nbands * band_rows;              /* lines of the batch */
     HIPCHK(hipSetDevice(a->device));
     hipStream_t s = (hipStream_t)stream;
     const int nphi = (int)sqrt((double)gather_nsamples), ntheta = nphi, N = nphi * ntheta;   /* ambientocclusion.c:378-380 */
@@ -1030,7 +1032,8 @@ extern "C" int lh_render_ao_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
         ensure_buf(&a->r_t, S * 8) || ensure_buf(&a->r_u, S * 8) || ensure_buf(&a->r_v, S * 8) ||
         ensure_buf(&a->r_slot, S * 4) || ensure_buf(&a->r_blocks, (size_t)nb * 4)) return -1;
     /* 1. camera rays */
-    if (lh_render_launch_primary(cam, x0, y0, w, h, ps, ps, (double *)a->r_org.p, (double *)a->r_dir.p, s) != 0)
+    if (lh_render_launch_primary_region(cam, x0, w, nbands, band_rows, d_band_y0, y0, cam->height, ps, ps,
+                                        (double *)a->r_org.p, (double *)a->r_dir.p, s) != 0)
         return fail("primary ray kernel launch failed");
     /* 2. closest hit */
     if (launch(a, S, a->r_org.p, a->r_dir.p, a->r_prim.p, a->r_t.p, a->r_u.p, a->r_v.p, NULL, LH_MODE_CLOSEST,
@@ -1043,7 +1046,7 @@ extern "C" int lh_render_ao_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
                                      (const double *)a->r_dir.p, (const uint32_t *)a->r_prim.p, (const double *)a->r_t.p,
                                      (const double *)a->r_u.p, (const double *)a->r_v.p, (uint32_t *)a->r_blocks.p,
                                      (uint32_t *)a->r_slot.p, (double *)a->r_hitrec.p, (unsigned long long *)a->r_key.p,
-                                     x0, y0, w, ps * ps, cam->width, a->d_total, s) != 0)
+                                     x0, w, nbands, band_rows, d_band_y0, y0, ps * ps, cam->width, a->d_total, s) != 0)
             return fail("compaction kernels failed: %s", hipGetErrorString(hipGetLastError()));
         HIPCHK(hipMemcpyAsync(&nhit, a->d_total, sizeof(nhit), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -1090,17 +1093,53 @@ extern "C" int lh_render_ao_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
     }
     /* 6. radiance */
     HIPCHK(hipMemsetAsync(a->d_total, 0, sizeof(unsigned long long), s));
-    if (lh_render_launch_resolve(w, h, ps, ps, N, (const uint32_t *)a->r_slot.p, (const uint8_t *)a->r_occ.p,
+    if (lh_render_launch_resolve(w, h, band_rows, ps, ps, N, (const uint32_t *)a->r_slot.p, (const uint8_t *)a->r_occ.p,
                                  fused ? (const unsigned int *)a->r_occcount.p : NULL, (float *)d_rgb, a->d_total, s) != 0)
         return fail("resolve kernel launch failed");
     HIPCHK(hipMemcpyAsync(&nocc, a->d_total, sizeof(nocc), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     a->r_nsamples = S; a->r_nslots = (size_t)nhit; a->r_nao = fused ? 0 : nao;
     if (stats) {
-        stats->primary_rays = S; stats->primary_hits = nhit; stats->ao_rays = nao; stats->ao_occluded = nocc;
+        stats->primary_rays = valid_pixels * (uint64_t)(ps * ps); stats->primary_hits = nhit; stats->ao_rays = nao; stats->ao_occluded = nocc;
     }
     HIPCHK(hipStreamSynchronize(s));
     return 0;
+}
+
+extern "C" int lh_render_ao_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int ps,
+                                 int gather_nsamples, uint64_t seed, const void *d_uniforms, void *d_rgb,
+                                 lh_tile_stats_t *stats, void *stream)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_render_ao_tile: accel not committed");
+    if (!cam || !d_rgb) return fail("lh_render_ao_tile: NULL argument");
+    if (w <= 0 || h <= 0 || ps < 1 || gather_nsamples < 1) return fail("lh_render_ao_tile: bad tile/sample counts");
+    return ao_region(a, cam, x0, w, 1, h, NULL, y0, (uint64_t)w * h, ps, gather_nsamples, seed, d_uniforms, d_rgb, stats, stream);
+}
+
+/* nbands full-width bands of band_rows lines (band b = frame lines band_y0[b] ...; a band that runs past the frame is
+ * clipped) as ONE device batch: how a rank renders all of its interleaved shards of a frame with one set of launches.
+ * d_rgb: float[nbands][band_rows][width][3], every band in image orientation (top line first) like a tile. */
+extern "C" int lh_render_ao_bands(lh_accel_t *a, const lh_camera_t *cam, int nbands, const int *band_y0, int band_rows, int ps,
+                                  int gather_nsamples, uint64_t seed, void *d_rgb, lh_tile_stats_t *stats, void *stream)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_render_ao_bands: accel not committed");
+    if (!cam || !d_rgb || (nbands > 0 && !band_y0)) return fail("lh_render_ao_bands: NULL argument");
+    if (nbands < 0 || band_rows <= 0 || ps < 1 || gather_nsamples < 1) return fail("lh_render_ao_bands: bad band/sample counts");
+    if (nbands == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return 0; }
+    HIPCHK(hipSetDevice(a->device));
+    uint64_t valid = 0;
+    for (int b = 0; b < nbands; b++) {
+        if (band_y0[b] < 0 || band_y0[b] >= cam->height) return fail("lh_render_ao_bands: band %d starts at line %d outside the frame", b, band_y0[b]);
+        const int rows = (band_y0[b] + band_rows <= cam->height) ? band_rows : cam->height - band_y0[b];
+        valid += (uint64_t)rows * cam->width;
+    }
+    if (ensure_buf(&a->r_bands, sizeof(int) * (size_t)nbands)) return -1;
+    HIPCHK(hipMemcpyAsync(a->r_bands.p, band_y0, sizeof(int) * (size_t)nbands, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));          /* band_y0 is the caller's memory */
+    return ao_region(a, cam, 0, cam->width, nbands, band_rows, (const int *)a->r_bands.p, 0, valid, ps, gather_nsamples, seed, NULL,
+                     d_rgb, stats, stream);
 }
 
 /* the same tile for a plain-C host program: uniforms (optional) come from and the tile goes to HOST memory */

@@ -43,6 +43,26 @@ struct DevCamera {
     int width, height, rh, ortho;
 };
 
+/* the pixels of one device batch: nbands full-rows-of-w bands of band_rows lines each, band b starting at frame line
+ * band_y0[b] (or y0 when there is a single band: a plain rectangle).  Pixel index p of the batch: band = p / (w * band_rows),
+ * line = (p / w) % band_rows, column = p % w.  A rank's interleaved shards of a frame are ONE such batch: one set of kernel
+ * launches -- and one kernel drain, ~1.7 ms on BASELINE config 5 where a few grazing AO rays walk thousands of floor boxes
+ * (profiles/README.md r02c) -- per frame instead of one per shard.  Lines >= height (a ragged last band) produce rays that
+ * start far outside the scene and miss. */
+struct Region {
+    int x0, w, band_rows, nbands, height, y0;
+    const int *band_y0;
+};
+
+__device__ __forceinline__ void region_pixel(const Region &rg, size_t pix, int &px, int &py)
+{
+    const size_t per = (size_t)rg.w * rg.band_rows;
+    const int band = (int)(pix / per);
+    const size_t within = pix % per;
+    px = rg.x0 + (int)(within % (size_t)rg.w);
+    py = (rg.band_y0 ? rg.band_y0[band] : rg.y0) + (int)(within / (size_t)rg.w);
+}
+
 __device__ __forceinline__ void vnormalize(double d[3])
 {   /* ri_vector_normalize (vector.h:75-86): FLOAT threshold literal */
     LH_NC
@@ -65,16 +85,22 @@ __device__ __forceinline__ unsigned sigma_of(unsigned i, unsigned period)
 }
 
 /* one thread per pixel sub-sample: sample id = ((ly*w + lx)*ys + sy)*xs + sx */
-__global__ void k_primary_rays(DevCamera cam, int x0, int y0, int w, int h, int xs, int ys,
+__global__ void k_primary_rays(DevCamera cam, Region rg, int xs, int ys,
                                double *__restrict__ org, double *__restrict__ dir)
 {
     LH_NC
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)w * h * xs * ys;
+    const size_t total = (size_t)rg.w * rg.band_rows * rg.nbands * xs * ys;
     if (id >= total) return;
     const int sx = (int)(id % xs), sy = (int)((id / xs) % ys);
     const size_t pix = id / ((size_t)xs * ys);
-    const int px = x0 + (int)(pix % w), py = y0 + (int)(pix / w);
+    int px, py;
+    region_pixel(rg, pix, px, py);
+    if (py >= rg.height) {          /* below the frame (ragged last band): a ray that misses everything */
+        org[3 * id] = 1.0e30; org[3 * id + 1] = 1.0e30; org[3 * id + 2] = 1.0e30;
+        dir[3 * id] = 1.0; dir[3 * id + 1] = 1.0; dir[3 * id + 2] = 1.0;
+        return;
+    }
     /* sample_subpixel (render.c:830-861) */
     const unsigned j = (unsigned)sx & ((unsigned)xs - 1), k = (unsigned)sy & ((unsigned)xs - 1);
     double jx = (double)sx + (double)sigma_of(k, (unsigned)xs) / (double)xs;
@@ -146,7 +172,7 @@ __global__ void k_ao_setup(size_t n, const lh_dev_scene_t sc, const double *__re
                            const double *__restrict__ u, const double *__restrict__ v,
                            const uint32_t *__restrict__ block_offsets, uint32_t *__restrict__ slot_of_sample,
                            double *__restrict__ hitrec, unsigned long long *__restrict__ slot_key,
-                           int x0, int y0, int w, int spp, int full_width)
+                           const Region rg, int spp, int full_width)
 {
     LH_NC
     __shared__ uint32_t wsum[4];
@@ -164,9 +190,9 @@ __global__ void k_ao_setup(size_t n, const lh_dev_scene_t sc, const double *__re
     slot_of_sample[i] = slot;
     {   /* absolute sample key (frame position, not tile position): keeps the built-in
          * RNG independent of how the frame is tiled or sharded */
-        const size_t pix = i / (size_t)spp;
-        const unsigned long long px = (unsigned long long)(x0 + (int)(pix % (size_t)w));
-        const unsigned long long py = (unsigned long long)(y0 + (int)(pix / (size_t)w));
+        int ipx, ipy;
+        region_pixel(rg, i / (size_t)spp, ipx, ipy);
+        const unsigned long long px = (unsigned long long)ipx, py = (unsigned long long)ipy;
         slot_key[slot] = (py * (unsigned long long)full_width + px) * (unsigned long long)spp + (i % (size_t)spp);
     }
 
@@ -239,14 +265,15 @@ __global__ void k_ao_rays(size_t nslots, int ntheta, int nphi, unsigned long lon
 
 /* one thread per pixel: accumulates its sub-samples exactly like subsample()
  * (render.c:749-822) and bucket_write (:962-975): rgb[(h-1-ly)*w + lx] */
-__global__ void k_ao_resolve(int w, int h, int xs, int ys, int N, const uint32_t *__restrict__ slot_of_sample,
+__global__ void k_ao_resolve(int w, int h, int band_rows, int xs, int ys, int N, const uint32_t *__restrict__ slot_of_sample,
                              const uint8_t *__restrict__ occ, const unsigned int *__restrict__ occ_count,
                              float *__restrict__ rgb, unsigned long long *__restrict__ occ_total)
 {
     LH_NC
     const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= (size_t)w * h) return;
-    const int lx = (int)(pix % w), ly = (int)(pix / w);
+    /* h = all lines of the batch (nbands * band_rows); every band is flipped within itself, as a tile is */
+    const int lx = (int)(pix % w), line = (int)(pix / w), band = line / band_rows, ly = line % band_rows;
     double accum = 0.0;
     unsigned int nocc = 0;
     const int S = xs * ys;
@@ -270,7 +297,7 @@ __global__ void k_ao_resolve(int w, int h, int xs, int ys, int N, const uint32_t
     const double val = accum * ((double)1.0 / (xs * ys));
     float f = (float)val;
     if (f < 0.0f) f = 0.0f;
-    float *o = rgb + 3 * ((size_t)(h - 1 - ly) * w + lx);
+    float *o = rgb + 3 * ((size_t)(band * band_rows + (band_rows - 1 - ly)) * w + lx);
     o[0] = f; o[1] = f; o[2] = f;
     if (occ_total && nocc) atomicAdd(occ_total, (unsigned long long)nocc);
 }
@@ -590,24 +617,39 @@ __global__ void k_pt_resolve(int w, int h, int spp, float inv_total_spp, const f
 
 /* ---- host side -------------------------------------------------------------- */
 
-extern "C" int lh_render_launch_primary(const lh_camera_t *cam, int x0, int y0, int w, int h, int xs, int ys,
-                                        double *d_org, double *d_dir, void *stream)
+static Region make_region(int x0, int w, int nbands, int band_rows, const int *d_band_y0, int y0, int height)
+{
+    Region rg; rg.x0 = x0; rg.w = w; rg.band_rows = band_rows; rg.nbands = nbands; rg.height = height; rg.y0 = y0; rg.band_y0 = d_band_y0;
+    return rg;
+}
+
+/* d_band_y0 NULL: one band starting at y0 (a rectangle); height_limit: lines at or beyond it produce missing rays
+ * (pass INT_MAX-like for "no limit": the plain rectangle entry points never clip) */
+extern "C" int lh_render_launch_primary_region(const lh_camera_t *cam, int x0, int w, int nbands, int band_rows, const int *d_band_y0,
+                                               int y0, int height_limit, int xs, int ys, double *d_org, double *d_dir, void *stream)
 {
     DevCamera c;
     for (int i = 0; i < 16; i++) c.c2w[i] = cam->cam2world[i];
     c.flength = cam->flength; c.width = cam->width; c.height = cam->height; c.rh = cam->rh; c.ortho = cam->ortho;
-    const size_t total = (size_t)w * h * xs * ys;
+    const size_t total = (size_t)w * band_rows * nbands * xs * ys;
     if (total == 0) return 0;
     hipLaunchKernelGGL(k_primary_rays, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       c, x0, y0, w, h, xs, ys, d_org, d_dir);
+                       c, make_region(x0, w, nbands, band_rows, d_band_y0, y0, height_limit), xs, ys, d_org, d_dir);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int lh_render_launch_primary(const lh_camera_t *cam, int x0, int y0, int w, int h, int xs, int ys,
+                                        double *d_org, double *d_dir, void *stream)
+{
+    return lh_render_launch_primary_region(cam, x0, w, 1, h, NULL, y0, 0x7fffffff, xs, ys, d_org, d_dir, stream);
 }
 
 extern "C" int lh_render_launch_compact(const lh_dev_scene_t *sc, const double *d_nrm9, size_t n, const double *d_org,
                                         const double *d_dir, const uint32_t *d_prim, const double *d_t,
                                         const double *d_u, const double *d_v, uint32_t *d_block_counts,
                                         uint32_t *d_slot_of_sample, double *d_hitrec,
-                                        unsigned long long *d_slot_key, int x0, int y0, int w, int spp, int full_width,
+                                        unsigned long long *d_slot_key, int x0, int w, int nbands, int band_rows,
+                                        const int *d_band_y0, int y0, int spp, int full_width,
                                         unsigned long long *d_total, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
@@ -616,7 +658,8 @@ extern "C" int lh_render_launch_compact(const lh_dev_scene_t *sc, const double *
     hipLaunchKernelGGL(k_hit_count, dim3(nb), dim3(256), 0, s, n, d_prim, d_block_counts);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, nb, d_block_counts, d_total);
     hipLaunchKernelGGL(k_ao_setup, dim3(nb), dim3(256), 0, s, n, *sc, d_nrm9, d_org, d_dir, d_prim, d_t, d_u, d_v,
-                       d_block_counts, d_slot_of_sample, d_hitrec, d_slot_key, x0, y0, w, spp, full_width);
+                       d_block_counts, d_slot_of_sample, d_hitrec, d_slot_key,
+                       make_region(x0, w, nbands, band_rows, d_band_y0, y0, 0x7fffffff), spp, full_width);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -631,14 +674,14 @@ extern "C" int lh_render_launch_ao_rays(size_t nslots, int ntheta, int nphi, uns
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-extern "C" int lh_render_launch_resolve(int w, int h, int xs, int ys, int N, const uint32_t *d_slot_of_sample,
+extern "C" int lh_render_launch_resolve(int w, int h, int band_rows, int xs, int ys, int N, const uint32_t *d_slot_of_sample,
                                         const uint8_t *d_occ, const unsigned int *d_occ_count, float *d_rgb,
                                         unsigned long long *d_occ_total, void *stream)
 {
     const size_t total = (size_t)w * h;
     if (total == 0) return 0;
     hipLaunchKernelGGL(k_ao_resolve, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       w, h, xs, ys, N, d_slot_of_sample, d_occ, d_occ_count, d_rgb, d_occ_total);
+                       w, h, band_rows, xs, ys, N, d_slot_of_sample, d_occ, d_occ_count, d_rgb, d_occ_total);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -28,6 +28,9 @@ static void usage(void)
            "    --resolution WxH  Override Format.\n"
            "    --gather       N  Override Option \"gather\" \"nsamples\" (AO rays per hit).\n"
            "    --device       N  HIP device ordinal.\n"
+           "    --gpus         N  Render on N GPUs of this node (one host build, replicated; tile queue; slabs\n"
+           "                      gathered on the first device).  --devices a,b,.. picks them (repeats allowed).\n"
+           "    --tile         N  Tile edge in pixels of the multi-GPU tile queue (default 256).\n"
            "    --seed         N  Seed of the AO sample stream.\n"
            "    --parse-only      Read the RIB, print what was found, do not render.\n\n");
 }
@@ -36,6 +39,7 @@ int main(int argc, char **argv)
 {
     const char *rib = NULL, *output = NULL; int i, verbose = 0, ps = -1, gather = -1, device = 0, parse_only = 0, W = -1, H = -1;
     unsigned long long seed = 1;
+    int ngpus = 1, devices[64], ndev_listed = 0, tile = 256; lh_multi_t *multi = NULL; double dev_secs[64];
     lh_rib_scene_t *scene = NULL; lh_rib_info_t info; lh_accel_t *accel = NULL; lh_accel_info_t ai; lh_tile_stats_t st;
     float *rgb; double t0, t1, t2, t3;
 
@@ -53,6 +57,12 @@ int main(int argc, char **argv)
         else if (i + 1 < argc && strcmp(a, "pixelsamples") == 0) ps = atoi(argv[++i]);
         else if (i + 1 < argc && strcmp(a, "gather") == 0) gather = atoi(argv[++i]);
         else if (i + 1 < argc && strcmp(a, "device") == 0) device = atoi(argv[++i]);
+        else if (i + 1 < argc && strcmp(a, "gpus") == 0) ngpus = atoi(argv[++i]);
+        else if (i + 1 < argc && strcmp(a, "tile") == 0) tile = atoi(argv[++i]);
+        else if (i + 1 < argc && strcmp(a, "devices") == 0) {
+            char *p = argv[++i];
+            while (*p && ndev_listed < 64) { devices[ndev_listed++] = (int)strtol(p, &p, 10); if (*p == ',') p++; }
+        }
         else if (i + 1 < argc && strcmp(a, "seed") == 0) seed = strtoull(argv[++i], NULL, 10);
         else if (i + 1 < argc && strcmp(a, "resolution") == 0) { if (sscanf(argv[++i], "%dx%d", &W, &H) != 2) { usage(); return 1; } }
         else { fprintf(stderr, "lsh_hip: unknown option %s\n", argv[i]); usage(); return 1; }
@@ -86,21 +96,34 @@ int main(int argc, char **argv)
         lh_rib_free(scene); return 0;
     }
 
-    if (lh_accel_create(&accel, device) != 0 || lh_accel_add_rib_scene(accel, scene) != 0 || lh_accel_commit(accel, 0) != 0) {
+    if (ndev_listed > 0) ngpus = ndev_listed;
+    if (ngpus > 1 || ndev_listed > 0) {
+        /* the G GPUs of this node from this one process (lh_multi_*: SURVEY 8b(4), 8e) */
+        if (lh_multi_create(&multi, ngpus, ndev_listed ? devices : NULL) != 0 || lh_multi_add_rib_scene(multi, scene) != 0 ||
+            lh_multi_commit(multi, 0) != 0) {
+            fprintf(stderr, "lsh_hip: %s\n", lh_last_error()); lh_rib_free(scene); return 1;
+        }
+        accel = lh_multi_accel(multi, 0);
+    } else if (lh_accel_create(&accel, device) != 0 || lh_accel_add_rib_scene(accel, scene) != 0 || lh_accel_commit(accel, 0) != 0) {
         fprintf(stderr, "lsh_hip: %s\n", lh_last_error()); lh_rib_free(scene); return 1;
     }
     lh_accel_info(accel, &ai);
     t2 = now_s();
-    printf("[lucille_hip] BVH building: %.3f s  (%u nodes, depth %u)\n", t2 - t1, ai.nnodes, ai.max_depth);
+    printf("[lucille_hip] BVH building: %.3f s  (%u nodes, depth %u%s)\n", t2 - t1, ai.nnodes, ai.max_depth, multi ? "; one host build, replicated" : "");
 
     rgb = (float *)malloc(sizeof(float) * 3 * (size_t)info.camera.width * info.camera.height);
     if (!rgb) { fprintf(stderr, "lsh_hip: out of memory\n"); return 1; }
-    if (lh_render_ao_frame_host(accel, &info.camera, ps, gather, seed, 0, rgb, &st) != 0) { fprintf(stderr, "lsh_hip: %s\n", lh_last_error()); return 1; }
+    if (multi) {
+        if (lh_multi_render_ao_frame_host(multi, &info.camera, ps, gather, seed, tile, rgb, &st, dev_secs) != 0) { fprintf(stderr, "lsh_hip: %s\n", lh_last_error()); return 1; }
+        if (verbose) for (i = 0; i < lh_multi_ndevices(multi); i++) printf("[lucille_hip] replica %d busy %.3f s\n", i, dev_secs[i]);
+    } else if (lh_render_ao_frame_host(accel, &info.camera, ps, gather, seed, 0, rgb, &st) != 0) { fprintf(stderr, "lsh_hip: %s\n", lh_last_error()); return 1; }
     t3 = now_s();
     printf("[lucille_hip] Rendering   : %.3f s  (%llu primary + %llu AO rays, %.1f Mrays/s)\n", t3 - t2, (unsigned long long)st.primary_rays,
            (unsigned long long)st.ao_rays, 1e-6 * (double)(st.primary_rays + st.ao_rays) / (t3 - t2));
     if (lh_hdr_write(output, info.camera.width, info.camera.height, rgb) != 0) { fprintf(stderr, "lsh_hip: %s\n", lh_rib_last_error()); return 1; }
     printf("[lucille_hip] (Disp) Output written to \"%s\"\n", output);
-    free(rgb); lh_accel_destroy(accel); lh_rib_free(scene);
+    free(rgb);
+    if (multi) lh_multi_destroy(multi); else lh_accel_destroy(accel);
+    lh_rib_free(scene);
     return 0;
 }

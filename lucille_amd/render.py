@@ -31,25 +31,38 @@ def render_ao_frame(acc, cam, pixel_samples, gather_nsamples, tile=256, seed=1, 
     return img, tot
 
 
-def bands_for(width, height, world, per_rank=8, min_rows=16):
-    """image-space shards for `world` ranks: full-width bands of equal height, `per_rank` of them for every rank,
-    interleaved (band_id % world == rank) so that sky / floor / silhouettes are spread over the ranks.  A band is one
-    device batch (one lh_render_ao_tile call: ~10 kernel launches + 2 small read-backs), so per_rank bounds the host
-    overhead per frame while the interleave bounds the imbalance.  -> list of (x0, y0, w, h)"""
-    n = max(1, world * per_rank)
-    rows = max(min_rows, -(-height // n))
-    return [(0, y0, width, min(rows, height - y0)) for y0 in range(0, height, rows)]
+def bands_for(height, world, rows=None):
+    """image-space shards for `world` ranks: full-width bands of `rows` lines (default 4; LH_BAND_ROWS overrides),
+    interleaved band_id % world == rank.  A rank renders ALL of its bands as ONE device batch (lh_render_ao_bands), so fine
+    bands cost nothing per band and spread sky / floor / silhouettes evenly over the ranks (profiles/r02_shard_cost_table.md:
+    32-line bands leave the busiest of 8 ranks 28 % above the mean).  -> (band_rows, [first line of every band])"""
+    import os
+    if rows is None:
+        rows = int(os.environ.get("LH_BAND_ROWS", "4"))
+    if world <= 1:
+        rows = height                      # one rank: the frame is one band
+    rows = max(1, min(rows, height))
+    return rows, list(range(0, height, rows))
 
 
-def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, world, tile=None, seed=1, per_rank=8):
-    """Each rank renders its interleaved shards straight into its slab; ONE gather of the equal-sized slabs assembles
-    the frame on rank 0 (None elsewhere).  tile=None: full-width bands (bands_for); an int: square tiles as before.
-    Returns (image|None, local stats)."""
+def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, world, tile=None, seed=1, band_rows=None):
+    """Each rank renders its interleaved shards; ONE gather of equal-sized slabs assembles the frame on rank 0 (None
+    elsewhere).  tile=None (default): full-width bands, all of a rank's bands in one device batch; an int: square tiles,
+    one batch each (the round-1 path, kept for comparison).  Returns (image|None, local stats)."""
     import torch
     W, H = cam.width, cam.height
-    shards = bands_for(W, H, world, per_rank) if tile is None else shard.tile_grid(W, H, tile)
-    mine = shard.tiles_of_rank(len(shards), rank, world)
     dev = torch.device("cuda", acc.device)
+    if tile is None:
+        rows, y0s = bands_for(H, world, band_rows)
+        mine = shard.tiles_of_rank(len(y0s), rank, world)
+        per = (len(y0s) + world - 1) // world
+        slab = torch.zeros((per, rows * W * 3), dtype=torch.float32, device=dev)
+        _, tot = acc.render_ao_bands(cam, [y0s[b] for b in mine], rows, pixel_samples, gather_nsamples, seed=seed,
+                                     out=slab[:len(mine)].view(len(mine), rows, W, 3))
+        shards = [(0, y0, W, min(rows, H - y0)) for y0 in y0s]
+        return assemble_shards(slab, shards, W, H, rank, world, stride_rows=rows), tot
+    shards = shard.tile_grid(W, H, tile)
+    mine = shard.tiles_of_rank(len(shards), rank, world)
     cap = max(w * h for (_, _, w, h) in shards) * 3
     per = (len(shards) + world - 1) // world
     slab = torch.zeros((per, cap), dtype=torch.float32, device=dev)      # one allocation per frame; padding stays zero
@@ -63,18 +76,31 @@ def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, worl
     return assemble_shards(slab, shards, W, H, rank, world), tot
 
 
-def assemble_shards(slab, shards, W, H, rank, world):
+def assemble_shards(slab, shards, W, H, rank, world, stride_rows=None):
     """the exchange step (one gather of [per_rank, cap] slabs to rank 0) + placement with the reference's y flip
-    (bucket_write, render.c:962-964)"""
+    (bucket_write, render.c:962-964).  stride_rows: the slab of a shard holds that many rows (bands of a batch: a clipped
+    last band keeps its lines at the BOTTOM of its slab, the clipped lines being below the frame); None: h rows."""
     import torch
     out = shard.gather_slabs(slab, rank, world)
     if rank != 0:
         return None
+    if stride_rows is not None and H % stride_rows == 0:
+        # regular bands: one strided copy per rank, then one flip -- band 0 is the BOTTOM of the image, every band is
+        # already top-line-first inside (thousands of bands per frame: no Python loop over them)
+        nb = H // stride_rows
+        bands = torch.empty((nb, stride_rows, W, 3), dtype=slab.dtype, device=slab.device)
+        for r in range(world):
+            cnt = len(range(r, nb, world))
+            bands[r::world] = out[r][:cnt].view(cnt, stride_rows, W, 3)
+        return bands.flip(0).reshape(H, W, 3)
     img = torch.zeros((H, W, 3), dtype=slab.dtype, device=slab.device)
     for r in range(world):
         for k, tid in enumerate(shard.tiles_of_rank(len(shards), r, world)):
             x0, y0, w, h = shards[tid]
-            img[H - (y0 + h):H - y0, x0:x0 + w] = out[r][k, :w * h * 3].view(h, w, 3)
+            if stride_rows is None:
+                img[H - (y0 + h):H - y0, x0:x0 + w] = out[r][k, :w * h * 3].view(h, w, 3)
+            else:                        # image orientation inside the band: its first frame line is the LAST slab row
+                img[H - (y0 + h):H - y0, x0:x0 + w] = out[r][k].view(stride_rows, w, 3)[stride_rows - h:]
     return img
 
 

@@ -38,7 +38,7 @@ def _worker(rank, world, port, q):
             acc.set_normals(k, g["nrm%d" % k], int(g["two_side%d" % k]))
     acc.commit()
     c = g["camera"]
-    cam = la.Camera.make(200, 150, c[16], c[:16], int(c[19]))
+    cam = la.Camera.make(200, 150, c[16], c[:16], int(c[19]))        # 150 lines: the last band is clipped
     out = {}
     for name, kw in (("bands", {}), ("tiles", {"tile": 64})):
         img, st = render.render_ao_frame_sharded(acc, cam, 2, 16, rank, world, seed=3, **kw)

@@ -193,3 +193,16 @@ def test_add_rib_scene_hands_every_mesh_its_own_normals():
         b2 = la.HipAccel(0); b2.add_mesh(meshes[0]["positions"], meshes[0]["indices"])
         b2.set_normals(0, np.zeros((1, 3)))              # short normals array: refused before the C ABI reads it
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_lsh_hip_multi_gpu_frame_equals_single(tmp_path):
+    """`lsh_hip --devices 0,0,0` (three replicas on one GPU through lh_multi_*: one build, tile queue, peer gather) writes
+    the same .hdr, byte for byte, as the single-device run"""
+    rib_path = os.path.join(RIB, "ambient_occlusion.rib")
+    common = ["--resolution", "200x136", "--gather", "16", "--pixelsamples", "2", "--seed", "5"]
+    r1 = _lsh(common + ["--output", "one.hdr", rib_path], str(tmp_path))
+    r3 = _lsh(common + ["--devices", "0,0,0", "--tile", "48", "--verbose", "--output", "three.hdr", rib_path], str(tmp_path))
+    assert r1.returncode == 0 and r3.returncode == 0, r1.stderr + r3.stderr
+    assert "one host build, replicated" in r3.stdout and r3.stdout.count("replica") >= 3
+    assert open(tmp_path / "one.hdr", "rb").read() == open(tmp_path / "three.hdr", "rb").read()

@@ -1,0 +1,64 @@
+"""Per-shard cost table of the BASELINE config 5 AO frame from a ONE-GPU run, and the max-over-ranks frame time it
+predicts for 2 / 4 / 8 GPUs under the shard assignment bench.py uses (render.bands_for: full-width bands, 8 per rank,
+band_id % world) -- SURVEY 8e / VERDICT r01 item 2c.  No multi-GPU hardware is involved: the prediction is
+sum-of-my-bands + the gather of the other ranks' slabs at a stated link rate.
+  python tools/shard_cost_table.py [size] [tess] [samples] > profiles/<round>_shard_cost_table.md"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import lucille_amd as la
+from lucille_amd import render, scenes, shard
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+tess = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+ns = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+LINK_GBPS = 45.0          # one xGMI link, one direction, achievable (MI355X_MICROARCH.md: 7 links x ~153 GB/s bidirectional peak per GPU)
+g = np.load(os.path.join(ROOT, "tests", "golden", "ao_c1.npz"))
+acc = la.HipAccel(0); ntri = 0
+for k in range(int(g["ngeoms"])):
+    P, I = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess); acc.add_mesh(P, I); ntri += I.shape[0] // 3
+info = acc.commit()
+c = g["camera"]; cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
+def t_of(x0, y0, w, h, out):
+    best = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        acc.render_ao_tile(cam, x0, y0, w, h, 1, ns, seed=1, out=out); torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best
+full = torch.empty((size, size, 3), dtype=torch.float32, device="cuda")
+t1 = t_of(0, 0, size, size, full)
+print("# Shard cost table: BASELINE config 5 AO frame (%d triangles, %dx%d, %d AO samples), one MI355X\n" % (ntri, size, size, ns))
+print("Whole frame as ONE device batch: **%.2f ms** (host build %.2f s + reference-order tree %.2f s, once per scene).\n" % (t1 * 1e3, info["build_seconds"], info["ref_build_seconds"]))
+print("Shards = `render.bands_for(H, world)`: full-width bands of a few lines (column 3), `band_id %% world == rank`; a rank's bands are ONE "
+      "`lh_render_ao_bands` call (one device batch).  Times are best-of-3 wall times of every rank's batch, run one after the other on one "
+      "GPU.  Prediction for N ranks = max over ranks of its batch + gather, where the gather moves "
+      "(N-1)/N of the frame (%d MB fp32 RGB) to rank 0 over N-1 xGMI links in parallel at %.0f GB/s per link.\n" % (size * size * 12 // 1000000, LINK_GBPS))
+print("| ranks | bands | band rows | sum over ranks (ms) | busiest rank (ms) | least busy (ms) | imbalance | gather (ms) | predicted frame (ms) | predicted speed-up |")
+print("|---|---|---|---|---|---|---|---|---|---|")
+rows = {}
+slab = torch.zeros(size * size * 3 + 64 * size * 3, dtype=torch.float32, device="cuda")
+for world, want_rows in ((1, None), (2, None), (4, None), (8, None), (8, 1), (8, 16), (8, 64)):
+    brow, y0s = render.bands_for(size, world, want_rows)
+    per = []
+    for r in range(world):
+        mine = [y0s[b] for b in shard.tiles_of_rank(len(y0s), r, world)]
+        out = slab[:len(mine) * brow * size * 3].view(len(mine), brow, size, 3)
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            acc.render_ao_bands(cam, mine, brow, 1, ns, seed=1, out=out); torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        per.append(best)
+    gather = 0.0 if world == 1 else (size * size * 12 / world) / (LINK_GBPS * 1e9)       # each peer sends its 1/N of the frame over its own link
+    pred = max(per) + gather
+    rows.setdefault(world, (per, pred))
+    print("| %d | %d | %d | %.2f | %.2f | %.2f | %.1f %% | %.2f | %.2f | %.2fx |" % (world, len(y0s), brow, sum(per) * 1e3, max(per) * 1e3, min(per) * 1e3,
+          100.0 * (max(per) / (sum(per) / world) - 1.0), gather * 1e3, pred * 1e3, rows[1][1] / pred))
+print("\nPer-rank batch time at 8 ranks (ms): " + " ".join("%.2f" % (x * 1e3) for x in rows[8][0]))
+print("\nReading: a rank renders ALL of its bands as one device batch (`lh_render_ao_bands`), so the per-launch drain of the persistent "
+      "traversal kernel (as long as its slowest ray: ~1.7 ms on this scene, where a few grazing AO rays walk thousands of floor boxes) is paid "
+      "once per rank and frame.  The sum over ranks exceeds the one-batch frame by (ranks - 1) drains plus what the finer interleave costs in "
+      "coherence; the imbalance column is the busiest rank against the mean (the extra 8-rank rows show other band heights: the "
+      "default is the first).  Rendering the same bands one launch at a time costs +1.7 ms per band "
+      "(`profiles/r02_shard_cost_table_bands_v1.md`: 3.75x predicted at 8 ranks).")
