@@ -1378,7 +1378,7 @@ static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w,
         ensure_buf(&a->p_dir2, S * 24) || ensure_buf(&a->r_prim, S * 4) || ensure_buf(&a->r_t, S * 8) ||
         ensure_buf(&a->r_u, S * 8) || ensure_buf(&a->r_v, S * 8) || ensure_buf(&a->p_path, S * 4) ||
         ensure_buf(&a->p_path2, S * 4) || ensure_buf(&a->p_thr, S * 12) || ensure_buf(&a->p_thr2, S * 12) ||
-        ensure_buf(&a->p_rad, S * 12) || ensure_buf(&a->p_alive, S) || ensure_buf(&a->r_blocks, (size_t)nb * 4)) return -1;
+        ensure_buf(&a->p_rad, S * 12) || ensure_buf(&a->p_alive, S) || ensure_buf(&a->r_blocks, ((size_t)nb + nb / 1024 + 4) * 4)) return -1;
     HIPCHK(hipMemsetAsync(a->p_rad.p, 0, S * 12, s));
     double *org = (double *)a->r_org.p, *dir = (double *)a->r_dir.p, *org2 = (double *)a->p_org2.p, *dir2 = (double *)a->p_dir2.p;
     uint32_t *path = (uint32_t *)a->p_path.p, *path2 = (uint32_t *)a->p_path2.p;

@@ -162,6 +162,34 @@ __global__ void k_scan_blocks(uint32_t nblocks, uint32_t *__restrict__ block_cou
     if (threadIdx.x == 0) *total_out = carry;
 }
 
+/* the same scan for many blocks (the path tracer scans 262 144 block counts per bounce): per-group sums, a scan of the
+ * group sums by one workgroup, then every group scans itself with its base */
+__global__ void k_scan_group_sums(uint32_t nblocks, const uint32_t *__restrict__ block_counts, uint32_t *__restrict__ group_sums)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    part[threadIdx.x] = (i < nblocks) ? block_counts[i] : 0;
+    __syncthreads();
+    for (uint32_t off = 512; off > 0; off >>= 1) { if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) group_sums[blockIdx.x] = part[0];
+}
+
+__global__ void k_scan_within_groups(uint32_t nblocks, uint32_t *__restrict__ block_counts, const uint32_t *__restrict__ group_base)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t v = (i < nblocks) ? block_counts[i] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t t = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (i < nblocks) block_counts[i] = group_base[blockIdx.x] + part[threadIdx.x] - v;
+}
+
 struct DevNormals { const double *nrm; };   /* 9 doubles per prim (n0 n1 n2), NaN n0.x => none */
 
 /* one thread per primary sample: slot = exclusive scan of the hit flags; writes the
@@ -390,6 +418,8 @@ __global__ void k_state_build(size_t n, const lh_dev_scene_t sc, const double *_
 
 __device__ __forceinline__ double rnd01(uint64_t key) { return (double)mix32(key) * 2.3283064365386963e-10; }
 
+#define LH_PT_INTERIOR 0x80000000u
+
 struct DevMaterial { float kd[3], ks[3], kt[3], ior; };
 struct DevEnv { float rgb[3]; const float4 *map; int w, h; };
 
@@ -451,47 +481,78 @@ __global__ void k_pt_primary(DevCamera cam, int x0, int y0, int w, int h, int sp
     thr[3 * id] = 1.0f; thr[3 * id + 1] = 1.0f; thr[3 * id + 2] = 1.0f;
 }
 
-#define LH_PT_INTERIOR 0x80000000u
 
-/* one thread per live path after the closest-hit launch of bounce `depth`:
- *   miss            -> radiance[path] = throughput x environment(dir); the path ends
- *   hit, depth/RR   -> the path ends with 0
- *   hit, survives   -> next ray by the sampled reflection type D / S / T */
-__global__ void k_pt_shade(size_t n, const lh_dev_scene_t sc, const double *__restrict__ nrm9, const double *__restrict__ col9,
-                           const uint32_t *__restrict__ prim_mesh, const DevMaterial *__restrict__ materials,
-                           const DevMaterial override_mat, int use_override, const DevEnv env, int ref_weights,
-                           int depth, int max_depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w, int full_width,
-                           double *__restrict__ org, double *__restrict__ dir,
-                           const uint32_t *__restrict__ prim, const double *__restrict__ t, const double *__restrict__ u,
-                           const double *__restrict__ v, uint32_t *__restrict__ path_of, float *__restrict__ thr,
-                           float *__restrict__ radiance, uint8_t *__restrict__ alive)
+/* After the closest-hit launch of bounce `depth`, two passes over the live paths with a scan in between, so that a
+ * surviving path's next ray is written ONCE, straight into its compacted slot (round 1 rewrote the ray in place and then
+ * copied the survivors: 2 x 48 + 2 x 48 bytes per path vertex; the path tracer's own kernels are bandwidth-bound streams).
+ * Both passes derive the same decisions from the same counter-based key (pixel, sample, bounce).
+ *   k_pt_decide: miss -> radiance[path] = throughput x environment(dir), the path ends; hit -> vertex limit and Russian
+ *                roulette on d + s + t (russian_roulette, pathtrace.c:407-430) -> alive flag
+ *   k_pt_emit:   for the survivors: hit epilogue, reflection type D / S / T, next ray, throughput -> slot j */
+__device__ __forceinline__ uint64_t pt_key(unsigned long long seed, uint32_t path, int spp, int s0, int x0, int y0, int w, int full_width, int depth)
 {
-    LH_NC
+    const size_t pix = path / (uint32_t)spp;
+    const uint64_t gx = (uint64_t)(x0 + (int)(pix % (size_t)w)), gy = (uint64_t)(y0 + (int)(pix / (size_t)w));
+    return ((seed * 0x9E3779B97F4A7C15ULL) ^ (((gy * (uint64_t)full_width + gx) << 20) + (uint64_t)(s0 + (int)(path % (uint32_t)spp))) * 64ull)
+           + 4ull * (uint64_t)(depth + 1);
+}
+
+__global__ void k_pt_decide(size_t n, const uint32_t *__restrict__ prim_mesh, const DevMaterial *__restrict__ materials,
+                            const DevMaterial override_mat, int use_override, const DevEnv env,
+                            int depth, int max_depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w, int full_width,
+                            const double *__restrict__ dir, const uint32_t *__restrict__ prim, const uint32_t *__restrict__ path_of,
+                            const float *__restrict__ thr, float *__restrict__ radiance, uint8_t *__restrict__ alive)
+{
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const uint32_t path = path_of[i] & ~LH_PT_INTERIOR;
+    const uint32_t p = prim[i];
+    if (p == LH_MISS_PRIM) {
+        float e[3];
+        env_fetch(env, dir[3 * i], dir[3 * i + 1], dir[3 * i + 2], e);
+        radiance[3 * (size_t)path] = thr[3 * i] * e[0]; radiance[3 * (size_t)path + 1] = thr[3 * i + 1] * e[1];
+        radiance[3 * (size_t)path + 2] = thr[3 * i + 2] * e[2];
+        alive[i] = 0; return;
+    }
+    const DevMaterial M = use_override ? override_mat : materials[prim_mesh[p]];
+    const double ksum = ((double)M.kd[0] + M.kd[1] + M.kd[2] + M.ks[0] + M.ks[1] + M.ks[2] + M.kt[0] + M.kt[1] + M.kt[2]) / 3.0;
+    const uint64_t key = pt_key(seed, path, spp, s0, x0, y0, w, full_width, depth);
+    const bool go = !(depth + 2 >= max_depth || !(ksum > 0.0) || rnd01(key) > ksum);
+    alive[i] = go ? 1 : 0;            /* radiance[] was zeroed for the pass: a path that ends here contributes nothing */
+}
+
+__global__ void k_pt_emit(size_t n, const lh_dev_scene_t sc, const double *__restrict__ nrm9, const double *__restrict__ col9,
+                          const uint32_t *__restrict__ prim_mesh, const DevMaterial *__restrict__ materials,
+                          const DevMaterial override_mat, int use_override, int ref_weights,
+                          int depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w, int full_width,
+                          const uint8_t *__restrict__ alive, const uint32_t *__restrict__ block_offsets,
+                          const double *__restrict__ org, const double *__restrict__ dir,
+                          const uint32_t *__restrict__ prim, const double *__restrict__ t, const double *__restrict__ u,
+                          const double *__restrict__ v, const uint32_t *__restrict__ path_of, const float *__restrict__ thr,
+                          double *__restrict__ org2, double *__restrict__ dir2, uint32_t *__restrict__ path_of2, float *__restrict__ thr2)
+{
+    LH_NC
+    __shared__ uint32_t wsum[4];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool f = (i < n) && alive[i];
+    const unsigned long long m = __ballot(f);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wsum[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (!f) return;
+    uint32_t woff = 0;
+    for (int k = 0; k < wv; k++) woff += wsum[k];
+    const size_t j = block_offsets[blockIdx.x] + woff + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+
     const uint32_t pword = path_of[i];
     const uint32_t path = pword & ~LH_PT_INTERIOR;
     const uint32_t p = prim[i];
     float G[3] = {thr[3 * i], thr[3 * i + 1], thr[3 * i + 2]};
     double D[3] = {dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]};
-    if (p == LH_MISS_PRIM) {
-        float e[3];
-        env_fetch(env, D[0], D[1], D[2], e);
-        radiance[3 * (size_t)path] = G[0] * e[0]; radiance[3 * (size_t)path + 1] = G[1] * e[1]; radiance[3 * (size_t)path + 2] = G[2] * e[2];
-        alive[i] = 0; return;
-    }
-    const size_t pix = path / (uint32_t)spp;
-    const uint64_t gx = (uint64_t)(x0 + (int)(pix % (size_t)w)), gy = (uint64_t)(y0 + (int)(pix / (size_t)w));
-    const uint64_t key = (seed * 0x9E3779B97F4A7C15ULL) ^ (((gy * (uint64_t)full_width + gx) << 20) + (uint64_t)(s0 + (int)(path % (uint32_t)spp))) * 64ull
-                         + 4ull * (uint64_t)(depth + 1);
+    const uint64_t key = pt_key(seed, path, spp, s0, x0, y0, w, full_width, depth);
     const DevMaterial M = use_override ? override_mat : materials[prim_mesh[p]];
-    const double kd_ = (M.kd[0] + M.kd[1] + M.kd[2]) / 3.0, ks_ = (M.ks[0] + M.ks[1] + M.ks[2]) / 3.0, kt_ = (M.kt[0] + M.kt[1] + M.kt[2]) / 3.0;
+    const double kd_ = ((double)M.kd[0] + M.kd[1] + M.kd[2]) / 3.0, ks_ = ((double)M.ks[0] + M.ks[1] + M.ks[2]) / 3.0, kt_ = ((double)M.kt[0] + M.kt[1] + M.kt[2]) / 3.0;
     const double ksum = kd_ + ks_ + kt_;
-    /* vertex limit, then Russian roulette on d + s + t (russian_roulette, pathtrace.c:407-430) */
-    if (depth + 2 >= max_depth || !(ksum > 0.0) || rnd01(key) > ksum) {
-        radiance[3 * (size_t)path] = 0.0f; radiance[3 * (size_t)path + 1] = 0.0f; radiance[3 * (size_t)path + 2] = 0.0f;
-        alive[i] = 0; return;
-    }
     /* ri_intersection_state_build subset: P, Ng, Ns, colour */
     const double *tv = (const double *)sc.tri64 + 9 * (size_t)p;
     const double tt = t[i], uu = u[i], vv = v[i], wgt = 1.0 - uu - vv;
@@ -521,7 +582,7 @@ __global__ void k_pt_shade(size_t n, const lh_dev_scene_t sc, const double *__re
     double O[3];
     double side = 1.0;                          /* which side of the surface the next ray starts on */
     if (type == 2) {
-        /* ri_refract (reflection.c:69-128) with the unit direction: eta = ior when leaving, 1 / ior when entering */
+        /* ri_refract (reflection.c:69-128) with the unit direction: relative index ior when leaving, 1 / ior when entering */
         double In[3] = {D[0], D[1], D[2]};
         vnormalize(In);
         const double e = interior ? (double)M.ior : 1.0 / (double)M.ior;
@@ -559,13 +620,11 @@ __global__ void k_pt_shade(size_t n, const lh_dev_scene_t sc, const double *__re
     const double pk = type == 0 ? kd_ : (type == 1 ? ks_ : kt_);
     const float wsel = ref_weights ? (type == 0 ? 0.318309886f : 1.0f) : (float)(1.0 / pk);     /* unbiased: / (P(type) x survival) */
     for (int k = 0; k < 3; k++) {
-        G[k] *= kk[k] * col[k] * wsel;
-        thr[3 * i + k] = G[k];
-        org[3 * i + k] = P[k] + side * N[k] * 1.0e-6;
-        dir[3 * i + k] = O[k];
+        thr2[3 * j + k] = G[k] * kk[k] * col[k] * wsel;
+        org2[3 * j + k] = P[k] + side * N[k] * 1.0e-6;
+        dir2[3 * j + k] = O[k];
     }
-    path_of[i] = path | interior;
-    alive[i] = 1;
+    path_of2[j] = path | interior;
 }
 
 __global__ void k_flag_count(size_t n, const uint8_t *__restrict__ flag, uint32_t *__restrict__ block_counts)
@@ -577,28 +636,6 @@ __global__ void k_flag_count(size_t n, const uint8_t *__restrict__ flag, uint32_
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-/* stable compaction of the surviving paths into the other ping-pong buffers */
-__global__ void k_pt_compact(size_t n, const uint8_t *__restrict__ flag, const uint32_t *__restrict__ block_offsets,
-                             const double *__restrict__ org, const double *__restrict__ dir,
-                             const uint32_t *__restrict__ path_of, const float *__restrict__ thr,
-                             double *__restrict__ org2, double *__restrict__ dir2, uint32_t *__restrict__ path_of2,
-                             float *__restrict__ thr2)
-{
-    __shared__ uint32_t wsum[4];
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const bool f = (i < n) && flag[i];
-    const unsigned long long m = __ballot(f);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) wsum[wv] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (!f) return;
-    uint32_t woff = 0;
-    for (int k = 0; k < wv; k++) woff += wsum[k];
-    const size_t j = block_offsets[blockIdx.x] + woff + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    for (int k = 0; k < 3; k++) { org2[3 * j + k] = org[3 * i + k]; dir2[3 * j + k] = dir[3 * i + k]; thr2[3 * j + k] = thr[3 * i + k]; }
-    path_of2[j] = path_of[i];
 }
 
 /* per pixel: add the mean of this pass's samples (in sample order) */
@@ -699,6 +736,16 @@ extern "C" int lh_pt_launch_primary(const lh_camera_t *cam, int x0, int y0, int 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+/* exclusive scan of d_blocks[nb] in place, total -> *d_total; d_groups: scratch of (nb + 1023) / 1024 + 1 words */
+static void launch_scan(uint32_t nb, uint32_t *d_blocks, uint32_t *d_groups, unsigned long long *d_total, hipStream_t s)
+{
+    if (nb <= 4096) { hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, nb, d_blocks, d_total); return; }
+    const uint32_t ng = (nb + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_group_sums, dim3(ng), dim3(1024), 0, s, nb, (const uint32_t *)d_blocks, d_groups);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, ng, d_groups, d_total);
+    hipLaunchKernelGGL(k_scan_within_groups, dim3(ng), dim3(1024), 0, s, nb, d_blocks, (const uint32_t *)d_groups);
+}
+
 extern "C" int lh_pt_launch_shade(size_t n, const lh_dev_scene_t *sc, const double *d_nrm9, const double *d_col9,
                                   const uint32_t *d_prim_mesh, const void *d_materials, const lh_material_t *override_mat,
                                   const float env_rgb[3], const void *d_env_map, int env_w, int env_h, int ref_weights,
@@ -718,13 +765,15 @@ extern "C" int lh_pt_launch_shade(size_t n, const lh_dev_scene_t *sc, const doub
     DevEnv env;
     env.rgb[0] = env_rgb[0]; env.rgb[1] = env_rgb[1]; env.rgb[2] = env_rgb[2];
     env.map = (const float4 *)d_env_map; env.w = env_w; env.h = env_h;
-    hipLaunchKernelGGL(k_pt_shade, dim3(nb), dim3(256), 0, s, n, *sc, d_nrm9, d_col9, d_prim_mesh, (const DevMaterial *)d_materials, om,
-                       override_mat != NULL, env, ref_weights, depth, max_depth, seed, s0, spp, x0, y0, w,
-                       full_width, d_org, d_dir, d_prim, d_t, d_u, d_v, d_path_of, d_thr, d_radiance, d_alive);
+    hipLaunchKernelGGL(k_pt_decide, dim3(nb), dim3(256), 0, s, n, d_prim_mesh, (const DevMaterial *)d_materials, om, override_mat != NULL, env,
+                       depth, max_depth, seed, s0, spp, x0, y0, w, full_width, (const double *)d_dir, d_prim, (const uint32_t *)d_path_of,
+                       (const float *)d_thr, d_radiance, d_alive);
     hipLaunchKernelGGL(k_flag_count, dim3(nb), dim3(256), 0, s, n, d_alive, d_blocks);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, nb, d_blocks, d_total);
-    hipLaunchKernelGGL(k_pt_compact, dim3(nb), dim3(256), 0, s, n, d_alive, d_blocks, d_org, d_dir, d_path_of, d_thr,
-                       d_org2, d_dir2, d_path_of2, d_thr2);
+    launch_scan(nb, d_blocks, d_blocks + nb, d_total, s);           /* the caller sizes d_blocks for nb + nb / 1024 + 2 words */
+    hipLaunchKernelGGL(k_pt_emit, dim3(nb), dim3(256), 0, s, n, *sc, d_nrm9, d_col9, d_prim_mesh, (const DevMaterial *)d_materials, om,
+                       override_mat != NULL, ref_weights, depth, seed, s0, spp, x0, y0, w, full_width, (const uint8_t *)d_alive,
+                       (const uint32_t *)d_blocks, (const double *)d_org, (const double *)d_dir, d_prim, d_t, d_u, d_v,
+                       (const uint32_t *)d_path_of, (const float *)d_thr, d_org2, d_dir2, d_path_of2, d_thr2);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
