@@ -73,6 +73,13 @@ int  lh_accel_add_mesh(lh_accel_t *accel, uint32_t npositions, const double *pos
  * Every entry point taking an accelerator holds its lock: calls from several threads are safe and
  * serialised (lucille's render threads call accel->intersect concurrently, render.c:1043-1105). */
 int  lh_accel_commit(lh_accel_t *accel, int build_threads);
+/* build_threads == LH_BUILD_ON_DEVICE (or LH_BUILD=device in the environment): the traversal tree is built on the GPU
+ * (LBVH -> the same 4-wide nodes; milliseconds instead of seconds: lucille re-builds its accelerator in every
+ * ri_scene_setup, scene.c:84-98) and lucille's own tree -- needed only for exact-t tie winners, fragile hits and beams --
+ * by a background host thread; queries issued before it is attached resolve exact-t ties by "larger primitive id wins".
+ * lh_accel_wait_exact blocks until it is attached.  Hit records are otherwise independent of the tree. */
+#define LH_BUILD_ON_DEVICE (-2)
+int  lh_accel_wait_exact(lh_accel_t *accel);
 void lh_accel_destroy(lh_accel_t *accel);
 int  lh_accel_info(const lh_accel_t *accel, lh_accel_info_t *out);
 
@@ -112,6 +119,9 @@ int  lh_accel_intersect_device_counted(lh_accel_t *accel, size_t n, const void *
                                        const void *d_dir_xyz, void *d_prim, void *d_t,
                                        void *d_u, void *d_v, void *d_occluded, int mode,
                                        int variant, uint64_t counters[4]);
+/* rays of the last counted launch that were finished outside the main kernel: the reference-order walk (exact-t ties,
+ * fragile hits) and the private-stack walk for rays whose LDS stack column would have overflowed */
+uint64_t lh_accel_last_retraced(const lh_accel_t *accel);
 
 /* ---- traversal statistics: ri_bvh_clear_stat_traversal / ri_bvh_report_stat_traversal ----
  * reference: src/render/bvh.c:669-706 (globals filled under -DRI_BVH_TRACE_STATISTICS,

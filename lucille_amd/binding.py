@@ -94,9 +94,9 @@ class TileStats(C.Structure):
 
 # every symbol include/lucille_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "lh_device_count", "lh_last_error", "lh_accel_create", "lh_accel_add_mesh", "lh_accel_commit",
+    "lh_device_count", "lh_last_error", "lh_accel_create", "lh_accel_add_mesh", "lh_accel_commit", "lh_accel_wait_exact",
     "lh_accel_destroy", "lh_accel_info", "lh_accel_prim_lookup", "lh_accel_intersect1",
-    "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted",
+    "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted", "lh_accel_last_retraced",
     "lh_accel_set_grid", "lh_accel_set_param", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
     "lh_render_ao_tile", "lh_render_ao_tile_host", "lh_render_ao_bands", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device", "lh_render_pt_tile",
     "lh_accel_trace_statistics", "lh_accel_statistics",
@@ -133,6 +133,7 @@ def lib():
     L.lh_accel_create.argtypes = [C.POINTER(vp), i32]
     L.lh_accel_add_mesh.argtypes = [vp, u32, vp, sz, u32, vp]
     L.lh_accel_commit.argtypes = [vp, i32]
+    L.lh_accel_wait_exact.argtypes = [vp]
     L.lh_accel_destroy.argtypes = [vp]
     L.lh_accel_destroy.restype = None
     L.lh_accel_info.argtypes = [vp, C.POINTER(AccelInfo)]
@@ -141,6 +142,7 @@ def lib():
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.lh_accel_intersect_host.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32]
     L.lh_accel_intersect_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.lh_accel_last_retraced.argtypes = [vp]; L.lh_accel_last_retraced.restype = C.c_uint64
     L.lh_accel_intersect_device_counted.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, i32,
                                                     C.POINTER(C.c_uint64)]
     L.lh_accel_set_grid.argtypes = [vp, i32]
@@ -265,10 +267,14 @@ class HipAccel:
                                            (N.shape[1] * 8) if N is not None else 24, int(two_side)),
                "lh_accel_set_normals")
 
-    def commit(self, build_threads=0):
-        _check(self.L.lh_accel_commit(self.h, int(build_threads)), "lh_accel_commit")
+    def commit(self, build_threads=0, on_device=False):
+        """on_device: the traversal tree is built on the GPU (LH_BUILD_ON_DEVICE), lucille's own tree in the background"""
+        _check(self.L.lh_accel_commit(self.h, -2 if on_device else int(build_threads)), "lh_accel_commit")
         self.committed = True
         return self.info()
+
+    def wait_exact(self):
+        _check(self.L.lh_accel_wait_exact(self.h), "lh_accel_wait_exact")
 
     def info(self):
         s = AccelInfo()
@@ -340,7 +346,8 @@ class HipAccel:
             _check(self.L.lh_accel_intersect_device_counted(self.h, n, _dptr(org), _dptr(dr), _dptr(prim), _dptr(t),
                                                             _dptr(u), _dptr(v), _dptr(occ), mode, variant, c),
                    "lh_accel_intersect_device_counted")
-            return out, {"nodes": int(c[0]), "tris": int(c[1]), "exact": int(c[2]), "rays": int(c[3])}
+            return out, {"nodes": int(c[0]), "tris": int(c[1]), "exact": int(c[2]), "rays": int(c[3]),
+                         "retraced": int(self.L.lh_accel_last_retraced(self.h))}
         if stream is None:
             stream = torch.cuda.current_stream(dev).cuda_stream
         _check(self.L.lh_accel_intersect_device(self.h, n, _dptr(org), _dptr(dr), _dptr(prim), _dptr(t), _dptr(u),

@@ -75,6 +75,10 @@ struct lh_host_scene {
     double *st6;              /* texture coordinates per primitive (6 doubles, NaN = none) or NULL */
     uint8_t *inside;          /* per primitive: the back half of a two-sided mesh (intersection_state.c:233-241) or NULL */
     uint32_t nmeshes;         /* meshes the scene was committed with */
+    /* device build (lh_build.hip): the host holds the flattened primitives only; the reference-order tree is built by a
+     * background thread and attached to the replicas when it is ready (ref_state: 0 none, 1 building, 2 ready, -1 failed) */
+    int device_built;
+    int ref_state; pthread_t ref_thread; int ref_thread_live; int ref_threads;
 };
 static pthread_mutex_t g_scene_mu = PTHREAD_MUTEX_INITIALIZER;
 
@@ -119,6 +123,7 @@ struct lh_accel {
     lh_buf r_bands;                    /* lh_render_ao_bands: first line of every band */
     /* tile-render scratch (lh_render_ao_tile) */
     lh_buf r_org, r_dir, r_prim, r_t, r_u, r_v, r_slot, r_hitrec, r_aorg, r_adir, r_occ, r_blocks, r_key, r_frame, r_occcount;
+    uint64_t last_retraced;            /* rays the last counted launch finished outside the main kernel */
     int ao_fused;                      /* AO rays generated inside the any-hit kernel (default); 0: materialised in HBM */
     lh_buf p_org2, p_dir2, p_path, p_path2, p_thr, p_thr2, p_rad, p_alive;   /* path tracer */
     unsigned long long *d_total;
@@ -309,8 +314,18 @@ static void release_device(lh_accel_t *a)
     a->d_stage = NULL; a->stage_bytes = 0; a->stream = NULL;
 }
 
+static void *ref_thread_main(void *arg)
+{
+    lh_host_scene *hs = (lh_host_scene *)arg;
+    const double t0 = now_s();
+    const int rc = lh_refbvh_build(&hs->ref, hs->bvh.tri64, hs->bvh.ntris, hs->ref_threads);
+    hs->ref_build_seconds = now_s() - t0;
+    __atomic_store_n(&hs->ref_state, rc == 0 ? 2 : -1, __ATOMIC_RELEASE);
+    return NULL;
+}
+
 /* ---- host build (once per scene) ------------------------------------------------------------ */
-static int host_build(lh_accel_t *a, int build_threads)
+static int host_build(lh_accel_t *a, int build_threads, bool on_device, bool keep_meshes)
 {
     lh_host_scene *hs = a->hs;
     if (build_threads <= 0) {
@@ -327,8 +342,9 @@ static int host_build(lh_accel_t *a, int build_threads)
         views[g].stride_bytes = 3 * sizeof(double);
         views[g].nindices = a->meshes[g].nidx; views[g].indices = a->meshes[g].idx;
     }
-    int rc = lh_bvh_build(&hs->bvh, views, a->nmeshes, build_threads);
+    int rc = on_device ? lh_bvh_flatten(&hs->bvh, views, a->nmeshes) : lh_bvh_build(&hs->bvh, views, a->nmeshes, build_threads);
     free(views);
+    hs->device_built = on_device ? 1 : 0;
     if (rc == -2) return fail("lh_accel_commit: a vertex coordinate is NaN, infinite or beyond 1e30");
     if (rc != 0) return fail("lh_accel_commit: BVH build failed (bad input or out of memory)");
     /* the reference-order tree: exact-t tie winners, the reference walk for fragile hits, beam
@@ -338,9 +354,17 @@ static int host_build(lh_accel_t *a, int build_threads)
         const char *e = getenv("LH_REFTREE");
         hs->have_ref = !(e && atoi(e) == 0);
         const double t0 = now_s();
-        if (hs->have_ref && lh_refbvh_build(&hs->ref, hs->bvh.tri64, hs->bvh.ntris, build_threads) != 0)
-            return fail("lh_accel_commit: reference-order tree build failed (out of memory)");
-        hs->ref_build_seconds = now_s() - t0;
+        if (hs->have_ref && on_device && hs->bvh.ntris) {
+            /* not in front of the first frame: a background thread builds it, launch() attaches it when it is ready */
+            hs->ref_threads = build_threads; hs->ref_state = 1;
+            if (pthread_create(&hs->ref_thread, NULL, ref_thread_main, hs) != 0) { hs->ref_state = 0; return fail("lh_accel_commit: cannot start the reference-tree thread"); }
+            hs->ref_thread_live = 1;
+        } else {
+            if (hs->have_ref && lh_refbvh_build(&hs->ref, hs->bvh.tri64, hs->bvh.ntris, build_threads) != 0)
+                return fail("lh_accel_commit: reference-order tree build failed (out of memory)");
+            hs->ref_build_seconds = now_s() - t0;
+            hs->ref_state = hs->have_ref ? 2 : 0;
+        }
     }
     /* per-primitive normals in primitive-id order, if any mesh carries normals */
     {
@@ -406,12 +430,14 @@ static int host_build(lh_accel_t *a, int build_threads)
             }
         }
     }
-    for (uint32_t g = 0; g < a->nmeshes; g++) {
-        free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm);
-        for (int k = 0; k < 5; k++) free(a->meshes[g].attr[k]);
+    if (!keep_meshes) {
+        for (uint32_t g = 0; g < a->nmeshes; g++) {
+            free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm);
+            for (int k = 0; k < 5; k++) free(a->meshes[g].attr[k]);
+        }
+        free(a->meshes); a->meshes = NULL; a->nmeshes = 0;
     }
-    free(a->meshes); a->meshes = NULL; a->nmeshes = 0;
-    if (hs->bvh.ntris && hs->bvh.max_depth + 1 > 64) return fail("lh_accel_commit: tree depth %u exceeds the kernel stack", hs->bvh.max_depth);
+    if (!on_device && hs->bvh.ntris && hs->bvh.max_depth + 1 > 64) return fail("lh_accel_commit: tree depth %u exceeds the kernel stack", hs->bvh.max_depth);
     return 0;
 }
 
@@ -419,10 +445,19 @@ static int host_build(lh_accel_t *a, int build_threads)
  * others (A/B variants, the deep-tree fallback) on first use */
 enum { LH_FMT_F32 = 1, LH_FMT_Q16 = 2, LH_FMT_Q16X4 = 4, LH_FMT_C8 = 8 };
 extern "C" int lh_trace_formats_needed(const lh_dev_scene_t *sc, int variant);      /* lh_kernels.hip */
+extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q4nodes, uint32_t *nq4, uint32_t *q4_depth,
+                               void **d_tri32, float bmin[3], float bmax[3], float grid_lo[3], float grid_step[3],
+                               void *stream, char *err, size_t errlen);                /* lh_build.hip */
+
+
 
 static int ensure_formats(lh_accel_t *a, int mask)
 {
     const lh_bvh_t *b = &a->hs->bvh;
+    if (a->hs->device_built) {
+        if (mask & ~LH_FMT_Q16X4) return fail("this scene's tree was built on the device: only the default 4-wide walk is available (variants 4 and 6)");
+        return 0;
+    }
     if ((mask & LH_FMT_F32) && !a->d_nodes) {
         const size_t nb = sizeof(lh_node_t) * (size_t)b->nnodes;
         HIPCHK(hipMalloc(&a->d_nodes, nb));
@@ -455,6 +490,60 @@ static int ensure_formats(lh_accel_t *a, int mask)
         a->dev.c8nodes = a->d_c8nodes; a->dev.tri32_c8 = a->d_tri32_c8; a->device_bytes += c8b + t32;
     }
     return 0;
+}
+
+/* the reference-order tree of the host scene onto this replica's device (exact-t tie winners, the reference walk for
+ * fragile hits, beams).  With a device-built traversal tree this happens when the background build has finished. */
+static int attach_ref(lh_accel_t *a)
+{
+    lh_host_scene *hs = a->hs;
+    if (a->d_ref_nodes || !hs->have_ref || hs->bvh.ntris == 0) return 0;
+    {
+        const uint32_t rn = hs->ref.nnodes;
+        int *lca = (int *)malloc(sizeof(int) * 4 * (size_t)rn);
+        uint32_t *lp = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (size_t)hs->bvh.ntris);
+        if (!lca || !lp) { free(lca); free(lp); return fail("out of memory"); }
+        for (uint32_t i = 0; i < rn; i++) {
+            lca[4 * i] = hs->ref.nodes[i].parent; lca[4 * i + 1] = hs->ref.nodes[i].depth;
+            lca[4 * i + 2] = hs->ref.nodes[i].axis; lca[4 * i + 3] = hs->ref.nodes[i].child[0];
+        }
+        for (uint32_t p = 0; p < hs->bvh.ntris; p++) { lp[2 * p] = hs->ref.prim_leaf[p]; lp[2 * p + 1] = hs->ref.prim_pos[p]; }
+        hipError_t e1 = hipMalloc(&a->d_ref_lca, sizeof(int) * 4 * (size_t)rn);
+        hipError_t e2 = hipMalloc(&a->d_prim_leafpos, sizeof(uint32_t) * 2 * (size_t)hs->bvh.ntris);
+        hipError_t e3 = hipMalloc(&a->d_ref_nodes, sizeof(lh_refnode_t) * (size_t)rn);
+        hipError_t e4 = hipMalloc(&a->d_ref_leaf_prims, sizeof(uint32_t) * (size_t)hs->bvh.ntris);
+        if (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess) {
+            e1 = hipMemcpy(a->d_ref_lca, lca, sizeof(int) * 4 * (size_t)rn, hipMemcpyHostToDevice);
+            e2 = hipMemcpy(a->d_prim_leafpos, lp, sizeof(uint32_t) * 2 * (size_t)hs->bvh.ntris, hipMemcpyHostToDevice);
+            e3 = hipMemcpy(a->d_ref_nodes, hs->ref.nodes, sizeof(lh_refnode_t) * (size_t)rn, hipMemcpyHostToDevice);
+            e4 = hipMemcpy(a->d_ref_leaf_prims, hs->ref.leaf_prims, sizeof(uint32_t) * (size_t)hs->bvh.ntris, hipMemcpyHostToDevice);
+        }
+        free(lca); free(lp);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) return fail("reference-order tree upload failed");
+        a->dev.ref_lca = a->d_ref_lca; a->dev.prim_leafpos = a->d_prim_leafpos;
+        a->dev.ref_nodes = a->d_ref_nodes; a->dev.ref_leaf_prims = a->d_ref_leaf_prims;
+        a->dev.ref_nnodes = rn; a->dev.ref_empty = hs->ref.empty;
+        for (int k = 0; k < 3; k++) { a->dev.ref_bmin[k] = hs->ref.bmin[k]; a->dev.ref_bmax[k] = hs->ref.bmax[k]; }
+        a->device_bytes += sizeof(int) * 4 * (size_t)rn + sizeof(uint32_t) * 3 * (size_t)hs->bvh.ntris + sizeof(lh_refnode_t) * (size_t)rn;
+    }
+    return 0;
+}
+
+/* the background build of the reference-order tree: attach it if it has finished (wait: block until it has) */
+static int sync_ref(lh_accel_t *a, bool wait)
+{
+    lh_host_scene *hs = a->hs;
+    if (!hs->have_ref || a->d_ref_nodes || hs->bvh.ntris == 0) return 0;
+    if (wait) {
+        pthread_mutex_lock(&g_scene_mu);
+        if (hs->ref_thread_live) { pthread_join(hs->ref_thread, NULL); hs->ref_thread_live = 0; }
+        pthread_mutex_unlock(&g_scene_mu);
+    }
+    const int st = __atomic_load_n(&hs->ref_state, __ATOMIC_ACQUIRE);
+    if (st == -1) return fail("the reference-order tree build failed (out of memory)");
+    if (st != 2) return 0;
+    HIPCHK(hipSetDevice(a->device));
+    return attach_ref(a);
 }
 
 /* ---- device replica of the host scene (once per GPU) ---------------------------------------- */
@@ -491,10 +580,28 @@ static int device_upload(lh_accel_t *a)
     if (hs->bvh.ntris) {
         size_t t32 = sizeof(lh_tri32_t) * (size_t)hs->bvh.ntris;
         size_t t64 = sizeof(lh_tri64_t) * (size_t)hs->bvh.ntris;
-        HIPCHK(hipMalloc(&a->d_tri32, t32 + 64));   /* the unified walk reads 16 B past a record */
         HIPCHK(hipMalloc(&a->d_tri64, t64));
-        HIPCHK(hipMemcpy(a->d_tri32, hs->bvh.tri32, t32, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(a->d_tri64, hs->bvh.tri64, t64, hipMemcpyHostToDevice));
+        if (hs->device_built) {
+            /* the traversal tree is built here, on this device (lh_build.hip): LBVH -> the same 4-wide nodes */
+            char berr[256] = "";
+            uint32_t nq4 = 0, d4 = 0; float bmin[3], bmax[3], glo[3], gst[3];
+            const double tb = now_s();
+            const int rcb = lh_device_build(hs->bvh.ntris, (const double *)a->d_tri64, &a->d_q4nodes, &nq4, &d4, &a->d_tri32, bmin, bmax, glo, gst,
+                                            (void *)a->stream, berr, sizeof(berr));
+            if (rcb == -2) return fail("lh_accel_commit: a vertex coordinate is NaN, infinite or beyond 1e30");
+            if (rcb != 0) return fail("device BVH build failed: %s", berr);
+            pthread_mutex_lock(&g_scene_mu);
+            hs->bvh.nq4nodes = nq4; hs->bvh.q4_depth = d4; hs->bvh.nnodes = nq4; hs->bvh.max_depth = d4; hs->bvh.build_seconds = now_s() - tb;
+            for (int k = 0; k < 3; k++) { hs->bvh.bmin[k] = bmin[k]; hs->bvh.bmax[k] = bmax[k]; hs->bvh.grid_lo[k] = glo[k]; hs->bvh.grid_step[k] = gst[k]; }
+            pthread_mutex_unlock(&g_scene_mu);
+            a->dev.q4nodes = a->d_q4nodes;
+            a->device_bytes += sizeof(lh_q4node_t) * (size_t)nq4;
+            if (3 * d4 + 5 > 264) return -3;          /* deeper than k_overflow_fix's private stack: the caller falls back to the host builder */
+        } else {
+            HIPCHK(hipMalloc(&a->d_tri32, t32 + 64));   /* the unified walk reads 16 B past a record */
+            HIPCHK(hipMemcpy(a->d_tri32, hs->bvh.tri32, t32, hipMemcpyHostToDevice));
+        }
         a->device_bytes += t32 + t64;
         float r = 0.0f;
         for (int k = 0; k < 3; k++) { r = fmaxf(r, fabsf(hs->bvh.bmin[k])); r = fmaxf(r, fabsf(hs->bvh.bmax[k])); }
@@ -502,34 +609,7 @@ static int device_upload(lh_accel_t *a)
         a->dev.ntris = hs->bvh.ntris; a->dev.nnodes = hs->bvh.nnodes;
         a->dev.max_depth = hs->bvh.max_depth; a->dev.scene_r = r; a->dev.ray_chunk = a->ray_chunk;
         for (int k = 0; k < 3; k++) { a->dev.grid_lo[k] = hs->bvh.grid_lo[k]; a->dev.grid_step[k] = hs->bvh.grid_step[k]; }
-        if (hs->have_ref) {
-            const uint32_t rn = hs->ref.nnodes;
-            int *lca = (int *)malloc(sizeof(int) * 4 * (size_t)rn);
-            uint32_t *lp = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (size_t)hs->bvh.ntris);
-            if (!lca || !lp) { free(lca); free(lp); return fail("out of memory"); }
-            for (uint32_t i = 0; i < rn; i++) {
-                lca[4 * i] = hs->ref.nodes[i].parent; lca[4 * i + 1] = hs->ref.nodes[i].depth;
-                lca[4 * i + 2] = hs->ref.nodes[i].axis; lca[4 * i + 3] = hs->ref.nodes[i].child[0];
-            }
-            for (uint32_t p = 0; p < hs->bvh.ntris; p++) { lp[2 * p] = hs->ref.prim_leaf[p]; lp[2 * p + 1] = hs->ref.prim_pos[p]; }
-            hipError_t e1 = hipMalloc(&a->d_ref_lca, sizeof(int) * 4 * (size_t)rn);
-            hipError_t e2 = hipMalloc(&a->d_prim_leafpos, sizeof(uint32_t) * 2 * (size_t)hs->bvh.ntris);
-            hipError_t e3 = hipMalloc(&a->d_ref_nodes, sizeof(lh_refnode_t) * (size_t)rn);
-            hipError_t e4 = hipMalloc(&a->d_ref_leaf_prims, sizeof(uint32_t) * (size_t)hs->bvh.ntris);
-            if (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess) {
-                e1 = hipMemcpy(a->d_ref_lca, lca, sizeof(int) * 4 * (size_t)rn, hipMemcpyHostToDevice);
-                e2 = hipMemcpy(a->d_prim_leafpos, lp, sizeof(uint32_t) * 2 * (size_t)hs->bvh.ntris, hipMemcpyHostToDevice);
-                e3 = hipMemcpy(a->d_ref_nodes, hs->ref.nodes, sizeof(lh_refnode_t) * (size_t)rn, hipMemcpyHostToDevice);
-                e4 = hipMemcpy(a->d_ref_leaf_prims, hs->ref.leaf_prims, sizeof(uint32_t) * (size_t)hs->bvh.ntris, hipMemcpyHostToDevice);
-            }
-            free(lca); free(lp);
-            if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) return fail("reference-order tree upload failed");
-            a->dev.ref_lca = a->d_ref_lca; a->dev.prim_leafpos = a->d_prim_leafpos;
-            a->dev.ref_nodes = a->d_ref_nodes; a->dev.ref_leaf_prims = a->d_ref_leaf_prims;
-            a->dev.ref_nnodes = rn; a->dev.ref_empty = hs->ref.empty;
-            for (int k = 0; k < 3; k++) { a->dev.ref_bmin[k] = hs->ref.bmin[k]; a->dev.ref_bmax[k] = hs->ref.bmax[k]; }
-            a->device_bytes += sizeof(int) * 4 * (size_t)rn + sizeof(uint32_t) * 3 * (size_t)hs->bvh.ntris + sizeof(lh_refnode_t) * (size_t)rn;
-        }
+        if (hs->have_ref && __atomic_load_n(&hs->ref_state, __ATOMIC_ACQUIRE) == 2 && attach_ref(a) != 0) return -1;
         a->dev.nq4nodes = hs->bvh.nq4nodes; a->dev.q4_depth = hs->bvh.q4_depth;
         a->dev.nc8nodes = hs->bvh.nc8nodes; a->dev.c8_depth = hs->bvh.c8_depth;
         a->dev.use_qnodes = 2;
@@ -537,7 +617,8 @@ static int device_upload(lh_accel_t *a)
             const char *fmt = getenv("LH_NODE_FORMAT");
             if (fmt && strcmp(fmt, "f32") == 0) a->dev.use_qnodes = 0;
             if (fmt && strcmp(fmt, "q16") == 0) a->dev.use_qnodes = 1;
-            if (3 * hs->bvh.q4_depth + 5 > 64) a->dev.use_qnodes = 1;     /* pathological depth: 2-wide walk */
+            if (3 * hs->bvh.q4_depth + 5 > 64 && !hs->device_built) a->dev.use_qnodes = 1;     /* pathological depth: 2-wide walk */
+            a->dev.nodes_2wide_available = !hs->device_built;
             /* 8-wide compressed nodes: stack overflow is handed to the reference walk, so that tree is needed */
             if (fmt && strcmp(fmt, "c8") == 0 && hs->have_ref) a->dev.use_qnodes = 3;
         }
@@ -550,6 +631,7 @@ static int device_upload(lh_accel_t *a)
         HIPCHK(hipGetDeviceProperties(&prop, a->device));
         uint32_t need = hs->bvh.max_depth + 1;
         if (a->dev.use_qnodes == 2) need = 3 * hs->bvh.q4_depth + 5;
+        if (need > 64) need = 64;
         uint32_t stack = (need + 1u) & ~1u;
         if (stack < 16) stack = 16;
         int per_cu = (int)(160u / stack);                     /* LDS: stack KiB per 256-thread workgroup */
@@ -573,10 +655,48 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
     if (a->committed) return fail("lh_accel_commit: already committed");
     if (a->commit_failed) return fail("lh_accel_commit: an earlier commit of this accelerator failed; create a new one");
     a->commit_failed = 1;                       /* cleared on success */
-    if (host_build(a, build_threads) != 0) return -1;
+    bool on_device = build_threads == LH_BUILD_ON_DEVICE;
+    { const char *e = getenv("LH_BUILD"); if (e && strcmp(e, "device") == 0) on_device = true; if (e && strcmp(e, "host") == 0) on_device = false; }
+    { const char *f = getenv("LH_NODE_FORMAT"); if (f && strcmp(f, "q16x4") != 0) on_device = false; }   /* the A/B formats come from the host builder */
+    if (build_threads < 0) build_threads = 0;
+    if (on_device) {
+        if (host_build(a, build_threads, true, true) != 0) return -1;
+        const int rc = device_upload(a);
+        if (rc == -3) {
+            /* an LBVH deeper than the kernel's stack bound (degenerate distributions): build on the host after all */
+            (void)hipSetDevice(a->device); release_device(a);
+            lh_host_scene *hs = a->hs;
+            pthread_mutex_lock(&g_scene_mu);
+            if (hs->ref_thread_live) { pthread_join(hs->ref_thread, NULL); hs->ref_thread_live = 0; }
+            pthread_mutex_unlock(&g_scene_mu);
+            free(hs->nrm9); free(hs->attr9[0]); free(hs->attr9[1]); free(hs->attr9[2]); free(hs->st6); free(hs->inside);
+            hs->nrm9 = NULL; hs->attr9[0] = hs->attr9[1] = hs->attr9[2] = NULL; hs->st6 = NULL; hs->inside = NULL;
+            lh_bvh_release(&hs->bvh); lh_refbvh_release(&hs->ref); hs->ref_state = 0;
+            on_device = false;
+        } else {
+            for (uint32_t g = 0; g < a->nmeshes; g++) {
+                free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm);
+                for (int k = 0; k < 5; k++) free(a->meshes[g].attr[k]);
+            }
+            free(a->meshes); a->meshes = NULL; a->nmeshes = 0;
+            if (rc != 0) return -1;
+            a->commit_failed = 0;
+            return 0;
+        }
+    }
+    if (host_build(a, build_threads, false, false) != 0) return -1;
     if (device_upload(a) != 0) return -1;
     a->commit_failed = 0;
     return 0;
+}
+
+/* blocks until the reference-order tree of a device-built scene is attached: from then on exact-t ties and fragile
+ * hits follow the reference's tree (before: ties fall back to "larger primitive id wins", as with LH_REFTREE=0) */
+extern "C" int lh_accel_wait_exact(lh_accel_t *a)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_accel_wait_exact: accel not committed");
+    return sync_ref(a, true);
 }
 
 /* lh_multi.hip: `dst` (created, nothing added) becomes a replica of `src`'s committed scene on its own device */
@@ -591,7 +711,7 @@ extern "C" int lh_accel_commit_replica(lh_accel_t *dst, lh_accel_t *src)
     pthread_mutex_unlock(&g_scene_mu);
     free(old);                                  /* a fresh accelerator's scene holds nothing */
     dst->commit_failed = 1;
-    if (device_upload(dst) != 0) return -1;
+    if (device_upload(dst) != 0) return -1;         /* a device-built scene is built again on this replica's device */
     dst->commit_failed = 0;
     return 0;
 }
@@ -609,6 +729,7 @@ extern "C" void lh_accel_destroy(lh_accel_t *a)
     const int last = (--a->hs->refs == 0);
     pthread_mutex_unlock(&g_scene_mu);
     if (last) {
+        if (a->hs->ref_thread_live) { pthread_join(a->hs->ref_thread, NULL); a->hs->ref_thread_live = 0; }
         free(a->hs->nrm9); free(a->hs->attr9[0]); free(a->hs->attr9[1]); free(a->hs->attr9[2]); free(a->hs->st6); free(a->hs->inside);
         lh_bvh_release(&a->hs->bvh);
         lh_refbvh_release(&a->hs->ref);
@@ -672,6 +793,7 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
     else if (!strcmp(name, "ray_chunk") && value > 0 && value <= (1 << 20)) { a->ray_chunk = (uint32_t)value; a->dev.ray_chunk = (uint32_t)value; }
     else if (!strcmp(name, "variant") && value >= 0 && value <= LH_VARIANT_LEAN) a->default_variant = value;
     else if (!strcmp(name, "ao_fused")) a->ao_fused = value != 0;
+    else if (!strcmp(name, "stack_cap") && (value == 0 || (value >= 8 && value <= 64 && value % 2 == 0))) a->dev.stack_cap = (uint32_t)value;
     else return fail("lh_accel_set_param: unknown parameter or bad value: %s = %d", name, value);
     return 0;
 }
@@ -679,6 +801,7 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
 extern "C" int lh_accel_export(const lh_accel_t *a, void *nodes, void *tri32)
 {
     if (!a || !a->committed) return fail("lh_accel_export: accel not committed");
+    if (a->hs->device_built) return fail("lh_accel_export: the tree was built on the device; there is no host copy");
     if (nodes && a->hs->bvh.nnodes) memcpy(nodes, a->hs->bvh.nodes, sizeof(lh_node_t) * (size_t)a->hs->bvh.nnodes);
     if (tri32 && a->hs->bvh.ntris) memcpy(tri32, a->hs->bvh.tri32, sizeof(lh_tri32_t) * (size_t)a->hs->bvh.ntris);
     return 0;
@@ -743,6 +866,7 @@ static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
         HIPCHK(hipGetLastError());
         return 0;
     }
+    if (a->hs->device_built && !a->d_ref_nodes && sync_ref(a, false) != 0) return -1;     /* background reference tree: attach when ready */
     if (variant == LH_VARIANT_DEFAULT) variant = a->default_variant;
     if (variant < 0 || variant > LH_VARIANT_LEAN) return fail("intersect: unknown variant %d", variant);
     if (variant == LH_VARIANT_LEAN) {
@@ -794,6 +918,7 @@ extern "C" int lh_accel_intersect_device_counted(lh_accel_t *a, size_t n, const 
         unsigned long long h[LH_CNT_DEV];
         HIPCHK(hipMemcpy(h, a->d_counters, sizeof(h), hipMemcpyDeviceToHost));
         for (int k = 0; k < LH_CNT_N; k++) counters[k] = h[k];
+        a->last_retraced = h[LH_CNT_RETRACED];
         if (getenv("LH_DEBUG_COUNTERS"))
             fprintf(stderr, "[lucille_hip] lane slots: node steps %llu of %llu, triangle steps %llu of %llu, regroup iterations %llu; "
                             "rays through the reference walk %llu\n",
@@ -801,6 +926,8 @@ extern "C" int lh_accel_intersect_device_counted(lh_accel_t *a, size_t n, const 
     }
     return 0;
 }
+
+extern "C" uint64_t lh_accel_last_retraced(const lh_accel_t *a) { return a ? a->last_retraced : 0; }
 
 static int ensure_stage(lh_accel_t *a, size_t bytes)
 {
@@ -1058,7 +1185,8 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
     /* AO stage.  Fused (default): the any-hit kernel generates ray (slot, r) in its refill (lh_ao.h) and counts
      * the occluded rays per slot -- nothing per AO ray goes through HBM.  Materialised: caller uniforms (the parity
      * replay), LH_AO_FUSED=0, a scene the lean walk cannot take, or a pending-queue overflow of the fused launch. */
-    bool fused = a->ao_fused && !d_uniforms && nao && nao < ((size_t)1 << 32) && a->dev.use_qnodes == 2 && 3 * a->dev.q4_depth + 5 <= 64;
+    bool fused = a->ao_fused && !d_uniforms && nao && nao < ((size_t)1 << 32) && a->dev.use_qnodes == 2 &&
+                 ((3 * a->dev.q4_depth + 5 <= 64 && !a->dev.stack_cap) || a->dev.ref_nodes != NULL);     /* deeper: rays whose stack would overflow go to the reference walk */
     if (fused) {
         if (ensure_buf(&a->r_occcount, (size_t)nhit * sizeof(unsigned int))) return -1;
         const int k = t2_slot(a, s, a->default_variant == LH_VARIANT_LEAN);
@@ -1320,6 +1448,7 @@ extern "C" int lh_accel_beam_visibility_device(lh_accel_t *a, size_t n, const vo
     if (n == 0) return 0;
     if (!d_org || !d_dirs || !d_result) return fail("beam_visibility: NULL argument");
     if (!a->hs->have_ref) return fail("beam_visibility: the reference-order tree was disabled (LH_REFTREE=0)");
+    if (sync_ref(a, true) != 0) return -1;
     HIPCHK(hipSetDevice(a->device));
     lh_dev_scene_t sc = a->dev;
     if (a->hs->bvh.ntris == 0) { sc.ref_empty = 1; }

@@ -648,6 +648,43 @@ int lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, 
     return 0;
 }
 
+/* primitive flattening only (create_triangle_list order: tri64, prim_geom, prim_index), no tree: the input of the
+ * device builder (lh_build.hip).  Same return codes as lh_bvh_build. */
+int lh_bvh_flatten(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes)
+{
+    uint64_t n64 = 0; uint32_t g, i, p = 0; int k, c;
+    memset(out, 0, sizeof(*out));
+    for (g = 0; g < nmeshes; g++) {
+        const lh_mesh_view_t *m = &meshes[g];
+        if (m->nindices && (!m->indices || !m->positions)) return -1;
+        n64 += m->nindices / 3;
+    }
+    if (n64 >= (1u << 29)) return -1;
+    out->ntris = (uint32_t)n64;
+    if (n64 == 0) return 0;
+    out->tri64 = (lh_tri64_t *)malloc(sizeof(lh_tri64_t) * (size_t)n64);
+    out->prim_geom = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n64);
+    out->prim_index = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n64);
+    if (!out->tri64 || !out->prim_geom || !out->prim_index) { lh_bvh_release(out); return -1; }
+    for (g = 0; g < nmeshes; g++) {
+        const lh_mesh_view_t *m = &meshes[g];
+        for (i = 0; i < m->nindices / 3; i++, p++) {
+            lh_tri64_t *t = &out->tri64[p];
+            for (c = 0; c < 3; c++) {
+                const uint32_t vi = m->indices[3 * i + c]; const double *P;
+                if (vi >= m->npositions) { lh_bvh_release(out); return -1; }
+                P = (const double *)((const char *)m->positions + (size_t)vi * m->stride_bytes);
+                for (k = 0; k < 3; k++) {
+                    if (!(fabs(P[k]) <= 1.0e30)) { lh_bvh_release(out); return -2; }
+                    t->v[c][k] = P[k];
+                }
+            }
+            out->prim_geom[p] = g; out->prim_index[p] = 3 * i;
+        }
+    }
+    return 0;
+}
+
 /* the 8-wide compressed collapse, built the first time something asks for it (not thread-safe: callers lock) */
 int lh_bvh_ensure_c8(lh_bvh_t *bvh)
 {

@@ -125,6 +125,7 @@ typedef struct lh_mesh_view {
 /* returns 0 on success, -1 on bad input / out of memory, -2 on a NaN / infinite / > 1e30 vertex coordinate */
 int  lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes,
                   int nthreads);
+int  lh_bvh_flatten(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes);   /* primitives only, no tree */
 int  lh_bvh_ensure_c8(lh_bvh_t *bvh);      /* builds c8nodes / tri32_c8 on first use; 0 / -1 */
 void lh_bvh_release(lh_bvh_t *bvh);
 

@@ -38,6 +38,8 @@ typedef struct lh_dev_scene {
     uint32_t    max_depth;
     float       scene_r;   /* max |coordinate| of the scene box              */
     uint32_t    ray_chunk; /* rays a persistent wave reserves per atomic on the global cursor */
+    uint32_t    stack_cap; /* 0: 64 LDS stack rows at most; 8..62: a lower cap (tests of the overflow path) */
+    int         nodes_2wide_available;   /* host-built scenes: the 2-wide formats can be uploaded on demand (deep-tree fallback) */
 } lh_dev_scene_t;
 
 /* traversal statistics accumulated by the COUNT variants (u64 each) */
@@ -63,6 +65,8 @@ enum {
 #define LH_T2_ROWS        16           /* LDS ring rows per lane of the lean walk */
 #define LH_PRIM_PENDING   0xFFFFFFF0u  /* | candidate count: the slot holds unresolved candidates (not a valid id: ids < 2^29) */
 #define LH_OCC_PENDING    3u           /* any-hit: the ray waits in the pending queue */
+#define LH_PRIM_OVERFLOW  0xFFFFFFFDu  /* the LDS stack column was too short for this ray: k_overflow_fix */
+#define LH_OCC_OVERFLOW   4u
 
 #ifdef __cplusplus
 extern "C" {

@@ -259,8 +259,13 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
     const float4 *__restrict__ tris  = (const float4 *)sc.tri32;
     constexpr int kNoLeaf = 0;
 
+    const int rows = (int)sc.stack_rows;
     for (;;) {
         if (COUNT) { if (__ballot(L.cur >= 0) != 0ull) c_nslots++; }
+        /* the step below writes up to slot sp + 3.  rows = 3 * depth + 5 covers every ray of a tree that deep; a deeper
+         * tree (an LBVH built on the device over a degenerate distribution) gets 64 rows and a ray that would overrun them
+         * is finished by k_overflow_fix with a private stack -- same arithmetic, same answer */
+        if (L.cur >= 0 && L.sp + 4 > rows) { L.over = true; L.cur = kDone; pend = kNoLeaf; }
         if (L.cur >= 0) {
             const uint4 *p = (const uint4 *)sc.q4nodes + 4 * (size_t)L.cur;
             const uint4 a = p[0], b = p[1], c = p[2], r = p[3];
@@ -486,8 +491,12 @@ template <bool ANYHIT>
 __device__ __forceinline__ void write_out(size_t i, const Lane &L, const Best &best,
                                           uint32_t *__restrict__ prim, double *__restrict__ t,
                                           double *__restrict__ u, double *__restrict__ v,
-                                          uint8_t *__restrict__ occ, const bool retrace_on)
+                                          uint8_t *__restrict__ occ, const bool retrace_on, const bool over_fix = false)
 {
+    if (over_fix && L.over) {            /* the LDS stack was too short for this ray: k_overflow_fix redoes it */
+        if (ANYHIT) occ[i] = (uint8_t)LH_OCC_OVERFLOW; else prim[i] = LH_PRIM_OVERFLOW;
+        return;
+    }
     /* a hit the reference may not reach goes through the reference's own walk (k_ref_retrace);
      * a certain fp32 hit is strictly inside its triangle, hence inside every box: never fragile */
     const bool retrace = retrace_on && (L.over || (best.prim != LH_MISS_PRIM && best.frag != 0u && !(ANYHIT && L.certain)));
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         if (idle) {
             if (my != (size_t)-1) {
                 finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
-                if (SRC == 0) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL);
+                if (SRC == 0) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL, WALK == 3);
                 else {
                     const bool hit = L.certain || best.prim != LH_MISS_PRIM;
                     const bool retrace = sc.ref_nodes != NULL && (L.over || (best.prim != LH_MISS_PRIM && best.frag != 0u && !L.certain));
@@ -681,6 +690,75 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         atomicAdd(&counters[LH_CNT_TRI_SLOTS], (unsigned long long)cts);
         atomicAdd(&counters[LH_CNT_REGROUP_SLOTS], (unsigned long long)crs);
     }
+}
+
+/* ------------------------------------------------------------------------ */
+/* rays whose LDS stack column was too short (trees deeper than 19 4-wide   */
+/* levels): the same walk, sequential, with a private stack                 */
+/* ------------------------------------------------------------------------ */
+#define LH_BIG_STACK 272        /* 3 * 88 + 8: the deepest 4-wide tree the device builder hands over */
+
+template <bool ANYHIT>
+__device__ void overflow_walk(const lh_dev_scene_t &sc, size_t i, const double *__restrict__ org, const double *__restrict__ dir,
+                              uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u, double *__restrict__ v,
+                              uint8_t *__restrict__ occ)
+{
+    const double ox = org[3 * i], oy = org[3 * i + 1], oz = org[3 * i + 2];
+    const double dx = dir[3 * i], dy = dir[3 * i + 1], dz = dir[3 * i + 2];
+    const float4 *__restrict__ tris = (const float4 *)sc.tri32;
+    Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM, 0u};
+    uint32_t ce = 0;
+    int stack[LH_BIG_STACK]; int sp = 0;
+    lane_init(L, sc, ox, oy, oz, dx, dy, dz);
+    int cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const uint4 *p = (const uint4 *)sc.q4nodes + 4 * (size_t)cur;
+            const uint4 a = p[0], b = p[1], c = p[2], r = p[3];
+            float tn[4]; bool h[4]; const int ref[4] = {(int)r.x, (int)r.y, (int)r.z, (int)r.w};
+            h[0] = slab_w(L, a.x, a.y, a.z, tn[0]) & (ref[0] != kDone);
+            h[1] = slab_w(L, a.w, b.x, b.y, tn[1]) & (ref[1] != kDone);
+            h[2] = slab_w(L, b.z, b.w, c.x, tn[2]) & (ref[2] != kDone);
+            h[3] = slab_w(L, c.y, c.z, c.w, tn[3]) & (ref[3] != kDone);
+            int order[4], nh = 0;
+            for (int k = 0; k < 4; k++) if (h[k]) {
+                int m = nh++;
+                while (m > 0 && tn[order[m - 1]] > tn[k]) { order[m] = order[m - 1]; m--; }
+                order[m] = k;
+            }
+            for (int k = nh - 1; k >= 1; k--) if (sp < LH_BIG_STACK) stack[sp++] = ref[order[k]];
+            if (nh) cur = ref[order[0]];
+            else if (sp) cur = stack[--sp];
+            else break;
+        } else {
+            const uint32_t x = ~(uint32_t)cur, first = x >> 2, cnt = (x & 3u) + 1u;
+            bool finished = false;
+            for (uint32_t k = 0; k < cnt && !finished; k++) {
+                const float4 *tp = tris + 3 * (size_t)(first + k);
+                const float4 ta = tp[0], tb_ = tp[1], tc = tp[2];
+                finished = tri_step<ANYHIT, false>(L, sc, ta.x, ta.y, ta.z, ta.w, tb_.x, tb_.y, tb_.z, tb_.w, tc.x, tc.z, tc.w,
+                                                   __float_as_uint(tc.y), ox, oy, oz, dx, dy, dz, best, ce);
+            }
+            if (finished || sp == 0) break;
+            cur = stack[--sp];
+        }
+    }
+    L.over = false;
+    finish<ANYHIT, false>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
+    write_out<ANYHIT>(i, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL);
+}
+
+__global__ __launch_bounds__(256) void k_overflow_fix(lh_dev_scene_t sc, size_t n, const double *__restrict__ org,
+                                                      const double *__restrict__ dir, uint32_t *__restrict__ prim,
+                                                      double *__restrict__ t, double *__restrict__ u, double *__restrict__ v,
+                                                      uint8_t *__restrict__ occ, int anyhit, unsigned long long *counters)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (anyhit ? (occ[i] != LH_OCC_OVERFLOW) : (prim[i] != LH_PRIM_OVERFLOW)) return;
+    if (anyhit) overflow_walk<true>(sc, i, org, dir, prim, t, u, v, occ);
+    else overflow_walk<false>(sc, i, org, dir, prim, t, u, v, occ);
+    if (counters) atomicAdd(&counters[LH_CNT_RETRACED], 1ull);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -783,9 +861,13 @@ extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int n
     if (n >= ((size_t)1 << 32) || sc->use_qnodes != 2) return -1;
     lh_dev_scene_t scl = *sc;
     uint32_t need = 3 * sc->q4_depth + 5;
-    if (need > 64) return -1;
+    const uint32_t cap = (sc->stack_cap >= 8 && sc->stack_cap < 64) ? sc->stack_cap : 64;
+    if (need > cap) {                /* a deep (device-built) tree: 64 rows, the rare ray that needs more is queued for the reference walk */
+        if (!sc->ref_nodes) return -1;
+        need = cap;
+    }
     need = (need + 1u) & ~1u;
-    if (need < 16) need = 16;
+    if (need < 16 && need != cap) need = 16;
     scl.stack_rows = need;
     const size_t lds_bytes = (size_t)need * LH_BLOCK * sizeof(int);
     {
@@ -823,7 +905,7 @@ extern "C" int lh_trace_formats_needed(const lh_dev_scene_t *sc, int variant)
         uq = (variant == LH_VARIANT_UNIFIED4) ? 2 : 1;
     }
     if ((variant == LH_VARIANT_SPEC || variant == LH_VARIANT_UNIFIED4) && uq == 2) {
-        if (3 * sc->q4_depth + 5 > 64) return 2;
+        if (3 * sc->q4_depth + 5 > 64 && sc->nodes_2wide_available) return 2;
         return 4;
     }
     if (uq == 0) return 1;
@@ -852,14 +934,22 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
         } else if (variant == LH_VARIANT_UNIFIED4) scl.use_qnodes = 2;
         else scl.use_qnodes = 1;                 /* the 2-wide walks read the 16-bit grid nodes */
     }
+    bool over_fix = false;
     if ((variant == LH_VARIANT_SPEC || variant == LH_VARIANT_UNIFIED4) && scl.use_qnodes == 2) {
         need = 3 * sc->q4_depth + 5;
         /* a very deep tree (chains of nested geometry): the 4-wide walk's worst case does not fit the
-         * 64-row LDS stack; the 2-wide walk over the same tree (<= LH_MAX_DEPTH + 1 rows) always does */
-        if (need > 64) { scl.use_qnodes = 1; need = sc->max_depth + 1; }
+         * 64-row LDS stack.  Host-built trees come with the 2-wide nodes: that walk (<= LH_MAX_DEPTH + 1 rows) always fits.
+         * Device-built trees have only the 4-wide nodes: 64 rows, and a ray that would overrun them (none in practice: the
+         * bound is three pushes on every level) is finished by k_overflow_fix */
+        const uint32_t cap = (sc->stack_cap >= 8 && sc->stack_cap < 64) ? sc->stack_cap : 64;     /* < 64: the tests' way to reach the overflow path */
+        if (need > cap) {
+            if (cap == 64 && sc->nodes_2wide_available) { scl.use_qnodes = 1; need = sc->max_depth + 1; }
+            else if (variant == LH_VARIANT_SPEC) { need = cap; over_fix = true; }
+            else return -1;
+        }
     }
     need = (need + 1u) & ~1u;
-    if (need < 16) need = 16;
+    if (need < 16 && !over_fix) need = 16;
     if (need > 64) return -1;
     scl.stack_rows = need;
     const size_t lds_bytes = (size_t)need * LH_BLOCK * sizeof(int);
@@ -873,6 +963,17 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
         if (scl.ray_chunk == 0) scl.ray_chunk = 64;
     }
     sc = &scl;
+    if (over_fix) {
+        const int rc = launch_stack(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
+                                    d_counters, d_workq, variant, grid_blocks, min_active, tri_batch, lds_bytes, s);
+        if (rc != 0) return rc;
+        hipLaunchKernelGGL(k_overflow_fix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, *sc, n, d_org, d_dir,
+                           d_prim, d_t, d_u, d_v, d_occluded, anyhit, d_counters);
+        if (sc->ref_nodes)
+            hipLaunchKernelGGL(k_ref_retrace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, *sc, n, d_org, d_dir,
+                               d_prim, d_t, d_u, d_v, d_occluded, anyhit, d_counters);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     if (sc->ref_nodes) {
         const int rc = launch_stack(*sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
                                     d_counters, d_workq, variant, grid_blocks, min_active, tri_batch, lds_bytes, s);

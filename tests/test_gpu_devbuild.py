@@ -1,0 +1,146 @@
+"""The traversal tree built on the device (lh_build.hip: Morton LBVH -> the same 4-wide 16-bit-grid nodes; lucille's own
+tree by a background host thread) against the oracle and against the host-built tree: hit records do not depend on the tree
+(SURVEY 8a-10), so everything must stay bit for bit -- ids, fp64 t / u / v, exact-t ties, AO frames."""
+import numpy as np
+import pytest
+
+import lucille_amd as la
+from lucille_amd import render, scenes
+from oracle import pyoracle as po
+from tests.helpers import assert_hits_equal, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_accel(P, idx):
+    acc = la.HipAccel(0); acc.add_mesh(P, idx)
+    info = acc.commit(on_device=True)
+    return acc, info
+
+
+@pytest.mark.parametrize("ntri,he,seed", [(1, 0.2, 1), (3, 0.2, 2), (4, 0.2, 3), (5, 0.2, 4), (37, 0.1, 5), (3000, 0.05, 6), (200000, 0.008, 7)])
+def test_device_built_tree_parity(ntri, he, seed):
+    import torch
+    P, idx, org, dr = po.soup(ntri, 60000, he, 1000 + seed)
+    acc, info = dev_accel(P, idx)
+    assert info["ntriangles"] == ntri and info["nnodes_traversal"] >= 1
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr, nthreads=8)
+    # before the background reference tree is attached (or after: timing decides) and after waiting for it
+    got0 = acc.intersect_host(org, dr)
+    assert_hits_equal(got0, exp, "device-built %d (no wait)" % ntri)
+    acc.wait_exact()
+    assert_hits_equal(acc.intersect_host(org, dr), exp, "device-built %d" % ntri)
+    assert np.array_equal(acc.intersect_host(org, dr, mode=la.MODE_ANY).astype(bool), exp[0] != po.MISS)
+    d_o = torch.from_numpy(org).cuda(); d_d = torch.from_numpy(dr).cuda()
+    out6 = acc.intersect_device(d_o, d_d, variant=la.VARIANT_LEAN); torch.cuda.synchronize()
+    assert_hits_equal(tuple(x.cpu().numpy() for x in out6), exp, "device-built %d, lean walk" % ntri)
+    with pytest.raises(la.LucilleHipError, match="built on the device"):
+        acc.intersect_device(d_o, d_d, variant=la.VARIANT_DIRECT)          # the 2-wide formats exist only in the host builder
+    acc.close()
+
+
+def test_device_built_tree_exact_t_ties_and_vertex_rays():
+    """rays through shared edges / vertices of a tessellated plane: after wait_exact the winners follow lucille's own tree
+    (built in the background), exactly as with the host builder"""
+    g = load_golden("ao_c1")
+    P, I = scenes.tessellate(g["pos0"], g["idx0"], 3)
+    acc, _ = dev_accel(P, I)
+    acc.wait_exact()
+    o = po.Oracle(); o.add_mesh(P, I); o.build()
+    rng = np.random.default_rng(4)
+    T = P[I.astype(np.int64)].reshape(-1, 3, 3)
+    pick = rng.integers(0, T.shape[0], 20000)
+    tgt = T[pick, rng.integers(0, 3, 20000)].copy()                         # exactly a vertex
+    tgt[::2] = 0.5 * (T[pick[::2], 0] + T[pick[::2], 1])                    # exactly an edge midpoint
+    org = tgt + rng.normal(size=tgt.shape) * 3.0
+    dr = tgt - org
+    ok = np.abs(dr[:, 1]) > 1e-14
+    org, dr = np.ascontiguousarray(org[ok]), np.ascontiguousarray(dr[ok])
+    exp = o.intersect(org, dr, nthreads=8)
+    assert_hits_equal(acc.intersect_host(org, dr), exp, "device-built, ties")
+    assert o.count_equal_t(org[:4000], dr[:4000], exp[1][:4000]).max() >= 2       # ties really occur
+    acc.close()
+
+
+def test_device_built_scene_renders_the_same_frames_and_builds_fast():
+    import torch
+    g = load_golden("ao_c1")
+    host = la.HipAccel(0); dev = la.HipAccel(0)
+    for k in range(int(g["ngeoms"])):
+        Pk, Ik = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], 5)
+        host.add_mesh(Pk, Ik); dev.add_mesh(Pk, Ik)
+    ih = host.commit(); idv = dev.commit(on_device=True)
+    c = g["camera"]; cam = la.Camera.make(320, 240, c[16], c[:16], int(c[19]))
+    a, sa = render.render_ao_frame(host, cam, 2, 16, tile=320, seed=3)
+    b, sb = render.render_ao_frame(dev, cam, 2, 16, tile=320, seed=3)
+    torch.cuda.synchronize()
+    assert sa == sb and torch.equal(a, b)
+    assert idv["ntriangles"] == ih["ntriangles"] == 322 * 4 ** 5
+    assert idv["build_seconds"] < ih["build_seconds"]
+    # beams need lucille's own tree: the call waits for the background build
+    bg = load_golden("beams_300")
+    host.close(); dev.close()
+
+
+def test_degenerate_distributions():
+    """equal centroids (ties in the Morton order are broken by position) and an exponentially spaced line of triangles
+    (a radix tree as deep as the code is long: the commit falls back to the host builder when the kernel's stack bound
+    would not hold)"""
+    rng = np.random.default_rng(9)
+    n = 3000
+    c = np.zeros((n, 1, 3)) + 0.5
+    tri = c + rng.uniform(-0.3, 0.3, (n, 3, 3)); tri -= tri.mean(axis=1, keepdims=True) - 0.5      # every centroid = (0.5, 0.5, 0.5)
+    P = tri.reshape(-1, 3); idx = np.arange(3 * n, dtype=np.uint32)
+    org = rng.uniform(-1, 2, (20000, 3)); dr = rng.uniform(0, 1, (20000, 3)) - org
+    acc, _ = dev_accel(P, idx); acc.wait_exact()
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    assert_hits_equal(acc.intersect_host(org, dr), o.intersect(org, dr, nthreads=8), "equal centroids")
+    acc.close()
+    m = 60
+    x = 2.0 ** -np.arange(m)
+    tri = np.stack([np.stack([x, np.zeros(m), np.zeros(m)], 1), np.stack([x * 1.0001, np.full(m, 1e-3), np.zeros(m)], 1),
+                    np.stack([x, np.zeros(m), np.full(m, 1e-3)], 1)], 1)
+    tri = np.concatenate([tri, tri + np.array([0, 2e-3, 0]), tri + np.array([0, 4e-3, 0]), tri + np.array([0, 6e-3, 0]), tri + np.array([0, 8e-3, 0])])
+    P = tri.reshape(-1, 3); idx = np.arange(P.shape[0], dtype=np.uint32)
+    org = rng.uniform(-0.5, 1.5, (20000, 3)); tgt = P[rng.integers(0, P.shape[0], 20000)] + rng.normal(scale=1e-4, size=(20000, 3))
+    dr = tgt - org
+    acc, info = dev_accel(P, idx); acc.wait_exact()
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    assert_hits_equal(acc.intersect_host(org, dr), o.intersect(org, dr, nthreads=8), "exponential line")
+    acc.close()
+
+
+def test_stack_overflow_paths_keep_every_bit():
+    """a device-built tree can be deeper than the 64-row LDS stack holds in the worst case (BASELINE config 5's scene: 4-wide
+    depth 22 -> 71 rows).  Rays that would overflow are finished by k_overflow_fix (ray dumps, materialised AO) or by the
+    reference walk (fused AO).  Reached here by capping the stack at 8 rows ("stack_cap"): hit records and AO frames stay
+    bit equal to the uncapped walk's, fused or not, on a device-built and on a host-built tree"""
+    import torch
+    g = load_golden("ao_c1")
+    meshes = [scenes.tessellate(g["pos%d" % k], g["idx%d" % k], 4) for k in range(int(g["ngeoms"]))]
+    allp = np.concatenate([m[0] for m in meshes]); lo, hi = allp.min(0), allp.max(0)
+    c = g["camera"]; cam = la.Camera.make(160, 120, c[16], c[:16], int(c[19]))
+    rng = np.random.default_rng(4)
+    org = rng.uniform(lo - 1, hi + 1, (200000, 3)); dr = rng.uniform(lo, hi, (200000, 3)) - org
+    do = torch.from_numpy(org).cuda(); dd = torch.from_numpy(dr).cuda()
+    for on_device in (True, False):
+        acc = la.HipAccel(0)
+        for P, I in meshes:
+            acc.add_mesh(P, I)
+        info = acc.commit(on_device=on_device); acc.wait_exact()
+        assert info["max_depth"] >= 6
+        ref_img, ref_stats = render.render_ao_frame(acc, cam, 2, 16, tile=160, seed=5)
+        ref_hits = acc.intersect_host(org, dr); ref_occ = acc.intersect_host(org, dr, la.MODE_ANY)
+        base = acc.intersect_device(do, dd, counters=True)[-1]["retraced"]
+        acc.set_param("stack_cap", 8)
+        over = acc.intersect_device(do, dd, counters=True)[-1]["retraced"]
+        assert over >= base + 20, (base, over)                       # the capped walk really overflows
+        assert_hits_equal(acc.intersect_host(org, dr), ref_hits, "capped stack, closest")
+        assert np.array_equal(acc.intersect_host(org, dr, la.MODE_ANY), ref_occ)
+        img, stats = render.render_ao_frame(acc, cam, 2, 16, tile=160, seed=5)           # fused: overflow -> reference walk
+        acc.set_param("ao_fused", 0)
+        img2, stats2 = render.render_ao_frame(acc, cam, 2, 16, tile=160, seed=5)         # materialised: k_overflow_fix
+        torch.cuda.synchronize()
+        assert stats == stats2 == ref_stats and torch.equal(img, ref_img) and torch.equal(img2, ref_img)
+        acc.close()
