@@ -92,7 +92,8 @@ struct lh_accel {
     void *d_ref_lca, *d_prim_leafpos, *d_ref_nodes, *d_ref_leaf_prims;
     /* device */
     lh_dev_scene_t dev;
-    void *d_nodes, *d_tri32, *d_tri64, *d_qnodes, *d_q4nodes, *d_c8nodes, *d_tri32_c8;
+    void *d_nodes, *d_tri32, *d_tri64, *d_qnodes, *d_q4nodes, *d_q4tnodes, *d_c8nodes, *d_tri32_c8;
+    int quad_grid;                     /* workgroups of the quad-per-ray walk (variant 7) */
     unsigned long long *d_cursor, *d_counters;   /* d_cursor: LH_NCURSOR slots, one per launch in flight */
     unsigned cursor_next;
     pthread_mutex_t mu;                /* serialises the entry points of ONE accelerator (recursive) */
@@ -284,7 +285,8 @@ static void release_device(lh_accel_t *a)
     if (a->d_qnodes) (void)hipFree(a->d_qnodes);
     a->d_qnodes = NULL;
     if (a->d_q4nodes) (void)hipFree(a->d_q4nodes);
-    a->d_q4nodes = NULL;
+    if (a->d_q4tnodes) (void)hipFree(a->d_q4tnodes);
+    a->d_q4nodes = a->d_q4tnodes = NULL; a->dev.q4tnodes = NULL;
     if (a->d_c8nodes) (void)hipFree(a->d_c8nodes);
     if (a->d_tri32_c8) (void)hipFree(a->d_tri32_c8);
     a->d_c8nodes = a->d_tri32_c8 = NULL;
@@ -443,7 +445,7 @@ static int host_build(lh_accel_t *a, int build_threads, bool on_device, bool kee
 
 /* node formats a walk can read; only the one the default kernel uses is uploaded at commit, the
  * others (A/B variants, the deep-tree fallback) on first use */
-enum { LH_FMT_F32 = 1, LH_FMT_Q16 = 2, LH_FMT_Q16X4 = 4, LH_FMT_C8 = 8 };
+enum { LH_FMT_F32 = 1, LH_FMT_Q16 = 2, LH_FMT_Q16X4 = 4, LH_FMT_C8 = 8, LH_FMT_Q4T = 16 };
 extern "C" int lh_trace_formats_needed(const lh_dev_scene_t *sc, int variant);      /* lh_kernels.hip */
 extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q4nodes, uint32_t *nq4, uint32_t *q4_depth,
                                void **d_tri32, float bmin[3], float bmax[3], float grid_lo[3], float grid_step[3],
@@ -454,8 +456,26 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
 static int ensure_formats(lh_accel_t *a, int mask)
 {
     const lh_bvh_t *b = &a->hs->bvh;
+    if ((mask & LH_FMT_Q4T) && !a->d_q4tnodes && (a->d_q4nodes || !a->hs->device_built)) {
+        /* the quad-per-ray walk's child-major copy of the 4-wide nodes, made on the device */
+        if (!a->d_q4nodes && ensure_formats(a, LH_FMT_Q16X4) != 0) return -1;
+        const size_t q4b = sizeof(lh_q4node_t) * (size_t)b->nq4nodes;
+        HIPCHK(hipMalloc(&a->d_q4tnodes, q4b));
+        if (lh_quad_make_nodes(b->nq4nodes, a->d_q4nodes, a->d_q4tnodes, (void *)a->stream) != 0) return fail("lh_quad_make_nodes failed");
+        HIPCHK(hipStreamSynchronize(a->stream));
+        a->dev.q4tnodes = a->d_q4tnodes; a->device_bytes += q4b;
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, a->device));
+        uint32_t need = 3 * b->q4_depth + 5;
+        if (need > 64) need = 64;
+        if (need < 16) need = 16;
+        a->quad_grid = prop.multiProcessorCount * lh_quad_blocks_per_cu(need);
+        const char *e = getenv("LH_QUAD_GRID");
+        if (e && atoi(e) > 0) a->quad_grid = atoi(e);
+    }
+    mask &= ~LH_FMT_Q4T;
     if (a->hs->device_built) {
-        if (mask & ~LH_FMT_Q16X4) return fail("this scene's tree was built on the device: only the default 4-wide walk is available (variants 4 and 6)");
+        if (mask & ~LH_FMT_Q16X4) return fail("this scene's tree was built on the device: only the 4-wide walks are available (variants 4, 6 and 7)");
         return 0;
     }
     if ((mask & LH_FMT_F32) && !a->d_nodes) {
@@ -791,8 +811,10 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
     else if (!strcmp(name, "min_active") && value > 0 && value <= 64) a->min_active = value;
     else if (!strcmp(name, "tri_batch") && value > 0 && value <= 64) a->tri_batch = value;
     else if (!strcmp(name, "ray_chunk") && value > 0 && value <= (1 << 20)) { a->ray_chunk = (uint32_t)value; a->dev.ray_chunk = (uint32_t)value; }
-    else if (!strcmp(name, "variant") && value >= 0 && value <= LH_VARIANT_LEAN) a->default_variant = value;
+    else if (!strcmp(name, "variant") && value >= 0 && value <= LH_VARIANT_QUAD) a->default_variant = value;
     else if (!strcmp(name, "ao_fused")) a->ao_fused = value != 0;
+    else if (!strcmp(name, "quad_grid") && value > 0) a->quad_grid = value;
+    else if (!strcmp(name, "tri_prefetch")) a->dev.tri_prefetch = value != 0;
     else if (!strcmp(name, "stack_cap") && (value == 0 || (value >= 8 && value <= 64 && value % 2 == 0))) a->dev.stack_cap = (uint32_t)value;
     else return fail("lh_accel_set_param: unknown parameter or bad value: %s = %d", name, value);
     return 0;
@@ -868,7 +890,7 @@ static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
     }
     if (a->hs->device_built && !a->d_ref_nodes && sync_ref(a, false) != 0) return -1;     /* background reference tree: attach when ready */
     if (variant == LH_VARIANT_DEFAULT) variant = a->default_variant;
-    if (variant < 0 || variant > LH_VARIANT_LEAN) return fail("intersect: unknown variant %d", variant);
+    if (variant < 0 || variant > LH_VARIANT_QUAD) return fail("intersect: unknown variant %d", variant);
     if (variant == LH_VARIANT_LEAN) {
         /* the lean walk reads the 4-wide 16-bit-grid nodes; scenes it cannot take (another format forced by
          * LH_NODE_FORMAT, a tree too deep for its 64-entry logical stack) go through the r01 walk */
@@ -887,7 +909,7 @@ static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
     if (ensure_formats(a, lh_trace_formats_needed(&a->dev, variant)) != 0) return -1;     /* A/B formats: uploaded on first use */
     int rc = lh_launch_trace(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim,
                              (double *)d_t, (double *)d_u, (double *)d_v, mode == LH_MODE_ANY,
-                             (uint8_t *)d_occ, d_counters, a->d_cursor + (a->cursor_next++ % LH_NCURSOR), variant, a->grid_blocks, a->min_active, a->tri_batch, (void *)s);
+                             (uint8_t *)d_occ, d_counters, a->d_cursor + (a->cursor_next++ % LH_NCURSOR), variant, (variant == LH_VARIANT_QUAD && a->dev.q4tnodes) ? a->quad_grid : a->grid_blocks, a->min_active, a->tri_batch, (void *)s);
     if (rc != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     return 0;
 }

@@ -21,6 +21,7 @@ typedef struct lh_dev_scene {
     float       grid_lo[3], grid_step[3];
     int         use_qnodes;   /* 0: fp32 2-wide, 1: 16-bit grid 2-wide, 2: 16-bit grid 4-wide, 3: 8-wide compressed */
     const void *q4nodes;      /* lh_q4node_t[nq4nodes] (64 B each)                          */
+    const void *q4tnodes;     /* the same nodes child-major (lh_quad.hip), or NULL                */
     uint32_t    nq4nodes, q4_depth;
     const void *c8nodes;      /* lh_c8node_t[nc8nodes] (80 B each): use_qnodes == 3               */
     const void *tri32_c8;     /* lh_tri32_t[ntris] in the 8-wide tree's leaf order                 */
@@ -38,6 +39,7 @@ typedef struct lh_dev_scene {
     uint32_t    max_depth;
     float       scene_r;   /* max |coordinate| of the scene box              */
     uint32_t    ray_chunk; /* rays a persistent wave reserves per atomic on the global cursor */
+    int         tri_prefetch;   /* A/B: the 4-wide walk loads a parked leaf's triangle when it parks it */
     uint32_t    stack_cap; /* 0: 64 LDS stack rows at most; 8..62: a lower cap (tests of the overflow path) */
     int         nodes_2wide_available;   /* host-built scenes: the 2-wide formats can be uploaded on demand (deep-tree fallback) */
 } lh_dev_scene_t;
@@ -58,6 +60,7 @@ enum {
     LH_VARIANT_UNIFIED      = 3,  /* + single-loop walk: one record per lane per iteration */
     LH_VARIANT_SPEC         = 4,  /* + speculative walk, leaves parked and tested in batches */
     LH_VARIANT_UNIFIED4     = 5,  /* single-loop walk over the 4-wide nodes: one record per lane per iteration */
+    LH_VARIANT_QUAD         = 7,  /* lh_quad.hip: one ray per quad of lanes, lane k tests child k / triangle k (A/B) */
     LH_VARIANT_LEAN         = 6   /* lh_trace2.hip: the speculative 4-wide walk without fp64 state, 16-row LDS ring
                                      stack, candidates resolved by a separate fp64 pass */
 };
@@ -87,6 +90,15 @@ int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int ntheta, int 
 int lh_launch_ao_queue(const lh_dev_scene_t *sc, int ntheta, int nphi, unsigned long long seed,
                        const double *d_hitrec, const unsigned long long *d_slot_key, unsigned int *d_occ_count,
                        unsigned long long *d_counters, uint32_t *d_queue, uint32_t *d_qcount, uint32_t qcap, void *stream);
+
+/* lh_quad.hip: the quad-per-ray walk (variant LH_VARIANT_QUAD) */
+#define LH_QUAD_WAVES_PER_SIMD 4         /* what its register allocation allows (128 VGPRs) */
+int lh_quad_make_nodes(uint32_t nq4, const void *d_q4nodes, void *d_q4tnodes, void *stream);
+int lh_quad_blocks_per_cu(uint32_t stack_rows);
+int lh_launch_trace_quad(const lh_dev_scene_t *sc, size_t n, const double *d_org, const double *d_dir, uint32_t *d_prim,
+                         double *d_t, double *d_u, double *d_v, int anyhit, uint8_t *d_occ,
+                         unsigned long long *d_counters, unsigned long long *d_cursor, int grid_blocks, int min_active,
+                         int tri_batch, int *over_fix_out, void *stream);
 
 /* launchers implemented in lh_trace2.hip */
 int lh_trace2_blocks_per_cu(void);

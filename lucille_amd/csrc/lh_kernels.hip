@@ -247,14 +247,16 @@ __device__ __forceinline__ void traverse_spec(Lane &L, int &pend, const lh_dev_s
  * nearest on top; misses: above the new top, i.e. into free space) and the next reference
  * is read back from the new top -- which is the nearest hit, or the previous top when
  * nothing was hit (a pop).  Leaves are parked and tested in batches as in traverse_spec. */
-template <bool ANYHIT, bool COUNT>
+struct TriRegs { float4 a, b, c; bool need; };      /* PF: the parked leaf's next triangle record, loaded one step ahead of its test */
+
+template <bool ANYHIT, bool COUNT, bool PF>
 __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_scene_t &sc,
                                                int (*stk)[LH_BLOCK], const int tid,
                                                double ox, double oy, double oz,
                                                double dx, double dy, double dz, Best &best,
                                                uint32_t &c_nodes, uint32_t &c_tris, uint32_t &c_exact,
                                                const int min_active, const int tri_batch,
-                                               uint32_t &c_nslots, uint32_t &c_tslots)
+                                               uint32_t &c_nslots, uint32_t &c_tslots, TriRegs &pf)
 {
     const float4 *__restrict__ tris  = (const float4 *)sc.tri32;
     constexpr int kNoLeaf = 0;
@@ -262,6 +264,15 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
     const int rows = (int)sc.stack_rows;
     for (;;) {
         if (COUNT) { if (__ballot(L.cur >= 0) != 0ull) c_nslots++; }
+        /* PF: a parked leaf's triangle is requested here, in front of the node record, and tested one step later: both
+         * requests are in flight together and the triangle pass never waits for memory */
+        const bool fresh = PF && pf.need && pend != kNoLeaf;          /* requested in this step: tested in a later one */
+        float4 na, nb, nc;                        /* landing registers: copied into pf after the node record has arrived */
+        if (fresh) {
+            const float4 *tp = tris + 3 * (size_t)((~(uint32_t)pend) >> 2);
+            na = tp[0]; nb = tp[1]; nc = tp[2];
+        }
+        if (PF) pf.need = false;
         /* the step below writes up to slot sp + 3.  rows = 3 * depth + 5 covers every ray of a tree that deep; a deeper
          * tree (an LBVH built on the device over a degenerate distribution) gets 64 rows and a ray that would overrun them
          * is finished by k_overflow_fix with a private stack -- same arithmetic, same answer */
@@ -297,23 +308,27 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
             pend = park ? nxt : pend;
             L.cur = park ? popped2 : nxt;
             L.sp -= park ? 1 : 0;
+            if (PF) pf.need = pf.need | park;
         }
+        if (fresh) { pf.a = na; pf.b = nb; pf.c = nc; }
+        const bool ready = (pend != kNoLeaf) & !(PF && (fresh | pf.need));      /* PF: only triangles that have arrived */
         const unsigned long long m_node = __ballot(L.cur >= 0);
-        const unsigned long long m_pend = __ballot(pend != kNoLeaf);
+        const unsigned long long m_pend = __ballot(ready);
         if (m_pend != 0ull && (__popcll(m_pend) >= tri_batch || m_node == 0ull)) {
             if (COUNT) c_tslots++;
-            if (pend != kNoLeaf) {
+            if (ready) {
                 const uint32_t x = ~(uint32_t)pend;
-                const float4 *tp = tris + 3 * (size_t)(x >> 2);
-                const float4 ta = tp[0], tb_ = tp[1], tc = tp[2];
+                float4 ta, tb_, tc;
+                if (PF) { ta = pf.a; tb_ = pf.b; tc = pf.c; }
+                else { const float4 *tp = tris + 3 * (size_t)(x >> 2); ta = tp[0]; tb_ = tp[1]; tc = tp[2]; }
                 if (COUNT) c_tris++;
                 const bool finished = tri_step<ANYHIT, COUNT>(L, sc, ta.x, ta.y, ta.z, ta.w, tb_.x, tb_.y, tb_.z, tb_.w, tc.x, tc.z, tc.w, __float_as_uint(tc.y), ox, oy, oz, dx, dy, dz, best, c_exact);
                 if (finished) { L.cur = kDone; pend = kNoLeaf; }
-                else if (x & 3u) pend = (int)~(((x >> 2) + 1u) << 2 | ((x & 3u) - 1u));
+                else if (x & 3u) { pend = (int)~(((x >> 2) + 1u) << 2 | ((x & 3u) - 1u)); if (PF) pf.need = true; }
                 else {
                     const bool waiting = (L.cur < 0) & (L.cur != kDone);
                     pend = waiting ? L.cur : kNoLeaf;
-                    if (waiting) { L.sp--; L.cur = stk[L.sp][tid]; }
+                    if (waiting) { L.sp--; L.cur = stk[L.sp][tid]; if (PF) pf.need = true; }
                 }
             }
         }
@@ -472,20 +487,6 @@ __device__ __forceinline__ void traverse_unified4(Lane &L, const lh_dev_scene_t 
 }
 
 /* resolve whatever is still queued; afterwards `best` is the exact answer */
-template <bool ANYHIT, bool COUNT>
-__device__ __forceinline__ void finish(Lane &L, const lh_dev_scene_t &sc,
-                                       double ox, double oy, double oz,
-                                       double dx, double dy, double dz, Best &best,
-                                       uint32_t &c_exact)
-{
-    if (ANYHIT && (L.certain || best.prim != LH_MISS_PRIM)) return;
-    if (COUNT) c_exact += (uint32_t)L.np;
-    if (L.np > 0) resolve(sc, L.p0, ox, oy, oz, dx, dy, dz, best);
-    if (L.np > 1) resolve(sc, L.p1, ox, oy, oz, dx, dy, dz, best);
-    if (L.np > 2) resolve(sc, L.p2, ox, oy, oz, dx, dy, dz, best);
-    if (L.np > 3) resolve(sc, L.p3, ox, oy, oz, dx, dy, dz, best);
-    L.np = 0;
-}
 
 template <bool ANYHIT>
 __device__ __forceinline__ void write_out(size_t i, const Lane &L, const Best &best,
@@ -605,6 +606,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
     uint32_t cn = 0, ct = 0, ce = 0, cr = 0, cns = 0, cts = 0, crs = 0;
     Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM, 0u};
     int pend = 0;                    /* WALK 2: parked leaf reference (0 = none) */
+    TriRegs pf = {};                 /* WALK 6: that leaf's next triangle, already loaded */
     size_t my = (size_t)-1;          /* ray this lane is working on */
     double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
     L.cur = kDone; L.sp = 1; L.np = 0; L.certain = false; L.over = false;
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         if (idle) {
             if (my != (size_t)-1) {
                 finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
-                if (SRC == 0) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL, WALK == 3);
+                if (SRC == 0) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL, WALK == 3 || WALK == 6);
                 else {
                     const bool hit = L.certain || best.prim != LH_MISS_PRIM;
                     const bool retrace = sc.ref_nodes != NULL && (L.over || (best.prim != LH_MISS_PRIM && best.frag != 0u && !L.certain));
@@ -675,7 +677,9 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         } else if (WALK == 4) {
             if (L.cur != kDone) traverse_unified4<ANYHIT, COUNT>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
         } else if (WALK == 3) {
-            traverse_spec4<ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts);
+            traverse_spec4<ANYHIT, COUNT, false>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
+        } else if (WALK == 6) {
+            traverse_spec4<ANYHIT, COUNT, true>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
         } else if (WALK == 2) {
             /* every lane enters (idle lanes just vote in the ballots) */
             traverse_spec<ANYHIT, COUNT, QN>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch);
@@ -809,6 +813,9 @@ int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const doub
         else if (variant == LH_VARIANT_UNIFIED4 && sc.use_qnodes == 2)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 4, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
+        else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2 && sc.tri_prefetch)
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 6, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
         else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 3, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
@@ -899,6 +906,7 @@ extern "C" int lh_trace_formats_needed(const lh_dev_scene_t *sc, int variant)
 {
     int uq = sc->use_qnodes;
     if (variant == LH_VARIANT_LEAN) variant = LH_VARIANT_SPEC;      /* same nodes; scenes it cannot take fall back to it */
+    if (variant == LH_VARIANT_QUAD) return (sc->use_qnodes == 2) ? (4 | 16) : lh_trace_formats_needed(sc, LH_VARIANT_SPEC);
     if (variant == LH_VARIANT_UNIFIED) return 1;
     if (uq == 3) {
         if (variant == LH_VARIANT_SPEC) return 8;          /* rays whose stack would overflow go through the reference walk */
@@ -933,6 +941,23 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
             if (need > 48) need = 48;
         } else if (variant == LH_VARIANT_UNIFIED4) scl.use_qnodes = 2;
         else scl.use_qnodes = 1;                 /* the 2-wide walks read the 16-bit grid nodes */
+    }
+    if (variant == LH_VARIANT_QUAD) {
+        /* one ray per quad of lanes (lh_quad.hip); scenes without the child-major nodes take the default walk */
+        if (sc->use_qnodes == 2 && sc->q4tnodes) {
+            int of = 0;
+            const int rc = lh_launch_trace_quad(sc, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded, d_counters,
+                                                d_workq, grid_blocks, min_active, tri_batch, &of, stream);
+            if (rc != 0) return rc;
+            if (of)
+                hipLaunchKernelGGL(k_overflow_fix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, *sc, n, d_org, d_dir,
+                                   d_prim, d_t, d_u, d_v, d_occluded, anyhit, d_counters);
+            if (sc->ref_nodes)
+                hipLaunchKernelGGL(k_ref_retrace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, *sc, n, d_org, d_dir,
+                                   d_prim, d_t, d_u, d_v, d_occluded, anyhit, d_counters);
+            return hipGetLastError() == hipSuccess ? 0 : -1;
+        }
+        variant = LH_VARIANT_SPEC;
     }
     bool over_fix = false;
     if ((variant == LH_VARIANT_SPEC || variant == LH_VARIANT_UNIFIED4) && scl.use_qnodes == 2) {

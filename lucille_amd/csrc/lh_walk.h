@@ -106,12 +106,10 @@ __device__ __forceinline__ bool slab_w(const Lane &L, uint32_t wx, uint32_t wy, 
  * Rejected: nothing.  Certain hit: ends an any-hit ray at once, shrinks the closest-hit culling bound.
  * Anything not rejected joins the pending list (resolved in fp64 now if the list is full).
  * Returns true when the ray is finished (any-hit only). */
-template <bool ANYHIT, bool COUNT>
-__device__ __forceinline__ bool tri_step(Lane &L, const lh_dev_scene_t &sc, float v0x, float v0y, float v0z,
-                                         float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
-                                         float ne1, float ne2, uint32_t prim,
-                                         double ox, double oy, double oz, double dx, double dy, double dz,
-                                         Best &best, uint32_t &c_exact)
+template <bool ANYHIT, bool COUNT, class RayLoad>
+__device__ __forceinline__ bool tri_step_g(Lane &L, const lh_dev_scene_t &sc, float v0x, float v0y, float v0z,
+                                           float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
+                                           float ne1, float ne2, uint32_t prim, RayLoad ray, Best &best, uint32_t &c_exact)
 {
     float t_hi;
     const int cls = lh_tri_filter(&L.r, v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, ne1, ne2, L.tb, &t_hi);
@@ -122,6 +120,8 @@ __device__ __forceinline__ bool tri_step(Lane &L, const lh_dev_scene_t &sc, floa
     if (L.np == kPend) {
         /* pending list full: resolve it now (rare) */
         if (COUNT) c_exact += kPend;
+        double ox, oy, oz, dx, dy, dz;
+        ray(ox, oy, oz, dx, dy, dz);
         resolve(sc, L.p0, ox, oy, oz, dx, dy, dz, best);
         resolve(sc, L.p1, ox, oy, oz, dx, dy, dz, best);
         resolve(sc, L.p2, ox, oy, oz, dx, dy, dz, best);
@@ -131,6 +131,35 @@ __device__ __forceinline__ bool tri_step(Lane &L, const lh_dev_scene_t &sc, floa
     }
     L.p3 = L.p2; L.p2 = L.p1; L.p1 = L.p0; L.p0 = prim; L.np++;
     return false;
+}
+
+/* the same with the fp64 ray held in registers (the lane walks) */
+template <bool ANYHIT, bool COUNT>
+__device__ __forceinline__ bool tri_step(Lane &L, const lh_dev_scene_t &sc, float v0x, float v0y, float v0z,
+                                         float e1x, float e1y, float e1z, float e2x, float e2y, float e2z,
+                                         float ne1, float ne2, uint32_t prim,
+                                         double ox, double oy, double oz, double dx, double dy, double dz,
+                                         Best &best, uint32_t &c_exact)
+{
+    return tri_step_g<ANYHIT, COUNT>(L, sc, v0x, v0y, v0z, e1x, e1y, e1z, e2x, e2y, e2z, ne1, ne2, prim,
+                                     [=](double &a, double &b, double &c, double &d, double &e, double &f) { a = ox; b = oy; c = oz; d = dx; e = dy; f = dz; },
+                                     best, c_exact);
+}
+
+/* the end of a ray's walk: its unresolved candidates through the fp64 test (bvh.c:730-791 order) */
+template <bool ANYHIT, bool COUNT>
+__device__ __forceinline__ void finish(Lane &L, const lh_dev_scene_t &sc,
+                                       double ox, double oy, double oz,
+                                       double dx, double dy, double dz, Best &best,
+                                       uint32_t &c_exact)
+{
+    if (ANYHIT && (L.certain || best.prim != LH_MISS_PRIM)) return;
+    if (COUNT) c_exact += (uint32_t)L.np;
+    if (L.np > 0) resolve(sc, L.p0, ox, oy, oz, dx, dy, dz, best);
+    if (L.np > 1) resolve(sc, L.p1, ox, oy, oz, dx, dy, dz, best);
+    if (L.np > 2) resolve(sc, L.p2, ox, oy, oz, dx, dy, dz, best);
+    if (L.np > 3) resolve(sc, L.p3, ox, oy, oz, dx, dy, dz, best);
+    L.np = 0;
 }
 
 #endif

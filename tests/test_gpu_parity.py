@@ -6,12 +6,13 @@ import numpy as np
 import pytest
 
 import lucille_amd as la
+from lucille_amd import scenes
 from oracle import pyoracle as po
 from tests.helpers import Model, assert_hits_equal, grid_mesh, load_golden, random_rays
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [la.VARIANT_DIRECT, la.VARIANT_PERSIST_WAVE, la.VARIANT_PERSIST_LANE, la.VARIANT_UNIFIED, la.VARIANT_SPEC, la.VARIANT_UNIFIED4, la.VARIANT_LEAN]
+VARIANTS = [la.VARIANT_DIRECT, la.VARIANT_PERSIST_WAVE, la.VARIANT_PERSIST_LANE, la.VARIANT_UNIFIED, la.VARIANT_SPEC, la.VARIANT_UNIFIED4, la.VARIANT_LEAN, la.VARIANT_QUAD]
 
 
 def torch_rays(org, dr):
@@ -365,3 +366,20 @@ def test_scaled_translated_degenerate_scenes(kind, log_scale, off):
     for variant in VARIANTS:
         assert_hits_equal(gpu_closest(acc, org, dr, variant), exp, "%s 1e%d v%d" % (kind, log_scale, variant))
     assert np.array_equal(gpu_any(acc, org, dr, la.VARIANT_DEFAULT).astype(bool), exp[0] != po.MISS)
+
+
+def test_triangle_prefetch_walk_equals_default():
+    """set_param("tri_prefetch", 1): the 4-wide walk with a parked leaf's triangle requested one step ahead (A/B, opt-in)"""
+    import torch
+    P, idx, st = scenes.soup_triangles(300000, 0.008)
+    ho, hd, _ = scenes.soup_rays(1500000, st)
+    o = torch.from_numpy(ho).cuda(); d = torch.from_numpy(hd).cuda()
+    acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit()
+    ref_c = [x.clone() for x in acc.intersect_device(o, d)]; ref_a = acc.intersect_device(o, d, mode=la.MODE_ANY)[0].clone()
+    acc.set_param("tri_prefetch", 1)
+    for tb in (1, 8, 32):
+        acc.set_param("tri_batch", tb)
+        got = acc.intersect_device(o, d)
+        assert all(torch.equal(a, b) for a, b in zip(got, ref_c)), tb
+        assert torch.equal(acc.intersect_device(o, d, mode=la.MODE_ANY)[0], ref_a), tb
+    acc.close()

@@ -5,7 +5,8 @@
 //   mode 3: one chain per PAIR of lanes, 2 x dwordx4 per lane (64-byte nodes)
 //   mode 4: one chain per lane, 1 x dwordx4 (16-byte nodes)
 // Each step's next index comes from the loaded data (dependent chain, like traversal).
-// Usage: gather <array MB> <steps> <blocks> <mode...>
+// Usage: gather <array MB> <steps> <blocks> <mode...>     (GATHER_LDS=<bytes>: dynamic LDS per 256-thread block, to cap
+//        the resident blocks per CU at 160 KB / bytes -- the traversal kernel's LDS stack allows 3)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -132,21 +133,23 @@ int main(int argc, char **argv)
     CHK(hipMalloc(&d, h.size() * 4)); CHK(hipMalloc(&out, (size_t)blocks * 256 * 4));
     CHK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    const size_t lds = getenv("GATHER_LDS") ? (size_t)atol(getenv("GATHER_LDS")) : 0;
+    if (lds) printf("dynamic LDS %zu bytes per block: at most %zu blocks (%zu waves per SIMD) per CU\n", lds, (size_t)(160 * 1024) / lds, (size_t)(160 * 1024) / lds);
     for (int a = 4; a < argc; a++) {
         const int mode = atoi(argv[a]);
         float best = 1e30f;
         for (int rep = 0; rep < 4; rep++) {
             CHK(hipEventRecord(e0));
             switch (mode) {
-            case 0: hipLaunchKernelGGL(k_gather<0>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
-            case 1: hipLaunchKernelGGL(k_gather<1>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
-            case 2: hipLaunchKernelGGL(k_gather<2>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
-            case 3: hipLaunchKernelGGL(k_gather<3>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
-            case 5: hipLaunchKernelGGL(k_gather<5>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
-            case 6: hipLaunchKernelGGL(k_gather<6>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
-            case 8: hipLaunchKernelGGL(k_gather<8>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
-            case 7: hipLaunchKernelGGL(k_gather<7>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
-            default: hipLaunchKernelGGL(k_gather<4>, dim3(blocks), dim3(256), 0, 0, d, nnodes, steps, out); break;
+            case 0: hipLaunchKernelGGL(k_gather<0>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            case 1: hipLaunchKernelGGL(k_gather<1>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            case 2: hipLaunchKernelGGL(k_gather<2>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            case 3: hipLaunchKernelGGL(k_gather<3>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            case 5: hipLaunchKernelGGL(k_gather<5>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            case 6: hipLaunchKernelGGL(k_gather<6>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            case 8: hipLaunchKernelGGL(k_gather<8>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            case 7: hipLaunchKernelGGL(k_gather<7>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            default: hipLaunchKernelGGL(k_gather<4>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
             }
             CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
             float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if (rep > 0 && ms < best) best = ms;
