@@ -408,7 +408,18 @@ def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
     ns = min(n, 4_000_000)
     cnt_out, cnt = acc.intersect_device(d_org[:ns], d_dir[:ns], counters=True)
     n_nodes = cnt["nodes"] / ns; n_tris = cnt["tris"] / ns
-    b_ray = B_IN + B_OUT + B_NODE[node_fmt] * n_nodes + B_TRI * n_tris
+    node_bytes = acc.dump_node_bytes()              # 128: the 8-wide nodes (hot set beyond the Infinity Cache), else the 4-wide node's 64
+    if node_bytes == 128:
+        node_fmt = "q16x8"
+    b_ray = B_IN + B_OUT + node_bytes * n_nodes + B_TRI * n_tris
+    # the same sample through the 4-wide walk: hit records do not depend on the tree
+    cross = None
+    if node_bytes == 128:
+        acc.set_param("wide8", 0)
+        alt = acc.intersect_device(d_org[:ns], d_dir[:ns]); torch.cuda.synchronize(dev)
+        cross = all(torch.equal(a, b) for a, b in zip(alt, cnt_out))
+        acc.set_param("wide8", -1)
+        del alt
     steps = 3
     evp = EventPairs(hip, steps)
     acc.intersect_device(d_org, d_dir, out=out); torch.cuda.synchronize(dev)
@@ -428,16 +439,21 @@ def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
                 traffic = j.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    info = acc.info()
     hot = info["nnodes_traversal"] * 64 + info["ntriangles"] * 48
     acc.close()
     return {"workload": "S-soup-10M ray dump: %d random triangles (half-extent 0.002), %d incoherent rays, closest-hit" % (args.hbm_tris, n),
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": traffic, "residency": "hot set %.0f MB (4-wide nodes + tri32) >> 256 MiB Infinity Cache: HBM" % (hot / 1e6),
+            "traffic": traffic, "residency": "hot set %.0f MB as 4-wide nodes + tri32 >> 256 MiB Infinity Cache: HBM" % (hot / 1e6),
+            "kernel": "k_trace_persist_lane<walk=spec8, q16x8 nodes: 128-byte 8-wide records, one cache line each>" if node_bytes == 128
+                      else "k_trace_persist_lane<walk=spec,%s nodes>" % node_fmt,
+            "node_bytes": node_bytes,
             "value": round(n / (ms * 1e-3) / 1e6, 1), "value_unit": "Mrays/s", "kernel_ms": round(ms, 3),
             "bytes_per_ray": round(b_ray, 1), "nodes_per_ray": round(n_nodes, 3), "tris_per_ray": round(n_tris, 3),
             "hit_rate": round(hit, 4), "device_bytes": info["device_bytes"],
             "build_s": round(info["build_seconds"], 3), "ref_tree_build_s": round(info["ref_build_seconds"], 3),
-            "validation": {"timed_equals_counted_launch": bool(ok), "ok": bool(ok) and 0.5 < hit < 0.999}}
+            "validation": {"timed_equals_counted_launch": bool(ok), "equals_4wide_walk_on_sample": cross,
+                           "ok": bool(ok) and cross is not False and 0.5 < hit < 0.999}}
 
 
 def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):

@@ -122,6 +122,10 @@ int  lh_accel_intersect_device_counted(lh_accel_t *accel, size_t n, const void *
 /* rays of the last counted launch that were finished outside the main kernel: the reference-order walk (exact-t ties,
  * fragile hits) and the private-stack walk for rays whose LDS stack column would have overflowed */
 uint64_t lh_accel_last_retraced(const lh_accel_t *accel);
+/* bytes of the node record the ray-dump entry points (lh_accel_intersect_host / _device) walk on this scene: 64 (4-wide
+ * 16-bit-grid node), or 128 (8-wide, one cache line) when the scene's hot set does not fit the 256 MiB Infinity Cache --
+ * there every record fetched costs a 128-byte line of HBM traffic.  lh_accel_set_param("wide8", -1 auto / 0 / 1). */
+int lh_accel_dump_node_bytes(const lh_accel_t *accel);
 
 /* ---- traversal statistics: ri_bvh_clear_stat_traversal / ri_bvh_report_stat_traversal ----
  * reference: src/render/bvh.c:669-706 (globals filled under -DRI_BVH_TRACE_STATISTICS,

@@ -96,7 +96,7 @@ class TileStats(C.Structure):
 ABI_SYMBOLS = [
     "lh_device_count", "lh_last_error", "lh_accel_create", "lh_accel_add_mesh", "lh_accel_commit", "lh_accel_wait_exact",
     "lh_accel_destroy", "lh_accel_info", "lh_accel_prim_lookup", "lh_accel_intersect1",
-    "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted", "lh_accel_last_retraced",
+    "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted", "lh_accel_last_retraced", "lh_accel_dump_node_bytes",
     "lh_accel_set_grid", "lh_accel_set_param", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
     "lh_render_ao_tile", "lh_render_ao_tile_host", "lh_render_ao_bands", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device", "lh_render_pt_tile",
     "lh_accel_trace_statistics", "lh_accel_statistics",
@@ -143,6 +143,7 @@ def lib():
     L.lh_accel_intersect_host.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32]
     L.lh_accel_intersect_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     L.lh_accel_last_retraced.argtypes = [vp]; L.lh_accel_last_retraced.restype = C.c_uint64
+    L.lh_accel_dump_node_bytes.argtypes = [vp]
     L.lh_accel_intersect_device_counted.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, i32, i32,
                                                     C.POINTER(C.c_uint64)]
     L.lh_accel_set_grid.argtypes = [vp, i32]
@@ -354,6 +355,10 @@ class HipAccel:
                                                 _dptr(v), _dptr(occ), mode, variant, C.c_void_p(stream)),
                "lh_accel_intersect_device")
         return out
+
+    def dump_node_bytes(self):
+        """64: ray dumps walk the 4-wide nodes; 128: the 8-wide nodes (scene larger than the Infinity Cache, or wide8 = 1)"""
+        return int(self.L.lh_accel_dump_node_bytes(self.h))
 
     def beam_visibility(self, org, corner_dirs):
         """ri_beam_set + ri_bvh_intersect_beam_visibility for n beams: org [n,3], corner_dirs [n,4,3]

@@ -92,7 +92,8 @@ struct lh_accel {
     void *d_ref_lca, *d_prim_leafpos, *d_ref_nodes, *d_ref_leaf_prims;
     /* device */
     lh_dev_scene_t dev;
-    void *d_nodes, *d_tri32, *d_tri64, *d_qnodes, *d_q4nodes, *d_q4tnodes, *d_c8nodes, *d_tri32_c8;
+    void *d_nodes, *d_tri32, *d_tri64, *d_qnodes, *d_q4nodes, *d_q4tnodes, *d_q8nodes, *d_c8nodes, *d_tri32_c8;
+    int wide8;                         /* ray dumps walk the 8-wide nodes: -1 when the hot set exceeds the Infinity Cache (default), 0 never, 1 always */
     int quad_grid;                     /* workgroups of the quad-per-ray walk (variant 7) */
     unsigned long long *d_cursor, *d_counters;   /* d_cursor: LH_NCURSOR slots, one per launch in flight */
     unsigned cursor_next;
@@ -171,6 +172,8 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     }
     a->default_variant = LH_VARIANT_SPEC;
     a->ao_fused = 1;
+    a->wide8 = -1;
+    { const char *e = getenv("LH_WIDE8"); if (e) a->wide8 = atoi(e); }
     { const char *e = getenv("LH_AO_FUSED"); if (e) a->ao_fused = atoi(e) != 0; }
     const char *env = getenv("LH_VARIANT");
     if (env) a->default_variant = atoi(env);
@@ -286,7 +289,8 @@ static void release_device(lh_accel_t *a)
     a->d_qnodes = NULL;
     if (a->d_q4nodes) (void)hipFree(a->d_q4nodes);
     if (a->d_q4tnodes) (void)hipFree(a->d_q4tnodes);
-    a->d_q4nodes = a->d_q4tnodes = NULL; a->dev.q4tnodes = NULL;
+    if (a->d_q8nodes) (void)hipFree(a->d_q8nodes);
+    a->d_q4nodes = a->d_q4tnodes = a->d_q8nodes = NULL; a->dev.q4tnodes = NULL; a->dev.q8nodes = NULL;
     if (a->d_c8nodes) (void)hipFree(a->d_c8nodes);
     if (a->d_tri32_c8) (void)hipFree(a->d_tri32_c8);
     a->d_c8nodes = a->d_tri32_c8 = NULL;
@@ -445,7 +449,7 @@ static int host_build(lh_accel_t *a, int build_threads, bool on_device, bool kee
 
 /* node formats a walk can read; only the one the default kernel uses is uploaded at commit, the
  * others (A/B variants, the deep-tree fallback) on first use */
-enum { LH_FMT_F32 = 1, LH_FMT_Q16 = 2, LH_FMT_Q16X4 = 4, LH_FMT_C8 = 8, LH_FMT_Q4T = 16 };
+enum { LH_FMT_F32 = 1, LH_FMT_Q16 = 2, LH_FMT_Q16X4 = 4, LH_FMT_C8 = 8, LH_FMT_Q4T = 16, LH_FMT_Q8 = 32 };
 extern "C" int lh_trace_formats_needed(const lh_dev_scene_t *sc, int variant);      /* lh_kernels.hip */
 extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q4nodes, uint32_t *nq4, uint32_t *q4_depth,
                                void **d_tri32, float bmin[3], float bmax[3], float grid_lo[3], float grid_step[3],
@@ -474,6 +478,18 @@ static int ensure_formats(lh_accel_t *a, int mask)
         if (e && atoi(e) > 0) a->quad_grid = atoi(e);
     }
     mask &= ~LH_FMT_Q4T;
+    if ((mask & LH_FMT_Q8) && !a->d_q8nodes && !a->hs->device_built) {
+        /* the 8-wide 16-bit-grid nodes for ray dumps over scenes larger than the Infinity Cache: built on first use */
+        pthread_mutex_lock(&g_scene_mu);
+        const int rc8 = lh_bvh_ensure_q8(&a->hs->bvh);
+        pthread_mutex_unlock(&g_scene_mu);
+        if (rc8 != 0) return fail("building the 8-wide tree failed (out of memory)");
+        const size_t q8b = sizeof(lh_q8node_t) * (size_t)b->nq8nodes;
+        HIPCHK(hipMalloc(&a->d_q8nodes, q8b));
+        HIPCHK(hipMemcpy(a->d_q8nodes, b->q8nodes, q8b, hipMemcpyHostToDevice));
+        a->dev.q8nodes = a->d_q8nodes; a->dev.nq8nodes = b->nq8nodes; a->dev.q8_depth = b->q8_depth; a->device_bytes += q8b;
+    }
+    mask &= ~LH_FMT_Q8;
     if (a->hs->device_built) {
         if (mask & ~LH_FMT_Q16X4) return fail("this scene's tree was built on the device: only the 4-wide walks are available (variants 4, 6 and 7)");
         return 0;
@@ -502,10 +518,14 @@ static int ensure_formats(lh_accel_t *a, int mask)
         pthread_mutex_unlock(&g_scene_mu);
         if (rc8 != 0) return fail("building the 8-wide compressed tree failed (out of memory)");
         a->dev.nc8nodes = b->nc8nodes; a->dev.c8_depth = b->c8_depth;
-        const size_t c8b = sizeof(lh_c8node_t) * (size_t)b->nc8nodes, t32 = sizeof(lh_tri32_t) * (size_t)b->ntris;
-        HIPCHK(hipMalloc(&a->d_c8nodes, c8b + 64));
+        const char *es = getenv("LH_C8_STRIDE");
+        const size_t stride = (es && atoi(es) == 128) ? 128 : sizeof(lh_c8node_t);
+        const size_t c8b = stride * (size_t)b->nc8nodes, t32 = sizeof(lh_tri32_t) * (size_t)b->ntris;
+        a->dev.c8_stride = (uint32_t)stride;
+        HIPCHK(hipMalloc(&a->d_c8nodes, c8b + 128));
         HIPCHK(hipMalloc(&a->d_tri32_c8, t32 + 64));
-        HIPCHK(hipMemcpy(a->d_c8nodes, b->c8nodes, c8b, hipMemcpyHostToDevice));
+        if (stride == sizeof(lh_c8node_t)) { HIPCHK(hipMemcpy(a->d_c8nodes, b->c8nodes, c8b, hipMemcpyHostToDevice)); }
+        else HIPCHK(hipMemcpy2D(a->d_c8nodes, stride, b->c8nodes, sizeof(lh_c8node_t), sizeof(lh_c8node_t), b->nc8nodes, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(a->d_tri32_c8, b->tri32_c8, t32, hipMemcpyHostToDevice));
         a->dev.c8nodes = a->d_c8nodes; a->dev.tri32_c8 = a->d_tri32_c8; a->device_bytes += c8b + t32;
     }
@@ -813,6 +833,7 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
     else if (!strcmp(name, "ray_chunk") && value > 0 && value <= (1 << 20)) { a->ray_chunk = (uint32_t)value; a->dev.ray_chunk = (uint32_t)value; }
     else if (!strcmp(name, "variant") && value >= 0 && value <= LH_VARIANT_QUAD) a->default_variant = value;
     else if (!strcmp(name, "ao_fused")) a->ao_fused = value != 0;
+    else if (!strcmp(name, "wide8") && value >= -1 && value <= 1) a->wide8 = value;
     else if (!strcmp(name, "quad_grid") && value > 0) a->quad_grid = value;
     else if (!strcmp(name, "tri_prefetch")) a->dev.tri_prefetch = value != 0;
     else if (!strcmp(name, "stack_cap") && (value == 0 || (value >= 8 && value <= 64 && value % 2 == 0))) a->dev.stack_cap = (uint32_t)value;
@@ -868,9 +889,16 @@ static int t2_slot(lh_accel_t *a, hipStream_t s, bool need_spill)
     return k;
 }
 
+/* hot set of a ray dump (4-wide nodes + 48-byte triangle records) against the Infinity Cache */
+static bool wide8_pays(const lh_accel_t *a)
+{
+    const lh_bvh_t *b = &a->hs->bvh;
+    return sizeof(lh_q4node_t) * (size_t)b->nq4nodes + sizeof(lh_tri32_t) * (size_t)b->ntris > ((size_t)256 << 20);
+}
+
 static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, void *d_prim,
                   void *d_t, void *d_u, void *d_v, void *d_occ, int mode, int variant,
-                  unsigned long long *d_counters, hipStream_t s)
+                  unsigned long long *d_counters, hipStream_t s, bool dump = false)
 {
     if (!a || !a->committed) return fail("intersect: accel not committed");
     if (n == 0) return 0;
@@ -907,6 +935,15 @@ static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
         }
     }
     if (ensure_formats(a, lh_trace_formats_needed(&a->dev, variant)) != 0) return -1;     /* A/B formats: uploaded on first use */
+    /* ray dumps (incoherent by assumption) over a scene whose hot set does not fit the 256 MiB Infinity Cache walk the 8-wide
+     * nodes: each record then costs a 128-byte line of HBM traffic whatever its size, and an 8-wide record uses all of it
+     * (S-soup-10M: 57 -> 40 records per ray).  The tile pipelines' coherent rays stay on the 4-wide nodes. */
+    a->dev.prefer_q8 = 0;
+    if (dump && variant == LH_VARIANT_SPEC && a->dev.use_qnodes == 2 && !a->hs->device_built && !a->dev.tri_prefetch &&
+        (a->wide8 == 1 || (a->wide8 == -1 && wide8_pays(a)))) {
+        if (ensure_formats(a, LH_FMT_Q8) != 0) return -1;
+        a->dev.prefer_q8 = 1;
+    }
     int rc = lh_launch_trace(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim,
                              (double *)d_t, (double *)d_u, (double *)d_v, mode == LH_MODE_ANY,
                              (uint8_t *)d_occ, d_counters, a->d_cursor + (a->cursor_next++ % LH_NCURSOR), variant, (variant == LH_VARIANT_QUAD && a->dev.q4tnodes) ? a->quad_grid : a->grid_blocks, a->min_active, a->tri_batch, (void *)s);
@@ -919,7 +956,7 @@ extern "C" int lh_accel_intersect_device(lh_accel_t *a, size_t n, const void *d_
                                          int mode, int variant, void *stream)
 {
     lh_guard guard(a);
-    return launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, variant, NULL, (hipStream_t)stream);
+    return launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, variant, NULL, (hipStream_t)stream, true);
 }
 
 extern "C" int lh_accel_intersect_device_counted(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
@@ -933,7 +970,7 @@ extern "C" int lh_accel_intersect_device_counted(lh_accel_t *a, size_t n, const 
     HIPCHK(hipMemsetAsync(a->d_counters, 0, sizeof(unsigned long long) * LH_CNT_DEV, a->stream));
     HIPCHK(hipDeviceSynchronize());
     if (a->hs->bvh.ntris == 0) { counters[0] = counters[1] = counters[2] = 0; counters[3] = n; }
-    int rc = launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, variant, a->d_counters, a->stream);
+    int rc = launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, variant, a->d_counters, a->stream, true);
     if (rc != 0) return rc;
     HIPCHK(hipStreamSynchronize(a->stream));
     if (a->hs->bvh.ntris) {
@@ -947,6 +984,16 @@ extern "C" int lh_accel_intersect_device_counted(lh_accel_t *a, size_t n, const 
                     h[LH_CNT_NODES], h[LH_CNT_NODE_SLOTS], h[LH_CNT_TRIS], h[LH_CNT_TRI_SLOTS], h[LH_CNT_REGROUP_SLOTS], h[LH_CNT_RETRACED]);
     }
     return 0;
+}
+
+/* bytes of the node record a ray dump walks on this scene: 128 when the 8-wide nodes are in use (hot set beyond the
+ * Infinity Cache, or "wide8" forced), else the default format's */
+extern "C" int lh_accel_dump_node_bytes(const lh_accel_t *a)
+{
+    if (!a || !a->committed || a->hs->bvh.ntris == 0) return 0;
+    if (a->default_variant == LH_VARIANT_SPEC && a->dev.use_qnodes == 2 && !a->hs->device_built && !a->dev.tri_prefetch &&
+        (a->wide8 == 1 || (a->wide8 == -1 && wide8_pays(a)))) return (int)sizeof(lh_q8node_t);
+    return a->dev.use_qnodes == 0 ? 64 : a->dev.use_qnodes == 1 ? 32 : a->dev.use_qnodes == 3 ? 80 : 64;
 }
 
 extern "C" uint64_t lh_accel_last_retraced(const lh_accel_t *a) { return a ? a->last_retraced : 0; }
@@ -1024,7 +1071,7 @@ static int intersect_host_pipelined(lh_accel_t *a, size_t n, const double *org, 
         HIPCHK(hipMemcpyAsync(di, hi, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(di + sizeof(double) * 3 * C, hi + sizeof(double) * 3 * C, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
         double *d_t = (double *)dout, *d_u = d_t + C, *d_v = d_u + C; uint32_t *d_prim = (uint32_t *)(d_v + C);
-        const int rc = launch(a, m, di, di + sizeof(double) * 3 * C, d_prim, d_t, d_u, d_v, (uint8_t *)dout, mode, LH_VARIANT_DEFAULT, NULL, s);
+        const int rc = launch(a, m, di, di + sizeof(double) * 3 * C, d_prim, d_t, d_u, d_v, (uint8_t *)dout, mode, LH_VARIANT_DEFAULT, NULL, s, true);
         if (rc != 0) return rc;
         char *ho = (char *)a->pipe.h_out[b];
         if (mode == LH_MODE_CLOSEST) {
@@ -1065,7 +1112,7 @@ extern "C" int lh_accel_intersect_host(lh_accel_t *a, size_t n, const double *or
     HIPCHK(hipMemcpyAsync(d_dir, dir, b_ray, hipMemcpyHostToDevice, a->stream));
     if (a->stat_on) HIPCHK(hipMemsetAsync(a->d_counters, 0, sizeof(unsigned long long) * LH_CNT_DEV, a->stream));
     int rc = launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, LH_VARIANT_DEFAULT,
-                    a->stat_on ? a->d_counters : NULL, a->stream);
+                    a->stat_on ? a->d_counters : NULL, a->stream, true);
     if (rc != 0) return rc;
     if (a->stat_on) {
         /* hits are counted from the device outputs whatever the caller asked to copy back */

@@ -351,23 +351,87 @@ static void quant_box(const lh_bvh_t *o, const float *lo, const float *hi, uint1
     }
 }
 
-static void build4(lh_bvh_t *o, uint32_t i2, uint32_t k4, uint32_t depth, uint32_t *next)
+/* Which binary nodes become 4-wide nodes.  A ray pays one record per 4-wide node whose box it enters, so the expected cost of
+ * a collapse is the sum of the surface areas of the binary nodes that are kept as 4-wide nodes (leaves are fixed by the
+ * binary build).  cost[n][k-1] = the cheapest way to hang subtree n into k free child slots of its 4-wide parent: either
+ * as one 4-wide node (area(n) + the best split of ITS four slots over its two children), or dissolved into its two
+ * children with the k slots split i : k - i.  (Ylitie et al. 2017 do the same for 8-wide nodes.)  The greedy rule used
+ * before -- open the child of largest area until four slots are full -- is what LH_COLLAPSE=greedy still selects. */
+typedef struct { double cost[8]; uint8_t split[8]; } dp4_t;      /* split[k-1]: 0 = a node of its own, i = left subtree gets i slots (widths 4 and 8) */
+
+static double dp_child(const dp4_t *dp, int32_t ref, int k) { return ref >= 0 ? dp[ref].cost[k - 1] : 0.0; }
+
+static int dp4_fill(const lh_bvh_t *o, dp4_t *dp, const int W)
+{
+    uint32_t ii;
+    for (ii = o->nnodes; ii-- > 0;) {              /* children sit behind their parent in the flat tree */
+        const lh_node_t *nd = &o->nodes[ii];
+        float lo[3], hi[3]; int k, i;
+        double g[9], area; uint8_t gi[9];
+        if ((nd->ref0 >= 0 && (uint32_t)nd->ref0 <= ii) || (nd->ref1 >= 0 && (uint32_t)nd->ref1 <= ii)) return -1;
+        for (k = 0; k < 3; k++) { lo[k] = nd->lo0[k]; hi[k] = nd->hi0[k]; }
+        if (nd->ref1 != LH_REF_EMPTY)
+            for (k = 0; k < 3; k++) { if (nd->lo1[k] < lo[k]) lo[k] = nd->lo1[k]; if (nd->hi1[k] > hi[k]) hi[k] = nd->hi1[k]; }
+        area = (double)area3(lo, hi);
+        if (nd->ref1 == LH_REF_EMPTY) {             /* a single child (one-leaf scenes): nothing to decide */
+            for (k = 1; k <= W; k++) { dp[ii].cost[k - 1] = area + dp_child(dp, nd->ref0, W); dp[ii].split[k - 1] = 0; }
+            continue;
+        }
+        for (k = 2; k <= W; k++) {
+            g[k] = 1e300; gi[k] = 1;
+            for (i = 1; i < k; i++) {
+                const double c = dp_child(dp, nd->ref0, i) + dp_child(dp, nd->ref1, k - i);
+                if (c < g[k]) { g[k] = c; gi[k] = (uint8_t)i; }
+            }
+        }
+        dp[ii].cost[0] = area + g[W];
+        for (k = 2; k <= W; k++) {
+            if (dp[ii].cost[0] <= g[k]) { dp[ii].cost[k - 1] = dp[ii].cost[0]; dp[ii].split[k - 1] = 0; }
+            else { dp[ii].cost[k - 1] = g[k]; dp[ii].split[k - 1] = gi[k]; }
+        }
+        /* the split of this node's own W slots, used when it IS a wide node */
+        dp[ii].split[0] = gi[W];
+    }
+    return 0;
+}
+
+/* children of a wide node: subtree `ref` (box lo/hi, as stored in its binary parent) into k slots */
+static void dp4_emit(const lh_bvh_t *o, const dp4_t *dp, const float *lo, const float *hi, int32_t ref, int k, child4_t *ch, int *n)
+{
+    if (ref >= 0 && k >= 2 && dp[ref].split[k - 1] != 0) {
+        const lh_node_t *g = &o->nodes[ref];
+        const int i = dp[ref].split[k - 1];
+        dp4_emit(o, dp, g->lo0, g->hi0, g->ref0, i, ch, n);
+        dp4_emit(o, dp, g->lo1, g->hi1, g->ref1, k - i, ch, n);
+        return;
+    }
+    ch[*n].lo = lo; ch[*n].hi = hi; ch[*n].ref = ref; (*n)++;
+}
+
+static void build4(lh_bvh_t *o, const dp4_t *dp, uint32_t i2, uint32_t k4, uint32_t depth, uint32_t *next)
 {
     child4_t ch[4]; int n = 2, c, k; uint32_t kid[4];
     const lh_node_t *nd = &o->nodes[i2];
-    ch[0].lo = nd->lo0; ch[0].hi = nd->hi0; ch[0].ref = nd->ref0;
-    ch[1].lo = nd->lo1; ch[1].hi = nd->hi1; ch[1].ref = nd->ref1;
-    if (ch[1].ref == LH_REF_EMPTY) n = 1;
-    while (n < 4) {
-        int best = -1; float ba = -1.0f;
-        for (c = 0; c < n; c++)
-            if (ch[c].ref >= 0) { float a = area3(ch[c].lo, ch[c].hi); if (a > ba) { ba = a; best = c; } }
-        if (best < 0) break;
-        {
-            const lh_node_t *g = &o->nodes[ch[best].ref];
-            ch[best].lo = g->lo0; ch[best].hi = g->hi0; ch[best].ref = g->ref0;
-            ch[n].lo = g->lo1; ch[n].hi = g->hi1; ch[n].ref = g->ref1;
-            n++;
+    if (dp && nd->ref1 != LH_REF_EMPTY) {
+        const int i = dp[i2].split[0];
+        n = 0;
+        dp4_emit(o, dp, nd->lo0, nd->hi0, nd->ref0, i, ch, &n);
+        dp4_emit(o, dp, nd->lo1, nd->hi1, nd->ref1, 4 - i, ch, &n);
+    } else {
+        ch[0].lo = nd->lo0; ch[0].hi = nd->hi0; ch[0].ref = nd->ref0;
+        ch[1].lo = nd->lo1; ch[1].hi = nd->hi1; ch[1].ref = nd->ref1;
+        if (ch[1].ref == LH_REF_EMPTY) n = 1;
+        while (n < 4) {
+            int best = -1; float ba = -1.0f;
+            for (c = 0; c < n; c++)
+                if (ch[c].ref >= 0) { float a = area3(ch[c].lo, ch[c].hi); if (a > ba) { ba = a; best = c; } }
+            if (best < 0) break;
+            {
+                const lh_node_t *g = &o->nodes[ch[best].ref];
+                ch[best].lo = g->lo0; ch[best].hi = g->hi0; ch[best].ref = g->ref0;
+                ch[n].lo = g->lo1; ch[n].hi = g->hi1; ch[n].ref = g->ref1;
+                n++;
+            }
         }
     }
     if (depth + 1 > o->q4_depth) o->q4_depth = depth + 1;
@@ -386,17 +450,95 @@ static void build4(lh_bvh_t *o, uint32_t i2, uint32_t k4, uint32_t depth, uint32
             }
         }
     }
-    for (c = 0; c < n; c++) if (ch[c].ref >= 0) build4(o, (uint32_t)ch[c].ref, kid[c], depth + 1, next);
+    for (c = 0; c < n; c++) if (ch[c].ref >= 0) build4(o, dp, (uint32_t)ch[c].ref, kid[c], depth + 1, next);
 }
 
 static int collapse4(lh_bvh_t *o)
 {
     uint32_t next = 1;
+    dp4_t *dp = NULL;
+    const char *e = getenv("LH_COLLAPSE");
     o->q4nodes = (lh_q4node_t *)calloc(o->nnodes ? o->nnodes : 1, sizeof(lh_q4node_t));   /* <= nnodes records */
     if (!o->q4nodes) return -1;
+    if (!(e && !strcmp(e, "greedy")) && o->nnodes) {
+        dp = (dp4_t *)malloc(sizeof(dp4_t) * (size_t)o->nnodes);
+        if (!dp) return -1;
+        if (dp4_fill(o, dp, 4) != 0) { free(dp); dp = NULL; }      /* not a parent-first order: the greedy rule */
+    }
     o->q4_depth = 0;
-    build4(o, 0, 0, 0, &next);
+    build4(o, dp, 0, 0, 0, &next);
     o->nq4nodes = next;
+    free(dp);
+    return 0;
+}
+
+/* ---- 8-wide collapse onto the 16-bit grid (see lh_q8node_t): one 128-byte record = one cache line -------------- */
+static void build8q(lh_bvh_t *o, const dp4_t *dp, uint32_t i2, uint32_t k8, uint32_t depth, uint32_t *next)
+{
+    child4_t ch[8]; int n = 0, c, k, s; uint32_t kid[8]; int slot_of[8], used[8];
+    const lh_node_t *nd = &o->nodes[i2];
+    float nlo[3], nhi[3]; double cen[3];
+    lh_q8node_t *q = &o->q8nodes[k8];
+    if (nd->ref1 != LH_REF_EMPTY) {
+        const int i = dp[i2].split[0];
+        dp4_emit(o, dp, nd->lo0, nd->hi0, nd->ref0, i, ch, &n);
+        dp4_emit(o, dp, nd->lo1, nd->hi1, nd->ref1, 8 - i, ch, &n);
+    } else { ch[0].lo = nd->lo0; ch[0].hi = nd->hi0; ch[0].ref = nd->ref0; n = 1; }
+    if (depth + 1 > o->q8_depth) o->q8_depth = depth + 1;
+    for (k = 0; k < 3; k++) {
+        nlo[k] = ch[0].lo[k]; nhi[k] = ch[0].hi[k];
+        for (c = 1; c < n; c++) { if (ch[c].lo[k] < nlo[k]) nlo[k] = ch[c].lo[k]; if (ch[c].hi[k] > nhi[k]) nhi[k] = ch[c].hi[k]; }
+        cen[k] = 0.5 * ((double)nlo[k] + (double)nhi[k]);
+    }
+    /* octant slots (as for the compressed 8-wide node): the walk visits slot s with priority s ^ (ray octant), so a child
+     * goes to the free slot whose diagonal its centroid offset points along most */
+    for (s = 0; s < 8; s++) used[s] = 0;
+    for (c = 0; c < n; c++) slot_of[c] = -1;
+    for (k = 0; k < n; k++) {
+        int bc = -1, bs = -1; double bv = -1.0e300;
+        for (c = 0; c < n; c++) {
+            double d[3]; int a;
+            if (slot_of[c] >= 0) continue;
+            for (a = 0; a < 3; a++) d[a] = 0.5 * ((double)ch[c].lo[a] + (double)ch[c].hi[a]) - cen[a];
+            for (s = 0; s < 8; s++) {
+                double v;
+                if (used[s]) continue;
+                v = ((s & 1) ? d[0] : -d[0]) + ((s & 2) ? d[1] : -d[1]) + ((s & 4) ? d[2] : -d[2]);
+                if (v > bv) { bv = v; bc = c; bs = s; }
+            }
+        }
+        slot_of[bc] = bs; used[bs] = 1;
+    }
+    for (s = 0; s < 8; s++) { for (k = 0; k < 3; k++) q->w[s][k] = 65535u; q->ref[s] = LH_REF_EMPTY; }     /* lo = 65535, hi = 0: inverted */
+    for (s = 0; s < 8; s++)                       /* inner children adjacent, in slot order */
+        for (c = 0; c < n; c++)
+            if (slot_of[c] == s) {
+                uint16_t qb[6];
+                quant_box(o, ch[c].lo, ch[c].hi, qb);
+                for (k = 0; k < 3; k++) q->w[s][k] = (uint32_t)qb[k] | ((uint32_t)qb[3 + k] << 16);
+                if (ch[c].ref >= 0) { kid[c] = (*next)++; q->ref[s] = (int32_t)kid[c]; } else q->ref[s] = ch[c].ref;
+            }
+    for (c = 0; c < n; c++) if (ch[c].ref >= 0) build8q(o, dp, (uint32_t)ch[c].ref, kid[c], depth + 1, next);
+}
+
+/* built the first time a large scene's ray dump asks for it (not thread-safe: callers lock); needs the binary nodes */
+int lh_bvh_ensure_q8(lh_bvh_t *o)
+{
+    uint32_t next = 1;
+    dp4_t *dp;
+    if (o->q8nodes || o->ntris == 0) return 0;
+    if (!o->nodes) return -1;
+    o->q8nodes = (lh_q8node_t *)calloc(o->nnodes ? o->nnodes : 1, sizeof(lh_q8node_t));
+    dp = (dp4_t *)malloc(sizeof(dp4_t) * (size_t)(o->nnodes ? o->nnodes : 1));
+    if (!o->q8nodes || !dp || dp4_fill(o, dp, 8) != 0) { free(dp); free(o->q8nodes); o->q8nodes = NULL; return -1; }
+    o->q8_depth = 0;
+    build8q(o, dp, 0, 0, 0, &next);
+    o->nq8nodes = next;
+    free(dp);
+    {
+        lh_q8node_t *sh = (lh_q8node_t *)realloc(o->q8nodes, sizeof(lh_q8node_t) * (size_t)next);
+        if (sh) o->q8nodes = sh;
+    }
     return 0;
 }
 
@@ -695,6 +837,6 @@ int lh_bvh_ensure_c8(lh_bvh_t *bvh)
 
 void lh_bvh_release(lh_bvh_t *bvh)
 {
-    free(bvh->nodes); free(bvh->qnodes); free(bvh->q4nodes); free(bvh->c8nodes); free(bvh->tri32_c8); free(bvh->tri32); free(bvh->tri64); free(bvh->prim_geom); free(bvh->prim_index);
+    free(bvh->nodes); free(bvh->qnodes); free(bvh->q4nodes); free(bvh->q8nodes); free(bvh->c8nodes); free(bvh->tri32_c8); free(bvh->tri32); free(bvh->tri64); free(bvh->prim_geom); free(bvh->prim_index);
     memset(bvh, 0, sizeof(*bvh));
 }

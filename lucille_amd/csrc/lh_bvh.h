@@ -93,6 +93,12 @@ typedef struct lh_c8node {
     uint8_t  qhi[3][8];
 } lh_c8node_t;
 
+/* 8-wide node on the scene's 16-bit grid: 128 bytes = one cache line decides eight children.  Slot s holds the child the
+ * walk visits with priority s ^ (ray octant); w[s][axis] = lo | hi << 16 as in lh_q4node_t; ref as in lh_q4node_t (the
+ * same leaves, the same tri32 order).  Empty slots: inverted box, LH_REF_EMPTY.  Used for ray dumps over scenes that do
+ * not fit the Infinity Cache, where every record fetched costs a whole 128-byte line of HBM traffic. */
+typedef struct { uint32_t w[8][3]; int32_t ref[8]; } lh_q8node_t;
+
 typedef struct lh_bvh {
     uint32_t    ntris;
     uint32_t    nnodes;
@@ -110,6 +116,8 @@ typedef struct lh_bvh {
     lh_c8node_t *c8nodes;          /* nc8nodes: 8-wide collapse of the same tree (lh_c8node_t) */
     lh_tri32_t  *tri32_c8;         /* ntris, in the 8-wide tree's leaf order */
     uint32_t    nc8nodes, c8_depth;
+    lh_q8node_t *q8nodes;          /* nq8nodes: 8-wide collapse on the 16-bit grid, or NULL (lh_bvh_ensure_q8) */
+    uint32_t    nq8nodes, q8_depth;
     float       grid_lo[3], grid_step[3];   /* quantisation grid of qnodes   */
     double      build_seconds;
 } lh_bvh_t;
@@ -126,6 +134,7 @@ typedef struct lh_mesh_view {
 int  lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes,
                   int nthreads);
 int  lh_bvh_flatten(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes);   /* primitives only, no tree */
+int  lh_bvh_ensure_q8(lh_bvh_t *bvh);      /* builds q8nodes on first use; 0 / -1 */
 int  lh_bvh_ensure_c8(lh_bvh_t *bvh);      /* builds c8nodes / tri32_c8 on first use; 0 / -1 */
 void lh_bvh_release(lh_bvh_t *bvh);
 

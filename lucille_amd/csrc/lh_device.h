@@ -21,11 +21,15 @@ typedef struct lh_dev_scene {
     float       grid_lo[3], grid_step[3];
     int         use_qnodes;   /* 0: fp32 2-wide, 1: 16-bit grid 2-wide, 2: 16-bit grid 4-wide, 3: 8-wide compressed */
     const void *q4nodes;      /* lh_q4node_t[nq4nodes] (64 B each)                          */
+    const void *q8nodes;      /* lh_q8node_t[nq8nodes] (128 B each), or NULL                       */
+    uint32_t    nq8nodes, q8_depth;
+    int         prefer_q8;    /* this launch walks the 8-wide nodes (ray dumps over scenes larger than the Infinity Cache) */
     const void *q4tnodes;     /* the same nodes child-major (lh_quad.hip), or NULL                */
     uint32_t    nq4nodes, q4_depth;
     const void *c8nodes;      /* lh_c8node_t[nc8nodes] (80 B each): use_qnodes == 3               */
     const void *tri32_c8;     /* lh_tri32_t[ntris] in the 8-wide tree's leaf order                 */
     uint32_t    nc8nodes, c8_depth, stack_rows;
+    uint32_t    c8_stride;    /* bytes between 8-wide records: 80 packed, 128 one record per cache line (LH_C8_STRIDE) */
     /* reference-order tree (lh_refbvh.c), for exact-t tie winners and beam queries; may be NULL */
     const void *ref_lca;      /* int4[ref_nnodes]: parent, depth, axis0, child[0]            */
     const void *prim_leafpos; /* uint2[ntris]: leaf node of the primitive, position in leaf  */

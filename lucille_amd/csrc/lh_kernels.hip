@@ -337,6 +337,83 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
     }
 }
 
+/* The same walk over the 8-wide 16-bit-grid nodes (lh_q8node_t): one 128-byte record -- one cache line -- decides eight
+ * children.  No distance sort: slot s has priority s ^ oct (0 = nearest; the builder put the children into octant slots),
+ * a hit child's stack slot is its rank among the hits in priority order (popcount of the nearer hits), nearest on top;
+ * misses write to a scratch row.  For ray dumps over scenes that do not fit the Infinity Cache: there every record costs a
+ * 128-byte line of HBM traffic, and this node uses all of it (S-soup-10M: 40 records per ray instead of 57). */
+template <bool ANYHIT, bool COUNT>
+__device__ __forceinline__ void traverse_spec8(Lane &L, int &pend, const lh_dev_scene_t &sc,
+                                               int (*stk)[LH_BLOCK], const int tid,
+                                               double ox, double oy, double oz,
+                                               double dx, double dy, double dz, Best &best,
+                                               uint32_t &c_nodes, uint32_t &c_tris, uint32_t &c_exact,
+                                               const int min_active, const int tri_batch,
+                                               uint32_t &c_nslots, uint32_t &c_tslots)
+{
+    const float4 *__restrict__ tris  = (const float4 *)sc.tri32;
+    constexpr int kNoLeaf = 0;
+    const uint32_t oct = (uint32_t)L.r.ngx | ((uint32_t)L.r.ngy << 1) | ((uint32_t)L.r.ngz << 2);
+    const int rows = (int)sc.stack_rows - 1;        /* the last row takes the misses' writes */
+
+    for (;;) {
+        if (COUNT) { if (__ballot(L.cur >= 0) != 0ull) c_nslots++; }
+        if (L.cur >= 0 && L.sp + 8 > rows) { L.over = true; L.cur = kDone; pend = kNoLeaf; }
+        if (L.cur >= 0) {
+            const uint4 *p = (const uint4 *)sc.q8nodes + 8 * (size_t)L.cur;
+            const uint4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], r0 = p[6], r1 = p[7];
+            if (COUNT) c_nodes++;
+            float t;
+            const bool h0 = slab_w(L, a.x, a.y, a.z, t) & ((int)r0.x != kDone);
+            const bool h1 = slab_w(L, a.w, b.x, b.y, t) & ((int)r0.y != kDone);
+            const bool h2 = slab_w(L, b.z, b.w, c.x, t) & ((int)r0.z != kDone);
+            const bool h3 = slab_w(L, c.y, c.z, c.w, t) & ((int)r0.w != kDone);
+            const bool h4 = slab_w(L, d.x, d.y, d.z, t) & ((int)r1.x != kDone);
+            const bool h5 = slab_w(L, d.w, e.x, e.y, t) & ((int)r1.y != kDone);
+            const bool h6 = slab_w(L, e.z, e.w, f.x, t) & ((int)r1.z != kDone);
+            const bool h7 = slab_w(L, f.y, f.z, f.w, t) & ((int)r1.w != kDone);
+            /* hits as a bit mask in priority order (bit q: the child visited q-th) */
+            const uint32_t pm = ((uint32_t)h0 << (0u ^ oct)) | ((uint32_t)h1 << (1u ^ oct)) | ((uint32_t)h2 << (2u ^ oct)) |
+                                ((uint32_t)h3 << (3u ^ oct)) | ((uint32_t)h4 << (4u ^ oct)) | ((uint32_t)h5 << (5u ^ oct)) |
+                                ((uint32_t)h6 << (6u ^ oct)) | ((uint32_t)h7 << (7u ^ oct));
+            const int base = L.sp + __popc(pm) - 1;
+#define LH_PUSH8(S, H, REF) stk[(H) ? base - __popc(pm & ((1u << ((S) ^ oct)) - 1u)) : rows][tid] = (int)(REF)
+            LH_PUSH8(0u, h0, r0.x); LH_PUSH8(1u, h1, r0.y); LH_PUSH8(2u, h2, r0.z); LH_PUSH8(3u, h3, r0.w);
+            LH_PUSH8(4u, h4, r1.x); LH_PUSH8(5u, h5, r1.y); LH_PUSH8(6u, h6, r1.z); LH_PUSH8(7u, h7, r1.w);
+#undef LH_PUSH8
+            L.sp = base;
+            const int nxt = stk[base][tid];
+            const int popped2 = stk[L.sp - 1][tid];
+            const bool is_leaf = (nxt < 0) & (nxt != kDone);
+            const bool park = is_leaf & (pend == kNoLeaf);
+            pend = park ? nxt : pend;
+            L.cur = park ? popped2 : nxt;
+            L.sp -= park ? 1 : 0;
+        }
+        const unsigned long long m_node = __ballot(L.cur >= 0);
+        const unsigned long long m_pend = __ballot(pend != kNoLeaf);
+        if (m_pend != 0ull && (__popcll(m_pend) >= tri_batch || m_node == 0ull)) {
+            if (COUNT) c_tslots++;
+            if (pend != kNoLeaf) {
+                const uint32_t x = ~(uint32_t)pend;
+                const float4 *tp = tris + 3 * (size_t)(x >> 2);
+                const float4 ta = tp[0], tb_ = tp[1], tc = tp[2];
+                if (COUNT) c_tris++;
+                const bool finished = tri_step<ANYHIT, COUNT>(L, sc, ta.x, ta.y, ta.z, ta.w, tb_.x, tb_.y, tb_.z, tb_.w, tc.x, tc.z, tc.w, __float_as_uint(tc.y), ox, oy, oz, dx, dy, dz, best, c_exact);
+                if (finished) { L.cur = kDone; pend = kNoLeaf; }
+                else if (x & 3u) pend = (int)~(((x >> 2) + 1u) << 2 | ((x & 3u) - 1u));
+                else {
+                    const bool waiting = (L.cur < 0) & (L.cur != kDone);
+                    pend = waiting ? L.cur : kNoLeaf;
+                    if (waiting) { L.sp--; L.cur = stk[L.sp][tid]; }
+                }
+            }
+        }
+        const unsigned long long m_work = __ballot((L.cur != kDone) | (pend != kNoLeaf));
+        if (__popcll(m_work) < min_active) break;
+    }
+}
+
 /* Speculative walk over the 8-wide compressed nodes (lh_c8node_t, use_qnodes == 3): 80-byte records,
  * five dwordx4 loads, eight children per visit in octant order -- no distance sort: child s has
  * priority s ^ oct (0 = nearest) and hit children are written to the stack by rank among the hits
@@ -358,7 +435,7 @@ __device__ __forceinline__ void traverse_c8(Lane &L, int &pend, const lh_dev_sce
 
     for (;;) {
         if (L.cur >= 0) {
-            const uint4 *p = (const uint4 *)((const char *)sc.c8nodes + 80 * (size_t)L.cur);
+            const uint4 *p = (const uint4 *)((const char *)sc.c8nodes + (size_t)sc.c8_stride * (size_t)L.cur);
             const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
             if (COUNT) c_nodes++;
             if (L.sp + 9 > rows) { L.over = true; L.cur = kDone; pend = kNoLeaf; }
@@ -621,7 +698,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         if (idle) {
             if (my != (size_t)-1) {
                 finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
-                if (SRC == 0) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL, WALK == 3 || WALK == 6);
+                if (SRC == 0) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL, WALK == 3 || WALK == 6 || WALK == 7);
                 else {
                     const bool hit = L.certain || best.prim != LH_MISS_PRIM;
                     const bool retrace = sc.ref_nodes != NULL && (L.over || (best.prim != LH_MISS_PRIM && best.frag != 0u && !L.certain));
@@ -678,6 +755,8 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
             if (L.cur != kDone) traverse_unified4<ANYHIT, COUNT>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
         } else if (WALK == 3) {
             traverse_spec4<ANYHIT, COUNT, false>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
+        } else if (WALK == 7) {
+            traverse_spec8<ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts);
         } else if (WALK == 6) {
             traverse_spec4<ANYHIT, COUNT, true>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
         } else if (WALK == 2) {
@@ -812,6 +891,9 @@ int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const doub
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
         else if (variant == LH_VARIANT_UNIFIED4 && sc.use_qnodes == 2)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 4, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
+        else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2 && sc.prefer_q8 && sc.q8nodes)
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 7, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
         else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2 && sc.tri_prefetch)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 6, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
@@ -960,7 +1042,14 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
         variant = LH_VARIANT_SPEC;
     }
     bool over_fix = false;
-    if ((variant == LH_VARIANT_SPEC || variant == LH_VARIANT_UNIFIED4) && scl.use_qnodes == 2) {
+    if (variant == LH_VARIANT_SPEC && scl.use_qnodes == 2 && sc->prefer_q8 && sc->q8nodes) {
+        /* the 8-wide walk pushes up to 7 per level and keeps a scratch row; beyond 48 rows the rare ray that needs them is
+         * finished by k_overflow_fix over the 4-wide nodes (always resident) */
+        need = 7 * sc->q8_depth + 10;
+        const uint32_t cap = (sc->stack_cap >= 16 && sc->stack_cap < 64) ? sc->stack_cap : 48;     /* 48 rows: three workgroups per CU */
+        if (need > cap) { need = cap; over_fix = true; }
+    } else if ((variant == LH_VARIANT_SPEC || variant == LH_VARIANT_UNIFIED4) && scl.use_qnodes == 2) {
+        scl.prefer_q8 = 0;
         need = 3 * sc->q4_depth + 5;
         /* a very deep tree (chains of nested geometry): the 4-wide walk's worst case does not fit the
          * 64-row LDS stack.  Host-built trees come with the 2-wide nodes: that walk (<= LH_MAX_DEPTH + 1 rows) always fits.

@@ -87,6 +87,18 @@ static void trace_one(job_t *j, size_t i)
                 cur = stack[--sp];
                 (void)pushed;
             }
+            while (cur >= 0 && j->qnodes == 4) {      /* 8-wide 16-bit grid nodes (lh_q8node_t), octant order */
+                const lh_q8node_t *n = &b->q8nodes[cur]; int pr;
+                const int oct = r.ngx | (r.ngy << 1) | (r.ngz << 2);
+                j->c[0]++;
+                for (pr = 7; pr >= 0; pr--) {              /* far to near: the nearest ends on top */
+                    const int s = pr ^ oct; float tn;
+                    if (n->ref[s] == DONE) continue;
+                    if (!lh_slab_w(&r, n->w[s][0], n->w[s][1], n->w[s][2], tb, &tn)) continue;
+                    stack[sp++] = n->ref[s];
+                }
+                cur = stack[--sp];
+            }
             while (cur >= 0 && j->qnodes == 2) {      /* 4-wide 16-bit grid nodes */
                 const lh_q4node_t *n = &b->q4nodes[cur]; float tn[4]; int h[4], c, nh = 0, order[4], m;
                 j->c[0]++;
@@ -177,7 +189,7 @@ int lhm_trace(const lh_bvh_t *b, size_t n, const double *org, const double *dir,
     for (i = 0; i < nthreads; i++) {
         jobs[i].b = b; jobs[i].begin = n * (size_t)i / (size_t)nthreads; jobs[i].end = n * (size_t)(i + 1) / (size_t)nthreads;
         jobs[i].org = org; jobs[i].dir = dir; jobs[i].prim = prim; jobs[i].t = t; jobs[i].u = u; jobs[i].v = v;
-        jobs[i].occ = occ; jobs[i].anyhit = anyhit & 1; jobs[i].qnodes = (anyhit >> 1) & 3;
+        jobs[i].occ = occ; jobs[i].anyhit = anyhit & 1; jobs[i].qnodes = (anyhit >> 1) & 7;
     }
     if (nthreads == 1) run(&jobs[0]);
     else { for (i = 0; i < nthreads; i++) pthread_create(&th[i], NULL, run, &jobs[i]); for (i = 0; i < nthreads; i++) pthread_join(th[i], NULL); }
@@ -191,13 +203,15 @@ lh_bvh_t *lhm_build(uint32_t npos, const double *pos_xyz, uint32_t nidx, const u
 {
     lh_bvh_t *b = (lh_bvh_t *)calloc(1, sizeof(*b)); lh_mesh_view_t m;
     m.npositions = npos; m.positions = pos_xyz; m.stride_bytes = 24; m.nindices = nidx; m.indices = idx;
-    if (lh_bvh_build(b, &m, 1, nthreads) != 0 || lh_bvh_ensure_c8(b) != 0) { free(b); return NULL; }   /* the model checks every format */
+    if (lh_bvh_build(b, &m, 1, nthreads) != 0 || lh_bvh_ensure_c8(b) != 0 || lh_bvh_ensure_q8(b) != 0) { free(b); return NULL; }   /* the model checks every format */
     return b;
 }
 void lhm_free(lh_bvh_t *b) { if (b) { lh_bvh_release(b); free(b); } }
 void lhm_info(const lh_bvh_t *b, uint32_t out[4]) { out[0] = b->ntris; out[1] = b->nnodes; out[2] = b->max_depth; out[3] = b->nleaves; }
 void lhm_info4(const lh_bvh_t *b, uint32_t out[2]) { out[0] = b->nq4nodes; out[1] = b->q4_depth; }
 void lhm_info8(const lh_bvh_t *b, uint32_t out[2]) { out[0] = b->nc8nodes; out[1] = b->c8_depth; }
+void lhm_infoq8(const lh_bvh_t *b, uint32_t out[2]) { out[0] = b->nq8nodes; out[1] = b->q8_depth; }
+const void *lhm_q8nodes(const lh_bvh_t *b) { return b->q8nodes; }
 const void *lhm_q4nodes(const lh_bvh_t *b) { return b->q4nodes; }
 double lhm_build_seconds(const lh_bvh_t *b) { return b->build_seconds; }
 const void *lhm_nodes(const lh_bvh_t *b) { return b->nodes; }

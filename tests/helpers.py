@@ -117,6 +117,25 @@ class Model:
         L.lhm_info8.argtypes = [C.c_void_p, _u32p]; L.lhm_info8(self.h, o.ctypes.data_as(_u32p))
         return int(o[0]), int(o[1])
 
+    def grid(self):
+        """(grid_lo[3], grid_step[3]) of the scene's 16-bit grid, as float64"""
+        L = self.lib()
+        L.lhm_grid.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        g = np.zeros(6, np.float32); L.lhm_grid(self.h, g.ctypes.data_as(C.POINTER(C.c_float)))
+        return g[:3].astype(np.float64), g[3:].astype(np.float64)
+
+    def q8info(self):
+        L = self.lib(); o = np.zeros(2, np.uint32)
+        L.lhm_infoq8.argtypes = [C.c_void_p, _u32p]; L.lhm_infoq8(self.h, o.ctypes.data_as(_u32p))
+        return int(o[0]), int(o[1])
+
+    def q8nodes(self):
+        """lh_q8node_t records as uint32 [n, 32]: 8 x (x, y, z) words (lo | hi << 16), then 8 child references"""
+        L = self.lib(); n, _ = self.q8info()
+        L.lhm_q8nodes.restype = C.c_void_p; L.lhm_q8nodes.argtypes = [C.c_void_p]
+        buf = (C.c_char * (128 * n)).from_address(L.lhm_q8nodes(self.h))
+        return np.frombuffer(buf, np.uint32).reshape(-1, 32).copy()
+
     def q4nodes(self):
         L = self.lib(); n, _ = self.q4info()
         L.lhm_q4nodes.restype = C.c_void_p; L.lhm_q4nodes.argtypes = [C.c_void_p]
@@ -134,7 +153,8 @@ class Model:
         return np.frombuffer(buf, np.uint16).reshape(-1, 16).copy(), grid
 
     def trace(self, org, dr, anyhit=False, nthreads=4, qnodes=2):
-        """qnodes: 0 fp32 2-wide nodes, 1 16-bit grid 2-wide, 2 16-bit grid 4-wide (the kernel's default)"""
+        """qnodes: 0 fp32 2-wide nodes, 1 16-bit grid 2-wide, 2 16-bit grid 4-wide (the kernel's default), 3 8-wide compressed,
+        4 8-wide on the 16-bit grid (128-byte records: ray dumps over scenes larger than the Infinity Cache)"""
         qnodes = int(qnodes)
         org = np.ascontiguousarray(org, np.float64).reshape(-1, 3)
         dr = np.ascontiguousarray(dr, np.float64).reshape(-1, 3)

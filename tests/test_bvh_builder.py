@@ -93,3 +93,47 @@ def test_parallel_build_is_equivalent():
     ra, _ = a.trace(org, dr); rb, _ = b.trace(org, dr)
     for x, y in zip(ra, rb):
         assert np.array_equal(x, y)
+
+
+def _wide_walk(words, refs, width, tri32, tri_dbl, grid_lo, grid_step):
+    """every primitive reached exactly once through a wide 16-bit-grid tree; every decoded child box contains its triangles"""
+    seen = []; visited = set(); maxd = 0
+    stack = [(0, 1)]
+    while stack:
+        k, d = stack.pop()
+        assert k not in visited
+        visited.add(k); maxd = max(maxd, d)
+        for c in range(width):
+            ref = int(refs[k, c])
+            w = words[k, 3 * c:3 * c + 3]
+            lo = grid_lo + (w & 0xFFFF).astype(np.float64) * grid_step; hi = grid_lo + (w >> 16).astype(np.float64) * grid_step
+            if ref == EMPTY:
+                assert ((w & 0xFFFF) > (w >> 16)).any(), "empty slot must carry an inverted box"
+                continue
+            if ref >= 0:
+                stack.append((ref, d + 1)); continue
+            x = (~ref) & 0xFFFFFFFF
+            first, cnt = x >> 2, (x & 3) + 1
+            prims = tri32[first:first + cnt, 9].view(np.uint32)
+            seen.extend(int(p) for p in prims)
+            tv = tri_dbl[prims].reshape(-1, 3)
+            assert (lo <= tv.min(0) + 1e-12).all() and (hi >= tv.max(0) - 1e-12).all()
+    return seen, len(visited), maxd
+
+
+@pytest.mark.parametrize("ntri,he", [(1, 0.2), (3, 0.2), (9, 0.1), (1000, 0.02), (30000, 0.005)])
+def test_wide_collapses_cover_every_triangle_once(ntri, he):
+    """the 4-wide (lh_q4node_t) and 8-wide (lh_q8node_t) collapses of the same binary tree: the slot choice minimises the summed
+    area of the kept nodes (dp4_fill); whatever it chooses, every triangle hangs under exactly one leaf reference, empty slots are
+    inverted, inner children are distinct records, and a decoded 16-bit box contains its triangles"""
+    P, idx, _, _ = po.soup(ntri, 1, he, 99)
+    m = Model(P, idx)
+    tri32 = m.tri32(); tri_dbl = P[idx].reshape(-1, 9)
+    lo, step = m.grid()
+    q4 = np.ascontiguousarray(m.q4nodes()).view(np.uint32).reshape(-1, 16); n4, d4 = m.q4info()
+    seen, nv, md = _wide_walk(q4[:, :12], q4[:, 12:16].view(np.int32), 4, tri32, tri_dbl, lo, step)
+    assert sorted(seen) == list(range(ntri)) and nv == n4 and md == d4
+    q8 = m.q8nodes(); n8, d8 = m.q8info()
+    seen, nv, md = _wide_walk(q8[:, :24], q8[:, 24:32].view(np.int32), 8, tri32, tri_dbl, lo, step)
+    assert sorted(seen) == list(range(ntri)) and nv == n8 and md == d8
+    assert n8 <= n4 and d8 <= d4

@@ -49,6 +49,22 @@ def test_model_matches_oracle_soups(ntri, he, seed):
     check(P, idx, org, dr, "soup %d" % ntri)
 
 
+@pytest.mark.parametrize("ntri,he,seed", [(100000, 0.005, 1), (20000, 0.0005, 2), (500, 0.2, 3), (3, 0.4, 4), (1, 0.4, 5)])
+def test_eight_wide_model_matches_oracle(ntri, he, seed):
+    """the 8-wide 16-bit-grid tree (lh_q8node_t: what ray dumps walk on scenes larger than the Infinity Cache) in octant order:
+    the same records as the oracle, and fewer node visits than the 4-wide tree"""
+    P, idx, org, dr = po.soup(ntri, 60000, he, seed)
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr, nthreads=4)
+    m = Model(P, idx)
+    got, c8 = m.trace(org, dr, qnodes=4)
+    assert_hits_equal(got, exp, "8-wide model, soup %d" % ntri)
+    occ, _ = m.trace(org, dr, anyhit=True, qnodes=4)
+    assert np.array_equal(occ.astype(bool), exp[0] != po.MISS)
+    _, c4 = m.trace(org, dr, qnodes=2)
+    assert c8["nodes"] <= c4["nodes"] and c8["tris"] <= 1.2 * c4["tris"] + 10
+
+
 def test_axis_aligned_grid_vertex_edge_diagonal_rays():
     """rays aimed exactly at shared vertices, edges and quad diagonals of an
     axis-aligned plane (zero-thickness boxes): the worst case for fp32 culling"""

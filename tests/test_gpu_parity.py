@@ -383,3 +383,76 @@ def test_triangle_prefetch_walk_equals_default():
         assert all(torch.equal(a, b) for a, b in zip(got, ref_c)), tb
         assert torch.equal(acc.intersect_device(o, d, mode=la.MODE_ANY)[0], ref_a), tb
     acc.close()
+
+
+def test_eight_wide_walk_parity():
+    """the 8-wide 16-bit-grid nodes (lh_q8node_t, 128-byte records: what ray dumps walk on scenes larger than the Infinity
+    Cache; forced here with set_param("wide8", 1)): goldens, seeded soups against the oracle, exact-t ties, deep chains,
+    vertex-aimed rays, ragged batches, a capped stack (overflowing rays finished over the 4-wide nodes) -- same records"""
+    import torch
+    from tests.helpers import chain_scene, vertex_aimed_rays
+    def wide(P, idx):
+        acc = make_accel(P, idx); acc.set_param("wide8", 1)
+        assert acc.dump_node_bytes() == 128
+        return acc
+    for name in ("soup_20k", "soup_3k_fat"):
+        g = load_golden(name)
+        P, idx, org, dr = po.soup(int(g["ntri"]), int(g["nrays"]), float(g["half_extent"]), int(g["seed"]))
+        acc = wide(P, idx)
+        assert_hits_equal(gpu_closest(acc, org, dr, la.VARIANT_DEFAULT), (g["prim"], g["t"], g["u"], g["v"]), name)
+        assert np.array_equal(gpu_any(acc, org, dr, la.VARIANT_DEFAULT).astype(bool), g["prim"] != po.MISS)
+        acc.close()
+    for ntri, nrays, he, seed in [(200000, 300000, 0.005, 21), (50000, 100000, 0.0007, 22), (7, 30001, 0.4, 23), (1, 5000, 0.3, 24)]:
+        P, idx, org, dr = po.soup(ntri, nrays, he, seed)
+        o = po.Oracle(); o.add_mesh(P, idx); o.build()
+        exp = o.intersect(org, dr, nthreads=16)
+        acc = wide(P, idx)
+        assert_hits_equal(gpu_closest(acc, org, dr, la.VARIANT_DEFAULT), exp, "8-wide soup %d" % ntri)
+        assert np.array_equal(gpu_any(acc, org, dr, la.VARIANT_DEFAULT).astype(bool), exp[0] != po.MISS)
+        for n in (1, 63, 65, 257):
+            assert_hits_equal(gpu_closest(acc, org[:n], dr[:n], la.VARIANT_DEFAULT), tuple(x[:n] for x in exp), "8-wide ragged %d" % n)
+        if ntri == 200000:
+            acc.set_param("stack_cap", 16)          # overflow path: k_overflow_fix over the 4-wide nodes
+            do = torch.from_numpy(org).cuda(); dd = torch.from_numpy(dr).cuda()
+            _, c = acc.intersect_device(do, dd, counters=True)
+            assert c["retraced"] > 0
+            assert_hits_equal(gpu_closest(acc, org, dr, la.VARIANT_DEFAULT), exp, "8-wide capped stack")
+            assert np.array_equal(gpu_any(acc, org, dr, la.VARIANT_DEFAULT).astype(bool), exp[0] != po.MISS)
+        acc.close()
+    P, idx = grid_mesh(8, 8)                      # shared vertices / edges: exact-t ties
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    acc = wide(P, idx)
+    org, dr = random_rays(np.random.default_rng(3), 20000)
+    assert_hits_equal(gpu_closest(acc, org, dr, la.VARIANT_DEFAULT), o.intersect(org, dr), "8-wide grid")
+    vo, vd = vertex_aimed_rays(np.random.default_rng(5), P, idx, 20000)
+    assert_hits_equal(gpu_closest(acc, vo, vd, la.VARIANT_DEFAULT), o.intersect(vo, vd), "8-wide vertex-aimed")
+    acc.close()
+    P, idx = chain_scene(40)
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    acc = wide(P, idx)
+    org, dr = random_rays(np.random.default_rng(6), 20000, lo=-1.0, hi=2.0)
+    assert_hits_equal(gpu_closest(acc, org, dr, la.VARIANT_DEFAULT), o.intersect(org, dr), "8-wide chain")
+    acc.close()
+
+
+def test_wide_walk_is_chosen_by_footprint():
+    """hot set (4-wide nodes + 48-byte triangle records) above 256 MiB -> ray dumps walk the 8-wide nodes; the records equal the
+    4-wide walk's and the oracle's"""
+    P, idx, st = scenes.soup_triangles(4000000, 0.003)
+    org, dr, _ = scenes.soup_rays(400000, st)
+    acc = make_accel(P, idx)
+    info = acc.info()
+    assert info["nnodes_traversal"] * 64 + info["ntriangles"] * 48 > 256 << 20 and acc.dump_node_bytes() == 128
+    a = gpu_closest(acc, org, dr, la.VARIANT_DEFAULT); oa = gpu_any(acc, org, dr, la.VARIANT_DEFAULT)
+    acc.set_param("wide8", 0)
+    assert acc.dump_node_bytes() == 64
+    b = gpu_closest(acc, org, dr, la.VARIANT_DEFAULT)
+    assert_hits_equal(a, b, "8-wide == 4-wide")
+    assert np.array_equal(oa, gpu_any(acc, org, dr, la.VARIANT_DEFAULT))
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org[:100000], dr[:100000], nthreads=16)
+    assert_hits_equal(tuple(x[:100000] for x in a), exp, "8-wide, 4 M triangles")
+    acc.close()
+    small = make_accel(*po.soup(20000, 10, 0.01, 3)[:2])
+    assert small.dump_node_bytes() == 64
+    small.close()
