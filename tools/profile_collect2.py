@@ -65,7 +65,8 @@ for leg in ("main", "hbm", "ao", "pt"):
         F = sorted(vals["FETCH_SIZE"])[-k:]; W = sorted(vals["WRITE_SIZE"])[-k:]
         F = sum(F) / len(F); W = sum(W) / len(W)
         line = json.load(open(bl)) if os.path.exists(bl) and os.path.getsize(bl) else {}
-        j = {"round": rnd, "kernel": mk["Name"], "kernel_tag": "q16x4", "mode": "closest",
+        wide = leg == "hbm" and (line.get("roofline_hbm") or {}).get("node_bytes") == 128
+        j = {"round": rnd, "kernel": mk["Name"], "kernel_tag": "q16x8" if wide else "q16x4", "mode": "closest",
              "rays_per_launch": 100000000 if leg == "main" else 50000000,
              "triangles": 1000000 if leg == "main" else 10000000,
              "FETCH_SIZE_KiB": F, "WRITE_SIZE_KiB": W, "kernel_avg_ms_rocprof": avg_ms,
