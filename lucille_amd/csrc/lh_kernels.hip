@@ -249,7 +249,7 @@ __device__ __forceinline__ void traverse_spec(Lane &L, int &pend, const lh_dev_s
  * nothing was hit (a pop).  Leaves are parked and tested in batches as in traverse_spec. */
 struct TriRegs { float4 a, b, c; bool need; };      /* PF: the parked leaf's next triangle record, loaded one step ahead of its test */
 
-template <bool ANYHIT, bool COUNT, bool PF>
+template <bool ANYHIT, bool COUNT, bool PF, bool GUARD>
 __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_scene_t &sc,
                                                int (*stk)[LH_BLOCK], const int tid,
                                                double ox, double oy, double oz,
@@ -276,7 +276,7 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
         /* the step below writes up to slot sp + 3.  rows = 3 * depth + 5 covers every ray of a tree that deep; a deeper
          * tree (an LBVH built on the device over a degenerate distribution) gets 64 rows and a ray that would overrun them
          * is finished by k_overflow_fix with a private stack -- same arithmetic, same answer */
-        if (L.cur >= 0 && L.sp + 4 > rows) { L.over = true; L.cur = kDone; pend = kNoLeaf; }
+        if (GUARD && L.cur >= 0 && L.sp + 4 > rows) { L.over = true; L.cur = kDone; pend = kNoLeaf; }     /* a separate instantiation: the check costs the path-traced frame 4 % */
         if (L.cur >= 0) {
             const uint4 *p = (const uint4 *)sc.q4nodes + 4 * (size_t)L.cur;
             const uint4 a = p[0], b = p[1], c = p[2], r = p[3];
@@ -358,7 +358,7 @@ __device__ __forceinline__ void traverse_spec8(Lane &L, int &pend, const lh_dev_
 
     for (;;) {
         if (COUNT) { if (__ballot(L.cur >= 0) != 0ull) c_nslots++; }
-        if (L.cur >= 0 && L.sp + 8 > rows) { L.over = true; L.cur = kDone; pend = kNoLeaf; }
+        if (sc.stack_guard && L.cur >= 0 && L.sp + 8 > rows) { L.over = true; L.cur = kDone; pend = kNoLeaf; }
         if (L.cur >= 0) {
             const uint4 *p = (const uint4 *)sc.q8nodes + 8 * (size_t)L.cur;
             const uint4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], r0 = p[6], r1 = p[7];
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         if (idle) {
             if (my != (size_t)-1) {
                 finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
-                if (SRC == 0) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL, WALK == 3 || WALK == 6 || WALK == 7);
+                if (SRC == 0) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL, WALK == 8 || WALK == 7);
                 else {
                     const bool hit = L.certain || best.prim != LH_MISS_PRIM;
                     const bool retrace = sc.ref_nodes != NULL && (L.over || (best.prim != LH_MISS_PRIM && best.frag != 0u && !L.certain));
@@ -754,11 +754,13 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         } else if (WALK == 4) {
             if (L.cur != kDone) traverse_unified4<ANYHIT, COUNT>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
         } else if (WALK == 3) {
-            traverse_spec4<ANYHIT, COUNT, false>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
+            traverse_spec4<ANYHIT, COUNT, false, false>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
+        } else if (WALK == 8) {          /* the same with the stack check: trees whose worst case the LDS rows do not cover */
+            traverse_spec4<ANYHIT, COUNT, false, true>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
         } else if (WALK == 7) {
             traverse_spec8<ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts);
         } else if (WALK == 6) {
-            traverse_spec4<ANYHIT, COUNT, true>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
+            traverse_spec4<ANYHIT, COUNT, true, false>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
         } else if (WALK == 2) {
             /* every lane enters (idle lanes just vote in the ballots) */
             traverse_spec<ANYHIT, COUNT, QN>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch);
@@ -895,6 +897,9 @@ int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const doub
         else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2 && sc.prefer_q8 && sc.q8nodes)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 7, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
+        else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2 && sc.stack_guard)
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 8, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
         else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2 && sc.tri_prefetch)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 6, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
@@ -953,7 +958,7 @@ extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int n
     const uint32_t cap = (sc->stack_cap >= 8 && sc->stack_cap < 64) ? sc->stack_cap : 64;
     if (need > cap) {                /* a deep (device-built) tree: 64 rows, the rare ray that needs more is queued for the reference walk */
         if (!sc->ref_nodes) return -1;
-        need = cap;
+        need = cap; scl.stack_guard = 1;
     }
     need = (need + 1u) & ~1u;
     if (need < 16 && need != cap) need = 16;
@@ -970,14 +975,12 @@ extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int n
     if (hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), s) != hipSuccess) return -1;
     if (hipMemsetAsync(d_qcount, 0, 2 * sizeof(uint32_t), s) != hipSuccess) return -1;
     if (hipMemsetAsync(d_occ_count, 0, sizeof(unsigned int) * nslots, s) != hipSuccess) return -1;
-    if (d_counters)
-        hipLaunchKernelGGL((k_trace_persist_lane<true, true, 3, true, 1>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                           scl, n, (const double *)NULL, (const double *)NULL, (uint32_t *)NULL, (double *)NULL, (double *)NULL,
-                           (double *)NULL, (uint8_t *)NULL, d_counters, d_cursor, min_active, tri_batch, ao);
-    else
-        hipLaunchKernelGGL((k_trace_persist_lane<true, false, 3, true, 1>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                           scl, n, (const double *)NULL, (const double *)NULL, (uint32_t *)NULL, (double *)NULL, (double *)NULL,
-                           (double *)NULL, (uint8_t *)NULL, d_counters, d_cursor, min_active, tri_batch, ao);
+#define LH_AO_LAUNCH(CNT, W) hipLaunchKernelGGL((k_trace_persist_lane<true, CNT, W, true, 1>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s, \
+                           scl, n, (const double *)NULL, (const double *)NULL, (uint32_t *)NULL, (double *)NULL, (double *)NULL, \
+                           (double *)NULL, (uint8_t *)NULL, d_counters, d_cursor, min_active, tri_batch, ao)
+    if (scl.stack_guard) { if (d_counters) LH_AO_LAUNCH(true, 8); else LH_AO_LAUNCH(false, 8); }
+    else { if (d_counters) LH_AO_LAUNCH(true, 3); else LH_AO_LAUNCH(false, 3); }
+#undef LH_AO_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1047,7 +1050,7 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
          * finished by k_overflow_fix over the 4-wide nodes (always resident) */
         need = 7 * sc->q8_depth + 10;
         const uint32_t cap = (sc->stack_cap >= 16 && sc->stack_cap < 64) ? sc->stack_cap : 48;     /* 48 rows: three workgroups per CU */
-        if (need > cap) { need = cap; over_fix = true; }
+        if (need > cap) { need = cap; over_fix = true; scl.stack_guard = 1; }
     } else if ((variant == LH_VARIANT_SPEC || variant == LH_VARIANT_UNIFIED4) && scl.use_qnodes == 2) {
         scl.prefer_q8 = 0;
         need = 3 * sc->q4_depth + 5;
@@ -1058,7 +1061,7 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
         const uint32_t cap = (sc->stack_cap >= 8 && sc->stack_cap < 64) ? sc->stack_cap : 64;     /* < 64: the tests' way to reach the overflow path */
         if (need > cap) {
             if (cap == 64 && sc->nodes_2wide_available) { scl.use_qnodes = 1; need = sc->max_depth + 1; }
-            else if (variant == LH_VARIANT_SPEC) { need = cap; over_fix = true; }
+            else if (variant == LH_VARIANT_SPEC) { need = cap; over_fix = true; scl.stack_guard = 1; }
             else return -1;
         }
     }

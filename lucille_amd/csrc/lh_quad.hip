@@ -96,7 +96,7 @@ __device__ __forceinline__ void traverse_quad(Lane &L, int &pend, const lh_dev_s
     const int rows = (int)sc.stack_rows;
 
     for (;;) {
-        if (L.cur >= 0 && L.sp + 4 > rows) { L.over = true; L.cur = kDone; pend = kNoLeaf; }
+        if (sc.stack_guard && L.cur >= 0 && L.sp + 4 > rows) { L.over = true; L.cur = kDone; pend = kNoLeaf; }
         if (L.cur >= 0) {                                   /* uniform over the quad */
             const uint4 w = nodes[4 * (size_t)L.cur + sub];
             if (COUNT) c_nodes += (sub == 0);
@@ -283,7 +283,7 @@ extern "C" int lh_launch_trace_quad(const lh_dev_scene_t *sc, size_t n, const do
     uint32_t need = 3 * sc->q4_depth + 5;
     const uint32_t cap = (sc->stack_cap >= 8 && sc->stack_cap < 64) ? sc->stack_cap : 64;
     int over_fix = 0;
-    if (need > cap) { need = cap; over_fix = 1; }
+    if (need > cap) { need = cap; over_fix = 1; scl.stack_guard = 1; }
     if (need < 16 && !over_fix) need = 16;
     scl.stack_rows = need;
     *over_fix_out = over_fix;
