@@ -9,10 +9,11 @@
  * triangle k.  Each lane keeps the unresolved candidates of its own triangles and resolves them in fp64 when the
  * ray ends; the four exact bests are merged over the quad with the reference's tie rule (lh_walk.h).
  *
- * Why: tools/ubench/gather.hip -- dependent random 64-byte gathers, one chain per lane top out at 129 G records/s
- * at any occupancy (mode 0), one chain per quad reaches 144 / 179 / 192 G/s at 3 / 4 / 8 waves per SIMD (mode 1).
- * What it costs: a wave carries 16 rays instead of 64, so the per-visit VALU work per ray is ~1.6x the lane walk's.
- * Measured result: profiles/README.md (r02 experiments).
+ * Why it was tried: tools/ubench/gather.hip -- in round 1's run dependent random 64-byte gathers with one chain per quad
+ * ran 1.45x the per-lane mode.  What it costs: a wave carries 16 rays instead of 64 -- 1.9x the VALU wave-instructions, and
+ * 256 rays in flight per CU instead of 768.  Measured: half the lane walk's rate (profiles/README.md, r02 experiments); and
+ * the microbenchmark's promise was an artefact of unperturbed chain links (corrected: 1.12x at the 4 waves per SIMD this
+ * kernel's registers allow).  Kept as a tested opt-in.
  *
  * Node layout: lh_q4node_t re-cut child-major ("q4t"): piece k = { x: lo|hi<<16, y, z, child ref } -- made on the
  * device from the q4 nodes the first time the variant is used (lh_quad_make_nodes).

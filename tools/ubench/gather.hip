@@ -13,9 +13,14 @@
 #include <vector>
 #include <cstdint>
 
+#define LAUNCH(M, ...) do { if (perturb) hipLaunchKernelGGL((k_gather<M, true>), __VA_ARGS__); else hipLaunchKernelGGL((k_gather<M, false>), __VA_ARGS__); } while (0)
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-template <int MODE>
+// PERTURB: modes 1, 3 and 6 originally followed the link unmodified -- a pure functional graph, on which the chains of a
+// launch merge into common trunks and cycles (a random mapping's rho structure) and the L2 hit rate climbs: their r01 figures
+// (181-193 G/s) overstate the quad-cooperative ceiling.  GATHER_PERTURB=1 (default now) xors the chain's own running sum into
+// the link, as modes 0, 2, 4, 5, 7, 8 always did.
+template <int MODE, bool PERTURB>
 __global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ nodes, uint32_t nnodes, int steps, uint32_t *out)
 {
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
@@ -35,7 +40,7 @@ __global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ nodes,
             uint4 a = nodes[4 * (size_t)cur + sub];
             acc += a.y;
             uint32_t nx = __shfl(a.x, (threadIdx.x & 63) & ~3);       // lane 0 of the quad holds the link
-            cur = (nx ^ (acc & 1 & 0)) % nnodes;
+            cur = (nx ^ (PERTURB ? (__shfl(acc, (threadIdx.x & 63) & ~3) & 1) : 0)) % nnodes;
         }
     } else if (MODE == 2) {
         uint32_t cur = (gid * 2654435761u) % (nnodes * 2);
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ nodes,
             uint4 a = p[0], b = p[1];
             acc += a.y + b.y;
             uint32_t nx = __shfl(a.x, (threadIdx.x & 63) & ~1);
-            cur = nx % nnodes;
+            cur = (nx ^ (PERTURB ? (__shfl(acc, (threadIdx.x & 63) & ~1) & 1) : 0)) % nnodes;
         }
     } else if (MODE == 5) {          /* 128-byte nodes, one chain per lane, 8 x dwordx4 */
         uint32_t cur = (gid * 2654435761u) % (nnodes / 2);
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ nodes,
             uint4 a = p[0], b = p[1];
             acc += a.y + b.y;
             uint32_t nx = __shfl(a.x, (threadIdx.x & 63) & ~3);
-            cur = nx % (nnodes / 2);
+            cur = (nx ^ (PERTURB ? (__shfl(acc, (threadIdx.x & 63) & ~3) & 1) : 0)) % (nnodes / 2);
         }
     } else if (MODE == 7) {          /* 256-byte nodes (2 lines), one chain per lane, first 5 x dwordx4 (80 B used) */
         uint32_t cur = (gid * 2654435761u) % (nnodes / 4);
@@ -133,6 +138,7 @@ int main(int argc, char **argv)
     CHK(hipMalloc(&d, h.size() * 4)); CHK(hipMalloc(&out, (size_t)blocks * 256 * 4));
     CHK(hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    const bool perturb = !(getenv("GATHER_PERTURB") && atoi(getenv("GATHER_PERTURB")) == 0);
     const size_t lds = getenv("GATHER_LDS") ? (size_t)atol(getenv("GATHER_LDS")) : 0;
     if (lds) printf("dynamic LDS %zu bytes per block: at most %zu blocks (%zu waves per SIMD) per CU\n", lds, (size_t)(160 * 1024) / lds, (size_t)(160 * 1024) / lds);
     for (int a = 4; a < argc; a++) {
@@ -141,15 +147,15 @@ int main(int argc, char **argv)
         for (int rep = 0; rep < 4; rep++) {
             CHK(hipEventRecord(e0));
             switch (mode) {
-            case 0: hipLaunchKernelGGL(k_gather<0>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
-            case 1: hipLaunchKernelGGL(k_gather<1>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
-            case 2: hipLaunchKernelGGL(k_gather<2>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
-            case 3: hipLaunchKernelGGL(k_gather<3>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
-            case 5: hipLaunchKernelGGL(k_gather<5>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
-            case 6: hipLaunchKernelGGL(k_gather<6>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
-            case 8: hipLaunchKernelGGL(k_gather<8>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
-            case 7: hipLaunchKernelGGL(k_gather<7>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
-            default: hipLaunchKernelGGL(k_gather<4>, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            case 0: LAUNCH(0, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            case 1: LAUNCH(1, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            case 2: LAUNCH(2, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            case 3: LAUNCH(3, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            case 5: LAUNCH(5, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            case 6: LAUNCH(6, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            case 8: LAUNCH(8, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            case 7: LAUNCH(7, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
+            default: LAUNCH(4, dim3(blocks), dim3(256), lds, 0, d, nnodes, steps, out); break;
             }
             CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
             float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if (rep > 0 && ms < best) best = ms;
