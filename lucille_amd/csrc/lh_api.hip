@@ -836,6 +836,7 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
     else if (!strcmp(name, "wide8") && value >= -1 && value <= 1) a->wide8 = value;
     else if (!strcmp(name, "quad_grid") && value > 0) a->quad_grid = value;
     else if (!strcmp(name, "tri_prefetch")) a->dev.tri_prefetch = value != 0;
+    else if (!strcmp(name, "coop_fetch")) a->dev.tri_prefetch = value ? 2 : 0;      /* A/B: quad-coalesced node fetch (same switch word) */
     else if (!strcmp(name, "stack_cap") && (value == 0 || (value >= 8 && value <= 64 && value % 2 == 0))) a->dev.stack_cap = (uint32_t)value;
     else return fail("lh_accel_set_param: unknown parameter or bad value: %s = %d", name, value);
     return 0;

@@ -249,7 +249,7 @@ __device__ __forceinline__ void traverse_spec(Lane &L, int &pend, const lh_dev_s
  * nothing was hit (a pop).  Leaves are parked and tested in batches as in traverse_spec. */
 struct TriRegs { float4 a, b, c; bool need; };      /* PF: the parked leaf's next triangle record, loaded one step ahead of its test */
 
-template <bool ANYHIT, bool COUNT, bool PF, bool GUARD>
+template <bool ANYHIT, bool COUNT, bool PF, bool GUARD, bool COOP = false>
 __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_scene_t &sc,
                                                int (*stk)[LH_BLOCK], const int tid,
                                                double ox, double oy, double oz,
@@ -277,9 +277,36 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
          * tree (an LBVH built on the device over a degenerate distribution) gets 64 rows and a ray that would overrun them
          * is finished by k_overflow_fix with a private stack -- same arithmetic, same answer */
         if (GUARD && L.cur >= 0 && L.sp + 4 > rows) { L.over = true; L.cur = kDone; pend = kNoLeaf; }     /* a separate instantiation: the check costs the path-traced frame 4 % */
+        uint4 ca, cb, cc, cr;
+        if (COOP && __ballot(L.cur >= 0) != 0ull) {
+            /* quad-coalesced fetch (A/B): in phase p every lane of a quad loads one 16-byte piece of quad-lane p's node -- four
+             * lanes, one contiguous 64-byte request -- and the quad transposes the pieces with DPP.  Lanes without a node
+             * step read node 0.  (gather microbenchmark mode 8: 147 instead of 129 G records/s) */
+            const int j = tid & 3;
+            const uint32_t mc = L.cur >= 0 ? (uint32_t)L.cur : 0u;
+            const uint4 *q = (const uint4 *)sc.q4nodes + j;
+#define LH_QB(v, P) (uint32_t)__builtin_amdgcn_mov_dpp((int)(v), (P) * 0x55, 0xf, 0xf, true)
+            ca = q[4 * (size_t)LH_QB(mc, 0)]; cb = q[4 * (size_t)LH_QB(mc, 1)];
+            cc = q[4 * (size_t)LH_QB(mc, 2)]; cr = q[4 * (size_t)LH_QB(mc, 3)];
+#undef LH_QB
+#define LH_XSWAP(A, B, CTRL, BIT) { \
+                const bool hi = (j & (BIT)) != 0; \
+                const uint4 snd = hi ? A : B; uint4 rcv; \
+                rcv.x = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd.x, CTRL, 0xf, 0xf, true); \
+                rcv.y = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd.y, CTRL, 0xf, 0xf, true); \
+                rcv.z = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd.z, CTRL, 0xf, 0xf, true); \
+                rcv.w = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd.w, CTRL, 0xf, 0xf, true); \
+                if (hi) A = rcv; else B = rcv; }
+            LH_XSWAP(ca, cb, 0xB1, 1)       /* quad_perm [1,0,3,2] */
+            LH_XSWAP(cc, cr, 0xB1, 1)
+            LH_XSWAP(ca, cc, 0x4E, 2)       /* quad_perm [2,3,0,1] */
+            LH_XSWAP(cb, cr, 0x4E, 2)
+#undef LH_XSWAP
+        }
         if (L.cur >= 0) {
-            const uint4 *p = (const uint4 *)sc.q4nodes + 4 * (size_t)L.cur;
-            const uint4 a = p[0], b = p[1], c = p[2], r = p[3];
+            uint4 a, b, c, r;
+            if (COOP) { a = ca; b = cb; c = cc; r = cr; }
+            else { const uint4 *p = (const uint4 *)sc.q4nodes + 4 * (size_t)L.cur; a = p[0]; b = p[1]; c = p[2]; r = p[3]; }
             if (COUNT) c_nodes++;
             float t0, t1, t2, t3;
             const bool h0 = slab_w(L, a.x, a.y, a.z, t0) & ((int)r.x != kDone);
@@ -755,6 +782,8 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
             if (L.cur != kDone) traverse_unified4<ANYHIT, COUNT>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
         } else if (WALK == 3) {
             traverse_spec4<ANYHIT, COUNT, false, false>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
+        } else if (WALK == 9) {          /* A/B: quad-coalesced node fetch */
+            traverse_spec4<ANYHIT, COUNT, false, false, true>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
         } else if (WALK == 8) {          /* the same with the stack check: trees whose worst case the LDS rows do not cover */
             traverse_spec4<ANYHIT, COUNT, false, true>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
         } else if (WALK == 7) {
@@ -899,6 +928,9 @@ int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const doub
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
         else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2 && sc.stack_guard)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 8, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
+        else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2 && sc.tri_prefetch == 2)
+            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 9, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
         else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2 && sc.tri_prefetch)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 6, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
