@@ -835,8 +835,6 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
     else if (!strcmp(name, "ao_fused")) a->ao_fused = value != 0;
     else if (!strcmp(name, "wide8") && value >= -1 && value <= 1) a->wide8 = value;
     else if (!strcmp(name, "quad_grid") && value > 0) a->quad_grid = value;
-    else if (!strcmp(name, "tri_prefetch")) a->dev.tri_prefetch = value != 0;
-    else if (!strcmp(name, "coop_fetch")) a->dev.tri_prefetch = value ? 2 : 0;      /* A/B: quad-coalesced node fetch (same switch word) */
     else if (!strcmp(name, "stack_cap") && (value == 0 || (value >= 8 && value <= 64 && value % 2 == 0))) a->dev.stack_cap = (uint32_t)value;
     else return fail("lh_accel_set_param: unknown parameter or bad value: %s = %d", name, value);
     return 0;
@@ -940,7 +938,7 @@ static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
      * nodes: each record then costs a 128-byte line of HBM traffic whatever its size, and an 8-wide record uses all of it
      * (S-soup-10M: 57 -> 40 records per ray).  The tile pipelines' coherent rays stay on the 4-wide nodes. */
     a->dev.prefer_q8 = 0;
-    if (dump && variant == LH_VARIANT_SPEC && a->dev.use_qnodes == 2 && !a->hs->device_built && !a->dev.tri_prefetch &&
+    if (dump && variant == LH_VARIANT_SPEC && a->dev.use_qnodes == 2 && !a->hs->device_built &&
         (a->wide8 == 1 || (a->wide8 == -1 && wide8_pays(a)))) {
         if (ensure_formats(a, LH_FMT_Q8) != 0) return -1;
         a->dev.prefer_q8 = 1;
@@ -992,7 +990,7 @@ extern "C" int lh_accel_intersect_device_counted(lh_accel_t *a, size_t n, const 
 extern "C" int lh_accel_dump_node_bytes(const lh_accel_t *a)
 {
     if (!a || !a->committed || a->hs->bvh.ntris == 0) return 0;
-    if (a->default_variant == LH_VARIANT_SPEC && a->dev.use_qnodes == 2 && !a->hs->device_built && !a->dev.tri_prefetch &&
+    if (a->default_variant == LH_VARIANT_SPEC && a->dev.use_qnodes == 2 && !a->hs->device_built &&
         (a->wide8 == 1 || (a->wide8 == -1 && wide8_pays(a)))) return (int)sizeof(lh_q8node_t);
     return a->dev.use_qnodes == 0 ? 64 : a->dev.use_qnodes == 1 ? 32 : a->dev.use_qnodes == 3 ? 80 : 64;
 }

@@ -43,7 +43,6 @@ typedef struct lh_dev_scene {
     uint32_t    max_depth;
     float       scene_r;   /* max |coordinate| of the scene box              */
     uint32_t    ray_chunk; /* rays a persistent wave reserves per atomic on the global cursor */
-    int         tri_prefetch;   /* A/B: the 4-wide walk loads a parked leaf's triangle when it parks it */
     int         stack_guard;    /* set by the launchers when the LDS rows do not cover the tree's worst case: the walks check before they push */
     uint32_t    stack_cap; /* 0: 64 LDS stack rows at most; 8..62: a lower cap (tests of the overflow path) */
     int         nodes_2wide_available;   /* host-built scenes: the 2-wide formats can be uploaded on demand (deep-tree fallback) */

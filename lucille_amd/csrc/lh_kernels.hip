@@ -247,16 +247,14 @@ __device__ __forceinline__ void traverse_spec(Lane &L, int &pend, const lh_dev_s
  * nearest on top; misses: above the new top, i.e. into free space) and the next reference
  * is read back from the new top -- which is the nearest hit, or the previous top when
  * nothing was hit (a pop).  Leaves are parked and tested in batches as in traverse_spec. */
-struct TriRegs { float4 a, b, c; bool need; };      /* PF: the parked leaf's next triangle record, loaded one step ahead of its test */
-
-template <bool ANYHIT, bool COUNT, bool PF, bool GUARD, bool COOP = false>
+template <bool ANYHIT, bool COUNT, bool GUARD>
 __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_scene_t &sc,
                                                int (*stk)[LH_BLOCK], const int tid,
                                                double ox, double oy, double oz,
                                                double dx, double dy, double dz, Best &best,
                                                uint32_t &c_nodes, uint32_t &c_tris, uint32_t &c_exact,
                                                const int min_active, const int tri_batch,
-                                               uint32_t &c_nslots, uint32_t &c_tslots, TriRegs &pf)
+                                               uint32_t &c_nslots, uint32_t &c_tslots)
 {
     const float4 *__restrict__ tris  = (const float4 *)sc.tri32;
     constexpr int kNoLeaf = 0;
@@ -264,49 +262,13 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
     const int rows = (int)sc.stack_rows;
     for (;;) {
         if (COUNT) { if (__ballot(L.cur >= 0) != 0ull) c_nslots++; }
-        /* PF: a parked leaf's triangle is requested here, in front of the node record, and tested one step later: both
-         * requests are in flight together and the triangle pass never waits for memory */
-        const bool fresh = PF && pf.need && pend != kNoLeaf;          /* requested in this step: tested in a later one */
-        float4 na, nb, nc;                        /* landing registers: copied into pf after the node record has arrived */
-        if (fresh) {
-            const float4 *tp = tris + 3 * (size_t)((~(uint32_t)pend) >> 2);
-            na = tp[0]; nb = tp[1]; nc = tp[2];
-        }
-        if (PF) pf.need = false;
         /* the step below writes up to slot sp + 3.  rows = 3 * depth + 5 covers every ray of a tree that deep; a deeper
          * tree (an LBVH built on the device over a degenerate distribution) gets 64 rows and a ray that would overrun them
          * is finished by k_overflow_fix with a private stack -- same arithmetic, same answer */
         if (GUARD && L.cur >= 0 && L.sp + 4 > rows) { L.over = true; L.cur = kDone; pend = kNoLeaf; }     /* a separate instantiation: the check costs the path-traced frame 4 % */
-        uint4 ca, cb, cc, cr;
-        if (COOP && __ballot(L.cur >= 0) != 0ull) {
-            /* quad-coalesced fetch (A/B): in phase p every lane of a quad loads one 16-byte piece of quad-lane p's node -- four
-             * lanes, one contiguous 64-byte request -- and the quad transposes the pieces with DPP.  Lanes without a node
-             * step read node 0.  (gather microbenchmark mode 8: 147 instead of 129 G records/s) */
-            const int j = tid & 3;
-            const uint32_t mc = L.cur >= 0 ? (uint32_t)L.cur : 0u;
-            const uint4 *q = (const uint4 *)sc.q4nodes + j;
-#define LH_QB(v, P) (uint32_t)__builtin_amdgcn_mov_dpp((int)(v), (P) * 0x55, 0xf, 0xf, true)
-            ca = q[4 * (size_t)LH_QB(mc, 0)]; cb = q[4 * (size_t)LH_QB(mc, 1)];
-            cc = q[4 * (size_t)LH_QB(mc, 2)]; cr = q[4 * (size_t)LH_QB(mc, 3)];
-#undef LH_QB
-#define LH_XSWAP(A, B, CTRL, BIT) { \
-                const bool hi = (j & (BIT)) != 0; \
-                const uint4 snd = hi ? A : B; uint4 rcv; \
-                rcv.x = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd.x, CTRL, 0xf, 0xf, true); \
-                rcv.y = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd.y, CTRL, 0xf, 0xf, true); \
-                rcv.z = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd.z, CTRL, 0xf, 0xf, true); \
-                rcv.w = (uint32_t)__builtin_amdgcn_mov_dpp((int)snd.w, CTRL, 0xf, 0xf, true); \
-                if (hi) A = rcv; else B = rcv; }
-            LH_XSWAP(ca, cb, 0xB1, 1)       /* quad_perm [1,0,3,2] */
-            LH_XSWAP(cc, cr, 0xB1, 1)
-            LH_XSWAP(ca, cc, 0x4E, 2)       /* quad_perm [2,3,0,1] */
-            LH_XSWAP(cb, cr, 0x4E, 2)
-#undef LH_XSWAP
-        }
         if (L.cur >= 0) {
-            uint4 a, b, c, r;
-            if (COOP) { a = ca; b = cb; c = cc; r = cr; }
-            else { const uint4 *p = (const uint4 *)sc.q4nodes + 4 * (size_t)L.cur; a = p[0]; b = p[1]; c = p[2]; r = p[3]; }
+            const uint4 *p = (const uint4 *)sc.q4nodes + 4 * (size_t)L.cur;
+            const uint4 a = p[0], b = p[1], c = p[2], r = p[3];
             if (COUNT) c_nodes++;
             float t0, t1, t2, t3;
             const bool h0 = slab_w(L, a.x, a.y, a.z, t0) & ((int)r.x != kDone);
@@ -335,27 +297,23 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
             pend = park ? nxt : pend;
             L.cur = park ? popped2 : nxt;
             L.sp -= park ? 1 : 0;
-            if (PF) pf.need = pf.need | park;
         }
-        if (fresh) { pf.a = na; pf.b = nb; pf.c = nc; }
-        const bool ready = (pend != kNoLeaf) & !(PF && (fresh | pf.need));      /* PF: only triangles that have arrived */
         const unsigned long long m_node = __ballot(L.cur >= 0);
-        const unsigned long long m_pend = __ballot(ready);
+        const unsigned long long m_pend = __ballot(pend != kNoLeaf);
         if (m_pend != 0ull && (__popcll(m_pend) >= tri_batch || m_node == 0ull)) {
             if (COUNT) c_tslots++;
-            if (ready) {
+            if (pend != kNoLeaf) {
                 const uint32_t x = ~(uint32_t)pend;
-                float4 ta, tb_, tc;
-                if (PF) { ta = pf.a; tb_ = pf.b; tc = pf.c; }
-                else { const float4 *tp = tris + 3 * (size_t)(x >> 2); ta = tp[0]; tb_ = tp[1]; tc = tp[2]; }
+                const float4 *tp = tris + 3 * (size_t)(x >> 2);
+                const float4 ta = tp[0], tb_ = tp[1], tc = tp[2];
                 if (COUNT) c_tris++;
                 const bool finished = tri_step<ANYHIT, COUNT>(L, sc, ta.x, ta.y, ta.z, ta.w, tb_.x, tb_.y, tb_.z, tb_.w, tc.x, tc.z, tc.w, __float_as_uint(tc.y), ox, oy, oz, dx, dy, dz, best, c_exact);
                 if (finished) { L.cur = kDone; pend = kNoLeaf; }
-                else if (x & 3u) { pend = (int)~(((x >> 2) + 1u) << 2 | ((x & 3u) - 1u)); if (PF) pf.need = true; }
+                else if (x & 3u) pend = (int)~(((x >> 2) + 1u) << 2 | ((x & 3u) - 1u));
                 else {
                     const bool waiting = (L.cur < 0) & (L.cur != kDone);
                     pend = waiting ? L.cur : kNoLeaf;
-                    if (waiting) { L.sp--; L.cur = stk[L.sp][tid]; if (PF) pf.need = true; }
+                    if (waiting) { L.sp--; L.cur = stk[L.sp][tid]; }
                 }
             }
         }
@@ -710,7 +668,6 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
     uint32_t cn = 0, ct = 0, ce = 0, cr = 0, cns = 0, cts = 0, crs = 0;
     Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM, 0u};
     int pend = 0;                    /* WALK 2: parked leaf reference (0 = none) */
-    TriRegs pf = {};                 /* WALK 6: that leaf's next triangle, already loaded */
     size_t my = (size_t)-1;          /* ray this lane is working on */
     double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
     L.cur = kDone; L.sp = 1; L.np = 0; L.certain = false; L.over = false;
@@ -781,15 +738,11 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         } else if (WALK == 4) {
             if (L.cur != kDone) traverse_unified4<ANYHIT, COUNT>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh);
         } else if (WALK == 3) {
-            traverse_spec4<ANYHIT, COUNT, false, false>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
-        } else if (WALK == 9) {          /* A/B: quad-coalesced node fetch */
-            traverse_spec4<ANYHIT, COUNT, false, false, true>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
+            traverse_spec4<ANYHIT, COUNT, false>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts);
         } else if (WALK == 8) {          /* the same with the stack check: trees whose worst case the LDS rows do not cover */
-            traverse_spec4<ANYHIT, COUNT, false, true>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
+            traverse_spec4<ANYHIT, COUNT, true>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts);
         } else if (WALK == 7) {
             traverse_spec8<ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts);
-        } else if (WALK == 6) {
-            traverse_spec4<ANYHIT, COUNT, true, false>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, pf);
         } else if (WALK == 2) {
             /* every lane enters (idle lanes just vote in the ballots) */
             traverse_spec<ANYHIT, COUNT, QN>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch);
@@ -928,12 +881,6 @@ int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const doub
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
         else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2 && sc.stack_guard)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 8, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
-        else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2 && sc.tri_prefetch == 2)
-            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 9, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
-        else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2 && sc.tri_prefetch)
-            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 6, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
         else if (variant == LH_VARIANT_SPEC && sc.use_qnodes == 2)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 3, true, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,

@@ -368,23 +368,6 @@ def test_scaled_translated_degenerate_scenes(kind, log_scale, off):
     assert np.array_equal(gpu_any(acc, org, dr, la.VARIANT_DEFAULT).astype(bool), exp[0] != po.MISS)
 
 
-def test_triangle_prefetch_walk_equals_default():
-    """set_param("tri_prefetch", 1): the 4-wide walk with a parked leaf's triangle requested one step ahead (A/B, opt-in)"""
-    import torch
-    P, idx, st = scenes.soup_triangles(300000, 0.008)
-    ho, hd, _ = scenes.soup_rays(1500000, st)
-    o = torch.from_numpy(ho).cuda(); d = torch.from_numpy(hd).cuda()
-    acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit()
-    ref_c = [x.clone() for x in acc.intersect_device(o, d)]; ref_a = acc.intersect_device(o, d, mode=la.MODE_ANY)[0].clone()
-    acc.set_param("tri_prefetch", 1)
-    for tb in (1, 8, 32):
-        acc.set_param("tri_batch", tb)
-        got = acc.intersect_device(o, d)
-        assert all(torch.equal(a, b) for a, b in zip(got, ref_c)), tb
-        assert torch.equal(acc.intersect_device(o, d, mode=la.MODE_ANY)[0], ref_a), tb
-    acc.close()
-
-
 def test_eight_wide_walk_parity():
     """the 8-wide 16-bit-grid nodes (lh_q8node_t, 128-byte records: what ray dumps walk on scenes larger than the Infinity
     Cache; forced here with set_param("wide8", 1)): goldens, seeded soups against the oracle, exact-t ties, deep chains,
