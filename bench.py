@@ -535,7 +535,7 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
     acc.commit()
     c = g["camera"]
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
-    times = []; st = None; img = None
+    times = []; st = None; img = None; first = None; repeat = True
     for it in range(3):
         if world > 1:
             torch.distributed.barrier()
@@ -550,6 +550,20 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
             torch.distributed.barrier()
         if it > 0:
             times.append(time.perf_counter() - t0)
+        if rank == 0:
+            if it == 0:
+                first = img.clone()
+            else:
+                repeat = repeat and bool(torch.equal(img, first))
+    retiled = None
+    if world == 1:
+        # the same frame cut into four tiles (other wavefront sizes, other compaction orders): every pixel's paths are keyed by
+        # (pixel, sample), so the image must not change by a bit
+        t2 = size // 2
+        img2, _ = render.render_pt_frame_sharded(acc, cam, spp, rank, world, tile=t2, spp_chunk=max(1, min(spp, (64 << 20) // (t2 * t2))),
+                                                 kd=0.8, env=(1.0, 1.0, 1.0), max_vertices=8, seed=7)
+        torch.cuda.synchronize(dev)
+        retiled = bool(torch.equal(img2, img)); del img2
     rdev = dev if (world == 1 or torch.distributed.get_backend() == "nccl") else torch.device("cpu")
     rays = torch.tensor([float(st["rays"])], dtype=torch.float64, device=rdev)
     tmax = torch.tensor([min(times)], dtype=torch.float64, device=rdev)
@@ -562,7 +576,11 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
                         % (size, size, spp),
             "rays_per_frame": int(rays.item()), "frame_ms": round(tmax.item() * 1e3, 3),
             "value": round(rays.item() / tmax.item() / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
-            "image_mean": float(img.mean().item())}
+            "image_mean": float(img.mean().item()),
+            # white furnace with albedo 0.8 under a unit environment: every pixel's radiance lies in (0, 1]
+            "validation": {"frames_repeat": repeat, "retiled_frame_bit_equal": retiled,
+                           "radiance_in_0_1": bool(float(img.min().item()) >= 0.0 and float(img.max().item()) <= 1.0 + 1e-6),
+                           "ok": repeat and retiled is not False and 0.0 < float(img.mean().item()) <= 1.0}}
 
 
 def cpu_baseline(P, idx, org, dr):
