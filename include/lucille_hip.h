@@ -304,7 +304,8 @@ int  lh_accel_beam_visibility_device(lh_accel_t *accel, size_t n, const void *d_
 /* whole AO frame into HOST memory: the tile loop of render_frame_controller + bucket_write
  * (src/render/render.c:1168-1207, 919-983) over lh_render_ao_tile.  rgb: height rows of width RGB
  * float triples, top row first (bucket_write's y flip applied) -- what the reference hands its
- * display driver.  tile = tile edge in pixels (0: 1024).  stats may be NULL. */
+ * display driver.  tile = tile edge in pixels (0: the largest power of two <= 4096 whose per-tile scratch stays under ~6 GB).
+ * stats may be NULL. */
 int  lh_render_ao_frame_host(lh_accel_t *accel, const lh_camera_t *cam, int pixel_samples,
                              int gather_nsamples, uint64_t seed, int tile, float *rgb,
                              lh_tile_stats_t *stats);

@@ -1642,7 +1642,15 @@ extern "C" int lh_render_ao_frame_host(lh_accel_t *a, const lh_camera_t *cam, in
     if (!a || !a->committed) return fail("lh_render_ao_frame_host: accel not committed");
     if (!cam || !rgb) return fail("lh_render_ao_frame_host: NULL argument");
     if (cam->width <= 0 || cam->height <= 0) return fail("lh_render_ao_frame_host: bad resolution");
-    if (tile <= 0) tile = 1024;
+    if (tile <= 0) {
+        /* default tile: the largest power of two (<= 4096) whose scratch stays under ~6 GB.  Per sub-sample: ~200 B of ray /
+         * hit / epilogue records, plus 49 B per AO ray when the AO stage has to materialise its rays (LH_AO_FUSED=0):
+         * ambient_occlusion.rib's own 3 x 3 pixel samples x 64 AO rays would otherwise ask for 30 GB per 1024^2 tile */
+        const int N = gather_nsamples > 0 ? gather_nsamples : 1;
+        const double per_pixel = (double)(ps > 0 ? ps : 1) * (ps > 0 ? ps : 1) * (200.0 + (a->ao_fused ? 0.0 : 49.0 * N));
+        tile = 4096;
+        while (tile > 64 && (double)tile * tile * per_pixel > 6.0e9) tile /= 2;
+    }
     HIPCHK(hipSetDevice(a->device));
     const int W = cam->width, H = cam->height;
     if (ensure_buf(&a->r_frame, (size_t)tile * tile * 3 * sizeof(float))) return -1;
