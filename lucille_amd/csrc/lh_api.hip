@@ -918,6 +918,8 @@ static int launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
     if (a->hs->device_built && !a->d_ref_nodes && sync_ref(a, false) != 0) return -1;     /* background reference tree: attach when ready */
     if (variant == LH_VARIANT_DEFAULT) variant = a->default_variant;
     if (variant < 0 || variant > LH_VARIANT_QUAD) return fail("intersect: unknown variant %d", variant);
+    /* a tree built on the device exists only as 4-wide nodes: the A/B walks over other formats run as the default walk */
+    if (a->hs->device_built && variant != LH_VARIANT_SPEC && variant != LH_VARIANT_LEAN && variant != LH_VARIANT_QUAD) variant = LH_VARIANT_SPEC;
     if (variant == LH_VARIANT_LEAN) {
         /* the lean walk reads the 4-wide 16-bit-grid nodes; scenes it cannot take (another format forced by
          * LH_NODE_FORMAT, a tree too deep for its 64-entry logical stack) go through the r01 walk */
