@@ -497,6 +497,22 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
     if world == 1:
         img2, st2 = render.render_ao_frame(acc, cam, 1, nsamples, tile=max(256, size // 4))
         ok = ok and bool(torch.equal(img, img2)) and st2 == stats[0]
+    # what the frame's rays cost: one more frame (untimed) through the counting instantiations of the same kernels
+    roof = None
+    if world == 1:
+        acc.trace_statistics(True); acc.statistics(clear=True)
+        render.render_ao_frame(acc, cam, 1, nsamples, tile=tile); torch.cuda.synchronize(dev)
+        c = acc.statistics(clear=True); acc.trace_statistics(False)
+        nr = max(1, c["rays"])
+        # algorithmic bytes: 64 B per node visit, 40 B per triangle test; camera rays also 48 B in + 28 B out (their records go
+        # through HBM to the epilogue), AO rays nothing (generated and counted inside the kernel: 4 B per hit slot)
+        b_frame = 64.0 * c["nodes"] + 40.0 * c["tris"] + (48.0 + 28.0) * st["primary_rays"] + 4.0 * st["primary_hits"]
+        roof = {"bound": "hbm", "achieved": round(b_frame / min(times) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(b_frame / min(times) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                "nodes_per_ray": round(c["nodes"] / nr, 2), "tris_per_ray": round(c["tris"] / nr, 2), "exact_per_ray": round(c["exact"] / nr, 4),
+                "rays_counted": c["rays"],
+                "note": "coherent rays: the frame is bound by instruction issue and dependent-fetch latency, not by bytes (fabric traffic "
+                        "0.15 KB per ray, VALU 57 % busy at 71 % lane use: profiles/r02b_pmc_ao_config5_sq_tcc.txt)"}
     rdev = dev if (world == 1 or torch.distributed.get_backend() == "nccl") else torch.device("cpu")
     rays = torch.tensor([st["primary_rays"] + st["ao_rays"]], dtype=torch.float64, device=rdev)
     tmax = torch.tensor([min(times)], dtype=torch.float64, device=rdev)
@@ -515,7 +531,7 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
             "ref_tree_build_s": round(info["ref_build_seconds"], 3),
             "rays_per_frame": int(rays.item()), "frame_ms": round(tmax.item() * 1e3, 3),
             "value": round(rays.item() / tmax.item() / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
-            "image_mean": float(img.mean().item()),
+            "image_mean": float(img.mean().item()), "roofline": roof,
             "validation": {"frames_repeat": bool(okt.item() > 0.5), "retiled_frame_bit_equal": bool(ok) if world == 1 else None,
                            "primary_hits": int(stats[0]["primary_hits"]) if world == 1 else None, "ok": bool(okt.item() > 0.5)}}
 
@@ -564,6 +580,24 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
                                                  kd=0.8, env=(1.0, 1.0, 1.0), max_vertices=8, seed=7)
         torch.cuda.synchronize(dev)
         retiled = bool(torch.equal(img2, img)); del img2
+    roof = None
+    if world == 1:
+        # one more frame (untimed) through the counting instantiation of the trace kernel.  Every ray of every bounce goes
+        # through HBM as fp64 records: 48 B written by the shader, 48 B read by the trace kernel, 28 B of hit record written
+        # and read again by the shader; plus 64 B per node visit and 40 B per triangle test
+        acc.trace_statistics(True); acc.statistics(clear=True)
+        render.render_pt_frame_sharded(acc, cam, spp, rank, world, tile=size, spp_chunk=max(1, min(spp, (64 << 20) // (size * size))),
+                                       kd=0.8, env=(1.0, 1.0, 1.0), max_vertices=8, seed=7)
+        torch.cuda.synchronize(dev)
+        c = acc.statistics(clear=True); acc.trace_statistics(False)
+        nr = max(1, c["rays"])
+        b_frame = 64.0 * c["nodes"] + 40.0 * c["tris"] + (2 * 48.0 + 2 * 28.0) * c["rays"]
+        roof = {"bound": "hbm", "achieved": round(b_frame / min(times) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(b_frame / min(times) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                "nodes_per_ray": round(c["nodes"] / nr, 2), "tris_per_ray": round(c["tris"] / nr, 2), "exact_per_ray": round(c["exact"] / nr, 4),
+                "rays_counted": c["rays"],
+                "note": "1 986 triangles: the tree is L2-resident; the frame is a chain of ~110 dependent launches per pass (trace, decide, "
+                        "scan, emit per bounce), the trace kernel is 59 % of the kernel time (profiles/r02d_pt_kernel_stats.csv)"}
     rdev = dev if (world == 1 or torch.distributed.get_backend() == "nccl") else torch.device("cpu")
     rays = torch.tensor([float(st["rays"])], dtype=torch.float64, device=rdev)
     tmax = torch.tensor([min(times)], dtype=torch.float64, device=rdev)
@@ -576,7 +610,7 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
                         % (size, size, spp),
             "rays_per_frame": int(rays.item()), "frame_ms": round(tmax.item() * 1e3, 3),
             "value": round(rays.item() / tmax.item() / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
-            "image_mean": float(img.mean().item()),
+            "image_mean": float(img.mean().item()), "roofline": roof,
             # white furnace with albedo 0.8 under a unit environment: every pixel's radiance lies in (0, 1]
             "validation": {"frames_repeat": repeat, "retiled_frame_bit_equal": retiled,
                            "radiance_in_0_1": bool(float(img.min().item()) >= 0.0 and float(img.max().item()) <= 1.0 + 1e-6),

@@ -129,10 +129,12 @@ int lh_accel_dump_node_bytes(const lh_accel_t *accel);
 
 /* ---- traversal statistics: ri_bvh_clear_stat_traversal / ri_bvh_report_stat_traversal ----
  * reference: src/render/bvh.c:669-706 (globals filled under -DRI_BVH_TRACE_STATISTICS,
- * :681-706, 829-831, 1149-1151).  While enabled, every lh_accel_intersect1/_host call runs
+ * :681-706, 829-831, 1149-1151).  While enabled, every lh_accel_intersect1/_host call and every
+ * batch of the tile pipelines (lh_render_ao_tile / _bands / _frame_host, lh_render_pt_tile*) runs
  * the counting kernel variant and accumulates: counters[0] node visits (one per 4-wide node
  * record fetched), [1] triangles put through the fp32 filter, [2] triangles re-tested in
- * fp64, [3] rays, [4] rays that hit.  Counts describe THIS build's tree, not lucille's. */
+ * fp64, [3] rays, [4] rays that hit (AO pipeline: camera-ray hits + occluded AO rays; not counted by
+ * the path tracer).  Counts describe THIS build's tree, not lucille's. */
 int  lh_accel_trace_statistics(lh_accel_t *accel, int enable);
 int  lh_accel_statistics(lh_accel_t *accel, uint64_t counters[5], int clear);
 

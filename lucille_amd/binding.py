@@ -356,6 +356,16 @@ class HipAccel:
                "lh_accel_intersect_device")
         return out
 
+    def trace_statistics(self, enable=True):
+        """ri_bvh_clear_stat_traversal / RI_BVH_TRACE_STATISTICS: count node visits, triangle tests, fp64 re-tests, rays and hits of
+        the host ray dumps and of the AO tile pipeline (the counting instantiations of the same kernels)"""
+        _check(self.L.lh_accel_trace_statistics(self.h, 1 if enable else 0), "lh_accel_trace_statistics")
+
+    def statistics(self, clear=False):
+        c = (C.c_uint64 * 5)()
+        _check(self.L.lh_accel_statistics(self.h, c, 1 if clear else 0), "lh_accel_statistics")
+        return dict(zip(("nodes", "tris", "exact", "rays", "hits"), (int(x) for x in c)))
+
     def dump_node_bytes(self):
         """64: ray dumps walk the 4-wide nodes; 128: the 8-wide nodes (scene larger than the Infinity Cache, or wide8 = 1)"""
         return int(self.L.lh_accel_dump_node_bytes(self.h))

@@ -1228,13 +1228,16 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
     if (ensure_buf(&a->r_org, S * 24) || ensure_buf(&a->r_dir, S * 24) || ensure_buf(&a->r_prim, S * 4) ||
         ensure_buf(&a->r_t, S * 8) || ensure_buf(&a->r_u, S * 8) || ensure_buf(&a->r_v, S * 8) ||
         ensure_buf(&a->r_slot, S * 4) || ensure_buf(&a->r_blocks, (size_t)nb * 4)) return -1;
+    /* lh_accel_trace_statistics: the counting instantiations of the same kernels, accumulated over the batch */
+    unsigned long long *cnt = (a->stat_on && a->hs->bvh.ntris) ? a->d_counters : NULL;
+    if (cnt) HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * LH_CNT_DEV, s));
     /* 1. camera rays */
     if (lh_render_launch_primary_region(cam, x0, w, nbands, band_rows, d_band_y0, y0, cam->height, ps, ps,
                                         (double *)a->r_org.p, (double *)a->r_dir.p, s) != 0)
         return fail("primary ray kernel launch failed");
     /* 2. closest hit */
     if (launch(a, S, a->r_org.p, a->r_dir.p, a->r_prim.p, a->r_t.p, a->r_u.p, a->r_v.p, NULL, LH_MODE_CLOSEST,
-               LH_VARIANT_DEFAULT, NULL, s) != 0) return -1;
+               LH_VARIANT_DEFAULT, cnt, s) != 0) return -1;
     /* 3. count hits (deterministic compaction needs the total before sizing the AO batch) */
     unsigned long long nhit = 0;
     if (a->hs->bvh.ntris) {
@@ -1257,6 +1260,7 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
      * replay), LH_AO_FUSED=0, a scene the lean walk cannot take, or a pending-queue overflow of the fused launch. */
     bool fused = a->ao_fused && !d_uniforms && nao && nao < ((size_t)1 << 32) && a->dev.use_qnodes == 2 &&
                  ((3 * a->dev.q4_depth + 5 <= 64 && !a->dev.stack_cap) || a->dev.ref_nodes != NULL);     /* deeper: rays whose stack would overflow go to the reference walk */
+    const bool fused_tried = fused;
     if (fused) {
         if (ensure_buf(&a->r_occcount, (size_t)nhit * sizeof(unsigned int))) return -1;
         const int k = t2_slot(a, s, a->default_variant == LH_VARIANT_LEAN);
@@ -1268,7 +1272,7 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
                                       a->min_active, a->tri_batch, a->t2[k].spill, a->t2[k].queue, a->t2[k].qcount, LH_T2_QCAP, (void *)s);
         else {
             rcf = lh_launch_trace_ao(&a->dev, (size_t)nhit, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const unsigned long long *)a->r_key.p,
-                                     (unsigned int *)a->r_occcount.p, NULL, a->d_cursor + (a->cursor_next++ % LH_NCURSOR), a->grid_blocks,
+                                     (unsigned int *)a->r_occcount.p, cnt, a->d_cursor + (a->cursor_next++ % LH_NCURSOR), a->grid_blocks,
                                      a->min_active, a->tri_batch, a->t2[k].queue, a->t2[k].qcount, LH_T2_QCAP, (void *)s);
             if (rcf == 0) rcf = lh_launch_ao_queue(&a->dev, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const unsigned long long *)a->r_key.p,
                                                    (unsigned int *)a->r_occcount.p, NULL, a->t2[k].queue, a->t2[k].qcount, LH_T2_QCAP, (void *)s);
@@ -1286,8 +1290,9 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
                                      (const unsigned long long *)a->r_key.p, (double *)a->r_aorg.p, (double *)a->r_adir.p, s) != 0)
             return fail("AO ray kernel launch failed");
         /* 5. any-hit */
+        if (cnt && fused_tried) HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * LH_CNT_DEV, s));   /* the abandoned fused pass is not counted (nor are the camera rays then) */
         if (launch(a, nao, a->r_aorg.p, a->r_adir.p, NULL, NULL, NULL, NULL, a->r_occ.p, LH_MODE_ANY,
-                   LH_VARIANT_DEFAULT, NULL, s) != 0) return -1;
+                   LH_VARIANT_DEFAULT, cnt, s) != 0) return -1;
     }
     /* 6. radiance */
     HIPCHK(hipMemsetAsync(a->d_total, 0, sizeof(unsigned long long), s));
@@ -1297,6 +1302,12 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
     HIPCHK(hipMemcpyAsync(&nocc, a->d_total, sizeof(nocc), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     a->r_nsamples = S; a->r_nslots = (size_t)nhit; a->r_nao = fused ? 0 : nao;
+    if (cnt) {
+        unsigned long long hc[LH_CNT_N];
+        HIPCHK(hipMemcpy(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost));
+        a->stat[0] += hc[LH_CNT_NODES]; a->stat[1] += hc[LH_CNT_TRIS]; a->stat[2] += hc[LH_CNT_EXACT];
+        a->stat[3] += hc[LH_CNT_RAYS]; a->stat[4] += nhit + nocc;
+    }
     if (stats) {
         stats->primary_rays = valid_pixels * (uint64_t)(ps * ps); stats->primary_hits = nhit; stats->ao_rays = nao; stats->ao_occluded = nocc;
     }
@@ -1572,6 +1583,8 @@ static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w,
     hipStream_t s = (hipStream_t)stream;
     const size_t S = (size_t)w * h * spp;
     if (S >= ((size_t)1 << 31)) return fail("lh_render_pt_tile: more than 2^31 paths in one pass; lower spp_count or the tile size");
+    unsigned long long *cnt = (a->stat_on && a->hs->bvh.ntris) ? a->d_counters : NULL;      /* lh_accel_trace_statistics */
+    if (cnt) HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * LH_CNT_DEV, s));
     const unsigned nb = (unsigned)((S + 255) / 256);
     if (ensure_buf(&a->r_org, S * 24) || ensure_buf(&a->r_dir, S * 24) || ensure_buf(&a->p_org2, S * 24) ||
         ensure_buf(&a->p_dir2, S * 24) || ensure_buf(&a->r_prim, S * 4) || ensure_buf(&a->r_t, S * 8) ||
@@ -1585,7 +1598,7 @@ static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w,
     if (lh_pt_launch_primary(cam, x0, y0, w, h, spp, s0, seed, org, dir, path, thr, s) != 0) return fail("pt primary launch failed");
     size_t n = S; uint64_t rays = 0; int depth = 0;
     while (n > 0) {
-        if (launch(a, n, org, dir, a->r_prim.p, a->r_t.p, a->r_u.p, a->r_v.p, NULL, LH_MODE_CLOSEST, LH_VARIANT_DEFAULT, NULL, s) != 0) return -1;
+        if (launch(a, n, org, dir, a->r_prim.p, a->r_t.p, a->r_u.p, a->r_v.p, NULL, LH_MODE_CLOSEST, LH_VARIANT_DEFAULT, cnt, s) != 0) return -1;
         rays += n;
         if (lh_pt_launch_shade(n, &a->dev, (const double *)a->d_nrm9, (const double *)a->d_attr9[0], (const uint32_t *)a->d_prim_mesh,
                                a->d_materials, override_mat, env_rgb, d_env_map, env_w, env_h, (flags & LH_PT_REFERENCE_WEIGHTS) != 0,
@@ -1603,6 +1616,11 @@ static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w,
     if (lh_pt_launch_resolve(w, h, spp, 1.0f / (float)spp_total, (const float *)a->p_rad.p, (float *)d_rgb, s) != 0)
         return fail("pt resolve launch failed");
     HIPCHK(hipStreamSynchronize(s));
+    if (cnt) {
+        unsigned long long hc[LH_CNT_N];
+        HIPCHK(hipMemcpy(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost));
+        a->stat[0] += hc[LH_CNT_NODES]; a->stat[1] += hc[LH_CNT_TRIS]; a->stat[2] += hc[LH_CNT_EXACT]; a->stat[3] += hc[LH_CNT_RAYS];
+    }
     if (stats) { stats->paths = S; stats->rays = rays; stats->max_depth_reached = (uint64_t)depth; }
     return 0;
 }

@@ -221,3 +221,29 @@ def test_fused_ao_stage_equals_materialised_rays(c1, ps):
         if case is c1:                                                    # flat-shaded scene: orthonormal basis
             n = np.linalg.norm(adir, axis=1)
             assert np.all(np.abs(n - 1.0) < 1e-6)                         # fp32 trigonometry, fp64 basis
+
+
+def test_traversal_statistics_cover_the_tile_pipelines():
+    """lh_accel_trace_statistics (ri_bvh_clear_stat_traversal / report, bvh.c:669-706) also counts the rays the AO and path-tracing
+    pipelines trace on the device: rays == camera rays + AO rays of the frame, frames unchanged by counting"""
+    import torch
+    g = load_golden("ao_c1")
+    acc = la.HipAccel(0)
+    for k in range(int(g["ngeoms"])):
+        acc.add_mesh(g["pos%d" % k], g["idx%d" % k])
+    acc.commit()
+    c = g["camera"]; cam = la.Camera.make(96, 64, c[16], c[:16], int(c[19]))
+    ref, st0 = render.render_ao_frame(acc, cam, 2, 16, tile=96, seed=11)
+    acc.trace_statistics(True); acc.statistics(clear=True)
+    img, st = render.render_ao_frame(acc, cam, 2, 16, tile=96, seed=11)
+    s = acc.statistics(clear=True)
+    assert torch.equal(img, ref) and st == st0
+    assert s["rays"] == st["primary_rays"] + st["ao_rays"] and s["nodes"] > s["rays"] and s["tris"] > 0
+    assert s["hits"] == st["primary_hits"] + st["ao_occluded"]
+    img_pt, stp = render.render_pt_frame_sharded(acc, cam, 4, 0, 1, tile=96, spp_chunk=4, kd=0.7, env=(1.0, 1.0, 1.0), max_vertices=4, seed=3)
+    sp = acc.statistics(clear=True)
+    assert sp["rays"] == stp["rays"] and sp["nodes"] > 0
+    acc.trace_statistics(False)
+    render.render_ao_frame(acc, cam, 2, 16, tile=96, seed=11)
+    assert acc.statistics()["rays"] == 0
+    acc.close()
