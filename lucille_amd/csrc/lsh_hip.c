@@ -31,6 +31,10 @@ static void usage(void)
            "    --gpus         N  Render on N GPUs of this node (one host build, replicated; tile queue; slabs\n"
            "                      gathered on the first device).  --devices a,b,.. picks them (repeats allowed).\n"
            "    --tile         N  Tile edge in pixels of the multi-GPU tile queue (default 256).\n"
+           "    --build host|device|auto  Where the traversal tree is built.  host: binned SAH on the CPU cores (best frame\n"
+           "                      time).  device: Morton LBVH on the GPU (21 M triangles in 0.2 s instead of 6 s; frames\n"
+           "                      4-15 %% slower).  auto (default): device from 1 M triangles on -- this program renders\n"
+           "                      one frame per scene set-up, like the reference's lsh.\n"
            "    --seed         N  Seed of the AO sample stream.\n"
            "    --parse-only      Read the RIB, print what was found, do not render.\n\n");
 }
@@ -38,7 +42,7 @@ static void usage(void)
 int main(int argc, char **argv)
 {
     const char *rib = NULL, *output = NULL; int i, verbose = 0, ps = -1, gather = -1, device = 0, parse_only = 0, W = -1, H = -1;
-    unsigned long long seed = 1;
+    unsigned long long seed = 1; int build = -1, build_threads = 0;      /* build: -1 auto, 0 host, 1 device */
     int ngpus = 1, devices[64], ndev_listed = 0, tile = 256; lh_multi_t *multi = NULL; double dev_secs[64];
     lh_rib_scene_t *scene = NULL; lh_rib_info_t info; lh_accel_t *accel = NULL; lh_accel_info_t ai; lh_tile_stats_t st;
     float *rgb; double t0, t1, t2, t3;
@@ -64,6 +68,11 @@ int main(int argc, char **argv)
             while (*p && ndev_listed < 64) { devices[ndev_listed++] = (int)strtol(p, &p, 10); if (*p == ',') p++; }
         }
         else if (i + 1 < argc && strcmp(a, "seed") == 0) seed = strtoull(argv[++i], NULL, 10);
+        else if (i + 1 < argc && strcmp(a, "build") == 0) {
+            const char *v = argv[++i];
+            build = strcmp(v, "host") == 0 ? 0 : strcmp(v, "device") == 0 ? 1 : strcmp(v, "auto") == 0 ? -1 : -2;
+            if (build == -2) { usage(); return 1; }
+        }
         else if (i + 1 < argc && strcmp(a, "resolution") == 0) { if (sscanf(argv[++i], "%dx%d", &W, &H) != 2) { usage(); return 1; } }
         else { fprintf(stderr, "lsh_hip: unknown option %s\n", argv[i]); usage(); return 1; }
     }
@@ -96,20 +105,22 @@ int main(int argc, char **argv)
         lh_rib_free(scene); return 0;
     }
 
+    if (build == 1 || (build == -1 && info.ntriangles >= 1000000ull)) build_threads = LH_BUILD_ON_DEVICE;
     if (ndev_listed > 0) ngpus = ndev_listed;
     if (ngpus > 1 || ndev_listed > 0) {
         /* the G GPUs of this node from this one process (lh_multi_*: SURVEY 8b(4), 8e) */
         if (lh_multi_create(&multi, ngpus, ndev_listed ? devices : NULL) != 0 || lh_multi_add_rib_scene(multi, scene) != 0 ||
-            lh_multi_commit(multi, 0) != 0) {
+            lh_multi_commit(multi, build_threads) != 0) {
             fprintf(stderr, "lsh_hip: %s\n", lh_last_error()); lh_rib_free(scene); return 1;
         }
         accel = lh_multi_accel(multi, 0);
-    } else if (lh_accel_create(&accel, device) != 0 || lh_accel_add_rib_scene(accel, scene) != 0 || lh_accel_commit(accel, 0) != 0) {
+    } else if (lh_accel_create(&accel, device) != 0 || lh_accel_add_rib_scene(accel, scene) != 0 || lh_accel_commit(accel, build_threads) != 0) {
         fprintf(stderr, "lsh_hip: %s\n", lh_last_error()); lh_rib_free(scene); return 1;
     }
     lh_accel_info(accel, &ai);
     t2 = now_s();
-    printf("[lucille_hip] BVH building: %.3f s  (%u nodes, depth %u%s)\n", t2 - t1, ai.nnodes, ai.max_depth, multi ? "; one host build, replicated" : "");
+    printf("[lucille_hip] BVH building: %.3f s  (%u nodes, depth %u; %s%s)\n", t2 - t1, ai.nnodes_traversal, ai.max_depth,
+           build_threads == LH_BUILD_ON_DEVICE ? "built on the device" : "built on the host", multi ? ", replicated" : "");
 
     rgb = (float *)malloc(sizeof(float) * 3 * (size_t)info.camera.width * info.camera.height);
     if (!rgb) { fprintf(stderr, "lsh_hip: out of memory\n"); return 1; }

@@ -204,5 +204,20 @@ def test_lsh_hip_multi_gpu_frame_equals_single(tmp_path):
     r1 = _lsh(common + ["--output", "one.hdr", rib_path], str(tmp_path))
     r3 = _lsh(common + ["--devices", "0,0,0", "--tile", "48", "--verbose", "--output", "three.hdr", rib_path], str(tmp_path))
     assert r1.returncode == 0 and r3.returncode == 0, r1.stderr + r3.stderr
-    assert "one host build, replicated" in r3.stdout and r3.stdout.count("replica") >= 3
+    assert "built on the host, replicated" in r3.stdout and r3.stdout.count("replica") >= 3
     assert open(tmp_path / "one.hdr", "rb").read() == open(tmp_path / "three.hdr", "rb").read()
+
+
+@pytest.mark.gpu
+def test_lsh_hip_device_build_writes_the_same_file(tmp_path):
+    """`--build device` (Morton LBVH on the GPU, lucille's own tree in the background; the default from 1 M triangles on) and
+    `--build host` write the same .hdr byte for byte -- hit records do not depend on the traversal tree -- alone and replicated"""
+    rib_path = os.path.join(RIB, "ambient_occlusion.rib")
+    common = ["--resolution", "200x136", "--gather", "16", "--pixelsamples", "2", "--seed", "5"]
+    rh = _lsh(common + ["--build", "host", "--output", "host.hdr", rib_path], str(tmp_path))
+    rd = _lsh(common + ["--build", "device", "--output", "dev.hdr", rib_path], str(tmp_path))
+    rm = _lsh(common + ["--build", "device", "--devices", "0,0", "--tile", "64", "--output", "dev2.hdr", rib_path], str(tmp_path))
+    assert rh.returncode == 0 and rd.returncode == 0 and rm.returncode == 0, rh.stderr + rd.stderr + rm.stderr
+    assert "built on the host" in rh.stdout and "built on the device" in rd.stdout and "built on the device, replicated" in rm.stdout
+    ref = open(tmp_path / "host.hdr", "rb").read()
+    assert open(tmp_path / "dev.hdr", "rb").read() == ref and open(tmp_path / "dev2.hdr", "rb").read() == ref
