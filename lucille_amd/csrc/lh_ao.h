@@ -32,6 +32,18 @@ __device__ __forceinline__ uint32_t lh_mix32(uint64_t x)
 /* hit record of one primary hit: AO origin (P + 1e-6 Ns), tangent, binormal, Ns -- 12 doubles */
 #define LH_HITREC_DOUBLES 12
 
+/* slot key: low 34 bits = absolute sample position (frame pixel x sub-sample; keys the built-in generator), high 30 bits =
+ * the primitive the AO rays of this slot start on WHEN that primitive cannot occlude them -- a flat-shaded hit: Ns = Ng, the
+ * origin lies 1e-6 off the triangle's plane on the side every direction of the hemisphere points to (d . Ns = sqrt(1 - z0) >=
+ * 2.4e-4), so the reference's own test of that triangle (bvh.c:730-791) ends at t < 0, ten orders of magnitude away from fp64
+ * rounding -- or LH_SLOT_NOSELF when it can (interpolated normals may tilt the hemisphere below the plane).  The any-hit
+ * kernel skips that one triangle instead of sending it through the fp64 test (1.0 fp64 re-tests per AO ray on BASELINE
+ * config 5 without this). */
+#define LH_SLOTKEY_BITS 34
+#define LH_SLOTKEY_MASK ((1ull << LH_SLOTKEY_BITS) - 1ull)
+#define LH_SLOT_NOSELF  0x3FFFFFFFu
+__device__ __forceinline__ uint32_t lh_slot_selfprim(unsigned long long key) { return (uint32_t)(key >> LH_SLOTKEY_BITS); }
+
 /* built-in generator: AO ray r (= j * ntheta + i) of the hit whose absolute sample key is `key` */
 __device__ __forceinline__ void lh_ao_ray_builtin(const double *__restrict__ h, unsigned long long key, unsigned long long seed,
                                                   int ntheta, int nphi, int r,
@@ -40,6 +52,7 @@ __device__ __forceinline__ void lh_ao_ray_builtin(const double *__restrict__ h, 
 #pragma clang fp contract(off)
     const int N = ntheta * nphi;
     const int i = r % ntheta, j = r / ntheta;
+    key &= LH_SLOTKEY_MASK;
     const uint64_t k = (seed * 0x9E3779B97F4A7C15ULL) ^ ((key * (uint64_t)N + (uint64_t)r) * 2ull);
     const float r0 = (float)(lh_mix32(k) >> 8) * 5.9604645e-8f;            /* 24 bits: stays below 1 in fp32 */
     const float r1 = (float)(lh_mix32(k + 1ull) >> 8) * 5.9604645e-8f;

@@ -1224,6 +1224,8 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
     hipStream_t s = (hipStream_t)stream;
     const int nphi = (int)sqrt((double)gather_nsamples), ntheta = nphi, N = nphi * ntheta;   /* ambientocclusion.c:378-380 */
     const size_t S = (size_t)w * h * ps * ps;
+    if ((unsigned long long)cam->width * (unsigned long long)cam->height * (unsigned long long)(ps * ps) >= (1ull << 34))
+        return fail("AO pipeline: more than 2^34 samples in the frame (slot keys carry 34 bits)");
     const unsigned nb = (unsigned)((S + 255) / 256);
     if (ensure_buf(&a->r_org, S * 24) || ensure_buf(&a->r_dir, S * 24) || ensure_buf(&a->r_prim, S * 4) ||
         ensure_buf(&a->r_t, S * 8) || ensure_buf(&a->r_u, S * 8) || ensure_buf(&a->r_v, S * 8) ||

@@ -668,6 +668,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
     uint32_t cn = 0, ct = 0, ce = 0, cr = 0, cns = 0, cts = 0, crs = 0;
     Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM, 0u};
     int pend = 0;                    /* WALK 2: parked leaf reference (0 = none) */
+    uint32_t selfp = LH_MISS_PRIM;   /* SRC 1: the triangle this AO ray starts on, when it cannot occlude the ray (lh_ao.h) */
     size_t my = (size_t)-1;          /* ray this lane is working on */
     double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
     L.cur = kDone; L.sp = 1; L.np = 0; L.certain = false; L.over = false;
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         if (COUNT) crs++;
         if (idle) {
             if (my != (size_t)-1) {
-                finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
+                finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce, SRC == 1 ? selfp : LH_MISS_PRIM);
                 if (SRC == 0) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL, WALK == 8 || WALK == 7);
                 else {
                     const bool hit = L.certain || best.prim != LH_MISS_PRIM;
@@ -719,8 +720,10 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
                     dx = dir[3 * i]; dy = dir[3 * i + 1]; dz = dir[3 * i + 2];
                 } else {
                     const uint32_t N = (uint32_t)(ao.ntheta * ao.nphi), slot = (uint32_t)i / N;
-                    lh_ao_ray_builtin(ao.hitrec + LH_HITREC_DOUBLES * (size_t)slot, ao.slot_key[slot], ao.seed, ao.ntheta, ao.nphi,
+                    const unsigned long long key = ao.slot_key[slot];
+                    lh_ao_ray_builtin(ao.hitrec + LH_HITREC_DOUBLES * (size_t)slot, key, ao.seed, ao.ntheta, ao.nphi,
                                       (int)((uint32_t)i - slot * N), ox, oy, oz, dx, dy, dz);
+                    selfp = lh_slot_selfprim(key);            /* LH_SLOT_NOSELF matches no primitive id (ids < 2^29) */
                 }
                 lane_init(L, sc, ox, oy, oz, dx, dy, dz);
                 best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM; best.frag = 0u;

@@ -221,7 +221,7 @@ __global__ void k_ao_setup(size_t n, const lh_dev_scene_t sc, const double *__re
         int ipx, ipy;
         region_pixel(rg, i / (size_t)spp, ipx, ipy);
         const unsigned long long px = (unsigned long long)ipx, py = (unsigned long long)ipy;
-        slot_key[slot] = (py * (unsigned long long)full_width + px) * (unsigned long long)spp + (i % (size_t)spp);
+        slot_key[slot] = (py * (unsigned long long)full_width + px) * (unsigned long long)spp + (i % (size_t)spp);      /* < 2^34: checked by the caller */
     }
 
     /* ri_intersection_state_build (intersection_state.c:99-248): P, Ng, Ns */
@@ -240,6 +240,9 @@ __global__ void k_ao_setup(size_t n, const lh_dev_scene_t sc, const double *__re
     } else {
         Ns[0] = Ng[0]; Ns[1] = Ng[1]; Ns[2] = Ng[2];
     }
+    /* flat-shaded: the origin triangle cannot occlude its own AO rays (lh_ao.h) -- unless it is degenerate (Ng = 0) */
+    const bool noself = !has_n && (Ng[0] != 0.0 || Ng[1] != 0.0 || Ng[2] != 0.0);
+    slot_key[slot] |= (unsigned long long)(noself ? p : LH_SLOT_NOSELF) << LH_SLOTKEY_BITS;
     /* ri_ortho_basis(basis, Ns) (reflection.c:311-333) and the 1e-6 offset (ambientocclusion.c:65-73) */
     double b0[3], b1[3] = {0.0, 0.0, 0.0};
     int ax = 3;

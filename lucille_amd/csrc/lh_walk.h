@@ -146,19 +146,19 @@ __device__ __forceinline__ bool tri_step(Lane &L, const lh_dev_scene_t &sc, floa
                                      best, c_exact);
 }
 
-/* the end of a ray's walk: its unresolved candidates through the fp64 test (bvh.c:730-791 order) */
+/* the end of a ray's walk: its unresolved candidates through the fp64 test (bvh.c:730-791 order).  skip: a primitive that
+ * is known not to be hit (the triangle a flat-shaded AO ray starts on, lh_ao.h), or LH_MISS_PRIM */
 template <bool ANYHIT, bool COUNT>
 __device__ __forceinline__ void finish(Lane &L, const lh_dev_scene_t &sc,
                                        double ox, double oy, double oz,
                                        double dx, double dy, double dz, Best &best,
-                                       uint32_t &c_exact)
+                                       uint32_t &c_exact, const uint32_t skip = LH_MISS_PRIM)
 {
     if (ANYHIT && (L.certain || best.prim != LH_MISS_PRIM)) return;
-    if (COUNT) c_exact += (uint32_t)L.np;
-    if (L.np > 0) resolve(sc, L.p0, ox, oy, oz, dx, dy, dz, best);
-    if (L.np > 1) resolve(sc, L.p1, ox, oy, oz, dx, dy, dz, best);
-    if (L.np > 2) resolve(sc, L.p2, ox, oy, oz, dx, dy, dz, best);
-    if (L.np > 3) resolve(sc, L.p3, ox, oy, oz, dx, dy, dz, best);
+    if (L.np > 0 && L.p0 != skip) { if (COUNT) c_exact++; resolve(sc, L.p0, ox, oy, oz, dx, dy, dz, best); }
+    if (L.np > 1 && L.p1 != skip) { if (COUNT) c_exact++; resolve(sc, L.p1, ox, oy, oz, dx, dy, dz, best); }
+    if (L.np > 2 && L.p2 != skip) { if (COUNT) c_exact++; resolve(sc, L.p2, ox, oy, oz, dx, dy, dz, best); }
+    if (L.np > 3 && L.p3 != skip) { if (COUNT) c_exact++; resolve(sc, L.p3, ox, oy, oz, dx, dy, dz, best); }
     L.np = 0;
 }
 
