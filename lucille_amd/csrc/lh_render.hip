@@ -641,14 +641,33 @@ __global__ void k_flag_count(size_t n, const uint8_t *__restrict__ flag, uint32_
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-/* per pixel: add the mean of this pass's samples (in sample order) */
-__global__ void k_pt_resolve(int w, int h, int spp, float inv_total_spp, const float *__restrict__ radiance, float *__restrict__ rgb)
+/* per pixel: add the mean of this pass's samples (in sample order).  A workgroup's 256 pixels are one contiguous run of
+ * 256 x spp x 3 floats: staged through LDS in coalesced 16-sample slices (one thread per pixel reading its own samples straight
+ * from HBM touched 64 different lines per load instruction: 1.15 ms per 2048^2 x 16 pass instead of 0.25) */
+#define LH_RESOLVE_SLICE 16
+__global__ __launch_bounds__(256) void k_pt_resolve(int w, int h, int spp, float inv_total_spp, const float *__restrict__ radiance, float *__restrict__ rgb)
 {
-    const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= (size_t)w * h) return;
-    const int lx = (int)(pix % w), ly = (int)(pix / w);
+    __shared__ float stage[256 * (3 * LH_RESOLVE_SLICE + 1)];        /* +1: odd row stride, conflict-free column reads */
+    const size_t npix = (size_t)w * h;
+    const size_t pix0 = (size_t)blockIdx.x * 256, pix = pix0 + threadIdx.x;
+    const size_t npb = (npix - pix0 < 256) ? npix - pix0 : 256;       /* pixels of this workgroup */
     float sr = 0.0f, sg = 0.0f, sb = 0.0f;
-    for (int s = 0; s < spp; s++) { const float *r = radiance + 3 * (pix * spp + s); sr += r[0]; sg += r[1]; sb += r[2]; }
+    for (int s0 = 0; s0 < spp; s0 += LH_RESOLVE_SLICE) {
+        const int ns = (spp - s0 < LH_RESOLVE_SLICE) ? spp - s0 : LH_RESOLVE_SLICE;
+        const size_t nfl = npb * (size_t)(3 * ns);                     /* floats of this slice, pixel-major */
+        for (size_t k = threadIdx.x; k < nfl; k += 256) {
+            const size_t p = k / (size_t)(3 * ns), c = k % (size_t)(3 * ns);
+            stage[p * (3 * LH_RESOLVE_SLICE + 1) + c] = radiance[3 * ((pix0 + p) * (size_t)spp + (size_t)s0) + c];
+        }
+        __syncthreads();
+        if (pix < npix) {
+            const float *r = stage + (size_t)threadIdx.x * (3 * LH_RESOLVE_SLICE + 1);
+            for (int s = 0; s < ns; s++) { sr += r[3 * s]; sg += r[3 * s + 1]; sb += r[3 * s + 2]; }
+        }
+        __syncthreads();
+    }
+    if (pix >= npix) return;
+    const int lx = (int)(pix % w), ly = (int)(pix / w);
     float *o = rgb + 3 * ((size_t)(h - 1 - ly) * w + lx);
     o[0] += sr * inv_total_spp; o[1] += sg * inv_total_spp; o[2] += sb * inv_total_spp;
 }
