@@ -12,10 +12,14 @@
  * Design (see DESIGN.md for the full argument):
  *
  *  - one ray per lane, 64-lane wavefronts, 256-thread workgroups; each lane
- *    owns a column of a [STACK][256] int stack in LDS (bank = lane % 32, so
- *    pushes and pops are conflict-free whatever the per-lane depth);
- *  - 64-byte SoA nodes holding BOTH children's fp32 boxes (4 x dwordx4 per
- *    visit) and 48-byte fp32 triangle records (3 x dwordx4 per test);
+ *    owns a column of a [rows][256] int stack in dynamic LDS (bank = lane % 32,
+ *    so pushes and pops are conflict-free whatever the per-lane depth);
+ *  - the default walk (traverse_spec4) reads 64-byte 4-wide nodes on the scene's
+ *    16-bit grid (4 x dwordx4 decide four children) and 48-byte fp32 triangle
+ *    records (3 x dwordx4 per test); ray dumps over scenes larger than the
+ *    Infinity Cache read 128-byte 8-wide nodes (traverse_spec8: one cache line
+ *    decides eight children); the 2-wide fp32 / 16-bit walks and the compressed
+ *    8-wide walk are kept for in-process A/B (variants 0-3, 5, LH_NODE_FORMAT);
  *  - traversal and the Moeller-Trumbore test run in fp32 as a CONSERVATIVE
  *    FILTER: boxes are rounded outward at build time, every slab interval is
  *    widened by a per-ray slack that bounds the fp32 perturbation of the ray,

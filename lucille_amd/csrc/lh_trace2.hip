@@ -1,5 +1,6 @@
 /*
- * lh_trace2.hip -- the lean traversal kernel + the fp64 resolve pass (round 2 default).
+ * lh_trace2.hip -- the lean traversal kernel + the fp64 resolve pass (variant 6: an opt-in A/B walk; measured 4 % slower
+ * than the default walk of lh_kernels.hip, whose AO source it also lost to -- DESIGN.md 3.1).
  *
  * Same algorithm and the same arithmetic as lh_kernels.hip's speculative 4-wide walk (fp32 conservative
  * filter over 64-byte 16-bit-grid nodes and 48-byte triangle records, parked leaves, ballot-compacted
