@@ -557,8 +557,14 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
             torch.distributed.barrier()
         torch.cuda.synchronize(dev); t0 = time.perf_counter()
         pt_tile = size if world == 1 else max(128, size // 4)
-        # paths per pass ~ 64 M (about 10 GB of path state): fewer, larger wavefronts -> fewer host syncs per tile
-        chunk = max(1, min(spp, (64 << 20) // (pt_tile * pt_tile)))
+        # paths per pass: as many as a third of the free HBM holds (~170 B of path state each; 288 GB -> 512 M paths, 128 spp of a
+        # 2048^2 tile): every pass costs one kernel drain per bounce and stage, so fewer, larger wavefronts are faster
+        # (tools/pt_chunk_probe.py: 192.7 / 182.9 / 175.6 ms at 64 M / 128 M / 512 M paths; the image does not change by a bit)
+        free_b = torch.cuda.mem_get_info(dev)[0]
+        per_pass = max(64 << 20, min(512 << 20, int(free_b // 3 // 170)))
+        chunk = max(1, min(spp, per_pass // (pt_tile * pt_tile)))
+        while spp % chunk:            # whole passes
+            chunk -= 1
         img, st = render.render_pt_frame_sharded(acc, cam, spp, rank, world, tile=pt_tile, spp_chunk=chunk,
                                                  kd=0.8, env=(1.0, 1.0, 1.0), max_vertices=8, seed=7)
         torch.cuda.synchronize(dev)
@@ -610,6 +616,7 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
                         % (size, size, spp),
             "rays_per_frame": int(rays.item()), "frame_ms": round(tmax.item() * 1e3, 3),
             "value": round(rays.item() / tmax.item() / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
+            "spp_per_pass": chunk, "paths_per_pass": chunk * pt_tile * pt_tile,
             "image_mean": float(img.mean().item()), "roofline": roof,
             # white furnace with albedo 0.8 under a unit environment: every pixel's radiance lies in (0, 1]
             "validation": {"frames_repeat": repeat, "retiled_frame_bit_equal": retiled,
