@@ -147,6 +147,22 @@ int ri_accel_intersect_batch(void *accel, size_t n, const double *org_xyz, const
 /* primitive id -> (geom, index), the pair state->geom/state->index carry */
 int ri_accel_prim_lookup(void *accel, uint32_t prim, ri_geom_t **geom, uint32_t *index);
 
+/* tile-level entry point: one w x h tile of the ambient-occlusion frame rendered on the device --
+ * camera rays (ri_camera_get_pos_and_dir, src/ri/camera.c:248-318), closest hits, hit epilogue, gather_nsamples
+ * cosine-stratified AO rays per hit (ambientocclusion.c:42-151), radiance (N - occluded) / N, box filter over
+ * pixel_samples^2 sub-samples -- into HOST memory: rgb = h rows of w RGB float triples in image orientation
+ * (bucket_write's y flip applied, render.c:962-964).  cam: the members of ri_camera_t the ray generator reads.
+ * Returns 0 / -1.  Several GPUs from one process: lh_multi_* in lucille_hip.h. */
+typedef struct _ri_tile_camera_t {
+    int    width, height;        /* Format */
+    int    rh;                   /* Orientation "rh": z flipped */
+    int    ortho;                /* Projection "orthographic" */
+    double flength;              /* 1 / tan(fov / 2), camera.c:219 */
+    double cam2world[16];        /* row-vector convention, vector.h:182-210 */
+} ri_tile_camera_t;
+int ri_render_tile_ao(void *accel, const ri_tile_camera_t *camera, int x0, int y0, int w, int h,
+                      int pixel_samples, int gather_nsamples, uint64_t seed, float *rgb);
+
 /* ---- BVH extras of the boundary (bvh.h:194-227) ---------------------------- */
 
 /* beam = frustum of 4 corner rays with a common origin (beam.h:45-84).  Only the members the

@@ -343,6 +343,22 @@ int ri_accel_intersect_batch(void *accel, size_t n, const double *org, const dou
     return 0;
 }
 
+int ri_render_tile_ao(void *accel, const ri_tile_camera_t *camera, int x0, int y0, int w, int h,
+                      int pixel_samples, int gather_nsamples, uint64_t seed, float *rgb)
+{
+    hipbvh_t *hb = (hipbvh_t *)accel;
+    lh_camera_t cam; int k;
+    if (!hb || !camera || !rgb) return -1;
+    cam.width = camera->width; cam.height = camera->height; cam.rh = camera->rh; cam.ortho = camera->ortho;
+    cam.flength = camera->flength;
+    for (k = 0; k < 16; k++) cam.cam2world[k] = camera->cam2world[k];
+    if (lh_render_ao_tile_host(hb->lh, &cam, x0, y0, w, h, pixel_samples, gather_nsamples, seed, NULL, 0, rgb, NULL) != 0) {
+        fprintf(stderr, "[lucille_hip] ERROR : (HIPBVH) %s\n", lh_last_error());
+        return -1;
+    }
+    return 0;
+}
+
 /* ---------------------------------------------------------------- beams ---- */
 
 /* ri_beam_set, src/render/beam.c:331-465 (incl. the maxval re-assignment at :387-390) */

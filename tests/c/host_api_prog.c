@@ -134,6 +134,18 @@ int main(int argc, char **argv)
 
     fwrite(stat, 8, 5, out);
     fwrite(&rc_unknown, 4, 1, out); fwrite(&empty_hit, 4, 1, out);
+
+    /* 4. the tile-level entry point: a 24 x 16 tile of a 32 x 32 ambient-occlusion frame, camera on the +z side looking at the soup */
+    {
+        ri_tile_camera_t cam; static float rgb[24 * 16 * 3];
+        memset(&cam, 0, sizeof(cam));
+        cam.width = 32; cam.height = 32; cam.rh = 1; cam.ortho = 0; cam.flength = 2.0;
+        cam.cam2world[0] = cam.cam2world[5] = cam.cam2world[10] = cam.cam2world[15] = 1.0;
+        cam.cam2world[12] = 0.5; cam.cam2world[13] = 0.5; cam.cam2world[14] = 3.0;
+        CHECK(ri_render_tile_ao(scene->accel->data, &cam, 4, 8, 24, 16, 2, 16, 77ull, rgb) == 0);
+        CHECK(ri_render_tile_ao(NULL, &cam, 4, 8, 24, 16, 2, 16, 77ull, rgb) == -1);
+        fwrite(rgb, sizeof(float), 24 * 16 * 3, out);
+    }
     ri_hipbvh_report_stat_traversal();
 
     fclose(in); fclose(out);

@@ -84,7 +84,8 @@ def test_lucille_style_c_program_matches_the_oracle(tmp_path):
     off = 2 * nrays * rec.itemsize
     beams = np.frombuffer(raw, "<i4", 2 * len(borg), off).reshape(-1, 2); off += 8 * len(borg)
     stat = np.frombuffer(raw, "<u8", 5, off); off += 40
-    rc_unknown, empty_hit = np.frombuffer(raw, "<i4", 2, off)
+    rc_unknown, empty_hit = np.frombuffer(raw, "<i4", 2, off); off += 8
+    tile_c = np.frombuffer(raw, "<f4", 24 * 16 * 3, off).reshape(16, 24, 3)
 
     assert rc_unknown == -1 and empty_hit == 0
     hit = prim != po.MISS
@@ -113,3 +114,18 @@ def test_lucille_style_c_program_matches_the_oracle(tmp_path):
     # statistics: both legs counted, hits agree with the oracle; work counters are plausible
     assert stat[0] == 2 * nrays and stat[4] == 2 * int(hit.sum())
     assert stat[1] > 0 and stat[2] >= stat[4] and stat[3] >= stat[4] // 2
+
+    # the tile-level entry point of the plain-C mirror == the same tile through the ctypes plumbing
+    import lucille_amd as la
+    acc = la.HipAccel(0)
+    for i, (P, idx, N) in enumerate(meshes):
+        acc.add_mesh(P, idx)
+        if N is not None:
+            acc.set_normals(i, N, 0)
+    acc.commit()
+    c2w = np.eye(4); c2w[3, :3] = (0.5, 0.5, 3.0)
+    cam = la.Camera.make(32, 32, 2.0, c2w.reshape(16), 1)
+    img, st = acc.render_ao_tile(cam, 4, 8, 24, 16, 2, 16, seed=77)
+    assert np.array_equal(img.cpu().numpy(), tile_c)
+    assert st["primary_hits"] > 50 and 0.0 < float(tile_c.mean()) < 1.0
+    acc.close()
