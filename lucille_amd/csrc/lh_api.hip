@@ -330,6 +330,16 @@ static void *ref_thread_main(void *arg)
     return NULL;
 }
 
+/* lh_bvh_build_hook's callback on the host path: the triangles are flattened, start lucille's own tree */
+static void start_ref_thread(void *arg)
+{
+    lh_host_scene *hs = (lh_host_scene *)arg;
+    if (hs->bvh.ntris == 0) return;
+    hs->ref_state = 1;
+    if (pthread_create(&hs->ref_thread, NULL, ref_thread_main, hs) != 0) { hs->ref_state = 0; return; }
+    hs->ref_thread_live = 1;
+}
+
 /* ---- host build (once per scene) ------------------------------------------------------------ */
 static int host_build(lh_accel_t *a, int build_threads, bool on_device, bool keep_meshes)
 {
@@ -348,8 +358,19 @@ static int host_build(lh_accel_t *a, int build_threads, bool on_device, bool kee
         views[g].stride_bytes = 3 * sizeof(double);
         views[g].nindices = a->meshes[g].nidx; views[g].indices = a->meshes[g].idx;
     }
-    int rc = on_device ? lh_bvh_flatten(&hs->bvh, views, a->nmeshes) : lh_bvh_build(&hs->bvh, views, a->nmeshes, build_threads);
+    /* host build: lucille's own tree (needs only the flattened triangles) is built next to the traversal tree */
+    {
+        const char *e = getenv("LH_REFTREE");
+        hs->have_ref = !(e && atoi(e) == 0);
+        hs->ref_threads = build_threads;
+    }
+    int rc = on_device ? lh_bvh_flatten(&hs->bvh, views, a->nmeshes)
+                       : lh_bvh_build_hook(&hs->bvh, views, a->nmeshes, build_threads, hs->have_ref ? start_ref_thread : NULL, hs);
     free(views);
+    if (!on_device && hs->ref_thread_live) {           /* the host path returns with both trees */
+        pthread_join(hs->ref_thread, NULL); hs->ref_thread_live = 0;
+        if (rc == 0 && hs->ref_state != 2) return fail("lh_accel_commit: reference-order tree build failed (out of memory)");
+    }
     hs->device_built = on_device ? 1 : 0;
     if (rc == -2) return fail("lh_accel_commit: a vertex coordinate is NaN, infinite or beyond 1e30");
     if (rc != 0) return fail("lh_accel_commit: BVH build failed (bad input or out of memory)");
@@ -357,15 +378,14 @@ static int host_build(lh_accel_t *a, int build_threads, bool on_device, bool kee
      * visibility (LH_REFTREE=0 skips it: ties then fall back to "larger primitive id wins",
      * fragile hits are not re-traced and beam queries are refused) */
     {
-        const char *e = getenv("LH_REFTREE");
-        hs->have_ref = !(e && atoi(e) == 0);
         const double t0 = now_s();
         if (hs->have_ref && on_device && hs->bvh.ntris) {
             /* not in front of the first frame: a background thread builds it, launch() attaches it when it is ready */
             hs->ref_threads = build_threads; hs->ref_state = 1;
             if (pthread_create(&hs->ref_thread, NULL, ref_thread_main, hs) != 0) { hs->ref_state = 0; return fail("lh_accel_commit: cannot start the reference-tree thread"); }
             hs->ref_thread_live = 1;
-        } else {
+        } else if (hs->ref_state != 2) {
+            /* not started next to the tree build (an empty scene, or the thread could not be created): now */
             if (hs->have_ref && lh_refbvh_build(&hs->ref, hs->bvh.tri64, hs->bvh.ntris, build_threads) != 0)
                 return fail("lh_accel_commit: reference-order tree build failed (out of memory)");
             hs->ref_build_seconds = now_s() - t0;
@@ -501,6 +521,10 @@ static int ensure_formats(lh_accel_t *a, int mask)
         a->dev.nodes = a->d_nodes; a->device_bytes += nb;
     }
     if ((mask & LH_FMT_Q16) && !a->d_qnodes) {
+        pthread_mutex_lock(&g_scene_mu);
+        const int rcq = lh_bvh_ensure_qnodes(&a->hs->bvh);
+        pthread_mutex_unlock(&g_scene_mu);
+        if (rcq != 0) return fail("building the 2-wide 16-bit grid nodes failed");
         const size_t qb = sizeof(lh_qnode_t) * (size_t)b->nnodes;
         HIPCHK(hipMalloc(&a->d_qnodes, qb));
         HIPCHK(hipMemcpy(a->d_qnodes, b->qnodes, qb, hipMemcpyHostToDevice));

@@ -33,6 +33,7 @@ typedef struct tnode {
     struct tnode *c[2];
     uint32_t first, count;   /* leaf range in order[] (count>0 => leaf) */
     int axis;
+    uint32_t task;           /* 1 + index of the subtree task rooted here, 0: none (the flatten pass hands these subtrees to threads) */
 } tnode_t;
 
 /* chunked arena so tnode pointers stay valid */
@@ -67,10 +68,96 @@ typedef struct {
     float     ci, ct;       /* SAH constants */
     uint32_t  task_threshold;
     /* deferred subtree tasks */
-    struct task { tnode_t *node; uint32_t first, count; int depth; } *tasks;
+    struct task { tnode_t *node; uint32_t first, count; int depth;
+                  uint32_t ninner;                                   /* inner nodes of the finished subtree */
+                  uint32_t idx, node_base, tri_base, fdepth;         /* flatten: where the subtree goes */
+                  uint32_t max_depth, nleaves; } *tasks;
     size_t ntasks, captasks;
     int collecting;
+    struct pool *pool;      /* the top of the tree (ranges of >= LH_PAR_MIN primitives while tasks are collected) runs its passes on it */
+    uint32_t *tmp;          /* [n]: scratch of the parallel partition */
 } build_ctx_t;
+
+#define LH_PAR_MIN (1u << 16)
+#define LH_POOL_MAX 64
+
+/* a small fork-join pool for the passes over the long ranges at the top of the tree: run(fn) calls fn(arg, t, nt) on every
+ * thread t and returns when all are done.  (pthreads, not OpenMP: libgomp may bind the calling thread to one core --
+ * OMP_PROC_BIND -- and the subtree workers created afterwards would inherit that mask.) */
+typedef struct pool {
+    int nt; pthread_t th[LH_POOL_MAX];
+    pthread_mutex_t mu; pthread_cond_t go, done;
+    void (*fn)(void *, int, int); void *arg;
+    unsigned gen; int pending, stop;
+} pool_t;
+typedef struct { pool_t *p; int t; } pool_arg_t;
+
+static void *pool_main(void *a_)
+{
+    pool_arg_t *a = (pool_arg_t *)a_; pool_t *p = a->p; const int t = a->t; unsigned seen = 0;
+    free(a);
+    for (;;) {
+        void (*fn)(void *, int, int); void *arg;
+        pthread_mutex_lock(&p->mu);
+        while (p->gen == seen && !p->stop) pthread_cond_wait(&p->go, &p->mu);
+        if (p->stop) { pthread_mutex_unlock(&p->mu); return NULL; }
+        seen = p->gen; fn = p->fn; arg = p->arg;
+        pthread_mutex_unlock(&p->mu);
+        fn(arg, t, p->nt);
+        pthread_mutex_lock(&p->mu);
+        if (--p->pending == 0) pthread_cond_signal(&p->done);
+        pthread_mutex_unlock(&p->mu);
+    }
+}
+
+static pool_t *pool_new(int nt)
+{
+    pool_t *p; int t;
+    if (nt < 2) return NULL;
+    if (nt > LH_POOL_MAX) nt = LH_POOL_MAX;
+    p = (pool_t *)calloc(1, sizeof(*p));
+    if (!p) return NULL;
+    pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->go, NULL); pthread_cond_init(&p->done, NULL);
+    for (t = 1; t < nt; t++) {           /* thread 0 is the caller */
+        pool_arg_t *a = (pool_arg_t *)malloc(sizeof(*a));
+        if (!a) break;
+        a->p = p; a->t = t;
+        if (pthread_create(&p->th[t], NULL, pool_main, a) != 0) { free(a); break; }
+    }
+    p->nt = t;
+    return p;
+}
+
+static void pool_run(pool_t *p, void (*fn)(void *, int, int), void *arg)
+{
+    pthread_mutex_lock(&p->mu);
+    p->fn = fn; p->arg = arg; p->pending = p->nt - 1; p->gen++;
+    pthread_cond_broadcast(&p->go);
+    pthread_mutex_unlock(&p->mu);
+    fn(arg, 0, p->nt);
+    pthread_mutex_lock(&p->mu);
+    while (p->pending) pthread_cond_wait(&p->done, &p->mu);
+    pthread_mutex_unlock(&p->mu);
+}
+
+static void pool_free(pool_t *p)
+{
+    int t;
+    if (!p) return;
+    pthread_mutex_lock(&p->mu); p->stop = 1; pthread_cond_broadcast(&p->go); pthread_mutex_unlock(&p->mu);
+    for (t = 1; t < p->nt; t++) pthread_join(p->th[t], NULL);
+    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->go); pthread_cond_destroy(&p->done);
+    free(p);
+}
+
+static void chunk_of(uint32_t first, uint32_t count, int t, int nt, uint32_t *a0, uint32_t *a1)
+{
+    const uint32_t chunk = (count + (uint32_t)nt - 1u) / (uint32_t)nt;
+    uint64_t b0 = (uint64_t)first + (uint64_t)t * chunk, b1 = b0 + chunk, end = (uint64_t)first + count;
+    if (b0 > end) b0 = end;
+    if (b1 > end) b1 = end;
+    *a0 = (uint32_t)b0; *a1 = (uint32_t)b1;
+}
 
 static inline float down32(double d) { float f = (float)d; if ((double)f > d) f = nextafterf(f, -INFINITY); return f; }
 static inline float up32(double d)   { float f = (float)d; if ((double)f < d) f = nextafterf(f,  INFINITY); return f; }
@@ -81,11 +168,47 @@ static inline float half_area(const float lo[3], const float hi[3])
     return dx * dy + dy * dz + dz * dx;
 }
 
+typedef struct { const build_ctx_t *b; uint32_t first, count; float part[LH_POOL_MAX][12]; } bounds_job_t;
+
+static void bounds_part(void *j_, int t, int nt)
+{
+    bounds_job_t *j = (bounds_job_t *)j_; const build_ctx_t *b = j->b; float *o = j->part[t];
+    uint32_t a0, a1, i; int k;
+    chunk_of(j->first, j->count, t, nt, &a0, &a1);
+    for (k = 0; k < 3; k++) { o[k] = o[6 + k] = INFINITY; o[3 + k] = o[9 + k] = -INFINITY; }
+    for (i = a0; i < a1; i++) {
+        const uint32_t p = b->order[i];
+        for (k = 0; k < 3; k++) {
+            const float l = b->plo[3 * (size_t)p + k], h = b->phi[3 * (size_t)p + k], c = b->cen[3 * (size_t)p + k];
+            if (l < o[k]) o[k] = l;
+            if (h > o[3 + k]) o[3 + k] = h;
+            if (c < o[6 + k]) o[6 + k] = c;
+            if (c > o[9 + k]) o[9 + k] = c;
+        }
+    }
+}
+
 static void range_bounds(const build_ctx_t *b, uint32_t first, uint32_t count,
                          float lo[3], float hi[3], float clo[3], float chi[3])
 {
     int k; uint32_t i;
     for (k = 0; k < 3; k++) { lo[k] = clo[k] = INFINITY; hi[k] = chi[k] = -INFINITY; }
+    if (b->collecting && b->pool && count >= LH_PAR_MIN) {        /* min / max: the same result in any order */
+        bounds_job_t *j = (bounds_job_t *)malloc(sizeof(*j)); int t;
+        if (j) {
+            j->b = b; j->first = first; j->count = count;
+            pool_run(b->pool, bounds_part, j);
+            for (t = 0; t < b->pool->nt; t++)
+                for (k = 0; k < 3; k++) {
+                    if (j->part[t][k] < lo[k]) lo[k] = j->part[t][k];
+                    if (j->part[t][3 + k] > hi[k]) hi[k] = j->part[t][3 + k];
+                    if (j->part[t][6 + k] < clo[k]) clo[k] = j->part[t][6 + k];
+                    if (j->part[t][9 + k] > chi[k]) chi[k] = j->part[t][9 + k];
+                }
+            free(j);
+            return;
+        }
+    }
     for (i = first; i < first + count; i++) {
         uint32_t p = b->order[i];
         for (k = 0; k < 3; k++) {
@@ -96,6 +219,70 @@ static void range_bounds(const build_ctx_t *b, uint32_t first, uint32_t count,
             if (c > chi[k]) chi[k] = c;
         }
     }
+}
+
+typedef struct { uint32_t cnt[3][NBINS]; float lo[3][NBINS][3], hi[3][NBINS][3]; } bins_t;
+
+static void bins_clear(bins_t *B)
+{
+    int a, j, k;
+    for (a = 0; a < 3; a++) for (j = 0; j < NBINS; j++) { B->cnt[a][j] = 0; for (k = 0; k < 3; k++) { B->lo[a][j][k] = INFINITY; B->hi[a][j][k] = -INFINITY; } }
+}
+
+static void bins_fill(const build_ctx_t *b, uint32_t i0, uint32_t i1, const int live[3], const float scale[3], const float clo[3], bins_t *B)
+{
+    uint32_t i; int a, k;
+    for (i = i0; i < i1; i++) {
+        const uint32_t p = b->order[i];
+        const float *pl = &b->plo[3 * (size_t)p], *ph = &b->phi[3 * (size_t)p];
+        for (a = 0; a < 3; a++) {
+            int bin;
+            if (!live[a]) continue;
+            bin = (int)((b->cen[3 * (size_t)p + a] - clo[a]) * scale[a]);
+            if (bin < 0) bin = 0;
+            if (bin >= NBINS) bin = NBINS - 1;
+            B->cnt[a][bin]++;
+            for (k = 0; k < 3; k++) { if (pl[k] < B->lo[a][bin][k]) B->lo[a][bin][k] = pl[k]; if (ph[k] > B->hi[a][bin][k]) B->hi[a][bin][k] = ph[k]; }
+        }
+    }
+}
+
+typedef struct { const build_ctx_t *b; uint32_t first, count; int live[3]; float scale[3], clo[3]; bins_t part[LH_POOL_MAX]; } bin_job_t;
+
+static void bin_part(void *j_, int t, int nt)
+{
+    bin_job_t *j = (bin_job_t *)j_; uint32_t a0, a1;
+    chunk_of(j->first, j->count, t, nt, &a0, &a1);
+    bins_clear(&j->part[t]);
+    bins_fill(j->b, a0, a1, j->live, j->scale, j->clo, &j->part[t]);
+}
+
+/* stable partition of order[first, first + count) by bin <= best_bin, by chunks: left counts, prefix sums, scatter, copy back */
+typedef struct { build_ctx_t *b; uint32_t first, count, nleft; int axis, best_bin; float c0, scale; uint32_t lcount[LH_POOL_MAX], loff[LH_POOL_MAX], roff[LH_POOL_MAX]; int phase; } part_job_t;
+
+static void part_part(void *j_, int t, int nt)
+{
+    part_job_t *j = (part_job_t *)j_; build_ctx_t *b = j->b; uint32_t a0, a1, i;
+    chunk_of(j->first, j->count, t, nt, &a0, &a1);
+    if (j->phase == 0) {
+        uint32_t c = 0;
+        for (i = a0; i < a1; i++) {
+            int bin = (int)((b->cen[3 * (size_t)b->order[i] + j->axis] - j->c0) * j->scale);
+            if (bin < 0) bin = 0;
+            if (bin >= NBINS) bin = NBINS - 1;
+            c += (bin <= j->best_bin);
+        }
+        j->lcount[t] = c;
+    } else if (j->phase == 1) {
+        uint32_t wl = j->first + j->loff[t], wr = j->first + j->nleft + j->roff[t];
+        for (i = a0; i < a1; i++) {
+            const uint32_t p = b->order[i];
+            int bin = (int)((b->cen[3 * (size_t)p + j->axis] - j->c0) * j->scale);
+            if (bin < 0) bin = 0;
+            if (bin >= NBINS) bin = NBINS - 1;
+            if (bin <= j->best_bin) b->tmp[wl++] = p; else b->tmp[wr++] = p;
+        }
+    } else if (a1 > a0) memcpy(&b->order[a0], &b->tmp[a0], sizeof(uint32_t) * (size_t)(a1 - a0));
 }
 
 static void build_range(build_ctx_t *b, arena_t *ar, tnode_t *node, uint32_t first,
@@ -121,7 +308,6 @@ static void build_range(build_ctx_t *b, arena_t *ar, tnode_t *node, uint32_t fir
     float clo[3], chi[3];
     int k, axis, best_axis = -1, best_bin = -1;
     float best_cost = INFINITY;
-    uint32_t i;
 
     if (b->collecting && count <= b->task_threshold && count > LH_MAX_LEAF_TRIS) {
         if (b->ntasks == b->captasks) {
@@ -131,6 +317,7 @@ static void build_range(build_ctx_t *b, arena_t *ar, tnode_t *node, uint32_t fir
         b->tasks[b->ntasks].node = node; b->tasks[b->ntasks].first = first;
         b->tasks[b->ntasks].count = count; b->tasks[b->ntasks].depth = depth;
         b->ntasks++;
+        node->task = (uint32_t)b->ntasks;
         return;
     }
 
@@ -145,48 +332,57 @@ static void build_range(build_ctx_t *b, arena_t *ar, tnode_t *node, uint32_t fir
         return;
     }
 
-    /* binned SAH */
+    /* binned SAH: one pass fills the bins of all three axes (counts and min / max boxes: the same in any order, so the
+     * long ranges at the top of the tree are binned by the pool's threads), then a sweep per axis */
     {
         float parent_area = half_area(node->lo, node->hi);
+        bins_t bins, *B = &bins;          /* 2.7 KB on the stack per level of the recursion */
+        int live[3]; float scale3[3];
+        int j;
         for (axis = 0; axis < 3; axis++) {
-            uint32_t cnt[NBINS]; float blo[NBINS][3], bhi[NBINS][3];
-            float ext = chi[axis] - clo[axis];
-            float scale;
+            const float ext = chi[axis] - clo[axis];
+            live[axis] = ext > 0.0f;
+            scale3[axis] = live[axis] ? (float)NBINS * (1.0f - 1e-6f) / ext : 0.0f;
+        }
+        if (b->collecting && b->pool && count >= LH_PAR_MIN) {
+            bin_job_t *jb = (bin_job_t *)malloc(sizeof(*jb)); int t, a, kk;
+            bins_clear(B);
+            if (jb) {
+                jb->b = b; jb->first = first; jb->count = count;
+                for (a = 0; a < 3; a++) { jb->live[a] = live[a]; jb->scale[a] = scale3[a]; jb->clo[a] = clo[a]; }
+                pool_run(b->pool, bin_part, jb);
+                for (t = 0; t < b->pool->nt; t++)
+                    for (a = 0; a < 3; a++) for (j = 0; j < NBINS; j++) {
+                        B->cnt[a][j] += jb->part[t].cnt[a][j];
+                        for (kk = 0; kk < 3; kk++) {
+                            if (jb->part[t].lo[a][j][kk] < B->lo[a][j][kk]) B->lo[a][j][kk] = jb->part[t].lo[a][j][kk];
+                            if (jb->part[t].hi[a][j][kk] > B->hi[a][j][kk]) B->hi[a][j][kk] = jb->part[t].hi[a][j][kk];
+                        }
+                    }
+                free(jb);
+            } else bins_fill(b, first, first + count, live, scale3, clo, B);
+        } else {
+            bins_clear(B);
+            bins_fill(b, first, first + count, live, scale3, clo, B);
+        }
+        for (axis = 0; axis < 3; axis++) {
             float rarea[NBINS]; uint32_t rcnt[NBINS];
             float lo[3], hi[3]; uint32_t n;
-            int j;
-            if (!(ext > 0.0f)) continue;
-            scale = (float)NBINS * (1.0f - 1e-6f) / ext;
-            for (j = 0; j < NBINS; j++) {
-                cnt[j] = 0;
-                for (k = 0; k < 3; k++) { blo[j][k] = INFINITY; bhi[j][k] = -INFINITY; }
-            }
-            for (i = first; i < first + count; i++) {
-                uint32_t p = b->order[i];
-                int bin = (int)((b->cen[3 * (size_t)p + axis] - clo[axis]) * scale);
-                if (bin < 0) bin = 0;
-                if (bin >= NBINS) bin = NBINS - 1;
-                cnt[bin]++;
-                for (k = 0; k < 3; k++) {
-                    float l = b->plo[3 * (size_t)p + k], h = b->phi[3 * (size_t)p + k];
-                    if (l < blo[bin][k]) blo[bin][k] = l;
-                    if (h > bhi[bin][k]) bhi[bin][k] = h;
-                }
-            }
+            if (!live[axis]) continue;
             /* right-to-left sweep */
             for (k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
             n = 0;
             for (j = NBINS - 1; j >= 1; j--) {
-                n += cnt[j];
-                for (k = 0; k < 3; k++) { if (blo[j][k] < lo[k]) lo[k] = blo[j][k]; if (bhi[j][k] > hi[k]) hi[k] = bhi[j][k]; }
+                n += B->cnt[axis][j];
+                for (k = 0; k < 3; k++) { if (B->lo[axis][j][k] < lo[k]) lo[k] = B->lo[axis][j][k]; if (B->hi[axis][j][k] > hi[k]) hi[k] = B->hi[axis][j][k]; }
                 rcnt[j] = n; rarea[j] = n ? half_area(lo, hi) : 0.0f;
             }
             for (k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
             n = 0;
             for (j = 0; j < NBINS - 1; j++) {
                 float cost;
-                n += cnt[j];
-                for (k = 0; k < 3; k++) { if (blo[j][k] < lo[k]) lo[k] = blo[j][k]; if (bhi[j][k] > hi[k]) hi[k] = bhi[j][k]; }
+                n += B->cnt[axis][j];
+                for (k = 0; k < 3; k++) { if (B->lo[axis][j][k] < lo[k]) lo[k] = B->lo[axis][j][k]; if (B->hi[axis][j][k] > hi[k]) hi[k] = B->hi[axis][j][k]; }
                 if (n == 0 || rcnt[j + 1] == 0) continue;
                 cost = half_area(lo, hi) * (float)n + rarea[j + 1] * (float)rcnt[j + 1];
                 if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = j; }
@@ -212,6 +408,25 @@ static void build_range(build_ctx_t *b, arena_t *ar, tnode_t *node, uint32_t fir
         float ext = chi[best_axis] - clo[best_axis];
         float scale = (float)NBINS * (1.0f - 1e-6f) / ext;
         uint32_t l = first, r = first + count;
+        if (b->collecting && b->pool && b->tmp && count >= LH_PAR_MIN) {
+            /* (the serial branch below swaps in place; which order the primitives of a child end up in only decides the order
+             * of the triangles inside a leaf -- the tree itself depends on the child SETS alone) */
+            part_job_t *j = (part_job_t *)malloc(sizeof(*j));
+            if (j) {
+                int t; uint32_t nl = 0, nr = 0;
+                j->b = b; j->first = first; j->count = count; j->axis = best_axis; j->best_bin = best_bin; j->c0 = clo[best_axis]; j->scale = scale;
+                j->phase = 0; pool_run(b->pool, part_part, j);
+                for (t = 0; t < b->pool->nt; t++) {
+                    uint32_t a0, a1; chunk_of(first, count, t, b->pool->nt, &a0, &a1);
+                    j->loff[t] = nl; j->roff[t] = nr; nl += j->lcount[t]; nr += (a1 - a0) - j->lcount[t];
+                }
+                j->nleft = nl;
+                j->phase = 1; pool_run(b->pool, part_part, j);
+                j->phase = 2; pool_run(b->pool, part_part, j);
+                free(j);
+                l = r = first + nl;
+            }
+        }
         while (l < r) {
             uint32_t p = b->order[l];
             int bin = (int)((b->cen[3 * (size_t)p + best_axis] - clo[best_axis]) * scale);
@@ -229,6 +444,16 @@ static void build_range(build_ctx_t *b, arena_t *ar, tnode_t *node, uint32_t fir
     }
 }
 
+/* inner nodes below (and including) n; a subtree task's root contributes the count its worker stored */
+static uint32_t count_inner(const tnode_t *n) { return n->count ? 0 : 1 + count_inner(n->c[0]) + count_inner(n->c[1]); }
+
+static uint32_t count_inner_top(const build_ctx_t *b, const tnode_t *n)
+{
+    if (n->count) return 0;
+    if (n->task) return b->tasks[n->task - 1].ninner;
+    return 1 + count_inner_top(b, n->c[0]) + count_inner_top(b, n->c[1]);
+}
+
 typedef struct { build_ctx_t *b; arena_t arena; volatile uint32_t *next; } worker_t;
 
 static void *worker_main(void *arg)
@@ -239,6 +464,7 @@ static void *worker_main(void *arg)
         if (t >= w->b->ntasks) break;
         build_range(w->b, &w->arena, w->b->tasks[t].node, w->b->tasks[t].first,
                     w->b->tasks[t].count, w->b->tasks[t].depth);
+        w->b->tasks[t].ninner = count_inner(w->b->tasks[t].node);
     }
     return NULL;
 }
@@ -248,6 +474,7 @@ static void *worker_main(void *arg)
 typedef struct {
     const build_ctx_t *b; lh_bvh_t *out; const lh_tri64_t *tri64;
     uint32_t next_node, next_tri, max_depth, nleaves;
+    int defer;               /* the serial pass over the top of the tree: subtree tasks are only given their place */
 } flat_t;
 
 static int32_t emit_leaf(flat_t *f, const tnode_t *n)
@@ -286,21 +513,58 @@ static void emit_inner(flat_t *f, const tnode_t *n, uint32_t idx, uint32_t depth
     if (c1->count == 0) k1 = f->next_node++;
     if (c0->count) o->ref0 = emit_leaf(f, c0); else { o->ref0 = (int32_t)k0; }
     if (c1->count) o->ref1 = emit_leaf(f, c1); else { o->ref1 = (int32_t)k1; }
-    if (c0->count == 0) emit_inner(f, c0, k0, depth + 1);
-    if (c1->count == 0) emit_inner(f, c1, k1, depth + 1);
+    {
+        const tnode_t *c[2] = { c0, c1 }; const uint32_t kk[2] = { k0, k1 }; int s;
+        for (s = 0; s < 2; s++) {
+            if (c[s]->count) continue;
+            if (f->defer && c[s]->task) {
+                /* a finished subtree: its nodes (all but its root) and its triangles are the next contiguous blocks of the
+                 * depth-first layout; a thread fills them in later (flatten_task) */
+                struct task *tk = &((build_ctx_t *)f->b)->tasks[c[s]->task - 1];
+                tk->idx = kk[s]; tk->fdepth = depth + 1; tk->node_base = f->next_node; tk->tri_base = f->next_tri;
+                f->next_node += tk->ninner - 1; f->next_tri += tk->count;
+            } else emit_inner(f, c[s], kk[s], depth + 1);
+        }
+    }
 }
 
-/* derive the 16-bit grid nodes from the fp32 nodes (see lh_qnode_t) */
-static int quantize_nodes(lh_bvh_t *o)
+typedef struct { flat_t base; build_ctx_t *b; volatile uint32_t *next; } flat_worker_t;
+
+static void *flatten_worker(void *arg)
 {
-    uint32_t i; int k, c;
-    o->qnodes = (lh_qnode_t *)malloc(sizeof(lh_qnode_t) * (size_t)(o->nnodes ? o->nnodes : 1));
-    if (!o->qnodes) return -1;
+    flat_worker_t *w = (flat_worker_t *)arg;
+    for (;;) {
+        uint32_t t = __sync_fetch_and_add(w->next, 1);
+        struct task *tk; flat_t f;
+        if (t >= w->b->ntasks) break;
+        tk = &w->b->tasks[t];
+        f = w->base; f.defer = 0; f.next_node = tk->node_base; f.next_tri = tk->tri_base; f.max_depth = 0; f.nleaves = 0;
+        emit_inner(&f, tk->node, tk->idx, tk->fdepth);
+        tk->max_depth = f.max_depth; tk->nleaves = f.nleaves;
+    }
+    return NULL;
+}
+
+/* the scene's 16-bit grid: every quantised node format (2-, 4-, 8-wide) lives on it */
+static void setup_grid(lh_bvh_t *o)
+{
+    int k;
     for (k = 0; k < 3; k++) {
         double ext = (double)o->bmax[k] - (double)o->bmin[k];
         o->grid_lo[k] = o->bmin[k];
         o->grid_step[k] = up32(ext > 0.0 ? ext / 65535.0 * (1.0 + 1e-6) : 1e-30);
     }
+}
+
+/* the 2-wide 16-bit grid nodes (lh_qnode_t), derived from the fp32 nodes the first time something asks for them (the A/B
+ * walks, the deep-tree fallback, the host model): not thread-safe, callers lock */
+int lh_bvh_ensure_qnodes(lh_bvh_t *o)
+{
+    uint32_t i; int k, c;
+    if (o->qnodes || o->ntris == 0) return 0;
+    if (!o->nodes) return -1;
+    o->qnodes = (lh_qnode_t *)malloc(sizeof(lh_qnode_t) * (size_t)(o->nnodes ? o->nnodes : 1));
+    if (!o->qnodes) return -1;
     for (i = 0; i < o->nnodes; i++) {
         const lh_node_t *n = &o->nodes[i]; lh_qnode_t *q = &o->qnodes[i];
         const float *lo[2] = { n->lo0, n->lo1 }, *hi[2] = { n->hi0, n->hi1 };
@@ -318,7 +582,7 @@ static int quantize_nodes(lh_bvh_t *o)
                 if (qh > 65535.0) qh = 65535.0;
                 while (ql > 0.0 && g + ql * st > (double)lo[c][k]) ql -= 1.0;
                 while (qh < 65535.0 && g + qh * st < (double)hi[c][k]) qh += 1.0;
-                if (g + ql * st > (double)lo[c][k] || g + qh * st < (double)hi[c][k]) return -1;   /* grid does not cover: bug */
+                if (g + ql * st > (double)lo[c][k] || g + qh * st < (double)hi[c][k]) { free(o->qnodes); o->qnodes = NULL; return -1; }   /* grid does not cover: bug */
                 q->q[6 * c + k] = (uint16_t)ql; q->q[6 * c + 3 + k] = (uint16_t)qh;
             }
         q->ref0 = ref[0]; q->ref1 = ref[1];
@@ -652,13 +916,56 @@ static int collapse8(lh_bvh_t *o)
     return next_tri == o->ntris ? 0 : -1;
 }
 
-static uint32_t count_inner(const tnode_t *n) { return n->count ? 0 : 1 + count_inner(n->c[0]) + count_inner(n->c[1]); }
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
+typedef struct { const lh_mesh_view_t *m; uint32_t g, p0; lh_bvh_t *out; build_ctx_t *b; volatile int err; } prep_job_t;
+
+/* triangles [a0, a1) of one mesh: fp64 vertices, primitive -> (geom, index), fp32 outward box, centroid */
+static void prep_part(void *j_, int t, int nt)
+{
+    prep_job_t *j = (prep_job_t *)j_; const lh_mesh_view_t *m = j->m; build_ctx_t *b = j->b; lh_bvh_t *out = j->out;
+    uint32_t a0, a1, i; int c, k;
+    chunk_of(0, m->nindices / 3, t, nt, &a0, &a1);
+    for (i = a0; i < a1; i++) {
+        const uint32_t p = j->p0 + i;
+        lh_tri64_t *tr = &out->tri64[p];
+        for (c = 0; c < 3; c++) {
+            const uint32_t vi = m->indices[3 * (size_t)i + c];
+            const double *P;
+            if (vi >= m->npositions) { j->err = -1; return; }
+            P = (const double *)((const char *)m->positions + (size_t)vi * m->stride_bytes);
+            for (k = 0; k < 3; k++) {
+                /* NaN, inf or beyond what the fp32 filter can bound: refuse the scene (return -2) */
+                if (!(fabs(P[k]) <= 1.0e30)) { j->err = -2; return; }
+                tr->v[c][k] = P[k];
+            }
+        }
+        out->prim_geom[p] = j->g; out->prim_index[p] = 3 * i;
+        for (k = 0; k < 3; k++) {
+            double lo = tr->v[0][k], hi = tr->v[0][k];
+            if (tr->v[1][k] < lo) lo = tr->v[1][k];
+            if (tr->v[2][k] < lo) lo = tr->v[2][k];
+            if (tr->v[1][k] > hi) hi = tr->v[1][k];
+            if (tr->v[2][k] > hi) hi = tr->v[2][k];
+            b->plo[3 * (size_t)p + k] = down32(lo); b->phi[3 * (size_t)p + k] = up32(hi);
+            b->cen[3 * (size_t)p + k] = (float)(0.5 * (lo + hi));
+        }
+        b->order[p] = p;
+    }
+}
+
 int lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, int nthreads)
 {
-    uint64_t n64 = 0; uint32_t g, i, n; int k, c;
+    return lh_bvh_build_hook(out, meshes, nmeshes, nthreads, NULL, NULL);
+}
+
+/* after_flatten (may be NULL) is called once tri64 / prim_geom / prim_index are complete and will not move: the caller can
+ * start work that only needs the flattened triangles (lucille's own tree, lh_refbvh.c) next to the tree build */
+int lh_bvh_build_hook(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, int nthreads,
+                      void (*after_flatten)(void *), void *hook_arg)
+{
+    uint64_t n64 = 0; uint32_t g, n; int k;
     build_ctx_t b; arena_t main_arena; tnode_t *root;
     double t0 = now_s();
     const char *env;
@@ -688,55 +995,41 @@ int lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, 
         free(b.plo); free(b.phi); free(b.cen); free(b.order); lh_bvh_release(out); return -1;
     }
 
-    /* flatten in create_triangle_list order: primitive id = running index */
+    /* flatten in create_triangle_list order: primitive id = running index (the meshes' triangles cut into chunks for the pool) */
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    if (nthreads > 1 && n > 100000) b.pool = pool_new(nthreads);
     {
         uint32_t p = 0;
         for (g = 0; g < nmeshes; g++) {
-            const lh_mesh_view_t *m = &meshes[g];
-            for (i = 0; i < m->nindices / 3; i++, p++) {
-                lh_tri64_t *t = &out->tri64[p];
-                for (c = 0; c < 3; c++) {
-                    uint32_t vi = m->indices[3 * i + c];
-                    const double *P;
-                    if (vi >= m->npositions) { free(b.plo); free(b.phi); free(b.cen); free(b.order); lh_bvh_release(out); return -1; }
-                    P = (const double *)((const char *)m->positions + (size_t)vi * m->stride_bytes);
-                    for (k = 0; k < 3; k++) {
-                        /* NaN, inf or beyond what the fp32 filter can bound: refuse the scene (return -2) */
-                        if (!(fabs(P[k]) <= 1.0e30)) { free(b.plo); free(b.phi); free(b.cen); free(b.order); lh_bvh_release(out); return -2; }
-                        t->v[c][k] = P[k];
-                    }
-                }
-                out->prim_geom[p] = g; out->prim_index[p] = 3 * i;
-                for (k = 0; k < 3; k++) {
-                    double lo = t->v[0][k], hi = t->v[0][k];
-                    if (t->v[1][k] < lo) lo = t->v[1][k];
-                    if (t->v[2][k] < lo) lo = t->v[2][k];
-                    if (t->v[1][k] > hi) hi = t->v[1][k];
-                    if (t->v[2][k] > hi) hi = t->v[2][k];
-                    b.plo[3 * (size_t)p + k] = down32(lo); b.phi[3 * (size_t)p + k] = up32(hi);
-                    b.cen[3 * (size_t)p + k] = (float)(0.5 * (lo + hi));
-                }
-                b.order[p] = p;
-            }
+            prep_job_t pj;
+            pj.m = &meshes[g]; pj.g = g; pj.p0 = p; pj.out = out; pj.b = &b; pj.err = 0;
+            if (b.pool && pj.m->nindices / 3 >= LH_PAR_MIN) pool_run(b.pool, prep_part, &pj);
+            else prep_part(&pj, 0, 1);
+            if (pj.err) { pool_free(b.pool); free(b.plo); free(b.phi); free(b.cen); free(b.order); lh_bvh_release(out); return pj.err; }
+            p += pj.m->nindices / 3;
         }
     }
+
+    if (after_flatten) after_flatten(hook_arg);
 
     b.ci = 1.0f; b.ct = 1.0f;
     if ((env = getenv("LH_BVH_CI")) != NULL) b.ci = (float)atof(env);
     if ((env = getenv("LH_BVH_CT")) != NULL) b.ct = (float)atof(env);
-    if (nthreads < 1) nthreads = 1;
-    if (nthreads > 64) nthreads = 64;
-
     memset(&main_arena, 0, sizeof(main_arena));
     root = arena_new(&main_arena);
     if (nthreads > 1 && n > 100000) {
+        b.tmp = (uint32_t *)malloc(sizeof(uint32_t) * n);       /* NULL: the top of the tree partitions serially */
         b.collecting = 1;
         b.task_threshold = n / (uint32_t)(nthreads * 8);
         if (b.task_threshold < 4096) b.task_threshold = 4096;
+        /* every range above the threshold is processed by the pool: no serial pass over more than LH_PAR_MIN primitives */
+        if (b.pool && b.task_threshold < LH_PAR_MIN && n / LH_PAR_MIN >= (uint32_t)(2 * nthreads)) b.task_threshold = LH_PAR_MIN;
     }
     double t_prep = now_s();
     build_range(&b, &main_arena, root, 0, n, 0);
     b.collecting = 0;
+    pool_free(b.pool); b.pool = NULL; free(b.tmp); b.tmp = NULL;
     double t_top = now_s();
 
     {
@@ -762,11 +1055,28 @@ int lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, 
                 out->nodes[0].ref0 = emit_leaf(&f, root);
                 out->nodes[0].ref1 = LH_REF_EMPTY;
             } else {
-                ninner = count_inner(root);
+                ninner = count_inner_top(&b, root);
                 out->nodes = (lh_node_t *)calloc(ninner, sizeof(lh_node_t));
                 out->nnodes = ninner;
                 f.next_node = 1;
+                f.defer = (b.ntasks > 0 && nthreads > 1);
                 emit_inner(&f, root, 0, 0);
+                if (f.defer) {
+                    /* the subtrees, each into its own block of the layout */
+                    flat_worker_t fw[LH_POOL_MAX]; pthread_t fth[LH_POOL_MAX]; volatile uint32_t fnext = 0; int t, nt = nthreads > LH_POOL_MAX ? LH_POOL_MAX : nthreads, started = 0;
+                    size_t q;
+                    for (t = 0; t < nt; t++) {
+                        fw[t].base = f; fw[t].b = &b; fw[t].next = &fnext;
+                        if (pthread_create(&fth[t], NULL, flatten_worker, &fw[t]) != 0) break;
+                        started++;
+                    }
+                    if (started == 0) flatten_worker(&fw[0]);
+                    for (t = 0; t < started; t++) pthread_join(fth[t], NULL);
+                    for (q = 0; q < b.ntasks; q++) {
+                        if (b.tasks[q].max_depth > f.max_depth) f.max_depth = b.tasks[q].max_depth;
+                        f.nleaves += b.tasks[q].nleaves;
+                    }
+                }
             }
             out->max_depth = f.max_depth + 1; out->nleaves = f.nleaves;
             for (k = 0; k < 3; k++) { out->bmin[k] = root->lo[k]; out->bmax[k] = root->hi[k]; }
@@ -779,7 +1089,7 @@ int lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, 
     free(b.tasks); free(b.plo); free(b.phi); free(b.cen); free(b.order);
     {
         double t1 = now_s(), t2, t3;
-        if (quantize_nodes(out) != 0) { lh_bvh_release(out); return -1; }
+        setup_grid(out);
         t2 = now_s();
         if (collapse4(out) != 0) { lh_bvh_release(out); return -1; }
         t3 = now_s();

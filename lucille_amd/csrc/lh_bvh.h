@@ -133,7 +133,10 @@ typedef struct lh_mesh_view {
 /* returns 0 on success, -1 on bad input / out of memory, -2 on a NaN / infinite / > 1e30 vertex coordinate */
 int  lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes,
                   int nthreads);
+int  lh_bvh_build_hook(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, int nthreads,
+                       void (*after_flatten)(void *), void *hook_arg);
 int  lh_bvh_flatten(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes);   /* primitives only, no tree */
+int  lh_bvh_ensure_qnodes(lh_bvh_t *bvh);  /* builds the 2-wide 16-bit grid nodes on first use; 0 / -1 */
 int  lh_bvh_ensure_q8(lh_bvh_t *bvh);      /* builds q8nodes on first use; 0 / -1 */
 int  lh_bvh_ensure_c8(lh_bvh_t *bvh);      /* builds c8nodes / tri32_c8 on first use; 0 / -1 */
 void lh_bvh_release(lh_bvh_t *bvh);

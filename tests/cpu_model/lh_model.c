@@ -203,7 +203,7 @@ lh_bvh_t *lhm_build(uint32_t npos, const double *pos_xyz, uint32_t nidx, const u
 {
     lh_bvh_t *b = (lh_bvh_t *)calloc(1, sizeof(*b)); lh_mesh_view_t m;
     m.npositions = npos; m.positions = pos_xyz; m.stride_bytes = 24; m.nindices = nidx; m.indices = idx;
-    if (lh_bvh_build(b, &m, 1, nthreads) != 0 || lh_bvh_ensure_c8(b) != 0 || lh_bvh_ensure_q8(b) != 0) { free(b); return NULL; }   /* the model checks every format */
+    if (lh_bvh_build(b, &m, 1, nthreads) != 0 || lh_bvh_ensure_qnodes(b) != 0 || lh_bvh_ensure_c8(b) != 0 || lh_bvh_ensure_q8(b) != 0) { free(b); return NULL; }   /* the model checks every format */
     return b;
 }
 void lhm_free(lh_bvh_t *b) { if (b) { lh_bvh_release(b); free(b); } }
