@@ -17,6 +17,7 @@
  * 128-byte line when both are visited).
  */
 #include "lh_bvh.h"
+#include "lh_tpool.h"
 
 #include <float.h>
 #include <math.h>
@@ -74,90 +75,9 @@ typedef struct {
                   uint32_t max_depth, nleaves; } *tasks;
     size_t ntasks, captasks;
     int collecting;
-    struct pool *pool;      /* the top of the tree (ranges of >= LH_PAR_MIN primitives while tasks are collected) runs its passes on it */
+    lh_tpool_t *pool;      /* the top of the tree (ranges of >= LH_PAR_MIN primitives while tasks are collected) runs its passes on it */
     uint32_t *tmp;          /* [n]: scratch of the parallel partition */
 } build_ctx_t;
-
-#define LH_PAR_MIN (1u << 16)
-#define LH_POOL_MAX 64
-
-/* a small fork-join pool for the passes over the long ranges at the top of the tree: run(fn) calls fn(arg, t, nt) on every
- * thread t and returns when all are done.  (pthreads, not OpenMP: libgomp may bind the calling thread to one core --
- * OMP_PROC_BIND -- and the subtree workers created afterwards would inherit that mask.) */
-typedef struct pool {
-    int nt; pthread_t th[LH_POOL_MAX];
-    pthread_mutex_t mu; pthread_cond_t go, done;
-    void (*fn)(void *, int, int); void *arg;
-    unsigned gen; int pending, stop;
-} pool_t;
-typedef struct { pool_t *p; int t; } pool_arg_t;
-
-static void *pool_main(void *a_)
-{
-    pool_arg_t *a = (pool_arg_t *)a_; pool_t *p = a->p; const int t = a->t; unsigned seen = 0;
-    free(a);
-    for (;;) {
-        void (*fn)(void *, int, int); void *arg;
-        pthread_mutex_lock(&p->mu);
-        while (p->gen == seen && !p->stop) pthread_cond_wait(&p->go, &p->mu);
-        if (p->stop) { pthread_mutex_unlock(&p->mu); return NULL; }
-        seen = p->gen; fn = p->fn; arg = p->arg;
-        pthread_mutex_unlock(&p->mu);
-        fn(arg, t, p->nt);
-        pthread_mutex_lock(&p->mu);
-        if (--p->pending == 0) pthread_cond_signal(&p->done);
-        pthread_mutex_unlock(&p->mu);
-    }
-}
-
-static pool_t *pool_new(int nt)
-{
-    pool_t *p; int t;
-    if (nt < 2) return NULL;
-    if (nt > LH_POOL_MAX) nt = LH_POOL_MAX;
-    p = (pool_t *)calloc(1, sizeof(*p));
-    if (!p) return NULL;
-    pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->go, NULL); pthread_cond_init(&p->done, NULL);
-    for (t = 1; t < nt; t++) {           /* thread 0 is the caller */
-        pool_arg_t *a = (pool_arg_t *)malloc(sizeof(*a));
-        if (!a) break;
-        a->p = p; a->t = t;
-        if (pthread_create(&p->th[t], NULL, pool_main, a) != 0) { free(a); break; }
-    }
-    p->nt = t;
-    return p;
-}
-
-static void pool_run(pool_t *p, void (*fn)(void *, int, int), void *arg)
-{
-    pthread_mutex_lock(&p->mu);
-    p->fn = fn; p->arg = arg; p->pending = p->nt - 1; p->gen++;
-    pthread_cond_broadcast(&p->go);
-    pthread_mutex_unlock(&p->mu);
-    fn(arg, 0, p->nt);
-    pthread_mutex_lock(&p->mu);
-    while (p->pending) pthread_cond_wait(&p->done, &p->mu);
-    pthread_mutex_unlock(&p->mu);
-}
-
-static void pool_free(pool_t *p)
-{
-    int t;
-    if (!p) return;
-    pthread_mutex_lock(&p->mu); p->stop = 1; pthread_cond_broadcast(&p->go); pthread_mutex_unlock(&p->mu);
-    for (t = 1; t < p->nt; t++) pthread_join(p->th[t], NULL);
-    pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->go); pthread_cond_destroy(&p->done);
-    free(p);
-}
-
-static void chunk_of(uint32_t first, uint32_t count, int t, int nt, uint32_t *a0, uint32_t *a1)
-{
-    const uint32_t chunk = (count + (uint32_t)nt - 1u) / (uint32_t)nt;
-    uint64_t b0 = (uint64_t)first + (uint64_t)t * chunk, b1 = b0 + chunk, end = (uint64_t)first + count;
-    if (b0 > end) b0 = end;
-    if (b1 > end) b1 = end;
-    *a0 = (uint32_t)b0; *a1 = (uint32_t)b1;
-}
 
 static inline float down32(double d) { float f = (float)d; if ((double)f > d) f = nextafterf(f, -INFINITY); return f; }
 static inline float up32(double d)   { float f = (float)d; if ((double)f < d) f = nextafterf(f,  INFINITY); return f; }
@@ -197,7 +117,7 @@ static void range_bounds(const build_ctx_t *b, uint32_t first, uint32_t count,
         bounds_job_t *j = (bounds_job_t *)malloc(sizeof(*j)); int t;
         if (j) {
             j->b = b; j->first = first; j->count = count;
-            pool_run(b->pool, bounds_part, j);
+            tpool_run(b->pool, bounds_part, j);
             for (t = 0; t < b->pool->nt; t++)
                 for (k = 0; k < 3; k++) {
                     if (j->part[t][k] < lo[k]) lo[k] = j->part[t][k];
@@ -350,7 +270,7 @@ static void build_range(build_ctx_t *b, arena_t *ar, tnode_t *node, uint32_t fir
             if (jb) {
                 jb->b = b; jb->first = first; jb->count = count;
                 for (a = 0; a < 3; a++) { jb->live[a] = live[a]; jb->scale[a] = scale3[a]; jb->clo[a] = clo[a]; }
-                pool_run(b->pool, bin_part, jb);
+                tpool_run(b->pool, bin_part, jb);
                 for (t = 0; t < b->pool->nt; t++)
                     for (a = 0; a < 3; a++) for (j = 0; j < NBINS; j++) {
                         B->cnt[a][j] += jb->part[t].cnt[a][j];
@@ -415,14 +335,14 @@ static void build_range(build_ctx_t *b, arena_t *ar, tnode_t *node, uint32_t fir
             if (j) {
                 int t; uint32_t nl = 0, nr = 0;
                 j->b = b; j->first = first; j->count = count; j->axis = best_axis; j->best_bin = best_bin; j->c0 = clo[best_axis]; j->scale = scale;
-                j->phase = 0; pool_run(b->pool, part_part, j);
+                j->phase = 0; tpool_run(b->pool, part_part, j);
                 for (t = 0; t < b->pool->nt; t++) {
                     uint32_t a0, a1; chunk_of(first, count, t, b->pool->nt, &a0, &a1);
                     j->loff[t] = nl; j->roff[t] = nr; nl += j->lcount[t]; nr += (a1 - a0) - j->lcount[t];
                 }
                 j->nleft = nl;
-                j->phase = 1; pool_run(b->pool, part_part, j);
-                j->phase = 2; pool_run(b->pool, part_part, j);
+                j->phase = 1; tpool_run(b->pool, part_part, j);
+                j->phase = 2; tpool_run(b->pool, part_part, j);
                 free(j);
                 l = r = first + nl;
             }
@@ -998,15 +918,15 @@ int lh_bvh_build_hook(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmes
     /* flatten in create_triangle_list order: primitive id = running index (the meshes' triangles cut into chunks for the pool) */
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 64) nthreads = 64;
-    if (nthreads > 1 && n > 100000) b.pool = pool_new(nthreads);
+    if (nthreads > 1 && n > 100000) b.pool = tpool_new(nthreads);
     {
         uint32_t p = 0;
         for (g = 0; g < nmeshes; g++) {
             prep_job_t pj;
             pj.m = &meshes[g]; pj.g = g; pj.p0 = p; pj.out = out; pj.b = &b; pj.err = 0;
-            if (b.pool && pj.m->nindices / 3 >= LH_PAR_MIN) pool_run(b.pool, prep_part, &pj);
+            if (b.pool && pj.m->nindices / 3 >= LH_PAR_MIN) tpool_run(b.pool, prep_part, &pj);
             else prep_part(&pj, 0, 1);
-            if (pj.err) { pool_free(b.pool); free(b.plo); free(b.phi); free(b.cen); free(b.order); lh_bvh_release(out); return pj.err; }
+            if (pj.err) { tpool_free(b.pool); free(b.plo); free(b.phi); free(b.cen); free(b.order); lh_bvh_release(out); return pj.err; }
             p += pj.m->nindices / 3;
         }
     }
@@ -1029,7 +949,7 @@ int lh_bvh_build_hook(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmes
     double t_prep = now_s();
     build_range(&b, &main_arena, root, 0, n, 0);
     b.collecting = 0;
-    pool_free(b.pool); b.pool = NULL; free(b.tmp); b.tmp = NULL;
+    tpool_free(b.pool); b.pool = NULL; free(b.tmp); b.tmp = NULL;
     double t_top = now_s();
 
     {

@@ -22,6 +22,10 @@
 
 #include <math.h>
 #include <pthread.h>
+#include "lh_tpool.h"
+#include <stdio.h>
+#include <time.h>
+static double rnow(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 #include <stdlib.h>
 #include <string.h>
 
@@ -104,7 +108,78 @@ typedef struct {
     int collecting;
     struct rtask { rnode_t *node; double bmin[3], bmax[3]; uint32_t il, ir; } *tasks;
     size_t ntasks, cap;
+    lh_tpool_t *tp;             /* the long ranges at the top of the tree: bins, partition and bounds on the thread pool.  Every one
+                                 * of these passes has an order-independent result (integer histograms, min / max) or a layout
+                                 * that can be computed from per-chunk counts (the partition), so the tree stays the reference's */
 } rctx_t;
+
+typedef struct { const tbox_t *b; uint32_t n; double part[LH_POOL_MAX][6]; } rbounds_job_t;
+static void rbounds_part(void *j_, int t, int nt)
+{
+    rbounds_job_t *j = (rbounds_job_t *)j_; uint32_t a0, a1, i; int k; double *o = j->part[t];
+    chunk_of(0, j->n, t, nt, &a0, &a1);
+    if (a0 >= a1) { for (k = 0; k < 3; k++) { o[k] = j->b[0].bmin[k]; o[3 + k] = j->b[0].bmax[k]; } return; }
+    for (k = 0; k < 3; k++) { o[k] = j->b[a0].bmin[k]; o[3 + k] = j->b[a0].bmax[k]; }
+    for (i = a0 + 1; i < a1; i++)
+        for (k = 0; k < 3; k++) {
+            o[k] = (o[k] < j->b[i].bmin[k]) ? o[k] : j->b[i].bmin[k];
+            o[3 + k] = (o[3 + k] > j->b[i].bmax[k]) ? o[3 + k] : j->b[i].bmax[k];
+        }
+}
+
+/* bounds_of on the pool (min / max of doubles: exact, whatever the order) */
+static void bounds_of_par(lh_tpool_t *tp, double bmin[3], double bmax[3], const tbox_t *b, uint32_t n)
+{
+    rbounds_job_t *j = (tp && n >= LH_PAR_MIN) ? (rbounds_job_t *)malloc(sizeof(*j)) : NULL; int t, k;
+    if (!j) { bounds_of(bmin, bmax, b, n); return; }
+    j->b = b; j->n = n;
+    tpool_run(tp, rbounds_part, j);
+    for (k = 0; k < 3; k++) { bmin[k] = j->part[0][k]; bmax[k] = j->part[0][3 + k]; }
+    for (t = 1; t < tp->nt; t++)
+        for (k = 0; k < 3; k++) {
+            bmin[k] = (bmin[k] < j->part[t][k]) ? bmin[k] : j->part[t][k];
+            bmax[k] = (bmax[k] > j->part[t][3 + k]) ? bmax[k] : j->part[t][3 + k];
+        }
+    free(j);
+}
+
+typedef struct { const tbox_t *b; uint32_t n; double bmin[3], inv[3]; uint32_t part[LH_POOL_MAX][2][3][REF_BIN_SIZE]; } rbin_job_t;
+static void rbin_part(void *j_, int t, int nt)
+{
+    rbin_job_t *j = (rbin_job_t *)j_; uint32_t a0, a1, i; int k;
+    chunk_of(0, j->n, t, nt, &a0, &a1);
+    memset(j->part[t], 0, sizeof(j->part[t]));
+    for (i = a0; i < a1; i++)
+        for (k = 0; k < 3; k++) {
+            double qmin = (j->b[i].bmin[k] - j->bmin[k]) * j->inv[k], qmax = (j->b[i].bmax[k] - j->bmin[k]) * j->inv[k];
+            uint32_t imin = (uint32_t)qmin, imax = (uint32_t)qmax;
+            if (imin >= REF_BIN_SIZE) imin = REF_BIN_SIZE - 1;
+            if (imax >= REF_BIN_SIZE) imax = REF_BIN_SIZE - 1;
+            j->part[t][0][k][imin]++; j->part[t][1][k][imax]++;
+        }
+}
+
+/* the reference's partition (bvh.c:1437-1478): left elements keep their order, right elements are written from the end
+ * backwards -- element i's place follows from how many lefts / rights precede it: per-chunk counts, prefix sums, scatter */
+typedef struct { tbox_t *dst; tbox_t *scratch; uint32_t n; int axis; double pos; uint32_t lcount[LH_POOL_MAX], loff[LH_POOL_MAX], roff[LH_POOL_MAX]; int phase; } rpart_job_t;
+static void rpart_part(void *j_, int t, int nt)
+{
+    rpart_job_t *j = (rpart_job_t *)j_; uint32_t a0, a1, i;
+    chunk_of(0, j->n, t, nt, &a0, &a1);
+    if (j->phase == 0) {
+        uint32_t c = 0;
+        if (a1 > a0) memcpy(j->scratch + a0, j->dst + a0, sizeof(tbox_t) * (size_t)(a1 - a0));
+        for (i = a0; i < a1; i++) c += (j->scratch[i].bmax[j->axis] < j->pos);
+        j->lcount[t] = c;
+    } else {
+        uint32_t wl = j->loff[t], wr = j->n - 1u - j->roff[t];
+        for (i = a0; i < a1; i++) {
+            if (j->scratch[i].bmax[j->axis] < j->pos) j->dst[wl++] = j->scratch[i];
+            else                                      j->dst[wr--] = j->scratch[i];
+        }
+    }
+}
+
 
 static void construct(rctx_t *cx, pool_t *pool, tbox_t *scratch, rnode_t *me, const double bmin[3],
                       const double bmax[3], uint32_t il, uint32_t ir)
@@ -133,6 +208,18 @@ static void construct(rctx_t *cx, pool_t *pool, tbox_t *scratch, rnode_t *me, co
         double size[3], inv[3];
         for (k = 0; k < 3; k++) { size[k] = bmax[k] - bmin[k]; inv[k] = (size[k] > REF_EPS) ? (double)REF_BIN_SIZE / size[k] : 0.0; }
         memset(bin, 0, sizeof(bin));
+        if (cx->collecting && cx->tp && n >= LH_PAR_MIN) {
+            rbin_job_t *jb = (rbin_job_t *)malloc(sizeof(*jb));
+            if (jb) {
+                int t, h, b2;
+                jb->b = boxes + il; jb->n = n;
+                for (k = 0; k < 3; k++) { jb->bmin[k] = bmin[k]; jb->inv[k] = inv[k]; }
+                tpool_run(cx->tp, rbin_part, jb);
+                for (t = 0; t < cx->tp->nt; t++) for (h = 0; h < 2; h++) for (k = 0; k < 3; k++) for (b2 = 0; b2 < REF_BIN_SIZE; b2++) bin[h][k][b2] += jb->part[t][h][k][b2];
+                free(jb);
+                goto binned;
+            }
+        }
         for (i = 0; i < n; i++)
             for (k = 0; k < 3; k++) {
                 double qmin = (boxes[il + i].bmin[k] - bmin[k]) * inv[k], qmax = (boxes[il + i].bmax[k] - bmin[k]) * inv[k];
@@ -141,6 +228,7 @@ static void construct(rctx_t *cx, pool_t *pool, tbox_t *scratch, rnode_t *me, co
                 if (imax >= REF_BIN_SIZE) imax = REF_BIN_SIZE - 1;
                 bin[0][k][imin]++; bin[1][k][imax]++;
             }
+        binned: ;
     }
     /* find_cut_from_bin bvh.c:1230-1326 */
     {
@@ -161,10 +249,26 @@ static void construct(rctx_t *cx, pool_t *pool, tbox_t *scratch, rnode_t *me, co
     }
     /* partition bvh.c:1437-1478 */
     nr = n - 1;
-    memcpy(scratch, boxes + il, sizeof(tbox_t) * n);
-    for (i = 0; i < n; i++) {
-        if (scratch[i].bmax[cut_axis] < cut_pos) boxes[il + nl++] = scratch[i];
-        else                                     boxes[il + nr--] = scratch[i];
+    {
+        rpart_job_t *jp = (cx->collecting && cx->tp && n >= LH_PAR_MIN) ? (rpart_job_t *)malloc(sizeof(*jp)) : NULL;
+        if (jp) {
+            int t; uint32_t cl = 0, cr = 0;
+            jp->dst = boxes + il; jp->scratch = scratch; jp->n = n; jp->axis = cut_axis; jp->pos = cut_pos;
+            jp->phase = 0; tpool_run(cx->tp, rpart_part, jp);
+            for (t = 0; t < cx->tp->nt; t++) {
+                uint32_t a0, a1; chunk_of(0, n, t, cx->tp->nt, &a0, &a1);
+                jp->loff[t] = cl; jp->roff[t] = cr; cl += jp->lcount[t]; cr += (a1 - a0) - jp->lcount[t];
+            }
+            jp->phase = 1; tpool_run(cx->tp, rpart_part, jp);
+            nl = cl;
+            free(jp);
+        } else {
+            memcpy(scratch, boxes + il, sizeof(tbox_t) * n);
+            for (i = 0; i < n; i++) {
+                if (scratch[i].bmax[cut_axis] < cut_pos) boxes[il + nl++] = scratch[i];
+                else                                     boxes[il + nr--] = scratch[i];
+            }
+        }
     }
     if (nl == 0 || nl == n) nl = n / 2;
 
@@ -172,10 +276,10 @@ static void construct(rctx_t *cx, pool_t *pool, tbox_t *scratch, rnode_t *me, co
     me->c[0] = pool_new(pool); me->c[1] = pool_new(pool);
     {
         double lmin[3], lmax[3], rmin[3], rmax[3];
-        bounds_of(lmin, lmax, boxes + il, nl); add_margin(lmin, lmax);
+        bounds_of_par(cx->collecting ? cx->tp : NULL, lmin, lmax, boxes + il, nl); add_margin(lmin, lmax);
         for (k = 0; k < 3; k++) { me->box[0][k] = lmin[k]; me->box[0][3 + k] = lmax[k]; }
         construct(cx, pool, scratch, me->c[0], lmin, lmax, il, il + nl);
-        bounds_of(rmin, rmax, boxes + il + nl, n - nl); add_margin(rmin, rmax);
+        bounds_of_par(cx->collecting ? cx->tp : NULL, rmin, rmax, boxes + il + nl, n - nl); add_margin(rmin, rmax);
         for (k = 0; k < 3; k++) { me->box[1][k] = rmin[k]; me->box[1][3 + k] = rmax[k]; }
         construct(cx, pool, scratch, me->c[1], rmin, rmax, il + nl, ir);
     }
@@ -224,6 +328,7 @@ static void flatten(lh_refbvh_t *o, const rnode_t *n, uint32_t idx, int32_t pare
 int lh_refbvh_build(lh_refbvh_t *o, const lh_tri64_t *tri64, uint32_t ntris, int nthreads)
 {
     rctx_t cx; pool_t main_pool; rnode_t *root; tbox_t *scratch; uint32_t i; int k;
+    const double t0 = rnow(); double t1, t2, t3;
     memset(o, 0, sizeof(*o));
     o->ntris = ntris;
     if (ntris == 0) { o->empty = 1; return 0; }     /* bvh.c:311-315 */
@@ -244,15 +349,22 @@ int lh_refbvh_build(lh_refbvh_t *o, const lh_tri64_t *tri64, uint32_t ntris, int
         }
         cx.boxes[i].index = i;
     }
-    bounds_of(o->bmin, o->bmax, cx.boxes, ntris);
-    add_margin(o->bmin, o->bmax);
-
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 64) nthreads = 64;
-    if (nthreads > 1 && ntris > 50000) { cx.collecting = 1; cx.threshold = ntris / (uint32_t)(nthreads * 8); if (cx.threshold < 2048) cx.threshold = 2048; }
+    if (nthreads > 1 && ntris > 50000) {
+        cx.collecting = 1; cx.threshold = ntris / (uint32_t)(nthreads * 8); if (cx.threshold < 2048) cx.threshold = 2048;
+        cx.tp = tpool_new(nthreads);
+        /* no serial pass over more than LH_PAR_MIN boxes at the top */
+        if (cx.tp && cx.threshold < LH_PAR_MIN && ntris / LH_PAR_MIN >= (uint32_t)(2 * nthreads)) cx.threshold = LH_PAR_MIN;
+    }
+    t1 = rnow();
+    bounds_of_par(cx.tp, o->bmin, o->bmax, cx.boxes, ntris);
+    add_margin(o->bmin, o->bmax);
     root = pool_new(&main_pool);
     construct(&cx, &main_pool, scratch, root, o->bmin, o->bmax, 0, ntris);
     cx.collecting = 0;
+    tpool_free(cx.tp); cx.tp = NULL;
+    t2 = rnow();
     {
         rworker_t *w = NULL; pthread_t *th = NULL; volatile uint32_t next = 0; int t; uint32_t max_n = 0; size_t q;
         for (q = 0; q < cx.ntasks; q++) if (cx.tasks[q].ir - cx.tasks[q].il > max_n) max_n = cx.tasks[q].ir - cx.tasks[q].il;
@@ -261,6 +373,7 @@ int lh_refbvh_build(lh_refbvh_t *o, const lh_tri64_t *tri64, uint32_t ntris, int
             for (t = 0; t < nthreads; t++) { w[t].cx = &cx; w[t].next = &next; w[t].max_n = max_n; pthread_create(&th[t], NULL, rworker_main, &w[t]); }
             for (t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
         }
+        t3 = rnow();
         o->nnodes = count_nodes(root);
         o->nodes = (lh_refnode_t *)calloc(o->nnodes, sizeof(lh_refnode_t));
         if (!o->nodes) { free(cx.boxes); free(scratch); lh_refbvh_release(o); return -1; }
@@ -269,6 +382,7 @@ int lh_refbvh_build(lh_refbvh_t *o, const lh_tri64_t *tri64, uint32_t ntris, int
         free(w); free(th);
     }
     pool_free(&main_pool);
+    if (getenv("LH_BUILD_TIMING")) fprintf(stderr, "[lh_refbvh] boxes %.3f top %.3f subtrees %.3f flatten %.3f (tasks %zu)\n", t1 - t0, t2 - t1, t3 - t2, rnow() - t3, cx.ntasks);
     free(cx.tasks); free(cx.boxes); free(scratch);
     return 0;
 }
