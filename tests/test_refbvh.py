@@ -59,3 +59,19 @@ def test_exact_t_ties_follow_the_reference():
         assert nties > 100                                          # the test really exercises ties
     finally:
         Model.ref_off()
+
+
+def test_parallel_top_levels_keep_lucilles_tree():
+    """above 2^17 primitives the top of lucille's tree is binned / partitioned by a thread pool (lh_tpool.h): integer histograms,
+    min / max bounds and a partition whose layout follows from per-chunk counts -- the tree and the leaf order (= the tie rule's
+    input) must equal the single-thread build's and the oracle's, bit for bit"""
+    from lucille_amd import scenes
+    P, idx, _ = scenes.soup_triangles(400000, 0.007)
+    a = Model(P, idx, nthreads=8); a.ref_build(nthreads=1)
+    b = Model(P, idx, nthreads=8); b.ref_build(nthreads=8)
+    la_, lb_ = a.ref_leaf_order(), b.ref_leaf_order()
+    assert np.array_equal(la_[0], lb_[0]) and np.array_equal(la_[1], lb_[1])
+    assert all(np.array_equal(x, y) for x, y in zip(a.ref_bbox(), b.ref_bbox()))
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    ol = o.leaf_order()
+    assert np.array_equal(ol[0], lb_[0]) and np.array_equal(ol[1], lb_[1])
