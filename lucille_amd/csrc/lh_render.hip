@@ -35,13 +35,7 @@
 
 namespace {
 
-#define LH_NC _Pragma("clang fp contract(off)")
-
-struct DevCamera {
-    double c2w[16];
-    double flength;
-    int width, height, rh, ortho;
-};
+#include "lh_pt.h"
 
 /* the pixels of one device batch: nbands full-rows-of-w bands of band_rows lines each, band b starting at frame line
  * band_y0[b] (or y0 when there is a single band: a plain rectangle).  Pixel index p of the batch: band = p / (w * band_rows),
@@ -61,19 +55,6 @@ __device__ __forceinline__ void region_pixel(const Region &rg, size_t pix, int &
     const size_t within = pix % per;
     px = rg.x0 + (int)(within % (size_t)rg.w);
     py = (rg.band_y0 ? rg.band_y0[band] : rg.y0) + (int)(within / (size_t)rg.w);
-}
-
-__device__ __forceinline__ void vnormalize(double d[3])
-{   /* ri_vector_normalize (vector.h:75-86): FLOAT threshold literal */
-    LH_NC
-    const double norm2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    if (norm2 > (double)1.0e-17f) { const double rsq = 1.0 / sqrt(norm2); d[0] *= rsq; d[1] *= rsq; d[2] *= rsq; }
-}
-
-__device__ __forceinline__ void vcross(double d[3], const double a[3], const double b[3])
-{
-    LH_NC
-    d[0] = a[1] * b[2] - a[2] * b[1]; d[1] = a[2] * b[0] - a[0] * b[2]; d[2] = a[0] * b[1] - a[1] * b[0];
 }
 
 /* radical inverse permutation of init_sigma (render.c:870-917) */
@@ -419,65 +400,17 @@ __global__ void k_state_build(size_t n, const lh_dev_scene_t sc, const double *_
 /* ri_raytrace level (every bounce goes through the closest-hit kernel and fp64 resolve).   */
 /* ------------------------------------------------------------------------------------ */
 
-__device__ __forceinline__ double rnd01(uint64_t key) { return (double)mix32(key) * 2.3283064365386963e-10; }
-
-#define LH_PT_INTERIOR 0x80000000u
-
-struct DevMaterial { float kd[3], ks[3], kt[3], ior; };
-struct DevEnv { float rgb[3]; const float4 *map; int w, h; };
-
-/* ri_texture_ibl_fetch (texture.c:238-276) + ri_texture_fetch's bilinear filter (:86-180) */
-__device__ __forceinline__ void env_fetch(const DevEnv &e, double dx, double dy, double dz, float out[3])
-{
-    if (!e.map) { out[0] = e.rgb[0]; out[1] = e.rgb[1]; out[2] = e.rgb[2]; return; }
-    double d[3] = {dx, dy, dz};
-    vnormalize(d);
-    const double pi = 3.1415926535;
-    double r = (d[2] >= -1.0 && d[2] < 1.0) ? (1.0 / pi) * acos(d[2]) : 0.0;
-    const double n2 = d[0] * d[0] + d[1] * d[1];
-    if (n2 > 1.0e-6) r /= sqrt(n2);
-    double u = 0.5 * (d[0] * r) + 0.5, v = 0.5 - 0.5 * (d[1] * r);
-    u -= floor(u); v -= floor(v);
-    if (u < 0.0) u = 0.0; if (u >= 1.0) u = 1.0;
-    if (v < 0.0) v = 0.0; if (v >= 1.0) v = 1.0;
-    const double px = u * (e.w - 1), py = v * (e.h - 1);
-    int x = (int)px, y = (int)py;
-    const double fx = px - x, fy = py - y;
-    const int x1 = x < e.w - 1 ? x + 1 : x, y1 = y < e.h - 1 ? y + 1 : y;
-    const float4 t00 = e.map[(size_t)y * e.w + x], t01 = e.map[(size_t)y1 * e.w + x];
-    const float4 t10 = e.map[(size_t)y * e.w + x1], t11 = e.map[(size_t)y1 * e.w + x1];
-    const double w0 = (1.0 - fx) * (1.0 - fy), w1 = (1.0 - fx) * fy, w2 = fx * (1.0 - fy), w3 = fx * fy;
-    out[0] = (float)(w0 * t00.x + w1 * t01.x + w2 * t10.x + w3 * t11.x) * e.rgb[0];
-    out[1] = (float)(w0 * t00.y + w1 * t01.y + w2 * t10.y + w3 * t11.y) * e.rgb[1];
-    out[2] = (float)(w0 * t00.z + w1 * t01.z + w2 * t10.z + w3 * t11.z) * e.rgb[2];
-}
-
 /* one thread per path: path id = (pixel * spp + s); primary camera ray through a random
  * sub-pixel position (sample_pixel, pathtrace.c:316-352) */
 __global__ void k_pt_primary(DevCamera cam, int x0, int y0, int w, int h, int spp, int s0, unsigned long long seed,
                              double *__restrict__ org, double *__restrict__ dir, uint32_t *__restrict__ path_of,
                              float *__restrict__ thr)
 {
-    LH_NC
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)w * h * spp;
     if (id >= total) return;
-    const int s = (int)(id % spp);
-    const size_t pix = id / spp;
-    const int px = x0 + (int)(pix % w), py = y0 + (int)(pix / w);
-    const uint64_t key = (seed * 0x9E3779B97F4A7C15ULL) ^ ((((uint64_t)py * (uint64_t)cam.width + (uint64_t)px) << 20) + (uint64_t)(s0 + s)) * 64ull;
-    const double x = (double)px + rnd01(key), y = (double)py + rnd01(key + 1);
-    const double W = cam.width, H = cam.height;
-    const float sign = cam.rh ? -1.0f : 1.0f;
-    double v[4], o[4] = {0.0, 0.0, 0.0, 1.0}, pos[4], dp[4];
-    v[0] = (2.0f * x - W) / W; v[1] = (2.0f * y - H) / H; v[2] = sign * cam.flength; v[3] = 1.0;
-    if (cam.ortho) { o[0] = v[0]; o[1] = v[1]; v[2] = sign * 1.0; }      /* camera.c:285-301 */
-    for (int c = 0; c < 4; c++) {
-        pos[c] = 0.0; dp[c] = 0.0;
-        for (int r = 0; r < 4; r++) { pos[c] += o[r] * cam.c2w[4 * r + c]; dp[c] += v[r] * cam.c2w[4 * r + c]; }
-    }
-    double d[3] = {dp[0] - pos[0], dp[1] - pos[1], dp[2] - pos[2]};
-    vnormalize(d);
+    double pos[3], d[3];
+    pt_primary_ray(cam, x0, y0, w, spp, s0, seed, id, pos, d);
     org[3 * id] = pos[0]; org[3 * id + 1] = pos[1]; org[3 * id + 2] = pos[2];
     dir[3 * id] = d[0]; dir[3 * id + 1] = d[1]; dir[3 * id + 2] = d[2];
     path_of[id] = (uint32_t)id;                      /* bit 31: the path is inside a refractive object */
@@ -492,14 +425,6 @@ __global__ void k_pt_primary(DevCamera cam, int x0, int y0, int w, int h, int sp
  *   k_pt_decide: miss -> radiance[path] = throughput x environment(dir), the path ends; hit -> vertex limit and Russian
  *                roulette on d + s + t (russian_roulette, pathtrace.c:407-430) -> alive flag
  *   k_pt_emit:   for the survivors: hit epilogue, reflection type D / S / T, next ray, throughput -> slot j */
-__device__ __forceinline__ uint64_t pt_key(unsigned long long seed, uint32_t path, int spp, int s0, int x0, int y0, int w, int full_width, int depth)
-{
-    const size_t pix = path / (uint32_t)spp;
-    const uint64_t gx = (uint64_t)(x0 + (int)(pix % (size_t)w)), gy = (uint64_t)(y0 + (int)(pix / (size_t)w));
-    return ((seed * 0x9E3779B97F4A7C15ULL) ^ (((gy * (uint64_t)full_width + gx) << 20) + (uint64_t)(s0 + (int)(path % (uint32_t)spp))) * 64ull)
-           + 4ull * (uint64_t)(depth + 1);
-}
-
 __global__ void k_pt_decide(size_t n, const uint32_t *__restrict__ prim_mesh, const DevMaterial *__restrict__ materials,
                             const DevMaterial override_mat, int use_override, const DevEnv env,
                             int depth, int max_depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w, int full_width,
@@ -518,9 +443,8 @@ __global__ void k_pt_decide(size_t n, const uint32_t *__restrict__ prim_mesh, co
         alive[i] = 0; return;
     }
     const DevMaterial M = use_override ? override_mat : materials[prim_mesh[p]];
-    const double ksum = ((double)M.kd[0] + M.kd[1] + M.kd[2] + M.ks[0] + M.ks[1] + M.ks[2] + M.kt[0] + M.kt[1] + M.kt[2]) / 3.0;
     const uint64_t key = pt_key(seed, path, spp, s0, x0, y0, w, full_width, depth);
-    const bool go = !(depth + 2 >= max_depth || !(ksum > 0.0) || rnd01(key) > ksum);
+    const bool go = pt_survives(M, key, depth, max_depth);
     alive[i] = go ? 1 : 0;            /* radiance[] was zeroed for the pass: a path that ends here contributes nothing */
 }
 
@@ -550,84 +474,14 @@ __global__ void k_pt_emit(size_t n, const lh_dev_scene_t sc, const double *__res
     const uint32_t pword = path_of[i];
     const uint32_t path = pword & ~LH_PT_INTERIOR;
     const uint32_t p = prim[i];
-    float G[3] = {thr[3 * i], thr[3 * i + 1], thr[3 * i + 2]};
-    double D[3] = {dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]};
+    const float G[3] = {thr[3 * i], thr[3 * i + 1], thr[3 * i + 2]};
+    const double Or[3] = {org[3 * i], org[3 * i + 1], org[3 * i + 2]}, D[3] = {dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]};
     const uint64_t key = pt_key(seed, path, spp, s0, x0, y0, w, full_width, depth);
     const DevMaterial M = use_override ? override_mat : materials[prim_mesh[p]];
-    const double kd_ = ((double)M.kd[0] + M.kd[1] + M.kd[2]) / 3.0, ks_ = ((double)M.ks[0] + M.ks[1] + M.ks[2]) / 3.0, kt_ = ((double)M.kt[0] + M.kt[1] + M.kt[2]) / 3.0;
-    const double ksum = kd_ + ks_ + kt_;
-    /* ri_intersection_state_build subset: P, Ng, Ns, colour */
-    const double *tv = (const double *)sc.tri64 + 9 * (size_t)p;
-    const double tt = t[i], uu = u[i], vv = v[i], wgt = 1.0 - uu - vv;
-    double P[3], Ng[3], Ns[3], v01[3], v02[3];
-    for (int k = 0; k < 3; k++) P[k] = org[3 * i + k] + D[k] * tt;
-    for (int k = 0; k < 3; k++) { v01[k] = tv[3 + k] - tv[k]; v02[k] = tv[6 + k] - tv[k]; }
-    vcross(Ng, v01, v02); vnormalize(Ng);
-    bool has_n = false;
-    if (nrm9) { const double n0x = nrm9[9 * (size_t)p]; has_n = (n0x == n0x); }
-    if (has_n) {
-        const double *nn = nrm9 + 9 * (size_t)p;
-        for (int k = 0; k < 3; k++) { const double a = nn[k] * wgt, b = nn[3 + k] * uu, c = nn[6 + k] * vv; Ns[k] = (a + b) + c; }
-        vnormalize(Ns);
-    } else { Ns[0] = Ng[0]; Ns[1] = Ng[1]; Ns[2] = Ng[2]; }
-    float col[3] = {1.0f, 1.0f, 1.0f};
-    if (col9) {
-        const double *cc = col9 + 9 * (size_t)p;
-        if (cc[0] == cc[0]) for (int k = 0; k < 3; k++) { const double a = cc[k] * wgt, b = cc[3 + k] * uu, c = cc[6 + k] * vv; col[k] = (float)((a + b) + c); }
-    }
-    /* the normal facing the incoming ray */
-    const bool back = Ns[0] * D[0] + Ns[1] * D[1] + Ns[2] * D[2] > 0.0;
-    double N[3] = {back ? -Ns[0] : Ns[0], back ? -Ns[1] : Ns[1], back ? -Ns[2] : Ns[2]};
-    /* reflection type (sample_reflection_type, pathtrace.c:432-459) */
-    const double rt = rnd01(key + 3) * ksum;
-    int type = rt < kd_ ? 0 : (rt < kd_ + ks_ ? 1 : 2);
-    uint32_t interior = pword & LH_PT_INTERIOR;
-    double O[3];
-    double side = 1.0;                          /* which side of the surface the next ray starts on */
-    if (type == 2) {
-        /* ri_refract (reflection.c:69-128) with the unit direction: relative index ior when leaving, 1 / ior when entering */
-        double In[3] = {D[0], D[1], D[2]};
-        vnormalize(In);
-        const double e = interior ? (double)M.ior : 1.0 / (double)M.ior;
-        const double cos1 = -(In[0] * N[0] + In[1] * N[1] + In[2] * N[2]);
-        const double coeff = 1.0 - (e * e) * (1.0 - cos1 * cos1);
-        if (coeff <= 0.0) type = 1;             /* total internal reflection */
-        else {
-            const double c2 = e * cos1 - sqrt(coeff);
-            for (int k = 0; k < 3; k++) O[k] = c2 * N[k] + e * In[k];
-            vnormalize(O);
-            side = -1.0;
-            interior ^= LH_PT_INTERIOR;
-        }
-    }
-    if (type == 1) {                            /* ri_reflect (reflection.c:26-50): r = in - 2 n (in . n) */
-        const double dn = D[0] * N[0] + D[1] * N[1] + D[2] * N[2];
-        for (int k = 0; k < 3; k++) O[k] = D[k] - 2.0 * dn * N[k];
-    } else if (type == 0) {                     /* sample_cosweight (pathtrace.c:500-531) about the facing normal */
-        double b0[3], b1[3] = {0.0, 0.0, 0.0};
-        int ax = 3;
-        for (int k = 0; k < 3; k++) if (N[k] < 0.6 && N[k] > -0.6) { ax = k; break; }
-        if (ax >= 3) ax = 0;
-        b1[ax] = 1.0;
-        vcross(b0, b1, N); vnormalize(b0);
-        vcross(b1, N, b0); vnormalize(b1);
-        const double z0 = rnd01(key + 1), z1 = rnd01(key + 2);
-        const double ct = sqrt(z0), phi = 2.0 * 3.14159265358979323846 * z1;
-        double sp, cp;
-        sincos(phi, &sp, &cp);
-        const double d0 = cp * ct, d1 = sp * ct, d2 = sqrt(1.0 - ct * ct);
-        for (int k = 0; k < 3; k++) O[k] = d0 * b0[k] + d1 * b1[k] + d2 * N[k];
-    }
-    /* throughput (brdf, pathtrace.c:533-565) */
-    const float *kk = type == 0 ? M.kd : (type == 1 ? M.ks : M.kt);
-    const double pk = type == 0 ? kd_ : (type == 1 ? ks_ : kt_);
-    const float wsel = ref_weights ? (type == 0 ? 0.318309886f : 1.0f) : (float)(1.0 / pk);     /* unbiased: / (P(type) x survival) */
-    for (int k = 0; k < 3; k++) {
-        thr2[3 * j + k] = G[k] * kk[k] * col[k] * wsel;
-        org2[3 * j + k] = P[k] + side * N[k] * 1.0e-6;
-        dir2[3 * j + k] = O[k];
-    }
-    path_of2[j] = path | interior;
+    double o2[3], O[3]; float G2[3]; uint32_t pw2;
+    pt_scatter(sc, nrm9, col9, M, ref_weights, key, p, pword, Or, D, t[i], u[i], v[i], G, o2, O, G2, pw2);
+    for (int k = 0; k < 3; k++) { thr2[3 * j + k] = G2[k]; org2[3 * j + k] = o2[k]; dir2[3 * j + k] = O[k]; }
+    path_of2[j] = pw2;
 }
 
 __global__ void k_flag_count(size_t n, const uint8_t *__restrict__ flag, uint32_t *__restrict__ block_counts)
