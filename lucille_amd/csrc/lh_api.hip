@@ -93,6 +93,8 @@ struct lh_accel {
     /* device */
     lh_dev_scene_t dev;
     void *d_nodes, *d_tri32, *d_tri64, *d_qnodes, *d_q4nodes, *d_q4tnodes, *d_q8nodes, *d_c8nodes, *d_tri32_c8;
+    int ncus, grid_forced_pt;          /* compute units of the device; "pt_grid": workgroups of the fused path-tracing kernel */
+    int pt_fused;                      /* path-tracing passes inside the walk (ray source 2 of the trace kernel); 0: wavefront passes */
     int wide8;                         /* ray dumps walk the 8-wide nodes: -1 when the hot set exceeds the Infinity Cache (default), 0 never, 1 always */
     int quad_grid;                     /* workgroups of the quad-per-ray walk (variant 7) */
     unsigned long long *d_cursor, *d_counters;   /* d_cursor: LH_NCURSOR slots, one per launch in flight */
@@ -174,6 +176,8 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     a->ao_fused = 1;
     a->wide8 = -1;
     { const char *e = getenv("LH_WIDE8"); if (e) a->wide8 = atoi(e); }
+    a->pt_fused = 0;
+    { const char *e = getenv("LH_PT_FUSED"); if (e) a->pt_fused = atoi(e) != 0; }
     { const char *e = getenv("LH_AO_FUSED"); if (e) a->ao_fused = atoi(e) != 0; }
     const char *env = getenv("LH_VARIANT");
     if (env) a->default_variant = atoi(env);
@@ -701,7 +705,7 @@ static int device_upload(lh_accel_t *a)
         int per_cu = (int)(160u / stack);                     /* LDS: stack KiB per 256-thread workgroup */
         if (per_cu > 5) per_cu = 5;
         if (per_cu < 1) per_cu = 1;
-        a->grid_blocks = prop.multiProcessorCount * per_cu;
+        a->grid_blocks = prop.multiProcessorCount * per_cu; a->ncus = prop.multiProcessorCount;
         const char *env = getenv("LH_GRID_BLOCKS");
         if (env && atoi(env) > 0) a->grid_blocks = atoi(env);
         a->t2_grid = prop.multiProcessorCount * lh_trace2_blocks_per_cu();
@@ -858,6 +862,8 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
     else if (!strcmp(name, "variant") && value >= 0 && value <= LH_VARIANT_QUAD) a->default_variant = value;
     else if (!strcmp(name, "ao_fused")) a->ao_fused = value != 0;
     else if (!strcmp(name, "wide8") && value >= -1 && value <= 1) a->wide8 = value;
+    else if (!strcmp(name, "pt_fused")) a->pt_fused = value != 0;
+    else if (!strcmp(name, "pt_grid") && value >= 0) a->grid_forced_pt = value;
     else if (!strcmp(name, "quad_grid") && value > 0) a->quad_grid = value;
     else if (!strcmp(name, "stack_cap") && (value == 0 || (value >= 8 && value <= 64 && value % 2 == 0))) a->dev.stack_cap = (uint32_t)value;
     else return fail("lh_accel_set_param: unknown parameter or bad value: %s = %d", name, value);
@@ -1611,6 +1617,33 @@ static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w,
     if (S >= ((size_t)1 << 31)) return fail("lh_render_pt_tile: more than 2^31 paths in one pass; lower spp_count or the tile size");
     unsigned long long *cnt = (a->stat_on && a->hs->bvh.ntris) ? a->d_counters : NULL;      /* lh_accel_trace_statistics */
     if (cnt) HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * LH_CNT_DEV, s));
+    if (a->pt_fused && a->hs->bvh.ntris && a->dev.use_qnodes == 2) {
+        /* the pass inside the walk: camera ray to last vertex per lane, only the radiance goes through HBM (lh_pt.h) */
+        if (a->hs->device_built && !a->d_ref_nodes && sync_ref(a, false) != 0) return -1;
+        if (ensure_buf(&a->p_rad, S * 12)) return -1;
+        HIPCHK(hipMemsetAsync(a->d_total + 1, 0, 2 * sizeof(unsigned long long), s));
+        const int grid = a->grid_forced_pt > 0 ? a->grid_forced_pt : a->ncus * 2;
+        const int rcf = lh_launch_trace_pt(&a->dev, S, cam, x0, y0, w, spp, s0, cam->width, max_vertices, seed, (const double *)a->d_nrm9,
+                                           (const double *)a->d_attr9[0], (const uint32_t *)a->d_prim_mesh, a->d_materials, override_mat, env_rgb,
+                                           d_env_map, env_w, env_h, (flags & LH_PT_REFERENCE_WEIGHTS) != 0, (float *)a->p_rad.p, a->d_total + 1,
+                                           (unsigned int *)(a->d_total + 2), cnt, a->d_cursor + (a->cursor_next++ % LH_NCURSOR), grid,
+                                           a->min_active, a->tri_batch, (void *)s);
+        if (rcf == 0) {
+            unsigned long long hv[2] = {0, 0};
+            if (lh_pt_launch_resolve(w, h, spp, 1.0f / (float)spp_total, (const float *)a->p_rad.p, (float *)d_rgb, s) != 0)
+                return fail("pt resolve launch failed");
+            HIPCHK(hipMemcpyAsync(hv, a->d_total + 1, sizeof(hv), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (cnt) {
+                unsigned long long hc[LH_CNT_N];
+                HIPCHK(hipMemcpy(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost));
+                a->stat[0] += hc[LH_CNT_NODES]; a->stat[1] += hc[LH_CNT_TRIS]; a->stat[2] += hc[LH_CNT_EXACT]; a->stat[3] += hc[LH_CNT_RAYS];
+            }
+            if (stats) { stats->paths = S; stats->rays = hv[0]; stats->max_depth_reached = (uint64_t)(unsigned int)hv[1] + 1u; }
+            return 0;
+        }
+        /* a tree the fused walk cannot take (deeper than the LDS rows and lucille's own tree not there yet): wavefront passes */
+    }
     const unsigned nb = (unsigned)((S + 255) / 256);
     if (ensure_buf(&a->r_org, S * 24) || ensure_buf(&a->r_dir, S * 24) || ensure_buf(&a->p_org2, S * 24) ||
         ensure_buf(&a->p_dir2, S * 24) || ensure_buf(&a->r_prim, S * 4) || ensure_buf(&a->r_t, S * 8) ||

@@ -7,6 +7,7 @@
 
 #include <stdint.h>
 #include <stddef.h>
+#include "../../include/lucille_hip.h"     /* lh_camera_t, lh_material_t in the launcher signatures */
 
 #define LH_BLOCK      256          /* 4 wavefronts of 64 lanes              */
 #define LH_MISS_PRIM  0xFFFFFFFFu
@@ -97,6 +98,13 @@ int lh_launch_ao_queue(const lh_dev_scene_t *sc, int ntheta, int nphi, unsigned 
 
 /* lh_quad.hip: the quad-per-ray walk (variant LH_VARIANT_QUAD) */
 #define LH_QUAD_WAVES_PER_SIMD 4         /* what its register allocation allows (128 VGPRs) */
+int lh_launch_trace_pt(const lh_dev_scene_t *sc, size_t npaths, const lh_camera_t *cam, int x0, int y0, int w, int spp, int s0,
+                       int full_width, int max_depth, unsigned long long seed, const double *d_nrm9, const double *d_col9,
+                       const uint32_t *d_prim_mesh, const void *d_materials, const lh_material_t *override_mat,
+                       const float env_rgb[3], const void *d_env_map, int env_w, int env_h, int ref_weights,
+                       float *d_radiance, unsigned long long *d_nrays, unsigned int *d_maxdepth,
+                       unsigned long long *d_counters, unsigned long long *d_cursor, int grid_blocks, int min_active,
+                       int tri_batch, void *stream);
 int lh_quad_make_nodes(uint32_t nq4, const void *d_q4nodes, void *d_q4tnodes, void *stream);
 int lh_quad_blocks_per_cu(uint32_t stack_rows);
 int lh_launch_trace_quad(const lh_dev_scene_t *sc, size_t n, const double *d_org, const double *d_dir, uint32_t *d_prim,

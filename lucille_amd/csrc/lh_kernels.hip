@@ -42,7 +42,9 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
+#include "../../include/lucille_hip.h"
 #include "lh_device.h"
 #include "lh_filter.h"
 #include "lh_reftrace.h"
@@ -51,6 +53,7 @@
 namespace {
 
 #include "lh_walk.h"
+#include "lh_pt.h"
 
 /* fetch one inner node and test both child boxes: fp32 nodes (4 x dwordx4) or 16-bit grid
  * nodes (2 x dwordx4) */
@@ -659,16 +662,71 @@ struct AoSrc {
     uint32_t *queue, *qcount; uint32_t qcap;
 };
 
+/* the reference's own walk for one ray, out of line: its private stack stays out of the persistent kernel's frame */
+struct RefHit { double t, u, v; uint32_t prim; };
+__device__ __noinline__ RefHit ref_trace_one(const lh_dev_scene_t &sc, double ox, double oy, double oz, double dx, double dy, double dz)
+{
+    RefHit h; uint32_t p = LH_MISS_PRIM; double tt = LH_T_INF, uu = 0.0, vv = 0.0;
+    (void)lh_ref_trace((const lh_refnode_t *)sc.ref_nodes, (const uint32_t *)sc.ref_leaf_prims, (const double *)sc.tri64,
+                       sc.ref_empty, sc.ref_bmin, sc.ref_bmax, ox, oy, oz, dx, dy, dz, &p, &tt, &uu, &vv);
+    h.prim = p; h.t = tt; h.u = uu; h.v = vv;
+    return h;
+}
+
+/* ray source 2: the paths of one path-tracing pass (lh_pt.h).  A lane takes path i, generates its camera ray, and every time
+ * its ray is finished it shades the hit and goes on with the path's next ray -- until the path leaves the scene (radiance =
+ * throughput x environment), loses the roulette or reaches the vertex limit.  Only radiance[path] goes through HBM. */
+struct PtSrc {
+    DevCamera cam; int x0, y0, w, spp, s0, full_width, max_depth, use_override, ref_weights;
+    unsigned long long seed;
+    const double *nrm9, *col9; const uint32_t *prim_mesh; const DevMaterial *materials; DevMaterial override_mat; DevEnv env;
+    float *radiance;                 /* [n][3], zeroed by the caller */
+    unsigned long long *nrays;       /* += rays traced */
+    unsigned int *maxdepth;          /* max= deepest vertex index reached */
+};
+
+/* one path vertex: the hit record of the finished ray -> radiance written (miss), path ended (roulette / vertex limit), or the
+ * next ray.  Inlined: out of line (to keep its fp64 temporaries out of the walk's register allocation) it was slower at every
+ * occupancy -- 228 / 234 / 291 ms at 2 / 3 / 4 waves per SIMD against 192 ms inline at 2 (profiles/README.md) */
+struct PtStep { double ox, oy, oz, dx, dy, dz; float g0, g1, g2; uint32_t pword; int go; };
+__device__ __forceinline__ PtStep pt_vertex(const lh_dev_scene_t &sc, const PtSrc &pt, uint32_t hp, double ht, double hu, double hv,
+                                         double ox, double oy, double oz, double dx, double dy, double dz,
+                                         float g0, float g1, float g2, uint32_t pword, int pdepth)
+{
+    PtStep o;
+    const uint32_t path = pword & ~LH_PT_INTERIOR;
+    o.ox = ox; o.oy = oy; o.oz = oz; o.dx = dx; o.dy = dy; o.dz = dz; o.g0 = g0; o.g1 = g1; o.g2 = g2; o.pword = pword; o.go = 0;
+    if (hp == LH_MISS_PRIM) {
+        float e[3];
+        env_fetch(pt.env, dx, dy, dz, e);
+        float *rad = pt.radiance + 3 * (size_t)path;
+        rad[0] = g0 * e[0]; rad[1] = g1 * e[1]; rad[2] = g2 * e[2];
+        return o;
+    }
+    const DevMaterial M = pt.use_override ? pt.override_mat : pt.materials[pt.prim_mesh[hp]];
+    const uint64_t key = pt_key(pt.seed, path, pt.spp, pt.s0, pt.x0, pt.y0, pt.w, pt.full_width, pdepth);
+    if (!pt_survives(M, key, pdepth, pt.max_depth)) return o;
+    {
+        const double Or[3] = {ox, oy, oz}, D[3] = {dx, dy, dz}; const float G[3] = {g0, g1, g2};
+        double o2[3], O[3]; float G2[3]; uint32_t pw2;
+        pt_scatter(sc, pt.nrm9, pt.col9, M, pt.ref_weights, key, hp, pword, Or, D, ht, hu, hv, G, o2, O, G2, pw2);
+        o.ox = o2[0]; o.oy = o2[1]; o.oz = o2[2]; o.dx = O[0]; o.dy = O[1]; o.dz = O[2];
+        o.g0 = G2[0]; o.g1 = G2[1]; o.g2 = G2[2]; o.pword = pw2; o.go = 1;
+    }
+    return o;
+}
+
 template <bool ANYHIT, bool COUNT, int WALK, bool QN, int SRC>
-__global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
-    lh_dev_scene_t sc, size_t n, const double *__restrict__ org, const double *__restrict__ dir,
+__device__ __forceinline__ void trace_persist_lane(
+    const lh_dev_scene_t &sc, size_t n, const double *__restrict__ org, const double *__restrict__ dir,
     uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
     double *__restrict__ v, uint8_t *__restrict__ occ, unsigned long long *counters,
-    unsigned long long *cursor, int min_active, int tri_batch, const AoSrc ao)
+    unsigned long long *cursor, int min_active, int tri_batch, const AoSrc &ao, const PtSrc &pt, int *lds)
 {
-    extern __shared__ int lh_stack_lds[];          /* [stack entries][LH_BLOCK], sized at launch */
-    int (*stk)[LH_BLOCK] = (int (*)[LH_BLOCK])lh_stack_lds;
+    int (*stk)[LH_BLOCK] = (int (*)[LH_BLOCK])lds;
     const int tid = threadIdx.x;
+    float g0 = 1.0f, g1 = 1.0f, g2 = 1.0f;      /* SRC 2: path throughput */
+    int pdepth = 0; uint32_t pword = 0u, lrays = 0u, ldeep = 0u;
     uint32_t cn = 0, ct = 0, ce = 0, cr = 0, cns = 0, cts = 0, crs = 0;
     Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM, 0u};
     int pend = 0;                    /* WALK 2: parked leaf reference (0 = none) */
@@ -681,14 +739,13 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
 
     for (;;) {
         /* ---- regroup: retire finished lanes, refill them ----------------- */
-        const bool idle = (L.cur == kDone) && (pend == 0);
-        const unsigned long long idle_mask = __ballot(idle);
+        bool idle = (L.cur == kDone) && (pend == 0);
         if (COUNT) crs++;
         if (idle) {
             if (my != (size_t)-1) {
                 finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce, SRC == 1 ? selfp : LH_MISS_PRIM);
                 if (SRC == 0) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL, WALK == 8 || WALK == 7);
-                else {
+                else if (SRC == 1) {
                     const bool hit = L.certain || best.prim != LH_MISS_PRIM;
                     const bool retrace = sc.ref_nodes != NULL && (L.over || (best.prim != LH_MISS_PRIM && best.frag != 0u && !L.certain));
                     if (retrace) {
@@ -696,11 +753,31 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
                         if (k < ao.qcap) { ao.queue[6 * (size_t)k] = (uint32_t)my; ao.queue[6 * (size_t)k + 1] = 5u; }   /* 5: the reference walk decides */
                         else atomicOr(ao.qcount + 1, 1u);
                     } else if (hit) atomicAdd(&ao.occ_count[(uint32_t)my / (uint32_t)(ao.ntheta * ao.nphi)], 1u);
+                } else {
+                    /* the path's vertex: the hit record as write_out + k_ref_retrace would leave it, then lh_pt.h */
+                    uint32_t hp = best.prim; double ht = best.t, hu = best.u, hv = best.v;
+                    if (sc.ref_nodes != NULL && (L.over || (best.prim != LH_MISS_PRIM && best.frag != 0u))) {
+                        const RefHit rh = ref_trace_one(sc, ox, oy, oz, dx, dy, dz);
+                        hp = rh.prim; ht = rh.t; hu = rh.u; hv = rh.v;
+                    }
+                    lrays++;
+                    const PtStep st = pt_vertex(sc, pt, hp, ht, hu, hv, ox, oy, oz, dx, dy, dz, g0, g1, g2, pword, pdepth);
+                    ox = st.ox; oy = st.oy; oz = st.oz; dx = st.dx; dy = st.dy; dz = st.dz;
+                    g0 = st.g0; g1 = st.g1; g2 = st.g2; pword = st.pword;
+                    if (st.go) {
+                        lane_init(L, sc, ox, oy, oz, dx, dy, dz);
+                        best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM; best.frag = 0u;
+                        stk[0][tid] = kDone;
+                        pdepth++;
+                        if ((uint32_t)pdepth > ldeep) ldeep = (uint32_t)pdepth;
+                        idle = false;                             /* the lane goes on with the same path */
+                    }
                 }
                 if (COUNT) cr++;
-                my = (size_t)-1;
+                if (idle) my = (size_t)-1;
             }
         }
+        const unsigned long long idle_mask = __ballot(idle);
         /* refill from the wave's private range [wbase, wend); one atomic on the global cursor reserves
          * sc.ray_chunk rays (the cursor is ONE address: at a refill per ~33 rays it serialised the whole
          * grid -- 64 M same-address atomics/s for 2.1 Grays/s, profiles/README.md r01e) */
@@ -722,6 +799,11 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
                 if (SRC == 0) {
                     ox = org[3 * i]; oy = org[3 * i + 1]; oz = org[3 * i + 2];
                     dx = dir[3 * i]; dy = dir[3 * i + 1]; dz = dir[3 * i + 2];
+                } else if (SRC == 2) {
+                    double po[3], pd[3];
+                    pt_primary_ray(pt.cam, pt.x0, pt.y0, pt.w, pt.spp, pt.s0, pt.seed, i, po, pd);
+                    ox = po[0]; oy = po[1]; oz = po[2]; dx = pd[0]; dy = pd[1]; dz = pd[2];
+                    g0 = g1 = g2 = 1.0f; pdepth = 0; pword = (uint32_t)i;
                 } else {
                     const uint32_t N = (uint32_t)(ao.ntheta * ao.nphi), slot = (uint32_t)i / N;
                     const unsigned long long key = ao.slot_key[slot];
@@ -764,6 +846,32 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
         atomicAdd(&counters[LH_CNT_TRI_SLOTS], (unsigned long long)cts);
         atomicAdd(&counters[LH_CNT_REGROUP_SLOTS], (unsigned long long)crs);
     }
+    if (SRC == 2) {
+        unsigned long long r = lrays; uint32_t dmax = ldeep;
+        for (int off = 32; off >= 1; off >>= 1) { r += __shfl_down(r, off); const uint32_t o = __shfl_down(dmax, off); dmax = o > dmax ? o : dmax; }
+        if ((tid & 63) == 0) { atomicAdd(pt.nrays, r); atomicMax(pt.maxdepth, dmax); }
+    }
+}
+
+template <bool ANYHIT, bool COUNT, int WALK, bool QN, int SRC>
+__global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
+    lh_dev_scene_t sc, size_t n, const double *__restrict__ org, const double *__restrict__ dir,
+    uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
+    double *__restrict__ v, uint8_t *__restrict__ occ, unsigned long long *counters,
+    unsigned long long *cursor, int min_active, int tri_batch, const AoSrc ao)
+{
+    extern __shared__ int lh_stack_lds[];          /* [stack entries][LH_BLOCK], sized at launch */
+    trace_persist_lane<ANYHIT, COUNT, WALK, QN, SRC>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, ao, PtSrc{}, lh_stack_lds);
+}
+
+/* one path-tracing pass, fused: n paths, camera ray to last vertex inside the walk (ray source 2) */
+template <bool COUNT, int WALK>
+__global__ __launch_bounds__(LH_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_trace_pt(lh_dev_scene_t sc, size_t n, unsigned long long *counters,
+                                                       unsigned long long *cursor, int min_active, int tri_batch, const PtSrc pt)
+{
+    extern __shared__ int lh_stack_lds[];
+    trace_persist_lane<false, COUNT, WALK, true, 2>(sc, n, (const double *)NULL, (const double *)NULL, (uint32_t *)NULL, (double *)NULL, (double *)NULL,
+                                                    (double *)NULL, (uint8_t *)NULL, counters, cursor, min_active, tri_batch, AoSrc{}, pt, lh_stack_lds);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -967,6 +1075,59 @@ extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int n
     if (scl.stack_guard) { if (d_counters) LH_AO_LAUNCH(true, 8); else LH_AO_LAUNCH(false, 8); }
     else { if (d_counters) LH_AO_LAUNCH(true, 3); else LH_AO_LAUNCH(false, 3); }
 #undef LH_AO_LAUNCH
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+/* one fused path-tracing pass (ray source 2): npaths paths of a w-wide tile at (x0, y0), spp samples per pixel starting at
+ * sample s0.  d_radiance [npaths][3] is zeroed here; *d_nrays += rays traced, *d_maxdepth = max(., deepest vertex).  Needs the
+ * 4-wide nodes; trees deeper than the LDS rows run the checked walk and lean on the reference walk for overflowing rays, so
+ * they need the reference-order tree (returns -1 otherwise: the caller falls back to the wavefront passes). */
+extern "C" int lh_launch_trace_pt(const lh_dev_scene_t *sc, size_t npaths, const lh_camera_t *cam, int x0, int y0, int w, int spp, int s0,
+                                  int full_width, int max_depth, unsigned long long seed, const double *d_nrm9, const double *d_col9,
+                                  const uint32_t *d_prim_mesh, const void *d_materials, const lh_material_t *override_mat,
+                                  const float env_rgb[3], const void *d_env_map, int env_w, int env_h, int ref_weights,
+                                  float *d_radiance, unsigned long long *d_nrays, unsigned int *d_maxdepth,
+                                  unsigned long long *d_counters, unsigned long long *d_cursor, int grid_blocks, int min_active,
+                                  int tri_batch, void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (npaths == 0) return 0;
+    if (npaths >= ((size_t)1 << 31) || sc->use_qnodes != 2) return -1;
+    lh_dev_scene_t scl = *sc;
+    uint32_t need = 3 * sc->q4_depth + 5;
+    const uint32_t cap = (sc->stack_cap >= 8 && sc->stack_cap < 64) ? sc->stack_cap : 64;
+    if (need > cap) {
+        if (!sc->ref_nodes) return -1;
+        need = cap; scl.stack_guard = 1;
+    }
+    need = (need + 1u) & ~1u;
+    if (need < 16 && need != cap) need = 16;
+    scl.stack_rows = need;
+    const size_t lds_bytes = (size_t)need * LH_BLOCK * sizeof(int);
+    {
+        const size_t waves = (size_t)(grid_blocks > 0 ? grid_blocks : 1) * (LH_BLOCK / 64);
+        size_t c = npaths / (waves * 4);
+        if (c < 64) c = 64;
+        if (c < scl.ray_chunk) scl.ray_chunk = (uint32_t)c;
+        if (scl.ray_chunk == 0) scl.ray_chunk = 64;
+    }
+    PtSrc pt;
+    memset(&pt, 0, sizeof(pt));
+    for (int k = 0; k < 16; k++) pt.cam.c2w[k] = cam->cam2world[k];
+    pt.cam.flength = cam->flength; pt.cam.width = cam->width; pt.cam.height = cam->height; pt.cam.rh = cam->rh; pt.cam.ortho = cam->ortho;
+    pt.x0 = x0; pt.y0 = y0; pt.w = w; pt.spp = spp; pt.s0 = s0; pt.full_width = full_width; pt.max_depth = max_depth;
+    pt.use_override = override_mat != NULL; pt.ref_weights = ref_weights; pt.seed = seed;
+    pt.nrm9 = d_nrm9; pt.col9 = d_col9; pt.prim_mesh = d_prim_mesh; pt.materials = (const DevMaterial *)d_materials;
+    if (override_mat) { for (int k = 0; k < 3; k++) { pt.override_mat.kd[k] = override_mat->kd[k]; pt.override_mat.ks[k] = override_mat->ks[k]; pt.override_mat.kt[k] = override_mat->kt[k]; } pt.override_mat.ior = override_mat->ior; }
+    pt.env.rgb[0] = env_rgb[0]; pt.env.rgb[1] = env_rgb[1]; pt.env.rgb[2] = env_rgb[2];
+    pt.env.map = (const float4 *)d_env_map; pt.env.w = env_w; pt.env.h = env_h;
+    pt.radiance = d_radiance; pt.nrays = d_nrays; pt.maxdepth = d_maxdepth;
+    if (hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), s) != hipSuccess) return -1;
+    if (hipMemsetAsync(d_radiance, 0, sizeof(float) * 3 * npaths, s) != hipSuccess) return -1;
+#define LH_PT_LAUNCH(CNT, W) hipLaunchKernelGGL((k_trace_pt<CNT, W>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s, scl, npaths, d_counters, d_cursor, min_active, tri_batch, pt)
+    if (scl.stack_guard) { if (d_counters) LH_PT_LAUNCH(true, 8); else LH_PT_LAUNCH(false, 8); }
+    else { if (d_counters) LH_PT_LAUNCH(true, 3); else LH_PT_LAUNCH(false, 3); }
+#undef LH_PT_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
