@@ -1060,6 +1060,7 @@ extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int n
     const size_t lds_bytes = (size_t)need * LH_BLOCK * sizeof(int);
     {
         const size_t waves = (size_t)(grid_blocks > 0 ? grid_blocks : 1) * (LH_BLOCK / 64);
+        if (scl.ray_chunk < 512) scl.ray_chunk = 512;      /* AO rays of a slot are coherent: longer ranges per wave (config 5: 92.9 -> 91.4 ms, tools/ao_sweep5.py) */
         size_t c = n / (waves * 4);
         if (c < 64) c = 64;
         if (c < scl.ray_chunk) scl.ray_chunk = (uint32_t)c;
