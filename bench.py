@@ -471,7 +471,7 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
         P_, I_ = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess)
         acc.add_mesh(P_, I_); ntri += I_.shape[0] // 3
         del P_, I_
-    info = acc.commit()
+    t0c = time.perf_counter(); info = acc.commit(); commit_host_s = time.perf_counter() - t0c
     c = g["camera"]
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
     # one GPU: the whole frame as one tile; sharded: full-width bands, ~16 per rank, band_id % world, ONE device batch per rank (render.bands_for / lh_render_ao_bands)
@@ -513,6 +513,22 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
                 "rays_counted": c["rays"],
                 "note": "coherent rays: the frame is bound by instruction issue and dependent-fetch latency, not by bytes (fabric traffic "
                         "0.15 KB per ray, VALU 57 % busy at 71 % lane use: profiles/r02b_pmc_ao_config5_sq_tcc.txt)"}
+    # the same scene with the traversal tree built on the device (lh_build.hip; what lsh_hip does from 1 M triangles on): commit
+    # time, frame time on that tree, and the image -- which must not change by a bit
+    devb = None
+    if world == 1 and commit_host_s is not None:
+        acc_d = la.HipAccel(acc_device)
+        for k in range(int(g["ngeoms"])):
+            P_, I_ = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess); acc_d.add_mesh(P_, I_); del P_, I_
+        t0 = time.perf_counter(); info_d = acc_d.commit(on_device=True); commit_dev_s = time.perf_counter() - t0
+        acc_d.wait_exact()
+        render.render_ao_frame(acc_d, cam, 1, nsamples, tile=tile); torch.cuda.synchronize(dev)
+        t0 = time.perf_counter(); img_d, st_d = render.render_ao_frame(acc_d, cam, 1, nsamples, tile=tile); torch.cuda.synchronize(dev)
+        devb = {"host_commit_s": round(commit_host_s, 3), "device_commit_s": round(commit_dev_s, 3), "device_tree_s": round(info_d["build_seconds"], 3),
+                "frame_ms_on_device_tree": round((time.perf_counter() - t0) * 1e3, 3),
+                "image_bit_equal": bool(torch.equal(img_d, img)) and dict(st_d) == stats[0]}
+        ok = ok and devb["image_bit_equal"]
+        acc_d.close(); del img_d
     rdev = dev if (world == 1 or torch.distributed.get_backend() == "nccl") else torch.device("cpu")
     rays = torch.tensor([st["primary_rays"] + st["ao_rays"]], dtype=torch.float64, device=rdev)
     tmax = torch.tensor([min(times)], dtype=torch.float64, device=rdev)
@@ -531,7 +547,7 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
             "ref_tree_build_s": round(info["ref_build_seconds"], 3),
             "rays_per_frame": int(rays.item()), "frame_ms": round(tmax.item() * 1e3, 3),
             "value": round(rays.item() / tmax.item() / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
-            "image_mean": float(img.mean().item()), "roofline": roof,
+            "image_mean": float(img.mean().item()), "roofline": roof, "device_build": devb,
             "validation": {"frames_repeat": bool(okt.item() > 0.5), "retiled_frame_bit_equal": bool(ok) if world == 1 else None,
                            "primary_hits": int(stats[0]["primary_hits"]) if world == 1 else None, "ok": bool(okt.item() > 0.5)}}
 
