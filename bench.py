@@ -219,7 +219,7 @@ def main():
     cnt_out, cnt = acc.intersect_device(d_org[:ns], d_dir[:ns], mode=mode, variant=args.variant, counters=True)
     n_nodes = cnt["nodes"] / ns; n_tris = cnt["tris"] / ns
     b_out = B_OUT if mode == la.MODE_CLOSEST else 4
-    node_fmt = {"f32": "f32", "q16": "q16"}.get(os.environ.get("LH_NODE_FORMAT", ""), "q16x4")
+    node_fmt = "f32" if args.variant == 0 else "q16x4"
     b_ray = B_IN + b_out + B_NODE[node_fmt] * n_nodes + B_TRI * n_tris
 
     # ---- timed region -------------------------------------------------------------
@@ -299,8 +299,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "residency": "hot set %.0f MB (4-wide nodes + tri32) < 256 MiB Infinity Cache: served by L2 + MALL, "
                                       "NOT an HBM measurement; see roofline_hbm" % hot_mb,
-                         "kernel": ("k_trace2<closest, ray arrays> (+ k_resolve2, k_ref_retrace2 inside the timed launch)" if args.variant == 6 and node_fmt == "q16x4"
-                                    else "k_trace_persist_lane<walk=spec,%s nodes>" % node_fmt if args.variant in (-1, 4) else "k_trace_v%d" % args.variant),
+                         "kernel": "k_trace_persist_lane<walk=spec,%s nodes>" % node_fmt if args.variant in (-1, 4) else "k_trace_direct<%s nodes>" % node_fmt,
                          "node_bytes": B_NODE[node_fmt], "launches_per_step": launches_per_step,
                          "kernel_ms": round(kernel_ms, 3), "bytes_per_ray": round(b_ray, 1),
                          "nodes_per_ray": round(n_nodes, 3), "tris_per_ray": round(n_tris, 3)},
@@ -340,7 +339,7 @@ def validate_dump(torch, la, args, mode, outs_of, cb, cnt_out, ns, gathered, wor
     if mode == la.MODE_CLOSEST:
         same = all(torch.equal(a[:k], b[:k]) for a, b in zip(o, cnt_out))
         v["timed_equals_counted_launch"] = bool(same); v["ok"] &= bool(same)
-        canonical = (args.tris == 1_000_000 and abs(args.half_extent - 0.005) < 1e-12 and args.variant in (-1, 4, 6))
+        canonical = (args.tris == 1_000_000 and abs(args.half_extent - 0.005) < 1e-12 and args.variant in (-1, 4))
         for nn, (hits, sumt) in SOUP1M_CHECK.items():
             if canonical and m >= nn:
                 hit = o[0][:nn] != -1

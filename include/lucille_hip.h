@@ -28,7 +28,7 @@ extern "C" {
 #define LH_MODE_ANY     1            /* boolean occlusion: the value calculate_occlusion
                                         actually consumes (ambientocclusion.c:123-129) */
 
-/* kernel variants; LH_VARIANT_DEFAULT picks the tuned one */
+/* kernel variants: LH_VARIANT_DEFAULT picks the tuned walk (= 4); 0 is the textbook walk kept as in-process reference */
 #define LH_VARIANT_DEFAULT (-1)
 
 typedef struct lh_accel lh_accel_t;  /* opaque: host BVH + device SoA copies  */
@@ -76,8 +76,9 @@ int  lh_accel_commit(lh_accel_t *accel, int build_threads);
 /* build_threads == LH_BUILD_ON_DEVICE (or LH_BUILD=device in the environment): the traversal tree is built on the GPU
  * (LBVH -> the same 4-wide nodes; milliseconds instead of seconds: lucille re-builds its accelerator in every
  * ri_scene_setup, scene.c:84-98) and lucille's own tree -- needed only for exact-t tie winners, fragile hits and beams --
- * by a background host thread; queries issued before it is attached resolve exact-t ties by "larger primitive id wins".
- * lh_accel_wait_exact blocks until it is attached.  Hit records are otherwise independent of the tree. */
+ * by a background host thread.  Queries are exact by default: the first one waits for that tree (lh_accel_wait_exact does
+ * so explicitly).  lh_accel_set_param(accel, "fast_start", 1) (or LH_FAST_START=1) lets queries run before it is
+ * attached; until then exact-t ties resolve to the larger primitive id.  Hit records are otherwise independent of the tree. */
 #define LH_BUILD_ON_DEVICE (-2)
 int  lh_accel_wait_exact(lh_accel_t *accel);
 void lh_accel_destroy(lh_accel_t *accel);
@@ -140,7 +141,8 @@ int  lh_accel_statistics(lh_accel_t *accel, uint64_t counters[5], int clear);
 
 /* number of persistent workgroups the persistent variants launch */
 int  lh_accel_set_grid(lh_accel_t *accel, int blocks);
-/* tuning knobs by name (sweeps): "grid", "t2_grid", "min_active", "tri_batch", "ray_chunk", "variant" */
+/* knobs by name: "grid", "min_active", "tri_batch", "ray_chunk" (sweeps), "variant" (0: the textbook reference walk, 4: the
+ * default), "ao_fused", "wide8" (-1 auto / 0 / 1), "fast_start", "stack_cap" (tests of the overflow path) */
 int  lh_accel_set_param(lh_accel_t *accel, const char *name, int value);
 
 /* ---- tile rendering: the callers on either side of the query, on the device ----

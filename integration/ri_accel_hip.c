@@ -66,8 +66,11 @@ void *ri_hipbvh_build(const void *data)
         /* positions are ri_vector_t = double[4]: stride 32 bytes */
         if (lh_accel_add_mesh(h->lh, geom->npositions, (const double *)geom->positions,
                               sizeof(ri_vector_t), geom->nindices, geom->indices) != 0) {
+            /* a geom the accelerator refuses (an out-of-range index): no accelerator at all, as lh_host.c does -- skipping it
+             * would let every later geom's ordinal run ahead of the mesh ordinal the hit records carry */
             ri_log(LOG_ERROR, "(HIPBVH) %s", lh_last_error());
-            continue;
+            lh_accel_destroy(h->lh); free(h->geoms); free(h);
+            return NULL;
         }
         /* what ri_intersection_state_build reads besides positions (geom.h:29-65): used by the device-side
          * epilogue of the batched frame loop (integration/ri_render_hip.c); the one-ray path below keeps calling
@@ -78,13 +81,19 @@ void *ri_hipbvh_build(const void *data)
                 fprintf(stderr, "(HIPBVH) geom %u: %u positions, %u indices, normals %p (%u), two_side %d, colors %p, tangents %p, texcoords %p / %p\n", m,
                         geom->npositions, geom->nindices, (void *)geom->normals, geom->nnormals, geom->two_side, (void *)geom->colors,
                         (void *)geom->tangents, (void *)geom->texcoords, (void *)geom->texcoords_unshared);
+            int bad = 0;
             if (geom->normals || geom->two_side)
-                lh_accel_set_normals(h->lh, m, (const double *)geom->normals, sizeof(ri_vector_t), geom->two_side);
-            if (geom->colors) lh_accel_set_attribute(h->lh, m, LH_ATTR_COLOR, (const double *)geom->colors, sizeof(ri_vector_t), geom->ncolors);
-            if (geom->tangents) lh_accel_set_attribute(h->lh, m, LH_ATTR_TANGENT, (const double *)geom->tangents, sizeof(ri_vector_t), geom->ntangents);
-            if (geom->binormals) lh_accel_set_attribute(h->lh, m, LH_ATTR_BINORMAL, (const double *)geom->binormals, sizeof(ri_vector_t), geom->nbinormals);
-            if (geom->texcoords) lh_accel_set_attribute(h->lh, m, LH_ATTR_TEXCOORD, geom->texcoords, 2 * sizeof(ri_float_t), geom->npositions);
-            else if (geom->texcoords_unshared) lh_accel_set_attribute(h->lh, m, LH_ATTR_TEXCOORD_UNSHARED, geom->texcoords_unshared, 2 * sizeof(ri_float_t), geom->nindices);
+                bad |= lh_accel_set_normals(h->lh, m, (const double *)geom->normals, sizeof(ri_vector_t), geom->two_side);
+            if (geom->colors) bad |= lh_accel_set_attribute(h->lh, m, LH_ATTR_COLOR, (const double *)geom->colors, sizeof(ri_vector_t), geom->ncolors);
+            if (geom->tangents) bad |= lh_accel_set_attribute(h->lh, m, LH_ATTR_TANGENT, (const double *)geom->tangents, sizeof(ri_vector_t), geom->ntangents);
+            if (geom->binormals) bad |= lh_accel_set_attribute(h->lh, m, LH_ATTR_BINORMAL, (const double *)geom->binormals, sizeof(ri_vector_t), geom->nbinormals);
+            if (geom->texcoords) bad |= lh_accel_set_attribute(h->lh, m, LH_ATTR_TEXCOORD, geom->texcoords, 2 * sizeof(ri_float_t), geom->npositions);
+            else if (geom->texcoords_unshared) bad |= lh_accel_set_attribute(h->lh, m, LH_ATTR_TEXCOORD_UNSHARED, geom->texcoords_unshared, 2 * sizeof(ri_float_t), geom->nindices);
+            if (bad) {
+                ri_log(LOG_ERROR, "(HIPBVH) geom %u: %s", m, lh_last_error());
+                lh_accel_destroy(h->lh); free(h->geoms); free(h);
+                return NULL;
+            }
         }
     }
     if (lh_accel_commit(h->lh, 0) != 0) {

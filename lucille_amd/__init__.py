@@ -17,7 +17,7 @@ There is no CPU fallback: loading fails loudly when the library is missing and
 every query fails loudly when no HIP device is visible.
 """
 from .binding import (Camera, HipAccel, LucilleHipError, MISS, MODE_ANY, MODE_CLOSEST,  # noqa: F401
-                      VARIANT_DEFAULT, VARIANT_DIRECT, VARIANT_PERSIST_LANE,
-                      VARIANT_PERSIST_WAVE, VARIANT_SPEC, VARIANT_UNIFIED, VARIANT_UNIFIED4, VARIANT_LEAN, VARIANT_QUAD, build_library, device_count, library_path,
+                      VARIANT_DEFAULT, VARIANT_DIRECT,
+                      VARIANT_SPEC, build_library, device_count, library_path,
                       HipMulti, Material, Environment, ALL_MESHES, PT_REFERENCE_WEIGHTS, ATTR_COLOR, ATTR_TANGENT, ATTR_BINORMAL,
                       ATTR_TEXCOORD, ATTR_TEXCOORD_UNSHARED, STATE_DOUBLES)

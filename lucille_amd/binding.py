@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 MISS = 0xFFFFFFFF
 T_INF = 1.0e38
 MODE_CLOSEST, MODE_ANY = 0, 1
-VARIANT_DEFAULT, VARIANT_DIRECT, VARIANT_PERSIST_WAVE, VARIANT_PERSIST_LANE, VARIANT_UNIFIED, VARIANT_SPEC, VARIANT_UNIFIED4, VARIANT_LEAN, VARIANT_QUAD = -1, 0, 1, 2, 3, 4, 5, 6, 7
+VARIANT_DEFAULT, VARIANT_DIRECT, VARIANT_SPEC = -1, 0, 4      # the tuned walk (= SPEC), the textbook reference walk
 
 
 class LucilleHipError(RuntimeError):

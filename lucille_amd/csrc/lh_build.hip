@@ -265,7 +265,7 @@ __global__ void k_tri32(uint32_t n, const uint32_t *__restrict__ sorted, const d
     out[i] = o;
 }
 
-static inline void dfree(void *p) { if (p) (void)dfree(p); }
+static inline void dfree(void *p) { if (p) (void)hipFree(p); }
 
 #define BCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(err, errlen, "%s failed: %s", #x, hipGetErrorString(e_)); goto fail; } } while (0)
 

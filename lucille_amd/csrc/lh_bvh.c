@@ -465,7 +465,7 @@ static void *flatten_worker(void *arg)
     return NULL;
 }
 
-/* the scene's 16-bit grid: every quantised node format (2-, 4-, 8-wide) lives on it */
+/* the scene's 16-bit grid: the 4-wide and 8-wide node formats live on it */
 static void setup_grid(lh_bvh_t *o)
 {
     int k;
@@ -474,40 +474,6 @@ static void setup_grid(lh_bvh_t *o)
         o->grid_lo[k] = o->bmin[k];
         o->grid_step[k] = up32(ext > 0.0 ? ext / 65535.0 * (1.0 + 1e-6) : 1e-30);
     }
-}
-
-/* the 2-wide 16-bit grid nodes (lh_qnode_t), derived from the fp32 nodes the first time something asks for them (the A/B
- * walks, the deep-tree fallback, the host model): not thread-safe, callers lock */
-int lh_bvh_ensure_qnodes(lh_bvh_t *o)
-{
-    uint32_t i; int k, c;
-    if (o->qnodes || o->ntris == 0) return 0;
-    if (!o->nodes) return -1;
-    o->qnodes = (lh_qnode_t *)malloc(sizeof(lh_qnode_t) * (size_t)(o->nnodes ? o->nnodes : 1));
-    if (!o->qnodes) return -1;
-    for (i = 0; i < o->nnodes; i++) {
-        const lh_node_t *n = &o->nodes[i]; lh_qnode_t *q = &o->qnodes[i];
-        const float *lo[2] = { n->lo0, n->lo1 }, *hi[2] = { n->hi0, n->hi1 };
-        int32_t ref[2] = { n->ref0, n->ref1 };
-        if (ref[1] == LH_REF_EMPTY) {       /* single-leaf scene: no empty boxes on a grid -> visit the leaf twice */
-            ref[1] = ref[0]; lo[1] = lo[0]; hi[1] = hi[0];
-        }
-        for (c = 0; c < 2; c++)
-            for (k = 0; k < 3; k++) {
-                const double g = o->grid_lo[k], st = o->grid_step[k];
-                double ql = floor(((double)lo[c][k] - g) / st), qh = ceil(((double)hi[c][k] - g) / st);
-                if (ql < 0.0) ql = 0.0;
-                if (ql > 65535.0) ql = 65535.0;
-                if (qh < 0.0) qh = 0.0;
-                if (qh > 65535.0) qh = 65535.0;
-                while (ql > 0.0 && g + ql * st > (double)lo[c][k]) ql -= 1.0;
-                while (qh < 65535.0 && g + qh * st < (double)hi[c][k]) qh += 1.0;
-                if (g + ql * st > (double)lo[c][k] || g + qh * st < (double)hi[c][k]) { free(o->qnodes); o->qnodes = NULL; return -1; }   /* grid does not cover: bug */
-                q->q[6 * c + k] = (uint16_t)ql; q->q[6 * c + 3 + k] = (uint16_t)qh;
-            }
-        q->ref0 = ref[0]; q->ref1 = ref[1];
-    }
-    return 0;
 }
 
 /* ---- 4-wide collapse of the flat binary tree (see lh_q4node_t) ------------------------- */
@@ -726,117 +692,6 @@ int lh_bvh_ensure_q8(lh_bvh_t *o)
     return 0;
 }
 
-/* ---- 8-wide compressed collapse (see lh_c8node_t) -------------------------------------------- */
-typedef struct { const float *lo, *hi; int32_t ref; } child8_t;
-
-/* slots a child takes: a leaf is one slot */
-static void build8(lh_bvh_t *o, uint32_t i2, uint32_t k8, uint32_t depth, uint32_t *next_node, uint32_t *next_tri)
-{
-    child8_t ch[8]; int n = 2, c, k, s; uint32_t kid[8]; int slot_of[8], used[8];
-    const lh_node_t *nd = &o->nodes[i2];
-    float nlo[3], nhi[3]; double cen[3];
-    lh_c8node_t *q = &o->c8nodes[k8];
-    ch[0].lo = nd->lo0; ch[0].hi = nd->hi0; ch[0].ref = nd->ref0;
-    ch[1].lo = nd->lo1; ch[1].hi = nd->hi1; ch[1].ref = nd->ref1;
-    if (ch[1].ref == LH_REF_EMPTY) n = 1;
-    while (n < 8) {                                   /* open the inner child with the largest area */
-        int best = -1; float ba = -1.0f;
-        for (c = 0; c < n; c++)
-            if (ch[c].ref >= 0) { float a = area3(ch[c].lo, ch[c].hi); if (a > ba) { ba = a; best = c; } }
-        if (best < 0) break;
-        {
-            const lh_node_t *g = &o->nodes[ch[best].ref];
-            ch[best].lo = g->lo0; ch[best].hi = g->hi0; ch[best].ref = g->ref0;
-            ch[n].lo = g->lo1; ch[n].hi = g->hi1; ch[n].ref = g->ref1;
-            n++;
-        }
-    }
-    if (depth + 1 > o->c8_depth) o->c8_depth = depth + 1;
-    for (k = 0; k < 3; k++) {
-        nlo[k] = ch[0].lo[k]; nhi[k] = ch[0].hi[k];
-        for (c = 1; c < n; c++) { if (ch[c].lo[k] < nlo[k]) nlo[k] = ch[c].lo[k]; if (ch[c].hi[k] > nhi[k]) nhi[k] = ch[c].hi[k]; }
-        cen[k] = 0.5 * ((double)nlo[k] + (double)nhi[k]);
-    }
-    /* octant slots: repeatedly take the (child, free slot) pair whose centroid offset points most
-     * along the slot's diagonal */
-    for (s = 0; s < 8; s++) used[s] = 0;
-    for (c = 0; c < n; c++) slot_of[c] = -1;
-    for (k = 0; k < n; k++) {
-        int bc = -1, bs = -1; double bv = -1.0e300;
-        for (c = 0; c < n; c++) {
-            double d[3]; int a;
-            if (slot_of[c] >= 0) continue;
-            for (a = 0; a < 3; a++) d[a] = 0.5 * ((double)ch[c].lo[a] + (double)ch[c].hi[a]) - cen[a];
-            for (s = 0; s < 8; s++) {
-                double v;
-                if (used[s]) continue;
-                v = ((s & 1) ? d[0] : -d[0]) + ((s & 2) ? d[1] : -d[1]) + ((s & 4) ? d[2] : -d[2]);
-                if (v > bv) { bv = v; bc = c; bs = s; }
-            }
-        }
-        slot_of[bc] = bs; used[bs] = 1;
-    }
-    /* node frame: origin = node lo, per-axis power-of-two cell so that 255 cells cover the extent */
-    for (k = 0; k < 3; k++) {
-        const double ext = (double)nhi[k] - (double)nlo[k];
-        int e = -126;
-        if (ext > 0.0) { int ex; (void)frexp(ext / 255.0, &ex); e = ex; }      /* 2^e >= ext/255 */
-        if (e < -126) e = -126;
-        if (e > 127) e = 127;
-        while (e < 127 && ldexp(255.0, e) < ext) e++;
-        q->p[k] = nlo[k];
-        q->e[k] = (uint8_t)(e + 127);
-    }
-    q->imask = 0; q->child_base = 0; q->tri_base = *next_tri;
-    for (s = 0; s < 8; s++) { q->meta[s] = 0; for (k = 0; k < 3; k++) { q->qlo[k][s] = 255; q->qhi[k][s] = 0; } }
-    /* inner children adjacent in slot order; leaves' triangles contiguous in slot order */
-    {
-        uint32_t off = 0, nin = 0, first_kid;
-        for (s = 0; s < 8; s++)
-            for (c = 0; c < n; c++)
-                if (slot_of[c] == s && ch[c].ref >= 0) nin++;
-        first_kid = *next_node; *next_node += nin; q->child_base = first_kid;
-        nin = 0;
-        for (s = 0; s < 8; s++)
-            for (c = 0; c < n; c++) {
-                if (slot_of[c] != s) continue;
-                for (k = 0; k < 3; k++) {
-                    const double st = ldexp(1.0, (int)q->e[k] - 127), p = (double)q->p[k];
-                    double ql = floor(((double)ch[c].lo[k] - p) / st), qh = ceil(((double)ch[c].hi[k] - p) / st);
-                    if (ql < 0.0) ql = 0.0;
-                    if (ql > 255.0) ql = 255.0;
-                    if (qh < 0.0) qh = 0.0;
-                    if (qh > 255.0) qh = 255.0;
-                    while (ql > 0.0 && p + ql * st > (double)ch[c].lo[k]) ql -= 1.0;
-                    while (qh < 255.0 && p + qh * st < (double)ch[c].hi[k]) qh += 1.0;
-                    q->qlo[k][s] = (uint8_t)ql; q->qhi[k][s] = (uint8_t)qh;
-                }
-                if (ch[c].ref >= 0) { q->imask |= (uint8_t)(1u << s); kid[c] = first_kid + nin; nin++; }
-                else {
-                    const uint32_t x = ~(uint32_t)ch[c].ref, first = x >> 2, cnt = (x & 3u) + 1u; uint32_t j;
-                    q->meta[s] = (uint8_t)(0x80u | ((cnt - 1u) << 5) | off);
-                    for (j = 0; j < cnt; j++) o->tri32_c8[*next_tri + off + j] = o->tri32[first + j];
-                    off += cnt;
-                }
-            }
-        *next_tri += off;
-    }
-    for (c = 0; c < n; c++) if (ch[c].ref >= 0) build8(o, (uint32_t)ch[c].ref, kid[c], depth + 1, next_node, next_tri);
-}
-
-static int collapse8(lh_bvh_t *o)
-{
-    uint32_t next_node = 1, next_tri = 0;
-    o->c8nodes = (lh_c8node_t *)calloc(o->nnodes ? o->nnodes : 1, sizeof(lh_c8node_t));
-    o->tri32_c8 = (lh_tri32_t *)malloc(sizeof(lh_tri32_t) * (o->ntris ? o->ntris : 1));
-    if (!o->c8nodes || !o->tri32_c8) return -1;
-    o->c8_depth = 0;
-    build8(o, 0, 0, 0, &next_node, &next_tri);
-    o->nc8nodes = next_node;
-    return next_tri == o->ntris ? 0 : -1;
-}
-
-
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 typedef struct { const lh_mesh_view_t *m; uint32_t g, p0; lh_bvh_t *out; build_ctx_t *b; volatile int err; } prep_job_t;
@@ -1013,7 +868,6 @@ int lh_bvh_build_hook(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmes
         t2 = now_s();
         if (collapse4(out) != 0) { lh_bvh_release(out); return -1; }
         t3 = now_s();
-        /* the 8-wide compressed tree is an opt-in experiment (slower: profiles/README.md r01d): lh_bvh_ensure_c8 */
         if (getenv("LH_BUILD_TIMING")) fprintf(stderr, "[lh_bvh] flatten+free ..%.3f quantize %.3f collapse4 %.3f \n", t1 - t0, t2 - t1, t3 - t2);
     }
     out->build_seconds = now_s() - t0;
@@ -1057,16 +911,8 @@ int lh_bvh_flatten(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes
     return 0;
 }
 
-/* the 8-wide compressed collapse, built the first time something asks for it (not thread-safe: callers lock) */
-int lh_bvh_ensure_c8(lh_bvh_t *bvh)
-{
-    if (bvh->c8nodes || bvh->ntris == 0) return 0;
-    if (collapse8(bvh) != 0) { free(bvh->c8nodes); free(bvh->tri32_c8); bvh->c8nodes = NULL; bvh->tri32_c8 = NULL; return -1; }
-    return 0;
-}
-
 void lh_bvh_release(lh_bvh_t *bvh)
 {
-    free(bvh->nodes); free(bvh->qnodes); free(bvh->q4nodes); free(bvh->q8nodes); free(bvh->c8nodes); free(bvh->tri32_c8); free(bvh->tri32); free(bvh->tri64); free(bvh->prim_geom); free(bvh->prim_index);
+    free(bvh->nodes); free(bvh->q4nodes); free(bvh->q8nodes); free(bvh->tri32); free(bvh->tri64); free(bvh->prim_geom); free(bvh->prim_index);
     memset(bvh, 0, sizeof(*bvh));
 }

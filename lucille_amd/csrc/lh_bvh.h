@@ -37,17 +37,6 @@ typedef struct lh_node {
 
 #define LH_REF_EMPTY ((int32_t)0x80000000)
 
-/* 32-byte quantised inner node: the same two child boxes on a 16-bit grid spanning the
- * scene box (x = grid_lo + q * grid_step, lo rounded down / hi rounded up, so the decoded
- * box CONTAINS the fp32 box).  Halves the 16-byte lane-loads per visit (2 instead of 4)
- * -- the traversal kernel is bound by the texture-addresser's per-lane request rate, not
- * by bytes (profiles/r01_pmc_diag.md) -- and doubles the nodes an L2 holds.
- *   q[0..2] lo0 xyz, q[3..5] hi0 xyz, q[6..8] lo1 xyz, q[9..11] hi1 xyz               */
-typedef struct lh_qnode {
-    uint16_t q[12];
-    int32_t  ref0, ref1;
-} lh_qnode_t;
-
 /* 48-byte leaf triangle record (fp32 filter form): v0, e1=v1-v0, e2=v2-v0
  * rounded from the fp64 differences, the primitive id and two precomputed
  * norms used by the conservative-filter tolerances.                        */
@@ -74,25 +63,6 @@ typedef struct lh_q4node {
     int32_t  ref[4];
 } lh_q4node_t;
 
-/* 80-byte 8-wide node, boxes on an 8-bit grid LOCAL to the node (Ylitie, Karras, Laine: "Efficient
- * Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", HPG 2017 -- the layout, not their
- * code): child s has box [p + qlo[k][s] * 2^(e[k]-127) , p + qhi[k][s] * 2^(e[k]-127)] per axis k
- * (lo rounded down, hi rounded up: the decoded box contains the fp32 box).  Inner children are
- * adjacent: index = child_base + popcount(imask & ((1 << s) - 1)).  Leaf children index a triangle
- * array kept in THIS tree's order (tri32_c8): meta = 0x80 | (count-1) << 5 | offset, triangles
- * [tri_base + offset, + count).  Children sit in octant order: slot s = (x high) | (y high) << 1 |
- * (z high) << 2 relative to the node centre (greedy assignment), so visiting slots in order of
- * s ^ (ray octant) is front to back without sorting distances.  Empty slot: meta 0, imask bit 0. */
-typedef struct lh_c8node {
-    float    p[3];
-    uint8_t  e[3];
-    uint8_t  imask;
-    uint32_t child_base, tri_base;
-    uint8_t  meta[8];
-    uint8_t  qlo[3][8];
-    uint8_t  qhi[3][8];
-} lh_c8node_t;
-
 /* 8-wide node on the scene's 16-bit grid: 128 bytes = one cache line decides eight children.  Slot s holds the child the
  * walk visits with priority s ^ (ray octant); w[s][axis] = lo | hi << 16 as in lh_q4node_t; ref as in lh_q4node_t (the
  * same leaves, the same tri32 order).  Empty slots: inverted box, LH_REF_EMPTY.  Used for ray dumps over scenes that do
@@ -110,15 +80,11 @@ typedef struct lh_bvh {
     uint32_t   *prim_geom; /* ntris: mesh ordinal of primitive              */
     uint32_t   *prim_index;/* ntris: 3*i offset into that mesh's indices    */
     float       bmin[3], bmax[3];  /* scene box, fp32 outward               */
-    lh_qnode_t *qnodes;            /* nnodes, same indexing as nodes         */
     lh_q4node_t *q4nodes;          /* nq4nodes: 4-wide collapse of the same tree */
     uint32_t    nq4nodes, q4_depth;
-    lh_c8node_t *c8nodes;          /* nc8nodes: 8-wide collapse of the same tree (lh_c8node_t) */
-    lh_tri32_t  *tri32_c8;         /* ntris, in the 8-wide tree's leaf order */
-    uint32_t    nc8nodes, c8_depth;
     lh_q8node_t *q8nodes;          /* nq8nodes: 8-wide collapse on the 16-bit grid, or NULL (lh_bvh_ensure_q8) */
     uint32_t    nq8nodes, q8_depth;
-    float       grid_lo[3], grid_step[3];   /* quantisation grid of qnodes   */
+    float       grid_lo[3], grid_step[3];   /* the 16-bit grid of q4nodes / q8nodes */
     double      build_seconds;
 } lh_bvh_t;
 
@@ -136,9 +102,7 @@ int  lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes,
 int  lh_bvh_build_hook(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, int nthreads,
                        void (*after_flatten)(void *), void *hook_arg);
 int  lh_bvh_flatten(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes);   /* primitives only, no tree */
-int  lh_bvh_ensure_qnodes(lh_bvh_t *bvh);  /* builds the 2-wide 16-bit grid nodes on first use; 0 / -1 */
 int  lh_bvh_ensure_q8(lh_bvh_t *bvh);      /* builds q8nodes on first use; 0 / -1 */
-int  lh_bvh_ensure_c8(lh_bvh_t *bvh);      /* builds c8nodes / tri32_c8 on first use; 0 / -1 */
 void lh_bvh_release(lh_bvh_t *bvh);
 
 #ifdef __cplusplus

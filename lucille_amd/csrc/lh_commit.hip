@@ -1,0 +1,692 @@
+/*
+ * lh_commit.hip -- lifetime of an accelerator behind the C ABI (include/lucille_hip.h): staging of the meshes, the host or
+ * device build, the device replica of the scene, parameters.  Reference: accel_build_func / accel_free_func
+ * (src/render/accel.h:24-28), ri_bvh_build (src/render/bvh.c:276-379), ri_bvh_free (bvh.c:381-387).
+ */
+#include <thread>
+#include <vector>
+
+#include "lh_internal.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" void lh_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }
+
+int lh_fail(const char *fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    return -1;
+}
+
+pthread_mutex_t g_scene_mu = PTHREAD_MUTEX_INITIALIZER;
+
+extern "C" const char *lh_last_error(void) { return g_err; }
+
+extern "C" int lh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int lh_accel_create(lh_accel_t **out, int device)
+{
+    if (!out) return fail("lh_accel_create: out is NULL");
+    int n = lh_device_count();
+    if (n <= 0) return fail("lh_accel_create: no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail("lh_accel_create: device %d out of range [0,%d)", device, n);
+    lh_accel_t *a = (lh_accel_t *)calloc(1, sizeof(*a));
+    if (!a) return fail("out of memory");
+    a->hs = (lh_host_scene *)calloc(1, sizeof(lh_host_scene));
+    if (!a->hs) { free(a); return fail("out of memory"); }
+    a->hs->refs = 1;
+    a->device = device;
+    {
+        pthread_mutexattr_t at; pthread_mutexattr_init(&at); pthread_mutexattr_settype(&at, PTHREAD_MUTEX_RECURSIVE);
+        pthread_mutex_init(&a->mu, &at); pthread_mutexattr_destroy(&at);
+    }
+    a->default_variant = LH_VARIANT_SPEC;
+    a->ao_fused = 1;
+    a->wide8 = -1;
+    { const char *e = getenv("LH_WIDE8"); if (e) a->wide8 = atoi(e); }
+    { const char *e = getenv("LH_AO_FUSED"); if (e) a->ao_fused = atoi(e) != 0; }
+    { const char *e = getenv("LH_FAST_START"); if (e) a->fast_start = atoi(e) != 0; }
+    const char *env;
+    a->min_active = 32;
+    a->tri_batch = 8;
+    env = getenv("LH_TRI_BATCH");
+    if (env && atoi(env) > 0 && atoi(env) <= 64) a->tri_batch = atoi(env);
+    env = getenv("LH_MIN_ACTIVE");
+    if (env && atoi(env) > 0 && atoi(env) <= 64) a->min_active = atoi(env);
+    a->ray_chunk = 256;
+    env = getenv("LH_RAY_CHUNK");
+    if (env && atoi(env) > 0 && atoi(env) <= (1 << 20)) a->ray_chunk = (uint32_t)atoi(env);
+    a->dev.ray_chunk = a->ray_chunk;
+    *out = a;
+    return 0;
+}
+
+extern "C" int lh_accel_add_mesh(lh_accel_t *a, uint32_t npos, const double *pos, size_t stride,
+                                 uint32_t nidx, const uint32_t *idx)
+{
+    lh_guard guard(a);
+    if (!a) return fail("lh_accel_add_mesh: accel is NULL");
+    if (a->committed) return fail("lh_accel_add_mesh: accel already committed");
+    if ((npos && !pos) || (nidx && !idx)) return fail("lh_accel_add_mesh: NULL array");
+    if (stride < 3 * sizeof(double) || (stride % sizeof(double)) != 0) return fail("lh_accel_add_mesh: bad stride %zu", stride);
+    for (uint32_t i = 0; i < nidx - (nidx % 3); i++)
+        if (idx[i] >= npos) return fail("lh_accel_add_mesh: index %u out of range (npositions %u)", idx[i], npos);
+    lh_mesh_copy *nm = (lh_mesh_copy *)realloc(a->meshes, sizeof(lh_mesh_copy) * (a->nmeshes + 1));
+    if (!nm) return fail("out of memory");
+    a->meshes = nm;
+    lh_mesh_copy *m = &a->meshes[a->nmeshes];
+    m->npos = npos; m->nidx = nidx; m->nrm = NULL; m->two_side = 0;
+    for (int k = 0; k < 5; k++) m->attr[k] = NULL;
+    m->pos = (double *)malloc(sizeof(double) * 3 * (size_t)(npos ? npos : 1));
+    m->idx = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(nidx ? nidx : 1));
+    if (!m->pos || !m->idx) return fail("out of memory");
+    for (uint32_t i = 0; i < npos; i++) {
+        const double *p = (const double *)((const char *)pos + (size_t)i * stride);
+        m->pos[3 * (size_t)i] = p[0]; m->pos[3 * (size_t)i + 1] = p[1]; m->pos[3 * (size_t)i + 2] = p[2];
+    }
+    memcpy(m->idx, idx, sizeof(uint32_t) * nidx);
+    a->nmeshes++;
+    return 0;
+}
+
+extern "C" int lh_accel_set_normals(lh_accel_t *a, uint32_t mesh, const double *nrm, size_t stride, int two_side)
+{
+    lh_guard guard(a);
+    if (!a) return fail("lh_accel_set_normals: accel is NULL");
+    if (a->committed) return fail("lh_accel_set_normals: accel already committed");
+    if (mesh >= a->nmeshes) return fail("lh_accel_set_normals: mesh %u out of range", mesh);
+    if (nrm && (stride < 3 * sizeof(double) || (stride % sizeof(double)) != 0)) return fail("lh_accel_set_normals: bad stride");
+    lh_mesh_copy *m = &a->meshes[mesh];
+    free(m->nrm); m->nrm = NULL; m->two_side = two_side;
+    if (nrm) {
+        m->nrm = (double *)malloc(sizeof(double) * 3 * (size_t)(m->npos ? m->npos : 1));
+        if (!m->nrm) return fail("out of memory");
+        for (uint32_t i = 0; i < m->npos; i++) {
+            const double *p = (const double *)((const char *)nrm + (size_t)i * stride);
+            m->nrm[3 * (size_t)i] = p[0]; m->nrm[3 * (size_t)i + 1] = p[1]; m->nrm[3 * (size_t)i + 2] = p[2];
+        }
+    }
+    return 0;
+}
+
+extern "C" int lh_accel_set_attribute(lh_accel_t *a, uint32_t mesh, int kind, const double *data, size_t stride, uint32_t count)
+{
+    lh_guard guard(a);
+    if (!a) return fail("lh_accel_set_attribute: accel is NULL");
+    if (a->committed) return fail("lh_accel_set_attribute: accel already committed");
+    if (mesh >= a->nmeshes) return fail("lh_accel_set_attribute: mesh %u out of range", mesh);
+    if (kind < LH_ATTR_COLOR || kind > LH_ATTR_TEXCOORD_UNSHARED) return fail("lh_accel_set_attribute: unknown attribute kind %d", kind);
+    lh_mesh_copy *m = &a->meshes[mesh];
+    const int ncomp = kind <= LH_ATTR_BINORMAL ? 3 : 2;
+    const uint32_t need = kind == LH_ATTR_TEXCOORD_UNSHARED ? m->nidx : m->npos;
+    free(m->attr[kind]); m->attr[kind] = NULL;
+    if (!data) return 0;
+    if (count != need) return fail("lh_accel_set_attribute: %u values given, the mesh needs %u (one per %s)", count, need,
+                                   kind == LH_ATTR_TEXCOORD_UNSHARED ? "index" : "vertex");
+    if (stride < (size_t)ncomp * sizeof(double) || (stride % sizeof(double)) != 0) return fail("lh_accel_set_attribute: bad stride %zu", stride);
+    m->attr[kind] = (double *)malloc(sizeof(double) * ncomp * (size_t)(need ? need : 1));
+    if (!m->attr[kind]) return fail("out of memory");
+    for (uint32_t i = 0; i < need; i++) {
+        const double *q = (const double *)((const char *)data + (size_t)i * stride);
+        for (int k = 0; k < ncomp; k++) m->attr[kind][(size_t)ncomp * i + k] = q[k];
+    }
+    return 0;
+}
+
+void lh_free_buf(lh_buf *b) { if (b->p) (void)hipFree(b->p); b->p = NULL; b->cap = 0; }
+#define free_buf lh_free_buf
+
+int lh_ensure_buf(lh_buf *b, size_t bytes)
+{
+    if (b->cap >= bytes && b->p) return 0;
+    if (b->p) { (void)hipFree(b->p); b->p = NULL; b->cap = 0; }
+    if (bytes == 0) bytes = 16;
+    HIPCHK(hipMalloc(&b->p, bytes));
+    b->cap = bytes;
+    return 0;
+}
+
+static void release_device(lh_accel_t *a)
+{
+    lh_buf *bufs[] = {&a->r_org, &a->r_dir, &a->r_prim, &a->r_t, &a->r_u, &a->r_v, &a->r_slot, &a->r_hitrec,
+                      &a->r_aorg, &a->r_adir, &a->r_occ, &a->r_blocks, &a->r_key, &a->r_frame, &a->r_occcount,
+                      &a->p_org2, &a->p_dir2, &a->p_path, &a->p_path2, &a->p_thr, &a->p_thr2, &a->p_rad, &a->p_alive};
+    for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) free_buf(bufs[i]);
+    if (a->d_total) (void)hipFree(a->d_total);
+    if (a->d_nrm9) (void)hipFree(a->d_nrm9);
+    for (int k = 0; k < 3; k++) { if (a->d_attr9[k]) (void)hipFree(a->d_attr9[k]); a->d_attr9[k] = NULL; }
+    if (a->d_st6) (void)hipFree(a->d_st6);
+    if (a->d_inside) (void)hipFree(a->d_inside);
+    if (a->d_prim_mesh) (void)hipFree(a->d_prim_mesh);
+    if (a->d_materials) (void)hipFree(a->d_materials);
+    if (a->d_env_map) (void)hipFree(a->d_env_map);
+    a->d_st6 = a->d_inside = a->d_prim_mesh = a->d_materials = a->d_env_map = NULL;
+    free_buf(&a->r_state); free_buf(&a->r_uni); free_buf(&a->r_bands);
+    a->d_total = NULL; a->d_nrm9 = NULL;
+    if (a->d_nodes) (void)hipFree(a->d_nodes);
+    if (a->d_tri32) (void)hipFree(a->d_tri32);
+    if (a->d_tri64) (void)hipFree(a->d_tri64);
+    if (a->d_q4nodes) (void)hipFree(a->d_q4nodes);
+    if (a->d_q8nodes) (void)hipFree(a->d_q8nodes);
+    a->d_q4nodes = a->d_q8nodes = NULL; a->dev.q4nodes = NULL; a->dev.q8nodes = NULL; a->dev.nodes = NULL;
+    if (a->d_ref_lca) (void)hipFree(a->d_ref_lca);
+    if (a->d_prim_leafpos) (void)hipFree(a->d_prim_leafpos);
+    if (a->d_ref_nodes) (void)hipFree(a->d_ref_nodes);
+    if (a->d_ref_leaf_prims) (void)hipFree(a->d_ref_leaf_prims);
+    a->d_ref_lca = a->d_prim_leafpos = a->d_ref_nodes = a->d_ref_leaf_prims = NULL;
+    if (a->d_cursor) (void)hipFree(a->d_cursor);
+    if (a->d_counters) (void)hipFree(a->d_counters);
+    for (int k = 0; k < LH_AOQ_SLOTS; k++) {
+        if (a->aoq[k].queue) (void)hipFree(a->aoq[k].queue);
+        a->aoq[k].queue = NULL; a->aoq[k].qcount = NULL; a->aoq[k].used = 0;
+    }
+    if (a->pipe.ready) {
+        for (int b = 0; b < 2; b++) {
+            (void)hipHostFree(a->pipe.h_in[b]); (void)hipHostFree(a->pipe.h_out[b]);
+            (void)hipFree(a->pipe.d_in[b]); (void)hipFree(a->pipe.d_out[b]);
+            (void)hipStreamDestroy(a->pipe.s[b]); (void)hipEventDestroy(a->pipe.done[b]);
+        }
+        a->pipe.ready = 0;
+    }
+    if (a->d_stage) (void)hipFree(a->d_stage);
+    if (a->stream) (void)hipStreamDestroy(a->stream);
+    a->d_nodes = a->d_tri32 = a->d_tri64 = NULL; a->d_cursor = a->d_counters = NULL;
+    a->d_stage = NULL; a->stage_bytes = 0; a->stream = NULL;
+}
+
+static void *ref_thread_main(void *arg)
+{
+    lh_host_scene *hs = (lh_host_scene *)arg;
+    const double t0 = now_s();
+    const int rc = lh_refbvh_build(&hs->ref, hs->bvh.tri64, hs->bvh.ntris, hs->ref_threads);
+    hs->ref_build_seconds = now_s() - t0;
+    __atomic_store_n(&hs->ref_state, rc == 0 ? 2 : -1, __ATOMIC_RELEASE);
+    return NULL;
+}
+
+/* lh_bvh_build_hook's callback on the host path: the triangles are flattened, start lucille's own tree */
+static void start_ref_thread(void *arg)
+{
+    lh_host_scene *hs = (lh_host_scene *)arg;
+    if (hs->bvh.ntris == 0) return;
+    hs->ref_state = 1;
+    if (pthread_create(&hs->ref_thread, NULL, ref_thread_main, hs) != 0) { hs->ref_state = 0; return; }
+    hs->ref_thread_live = 1;
+}
+
+/* ---- host build (once per scene) ------------------------------------------------------------ */
+static int host_build(lh_accel_t *a, int build_threads, bool on_device, bool keep_meshes)
+{
+    lh_host_scene *hs = a->hs;
+    if (build_threads <= 0) {
+        /* LH_BUILD_THREADS: how a multi-process launcher (one rank per GPU) keeps N ranks from
+         * oversubscribing the host N times over (lucille_amd/shard.py sets cores / world) */
+        const char *e = getenv("LH_BUILD_THREADS");
+        long nc = (e && atoi(e) > 0) ? atoi(e) : sysconf(_SC_NPROCESSORS_ONLN);
+        build_threads = nc > 0 ? (int)nc : 1;
+    }
+    lh_mesh_view_t *views = (lh_mesh_view_t *)calloc(a->nmeshes ? a->nmeshes : 1, sizeof(*views));
+    if (!views) return fail("out of memory");
+    for (uint32_t g = 0; g < a->nmeshes; g++) {
+        views[g].npositions = a->meshes[g].npos; views[g].positions = a->meshes[g].pos;
+        views[g].stride_bytes = 3 * sizeof(double);
+        views[g].nindices = a->meshes[g].nidx; views[g].indices = a->meshes[g].idx;
+    }
+    /* host build: lucille's own tree (needs only the flattened triangles) is built next to the traversal tree */
+    {
+        const char *e = getenv("LH_REFTREE");
+        hs->have_ref = !(e && atoi(e) == 0);
+        hs->ref_threads = build_threads;
+    }
+    int rc = on_device ? lh_bvh_flatten(&hs->bvh, views, a->nmeshes)
+                       : lh_bvh_build_hook(&hs->bvh, views, a->nmeshes, build_threads, hs->have_ref ? start_ref_thread : NULL, hs);
+    free(views);
+    if (!on_device && hs->ref_thread_live) {           /* the host path returns with both trees */
+        pthread_join(hs->ref_thread, NULL); hs->ref_thread_live = 0;
+        if (rc == 0 && hs->ref_state != 2) return fail("lh_accel_commit: reference-order tree build failed (out of memory)");
+    }
+    hs->device_built = on_device ? 1 : 0;
+    if (rc == -2) return fail("lh_accel_commit: a vertex coordinate is NaN, infinite or beyond 1e30");
+    if (rc != 0) return fail("lh_accel_commit: BVH build failed (bad input or out of memory)");
+    /* the reference-order tree: exact-t tie winners, the reference walk for fragile hits, beam
+     * visibility (LH_REFTREE=0 skips it: ties then fall back to "larger primitive id wins",
+     * fragile hits are not re-traced and beam queries are refused) */
+    {
+        const double t0 = now_s();
+        if (hs->have_ref && on_device && hs->bvh.ntris) {
+            /* not in front of the first frame: a background thread builds it, launch() attaches it when it is ready */
+            hs->ref_threads = build_threads; hs->ref_state = 1;
+            if (pthread_create(&hs->ref_thread, NULL, ref_thread_main, hs) != 0) { hs->ref_state = 0; return fail("lh_accel_commit: cannot start the reference-tree thread"); }
+            hs->ref_thread_live = 1;
+        } else if (hs->ref_state != 2) {
+            /* not started next to the tree build (an empty scene, or the thread could not be created): now */
+            if (hs->have_ref && lh_refbvh_build(&hs->ref, hs->bvh.tri64, hs->bvh.ntris, build_threads) != 0)
+                return fail("lh_accel_commit: reference-order tree build failed (out of memory)");
+            hs->ref_build_seconds = now_s() - t0;
+            hs->ref_state = hs->have_ref ? 2 : 0;
+        }
+    }
+    /* per-primitive normals in primitive-id order, if any mesh carries normals */
+    {
+        bool any = false;
+        for (uint32_t g = 0; g < a->nmeshes; g++) any = any || a->meshes[g].nrm != NULL;
+        if (any && hs->bvh.ntris) {
+            hs->nrm9 = (double *)malloc(sizeof(double) * 9 * (size_t)hs->bvh.ntris);
+            if (!hs->nrm9) return fail("out of memory");
+            for (uint32_t p = 0; p < hs->bvh.ntris; p++) {
+                const lh_mesh_copy *m = &a->meshes[hs->bvh.prim_geom[p]];
+                double *o = hs->nrm9 + 9 * (size_t)p;
+                if (!m->nrm) { for (int k = 0; k < 9; k++) o[k] = NAN; continue; }
+                for (int c = 0; c < 3; c++) {
+                    uint32_t vi = m->idx[hs->bvh.prim_index[p] + c];
+                    for (int k = 0; k < 3; k++) o[3 * c + k] = m->nrm[3 * (size_t)vi + k];
+                }
+            }
+        }
+    }
+    /* the packed mesh copies are no longer needed: the BVH holds tri64 */
+    /* the other per-vertex attributes ri_intersection_state_build reads, flattened the same way */
+    {
+        const uint32_t n = hs->bvh.ntris;
+        hs->nmeshes = a->nmeshes;
+        for (int kind = 0; kind < 3 && n; kind++) {
+            bool anyk = false;
+            for (uint32_t g = 0; g < a->nmeshes; g++) anyk = anyk || a->meshes[g].attr[kind] != NULL;
+            if (!anyk) continue;
+            hs->attr9[kind] = (double *)malloc(sizeof(double) * 9 * (size_t)n);
+            if (!hs->attr9[kind]) return fail("out of memory");
+            for (uint32_t p = 0; p < n; p++) {
+                const lh_mesh_copy *m = &a->meshes[hs->bvh.prim_geom[p]];
+                double *o = hs->attr9[kind] + 9 * (size_t)p;
+                if (!m->attr[kind]) { for (int k = 0; k < 9; k++) o[k] = NAN; continue; }
+                for (int c = 0; c < 3; c++) {
+                    const uint32_t vi = m->idx[hs->bvh.prim_index[p] + c];
+                    for (int k = 0; k < 3; k++) o[3 * c + k] = m->attr[kind][3 * (size_t)vi + k];
+                }
+            }
+        }
+        bool any_st = false, any_two = false;
+        for (uint32_t g = 0; g < a->nmeshes; g++) { any_st = any_st || a->meshes[g].attr[3] || a->meshes[g].attr[4]; any_two = any_two || a->meshes[g].two_side; }
+        if (any_st && n) {
+            hs->st6 = (double *)malloc(sizeof(double) * 6 * (size_t)n);
+            if (!hs->st6) return fail("out of memory");
+            for (uint32_t p = 0; p < n; p++) {
+                const lh_mesh_copy *m = &a->meshes[hs->bvh.prim_geom[p]];
+                double *o = hs->st6 + 6 * (size_t)p;
+                const uint32_t first = hs->bvh.prim_index[p];
+                if (m->attr[3]) {                 /* shared: geom->texcoords[2 * i_c] (intersection_state.c:210-216) */
+                    for (int c = 0; c < 3; c++) { const uint32_t vi = m->idx[first + c]; o[2 * c] = m->attr[3][2 * (size_t)vi]; o[2 * c + 1] = m->attr[3][2 * (size_t)vi + 1]; }
+                } else if (m->attr[4]) {          /* unshared: geom->texcoords_unshared[2 * (index + c)] (:218-224) */
+                    for (int c = 0; c < 3; c++) { o[2 * c] = m->attr[4][2 * (size_t)(first + c)]; o[2 * c + 1] = m->attr[4][2 * (size_t)(first + c) + 1]; }
+                } else for (int k = 0; k < 6; k++) o[k] = NAN;
+            }
+        }
+        if (any_two && n) {
+            hs->inside = (uint8_t *)calloc(n, 1);
+            if (!hs->inside) return fail("out of memory");
+            for (uint32_t p = 0; p < n; p++) {
+                const lh_mesh_copy *m = &a->meshes[hs->bvh.prim_geom[p]];
+                hs->inside[p] = (m->two_side && hs->bvh.prim_index[p] >= m->nidx / 2) ? 1 : 0;
+            }
+        }
+    }
+    if (!keep_meshes) {
+        for (uint32_t g = 0; g < a->nmeshes; g++) {
+            free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm);
+            for (int k = 0; k < 5; k++) free(a->meshes[g].attr[k]);
+        }
+        free(a->meshes); a->meshes = NULL; a->nmeshes = 0;
+    }
+    return 0;
+}
+
+extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q4nodes, uint32_t *nq4, uint32_t *q4_depth,
+                               void **d_tri32, float bmin[3], float bmax[3], float grid_lo[3], float grid_step[3],
+                               void *stream, char *err, size_t errlen);                /* lh_build.hip */
+
+int lh_ensure_formats(lh_accel_t *a, int mask)
+{
+    const lh_bvh_t *b = &a->hs->bvh;
+    if ((mask & LH_FMT_Q8) && !a->d_q8nodes && !a->hs->device_built) {
+        /* the 8-wide 16-bit-grid nodes for ray dumps over scenes larger than the Infinity Cache: built on first use */
+        pthread_mutex_lock(&g_scene_mu);
+        const int rc8 = lh_bvh_ensure_q8(&a->hs->bvh);
+        pthread_mutex_unlock(&g_scene_mu);
+        if (rc8 != 0) return fail("building the 8-wide tree failed (out of memory)");
+        const size_t q8b = sizeof(lh_q8node_t) * (size_t)b->nq8nodes;
+        HIPCHK(hipMalloc(&a->d_q8nodes, q8b));
+        HIPCHK(hipMemcpy(a->d_q8nodes, b->q8nodes, q8b, hipMemcpyHostToDevice));
+        a->dev.q8nodes = a->d_q8nodes; a->dev.nq8nodes = b->nq8nodes; a->dev.q8_depth = b->q8_depth; a->device_bytes += q8b;
+    }
+    if (a->hs->device_built) return 0;         /* the tree exists only as 4-wide nodes on the device */
+    if ((mask & LH_FMT_F32) && !a->d_nodes) {
+        const size_t nb = sizeof(lh_node_t) * (size_t)b->nnodes;
+        HIPCHK(hipMalloc(&a->d_nodes, nb));
+        HIPCHK(hipMemcpy(a->d_nodes, b->nodes, nb, hipMemcpyHostToDevice));
+        a->dev.nodes = a->d_nodes; a->device_bytes += nb;
+    }
+    if ((mask & LH_FMT_Q16X4) && !a->d_q4nodes) {
+        const size_t q4b = sizeof(lh_q4node_t) * (size_t)b->nq4nodes;
+        HIPCHK(hipMalloc(&a->d_q4nodes, q4b));
+        HIPCHK(hipMemcpy(a->d_q4nodes, b->q4nodes, q4b, hipMemcpyHostToDevice));
+        a->dev.q4nodes = a->d_q4nodes; a->device_bytes += q4b;
+    }
+    return 0;
+}
+
+/* the reference-order tree of the host scene onto this replica's device (exact-t tie winners, the reference walk for
+ * fragile hits, beams).  With a device-built traversal tree this happens when the background build has finished. */
+static int attach_ref(lh_accel_t *a)
+{
+    lh_host_scene *hs = a->hs;
+    if (a->d_ref_nodes || !hs->have_ref || hs->bvh.ntris == 0) return 0;
+    {
+        const uint32_t rn = hs->ref.nnodes;
+        int *lca = (int *)malloc(sizeof(int) * 4 * (size_t)rn);
+        uint32_t *lp = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (size_t)hs->bvh.ntris);
+        if (!lca || !lp) { free(lca); free(lp); return fail("out of memory"); }
+        for (uint32_t i = 0; i < rn; i++) {
+            lca[4 * i] = hs->ref.nodes[i].parent; lca[4 * i + 1] = hs->ref.nodes[i].depth;
+            lca[4 * i + 2] = hs->ref.nodes[i].axis; lca[4 * i + 3] = hs->ref.nodes[i].child[0];
+        }
+        for (uint32_t p = 0; p < hs->bvh.ntris; p++) { lp[2 * p] = hs->ref.prim_leaf[p]; lp[2 * p + 1] = hs->ref.prim_pos[p]; }
+        hipError_t e1 = hipMalloc(&a->d_ref_lca, sizeof(int) * 4 * (size_t)rn);
+        hipError_t e2 = hipMalloc(&a->d_prim_leafpos, sizeof(uint32_t) * 2 * (size_t)hs->bvh.ntris);
+        hipError_t e3 = hipMalloc(&a->d_ref_nodes, sizeof(lh_refnode_t) * (size_t)rn);
+        hipError_t e4 = hipMalloc(&a->d_ref_leaf_prims, sizeof(uint32_t) * (size_t)hs->bvh.ntris);
+        if (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess && e4 == hipSuccess) {
+            e1 = hipMemcpy(a->d_ref_lca, lca, sizeof(int) * 4 * (size_t)rn, hipMemcpyHostToDevice);
+            e2 = hipMemcpy(a->d_prim_leafpos, lp, sizeof(uint32_t) * 2 * (size_t)hs->bvh.ntris, hipMemcpyHostToDevice);
+            e3 = hipMemcpy(a->d_ref_nodes, hs->ref.nodes, sizeof(lh_refnode_t) * (size_t)rn, hipMemcpyHostToDevice);
+            e4 = hipMemcpy(a->d_ref_leaf_prims, hs->ref.leaf_prims, sizeof(uint32_t) * (size_t)hs->bvh.ntris, hipMemcpyHostToDevice);
+        }
+        free(lca); free(lp);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) return fail("reference-order tree upload failed");
+        a->dev.ref_lca = a->d_ref_lca; a->dev.prim_leafpos = a->d_prim_leafpos;
+        a->dev.ref_nodes = a->d_ref_nodes; a->dev.ref_leaf_prims = a->d_ref_leaf_prims;
+        a->dev.ref_nnodes = rn; a->dev.ref_empty = hs->ref.empty;
+        for (int k = 0; k < 3; k++) { a->dev.ref_bmin[k] = hs->ref.bmin[k]; a->dev.ref_bmax[k] = hs->ref.bmax[k]; }
+        a->device_bytes += sizeof(int) * 4 * (size_t)rn + sizeof(uint32_t) * 3 * (size_t)hs->bvh.ntris + sizeof(lh_refnode_t) * (size_t)rn;
+    }
+    return 0;
+}
+
+/* the background build of the reference-order tree: attach it if it has finished (wait: block until it has) */
+int lh_sync_ref(lh_accel_t *a, bool wait)
+{
+    lh_host_scene *hs = a->hs;
+    if (!hs->have_ref || a->d_ref_nodes || hs->bvh.ntris == 0) return 0;
+    if (wait) {
+        pthread_mutex_lock(&g_scene_mu);
+        if (hs->ref_thread_live) { pthread_join(hs->ref_thread, NULL); hs->ref_thread_live = 0; }
+        pthread_mutex_unlock(&g_scene_mu);
+    }
+    const int st = __atomic_load_n(&hs->ref_state, __ATOMIC_ACQUIRE);
+    if (st == -1) return fail("the reference-order tree build failed (out of memory)");
+    if (st != 2) return 0;
+    HIPCHK(hipSetDevice(a->device));
+    return attach_ref(a);
+}
+
+/* ---- device replica of the host scene (once per GPU) ---------------------------------------- */
+static int device_upload(lh_accel_t *a)
+{
+    lh_host_scene *hs = a->hs;
+    HIPCHK(hipSetDevice(a->device));
+    double t0 = now_s();
+    HIPCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(unsigned long long) * LH_NCURSOR));
+    HIPCHK(hipMalloc((void **)&a->d_counters, sizeof(unsigned long long) * LH_CNT_DEV));
+    HIPCHK(hipMalloc((void **)&a->d_total, sizeof(unsigned long long) * 4));
+    a->device_bytes = 0;
+    if (hs->nrm9) {
+        HIPCHK(hipMalloc(&a->d_nrm9, sizeof(double) * 9 * (size_t)hs->bvh.ntris));
+        HIPCHK(hipMemcpy(a->d_nrm9, hs->nrm9, sizeof(double) * 9 * (size_t)hs->bvh.ntris, hipMemcpyHostToDevice));
+        a->device_bytes += sizeof(double) * 9 * (size_t)hs->bvh.ntris;
+    }
+    for (int kind = 0; kind < 3; kind++) if (hs->attr9[kind]) {
+        const size_t b = sizeof(double) * 9 * (size_t)hs->bvh.ntris;
+        HIPCHK(hipMalloc(&a->d_attr9[kind], b));
+        HIPCHK(hipMemcpy(a->d_attr9[kind], hs->attr9[kind], b, hipMemcpyHostToDevice));
+        a->device_bytes += b;
+    }
+    if (hs->st6) {
+        const size_t b = sizeof(double) * 6 * (size_t)hs->bvh.ntris;
+        HIPCHK(hipMalloc(&a->d_st6, b)); HIPCHK(hipMemcpy(a->d_st6, hs->st6, b, hipMemcpyHostToDevice));
+        a->device_bytes += b;
+    }
+    if (hs->inside) {
+        HIPCHK(hipMalloc(&a->d_inside, hs->bvh.ntris)); HIPCHK(hipMemcpy(a->d_inside, hs->inside, hs->bvh.ntris, hipMemcpyHostToDevice));
+        a->device_bytes += hs->bvh.ntris;
+    }
+    if (hs->bvh.ntris) {
+        size_t t32 = sizeof(lh_tri32_t) * (size_t)hs->bvh.ntris;
+        size_t t64 = sizeof(lh_tri64_t) * (size_t)hs->bvh.ntris;
+        HIPCHK(hipMalloc(&a->d_tri64, t64));
+        HIPCHK(hipMemcpy(a->d_tri64, hs->bvh.tri64, t64, hipMemcpyHostToDevice));
+        if (hs->device_built) {
+            /* the traversal tree is built here, on this device (lh_build.hip): LBVH -> the same 4-wide nodes */
+            char berr[256] = "";
+            uint32_t nq4 = 0, d4 = 0; float bmin[3], bmax[3], glo[3], gst[3];
+            const double tb = now_s();
+            const int rcb = lh_device_build(hs->bvh.ntris, (const double *)a->d_tri64, &a->d_q4nodes, &nq4, &d4, &a->d_tri32, bmin, bmax, glo, gst,
+                                            (void *)a->stream, berr, sizeof(berr));
+            if (rcb == -2) return fail("lh_accel_commit: a vertex coordinate is NaN, infinite or beyond 1e30");
+            if (rcb != 0) return fail("device BVH build failed: %s", berr);
+            pthread_mutex_lock(&g_scene_mu);
+            hs->bvh.nq4nodes = nq4; hs->bvh.q4_depth = d4; hs->bvh.nnodes = nq4; hs->bvh.max_depth = d4; hs->bvh.build_seconds = now_s() - tb;
+            for (int k = 0; k < 3; k++) { hs->bvh.bmin[k] = bmin[k]; hs->bvh.bmax[k] = bmax[k]; hs->bvh.grid_lo[k] = glo[k]; hs->bvh.grid_step[k] = gst[k]; }
+            pthread_mutex_unlock(&g_scene_mu);
+            a->dev.q4nodes = a->d_q4nodes;
+            a->device_bytes += sizeof(lh_q4node_t) * (size_t)nq4;
+            if (3 * d4 + 5 > 264) return -3;          /* deeper than k_overflow_fix's private stack: the caller falls back to the host builder */
+        } else {
+            HIPCHK(hipMalloc(&a->d_tri32, t32 + 64));   /* the unified walk reads 16 B past a record */
+            HIPCHK(hipMemcpy(a->d_tri32, hs->bvh.tri32, t32, hipMemcpyHostToDevice));
+        }
+        a->device_bytes += t32 + t64;
+        float r = 0.0f;
+        for (int k = 0; k < 3; k++) { r = fmaxf(r, fabsf(hs->bvh.bmin[k])); r = fmaxf(r, fabsf(hs->bvh.bmax[k])); }
+        a->dev.tri32 = a->d_tri32; a->dev.tri64 = a->d_tri64;
+        a->dev.ntris = hs->bvh.ntris; a->dev.nnodes = hs->bvh.nnodes;
+        a->dev.max_depth = hs->bvh.max_depth; a->dev.scene_r = r; a->dev.ray_chunk = a->ray_chunk;
+        for (int k = 0; k < 3; k++) { a->dev.grid_lo[k] = hs->bvh.grid_lo[k]; a->dev.grid_step[k] = hs->bvh.grid_step[k]; }
+        if (hs->have_ref && __atomic_load_n(&hs->ref_state, __ATOMIC_ACQUIRE) == 2 && attach_ref(a) != 0) return -1;
+        a->dev.nq4nodes = hs->bvh.nq4nodes; a->dev.q4_depth = hs->bvh.q4_depth;
+        /* resident from the start: what the default kernel reads (everything else on first use) */
+        if (lh_ensure_formats(a, LH_FMT_Q16X4) != 0) return -1;
+    }
+    a->upload_seconds = now_s() - t0;
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, a->device));
+        uint32_t need = 3 * hs->bvh.q4_depth + 5;
+        if (need > 64) need = 64;
+        uint32_t stack = (need + 1u) & ~1u;
+        if (stack < 16) stack = 16;
+        int per_cu = (int)(160u / stack);                     /* LDS: stack KiB per 256-thread workgroup */
+        if (per_cu > 5) per_cu = 5;
+        if (per_cu < 1) per_cu = 1;
+        a->grid_blocks = prop.multiProcessorCount * per_cu; a->ncus = prop.multiProcessorCount;
+        const char *env = getenv("LH_GRID_BLOCKS");
+        if (env && atoi(env) > 0) a->grid_blocks = atoi(env);
+    }
+    a->committed = 1;
+    return 0;
+}
+
+extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
+{
+    lh_guard guard(a);
+    if (!a) return fail("lh_accel_commit: accel is NULL");
+    if (a->committed) return fail("lh_accel_commit: already committed");
+    if (a->commit_failed) return fail("lh_accel_commit: an earlier commit of this accelerator failed; create a new one");
+    a->commit_failed = 1;                       /* cleared on success */
+    bool on_device = build_threads == LH_BUILD_ON_DEVICE;
+    { const char *e = getenv("LH_BUILD"); if (e && strcmp(e, "device") == 0) on_device = true; if (e && strcmp(e, "host") == 0) on_device = false; }
+    if (build_threads < 0) build_threads = 0;
+    if (on_device) {
+        if (host_build(a, build_threads, true, true) != 0) return -1;
+        const int rc = device_upload(a);
+        if (rc == -3) {
+            /* an LBVH deeper than the kernel's stack bound (degenerate distributions): build on the host after all */
+            (void)hipSetDevice(a->device); release_device(a);
+            lh_host_scene *hs = a->hs;
+            pthread_mutex_lock(&g_scene_mu);
+            if (hs->ref_thread_live) { pthread_join(hs->ref_thread, NULL); hs->ref_thread_live = 0; }
+            pthread_mutex_unlock(&g_scene_mu);
+            free(hs->nrm9); free(hs->attr9[0]); free(hs->attr9[1]); free(hs->attr9[2]); free(hs->st6); free(hs->inside);
+            hs->nrm9 = NULL; hs->attr9[0] = hs->attr9[1] = hs->attr9[2] = NULL; hs->st6 = NULL; hs->inside = NULL;
+            lh_bvh_release(&hs->bvh); lh_refbvh_release(&hs->ref); hs->ref_state = 0;
+            on_device = false;
+        } else {
+            for (uint32_t g = 0; g < a->nmeshes; g++) {
+                free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm);
+                for (int k = 0; k < 5; k++) free(a->meshes[g].attr[k]);
+            }
+            free(a->meshes); a->meshes = NULL; a->nmeshes = 0;
+            if (rc != 0) return -1;
+            a->commit_failed = 0;
+            return 0;
+        }
+    }
+    if (host_build(a, build_threads, false, false) != 0) return -1;
+    if (device_upload(a) != 0) return -1;
+    a->commit_failed = 0;
+    return 0;
+}
+
+/* blocks until the reference-order tree of a device-built scene is attached: from then on exact-t ties and fragile
+ * hits follow the reference's tree (before: ties fall back to "larger primitive id wins", as with LH_REFTREE=0) */
+extern "C" int lh_accel_wait_exact(lh_accel_t *a)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_accel_wait_exact: accel not committed");
+    return lh_sync_ref(a, true);
+}
+
+/* lh_multi.hip: `dst` (created, nothing added) becomes a replica of `src`'s committed scene on its own device */
+extern "C" int lh_accel_commit_replica(lh_accel_t *dst, lh_accel_t *src)
+{
+    if (!dst || !src || !src->committed) return fail("lh_accel_commit_replica: source not committed");
+    lh_guard guard(dst);
+    if (dst->committed || dst->commit_failed || dst->nmeshes) return fail("lh_accel_commit_replica: destination is not a fresh accelerator");
+    pthread_mutex_lock(&g_scene_mu);
+    lh_host_scene *old = dst->hs;
+    dst->hs = src->hs; dst->hs->refs++;
+    pthread_mutex_unlock(&g_scene_mu);
+    free(old);                                  /* a fresh accelerator's scene holds nothing */
+    dst->commit_failed = 1;
+    {
+        const int rc = device_upload(dst);              /* a device-built scene is built again on this replica's device */
+        if (rc == -3) return fail("lh_accel_commit_replica: the device-built tree is deeper than the traversal kernels' stacks (the source fell back to the host builder?)");
+        if (rc != 0) return -1;
+    }
+    dst->commit_failed = 0;
+    return 0;
+}
+
+extern "C" void lh_accel_destroy(lh_accel_t *a)
+{
+    if (!a) return;
+    if (a->committed || a->commit_failed) { (void)hipSetDevice(a->device); release_device(a); }
+    for (uint32_t g = 0; g < a->nmeshes; g++) {
+        free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm);
+        for (int k = 0; k < 5; k++) free(a->meshes[g].attr[k]);
+    }
+    free(a->meshes);
+    pthread_mutex_lock(&g_scene_mu);
+    const int last = (--a->hs->refs == 0);
+    pthread_mutex_unlock(&g_scene_mu);
+    if (last) {
+        if (a->hs->ref_thread_live) { pthread_join(a->hs->ref_thread, NULL); a->hs->ref_thread_live = 0; }
+        free(a->hs->nrm9); free(a->hs->attr9[0]); free(a->hs->attr9[1]); free(a->hs->attr9[2]); free(a->hs->st6); free(a->hs->inside);
+        lh_bvh_release(&a->hs->bvh);
+        lh_refbvh_release(&a->hs->ref);
+        free(a->hs);
+    }
+    pthread_mutex_destroy(&a->mu);
+    free(a);
+}
+
+extern "C" int lh_accel_info(const lh_accel_t *a, lh_accel_info_t *o)
+{
+    if (!a || !o) return fail("lh_accel_info: NULL argument");
+    if (!a->committed) return fail("lh_accel_info: accel not committed");
+    o->ntriangles = a->hs->bvh.ntris; o->nnodes = a->hs->bvh.nnodes; o->nleaves = a->hs->bvh.nleaves;
+    o->max_depth = a->hs->bvh.max_depth; o->device_bytes = a->device_bytes;
+    o->build_seconds = a->hs->bvh.build_seconds; o->upload_seconds = a->upload_seconds;
+    o->device = a->device;
+    o->ref_build_seconds = a->hs->ref_build_seconds;
+    o->nnodes_traversal = a->hs->bvh.nq4nodes;
+    return 0;
+}
+
+extern "C" int lh_accel_prim_lookup(const lh_accel_t *a, uint32_t prim, uint32_t *mesh, uint32_t *index)
+{
+    if (!a || !a->committed) return fail("lh_accel_prim_lookup: accel not committed");
+    if (prim >= a->hs->bvh.ntris) return fail("lh_accel_prim_lookup: prim %u out of range", prim);
+    if (mesh) *mesh = a->hs->bvh.prim_geom[prim];
+    if (index) *index = a->hs->bvh.prim_index[prim];
+    return 0;
+}
+
+extern "C" int lh_accel_set_grid(lh_accel_t *a, int blocks)
+{
+    lh_guard guard(a);
+    if (!a || blocks <= 0) return fail("lh_accel_set_grid: bad argument");
+    a->grid_blocks = blocks;
+    return 0;
+}
+
+/* tuning knobs of the traversal kernel (sweeps, tools/): "grid" persistent workgroups, "min_active" regroup threshold,
+ * "tri_batch" parked leaves per triangle pass, "ray_chunk" rays per cursor atomic, "variant" default kernel variant,
+ * "ao_fused", "wide8" (-1 auto / 0 / 1), "stack_cap" (tests of the overflow path) */
+extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
+{
+    lh_guard guard(a);
+    if (!a || !name) return fail("lh_accel_set_param: NULL argument");
+    if (!strcmp(name, "grid") && value > 0) a->grid_blocks = value;
+    else if (!strcmp(name, "min_active") && value > 0 && value <= 64) a->min_active = value;
+    else if (!strcmp(name, "tri_batch") && value > 0 && value <= 64) a->tri_batch = value;
+    else if (!strcmp(name, "ray_chunk") && value > 0 && value <= (1 << 20)) { a->ray_chunk = (uint32_t)value; a->dev.ray_chunk = (uint32_t)value; }
+    else if (!strcmp(name, "variant") && (value == LH_VARIANT_DIRECT || value == LH_VARIANT_SPEC)) a->default_variant = value;
+    else if (!strcmp(name, "ao_fused")) a->ao_fused = value != 0;
+    else if (!strcmp(name, "fast_start")) a->fast_start = value != 0;
+    else if (!strcmp(name, "wide8") && value >= -1 && value <= 1) a->wide8 = value;
+    else if (!strcmp(name, "stack_cap") && (value == 0 || (value >= 8 && value <= 64 && value % 2 == 0))) a->dev.stack_cap = (uint32_t)value;
+    else return fail("lh_accel_set_param: unknown parameter or bad value: %s = %d", name, value);
+    return 0;
+}
+
+extern "C" int lh_accel_export(const lh_accel_t *a, void *nodes, void *tri32)
+{
+    if (!a || !a->committed) return fail("lh_accel_export: accel not committed");
+    if (a->hs->device_built) return fail("lh_accel_export: the tree was built on the device; there is no host copy");
+    if (nodes && a->hs->bvh.nnodes) memcpy(nodes, a->hs->bvh.nodes, sizeof(lh_node_t) * (size_t)a->hs->bvh.nnodes);
+    if (tri32 && a->hs->bvh.ntris) memcpy(tri32, a->hs->bvh.tri32, sizeof(lh_tri32_t) * (size_t)a->hs->bvh.ntris);
+    return 0;
+}
+
+/* fill miss results without touching the scene (empty accel) */
+extern "C" int lh_accel_add_rib_scene(lh_accel_t *a, const lh_rib_scene_t *scene)
+{
+    lh_guard guard(a);
+    lh_rib_info_t info;
+    if (!a || !scene) return fail("lh_accel_add_rib_scene: NULL argument");
+    if (lh_rib_info(scene, &info) != 0) return fail("lh_accel_add_rib_scene: %s", lh_rib_last_error());
+    for (uint32_t m = 0; m < info.nmeshes; m++) {
+        uint32_t npos = 0, nidx = 0; const double *pos = NULL, *nrm = NULL; const uint32_t *idx = NULL; int two = 0;
+        if (lh_rib_mesh(scene, m, &npos, &pos, &nidx, &idx, &nrm, &two) != 0) return fail("lh_accel_add_rib_scene: %s", lh_rib_last_error());
+        const uint32_t ord = a->nmeshes;          /* add_mesh returns 0 / -1, not the ordinal */
+        if (lh_accel_add_mesh(a, npos, pos, 4 * sizeof(double), nidx, idx) != 0) return -1;
+        if (nrm && lh_accel_set_normals(a, ord, nrm, 4 * sizeof(double), two) != 0) return -1;
+    }
+    return 0;
+}
+

@@ -52,7 +52,6 @@ typedef struct lh_ray32 {
     float cfx, cfy, cfz;              /* -org*idir + slack                   */
     /* 16-bit grid nodes: t = q*qa + qbn/qbf  (qa = step*idir, qb = (grid_lo-org)*idir -/+ slack) */
     float qax, qay, qaz, qbnx, qbny, qbnz, qbfx, qbfy, qbfz;
-    float slx, sly, slz;              /* slab slack per axis: KBOX*2^-24*(|org|_inf+R)*|1/dir_k| */
     float keps;                       /* KTRI*2^-24*(|org|_inf+R)            */
     float dn;                         /* |dir|_2 rounded up                  */
     int   ngx, ngy, ngz;              /* dir_k < 0                           */
@@ -97,7 +96,6 @@ LH_HD void lh_ray_setup(lh_ray32_t *r, double ox, double oy, double oz,
     r->cnx = fmaf(-r->ox, r->ix, -sx); r->cfx = fmaf(-r->ox, r->ix, sx);
     r->cny = fmaf(-r->oy, r->iy, -sy); r->cfy = fmaf(-r->oy, r->iy, sy);
     r->cnz = fmaf(-r->oz, r->iz, -sz); r->cfz = fmaf(-r->oz, r->iz, sz);
-    r->slx = sx; r->sly = sy; r->slz = sz;
     r->ngx = r->dx < 0.0f; r->ngy = r->dy < 0.0f; r->ngz = r->dz < 0.0f;
     r->keps = LH_KTRI * LH_EPS24 * scale;
     r->qax = r->qay = r->qaz = 0.0f; r->qbnx = r->qbny = r->qbnz = 0.0f; r->qbfx = r->qbfy = r->qbfz = 0.0f;
@@ -122,22 +120,7 @@ LH_HD int lh_slab(const lh_ray32_t *r, float lox, float loy, float loz,
     return tn <= tf;
 }
 
-/* the same test on a 16-bit grid box (lh_qnode_t): qlo/qhi already converted to float */
-LH_HD int lh_slab_q(const lh_ray32_t *r, float lox, float loy, float loz,
-                    float hix, float hiy, float hiz, float tb, float *tn_out)
-{
-    const float ax = r->ngx ? hix : lox, bx = r->ngx ? lox : hix;
-    const float ay = r->ngy ? hiy : loy, by = r->ngy ? loy : hiy;
-    const float az = r->ngz ? hiz : loz, bz = r->ngz ? loz : hiz;
-    const float tn = fmaxf(fmaxf(fmaf(ax, r->qax, r->qbnx), fmaf(ay, r->qay, r->qbny)),
-                           fmaxf(fmaf(az, r->qaz, r->qbnz), 0.0f));
-    const float tf = fminf(fminf(fmaf(bx, r->qax, r->qbfx), fmaf(by, r->qay, r->qbfy)),
-                           fminf(fmaf(bz, r->qaz, r->qbfz), tb));
-    *tn_out = tn;
-    return tn <= tf;
-}
-
-/* the same test on lh_q4node_t's packing: w = lo | hi << 16 per axis */
+/* the same test on a 16-bit grid box in lh_q4node_t's / lh_q8node_t's packing: w = lo | hi << 16 per axis */
 LH_HD int lh_slab_w(const lh_ray32_t *r, uint32_t wx, uint32_t wy, uint32_t wz, float tb, float *tn_out)
 {
     const uint32_t sx = r->ngx ? ((wx >> 16) | (wx << 16)) : wx;
@@ -147,34 +130,6 @@ LH_HD int lh_slab_w(const lh_ray32_t *r, uint32_t wx, uint32_t wy, uint32_t wz, 
                            fmaxf(fmaf((float)(sz & 0xffffu), r->qaz, r->qbnz), 0.0f));
     const float tf = fminf(fminf(fmaf((float)(sx >> 16), r->qax, r->qbfx), fmaf((float)(sy >> 16), r->qay, r->qbfy)),
                            fminf(fmaf((float)(sz >> 16), r->qaz, r->qbfz), tb));
-    *tn_out = tn;
-    return tn <= tf;
-}
-
-/* 8-wide compressed nodes (lh_c8node_t): per node, the ray's plane-distance coefficients in the node's
- * own frame: t(q) = q * a + b with a = 2^(e-127) * idir (exact scaling), b = (p - org) * idir -/+ slack.
- * Rounding: one in (p - org), one in the product, one in the FMA -- the same budget as the fp32-node
- * form lo*idir - org*idir, inside the KBOX margin. */
-typedef struct lh_c8frame { float ax, ay, az, bnx, bny, bnz, bfx, bfy, bfz; } lh_c8frame_t;
-
-LH_HD float lh_exp2_bits(uint32_t biased) { union { uint32_t u; float f; } c; c.u = biased << 23; return c.f; }
-
-LH_HD void lh_c8_frame(const lh_ray32_t *r, float px, float py, float pz, uint32_t ex, uint32_t ey, uint32_t ez,
-                       lh_c8frame_t *f)
-{
-    const float bx = (px - r->ox) * r->ix, by = (py - r->oy) * r->iy, bz = (pz - r->oz) * r->iz;
-    f->ax = lh_exp2_bits(ex) * r->ix; f->ay = lh_exp2_bits(ey) * r->iy; f->az = lh_exp2_bits(ez) * r->iz;
-    f->bnx = bx - r->slx; f->bfx = bx + r->slx;
-    f->bny = by - r->sly; f->bfy = by + r->sly;
-    f->bnz = bz - r->slz; f->bfz = bz + r->slz;
-}
-
-/* near/far plane indices already selected for the ray's direction signs */
-LH_HD int lh_slab_c8(const lh_c8frame_t *f, float nx, float ny, float nz, float fx, float fy, float fz,
-                     float tb, float *tn_out)
-{
-    const float tn = fmaxf(fmaxf(fmaf(nx, f->ax, f->bnx), fmaf(ny, f->ay, f->bny)), fmaxf(fmaf(nz, f->az, f->bnz), 0.0f));
-    const float tf = fminf(fminf(fmaf(fx, f->ax, f->bfx), fmaf(fy, f->ay, f->bfy)), fminf(fmaf(fz, f->az, f->bfz), tb));
     *tn_out = tn;
     return tn <= tf;
 }

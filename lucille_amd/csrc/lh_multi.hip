@@ -303,7 +303,8 @@ extern "C" int lh_multi_render_ao_frame_host(lh_multi_t *m, const lh_camera_t *c
 
 extern "C" int lh_multi_set_material(lh_multi_t *m, uint32_t mesh, const lh_material_t *material)
 {
-    if (!m) return mfail("lh_multi_set_material: NULL");
+    /* materials live on the replicas, and replicas 1..n-1 get their meshes in lh_multi_commit */
+    if (!m || !m->committed) return mfail("lh_multi_set_material: not committed (set materials after lh_multi_commit)");
     for (int k = 0; k < m->n; k++) if (lh_accel_set_material(m->acc[k], mesh, material) != 0) return -1;
     return 0;
 }

@@ -1,0 +1,364 @@
+/*
+ * lh_query.hip -- the ray queries of the C ABI: accel_intersect_func (src/render/accel.h:30-34) as device-resident, host
+ * and pipelined host batches, one synchronous ray, traversal statistics (src/render/bvh.c:669-706) and beam visibility
+ * (ri_bvh_intersect_beam_visibility, bvh.c:612-667).  The kernels are in lh_kernels.hip / lh_beam.hip.
+ */
+#include <thread>
+#include <vector>
+
+#include "lh_internal.h"
+
+/* fill miss results without touching the scene (empty accel) */
+__global__ void k_fill_miss(size_t n, uint32_t *prim, double *t, double *u, double *v, uint8_t *occ)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (prim) prim[i] = LH_MISS_PRIM;
+    if (t) t[i] = LH_T_INF;
+    if (u) u[i] = 0.0;
+    if (v) v[i] = 0.0;
+    if (occ) occ[i] = 0;
+}
+
+/* the fused AO stage's queue for launches on `s`: launches on one stream are ordered, so they share a slot;
+ * different streams (replicas' tile loops) get their own */
+int lh_aoq_slot(lh_accel_t *a, hipStream_t s)
+{
+    int k, free_k = -1;
+    for (k = 0; k < LH_AOQ_SLOTS; k++) {
+        if (a->aoq[k].used && a->aoq[k].stream == s) return k;
+        if (!a->aoq[k].used && free_k < 0) free_k = k;
+    }
+    if (free_k < 0) {
+        /* more concurrent streams than slots: wait for the device, then recycle slot 0 */
+        HIPCHK(hipDeviceSynchronize());
+        free_k = 0;
+    }
+    k = free_k;
+    if (!a->aoq[k].queue) {
+        HIPCHK(hipMalloc((void **)&a->aoq[k].queue, (size_t)LH_AO_QCAP * 2 * sizeof(uint32_t) + 2 * sizeof(uint32_t)));
+        a->aoq[k].qcount = a->aoq[k].queue + (size_t)LH_AO_QCAP * 2;
+    }
+    a->aoq[k].stream = s; a->aoq[k].used = 1;
+    return k;
+}
+
+/* hot set of a ray dump (4-wide nodes + 48-byte triangle records) against the Infinity Cache */
+static bool wide8_pays(const lh_accel_t *a)
+{
+    const lh_bvh_t *b = &a->hs->bvh;
+    return sizeof(lh_q4node_t) * (size_t)b->nq4nodes + sizeof(lh_tri32_t) * (size_t)b->ntris > ((size_t)256 << 20);
+}
+
+int lh_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, void *d_prim,
+              void *d_t, void *d_u, void *d_v, void *d_occ, int mode, int variant,
+              unsigned long long *d_counters, hipStream_t s, bool dump)
+{
+    if (!a || !a->committed) return fail("intersect: accel not committed");
+    if (n == 0) return 0;
+    if (!d_org || !d_dir) return fail("intersect: NULL ray arrays");
+    if (mode == LH_MODE_CLOSEST && (!d_prim || !d_t || !d_u || !d_v)) return fail("intersect: closest mode needs prim,t,u,v outputs");
+    if (mode == LH_MODE_ANY && !d_occ) return fail("intersect: any mode needs the occluded output");
+    if (mode != LH_MODE_CLOSEST && mode != LH_MODE_ANY) return fail("intersect: unknown mode %d", mode);
+    HIPCHK(hipSetDevice(a->device));
+    if (a->hs->bvh.ntris == 0) {
+        size_t blocks = (n + 255) / 256;
+        hipLaunchKernelGGL(k_fill_miss, dim3((unsigned)blocks), dim3(256), 0, s, n,
+                           mode == LH_MODE_CLOSEST ? (uint32_t *)d_prim : NULL, (double *)(mode == LH_MODE_CLOSEST ? d_t : NULL),
+                           (double *)(mode == LH_MODE_CLOSEST ? d_u : NULL), (double *)(mode == LH_MODE_CLOSEST ? d_v : NULL),
+                           mode == LH_MODE_ANY ? (uint8_t *)d_occ : NULL);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    /* a device-built scene: lucille's own tree (exact-t tie winners, fragile hits) is built by a background host thread.
+     * Queries are exact by default -- the first launch waits for it; set_param("fast_start", 1) / LH_FAST_START=1 launches
+     * at once and attaches the tree when it is ready (until then ties resolve to the larger primitive id) */
+    if (a->hs->device_built && !a->d_ref_nodes && lh_sync_ref(a, !a->fast_start) != 0) return -1;
+    if (variant == LH_VARIANT_DEFAULT) variant = a->default_variant;
+    if (variant != LH_VARIANT_DIRECT && variant != LH_VARIANT_SPEC)
+        return fail("intersect: unknown variant %d (%d: the textbook reference walk, %d: the default)", variant, LH_VARIANT_DIRECT, LH_VARIANT_SPEC);
+    /* a tree built on the device exists only as 4-wide nodes: the textbook walk runs as the default walk there */
+    if (a->hs->device_built) variant = LH_VARIANT_SPEC;
+    if (lh_ensure_formats(a, lh_trace_formats_needed(&a->dev, variant)) != 0) return -1;     /* the textbook walk's nodes: uploaded on first use */
+    /* ray dumps (incoherent by assumption) over a scene whose hot set does not fit the 256 MiB Infinity Cache walk the 8-wide
+     * nodes: each record then costs a 128-byte line of HBM traffic whatever its size, and an 8-wide record uses all of it
+     * (S-soup-10M: 57 -> 40 records per ray).  The tile pipelines' coherent rays stay on the 4-wide nodes. */
+    a->dev.prefer_q8 = 0;
+    if (dump && variant == LH_VARIANT_SPEC && !a->hs->device_built && (a->wide8 == 1 || (a->wide8 == -1 && wide8_pays(a)))) {
+        if (lh_ensure_formats(a, LH_FMT_Q8) != 0) return -1;
+        a->dev.prefer_q8 = 1;
+    }
+    int rc = lh_launch_trace(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim,
+                             (double *)d_t, (double *)d_u, (double *)d_v, mode == LH_MODE_ANY,
+                             (uint8_t *)d_occ, d_counters, a->d_cursor + (a->cursor_next++ % LH_NCURSOR), variant, a->grid_blocks, a->min_active, a->tri_batch, (void *)s);
+    if (rc != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+extern "C" int lh_accel_intersect_device(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
+                                         void *d_prim, void *d_t, void *d_u, void *d_v, void *d_occ,
+                                         int mode, int variant, void *stream)
+{
+    lh_guard guard(a);
+    return lh_launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, variant, NULL, (hipStream_t)stream, true);
+}
+
+extern "C" int lh_accel_intersect_device_counted(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir,
+                                                 void *d_prim, void *d_t, void *d_u, void *d_v, void *d_occ,
+                                                 int mode, int variant, uint64_t counters[4])
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("intersect: accel not committed");
+    if (!counters) return fail("intersect_counted: counters is NULL");
+    HIPCHK(hipSetDevice(a->device));
+    HIPCHK(hipMemsetAsync(a->d_counters, 0, sizeof(unsigned long long) * LH_CNT_DEV, a->stream));
+    HIPCHK(hipDeviceSynchronize());
+    if (a->hs->bvh.ntris == 0) { counters[0] = counters[1] = counters[2] = 0; counters[3] = n; }
+    int rc = lh_launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, variant, a->d_counters, a->stream, true);
+    if (rc != 0) return rc;
+    HIPCHK(hipStreamSynchronize(a->stream));
+    if (a->hs->bvh.ntris) {
+        unsigned long long h[LH_CNT_DEV];
+        HIPCHK(hipMemcpy(h, a->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+        for (int k = 0; k < LH_CNT_N; k++) counters[k] = h[k];
+        a->last_retraced = h[LH_CNT_RETRACED];
+        if (getenv("LH_DEBUG_COUNTERS"))
+            fprintf(stderr, "[lucille_hip] lane slots: node steps %llu of %llu, triangle steps %llu of %llu, regroup iterations %llu; "
+                            "rays through the reference walk %llu\n",
+                    h[LH_CNT_NODES], h[LH_CNT_NODE_SLOTS], h[LH_CNT_TRIS], h[LH_CNT_TRI_SLOTS], h[LH_CNT_REGROUP_SLOTS], h[LH_CNT_RETRACED]);
+    }
+    return 0;
+}
+
+/* bytes of the node record a ray dump walks on this scene: 128 when the 8-wide nodes are in use (hot set beyond the
+ * Infinity Cache, or "wide8" forced), else the default format's */
+extern "C" int lh_accel_dump_node_bytes(const lh_accel_t *a)
+{
+    if (!a || !a->committed || a->hs->bvh.ntris == 0) return 0;
+    if (a->default_variant == LH_VARIANT_SPEC && !a->hs->device_built &&
+        (a->wide8 == 1 || (a->wide8 == -1 && wide8_pays(a)))) return (int)sizeof(lh_q8node_t);
+    return 64;
+}
+
+extern "C" uint64_t lh_accel_last_retraced(const lh_accel_t *a) { return a ? a->last_retraced : 0; }
+
+int lh_ensure_stage(lh_accel_t *a, size_t bytes)
+{
+    if (a->stage_bytes >= bytes) return 0;
+    if (a->d_stage) { (void)hipFree(a->d_stage); a->d_stage = NULL; a->stage_bytes = 0; }
+    HIPCHK(hipMalloc(&a->d_stage, bytes));
+    a->stage_bytes = bytes;
+    return 0;
+}
+
+/* ---- large host batches: chunks pipelined through pinned staging -----------------------------------
+ * A pageable hipMemcpy moves ~12 GB/s; the link does ~50.  Rays are cut into chunks of LH_PIPE_CHUNK;
+ * chunk k is copied into pinned memory by a few host threads, sent, traced and brought back on stream
+ * k & 1 while the host stages chunk k+1 and un-stages chunk k-1. */
+#define LH_PIPE_CHUNK ((size_t)1 << 21)
+#define LH_PIPE_MIN   ((size_t)1 << 20)
+
+static void par_copy(void *dst, const void *src, size_t bytes)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t nt = bytes < ((size_t)8 << 20) ? 1 : (hw >= 16 ? 8 : (hw >= 4 ? 4 : 1));
+    if (nt == 1) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
+    for (size_t k = 0; k < nt; k++) {
+        const size_t b = k * per; if (b >= bytes) break;
+        const size_t e = (b + per < bytes) ? b + per : bytes;
+        th.emplace_back([=] { memcpy((char *)dst + b, (const char *)src + b, e - b); });
+    }
+    for (auto &t : th) t.join();
+}
+
+static int pipe_init(lh_accel_t *a)
+{
+    if (a->pipe.ready) return 0;
+    const size_t C = LH_PIPE_CHUNK;
+    const size_t in_b = sizeof(double) * 6 * C, out_b = (sizeof(double) * 3 + sizeof(uint32_t)) * C;
+    for (int b = 0; b < 2; b++) {
+        HIPCHK(hipHostMalloc(&a->pipe.h_in[b], in_b, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&a->pipe.h_out[b], out_b, hipHostMallocDefault));
+        HIPCHK(hipMalloc(&a->pipe.d_in[b], in_b));
+        HIPCHK(hipMalloc(&a->pipe.d_out[b], out_b));
+        HIPCHK(hipStreamCreateWithFlags(&a->pipe.s[b], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&a->pipe.done[b], hipEventDisableTiming));
+    }
+    a->pipe.cap = C; a->pipe.ready = 1;
+    return 0;
+}
+
+static int intersect_host_pipelined(lh_accel_t *a, size_t n, const double *org, const double *dir,
+                                    uint32_t *prim, double *t, double *u, double *v, uint8_t *occ, int mode)
+{
+    if (pipe_init(a) != 0) return -1;
+    const size_t C = a->pipe.cap, nchunks = (n + C - 1) / C;
+    auto unstage = [&](size_t k) {
+        const int b = (int)(k & 1); const size_t first = k * C, m = (first + C <= n) ? C : n - first;
+        const char *ho = (const char *)a->pipe.h_out[b];
+        if (mode == LH_MODE_CLOSEST) {
+            if (t) par_copy(t + first, ho, sizeof(double) * m);
+            if (u) par_copy(u + first, ho + sizeof(double) * C, sizeof(double) * m);
+            if (v) par_copy(v + first, ho + 2 * sizeof(double) * C, sizeof(double) * m);
+            if (prim) par_copy(prim + first, ho + 3 * sizeof(double) * C, sizeof(uint32_t) * m);
+        } else if (occ) par_copy(occ + first, ho, m);
+    };
+    for (size_t k = 0; k < nchunks; k++) {
+        const int b = (int)(k & 1); const size_t first = k * C, m = (first + C <= n) ? C : n - first;
+        if (k >= 2) { HIPCHK(hipEventSynchronize(a->pipe.done[b])); unstage(k - 2); }
+        char *hi = (char *)a->pipe.h_in[b], *di = (char *)a->pipe.d_in[b], *dout = (char *)a->pipe.d_out[b];
+        par_copy(hi, org + 3 * first, sizeof(double) * 3 * m);
+        par_copy(hi + sizeof(double) * 3 * C, dir + 3 * first, sizeof(double) * 3 * m);
+        hipStream_t s = a->pipe.s[b];
+        HIPCHK(hipMemcpyAsync(di, hi, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(di + sizeof(double) * 3 * C, hi + sizeof(double) * 3 * C, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
+        double *d_t = (double *)dout, *d_u = d_t + C, *d_v = d_u + C; uint32_t *d_prim = (uint32_t *)(d_v + C);
+        const int rc = lh_launch(a, m, di, di + sizeof(double) * 3 * C, d_prim, d_t, d_u, d_v, (uint8_t *)dout, mode, LH_VARIANT_DEFAULT, NULL, s, true);
+        if (rc != 0) return rc;
+        char *ho = (char *)a->pipe.h_out[b];
+        if (mode == LH_MODE_CLOSEST) {
+            if (t) HIPCHK(hipMemcpyAsync(ho, d_t, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+            if (u) HIPCHK(hipMemcpyAsync(ho + sizeof(double) * C, d_u, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+            if (v) HIPCHK(hipMemcpyAsync(ho + 2 * sizeof(double) * C, d_v, sizeof(double) * m, hipMemcpyDeviceToHost, s));
+            if (prim) HIPCHK(hipMemcpyAsync(ho + 3 * sizeof(double) * C, d_prim, sizeof(uint32_t) * m, hipMemcpyDeviceToHost, s));
+        } else if (occ) HIPCHK(hipMemcpyAsync(ho, dout, m, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(a->pipe.done[b], s));
+    }
+    for (size_t k = (nchunks >= 2 ? nchunks - 2 : 0); k < nchunks; k++) {
+        HIPCHK(hipEventSynchronize(a->pipe.done[k & 1])); unstage(k);
+    }
+    return 0;
+}
+
+extern "C" int lh_accel_intersect_host(lh_accel_t *a, size_t n, const double *org, const double *dir,
+                                       uint32_t *prim, double *t, double *u, double *v, uint8_t *occ, int mode)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("intersect: accel not committed");
+    if (n == 0) return 0;
+    if (!org || !dir) return fail("intersect: NULL ray arrays");
+    if (mode != LH_MODE_CLOSEST && mode != LH_MODE_ANY) return fail("intersect: unknown mode %d", mode);
+    HIPCHK(hipSetDevice(a->device));
+    if (n >= LH_PIPE_MIN && !a->stat_on && !getenv("LH_HOST_SIMPLE"))
+        return intersect_host_pipelined(a, n, org, dir, prim, t, u, v, occ, mode);
+    /* layout of the staging block: org | dir | t | u | v | prim | occ */
+    const size_t b_ray = sizeof(double) * 3 * n, b_d = sizeof(double) * n;
+    const size_t total = 2 * b_ray + 3 * b_d + sizeof(uint32_t) * n + n + 64;
+    if (lh_ensure_stage(a, total) != 0) return -1;
+    char *base = (char *)a->d_stage;
+    double *d_org = (double *)base, *d_dir = (double *)(base + b_ray);
+    double *d_t = (double *)(base + 2 * b_ray), *d_u = d_t + n, *d_v = d_u + n;
+    uint32_t *d_prim = (uint32_t *)(d_v + n);
+    uint8_t *d_occ = (uint8_t *)(d_prim + n);
+    HIPCHK(hipMemcpyAsync(d_org, org, b_ray, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_dir, dir, b_ray, hipMemcpyHostToDevice, a->stream));
+    if (a->stat_on) HIPCHK(hipMemsetAsync(a->d_counters, 0, sizeof(unsigned long long) * LH_CNT_DEV, a->stream));
+    int rc = lh_launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, LH_VARIANT_DEFAULT,
+                    a->stat_on ? a->d_counters : NULL, a->stream, true);
+    if (rc != 0) return rc;
+    if (a->stat_on) {
+        /* hits are counted from the device outputs whatever the caller asked to copy back */
+        std::vector<uint32_t> hp; std::vector<uint8_t> ho; unsigned long long h[LH_CNT_N] = {0, 0, 0, 0}, nh = 0;
+        if (mode == LH_MODE_CLOSEST) {
+            hp.resize(n); HIPCHK(hipMemcpyAsync(hp.data(), d_prim, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, a->stream));
+        } else {
+            ho.resize(n); HIPCHK(hipMemcpyAsync(ho.data(), d_occ, n, hipMemcpyDeviceToHost, a->stream));
+        }
+        if (a->hs->bvh.ntris) HIPCHK(hipMemcpyAsync(h, a->d_counters, sizeof(h), hipMemcpyDeviceToHost, a->stream));
+        HIPCHK(hipStreamSynchronize(a->stream));
+        for (size_t i = 0; i < n; i++) nh += (mode == LH_MODE_CLOSEST) ? (hp[i] != LH_MISS_PRIM) : (ho[i] != 0);
+        a->stat[0] += h[LH_CNT_NODES]; a->stat[1] += h[LH_CNT_TRIS]; a->stat[2] += h[LH_CNT_EXACT];
+        a->stat[3] += n; a->stat[4] += nh;
+    }
+    if (mode == LH_MODE_CLOSEST) {
+        if (prim) HIPCHK(hipMemcpyAsync(prim, d_prim, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, a->stream));
+        if (t) HIPCHK(hipMemcpyAsync(t, d_t, b_d, hipMemcpyDeviceToHost, a->stream));
+        if (u) HIPCHK(hipMemcpyAsync(u, d_u, b_d, hipMemcpyDeviceToHost, a->stream));
+        if (v) HIPCHK(hipMemcpyAsync(v, d_v, b_d, hipMemcpyDeviceToHost, a->stream));
+    } else {
+        if (occ) HIPCHK(hipMemcpyAsync(occ, d_occ, n, hipMemcpyDeviceToHost, a->stream));
+    }
+    HIPCHK(hipStreamSynchronize(a->stream));
+    return 0;
+}
+
+extern "C" int lh_accel_trace_statistics(lh_accel_t *a, int enable)
+{
+    lh_guard guard(a);
+    if (!a) return fail("lh_accel_trace_statistics: NULL accel");
+    a->stat_on = enable != 0;
+    return 0;
+}
+
+extern "C" int lh_accel_statistics(lh_accel_t *a, uint64_t counters[5], int clear)
+{
+    lh_guard guard(a);
+    if (!a) return fail("lh_accel_statistics: NULL accel");
+    if (counters) for (int k = 0; k < 5; k++) counters[k] = a->stat[k];
+    if (clear) for (int k = 0; k < 5; k++) a->stat[k] = 0;
+    return 0;
+}
+
+extern "C" int lh_accel_intersect1(lh_accel_t *a, const double org[3], const double dir[3],
+                                   uint32_t *prim, double *t, double *u, double *v)
+{
+    uint32_t p = LH_MISS_PRIM; double tt = LH_T_INF, uu = 0.0, vv = 0.0;
+    if (!org || !dir) return fail("lh_accel_intersect1: NULL ray");
+    if (lh_accel_intersect_host(a, 1, org, dir, &p, &tt, &uu, &vv, NULL, LH_MODE_CLOSEST) != 0) return -1;
+    if (prim) *prim = p;
+    if (t) *t = tt;
+    if (u) *u = uu;
+    if (v) *v = vv;
+    return p != LH_MISS_PRIM;
+}
+
+
+/* ------------------------------------------------------------------------ */
+/* beam visibility                                                          */
+/* ------------------------------------------------------------------------ */
+extern "C" int lh_launch_beam_visibility(const lh_dev_scene_t *sc, size_t n, const double *d_org, const double *d_dirs,
+                                         int32_t *d_result, void *stream);
+
+__global__ void k_fill_i32(size_t n, int32_t *p, int32_t v)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+extern "C" int lh_accel_beam_visibility_device(lh_accel_t *a, size_t n, const void *d_org, const void *d_dirs,
+                                               void *d_result, void *stream)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("beam_visibility: accel not committed");
+    if (n == 0) return 0;
+    if (!d_org || !d_dirs || !d_result) return fail("beam_visibility: NULL argument");
+    if (!a->hs->have_ref) return fail("beam_visibility: the reference-order tree was disabled (LH_REFTREE=0)");
+    if (lh_sync_ref(a, true) != 0) return -1;
+    HIPCHK(hipSetDevice(a->device));
+    lh_dev_scene_t sc = a->dev;
+    if (a->hs->bvh.ntris == 0) { sc.ref_empty = 1; }
+    if (lh_launch_beam_visibility(&sc, n, (const double *)d_org, (const double *)d_dirs, (int32_t *)d_result, stream) != 0)
+        return fail("beam kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+extern "C" int lh_accel_beam_visibility_host(lh_accel_t *a, size_t n, const double *org, const double *dirs, int32_t *result)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("beam_visibility: accel not committed");
+    if (n == 0) return 0;
+    if (!org || !dirs || !result) return fail("beam_visibility: NULL argument");
+    HIPCHK(hipSetDevice(a->device));
+    const size_t bo = sizeof(double) * 3 * n, bd = sizeof(double) * 12 * n, br = sizeof(int32_t) * n;
+    if (lh_ensure_stage(a, bo + bd + br + 64) != 0) return -1;
+    char *base = (char *)a->d_stage;
+    HIPCHK(hipMemcpyAsync(base, org, bo, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(base + bo, dirs, bd, hipMemcpyHostToDevice, a->stream));
+    if (lh_accel_beam_visibility_device(a, n, base, base + bo, base + bo + bd, a->stream) != 0) return -1;
+    HIPCHK(hipMemcpyAsync(result, base + bo + bd, br, hipMemcpyDeviceToHost, a->stream));
+    HIPCHK(hipStreamSynchronize(a->stream));
+    return 0;
+}
+

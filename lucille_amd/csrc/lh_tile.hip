@@ -1,0 +1,491 @@
+/*
+ * lh_tile.hip -- the callers on either side of the query, kept on the device: AO tiles / bands / frames (subsample,
+ * render_bucket, bucket_write: src/render/render.c:715-823,1107-1166,919-983; ri_transport_ambientocclusion:
+ * src/transport/ambientocclusion.c:42-151,332-415), the hit epilogue (ri_intersection_state_build,
+ * src/render/intersection_state.c:99-248) and the wavefront path tracer's tile loop (src/transport/pathtrace.c:189-314,
+ * 407-537).  The kernels are in lh_render.hip / lh_kernels.hip.
+ */
+#include <thread>
+#include <vector>
+
+#include "lh_internal.h"
+
+#define ensure_buf lh_ensure_buf
+
+/* launchers in lh_render.hip */
+extern "C" int lh_render_launch_primary(const lh_camera_t *cam, int x0, int y0, int w, int h, int xs, int ys,
+                                        double *d_org, double *d_dir, void *stream);
+extern "C" int lh_render_launch_compact(const lh_dev_scene_t *sc, const double *d_nrm9, size_t n, const double *d_org,
+                                        const double *d_dir, const uint32_t *d_prim, const double *d_t,
+                                        const double *d_u, const double *d_v, uint32_t *d_block_counts,
+                                        uint32_t *d_slot_of_sample, double *d_hitrec,
+                                        unsigned long long *d_slot_key, int x0, int w, int nbands, int band_rows,
+                                        const int *d_band_y0, int y0, int spp, int full_width,
+                                        unsigned long long *d_total, void *stream);
+extern "C" int lh_render_launch_primary_region(const lh_camera_t *cam, int x0, int w, int nbands, int band_rows, const int *d_band_y0,
+                                               int y0, int height_limit, int xs, int ys, double *d_org, double *d_dir, void *stream);
+extern "C" int lh_render_launch_ao_rays(size_t nslots, int ntheta, int nphi, unsigned long long seed,
+                                        const double *d_hitrec, const double *d_rnd,
+                                        const unsigned long long *d_slot_key, double *d_org, double *d_dir, void *stream);
+extern "C" int lh_render_launch_resolve(int w, int h, int band_rows, int xs, int ys, int N, const uint32_t *d_slot_of_sample,
+                                        const uint8_t *d_occ, const unsigned int *d_occ_count, float *d_rgb,
+                                        unsigned long long *d_occ_total, void *stream);
+
+extern "C" int lh_render_primary_rays(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h,
+                                      int ps, void *d_org, void *d_dir, void *stream)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_render_primary_rays: accel not committed");
+    if (!cam || !d_org || !d_dir) return fail("lh_render_primary_rays: NULL argument");
+    if (w < 0 || h < 0 || ps < 1) return fail("lh_render_primary_rays: bad tile");
+    HIPCHK(hipSetDevice(a->device));
+    if (lh_render_launch_primary(cam, x0, y0, w, h, ps, ps, (double *)d_org, (double *)d_dir, stream) != 0)
+        return fail("primary ray kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+/* one device batch of the AO pipeline over a Region (lh_render.hip): a rectangle, or nbands full-width bands */
+static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int nbands, int band_rows, const int *d_band_y0, int y0,
+                     uint64_t valid_pixels, int ps, int gather_nsamples, uint64_t seed, const void *d_uniforms, void *d_rgb,
+                     lh_tile_stats_t *stats, void *stream)
+{
+    const int h = nbands * band_rows;              /* lines of the batch */
+    HIPCHK(hipSetDevice(a->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int nphi = (int)sqrt((double)gather_nsamples), ntheta = nphi, N = nphi * ntheta;   /* ambientocclusion.c:378-380 */
+    const size_t S = (size_t)w * h * ps * ps;
+    if ((unsigned long long)cam->width * (unsigned long long)cam->height * (unsigned long long)(ps * ps) >= (1ull << 34))
+        return fail("AO pipeline: more than 2^34 samples in the frame (slot keys carry 34 bits)");
+    const unsigned nb = (unsigned)((S + 255) / 256);
+    if (ensure_buf(&a->r_org, S * 24) || ensure_buf(&a->r_dir, S * 24) || ensure_buf(&a->r_prim, S * 4) ||
+        ensure_buf(&a->r_t, S * 8) || ensure_buf(&a->r_u, S * 8) || ensure_buf(&a->r_v, S * 8) ||
+        ensure_buf(&a->r_slot, S * 4) || ensure_buf(&a->r_blocks, (size_t)nb * 4)) return -1;
+    /* lh_accel_trace_statistics: the counting instantiations of the same kernels, accumulated over the batch */
+    unsigned long long *cnt = (a->stat_on && a->hs->bvh.ntris) ? a->d_counters : NULL;
+    if (cnt) HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * LH_CNT_DEV, s));
+    /* LH_STAGE_TIMING=1: HIP events between the stages of the batch, printed to stderr (tools/rank_breakdown.py) */
+    const bool stage_timing = getenv("LH_STAGE_TIMING") != NULL;
+    hipEvent_t ev[6] = {NULL, NULL, NULL, NULL, NULL, NULL};
+    if (stage_timing) { for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&ev[k])); HIPCHK(hipEventRecord(ev[0], s)); }
+    /* 1. camera rays */
+    if (lh_render_launch_primary_region(cam, x0, w, nbands, band_rows, d_band_y0, y0, cam->height, ps, ps,
+                                        (double *)a->r_org.p, (double *)a->r_dir.p, s) != 0)
+        return fail("primary ray kernel launch failed");
+    if (stage_timing) HIPCHK(hipEventRecord(ev[1], s));
+    /* 2. closest hit */
+    if (lh_launch(a, S, a->r_org.p, a->r_dir.p, a->r_prim.p, a->r_t.p, a->r_u.p, a->r_v.p, NULL, LH_MODE_CLOSEST,
+               LH_VARIANT_DEFAULT, cnt, s, false) != 0) return -1;
+    if (stage_timing) HIPCHK(hipEventRecord(ev[2], s));
+    /* 3. count hits (deterministic compaction needs the total before sizing the AO batch) */
+    unsigned long long nhit = 0;
+    if (a->hs->bvh.ntris) {
+        if (ensure_buf(&a->r_hitrec, S * 96) || ensure_buf(&a->r_key, S * 8)) return -1;   /* worst case: every sample hits */
+        if (lh_render_launch_compact(&a->dev, (const double *)a->d_nrm9, S, (const double *)a->r_org.p,
+                                     (const double *)a->r_dir.p, (const uint32_t *)a->r_prim.p, (const double *)a->r_t.p,
+                                     (const double *)a->r_u.p, (const double *)a->r_v.p, (uint32_t *)a->r_blocks.p,
+                                     (uint32_t *)a->r_slot.p, (double *)a->r_hitrec.p, (unsigned long long *)a->r_key.p,
+                                     x0, w, nbands, band_rows, d_band_y0, y0, ps * ps, cam->width, a->d_total, s) != 0)
+            return fail("compaction kernels failed: %s", hipGetErrorString(hipGetLastError()));
+        HIPCHK(hipMemcpyAsync(&nhit, a->d_total, sizeof(nhit), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    } else {
+        HIPCHK(hipMemsetAsync(a->r_slot.p, 0xFF, S * 4, s));
+    }
+    const size_t nao = (size_t)nhit * N;
+    unsigned long long nocc = 0;
+    if (stage_timing) HIPCHK(hipEventRecord(ev[3], s));
+    /* AO stage.  Fused (default): the any-hit kernel generates ray (slot, r) in its refill (lh_ao.h) and counts
+     * the occluded rays per slot -- nothing per AO ray goes through HBM.  Materialised: caller uniforms (the parity
+     * replay), LH_AO_FUSED=0, a scene the lean walk cannot take, or a pending-queue overflow of the fused launch. */
+    bool fused = a->ao_fused && !d_uniforms && nao && nao < ((size_t)1 << 32) &&
+                 ((3 * a->dev.q4_depth + 5 <= 64 && !a->dev.stack_cap) || a->dev.ref_nodes != NULL);     /* deeper: rays whose stack would overflow go to the reference walk */
+    const bool fused_tried = fused;
+    if (fused) {
+        if (ensure_buf(&a->r_occcount, (size_t)nhit * sizeof(unsigned int))) return -1;
+        const int k = lh_aoq_slot(a, s);
+        if (k < 0) return -1;
+        if (lh_launch_trace_ao(&a->dev, (size_t)nhit, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const unsigned long long *)a->r_key.p,
+                               (unsigned int *)a->r_occcount.p, cnt, a->d_cursor + (a->cursor_next++ % LH_NCURSOR), a->grid_blocks,
+                               a->min_active, a->tri_batch, a->aoq[k].queue, a->aoq[k].qcount, LH_AO_QCAP, (void *)s) != 0)
+            return fail("fused AO launch failed: %s", hipGetErrorString(hipGetLastError()));
+        uint32_t qc[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(qc, a->aoq[k].qcount, sizeof(qc), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (qc[1] != 0) fused = false;             /* more than LH_AO_QCAP uncertain AO rays: redo the stage materialised */
+    }
+    if (nao && !fused) {
+        if (ensure_buf(&a->r_aorg, nao * 24) || ensure_buf(&a->r_adir, nao * 24) || ensure_buf(&a->r_occ, nao)) return -1;
+        /* 4. AO rays */
+        if (lh_render_launch_ao_rays(nhit, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const double *)d_uniforms,
+                                     (const unsigned long long *)a->r_key.p, (double *)a->r_aorg.p, (double *)a->r_adir.p, s) != 0)
+            return fail("AO ray kernel launch failed");
+        /* 5. any-hit */
+        if (cnt && fused_tried) HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * LH_CNT_DEV, s));   /* the abandoned fused pass is not counted (nor are the camera rays then) */
+        if (lh_launch(a, nao, a->r_aorg.p, a->r_adir.p, NULL, NULL, NULL, NULL, a->r_occ.p, LH_MODE_ANY,
+                   LH_VARIANT_DEFAULT, cnt, s, false) != 0) return -1;
+    }
+    if (stage_timing) HIPCHK(hipEventRecord(ev[4], s));
+    /* 6. radiance */
+    HIPCHK(hipMemsetAsync(a->d_total, 0, sizeof(unsigned long long), s));
+    if (lh_render_launch_resolve(w, h, band_rows, ps, ps, N, (const uint32_t *)a->r_slot.p, (const uint8_t *)a->r_occ.p,
+                                 fused ? (const unsigned int *)a->r_occcount.p : NULL, (float *)d_rgb, a->d_total, s) != 0)
+        return fail("resolve kernel launch failed");
+    HIPCHK(hipMemcpyAsync(&nocc, a->d_total, sizeof(nocc), hipMemcpyDeviceToHost, s));
+    if (stage_timing) HIPCHK(hipEventRecord(ev[5], s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (stage_timing) {
+        float ms[5] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < 5; k++) (void)hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]);
+        fprintf(stderr, "[lucille_hip] AO batch stages (ms): primary %.3f closest %.3f compact %.3f ao %.3f resolve %.3f | samples %zu hits %llu ao rays %zu\n",
+                ms[0], ms[1], ms[2], ms[3], ms[4], S, nhit, nao);
+        for (int k = 0; k < 6; k++) (void)hipEventDestroy(ev[k]);
+    }
+    a->r_nsamples = S; a->r_nslots = (size_t)nhit; a->r_nao = fused ? 0 : nao;
+    if (cnt) {
+        unsigned long long hc[LH_CNT_DEV];
+        HIPCHK(hipMemcpy(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost));
+        a->stat[0] += hc[LH_CNT_NODES]; a->stat[1] += hc[LH_CNT_TRIS]; a->stat[2] += hc[LH_CNT_EXACT];
+        a->stat[3] += hc[LH_CNT_RAYS]; a->stat[4] += nhit + nocc;
+        if (getenv("LH_DEBUG_COUNTERS")) {
+            fprintf(stderr, "[lucille_hip] AO batch: rays by node visits (bucket b: [2^(b-1), 2^b)):");
+            for (int b = 0; b < 24; b++) fprintf(stderr, " %llu", hc[LH_CNT_HIST + b]);
+            fprintf(stderr, "\n");
+        }
+    }
+    if (stats) {
+        stats->primary_rays = valid_pixels * (uint64_t)(ps * ps); stats->primary_hits = nhit; stats->ao_rays = nao; stats->ao_occluded = nocc;
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int lh_render_ao_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int ps,
+                                 int gather_nsamples, uint64_t seed, const void *d_uniforms, void *d_rgb,
+                                 lh_tile_stats_t *stats, void *stream)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_render_ao_tile: accel not committed");
+    if (!cam || !d_rgb) return fail("lh_render_ao_tile: NULL argument");
+    if (w <= 0 || h <= 0 || ps < 1 || gather_nsamples < 1) return fail("lh_render_ao_tile: bad tile/sample counts");
+    return ao_region(a, cam, x0, w, 1, h, NULL, y0, (uint64_t)w * h, ps, gather_nsamples, seed, d_uniforms, d_rgb, stats, stream);
+}
+
+/* nbands full-width bands of band_rows lines (band b = frame lines band_y0[b] ...; a band that runs past the frame is
+ * clipped) as ONE device batch: how a rank renders all of its interleaved shards of a frame with one set of launches.
+ * d_rgb: float[nbands][band_rows][width][3], every band in image orientation (top line first) like a tile. */
+extern "C" int lh_render_ao_bands(lh_accel_t *a, const lh_camera_t *cam, int nbands, const int *band_y0, int band_rows, int ps,
+                                  int gather_nsamples, uint64_t seed, void *d_rgb, lh_tile_stats_t *stats, void *stream)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_render_ao_bands: accel not committed");
+    if (!cam || !d_rgb || (nbands > 0 && !band_y0)) return fail("lh_render_ao_bands: NULL argument");
+    if (nbands < 0 || band_rows <= 0 || ps < 1 || gather_nsamples < 1) return fail("lh_render_ao_bands: bad band/sample counts");
+    if (nbands == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return 0; }
+    HIPCHK(hipSetDevice(a->device));
+    uint64_t valid = 0;
+    for (int b = 0; b < nbands; b++) {
+        if (band_y0[b] < 0 || band_y0[b] >= cam->height) return fail("lh_render_ao_bands: band %d starts at line %d outside the frame", b, band_y0[b]);
+        const int rows = (band_y0[b] + band_rows <= cam->height) ? band_rows : cam->height - band_y0[b];
+        valid += (uint64_t)rows * cam->width;
+    }
+    if (ensure_buf(&a->r_bands, sizeof(int) * (size_t)nbands)) return -1;
+    HIPCHK(hipMemcpyAsync(a->r_bands.p, band_y0, sizeof(int) * (size_t)nbands, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));          /* band_y0 is the caller's memory */
+    return ao_region(a, cam, 0, cam->width, nbands, band_rows, (const int *)a->r_bands.p, 0, valid, ps, gather_nsamples, seed, NULL,
+                     d_rgb, stats, stream);
+}
+
+/* the same tile for a plain-C host program: uniforms (optional) come from and the tile goes to HOST memory */
+extern "C" int lh_render_ao_tile_host(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int ps,
+                                      int gather_nsamples, uint64_t seed, const double *uniforms, size_t nuniforms,
+                                      float *rgb, lh_tile_stats_t *stats)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_render_ao_tile_host: accel not committed");
+    if (!cam || !rgb) return fail("lh_render_ao_tile_host: NULL argument");
+    if (w <= 0 || h <= 0) return fail("lh_render_ao_tile_host: bad tile");
+    HIPCHK(hipSetDevice(a->device));
+    const size_t fb = (size_t)w * h * 3 * sizeof(float);
+    if (ensure_buf(&a->r_frame, fb)) return -1;
+    void *d_uni = NULL;
+    if (uniforms) {
+        const int nphi = (int)sqrt((double)gather_nsamples);
+        const size_t need = (size_t)2 * nphi * nphi * w * h * ps * ps;       /* worst case: every sample hits */
+        if (nuniforms < need) return fail("lh_render_ao_tile_host: %zu uniforms given, the tile may consume %zu", nuniforms, need);
+        if (ensure_buf(&a->r_uni, need * sizeof(double))) return -1;
+        HIPCHK(hipMemcpyAsync(a->r_uni.p, uniforms, need * sizeof(double), hipMemcpyHostToDevice, a->stream));
+        d_uni = a->r_uni.p;
+    }
+    if (lh_render_ao_tile(a, cam, x0, y0, w, h, ps, gather_nsamples, seed, d_uni, a->r_frame.p, stats, a->stream) != 0) return -1;
+    HIPCHK(hipMemcpyAsync(rgb, a->r_frame.p, fb, hipMemcpyDeviceToHost, a->stream));
+    HIPCHK(hipStreamSynchronize(a->stream));
+    return 0;
+}
+
+extern "C" int lh_render_scratch(lh_accel_t *a, int which, void **d_ptr, size_t *count)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed || !d_ptr || !count) return fail("lh_render_scratch: bad argument");
+    lh_buf *b[] = {&a->r_org, &a->r_dir, &a->r_prim, &a->r_t, &a->r_u, &a->r_v, &a->r_slot, &a->r_hitrec,
+                   &a->r_aorg, &a->r_adir, &a->r_occ};
+    if (which < 0 || which > 10) return fail("lh_render_scratch: unknown buffer %d", which);
+    *d_ptr = b[which]->p;
+    *count = which <= 6 ? a->r_nsamples : (which == 7 ? a->r_nslots : a->r_nao);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* hit epilogue for a batch (ri_intersection_state_build)                   */
+/* ------------------------------------------------------------------------ */
+extern "C" int lh_render_launch_state_build(size_t n, const lh_dev_scene_t *sc, const double *d_nrm9, const double *d_col9,
+                                            const double *d_tan9, const double *d_bin9, const double *d_st6, const uint8_t *d_inside,
+                                            const double *d_org, const double *d_dir, const uint32_t *d_prim, const double *d_t,
+                                            const double *d_u, const double *d_v, double *d_state, void *stream);
+
+extern "C" int lh_accel_state_build_device(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, const void *d_prim,
+                                           const void *d_t, const void *d_u, const void *d_v, void *d_state, void *stream)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_accel_state_build_device: accel not committed");
+    if (n == 0 || a->hs->bvh.ntris == 0) return 0;
+    if (!d_org || !d_dir || !d_prim || !d_t || !d_u || !d_v || !d_state) return fail("lh_accel_state_build_device: NULL argument");
+    HIPCHK(hipSetDevice(a->device));
+    if (lh_render_launch_state_build(n, &a->dev, (const double *)a->d_nrm9, (const double *)a->d_attr9[0], (const double *)a->d_attr9[1],
+                                     (const double *)a->d_attr9[2], (const double *)a->d_st6, (const uint8_t *)a->d_inside,
+                                     (const double *)d_org, (const double *)d_dir, (const uint32_t *)d_prim, (const double *)d_t,
+                                     (const double *)d_u, (const double *)d_v, (double *)d_state, stream) != 0)
+        return fail("state-build kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+extern "C" int lh_accel_state_build_host(lh_accel_t *a, size_t n, const double *org, const double *dir, const uint32_t *prim,
+                                         const double *t, const double *u, const double *v, double *state)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_accel_state_build_host: accel not committed");
+    if (n == 0) return 0;
+    if (!org || !dir || !prim || !t || !u || !v || !state) return fail("lh_accel_state_build_host: NULL argument");
+    HIPCHK(hipSetDevice(a->device));
+    const size_t b_ray = sizeof(double) * 3 * n, b_d = sizeof(double) * n, b_state = sizeof(double) * LH_STATE_DOUBLES * n;
+    if (ensure_buf(&a->r_state, 2 * b_ray + 3 * b_d + sizeof(uint32_t) * n + 8 + b_state)) return -1;
+    char *base = (char *)a->r_state.p;
+    double *d_state = (double *)base, *d_org = (double *)(base + b_state), *d_dir = d_org + 3 * n, *d_t = d_dir + 3 * n, *d_u = d_t + n, *d_v = d_u + n;
+    uint32_t *d_prim = (uint32_t *)(d_v + n);
+    HIPCHK(hipMemcpyAsync(d_org, org, b_ray, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_dir, dir, b_ray, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_t, t, b_d, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_u, u, b_d, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_v, v, b_d, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_prim, prim, sizeof(uint32_t) * n, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemsetAsync(d_state, 0, b_state, a->stream));
+    if (lh_accel_state_build_device(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_state, a->stream) != 0) return -1;
+    HIPCHK(hipMemcpyAsync(state, d_state, b_state, hipMemcpyDeviceToHost, a->stream));
+    HIPCHK(hipStreamSynchronize(a->stream));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* materials / environment of the path tracer                               */
+/* ------------------------------------------------------------------------ */
+extern "C" int lh_accel_set_material(lh_accel_t *a, uint32_t mesh, const lh_material_t *mat)
+{
+    lh_guard guard(a);
+    if (!a || !mat) return fail("lh_accel_set_material: NULL argument");
+    const uint32_t nm = a->committed ? a->hs->nmeshes : a->nmeshes;
+    if (mesh != LH_ALL_MESHES && mesh >= nm) return fail("lh_accel_set_material: mesh %u out of range", mesh);
+    for (int k = 0; k < 3; k++) {
+        if (!(mat->kd[k] >= 0.0f && mat->ks[k] >= 0.0f && mat->kt[k] >= 0.0f)) return fail("lh_accel_set_material: negative or NaN reflectance");
+    }
+    const double sum = (mat->kd[0] + mat->kd[1] + mat->kd[2] + mat->ks[0] + mat->ks[1] + mat->ks[2] + mat->kt[0] + mat->kt[1] + mat->kt[2]) / 3.0;
+    if (sum > 1.0 + 1e-6) return fail("lh_accel_set_material: kd + ks + kt averages exceed 1 (pathtrace.c:419 asserts d + s + t <= 1)");
+    if (!(mat->ior > 0.0f)) return fail("lh_accel_set_material: ior must be positive");
+    if (a->nmaterials < nm) {
+        lh_material_t *nmats = (lh_material_t *)realloc(a->materials, sizeof(lh_material_t) * (nm ? nm : 1));
+        if (!nmats) return fail("out of memory");
+        for (uint32_t k = a->nmaterials; k < nm; k++) {        /* ri_material_new (material.c:20-40): kd 1, ks 0, kt 0, ior 1 */
+            memset(&nmats[k], 0, sizeof(lh_material_t));
+            nmats[k].kd[0] = nmats[k].kd[1] = nmats[k].kd[2] = 1.0f; nmats[k].ior = 1.0f;
+        }
+        a->materials = nmats; a->nmaterials = nm;
+    }
+    for (uint32_t k = 0; k < a->nmaterials; k++) if (mesh == LH_ALL_MESHES || mesh == k) a->materials[k] = *mat;
+    a->materials_dirty = 1;
+    return 0;
+}
+
+extern "C" int lh_accel_set_environment(lh_accel_t *a, const lh_environment_t *env)
+{
+    lh_guard guard(a);
+    if (!a || !env) return fail("lh_accel_set_environment: NULL argument");
+    if (!a->committed) return fail("lh_accel_set_environment: accel not committed");
+    if (env->map_rgba && (env->width < 1 || env->height < 1)) return fail("lh_accel_set_environment: bad map size");
+    HIPCHK(hipSetDevice(a->device));
+    if (a->d_env_map) { (void)hipFree(a->d_env_map); a->d_env_map = NULL; }
+    a->env = *env; a->env.map_rgba = NULL;
+    if (env->map_rgba) {
+        const size_t b = sizeof(float) * 4 * (size_t)env->width * env->height;
+        HIPCHK(hipMalloc(&a->d_env_map, b));
+        HIPCHK(hipMemcpy(a->d_env_map, env->map_rgba, b, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+static int sync_materials(lh_accel_t *a)
+{
+    const uint32_t nm = a->hs->nmeshes ? a->hs->nmeshes : 1;
+    if (a->nmaterials < nm) {
+        lh_material_t def; memset(&def, 0, sizeof(def)); def.kd[0] = def.kd[1] = def.kd[2] = 1.0f; def.ior = 1.0f;
+        lh_material_t *nmats = (lh_material_t *)realloc(a->materials, sizeof(lh_material_t) * nm);
+        if (!nmats) return fail("out of memory");
+        for (uint32_t k = a->nmaterials; k < nm; k++) nmats[k] = def;
+        a->materials = nmats; a->nmaterials = nm; a->materials_dirty = 1;
+    }
+    if (a->materials_dirty || !a->d_materials) {
+        if (a->d_materials) { (void)hipFree(a->d_materials); a->d_materials = NULL; }
+        HIPCHK(hipMalloc(&a->d_materials, sizeof(lh_material_t) * a->nmaterials));
+        HIPCHK(hipMemcpy(a->d_materials, a->materials, sizeof(lh_material_t) * a->nmaterials, hipMemcpyHostToDevice));
+        a->materials_dirty = 0;
+    }
+    if (!a->d_prim_mesh && a->hs->bvh.ntris) {
+        HIPCHK(hipMalloc(&a->d_prim_mesh, sizeof(uint32_t) * (size_t)a->hs->bvh.ntris));
+        HIPCHK(hipMemcpy(a->d_prim_mesh, a->hs->bvh.prim_geom, sizeof(uint32_t) * (size_t)a->hs->bvh.ntris, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* wavefront path tracer                                                    */
+/* ------------------------------------------------------------------------ */
+extern "C" int lh_pt_launch_primary(const lh_camera_t *cam, int x0, int y0, int w, int h, int spp, int s0,
+                                    unsigned long long seed, double *d_org, double *d_dir, uint32_t *d_path_of,
+                                    float *d_thr, void *stream);
+extern "C" int lh_pt_launch_shade(size_t n, const lh_dev_scene_t *sc, const double *d_nrm9, const double *d_col9,
+                                  const uint32_t *d_prim_mesh, const void *d_materials, const lh_material_t *override_mat,
+                                  const float env_rgb[3], const void *d_env_map, int env_w, int env_h, int ref_weights,
+                                  int depth, int max_depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w,
+                                  int full_width, double *d_org, double *d_dir, const uint32_t *d_prim,
+                                  const double *d_t, const double *d_u, const double *d_v, uint32_t *d_path_of,
+                                  float *d_thr, float *d_radiance, uint8_t *d_alive, uint32_t *d_blocks,
+                                  unsigned long long *d_total, double *d_org2, double *d_dir2, uint32_t *d_path_of2,
+                                  float *d_thr2, void *stream);
+extern "C" int lh_pt_launch_resolve(int w, int h, int spp, float inv_total_spp, const float *d_radiance, float *d_rgb, void *stream);
+
+static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int s0, int spp, int spp_total, int max_vertices,
+                   const lh_material_t *override_mat, const float env_rgb[3], const void *d_env_map, int env_w, int env_h, int flags,
+                   uint64_t seed, void *d_rgb, lh_pt_stats_t *stats, void *stream)
+{
+    if (w <= 0 || h <= 0 || spp < 1 || spp_total < spp || max_vertices < 2) return fail("lh_render_pt_tile: bad arguments");
+    HIPCHK(hipSetDevice(a->device));
+    if (sync_materials(a) != 0) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t S = (size_t)w * h * spp;
+    if (S >= ((size_t)1 << 31)) return fail("lh_render_pt_tile: more than 2^31 paths in one pass; lower spp_count or the tile size");
+    unsigned long long *cnt = (a->stat_on && a->hs->bvh.ntris) ? a->d_counters : NULL;      /* lh_accel_trace_statistics */
+    if (cnt) HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * LH_CNT_DEV, s));
+    const unsigned nb = (unsigned)((S + 255) / 256);
+    if (ensure_buf(&a->r_org, S * 24) || ensure_buf(&a->r_dir, S * 24) || ensure_buf(&a->p_org2, S * 24) ||
+        ensure_buf(&a->p_dir2, S * 24) || ensure_buf(&a->r_prim, S * 4) || ensure_buf(&a->r_t, S * 8) ||
+        ensure_buf(&a->r_u, S * 8) || ensure_buf(&a->r_v, S * 8) || ensure_buf(&a->p_path, S * 4) ||
+        ensure_buf(&a->p_path2, S * 4) || ensure_buf(&a->p_thr, S * 12) || ensure_buf(&a->p_thr2, S * 12) ||
+        ensure_buf(&a->p_rad, S * 12) || ensure_buf(&a->p_alive, S) || ensure_buf(&a->r_blocks, ((size_t)nb + nb / 1024 + 4) * 4)) return -1;
+    HIPCHK(hipMemsetAsync(a->p_rad.p, 0, S * 12, s));
+    double *org = (double *)a->r_org.p, *dir = (double *)a->r_dir.p, *org2 = (double *)a->p_org2.p, *dir2 = (double *)a->p_dir2.p;
+    uint32_t *path = (uint32_t *)a->p_path.p, *path2 = (uint32_t *)a->p_path2.p;
+    float *thr = (float *)a->p_thr.p, *thr2 = (float *)a->p_thr2.p;
+    if (lh_pt_launch_primary(cam, x0, y0, w, h, spp, s0, seed, org, dir, path, thr, s) != 0) return fail("pt primary launch failed");
+    size_t n = S; uint64_t rays = 0; int depth = 0;
+    while (n > 0) {
+        if (lh_launch(a, n, org, dir, a->r_prim.p, a->r_t.p, a->r_u.p, a->r_v.p, NULL, LH_MODE_CLOSEST, LH_VARIANT_DEFAULT, cnt, s, false) != 0) return -1;
+        rays += n;
+        if (lh_pt_launch_shade(n, &a->dev, (const double *)a->d_nrm9, (const double *)a->d_attr9[0], (const uint32_t *)a->d_prim_mesh,
+                               a->d_materials, override_mat, env_rgb, d_env_map, env_w, env_h, (flags & LH_PT_REFERENCE_WEIGHTS) != 0,
+                               depth, max_vertices, seed, s0, spp, x0, y0, w, cam->width, org, dir, (const uint32_t *)a->r_prim.p,
+                               (const double *)a->r_t.p, (const double *)a->r_u.p, (const double *)a->r_v.p, path, thr, (float *)a->p_rad.p,
+                               (uint8_t *)a->p_alive.p, (uint32_t *)a->r_blocks.p, a->d_total, org2, dir2, path2, thr2, s) != 0)
+            return fail("pt shade launch failed: %s", hipGetErrorString(hipGetLastError()));
+        unsigned long long alive = 0;
+        HIPCHK(hipMemcpyAsync(&alive, a->d_total, sizeof(alive), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        n = (size_t)alive; depth++;
+        { double *t1 = org; org = org2; org2 = t1; t1 = dir; dir = dir2; dir2 = t1; }
+        { uint32_t *t2 = path; path = path2; path2 = t2; float *t3 = thr; thr = thr2; thr2 = t3; }
+    }
+    if (lh_pt_launch_resolve(w, h, spp, 1.0f / (float)spp_total, (const float *)a->p_rad.p, (float *)d_rgb, s) != 0)
+        return fail("pt resolve launch failed");
+    HIPCHK(hipStreamSynchronize(s));
+    if (cnt) {
+        unsigned long long hc[LH_CNT_N];
+        HIPCHK(hipMemcpy(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost));
+        a->stat[0] += hc[LH_CNT_NODES]; a->stat[1] += hc[LH_CNT_TRIS]; a->stat[2] += hc[LH_CNT_EXACT]; a->stat[3] += hc[LH_CNT_RAYS];
+    }
+    if (stats) { stats->paths = S; stats->rays = rays; stats->max_depth_reached = (uint64_t)depth; }
+    return 0;
+}
+
+/* round-1 entry point: one diffuse reflectance for every mesh, constant environment */
+extern "C" int lh_render_pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int s0, int spp,
+                                 int spp_total, int max_vertices, float kd, const float env[3], uint64_t seed,
+                                 void *d_rgb, lh_pt_stats_t *stats, void *stream)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_render_pt_tile: accel not committed");
+    if (!cam || !d_rgb || !env) return fail("lh_render_pt_tile: NULL argument");
+    if (!(kd > 0.0f) || kd > 1.0f) return fail("lh_render_pt_tile: bad arguments");
+    lh_material_t m; memset(&m, 0, sizeof(m)); m.kd[0] = m.kd[1] = m.kd[2] = kd; m.ior = 1.0f;
+    return pt_tile(a, cam, x0, y0, w, h, s0, spp, spp_total, max_vertices, &m, env, NULL, 0, 0, 0, seed, d_rgb, stats, stream);
+}
+
+/* per-mesh materials (lh_accel_set_material) and the accelerator's environment (lh_accel_set_environment) */
+extern "C" int lh_render_pt_tile2(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int s0, int spp,
+                                  int spp_total, int max_vertices, int flags, uint64_t seed, void *d_rgb, lh_pt_stats_t *stats, void *stream)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_render_pt_tile2: accel not committed");
+    if (!cam || !d_rgb) return fail("lh_render_pt_tile2: NULL argument");
+    float one[3] = {1.0f, 1.0f, 1.0f};
+    const float *rgb = (a->env.rgb[0] != 0.0f || a->env.rgb[1] != 0.0f || a->env.rgb[2] != 0.0f || a->d_env_map) ? a->env.rgb : one;
+    return pt_tile(a, cam, x0, y0, w, h, s0, spp, spp_total, max_vertices, NULL, rgb, a->d_env_map, a->env.width, a->env.height, flags,
+                   seed, d_rgb, stats, stream);
+}
+
+/* ------------------------------------------------------------------------ */
+/* whole frame into host memory (render_frame_controller + bucket_write)     */
+/* ------------------------------------------------------------------------ */
+
+extern "C" int lh_render_ao_frame_host(lh_accel_t *a, const lh_camera_t *cam, int ps, int gather_nsamples,
+                                       uint64_t seed, int tile, float *rgb, lh_tile_stats_t *stats)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_render_ao_frame_host: accel not committed");
+    if (!cam || !rgb) return fail("lh_render_ao_frame_host: NULL argument");
+    if (cam->width <= 0 || cam->height <= 0) return fail("lh_render_ao_frame_host: bad resolution");
+    if (tile <= 0) {
+        /* default tile: the largest power of two (<= 4096) whose scratch stays under ~6 GB.  Per sub-sample: ~200 B of ray /
+         * hit / epilogue records, plus 49 B per AO ray when the AO stage has to materialise its rays (LH_AO_FUSED=0):
+         * ambient_occlusion.rib's own 3 x 3 pixel samples x 64 AO rays would otherwise ask for 30 GB per 1024^2 tile */
+        const int N = gather_nsamples > 0 ? gather_nsamples : 1;
+        const double per_pixel = (double)(ps > 0 ? ps : 1) * (ps > 0 ? ps : 1) * (200.0 + (a->ao_fused ? 0.0 : 49.0 * N));
+        tile = 4096;
+        while (tile > 64 && (double)tile * tile * per_pixel > 6.0e9) tile /= 2;
+    }
+    HIPCHK(hipSetDevice(a->device));
+    const int W = cam->width, H = cam->height;
+    if (ensure_buf(&a->r_frame, (size_t)tile * tile * 3 * sizeof(float))) return -1;
+    std::vector<float> host((size_t)tile * tile * 3);
+    lh_tile_stats_t tot = {0, 0, 0, 0};
+    for (int y0 = 0; y0 < H; y0 += tile)
+        for (int x0 = 0; x0 < W; x0 += tile) {
+            const int w = (x0 + tile <= W) ? tile : W - x0, h = (y0 + tile <= H) ? tile : H - y0;
+            lh_tile_stats_t st;
+            if (lh_render_ao_tile(a, cam, x0, y0, w, h, ps, gather_nsamples, seed, NULL, a->r_frame.p, &st, a->stream) != 0) return -1;
+            HIPCHK(hipMemcpyAsync(host.data(), a->r_frame.p, (size_t)w * h * 3 * sizeof(float), hipMemcpyDeviceToHost, a->stream));
+            HIPCHK(hipStreamSynchronize(a->stream));
+            /* the tile comes back with its rows already flipped (row 0 = pixel row y0+h-1) */
+            for (int r = 0; r < h; r++)
+                memcpy(rgb + ((size_t)(H - (y0 + h) + r) * W + x0) * 3, host.data() + (size_t)r * w * 3, (size_t)w * 3 * sizeof(float));
+            tot.primary_rays += st.primary_rays; tot.primary_hits += st.primary_hits;
+            tot.ao_rays += st.ao_rays; tot.ao_occluded += st.ao_occluded;
+        }
+    if (stats) *stats = tot;
+    return 0;
+}

@@ -1,7 +1,6 @@
 /*
- * lh_walk.h -- device-side pieces shared by the traversal kernels (lh_kernels.hip: the r01 walks kept
- * for A/B; lh_trace2.hip: the lean walk + resolve pass): the exact-hit record, the reference's tie
- * rule, the fp64 resolve of one candidate, the per-lane walk state and the 16-bit-grid slab test.
+ * lh_walk.h -- device-side pieces of the traversal kernels (lh_kernels.hip): the exact-hit record, the
+ * reference's tie rule, the fp64 resolve of one candidate, the per-lane walk state and the 16-bit-grid slab test.
  * Device code only (included inside the including file's anonymous namespace).
  */
 #ifndef LH_WALK_H
@@ -75,7 +74,7 @@ __device__ __forceinline__ void lane_init(Lane &L, const lh_dev_scene_t &sc,
                                           double dx, double dy, double dz)
 {
     lh_ray_setup(&L.r, ox, oy, oz, dx, dy, dz, sc.scene_r);
-    if (sc.use_qnodes) lh_ray_setup_grid(&L.r, sc.grid_lo, sc.grid_step, sc.scene_r);
+    lh_ray_setup_grid(&L.r, sc.grid_lo, sc.grid_step, sc.scene_r);
     L.sh[0] = L.r.ngx ? 16u : 0u; L.sh[1] = L.r.ngy ? 16u : 0u; L.sh[2] = L.r.ngz ? 16u : 0u;
     L.tb = 1.0e38f;
     L.cur = 0; L.sp = 1;

@@ -64,29 +64,9 @@ static void trace_one(job_t *j, size_t i)
         uint32_t pend[PEND];
         for (k = 0; k < 3; k++) { scene_r = fmaxf(scene_r, fabsf(b->bmin[k])); scene_r = fmaxf(scene_r, fabsf(b->bmax[k])); }
         lh_ray_setup(&r, o[0], o[1], o[2], d[0], d[1], d[2], scene_r);
-        if (j->qnodes) lh_ray_setup_grid(&r, b->grid_lo, b->grid_step, scene_r);
+        lh_ray_setup_grid(&r, b->grid_lo, b->grid_step, scene_r);
         stack[0] = DONE;
         while (cur != DONE) {
-            while (cur >= 0 && j->qnodes == 3) {      /* 8-wide compressed nodes, octant order */
-                const lh_c8node_t *n = &b->c8nodes[cur]; lh_c8frame_t f; int pr, pushed = 0;
-                const int oct = r.ngx | (r.ngy << 1) | (r.ngz << 2);
-                j->c[0]++;
-                lh_c8_frame(&r, n->p[0], n->p[1], n->p[2], n->e[0], n->e[1], n->e[2], &f);
-                for (pr = 7; pr >= 0; pr--) {              /* far to near: the nearest ends on top */
-                    const int s = pr ^ oct; float tn; int hit; int32_t ref;
-                    const int inner = (n->imask >> s) & 1;
-                    if (!inner && n->meta[s] == 0) continue;
-                    hit = lh_slab_c8(&f, r.ngx ? n->qhi[0][s] : n->qlo[0][s], r.ngy ? n->qhi[1][s] : n->qlo[1][s],
-                                     r.ngz ? n->qhi[2][s] : n->qlo[2][s], r.ngx ? n->qlo[0][s] : n->qhi[0][s],
-                                     r.ngy ? n->qlo[1][s] : n->qhi[1][s], r.ngz ? n->qlo[2][s] : n->qhi[2][s], tb, &tn);
-                    if (!hit) continue;
-                    if (inner) ref = (int32_t)(n->child_base + (uint32_t)__builtin_popcount(n->imask & ((1u << s) - 1u)));
-                    else ref = (int32_t)~(((n->tri_base + (n->meta[s] & 31u)) << 2) | ((n->meta[s] >> 5) & 3u));
-                    stack[sp++] = ref; pushed++;
-                }
-                cur = stack[--sp];
-                (void)pushed;
-            }
             while (cur >= 0 && j->qnodes == 4) {      /* 8-wide 16-bit grid nodes (lh_q8node_t), octant order */
                 const lh_q8node_t *n = &b->q8nodes[cur]; int pr;
                 const int oct = r.ngx | (r.ngy << 1) | (r.ngz << 2);
@@ -118,12 +98,7 @@ static void trace_one(job_t *j, size_t i)
             while (cur >= 0) {
                 float tn0, tn1; int h0, h1; int32_t r0, r1;
                 j->c[0]++;
-                if (j->qnodes) {
-                    const lh_qnode_t *n = &b->qnodes[cur];
-                    h0 = lh_slab_q(&r, n->q[0], n->q[1], n->q[2], n->q[3], n->q[4], n->q[5], tb, &tn0);
-                    h1 = lh_slab_q(&r, n->q[6], n->q[7], n->q[8], n->q[9], n->q[10], n->q[11], tb, &tn1);
-                    r0 = n->ref0; r1 = n->ref1;
-                } else {
+                {
                     const lh_node_t *n = &b->nodes[cur];
                     h0 = lh_slab(&r, n->lo0[0], n->lo0[1], n->lo0[2], n->hi0[0], n->hi0[1], n->hi0[2], tb, &tn0);
                     h1 = lh_slab(&r, n->lo1[0], n->lo1[1], n->lo1[2], n->hi1[0], n->hi1[1], n->hi1[2], tb, &tn1);
@@ -139,7 +114,7 @@ static void trace_one(job_t *j, size_t i)
             {
                 uint32_t x = ~(uint32_t)cur, first = x >> 2, cnt = (x & 3u) + 1u, q; int finished = 0;
                 for (q = 0; q < cnt; q++) {
-                    const lh_tri32_t *T = (j->qnodes == 3) ? &b->tri32_c8[first + q] : &b->tri32[first + q]; float t_hi; int cls;
+                    const lh_tri32_t *T = &b->tri32[first + q]; float t_hi; int cls;
                     j->c[1]++;
                     cls = lh_tri_filter(&r, T->v0[0], T->v0[1], T->v0[2], T->e1x, T->e1y, T->e1z,
                                         T->e2x, T->e2y, T->e2z, T->ne1, T->ne2, tb, &t_hi);
@@ -203,20 +178,18 @@ lh_bvh_t *lhm_build(uint32_t npos, const double *pos_xyz, uint32_t nidx, const u
 {
     lh_bvh_t *b = (lh_bvh_t *)calloc(1, sizeof(*b)); lh_mesh_view_t m;
     m.npositions = npos; m.positions = pos_xyz; m.stride_bytes = 24; m.nindices = nidx; m.indices = idx;
-    if (lh_bvh_build(b, &m, 1, nthreads) != 0 || lh_bvh_ensure_qnodes(b) != 0 || lh_bvh_ensure_c8(b) != 0 || lh_bvh_ensure_q8(b) != 0) { free(b); return NULL; }   /* the model checks every format */
+    if (lh_bvh_build(b, &m, 1, nthreads) != 0 || lh_bvh_ensure_q8(b) != 0) { free(b); return NULL; }   /* the model checks every format */
     return b;
 }
 void lhm_free(lh_bvh_t *b) { if (b) { lh_bvh_release(b); free(b); } }
 void lhm_info(const lh_bvh_t *b, uint32_t out[4]) { out[0] = b->ntris; out[1] = b->nnodes; out[2] = b->max_depth; out[3] = b->nleaves; }
 void lhm_info4(const lh_bvh_t *b, uint32_t out[2]) { out[0] = b->nq4nodes; out[1] = b->q4_depth; }
-void lhm_info8(const lh_bvh_t *b, uint32_t out[2]) { out[0] = b->nc8nodes; out[1] = b->c8_depth; }
 void lhm_infoq8(const lh_bvh_t *b, uint32_t out[2]) { out[0] = b->nq8nodes; out[1] = b->q8_depth; }
 const void *lhm_q8nodes(const lh_bvh_t *b) { return b->q8nodes; }
 const void *lhm_q4nodes(const lh_bvh_t *b) { return b->q4nodes; }
 double lhm_build_seconds(const lh_bvh_t *b) { return b->build_seconds; }
 const void *lhm_nodes(const lh_bvh_t *b) { return b->nodes; }
 const void *lhm_tri32(const lh_bvh_t *b) { return b->tri32; }
-const void *lhm_qnodes(const lh_bvh_t *b) { return b->qnodes; }
 void lhm_grid(const lh_bvh_t *b, float out[6]) { int k; for (k = 0; k < 3; k++) { out[k] = b->grid_lo[k]; out[3 + k] = b->grid_step[k]; } }
 
 /* reference-order tree of the same scene */

@@ -112,11 +112,6 @@ class Model:
         L.lhm_info4.argtypes = [C.c_void_p, _u32p]; L.lhm_info4(self.h, o.ctypes.data_as(_u32p))
         return int(o[0]), int(o[1])
 
-    def c8info(self):
-        L = self.lib(); o = np.zeros(2, np.uint32)
-        L.lhm_info8.argtypes = [C.c_void_p, _u32p]; L.lhm_info8(self.h, o.ctypes.data_as(_u32p))
-        return int(o[0]), int(o[1])
-
     def grid(self):
         """(grid_lo[3], grid_step[3]) of the scene's 16-bit grid, as float64"""
         L = self.lib()
@@ -142,20 +137,11 @@ class Model:
         buf = (C.c_uint16 * (32 * n)).from_address(L.lhm_q4nodes(self.h))
         return np.frombuffer(buf, np.uint16).reshape(-1, 32).copy()
 
-    def qnodes(self):
-        L = self.lib()
-        L.lhm_qnodes.restype = C.c_void_p; L.lhm_qnodes.argtypes = [C.c_void_p]
-        L.lhm_grid.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
-        grid = np.zeros(6, np.float32); L.lhm_grid(self.h, grid.ctypes.data_as(C.POINTER(C.c_float)))
-        if self.nnodes == 0:
-            return np.zeros((0, 16), np.uint16), grid
-        buf = (C.c_uint16 * (16 * self.nnodes)).from_address(L.lhm_qnodes(self.h))
-        return np.frombuffer(buf, np.uint16).reshape(-1, 16).copy(), grid
-
     def trace(self, org, dr, anyhit=False, nthreads=4, qnodes=2):
-        """qnodes: 0 fp32 2-wide nodes, 1 16-bit grid 2-wide, 2 16-bit grid 4-wide (the kernel's default), 3 8-wide compressed,
+        """qnodes: 0 fp32 2-wide nodes (the textbook variant), 2 16-bit grid 4-wide (the kernel's default),
         4 8-wide on the 16-bit grid (128-byte records: ray dumps over scenes larger than the Infinity Cache)"""
         qnodes = int(qnodes)
+        assert qnodes in (0, 2, 4)
         org = np.ascontiguousarray(org, np.float64).reshape(-1, 3)
         dr = np.ascontiguousarray(dr, np.float64).reshape(-1, 3)
         n = org.shape[0]

@@ -91,7 +91,7 @@ def test_c1_ray_dump_hit_records(c1):
     g, rec, acc = c1["g"], c1["rec"], c1["acc"]
     o_ = torch.from_numpy(rec["org"]).cuda(); d_ = torch.from_numpy(rec["dir"]).cuda()
     hit = g["prim"] != po.MISS
-    for variant in (0, 1, 2, 3, 4):
+    for variant in (0, 4):
         out = acc.intersect_device(o_, d_, variant=variant)
         torch.cuda.synchronize()
         prim = out[0].cpu().numpy().view(np.uint32)

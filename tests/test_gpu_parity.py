@@ -12,7 +12,7 @@ from tests.helpers import Model, assert_hits_equal, grid_mesh, load_golden, rand
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [la.VARIANT_DIRECT, la.VARIANT_PERSIST_WAVE, la.VARIANT_PERSIST_LANE, la.VARIANT_UNIFIED, la.VARIANT_SPEC, la.VARIANT_UNIFIED4, la.VARIANT_LEAN, la.VARIANT_QUAD]
+VARIANTS = [la.VARIANT_DIRECT, la.VARIANT_SPEC]      # the textbook reference walk, the tuned default
 
 
 def torch_rays(org, dr):
@@ -65,21 +65,21 @@ def test_oracle_parity_seeded(ntri, nrays, he, seed, variant):
     assert np.array_equal(gpu_any(acc, org, dr, variant).astype(bool), exp[0] != po.MISS)
 
 
-@pytest.mark.parametrize("fmt", ["f32", "q16", "q16x4", "c8"])
-def test_node_formats(fmt, monkeypatch):
-    """every node format the kernels can walk (LH_NODE_FORMAT is read at commit): fp32 2-wide, 16-bit grid
-    2-wide, 16-bit grid 4-wide (default), 8-wide compressed (experiment) -- same records"""
-    monkeypatch.setenv("LH_NODE_FORMAT", fmt)
+@pytest.mark.parametrize("wide8", [0, 1])
+def test_node_formats(wide8):
+    """every node format the kernels can walk -- fp32 2-wide (the textbook variant), 16-bit grid 4-wide (default),
+    16-bit grid 8-wide (ray dumps over large scenes; forced here) -- same records"""
+    fmt = "wide8=%d" % wide8
     P, idx, org, dr = po.soup(60000, 120000, 0.01, 8)
     o = po.Oracle(); o.add_mesh(P, idx); o.build()
     exp = o.intersect(org, dr, nthreads=16)
-    acc = make_accel(P, idx)
+    acc = make_accel(P, idx); acc.set_param("wide8", wide8)
     for variant in VARIANTS:
         assert_hits_equal(gpu_closest(acc, org, dr, variant), exp, "format %s variant %d" % (fmt, variant))
         assert np.array_equal(gpu_any(acc, org, dr, variant).astype(bool), exp[0] != po.MISS)
     P, idx = grid_mesh(8, 8)                      # shared vertices / edges: exact-t ties
     o = po.Oracle(); o.add_mesh(P, idx); o.build()
-    acc = make_accel(P, idx)
+    acc = make_accel(P, idx); acc.set_param("wide8", wide8)
     org, dr = random_rays(np.random.default_rng(3), 20000)
     assert_hits_equal(gpu_closest(acc, org, dr, la.VARIANT_DEFAULT), o.intersect(org, dr), "format %s grid" % fmt)
 
@@ -240,8 +240,8 @@ def test_tolerance_band_geometry():
     for z in (1e-6, 0.0, -1e-9):
         org[:, 2] = z
         exp = o.intersect(org, d, nthreads=8)
-        assert_hits_equal(gpu_closest(acc, org, d, la.VARIANT_PERSIST_LANE), exp, "surface z=%g" % z)
-        assert np.array_equal(gpu_any(acc, org, d, la.VARIANT_PERSIST_LANE).astype(bool), exp[0] != po.MISS)
+        assert_hits_equal(gpu_closest(acc, org, d, la.VARIANT_DEFAULT), exp, "surface z=%g" % z)
+        assert np.array_equal(gpu_any(acc, org, d, la.VARIANT_DEFAULT).astype(bool), exp[0] != po.MISS)
 
 
 def test_counters_match_host_model():
@@ -251,9 +251,9 @@ def test_counters_match_host_model():
     P, idx, org, dr = po.soup(30000, 20000, 0.005, 61)
     acc = make_accel(P, idx)
     o_, d_ = torch_rays(org, dr)
-    _, cnt = acc.intersect_device(o_, d_, counters=True, variant=la.VARIANT_DIRECT)     # 2-wide 16-bit grid nodes
+    _, cnt = acc.intersect_device(o_, d_, counters=True, variant=la.VARIANT_DIRECT)     # 2-wide fp32 nodes
     m = Model(P, idx)
-    _, mc = m.trace(org, dr, qnodes=1)
+    _, mc = m.trace(org, dr, qnodes=0)
     assert cnt["rays"] == mc["rays"] == 20000
     # v_rcp_f32 vs 1/x may move a handful of band decisions: counts agree to 1e-4
     for k in ("nodes", "tris"):
@@ -296,7 +296,7 @@ def test_full_size_properties_soup_1m():
     n = 200000
     o = po.Oracle(); o.add_mesh(P, idx); o.build()
     exp = o.intersect(org[:n], dr[:n], nthreads=32)
-    assert_hits_equal(tuple(x.cpu().numpy()[:n] for x in res[2]), exp, "soup-1M prefix")
+    assert_hits_equal(tuple(x.cpu().numpy()[:n] for x in res[la.VARIANT_SPEC]), exp, "soup-1M prefix")
 
 
 def test_full_size_properties_soup_10m():

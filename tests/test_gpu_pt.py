@@ -183,40 +183,3 @@ def test_mirror_and_glass_conserve_energy_and_roulette_is_unbiased(ps):
     with pytest.raises(la.LucilleHipError, match="exceed 1"):
         acc.set_material(0, la.Material.make(kd=(1, 1, 1), ks=(0.5, 0.5, 0.5)))
     acc.set_material(la.ALL_MESHES, la.Material.make())
-
-
-def test_fused_passes_equal_the_wavefront_passes(ps):
-    """set_param("pt_fused", 1): a pass runs inside the walk (ray source 2 of the trace kernel: camera ray to last vertex per lane,
-    the same lh_pt.h arithmetic keyed by pixel / sample / bounce) -- image, ray count and depth bit-equal to the wavefront passes,
-    for diffuse, glass + mirror materials with an environment map, tiled or not; statistics count the same rays"""
-    acc, cam = ps["acc"], ps["cam"]
-    g = ps["g"]; nm = int(g["ngeoms"])
-    rng = np.random.default_rng(3)
-    envmap = rng.uniform(0.0, 2.0, (16, 32, 4)).astype(np.float32)
-    cases = []
-    for label in ("diffuse", "glass"):
-        if label == "diffuse":
-            acc.set_environment((1.0, 1.0, 1.0), None); acc.set_material(la.ALL_MESHES, la.Material.make(kd=(0.8, 0.7, 0.6)))
-        else:
-            acc.set_environment((1.0, 0.9, 0.8), envmap)
-            for k in range(nm):
-                acc.set_material(k, la.Material.make(kd=(0.2, 0.2, 0.2), ks=(0.1, 0.1, 0.1), kt=(0.7, 0.7, 0.7), ior=1.5) if k == nm - 1
-                                 else la.Material.make(kd=(0.5, 0.4, 0.3), ks=(0.3, 0.3, 0.3)))
-        acc.set_param("pt_fused", 0)
-        a, sa = render2(acc, cam, 16, max_vertices=12, seed=9)
-        acc.set_param("pt_fused", 1)
-        b, sb = render2(acc, cam, 16, max_vertices=12, seed=9)
-        assert np.array_equal(a, b) and sa == sb, label
-        rgb1, _ = acc.render_pt_tile2(cam, 8, 16, 40, 24, 0, 16, 16, max_vertices=12, seed=9)
-        acc.set_param("pt_fused", 0)
-        rgb0, _ = acc.render_pt_tile2(cam, 8, 16, 40, 24, 0, 16, 16, max_vertices=12, seed=9)
-        import torch
-        assert torch.equal(rgb0, rgb1), label + " tile"
-        cases.append(sa["rays"])
-    acc.set_param("pt_fused", 1)
-    acc.trace_statistics(True); acc.statistics(clear=True)
-    _, sc = render2(acc, cam, 16, max_vertices=12, seed=9)
-    s = acc.statistics(clear=True); acc.trace_statistics(False)
-    assert s["rays"] == sc["rays"] == cases[-1] and s["nodes"] > 0
-    acc.set_param("pt_fused", 0)
-    acc.set_environment((1.0, 1.0, 1.0), None); acc.set_material(la.ALL_MESHES, la.Material.make())
