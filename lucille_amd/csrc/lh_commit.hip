@@ -62,6 +62,11 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     env = getenv("LH_RAY_CHUNK");
     if (env && atoi(env) > 0 && atoi(env) <= (1 << 20)) a->ray_chunk = (uint32_t)atoi(env);
     a->dev.ray_chunk = a->ray_chunk;
+    a->dev.ray_budget = LH_RAY_BUDGET; a->dump_budget = LH_DUMP_BUDGET;
+    env = getenv("LH_DUMP_BUDGET");
+    if (env && atoi(env) > 0) a->dump_budget = (uint32_t)atoi(env);
+    env = getenv("LH_RAY_BUDGET");
+    if (env && atoi(env) > 0) a->dev.ray_budget = (uint32_t)atoi(env);
     *out = a;
     return 0;
 }
@@ -166,7 +171,7 @@ static void release_device(lh_accel_t *a)
     if (a->d_materials) (void)hipFree(a->d_materials);
     if (a->d_env_map) (void)hipFree(a->d_env_map);
     a->d_st6 = a->d_inside = a->d_prim_mesh = a->d_materials = a->d_env_map = NULL;
-    free_buf(&a->r_state); free_buf(&a->r_uni); free_buf(&a->r_bands);
+    free_buf(&a->r_state); free_buf(&a->r_uni); free_buf(&a->r_bands); free_buf(&a->r_diag);
     a->d_total = NULL; a->d_nrm9 = NULL;
     if (a->d_nodes) (void)hipFree(a->d_nodes);
     if (a->d_tri32) (void)hipFree(a->d_tri32);
@@ -182,8 +187,12 @@ static void release_device(lh_accel_t *a)
     if (a->d_cursor) (void)hipFree(a->d_cursor);
     if (a->d_counters) (void)hipFree(a->d_counters);
     for (int k = 0; k < LH_AOQ_SLOTS; k++) {
-        if (a->aoq[k].queue) (void)hipFree(a->aoq[k].queue);
-        a->aoq[k].queue = NULL; a->aoq[k].qcount = NULL; a->aoq[k].used = 0;
+        lh_fixq_t *q = &a->aoq[k].q;
+        if (q->queue) {
+            (void)hipFree(q->queue); (void)hipFree(q->qcount);
+            (void)hipStreamDestroy((hipStream_t)q->aux_stream); (void)hipEventDestroy((hipEvent_t)q->ev_ready); (void)hipEventDestroy((hipEvent_t)q->ev_done);
+        }
+        memset(q, 0, sizeof(*q)); a->aoq[k].used = 0;
     }
     if (a->pipe.ready) {
         for (int b = 0; b < 2; b++) {
@@ -440,7 +449,7 @@ static int device_upload(lh_accel_t *a)
     HIPCHK(hipSetDevice(a->device));
     double t0 = now_s();
     HIPCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
-    HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(unsigned long long) * LH_NCURSOR));
+    HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(unsigned long long) * LH_NPART * LH_NCURSOR));
     HIPCHK(hipMalloc((void **)&a->d_counters, sizeof(unsigned long long) * LH_CNT_DEV));
     HIPCHK(hipMalloc((void **)&a->d_total, sizeof(unsigned long long) * 4));
     a->device_bytes = 0;
@@ -656,6 +665,8 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
     else if (!strcmp(name, "tri_batch") && value > 0 && value <= 64) a->tri_batch = value;
     else if (!strcmp(name, "ray_chunk") && value > 0 && value <= (1 << 20)) { a->ray_chunk = (uint32_t)value; a->dev.ray_chunk = (uint32_t)value; }
     else if (!strcmp(name, "variant") && (value == LH_VARIANT_DIRECT || value == LH_VARIANT_SPEC)) a->default_variant = value;
+    else if (!strcmp(name, "ray_budget") && value > 0) { a->dev.ray_budget = (uint32_t)value; a->dump_budget = (uint32_t)value; }
+    else if (!strcmp(name, "dump_budget") && value > 0) a->dump_budget = (uint32_t)value;
     else if (!strcmp(name, "ao_fused")) a->ao_fused = value != 0;
     else if (!strcmp(name, "fast_start")) a->fast_start = value != 0;
     else if (!strcmp(name, "wide8") && value >= -1 && value <= 1) a->wide8 = value;

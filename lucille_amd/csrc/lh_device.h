@@ -38,8 +38,10 @@ typedef struct lh_dev_scene {
     uint32_t    max_depth;
     float       scene_r;   /* max |coordinate| of the scene box              */
     uint32_t    ray_chunk; /* rays a persistent wave reserves per atomic on the global cursor */
+    uint32_t    ray_budget;/* wave iterations after which a ray leaves the persistent walk for the cooperative one */
     int         stack_guard;    /* set by the launchers when the LDS rows do not cover the tree's worst case: the walks check before they push */
     uint32_t    stack_cap; /* 0: 64 LDS stack rows at most; 8..62: a lower cap (tests of the overflow path) */
+    unsigned long long *diag_clock;   /* diagnostics (LH_STAGE_TIMING): [2][waves] start / exit wall clock of every persistent wave, or NULL */
 } lh_dev_scene_t;
 
 /* traversal statistics accumulated by the COUNT variants (u64 each) */
@@ -57,7 +59,10 @@ enum {
     LH_VARIANT_SPEC   = 4    /* the default: persistent waves, branch-free 4-wide (or 8-wide) node step, parked leaves */
 };
 
-#define LH_AO_QCAP        (1u << 20)   /* AO rays of one fused launch that may wait for the reference walk (8 B each) */
+#define LH_NPART          8            /* cursor partitions of a persistent launch: one per XCD (each with its own L2) */
+#define LH_AO_QCAP        (1u << 20)   /* rays of one launch that may wait in the fix-up queue (8 B each): fragile AO hits, rays out of visit budget */
+#define LH_DUMP_BUDGET    2048u        /* ... of ray-dump launches (incoherent rays: ages run to several times the steps) */
+#define LH_RAY_BUDGET     128u         /* default visit budget of the persistent walk (set_param "ray_budget") */
 #define LH_PRIM_OVERFLOW  0xFFFFFFFDu  /* the LDS stack column was too short for this ray: k_overflow_fix */
 #define LH_OCC_OVERFLOW   4u
 
@@ -65,17 +70,28 @@ enum {
 extern "C" {
 #endif
 
+/* the fix-up queue of the persistent launches of one stream (rays out of visit budget, fragile AO hits) and the second
+ * stream its consumer runs on, concurrently with the launch that fills it */
+typedef struct lh_fixq {
+    void     *queue;          /* qcap x u64 (device), zero = empty slot */
+    uint32_t *qcount;         /* [0] appends, [1] overflow flag, [2] producer waves that have left (device) */
+    uint32_t  qcap;
+    void     *aux_stream;     /* hipStream_t */
+    void     *ev_ready, *ev_done;     /* hipEvent_t: queue reset on the launch stream; consumer finished */
+} lh_fixq_t;
+
 /* launchers implemented in lh_kernels.hip; stream is a hipStream_t */
 int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double *d_org,
                     const double *d_dir, uint32_t *d_prim, double *d_t,
                     double *d_u, double *d_v, int anyhit, uint8_t *d_occluded,
                     unsigned long long *d_counters /* LH_CNT_DEV or NULL */,
-                    unsigned long long *d_workq /* persistent cursor */,
-                    int variant, int grid_blocks, int min_active, int tri_batch, void *stream);
+                    unsigned long long *d_workq /* LH_NPART persistent cursors */,
+                    int variant, int grid_blocks, int min_active, int tri_batch,
+                    const lh_fixq_t *q, int ncus, void *stream);
 int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int ntheta, int nphi, unsigned long long seed,
                        const double *d_hitrec, const unsigned long long *d_slot_key, unsigned int *d_occ_count,
                        unsigned long long *d_counters, unsigned long long *d_cursor, int grid_blocks, int min_active,
-                       int tri_batch, uint32_t *d_queue, uint32_t *d_qcount, uint32_t qcap, void *stream);
+                       int tri_batch, const lh_fixq_t *q, int ncus, void *stream);
 int lh_trace_formats_needed(const lh_dev_scene_t *sc, int variant);
 
 #ifdef __cplusplus

@@ -72,7 +72,7 @@ struct lh_accel {
     void *d_nodes, *d_tri32, *d_tri64, *d_q4nodes, *d_q8nodes;
     int ncus;                          /* compute units of the device */
     int wide8;                         /* ray dumps walk the 8-wide nodes: -1 when the hot set exceeds the Infinity Cache (default), 0 never, 1 always */
-    unsigned long long *d_cursor, *d_counters;   /* d_cursor: LH_NCURSOR slots, one per launch in flight */
+    unsigned long long *d_cursor, *d_counters;   /* d_cursor: LH_NCURSOR blocks of LH_NPART cursors, one block per launch in flight */
     unsigned cursor_next;
     pthread_mutex_t mu;                /* serialises the entry points of ONE accelerator (recursive) */
     int stat_on;                       /* lh_accel_trace_statistics */
@@ -85,8 +85,8 @@ struct lh_accel {
     uint32_t ray_chunk;                /* rays reserved per cursor atomic (LH_RAY_CHUNK) */
     int tri_batch;
     int default_variant;
-    /* fused AO stage: per-stream queue of the AO rays that wait for the reference walk (fragile hits, stack overflow) */
-    struct { hipStream_t stream; int used; uint32_t *queue; uint32_t *qcount; } aoq[LH_AOQ_SLOTS];
+    /* per-stream fix-up queues of the persistent launches (rays out of visit budget / stack rows, fragile AO hits) */
+    struct { hipStream_t stream; int used; lh_fixq_t q; } aoq[LH_AOQ_SLOTS];
     /* staging for host batches */
     void *d_stage; size_t stage_bytes;
     /* pipelined host batches: two pinned in/out staging pairs, two device pairs, two streams */
@@ -98,11 +98,13 @@ struct lh_accel {
     lh_environment_t env; void *d_env_map;
     lh_buf r_state;                    /* lh_accel_state_build_host staging */
     lh_buf r_uni;                      /* lh_render_ao_tile_host: caller uniforms on the device */
+    lh_buf r_diag;                     /* LH_STAGE_TIMING: wave start / exit clocks */
     lh_buf r_bands;                    /* lh_render_ao_bands: first line of every band */
     /* tile-render scratch (lh_render_ao_tile) */
     lh_buf r_org, r_dir, r_prim, r_t, r_u, r_v, r_slot, r_hitrec, r_aorg, r_adir, r_occ, r_blocks, r_key, r_frame, r_occcount;
     uint64_t last_retraced;            /* rays the last counted launch finished outside the main kernel */
     int ao_fused;                      /* AO rays generated inside the any-hit kernel (default); 0: materialised in HBM */
+    uint32_t dump_budget;              /* visit budget of ray-dump launches (the tile pipelines': dev.ray_budget) */
     int fast_start;                    /* device-built scenes: launch before lucille's own tree is attached (ties by primitive id until then) */
     lh_buf p_org2, p_dir2, p_path, p_path2, p_thr, p_thr2, p_rad, p_alive;   /* path tracer */
     unsigned long long *d_total;

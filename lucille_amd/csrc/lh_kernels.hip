@@ -113,7 +113,85 @@ __device__ __forceinline__ void traverse(Lane &L, const lh_dev_scene_t &sc,
  * writes its reference to the LDS stack at a rank-derived slot (hits: farthest at the bottom,
  * nearest on top; misses: above the new top, i.e. into free space) and the next reference
  * is read back from the new top -- which is the nearest hit, or the previous top when
- * nothing was hit (a pop).  Leaves are parked and tested in batches as in traverse_spec. */
+ * nothing was hit (a pop).  A lane that reaches a leaf parks it in `pend` and keeps
+ * descending from its stack; the ~75-instruction triangle path runs only when at least
+ * `tri_batch` lanes hold a parked leaf (or nobody has an inner node left), one triangle per
+ * parked lane per pass.
+ *
+ * The visit budget: `it` counts the wave's iterations (one node step and at most one triangle step per lane each); a ray
+ * that has been in its lane for more than sc.ray_budget iterations when the wave regroups (at least every 64 iterations) --
+ * a grazing ray skimming a tessellated floor: 4 of the 443 M AO rays of the config-5 frame visit more than 1024 nodes, and
+ * the leaves they park cost a triangle step each, at 1-2 us per dependent step -- is marked `over` and handed to the
+ * wave-cooperative walk (k_coop_walk below), so that the tail of a launch is bounded by
+ * budget x latency instead of by its longest ray (profiles/README.md r03: 3-6 ms per launch on a
+ * rank's share of the frame).  STRIDE: lanes per LDS stack row (LH_BLOCK, or 64 in k_coop_walk). */
+constexpr int kNoLeaf = 0;       /* never a valid leaf reference (leaf refs are negative) */
+constexpr uint32_t kRegroupMask = 63u;   /* the walk returns to the regroup point at least every 64 iterations */
+
+/* RING: stack positions are taken modulo ring_mask + 1 rows (k_coop_walk: a lane that gives entries away from the bottom of
+ * its stack drifts upwards without bound); the persistent kernel indexes rows directly */
+template <bool COUNT, int STRIDE, bool RING>
+__device__ __forceinline__ void node_step4(Lane &L, int &pend, const lh_dev_scene_t &sc, int (*stk)[STRIDE], const int tid, uint32_t &c_nodes,
+                                           const int ring_mask = 0)
+{
+#define LH_ROW(x) (RING ? ((x) & ring_mask) : (x))
+    const uint4 *p = (const uint4 *)sc.q4nodes + 4 * (size_t)L.cur;
+    const uint4 a = p[0], b = p[1], c = p[2], r = p[3];
+    if (COUNT) c_nodes++;
+    float t0, t1, t2, t3;
+    const bool h0 = slab_w(L, a.x, a.y, a.z, t0) & ((int)r.x != kDone);
+    const bool h1 = slab_w(L, a.w, b.x, b.y, t1) & ((int)r.y != kDone);
+    const bool h2 = slab_w(L, b.z, b.w, c.x, t2) & ((int)r.z != kDone);
+    const bool h3 = slab_w(L, c.y, c.z, c.w, t3) & ((int)r.w != kDone);
+    /* entry distances are >= 0, so their bit patterns order like unsigned integers */
+    const uint32_t k0 = h0 ? ((__float_as_uint(t0) & ~3u) | 0u) : 0xFFFFFFFCu;
+    const uint32_t k1 = h1 ? ((__float_as_uint(t1) & ~3u) | 1u) : 0xFFFFFFFDu;
+    const uint32_t k2 = h2 ? ((__float_as_uint(t2) & ~3u) | 2u) : 0xFFFFFFFEu;
+    const uint32_t k3 = h3 ? ((__float_as_uint(t3) & ~3u) | 3u) : 0xFFFFFFFFu;
+    const int b10 = k1 < k0, b20 = k2 < k0, b30 = k3 < k0, b21 = k2 < k1, b31 = k3 < k1, b32 = k3 < k2;
+    const int rk0 = b10 + b20 + b30, rk1 = (1 - b10) + b21 + b31;
+    const int rk2 = (2 - b20 - b21) + b32, rk3 = 3 - b30 - b31 - b32;
+    const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+    const int base = L.sp + nh - 1;
+    stk[LH_ROW(h0 ? base - rk0 : L.sp + rk0)][tid] = (int)r.x;
+    stk[LH_ROW(h1 ? base - rk1 : L.sp + rk1)][tid] = (int)r.y;
+    stk[LH_ROW(h2 ? base - rk2 : L.sp + rk2)][tid] = (int)r.z;
+    stk[LH_ROW(h3 ? base - rk3 : L.sp + rk3)][tid] = (int)r.w;
+    L.sp = base;
+    const int nxt = stk[LH_ROW(base)][tid];
+    const int popped2 = stk[LH_ROW(L.sp - 1)][tid];
+    const bool is_leaf = (nxt < 0) & (nxt != kDone);
+    const bool park = is_leaf & (pend == kNoLeaf);
+    pend = park ? nxt : pend;
+    L.cur = park ? popped2 : nxt;
+    L.sp -= park ? 1 : 0;
+}
+
+/* one triangle of the parked leaf of every lane that holds one */
+template <bool ANYHIT, bool COUNT, int STRIDE, bool RING>
+__device__ __forceinline__ void tri_pass(Lane &L, int &pend, const lh_dev_scene_t &sc, int (*stk)[STRIDE], const int tid,
+                                         double ox, double oy, double oz, double dx, double dy, double dz, Best &best,
+                                         uint32_t &c_tris, uint32_t &c_exact, const int ring_mask = 0)
+{
+    if (pend != kNoLeaf) {
+        const float4 *__restrict__ tris = (const float4 *)sc.tri32;
+        const uint32_t x = ~(uint32_t)pend;
+        const float4 *tp = tris + 3 * (size_t)(x >> 2);
+        const float4 ta = tp[0], tb_ = tp[1], tc = tp[2];
+        if (COUNT) c_tris++;
+        const bool finished = tri_step<ANYHIT, COUNT>(L, sc, ta.x, ta.y, ta.z, ta.w, tb_.x, tb_.y, tb_.z, tb_.w, tc.x, tc.z, tc.w, __float_as_uint(tc.y), ox, oy, oz, dx, dy, dz, best, c_exact);
+        if (finished) { L.cur = kDone; pend = kNoLeaf; }
+        else if (x & 3u) pend = (int)~(((x >> 2) + 1u) << 2 | ((x & 3u) - 1u));
+        else {
+            /* leaf finished: a lane that was waiting with a second leaf parks it now */
+            const bool waiting = (L.cur < 0) & (L.cur != kDone);
+            pend = waiting ? L.cur : kNoLeaf;
+            if (waiting) { L.sp--; L.cur = stk[LH_ROW(L.sp)][tid]; }
+        }
+    }
+#undef LH_ROW
+}
+
 template <bool ANYHIT, bool COUNT, bool GUARD>
 __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_scene_t &sc,
                                                int (*stk)[LH_BLOCK], const int tid,
@@ -121,71 +199,26 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
                                                double dx, double dy, double dz, Best &best,
                                                uint32_t &c_nodes, uint32_t &c_tris, uint32_t &c_exact,
                                                const int min_active, const int tri_batch,
-                                               uint32_t &c_nslots, uint32_t &c_tslots)
+                                               uint32_t &c_nslots, uint32_t &c_tslots, uint32_t &it)
 {
-    const float4 *__restrict__ tris  = (const float4 *)sc.tri32;
-    constexpr int kNoLeaf = 0;
-
     const int rows = (int)sc.stack_rows;
     for (;;) {
         if (COUNT) { if (__ballot(L.cur >= 0) != 0ull) c_nslots++; }
         /* the step below writes up to slot sp + 3.  rows = 3 * depth + 5 covers every ray of a tree that deep; a deeper
          * tree (an LBVH built on the device over a degenerate distribution) gets 64 rows and a ray that would overrun them
-         * is finished by k_overflow_fix with a private stack -- same arithmetic, same answer */
+         * is finished by k_coop_walk -- same arithmetic, same answer */
         if (GUARD && L.cur >= 0 && L.sp + 4 > rows) { L.over = true; L.cur = kDone; pend = kNoLeaf; }     /* a separate instantiation: the check costs the path-traced frame 4 % */
         if (L.cur >= 0) {
-            const uint4 *p = (const uint4 *)sc.q4nodes + 4 * (size_t)L.cur;
-            const uint4 a = p[0], b = p[1], c = p[2], r = p[3];
-            if (COUNT) c_nodes++;
-            float t0, t1, t2, t3;
-            const bool h0 = slab_w(L, a.x, a.y, a.z, t0) & ((int)r.x != kDone);
-            const bool h1 = slab_w(L, a.w, b.x, b.y, t1) & ((int)r.y != kDone);
-            const bool h2 = slab_w(L, b.z, b.w, c.x, t2) & ((int)r.z != kDone);
-            const bool h3 = slab_w(L, c.y, c.z, c.w, t3) & ((int)r.w != kDone);
-            /* entry distances are >= 0, so their bit patterns order like unsigned integers */
-            const uint32_t k0 = h0 ? ((__float_as_uint(t0) & ~3u) | 0u) : 0xFFFFFFFCu;
-            const uint32_t k1 = h1 ? ((__float_as_uint(t1) & ~3u) | 1u) : 0xFFFFFFFDu;
-            const uint32_t k2 = h2 ? ((__float_as_uint(t2) & ~3u) | 2u) : 0xFFFFFFFEu;
-            const uint32_t k3 = h3 ? ((__float_as_uint(t3) & ~3u) | 3u) : 0xFFFFFFFFu;
-            const int b10 = k1 < k0, b20 = k2 < k0, b30 = k3 < k0, b21 = k2 < k1, b31 = k3 < k1, b32 = k3 < k2;
-            const int rk0 = b10 + b20 + b30, rk1 = (1 - b10) + b21 + b31;
-            const int rk2 = (2 - b20 - b21) + b32, rk3 = 3 - b30 - b31 - b32;
-            const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-            const int base = L.sp + nh - 1;
-            stk[h0 ? base - rk0 : L.sp + rk0][tid] = (int)r.x;
-            stk[h1 ? base - rk1 : L.sp + rk1][tid] = (int)r.y;
-            stk[h2 ? base - rk2 : L.sp + rk2][tid] = (int)r.z;
-            stk[h3 ? base - rk3 : L.sp + rk3][tid] = (int)r.w;
-            L.sp = base;
-            const int nxt = stk[base][tid];
-            const int popped2 = stk[L.sp - 1][tid];
-            const bool is_leaf = (nxt < 0) & (nxt != kDone);
-            const bool park = is_leaf & (pend == kNoLeaf);
-            pend = park ? nxt : pend;
-            L.cur = park ? popped2 : nxt;
-            L.sp -= park ? 1 : 0;
+            node_step4<COUNT, LH_BLOCK, false>(L, pend, sc, stk, tid, c_nodes);
         }
         const unsigned long long m_node = __ballot(L.cur >= 0);
         const unsigned long long m_pend = __ballot(pend != kNoLeaf);
         if (m_pend != 0ull && (__popcll(m_pend) >= tri_batch || m_node == 0ull)) {
             if (COUNT) c_tslots++;
-            if (pend != kNoLeaf) {
-                const uint32_t x = ~(uint32_t)pend;
-                const float4 *tp = tris + 3 * (size_t)(x >> 2);
-                const float4 ta = tp[0], tb_ = tp[1], tc = tp[2];
-                if (COUNT) c_tris++;
-                const bool finished = tri_step<ANYHIT, COUNT>(L, sc, ta.x, ta.y, ta.z, ta.w, tb_.x, tb_.y, tb_.z, tb_.w, tc.x, tc.z, tc.w, __float_as_uint(tc.y), ox, oy, oz, dx, dy, dz, best, c_exact);
-                if (finished) { L.cur = kDone; pend = kNoLeaf; }
-                else if (x & 3u) pend = (int)~(((x >> 2) + 1u) << 2 | ((x & 3u) - 1u));
-                else {
-                    const bool waiting = (L.cur < 0) & (L.cur != kDone);
-                    pend = waiting ? L.cur : kNoLeaf;
-                    if (waiting) { L.sp--; L.cur = stk[L.sp][tid]; }
-                }
-            }
+            tri_pass<ANYHIT, COUNT, LH_BLOCK, false>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, c_tris, c_exact);
         }
         const unsigned long long m_work = __ballot((L.cur != kDone) | (pend != kNoLeaf));
-        if (__popcll(m_work) < min_active) break;
+        if (__popcll(m_work) < min_active || (++it & kRegroupMask) == 0u) break;      /* at least every 64 iterations: the visit budget is checked at regroup points */
     }
 }
 
@@ -201,10 +234,9 @@ __device__ __forceinline__ void traverse_spec8(Lane &L, int &pend, const lh_dev_
                                                double dx, double dy, double dz, Best &best,
                                                uint32_t &c_nodes, uint32_t &c_tris, uint32_t &c_exact,
                                                const int min_active, const int tri_batch,
-                                               uint32_t &c_nslots, uint32_t &c_tslots)
+                                               uint32_t &c_nslots, uint32_t &c_tslots, uint32_t &it)
 {
     const float4 *__restrict__ tris  = (const float4 *)sc.tri32;
-    constexpr int kNoLeaf = 0;
     const uint32_t oct = (uint32_t)L.r.ngx | ((uint32_t)L.r.ngy << 1) | ((uint32_t)L.r.ngz << 2);
     const int rows = (int)sc.stack_rows - 1;        /* the last row takes the misses' writes */
 
@@ -262,7 +294,7 @@ __device__ __forceinline__ void traverse_spec8(Lane &L, int &pend, const lh_dev_
             }
         }
         const unsigned long long m_work = __ballot((L.cur != kDone) | (pend != kNoLeaf));
-        if (__popcll(m_work) < min_active) break;
+        if (__popcll(m_work) < min_active || (++it & kRegroupMask) == 0u) break;      /* at least every 64 iterations: the visit budget is checked at regroup points */
     }
 }
 
@@ -272,20 +304,49 @@ template <bool ANYHIT>
 __device__ __forceinline__ void write_out(size_t i, const Lane &L, const Best &best,
                                           uint32_t *__restrict__ prim, double *__restrict__ t,
                                           double *__restrict__ u, double *__restrict__ v,
-                                          uint8_t *__restrict__ occ, const bool retrace_on, const bool over_fix = false)
+                                          uint8_t *__restrict__ occ, const bool retrace_on)
 {
-    if (over_fix && L.over) {            /* the LDS stack was too short for this ray: k_overflow_fix redoes it */
+    if (L.over) {            /* out of visit budget, or the LDS stack was too short for this ray: k_coop_walk redoes it */
         if (ANYHIT) occ[i] = (uint8_t)LH_OCC_OVERFLOW; else prim[i] = LH_PRIM_OVERFLOW;
         return;
     }
-    /* a hit the reference may not reach goes through the reference's own walk (k_ref_retrace);
+    /* a hit the reference may not reach goes through the reference's own walk (k_fixups);
      * a certain fp32 hit is strictly inside its triangle, hence inside every box: never fragile */
-    const bool retrace = retrace_on && (L.over || (best.prim != LH_MISS_PRIM && best.frag != 0u && !(ANYHIT && L.certain)));
+    const bool retrace = retrace_on && best.prim != LH_MISS_PRIM && best.frag != 0u && !(ANYHIT && L.certain);
     if (ANYHIT) {
         occ[i] = retrace ? (uint8_t)LH_OCC_RETRACE : ((L.certain || best.prim != LH_MISS_PRIM) ? 1 : 0);
     } else {
         prim[i] = retrace ? LH_PRIM_RETRACE : best.prim; t[i] = best.t; u[i] = best.u; v[i] = best.v;
     }
+}
+
+/* the fix-up queue of a launch: 64-bit entries (ray index | reason << 56) appended by the persistent kernel -- LH_Q_REF: a
+ * fragile hit of the fused AO stage, the reference's own walk decides; LH_Q_COOP: out of visit budget / LDS stack rows,
+ * k_coop_walk finishes it.  The consumer (k_coop_walk) runs CONCURRENTLY on a second stream: an entry is one agent-scope
+ * atomic store into a slot that was zero, qcount[0] counts the appends (it may pass qcap: the entries beyond are not stored
+ * and qcount[1] is set), qcount[2] counts the producer waves that have left (release: their entries are visible). */
+#define LH_Q_REF  5u
+#define LH_Q_COOP 6u
+struct FixQ { unsigned long long *queue; uint32_t *qcount; uint32_t qcap, nprod; };
+
+__device__ __forceinline__ bool fixq_push(const FixQ &q, size_t i, uint32_t reason)
+{
+    const uint32_t k = atomicAdd(q.qcount, 1u);
+    if (k < q.qcap) {
+        __hip_atomic_store(q.queue + k, (unsigned long long)i | ((unsigned long long)reason << 56), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+    }
+    atomicOr(q.qcount + 1, 1u);
+    return false;
+}
+
+/* before a launch: the entries of the previous launch on this queue back to zero, then its counters */
+__global__ __launch_bounds__(256) void k_fixq_reset(unsigned long long *queue, uint32_t *qcount, uint32_t qcap)
+{
+    const uint32_t used = qcount[0] < qcap ? qcount[0] : qcap;
+    for (uint32_t k = threadIdx.x; k < used; k += 256) queue[k] = 0ull;
+    __syncthreads();
+    if (threadIdx.x < 3) qcount[threadIdx.x] = 0u;
 }
 
 __device__ __forceinline__ void add_counters(unsigned long long *c, uint32_t nodes, uint32_t tris,
@@ -337,15 +398,16 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_direct(
 struct AoSrc {
     const double *hitrec; const unsigned long long *slot_key; unsigned int *occ_count;
     unsigned long long seed; int ntheta, nphi;
-    uint32_t *queue, *qcount; uint32_t qcap;
 };
+
+constexpr uint32_t kNoRay = 0xFFFFFFFFu;
 
 template <bool ANYHIT, bool COUNT, int WALK, int SRC>
 __device__ __forceinline__ void trace_persist_lane(
-    const lh_dev_scene_t &sc, size_t n, const double *__restrict__ org, const double *__restrict__ dir,
+    const lh_dev_scene_t &sc, const uint32_t n, const double *__restrict__ org, const double *__restrict__ dir,
     uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
     double *__restrict__ v, uint8_t *__restrict__ occ, unsigned long long *counters,
-    unsigned long long *cursor, int min_active, int tri_batch, const AoSrc &ao, int *lds)
+    uint32_t *cursor, int min_active, int tri_batch, const AoSrc &ao, const FixQ &fq, int *lds)
 {
     int (*stk)[LH_BLOCK] = (int (*)[LH_BLOCK])lds;
     const int tid = threadIdx.x;
@@ -353,83 +415,108 @@ __device__ __forceinline__ void trace_persist_lane(
     Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM, 0u};
     int pend = 0;                    /* parked leaf reference (0 = none) */
     uint32_t selfp = LH_MISS_PRIM;   /* SRC 1: the triangle this AO ray starts on, when it cannot occlude the ray (lh_ao.h) */
-    size_t my = (size_t)-1;          /* ray this lane is working on */
+    uint32_t my = kNoRay;            /* ray this lane is working on (a launch holds fewer than 2^31 rays: 32-bit indices keep the walk under 128 VGPRs) */
     double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
     L.cur = kDone; L.sp = 1; L.np = 0; L.certain = false; L.over = false;
-    bool exhausted = false;          /* wave-uniform: cursor ran past n */
-    unsigned long long wbase = 0, wend = 0;   /* wave-uniform: this wave's reserved ray range */
+#ifdef LH_DIAG_CLOCK      /* wave start / exit clocks (LH_STAGE_TIMING); off in the product: two SGPRs live across the whole kernel */
+    if (sc.diag_clock && (tid & 63) == 0) sc.diag_clock[(size_t)blockIdx.x * (LH_BLOCK / 64) + (tid >> 6)] = wall_clock64();
+#endif
+    bool exhausted = false;          /* wave-uniform: every partition's cursor ran past its end */
+    uint32_t wbase = 0, wend = 0;    /* wave-uniform: this wave's reserved ray range */
+    uint32_t part, drained = 0;      /* wave-uniform: the partition this wave draws from, partitions it has found empty */
+    uint32_t it = 0, it0 = 0;        /* wave-uniform iteration counter of the walk; its value when this lane's ray started */
+    {
+        int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));      /* for speed only: any placement is correct */
+        part = ((uint32_t)xcc & 7u) % LH_NPART;
+    }
 
     for (;;) {
         /* ---- regroup: retire finished lanes, refill them ----------------- */
+        /* out of budget: the ray leaves the persistent walk here and is finished cooperatively (its partial results are dropped) */
+        if (__builtin_expect(my != kNoRay && it - it0 > sc.ray_budget && ((L.cur != kDone) | (pend != 0)), 0)) { L.over = true; L.cur = kDone; pend = 0; }
         const bool idle = (L.cur == kDone) && (pend == 0);
         if (COUNT) crs++;
-        if (idle && my != (size_t)-1) {
-            finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce, SRC == 1 ? selfp : LH_MISS_PRIM);
-            if (SRC == 0) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL, WALK == 8 || WALK == 7);
-            else {
-                const bool hit = L.certain || best.prim != LH_MISS_PRIM;
-                const bool retrace = sc.ref_nodes != NULL && (L.over || (best.prim != LH_MISS_PRIM && best.frag != 0u && !L.certain));
-                if (retrace) {
-                    const uint32_t k = atomicAdd(ao.qcount, 1u);
-                    if (k < ao.qcap) { ao.queue[2 * (size_t)k] = (uint32_t)my; ao.queue[2 * (size_t)k + 1] = 5u; }   /* 5: the reference walk decides */
-                    else atomicOr(ao.qcount + 1, 1u);
-                } else if (hit) atomicAdd(&ao.occ_count[(uint32_t)my / (uint32_t)(ao.ntheta * ao.nphi)], 1u);
-            }
+        if (idle && my != kNoRay) {
+            if (!L.over) finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce, SRC == 1 ? selfp : LH_MISS_PRIM);
+            /* rays the persistent walk does not finish go through the fix-up queue to the concurrent consumer: out of budget /
+             * stack rows -> the cooperative walk; a hit the reference may not reach (fragile; a certain fp32 hit is strictly
+             * inside its triangle, hence inside every box: never fragile) -> the reference's own walk.  A full queue (ray dumps:
+             * the ray stays flagged in its output slot for k_fixups; AO stage: the caller redoes the stage materialised) */
+            const bool fragile = sc.ref_nodes != NULL && !L.over && best.prim != LH_MISS_PRIM && best.frag != 0u && !(ANYHIT && L.certain);
+            bool queued = false;
+            if (__builtin_expect(L.over | fragile, 0)) queued = fixq_push(fq, my, L.over ? LH_Q_COOP : LH_Q_REF);
+            if (SRC == 0) { if (__builtin_expect(!queued, 1)) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL); }
+            else if (!L.over && !fragile && (L.certain || best.prim != LH_MISS_PRIM)) atomicAdd(&ao.occ_count[my / (uint32_t)(ao.ntheta * ao.nphi)], 1u);
             if (COUNT) {
                 cr++;
                 const uint32_t visits = cn - cn_ray0; cn_ray0 = cn;
                 const int bkt = visits ? 32 - __clz((int)visits) : 0;
                 atomicAdd(&counters[LH_CNT_HIST + (bkt < 23 ? bkt : 23)], 1ull);
             }
-            my = (size_t)-1;
+            my = kNoRay;
         }
         const unsigned long long idle_mask = __ballot(idle);
-        /* refill from the wave's private range [wbase, wend); one atomic on the global cursor reserves
-         * sc.ray_chunk rays (the cursor is ONE address: at a refill per ~33 rays it serialised the whole
-         * grid -- 64 M same-address atomics/s for 2.1 Grays/s, profiles/README.md r01e) */
+        /* refill from the wave's private range [wbase, wend); one atomic on a cursor reserves sc.ray_chunk rays (one atomic
+         * per regroup -- a refill every ~33 rays -- made the single cursor address the serialisation point of the whole grid:
+         * 64 M same-address atomics/s at 2.1 Grays/s, profiles/README.md r01e).
+         * XCD-aware: the batch is cut into LH_NPART contiguous partitions with a cursor each; a wave draws from the partition
+         * of the XCD it runs on (each XCD has its own 4 MiB L2: the rays of one image region -- and the nodes and triangles
+         * they touch -- stay in ONE L2 instead of all eight), and moves on to the next partition when its own is drained. */
         if (idle_mask != 0ull && !exhausted) {
-            if (wbase == wend) {
-                unsigned long long b = 0;
-                if ((tid & 63) == 0) b = atomicAdd(cursor, (unsigned long long)sc.ray_chunk);
-                b = __shfl(b, 0);
-                wbase = b < n ? b : n;
-                wend = (b + sc.ray_chunk < n) ? b + sc.ray_chunk : n;
+            if (__builtin_expect(wbase == wend, 0)) {
+                const uint32_t per = (n + LH_NPART - 1) / LH_NPART;
+                for (;;) {
+                    const uint32_t p0 = per * part, p1 = (p0 + per < n) ? p0 + per : n;      /* per * LH_NPART < 2^31 + 8 */
+                    const uint32_t plen = p1 > p0 ? p1 - p0 : 0u;                              /* a small batch leaves the last partitions empty */
+                    uint32_t b = 0;
+                    if ((tid & 63) == 0) b = atomicAdd(cursor + part, sc.ray_chunk);           /* < 2^31 + waves * chunk: no wrap */
+                    b = (uint32_t)__shfl((int)b, 0);
+                    if (b < plen) { b += p0; wbase = b; wend = (p1 - b > sc.ray_chunk) ? b + sc.ray_chunk : p1; break; }
+                    part = (part + 1u) % LH_NPART;
+                    if (++drained >= LH_NPART) { exhausted = true; break; }     /* every partition has been handed out */
+                }
             }
             const int need = __popcll(idle_mask);
-            const unsigned long long avail = wend - wbase;
-            const int take = avail < (unsigned long long)need ? (int)avail : need;
+            const uint32_t avail = wend - wbase;
+            const int take = avail < (uint32_t)need ? (int)avail : need;
             const int rank = __popcll(idle_mask & ((1ull << (tid & 63)) - 1ull));
             if (idle && rank < take) {
-                const size_t i = wbase + rank;
+                const uint32_t i = wbase + (uint32_t)rank;
                 my = i;
                 if (SRC == 0) {
-                    ox = org[3 * i]; oy = org[3 * i + 1]; oz = org[3 * i + 2];
-                    dx = dir[3 * i]; dy = dir[3 * i + 1]; dz = dir[3 * i + 2];
+                    ox = org[3 * (size_t)i]; oy = org[3 * (size_t)i + 1]; oz = org[3 * (size_t)i + 2];
+                    dx = dir[3 * (size_t)i]; dy = dir[3 * (size_t)i + 1]; dz = dir[3 * (size_t)i + 2];
                 } else {
-                    const uint32_t N = (uint32_t)(ao.ntheta * ao.nphi), slot = (uint32_t)i / N;
+                    const uint32_t N = (uint32_t)(ao.ntheta * ao.nphi), slot = i / N;
                     const unsigned long long key = ao.slot_key[slot];
                     lh_ao_ray_builtin(ao.hitrec + LH_HITREC_DOUBLES * (size_t)slot, key, ao.seed, ao.ntheta, ao.nphi,
-                                      (int)((uint32_t)i - slot * N), ox, oy, oz, dx, dy, dz);
+                                      (int)(i - slot * N), ox, oy, oz, dx, dy, dz);
                     selfp = lh_slot_selfprim(key);            /* LH_SLOT_NOSELF matches no primitive id (ids < 2^29) */
                 }
                 lane_init(L, sc, ox, oy, oz, dx, dy, dz);
                 best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM; best.frag = 0u;
                 stk[0][tid] = kDone;
+                it0 = it;
             }
             wbase += take;
-            if (wbase >= n) exhausted = true;          /* the grid has handed out every ray */
         }
         const unsigned long long work = __ballot((L.cur != kDone) | (pend != 0));
         if (work == 0ull) break;
         /* ---- walk until too few lanes remain active ---------------------- */
         const int thresh = exhausted ? 1 : min_active;
         if (WALK == 3)
-            traverse_spec4<ANYHIT, COUNT, false>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts);
+            traverse_spec4<ANYHIT, COUNT, false>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, it);
         else if (WALK == 8)          /* the same with the stack check: trees whose worst case the LDS rows do not cover */
-            traverse_spec4<ANYHIT, COUNT, true>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts);
+            traverse_spec4<ANYHIT, COUNT, true>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, it);
         else
-            traverse_spec8<ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts);
+            traverse_spec8<ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, it);
     }
+#ifdef LH_DIAG_CLOCK
+    if (sc.diag_clock && (tid & 63) == 0) sc.diag_clock[(size_t)(gridDim.x + blockIdx.x) * (LH_BLOCK / 64) + (tid >> 6)] = wall_clock64();
+#endif
+    /* this wave appends nothing more: its entries become visible to the concurrent consumer before the count does */
+    if ((tid & 63) == 0) __hip_atomic_fetch_add(fq.qcount + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if (COUNT) {
         add_counters(counters, cn, ct, ce, cr);
         atomicAdd(&counters[LH_CNT_NODE_SLOTS], (unsigned long long)cns);
@@ -439,22 +526,216 @@ __device__ __forceinline__ void trace_persist_lane(
 }
 
 template <bool ANYHIT, bool COUNT, int WALK, int SRC>
-__global__ __launch_bounds__(LH_BLOCK) void k_trace_persist_lane(
-    lh_dev_scene_t sc, size_t n, const double *__restrict__ org, const double *__restrict__ dir,
+__global__ __launch_bounds__(LH_BLOCK, WALK == 7 ? 3 : 4) void k_trace_persist_lane(
+    lh_dev_scene_t sc, uint32_t n, const double *__restrict__ org, const double *__restrict__ dir,
     uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
     double *__restrict__ v, uint8_t *__restrict__ occ, unsigned long long *counters,
-    unsigned long long *cursor, int min_active, int tri_batch, const AoSrc ao)
+    uint32_t *cursor, int min_active, int tri_batch, const AoSrc ao, const FixQ fq)
 {
     extern __shared__ int lh_stack_lds[];          /* [stack entries][LH_BLOCK], sized at launch */
-    trace_persist_lane<ANYHIT, COUNT, WALK, SRC>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, ao, lh_stack_lds);
+    trace_persist_lane<ANYHIT, COUNT, WALK, SRC>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, ao, fq, lh_stack_lds);
 }
 
 /* ------------------------------------------------------------------------ */
-/* rays whose LDS stack column was too short (trees deeper than 19 4-wide   */
-/* levels): the same walk, sequential, with a private stack                 */
+/* the wave-cooperative walk: queued rays, 16 lanes each                      */
 /* ------------------------------------------------------------------------ */
-#define LH_BIG_STACK 272        /* 3 * 88 + 8: the deepest 4-wide tree the device builder hands over */
+/* A ray the persistent kernel gave up on (visit budget, LDS rows) is traced again from the root by a group of lanes: its first lane
+ * starts at the root; every iteration each busy lane takes one step of the default walk in its own LDS stack column, and
+ * every idle lane takes over the BOTTOM entry of a busy lane's stack -- the largest unvisited subtree -- and walks it as
+ * its own (same ray, own culling bound, own candidates).  Subtrees are disjoint, so every leaf is visited by exactly one
+ * lane; the lanes' exact bests are merged at the end with resolve()'s rules (strictly smaller t wins, exact-t ties by the
+ * reference's tree, nearly-equal t of two triangles marks the hit fragile).  Any-hit rays stop as soon as one lane holds a
+ * certain hit.  Culling uses each lane's own bound (a donated subtree starts with the donor's), which is never tighter than
+ * the sequential walk's: the same candidates or more reach the fp64 test, so the answer is the sequential walk's answer.
+ * The chain of dependent node fetches of a long ray (thousands, ~1 us each) is cut by up to 16. */
+#define LH_COOP_ROWS_MAX 272        /* 3 * 88 + 8: the deepest 4-wide tree the builders hand over */
 
+__device__ __forceinline__ void merge_best(const lh_dev_scene_t &sc, Best &g, const Best &b, double dx, double dy, double dz)
+{
+    if (b.prim == LH_MISS_PRIM) return;
+    if (g.prim == LH_MISS_PRIM) { g = b; return; }
+    bool take = b.t < g.t;
+    if (!take && b.t == g.t && b.prim != g.prim) take = tie_takes_new(sc, b.prim, g.prim, dx, dy, dz);
+    const double tm = fabs(b.t) > fabs(g.t) ? fabs(b.t) : fabs(g.t);
+    const uint32_t near2 = (b.prim != g.prim && b.t != g.t && fabs(b.t - g.t) <= LH_FRAGILE_REL * tm) ? 2u : 0u;
+    const uint32_t sticky = ((g.frag | b.frag) & 2u) | near2;
+    if (take) { g.t = b.t; g.u = b.u; g.v = b.v; g.prim = b.prim; g.frag = b.frag & 1u; }
+    g.frag = (g.frag & 1u) | sticky;
+}
+
+/* the reference's own walk for one ray, out of line (its private stack stays out of the callers' frames) */
+struct RefHit { double t, u, v; uint32_t prim; };
+__device__ __noinline__ RefHit ref_trace_one(const lh_dev_scene_t &sc, double ox, double oy, double oz, double dx, double dy, double dz)
+{
+    RefHit h; uint32_t p = LH_MISS_PRIM; double tt = LH_T_INF, uu = 0.0, vv = 0.0;
+    const int hit = lh_ref_trace((const lh_refnode_t *)sc.ref_nodes, (const uint32_t *)sc.ref_leaf_prims, (const double *)sc.tri64,
+                                 sc.ref_empty, sc.ref_bmin, sc.ref_bmax, ox, oy, oz, dx, dy, dz, &p, &tt, &uu, &vv);
+    h.prim = hit ? p : LH_MISS_PRIM; h.t = tt; h.u = uu; h.v = vv;
+    return h;
+}
+
+/* One wave works on FOUR queued rays at a time, a group of 16 lanes each (most rays in the queue are only a little over
+ * budget: a whole wave per ray would idle; donation stays inside the group); a group that has finished its ray takes the
+ * next entry of its stride.
+ * SRC 0: rays from org / dir, results into prim / t / u / v / occ.
+ * SRC 1: AO rays regenerated from (slot, sample), occluded rays counted per slot; LH_Q_REF entries (and fragile results)
+ * are decided by the reference's own walk, by the group's first lane. */
+template <bool ANYHIT, int SRC>
+__global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const double *__restrict__ org, const double *__restrict__ dir,
+                                                  uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
+                                                  double *__restrict__ v, uint8_t *__restrict__ occ, const AoSrc ao, const FixQ fq,
+                                                  unsigned long long *counters)
+{
+    extern __shared__ int lh_stack_lds[];          /* [rows][64] stack + 2 x 64 exchange words */
+    const int rows = (int)sc.stack_rows, rmask = rows - 1;          /* rows: a power of two (ring of stack positions) */
+    int (*stk)[64] = (int (*)[64])lh_stack_lds;
+    int *xref = lh_stack_lds + (size_t)rows * 64; float *xtb = (float *)(xref + 64);
+    const int lane = threadIdx.x, g = lane >> 4;
+    const unsigned long long gmask = 0xFFFFull << (16 * g), lt_mask = (1ull << lane) - 1ull;
+    const uint32_t ngroups = gridDim.x * 4u;
+    uint32_t e = blockIdx.x * 4u + (uint32_t)g;       /* the group's next queue entry */
+    bool have = false;                                /* the group holds a ray */
+    bool gdone = e >= fq.qcap;                        /* the group has seen the end of the queue */
+    uint32_t known = 0, look = 0;                     /* wave-uniform: the append count at the wave's last look; iterations since */
+    size_t i = 0; double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1; uint32_t selfp = LH_MISS_PRIM;
+    Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM, 0u};
+    int pend = kNoLeaf, floor_ = 1; uint32_t cn = 0, ct = 0, ce = 0;
+    L.cur = kDone; L.sp = 1; L.np = 0; L.certain = false; L.over = false;
+    stk[0][lane] = kDone;
+
+    for (;;) {
+        const unsigned long long m_busy0 = __ballot((L.cur != kDone) | (pend != kNoLeaf));
+        if ((m_busy0 & gmask) == 0ull) {                 /* group-uniform: nothing left to walk */
+            if (have) {
+                /* every lane's candidates through the fp64 test, then the merge over the group */
+                bool need_ref = false, hit = false;
+                finish<ANYHIT, false>(L, sc, ox, oy, oz, dx, dy, dz, best, ce, selfp);
+                if (ANYHIT) {
+                    const bool exact = best.prim != LH_MISS_PRIM;
+                    const bool sure = (__ballot(L.certain || (exact && best.frag == 0u)) & gmask) != 0ull;
+                    hit = sure;
+                    if (!sure && (__ballot(exact) & gmask) != 0ull) { need_ref = sc.ref_nodes != NULL; hit = true; }   /* only fragile hits: the reference walk decides */
+                    if (SRC == 0 && (lane & 15) == 0) {
+                        if (need_ref) hit = ref_trace_one(sc, ox, oy, oz, dx, dy, dz).prim != LH_MISS_PRIM;
+                        occ[i] = (uint8_t)(hit ? 1 : 0);
+                    }
+                } else {
+                    Best gb = best;
+                    for (int off = 1; off < 16; off <<= 1) {
+                        Best b;
+                        b.t = __shfl_xor(gb.t, off); b.u = __shfl_xor(gb.u, off); b.v = __shfl_xor(gb.v, off);
+                        b.prim = (uint32_t)__shfl_xor((int)gb.prim, off); b.frag = (uint32_t)__shfl_xor((int)gb.frag, off);
+                        merge_best(sc, gb, b, dx, dy, dz);
+                    }
+                    if ((lane & 15) == 0) {
+                        if (sc.ref_nodes != NULL && gb.prim != LH_MISS_PRIM && gb.frag != 0u) {        /* a fragile hit: the reference walk decides */
+                            const RefHit rh = ref_trace_one(sc, ox, oy, oz, dx, dy, dz);
+                            gb.prim = rh.prim; gb.t = rh.t; gb.u = rh.u; gb.v = rh.v;
+                        }
+                        prim[i] = gb.prim; t[i] = gb.t; u[i] = gb.u; v[i] = gb.v;
+                    }
+                }
+                if (SRC == 1 && (lane & 15) == 0) {
+                    if (need_ref) hit = ref_trace_one(sc, ox, oy, oz, dx, dy, dz).prim != LH_MISS_PRIM;
+                    if (hit) atomicAdd(&ao.occ_count[(uint32_t)i / (uint32_t)(ao.ntheta * ao.nphi)], 1u);
+                }
+                if (counters && (lane & 15) == 0) atomicAdd(&counters[LH_CNT_RETRACED], 1ull);
+                have = false;
+            }
+            /* the producer may still be running.  `known` is the wave's last look at the append count (refreshed rarely: every
+             * look is a load of ONE word that 256 waves share); a slot below it is, or is about to be, non-zero */
+            unsigned long long ent = 0ull;
+            if (!gdone && e < known) ent = __hip_atomic_load(fq.queue + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ent != 0ull) {
+                const uint32_t reason = (uint32_t)(ent >> 56);
+                i = (size_t)(ent & 0x00FFFFFFFFFFFFFFull);
+                e += ngroups;
+                if (e >= fq.qcap) gdone = true;
+                if (SRC == 0) {
+                    ox = org[3 * i]; oy = org[3 * i + 1]; oz = org[3 * i + 2]; dx = dir[3 * i]; dy = dir[3 * i + 1]; dz = dir[3 * i + 2];
+                } else {
+                    const uint32_t N = (uint32_t)(ao.ntheta * ao.nphi), slot = (uint32_t)i / N;
+                    const unsigned long long key = ao.slot_key[slot];
+                    lh_ao_ray_builtin(ao.hitrec + LH_HITREC_DOUBLES * (size_t)slot, key, ao.seed, ao.ntheta, ao.nphi, (int)((uint32_t)i - slot * N), ox, oy, oz, dx, dy, dz);
+                    selfp = lh_slot_selfprim(key);
+                }
+                if (reason == LH_Q_REF) {
+                    /* a fragile hit: the reference's own walk on its own tree decides, no cooperative walk */
+                    if ((lane & 15) == 0) {
+                        const RefHit rh = ref_trace_one(sc, ox, oy, oz, dx, dy, dz);
+                        if (counters) atomicAdd(&counters[LH_CNT_RETRACED], 1ull);
+                        if (SRC == 1) { if (rh.prim != LH_MISS_PRIM) atomicAdd(&ao.occ_count[(uint32_t)i / (uint32_t)(ao.ntheta * ao.nphi)], 1u); }
+                        else if (ANYHIT) occ[i] = rh.prim != LH_MISS_PRIM ? 1 : 0;
+                        else { prim[i] = rh.prim; t[i] = rh.t; u[i] = rh.u; v[i] = rh.v; }
+                    }
+                } else {
+                    lane_init(L, sc, ox, oy, oz, dx, dy, dz);
+                    best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM; best.frag = 0u;
+                    pend = kNoLeaf; floor_ = 1; stk[0][lane] = kDone;
+                    L.cur = (lane & 15) == 0 ? 0 : kDone;
+                    have = true;
+                }
+            }
+        }
+        /* a look at the queue's counters: when the whole wave is idle (after a nap of ~25 us), else every 128 iterations */
+        const bool wave_idle = __ballot(have) == 0ull;
+        if (wave_idle || (++look & 127u) == 0u) {
+            if (wave_idle) {
+                if (__ballot(!gdone && e < known) != 0ull) continue;        /* a slot below the known count: it is being written */
+                if (__ballot(!gdone) == 0ull) break;                          /* the queue has ended for every group */
+                for (int k = 0; k < 8; k++) __builtin_amdgcn_s_sleep(127);
+            }
+            uint32_t left = 0, cnt = 0;
+            if (lane == 0) {
+                left = __hip_atomic_load(fq.qcount + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                cnt = __hip_atomic_load(fq.qcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            left = (uint32_t)__shfl((int)left, 0); cnt = (uint32_t)__shfl((int)cnt, 0);
+            known = cnt < fq.qcap ? cnt : fq.qcap;
+            if (left >= fq.nprod && e >= known) gdone = true;      /* every producer wave has left (acquire): the count is final */
+            if (wave_idle) continue;
+        }
+        if (L.cur >= 0) node_step4<false, 64, true>(L, pend, sc, stk, lane, cn, rmask);
+        const unsigned long long m_node = __ballot(L.cur >= 0);
+        const unsigned long long m_pend = __ballot(pend != kNoLeaf);
+        if (m_pend != 0ull && (__popcll(m_pend) >= 8 || m_node == 0ull))
+            tri_pass<ANYHIT, false, 64, true>(L, pend, sc, stk, lane, ox, oy, oz, dx, dy, dz, best, ct, ce, rmask);
+        if (ANYHIT) {                                    /* a certain hit ends the group's ray */
+            if ((__ballot(L.certain) & gmask) != 0ull) { L.cur = kDone; pend = kNoLeaf; }
+        }
+        /* donation inside a group: its k-th idle lane takes the bottom stack entry of its k-th lane that has one to give */
+        const bool busy = (L.cur != kDone) | (pend != kNoLeaf);
+        const bool donor = busy && L.sp > floor_;
+        const unsigned long long m_donor = __ballot(donor), m_idle = __ballot(!busy && have);
+        const unsigned long long gd = m_donor & gmask, gi = m_idle & gmask;
+        if (__ballot(gd != 0ull && gi != 0ull) != 0ull) {
+            const int nd = __popcll(gd), ni = __popcll(gi);
+            const int ngive = nd < ni ? nd : ni;
+            const int drank = __popcll(gd & lt_mask), irank = __popcll(gi & lt_mask);
+            if (donor && drank < ngive) {
+                xref[16 * g + drank] = stk[floor_ & rmask][lane]; xtb[16 * g + drank] = L.tb;
+                stk[floor_ & rmask][lane] = kDone; floor_++;    /* the slot becomes the stack-bottom sentinel */
+            }
+            __syncthreads();
+            if (!busy && have && irank < ngive) {
+                const int r = xref[16 * g + irank];
+                L.tb = fminf(L.tb, xtb[16 * g + irank]);
+                L.sp = 1; floor_ = 1; stk[0][lane] = kDone;
+                const bool is_leaf = (r < 0) & (r != kDone);
+                pend = is_leaf ? r : kNoLeaf;
+                L.cur = is_leaf ? kDone : r;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* one scan over the outputs of a ray dump: what is still flagged            */
+/* ------------------------------------------------------------------------ */
+/* LH_PRIM_RETRACE / LH_OCC_RETRACE: a hit the reference may not reach -- the reference's own walk on its own tree decides.
+ * LH_PRIM_OVERFLOW / LH_OCC_OVERFLOW: only when the fix-up queue was full (more than qcap rays out of budget in one launch) --
+ * the same walk as the kernel's, sequential, with a private stack. */
 template <bool ANYHIT>
 __device__ void overflow_walk(const lh_dev_scene_t &sc, size_t i, const double *__restrict__ org, const double *__restrict__ dir,
                               uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u, double *__restrict__ v,
@@ -465,7 +746,7 @@ __device__ void overflow_walk(const lh_dev_scene_t &sc, size_t i, const double *
     const float4 *__restrict__ tris = (const float4 *)sc.tri32;
     Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM, 0u};
     uint32_t ce = 0;
-    int stack[LH_BIG_STACK]; int sp = 0;
+    int stack[LH_COOP_ROWS_MAX]; int sp = 0;
     lane_init(L, sc, ox, oy, oz, dx, dy, dz);
     int cur = 0;
     for (;;) {
@@ -483,7 +764,7 @@ __device__ void overflow_walk(const lh_dev_scene_t &sc, size_t i, const double *
                 while (m > 0 && tn[order[m - 1]] > tn[k]) { order[m] = order[m - 1]; m--; }
                 order[m] = k;
             }
-            for (int k = nh - 1; k >= 1; k--) if (sp < LH_BIG_STACK) stack[sp++] = ref[order[k]];
+            for (int k = nh - 1; k >= 1; k--) if (sp < LH_COOP_ROWS_MAX) stack[sp++] = ref[order[k]];
             if (nh) cur = ref[order[0]];
             else if (sp) cur = stack[--sp];
             else break;
@@ -505,55 +786,26 @@ __device__ void overflow_walk(const lh_dev_scene_t &sc, size_t i, const double *
     write_out<ANYHIT>(i, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL);
 }
 
-__global__ __launch_bounds__(256) void k_overflow_fix(lh_dev_scene_t sc, size_t n, const double *__restrict__ org,
-                                                      const double *__restrict__ dir, uint32_t *__restrict__ prim,
-                                                      double *__restrict__ t, double *__restrict__ u, double *__restrict__ v,
-                                                      uint8_t *__restrict__ occ, int anyhit, unsigned long long *counters)
+__global__ __launch_bounds__(256) void k_fixups(lh_dev_scene_t sc, size_t n, const double *__restrict__ org,
+                                                const double *__restrict__ dir, uint32_t *__restrict__ prim,
+                                                double *__restrict__ t, double *__restrict__ u, double *__restrict__ v,
+                                                uint8_t *__restrict__ occ, int anyhit, unsigned long long *counters,
+                                                const uint32_t *qcount, int force)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    if (anyhit ? (occ[i] != LH_OCC_OVERFLOW) : (prim[i] != LH_PRIM_OVERFLOW)) return;
-    if (anyhit) overflow_walk<true>(sc, i, org, dir, prim, t, u, v, occ);
-    else overflow_walk<false>(sc, i, org, dir, prim, t, u, v, occ);
-    if (counters) atomicAdd(&counters[LH_CNT_RETRACED], 1ull);
-}
-
-/* ------------------------------------------------------------------------ */
-/* rays flagged by write_out: the reference's own walk on its own tree       */
-/* ------------------------------------------------------------------------ */
-__global__ __launch_bounds__(256) void k_ref_retrace(lh_dev_scene_t sc, size_t n, const double *__restrict__ org,
-                                                     const double *__restrict__ dir, uint32_t *__restrict__ prim,
-                                                     double *__restrict__ t, double *__restrict__ u, double *__restrict__ v,
-                                                     uint8_t *__restrict__ occ, int anyhit, unsigned long long *counters)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    if (anyhit ? (occ[i] != LH_OCC_RETRACE) : (prim[i] != LH_PRIM_RETRACE)) return;
-    uint32_t p; double tt, uu, vv;
-    const int hit = lh_ref_trace((const lh_refnode_t *)sc.ref_nodes, (const uint32_t *)sc.ref_leaf_prims, (const double *)sc.tri64,
-                                 sc.ref_empty, sc.ref_bmin, sc.ref_bmax, org[3 * i], org[3 * i + 1], org[3 * i + 2],
-                                 dir[3 * i], dir[3 * i + 1], dir[3 * i + 2], &p, &tt, &uu, &vv);
-    if (anyhit) occ[i] = hit ? 1 : 0;
-    else { prim[i] = p; t[i] = tt; u[i] = uu; v[i] = vv; }
-    if (counters) atomicAdd(&counters[LH_CNT_RETRACED], 1ull);
-}
-
-/* the queued AO rays of the fused stage (SRC 1 above): regenerated from (slot, sample), decided by the reference's own
- * walk on its own tree, added to their slot's count.  Queue entries: (ray index, reason) pairs. */
-__global__ __launch_bounds__(256) void k_ao_queue(const lh_dev_scene_t sc, const AoSrc ao, unsigned long long *counters)
-{
-    const uint32_t total = *ao.qcount < ao.qcap ? *ao.qcount : ao.qcap;
-    const uint32_t N = (uint32_t)(ao.ntheta * ao.nphi);
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-        const uint32_t i = ao.queue[2 * e], slot = i / N;
-        double ox, oy, oz, dx, dy, dz;
-        lh_ao_ray_builtin(ao.hitrec + LH_HITREC_DOUBLES * (size_t)slot, ao.slot_key[slot], ao.seed, ao.ntheta, ao.nphi,
-                          (int)(i - slot * N), ox, oy, oz, dx, dy, dz);
-        uint32_t p; double tt, uu, vv;
-        const int hit = lh_ref_trace((const lh_refnode_t *)sc.ref_nodes, (const uint32_t *)sc.ref_leaf_prims, (const double *)sc.tri64,
-                                     sc.ref_empty, sc.ref_bmin, sc.ref_bmax, ox, oy, oz, dx, dy, dz, &p, &tt, &uu, &vv);
+    /* nothing was left flagged unless a push found the queue full (or the launch had no queue: force) */
+    if (!force && qcount[1] == 0u) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        if (anyhit ? (occ[i] == LH_OCC_OVERFLOW) : (prim[i] == LH_PRIM_OVERFLOW)) {
+            if (anyhit) overflow_walk<true>(sc, i, org, dir, prim, t, u, v, occ);
+            else overflow_walk<false>(sc, i, org, dir, prim, t, u, v, occ);
+            if (counters) atomicAdd(&counters[LH_CNT_RETRACED], 1ull);
+        }
+        if (sc.ref_nodes == NULL) continue;
+        if (anyhit ? (occ[i] != LH_OCC_RETRACE) : (prim[i] != LH_PRIM_RETRACE)) continue;
+        const RefHit rh = ref_trace_one(sc, org[3 * i], org[3 * i + 1], org[3 * i + 2], dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+        if (anyhit) occ[i] = rh.prim != LH_MISS_PRIM ? 1 : 0;
+        else { prim[i] = rh.prim; t[i] = rh.t; u[i] = rh.u; v[i] = rh.v; }
         if (counters) atomicAdd(&counters[LH_CNT_RETRACED], 1ull);
-        if (hit) atomicAdd(&ao.occ_count[slot], 1u);
     }
 }
 
@@ -561,7 +813,7 @@ template <bool ANYHIT, bool COUNT>
 int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const double *dir,
                uint32_t *prim, double *t, double *u, double *v, uint8_t *occ,
                unsigned long long *counters, unsigned long long *cursor, int walk,
-               int grid_blocks, int min_active, int tri_batch, size_t lds_bytes, hipStream_t s)
+               int grid_blocks, int min_active, int tri_batch, size_t lds_bytes, const FixQ &fq, hipStream_t s)
 {
     if (walk == 0) {
         const size_t blocks = (n + LH_BLOCK - 1) / LH_BLOCK;
@@ -569,16 +821,16 @@ int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const doub
         hipLaunchKernelGGL((k_trace_direct<ANYHIT, COUNT>), dim3((unsigned)blocks), dim3(LH_BLOCK), lds_bytes, s,
                            sc, n, org, dir, prim, t, u, v, occ, counters);
     } else {
-        if (hipMemsetAsync(cursor, 0, sizeof(unsigned long long), s) != hipSuccess) return -1;
+        if (hipMemsetAsync(cursor, 0, sizeof(unsigned long long) * LH_NPART, s) != hipSuccess) return -1;
         if (walk == 7)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 7, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
+                               sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
         else if (walk == 8)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 8, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
+                               sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
         else
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 3, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                               sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, AoSrc{});
+                               sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -586,18 +838,18 @@ int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const doub
 int launch_walk(const lh_dev_scene_t &sc, size_t n, const double *org, const double *dir,
                 uint32_t *prim, double *t, double *u, double *v, int anyhit, uint8_t *occ,
                 unsigned long long *counters, unsigned long long *cursor, int walk,
-                int grid_blocks, int min_active, int tri_batch, size_t lds_bytes, hipStream_t s)
+                int grid_blocks, int min_active, int tri_batch, size_t lds_bytes, const FixQ &fq, hipStream_t s)
 {
     if (anyhit) {
-        if (counters) return launch_one<true, true>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, walk, grid_blocks, min_active, tri_batch, lds_bytes, s);
-        return launch_one<true, false>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, walk, grid_blocks, min_active, tri_batch, lds_bytes, s);
+        if (counters) return launch_one<true, true>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, walk, grid_blocks, min_active, tri_batch, lds_bytes, fq, s);
+        return launch_one<true, false>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, walk, grid_blocks, min_active, tri_batch, lds_bytes, fq, s);
     }
-    if (counters) return launch_one<false, true>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, walk, grid_blocks, min_active, tri_batch, lds_bytes, s);
-    return launch_one<false, false>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, walk, grid_blocks, min_active, tri_batch, lds_bytes, s);
+    if (counters) return launch_one<false, true>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, walk, grid_blocks, min_active, tri_batch, lds_bytes, fq, s);
+    return launch_one<false, false>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, walk, grid_blocks, min_active, tri_batch, lds_bytes, fq, s);
 }
 
 /* LDS stack rows of a 4-wide walk over this scene: 3 * depth + 5 covers every ray; beyond the cap (64 rows; tests lower it
- * through "stack_cap") the walk checks before it pushes and a ray that would overrun is finished elsewhere */
+ * through "stack_cap") the walk checks before it pushes and a ray that would overrun goes to the cooperative walk */
 uint32_t rows4(const lh_dev_scene_t &sc, bool *guard)
 {
     uint32_t need = 3 * sc.q4_depth + 5;
@@ -607,6 +859,16 @@ uint32_t rows4(const lh_dev_scene_t &sc, bool *guard)
     need = (need + 1u) & ~1u;
     if (need < 16 && !*guard) need = 16;
     return need;
+}
+
+/* the cooperative walk's ring of stack rows: a power of two covering the tree's worst case (3 per level + sentinel + the
+ * step's scratch slots); 0: the tree is deeper than any builder hands over */
+uint32_t coop_rows(const lh_dev_scene_t &sc)
+{
+    const uint32_t need = 3 * sc.q4_depth + 6;
+    uint32_t r = 16;
+    while (r < need) r <<= 1;
+    return r <= 512 ? r : 0;
 }
 
 /* rays per cursor atomic: the scene's setting, but never so large that a wave gets fewer than
@@ -620,42 +882,76 @@ void clamp_chunk(lh_dev_scene_t &scl, size_t n, int grid_blocks)
     if (scl.ray_chunk == 0) scl.ray_chunk = 64;
 }
 
+/* the cooperative walk over the fix-up queue of the persistent launch just enqueued on s.  It runs on the queue's second
+ * stream, CONCURRENTLY with that launch (a few small workgroups per CU next to the persistent ones: its low efficiency --
+ * one ray per 16 lanes, restarted from the root -- is hidden behind the bulk of the frame), submitted AFTER it: if the two
+ * streams share a hardware queue it simply runs afterwards. */
+template <bool ANYHIT, int SRC>
+int launch_coop(const lh_dev_scene_t &sc, const double *org, const double *dir, uint32_t *prim, double *t, double *u, double *v,
+                uint8_t *occ, const AoSrc &ao, const FixQ &fq, const lh_fixq_t *q, unsigned long long *counters, int ncus, hipStream_t s)
+{
+    lh_dev_scene_t scl = sc;
+    scl.stack_rows = coop_rows(sc);
+    if (scl.stack_rows == 0) return -1;
+    const size_t lds = ((size_t)scl.stack_rows * 64 + 128) * sizeof(int);
+    static bool attr_set[2][2] = {{false, false}, {false, false}};
+    if (lds > 64 * 1024 && !attr_set[ANYHIT][SRC]) {
+        if (hipFuncSetAttribute((const void *)k_coop_walk<ANYHIT, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        attr_set[ANYHIT][SRC] = true;
+    }
+    hipStream_t aux = (hipStream_t)q->aux_stream;
+    const int grid = ncus > 0 ? ncus : 256;                /* one wave per workgroup and CU, 4 rays per wave */
+    if (hipStreamWaitEvent(aux, (hipEvent_t)q->ev_ready, 0) != hipSuccess) return -1;
+    hipLaunchKernelGGL((k_coop_walk<ANYHIT, SRC>), dim3(grid), dim3(64), lds, aux, scl, org, dir, prim, t, u, v, occ, ao, fq, counters);
+    if (hipGetLastError() != hipSuccess) return -1;
+    if (hipEventRecord((hipEvent_t)q->ev_done, aux) != hipSuccess) return -1;
+    if (hipStreamWaitEvent(s, (hipEvent_t)q->ev_done, 0) != hipSuccess) return -1;
+    return 0;
+}
+
+/* the queue back to empty (stream-ordered), and the point the consumer's stream waits for */
+int fixq_begin(const lh_fixq_t *q, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fixq_reset, dim3(1), dim3(256), 0, s, (unsigned long long *)q->queue, q->qcount, q->qcap);
+    if (hipGetLastError() != hipSuccess) return -1;
+    return hipEventRecord((hipEvent_t)q->ev_ready, s) == hipSuccess ? 0 : -1;
+}
+
 } /* namespace */
 
 /* the AO stage of a tile with the rays generated inside the any-hit kernel (SRC 1 above): nslots primary hits,
- * N = ntheta * nphi rays each, occluded rays counted per slot in d_occ_count (zeroed here).  Fragile hits go to
- * d_queue (2 words per entry, count + overflow flag in d_qcount[0..1]); lh_launch_ao_queue runs the reference walk
- * for them.  A tree deeper than the LDS rows needs the reference-order tree (overflowing rays are queued too). */
+ * N = ntheta * nphi rays each, occluded rays counted per slot in d_occ_count (zeroed here).  Rays the persistent kernel
+ * does not finish -- fragile hits (the reference's own walk decides), rays out of visit budget or LDS rows (the cooperative
+ * walk) -- go through d_queue (2 words per entry, count + overflow flag in d_qcount[0..1]) to k_coop_walk. */
 extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int ntheta, int nphi, unsigned long long seed,
                                   const double *d_hitrec, const unsigned long long *d_slot_key, unsigned int *d_occ_count,
                                   unsigned long long *d_counters, unsigned long long *d_cursor, int grid_blocks, int min_active,
-                                  int tri_batch, uint32_t *d_queue, uint32_t *d_qcount, uint32_t qcap, void *stream)
+                                  int tri_batch, const lh_fixq_t *q, int ncus, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
     const size_t n = nslots * (size_t)(ntheta * nphi);
     if (n == 0) return 0;
-    if (n >= ((size_t)1 << 32)) return -1;
+    if (n >= ((size_t)1 << 31)) return -1;
     lh_dev_scene_t scl = *sc;
     bool guard = false;
     scl.stack_rows = rows4(*sc, &guard);
-    if (guard && !sc->ref_nodes) return -1;
     scl.stack_guard = guard ? 1 : 0;
     const size_t lds_bytes = (size_t)scl.stack_rows * LH_BLOCK * sizeof(int);
     if (scl.ray_chunk < 512) scl.ray_chunk = 512;      /* AO rays of a slot are coherent: longer ranges per wave (config 5: 92.9 -> 91.4 ms, tools/ao_sweep5.py) */
     clamp_chunk(scl, n, grid_blocks);
-    AoSrc ao = {d_hitrec, d_slot_key, d_occ_count, seed, ntheta, nphi, d_queue, d_qcount, qcap};
-    if (hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long), s) != hipSuccess) return -1;
-    if (hipMemsetAsync(d_qcount, 0, 2 * sizeof(uint32_t), s) != hipSuccess) return -1;
+    AoSrc ao = {d_hitrec, d_slot_key, d_occ_count, seed, ntheta, nphi};
+    FixQ fq = {(unsigned long long *)q->queue, q->qcount, q->qcap, (uint32_t)grid_blocks * (LH_BLOCK / 64)};
+    if (hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long) * LH_NPART, s) != hipSuccess) return -1;
     if (hipMemsetAsync(d_occ_count, 0, sizeof(unsigned int) * nslots, s) != hipSuccess) return -1;
+    if (fixq_begin(q, s) != 0) return -1;
 #define LH_AO_LAUNCH(CNT, W) hipLaunchKernelGGL((k_trace_persist_lane<true, CNT, W, 1>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s, \
-                           scl, n, (const double *)NULL, (const double *)NULL, (uint32_t *)NULL, (double *)NULL, (double *)NULL, \
-                           (double *)NULL, (uint8_t *)NULL, d_counters, d_cursor, min_active, tri_batch, ao)
+                           scl, (uint32_t)n, (const double *)NULL, (const double *)NULL, (uint32_t *)NULL, (double *)NULL, (double *)NULL, \
+                           (double *)NULL, (uint8_t *)NULL, d_counters, (uint32_t *)d_cursor, min_active, tri_batch, ao, fq)
     if (guard) { if (d_counters) LH_AO_LAUNCH(true, 8); else LH_AO_LAUNCH(false, 8); }
     else { if (d_counters) LH_AO_LAUNCH(true, 3); else LH_AO_LAUNCH(false, 3); }
 #undef LH_AO_LAUNCH
     if (hipGetLastError() != hipSuccess) return -1;
-    hipLaunchKernelGGL(k_ao_queue, dim3(64), dim3(256), 0, s, scl, ao, d_counters);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_coop<true, 1>(scl, NULL, NULL, NULL, NULL, NULL, NULL, NULL, ao, fq, q, d_counters, ncus, s);
 }
 
 /* the node formats a launch of `variant` reads on this scene (bit mask, LH_FMT_* in lh_internal.h): so that the commit
@@ -667,17 +963,31 @@ extern "C" int lh_trace_formats_needed(const lh_dev_scene_t *sc, int variant)
 }
 
 /* one batch of rays through the hot path.  variant: LH_VARIANT_SPEC (the default: 4-wide nodes, or the 8-wide nodes when
- * sc->prefer_q8) or LH_VARIANT_DIRECT (the textbook walk over the 2-wide fp32 nodes; needs sc->nodes). */
+ * sc->prefer_q8) or LH_VARIANT_DIRECT (the textbook walk over the 2-wide fp32 nodes; needs sc->nodes).  q: the launch's
+ * fix-up queue with its second stream, private to the stream. */
 extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double *d_org,
                                const double *d_dir, uint32_t *d_prim, double *d_t, double *d_u,
                                double *d_v, int anyhit, uint8_t *d_occluded,
                                unsigned long long *d_counters, unsigned long long *d_workq,
-                               int variant, int grid_blocks, int min_active, int tri_batch, void *stream)
+                               int variant, int grid_blocks, int min_active, int tri_batch,
+                               const lh_fixq_t *q, int ncus, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
     if (n == 0) return 0;
+    /* the persistent kernel indexes rays with 32 bits: a larger batch is a sequence of launches */
+    const size_t kMaxLaunch = (size_t)1 << 30;
+    if (n > kMaxLaunch) {
+        for (size_t off = 0; off < n; off += kMaxLaunch) {
+            const size_t m = (n - off < kMaxLaunch) ? n - off : kMaxLaunch;
+            const int rc = lh_launch_trace(sc, m, d_org + 3 * off, d_dir + 3 * off, d_prim ? d_prim + off : NULL, d_t ? d_t + off : NULL,
+                                           d_u ? d_u + off : NULL, d_v ? d_v + off : NULL, anyhit, d_occluded ? d_occluded + off : NULL,
+                                           d_counters, d_workq, variant, grid_blocks, min_active, tri_batch, q, ncus, stream);
+            if (rc != 0) return rc;
+        }
+        return 0;
+    }
     lh_dev_scene_t scl = *sc;
-    uint32_t need; int walk; bool over_fix = false;
+    uint32_t need; int walk; bool guard = false;
     if (variant == LH_VARIANT_DIRECT) {
         if (!sc->nodes) return -1;
         need = sc->max_depth + 2; walk = 0;          /* 2-wide: one push per level + the sentinel */
@@ -685,32 +995,45 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
         if (need < 16) need = 16;
     } else if (sc->prefer_q8 && sc->q8nodes) {
         /* the 8-wide walk pushes up to 7 per level and keeps a scratch row; beyond 48 rows (three workgroups per CU) the rare
-         * ray that needs them is finished by k_overflow_fix over the 4-wide nodes (always resident) */
+         * ray that needs them is finished by the cooperative walk over the 4-wide nodes (always resident) */
         need = 7 * sc->q8_depth + 10; walk = 7;
         const uint32_t cap = (sc->stack_cap >= 16 && sc->stack_cap < 64) ? sc->stack_cap : 48;
-        if (need > cap) { need = cap; over_fix = true; scl.stack_guard = 1; }
+        if (need > cap) { need = cap; guard = true; }
         need = (need + 1u) & ~1u;
-        if (need < 16 && !over_fix) need = 16;
+        if (need < 16 && !guard) need = 16;
+        scl.stack_guard = guard ? 1 : 0;
     } else {
         /* a very deep tree (chains of nested geometry, an LBVH over a degenerate distribution): the 4-wide walk's worst case
          * does not fit the 64-row LDS stack; a ray that would overrun it (none in practice: the bound is three pushes on
-         * every level) is finished by k_overflow_fix */
+         * every level) is finished by the cooperative walk */
         scl.prefer_q8 = 0;
-        need = rows4(*sc, &over_fix); walk = over_fix ? 8 : 3;
-        scl.stack_guard = over_fix ? 1 : 0;
+        need = rows4(*sc, &guard); walk = guard ? 8 : 3;
+        scl.stack_guard = guard ? 1 : 0;
     }
     if (need > 64) return -1;
     scl.stack_rows = need;
     const size_t lds_bytes = (size_t)need * LH_BLOCK * sizeof(int);
     clamp_chunk(scl, n, grid_blocks);
-    const int rc = launch_walk(scl, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
-                               d_counters, d_workq, walk, grid_blocks, min_active, tri_batch, lds_bytes, s);
+    /* small batches (one synchronous ray, a bucket of lucille's renderer): no visit budget, no second stream -- a ray the walk
+     * cannot finish (LDS rows) stays flagged for k_fixups */
+    const bool coop = walk != 0 && q != NULL && n >= 65536;
+    FixQ fq = {coop ? (unsigned long long *)q->queue : NULL, q ? q->qcount : NULL, coop ? q->qcap : 0u, (uint32_t)grid_blocks * (LH_BLOCK / 64)};
+    if (!coop) scl.ray_budget = 0xFFFFFFFFu;
+    if (walk != 0 && q != NULL && fixq_begin(q, s) != 0) return -1;
+    if (walk != 0 && q == NULL) return -1;
+    int rc = launch_walk(scl, n, d_org, d_dir, d_prim, d_t, d_u, d_v, anyhit, d_occluded,
+                         d_counters, d_workq, walk, grid_blocks, min_active, tri_batch, lds_bytes, fq, s);
     if (rc != 0) return rc;
-    if (over_fix)
-        hipLaunchKernelGGL(k_overflow_fix, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scl, n, d_org, d_dir,
-                           d_prim, d_t, d_u, d_v, d_occluded, anyhit, d_counters);
-    if (sc->ref_nodes)
-        hipLaunchKernelGGL(k_ref_retrace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scl, n, d_org, d_dir,
-                           d_prim, d_t, d_u, d_v, d_occluded, anyhit, d_counters);
+    if (coop) {
+        rc = anyhit ? launch_coop<true, 0>(scl, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occluded, AoSrc{}, fq, q, d_counters, ncus, s)
+                    : launch_coop<false, 0>(scl, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occluded, AoSrc{}, fq, q, d_counters, ncus, s);
+        if (rc != 0) return rc;
+    }
+    /* what is still flagged: fragile hits (the reference's own walk), and out-of-budget rays the queue had no room for */
+    {
+        const size_t blocks = (n + 255) / 256;
+        hipLaunchKernelGGL(k_fixups, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, scl, n, d_org, d_dir,
+                           d_prim, d_t, d_u, d_v, d_occluded, anyhit, d_counters, q ? q->qcount : NULL, (walk == 0 || q == NULL) ? 1 : 0);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

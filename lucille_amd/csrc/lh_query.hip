@@ -20,8 +20,8 @@ __global__ void k_fill_miss(size_t n, uint32_t *prim, double *t, double *u, doub
     if (occ) occ[i] = 0;
 }
 
-/* the fused AO stage's queue for launches on `s`: launches on one stream are ordered, so they share a slot;
- * different streams (replicas' tile loops) get their own */
+/* the fix-up queue for launches on `s`: launches on one stream are ordered, so they share a slot (queue, second stream,
+ * events); different streams (replicas' tile loops, the pipelined host path) get their own */
 int lh_aoq_slot(lh_accel_t *a, hipStream_t s)
 {
     int k, free_k = -1;
@@ -35,9 +35,18 @@ int lh_aoq_slot(lh_accel_t *a, hipStream_t s)
         free_k = 0;
     }
     k = free_k;
-    if (!a->aoq[k].queue) {
-        HIPCHK(hipMalloc((void **)&a->aoq[k].queue, (size_t)LH_AO_QCAP * 2 * sizeof(uint32_t) + 2 * sizeof(uint32_t)));
-        a->aoq[k].qcount = a->aoq[k].queue + (size_t)LH_AO_QCAP * 2;
+    lh_fixq_t *q = &a->aoq[k].q;
+    if (!q->queue) {
+        HIPCHK(hipMalloc(&q->queue, (size_t)LH_AO_QCAP * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc((void **)&q->qcount, 4 * sizeof(uint32_t)));
+        HIPCHK(hipMemset(q->queue, 0, (size_t)LH_AO_QCAP * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(q->qcount, 0, 4 * sizeof(uint32_t)));
+        q->qcap = LH_AO_QCAP;
+        hipStream_t aux; hipEvent_t e0, e1;
+        HIPCHK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        q->aux_stream = (void *)aux; q->ev_ready = (void *)e0; q->ev_done = (void *)e1;
     }
     a->aoq[k].stream = s; a->aoq[k].used = 1;
     return k;
@@ -88,9 +97,17 @@ int lh_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, voi
         if (lh_ensure_formats(a, LH_FMT_Q8) != 0) return -1;
         a->dev.prefer_q8 = 1;
     }
+    /* ray dumps are incoherent by assumption: a wave's iterations serve 64 unrelated rays, a ray's age in iterations runs to
+     * several times its own steps -- the tile pipelines' budget (128) would send half the batch to the cooperative walk */
+    const uint32_t budget_keep = a->dev.ray_budget;
+    if (dump) a->dev.ray_budget = a->dump_budget;
+    const int qk = lh_aoq_slot(a, s);             /* the stream's fix-up queue (rays out of visit budget -> the cooperative walk) */
+    if (qk < 0) { a->dev.ray_budget = budget_keep; return -1; }
     int rc = lh_launch_trace(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim,
                              (double *)d_t, (double *)d_u, (double *)d_v, mode == LH_MODE_ANY,
-                             (uint8_t *)d_occ, d_counters, a->d_cursor + (a->cursor_next++ % LH_NCURSOR), variant, a->grid_blocks, a->min_active, a->tri_batch, (void *)s);
+                             (uint8_t *)d_occ, d_counters, a->d_cursor + (size_t)LH_NPART * (a->cursor_next++ % LH_NCURSOR), variant, a->grid_blocks, a->min_active, a->tri_batch,
+                             &a->aoq[qk].q, a->ncus, (void *)s);
+    a->dev.ray_budget = budget_keep;
     if (rc != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     return 0;
 }

@@ -5,6 +5,7 @@
  * src/render/intersection_state.c:99-248) and the wavefront path tracer's tile loop (src/transport/pathtrace.c:189-314,
  * 407-537).  The kernels are in lh_render.hip / lh_kernels.hip.
  */
+#include <algorithm>
 #include <thread>
 #include <vector>
 
@@ -67,6 +68,10 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
     const bool stage_timing = getenv("LH_STAGE_TIMING") != NULL;
     hipEvent_t ev[6] = {NULL, NULL, NULL, NULL, NULL, NULL};
     if (stage_timing) { for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&ev[k])); HIPCHK(hipEventRecord(ev[0], s)); }
+    /* ... and the wall clock at which every persistent wave starts and leaves (two launches: closest, AO) */
+    const size_t nwaves = (size_t)a->grid_blocks * (LH_BLOCK / 64);
+    if (stage_timing) { if (ensure_buf(&a->r_diag, sizeof(unsigned long long) * 4 * nwaves)) return -1; HIPCHK(hipMemsetAsync(a->r_diag.p, 0, sizeof(unsigned long long) * 4 * nwaves, s)); }
+    a->dev.diag_clock = stage_timing ? (unsigned long long *)a->r_diag.p : NULL;
     /* 1. camera rays */
     if (lh_render_launch_primary_region(cam, x0, w, nbands, band_rows, d_band_y0, y0, cam->height, ps, ps,
                                         (double *)a->r_org.p, (double *)a->r_dir.p, s) != 0)
@@ -75,7 +80,7 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
     /* 2. closest hit */
     if (lh_launch(a, S, a->r_org.p, a->r_dir.p, a->r_prim.p, a->r_t.p, a->r_u.p, a->r_v.p, NULL, LH_MODE_CLOSEST,
                LH_VARIANT_DEFAULT, cnt, s, false) != 0) return -1;
-    if (stage_timing) HIPCHK(hipEventRecord(ev[2], s));
+    if (stage_timing) { HIPCHK(hipEventRecord(ev[2], s)); a->dev.diag_clock = (unsigned long long *)a->r_diag.p + 2 * nwaves; }
     /* 3. count hits (deterministic compaction needs the total before sizing the AO batch) */
     unsigned long long nhit = 0;
     if (a->hs->bvh.ntris) {
@@ -97,21 +102,21 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
     /* AO stage.  Fused (default): the any-hit kernel generates ray (slot, r) in its refill (lh_ao.h) and counts
      * the occluded rays per slot -- nothing per AO ray goes through HBM.  Materialised: caller uniforms (the parity
      * replay), LH_AO_FUSED=0, a scene the lean walk cannot take, or a pending-queue overflow of the fused launch. */
-    bool fused = a->ao_fused && !d_uniforms && nao && nao < ((size_t)1 << 32) &&
-                 ((3 * a->dev.q4_depth + 5 <= 64 && !a->dev.stack_cap) || a->dev.ref_nodes != NULL);     /* deeper: rays whose stack would overflow go to the reference walk */
+    bool fused = a->ao_fused && !d_uniforms && nao && nao < ((size_t)1 << 31);      /* the persistent kernel's 32-bit ray index */
     const bool fused_tried = fused;
     if (fused) {
         if (ensure_buf(&a->r_occcount, (size_t)nhit * sizeof(unsigned int))) return -1;
         const int k = lh_aoq_slot(a, s);
         if (k < 0) return -1;
         if (lh_launch_trace_ao(&a->dev, (size_t)nhit, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const unsigned long long *)a->r_key.p,
-                               (unsigned int *)a->r_occcount.p, cnt, a->d_cursor + (a->cursor_next++ % LH_NCURSOR), a->grid_blocks,
-                               a->min_active, a->tri_batch, a->aoq[k].queue, a->aoq[k].qcount, LH_AO_QCAP, (void *)s) != 0)
+                               (unsigned int *)a->r_occcount.p, cnt, a->d_cursor + (size_t)LH_NPART * (a->cursor_next++ % LH_NCURSOR), a->grid_blocks,
+                               a->min_active, a->tri_batch, &a->aoq[k].q, a->ncus, (void *)s) != 0)
             return fail("fused AO launch failed: %s", hipGetErrorString(hipGetLastError()));
         uint32_t qc[2] = {0, 0};
-        HIPCHK(hipMemcpyAsync(qc, a->aoq[k].qcount, sizeof(qc), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(qc, a->aoq[k].q.qcount, sizeof(qc), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         if (qc[1] != 0) fused = false;             /* more than LH_AO_QCAP uncertain AO rays: redo the stage materialised */
+        if (stage_timing) fprintf(stderr, "[lucille_hip]   fused AO stage: %u rays through the fix-up queue (budget %u)\n", qc[0], a->dev.ray_budget);
     }
     if (nao && !fused) {
         if (ensure_buf(&a->r_aorg, nao * 24) || ensure_buf(&a->r_adir, nao * 24) || ensure_buf(&a->r_occ, nao)) return -1;
@@ -139,6 +144,21 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
         fprintf(stderr, "[lucille_hip] AO batch stages (ms): primary %.3f closest %.3f compact %.3f ao %.3f resolve %.3f | samples %zu hits %llu ao rays %zu\n",
                 ms[0], ms[1], ms[2], ms[3], ms[4], S, nhit, nao);
         for (int k = 0; k < 6; k++) (void)hipEventDestroy(ev[k]);
+        std::vector<unsigned long long> clk(4 * nwaves);
+        HIPCHK(hipMemcpy(clk.data(), a->r_diag.p, sizeof(unsigned long long) * 4 * nwaves, hipMemcpyDeviceToHost));
+        for (int launch = 0; launch < 2; launch++) {
+            const unsigned long long *st = clk.data() + 2 * nwaves * launch, *ex = st + nwaves;
+            unsigned long long t0 = ~0ull; std::vector<double> e;
+            for (size_t w = 0; w < nwaves; w++) if (st[w] && st[w] < t0) t0 = st[w];
+            for (size_t w = 0; w < nwaves; w++) if (ex[w]) e.push_back((double)(ex[w] - t0) * 1e-5);        /* 100 MHz -> ms */
+            if (e.empty()) continue;
+            std::sort(e.begin(), e.end());
+            auto q = [&](double f) { return e[(size_t)(f * (e.size() - 1))]; };
+            double last_start = 0; for (size_t w = 0; w < nwaves; w++) if (st[w]) last_start = fmax(last_start, (double)(st[w] - t0) * 1e-5);
+            fprintf(stderr, "[lucille_hip]   %s kernel: %zu waves, last start %.3f ms; exits (ms) min %.3f p10 %.3f p50 %.3f p90 %.3f p99 %.3f max %.3f\n",
+                    launch ? "AO" : "closest", e.size(), last_start, e.front(), q(0.10), q(0.50), q(0.90), q(0.99), e.back());
+        }
+        a->dev.diag_clock = NULL;
     }
     a->r_nsamples = S; a->r_nslots = (size_t)nhit; a->r_nao = fused ? 0 : nao;
     if (cnt) {

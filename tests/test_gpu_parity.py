@@ -439,3 +439,67 @@ def test_wide_walk_is_chosen_by_footprint():
     small = make_accel(*po.soup(20000, 10, 0.01, 3)[:2])
     assert small.dump_node_bytes() == 64
     small.close()
+
+
+@pytest.mark.parametrize("budget", [1, 3, 17])
+def test_cooperative_walk_keeps_every_bit(budget):
+    """set_param("ray_budget", b): a ray that visits more than b nodes leaves the persistent kernel and is finished by the
+    wave-cooperative walk (one wave per ray, idle lanes take over the bottom of busy lanes' stacks; per-lane bests merged with
+    the reference's tie rule).  With tiny budgets nearly every ray takes that path: records must stay the oracle's bits --
+    seeded soups, exact-t ties on a shared-edge grid, vertex-aimed rays, a deep chain, any-hit, and the 8-wide nodes."""
+    import torch
+    from tests.helpers import chain_scene, vertex_aimed_rays
+    def check(P, idx, org, dr, label, wide8=0, expect_coop=False):
+        o = po.Oracle(); o.add_mesh(P, idx); o.build()
+        exp = o.intersect(org, dr, nthreads=16)
+        acc = make_accel(P, idx); acc.set_param("wide8", wide8); acc.set_param("ray_budget", budget)
+        do = torch.from_numpy(org).cuda(); dd = torch.from_numpy(dr).cuda()
+        out, c = acc.intersect_device(do, dd, counters=True)
+        assert c["retraced"] > 0.2 * org.shape[0] or not expect_coop, (label, c)          # the cooperative walk really ran
+        assert_hits_equal(tuple(x.cpu().numpy().view(np.uint32) if k == 0 else x.cpu().numpy() for k, x in enumerate(out)), exp, label)
+        assert np.array_equal(gpu_any(acc, org, dr, la.VARIANT_DEFAULT).astype(bool), exp[0] != po.MISS), label
+        for n in (1, 63, 65):
+            assert_hits_equal(gpu_closest(acc, org[:n], dr[:n], la.VARIANT_DEFAULT), tuple(x[:n] for x in exp), label + " ragged")
+        acc.close()
+    P, idx, org, dr = po.soup(60000, 120000, 0.01, 8)
+    check(P, idx, org, dr, "soup b%d" % budget, expect_coop=True)
+    check(P, idx, org, dr, "soup 8-wide b%d" % budget, wide8=1, expect_coop=budget < 10)
+    P, idx, org, dr = po.soup(3000, 40000, 0.08, 9)            # fat triangles: many candidates per ray
+    check(P, idx, org, dr, "fat soup b%d" % budget)
+    P, idx = grid_mesh(8, 8)                                   # shared vertices / edges: exact-t ties across lanes' subtrees
+    org, dr = random_rays(np.random.default_rng(3), 20000)
+    check(P, idx, org, dr, "grid b%d" % budget)
+    vo, vd = vertex_aimed_rays(np.random.default_rng(5), P, idx, 20000)
+    check(P, idx, vo, vd, "grid vertex-aimed b%d" % budget)
+    P, idx = chain_scene(40)
+    org, dr = random_rays(np.random.default_rng(6), 20000, lo=-1.0, hi=2.0)
+    check(P, idx, org, dr, "chain b%d" % budget)
+
+
+def test_cooperative_walk_in_the_fused_ao_stage():
+    """the AO frame must not depend on the visit budget: tiny budgets send most AO rays through the fix-up queue and the
+    cooperative walk (SRC 1: rays regenerated from (slot, sample)); a queue that overflows falls back to the materialised
+    stage -- same frame bit for bit"""
+    import torch
+    from lucille_amd import render, scenes
+    g = load_golden("ao_c1")
+    acc = la.HipAccel(0)
+    for k in range(int(g["ngeoms"])):
+        P, I = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], 3); acc.add_mesh(P, I)
+    acc.commit()
+    c = g["camera"]; cam = la.Camera.make(200, 150, c[16], c[:16], int(c[19]))
+    ref_img, ref_stats = render.render_ao_frame(acc, cam, 2, 16, tile=200, seed=5)
+    for budget in (2, 9, 40):
+        acc.set_param("ray_budget", budget)
+        img, stats = render.render_ao_frame(acc, cam, 2, 16, tile=200, seed=5)
+        torch.cuda.synchronize()
+        assert stats == ref_stats and torch.equal(img, ref_img), budget
+    acc.set_param("ray_budget", 1)                 # 960 k AO rays, all out of budget: fits the queue (2^20)
+    big = la.Camera.make(400, 300, c[16], c[:16], int(c[19]))
+    acc.set_param("ray_budget", 256)
+    ref_big, st_big = render.render_ao_frame(acc, big, 2, 16, tile=400, seed=5)
+    acc.set_param("ray_budget", 1)                 # ~4 M AO rays out of budget: the queue overflows -> materialised stage
+    img, stats = render.render_ao_frame(acc, big, 2, 16, tile=400, seed=5)
+    torch.cuda.synchronize()
+    assert stats == st_big and torch.equal(img, ref_big)
+    acc.close()
