@@ -126,9 +126,9 @@ def main():
     ap.add_argument("--no-pt", action="store_true", help="skip the secondary path-traced leg")
     ap.add_argument("--pt-size", type=int, default=2048)      # BASELINE config 4: 2048 x 2048, 256 spp
     ap.add_argument("--pt-spp", type=int, default=256)
-    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--backend", default=None, help="accepted for compatibility: torch.distributed is the launcher only (gloo control plane), device data moves through lh_dist_* = RCCL")
     ap.add_argument("--device-override", type=int, default=None,
-                    help="testing only: put every rank on this device (2 ranks on a 1-GPU box, use with --backend gloo)")
+                    help="testing only: put every rank on this device (2 ranks on a 1-GPU box: the shared-memory transport of lh_dist_*)")
     ap.add_argument("--ao-size", type=int, default=4096)
     ap.add_argument("--ao-samples", type=int, default=64)
     ap.add_argument("--ao-tess", type=int, default=8, help="midpoint-subdivision levels of the example scene (4^n x 322 triangles; 8 -> 21.1 M = BASELINE config 5's '>= 10 M', 7 -> 5.3 M)")
@@ -145,15 +145,15 @@ def main():
 
     if args.device_override is not None:
         os.environ["LH_DEVICE_OVERRIDE"] = str(args.device_override)
-    rank, world, local = shard.init_process_group(backend=args.backend)
-    assert world == args.gpus, "launch with --nproc-per-node == --gpus"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    # torch.distributed is the launcher (gloo control plane); device data moves through lh_dist_* in the C ABI (RCCL over xGMI)
+    rank, world, local = shard.init_process_group(backend=args.backend)
+    assert world == args.gpus, "launch with --nproc-per-node == --gpus"
     if args.device_override is not None:
         local = args.device_override
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    nccl = world > 1 and torch.distributed.get_backend() == "nccl"
 
     # ---- synthetic inputs: the scene on every rank, this rank's slice of the dump -> HBM ----
     P, idx, st_after_tris = scenes.soup_triangles(args.tris, args.half_extent)
@@ -163,9 +163,9 @@ def main():
     d_org, d_dir, first = upload_rays(scenes, torch, dev, scenes.skip(st_after_tris, 5 * b0), n,
                                       keep_first=args.cpu_rays if rank == 0 else 0)
 
+    # ONE host build (rank 0), then the flattened scene into every rank's HBM: ncclBroadcast
     acc = la.HipAccel(local)
-    acc.add_mesh(P, idx)
-    info = acc.commit()
+    info, commit_s, bcast_s = shard.commit_shared(acc, lambda a: a.add_mesh(P, idx), rank, world)
 
     mode = la.MODE_CLOSEST if args.mode == "closest" else la.MODE_ANY
     rec_bytes = 28 if mode == la.MODE_CLOSEST else 1
@@ -182,8 +182,8 @@ def main():
 
     gathered = None
     if world > 1 and rank == 0:
-        gathered = [[torch.empty(per * rec_bytes, dtype=torch.uint8, device=dev if nccl else "cpu") for _ in range(world)]
-                    for _ in range(nchunks)]
+        gathered = [torch.empty((world, per * rec_bytes), dtype=torch.uint8, device=dev) for _ in range(nchunks)]
+    gstream = torch.cuda.Stream(device=dev) if world > 1 else None       # the exchange step's own stream: chunk c on the links while chunk c + 1 is traced
 
     hip = hip_events()
     stream = torch.cuda.current_stream(dev)
@@ -191,7 +191,6 @@ def main():
     evp = EventPairs(hip, (args.steps + args.warmup + 2) * nchunks)
 
     def one_step(timed):
-        works = []
         for c in range(nchunks):
             (o, m) = outs_of(c)
             if m > 0:
@@ -203,13 +202,14 @@ def main():
                 if timed:
                     evp.end(sptr)
             if world > 1:
-                works.append(shard.gather_bytes(bufs[c], gathered[c] if rank == 0 else None, async_op=True))
-        for w in works:
-            shard.wait(w)
+                gstream.wait_stream(stream)
+                shard.gather_bytes(bufs[c], gathered[c] if rank == 0 else None, stream=gstream)
+        if world > 1:
+            stream.wait_stream(gstream)
 
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            shard.barrier()
 
     one_step(False)                                   # allocations, lazy uploads (untimed)
     torch.cuda.synchronize(dev)
@@ -237,10 +237,7 @@ def main():
     kernel_ms = float(np.sum(kms)) / max(1, args.steps)            # per step, this rank's launches together
 
     if world > 1:
-        rdev = dev if nccl else torch.device("cpu")
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = shard.all_reduce_max(elapsed)
 
     # ---- validation of the timed launches (rank 0) --------------------------------
     validation = None
@@ -293,6 +290,9 @@ def main():
                                                                       "" if world == 1 else ", 28-B hit records gathered to rank 0 inside the timed region"),
                        "rays": n_total, "rays_per_gpu": n, "triangles": args.tris, "mode": args.mode,
                        "variant": args.variant, "parallelism": "replicated BVH, ray slices x%d%s" % (world, "" if world == 1 else ", %d-chunk trace/gather pipeline" % nchunks),
+                       "scene_load": {"rank0_commit_s": round(commit_s, 3), "broadcast_s": round(bcast_s, 3) if world > 1 else None,
+                                      "transport": None if world == 1 else ("rccl" if shard.dist().transport == la.DIST_RCCL else "shm (ranks share a device)"),
+                                      "note": "one host build on rank 0, flattened arrays broadcast to every rank (lh_dist_broadcast_scene)"},
                        "bvh": {"nodes": info["nnodes_traversal"], "depth": info["max_depth"], "device_bytes": info["device_bytes"],
                                "build_s": round(info["build_seconds"], 3), "ref_tree_build_s": round(info["ref_build_seconds"], 3)}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -325,6 +325,8 @@ def main():
         print(json.dumps(res), flush=True)
     acc.close()
     if world > 1:
+        shard.barrier()
+        shard.dist().close()
         torch.distributed.destroy_process_group()
 
 
@@ -355,8 +357,7 @@ def validate_dump(torch, la, args, mode, outs_of, cb, cnt_out, ns, gathered, wor
     if world > 1:
         ok = True
         for c in range(len(cb)):
-            own = gathered[c][0].to(bufs[c].device)
-            ok &= bool(torch.equal(own, bufs[c]))
+            ok &= bool(torch.equal(gathered[c][0], bufs[c]))
             if mode == la.MODE_CLOSEST:
                 for r in range(world):
                     p = gathered[c][r][24 * per:28 * per].view(torch.int32)
@@ -464,29 +465,30 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
     import torch
     from lucille_amd import render, scenes
     g = np.load(os.path.join(ROOT, "tests", "golden", "ao_c1.npz"))
+    from lucille_amd import shard
     acc = la.HipAccel(acc_device)
-    ntri = 0
-    for k in range(int(g["ngeoms"])):
-        P_, I_ = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess)
-        acc.add_mesh(P_, I_); ntri += I_.shape[0] // 3
-        del P_, I_
-    t0c = time.perf_counter(); info = acc.commit(); commit_host_s = time.perf_counter() - t0c
+    ntri = sum(int(g["idx%d" % k].shape[0]) // 3 for k in range(int(g["ngeoms"]))) * 4 ** tess
+    def add_meshes(a):
+        for k in range(int(g["ngeoms"])):
+            P_, I_ = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess)
+            a.add_mesh(P_, I_)
+            del P_, I_
+    # ONE build (rank 0: tessellation + commit), then the broadcast of the flattened scene to every rank
+    t0c = time.perf_counter(); info, commit_s, bcast_s = shard.commit_shared(acc, add_meshes, rank, world); commit_host_s = time.perf_counter() - t0c
     c = g["camera"]
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
     # one GPU: the whole frame as one tile; sharded: full-width bands, ~16 per rank, band_id % world, ONE device batch per rank (render.bands_for / lh_render_ao_bands)
     tile = None if world > 1 else min(size, 4096)
     times = []; st = None; img = None; stats = []
     for it in range(steps + 1):
-        if world > 1:
-            torch.distributed.barrier()
+        shard.barrier()
         torch.cuda.synchronize(dev); t0 = time.perf_counter()
         if world > 1:
             img, st = render.render_ao_frame_sharded(acc, cam, 1, nsamples, rank, world)
         else:
             img, st = render.render_ao_frame(acc, cam, 1, nsamples, tile=tile)
         torch.cuda.synchronize(dev)
-        if world > 1:
-            torch.distributed.barrier()
+        shard.barrier()
         stats.append(dict(st))
         if it > 0:
             times.append(time.perf_counter() - t0)
@@ -528,13 +530,9 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
                 "image_bit_equal": bool(torch.equal(img_d, img)) and dict(st_d) == stats[0]}
         ok = ok and devb["image_bit_equal"]
         acc_d.close(); del img_d
-    rdev = dev if (world == 1 or torch.distributed.get_backend() == "nccl") else torch.device("cpu")
-    rays = torch.tensor([st["primary_rays"] + st["ao_rays"]], dtype=torch.float64, device=rdev)
-    tmax = torch.tensor([min(times)], dtype=torch.float64, device=rdev)
-    okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=rdev)
-    if world > 1:
-        torch.distributed.all_reduce(rays); torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        torch.distributed.all_reduce(okt, op=torch.distributed.ReduceOp.MIN)
+    rays_all = shard.all_reduce_sum(float(st["primary_rays"] + st["ao_rays"])) if world > 1 else float(st["primary_rays"] + st["ao_rays"])
+    t_all = shard.all_reduce_max(min(times)) if world > 1 else min(times)
+    ok_all = (shard.all_reduce_min(1.0 if ok else 0.0) if world > 1 else (1.0 if ok else 0.0)) > 0.5
     acc.close()
     if rank != 0:
         return None
@@ -544,11 +542,12 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
                 len(render.bands_for(size, world)[1]), render.bands_for(size, world)[0], world),
             "device_bytes": info["device_bytes"], "build_s": round(info["build_seconds"], 3),
             "ref_tree_build_s": round(info["ref_build_seconds"], 3),
-            "rays_per_frame": int(rays.item()), "frame_ms": round(tmax.item() * 1e3, 3),
-            "value": round(rays.item() / tmax.item() / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
+            "scene_load": {"rank0_commit_s": round(commit_s, 3), "broadcast_s": round(bcast_s, 3) if world > 1 else None},
+            "rays_per_frame": int(rays_all), "frame_ms": round(t_all * 1e3, 3),
+            "value": round(rays_all / t_all / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
             "image_mean": float(img.mean().item()), "roofline": roof, "device_build": devb,
-            "validation": {"frames_repeat": bool(okt.item() > 0.5), "retiled_frame_bit_equal": bool(ok) if world == 1 else None,
-                           "primary_hits": int(stats[0]["primary_hits"]) if world == 1 else None, "ok": bool(okt.item() > 0.5)}}
+            "validation": {"frames_repeat": ok_all, "retiled_frame_bit_equal": bool(ok) if world == 1 else None,
+                           "primary_hits": int(stats[0]["primary_hits"]) if world == 1 else None, "ok": ok_all}}
 
 
 def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
@@ -558,18 +557,19 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
     import torch
     from lucille_amd import render
     g = np.load(os.path.join(ROOT, "tests", "golden", "ao_ps.npz"))
+    from lucille_amd import shard
     acc = la.HipAccel(acc_device)
-    for k in range(int(g["ngeoms"])):
-        acc.add_mesh(g["pos%d" % k], g["idx%d" % k])
-        if ("nrm%d" % k) in g.files:
-            acc.set_normals(k, g["nrm%d" % k], int(g["two_side%d" % k]))
-    acc.commit()
+    def add_meshes(a):
+        for k in range(int(g["ngeoms"])):
+            a.add_mesh(g["pos%d" % k], g["idx%d" % k])
+            if ("nrm%d" % k) in g.files:
+                a.set_normals(k, g["nrm%d" % k], int(g["two_side%d" % k]))
+    shard.commit_shared(acc, add_meshes, rank, world)
     c = g["camera"]
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
     times = []; st = None; img = None; first = None; repeat = True
     for it in range(3):
-        if world > 1:
-            torch.distributed.barrier()
+        shard.barrier()
         torch.cuda.synchronize(dev); t0 = time.perf_counter()
         pt_tile = size if world == 1 else max(128, size // 4)
         # paths per pass: as many as a third of the free HBM holds (~170 B of path state each; 288 GB -> 512 M paths, 128 spp of a
@@ -583,8 +583,7 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
         img, st = render.render_pt_frame_sharded(acc, cam, spp, rank, world, tile=pt_tile, spp_chunk=chunk,
                                                  kd=0.8, env=(1.0, 1.0, 1.0), max_vertices=8, seed=7)
         torch.cuda.synchronize(dev)
-        if world > 1:
-            torch.distributed.barrier()
+        shard.barrier()
         if it > 0:
             times.append(time.perf_counter() - t0)
         if rank == 0:
@@ -619,18 +618,15 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
                 "rays_counted": c["rays"],
                 "note": "1 986 triangles: the tree is L2-resident; the frame is a chain of ~110 dependent launches per pass (trace, decide, "
                         "scan, emit per bounce), the trace kernel is 59 % of the kernel time (profiles/r02d_pt_kernel_stats.csv)"}
-    rdev = dev if (world == 1 or torch.distributed.get_backend() == "nccl") else torch.device("cpu")
-    rays = torch.tensor([float(st["rays"])], dtype=torch.float64, device=rdev)
-    tmax = torch.tensor([min(times)], dtype=torch.float64, device=rdev)
-    if world > 1:
-        torch.distributed.all_reduce(rays); torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    rays_all = shard.all_reduce_sum(float(st["rays"])) if world > 1 else float(st["rays"])
+    t_all = shard.all_reduce_max(min(times)) if world > 1 else min(times)
     acc.close()
     if rank != 0:
         return None
     return {"workload": "examples/plane_sphere (1986 tris, vertex normals), %dx%d, %d spp, <=8 path vertices, kd 0.8, frame wall incl. ray gen, shading, compaction, tile gather"
                         % (size, size, spp),
-            "rays_per_frame": int(rays.item()), "frame_ms": round(tmax.item() * 1e3, 3),
-            "value": round(rays.item() / tmax.item() / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
+            "rays_per_frame": int(rays_all), "frame_ms": round(t_all * 1e3, 3),
+            "value": round(rays_all / t_all / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
             "spp_per_pass": chunk, "paths_per_pass": chunk * pt_tile * pt_tile,
             "image_mean": float(img.mean().item()), "roofline": roof,
             # white furnace with albedo 0.8 under a unit environment: every pixel's radiance lies in (0, 1]

@@ -282,6 +282,39 @@ int  lh_multi_render_ao_frame_host(lh_multi_t *multi, const lh_camera_t *cam, in
 int  lh_multi_render_pt_frame_host(lh_multi_t *multi, const lh_camera_t *cam, int spp, int spp_chunk, int max_path_vertices,
                                    int flags, uint64_t seed, int tile, float *rgb, lh_pt_stats_t *stats, double *device_seconds);
 
+/* ---- one process per GPU: lucille's compiled-out MPI layer over RCCL ----
+ * reference: ri_parallel_init / _barrier / _bcast / _gather / _send / _recv (src/base/parallel.c:62-232) and the frame
+ * protocol on top of it, "every rank renders, rank 0 owns the display" (src/render/render.c:468-514).  One lh_dist_t per
+ * process = one rank = one GPU.  Scene load: ONE host build on rank 0, then ncclBroadcast of the flattened arrays into
+ * every rank's HBM (lh_dist_broadcast_scene).  Frames: image space in interleaved bands, a rank's bands one device batch,
+ * ONE exchange step -- ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd of the ranks' slabs to rank 0.  RCCL is loaded at
+ * run time (librccl.so.1).  LH_DIST_SHM: the same interface over a POSIX shared-memory segment, for ranks that share a
+ * device (RCCL refuses those): how the N > 1 path is tested on a one-GPU box.
+ * Rendezvous: the caller distributes the 128-byte id of rank 0 (lh_dist_unique_id) by its own means (torch.distributed, MPI),
+ * or names a file on a shared file system (lh_dist_init_file: a fresh path per job). */
+typedef struct lh_dist lh_dist_t;
+#define LH_DIST_ID_BYTES 128
+#define LH_DIST_RCCL 0
+#define LH_DIST_SHM  1
+int  lh_dist_unique_id(void *id128);                                        /* rank 0: ncclGetUniqueId */
+int  lh_dist_init(lh_dist_t **out, const void *id128, int rank, int world, int device, int transport);   /* ncclCommInitRank */
+int  lh_dist_init_file(lh_dist_t **out, const char *rendezvous_path, int rank, int world, int device);
+void lh_dist_destroy(lh_dist_t *dist);
+int  lh_dist_rank(const lh_dist_t *dist);
+int  lh_dist_world(const lh_dist_t *dist);
+int  lh_dist_transport(const lh_dist_t *dist);
+int  lh_dist_barrier(lh_dist_t *dist);
+/* device buffers; stream NULL: the communicator's own.  gather: d_recv (rank 0 only) holds world * bytes */
+int  lh_dist_broadcast(lh_dist_t *dist, void *d_buf, size_t bytes, void *stream);
+int  lh_dist_gather(lh_dist_t *dist, const void *d_send, size_t bytes, void *d_recv, void *stream);
+/* rank 0: a committed accelerator; the others: a fresh one (lh_accel_create), committed on return -- no build, no host
+ * copy of the tree on those ranks (lh_accel_export and replicas of it are refused) */
+int  lh_dist_broadcast_scene(lh_dist_t *dist, lh_accel_t *accel);
+/* the AO frame sharded over the ranks: bands of band_rows lines (<= 0: 4), band_id % world == rank; rgb (rank 0 only): height
+ * rows of width RGB floats, top row first; stats: the frame's totals on rank 0, the rank's own elsewhere */
+int  lh_dist_render_ao_frame_host(lh_dist_t *dist, lh_accel_t *accel, const lh_camera_t *cam, int pixel_samples,
+                                  int gather_nsamples, uint64_t seed, int band_rows, float *rgb, lh_tile_stats_t *stats);
+
 /* device scratch of the last lh_render_ao_tile call (for tests / pipelines):
  * which: 0 primary org, 1 primary dir, 2 prim, 3 t, 4 u, 5 v, 6 slot_of_sample,
  *        7 hit records (12 doubles: AO origin, tangent, binormal, Ns), 8 AO org, 9 AO dir,

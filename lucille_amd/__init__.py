@@ -19,5 +19,5 @@ every query fails loudly when no HIP device is visible.
 from .binding import (Camera, HipAccel, LucilleHipError, MISS, MODE_ANY, MODE_CLOSEST,  # noqa: F401
                       VARIANT_DEFAULT, VARIANT_DIRECT,
                       VARIANT_SPEC, build_library, device_count, library_path,
-                      HipMulti, Material, Environment, ALL_MESHES, PT_REFERENCE_WEIGHTS, ATTR_COLOR, ATTR_TANGENT, ATTR_BINORMAL,
+                      HipMulti, HipDist, DIST_RCCL, DIST_SHM, Material, Environment, ALL_MESHES, PT_REFERENCE_WEIGHTS, ATTR_COLOR, ATTR_TANGENT, ATTR_BINORMAL,
                       ATTR_TEXCOORD, ATTR_TEXCOORD_UNSHARED, STATE_DOUBLES)

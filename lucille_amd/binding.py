@@ -108,6 +108,8 @@ ABI_SYMBOLS = [
     "lh_multi_add_rib_scene", "lh_multi_commit", "lh_multi_set_material", "lh_multi_set_environment", "lh_multi_intersect_host",
     "lh_multi_render_ao_frame_host", "lh_multi_render_pt_frame_host",
     "lh_synth_soup_triangles", "lh_synth_soup_rays", "lh_synth_tessellate", "lh_synth_skip",
+    "lh_dist_unique_id", "lh_dist_init", "lh_dist_init_file", "lh_dist_destroy", "lh_dist_rank", "lh_dist_world", "lh_dist_transport",
+    "lh_dist_barrier", "lh_dist_broadcast", "lh_dist_gather", "lh_dist_broadcast_scene", "lh_dist_render_ao_frame_host",
 ]
 
 _lib = None
@@ -406,6 +408,15 @@ class HipAccel:
                "lh_render_ao_tile")
         return out, {k: int(getattr(st, k)) for k, _ in st._fields_}
 
+    def render_ao_frame_host(self, cam, pixel_samples, gather_nsamples, seed=1, tile=0):
+        """lh_render_ao_frame_host: the whole frame into host memory -> (float32 [H, W, 3] numpy, top row first; stats)"""
+        rgb = np.empty((cam.height, cam.width, 3), np.float32)
+        st = TileStats()
+        self.L.lh_render_ao_frame_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+        _check(self.L.lh_render_ao_frame_host(self.h, C.byref(cam), int(pixel_samples), int(gather_nsamples), int(seed), int(tile),
+                                              rgb.ctypes.data, C.byref(st)), "lh_render_ao_frame_host")
+        return rgb, {k: int(getattr(st, k)) for k, _ in st._fields_}
+
     def render_ao_bands(self, cam, band_y0, band_rows, pixel_samples, gather_nsamples, seed=1, out=None, stream=None):
         """full-width bands (first lines band_y0, band_rows lines each) as ONE device batch ->
         (float32 [nbands, band_rows, W, 3] CUDA tensor, every band in image orientation, stats)"""
@@ -585,3 +596,77 @@ class HipMulti:
                                                     int(seed), int(tile), rgb.ctypes.data, C.byref(st), secs),
                "lh_multi_render_pt_frame_host")
         return rgb, {k: int(getattr(st, k)) for k, _ in st._fields_}, list(secs)
+
+
+DIST_RCCL, DIST_SHM = 0, 1
+
+
+class HipDist:
+    """lh_dist_t: this process as one rank of a one-process-per-GPU job (RCCL over xGMI through the C ABI; DIST_SHM when the
+    ranks share a device).  Rendezvous: `unique_id()` on rank 0 + any out-of-band channel (torch.distributed's store), or a
+    fresh file path."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * 128)()
+        _check(lib().lh_dist_unique_id(buf), "lh_dist_unique_id")
+        return bytes(buf)
+
+    def __init__(self, rank, world, device, unique_id=None, rendezvous=None, transport=DIST_RCCL):
+        self.L = lib(); self.h = C.c_void_p()
+        self.L.lh_dist_init.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        self.L.lh_dist_init_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        if rendezvous is not None:
+            _check(self.L.lh_dist_init_file(C.byref(self.h), str(rendezvous).encode(), int(rank), int(world), int(device)), "lh_dist_init_file")
+        else:
+            assert unique_id is not None and len(unique_id) == 128
+            _check(self.L.lh_dist_init(C.byref(self.h), bytes(unique_id), int(rank), int(world), int(device), int(transport)), "lh_dist_init")
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        self.transport = int(self.L.lh_dist_transport(self.h))
+        _live.add(self)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.lh_dist_destroy.argtypes = [C.c_void_p]
+            self.L.lh_dist_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def barrier(self):
+        self.L.lh_dist_barrier.argtypes = [C.c_void_p]
+        _check(self.L.lh_dist_barrier(self.h), "lh_dist_barrier")
+
+    def broadcast(self, tensor, stream=None):
+        """in-place broadcast of a CUDA tensor from rank 0"""
+        self.L.lh_dist_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        _check(self.L.lh_dist_broadcast(self.h, tensor.data_ptr(), tensor.numel() * tensor.element_size(), stream), "lh_dist_broadcast")
+        return tensor
+
+    def gather(self, tensor, stream=None):
+        """equal-sized contiguous CUDA tensors to rank 0 -> [world, ...] there, None elsewhere"""
+        import torch
+        t = tensor.contiguous()
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device) if self.rank == 0 else None
+        self.L.lh_dist_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        _check(self.L.lh_dist_gather(self.h, t.data_ptr(), t.numel() * t.element_size(), out.data_ptr() if out is not None else None, stream), "lh_dist_gather")
+        torch.cuda.synchronize(t.device)
+        return out
+
+    def broadcast_scene(self, acc):
+        """rank 0: a committed HipAccel; other ranks: a fresh one (committed on return: no build on those ranks)"""
+        self.L.lh_dist_broadcast_scene.argtypes = [C.c_void_p, C.c_void_p]
+        _check(self.L.lh_dist_broadcast_scene(self.h, acc.h), "lh_dist_broadcast_scene")
+        return acc
+
+    def render_ao_frame(self, acc, cam, pixel_samples, gather_nsamples, seed=1, band_rows=0):
+        """-> (frame [H, W, 3] float32 numpy on rank 0 | None, stats)"""
+        rgb = np.empty((cam.height, cam.width, 3), np.float32) if self.rank == 0 else None
+        st = TileStats()
+        self.L.lh_dist_render_ao_frame_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+        _check(self.L.lh_dist_render_ao_frame_host(self.h, acc.h, C.byref(cam), int(pixel_samples), int(gather_nsamples), int(seed), int(band_rows),
+                                                   rgb.ctypes.data if rgb is not None else None, C.byref(st)), "lh_dist_render_ao_frame_host")
+        return rgb, {"primary_rays": st.primary_rays, "primary_hits": st.primary_hits, "ao_rays": st.ao_rays, "ao_occluded": st.ao_occluded}

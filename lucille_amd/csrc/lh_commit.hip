@@ -442,6 +442,24 @@ int lh_sync_ref(lh_accel_t *a, bool wait)
     return attach_ref(a);
 }
 
+/* persistent workgroups per launch: as many as the LDS stack rows of this scene let a CU hold (at most 5) */
+static int size_grid(lh_accel_t *a)
+{
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, a->device));
+    uint32_t need = 3 * a->hs->bvh.q4_depth + 5;
+    if (need > 64) need = 64;
+    uint32_t stack = (need + 1u) & ~1u;
+    if (stack < 16) stack = 16;
+    int per_cu = (int)(160u / stack);                     /* LDS: stack KiB per 256-thread workgroup */
+    if (per_cu > 5) per_cu = 5;
+    if (per_cu < 1) per_cu = 1;
+    a->grid_blocks = prop.multiProcessorCount * per_cu; a->ncus = prop.multiProcessorCount;
+    const char *env = getenv("LH_GRID_BLOCKS");
+    if (env && atoi(env) > 0) a->grid_blocks = atoi(env);
+    return 0;
+}
+
 /* ---- device replica of the host scene (once per GPU) ---------------------------------------- */
 static int device_upload(lh_accel_t *a)
 {
@@ -511,20 +529,7 @@ static int device_upload(lh_accel_t *a)
         if (lh_ensure_formats(a, LH_FMT_Q16X4) != 0) return -1;
     }
     a->upload_seconds = now_s() - t0;
-    {
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, a->device));
-        uint32_t need = 3 * hs->bvh.q4_depth + 5;
-        if (need > 64) need = 64;
-        uint32_t stack = (need + 1u) & ~1u;
-        if (stack < 16) stack = 16;
-        int per_cu = (int)(160u / stack);                     /* LDS: stack KiB per 256-thread workgroup */
-        if (per_cu > 5) per_cu = 5;
-        if (per_cu < 1) per_cu = 1;
-        a->grid_blocks = prop.multiProcessorCount * per_cu; a->ncus = prop.multiProcessorCount;
-        const char *env = getenv("LH_GRID_BLOCKS");
-        if (env && atoi(env) > 0) a->grid_blocks = atoi(env);
-    }
+    if (size_grid(a) != 0) return -1;
     a->committed = 1;
     return 0;
 }
@@ -583,6 +588,7 @@ extern "C" int lh_accel_wait_exact(lh_accel_t *a)
 extern "C" int lh_accel_commit_replica(lh_accel_t *dst, lh_accel_t *src)
 {
     if (!dst || !src || !src->committed) return fail("lh_accel_commit_replica: source not committed");
+    if (src->hs->received) return fail("lh_accel_commit_replica: the source scene was received from another rank (no host copy to replicate)");
     lh_guard guard(dst);
     if (dst->committed || dst->commit_failed || dst->nmeshes) return fail("lh_accel_commit_replica: destination is not a fresh accelerator");
     pthread_mutex_lock(&g_scene_mu);
@@ -683,6 +689,130 @@ extern "C" int lh_accel_export(const lh_accel_t *a, void *nodes, void *tri32)
     if (tri32 && a->hs->bvh.ntris) memcpy(tri32, a->hs->bvh.tri32, sizeof(lh_tri32_t) * (size_t)a->hs->bvh.ntris);
     return 0;
 }
+
+/* ------------------------------------------------------------------------ */
+/* the scene image: what one rank's commit hands the other ranks (lh_dist.hip) */
+/* ------------------------------------------------------------------------ */
+/* ONE host build, then a broadcast of the flattened arrays into every GPU's HBM.  The image is a header
+ * (lh_scene_image_t), the device arrays in a fixed order (lh_scene_image_arrays) and two host arrays (primitive ->
+ * mesh ordinal / index, for lh_accel_prim_lookup and the materials).  A receiver has no host tree and no host
+ * triangles: it cannot spawn replicas or upload other node formats, everything else works. */
+int lh_scene_image_header(lh_accel_t *a, lh_scene_image_t *h)
+{
+    if (!a || !a->committed) return fail("scene image: accel not committed");
+    if (lh_sync_ref(a, true) != 0) return -1;           /* a device-built scene: lucille's own tree must be attached */
+    const lh_host_scene *hs = a->hs;
+    memset(h, 0, sizeof(*h));
+    h->magic = 0x4C48494Du;
+    h->ntris = hs->bvh.ntris; h->nnodes = hs->bvh.nnodes; h->max_depth = hs->bvh.max_depth; h->nleaves = hs->bvh.nleaves;
+    h->nq4 = hs->bvh.nq4nodes; h->q4_depth = hs->bvh.q4_depth;
+    h->nq8 = a->d_q8nodes ? a->dev.nq8nodes : 0; h->q8_depth = a->d_q8nodes ? a->dev.q8_depth : 0;
+    h->nmeshes = hs->nmeshes;
+    h->have_ref = a->d_ref_nodes != NULL; h->ref_nnodes = a->dev.ref_nnodes; h->ref_empty = a->dev.ref_empty;
+    h->has_nrm = a->d_nrm9 != NULL; h->has_st = a->d_st6 != NULL; h->has_inside = a->d_inside != NULL;
+    for (int k = 0; k < 3; k++) {
+        h->has_attr[k] = a->d_attr9[k] != NULL;
+        h->bmin[k] = hs->bvh.bmin[k]; h->bmax[k] = hs->bvh.bmax[k]; h->grid_lo[k] = hs->bvh.grid_lo[k]; h->grid_step[k] = hs->bvh.grid_step[k];
+        h->ref_bmin[k] = a->dev.ref_bmin[k]; h->ref_bmax[k] = a->dev.ref_bmax[k];
+    }
+    h->build_seconds = hs->bvh.build_seconds; h->ref_build_seconds = hs->ref_build_seconds;
+    return 0;
+}
+
+/* the device arrays of the image, same order on the sender and on a receiver that ran lh_scene_image_alloc */
+int lh_scene_image_arrays(lh_accel_t *a, const lh_scene_image_t *h, void **ptr, size_t *bytes, int cap)
+{
+    int n = 0;
+    const size_t nt = h->ntris;
+#define LH_IMG(P, B) do { if (n < cap) { ptr[n] = (P); bytes[n] = (B); } n++; } while (0)
+    if (nt) {
+        LH_IMG(a->d_tri32, sizeof(lh_tri32_t) * nt + 64); LH_IMG(a->d_tri64, sizeof(lh_tri64_t) * nt);
+        LH_IMG(a->d_q4nodes, sizeof(lh_q4node_t) * (size_t)h->nq4);
+        if (h->nq8) LH_IMG(a->d_q8nodes, sizeof(lh_q8node_t) * (size_t)h->nq8);
+        if (h->have_ref) {
+            LH_IMG(a->d_ref_lca, sizeof(int) * 4 * (size_t)h->ref_nnodes); LH_IMG(a->d_prim_leafpos, sizeof(uint32_t) * 2 * nt);
+            LH_IMG(a->d_ref_nodes, sizeof(lh_refnode_t) * (size_t)h->ref_nnodes); LH_IMG(a->d_ref_leaf_prims, sizeof(uint32_t) * nt);
+        }
+        if (h->has_nrm) LH_IMG(a->d_nrm9, sizeof(double) * 9 * nt);
+        for (int k = 0; k < 3; k++) if (h->has_attr[k]) LH_IMG(a->d_attr9[k], sizeof(double) * 9 * nt);
+        if (h->has_st) LH_IMG(a->d_st6, sizeof(double) * 6 * nt);
+        if (h->has_inside) LH_IMG(a->d_inside, nt);
+    }
+#undef LH_IMG
+    return n;
+}
+
+/* host side of the image: prim -> mesh ordinal, prim -> 3 * i (ntris uint32 each) */
+uint32_t *lh_scene_image_prim_geom(lh_accel_t *a) { return a->hs->bvh.prim_geom; }
+uint32_t *lh_scene_image_prim_index(lh_accel_t *a) { return a->hs->bvh.prim_index; }
+
+/* a fresh accelerator becomes the receiving end: device arrays allocated as the header says */
+int lh_scene_image_alloc(lh_accel_t *a, const lh_scene_image_t *h)
+{
+    if (!a || a->committed || a->commit_failed || a->nmeshes) return fail("scene image: the receiver must be a fresh accelerator");
+    if (h->magic != 0x4C48494Du) return fail("scene image: bad header");
+    lh_guard guard(a);
+    lh_host_scene *hs = a->hs;
+    a->commit_failed = 1;
+    HIPCHK(hipSetDevice(a->device));
+    HIPCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(unsigned long long) * LH_NPART * LH_NCURSOR));
+    HIPCHK(hipMalloc((void **)&a->d_counters, sizeof(unsigned long long) * LH_CNT_DEV));
+    HIPCHK(hipMalloc((void **)&a->d_total, sizeof(unsigned long long) * 4));
+    hs->received = 1; hs->device_built = 1;              /* no host tree: the walks over other node formats are not available */
+    hs->bvh.ntris = h->ntris; hs->bvh.nnodes = h->nnodes; hs->bvh.max_depth = h->max_depth; hs->bvh.nleaves = h->nleaves;
+    hs->bvh.nq4nodes = h->nq4; hs->bvh.q4_depth = h->q4_depth; hs->nmeshes = h->nmeshes;
+    hs->bvh.build_seconds = h->build_seconds; hs->ref_build_seconds = h->ref_build_seconds;
+    hs->have_ref = h->have_ref; hs->ref_state = h->have_ref ? 2 : 0;
+    float r = 0.0f;
+    for (int k = 0; k < 3; k++) {
+        hs->bvh.bmin[k] = h->bmin[k]; hs->bvh.bmax[k] = h->bmax[k]; hs->bvh.grid_lo[k] = h->grid_lo[k]; hs->bvh.grid_step[k] = h->grid_step[k];
+        a->dev.grid_lo[k] = h->grid_lo[k]; a->dev.grid_step[k] = h->grid_step[k];
+        a->dev.ref_bmin[k] = h->ref_bmin[k]; a->dev.ref_bmax[k] = h->ref_bmax[k];
+        r = fmaxf(r, fabsf(h->bmin[k])); r = fmaxf(r, fabsf(h->bmax[k]));
+    }
+    const size_t nt = h->ntris;
+    a->device_bytes = 0;
+    if (nt) {
+        hs->bvh.prim_geom = (uint32_t *)malloc(sizeof(uint32_t) * nt); hs->bvh.prim_index = (uint32_t *)malloc(sizeof(uint32_t) * nt);
+        if (!hs->bvh.prim_geom || !hs->bvh.prim_index) return fail("out of memory");
+        HIPCHK(hipMalloc(&a->d_tri32, sizeof(lh_tri32_t) * nt + 64)); HIPCHK(hipMalloc(&a->d_tri64, sizeof(lh_tri64_t) * nt));
+        HIPCHK(hipMalloc(&a->d_q4nodes, sizeof(lh_q4node_t) * (size_t)h->nq4));
+        if (h->nq8) HIPCHK(hipMalloc(&a->d_q8nodes, sizeof(lh_q8node_t) * (size_t)h->nq8));
+        if (h->have_ref) {
+            HIPCHK(hipMalloc(&a->d_ref_lca, sizeof(int) * 4 * (size_t)h->ref_nnodes)); HIPCHK(hipMalloc(&a->d_prim_leafpos, sizeof(uint32_t) * 2 * nt));
+            HIPCHK(hipMalloc(&a->d_ref_nodes, sizeof(lh_refnode_t) * (size_t)h->ref_nnodes)); HIPCHK(hipMalloc(&a->d_ref_leaf_prims, sizeof(uint32_t) * nt));
+        }
+        if (h->has_nrm) HIPCHK(hipMalloc(&a->d_nrm9, sizeof(double) * 9 * nt));
+        for (int k = 0; k < 3; k++) if (h->has_attr[k]) HIPCHK(hipMalloc(&a->d_attr9[k], sizeof(double) * 9 * nt));
+        if (h->has_st) HIPCHK(hipMalloc(&a->d_st6, sizeof(double) * 6 * nt));
+        if (h->has_inside) HIPCHK(hipMalloc(&a->d_inside, nt));
+        a->dev.tri32 = a->d_tri32; a->dev.tri64 = a->d_tri64; a->dev.q4nodes = a->d_q4nodes;
+        a->dev.q8nodes = a->d_q8nodes; a->dev.nq8nodes = h->nq8; a->dev.q8_depth = h->q8_depth;
+        a->dev.ntris = h->ntris; a->dev.nnodes = h->nnodes; a->dev.max_depth = h->max_depth; a->dev.scene_r = r; a->dev.ray_chunk = a->ray_chunk;
+        a->dev.nq4nodes = h->nq4; a->dev.q4_depth = h->q4_depth;
+        if (h->have_ref) {
+            a->dev.ref_lca = a->d_ref_lca; a->dev.prim_leafpos = a->d_prim_leafpos; a->dev.ref_nodes = a->d_ref_nodes;
+            a->dev.ref_leaf_prims = a->d_ref_leaf_prims; a->dev.ref_nnodes = h->ref_nnodes; a->dev.ref_empty = h->ref_empty;
+        }
+        void *ptr[32]; size_t bytes[32];
+        const int n = lh_scene_image_arrays(a, h, ptr, bytes, 32);
+        for (int k = 0; k < n; k++) a->device_bytes += bytes[k];
+    }
+    return 0;
+}
+
+/* ... and, once the arrays have arrived, a committed replica */
+int lh_scene_image_finish(lh_accel_t *a)
+{
+    if (!a || !a->hs->received || a->committed) return fail("scene image: not a receiving accelerator");
+    HIPCHK(hipSetDevice(a->device));
+    if (size_grid(a) != 0) return -1;
+    a->upload_seconds = 0.0;
+    a->committed = 1; a->commit_failed = 0;
+    return 0;
+}
+
 
 /* fill miss results without touching the scene (empty accel) */
 extern "C" int lh_accel_add_rib_scene(lh_accel_t *a, const lh_rib_scene_t *scene)

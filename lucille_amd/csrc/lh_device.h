@@ -74,7 +74,7 @@ extern "C" {
  * stream its consumer runs on, concurrently with the launch that fills it */
 typedef struct lh_fixq {
     void     *queue;          /* qcap x u64 (device), zero = empty slot */
-    uint32_t *qcount;         /* [0] appends, [1] overflow flag, [2] producer waves that have left (device) */
+    uint32_t *qcount;         /* [0] appends, [1] overflow flag, [2] producer waves that have left, [4 ..] consumer heads (device) */
     uint32_t  qcap;
     void     *aux_stream;     /* hipStream_t */
     void     *ev_ready, *ev_done;     /* hipEvent_t: queue reset on the launch stream; consumer finished */

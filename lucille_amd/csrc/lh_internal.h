@@ -55,6 +55,7 @@ struct lh_host_scene {
     /* device build (lh_build.hip): the host holds the flattened primitives only; the reference-order tree is built by a
      * background thread and attached to the replicas when it is ready (ref_state: 0 none, 1 building, 2 ready, -1 failed) */
     int device_built;
+    int received;             /* the scene arrived as an image from another rank (lh_dist.hip): device arrays only */
     int ref_state; pthread_t ref_thread; int ref_thread_live; int ref_threads;
 };
 extern pthread_mutex_t g_scene_mu;
@@ -134,6 +135,19 @@ int  lh_ensure_formats(lh_accel_t *a, int mask);
 int  lh_sync_ref(lh_accel_t *a, bool wait);          /* attach the background-built reference-order tree (wait: block for it) */
 int  lh_ensure_buf(lh_buf *b, size_t bytes);
 void lh_free_buf(lh_buf *b);
+/* the scene image (lh_commit.hip): one rank's committed scene handed to the others (lh_dist.hip) */
+typedef struct lh_scene_image {
+    uint32_t magic, ntris, nnodes, max_depth, nleaves, nq4, q4_depth, nq8, q8_depth, ref_nnodes, nmeshes;
+    int      have_ref, ref_empty, has_nrm, has_attr[3], has_st, has_inside;
+    float    bmin[3], bmax[3], grid_lo[3], grid_step[3];
+    double   ref_bmin[3], ref_bmax[3], build_seconds, ref_build_seconds;
+} lh_scene_image_t;
+int  lh_scene_image_header(lh_accel_t *a, lh_scene_image_t *h);
+int  lh_scene_image_arrays(lh_accel_t *a, const lh_scene_image_t *h, void **ptr, size_t *bytes, int cap);
+uint32_t *lh_scene_image_prim_geom(lh_accel_t *a);
+uint32_t *lh_scene_image_prim_index(lh_accel_t *a);
+int  lh_scene_image_alloc(lh_accel_t *a, const lh_scene_image_t *h);
+int  lh_scene_image_finish(lh_accel_t *a);
 /* lh_query.hip */
 int  lh_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, void *d_prim, void *d_t, void *d_u, void *d_v,
                void *d_occ, int mode, int variant, unsigned long long *d_counters, hipStream_t s, bool dump);

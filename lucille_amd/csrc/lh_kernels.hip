@@ -324,10 +324,12 @@ __device__ __forceinline__ void write_out(size_t i, const Lane &L, const Best &b
  * fragile hit of the fused AO stage, the reference's own walk decides; LH_Q_COOP: out of visit budget / LDS stack rows,
  * k_coop_walk finishes it.  The consumer (k_coop_walk) runs CONCURRENTLY on a second stream: an entry is one agent-scope
  * atomic store into a slot that was zero, qcount[0] counts the appends (it may pass qcap: the entries beyond are not stored
- * and qcount[1] is set), qcount[2] counts the producer waves that have left (release: their entries are visible). */
+ * and qcount[1] is set), qcount[2] counts the producer waves that have left (release: their entries are visible),
+ * qcount[4 ..] holds the consumer groups' next entries. */
 #define LH_Q_REF  5u
 #define LH_Q_COOP 6u
-struct FixQ { unsigned long long *queue; uint32_t *qcount; uint32_t qcap, nprod; };
+struct FixQ { unsigned long long *queue; uint32_t *qcount; uint32_t qcap, nprod; uint32_t *heads; };
+#define LH_Q_GROUPS 4096u           /* consumer groups at most (4 per wave, one wave per CU and a few) */
 
 __device__ __forceinline__ bool fixq_push(const FixQ &q, size_t i, uint32_t reason)
 {
@@ -345,6 +347,7 @@ __global__ __launch_bounds__(256) void k_fixq_reset(unsigned long long *queue, u
 {
     const uint32_t used = qcount[0] < qcap ? qcount[0] : qcap;
     for (uint32_t k = threadIdx.x; k < used; k += 256) queue[k] = 0ull;
+    for (uint32_t k = threadIdx.x; k < LH_Q_GROUPS; k += 256) qcount[4 + k] = k;       /* heads: group g starts at entry g */
     __syncthreads();
     if (threadIdx.x < 3) qcount[threadIdx.x] = 0u;
 }
@@ -593,10 +596,13 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
     const int lane = threadIdx.x, g = lane >> 4;
     const unsigned long long gmask = 0xFFFFull << (16 * g), lt_mask = (1ull << lane) - 1ull;
     const uint32_t ngroups = gridDim.x * 4u;
-    uint32_t e = blockIdx.x * 4u + (uint32_t)g;       /* the group's next queue entry */
+    const uint32_t gid = blockIdx.x * 4u + (uint32_t)g;
+    uint32_t e = fq.heads[gid];                       /* the group's next queue entry: gid, gid + ngroups, ... (the sweep resumes where the concurrent pass left) */
     bool have = false;                                /* the group holds a ray */
     bool gdone = e >= fq.qcap;                        /* the group has seen the end of the queue */
     uint32_t known = 0, look = 0;                     /* wave-uniform: the append count at the wave's last look; iterations since */
+    bool prod_done = false;                           /* wave-uniform: every producer wave was seen to have left */
+    unsigned long long progress = wall_clock64();     /* when this wave last took an entry / saw the producer finish */
     size_t i = 0; double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1; uint32_t selfp = LH_MISS_PRIM;
     Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM, 0u};
     int pend = kNoLeaf, floor_ = 1; uint32_t cn = 0, ct = 0, ce = 0;
@@ -645,12 +651,15 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
             /* the producer may still be running.  `known` is the wave's last look at the append count (refreshed rarely: every
              * look is a load of ONE word that 256 waves share); a slot below it is, or is about to be, non-zero */
             unsigned long long ent = 0ull;
-            if (!gdone && e < known) ent = __hip_atomic_load(fq.queue + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!gdone && e < known) {
+                ent = __hip_atomic_load(fq.queue + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (ent != 0ull) {
                 const uint32_t reason = (uint32_t)(ent >> 56);
                 i = (size_t)(ent & 0x00FFFFFFFFFFFFFFull);
                 e += ngroups;
                 if (e >= fq.qcap) gdone = true;
+                progress = wall_clock64();
                 if (SRC == 0) {
                     ox = org[3 * i]; oy = org[3 * i + 1]; oz = org[3 * i + 2]; dx = dir[3 * i]; dy = dir[3 * i + 1]; dz = dir[3 * i + 2];
                 } else {
@@ -681,8 +690,12 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
         const bool wave_idle = __ballot(have) == 0ull;
         if (wave_idle || (++look & 127u) == 0u) {
             if (wave_idle) {
-                if (__ballot(!gdone && e < known) != 0ull) continue;        /* a slot below the known count: it is being written */
                 if (__ballot(!gdone) == 0ull) break;                          /* the queue has ended for every group */
+                /* never wait for ever: if the producer makes no progress for half a second (it may not be running at all: two
+                 * streams can share a hardware queue, and then this kernel runs in front of it) leave -- the sweep launched
+                 * behind the producer takes what is left */
+                if (wall_clock64() - progress > 50000000ull) break;
+                if (__ballot(!gdone && e < known) != 0ull) { __builtin_amdgcn_s_sleep(16); continue; }     /* a slot below the known count: being written, or skipped above */
                 for (int k = 0; k < 8; k++) __builtin_amdgcn_s_sleep(127);
             }
             uint32_t left = 0, cnt = 0;
@@ -692,7 +705,10 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
             }
             left = (uint32_t)__shfl((int)left, 0); cnt = (uint32_t)__shfl((int)cnt, 0);
             known = cnt < fq.qcap ? cnt : fq.qcap;
-            if (left >= fq.nprod && e >= known) gdone = true;      /* every producer wave has left (acquire): the count is final */
+            if (left >= fq.nprod) {                                /* every producer wave has left (acquire): the count is final */
+                if (!prod_done) { prod_done = true; progress = wall_clock64(); continue; }      /* one more look at the count, now final */
+                if (e >= known) gdone = true;
+            }
             if (wave_idle) continue;
         }
         if (L.cur >= 0) node_step4<false, 64, true>(L, pend, sc, stk, lane, cn, rmask);
@@ -728,6 +744,7 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
             __syncthreads();
         }
     }
+    if ((lane & 15) == 0) fq.heads[gid] = e;          /* where the sweep (or nobody) goes on */
 }
 
 /* ------------------------------------------------------------------------ */
@@ -900,13 +917,17 @@ int launch_coop(const lh_dev_scene_t &sc, const double *org, const double *dir, 
         attr_set[ANYHIT][SRC] = true;
     }
     hipStream_t aux = (hipStream_t)q->aux_stream;
-    const int grid = ncus > 0 ? ncus : 256;                /* one wave per workgroup and CU, 4 rays per wave */
+    int grid = ncus > 0 ? ncus : 256;                      /* one wave per workgroup and CU, 4 rays per wave */
+    if (grid * 4 > (int)LH_Q_GROUPS) grid = (int)LH_Q_GROUPS / 4;
     if (hipStreamWaitEvent(aux, (hipEvent_t)q->ev_ready, 0) != hipSuccess) return -1;
     hipLaunchKernelGGL((k_coop_walk<ANYHIT, SRC>), dim3(grid), dim3(64), lds, aux, scl, org, dir, prim, t, u, v, occ, ao, fq, counters);
     if (hipGetLastError() != hipSuccess) return -1;
     if (hipEventRecord((hipEvent_t)q->ev_done, aux) != hipSuccess) return -1;
     if (hipStreamWaitEvent(s, (hipEvent_t)q->ev_done, 0) != hipSuccess) return -1;
-    return 0;
+    /* the sweep: the same kernel behind the producer, on its stream -- whatever the concurrent pass did not take (nothing, when it
+     * ran next to the producer: 256 waves read two words and leave) */
+    hipLaunchKernelGGL((k_coop_walk<ANYHIT, SRC>), dim3(grid), dim3(64), lds, s, scl, org, dir, prim, t, u, v, occ, ao, fq, counters);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 /* the queue back to empty (stream-ordered), and the point the consumer's stream waits for */
@@ -940,7 +961,7 @@ extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int n
     if (scl.ray_chunk < 512) scl.ray_chunk = 512;      /* AO rays of a slot are coherent: longer ranges per wave (config 5: 92.9 -> 91.4 ms, tools/ao_sweep5.py) */
     clamp_chunk(scl, n, grid_blocks);
     AoSrc ao = {d_hitrec, d_slot_key, d_occ_count, seed, ntheta, nphi};
-    FixQ fq = {(unsigned long long *)q->queue, q->qcount, q->qcap, (uint32_t)grid_blocks * (LH_BLOCK / 64)};
+    FixQ fq = {(unsigned long long *)q->queue, q->qcount, q->qcap, (uint32_t)grid_blocks * (LH_BLOCK / 64), q->qcount + 4};
     if (hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long) * LH_NPART, s) != hipSuccess) return -1;
     if (hipMemsetAsync(d_occ_count, 0, sizeof(unsigned int) * nslots, s) != hipSuccess) return -1;
     if (fixq_begin(q, s) != 0) return -1;
@@ -1017,7 +1038,7 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
     /* small batches (one synchronous ray, a bucket of lucille's renderer): no visit budget, no second stream -- a ray the walk
      * cannot finish (LDS rows) stays flagged for k_fixups */
     const bool coop = walk != 0 && q != NULL && n >= 65536;
-    FixQ fq = {coop ? (unsigned long long *)q->queue : NULL, q ? q->qcount : NULL, coop ? q->qcap : 0u, (uint32_t)grid_blocks * (LH_BLOCK / 64)};
+    FixQ fq = {coop ? (unsigned long long *)q->queue : NULL, q ? q->qcount : NULL, coop ? q->qcap : 0u, (uint32_t)grid_blocks * (LH_BLOCK / 64), q ? q->qcount + 4 : NULL};
     if (!coop) scl.ray_budget = 0xFFFFFFFFu;
     if (walk != 0 && q != NULL && fixq_begin(q, s) != 0) return -1;
     if (walk != 0 && q == NULL) return -1;

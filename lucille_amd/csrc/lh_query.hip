@@ -38,9 +38,9 @@ int lh_aoq_slot(lh_accel_t *a, hipStream_t s)
     lh_fixq_t *q = &a->aoq[k].q;
     if (!q->queue) {
         HIPCHK(hipMalloc(&q->queue, (size_t)LH_AO_QCAP * sizeof(unsigned long long)));
-        HIPCHK(hipMalloc((void **)&q->qcount, 4 * sizeof(uint32_t)));
+        HIPCHK(hipMalloc((void **)&q->qcount, (4 + 4096) * sizeof(uint32_t)));       /* counters + the consumer groups' heads (LH_Q_GROUPS) */
         HIPCHK(hipMemset(q->queue, 0, (size_t)LH_AO_QCAP * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(q->qcount, 0, 4 * sizeof(uint32_t)));
+        HIPCHK(hipMemset(q->qcount, 0, (4 + 4096) * sizeof(uint32_t)));
         q->qcap = LH_AO_QCAP;
         hipStream_t aux; hipEvent_t e0, e1;
         HIPCHK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));

@@ -4,9 +4,9 @@ The reference decomposes a frame into independent 32x32 buckets pulled from a
 queue by worker threads (lucille src/render/render.c:582-710,1043-1105) and its
 (compiled-out) MPI design is "every rank renders, rank 0 owns the display"
 (render.c:468-514, src/base/parallel.c:101-119).  Here: one process per GPU
-(torch.distributed, backend "nccl" == RCCL over xGMI), the BVH replicated in
-every GPU's HBM (each rank builds the same deterministic tree; no broadcast
-needed), units sharded with NO per-ray communication:
+(launched by torch.distributed.run; data through lh_dist_* in the C ABI = RCCL over
+xGMI), the BVH replicated in every GPU's HBM (ONE host build on rank 0, then a
+broadcast of the flattened arrays), units sharded with NO per-ray communication:
 
   * ray dumps   -> contiguous slices            (ray_slice)
   * image tiles -> tile_id % world == rank      (tiles_of_rank)
@@ -42,63 +42,124 @@ def tiles_of_rank(ntiles, rank, world):
     return list(range(rank, ntiles, world))
 
 
-def init_process_group(backend=None):
-    """env:// rendezvous as launched by torch.distributed.run; returns (rank, world, local_rank)."""
+_DIST = None      # this process's lh_dist_t (binding.HipDist) when world > 1
+
+
+def dist():
+    """the C-ABI communicator of this rank (RCCL over xGMI; shared memory when ranks share a device), or None at world 1"""
+    return _DIST
+
+
+def init_process_group(backend=None, device=None):
+    """env:// rendezvous as launched by torch.distributed.run; returns (rank, world, local_rank).
+
+    torch.distributed is the LAUNCHER only: a gloo group carries the control plane (the 128-byte RCCL id, barriers, the
+    max-over-ranks of a timing).  Everything that moves device data -- the scene broadcast, the gather of hit records and
+    tile slabs -- goes through lh_dist_* in the C ABI (ncclBroadcast / grouped ncclSend + ncclRecv), the same entry points
+    `lsh_hip --rank R --world N` uses without Python.  `backend` is accepted for compatibility and ignored."""
+    global _DIST
     import torch
-    import torch.distributed as dist
+    import torch.distributed as tdist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        # N ranks on one host: each builds its BVH replica with its share of the cores, not all of them
-        # (lh_accel_commit reads LH_BUILD_THREADS when build_threads <= 0)
-        os.environ.setdefault("LH_BUILD_THREADS", str(max(1, (os.cpu_count() or 1) // world)))
-    if world > 1 and not dist.is_initialized():
+    if world > 1 and not tdist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LH_DEVICE_OVERRIDE", local)))
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        tdist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if world > 1 and _DIST is None and torch.cuda.is_available():
+        from . import binding
+        dev = int(os.environ.get("LH_DEVICE_OVERRIDE", local if device is None else device))
+        devs = [None] * world
+        tdist.all_gather_object(devs, dev)
+        shared = len(set(devs)) < world                       # one node: equal ordinals = one GPU (tests on a one-GPU box)
+        transport = binding.DIST_SHM if shared or os.environ.get("LH_DIST_TRANSPORT") == "shm" else binding.DIST_RCCL
+        ids = [binding.HipDist.unique_id() if (rank == 0 and transport == binding.DIST_RCCL) else (os.urandom(128) if rank == 0 else None)]
+        tdist.broadcast_object_list(ids, src=0)
+        torch.cuda.set_device(dev)
+        _DIST = binding.HipDist(rank, world, dev, unique_id=ids[0], transport=transport)
     return rank, world, local
 
 
-def gather_bytes(buf, dst_list, async_op=False):
-    """the exchange step: every rank's `buf` (same size everywhere) lands in rank 0's dst_list[r]
-    (None on the other ranks).  RCCL: seven point-to-point transfers into rank 0 (xGMI is a full mesh:
-    they run in parallel, one link each), enqueued behind the work already on the current stream;
-    with async_op the caller keeps tracing the next chunk while this one is on the links.
-    gloo (CPU tests, 2 ranks on one GPU): staged through the host, synchronous.
-    Returns a handle for wait()."""
-    import torch.distributed as dist
-    if dist.get_world_size() == 1:
-        return None
-    if dist.get_backend() == "nccl":
-        return dist.gather(buf, dst_list, dst=0, async_op=async_op)
-    hb = buf.cpu() if buf.is_cuda else buf
-    dist.gather(hb, dst_list, dst=0)
-    return None
+def commit_shared(acc, add_meshes, rank, world, **commit_kw):
+    """ONE host build: rank 0 stages the meshes (add_meshes(acc)) and commits, the flattened scene is broadcast into every
+    rank's HBM (lh_dist_broadcast_scene).  -> (info dict, seconds spent in rank 0's commit, seconds in the broadcast)"""
+    import time
+    t0 = time.perf_counter()
+    if rank == 0 or world == 1:
+        add_meshes(acc)
+        acc.commit(**commit_kw)
+    t1 = time.perf_counter()
+    if world > 1:
+        _DIST.broadcast_scene(acc)
+    return acc.info(), t1 - t0, time.perf_counter() - t1
 
 
-def wait(work):
-    if work is not None:
-        work.wait()
+def barrier():
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized():
+        tdist.barrier()
+
+
+def all_reduce_max(x):
+    """max over the ranks of a Python float (control plane)"""
+    import torch, torch.distributed as tdist
+    if not (tdist.is_available() and tdist.is_initialized()):
+        return x
+    t = torch.tensor([x], dtype=torch.float64); tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_reduce_sum(x):
+    import torch, torch.distributed as tdist
+    if not (tdist.is_available() and tdist.is_initialized()):
+        return x
+    t = torch.tensor([x], dtype=torch.float64); tdist.all_reduce(t)
+    return float(t.item())
+
+
+def all_reduce_min(x):
+    import torch, torch.distributed as tdist
+    if not (tdist.is_available() and tdist.is_initialized()):
+        return x
+    t = torch.tensor([x], dtype=torch.float64); tdist.all_reduce(t, op=tdist.ReduceOp.MIN)
+    return float(t.item())
+
+
+def gather_bytes(buf, dst, stream=None):
+    """the exchange step: every rank's `buf` (same size everywhere, CUDA) lands in rank 0's dst[r] (dst: a [world, nbytes]
+    CUDA tensor on rank 0, None elsewhere).  RCCL: N - 1 point-to-point transfers into rank 0 in one group (xGMI is a full
+    mesh: they run in parallel, one link each), enqueued on `stream` (a torch.cuda.Stream; default: the current one) behind
+    the work already there -- the caller keeps tracing the next chunk on its own stream."""
+    import torch
+    if not buf.is_cuda:
+        # the CPU tests of the host logic (world-size-2 gloo, no GPU): the same exchange through torch.distributed
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1:
+            tdist.gather(buf, [dst[r] for r in range(tdist.get_world_size())] if dst is not None else None, dst=0)
+        return
+    if _DIST is None:
+        return
+    s = stream if stream is not None else torch.cuda.current_stream(buf.device)
+    L = _DIST.L
+    import ctypes as C
+    L.lh_dist_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    rc = L.lh_dist_gather(_DIST.h, buf.data_ptr(), buf.numel() * buf.element_size(), dst.data_ptr() if dst is not None else None, s.cuda_stream)
+    if rc != 0:
+        from . import binding
+        raise binding.LucilleHipError("lh_dist_gather: " + L.lh_last_error().decode())
 
 
 def gather_slabs(slab, rank, world):
-    """every rank's slab tensor (same shape everywhere) -> list of `world` tensors on rank 0, None elsewhere.
-    The display owner is rank 0 (the reference's compiled-out MPI design: "everyone renders, rank 0 owns the display",
-    render.c:468-514): a GATHER -- seven point-to-point xGMI transfers landing on rank 0 in parallel -- not an
+    """every rank's slab tensor (same shape everywhere) -> a [world, ...] tensor on rank 0 (indexable like a list), None
+    elsewhere.  The display owner is rank 0 (the reference's compiled-out MPI design: "everyone renders, rank 0 owns the
+    display", render.c:468-514): a GATHER -- seven point-to-point xGMI transfers landing on rank 0 in parallel -- not an
     all-gather whose ring would carry every slab past every GPU."""
-    import torch
-    import torch.distributed as dist
     if world == 1:
         return [slab]
-    if dist.get_backend() != "nccl" and slab.is_cuda:          # gloo (tests): stage through the host
-        hp = slab.cpu(); ho = [torch.empty_like(hp) for _ in range(world)] if rank == 0 else None
-        dist.gather(hp, ho, dst=0)
-        return [t.to(slab.device) for t in ho] if rank == 0 else None
-    out = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
-    dist.gather(slab, out, dst=0)
-    return out
+    if not slab.is_cuda:                  # CPU tests of the assembly logic: gloo
+        import torch, torch.distributed as tdist
+        out = torch.empty((world,) + tuple(slab.shape), dtype=slab.dtype) if rank == 0 else None
+        tdist.gather(slab.contiguous(), [out[r] for r in range(world)] if rank == 0 else None, dst=0)
+        return out
+    return _DIST.gather(slab)

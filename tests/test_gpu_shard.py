@@ -1,5 +1,6 @@
 """N > 1 on a ONE-GPU box, the torch.distributed way (one process per rank, as bench.py / the driver launch it): two
-ranks share cuda:0 (gloo for the exchange step), each with its own replica of the BVH.  The sharded AO and path-traced
+ranks share cuda:0 (lh_dist_* over its shared-memory transport for the scene broadcast and the exchange step; gloo is the
+control plane only), each with its own replica of the BVH -- built ONCE, on rank 0.  The sharded AO and path-traced
 frames gathered on rank 0 must equal the unsharded frame bit for bit, and bench.py's own N = 2 code path (strong-scaling
 ray dump with the hit-record gather inside the timed region, sharded AO / PT legs) must validate itself."""
 import json
@@ -32,11 +33,14 @@ def _worker(rank, world, port, q):
     torch.cuda.set_device(0)
     g = load_golden("ao_ps")
     acc = la.HipAccel(0)
-    for k in range(int(g["ngeoms"])):
-        acc.add_mesh(g["pos%d" % k], g["idx%d" % k])
-        if ("nrm%d" % k) in g.files:
-            acc.set_normals(k, g["nrm%d" % k], int(g["two_side%d" % k]))
-    acc.commit()
+    def add_meshes(a):
+        for k in range(int(g["ngeoms"])):
+            a.add_mesh(g["pos%d" % k], g["idx%d" % k])
+            if ("nrm%d" % k) in g.files:
+                a.set_normals(k, g["nrm%d" % k], int(g["two_side%d" % k]))
+    # rank 0 builds, rank 1 receives the flattened scene (lh_dist_broadcast_scene; shared-memory transport: one GPU)
+    info, _, _ = shard.commit_shared(acc, add_meshes, rank, world)
+    assert shard.dist().transport == la.DIST_SHM and info["ntriangles"] == 1986
     c = g["camera"]
     cam = la.Camera.make(200, 150, c[16], c[:16], int(c[19]))        # 150 lines: the last band is clipped
     out = {}
@@ -56,6 +60,7 @@ def _worker(rank, world, port, q):
         out["pt"] = bool(torch.allclose(pimg, ref, rtol=0, atol=1e-6))
         q.put(out)
     dist.barrier()
+    shard.dist().close()
     acc.close()
     dist.destroy_process_group()
 

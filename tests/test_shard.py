@@ -1,6 +1,6 @@
-"""N>1 path on CPU: world_size-2 gloo processes exercise the sharding and the one
-exchange step (all-gather of tile slabs to the display owner) used by
-lucille_amd.render / bench.py on RCCL."""
+"""N>1 path on CPU: world_size-2 gloo processes exercise the host logic of the sharding -- slices, chunks, the
+placement of gathered tile slabs on the display owner -- that lucille_amd.render / bench.py run on top of the
+C-ABI exchange (lh_dist_*: RCCL on a GPU node; tests/test_gpu_dist.py, test_gpu_shard.py cover that side)."""
 import os
 import socket
 
@@ -94,19 +94,15 @@ def _dump_worker(rank, world, port, n, nchunks, q):
     slice of one dump (here: a function of the absolute ray id), chunk by chunk, and rank 0 gathers them"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     shard.init_process_group(backend="gloo")
-    assert os.environ["LH_BUILD_THREADS"] == str(max(1, (os.cpu_count() or 1) // world))
     b0, b1 = shard.ray_slice(n, rank, world)
     per = shard.chunk_capacity(n, world, nchunks)
-    got = [[torch.zeros(per * 4, dtype=torch.uint8) for _ in range(world)] for _ in range(nchunks)] if rank == 0 else None
-    works = []
+    got = [torch.zeros((world, per * 4), dtype=torch.uint8) for _ in range(nchunks)] if rank == 0 else None
     for c in range(nchunks):
         lo, hi = b0 + c * per, min(b1, b0 + (c + 1) * per)
         rec = torch.full((per,), -1, dtype=torch.int32)
         if hi > lo:
             rec[:hi - lo] = torch.arange(lo, hi, dtype=torch.int32) * 3 + 1
-        works.append(shard.gather_bytes(rec.view(torch.uint8), got[c] if rank == 0 else None, async_op=True))
-    for w in works:
-        shard.wait(w)
+        shard.gather_bytes(rec.view(torch.uint8), got[c] if rank == 0 else None)
     if rank == 0:
         out = np.full(n, -7, np.int64)
         for r in range(world):
