@@ -40,7 +40,14 @@ struct BNode {              /* inner node of the binary radix tree */
     int parent;
     uint32_t first, last;   /* range of sorted positions it covers */
     float lo[3], hi[3];
+    float cost;             /* SAH cost of the cheapest way to finish this subtree (k_refit) */
+    int leaf;               /* 1: cheapest as ONE leaf of its <= 4 primitives */
 };
+
+/* SAH constants of the collapse decision: a triangle step of the walk against a node step (both one record fetch and ~100
+ * instructions; the triangle pass runs at lower lane use) */
+#define LH_SAH_CT 1.2f
+#define LH_SAH_CI 1.0f
 
 __device__ __forceinline__ float f_down(double d) { return __double2float_rd(d); }
 __device__ __forceinline__ float f_up(double d) { return __double2float_ru(d); }
@@ -129,7 +136,7 @@ __global__ void k_radix_tree(int n, const uint64_t *__restrict__ key, BNode *__r
 }
 
 __global__ void k_refit(int n, const uint32_t *__restrict__ sorted, const float *__restrict__ plo, const float *__restrict__ phi,
-                        BNode *__restrict__ nodes, const int *__restrict__ leaf_parent, uint32_t *__restrict__ visits)
+                        BNode *__restrict__ nodes, const int *__restrict__ leaf_parent, uint32_t *__restrict__ visits, int leaf_max)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -150,6 +157,26 @@ __global__ void k_refit(int n, const uint32_t *__restrict__ sorted, const float 
             }
         }
         for (int k = 0; k < 3; k++) { nd.lo[k] = lo[k]; nd.hi[k] = hi[k]; }
+        /* bottom-up SAH: this subtree as inner node + its children's best, or -- up to leaf_max primitives -- as one leaf.  A soup
+         * of unrelated triangles keeps one triangle per leaf (its boxes barely shrink towards the leaves: the leaf's area is the
+         * node's), a tessellated surface merges neighbours into leaves of up to four */
+        {
+            const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+            const float area = dx * dy + dy * dz + dz * dx;
+            float csum = 0.0f;
+            for (int side = 0; side < 2; side++) {
+                const int c = side ? nd.right : nd.left;
+                if (c < 0) {
+                    const uint32_t p = sorted[~c];
+                    const float ex = phi[3 * (size_t)p] - plo[3 * (size_t)p], ey = phi[3 * (size_t)p + 1] - plo[3 * (size_t)p + 1], ez = phi[3 * (size_t)p + 2] - plo[3 * (size_t)p + 2];
+                    csum += LH_SAH_CT * (ex * ey + ey * ez + ez * ex);
+                } else csum += ((volatile const float *)&nodes[c].cost)[0];
+            }
+            const uint32_t cnt = nd.last - nd.first + 1u;
+            const float as_node = LH_SAH_CI * area + csum, as_leaf = LH_SAH_CT * area * (float)cnt;
+            const bool leaf = cnt <= (uint32_t)leaf_max && as_leaf <= as_node;
+            nd.cost = leaf ? as_leaf : as_node; nd.leaf = leaf ? 1 : 0;
+        }
         __threadfence();
         cur = nd.parent;
     }
@@ -168,7 +195,8 @@ __device__ __forceinline__ void child_of(const BNode *__restrict__ nodes, const 
         const BNode &b = nodes[ref];
         for (int k = 0; k < 3; k++) { c.lo[k] = b.lo[k]; c.hi[k] = b.hi[k]; }
         c.first = b.first; c.count = b.last - b.first + 1;
-        c.node = c.count > (uint32_t)leaf_max ? ref : -1;
+        c.node = b.leaf ? -1 : ref;            /* k_refit's SAH decision: one leaf of its <= leaf_max primitives, or an inner node */
+        (void)leaf_max;
     }
 }
 
@@ -286,7 +314,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     const unsigned nb = (n + 255) / 256;
     uint32_t h_scene[6], h_cnt[2], level = 0, nwork = 0, nq = 1;
     const uint32_t init_scene[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    int h_bad = 0, leaf_max = 1;     /* one triangle per leaf: S-soup-1M walks this tree at 2 052 Mrays/s, 4-triangle leaves at 1 296 (tools/leaf_probe.py) */
+    int h_bad = 0, leaf_max = LH_MAX_LEAF_TRIS;     /* leaves of up to 4 triangles WHERE THE SAH SAYS SO (k_refit): forced 4-triangle leaves cost S-soup-1M 37 % (tools/leaf_probe.py), the SAH keeps that soup at one per leaf */
     { const char *e = getenv("LH_DEVICE_LEAF"); if (e && atoi(e) >= 1 && atoi(e) <= LH_MAX_LEAF_TRIS) leaf_max = atoi(e); }
     *d_q4nodes = NULL; *d_tri32 = NULL; *nq4 = 0; *q4_depth = 0;
     if (n == 0) return 0;
@@ -333,7 +361,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
             BCHK(hipMalloc((void **)&visits, sizeof(uint32_t) * (size_t)(n - 1)));
             BCHK(hipMemsetAsync(visits, 0, sizeof(uint32_t) * (size_t)(n - 1), s));
             hipLaunchKernelGGL(k_radix_tree, dim3((n - 1 + 255) / 256), dim3(256), 0, s, (int)n, key, nodes, leaf_parent);
-            hipLaunchKernelGGL(k_refit, dim3(nb), dim3(256), 0, s, (int)n, sorted, plo, phi, nodes, leaf_parent, visits);
+            hipLaunchKernelGGL(k_refit, dim3(nb), dim3(256), 0, s, (int)n, sorted, plo, phi, nodes, leaf_parent, visits, leaf_max);
             /* level-by-level collapse; every level's children are allocated adjacently */
             BCHK(hipMalloc((void **)&work[0], sizeof(uint2) * (size_t)n)); BCHK(hipMalloc((void **)&work[1], sizeof(uint2) * (size_t)n));
             BCHK(hipMalloc((void **)&counters, sizeof(uint32_t) * 2));

@@ -447,10 +447,7 @@ static int size_grid(lh_accel_t *a)
 {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, a->device));
-    uint32_t need = 3 * a->hs->bvh.q4_depth + 5;
-    if (need > 64) need = 64;
-    uint32_t stack = (need + 1u) & ~1u;
-    if (stack < 16) stack = 16;
+    const uint32_t stack = (uint32_t)lh_trace_rows(&a->dev);
     int per_cu = (int)(160u / stack);                     /* LDS: stack KiB per 256-thread workgroup */
     if (per_cu > 5) per_cu = 5;
     if (per_cu < 1) per_cu = 1;

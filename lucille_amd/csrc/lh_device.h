@@ -59,8 +59,10 @@ enum {
     LH_VARIANT_SPEC   = 4    /* the default: persistent waves, branch-free 4-wide (or 8-wide) node step, parked leaves */
 };
 
+#define LH_ROWS_UNCHECKED 64u          /* LDS stack rows (1 KiB each per 256-thread workgroup) up to which the walk runs unchecked */
+#define LH_ROWS_CHECKED   40u          /* ... of the checked walk: four workgroups per CU */
 #define LH_NPART          8            /* cursor partitions of a persistent launch: one per XCD (each with its own L2) */
-#define LH_AO_QCAP        (1u << 20)   /* rays of one launch that may wait in the fix-up queue (8 B each): fragile AO hits, rays out of visit budget */
+#define LH_AO_QCAP        (1u << 22)   /* rays of one launch that may wait in the fix-up queue (8 B each): fragile AO hits, rays out of visit budget */
 #define LH_DUMP_BUDGET    2048u        /* ... of ray-dump launches (incoherent rays: ages run to several times the steps) */
 #define LH_RAY_BUDGET     128u         /* default visit budget of the persistent walk (set_param "ray_budget") */
 #define LH_PRIM_OVERFLOW  0xFFFFFFFDu  /* the LDS stack column was too short for this ray: k_overflow_fix */
@@ -93,6 +95,7 @@ int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int ntheta, int 
                        unsigned long long *d_counters, unsigned long long *d_cursor, int grid_blocks, int min_active,
                        int tri_batch, const lh_fixq_t *q, int ncus, void *stream);
 int lh_trace_formats_needed(const lh_dev_scene_t *sc, int variant);
+int lh_trace_rows(const lh_dev_scene_t *sc);        /* LDS stack rows the default walk launches with on this scene */
 
 #ifdef __cplusplus
 }

@@ -207,9 +207,12 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
         /* the step below writes up to slot sp + 3.  rows = 3 * depth + 5 covers every ray of a tree that deep; a deeper
          * tree (an LBVH built on the device over a degenerate distribution) gets 64 rows and a ray that would overrun them
          * is finished by k_coop_walk -- same arithmetic, same answer */
-        if (GUARD && L.cur >= 0 && L.sp + 4 > rows) { L.over = true; L.cur = kDone; pend = kNoLeaf; }     /* a separate instantiation: the check costs the path-traced frame 4 % */
         if (L.cur >= 0) {
             node_step4<COUNT, LH_BLOCK, false>(L, pend, sc, stk, tid, c_nodes);
+            if (GUARD) {          /* branch-free, for the NEXT step (a fresh ray starts at sp = 1); a separate instantiation: the check costs ~5 % */
+                const bool ov = (L.cur >= 0) & (L.sp + 4 > rows);
+                L.over = L.over | ov; L.cur = ov ? kDone : L.cur; pend = ov ? kNoLeaf : pend;
+            }
         }
         const unsigned long long m_node = __ballot(L.cur >= 0);
         const unsigned long long m_pend = __ballot(pend != kNoLeaf);
@@ -453,9 +456,12 @@ __device__ __forceinline__ void trace_persist_lane(
             else if (!L.over && !fragile && (L.certain || best.prim != LH_MISS_PRIM)) atomicAdd(&ao.occ_count[my / (uint32_t)(ao.ntheta * ao.nphi)], 1u);
             if (COUNT) {
                 cr++;
+                /* rays by node visits: every ray of 64 visits or more, one in 256 of the shorter ones (weighted 256: the
+                 * histogram's atomics land on a few addresses -- 1.7 G of them made a counted path-traced frame take 18 s) */
                 const uint32_t visits = cn - cn_ray0; cn_ray0 = cn;
                 const int bkt = visits ? 32 - __clz((int)visits) : 0;
-                atomicAdd(&counters[LH_CNT_HIST + (bkt < 23 ? bkt : 23)], 1ull);
+                if (visits >= 64u) atomicAdd(&counters[LH_CNT_HIST + (bkt < 23 ? bkt : 23)], 1ull);
+                else if ((my & 255u) == 0u) atomicAdd(&counters[LH_CNT_HIST + bkt], 256ull);
             }
             my = kNoRay;
         }
@@ -694,7 +700,7 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
                 /* never wait for ever: if the producer makes no progress for half a second (it may not be running at all: two
                  * streams can share a hardware queue, and then this kernel runs in front of it) leave -- the sweep launched
                  * behind the producer takes what is left */
-                if (wall_clock64() - progress > 50000000ull) break;
+                if (__ballot(wall_clock64() - progress <= 50000000ull) == 0ull) break;          /* wave-uniform: no group has seen anything for 0.5 s */
                 if (__ballot(!gdone && e < known) != 0ull) { __builtin_amdgcn_s_sleep(16); continue; }     /* a slot below the known count: being written, or skipped above */
                 for (int k = 0; k < 8; k++) __builtin_amdgcn_s_sleep(127);
             }
@@ -865,12 +871,16 @@ int launch_walk(const lh_dev_scene_t &sc, size_t n, const double *org, const dou
     return launch_one<false, false>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, walk, grid_blocks, min_active, tri_batch, lds_bytes, fq, s);
 }
 
-/* LDS stack rows of a 4-wide walk over this scene: 3 * depth + 5 covers every ray; beyond the cap (64 rows; tests lower it
- * through "stack_cap") the walk checks before it pushes and a ray that would overrun goes to the cooperative walk */
+/* LDS stack rows of a 4-wide walk over this scene.  3 * depth + 5 covers every ray: up to 64 rows the walk runs unchecked (the
+ * config-5 host tree needs 56-64: two workgroups per CU, 87 ms; checked at 40 rows / four per CU it is 91 ms -- the check costs
+ * what the occupancy gives).  A deeper tree (an LBVH built on the device is: BASELINE config 5's needs 65) gets 40 rows -- FOUR
+ * workgroups per CU: the walk is bound by rays in flight (140 ms at 64 rows / 2 workgroups, 113 at 48 / 3, 100 at 40 / 4) --
+ * checks after every push, and the rare ray that would overrun its column goes to the cooperative walk.  "stack_cap" (tests)
+ * forces a lower cap. */
 uint32_t rows4(const lh_dev_scene_t &sc, bool *guard)
 {
     uint32_t need = 3 * sc.q4_depth + 5;
-    const uint32_t cap = (sc.stack_cap >= 8 && sc.stack_cap < 64) ? sc.stack_cap : 64;
+    const uint32_t cap = (sc.stack_cap >= 8 && sc.stack_cap < 64) ? sc.stack_cap : (need <= LH_ROWS_UNCHECKED ? LH_ROWS_UNCHECKED : LH_ROWS_CHECKED);
     *guard = need > cap;
     if (need > cap) need = cap;
     need = (need + 1u) & ~1u;
@@ -977,6 +987,12 @@ extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int n
 
 /* the node formats a launch of `variant` reads on this scene (bit mask, LH_FMT_* in lh_internal.h): so that the commit
  * code can upload a format the first time a variant asks for it */
+extern "C" int lh_trace_rows(const lh_dev_scene_t *sc)
+{
+    bool guard = false;
+    return (int)rows4(*sc, &guard);
+}
+
 extern "C" int lh_trace_formats_needed(const lh_dev_scene_t *sc, int variant)
 {
     (void)sc;

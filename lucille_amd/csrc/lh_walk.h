@@ -82,6 +82,7 @@ __device__ __forceinline__ void lane_init(Lane &L, const lh_dev_scene_t &sc,
     L.certain = false; L.over = false;
 }
 
+
 /* lh_slab_w (lh_filter.h) written for the VALU: per axis one rotate (v_alignbit_b32 by 0 or 16)
  * puts (near, far) into the (low, high) halves, two SDWA converts, two FMAs: 136 VALU ops per
  * 4-wide node step instead of 161 with per-plane selects.  Measured (A/B, 50 M rays): +1.5 %;
