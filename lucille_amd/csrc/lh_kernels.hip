@@ -209,9 +209,9 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
          * is finished by k_coop_walk -- same arithmetic, same answer */
         if (L.cur >= 0) {
             node_step4<COUNT, LH_BLOCK, false>(L, pend, sc, stk, tid, c_nodes);
-            if (GUARD) {          /* branch-free, for the NEXT step (a fresh ray starts at sp = 1); a separate instantiation: the check costs ~5 % */
+            if (GUARD) {          /* for the NEXT step (a fresh ray starts at sp = 1): one compare and a scalar branch per iteration */
                 const bool ov = (L.cur >= 0) & (L.sp + 4 > rows);
-                L.over = L.over | ov; L.cur = ov ? kDone : L.cur; pend = ov ? kNoLeaf : pend;
+                if (__builtin_expect(__ballot(ov) != 0ull, 0)) { if (ov) { L.over = true; L.cur = kDone; pend = kNoLeaf; } }
             }
         }
         const unsigned long long m_node = __ballot(L.cur >= 0);
