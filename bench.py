@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--hbm-rays", type=int, default=50_000_000)
     ap.add_argument("--no-ao", action="store_true", help="skip the secondary AO-frame leg")
     ap.add_argument("--no-pt", action="store_true", help="skip the secondary path-traced leg")
+    ap.add_argument("--no-config2", action="store_true", help="skip the BASELINE config 2 leg (the AO example RIB, 1024 x 1024, 64 AO samples)")
     ap.add_argument("--pt-size", type=int, default=2048)      # BASELINE config 4: 2048 x 2048, 256 spp
     ap.add_argument("--pt-spp", type=int, default=256)
     ap.add_argument("--backend", default=None, help="accepted for compatibility: torch.distributed is the launcher only (gloo control plane), device data moves through lh_dist_* = RCCL")
@@ -132,12 +133,12 @@ def main():
     ap.add_argument("--ao-size", type=int, default=4096)
     ap.add_argument("--ao-samples", type=int, default=64)
     ap.add_argument("--ao-tess", type=int, default=8, help="midpoint-subdivision levels of the example scene (4^n x 322 triangles; 8 -> 21.1 M = BASELINE config 5's '>= 10 M', 7 -> 5.3 M)")
-    ap.add_argument("--only", choices=["hbm", "ao", "pt"], default=None,
+    ap.add_argument("--only", choices=["hbm", "ao", "pt", "config2"], default=None,
                     help="profiling aid: run one secondary leg (the headline shrinks to a 1 M-ray smoke pass)")
     args = ap.parse_args()
     if args.only:
         args.rays = 1_000_000; args.steps = max(1, min(args.steps, 2)); args.no_cpu = True
-        args.no_hbm = args.only != "hbm"; args.no_ao = args.only != "ao"; args.no_pt = args.only != "pt"
+        args.no_hbm = args.only != "hbm"; args.no_ao = args.only != "ao"; args.no_pt = args.only != "pt"; args.no_config2 = args.only != "config2"
 
     import torch
     import lucille_amd as la
@@ -261,6 +262,10 @@ def main():
         ao = ao_frame_leg(la, acc_device=local, rank=rank, world=world, size=args.ao_size, nsamples=args.ao_samples,
                           steps=max(2, args.steps), dev=dev, tess=args.ao_tess)
 
+    c2 = None
+    if rank == 0 and world == 1 and not args.no_config2:
+        c2 = config2_leg(la, local, dev, max(3, args.steps))
+
     pt = None
     if not args.no_pt:
         pt = pt_frame_leg(la, acc_device=local, rank=rank, world=world, size=args.pt_size, spp=args.pt_spp, dev=dev)
@@ -320,6 +325,8 @@ def main():
             res["ao_render"] = ao
         if pt is not None:
             res["pt_render"] = pt
+        if c2 is not None:
+            res["config2"] = c2
         if not args.no_cpu and world == 1:            # rank 0 at N = 1 only (the contract)
             res["cpu_baseline"] = cpu_baseline(P, idx, first[0], first[1])
         print(json.dumps(res), flush=True)
@@ -548,6 +555,46 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
             "image_mean": float(img.mean().item()), "roofline": roof, "device_build": devb,
             "validation": {"frames_repeat": ok_all, "retiled_frame_bit_equal": bool(ok) if world == 1 else None,
                            "primary_hits": int(stats[0]["primary_hits"]) if world == 1 else None, "ok": ok_all}}
+
+
+def config2_leg(la, acc_device, dev, steps, size=1024, gather=64):
+    """BASELINE config 2 as stated: the reference's examples/ambient_occlusion.rib (tests/golden/rib/: 322 triangles, its own
+    PixelSamples 3 3), 1024 x 1024, 64 AO samples, one GPU.  RIB reader -> accelerator -> one frame; timed: the frame with the
+    image left in HBM (`frame_ms`) and through lh_render_ao_frame_host, the call lsh_hip makes (`frame_host_ms`: + the 12.6 MB
+    image over PCIe).  tests/test_gpu_config2.py holds the parity side (camera-ray hits against the oracle, tiling, the driver)."""
+    import torch
+    from lucille_amd import render, rib
+    t0 = time.perf_counter()
+    sc = rib.RibScene(os.path.join(ROOT, "tests", "golden", "rib", "ambient_occlusion.rib"))
+    parse_s = time.perf_counter() - t0
+    acc = la.HipAccel(acc_device); sc.add_to(acc)
+    t0 = time.perf_counter(); info = acc.commit(); commit_s = time.perf_counter() - t0
+    ps = int(sc.info.pixel_samples[0])
+    cam = la.Camera.make(size, size, sc.camera.flength, list(sc.camera.cam2world), sc.camera.rh)
+    times = []; host_times = []; stats = []
+    for it in range(steps + 1):
+        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+        img, st = render.render_ao_frame(acc, cam, ps, gather, tile=size)
+        torch.cuda.synchronize(dev)
+        if it:
+            times.append(time.perf_counter() - t0)
+        stats.append(dict(st))
+        t0 = time.perf_counter()
+        himg, hst = acc.render_ao_frame_host(cam, ps, gather)
+        if it:
+            host_times.append(time.perf_counter() - t0)
+    img2, st2 = render.render_ao_frame(acc, cam, ps, gather, tile=160)
+    ok = all(s == stats[0] for s in stats) and st2 == stats[0] and bool(torch.equal(img, img2)) \
+        and bool(np.array_equal(np.asarray(himg).reshape(size, size, 3), img.cpu().numpy()))
+    rays = st["primary_rays"] + st["ao_rays"]
+    acc.close(); sc.close()
+    return {"workload": "BASELINE config 2: examples/ambient_occlusion.rib, %d triangles, %dx%d, PixelSamples %d %d, %d AO samples, one GPU"
+                        % (info["ntriangles"], size, size, ps, ps, gather),
+            "rib_parse_s": round(parse_s, 4), "commit_s": round(commit_s, 4), "rays_per_frame": int(rays),
+            "primary_rays": int(st["primary_rays"]), "primary_hits": int(st["primary_hits"]), "ao_rays": int(st["ao_rays"]),
+            "frame_ms": round(min(times) * 1e3, 3), "frame_host_ms": round(min(host_times) * 1e3, 3),
+            "value": round(rays / min(times) / 1e6, 1), "unit": "Mrays/s",
+            "validation": {"frames_repeat_and_retiled_bit_equal_and_host_call_equal": ok, "ok": ok}}
 
 
 def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):

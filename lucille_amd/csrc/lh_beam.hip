@@ -80,7 +80,10 @@ __device__ int beam_set(Beam &b, const double *org, const double *dir /* 4x3 */)
     return 0;
 }
 
-/* test_beam_aabb (bvh.c:2053-2089): 1 = the box may be hit */
+/* test_beam_aabb (bvh.c:2053-2089): 1 = the box may be hit.  The "cull by t" block at the top of the reference function
+ * (bvh.c:2065-2074, beam->t_max against the box's near side) sits inside `#if 0`: it is not part of the compiled reference, and
+ * ri_beam_set leaves t_max = RI_INFINITY (beam.c:344), so there is nothing to restate -- the plane test below is the whole
+ * function.  (t_max does bound the triangle test, bvh.c:2194: that is kTInf in beam_triangle.) */
 __device__ __forceinline__ int beam_aabb(const double *box, const Beam &b)
 {
     LH_NC

@@ -848,38 +848,51 @@ static void to_rgbe(unsigned char out[4], float r, float g, float b)
     out[3] = (unsigned char)(e + 128);
 }
 
-/* run-length code of one channel of one scanline, with the reference writer's policy
- * (rgbe.c:241-291): runs of >= 4 (<= 127) are coded as runs; literals go out in chunks of
- * <= 128; a 2- or 3-byte run that makes up ALL of the literal stretch before the next long run is
- * coded as a run as well. */
+/* Run-length code of one channel of one scanline.  The file has to come out byte for byte like the reference driver's
+ * (tests/test_rib.py compares with the compiled reference), so the POLICY is the reference writer's (rgbe.c:241-291),
+ * stated here as rules over spans and implemented as a span stream, not as that function's scan loop:
+ *   - the channel is a sequence of spans: maximal stretches of one byte value, cut at 127;
+ *   - a span of 4 or more is written as a run record (128 + length, value);
+ *   - the short spans between two such runs (or the line's ends) form one literal stretch, written as literal records
+ *     (count <= 128, bytes) -- unless the stretch is a single span of 2 or 3, which is written as a run record. */
+typedef struct { FILE *fp; const unsigned char *d; int lit_at, lit_len, lit_spans, err; } rle_out_t;
+
+static void rle_record(rle_out_t *o, int is_run, const unsigned char *bytes, int count)
+{
+    unsigned char head = (unsigned char)(is_run ? 128 + count : count);
+    if (o->err) return;
+    if (fwrite(&head, 1, 1, o->fp) != 1 || fwrite(bytes, is_run ? 1 : (size_t)count, 1, o->fp) != 1) o->err = 1;
+}
+
+static void rle_flush_literals(rle_out_t *o)
+{
+    if (o->lit_spans == 1 && o->lit_len >= 2) rle_record(o, 1, o->d + o->lit_at, o->lit_len);
+    else {
+        int off;
+        for (off = 0; off < o->lit_len; off += 128)
+            rle_record(o, 0, o->d + o->lit_at + off, o->lit_len - off < 128 ? o->lit_len - off : 128);
+    }
+    o->lit_len = 0; o->lit_spans = 0;
+}
+
 static int put_channel(FILE *fp, const unsigned char *d, int n)
 {
-    int at = 0;
-    while (at < n) {
-        int start = at, len = 0, prev = 0;
-        while (len < 4 && start < n) {             /* look for the next run of >= 4 */
-            start += len; prev = len; len = 1;
-            while (start + len < n && len < 127 && d[start] == d[start + len]) len++;
+    rle_out_t o; int pos = 0;
+    o.fp = fp; o.d = d; o.lit_at = 0; o.lit_len = 0; o.lit_spans = 0; o.err = 0;
+    while (pos < n) {
+        int span = 1;
+        while (span < 127 && pos + span < n && d[pos + span] == d[pos]) span++;
+        if (span >= 4) {
+            rle_flush_literals(&o);
+            rle_record(&o, 1, d + pos, span);
+        } else {
+            if (o.lit_spans == 0) o.lit_at = pos;
+            o.lit_len += span; o.lit_spans++;
         }
-        if (prev > 1 && prev == start - at) {
-            const unsigned char b[2] = {(unsigned char)(128 + prev), d[at]};
-            if (fwrite(b, 2, 1, fp) != 1) return -1;
-            at = start;
-        }
-        while (at < start) {
-            int lit = start - at; unsigned char c;
-            if (lit > 128) lit = 128;
-            c = (unsigned char)lit;
-            if (fwrite(&c, 1, 1, fp) != 1 || fwrite(d + at, (size_t)lit, 1, fp) != 1) return -1;
-            at += lit;
-        }
-        if (len >= 4) {
-            const unsigned char b[2] = {(unsigned char)(128 + len), d[start]};
-            if (fwrite(b, 2, 1, fp) != 1) return -1;
-            at += len;
-        }
+        pos += span;
     }
-    return 0;
+    rle_flush_literals(&o);
+    return o.err ? -1 : 0;
 }
 
 /* rgb: height rows of width RGB float triples, top row first (what bucket_write hands the display

@@ -141,6 +141,15 @@ size_t lo_render_ao(const lo_scene_t *scene, const lo_camera_t *cam, int xsample
                     double *rec_org, double *rec_dir, uint32_t *rec_prim, double *rec_t,
                     double *rec_u, double *rec_v, size_t rec_cap);
 
+/* the path-traced tile (lucille_oracle_pt.c; transport arithmetic UNPINNED, see that file's header): spp samples
+ * s0 .. s0 + spp - 1 of spp_total per pixel, rgb[h][w][3] += their mean; materials10 = ten floats (kd, ks, kt, ior) per
+ * mesh, or override10 for every mesh; returns the rays traced */
+double   lo_pt_rnd(uint64_t key);
+uint64_t lo_render_pt(const lo_scene_t *scene, const lo_camera_t *cam, int x0, int y0, int w, int h, int s0, int spp, int spp_total,
+                      int max_vertices, const uint32_t *prim_mesh, const float *materials10, const float *override10,
+                      const float env_rgb[3], const float *env_map, int env_w, int env_h, int ref_weights, uint64_t seed,
+                      float *rgb, uint16_t *path_rays, uint64_t *max_rays_on_a_path);
+
 /* beam (frustum) visibility: ri_beam_set + ri_bvh_intersect_beam_visibility
  * (lucille_oracle_beam.c).  dirs_xyz: n x 4 corner directions.  result: 0 miss, 1 hit
  * completely, 2 hit partially (beam.h:27-29), -1 where ri_beam_set returns -1 */

@@ -27,7 +27,7 @@ def _p(a, ty):
 
 def build_oracle(force=False):
     so = os.path.join(HERE, "liblucille_oracle.so")
-    srcs = [os.path.join(HERE, f) for f in ("lucille_oracle.c", "lucille_oracle_ao.c", "lucille_oracle_beam.c", "lucille_oracle.h")]
+    srcs = [os.path.join(HERE, f) for f in ("lucille_oracle.c", "lucille_oracle_ao.c", "lucille_oracle_beam.c", "lucille_oracle_pt.c", "lucille_oracle.h")]
     stale = (not os.path.exists(so)) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
@@ -114,6 +114,10 @@ def lib():
                                    C.POINTER(C.c_float), _dp, _dp, _u32p, _dp, _dp, _dp, C.c_size_t]
         L.lo_scene_set_attribute.argtypes = [C.c_void_p, C.c_uint32, C.c_int, _dp]
         L.lo_state_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _u32p, _dp]
+        L.lo_render_pt.restype = C.c_uint64
+        L.lo_render_pt.argtypes = [C.c_void_p, C.POINTER(Camera)] + [C.c_int] * 8 + [_u32p, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                   C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_uint64,
+                                   C.POINTER(C.c_float), C.POINTER(C.c_uint16), _u64p]
         L.lo_soup_triangles.argtypes = [_u64p, C.c_uint32, C.c_double, _dp, _u32p]
         L.lo_soup_rays.argtypes = [_u64p, C.c_size_t, _dp, _dp]
         _lib = L
@@ -194,6 +198,30 @@ class Oracle:
         if not record:
             return img, n
         return img, {"org": ro[:n], "dir": rd[:n], "prim": rp[:n], "t": rt[:n], "u": ru[:n], "v": rv[:n]}
+
+    def render_pt(self, cam, x0, y0, w, h, s0, spp, spp_total, max_vertices=8, materials=None, override=None,
+                  env_rgb=(1.0, 1.0, 1.0), env_map=None, ref_weights=0, seed=1, out=None):
+        """lo_render_pt (lucille_oracle_pt.c): the path-traced tile, one path at a time.  materials: [nmesh, 10] float32
+        (kd, ks, kt, ior) or override: 10 floats for every mesh.  -> (rgb [h, w, 3] float32 (accumulated into `out`),
+        {"rays", "max_depth_reached", "paths"}, rays per path [h * w, spp] uint16)"""
+        fp = C.POINTER(C.c_float)
+        rgb = np.zeros((h, w, 3), np.float32) if out is None else out
+        _, g, _ = self.triangles()
+        g = _c(g, np.uint32)
+        mats = None if materials is None else _c(materials, np.float32).reshape(-1, 10)
+        ov = None if override is None else _c(override, np.float32).reshape(10)
+        assert (mats is None) != (ov is None)
+        if mats is not None:
+            assert mats.shape[0] > int(g.max())
+        env = _c(env_rgb, np.float32).reshape(3)
+        em = None if env_map is None else _c(env_map, np.float32)
+        per = np.zeros((h * w, spp), np.uint16); longest = C.c_uint64(0)
+        rays = self.L.lo_render_pt(self.h, C.byref(cam), x0, y0, w, h, s0, spp, spp_total, max_vertices, _p(g, _u32p),
+                                   None if mats is None else mats.ctypes.data_as(fp), None if ov is None else ov.ctypes.data_as(fp),
+                                   env.ctypes.data_as(fp), None if em is None else em.ctypes.data_as(fp),
+                                   0 if em is None else em.shape[1], 0 if em is None else em.shape[0], int(ref_weights), int(seed),
+                                   rgb.ctypes.data_as(fp), per.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(longest))
+        return rgb, {"paths": w * h * spp, "rays": int(rays), "max_depth_reached": int(longest.value)}, per
 
     @property
     def ntriangles(self):
