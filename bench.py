@@ -615,18 +615,20 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
     c = g["camera"]
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
     times = []; st = None; img = None; first = None; repeat = True
+    pt_tile = size if world == 1 else max(128, size // 4)
+    # paths per pass (decided once: the first frame's buffers stay allocated): as many as 70 % of the free HBM holds (176 B of
+    # path state each; a 2048^2 x 256 spp frame is 2^30 paths = 189 GB of the 288): every pass costs one kernel ramp + drain per
+    # bounce, so fewer, larger wavefronts are faster (tools/pt_frames.py: 166.3 / 154.7 / 148.6 ms per frame as 4 / 2 / 1 passes;
+    # the image does not change by a bit)
+    torch.cuda.empty_cache()
+    free_b = torch.cuda.mem_get_info(dev)[0]
+    per_pass = max(64 << 20, min(1 << 30, int(free_b * 7 // 10 // 176)))
+    chunk = max(1, min(spp, per_pass // (pt_tile * pt_tile)))
+    while spp % chunk:            # whole passes
+        chunk -= 1
     for it in range(3):
         shard.barrier()
         torch.cuda.synchronize(dev); t0 = time.perf_counter()
-        pt_tile = size if world == 1 else max(128, size // 4)
-        # paths per pass: as many as a third of the free HBM holds (~170 B of path state each; 288 GB -> 512 M paths, 128 spp of a
-        # 2048^2 tile): every pass costs one kernel drain per bounce and stage, so fewer, larger wavefronts are faster
-        # (tools/pt_chunk_probe.py: 192.7 / 182.9 / 175.6 ms at 64 M / 128 M / 512 M paths; the image does not change by a bit)
-        free_b = torch.cuda.mem_get_info(dev)[0]
-        per_pass = max(64 << 20, min(512 << 20, int(free_b // 3 // 170)))
-        chunk = max(1, min(spp, per_pass // (pt_tile * pt_tile)))
-        while spp % chunk:            # whole passes
-            chunk -= 1
         img, st = render.render_pt_frame_sharded(acc, cam, spp, rank, world, tile=pt_tile, spp_chunk=chunk,
                                                  kd=0.8, env=(1.0, 1.0, 1.0), max_vertices=8, seed=7)
         torch.cuda.synchronize(dev)
@@ -649,22 +651,23 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
         retiled = bool(torch.equal(img2, img)); del img2
     roof = None
     if world == 1:
-        # one more frame (untimed) through the counting instantiation of the trace kernel.  Every ray of every bounce goes
-        # through HBM as fp64 records: 48 B written by the shader, 48 B read by the trace kernel, 28 B of hit record written
-        # and read again by the shader; plus 64 B per node visit and 40 B per triangle test
+        # one more frame (untimed) through the counting instantiation of the trace kernel.  Every ray of a bounce goes through
+        # HBM as fp64 records: 48 B written by the shader, 48 B read by the trace kernel (camera rays: generated in the kernel,
+        # nothing), 28 B of hit record written and read again by the shader; plus 64 B per node visit and 40 B per triangle test
         acc.trace_statistics(True); acc.statistics(clear=True)
         render.render_pt_frame_sharded(acc, cam, spp, rank, world, tile=size, spp_chunk=max(1, min(spp, (64 << 20) // (size * size))),
                                        kd=0.8, env=(1.0, 1.0, 1.0), max_vertices=8, seed=7)
         torch.cuda.synchronize(dev)
         c = acc.statistics(clear=True); acc.trace_statistics(False)
         nr = max(1, c["rays"])
-        b_frame = 64.0 * c["nodes"] + 40.0 * c["tris"] + (2 * 48.0 + 2 * 28.0) * c["rays"]
+        b_frame = 64.0 * c["nodes"] + 40.0 * c["tris"] + 2 * 28.0 * c["rays"] + 2 * 48.0 * (c["rays"] - st["paths"])
         roof = {"bound": "hbm", "achieved": round(b_frame / min(times) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(b_frame / min(times) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
                 "nodes_per_ray": round(c["nodes"] / nr, 2), "tris_per_ray": round(c["tris"] / nr, 2), "exact_per_ray": round(c["exact"] / nr, 4),
                 "rays_counted": c["rays"],
-                "note": "1 986 triangles: the tree is L2-resident; the frame is a chain of ~110 dependent launches per pass (trace, decide, "
-                        "scan, emit per bounce), the trace kernel is 59 % of the kernel time (profiles/r02d_pt_kernel_stats.csv)"}
+                "note": "1 986 triangles: the tree is L2-resident.  Per pass: closest hit with the camera rays generated in the kernel, then per "
+                        "bounce one shading pass (decide + compact + scatter, ray counts stay on the device) and one closest-hit launch: 15 "
+                        "launches, no host round trip; kernel time = frame time, closest-hit kernels 67 % of it (profiles/r03_pt_kernel_stats.csv)"}
     rays_all = shard.all_reduce_sum(float(st["rays"])) if world > 1 else float(st["rays"])
     t_all = shard.all_reduce_max(min(times)) if world > 1 else min(times)
     acc.close()

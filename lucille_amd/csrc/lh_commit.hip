@@ -160,7 +160,7 @@ static void release_device(lh_accel_t *a)
 {
     lh_buf *bufs[] = {&a->r_org, &a->r_dir, &a->r_prim, &a->r_t, &a->r_u, &a->r_v, &a->r_slot, &a->r_hitrec,
                       &a->r_aorg, &a->r_adir, &a->r_occ, &a->r_blocks, &a->r_key, &a->r_frame, &a->r_occcount,
-                      &a->p_org2, &a->p_dir2, &a->p_path, &a->p_path2, &a->p_thr, &a->p_thr2, &a->p_rad, &a->p_alive};
+                      &a->p_org2, &a->p_dir2, &a->p_path, &a->p_path2, &a->p_thr, &a->p_thr2, &a->p_rad, &a->p_counts};
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); i++) free_buf(bufs[i]);
     if (a->d_total) (void)hipFree(a->d_total);
     if (a->d_nrm9) (void)hipFree(a->d_nrm9);

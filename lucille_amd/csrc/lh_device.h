@@ -41,6 +41,8 @@ typedef struct lh_dev_scene {
     uint32_t    ray_budget;/* wave iterations after which a ray leaves the persistent walk for the cooperative one */
     int         stack_guard;    /* set by the launchers when the LDS rows do not cover the tree's worst case: the walks check before they push */
     uint32_t    stack_cap; /* 0: 64 LDS stack rows at most; 8..62: a lower cap (tests of the overflow path) */
+    const void *cam_src;       /* NULL, or: ray source 2 -- the launch's rays are the camera rays of a path-traced pass (PtCamSrc, lh_pt.h), org / dir unused */
+    const uint32_t *n_dev;     /* NULL, or: the launch's ray count lives on the device (the path tracer's bounce chain; the host passes an upper bound) */
     unsigned long long *diag_clock;   /* diagnostics (LH_STAGE_TIMING): [2][waves] start / exit wall clock of every persistent wave, or NULL */
 } lh_dev_scene_t;
 

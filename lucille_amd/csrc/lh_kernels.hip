@@ -56,6 +56,7 @@
 namespace {
 
 #include "lh_walk.h"
+#include "lh_pt.h"
 
 /* the textbook walk (LH_VARIANT_DIRECT): while-while over the 2-wide fp32 nodes (the SURVEY 8d layout), one ray per lane,
  * no regrouping, no parked leaves.  Kept as the in-process reference the tuned walks are compared against. */
@@ -406,6 +407,28 @@ struct AoSrc {
     unsigned long long seed; int ntheta, nphi;
 };
 
+/* ray `i` of the launch.  SRC 0: from the arrays; 1: the AO ray (slot i / N, sample i % N) regenerated from the hit record
+ * (selfp: the triangle it starts on, when that cannot occlude it); 2: the camera ray of path i of a path-traced pass */
+template <int SRC>
+__device__ __forceinline__ void src_ray(const lh_dev_scene_t &sc, uint32_t i, const double *__restrict__ org, const double *__restrict__ dir,
+                                        const AoSrc &ao, double &ox, double &oy, double &oz, double &dx, double &dy, double &dz, uint32_t &selfp)
+{
+    if (SRC == 0) {
+        ox = org[3 * (size_t)i]; oy = org[3 * (size_t)i + 1]; oz = org[3 * (size_t)i + 2];
+        dx = dir[3 * (size_t)i]; dy = dir[3 * (size_t)i + 1]; dz = dir[3 * (size_t)i + 2];
+    } else if (SRC == 1) {
+        const uint32_t N = (uint32_t)(ao.ntheta * ao.nphi), slot = i / N;
+        const unsigned long long key = ao.slot_key[slot];
+        lh_ao_ray_builtin(ao.hitrec + LH_HITREC_DOUBLES * (size_t)slot, key, ao.seed, ao.ntheta, ao.nphi,
+                          (int)(i - slot * N), ox, oy, oz, dx, dy, dz);
+        selfp = lh_slot_selfprim(key);            /* LH_SLOT_NOSELF matches no primitive id (ids < 2^29) */
+    } else {
+        double o[3], d[3];
+        pt_camera_ray((const PtCamSrc *)sc.cam_src, i, o, d);
+        ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
+    }
+}
+
 constexpr uint32_t kNoRay = 0xFFFFFFFFu;
 
 template <bool ANYHIT, bool COUNT, int WALK, int SRC>
@@ -452,7 +475,7 @@ __device__ __forceinline__ void trace_persist_lane(
             const bool fragile = sc.ref_nodes != NULL && !L.over && best.prim != LH_MISS_PRIM && best.frag != 0u && !(ANYHIT && L.certain);
             bool queued = false;
             if (__builtin_expect(L.over | fragile, 0)) queued = fixq_push(fq, my, L.over ? LH_Q_COOP : LH_Q_REF);
-            if (SRC == 0) { if (__builtin_expect(!queued, 1)) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL); }
+            if (SRC != 1) { if (__builtin_expect(!queued, 1)) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL); }
             else if (!L.over && !fragile && (L.certain || best.prim != LH_MISS_PRIM)) atomicAdd(&ao.occ_count[my / (uint32_t)(ao.ntheta * ao.nphi)], 1u);
             if (COUNT) {
                 cr++;
@@ -475,13 +498,18 @@ __device__ __forceinline__ void trace_persist_lane(
         if (idle_mask != 0ull && !exhausted) {
             if (__builtin_expect(wbase == wend, 0)) {
                 const uint32_t per = (n + LH_NPART - 1) / LH_NPART;
+                uint32_t chunk = sc.ray_chunk;
+                if (SRC != 1 && sc.n_dev) {                   /* the host sized the chunk for its upper bound of n */
+                    const uint32_t c = n / (gridDim.x * (LH_BLOCK / 64) * 4u);
+                    chunk = c < 64u ? 64u : (c < chunk ? c : chunk);
+                }
                 for (;;) {
                     const uint32_t p0 = per * part, p1 = (p0 + per < n) ? p0 + per : n;      /* per * LH_NPART < 2^31 + 8 */
                     const uint32_t plen = p1 > p0 ? p1 - p0 : 0u;                              /* a small batch leaves the last partitions empty */
                     uint32_t b = 0;
-                    if ((tid & 63) == 0) b = atomicAdd(cursor + part, sc.ray_chunk);           /* < 2^31 + waves * chunk: no wrap */
+                    if ((tid & 63) == 0) b = atomicAdd(cursor + part, chunk);                  /* < 2^31 + waves * chunk: no wrap */
                     b = (uint32_t)__shfl((int)b, 0);
-                    if (b < plen) { b += p0; wbase = b; wend = (p1 - b > sc.ray_chunk) ? b + sc.ray_chunk : p1; break; }
+                    if (b < plen) { b += p0; wbase = b; wend = (p1 - b > chunk) ? b + chunk : p1; break; }
                     part = (part + 1u) % LH_NPART;
                     if (++drained >= LH_NPART) { exhausted = true; break; }     /* every partition has been handed out */
                 }
@@ -493,16 +521,7 @@ __device__ __forceinline__ void trace_persist_lane(
             if (idle && rank < take) {
                 const uint32_t i = wbase + (uint32_t)rank;
                 my = i;
-                if (SRC == 0) {
-                    ox = org[3 * (size_t)i]; oy = org[3 * (size_t)i + 1]; oz = org[3 * (size_t)i + 2];
-                    dx = dir[3 * (size_t)i]; dy = dir[3 * (size_t)i + 1]; dz = dir[3 * (size_t)i + 2];
-                } else {
-                    const uint32_t N = (uint32_t)(ao.ntheta * ao.nphi), slot = i / N;
-                    const unsigned long long key = ao.slot_key[slot];
-                    lh_ao_ray_builtin(ao.hitrec + LH_HITREC_DOUBLES * (size_t)slot, key, ao.seed, ao.ntheta, ao.nphi,
-                                      (int)(i - slot * N), ox, oy, oz, dx, dy, dz);
-                    selfp = lh_slot_selfprim(key);            /* LH_SLOT_NOSELF matches no primitive id (ids < 2^29) */
-                }
+                src_ray<SRC>(sc, i, org, dir, ao, ox, oy, oz, dx, dy, dz, selfp);
                 lane_init(L, sc, ox, oy, oz, dx, dy, dz);
                 best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM; best.frag = 0u;
                 stk[0][tid] = kDone;
@@ -542,6 +561,7 @@ __global__ __launch_bounds__(LH_BLOCK, WALK == 7 ? 3 : 4) void k_trace_persist_l
     uint32_t *cursor, int min_active, int tri_batch, const AoSrc ao, const FixQ fq)
 {
     extern __shared__ int lh_stack_lds[];          /* [stack entries][LH_BLOCK], sized at launch */
+    if (SRC != 1 && sc.n_dev) n = *sc.n_dev;       /* the path tracer's bounce chain: the count the previous shading pass left */
     trace_persist_lane<ANYHIT, COUNT, WALK, SRC>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, ao, fq, lh_stack_lds);
 }
 
@@ -627,7 +647,7 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
                     const bool sure = (__ballot(L.certain || (exact && best.frag == 0u)) & gmask) != 0ull;
                     hit = sure;
                     if (!sure && (__ballot(exact) & gmask) != 0ull) { need_ref = sc.ref_nodes != NULL; hit = true; }   /* only fragile hits: the reference walk decides */
-                    if (SRC == 0 && (lane & 15) == 0) {
+                    if (SRC != 1 && (lane & 15) == 0) {
                         if (need_ref) hit = ref_trace_one(sc, ox, oy, oz, dx, dy, dz).prim != LH_MISS_PRIM;
                         occ[i] = (uint8_t)(hit ? 1 : 0);
                     }
@@ -666,14 +686,7 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
                 e += ngroups;
                 if (e >= fq.qcap) gdone = true;
                 progress = wall_clock64();
-                if (SRC == 0) {
-                    ox = org[3 * i]; oy = org[3 * i + 1]; oz = org[3 * i + 2]; dx = dir[3 * i]; dy = dir[3 * i + 1]; dz = dir[3 * i + 2];
-                } else {
-                    const uint32_t N = (uint32_t)(ao.ntheta * ao.nphi), slot = (uint32_t)i / N;
-                    const unsigned long long key = ao.slot_key[slot];
-                    lh_ao_ray_builtin(ao.hitrec + LH_HITREC_DOUBLES * (size_t)slot, key, ao.seed, ao.ntheta, ao.nphi, (int)((uint32_t)i - slot * N), ox, oy, oz, dx, dy, dz);
-                    selfp = lh_slot_selfprim(key);
-                }
+                src_ray<SRC>(sc, (uint32_t)i, org, dir, ao, ox, oy, oz, dx, dy, dz, selfp);
                 if (reason == LH_Q_REF) {
                     /* a fragile hit: the reference's own walk on its own tree decides, no cooperative walk */
                     if ((lane & 15) == 0) {
@@ -759,13 +772,26 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
 /* LH_PRIM_RETRACE / LH_OCC_RETRACE: a hit the reference may not reach -- the reference's own walk on its own tree decides.
  * LH_PRIM_OVERFLOW / LH_OCC_OVERFLOW: only when the fix-up queue was full (more than qcap rays out of budget in one launch) --
  * the same walk as the kernel's, sequential, with a private stack. */
+/* ray i of a launch whose output slot was left flagged (the cold path: arrays, or the camera rays of a path-traced pass) */
+__device__ __forceinline__ void flagged_ray(const lh_dev_scene_t &sc, size_t i, const double *__restrict__ org, const double *__restrict__ dir,
+                                            double &ox, double &oy, double &oz, double &dx, double &dy, double &dz)
+{
+    if (sc.cam_src) {
+        double o[3], d[3];
+        pt_camera_ray((const PtCamSrc *)sc.cam_src, (uint32_t)i, o, d);
+        ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
+    } else {
+        ox = org[3 * i]; oy = org[3 * i + 1]; oz = org[3 * i + 2]; dx = dir[3 * i]; dy = dir[3 * i + 1]; dz = dir[3 * i + 2];
+    }
+}
+
 template <bool ANYHIT>
 __device__ void overflow_walk(const lh_dev_scene_t &sc, size_t i, const double *__restrict__ org, const double *__restrict__ dir,
                               uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u, double *__restrict__ v,
                               uint8_t *__restrict__ occ)
 {
-    const double ox = org[3 * i], oy = org[3 * i + 1], oz = org[3 * i + 2];
-    const double dx = dir[3 * i], dy = dir[3 * i + 1], dz = dir[3 * i + 2];
+    double ox, oy, oz, dx, dy, dz;
+    flagged_ray(sc, i, org, dir, ox, oy, oz, dx, dy, dz);
     const float4 *__restrict__ tris = (const float4 *)sc.tri32;
     Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM, 0u};
     uint32_t ce = 0;
@@ -817,6 +843,7 @@ __global__ __launch_bounds__(256) void k_fixups(lh_dev_scene_t sc, size_t n, con
 {
     /* nothing was left flagged unless a push found the queue full (or the launch had no queue: force) */
     if (!force && qcount[1] == 0u) return;
+    if (sc.n_dev && (size_t)*sc.n_dev < n) n = *sc.n_dev;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         if (anyhit ? (occ[i] == LH_OCC_OVERFLOW) : (prim[i] == LH_PRIM_OVERFLOW)) {
             if (anyhit) overflow_walk<true>(sc, i, org, dir, prim, t, u, v, occ);
@@ -825,7 +852,9 @@ __global__ __launch_bounds__(256) void k_fixups(lh_dev_scene_t sc, size_t n, con
         }
         if (sc.ref_nodes == NULL) continue;
         if (anyhit ? (occ[i] != LH_OCC_RETRACE) : (prim[i] != LH_PRIM_RETRACE)) continue;
-        const RefHit rh = ref_trace_one(sc, org[3 * i], org[3 * i + 1], org[3 * i + 2], dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+        double ox, oy, oz, dx, dy, dz;
+        flagged_ray(sc, i, org, dir, ox, oy, oz, dx, dy, dz);
+        const RefHit rh = ref_trace_one(sc, ox, oy, oz, dx, dy, dz);
         if (anyhit) occ[i] = rh.prim != LH_MISS_PRIM ? 1 : 0;
         else { prim[i] = rh.prim; t[i] = rh.t; u[i] = rh.u; v[i] = rh.v; }
         if (counters) atomicAdd(&counters[LH_CNT_RETRACED], 1ull);
@@ -845,7 +874,14 @@ int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const doub
                            sc, n, org, dir, prim, t, u, v, occ, counters);
     } else {
         if (hipMemsetAsync(cursor, 0, sizeof(unsigned long long) * LH_NPART, s) != hipSuccess) return -1;
-        if (walk == 7)
+        if (sc.cam_src) {                    /* ray source 2: closest hit over the 4-wide nodes only (lh_launch_trace checks) */
+            if (walk == 8)
+                hipLaunchKernelGGL((k_trace_persist_lane<false, COUNT, 8, 2>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                                   sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
+            else
+                hipLaunchKernelGGL((k_trace_persist_lane<false, COUNT, 3, 2>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
+                                   sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
+        } else if (walk == 7)
             hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 7, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
                                sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
         else if (walk == 8)
@@ -921,7 +957,7 @@ int launch_coop(const lh_dev_scene_t &sc, const double *org, const double *dir, 
     scl.stack_rows = coop_rows(sc);
     if (scl.stack_rows == 0) return -1;
     const size_t lds = ((size_t)scl.stack_rows * 64 + 128) * sizeof(int);
-    static bool attr_set[2][2] = {{false, false}, {false, false}};
+    static bool attr_set[2][3] = {{false, false, false}, {false, false, false}};
     if (lds > 64 * 1024 && !attr_set[ANYHIT][SRC]) {
         if (hipFuncSetAttribute((const void *)k_coop_walk<ANYHIT, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         attr_set[ANYHIT][SRC] = true;
@@ -1025,12 +1061,14 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
     }
     lh_dev_scene_t scl = *sc;
     uint32_t need; int walk; bool guard = false;
+    if ((sc->cam_src || sc->n_dev) && (variant == LH_VARIANT_DIRECT || anyhit || q == NULL)) return -1;      /* the path tracer's chain: default walk, closest hit */
+    if (sc->cam_src) scl.prefer_q8 = 0;
     if (variant == LH_VARIANT_DIRECT) {
         if (!sc->nodes) return -1;
         need = sc->max_depth + 2; walk = 0;          /* 2-wide: one push per level + the sentinel */
         need = (need + 1u) & ~1u;
         if (need < 16) need = 16;
-    } else if (sc->prefer_q8 && sc->q8nodes) {
+    } else if (scl.prefer_q8 && sc->q8nodes) {
         /* the 8-wide walk pushes up to 7 per level and keeps a scratch row; beyond 48 rows (three workgroups per CU) the rare
          * ray that needs them is finished by the cooperative walk over the 4-wide nodes (always resident) */
         need = 7 * sc->q8_depth + 10; walk = 7;
@@ -1053,7 +1091,7 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
     clamp_chunk(scl, n, grid_blocks);
     /* small batches (one synchronous ray, a bucket of lucille's renderer): no visit budget, no second stream -- a ray the walk
      * cannot finish (LDS rows) stays flagged for k_fixups */
-    const bool coop = walk != 0 && q != NULL && n >= 65536;
+    const bool coop = walk != 0 && q != NULL && (n >= 65536 || sc->n_dev != NULL);
     FixQ fq = {coop ? (unsigned long long *)q->queue : NULL, q ? q->qcount : NULL, coop ? q->qcap : 0u, (uint32_t)grid_blocks * (LH_BLOCK / 64), q ? q->qcount + 4 : NULL};
     if (!coop) scl.ray_budget = 0xFFFFFFFFu;
     if (walk != 0 && q != NULL && fixq_begin(q, s) != 0) return -1;
@@ -1063,6 +1101,7 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
     if (rc != 0) return rc;
     if (coop) {
         rc = anyhit ? launch_coop<true, 0>(scl, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occluded, AoSrc{}, fq, q, d_counters, ncus, s)
+             : sc->cam_src ? launch_coop<false, 2>(scl, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occluded, AoSrc{}, fq, q, d_counters, ncus, s)
                     : launch_coop<false, 0>(scl, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occluded, AoSrc{}, fq, q, d_counters, ncus, s);
         if (rc != 0) return rc;
     }

@@ -1,9 +1,8 @@
 /*
- * lh_pt.h -- the path tracer's per-vertex arithmetic, written once for the two places that run it on the device: the
- * wavefront kernels of lh_render.hip (k_pt_primary / k_pt_decide / k_pt_emit: one launch per bounce, rays materialised in
- * HBM) and the fused walk of lh_kernels.hip (ray source 2 of k_trace_persist_lane: a lane that finishes a ray shades the
- * hit and continues with the path's next ray; nothing but the radiance goes through HBM).  Same functions, same counter-
- * based keys (pixel, sample, bounce): the two give the same image bit for bit.
+ * lh_pt.h -- the path tracer's per-vertex arithmetic, for the two places that run it on the device: the shading pass of
+ * lh_render.hip (k_pt_shade: one launch per bounce; decides, compacts and scatters the live paths) and the closest-hit walk
+ * of lh_kernels.hip, whose ray source 2 generates the camera rays of a pass in its refill (pt_camera_ray) instead of reading
+ * them from HBM.  Counter-based keys (pixel, sample, bounce): a frame does not depend on tiling, sharding or slot order.
  *
  * Reference (dead code in the tree, so this is its documented algorithm): src/transport/pathtrace.c:189-314 (trace loop),
  * 316-352 (sample_pixel), 407-430 (russian_roulette), 432-459 (sample_reflection_type), 500-531 (sample_cosweight),
@@ -21,7 +20,10 @@ struct DevCamera {
     double flength;
     int width, height, rh, ortho;
 };
-struct DevMaterial { float kd[3], ks[3], kt[3], ior; };
+/* lh_material_t + what every vertex would otherwise recompute from it with fp64 divisions: the channel averages the
+ * roulette and the lobe choice run on, and 1 / P(lobe).  Packed on the host (lh_pt_material_pack: the same IEEE operations,
+ * so the same bits as computing them here). */
+struct DevMaterial { float kd[3], ks[3], kt[3], ior; double ad, as, at, asum9; float wd, ws, wt, pad; };
 struct DevEnv { float rgb[3]; const float4 *map; int w, h; };
 
 __device__ __forceinline__ void vnormalize(double d[3])
@@ -35,6 +37,25 @@ __device__ __forceinline__ void vcross(double d[3], const double a[3], const dou
 {
     LH_NC
     d[0] = a[1] * b[2] - a[2] * b[1]; d[1] = a[2] * b[0] - a[0] * b[2]; d[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* cosine-weighted direction about +z from two uniforms, single precision: radius sqrt(z0) in the plane at angle 2 pi z1,
+ * sqrt(1 - z0) along the axis.  sin / cos of 2 pi z1 by quadrant reduction (exact) and the Cephes sinf / cosf kernels on
+ * |x| <= pi / 4, every operation a single IEEE multiply or add (no contraction): bit-identical on the host and the device. */
+__device__ __forceinline__ void pt_lobe(float z0, float z1, float &d0, float &d1, float &d2)
+{
+    LH_NC
+    const int k = (int)(4.0f * z1 + 0.5f);                 /* nearest quarter turn, 0 .. 4 */
+    const float r = z1 - 0.25f * (float)k;                  /* exact; |r| <= 1 / 8 */
+    const float x = 6.28318530717958647692f * r, x2 = x * x;
+    float sp = -1.9515295891e-4f * x2; sp = sp + 8.3321608736e-3f; sp = sp * x2; sp = sp - 1.6666654611e-1f; sp = sp * x2; sp = sp * x; sp = sp + x;
+    float cp = 2.443315711809948e-5f * x2; cp = cp - 1.388731625493765e-3f; cp = cp * x2; cp = cp + 4.166664568298827e-2f; cp = cp * x2; cp = cp * x2;
+    cp = cp - 0.5f * x2; cp = cp + 1.0f;
+    const int q = k & 3;
+    const float s = q == 0 ? sp : (q == 1 ? cp : (q == 2 ? -sp : -cp));
+    const float c = q == 0 ? cp : (q == 1 ? -sp : (q == 2 ? -cp : sp));
+    const float rad = sqrtf(z0);
+    d0 = c * rad; d1 = s * rad; d2 = sqrtf(1.0f - z0);
 }
 
 __device__ __forceinline__ double rnd01(uint64_t key) { return (double)lh_mix32(key) * 2.3283064365386963e-10; }
@@ -71,9 +92,11 @@ __device__ __forceinline__ void pt_primary_ray(const DevCamera &cam, int x0, int
                                                size_t id, double pos3[3], double d[3])
 {
     LH_NC
-    const int s = (int)(id % spp);
-    const size_t pix = id / spp;
-    const int px = x0 + (int)(pix % w), py = y0 + (int)(pix / w);
+    /* 32-bit divisions: a pass holds fewer than 2^30 paths (64-bit ones cost ~4x the instructions, four per key) */
+    const uint32_t id32 = (uint32_t)id, pix = id32 / (uint32_t)spp;
+    const int s = (int)(id32 - pix * (uint32_t)spp);
+    const uint32_t row = pix / (uint32_t)w;
+    const int px = x0 + (int)(pix - row * (uint32_t)w), py = y0 + (int)row;
     const uint64_t key = (seed * 0x9E3779B97F4A7C15ULL) ^ ((((uint64_t)py * (uint64_t)cam.width + (uint64_t)px) << 20) + (uint64_t)(s0 + s)) * 64ull;
     const double x = (double)px + rnd01(key), y = (double)py + rnd01(key + 1);
     const double W = cam.width, H = cam.height;
@@ -90,18 +113,27 @@ __device__ __forceinline__ void pt_primary_ray(const DevCamera &cam, int x0, int
     pos3[0] = pos[0]; pos3[1] = pos[1]; pos3[2] = pos[2];
 }
 
+/* the camera rays of one pass as a ray SOURCE (lh_kernels.hip, ray source 2; the first bounce's shading pass): path id ->
+ * ray, nothing materialised.  Lives in device memory (written by k_pt_begin), read with scalar loads. */
+struct PtCamSrc { DevCamera cam; unsigned long long seed; int x0, y0, w, spp, s0, pad; };
+
+__device__ __forceinline__ void pt_camera_ray(const PtCamSrc *__restrict__ c, uint32_t id, double pos3[3], double d[3])
+{
+    pt_primary_ray(c->cam, c->x0, c->y0, c->w, c->spp, c->s0, c->seed, (size_t)id, pos3, d);
+}
+
 __device__ __forceinline__ uint64_t pt_key(unsigned long long seed, uint32_t path, int spp, int s0, int x0, int y0, int w, int full_width, int depth)
 {
-    const size_t pix = path / (uint32_t)spp;
-    const uint64_t gx = (uint64_t)(x0 + (int)(pix % (size_t)w)), gy = (uint64_t)(y0 + (int)(pix / (size_t)w));
-    return ((seed * 0x9E3779B97F4A7C15ULL) ^ (((gy * (uint64_t)full_width + gx) << 20) + (uint64_t)(s0 + (int)(path % (uint32_t)spp))) * 64ull)
+    const uint32_t pix = path / (uint32_t)spp, row = pix / (uint32_t)w;
+    const uint64_t gx = (uint64_t)(x0 + (int)(pix - row * (uint32_t)w)), gy = (uint64_t)(y0 + (int)row);
+    return ((seed * 0x9E3779B97F4A7C15ULL) ^ (((gy * (uint64_t)full_width + gx) << 20) + (uint64_t)(s0 + (int)(path - pix * (uint32_t)spp))) * 64ull)
            + 4ull * (uint64_t)(depth + 1);
 }
 
 /* a path vertex that hit something: does the path go on?  (vertex limit; Russian roulette on d + s + t, pathtrace.c:407-430) */
 __device__ __forceinline__ bool pt_survives(const DevMaterial &M, uint64_t key, int depth, int max_depth)
 {
-    const double ksum = ((double)M.kd[0] + M.kd[1] + M.kd[2] + M.ks[0] + M.ks[1] + M.ks[2] + M.kt[0] + M.kt[1] + M.kt[2]) / 3.0;
+    const double ksum = M.asum9;        /* (kd0 + kd1 + kd2 + ks0 + ... + kt2) / 3 */
     return !(depth + 2 >= max_depth || !(ksum > 0.0) || rnd01(key) > ksum);
 }
 
@@ -112,7 +144,7 @@ __device__ __forceinline__ void pt_scatter(const lh_dev_scene_t &sc, const doubl
                                            double org2[3], double O[3], float G2[3], uint32_t &pword2)
 {
     LH_NC
-    const double kd_ = ((double)M.kd[0] + M.kd[1] + M.kd[2]) / 3.0, ks_ = ((double)M.ks[0] + M.ks[1] + M.ks[2]) / 3.0, kt_ = ((double)M.kt[0] + M.kt[1] + M.kt[2]) / 3.0;
+    const double kd_ = M.ad, ks_ = M.as, kt_ = M.at;            /* ri_vector_ave of kd, ks, kt */
     const double ksum = kd_ + ks_ + kt_;
     /* ri_intersection_state_build subset: P, Ng, Ns, colour */
     const double *tv = (const double *)sc.tri64 + 9 * (size_t)p;
@@ -120,14 +152,16 @@ __device__ __forceinline__ void pt_scatter(const lh_dev_scene_t &sc, const doubl
     double P[3], Ng[3], Ns[3], v01[3], v02[3];
     for (int k = 0; k < 3; k++) P[k] = org[k] + D[k] * tt;
     for (int k = 0; k < 3; k++) { v01[k] = tv[3 + k] - tv[k]; v02[k] = tv[6 + k] - tv[k]; }
-    vcross(Ng, v01, v02); vnormalize(Ng);
     bool has_n = false;
     if (nrm9) { const double n0x = nrm9[9 * (size_t)p]; has_n = (n0x == n0x); }
     if (has_n) {
         const double *nn = nrm9 + 9 * (size_t)p;
         for (int k = 0; k < 3; k++) { const double a = nn[k] * wgt, b = nn[3 + k] * uu, c = nn[6 + k] * vv; Ns[k] = (a + b) + c; }
         vnormalize(Ns);
-    } else { Ns[0] = Ng[0]; Ns[1] = Ng[1]; Ns[2] = Ng[2]; }
+    } else {                                    /* flat shaded: the geometric normal (only then is it needed at all) */
+        vcross(Ng, v01, v02); vnormalize(Ng);
+        Ns[0] = Ng[0]; Ns[1] = Ng[1]; Ns[2] = Ng[2];
+    }
     float col[3] = {1.0f, 1.0f, 1.0f};
     if (col9) {
         const double *cc = col9 + 9 * (size_t)p;
@@ -168,17 +202,15 @@ __device__ __forceinline__ void pt_scatter(const lh_dev_scene_t &sc, const doubl
         b1[ax] = 1.0;
         vcross(b0, b1, N); vnormalize(b0);
         vcross(b1, N, b0); vnormalize(b1);
-        const double z0 = rnd01(key + 1), z1 = rnd01(key + 2);
-        const double ct = sqrt(z0), phi = 2.0 * 3.14159265358979323846 * z1;
-        double sp, cp;
-        sincos(phi, &sp, &cp);
-        const double d0 = cp * ct, d1 = sp * ct, d2 = sqrt(1.0 - ct * ct);
-        for (int k = 0; k < 3; k++) O[k] = d0 * b0[k] + d1 * b1[k] + d2 * N[k];
+        /* the local direction in single precision, as the reference holds it (v.f[] = (float)(...), pathtrace.c:519-521),
+         * by arithmetic that gives the same bits on any IEEE machine (pt_lobe): the oracle repeats it exactly */
+        float d0, d1, d2;
+        pt_lobe((float)rnd01(key + 1), (float)rnd01(key + 2), d0, d1, d2);
+        for (int k = 0; k < 3; k++) O[k] = (double)d0 * b0[k] + (double)d1 * b1[k] + (double)d2 * N[k];
     }
     /* throughput (brdf, pathtrace.c:533-565) */
     const float *kk = type == 0 ? M.kd : (type == 1 ? M.ks : M.kt);
-    const double pk = type == 0 ? kd_ : (type == 1 ? ks_ : kt_);
-    const float wsel = ref_weights ? (type == 0 ? 0.318309886f : 1.0f) : (float)(1.0 / pk);     /* unbiased: / (P(type) x survival) */
+    const float wsel = ref_weights ? (type == 0 ? 0.318309886f : 1.0f) : (type == 0 ? M.wd : (type == 1 ? M.ws : M.wt));     /* unbiased: 1 / (P(type) x survival) = (float)(1 / ave) */
     for (int k = 0; k < 3; k++) {
         G2[k] = G[k] * kk[k] * col[k] * wsel;
         org2[k] = P[k] + side * N[k] * 1.0e-6;

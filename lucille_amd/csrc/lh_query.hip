@@ -65,7 +65,7 @@ int lh_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, voi
 {
     if (!a || !a->committed) return fail("intersect: accel not committed");
     if (n == 0) return 0;
-    if (!d_org || !d_dir) return fail("intersect: NULL ray arrays");
+    if ((!d_org || !d_dir) && !a->dev.cam_src) return fail("intersect: NULL ray arrays");
     if (mode == LH_MODE_CLOSEST && (!d_prim || !d_t || !d_u || !d_v)) return fail("intersect: closest mode needs prim,t,u,v outputs");
     if (mode == LH_MODE_ANY && !d_occ) return fail("intersect: any mode needs the occluded output");
     if (mode != LH_MODE_CLOSEST && mode != LH_MODE_ANY) return fail("intersect: unknown mode %d", mode);

@@ -143,34 +143,6 @@ __global__ void k_scan_blocks(uint32_t nblocks, uint32_t *__restrict__ block_cou
     if (threadIdx.x == 0) *total_out = carry;
 }
 
-/* the same scan for many blocks (the path tracer scans 262 144 block counts per bounce): per-group sums, a scan of the
- * group sums by one workgroup, then every group scans itself with its base */
-__global__ void k_scan_group_sums(uint32_t nblocks, const uint32_t *__restrict__ block_counts, uint32_t *__restrict__ group_sums)
-{
-    __shared__ uint32_t part[1024];
-    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
-    part[threadIdx.x] = (i < nblocks) ? block_counts[i] : 0;
-    __syncthreads();
-    for (uint32_t off = 512; off > 0; off >>= 1) { if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off]; __syncthreads(); }
-    if (threadIdx.x == 0) group_sums[blockIdx.x] = part[0];
-}
-
-__global__ void k_scan_within_groups(uint32_t nblocks, uint32_t *__restrict__ block_counts, const uint32_t *__restrict__ group_base)
-{
-    __shared__ uint32_t part[1024];
-    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
-    const uint32_t v = (i < nblocks) ? block_counts[i] : 0;
-    part[threadIdx.x] = v;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t t = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += t;
-        __syncthreads();
-    }
-    if (i < nblocks) block_counts[i] = group_base[blockIdx.x] + part[threadIdx.x] - v;
-}
-
 struct DevNormals { const double *nrm; };   /* 9 doubles per prim (n0 n1 n2), NaN n0.x => none */
 
 /* one thread per primary sample: slot = exclusive scan of the hit flags; writes the
@@ -400,99 +372,119 @@ __global__ void k_state_build(size_t n, const lh_dev_scene_t sc, const double *_
 /* ri_raytrace level (every bounce goes through the closest-hit kernel and fp64 resolve).   */
 /* ------------------------------------------------------------------------------------ */
 
-/* one thread per path: path id = (pixel * spp + s); primary camera ray through a random
- * sub-pixel position (sample_pixel, pathtrace.c:316-352) */
-__global__ void k_pt_primary(DevCamera cam, int x0, int y0, int w, int h, int spp, int s0, unsigned long long seed,
-                             double *__restrict__ org, double *__restrict__ dir, uint32_t *__restrict__ path_of,
-                             float *__restrict__ thr)
-{
-    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)w * h * spp;
-    if (id >= total) return;
-    double pos[3], d[3];
-    pt_primary_ray(cam, x0, y0, w, spp, s0, seed, id, pos, d);
-    org[3 * id] = pos[0]; org[3 * id + 1] = pos[1]; org[3 * id + 2] = pos[2];
-    dir[3 * id] = d[0]; dir[3 * id + 1] = d[1]; dir[3 * id + 2] = d[2];
-    path_of[id] = (uint32_t)id;                      /* bit 31: the path is inside a refractive object */
-    thr[3 * id] = 1.0f; thr[3 * id + 1] = 1.0f; thr[3 * id + 2] = 1.0f;
-}
+/* After the closest-hit launch of bounce `depth`: ONE pass over the live paths.  Round 2 ran decide -> flag count -> scan ->
+ * emit with the survivor count read back by the host before the next launch (110 dependent launches and 28 host round trips
+ * per 64-sample pass; the decide pass alone re-read 44 bytes per path vertex).  Here a workgroup takes LH_PT_ITEMS x 256
+ * consecutive paths, decides them all (miss -> radiance = throughput x environment, the path ends; hit -> vertex limit and
+ * Russian roulette on d + s + t, pathtrace.c:407-430 -> ends with radiance 0, or goes on), reserves the survivors' slots with
+ * one atomic on counts[depth + 1], and writes each survivor's next ray ONCE into its slot, in path order within the workgroup.
+ * The launch's own path count is counts[depth], left there by the previous bounce: nothing comes back to the host inside a
+ * pass.  Every path writes its radiance exactly once (where it ends), so the buffer needs no clearing.  Slot order across
+ * workgroups depends on scheduling; a path's arithmetic does not (keys are (pixel, sample, bounce)): the frame is the same. */
+#define LH_PT_ITEMS 8
+struct PtPass {
+    DevMaterial override_mat; DevEnv env;
+    const PtCamSrc *cam;                 /* bounce 0: the pass's rays are the camera rays, regenerated from the path id */
+    unsigned long long seed;
+    int use_override, ref_weights, depth, max_depth, s0, spp, x0, y0, w, full_width;
+};
 
-
-/* After the closest-hit launch of bounce `depth`, two passes over the live paths with a scan in between, so that a
- * surviving path's next ray is written ONCE, straight into its compacted slot (round 1 rewrote the ray in place and then
- * copied the survivors: 2 x 48 + 2 x 48 bytes per path vertex; the path tracer's own kernels are bandwidth-bound streams).
- * Both passes derive the same decisions from the same counter-based key (pixel, sample, bounce).
- *   k_pt_decide: miss -> radiance[path] = throughput x environment(dir), the path ends; hit -> vertex limit and Russian
- *                roulette on d + s + t (russian_roulette, pathtrace.c:407-430) -> alive flag
- *   k_pt_emit:   for the survivors: hit epilogue, reflection type D / S / T, next ray, throughput -> slot j */
-__global__ void k_pt_decide(size_t n, const uint32_t *__restrict__ prim_mesh, const DevMaterial *__restrict__ materials,
-                            const DevMaterial override_mat, int use_override, const DevEnv env,
-                            int depth, int max_depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w, int full_width,
-                            const double *__restrict__ dir, const uint32_t *__restrict__ prim, const uint32_t *__restrict__ path_of,
-                            const float *__restrict__ thr, float *__restrict__ radiance, uint8_t *__restrict__ alive)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t path = path_of[i] & ~LH_PT_INTERIOR;
-    const uint32_t p = prim[i];
-    if (p == LH_MISS_PRIM) {
-        float e[3];
-        env_fetch(env, dir[3 * i], dir[3 * i + 1], dir[3 * i + 2], e);
-        radiance[3 * (size_t)path] = thr[3 * i] * e[0]; radiance[3 * (size_t)path + 1] = thr[3 * i + 1] * e[1];
-        radiance[3 * (size_t)path + 2] = thr[3 * i + 2] * e[2];
-        alive[i] = 0; return;
-    }
-    const DevMaterial M = use_override ? override_mat : materials[prim_mesh[p]];
-    const uint64_t key = pt_key(seed, path, spp, s0, x0, y0, w, full_width, depth);
-    const bool go = pt_survives(M, key, depth, max_depth);
-    alive[i] = go ? 1 : 0;            /* radiance[] was zeroed for the pass: a path that ends here contributes nothing */
-}
-
-__global__ void k_pt_emit(size_t n, const lh_dev_scene_t sc, const double *__restrict__ nrm9, const double *__restrict__ col9,
-                          const uint32_t *__restrict__ prim_mesh, const DevMaterial *__restrict__ materials,
-                          const DevMaterial override_mat, int use_override, int ref_weights,
-                          int depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w, int full_width,
-                          const uint8_t *__restrict__ alive, const uint32_t *__restrict__ block_offsets,
-                          const double *__restrict__ org, const double *__restrict__ dir,
-                          const uint32_t *__restrict__ prim, const double *__restrict__ t, const double *__restrict__ u,
-                          const double *__restrict__ v, const uint32_t *__restrict__ path_of, const float *__restrict__ thr,
-                          double *__restrict__ org2, double *__restrict__ dir2, uint32_t *__restrict__ path_of2, float *__restrict__ thr2)
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_pt_shade(const PtPass ps, const lh_dev_scene_t sc, const double *__restrict__ nrm9,
+                                                  const double *__restrict__ col9, const uint32_t *__restrict__ prim_mesh,
+                                                  const DevMaterial *__restrict__ materials, uint32_t *__restrict__ counts,
+                                                  const double *__restrict__ org, const double *__restrict__ dir,
+                                                  const uint32_t *__restrict__ prim, const double *__restrict__ t,
+                                                  const double *__restrict__ u, const double *__restrict__ v,
+                                                  const uint32_t *__restrict__ path_of, const float *__restrict__ thr,
+                                                  float *__restrict__ radiance, double *__restrict__ org2, double *__restrict__ dir2,
+                                                  uint32_t *__restrict__ path_of2, float *__restrict__ thr2)
 {
     LH_NC
-    __shared__ uint32_t wsum[4];
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const bool f = (i < n) && alive[i];
-    const unsigned long long m = __ballot(f);
+    __shared__ unsigned long long sbal[LH_PT_ITEMS][4];
+    __shared__ uint32_t soff[LH_PT_ITEMS][4];
+    __shared__ uint32_t gbase, stotal;
+    __shared__ uint16_t slist[256 * LH_PT_ITEMS];
+    const uint32_t n = counts[ps.depth];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) wsum[wv] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (!f) return;
-    uint32_t woff = 0;
-    for (int k = 0; k < wv; k++) woff += wsum[k];
-    const size_t j = block_offsets[blockIdx.x] + woff + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-
-    const uint32_t pword = path_of[i];
-    const uint32_t path = pword & ~LH_PT_INTERIOR;
-    const uint32_t p = prim[i];
-    const float G[3] = {thr[3 * i], thr[3 * i + 1], thr[3 * i + 2]};
-    const double Or[3] = {org[3 * i], org[3 * i + 1], org[3 * i + 2]}, D[3] = {dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]};
-    const uint64_t key = pt_key(seed, path, spp, s0, x0, y0, w, full_width, depth);
-    const DevMaterial M = use_override ? override_mat : materials[prim_mesh[p]];
-    double o2[3], O[3]; float G2[3]; uint32_t pw2;
-    pt_scatter(sc, nrm9, col9, M, ref_weights, key, p, pword, Or, D, t[i], u[i], v[i], G, o2, O, G2, pw2);
-    for (int k = 0; k < 3; k++) { thr2[3 * j + k] = G2[k]; org2[3 * j + k] = o2[k]; dir2[3 * j + k] = O[k]; }
-    path_of2[j] = pw2;
+    const uint32_t span = 256u * LH_PT_ITEMS;
+    for (uint32_t base = blockIdx.x * span; base < n; base += gridDim.x * span) {      /* n < 2^31: no wrap */
+#pragma unroll 1
+        for (int k = 0; k < LH_PT_ITEMS; k++) {
+            const uint32_t i = base + (uint32_t)k * 256u + threadIdx.x;
+            bool go = false;
+            if (i < n) {
+                const uint32_t p = prim[i];
+                const uint32_t path = FIRST ? i : (path_of[i] & ~LH_PT_INTERIOR);
+                float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+                if (p == LH_MISS_PRIM) {
+                    float e[3];
+                    if (ps.env.map) {
+                        double o[3], d[3];
+                        if (FIRST) pt_camera_ray(ps.cam, i, o, d);
+                        else { d[0] = dir[3 * (size_t)i]; d[1] = dir[3 * (size_t)i + 1]; d[2] = dir[3 * (size_t)i + 2]; }
+                        env_fetch(ps.env, d[0], d[1], d[2], e);
+                    } else { e[0] = ps.env.rgb[0]; e[1] = ps.env.rgb[1]; e[2] = ps.env.rgb[2]; }
+                    if (FIRST) { r0 = e[0]; r1 = e[1]; r2 = e[2]; }
+                    else { r0 = thr[3 * (size_t)i] * e[0]; r1 = thr[3 * (size_t)i + 1] * e[1]; r2 = thr[3 * (size_t)i + 2] * e[2]; }
+                } else {
+                    const DevMaterial M = ps.use_override ? ps.override_mat : materials[prim_mesh[p]];
+                    go = pt_survives(M, pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.full_width, ps.depth), ps.depth, ps.max_depth);
+                }
+                if (!go) { radiance[3 * (size_t)path] = r0; radiance[3 * (size_t)path + 1] = r1; radiance[3 * (size_t)path + 2] = r2; }
+            }
+            const unsigned long long m = __ballot(go);
+            if (lane == 0) { sbal[k][wv] = m; soff[k][wv] = (uint32_t)__popcll(m); }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {                      /* 32 counts -> exclusive offsets in path order (item-major, then wave) */
+            uint32_t run = 0;
+            for (int k = 0; k < LH_PT_ITEMS; k++) for (int w = 0; w < 4; w++) { const uint32_t c = soff[k][w]; soff[k][w] = run; run += c; }
+            gbase = run ? atomicAdd(&counts[ps.depth + 1], run) : 0u;
+            stotal = run;
+        }
+        __syncthreads();
+        const uint32_t g = gbase;
+        /* the survivors' item numbers, in slot order: the expensive part below (hit epilogue, fp64 sincos / sqrt / divisions) then
+         * runs with every lane busy instead of the ~half that survive (depth 0) or fewer (later bounces) */
+#pragma unroll 1
+        for (int k = 0; k < LH_PT_ITEMS; k++) {
+            const unsigned long long m = sbal[k][wv];
+            if ((m >> lane) & 1ull) slist[soff[k][wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(k * 256 + (int)threadIdx.x);
+        }
+        __syncthreads();
+        const uint32_t nlive = stotal;
+#pragma unroll 1
+        for (uint32_t q = threadIdx.x; q < nlive; q += 256u) {
+            const uint32_t i = base + (uint32_t)slist[q];
+            const size_t j = (size_t)g + q;
+            const uint32_t pword = FIRST ? i : path_of[i];
+            const uint32_t path = pword & ~LH_PT_INTERIOR;
+            const uint32_t p = prim[i];
+            float G[3] = {1.0f, 1.0f, 1.0f};
+            if (!FIRST) { G[0] = thr[3 * (size_t)i]; G[1] = thr[3 * (size_t)i + 1]; G[2] = thr[3 * (size_t)i + 2]; }
+            double Or[3], D[3];
+            if (FIRST) pt_camera_ray(ps.cam, i, Or, D);
+            else {
+                Or[0] = org[3 * (size_t)i]; Or[1] = org[3 * (size_t)i + 1]; Or[2] = org[3 * (size_t)i + 2];
+                D[0] = dir[3 * (size_t)i]; D[1] = dir[3 * (size_t)i + 1]; D[2] = dir[3 * (size_t)i + 2];
+            }
+            const uint64_t key = pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.full_width, ps.depth);
+            const DevMaterial M = ps.use_override ? ps.override_mat : materials[prim_mesh[p]];
+            double o2[3], O[3]; float G2[3]; uint32_t pw2;
+            pt_scatter(sc, nrm9, col9, M, ps.ref_weights, key, p, pword, Or, D, t[i], u[i], v[i], G, o2, O, G2, pw2);
+            for (int c = 0; c < 3; c++) { thr2[3 * j + c] = G2[c]; org2[3 * j + c] = o2[c]; dir2[3 * j + c] = O[c]; }
+            path_of2[j] = pw2;
+        }
+        __syncthreads();
+    }
 }
 
-__global__ void k_flag_count(size_t n, const uint8_t *__restrict__ flag, uint32_t *__restrict__ block_counts)
+/* counts[0] = the pass's paths, counts[1 ..] = 0; the pass's camera-ray source into device memory */
+__global__ void k_pt_begin(uint32_t *counts, uint32_t paths, int nentries, const PtCamSrc src, PtCamSrc *dst)
 {
-    __shared__ uint32_t wsum[4];
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const bool f = (i < n) && flag[i];
-    const unsigned long long m = __ballot(f);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    for (int i = threadIdx.x; i < nentries; i += blockDim.x) counts[i] = i == 0 ? paths : 0u;
+    if (threadIdx.x == 0) *dst = src;
 }
 
 /* per pixel: add the mean of this pass's samples (in sample order).  A workgroup's 256 pixels are one contiguous run of
@@ -598,58 +590,65 @@ extern "C" int lh_render_launch_resolve(int w, int h, int band_rows, int xs, int
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-extern "C" int lh_pt_launch_primary(const lh_camera_t *cam, int x0, int y0, int w, int h, int spp, int s0,
-                                    unsigned long long seed, double *d_org, double *d_dir, uint32_t *d_path_of,
-                                    float *d_thr, void *stream)
+/* lh_material_t -> the device record (lh_pt.h: + channel averages, 1 / P(lobe)) */
+static void pack_material(const lh_material_t *m, DevMaterial *d)
 {
-    DevCamera c;
-    for (int i = 0; i < 16; i++) c.c2w[i] = cam->cam2world[i];
-    c.flength = cam->flength; c.width = cam->width; c.height = cam->height; c.rh = cam->rh; c.ortho = cam->ortho;
+    memset(d, 0, sizeof(*d));
+    for (int k = 0; k < 3; k++) { d->kd[k] = m->kd[k]; d->ks[k] = m->ks[k]; d->kt[k] = m->kt[k]; }
+    d->ior = m->ior;
+    d->ad = ((double)m->kd[0] + m->kd[1] + m->kd[2]) / 3.0; d->as = ((double)m->ks[0] + m->ks[1] + m->ks[2]) / 3.0;
+    d->at = ((double)m->kt[0] + m->kt[1] + m->kt[2]) / 3.0;
+    d->asum9 = ((double)m->kd[0] + m->kd[1] + m->kd[2] + m->ks[0] + m->ks[1] + m->ks[2] + m->kt[0] + m->kt[1] + m->kt[2]) / 3.0;
+    d->wd = (float)(1.0 / d->ad); d->ws = (float)(1.0 / d->as); d->wt = (float)(1.0 / d->at);
+}
+extern "C" size_t lh_pt_material_bytes(void) { return sizeof(DevMaterial); }
+extern "C" void lh_pt_material_pack(const lh_material_t *m, void *out) { pack_material(m, (DevMaterial *)out); }
+
+/* start of a pass: counts[0] = its paths, the camera-ray source (PtCamSrc) into d_cam */
+extern "C" int lh_pt_launch_begin(const lh_camera_t *cam, int x0, int y0, int w, int h, int spp, int s0,
+                                  unsigned long long seed, void *d_cam, uint32_t *d_counts, int ncounts, void *stream)
+{
+    PtCamSrc c;
+    memset(&c, 0, sizeof(c));
+    for (int i = 0; i < 16; i++) c.cam.c2w[i] = cam->cam2world[i];
+    c.cam.flength = cam->flength; c.cam.width = cam->width; c.cam.height = cam->height; c.cam.rh = cam->rh; c.cam.ortho = cam->ortho;
+    c.seed = seed; c.x0 = x0; c.y0 = y0; c.w = w; c.spp = spp; c.s0 = s0;
     const size_t total = (size_t)w * h * spp;
-    if (total == 0) return 0;
-    hipLaunchKernelGGL(k_pt_primary, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       c, x0, y0, w, h, spp, s0, seed, d_org, d_dir, d_path_of, d_thr);
+    hipLaunchKernelGGL(k_pt_begin, dim3(1), dim3(256), 0, (hipStream_t)stream, d_counts, (uint32_t)total, ncounts, c, (PtCamSrc *)d_cam);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-/* exclusive scan of d_blocks[nb] in place, total -> *d_total; d_groups: scratch of (nb + 1023) / 1024 + 1 words */
-static void launch_scan(uint32_t nb, uint32_t *d_blocks, uint32_t *d_groups, unsigned long long *d_total, hipStream_t s)
-{
-    if (nb <= 4096) { hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, nb, d_blocks, d_total); return; }
-    const uint32_t ng = (nb + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_group_sums, dim3(ng), dim3(1024), 0, s, nb, (const uint32_t *)d_blocks, d_groups);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, ng, d_groups, d_total);
-    hipLaunchKernelGGL(k_scan_within_groups, dim3(ng), dim3(1024), 0, s, nb, d_blocks, (const uint32_t *)d_groups);
-}
+extern "C" size_t lh_pt_cam_bytes(void) { return sizeof(PtCamSrc); }
 
-extern "C" int lh_pt_launch_shade(size_t n, const lh_dev_scene_t *sc, const double *d_nrm9, const double *d_col9,
+/* the shading pass of bounce `depth` over counts[depth] paths (at most n_max); survivors are counted into counts[depth + 1] */
+extern "C" int lh_pt_launch_shade(size_t n_max, const lh_dev_scene_t *sc, const double *d_nrm9, const double *d_col9,
                                   const uint32_t *d_prim_mesh, const void *d_materials, const lh_material_t *override_mat,
                                   const float env_rgb[3], const void *d_env_map, int env_w, int env_h, int ref_weights,
                                   int depth, int max_depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w,
-                                  int full_width, double *d_org, double *d_dir, const uint32_t *d_prim,
-                                  const double *d_t, const double *d_u, const double *d_v, uint32_t *d_path_of,
-                                  float *d_thr, float *d_radiance, uint8_t *d_alive, uint32_t *d_blocks,
-                                  unsigned long long *d_total, double *d_org2, double *d_dir2, uint32_t *d_path_of2,
-                                  float *d_thr2, void *stream)
+                                  int full_width, const void *d_cam, uint32_t *d_counts, const double *d_org, const double *d_dir, const uint32_t *d_prim,
+                                  const double *d_t, const double *d_u, const double *d_v, const uint32_t *d_path_of,
+                                  const float *d_thr, float *d_radiance, double *d_org2, double *d_dir2, uint32_t *d_path_of2,
+                                  float *d_thr2, int ncus, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
-    if (n == 0) return 0;
-    const unsigned nb = (unsigned)((n + 255) / 256);
-    DevMaterial om;
-    memset(&om, 0, sizeof(om));
-    if (override_mat) { for (int k = 0; k < 3; k++) { om.kd[k] = override_mat->kd[k]; om.ks[k] = override_mat->ks[k]; om.kt[k] = override_mat->kt[k]; } om.ior = override_mat->ior; }
-    DevEnv env;
-    env.rgb[0] = env_rgb[0]; env.rgb[1] = env_rgb[1]; env.rgb[2] = env_rgb[2];
-    env.map = (const float4 *)d_env_map; env.w = env_w; env.h = env_h;
-    hipLaunchKernelGGL(k_pt_decide, dim3(nb), dim3(256), 0, s, n, d_prim_mesh, (const DevMaterial *)d_materials, om, override_mat != NULL, env,
-                       depth, max_depth, seed, s0, spp, x0, y0, w, full_width, (const double *)d_dir, d_prim, (const uint32_t *)d_path_of,
-                       (const float *)d_thr, d_radiance, d_alive);
-    hipLaunchKernelGGL(k_flag_count, dim3(nb), dim3(256), 0, s, n, d_alive, d_blocks);
-    launch_scan(nb, d_blocks, d_blocks + nb, d_total, s);           /* the caller sizes d_blocks for nb + nb / 1024 + 2 words */
-    hipLaunchKernelGGL(k_pt_emit, dim3(nb), dim3(256), 0, s, n, *sc, d_nrm9, d_col9, d_prim_mesh, (const DevMaterial *)d_materials, om,
-                       override_mat != NULL, ref_weights, depth, seed, s0, spp, x0, y0, w, full_width, (const uint8_t *)d_alive,
-                       (const uint32_t *)d_blocks, (const double *)d_org, (const double *)d_dir, d_prim, d_t, d_u, d_v,
-                       (const uint32_t *)d_path_of, (const float *)d_thr, d_org2, d_dir2, d_path_of2, d_thr2);
+    if (n_max == 0) return 0;
+    PtPass ps;
+    memset(&ps, 0, sizeof(ps));
+    if (override_mat) pack_material(override_mat, &ps.override_mat);
+    ps.env.rgb[0] = env_rgb[0]; ps.env.rgb[1] = env_rgb[1]; ps.env.rgb[2] = env_rgb[2];
+    ps.env.map = (const float4 *)d_env_map; ps.env.w = env_w; ps.env.h = env_h;
+    ps.cam = (const PtCamSrc *)d_cam;
+    ps.seed = seed; ps.use_override = override_mat != NULL; ps.ref_weights = ref_weights; ps.depth = depth; ps.max_depth = max_depth;
+    ps.s0 = s0; ps.spp = spp; ps.x0 = x0; ps.y0 = y0; ps.w = w; ps.full_width = full_width;
+    const size_t spans = (n_max + 256 * LH_PT_ITEMS - 1) / (256 * LH_PT_ITEMS);
+    const size_t cap = (size_t)(ncus > 0 ? ncus : 256) * 8;
+    const unsigned nb = (unsigned)(spans < cap ? spans : cap);
+    if (depth == 0)
+        hipLaunchKernelGGL((k_pt_shade<true>), dim3(nb), dim3(256), 0, s, ps, *sc, d_nrm9, d_col9, d_prim_mesh, (const DevMaterial *)d_materials,
+                           d_counts, d_org, d_dir, d_prim, d_t, d_u, d_v, d_path_of, d_thr, d_radiance, d_org2, d_dir2, d_path_of2, d_thr2);
+    else
+        hipLaunchKernelGGL((k_pt_shade<false>), dim3(nb), dim3(256), 0, s, ps, *sc, d_nrm9, d_col9, d_prim_mesh, (const DevMaterial *)d_materials,
+                           d_counts, d_org, d_dir, d_prim, d_t, d_u, d_v, d_path_of, d_thr, d_radiance, d_org2, d_dir2, d_path_of2, d_thr2);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -350,6 +350,9 @@ extern "C" int lh_accel_set_environment(lh_accel_t *a, const lh_environment_t *e
     return 0;
 }
 
+extern "C" size_t lh_pt_material_bytes(void);
+extern "C" void lh_pt_material_pack(const lh_material_t *m, void *out);
+
 static int sync_materials(lh_accel_t *a)
 {
     const uint32_t nm = a->hs->nmeshes ? a->hs->nmeshes : 1;
@@ -362,8 +365,11 @@ static int sync_materials(lh_accel_t *a)
     }
     if (a->materials_dirty || !a->d_materials) {
         if (a->d_materials) { (void)hipFree(a->d_materials); a->d_materials = NULL; }
-        HIPCHK(hipMalloc(&a->d_materials, sizeof(lh_material_t) * a->nmaterials));
-        HIPCHK(hipMemcpy(a->d_materials, a->materials, sizeof(lh_material_t) * a->nmaterials, hipMemcpyHostToDevice));
+        const size_t mb = lh_pt_material_bytes();
+        std::vector<char> packed(mb * a->nmaterials);
+        for (uint32_t k = 0; k < a->nmaterials; k++) lh_pt_material_pack(&a->materials[k], packed.data() + mb * k);
+        HIPCHK(hipMalloc(&a->d_materials, packed.size()));
+        HIPCHK(hipMemcpy(a->d_materials, packed.data(), packed.size(), hipMemcpyHostToDevice));
         a->materials_dirty = 0;
     }
     if (!a->d_prim_mesh && a->hs->bvh.ntris) {
@@ -374,71 +380,91 @@ static int sync_materials(lh_accel_t *a)
 }
 
 /* ------------------------------------------------------------------------ */
-/* wavefront path tracer                                                    */
+/* wavefront path tracer (kernels: lh_render.hip, arithmetic: lh_pt.h)       */
 /* ------------------------------------------------------------------------ */
-extern "C" int lh_pt_launch_primary(const lh_camera_t *cam, int x0, int y0, int w, int h, int spp, int s0,
-                                    unsigned long long seed, double *d_org, double *d_dir, uint32_t *d_path_of,
-                                    float *d_thr, void *stream);
-extern "C" int lh_pt_launch_shade(size_t n, const lh_dev_scene_t *sc, const double *d_nrm9, const double *d_col9,
+extern "C" int lh_pt_launch_begin(const lh_camera_t *cam, int x0, int y0, int w, int h, int spp, int s0,
+                                  unsigned long long seed, void *d_cam, uint32_t *d_counts, int ncounts, void *stream);
+extern "C" size_t lh_pt_cam_bytes(void);
+extern "C" int lh_pt_launch_shade(size_t n_max, const lh_dev_scene_t *sc, const double *d_nrm9, const double *d_col9,
                                   const uint32_t *d_prim_mesh, const void *d_materials, const lh_material_t *override_mat,
                                   const float env_rgb[3], const void *d_env_map, int env_w, int env_h, int ref_weights,
                                   int depth, int max_depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w,
-                                  int full_width, double *d_org, double *d_dir, const uint32_t *d_prim,
-                                  const double *d_t, const double *d_u, const double *d_v, uint32_t *d_path_of,
-                                  float *d_thr, float *d_radiance, uint8_t *d_alive, uint32_t *d_blocks,
-                                  unsigned long long *d_total, double *d_org2, double *d_dir2, uint32_t *d_path_of2,
-                                  float *d_thr2, void *stream);
+                                  int full_width, const void *d_cam, uint32_t *d_counts, const double *d_org, const double *d_dir, const uint32_t *d_prim,
+                                  const double *d_t, const double *d_u, const double *d_v, const uint32_t *d_path_of,
+                                  const float *d_thr, float *d_radiance, double *d_org2, double *d_dir2, uint32_t *d_path_of2,
+                                  float *d_thr2, int ncus, void *stream);
 extern "C" int lh_pt_launch_resolve(int w, int h, int spp, float inv_total_spp, const float *d_radiance, float *d_rgb, void *stream);
 
 static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int s0, int spp, int spp_total, int max_vertices,
                    const lh_material_t *override_mat, const float env_rgb[3], const void *d_env_map, int env_w, int env_h, int flags,
                    uint64_t seed, void *d_rgb, lh_pt_stats_t *stats, void *stream)
 {
-    if (w <= 0 || h <= 0 || spp < 1 || spp_total < spp || max_vertices < 2) return fail("lh_render_pt_tile: bad arguments");
+    if (w <= 0 || h <= 0 || spp < 1 || spp_total < spp || max_vertices < 2 || max_vertices > 65536) return fail("lh_render_pt_tile: bad arguments");
     HIPCHK(hipSetDevice(a->device));
     if (sync_materials(a) != 0) return -1;
     hipStream_t s = (hipStream_t)stream;
     const size_t S = (size_t)w * h * spp;
-    if (S >= ((size_t)1 << 31)) return fail("lh_render_pt_tile: more than 2^31 paths in one pass; lower spp_count or the tile size");
+    if (S > ((size_t)1 << 30)) return fail("lh_render_pt_tile: more than 2^30 paths in one pass; lower spp_count or the tile size");
     unsigned long long *cnt = (a->stat_on && a->hs->bvh.ntris) ? a->d_counters : NULL;      /* lh_accel_trace_statistics */
     if (cnt) HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * LH_CNT_DEV, s));
-    const unsigned nb = (unsigned)((S + 255) / 256);
+    const int nbounce = max_vertices - 1;                  /* bounce d traces the ray to path vertex d + 2; the last vertex scatters nothing */
     if (ensure_buf(&a->r_org, S * 24) || ensure_buf(&a->r_dir, S * 24) || ensure_buf(&a->p_org2, S * 24) ||
         ensure_buf(&a->p_dir2, S * 24) || ensure_buf(&a->r_prim, S * 4) || ensure_buf(&a->r_t, S * 8) ||
         ensure_buf(&a->r_u, S * 8) || ensure_buf(&a->r_v, S * 8) || ensure_buf(&a->p_path, S * 4) ||
         ensure_buf(&a->p_path2, S * 4) || ensure_buf(&a->p_thr, S * 12) || ensure_buf(&a->p_thr2, S * 12) ||
-        ensure_buf(&a->p_rad, S * 12) || ensure_buf(&a->p_alive, S) || ensure_buf(&a->r_blocks, ((size_t)nb + nb / 1024 + 4) * 4)) return -1;
-    HIPCHK(hipMemsetAsync(a->p_rad.p, 0, S * 12, s));
-    double *org = (double *)a->r_org.p, *dir = (double *)a->r_dir.p, *org2 = (double *)a->p_org2.p, *dir2 = (double *)a->p_dir2.p;
-    uint32_t *path = (uint32_t *)a->p_path.p, *path2 = (uint32_t *)a->p_path2.p;
-    float *thr = (float *)a->p_thr.p, *thr2 = (float *)a->p_thr2.p;
-    if (lh_pt_launch_primary(cam, x0, y0, w, h, spp, s0, seed, org, dir, path, thr, s) != 0) return fail("pt primary launch failed");
-    size_t n = S; uint64_t rays = 0; int depth = 0;
-    while (n > 0) {
-        if (lh_launch(a, n, org, dir, a->r_prim.p, a->r_t.p, a->r_u.p, a->r_v.p, NULL, LH_MODE_CLOSEST, LH_VARIANT_DEFAULT, cnt, s, false) != 0) return -1;
-        rays += n;
-        if (lh_pt_launch_shade(n, &a->dev, (const double *)a->d_nrm9, (const double *)a->d_attr9[0], (const uint32_t *)a->d_prim_mesh,
+        ensure_buf(&a->p_rad, S * 12) || ensure_buf(&a->p_counts, ((size_t)nbounce + 2) * 4 + 64 + lh_pt_cam_bytes())) return -1;
+    /* the chain's ray / path-word / throughput records alternate between two sets; bounce 0 reads none (its rays are the camera
+     * rays, generated inside the closest-hit kernel and again by the shading pass for the paths that go on) */
+    double *org = NULL, *dir = NULL, *org2 = (double *)a->r_org.p, *dir2 = (double *)a->r_dir.p;
+    uint32_t *path = NULL, *path2 = (uint32_t *)a->p_path.p, *counts = (uint32_t *)a->p_counts.p;
+    float *thr = NULL, *thr2 = (float *)a->p_thr.p;
+    void *d_cam = (char *)a->p_counts.p + (((size_t)nbounce + 2) * 4 + 63) / 64 * 64;
+    /* counts[d] = rays of bounce d: [0] = S here, [d + 1] accumulated by bounce d's shading pass.  The host never reads a count
+     * inside the chain (every launch gets S as its upper bound and the count's address) -- except every 8th bounce of a long
+     * chain (a furnace test's 400 vertices), to stop once every path has ended */
+    if (lh_pt_launch_begin(cam, x0, y0, w, h, spp, s0, seed, d_cam, counts, nbounce + 2, s) != 0) return fail("pt begin launch failed");
+    int rc = 0;
+    for (int depth = 0; depth < nbounce && rc == 0; depth++) {
+        a->dev.n_dev = counts + depth; a->dev.cam_src = depth == 0 ? d_cam : NULL;
+        rc = lh_launch(a, S, org, dir, a->r_prim.p, a->r_t.p, a->r_u.p, a->r_v.p, NULL, LH_MODE_CLOSEST, LH_VARIANT_SPEC, cnt, s, false);
+        a->dev.n_dev = NULL; a->dev.cam_src = NULL;
+        if (rc != 0) break;
+        if (lh_pt_launch_shade(S, &a->dev, (const double *)a->d_nrm9, (const double *)a->d_attr9[0], (const uint32_t *)a->d_prim_mesh,
                                a->d_materials, override_mat, env_rgb, d_env_map, env_w, env_h, (flags & LH_PT_REFERENCE_WEIGHTS) != 0,
-                               depth, max_vertices, seed, s0, spp, x0, y0, w, cam->width, org, dir, (const uint32_t *)a->r_prim.p,
+                               depth, max_vertices, seed, s0, spp, x0, y0, w, cam->width, d_cam, counts, org, dir, (const uint32_t *)a->r_prim.p,
                                (const double *)a->r_t.p, (const double *)a->r_u.p, (const double *)a->r_v.p, path, thr, (float *)a->p_rad.p,
-                               (uint8_t *)a->p_alive.p, (uint32_t *)a->r_blocks.p, a->d_total, org2, dir2, path2, thr2, s) != 0)
+                               org2, dir2, path2, thr2, a->ncus, s) != 0)
             return fail("pt shade launch failed: %s", hipGetErrorString(hipGetLastError()));
-        unsigned long long alive = 0;
-        HIPCHK(hipMemcpyAsync(&alive, a->d_total, sizeof(alive), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        n = (size_t)alive; depth++;
-        { double *t1 = org; org = org2; org2 = t1; t1 = dir; dir = dir2; dir2 = t1; }
-        { uint32_t *t2 = path; path = path2; path2 = t2; float *t3 = thr; thr = thr2; thr2 = t3; }
+        if (depth == 0) {
+            org = org2; dir = dir2; path = path2; thr = thr2;
+            org2 = (double *)a->p_org2.p; dir2 = (double *)a->p_dir2.p; path2 = (uint32_t *)a->p_path2.p; thr2 = (float *)a->p_thr2.p;
+        } else {
+            { double *t1 = org; org = org2; org2 = t1; t1 = dir; dir = dir2; dir2 = t1; }
+            { uint32_t *t2 = path; path = path2; path2 = t2; float *t3 = thr; thr = thr2; thr2 = t3; }
+        }
+        if ((depth & 7) == 7 && depth + 1 < nbounce) {
+            uint32_t left = 0;
+            HIPCHK(hipMemcpyAsync(&left, counts + depth + 1, sizeof(left), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (left == 0) break;
+        }
     }
+    if (rc != 0) return -1;
     if (lh_pt_launch_resolve(w, h, spp, 1.0f / (float)spp_total, (const float *)a->p_rad.p, (float *)d_rgb, s) != 0)
         return fail("pt resolve launch failed");
+    std::vector<uint32_t> hcounts((size_t)nbounce + 1);
+    HIPCHK(hipMemcpyAsync(hcounts.data(), counts, hcounts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (cnt) {
         unsigned long long hc[LH_CNT_N];
         HIPCHK(hipMemcpy(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost));
         a->stat[0] += hc[LH_CNT_NODES]; a->stat[1] += hc[LH_CNT_TRIS]; a->stat[2] += hc[LH_CNT_EXACT]; a->stat[3] += hc[LH_CNT_RAYS];
     }
-    if (stats) { stats->paths = S; stats->rays = rays; stats->max_depth_reached = (uint64_t)depth; }
+    if (stats) {
+        uint64_t rays = 0, depth = 0;
+        for (int d = 0; d < nbounce; d++) { rays += hcounts[d]; if (hcounts[d]) depth = (uint64_t)d + 1; }
+        stats->paths = S; stats->rays = rays; stats->max_depth_reached = depth;
+    }
     return 0;
 }
 

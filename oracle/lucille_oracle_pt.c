@@ -27,8 +27,8 @@
  *       in the direction it left (light_sample's extra visibility ray, :354-382, is that ray);
  *   (3) weights: flag 0 = the unbiased estimator of this sampling scheme (divide by P(type) x survival), flag 1 =
  *       the reference's own factors (1/pi on 'D', nothing else).
- * libm's sin/cos here vs the device's sincos may differ in the last place; everything else is the same IEEE arithmetic
- * (no contraction: oracle/Makefile builds with -ffp-contract=off).
+ * Every operation is a single IEEE operation on both sides (no contraction: oracle/Makefile builds with -ffp-contract=off;
+ * the cosine lobe's sin / cos are the product's own polynomial, lobe_f32); only the light probe's acos comes from libm.
  */
 #include "lucille_oracle.h"
 
@@ -69,6 +69,23 @@ static void normalize3(double d[3])
 static void cross3(double d[3], const double a[3], const double b[3])
 {
     d[0] = a[1] * b[2] - a[2] * b[1]; d[1] = a[2] * b[0] - a[0] * b[2]; d[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* the product's pt_lobe (lh_pt.h), operation for operation: single IEEE multiplies and adds only, so the bits agree */
+static void lobe_f32(float z0, float z1, float *d0, float *d1, float *d2)
+{
+    const int k = (int)(4.0f * z1 + 0.5f);
+    const float r = z1 - 0.25f * (float)k;
+    const float x = 6.28318530717958647692f * r, x2 = x * x;
+    float sp, cp, s, c, rad; int q;
+    sp = -1.9515295891e-4f * x2; sp = sp + 8.3321608736e-3f; sp = sp * x2; sp = sp - 1.6666654611e-1f; sp = sp * x2; sp = sp * x; sp = sp + x;
+    cp = 2.443315711809948e-5f * x2; cp = cp - 1.388731625493765e-3f; cp = cp * x2; cp = cp + 4.166664568298827e-2f; cp = cp * x2; cp = cp * x2;
+    cp = cp - 0.5f * x2; cp = cp + 1.0f;
+    q = k & 3;
+    s = q == 0 ? sp : (q == 1 ? cp : (q == 2 ? -sp : -cp));
+    c = q == 0 ? cp : (q == 1 ? -sp : (q == 2 ? -cp : sp));
+    rad = sqrtf(z0);
+    *d0 = c * rad; *d1 = s * rad; *d2 = sqrtf(1.0f - z0);
 }
 
 static double ave3(const float k[3]) { return ((double)k[0] + k[1] + k[2]) / 3.0; }
@@ -177,12 +194,10 @@ static uint32_t one_path(const lo_scene_t *s, const lo_camera_t *cam, int px, in
             const double dn = dir[0] * N[0] + dir[1] * N[1] + dir[2] * N[2];
             for (k = 0; k < 3; k++) O[k] = dir[k] - 2.0 * dn * N[k];
         } else if (type == 'D') {                                               /* sample_cosweight about ri_ortho_basis(N) */
-            double basis[3][3], z0, z1, ct, phi, d0, d1, d2;
+            double basis[3][3]; float d0, d1, d2;
             lo_ortho_basis(basis, N);
-            z0 = lo_pt_rnd(key + 1); z1 = lo_pt_rnd(key + 2);
-            ct = sqrt(z0); phi = 2.0 * 3.14159265358979323846 * z1;
-            d0 = cos(phi) * ct; d1 = sin(phi) * ct; d2 = sqrt(1.0 - ct * ct);
-            for (k = 0; k < 3; k++) O[k] = d0 * basis[0][k] + d1 * basis[1][k] + d2 * N[k];
+            lobe_f32((float)lo_pt_rnd(key + 1), (float)lo_pt_rnd(key + 2), &d0, &d1, &d2);     /* v.f[] = (float)(...), pathtrace.c:519-521 */
+            for (k = 0; k < 3; k++) O[k] = (double)d0 * basis[0][k] + (double)d1 * basis[1][k] + (double)d2 * N[k];
         }
         kk = type == 'D' ? M->kd : (type == 'S' ? M->ks : M->kt);               /* brdf */
         pk = type == 'D' ? kd_ : (type == 'S' ? ks_ : kt_);
