@@ -623,7 +623,9 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
     torch.cuda.empty_cache()
     free_b = torch.cuda.mem_get_info(dev)[0]
     per_pass = max(64 << 20, min(1 << 30, int(free_b * 7 // 10 // 176)))
-    chunk = max(1, min(spp, per_pass // (pt_tile * pt_tile)))
+    # sharded: a rank's interleaved 4-line bands (1 / world of the frame) are one pass per sample chunk (render_pt_frame_sharded)
+    area = pt_tile * pt_tile if world == 1 else max(1, size * size // world)
+    chunk = max(1, min(spp, per_pass // area))
     while spp % chunk:            # whole passes
         chunk -= 1
     for it in range(3):
@@ -677,7 +679,8 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
                         % (size, size, spp),
             "rays_per_frame": int(rays_all), "frame_ms": round(t_all * 1e3, 3),
             "value": round(rays_all / t_all / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
-            "spp_per_pass": chunk, "paths_per_pass": chunk * pt_tile * pt_tile,
+            "spp_per_pass": chunk, "paths_per_pass": chunk * area,
+            "shards": "one tile" if world == 1 else "full-width 4-line bands, band_id %% %d, a rank's bands = one pass per sample chunk (lh_render_pt_bands)" % world,
             "image_mean": float(img.mean().item()), "roofline": roof,
             # white furnace with albedo 0.8 under a unit environment: every pixel's radiance lies in (0, 1]
             "validation": {"frames_repeat": repeat, "retiled_frame_bit_equal": retiled,

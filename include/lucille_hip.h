@@ -237,6 +237,15 @@ int  lh_render_pt_tile2(lh_accel_t *accel, const lh_camera_t *cam, int x0, int y
                         int spp_begin, int spp_count, int spp_total, int max_path_vertices, int flags,
                         uint64_t seed, void *d_rgb, lh_pt_stats_t *stats, void *stream);
 
+/* a rank's interleaved full-width bands of an image-space sharded frame (BASELINE config 4 on N GPUs) as ONE pass: nbands bands
+ * of band_rows lines, band k starting at frame line y0_first + k * band_stride, all inside the frame.  d_rgb:
+ * [nbands][band_rows][width][3] float32, every band in image orientation (lh_render_ao_bands' layout).  Uses the accelerator's
+ * environment; override NULL: its per-mesh materials, else that material for every mesh.  Paths are keyed by (frame pixel,
+ * sample, bounce): the bands of all ranks together are the frame lh_render_pt_tile2 renders, bit for bit. */
+int  lh_render_pt_bands(lh_accel_t *accel, const lh_camera_t *cam, int y0_first, int band_rows, int band_stride, int nbands,
+                        int spp_begin, int spp_count, int spp_total, int max_path_vertices, int flags,
+                        const lh_material_t *override_material, uint64_t seed, void *d_rgb, lh_pt_stats_t *stats, void *stream);
+
 /* ---- the whole hit epilogue: ri_intersection_state_build (src/render/intersection_state.c:99-248) ----
  * Optional per-vertex attributes of mesh `mesh`, before commit (geom.h:34-48): colours, tangents, binormals
  * (xyz, `count` = vertices), texture coordinates (s, t per vertex) or texcoords_unshared (s, t per INDEX: `count` =

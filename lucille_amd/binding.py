@@ -102,7 +102,7 @@ ABI_SYMBOLS = [
     "lh_accel_trace_statistics", "lh_accel_statistics",
     "lh_render_ao_frame_host", "lh_rib_load", "lh_rib_free", "lh_rib_last_error", "lh_rib_info", "lh_rib_messages",
     "lh_rib_mesh", "lh_accel_add_rib_scene", "lh_hdr_write",
-    "lh_accel_set_material", "lh_accel_set_environment", "lh_render_pt_tile2", "lh_accel_set_attribute",
+    "lh_accel_set_material", "lh_accel_set_environment", "lh_render_pt_tile2", "lh_render_pt_bands", "lh_accel_set_attribute",
     "lh_accel_state_build_device", "lh_accel_state_build_host",
     "lh_multi_create", "lh_multi_destroy", "lh_multi_ndevices", "lh_multi_accel", "lh_multi_add_mesh", "lh_multi_set_normals",
     "lh_multi_add_rib_scene", "lh_multi_commit", "lh_multi_set_material", "lh_multi_set_environment", "lh_multi_intersect_host",
@@ -165,6 +165,8 @@ def lib():
     L.lh_accel_beam_visibility_device.argtypes = [vp, sz, vp, vp, vp, vp]
     L.lh_accel_set_material.argtypes = [vp, u32, C.POINTER(Material)]
     L.lh_accel_set_environment.argtypes = [vp, C.POINTER(Environment)]
+    L.lh_render_pt_bands.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(Material), C.c_uint64, vp,
+                                     C.POINTER(PtStats), vp]
     L.lh_render_pt_tile2.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, i32, i32, i32, C.c_uint64, vp,
                                      C.POINTER(PtStats), vp]
     L.lh_accel_set_attribute.argtypes = [vp, u32, i32, vp, sz, u32]
@@ -459,6 +461,24 @@ class HipAccel:
         st = PtStats()
         _check(self.L.lh_render_pt_tile2(self.h, C.byref(cam), x0, y0, w, h, spp_begin, spp_count, spp_total, max_vertices,
                                          int(flags), int(seed), _dptr(out), C.byref(st), C.c_void_p(stream)), "lh_render_pt_tile2")
+        return out, {k: int(getattr(st, k)) for k, _ in st._fields_}
+
+    def render_pt_bands(self, cam, y0_first, band_rows, band_stride, nbands, spp_begin, spp_count, spp_total, max_vertices=8, flags=0,
+                        override=None, seed=1, out=None, stream=None):
+        """lh_render_pt_bands: nbands full-width bands (band k starts at frame line y0_first + k * band_stride) as ONE pass ->
+        (float32 [nbands, band_rows, W, 3] CUDA tensor, accumulated into `out`; every band in image orientation; stats).
+        override: a Material for every mesh, None: the accelerator's own; environment: the accelerator's."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        if out is None:
+            out = torch.zeros((nbands, band_rows, cam.width, 3), dtype=torch.float32, device=dev)
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        st = PtStats()
+        _check(self.L.lh_render_pt_bands(self.h, C.byref(cam), int(y0_first), int(band_rows), int(band_stride), int(nbands), int(spp_begin),
+                                         int(spp_count), int(spp_total), int(max_vertices), int(flags),
+                                         C.byref(override) if override is not None else None, int(seed), _dptr(out), C.byref(st),
+                                         C.c_void_p(stream)), "lh_render_pt_bands")
         return out, {k: int(getattr(st, k)) for k, _ in st._fields_}
 
     def set_material(self, mesh, material):

@@ -452,13 +452,17 @@ __device__ __forceinline__ void trace_persist_lane(
 #endif
     bool exhausted = false;          /* wave-uniform: every partition's cursor ran past its end */
     uint32_t wbase = 0, wend = 0;    /* wave-uniform: this wave's reserved ray range */
-    uint32_t part, drained = 0;      /* wave-uniform: the partition this wave draws from, partitions it has found empty */
+    uint32_t part, drained = 0;      /* wave-uniform: the partition this wave draws from, bit mask of the partitions known to be handed out */
     uint32_t it = 0, it0 = 0;        /* wave-uniform iteration counter of the walk; its value when this lane's ray started */
     {
         int xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));      /* for speed only: any placement is correct */
         part = ((uint32_t)xcc & 7u) % LH_NPART;
     }
+
+    /* a batch smaller than the grid: the cursors hand out at most n / 64 + LH_NPART reservations, the waves beyond that count
+     * could only find them spent */
+    if ((uint64_t)(blockIdx.x * (LH_BLOCK / 64) + (tid >> 6)) * 64ull >= (uint64_t)n + 64ull * LH_NPART) exhausted = true;
 
     for (;;) {
         /* ---- regroup: retire finished lanes, refill them ----------------- */
@@ -503,15 +507,30 @@ __device__ __forceinline__ void trace_persist_lane(
                     const uint32_t c = n / (gridDim.x * (LH_BLOCK / 64) * 4u);
                     chunk = c < 64u ? 64u : (c < chunk ? c : chunk);
                 }
+                /* A partition found handed out is published in cursor[LH_NPART] (a bit mask, zeroed with the cursors), and a wave
+                 * that runs dry reads that word before it probes further.  Without it every wave probed all LH_NPART cursors at
+                 * the end of a launch: ~5000 waves x 8 device-scope atomics, serialised per address at ~95 ns each, were the
+                 * ~0.5 ms "drain" of every launch -- an EMPTY launch of the path tracer's bounce chain took 0.49 ms
+                 * (profiles/r03_pt_sky_timeline.csv) */
                 for (;;) {
+                    if (drained == (1u << LH_NPART) - 1u) { exhausted = true; break; }       /* every partition has been handed out */
+                    if (drained & (1u << part)) { part = (part + 1u) % LH_NPART; continue; }
                     const uint32_t p0 = per * part, p1 = (p0 + per < n) ? p0 + per : n;      /* per * LH_NPART < 2^31 + 8 */
                     const uint32_t plen = p1 > p0 ? p1 - p0 : 0u;                              /* a small batch leaves the last partitions empty */
-                    uint32_t b = 0;
-                    if ((tid & 63) == 0) b = atomicAdd(cursor + part, chunk);                  /* < 2^31 + waves * chunk: no wrap */
-                    b = (uint32_t)__shfl((int)b, 0);
+                    uint32_t b = plen;
+                    if (plen) {
+                        if ((tid & 63) == 0) b = atomicAdd(cursor + part, chunk);              /* < 2^31 + waves * chunk: no wrap */
+                        b = (uint32_t)__shfl((int)b, 0);
+                    }
                     if (b < plen) { b += p0; wbase = b; wend = (p1 - b > chunk) ? b + chunk : p1; break; }
+                    drained |= 1u << part;
+                    uint32_t seen = 0;
+                    if ((tid & 63) == 0) {
+                        seen = __hip_atomic_load(cursor + LH_NPART, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((seen & drained) != drained) atomicOr(cursor + LH_NPART, drained);
+                    }
+                    drained |= (uint32_t)__shfl((int)seen, 0);
                     part = (part + 1u) % LH_NPART;
-                    if (++drained >= LH_NPART) { exhausted = true; break; }     /* every partition has been handed out */
                 }
             }
             const int need = __popcll(idle_mask);

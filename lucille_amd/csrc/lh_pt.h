@@ -88,15 +88,25 @@ __device__ __forceinline__ void env_fetch(const DevEnv &e, double dx, double dy,
 
 /* the camera ray of path `id` = (pixel * spp + s) of a w-wide tile at (x0, y0): through a random sub-pixel position
  * (sample_pixel, pathtrace.c:316-352; ri_camera_get_pos_and_dir, camera.c:248-318) */
-__device__ __forceinline__ void pt_primary_ray(const DevCamera &cam, int x0, int y0, int w, int spp, int s0, unsigned long long seed,
-                                               size_t id, double pos3[3], double d[3])
+/* path id -> frame pixel.  The pass covers a w-wide region whose lines are those of full bands: line `row` of the pass is
+ * line y0 + (row / band_rows) * band_stride + row % band_rows of the frame (an ordinary tile: band_rows = its height; a rank's
+ * interleaved bands of a sharded frame: band_stride = world x band_rows) */
+__device__ __forceinline__ void pt_pixel(uint32_t pix, int x0, int y0, int w, int band_rows, int band_stride, int &px, int &py)
+{
+    const uint32_t row = pix / (uint32_t)w, band = row / (uint32_t)band_rows;
+    px = x0 + (int)(pix - row * (uint32_t)w);
+    py = y0 + (int)band * band_stride + (int)(row - band * (uint32_t)band_rows);
+}
+
+__device__ __forceinline__ void pt_primary_ray(const DevCamera &cam, int x0, int y0, int w, int band_rows, int band_stride, int spp, int s0,
+                                               unsigned long long seed, size_t id, double pos3[3], double d[3])
 {
     LH_NC
     /* 32-bit divisions: a pass holds fewer than 2^30 paths (64-bit ones cost ~4x the instructions, four per key) */
     const uint32_t id32 = (uint32_t)id, pix = id32 / (uint32_t)spp;
     const int s = (int)(id32 - pix * (uint32_t)spp);
-    const uint32_t row = pix / (uint32_t)w;
-    const int px = x0 + (int)(pix - row * (uint32_t)w), py = y0 + (int)row;
+    int px, py;
+    pt_pixel(pix, x0, y0, w, band_rows, band_stride, px, py);
     const uint64_t key = (seed * 0x9E3779B97F4A7C15ULL) ^ ((((uint64_t)py * (uint64_t)cam.width + (uint64_t)px) << 20) + (uint64_t)(s0 + s)) * 64ull;
     const double x = (double)px + rnd01(key), y = (double)py + rnd01(key + 1);
     const double W = cam.width, H = cam.height;
@@ -115,17 +125,20 @@ __device__ __forceinline__ void pt_primary_ray(const DevCamera &cam, int x0, int
 
 /* the camera rays of one pass as a ray SOURCE (lh_kernels.hip, ray source 2; the first bounce's shading pass): path id ->
  * ray, nothing materialised.  Lives in device memory (written by k_pt_begin), read with scalar loads. */
-struct PtCamSrc { DevCamera cam; unsigned long long seed; int x0, y0, w, spp, s0, pad; };
+struct PtCamSrc { DevCamera cam; unsigned long long seed; int x0, y0, w, spp, s0, band_rows, band_stride, pad; };
 
 __device__ __forceinline__ void pt_camera_ray(const PtCamSrc *__restrict__ c, uint32_t id, double pos3[3], double d[3])
 {
-    pt_primary_ray(c->cam, c->x0, c->y0, c->w, c->spp, c->s0, c->seed, (size_t)id, pos3, d);
+    pt_primary_ray(c->cam, c->x0, c->y0, c->w, c->band_rows, c->band_stride, c->spp, c->s0, c->seed, (size_t)id, pos3, d);
 }
 
-__device__ __forceinline__ uint64_t pt_key(unsigned long long seed, uint32_t path, int spp, int s0, int x0, int y0, int w, int full_width, int depth)
+__device__ __forceinline__ uint64_t pt_key(unsigned long long seed, uint32_t path, int spp, int s0, int x0, int y0, int w, int band_rows, int band_stride,
+                                           int full_width, int depth)
 {
-    const uint32_t pix = path / (uint32_t)spp, row = pix / (uint32_t)w;
-    const uint64_t gx = (uint64_t)(x0 + (int)(pix - row * (uint32_t)w)), gy = (uint64_t)(y0 + (int)row);
+    const uint32_t pix = path / (uint32_t)spp;
+    int px, py;
+    pt_pixel(pix, x0, y0, w, band_rows, band_stride, px, py);
+    const uint64_t gx = (uint64_t)px, gy = (uint64_t)py;
     return ((seed * 0x9E3779B97F4A7C15ULL) ^ (((gy * (uint64_t)full_width + gx) << 20) + (uint64_t)(s0 + (int)(path - pix * (uint32_t)spp))) * 64ull)
            + 4ull * (uint64_t)(depth + 1);
 }

@@ -386,7 +386,7 @@ struct PtPass {
     DevMaterial override_mat; DevEnv env;
     const PtCamSrc *cam;                 /* bounce 0: the pass's rays are the camera rays, regenerated from the path id */
     unsigned long long seed;
-    int use_override, ref_weights, depth, max_depth, s0, spp, x0, y0, w, full_width;
+    int use_override, ref_weights, depth, max_depth, s0, spp, x0, y0, w, band_rows, band_stride, full_width;
 };
 
 template <bool FIRST>
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void k_pt_shade(const PtPass ps, const lh_dev_
                     else { r0 = thr[3 * (size_t)i] * e[0]; r1 = thr[3 * (size_t)i + 1] * e[1]; r2 = thr[3 * (size_t)i + 2] * e[2]; }
                 } else {
                     const DevMaterial M = ps.use_override ? ps.override_mat : materials[prim_mesh[p]];
-                    go = pt_survives(M, pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.full_width, ps.depth), ps.depth, ps.max_depth);
+                    go = pt_survives(M, pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.band_rows, ps.band_stride, ps.full_width, ps.depth), ps.depth, ps.max_depth);
                 }
                 if (!go) { radiance[3 * (size_t)path] = r0; radiance[3 * (size_t)path + 1] = r1; radiance[3 * (size_t)path + 2] = r2; }
             }
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void k_pt_shade(const PtPass ps, const lh_dev_
                 Or[0] = org[3 * (size_t)i]; Or[1] = org[3 * (size_t)i + 1]; Or[2] = org[3 * (size_t)i + 2];
                 D[0] = dir[3 * (size_t)i]; D[1] = dir[3 * (size_t)i + 1]; D[2] = dir[3 * (size_t)i + 2];
             }
-            const uint64_t key = pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.full_width, ps.depth);
+            const uint64_t key = pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.band_rows, ps.band_stride, ps.full_width, ps.depth);
             const DevMaterial M = ps.use_override ? ps.override_mat : materials[prim_mesh[p]];
             double o2[3], O[3]; float G2[3]; uint32_t pw2;
             pt_scatter(sc, nrm9, col9, M, ps.ref_weights, key, p, pword, Or, D, t[i], u[i], v[i], G, o2, O, G2, pw2);
@@ -491,7 +491,7 @@ __global__ void k_pt_begin(uint32_t *counts, uint32_t paths, int nentries, const
  * 256 x spp x 3 floats: staged through LDS in coalesced 16-sample slices (one thread per pixel reading its own samples straight
  * from HBM touched 64 different lines per load instruction: 1.15 ms per 2048^2 x 16 pass instead of 0.25) */
 #define LH_RESOLVE_SLICE 16
-__global__ __launch_bounds__(256) void k_pt_resolve(int w, int h, int spp, float inv_total_spp, const float *__restrict__ radiance, float *__restrict__ rgb)
+__global__ __launch_bounds__(256) void k_pt_resolve(int w, int h, int band_rows, int spp, float inv_total_spp, const float *__restrict__ radiance, float *__restrict__ rgb)
 {
     __shared__ float stage[256 * (3 * LH_RESOLVE_SLICE + 1)];        /* +1: odd row stride, conflict-free column reads */
     const size_t npix = (size_t)w * h;
@@ -513,8 +513,9 @@ __global__ __launch_bounds__(256) void k_pt_resolve(int w, int h, int spp, float
         __syncthreads();
     }
     if (pix >= npix) return;
-    const int lx = (int)(pix % w), ly = (int)(pix / w);
-    float *o = rgb + 3 * ((size_t)(h - 1 - ly) * w + lx);
+    /* every band is written in image orientation (its first frame line last); a tile is one band */
+    const int lx = (int)(pix % w), ly = (int)(pix / w), band = ly / band_rows;
+    float *o = rgb + 3 * ((size_t)(band * band_rows + (band_rows - 1 - (ly - band * band_rows))) * w + lx);
     o[0] += sr * inv_total_spp; o[1] += sg * inv_total_spp; o[2] += sb * inv_total_spp;
 }
 
@@ -605,14 +606,14 @@ extern "C" size_t lh_pt_material_bytes(void) { return sizeof(DevMaterial); }
 extern "C" void lh_pt_material_pack(const lh_material_t *m, void *out) { pack_material(m, (DevMaterial *)out); }
 
 /* start of a pass: counts[0] = its paths, the camera-ray source (PtCamSrc) into d_cam */
-extern "C" int lh_pt_launch_begin(const lh_camera_t *cam, int x0, int y0, int w, int h, int spp, int s0,
+extern "C" int lh_pt_launch_begin(const lh_camera_t *cam, int x0, int y0, int w, int h, int band_rows, int band_stride, int spp, int s0,
                                   unsigned long long seed, void *d_cam, uint32_t *d_counts, int ncounts, void *stream)
 {
     PtCamSrc c;
     memset(&c, 0, sizeof(c));
     for (int i = 0; i < 16; i++) c.cam.c2w[i] = cam->cam2world[i];
     c.cam.flength = cam->flength; c.cam.width = cam->width; c.cam.height = cam->height; c.cam.rh = cam->rh; c.cam.ortho = cam->ortho;
-    c.seed = seed; c.x0 = x0; c.y0 = y0; c.w = w; c.spp = spp; c.s0 = s0;
+    c.seed = seed; c.x0 = x0; c.y0 = y0; c.w = w; c.spp = spp; c.s0 = s0; c.band_rows = band_rows; c.band_stride = band_stride;
     const size_t total = (size_t)w * h * spp;
     hipLaunchKernelGGL(k_pt_begin, dim3(1), dim3(256), 0, (hipStream_t)stream, d_counts, (uint32_t)total, ncounts, c, (PtCamSrc *)d_cam);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -625,7 +626,7 @@ extern "C" int lh_pt_launch_shade(size_t n_max, const lh_dev_scene_t *sc, const 
                                   const uint32_t *d_prim_mesh, const void *d_materials, const lh_material_t *override_mat,
                                   const float env_rgb[3], const void *d_env_map, int env_w, int env_h, int ref_weights,
                                   int depth, int max_depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w,
-                                  int full_width, const void *d_cam, uint32_t *d_counts, const double *d_org, const double *d_dir, const uint32_t *d_prim,
+                                  int band_rows, int band_stride, int full_width, const void *d_cam, uint32_t *d_counts, const double *d_org, const double *d_dir, const uint32_t *d_prim,
                                   const double *d_t, const double *d_u, const double *d_v, const uint32_t *d_path_of,
                                   const float *d_thr, float *d_radiance, double *d_org2, double *d_dir2, uint32_t *d_path_of2,
                                   float *d_thr2, int ncus, void *stream)
@@ -639,7 +640,7 @@ extern "C" int lh_pt_launch_shade(size_t n_max, const lh_dev_scene_t *sc, const 
     ps.env.map = (const float4 *)d_env_map; ps.env.w = env_w; ps.env.h = env_h;
     ps.cam = (const PtCamSrc *)d_cam;
     ps.seed = seed; ps.use_override = override_mat != NULL; ps.ref_weights = ref_weights; ps.depth = depth; ps.max_depth = max_depth;
-    ps.s0 = s0; ps.spp = spp; ps.x0 = x0; ps.y0 = y0; ps.w = w; ps.full_width = full_width;
+    ps.s0 = s0; ps.spp = spp; ps.x0 = x0; ps.y0 = y0; ps.w = w; ps.band_rows = band_rows; ps.band_stride = band_stride; ps.full_width = full_width;
     const size_t spans = (n_max + 256 * LH_PT_ITEMS - 1) / (256 * LH_PT_ITEMS);
     const size_t cap = (size_t)(ncus > 0 ? ncus : 256) * 8;
     const unsigned nb = (unsigned)(spans < cap ? spans : cap);
@@ -652,12 +653,12 @@ extern "C" int lh_pt_launch_shade(size_t n_max, const lh_dev_scene_t *sc, const 
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-extern "C" int lh_pt_launch_resolve(int w, int h, int spp, float inv_total_spp, const float *d_radiance, float *d_rgb, void *stream)
+extern "C" int lh_pt_launch_resolve(int w, int h, int band_rows, int spp, float inv_total_spp, const float *d_radiance, float *d_rgb, void *stream)
 {
     const size_t total = (size_t)w * h;
     if (total == 0) return 0;
     hipLaunchKernelGGL(k_pt_resolve, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       w, h, spp, inv_total_spp, d_radiance, d_rgb);
+                       w, h, band_rows, spp, inv_total_spp, d_radiance, d_rgb);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -382,24 +382,27 @@ static int sync_materials(lh_accel_t *a)
 /* ------------------------------------------------------------------------ */
 /* wavefront path tracer (kernels: lh_render.hip, arithmetic: lh_pt.h)       */
 /* ------------------------------------------------------------------------ */
-extern "C" int lh_pt_launch_begin(const lh_camera_t *cam, int x0, int y0, int w, int h, int spp, int s0,
+extern "C" int lh_pt_launch_begin(const lh_camera_t *cam, int x0, int y0, int w, int h, int band_rows, int band_stride, int spp, int s0,
                                   unsigned long long seed, void *d_cam, uint32_t *d_counts, int ncounts, void *stream);
 extern "C" size_t lh_pt_cam_bytes(void);
 extern "C" int lh_pt_launch_shade(size_t n_max, const lh_dev_scene_t *sc, const double *d_nrm9, const double *d_col9,
                                   const uint32_t *d_prim_mesh, const void *d_materials, const lh_material_t *override_mat,
                                   const float env_rgb[3], const void *d_env_map, int env_w, int env_h, int ref_weights,
                                   int depth, int max_depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w,
-                                  int full_width, const void *d_cam, uint32_t *d_counts, const double *d_org, const double *d_dir, const uint32_t *d_prim,
+                                  int band_rows, int band_stride, int full_width, const void *d_cam, uint32_t *d_counts, const double *d_org, const double *d_dir, const uint32_t *d_prim,
                                   const double *d_t, const double *d_u, const double *d_v, const uint32_t *d_path_of,
                                   const float *d_thr, float *d_radiance, double *d_org2, double *d_dir2, uint32_t *d_path_of2,
                                   float *d_thr2, int ncus, void *stream);
-extern "C" int lh_pt_launch_resolve(int w, int h, int spp, float inv_total_spp, const float *d_radiance, float *d_rgb, void *stream);
+extern "C" int lh_pt_launch_resolve(int w, int h, int band_rows, int spp, float inv_total_spp, const float *d_radiance, float *d_rgb, void *stream);
 
-static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int s0, int spp, int spp_total, int max_vertices,
+/* the pass over a w-wide region of h lines = full bands of band_rows lines, band k starting at frame line y0 + k * band_stride
+ * (an ordinary tile: band_rows = h) */
+static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w, int h, int band_rows, int band_stride, int s0, int spp, int spp_total, int max_vertices,
                    const lh_material_t *override_mat, const float env_rgb[3], const void *d_env_map, int env_w, int env_h, int flags,
                    uint64_t seed, void *d_rgb, lh_pt_stats_t *stats, void *stream)
 {
-    if (w <= 0 || h <= 0 || spp < 1 || spp_total < spp || max_vertices < 2 || max_vertices > 65536) return fail("lh_render_pt_tile: bad arguments");
+    if (w <= 0 || h <= 0 || spp < 1 || spp_total < spp || max_vertices < 2 || max_vertices > 65536 || band_rows < 1 || h % band_rows != 0)
+        return fail("lh_render_pt_tile: bad arguments");
     HIPCHK(hipSetDevice(a->device));
     if (sync_materials(a) != 0) return -1;
     hipStream_t s = (hipStream_t)stream;
@@ -422,7 +425,7 @@ static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w,
     /* counts[d] = rays of bounce d: [0] = S here, [d + 1] accumulated by bounce d's shading pass.  The host never reads a count
      * inside the chain (every launch gets S as its upper bound and the count's address) -- except every 8th bounce of a long
      * chain (a furnace test's 400 vertices), to stop once every path has ended */
-    if (lh_pt_launch_begin(cam, x0, y0, w, h, spp, s0, seed, d_cam, counts, nbounce + 2, s) != 0) return fail("pt begin launch failed");
+    if (lh_pt_launch_begin(cam, x0, y0, w, h, band_rows, band_stride, spp, s0, seed, d_cam, counts, nbounce + 2, s) != 0) return fail("pt begin launch failed");
     int rc = 0;
     for (int depth = 0; depth < nbounce && rc == 0; depth++) {
         a->dev.n_dev = counts + depth; a->dev.cam_src = depth == 0 ? d_cam : NULL;
@@ -431,7 +434,7 @@ static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w,
         if (rc != 0) break;
         if (lh_pt_launch_shade(S, &a->dev, (const double *)a->d_nrm9, (const double *)a->d_attr9[0], (const uint32_t *)a->d_prim_mesh,
                                a->d_materials, override_mat, env_rgb, d_env_map, env_w, env_h, (flags & LH_PT_REFERENCE_WEIGHTS) != 0,
-                               depth, max_vertices, seed, s0, spp, x0, y0, w, cam->width, d_cam, counts, org, dir, (const uint32_t *)a->r_prim.p,
+                               depth, max_vertices, seed, s0, spp, x0, y0, w, band_rows, band_stride, cam->width, d_cam, counts, org, dir, (const uint32_t *)a->r_prim.p,
                                (const double *)a->r_t.p, (const double *)a->r_u.p, (const double *)a->r_v.p, path, thr, (float *)a->p_rad.p,
                                org2, dir2, path2, thr2, a->ncus, s) != 0)
             return fail("pt shade launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -450,7 +453,7 @@ static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w,
         }
     }
     if (rc != 0) return -1;
-    if (lh_pt_launch_resolve(w, h, spp, 1.0f / (float)spp_total, (const float *)a->p_rad.p, (float *)d_rgb, s) != 0)
+    if (lh_pt_launch_resolve(w, h, band_rows, spp, 1.0f / (float)spp_total, (const float *)a->p_rad.p, (float *)d_rgb, s) != 0)
         return fail("pt resolve launch failed");
     std::vector<uint32_t> hcounts((size_t)nbounce + 1);
     HIPCHK(hipMemcpyAsync(hcounts.data(), counts, hcounts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -478,7 +481,7 @@ extern "C" int lh_render_pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, 
     if (!cam || !d_rgb || !env) return fail("lh_render_pt_tile: NULL argument");
     if (!(kd > 0.0f) || kd > 1.0f) return fail("lh_render_pt_tile: bad arguments");
     lh_material_t m; memset(&m, 0, sizeof(m)); m.kd[0] = m.kd[1] = m.kd[2] = kd; m.ior = 1.0f;
-    return pt_tile(a, cam, x0, y0, w, h, s0, spp, spp_total, max_vertices, &m, env, NULL, 0, 0, 0, seed, d_rgb, stats, stream);
+    return pt_tile(a, cam, x0, y0, w, h, h, 0, s0, spp, spp_total, max_vertices, &m, env, NULL, 0, 0, 0, seed, d_rgb, stats, stream);
 }
 
 /* per-mesh materials (lh_accel_set_material) and the accelerator's environment (lh_accel_set_environment) */
@@ -490,8 +493,27 @@ extern "C" int lh_render_pt_tile2(lh_accel_t *a, const lh_camera_t *cam, int x0,
     if (!cam || !d_rgb) return fail("lh_render_pt_tile2: NULL argument");
     float one[3] = {1.0f, 1.0f, 1.0f};
     const float *rgb = (a->env.rgb[0] != 0.0f || a->env.rgb[1] != 0.0f || a->env.rgb[2] != 0.0f || a->d_env_map) ? a->env.rgb : one;
-    return pt_tile(a, cam, x0, y0, w, h, s0, spp, spp_total, max_vertices, NULL, rgb, a->d_env_map, a->env.width, a->env.height, flags,
+    return pt_tile(a, cam, x0, y0, w, h, h, 0, s0, spp, spp_total, max_vertices, NULL, rgb, a->d_env_map, a->env.width, a->env.height, flags,
                    seed, d_rgb, stats, stream);
+}
+
+/* a rank's interleaved full-width bands of a sharded frame as ONE pass: nbands bands of band_rows lines, band k starting at
+ * frame line y0_first + k * band_stride (all inside the frame).  d_rgb: [nbands][band_rows][width][3], every band in image
+ * orientation (lh_render_ao_bands' layout).  override_mat NULL: the accelerator's per-mesh materials. */
+extern "C" int lh_render_pt_bands(lh_accel_t *a, const lh_camera_t *cam, int y0_first, int band_rows, int band_stride, int nbands,
+                                  int s0, int spp, int spp_total, int max_vertices, int flags, const lh_material_t *override_mat,
+                                  uint64_t seed, void *d_rgb, lh_pt_stats_t *stats, void *stream)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_render_pt_bands: accel not committed");
+    if (!cam || !d_rgb) return fail("lh_render_pt_bands: NULL argument");
+    if (nbands < 1 || band_rows < 1 || y0_first < 0 || (nbands > 1 && band_stride < band_rows) ||
+        (long long)y0_first + (long long)(nbands - 1) * band_stride + band_rows > cam->height)
+        return fail("lh_render_pt_bands: bands must be disjoint and inside the frame");
+    float one[3] = {1.0f, 1.0f, 1.0f};
+    const float *rgb = (a->env.rgb[0] != 0.0f || a->env.rgb[1] != 0.0f || a->env.rgb[2] != 0.0f || a->d_env_map) ? a->env.rgb : one;
+    return pt_tile(a, cam, 0, y0_first, cam->width, nbands * band_rows, band_rows, band_stride, s0, spp, spp_total, max_vertices, override_mat, rgb,
+                   a->d_env_map, a->env.width, a->env.height, flags, seed, d_rgb, stats, stream);
 }
 
 /* ------------------------------------------------------------------------ */

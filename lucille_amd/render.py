@@ -123,17 +123,44 @@ def assemble(slab, W, H, tile, rank, world):
     return img
 
 
-def render_pt_frame_sharded(acc, cam, spp, rank, world, tile=256, spp_chunk=16, **kw):
-    """Path-traced frame (BASELINE config 4): tiles `tile_id % world == rank`, samples in passes
-    of `spp_chunk` per tile (bounded device memory), one gather of tile slabs.
-    Returns (image on rank 0 | None, local stats)."""
+def render_pt_frame_sharded(acc, cam, spp, rank, world, tile=256, spp_chunk=16, band_rows=None, **kw):
+    """Path-traced frame (BASELINE config 4), samples in passes of `spp_chunk` (bounded device memory), one gather of slabs.
+    world > 1 (or band_rows given): a rank's interleaved full-width bands (bands_for) are ONE pass per sample chunk
+    (lh_render_pt_bands: a pass costs a fixed ~3 ms of kernel ramps whatever its size, and fine bands spread sky / floor / sphere
+    evenly over the ranks); else square tiles `tile_id % world == rank`, one pass each.  kw: kd | material, env, max_vertices,
+    flags, seed.  Returns (image on rank 0 | None, local stats)."""
     import torch
+    from . import binding
     W, H = cam.width, cam.height
+    dev = torch.device("cuda", acc.device)
+    tot = {"paths": 0, "rays": 0}
+    rows = None
+    if world > 1 or band_rows is not None:
+        rows, y0s = bands_for(H, max(world, 2) if band_rows is not None else world, band_rows)
+        if H % rows != 0 or len(y0s) < world:
+            rows = None                                   # ragged last band: the tile path below
+    if rows is not None:
+        mine = shard.tiles_of_rank(len(y0s), rank, world)
+        per = (len(y0s) + world - 1) // world
+        slab = torch.zeros((per, rows * W * 3), dtype=torch.float32, device=dev)
+        if "env" in kw:
+            acc.set_environment(kw["env"], None)
+        mat = kw.get("material")
+        if mat is None and "kd" in kw:
+            mat = binding.Material.make(kd=(kw["kd"],) * 3)
+        if mine:
+            out = slab[:len(mine)].view(len(mine), rows, W, 3)
+            for s0 in range(0, spp, spp_chunk):
+                _, st = acc.render_pt_bands(cam, y0s[mine[0]], rows, rows * world, len(mine), s0, min(spp_chunk, spp - s0), spp,
+                                            max_vertices=kw.get("max_vertices", 8), flags=kw.get("flags", 0), override=mat,
+                                            seed=kw.get("seed", 1), out=out)
+                tot["paths"] += st["paths"]; tot["rays"] += st["rays"]
+        shards = [(0, y0, W, rows) for y0 in y0s]
+        return assemble_shards(slab, shards, W, H, rank, world, stride_rows=rows), tot
+    kw = {k: v for k, v in kw.items() if k not in ("material", "flags")}
     tiles = shard.tile_grid(W, H, tile)
     mine = shard.tiles_of_rank(len(tiles), rank, world)
-    dev = torch.device("cuda", acc.device)
     slab = torch.zeros((len(mine), tile * tile * 3), dtype=torch.float32, device=dev)
-    tot = {"paths": 0, "rays": 0}
     for k, tid in enumerate(mine):
         x0, y0, w, h = tiles[tid]
         out = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)

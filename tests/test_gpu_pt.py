@@ -183,3 +183,25 @@ def test_mirror_and_glass_conserve_energy_and_roulette_is_unbiased(ps):
     with pytest.raises(la.LucilleHipError, match="exceed 1"):
         acc.set_material(0, la.Material.make(kd=(1, 1, 1), ks=(0.5, 0.5, 0.5)))
     acc.set_material(la.ALL_MESHES, la.Material.make())
+
+
+def test_interleaved_bands_as_one_pass_equal_the_frame(ps):
+    """lh_render_pt_bands: the bands three ranks would own (4 lines each, band_id % 3 == rank), each rank's as ONE pass, put
+    back together == the frame rendered as one tile, bit for bit (keys are (frame pixel, sample, bounce)); ray counts add up"""
+    import torch
+    acc, cam = ps["acc"], ps["cam"]
+    W, H = cam.width, cam.height
+    assert H % 4 == 0
+    acc.set_environment((0.9, 0.8, 0.7), None)
+    ref, st = acc.render_pt_tile(cam, 0, 0, W, H, 0, 8, 8, kd=0.75, env=(0.9, 0.8, 0.7), max_vertices=6, seed=4)
+    nb = H // 4
+    img = torch.zeros((nb, 4, W, 3), dtype=torch.float32, device="cuda"); rays = 0
+    for r in range(3):
+        mine = list(range(r, nb, 3))
+        out, s = acc.render_pt_bands(cam, 4 * r, 4, 12, len(mine), 0, 8, 8, max_vertices=6, override=la.Material.make(kd=(0.75,) * 3), seed=4)
+        img[r::3] = out; rays += s["rays"]
+    torch.cuda.synchronize()
+    acc.set_environment((1.0, 1.0, 1.0), None)
+    assert torch.equal(img.flip(0).reshape(H, W, 3), ref) and rays == st["rays"]
+    with pytest.raises(la.LucilleHipError, match="inside the frame"):
+        acc.render_pt_bands(cam, 4, 4, 12, nb // 3 + 1, 0, 8, 8)

@@ -58,6 +58,16 @@ def _worker(rank, world, port, q):
             acc.render_pt_tile(cam, 0, 0, 200, 150, s0, 6, 12, kd=0.7, env=(1.0, 0.9, 0.8), max_vertices=5, seed=2, out=ref)
         torch.cuda.synchronize()
         out["pt"] = bool(torch.allclose(pimg, ref, rtol=0, atol=1e-6))
+    # 152 lines: whole 4-line bands -> every rank's interleaved bands as ONE pass per sample chunk (lh_render_pt_bands)
+    cam2 = la.Camera.make(200, 152, c[16], c[:16], int(c[19]))
+    pimg, pst = render.render_pt_frame_sharded(acc, cam2, 12, rank, world, spp_chunk=6, kd=0.7, env=(1.0, 0.9, 0.8), max_vertices=5, seed=2)
+    rays = torch.tensor([pst["rays"], pst["paths"]], dtype=torch.int64); dist.all_reduce(rays)
+    if rank == 0:
+        ref = torch.zeros((152, 200, 3), dtype=torch.float32, device="cuda"); rr = 0
+        for s0 in (0, 6):
+            _, st = acc.render_pt_tile(cam2, 0, 0, 200, 152, s0, 6, 12, kd=0.7, env=(1.0, 0.9, 0.8), max_vertices=5, seed=2, out=ref); rr += st["rays"]
+        torch.cuda.synchronize()
+        out["pt_bands"] = bool(torch.equal(pimg, ref)) and int(rays[0]) == rr and int(rays[1]) == 2 * 200 * 152 * 6
         q.put(out)
     dist.barrier()
     shard.dist().close()
@@ -77,7 +87,7 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_frames():
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0
-    assert out == {"bands": True, "tiles": True, "pt": True}, out
+    assert out == {"bands": True, "tiles": True, "pt": True, "pt_bands": True}, out
 
 
 def test_bench_n2_code_path_on_one_gpu():
