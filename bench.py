@@ -273,7 +273,7 @@ def main():
     if rank == 0:
         value = n_total * args.steps / elapsed / 1e6
         achieved = b_ray * n / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = traffic_source = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc) and world == 1:
             try:
@@ -281,8 +281,9 @@ def main():
                 if j.get("rays_per_launch") == n and j.get("mode") == args.mode and j.get("kernel_tag") == node_fmt \
                         and args.variant in (-1, 4):
                     traffic = j.get("hbm_bytes_per_launch")
+                    traffic_source = pmc_source("profiles/pmc_latest.json", j)
             except Exception:
-                traffic = None
+                traffic = traffic_source = None
         hot_mb = (info["nnodes_traversal"] * 64 + info["ntriangles"] * 48) / 1e6
         res = {
             "metric": "Mrays/s (primary+AO)", "value": round(value, 2), "unit": "Mrays/s",
@@ -301,7 +302,7 @@ def main():
                        "bvh": {"nodes": info["nnodes_traversal"], "depth": info["max_depth"], "device_bytes": info["device_bytes"],
                                "build_s": round(info["build_seconds"], 3), "ref_tree_build_s": round(info["ref_build_seconds"], 3)}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "residency": "hot set %.0f MB (4-wide nodes + tri32) < 256 MiB Infinity Cache: served by L2 + MALL, "
                                       "NOT an HBM measurement; see roofline_hbm" % hot_mb,
                          "kernel": "k_trace_persist_lane<walk=spec,%s nodes>" % node_fmt if args.variant in (-1, 4) else "k_trace_direct<%s nodes>" % node_fmt,
@@ -403,6 +404,15 @@ def host_path_leg(acc, d_org, d_dir, n):
                       "streams, 48 B/ray up + 28 B/ray down over PCIe; never the headline value" % nh}
 
 
+def pmc_source(path, j):
+    """where a `traffic` figure comes from: it is NOT measured inside this run (rocprofv3 counter passes re-run the whole
+    command: tools/profile_round2.sh), it is the committed summary of the same command's last counter passes"""
+    return {"file": path, "round": j.get("round"), "commit": j.get("commit"), "raw": j.get("source"),
+            "FETCH_SIZE_KiB": j.get("FETCH_SIZE_KiB"), "WRITE_SIZE_KiB": j.get("WRITE_SIZE_KiB"),
+            "formula": "2 x FETCH_SIZE x 1024 (gfx950: 128-B fabric requests tallied as 64 B) + WRITE_SIZE x 1024",
+            "kernel_avg_ms_in_that_run": j.get("kernel_avg_ms_rocprof")}
+
+
 def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
     """the HBM roofline: the same closest-hit kernel on S-soup-10M (10 M triangles, half-extent 0.002: the
     SURVEY's config-5 stress soup).  Hot set = 4-wide nodes + tri32 ~ 0.8 GB >> the 256 MiB Infinity Cache."""
@@ -437,21 +447,33 @@ def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
     ok = all(torch.equal(a[:ns], b) for a, b in zip(out, cnt_out))
     hit = float((out[0] != -1).float().mean().item())
     achieved = b_ray * n / (ms * 1e-3) / 1e9
-    traffic = None
+    # both definitions of the per-visit bytes: SURVEY 8d prices a node visit at 64 B (its 2-wide fp32 node); the 8-wide walk this
+    # scene runs fetches one 128-B record per visit (and makes fewer visits).  Same counted visits, same kernel time.
+    defs = {}
+    for name, nb in (("survey_8d_64B_per_node_visit", 64), ("record_bytes_%dB_per_node_visit" % node_bytes, node_bytes)):
+        br = B_IN + B_OUT + nb * n_nodes + B_TRI * n_tris
+        defs[name] = {"bytes_per_ray": round(br, 1), "achieved": round(br * n / (ms * 1e-3) / 1e9, 1),
+                      "frac": round(br * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    traffic = traffic_source = None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest_hbm.json")
     if os.path.exists(pmc):
         try:
             j = json.load(open(pmc))
             if j.get("rays_per_launch") == n and j.get("triangles") == args.hbm_tris and j.get("kernel_tag") == node_fmt:
                 traffic = j.get("hbm_bytes_per_launch")
+                traffic_source = pmc_source("profiles/pmc_latest_hbm.json", j)
         except Exception:
-            traffic = None
+            traffic = traffic_source = None
     info = acc.info()
     hot = info["nnodes_traversal"] * 64 + info["ntriangles"] * 48
     acc.close()
     return {"workload": "S-soup-10M ray dump: %d random triangles (half-extent 0.002), %d incoherent rays, closest-hit" % (args.hbm_tris, n),
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            "traffic": traffic, "residency": "hot set %.0f MB as 4-wide nodes + tri32 >> 256 MiB Infinity Cache: HBM" % (hot / 1e6),
+            "traffic": traffic, "traffic_source": traffic_source,
+            "traffic_frac_of_peak": None if traffic is None else round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "definitions": defs, "formula": "bytes_per_ray = 48 (ray in) + 28 (hit record out) + B_node x nodes_per_ray + 40 x tris_per_ray; "
+                                            "achieved = bytes_per_ray x rays / kernel_ms; frac = achieved / peak",
+            "residency": "hot set %.0f MB as 4-wide nodes + tri32 >> 256 MiB Infinity Cache: HBM" % (hot / 1e6),
             "kernel": "k_trace_persist_lane<walk=spec8, q16x8 nodes: 128-byte 8-wide records, one cache line each>" if node_bytes == 128
                       else "k_trace_persist_lane<walk=spec,%s nodes>" % node_fmt,
             "node_bytes": node_bytes,
@@ -508,19 +530,29 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
     # what the frame's rays cost: one more frame (untimed) through the counting instantiations of the same kernels
     roof = None
     if world == 1:
-        acc.trace_statistics(True); acc.statistics(clear=True)
+        acc.trace_statistics(True); acc.statistics(clear=True); acc.slot_statistics(clear=True)
         render.render_ao_frame(acc, cam, 1, nsamples, tile=tile); torch.cuda.synchronize(dev)
-        c = acc.statistics(clear=True); acc.trace_statistics(False)
+        c = acc.statistics(clear=True); sl = acc.slot_statistics(clear=True); acc.trace_statistics(False)
         nr = max(1, c["rays"])
-        # algorithmic bytes: 64 B per node visit, 40 B per triangle test; camera rays also 48 B in + 28 B out (their records go
-        # through HBM to the epilogue), AO rays nothing (generated and counted inside the kernel: 4 B per hit slot)
+        # The frame is NOT bandwidth-bound (coherent rays: 0.06 KB of fabric traffic per ray).  What bounds it is how fast the CUs
+        # issue the walk: every node / triangle record is one dependent 64 / 48-byte fetch followed by ~150 VALU instructions, and
+        # the walk's fetch rate sits at 3/4 of what the same chip reaches on a pure gather of such records
+        # (tools/ubench/gather: 129 G records/s with 2048 waves resident).  `achieved` / `peak` are record fetches per second;
+        # the algorithmic-bytes figure (64 B per node visit, 40 B per triangle test, 76 B per camera ray, 4 B per hit slot) is
+        # kept beside it without a fraction.
+        recs = c["nodes"] + c["tris"]
         b_frame = 64.0 * c["nodes"] + 40.0 * c["tris"] + (48.0 + 28.0) * st["primary_rays"] + 4.0 * st["primary_hits"]
-        roof = {"bound": "hbm", "achieved": round(b_frame / min(times) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(b_frame / min(times) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+        sq = {"source": "profiles/r03_pmc_ao_config5_sq_tcc.txt (tools/pmc_cmd.sh: separate SQ / TCC passes of this frame, the fused any-hit launch)",
+              "valu_busy": 0.59, "valu_lane_use": 0.73, "wave_cycles_waiting": 0.55, "l2_hit_rate": 0.53,
+              "fabric_read_bytes_per_frame": 59.3e9}
+        roof = {"bound": "issue", "achieved": round(recs / min(times) / 1e9, 1), "peak": 129.0, "unit": "G records/s",
+                "frac": round(recs / min(times) / 1e9 / 129.0, 4), "traffic": sq["fabric_read_bytes_per_frame"],
+                "peak_source": "tools/ubench/gather (profiles/r01_ubench_gather.log): dependent 64-B record gathers, 2048 resident waves",
+                "counters": sq, "algorithmic_GBps": round(b_frame / min(times) / 1e9, 1),
                 "nodes_per_ray": round(c["nodes"] / nr, 2), "tris_per_ray": round(c["tris"] / nr, 2), "exact_per_ray": round(c["exact"] / nr, 4),
-                "rays_counted": c["rays"],
-                "note": "coherent rays: the frame is bound by instruction issue and dependent-fetch latency, not by bytes (fabric traffic "
-                        "0.15 KB per ray, VALU 57 % busy at 71 % lane use: profiles/r02b_pmc_ao_config5_sq_tcc.txt)"}
+                "lane_use_node_steps": round(c["nodes"] / max(1, 64 * sl["node_slots"]), 3),
+                "lane_use_triangle_passes": round(c["tris"] / max(1, 64 * sl["tri_slots"]), 3),
+                "rays_counted": c["rays"]}
     # the same scene with the traversal tree built on the device (lh_build.hip; what lsh_hip does from 1 M triangles on): commit
     # time, frame time on that tree, and the image -- which must not change by a bit
     devb = None

@@ -99,7 +99,7 @@ ABI_SYMBOLS = [
     "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted", "lh_accel_last_retraced", "lh_accel_dump_node_bytes",
     "lh_accel_set_grid", "lh_accel_set_param", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
     "lh_render_ao_tile", "lh_render_ao_tile_host", "lh_render_ao_bands", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device", "lh_render_pt_tile",
-    "lh_accel_trace_statistics", "lh_accel_statistics",
+    "lh_accel_trace_statistics", "lh_accel_statistics", "lh_accel_slot_statistics",
     "lh_render_ao_frame_host", "lh_rib_load", "lh_rib_free", "lh_rib_last_error", "lh_rib_info", "lh_rib_messages",
     "lh_rib_mesh", "lh_accel_add_rib_scene", "lh_hdr_write",
     "lh_accel_set_material", "lh_accel_set_environment", "lh_render_pt_tile2", "lh_render_pt_bands", "lh_accel_set_attribute",
@@ -152,6 +152,7 @@ def lib():
     L.lh_accel_set_param.argtypes = [vp, C.c_char_p, i32]
     L.lh_accel_trace_statistics.argtypes = [vp, i32]
     L.lh_accel_statistics.argtypes = [vp, C.POINTER(C.c_uint64), i32]
+    L.lh_accel_slot_statistics.argtypes = [vp, C.POINTER(C.c_uint64), i32]
     L.lh_accel_export.argtypes = [vp, vp, vp]
     L.lh_accel_set_normals.argtypes = [vp, u32, vp, sz, i32]
     L.lh_render_primary_rays.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, vp, vp, vp]
@@ -369,6 +370,11 @@ class HipAccel:
         c = (C.c_uint64 * 5)()
         _check(self.L.lh_accel_statistics(self.h, c, 1 if clear else 0), "lh_accel_statistics")
         return dict(zip(("nodes", "tris", "exact", "rays", "hits"), (int(x) for x in c)))
+
+    def slot_statistics(self, clear=False):
+        c = (C.c_uint64 * 3)()
+        _check(self.L.lh_accel_slot_statistics(self.h, c, 1 if clear else 0), "lh_accel_slot_statistics")
+        return dict(zip(("node_slots", "tri_slots", "regroups"), (int(x) for x in c)))
 
     def dump_node_bytes(self):
         """64: ray dumps walk the 4-wide nodes; 128: the 8-wide nodes (scene larger than the Infinity Cache, or wide8 = 1)"""

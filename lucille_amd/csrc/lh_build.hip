@@ -22,6 +22,9 @@
  * magnitude quicker to build; lh_api.hip chooses (LH_BUILD=device, lh_accel_commit's build_threads == LH_BUILD_ON_DEVICE).
  */
 #include <hip/hip_runtime.h>
+#include <time.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <hipcub/hipcub.hpp>
 
 #include <math.h>
@@ -60,14 +63,25 @@ __global__ void k_prim_boxes(uint32_t n, const double *__restrict__ tri64, float
                              uint32_t *__restrict__ scene /* 6 ordered uints: min xyz, max xyz */, int *__restrict__ bad)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const double *t = tri64 + 9 * (size_t)p;
+    uint32_t omin[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, omax[3] = {0u, 0u, 0u};
+    if (p < n) {
+        const double *t = tri64 + 9 * (size_t)p;
+        for (int k = 0; k < 3; k++) {
+            const double a = t[k], b = t[3 + k], c = t[6 + k];
+            if (!(fabs(a) <= 1.0e30) || !(fabs(b) <= 1.0e30) || !(fabs(c) <= 1.0e30)) atomicExch(bad, 1);
+            const float lo = f_down(fmin(a, fmin(b, c))), hi = f_up(fmax(a, fmax(b, c)));
+            plo[3 * (size_t)p + k] = lo; phi[3 * (size_t)p + k] = hi;
+            omin[k] = f2o(lo); omax[k] = f2o(hi);
+        }
+    }
+    /* scene bounds: one atomic per wave and component (one per THREAD was 126 M same-address atomics on a 21 M-triangle scene:
+     * 22 ms of a 170 ms build) */
     for (int k = 0; k < 3; k++) {
-        const double a = t[k], b = t[3 + k], c = t[6 + k];
-        if (!(fabs(a) <= 1.0e30) || !(fabs(b) <= 1.0e30) || !(fabs(c) <= 1.0e30)) atomicExch(bad, 1);
-        const float lo = f_down(fmin(a, fmin(b, c))), hi = f_up(fmax(a, fmax(b, c)));
-        plo[3 * (size_t)p + k] = lo; phi[3 * (size_t)p + k] = hi;
-        atomicMin(&scene[k], f2o(lo)); atomicMax(&scene[3 + k], f2o(hi));
+        for (int off = 32; off >= 1; off >>= 1) {
+            const uint32_t a = (uint32_t)__shfl_xor((int)omin[k], off), b = (uint32_t)__shfl_xor((int)omax[k], off);
+            omin[k] = a < omin[k] ? a : omin[k]; omax[k] = b > omax[k] ? b : omax[k];
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&scene[k], omin[k]); atomicMax(&scene[3 + k], omax[k]); }
     }
 }
 
@@ -135,51 +149,93 @@ __global__ void k_radix_tree(int n, const uint64_t *__restrict__ key, BNode *__r
     if (i == 0) nd.parent = -1;
 }
 
-__global__ void k_refit(int n, const uint32_t *__restrict__ sorted, const float *__restrict__ plo, const float *__restrict__ phi,
-                        BNode *__restrict__ nodes, const int *__restrict__ leaf_parent, uint32_t *__restrict__ visits, int leaf_max)
+/* ---- node boxes and the SAH leaf decision, one thread per inner node, no hand-over between threads ----
+ * The textbook bottom-up refit (every leaf walks up, the second arrival at a node merges) needs two device-scope fences per
+ * node -- on eight XCDs with an L2 each that is a cache write-back and invalidate: 137 ms for 21 M triangles.  A radix-tree
+ * node covers a contiguous RANGE of the sorted primitives, so its box is a range query: boxes of the sorted primitives, then
+ * of every 64 of them, every 4096, every 262144 (k_box_blocks); a node merges at most 63 + 63 entries per level. */
+#define LH_BOX_RADIX 64u
+#define LH_BOX_LEVELS 4
+
+struct BoxTable { const float *lo[LH_BOX_LEVELS], *hi[LH_BOX_LEVELS]; };       /* level 0: the sorted primitives */
+
+__global__ void k_sorted_boxes(uint32_t n, const uint32_t *__restrict__ sorted, const float *__restrict__ plo, const float *__restrict__ phi,
+                               float *__restrict__ slo, float *__restrict__ shi)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = sorted[i];
+    for (int k = 0; k < 3; k++) { slo[3 * (size_t)i + k] = plo[3 * (size_t)p + k]; shi[3 * (size_t)i + k] = phi[3 * (size_t)p + k]; }
+}
+
+/* out[b] = union of in[64 b .. 64 b + 63]: a wave per output box */
+__global__ void k_box_blocks(uint32_t n_in, const float *__restrict__ ilo, const float *__restrict__ ihi, float *__restrict__ olo, float *__restrict__ ohi)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (i < n_in) for (int k = 0; k < 3; k++) { lo[k] = ilo[3 * (size_t)i + k]; hi[k] = ihi[3 * (size_t)i + k]; }
+    for (int k = 0; k < 3; k++)
+        for (int off = 32; off >= 1; off >>= 1) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off)); }
+    if ((threadIdx.x & 63) == 0 && i < n_in) for (int k = 0; k < 3; k++) { olo[3 * (size_t)(i / 64u) + k] = lo[k]; ohi[3 * (size_t)(i / 64u) + k] = hi[k]; }
+}
+
+__device__ __forceinline__ void range_box(const BoxTable &T, uint32_t first, uint32_t last, float lo[3], float hi[3])
+{
+    for (int k = 0; k < 3; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+    uint32_t i = first;
+    while (i <= last) {
+        uint32_t step = 1; int lev = 0;
+        while (lev + 1 < LH_BOX_LEVELS && (i % (step * LH_BOX_RADIX)) == 0u && (uint64_t)i + (uint64_t)step * LH_BOX_RADIX - 1u <= (uint64_t)last) { step *= LH_BOX_RADIX; lev++; }
+        const size_t e = (size_t)(i / step);
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], T.lo[lev][3 * e + k]); hi[k] = fmaxf(hi[k], T.hi[lev][3 * e + k]); }
+        if ((uint64_t)i + step > 0xffffffffull) break;
+        i += step;
+    }
+}
+
+__device__ __forceinline__ float half_area(const float lo[3], const float hi[3])
+{
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+/* bottom-up SAH of a subtree of at most LH_MAX_LEAF_TRIS primitives: the cost of the cheapest way to finish it -- as inner
+ * node + its children's best, or as ONE leaf (same rule, same arithmetic as the round-2 refit).  A soup of unrelated triangles
+ * keeps one triangle per leaf (its boxes barely shrink towards the leaves: the leaf's area is the node's), a tessellated
+ * surface merges neighbours into leaves of up to four.  D bounds the recursion (a subtree of <= 4 leaves is <= 3 nodes deep) */
+template <int D>
+__device__ float subtree_cost(const BNode *__restrict__ nodes, const BoxTable &T, int ref, int leaf_max, bool *leaf_out)
+{
+    float lo[3], hi[3];
+    if (ref < 0) {
+        const size_t e = (size_t)~ref;
+        for (int k = 0; k < 3; k++) { lo[k] = T.lo[0][3 * e + k]; hi[k] = T.hi[0][3 * e + k]; }
+        if (leaf_out) *leaf_out = true;
+        return LH_SAH_CT * half_area(lo, hi);
+    }
+    const BNode &nd = nodes[ref];
+    range_box(T, nd.first, nd.last, lo, hi);
+    const float area = half_area(lo, hi);
+    float csum = 0.0f;
+    if (D > 0) { csum += subtree_cost<(D > 0 ? D - 1 : 0)>(nodes, T, nd.left, leaf_max, NULL); csum += subtree_cost<(D > 0 ? D - 1 : 0)>(nodes, T, nd.right, leaf_max, NULL); }
+    const uint32_t cnt = nd.last - nd.first + 1u;
+    const float as_node = LH_SAH_CI * area + csum, as_leaf = LH_SAH_CT * area * (float)cnt;
+    const bool leaf = cnt <= (uint32_t)leaf_max && as_leaf <= as_node;
+    if (leaf_out) *leaf_out = leaf;
+    return leaf ? as_leaf : as_node;
+}
+
+__global__ void k_node_boxes(int n, BNode *__restrict__ nodes, const BoxTable T, int leaf_max)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int cur = leaf_parent[i];
-    while (cur >= 0) {
-        if (atomicAdd(&visits[cur], 1u) == 0u) return;          /* the second arrival merges */
-        __threadfence();
-        BNode &nd = nodes[cur];
-        float lo[3], hi[3];
-        for (int side = 0; side < 2; side++) {
-            const int c = side ? nd.right : nd.left;
-            const float *cl, *ch;
-            if (c < 0) { const uint32_t p = sorted[~c]; cl = plo + 3 * (size_t)p; ch = phi + 3 * (size_t)p; }
-            else { cl = nodes[c].lo; ch = nodes[c].hi; }
-            for (int k = 0; k < 3; k++) {
-                const float a = ((volatile const float *)cl)[k], b = ((volatile const float *)ch)[k];
-                if (side == 0) { lo[k] = a; hi[k] = b; } else { lo[k] = fminf(lo[k], a); hi[k] = fmaxf(hi[k], b); }
-            }
-        }
-        for (int k = 0; k < 3; k++) { nd.lo[k] = lo[k]; nd.hi[k] = hi[k]; }
-        /* bottom-up SAH: this subtree as inner node + its children's best, or -- up to leaf_max primitives -- as one leaf.  A soup
-         * of unrelated triangles keeps one triangle per leaf (its boxes barely shrink towards the leaves: the leaf's area is the
-         * node's), a tessellated surface merges neighbours into leaves of up to four */
-        {
-            const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-            const float area = dx * dy + dy * dz + dz * dx;
-            float csum = 0.0f;
-            for (int side = 0; side < 2; side++) {
-                const int c = side ? nd.right : nd.left;
-                if (c < 0) {
-                    const uint32_t p = sorted[~c];
-                    const float ex = phi[3 * (size_t)p] - plo[3 * (size_t)p], ey = phi[3 * (size_t)p + 1] - plo[3 * (size_t)p + 1], ez = phi[3 * (size_t)p + 2] - plo[3 * (size_t)p + 2];
-                    csum += LH_SAH_CT * (ex * ey + ey * ez + ez * ex);
-                } else csum += ((volatile const float *)&nodes[c].cost)[0];
-            }
-            const uint32_t cnt = nd.last - nd.first + 1u;
-            const float as_node = LH_SAH_CI * area + csum, as_leaf = LH_SAH_CT * area * (float)cnt;
-            const bool leaf = cnt <= (uint32_t)leaf_max && as_leaf <= as_node;
-            nd.cost = leaf ? as_leaf : as_node; nd.leaf = leaf ? 1 : 0;
-        }
-        __threadfence();
-        cur = nd.parent;
-    }
+    if (i >= n - 1) return;
+    BNode &nd = nodes[i];
+    float lo[3], hi[3];
+    range_box(T, nd.first, nd.last, lo, hi);
+    for (int k = 0; k < 3; k++) { nd.lo[k] = lo[k]; nd.hi[k] = hi[k]; }
+    bool leaf = false; float cost = 0.0f;
+    if (nd.last - nd.first + 1u <= (uint32_t)leaf_max) cost = subtree_cost<LH_MAX_LEAF_TRIS - 1>(nodes, T, i, leaf_max, &leaf);
+    nd.cost = cost; nd.leaf = leaf ? 1 : 0;
 }
 
 struct Child { float lo[3], hi[3]; int node; uint32_t first, count; };   /* node >= 0: inner binary node with > 4 primitives */
@@ -308,7 +364,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
 {
     hipStream_t s = (hipStream_t)stream;
     const uint32_t n = ntris;
-    float *plo = NULL, *phi = NULL; uint32_t *scene = NULL, *val_in = NULL, *sorted = NULL, *visits = NULL, *counters = NULL;
+    float *plo = NULL, *phi = NULL; uint32_t *scene = NULL, *val_in = NULL, *sorted = NULL, *counters = NULL; float *boxes = NULL;
     uint64_t *key_in = NULL, *key = NULL; int *leaf_parent = NULL, *bad = NULL; BNode *nodes = NULL; void *tmp = NULL; size_t tmp_bytes = 0;
     uint2 *work[2] = {NULL, NULL}; lh_q4node_t *q4 = NULL; lh_tri32_t *t32 = NULL;
     const unsigned nb = (n + 255) / 256;
@@ -318,6 +374,18 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     { const char *e = getenv("LH_DEVICE_LEAF"); if (e && atoi(e) >= 1 && atoi(e) <= LH_MAX_LEAF_TRIS) leaf_max = atoi(e); }
     *d_q4nodes = NULL; *d_tri32 = NULL; *nq4 = 0; *q4_depth = 0;
     if (n == 0) return 0;
+    /* LH_BUILD_TIMING=1: phase times on stderr (each mark synchronises the stream: diagnostics only) */
+    const bool timing = getenv("LH_BUILD_TIMING") != NULL;
+    double tmark = 0.0;
+    auto mark = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+        const double now = ts.tv_sec + 1e-9 * ts.tv_nsec;
+        if (what) fprintf(stderr, "[lucille_hip] device build: %-28s %8.2f ms\n", what, (now - tmark) * 1e3);
+        tmark = now;
+    };
+    mark(NULL);
 
     BCHK(hipMalloc((void **)&plo, sizeof(float) * 3 * (size_t)n)); BCHK(hipMalloc((void **)&phi, sizeof(float) * 3 * (size_t)n));
     BCHK(hipMalloc((void **)&scene, sizeof(uint32_t) * 8)); BCHK(hipMalloc((void **)&bad, sizeof(int)));
@@ -328,6 +396,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     BCHK(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
     BCHK(hipStreamSynchronize(s));
     if (h_bad) { dfree(plo); dfree(phi); dfree(scene); dfree(bad); return -2; }
+    mark("boxes + scene bounds");
     for (int k = 0; k < 3; k++) {
         uint32_t lo = h_scene[k], hi = h_scene[3 + k]; float fl, fh;
         lo = (lo & 0x80000000u) ? (lo & 0x7fffffffu) : ~lo; hi = (hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi;
@@ -356,12 +425,27 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
             BCHK(hipcub::DeviceRadixSort::SortPairs(NULL, tmp_bytes, key_in, key, val_in, sorted, (int)n, 0, 63, s));
             BCHK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
             BCHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key_in, key, val_in, sorted, (int)n, 0, 63, s));
+            mark("morton + radix sort");
             BCHK(hipMalloc((void **)&nodes, sizeof(BNode) * (size_t)(n - 1)));
             BCHK(hipMalloc((void **)&leaf_parent, sizeof(int) * (size_t)n));
-            BCHK(hipMalloc((void **)&visits, sizeof(uint32_t) * (size_t)(n - 1)));
-            BCHK(hipMemsetAsync(visits, 0, sizeof(uint32_t) * (size_t)(n - 1), s));
             hipLaunchKernelGGL(k_radix_tree, dim3((n - 1 + 255) / 256), dim3(256), 0, s, (int)n, key, nodes, leaf_parent);
-            hipLaunchKernelGGL(k_refit, dim3(nb), dim3(256), 0, s, (int)n, sorted, plo, phi, nodes, leaf_parent, visits, leaf_max);
+            mark("radix tree");
+            {
+                /* boxes of the sorted primitives and of their blocks of 64 / 4096 / 262144, all in one allocation */
+                size_t cnt[LH_BOX_LEVELS], total = 0;
+                cnt[0] = n;
+                for (int l = 1; l < LH_BOX_LEVELS; l++) cnt[l] = (cnt[l - 1] + LH_BOX_RADIX - 1) / LH_BOX_RADIX;
+                for (int l = 0; l < LH_BOX_LEVELS; l++) total += cnt[l];
+                BCHK(hipMalloc((void **)&boxes, sizeof(float) * 6 * total));
+                BoxTable T; size_t off = 0;
+                for (int l = 0; l < LH_BOX_LEVELS; l++) { T.lo[l] = boxes + 6 * off; T.hi[l] = boxes + 6 * off + 3 * cnt[l]; off += cnt[l]; }
+                hipLaunchKernelGGL(k_sorted_boxes, dim3(nb), dim3(256), 0, s, n, (const uint32_t *)sorted, (const float *)plo, (const float *)phi,
+                                   (float *)T.lo[0], (float *)T.hi[0]);
+                for (int l = 1; l < LH_BOX_LEVELS; l++)
+                    hipLaunchKernelGGL(k_box_blocks, dim3((unsigned)((cnt[l - 1] + 255) / 256)), dim3(256), 0, s, (uint32_t)cnt[l - 1], T.lo[l - 1], T.hi[l - 1],
+                                       (float *)T.lo[l], (float *)T.hi[l]);
+                hipLaunchKernelGGL(k_node_boxes, dim3((n - 1 + 255) / 256), dim3(256), 0, s, (int)n, nodes, T, leaf_max);
+            }
             /* level-by-level collapse; every level's children are allocated adjacently */
             BCHK(hipMalloc((void **)&work[0], sizeof(uint2) * (size_t)n)); BCHK(hipMalloc((void **)&work[1], sizeof(uint2) * (size_t)n));
             BCHK(hipMalloc((void **)&counters, sizeof(uint32_t) * 2));
@@ -382,16 +466,19 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
             }
         }
     }
+    mark("collapse to 4-wide nodes");
     hipLaunchKernelGGL(k_tri32, dim3(nb), dim3(256), 0, s, n, (const uint32_t *)sorted, d_tri64, t32);
     BCHK(hipGetLastError());
     BCHK(hipStreamSynchronize(s));
+    mark("tri32 records");
     *d_q4nodes = q4; *d_tri32 = t32; *nq4 = nq; *q4_depth = level;
     dfree(plo); dfree(phi); dfree(scene); dfree(bad); dfree(key_in); dfree(key); dfree(val_in); dfree(sorted);
-    dfree(nodes); dfree(leaf_parent); dfree(visits); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters);
+    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters);
+    mark("free temporaries");
     return 0;
 fail:
     dfree(plo); dfree(phi); dfree(scene); dfree(bad); dfree(key_in); dfree(key); dfree(val_in); dfree(sorted);
-    dfree(nodes); dfree(leaf_parent); dfree(visits); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters);
+    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters);
     dfree(q4); dfree(t32);
     return -1;
 }

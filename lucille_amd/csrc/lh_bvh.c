@@ -876,9 +876,40 @@ int lh_bvh_build_hook(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmes
 
 /* primitive flattening only (create_triangle_list order: tri64, prim_geom, prim_index), no tree: the input of the
  * device builder (lh_build.hip).  Same return codes as lh_bvh_build. */
-int lh_bvh_flatten(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes)
+/* primitives in lucille's order (create_triangle_list, bvh.c:1736-1826: geoms in list order, triangles in index order), no
+ * tree.  The device-side commit waits for exactly this (0.33 s single-threaded for 21 M triangles), so the copy is cut into
+ * ranges of the global primitive order, one thread each */
+typedef struct {
+    lh_bvh_t *out; const lh_mesh_view_t *meshes; const uint32_t *first_prim; uint32_t nmeshes, p0, p1; int rc, started;
+} soup_job_t;
+
+static void *soup_worker(void *arg)
 {
-    uint64_t n64 = 0; uint32_t g, i, p = 0; int k, c;
+    soup_job_t *j = (soup_job_t *)arg;
+    uint32_t g = 0, p; int c, k;
+    while (g + 1 < j->nmeshes && j->first_prim[g + 1] <= j->p0) g++;
+    for (p = j->p0; p < j->p1; p++) {
+        const lh_mesh_view_t *m; uint32_t i; lh_tri64_t *t = &j->out->tri64[p];
+        while (g + 1 < j->nmeshes && j->first_prim[g + 1] <= p) g++;
+        m = &j->meshes[g]; i = p - j->first_prim[g];
+        for (c = 0; c < 3; c++) {
+            const uint32_t vi = m->indices[3 * i + c]; const double *P;
+            if (vi >= m->npositions) { j->rc = -1; return NULL; }
+            P = (const double *)((const char *)m->positions + (size_t)vi * m->stride_bytes);
+            for (k = 0; k < 3; k++) {
+                if (!(fabs(P[k]) <= 1.0e30)) { j->rc = -2; return NULL; }
+                t->v[c][k] = P[k];
+            }
+        }
+        j->out->prim_geom[p] = g; j->out->prim_index[p] = 3 * i;
+    }
+    return NULL;
+}
+
+int lh_bvh_flatten(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, int nthreads)
+{
+    uint64_t n64 = 0; uint32_t g, *first_prim; int t, nt, rc = 0;
+    soup_job_t *jobs; pthread_t *th;
     memset(out, 0, sizeof(*out));
     for (g = 0; g < nmeshes; g++) {
         const lh_mesh_view_t *m = &meshes[g];
@@ -891,24 +922,29 @@ int lh_bvh_flatten(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes
     out->tri64 = (lh_tri64_t *)malloc(sizeof(lh_tri64_t) * (size_t)n64);
     out->prim_geom = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n64);
     out->prim_index = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n64);
-    if (!out->tri64 || !out->prim_geom || !out->prim_index) { lh_bvh_release(out); return -1; }
-    for (g = 0; g < nmeshes; g++) {
-        const lh_mesh_view_t *m = &meshes[g];
-        for (i = 0; i < m->nindices / 3; i++, p++) {
-            lh_tri64_t *t = &out->tri64[p];
-            for (c = 0; c < 3; c++) {
-                const uint32_t vi = m->indices[3 * i + c]; const double *P;
-                if (vi >= m->npositions) { lh_bvh_release(out); return -1; }
-                P = (const double *)((const char *)m->positions + (size_t)vi * m->stride_bytes);
-                for (k = 0; k < 3; k++) {
-                    if (!(fabs(P[k]) <= 1.0e30)) { lh_bvh_release(out); return -2; }
-                    t->v[c][k] = P[k];
-                }
-            }
-            out->prim_geom[p] = g; out->prim_index[p] = 3 * i;
-        }
+    first_prim = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)nmeshes + 1));
+    nt = nthreads < 1 ? 1 : (nthreads > 64 ? 64 : nthreads);
+    if ((uint64_t)nt * 65536u > n64) nt = (int)(n64 / 65536u) + 1;          /* a thread per >= 64 K primitives */
+    jobs = (soup_job_t *)calloc((size_t)nt, sizeof(*jobs)); th = (pthread_t *)calloc((size_t)nt, sizeof(*th));
+    if (!out->tri64 || !out->prim_geom || !out->prim_index || !first_prim || !jobs || !th) {
+        free(first_prim); free(jobs); free(th); lh_bvh_release(out); return -1;
     }
-    return 0;
+    first_prim[0] = 0;
+    for (g = 0; g < nmeshes; g++) first_prim[g + 1] = first_prim[g] + meshes[g].nindices / 3;
+    for (t = 0; t < nt; t++) {
+        jobs[t].out = out; jobs[t].meshes = meshes; jobs[t].first_prim = first_prim; jobs[t].nmeshes = nmeshes;
+        jobs[t].p0 = (uint32_t)(n64 * (uint64_t)t / (uint64_t)nt); jobs[t].p1 = (uint32_t)(n64 * (uint64_t)(t + 1) / (uint64_t)nt);
+    }
+    for (t = 1; t < nt; t++) {
+        jobs[t].started = pthread_create(&th[t], NULL, soup_worker, &jobs[t]) == 0;
+        if (!jobs[t].started) soup_worker(&jobs[t]);                              /* no thread: this one does the range */
+    }
+    soup_worker(&jobs[0]);
+    for (t = 1; t < nt; t++) if (jobs[t].started) pthread_join(th[t], NULL);
+    for (t = 0; t < nt; t++) if (jobs[t].rc != 0 && (rc == 0 || jobs[t].rc == -1)) rc = jobs[t].rc;
+    free(first_prim); free(jobs); free(th);
+    if (rc != 0) lh_bvh_release(out);
+    return rc;
 }
 
 void lh_bvh_release(lh_bvh_t *bvh)

@@ -101,7 +101,7 @@ int  lh_bvh_build(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes,
                   int nthreads);
 int  lh_bvh_build_hook(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, int nthreads,
                        void (*after_flatten)(void *), void *hook_arg);
-int  lh_bvh_flatten(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes);   /* primitives only, no tree */
+int  lh_bvh_flatten(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes, int nthreads);   /* primitives only, no tree */
 int  lh_bvh_ensure_q8(lh_bvh_t *bvh);      /* builds q8nodes on first use; 0 / -1 */
 void lh_bvh_release(lh_bvh_t *bvh);
 

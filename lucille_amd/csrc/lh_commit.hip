@@ -208,10 +208,18 @@ static void release_device(lh_accel_t *a)
     a->d_stage = NULL; a->stage_bytes = 0; a->stream = NULL;
 }
 
+static void free_trash(lh_host_scene *hs)
+{
+    if (!hs->trash) return;
+    for (uint32_t k = 0; k < hs->ntrash; k++) free(hs->trash[k]);
+    free(hs->trash); hs->trash = NULL; hs->ntrash = 0;
+}
+
 static void *ref_thread_main(void *arg)
 {
     lh_host_scene *hs = (lh_host_scene *)arg;
     const double t0 = now_s();
+    free_trash(hs);
     const int rc = lh_refbvh_build(&hs->ref, hs->bvh.tri64, hs->bvh.ntris, hs->ref_threads);
     hs->ref_build_seconds = now_s() - t0;
     __atomic_store_n(&hs->ref_state, rc == 0 ? 2 : -1, __ATOMIC_RELEASE);
@@ -252,9 +260,11 @@ static int host_build(lh_accel_t *a, int build_threads, bool on_device, bool kee
         hs->have_ref = !(e && atoi(e) == 0);
         hs->ref_threads = build_threads;
     }
-    int rc = on_device ? lh_bvh_flatten(&hs->bvh, views, a->nmeshes)
+    const double tf = now_s();
+    int rc = on_device ? lh_bvh_flatten(&hs->bvh, views, a->nmeshes, build_threads)
                        : lh_bvh_build_hook(&hs->bvh, views, a->nmeshes, build_threads, hs->have_ref ? start_ref_thread : NULL, hs);
     free(views);
+    if (on_device && getenv("LH_BUILD_TIMING")) fprintf(stderr, "[lucille_hip] commit: host flatten                 %8.2f ms\n", (now_s() - tf) * 1e3);
     if (!on_device && hs->ref_thread_live) {           /* the host path returns with both trees */
         pthread_join(hs->ref_thread, NULL); hs->ref_thread_live = 0;
         if (rc == 0 && hs->ref_state != 2) return fail("lh_accel_commit: reference-order tree build failed (out of memory)");
@@ -268,10 +278,10 @@ static int host_build(lh_accel_t *a, int build_threads, bool on_device, bool kee
     {
         const double t0 = now_s();
         if (hs->have_ref && on_device && hs->bvh.ntris) {
-            /* not in front of the first frame: a background thread builds it, launch() attaches it when it is ready */
+            /* not in front of the first frame: a background thread builds it, launch() attaches it when it is ready.  It is
+             * started by lh_accel_commit AFTER the device has its scene (start_ref_background): its first phase streams the
+             * same 1.5 GB the upload reads and would take a third of the host's memory bandwidth from it */
             hs->ref_threads = build_threads; hs->ref_state = 1;
-            if (pthread_create(&hs->ref_thread, NULL, ref_thread_main, hs) != 0) { hs->ref_state = 0; return fail("lh_accel_commit: cannot start the reference-tree thread"); }
-            hs->ref_thread_live = 1;
         } else if (hs->ref_state != 2) {
             /* not started next to the tree build (an empty scene, or the thread could not be created): now */
             if (hs->have_ref && lh_refbvh_build(&hs->ref, hs->bvh.tri64, hs->bvh.ntris, build_threads) != 0)
@@ -491,8 +501,10 @@ static int device_upload(lh_accel_t *a)
     if (hs->bvh.ntris) {
         size_t t32 = sizeof(lh_tri32_t) * (size_t)hs->bvh.ntris;
         size_t t64 = sizeof(lh_tri64_t) * (size_t)hs->bvh.ntris;
+        const double tu = now_s();
         HIPCHK(hipMalloc(&a->d_tri64, t64));
         HIPCHK(hipMemcpy(a->d_tri64, hs->bvh.tri64, t64, hipMemcpyHostToDevice));
+        if (getenv("LH_BUILD_TIMING")) fprintf(stderr, "[lucille_hip] commit: tri64 upload (%.0f MB)      %8.2f ms\n", t64 / 1e6, (now_s() - tu) * 1e3);
         if (hs->device_built) {
             /* the traversal tree is built here, on this device (lh_build.hip): LBVH -> the same 4-wide nodes */
             char berr[256] = "";
@@ -542,8 +554,31 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
     { const char *e = getenv("LH_BUILD"); if (e && strcmp(e, "device") == 0) on_device = true; if (e && strcmp(e, "host") == 0) on_device = false; }
     if (build_threads < 0) build_threads = 0;
     if (on_device) {
+        const bool timing = getenv("LH_BUILD_TIMING") != NULL;
+        const double tc0 = now_s();
         if (host_build(a, build_threads, true, true) != 0) return -1;
+        const double tc1 = now_s();
         const int rc = device_upload(a);
+        if (timing) fprintf(stderr, "[lucille_hip] commit: host side %.2f ms, device side %.2f ms\n", (tc1 - tc0) * 1e3, (now_s() - tc1) * 1e3);
+        {
+            lh_host_scene *hs = a->hs;
+            if (hs->ref_state == 1 && !hs->ref_thread_live) {
+                if (rc == 0 && a->nmeshes) {
+                    /* the mesh copies are no longer needed: the background thread returns them to the system */
+                    hs->trash = (void **)calloc((size_t)a->nmeshes * 8, sizeof(void *));
+                    if (hs->trash) {
+                        for (uint32_t g = 0; g < a->nmeshes; g++) {
+                            hs->trash[hs->ntrash++] = a->meshes[g].pos; hs->trash[hs->ntrash++] = a->meshes[g].idx; hs->trash[hs->ntrash++] = a->meshes[g].nrm;
+                            for (int k = 0; k < 5; k++) hs->trash[hs->ntrash++] = a->meshes[g].attr[k];
+                            a->meshes[g].pos = NULL; a->meshes[g].idx = NULL; a->meshes[g].nrm = NULL;
+                            for (int k = 0; k < 5; k++) a->meshes[g].attr[k] = NULL;
+                        }
+                    }
+                }
+                if (pthread_create(&hs->ref_thread, NULL, ref_thread_main, hs) != 0) { hs->ref_state = 0; free_trash(hs); return fail("lh_accel_commit: cannot start the reference-tree thread"); }
+                hs->ref_thread_live = 1;
+            }
+        }
         if (rc == -3) {
             /* an LBVH deeper than the kernel's stack bound (degenerate distributions): build on the host after all */
             (void)hipSetDevice(a->device); release_device(a);
@@ -617,6 +652,7 @@ extern "C" void lh_accel_destroy(lh_accel_t *a)
     pthread_mutex_unlock(&g_scene_mu);
     if (last) {
         if (a->hs->ref_thread_live) { pthread_join(a->hs->ref_thread, NULL); a->hs->ref_thread_live = 0; }
+        free_trash(a->hs);
         free(a->hs->nrm9); free(a->hs->attr9[0]); free(a->hs->attr9[1]); free(a->hs->attr9[2]); free(a->hs->st6); free(a->hs->inside);
         lh_bvh_release(&a->hs->bvh);
         lh_refbvh_release(&a->hs->ref);

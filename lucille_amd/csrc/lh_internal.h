@@ -57,6 +57,7 @@ struct lh_host_scene {
     int device_built;
     int received;             /* the scene arrived as an image from another rank (lh_dist.hip): device arrays only */
     int ref_state; pthread_t ref_thread; int ref_thread_live; int ref_threads;
+    void **trash; uint32_t ntrash;   /* host blocks the device-side commit no longer needs: freed by the background thread (unmapping 0.5 GB takes 0.1 s) */
 };
 extern pthread_mutex_t g_scene_mu;
 
@@ -78,6 +79,7 @@ struct lh_accel {
     pthread_mutex_t mu;                /* serialises the entry points of ONE accelerator (recursive) */
     int stat_on;                       /* lh_accel_trace_statistics */
     unsigned long long stat[5];        /* nodes, filter tests, fp64 tests, rays, hits */
+    unsigned long long stat_slots[3];  /* wave-level: iterations with a node step, triangle passes, regroups (tile pipelines, lh_accel_slot_statistics) */
     hipStream_t stream;
     uint64_t device_bytes;
     double upload_seconds;

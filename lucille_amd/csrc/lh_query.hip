@@ -318,6 +318,15 @@ extern "C" int lh_accel_statistics(lh_accel_t *a, uint64_t counters[5], int clea
     return 0;
 }
 
+extern "C" int lh_accel_slot_statistics(lh_accel_t *a, uint64_t slots[3], int clear)
+{
+    lh_guard guard(a);
+    if (!a) return fail("lh_accel_slot_statistics: NULL accel");
+    if (slots) for (int k = 0; k < 3; k++) slots[k] = a->stat_slots[k];
+    if (clear) for (int k = 0; k < 3; k++) a->stat_slots[k] = 0;
+    return 0;
+}
+
 extern "C" int lh_accel_intersect1(lh_accel_t *a, const double org[3], const double dir[3],
                                    uint32_t *prim, double *t, double *u, double *v)
 {

@@ -166,6 +166,7 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
         HIPCHK(hipMemcpy(hc, cnt, sizeof(hc), hipMemcpyDeviceToHost));
         a->stat[0] += hc[LH_CNT_NODES]; a->stat[1] += hc[LH_CNT_TRIS]; a->stat[2] += hc[LH_CNT_EXACT];
         a->stat[3] += hc[LH_CNT_RAYS]; a->stat[4] += nhit + nocc;
+        a->stat_slots[0] += hc[LH_CNT_NODE_SLOTS]; a->stat_slots[1] += hc[LH_CNT_TRI_SLOTS]; a->stat_slots[2] += hc[LH_CNT_REGROUP_SLOTS];
         if (getenv("LH_DEBUG_COUNTERS")) {
             fprintf(stderr, "[lucille_hip] AO batch: rays by node visits (bucket b: [2^(b-1), 2^b)):");
             for (int b = 0; b < 24; b++) fprintf(stderr, " %llu", hc[LH_CNT_HIST + b]);

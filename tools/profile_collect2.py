@@ -1,7 +1,7 @@
 """Copy the summaries of gpurun_out/<tag>/<leg>/ (tools/profile_round2.sh) into profiles/<round>_<leg>_* and
 refresh profiles/pmc_latest.json (headline) / pmc_latest_hbm.json (S-soup-10M).
   python tools/profile_collect2.py <tag> <round-name>"""
-import csv, json, os, shutil, sys
+import csv, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, rnd = sys.argv[1], sys.argv[2]
 CORR = ("gfx950: every L2->fabric read request of this access pattern is a 128-B request (TCC_EA0_RDREQ_128B == TCC_EA0_RDREQ on "
@@ -66,7 +66,12 @@ for leg in ("main", "hbm", "ao", "pt"):
         F = sum(F) / len(F); W = sum(W) / len(W)
         line = json.load(open(bl)) if os.path.exists(bl) and os.path.getsize(bl) else {}
         wide = leg == "hbm" and (line.get("roofline_hbm") or {}).get("node_bytes") == 128
-        j = {"round": rnd, "kernel": mk["Name"], "kernel_tag": "q16x8" if wide else "q16x4", "mode": "closest",
+        try:
+            commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        except Exception:
+            commit = ""
+        j = {"round": rnd, "commit": commit, "source": "profiles/%s_%s_pmc_fetch_write.csv (tools/profile_round2.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes of the bench command)" % (rnd, leg),
+             "kernel": mk["Name"], "kernel_tag": "q16x8" if wide else "q16x4", "mode": "closest",
              "rays_per_launch": 100000000 if leg == "main" else 50000000,
              "triangles": 1000000 if leg == "main" else 10000000,
              "FETCH_SIZE_KiB": F, "WRITE_SIZE_KiB": W, "kernel_avg_ms_rocprof": avg_ms,
