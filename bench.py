@@ -550,8 +550,8 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
                 "peak_source": "tools/ubench/gather (profiles/r01_ubench_gather.log): dependent 64-B record gathers, 2048 resident waves",
                 "counters": sq, "algorithmic_GBps": round(b_frame / min(times) / 1e9, 1),
                 "nodes_per_ray": round(c["nodes"] / nr, 2), "tris_per_ray": round(c["tris"] / nr, 2), "exact_per_ray": round(c["exact"] / nr, 4),
-                "lane_use_node_steps": round(c["nodes"] / max(1, 64 * sl["node_slots"]), 3),
-                "lane_use_triangle_passes": round(c["tris"] / max(1, 64 * sl["tri_slots"]), 3),
+                "lane_use_node_steps": round(c["nodes"] / max(1, sl["node_slots"]), 3),
+                "lane_use_triangle_passes": round(c["tris"] / max(1, sl["tri_slots"]), 3),
                 "rays_counted": c["rays"]}
     # the same scene with the traversal tree built on the device (lh_build.hip; what lsh_hip does from 1 M triangles on): commit
     # time, frame time on that tree, and the image -- which must not change by a bit

@@ -138,8 +138,8 @@ int lh_accel_dump_node_bytes(const lh_accel_t *accel);
  * the path tracer).  Counts describe THIS build's tree, not lucille's. */
 int  lh_accel_trace_statistics(lh_accel_t *accel, int enable);
 int  lh_accel_statistics(lh_accel_t *accel, uint64_t counters[5], int clear);
-/* wave-level counts of the tile pipelines' counted launches: wave iterations that made a node step, triangle passes, regroups.
- * counters[0] / (64 x slots[0]) = lane use of the node steps, counters[1] / (64 x slots[1]) = of the triangle passes */
+/* lane slots of the tile pipelines' counted launches: 64 per wave iteration that made a node step / ran a triangle pass / regrouped.
+ * counters[0] / slots[0] = lane use of the node steps, counters[1] / slots[1] = of the triangle passes */
 int  lh_accel_slot_statistics(lh_accel_t *accel, uint64_t slots[3], int clear);
 
 /* number of persistent workgroups the persistent variants launch */

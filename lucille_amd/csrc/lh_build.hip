@@ -33,6 +33,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "lh_bvh.h"
 #include "lh_device.h"
 
@@ -102,9 +105,12 @@ __global__ void k_morton(uint32_t n, const float *__restrict__ plo, const float 
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     uint64_t code = 0;
+    /* one scale for the three axes (the largest extent): cubic cells.  A scale per axis makes the cells of a flat scene -- a
+     * floor with objects on it -- slabs, and every third split of the radix tree a cut across the thin direction */
+    double ext = 0.0;
+    for (int k = 0; k < 3; k++) { const double e = (double)o2f(scene[3 + k]) - (double)o2f(scene[k]); ext = e > ext ? e : ext; }
     for (int k = 0; k < 3; k++) {
-        const float smin = o2f(scene[k]), smax = o2f(scene[3 + k]);
-        const double ext = (double)smax - (double)smin;
+        const float smin = o2f(scene[k]);
         const double c = 0.5 * ((double)plo[3 * (size_t)p + k] + (double)phi[3 * (size_t)p + k]);
         double q = ext > 0.0 ? (c - (double)smin) / ext * 2097152.0 : 0.0;
         if (q < 0.0) q = 0.0;
@@ -238,6 +244,110 @@ __global__ void k_node_boxes(int n, BNode *__restrict__ nodes, const BoxTable T,
     nd.cost = cost; nd.leaf = leaf ? 1 : 0;
 }
 
+/* ---- SAH over the top of the tree (HLBVH) ----------------------------------------------------------------------
+ * A radix tree cuts space where the Morton code says, whatever lies there: its upper levels slice through objects and leave
+ * overlapping halves, and those are the nodes every ray visits.  The subtrees of at most `cut` primitives below them are
+ * compact patches and fine as they are.  So: the roots of those subtrees (k_cut_roots; ~3 n / cut of them) go to the host,
+ * which builds a binned-SAH tree over their boxes in a few milliseconds (top_build) and hands it back as ordinary BNodes
+ * behind the radix nodes; the collapse then starts at the new root. */
+struct CutRoot { int ref; uint32_t count; float lo[3], hi[3]; };
+
+__global__ void k_cut_roots(int n, const BNode *__restrict__ nodes, const BoxTable T, uint32_t cut, CutRoot *__restrict__ out, uint32_t cap,
+                            uint32_t *__restrict__ nout)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const BNode &nd = nodes[i];
+    const uint32_t size = nd.last - nd.first + 1u;
+    if (size <= cut) {
+        const int p = nd.parent;
+        if (p >= 0 && nodes[p].last - nodes[p].first + 1u <= cut) return;        /* inside a subtree */
+        const uint32_t k = atomicAdd(nout, 1u);
+        if (k < cap) { CutRoot r; r.ref = i; r.count = size; for (int c = 0; c < 3; c++) { r.lo[c] = nd.lo[c]; r.hi[c] = nd.hi[c]; } out[k] = r; }
+        return;
+    }
+    for (int side = 0; side < 2; side++) {                                        /* a single primitive hanging off a large node */
+        const int c = side ? nd.right : nd.left;
+        if (c >= 0) continue;
+        const uint32_t k = atomicAdd(nout, 1u);
+        if (k < cap) {
+            CutRoot r; r.ref = c; r.count = 1; const size_t e = (size_t)~c;
+            for (int a = 0; a < 3; a++) { r.lo[a] = T.lo[0][3 * e + a]; r.hi[a] = T.hi[0][3 * e + a]; }
+            out[k] = r;
+        }
+    }
+}
+
+static float top_area(const float lo[3], const float hi[3])
+{
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+/* binned SAH (16 bins, the three axes, subtrees weighted by their primitive counts) over it[b .. e); nodes appended to `out`,
+ * their global index = base + position.  Returns the reference of the subtree's root */
+static int top_build(CutRoot *it, int b, int e, std::vector<BNode> &out, int base)
+{
+    if (e - b == 1) return it[b].ref;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = b; i < e; i++)
+        for (int k = 0; k < 3; k++) {
+            lo[k] = fminf(lo[k], it[i].lo[k]); hi[k] = fmaxf(hi[k], it[i].hi[k]);
+            const float c = 0.5f * (it[i].lo[k] + it[i].hi[k]);
+            clo[k] = fminf(clo[k], c); chi[k] = fmaxf(chi[k], c);
+        }
+    enum { NB = 16 };
+    int best_axis = -1, best_bin = 0; float best_cost = INFINITY;
+    for (int k = 0; k < 3; k++) {
+        const float ext = chi[k] - clo[k];
+        if (!(ext > 0.0f)) continue;
+        float blo[NB][3], bhi[NB][3]; double bcnt[NB];
+        for (int j = 0; j < NB; j++) { bcnt[j] = 0.0; for (int a = 0; a < 3; a++) { blo[j][a] = INFINITY; bhi[j][a] = -INFINITY; } }
+        const float scale = (float)NB / ext;
+        for (int i = b; i < e; i++) {
+            int j = (int)((0.5f * (it[i].lo[k] + it[i].hi[k]) - clo[k]) * scale);
+            j = j < 0 ? 0 : (j >= NB ? NB - 1 : j);
+            bcnt[j] += it[i].count;
+            for (int a = 0; a < 3; a++) { blo[j][a] = fminf(blo[j][a], it[i].lo[a]); bhi[j][a] = fmaxf(bhi[j][a], it[i].hi[a]); }
+        }
+        float rarea[NB]; double rcnt[NB];
+        {
+            float rl[3] = {INFINITY, INFINITY, INFINITY}, rh[3] = {-INFINITY, -INFINITY, -INFINITY}; double rc = 0.0;
+            for (int j = NB - 1; j >= 1; j--) {
+                for (int a = 0; a < 3; a++) { rl[a] = fminf(rl[a], blo[j][a]); rh[a] = fmaxf(rh[a], bhi[j][a]); }
+                rc += bcnt[j]; rcnt[j] = rc; rarea[j] = rc > 0.0 ? top_area(rl, rh) : 0.0f;
+            }
+        }
+        float ll[3] = {INFINITY, INFINITY, INFINITY}, lh[3] = {-INFINITY, -INFINITY, -INFINITY}; double lc = 0.0;
+        for (int j = 0; j + 1 < NB; j++) {
+            for (int a = 0; a < 3; a++) { ll[a] = fminf(ll[a], blo[j][a]); lh[a] = fmaxf(lh[a], bhi[j][a]); }
+            lc += bcnt[j];
+            if (lc <= 0.0 || rcnt[j + 1] <= 0.0) continue;
+            const float cost = (float)(top_area(ll, lh) * lc + rarea[j + 1] * rcnt[j + 1]);
+            if (cost < best_cost) { best_cost = cost; best_axis = k; best_bin = j; }
+        }
+    }
+    int mid;
+    if (best_axis >= 0) {
+        const int k = best_axis; const float scale = (float)NB / (chi[k] - clo[k]);
+        CutRoot *m = std::partition(it + b, it + e, [&](const CutRoot &r) {
+            int j = (int)((0.5f * (r.lo[k] + r.hi[k]) - clo[k]) * scale);
+            j = j < 0 ? 0 : (j >= NB ? NB - 1 : j);
+            return j <= best_bin;
+        });
+        mid = (int)(m - it);
+    } else mid = b;
+    if (mid <= b || mid >= e) mid = b + (e - b) / 2;                 /* equal centroids: split the list */
+    const int me = (int)out.size();
+    out.push_back(BNode());
+    const int l = top_build(it, b, mid, out, base), r = top_build(it, mid, e, out, base);
+    BNode &nd = out[(size_t)me];
+    memset(&nd, 0, sizeof(nd));
+    nd.left = l; nd.right = r; nd.parent = -1;
+    for (int k = 0; k < 3; k++) { nd.lo[k] = lo[k]; nd.hi[k] = hi[k]; }
+    return base + me;
+}
+
 struct Child { float lo[3], hi[3]; int node; uint32_t first, count; };   /* node >= 0: inner binary node with > 4 primitives */
 
 __device__ __forceinline__ void child_of(const BNode *__restrict__ nodes, const uint32_t *__restrict__ sorted,
@@ -318,6 +428,23 @@ __global__ void k_collapse_level(uint32_t nwork, const uint2 *__restrict__ work_
     q4[k4] = out;
 }
 
+/* ---- how many LDS stack rows the walk really needs ------------------------------------------------------------------
+ * A step at node X leaves at most (children of X) - 1 entries on the stack, so a ray that is about to step at X holds at most
+ * the sum of that over X's ancestors.  The walk sizes its stack for the largest such sum (+ 5: sentinel and the step's own
+ * writes) instead of 3 x depth: a 20-level tree of this builder needs fewer than the 64 rows up to which the walk runs without
+ * a stack check.  (Re-laying the nodes depth first instead of level by level was tried here as well: 92.4 -> 95.3 ms on
+ * BASELINE config 5 -- rays of a wave share the level-ordered lines -- and removed.) */
+__global__ void k_stack_need(uint32_t begin, uint32_t end, const lh_q4node_t *__restrict__ q4, uint32_t *__restrict__ acc, uint32_t *__restrict__ need_max)
+{
+    const uint32_t k = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= end) return;
+    const uint32_t mine = k == 0 ? 0u : acc[k];
+    atomicMax(need_max, mine);
+    uint32_t nch = 0;
+    for (int c = 0; c < 4; c++) nch += q4[k].ref[c] != LH_REF_EMPTY;
+    for (int c = 0; c < 4; c++) { const int32_t r = q4[k].ref[c]; if (r >= 0) acc[r] = mine + (nch ? nch - 1u : 0u); }
+}
+
 /* a scene of <= 4 primitives: one node, one leaf */
 __global__ void k_single_leaf(uint32_t n, const uint32_t *__restrict__ scene, const float3 glo, const float3 gstep, lh_q4node_t *__restrict__ q4)
 {
@@ -358,21 +485,25 @@ static inline void dfree(void *p) { if (p) (void)hipFree(p); }
 /* d_tri64: ntris x 9 doubles (primitive-id order) on the current device.  On success *d_q4nodes (capacity ntris records,
  * *nq4 used) and *d_tri32 (ntris + 2 records) are hipMalloc'ed here and owned by the caller; bmin / bmax / grid as lh_bvh_t.
  * Returns 0, -1 (err filled), or -2 for a NaN / infinite / > 1e30 coordinate. */
-extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q4nodes, uint32_t *nq4, uint32_t *q4_depth,
+extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q4nodes, uint32_t *nq4, uint32_t *q4_depth, uint32_t *q4_stack,
                                void **d_tri32, float bmin[3], float bmax[3], float grid_lo[3], float grid_step[3],
                                void *stream, char *err, size_t errlen)
 {
     hipStream_t s = (hipStream_t)stream;
     const uint32_t n = ntris;
-    float *plo = NULL, *phi = NULL; uint32_t *scene = NULL, *val_in = NULL, *sorted = NULL, *counters = NULL; float *boxes = NULL;
+    float *plo = NULL, *phi = NULL; uint32_t *scene = NULL, *val_in = NULL, *sorted = NULL, *counters = NULL, *ncut = NULL; float *boxes = NULL; CutRoot *cuts = NULL;
     uint64_t *key_in = NULL, *key = NULL; int *leaf_parent = NULL, *bad = NULL; BNode *nodes = NULL; void *tmp = NULL; size_t tmp_bytes = 0;
-    uint2 *work[2] = {NULL, NULL}; lh_q4node_t *q4 = NULL; lh_tri32_t *t32 = NULL;
+    uint2 *work[2] = {NULL, NULL}; lh_q4node_t *q4 = NULL; lh_tri32_t *t32 = NULL; uint32_t *lay = NULL, need_rows = 0; std::vector<uint32_t> lvl_begin;
     const unsigned nb = (n + 255) / 256;
     uint32_t h_scene[6], h_cnt[2], level = 0, nwork = 0, nq = 1;
     const uint32_t init_scene[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     int h_bad = 0, leaf_max = LH_MAX_LEAF_TRIS;     /* leaves of up to 4 triangles WHERE THE SAH SAYS SO (k_refit): forced 4-triangle leaves cost S-soup-1M 37 % (tools/leaf_probe.py), the SAH keeps that soup at one per leaf */
     { const char *e = getenv("LH_DEVICE_LEAF"); if (e && atoi(e) >= 1 && atoi(e) <= LH_MAX_LEAF_TRIS) leaf_max = atoi(e); }
-    *d_q4nodes = NULL; *d_tri32 = NULL; *nq4 = 0; *q4_depth = 0;
+    uint32_t cut = 1024;                            /* primitives per subtree below the SAH-built top (LH_DEVICE_CUT; 0: plain radix tree) */
+    { const char *e = getenv("LH_DEVICE_CUT"); if (e && atoi(e) >= 0) cut = (uint32_t)atoi(e); }
+    const uint32_t cut_cap = cut ? (uint32_t)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(65536u, 16ull * n / cut)) : 0u;
+    int root_ref = 0;
+    *d_q4nodes = NULL; *d_tri32 = NULL; *nq4 = 0; *q4_depth = 0; *q4_stack = 0;
     if (n == 0) return 0;
     /* LH_BUILD_TIMING=1: phase times on stderr (each mark synchronises the stream: diagnostics only) */
     const bool timing = getenv("LH_BUILD_TIMING") != NULL;
@@ -426,7 +557,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
             BCHK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
             BCHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key_in, key, val_in, sorted, (int)n, 0, 63, s));
             mark("morton + radix sort");
-            BCHK(hipMalloc((void **)&nodes, sizeof(BNode) * (size_t)(n - 1)));
+            BCHK(hipMalloc((void **)&nodes, sizeof(BNode) * ((size_t)(n - 1) + cut_cap)));
             BCHK(hipMalloc((void **)&leaf_parent, sizeof(int) * (size_t)n));
             hipLaunchKernelGGL(k_radix_tree, dim3((n - 1 + 255) / 256), dim3(256), 0, s, (int)n, key, nodes, leaf_parent);
             mark("radix tree");
@@ -445,12 +576,30 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                     hipLaunchKernelGGL(k_box_blocks, dim3((unsigned)((cnt[l - 1] + 255) / 256)), dim3(256), 0, s, (uint32_t)cnt[l - 1], T.lo[l - 1], T.hi[l - 1],
                                        (float *)T.lo[l], (float *)T.hi[l]);
                 hipLaunchKernelGGL(k_node_boxes, dim3((n - 1 + 255) / 256), dim3(256), 0, s, (int)n, nodes, T, leaf_max);
+                mark("node boxes + SAH leaves");
+                if (cut > 0 && n > 4 * cut) {
+                    uint32_t h_ncut = 0;
+                    BCHK(hipMalloc((void **)&cuts, sizeof(CutRoot) * (size_t)cut_cap)); BCHK(hipMalloc((void **)&ncut, sizeof(uint32_t)));
+                    BCHK(hipMemsetAsync(ncut, 0, sizeof(uint32_t), s));
+                    hipLaunchKernelGGL(k_cut_roots, dim3((n - 1 + 255) / 256), dim3(256), 0, s, (int)n, (const BNode *)nodes, T, cut, cuts, cut_cap, ncut);
+                    BCHK(hipMemcpyAsync(&h_ncut, ncut, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    BCHK(hipStreamSynchronize(s));
+                    if (h_ncut >= 2 && h_ncut <= cut_cap) {                    /* (more roots than room: a degenerate tree, left as it is) */
+                        std::vector<CutRoot> items(h_ncut); std::vector<BNode> top; top.reserve(h_ncut);
+                        BCHK(hipMemcpy(items.data(), cuts, sizeof(CutRoot) * (size_t)h_ncut, hipMemcpyDeviceToHost));
+                        std::sort(items.begin(), items.end(), [](const CutRoot &a, const CutRoot &b) { return a.ref < b.ref; });   /* the append order is not reproducible */
+                        root_ref = top_build(items.data(), 0, (int)h_ncut, top, (int)(n - 1));
+                        BCHK(hipMemcpyAsync(nodes + (n - 1), top.data(), sizeof(BNode) * top.size(), hipMemcpyHostToDevice, s));
+                        BCHK(hipStreamSynchronize(s));
+                    }
+                    mark("SAH over the subtree roots");
+                }
             }
             /* level-by-level collapse; every level's children are allocated adjacently */
             BCHK(hipMalloc((void **)&work[0], sizeof(uint2) * (size_t)n)); BCHK(hipMalloc((void **)&work[1], sizeof(uint2) * (size_t)n));
             BCHK(hipMalloc((void **)&counters, sizeof(uint32_t) * 2));
             {
-                const uint2 root = make_uint2(0u, 0u);
+                const uint2 root = make_uint2((uint32_t)root_ref, 0u);
                 BCHK(hipMemcpyAsync(work[0], &root, sizeof(root), hipMemcpyHostToDevice, s));
             }
             nwork = 1; nq = 1;
@@ -461,24 +610,40 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                                    counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q4, leaf_max);
                 BCHK(hipMemcpyAsync(h_cnt, counters, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
                 BCHK(hipStreamSynchronize(s));
+                lvl_begin.push_back(nq);                                  /* first index of the level the kernel just filled */
                 nq = h_cnt[0]; nwork = h_cnt[1]; level++;
                 if (level > 200) { snprintf(err, errlen, "device build: runaway collapse"); goto fail; }
             }
+            mark("collapse to 4-wide nodes");
+            if (nq > 1) {
+                /* level l = indices [lb[l], lb[l + 1]): lb = 0, 1, then what the iterations recorded */
+                std::vector<uint32_t> lb; lb.push_back(0);
+                for (size_t k = 0; k < lvl_begin.size(); k++) lb.push_back(lvl_begin[k]);
+                lb.push_back(nq);
+                while (lb.size() >= 2 && lb[lb.size() - 1] == lb[lb.size() - 2]) lb.pop_back();       /* the last iteration adds nothing */
+                const int nl = (int)lb.size() - 1;
+                BCHK(hipMalloc((void **)&lay, sizeof(uint32_t) * ((size_t)nq + 1)));
+                BCHK(hipMemsetAsync(lay + nq, 0, sizeof(uint32_t), s));
+                for (int l = 0; l < nl; l++)
+                    hipLaunchKernelGGL(k_stack_need, dim3((lb[l + 1] - lb[l] + 255) / 256), dim3(256), 0, s, lb[l], lb[l + 1], (const lh_q4node_t *)q4, lay, lay + nq);
+                BCHK(hipMemcpyAsync(&need_rows, lay + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                BCHK(hipStreamSynchronize(s));
+                mark("stack rows of the deepest path");
+            }
         }
     }
-    mark("collapse to 4-wide nodes");
     hipLaunchKernelGGL(k_tri32, dim3(nb), dim3(256), 0, s, n, (const uint32_t *)sorted, d_tri64, t32);
     BCHK(hipGetLastError());
     BCHK(hipStreamSynchronize(s));
     mark("tri32 records");
-    *d_q4nodes = q4; *d_tri32 = t32; *nq4 = nq; *q4_depth = level;
+    *d_q4nodes = q4; *d_tri32 = t32; *nq4 = nq; *q4_depth = level; *q4_stack = nq > 1 ? need_rows + 5u : 0u;     /* LDS stack rows the walk needs (0: unknown, 3 x depth + 5) */
     dfree(plo); dfree(phi); dfree(scene); dfree(bad); dfree(key_in); dfree(key); dfree(val_in); dfree(sorted);
-    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters);
+    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters);
     mark("free temporaries");
     return 0;
 fail:
     dfree(plo); dfree(phi); dfree(scene); dfree(bad); dfree(key_in); dfree(key); dfree(val_in); dfree(sorted);
-    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters);
+    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters);
     dfree(q4); dfree(t32);
     return -1;
 }

@@ -82,6 +82,7 @@ typedef struct lh_bvh {
     float       bmin[3], bmax[3];  /* scene box, fp32 outward               */
     lh_q4node_t *q4nodes;          /* nq4nodes: 4-wide collapse of the same tree */
     uint32_t    nq4nodes, q4_depth;
+    uint32_t    q4_stack;      /* LDS stack rows the 4-wide walk needs on this tree (the device builder measures its deepest path); 0: 3 x q4_depth + 5 */
     lh_q8node_t *q8nodes;          /* nq8nodes: 8-wide collapse on the 16-bit grid, or NULL (lh_bvh_ensure_q8) */
     uint32_t    nq8nodes, q8_depth;
     float       grid_lo[3], grid_step[3];   /* the 16-bit grid of q4nodes / q8nodes */

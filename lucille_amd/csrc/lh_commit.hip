@@ -364,7 +364,7 @@ static int host_build(lh_accel_t *a, int build_threads, bool on_device, bool kee
     return 0;
 }
 
-extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q4nodes, uint32_t *nq4, uint32_t *q4_depth,
+extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q4nodes, uint32_t *nq4, uint32_t *q4_depth, uint32_t *q4_stack,
                                void **d_tri32, float bmin[3], float bmax[3], float grid_lo[3], float grid_step[3],
                                void *stream, char *err, size_t errlen);                /* lh_build.hip */
 
@@ -508,14 +508,14 @@ static int device_upload(lh_accel_t *a)
         if (hs->device_built) {
             /* the traversal tree is built here, on this device (lh_build.hip): LBVH -> the same 4-wide nodes */
             char berr[256] = "";
-            uint32_t nq4 = 0, d4 = 0; float bmin[3], bmax[3], glo[3], gst[3];
+            uint32_t nq4 = 0, d4 = 0, st4 = 0; float bmin[3], bmax[3], glo[3], gst[3];
             const double tb = now_s();
-            const int rcb = lh_device_build(hs->bvh.ntris, (const double *)a->d_tri64, &a->d_q4nodes, &nq4, &d4, &a->d_tri32, bmin, bmax, glo, gst,
+            const int rcb = lh_device_build(hs->bvh.ntris, (const double *)a->d_tri64, &a->d_q4nodes, &nq4, &d4, &st4, &a->d_tri32, bmin, bmax, glo, gst,
                                             (void *)a->stream, berr, sizeof(berr));
             if (rcb == -2) return fail("lh_accel_commit: a vertex coordinate is NaN, infinite or beyond 1e30");
             if (rcb != 0) return fail("device BVH build failed: %s", berr);
             pthread_mutex_lock(&g_scene_mu);
-            hs->bvh.nq4nodes = nq4; hs->bvh.q4_depth = d4; hs->bvh.nnodes = nq4; hs->bvh.max_depth = d4; hs->bvh.build_seconds = now_s() - tb;
+            hs->bvh.nq4nodes = nq4; hs->bvh.q4_depth = d4; hs->bvh.q4_stack = st4; hs->bvh.nnodes = nq4; hs->bvh.max_depth = d4; hs->bvh.build_seconds = now_s() - tb;
             for (int k = 0; k < 3; k++) { hs->bvh.bmin[k] = bmin[k]; hs->bvh.bmax[k] = bmax[k]; hs->bvh.grid_lo[k] = glo[k]; hs->bvh.grid_step[k] = gst[k]; }
             pthread_mutex_unlock(&g_scene_mu);
             a->dev.q4nodes = a->d_q4nodes;
@@ -533,7 +533,7 @@ static int device_upload(lh_accel_t *a)
         a->dev.max_depth = hs->bvh.max_depth; a->dev.scene_r = r; a->dev.ray_chunk = a->ray_chunk;
         for (int k = 0; k < 3; k++) { a->dev.grid_lo[k] = hs->bvh.grid_lo[k]; a->dev.grid_step[k] = hs->bvh.grid_step[k]; }
         if (hs->have_ref && __atomic_load_n(&hs->ref_state, __ATOMIC_ACQUIRE) == 2 && attach_ref(a) != 0) return -1;
-        a->dev.nq4nodes = hs->bvh.nq4nodes; a->dev.q4_depth = hs->bvh.q4_depth;
+        a->dev.nq4nodes = hs->bvh.nq4nodes; a->dev.q4_depth = hs->bvh.q4_depth; a->dev.q4_stack = hs->bvh.q4_stack;
         /* resident from the start: what the default kernel reads (everything else on first use) */
         if (lh_ensure_formats(a, LH_FMT_Q16X4) != 0) return -1;
     }
@@ -738,7 +738,7 @@ int lh_scene_image_header(lh_accel_t *a, lh_scene_image_t *h)
     memset(h, 0, sizeof(*h));
     h->magic = 0x4C48494Du;
     h->ntris = hs->bvh.ntris; h->nnodes = hs->bvh.nnodes; h->max_depth = hs->bvh.max_depth; h->nleaves = hs->bvh.nleaves;
-    h->nq4 = hs->bvh.nq4nodes; h->q4_depth = hs->bvh.q4_depth;
+    h->nq4 = hs->bvh.nq4nodes; h->q4_depth = hs->bvh.q4_depth; h->q4_stack = hs->bvh.q4_stack;
     h->nq8 = a->d_q8nodes ? a->dev.nq8nodes : 0; h->q8_depth = a->d_q8nodes ? a->dev.q8_depth : 0;
     h->nmeshes = hs->nmeshes;
     h->have_ref = a->d_ref_nodes != NULL; h->ref_nnodes = a->dev.ref_nnodes; h->ref_empty = a->dev.ref_empty;
@@ -794,7 +794,7 @@ int lh_scene_image_alloc(lh_accel_t *a, const lh_scene_image_t *h)
     HIPCHK(hipMalloc((void **)&a->d_total, sizeof(unsigned long long) * 4));
     hs->received = 1; hs->device_built = 1;              /* no host tree: the walks over other node formats are not available */
     hs->bvh.ntris = h->ntris; hs->bvh.nnodes = h->nnodes; hs->bvh.max_depth = h->max_depth; hs->bvh.nleaves = h->nleaves;
-    hs->bvh.nq4nodes = h->nq4; hs->bvh.q4_depth = h->q4_depth; hs->nmeshes = h->nmeshes;
+    hs->bvh.nq4nodes = h->nq4; hs->bvh.q4_depth = h->q4_depth; hs->bvh.q4_stack = h->q4_stack; hs->nmeshes = h->nmeshes;
     hs->bvh.build_seconds = h->build_seconds; hs->ref_build_seconds = h->ref_build_seconds;
     hs->have_ref = h->have_ref; hs->ref_state = h->have_ref ? 2 : 0;
     float r = 0.0f;
@@ -823,7 +823,7 @@ int lh_scene_image_alloc(lh_accel_t *a, const lh_scene_image_t *h)
         a->dev.tri32 = a->d_tri32; a->dev.tri64 = a->d_tri64; a->dev.q4nodes = a->d_q4nodes;
         a->dev.q8nodes = a->d_q8nodes; a->dev.nq8nodes = h->nq8; a->dev.q8_depth = h->q8_depth;
         a->dev.ntris = h->ntris; a->dev.nnodes = h->nnodes; a->dev.max_depth = h->max_depth; a->dev.scene_r = r; a->dev.ray_chunk = a->ray_chunk;
-        a->dev.nq4nodes = h->nq4; a->dev.q4_depth = h->q4_depth;
+        a->dev.nq4nodes = h->nq4; a->dev.q4_depth = h->q4_depth; a->dev.q4_stack = h->q4_stack;
         if (h->have_ref) {
             a->dev.ref_lca = a->d_ref_lca; a->dev.prim_leafpos = a->d_prim_leafpos; a->dev.ref_nodes = a->d_ref_nodes;
             a->dev.ref_leaf_prims = a->d_ref_leaf_prims; a->dev.ref_nnodes = h->ref_nnodes; a->dev.ref_empty = h->ref_empty;

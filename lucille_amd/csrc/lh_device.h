@@ -21,6 +21,7 @@ typedef struct lh_dev_scene {
     float       grid_lo[3], grid_step[3];   /* the scene's 16-bit grid (lh_q4node_t, lh_q8node_t)  */
     const void *q4nodes;      /* lh_q4node_t[nq4nodes] (64 B each): what the default walk reads   */
     uint32_t    nq4nodes, q4_depth;
+    uint32_t    q4_stack;  /* rows the 4-wide walk needs (lh_bvh_t); 0: 3 x q4_depth + 5 */
     const void *q8nodes;      /* lh_q8node_t[nq8nodes] (128 B each), or NULL                       */
     uint32_t    nq8nodes, q8_depth;
     int         prefer_q8;    /* this launch walks the 8-wide nodes (ray dumps over scenes larger than the Infinity Cache) */
@@ -61,7 +62,9 @@ enum {
     LH_VARIANT_SPEC   = 4    /* the default: persistent waves, branch-free 4-wide (or 8-wide) node step, parked leaves */
 };
 
-#define LH_ROWS_UNCHECKED 64u          /* LDS stack rows (1 KiB each per 256-thread workgroup) up to which the walk runs unchecked */
+#define LH_ROWS_UNCHECKED 64u          /* LDS stack rows (1 KiB each per 256-thread workgroup) up to which the walk runs unchecked (3 x depth + 5 rows:
+                                         depth <= 19).  Beyond 64 KiB per workgroup the frame collapses -- a 20-level device-built tree at
+                                         66 unchecked rows: 129 ms against 94 ms at 40 checked rows (r03) -- so deeper trees take the checked walk */
 #define LH_ROWS_CHECKED   40u          /* ... of the checked walk: four workgroups per CU */
 #define LH_NPART          8            /* cursor partitions of a persistent launch: one per XCD (each with its own L2) */
 #define LH_AO_QCAP        (1u << 22)   /* rays of one launch that may wait in the fix-up queue (8 B each): fragile AO hits, rays out of visit budget */

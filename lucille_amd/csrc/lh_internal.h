@@ -79,7 +79,7 @@ struct lh_accel {
     pthread_mutex_t mu;                /* serialises the entry points of ONE accelerator (recursive) */
     int stat_on;                       /* lh_accel_trace_statistics */
     unsigned long long stat[5];        /* nodes, filter tests, fp64 tests, rays, hits */
-    unsigned long long stat_slots[3];  /* wave-level: iterations with a node step, triangle passes, regroups (tile pipelines, lh_accel_slot_statistics) */
+    unsigned long long stat_slots[3];  /* lane slots (64 per wave iteration) of node steps, triangle passes, regroups (tile pipelines, lh_accel_slot_statistics) */
     hipStream_t stream;
     uint64_t device_bytes;
     double upload_seconds;
@@ -139,7 +139,7 @@ int  lh_ensure_buf(lh_buf *b, size_t bytes);
 void lh_free_buf(lh_buf *b);
 /* the scene image (lh_commit.hip): one rank's committed scene handed to the others (lh_dist.hip) */
 typedef struct lh_scene_image {
-    uint32_t magic, ntris, nnodes, max_depth, nleaves, nq4, q4_depth, nq8, q8_depth, ref_nnodes, nmeshes;
+    uint32_t magic, ntris, nnodes, max_depth, nleaves, nq4, q4_depth, q4_stack, nq8, q8_depth, ref_nnodes, nmeshes;
     int      have_ref, ref_empty, has_nrm, has_attr[3], has_st, has_inside;
     float    bmin[3], bmax[3], grid_lo[3], grid_step[3];
     double   ref_bmin[3], ref_bmax[3], build_seconds, ref_build_seconds;

@@ -46,6 +46,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <pthread.h>
 
 #include "../../include/lucille_hip.h"
 #include "lh_device.h"
@@ -632,8 +633,14 @@ template <bool ANYHIT, int SRC>
 __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const double *__restrict__ org, const double *__restrict__ dir,
                                                   uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
                                                   double *__restrict__ v, uint8_t *__restrict__ occ, const AoSrc ao, const FixQ fq,
-                                                  unsigned long long *counters)
+                                                  unsigned long long *counters, const uint32_t owner_groups)
 {
+    /* owner_groups == 0: the pass that runs NEXT TO the producer (second stream; few waves: it must not take the CUs from it).
+     * Group g owns the queue entries g, g + groups, ...; where it stopped is left in fq.heads[g].  If the two streams turn out to
+     * share a hardware queue this kernel only starts when the producer has finished: it then leaves at once, and the sweep --
+     * owner_groups = that pass's group count, launched behind the producer on its own stream with a grid that fills the chip --
+     * takes every entry no owner has taken (e >= heads[e mod owner_groups]).  (A serialised small pass over the 475 000 queued
+     * rays of a BASELINE config-5 frame took 30 ms: bench.py's device-tree frame, 89 -> 122 ms, until r03.) */
     extern __shared__ int lh_stack_lds[];          /* [rows][64] stack + 2 x 64 exchange words */
     const int rows = (int)sc.stack_rows, rmask = rows - 1;          /* rows: a power of two (ring of stack positions) */
     int (*stk)[64] = (int (*)[64])lh_stack_lds;
@@ -642,11 +649,24 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
     const unsigned long long gmask = 0xFFFFull << (16 * g), lt_mask = (1ull << lane) - 1ull;
     const uint32_t ngroups = gridDim.x * 4u;
     const uint32_t gid = blockIdx.x * 4u + (uint32_t)g;
-    uint32_t e = fq.heads[gid];                       /* the group's next queue entry: gid, gid + ngroups, ... (the sweep resumes where the concurrent pass left) */
+    if (owner_groups == 0u) {
+        uint32_t left = 0;
+        if (lane == 0) left = __hip_atomic_load(fq.qcount + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)__shfl((int)left, 0) >= fq.nprod) return;          /* the producer is gone already: the sweep is faster */
+    }
+    uint32_t e = owner_groups ? gid : fq.heads[gid];  /* the group's next queue entry: gid, gid + ngroups, ... */
+    if (owner_groups) while (e < fq.qcap && e < fq.heads[e % owner_groups]) e += ngroups;
     bool have = false;                                /* the group holds a ray */
     bool gdone = e >= fq.qcap;                        /* the group has seen the end of the queue */
     uint32_t known = 0, look = 0;                     /* wave-uniform: the append count at the wave's last look; iterations since */
     bool prod_done = false;                           /* wave-uniform: every producer wave was seen to have left */
+    if (owner_groups) {                               /* the sweep runs behind the producer: the count is final */
+        uint32_t cnt = 0;
+        if (lane == 0) cnt = __hip_atomic_load(fq.qcount, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        cnt = (uint32_t)__shfl((int)cnt, 0);
+        known = cnt < fq.qcap ? cnt : fq.qcap; prod_done = true;
+        if (e >= known) gdone = true;
+    }
     unsigned long long progress = wall_clock64();     /* when this wave last took an entry / saw the producer finish */
     size_t i = 0; double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1; uint32_t selfp = LH_MISS_PRIM;
     Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM, 0u};
@@ -703,7 +723,8 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
                 const uint32_t reason = (uint32_t)(ent >> 56);
                 i = (size_t)(ent & 0x00FFFFFFFFFFFFFFull);
                 e += ngroups;
-                if (e >= fq.qcap) gdone = true;
+                if (owner_groups) while (e < fq.qcap && e < fq.heads[e % owner_groups]) e += ngroups;
+                if (e >= fq.qcap || (owner_groups && e >= known)) gdone = true;
                 progress = wall_clock64();
                 src_ray<SRC>(sc, (uint32_t)i, org, dir, ao, ox, oy, oz, dx, dy, dz, selfp);
                 if (reason == LH_Q_REF) {
@@ -782,7 +803,7 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
             __syncthreads();
         }
     }
-    if ((lane & 15) == 0) fq.heads[gid] = e;          /* where the sweep (or nobody) goes on */
+    if (owner_groups == 0u && (lane & 15) == 0) fq.heads[gid] = e;          /* where the sweep goes on */
 }
 
 /* ------------------------------------------------------------------------ */
@@ -880,6 +901,26 @@ __global__ __launch_bounds__(256) void k_fixups(lh_dev_scene_t sc, size_t n, con
     }
 }
 
+/* a workgroup's LDS stack beyond 64 KiB (trees deeper than 19 four-wide levels: up to LH_ROWS_UNCHECKED rows) has to be
+ * allowed per kernel function, once */
+static int allow_lds(const void *func, size_t bytes)
+{
+    static const void *done[64]; static int ndone = 0; static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    if (bytes <= 64 * 1024) return 0;
+    pthread_mutex_lock(&mu);
+    bool have = false;
+    for (int k = 0; k < ndone; k++) have = have || done[k] == func;
+    int rc = 0;
+    if (!have) {
+        rc = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LH_ROWS_UNCHECKED * LH_BLOCK * sizeof(int))) == hipSuccess ? 0 : -1;
+        if (rc == 0 && ndone < 64) done[ndone++] = func;
+    }
+    pthread_mutex_unlock(&mu);
+    return rc;
+}
+#define LH_LAUNCH_PERSIST(KERNEL, ...) do { if (allow_lds((const void *)(KERNEL), lds_bytes) != 0) return -1; \
+                                            hipLaunchKernelGGL((KERNEL), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s, __VA_ARGS__); } while (0)
+
 template <bool ANYHIT, bool COUNT>
 int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const double *dir,
                uint32_t *prim, double *t, double *u, double *v, uint8_t *occ,
@@ -895,20 +936,15 @@ int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const doub
         if (hipMemsetAsync(cursor, 0, sizeof(unsigned long long) * LH_NPART, s) != hipSuccess) return -1;
         if (sc.cam_src) {                    /* ray source 2: closest hit over the 4-wide nodes only (lh_launch_trace checks) */
             if (walk == 8)
-                hipLaunchKernelGGL((k_trace_persist_lane<false, COUNT, 8, 2>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                                   sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
+                LH_LAUNCH_PERSIST((k_trace_persist_lane<false, COUNT, 8, 2>), sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
             else
-                hipLaunchKernelGGL((k_trace_persist_lane<false, COUNT, 3, 2>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                                   sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
+                LH_LAUNCH_PERSIST((k_trace_persist_lane<false, COUNT, 3, 2>), sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
         } else if (walk == 7)
-            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 7, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                               sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
+            LH_LAUNCH_PERSIST((k_trace_persist_lane<ANYHIT, COUNT, 7, 0>), sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
         else if (walk == 8)
-            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 8, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                               sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
+            LH_LAUNCH_PERSIST((k_trace_persist_lane<ANYHIT, COUNT, 8, 0>), sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
         else
-            hipLaunchKernelGGL((k_trace_persist_lane<ANYHIT, COUNT, 3, 0>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s,
-                               sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
+            LH_LAUNCH_PERSIST((k_trace_persist_lane<ANYHIT, COUNT, 3, 0>), sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -934,8 +970,8 @@ int launch_walk(const lh_dev_scene_t &sc, size_t n, const double *org, const dou
  * forces a lower cap. */
 uint32_t rows4(const lh_dev_scene_t &sc, bool *guard)
 {
-    uint32_t need = 3 * sc.q4_depth + 5;
-    const uint32_t cap = (sc.stack_cap >= 8 && sc.stack_cap < 64) ? sc.stack_cap : (need <= LH_ROWS_UNCHECKED ? LH_ROWS_UNCHECKED : LH_ROWS_CHECKED);
+    uint32_t need = sc.q4_stack ? sc.q4_stack : 3 * sc.q4_depth + 5;      /* the builder's own count of the deepest path, or the bound of any tree that deep */
+    const uint32_t cap = (sc.stack_cap >= 8 && sc.stack_cap < LH_ROWS_UNCHECKED) ? sc.stack_cap : (need <= LH_ROWS_UNCHECKED ? LH_ROWS_UNCHECKED : LH_ROWS_CHECKED);
     *guard = need > cap;
     if (need > cap) need = cap;
     need = (need + 1u) & ~1u;
@@ -985,13 +1021,13 @@ int launch_coop(const lh_dev_scene_t &sc, const double *org, const double *dir, 
     int grid = ncus > 0 ? ncus : 256;                      /* one wave per workgroup and CU, 4 rays per wave */
     if (grid * 4 > (int)LH_Q_GROUPS) grid = (int)LH_Q_GROUPS / 4;
     if (hipStreamWaitEvent(aux, (hipEvent_t)q->ev_ready, 0) != hipSuccess) return -1;
-    hipLaunchKernelGGL((k_coop_walk<ANYHIT, SRC>), dim3(grid), dim3(64), lds, aux, scl, org, dir, prim, t, u, v, occ, ao, fq, counters);
+    hipLaunchKernelGGL((k_coop_walk<ANYHIT, SRC>), dim3(grid), dim3(64), lds, aux, scl, org, dir, prim, t, u, v, occ, ao, fq, counters, 0u);
     if (hipGetLastError() != hipSuccess) return -1;
     if (hipEventRecord((hipEvent_t)q->ev_done, aux) != hipSuccess) return -1;
     if (hipStreamWaitEvent(s, (hipEvent_t)q->ev_done, 0) != hipSuccess) return -1;
-    /* the sweep: the same kernel behind the producer, on its stream -- whatever the concurrent pass did not take (nothing, when it
-     * ran next to the producer: 256 waves read two words and leave) */
-    hipLaunchKernelGGL((k_coop_walk<ANYHIT, SRC>), dim3(grid), dim3(64), lds, s, scl, org, dir, prim, t, u, v, occ, ao, fq, counters);
+    /* the sweep: the same kernel behind the producer, on its stream, sixteen waves per CU -- whatever the concurrent pass did not
+     * take (nothing, when it ran next to the producer: the waves read a few words and leave) */
+    hipLaunchKernelGGL((k_coop_walk<ANYHIT, SRC>), dim3(grid * 16), dim3(64), lds, s, scl, org, dir, prim, t, u, v, occ, ao, fq, counters, (uint32_t)grid * 4u);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1030,7 +1066,7 @@ extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int n
     if (hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long) * LH_NPART, s) != hipSuccess) return -1;
     if (hipMemsetAsync(d_occ_count, 0, sizeof(unsigned int) * nslots, s) != hipSuccess) return -1;
     if (fixq_begin(q, s) != 0) return -1;
-#define LH_AO_LAUNCH(CNT, W) hipLaunchKernelGGL((k_trace_persist_lane<true, CNT, W, 1>), dim3(grid_blocks), dim3(LH_BLOCK), lds_bytes, s, \
+#define LH_AO_LAUNCH(CNT, W) LH_LAUNCH_PERSIST((k_trace_persist_lane<true, CNT, W, 1>), \
                            scl, (uint32_t)n, (const double *)NULL, (const double *)NULL, (uint32_t *)NULL, (double *)NULL, (double *)NULL, \
                            (double *)NULL, (uint8_t *)NULL, d_counters, (uint32_t *)d_cursor, min_active, tri_batch, ao, fq)
     if (guard) { if (d_counters) LH_AO_LAUNCH(true, 8); else LH_AO_LAUNCH(false, 8); }
@@ -1104,7 +1140,7 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
         need = rows4(*sc, &guard); walk = guard ? 8 : 3;
         scl.stack_guard = guard ? 1 : 0;
     }
-    if (need > 64) return -1;
+    if (need > LH_ROWS_UNCHECKED) return -1;
     scl.stack_rows = need;
     const size_t lds_bytes = (size_t)need * LH_BLOCK * sizeof(int);
     clamp_chunk(scl, n, grid_blocks);

@@ -43,7 +43,15 @@ int lh_aoq_slot(lh_accel_t *a, hipStream_t s)
         HIPCHK(hipMemset(q->qcount, 0, (4 + 4096) * sizeof(uint32_t)));
         q->qcap = LH_AO_QCAP;
         hipStream_t aux; hipEvent_t e0, e1;
-        HIPCHK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        /* the consumer's stream gets the highest priority: streams of one priority share a handful of hardware queues round
+         * robin (four by default), and a consumer that lands on its producer's queue runs BEHIND it instead of next to it
+         * (bench.py's second accelerator: config-5 frame 89 -> 122 ms); priority streams have queues of their own */
+        {
+            int prio_lo = 0, prio_hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess || prio_hi == prio_lo ||
+                hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, prio_hi) != hipSuccess)
+                HIPCHK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        }
         HIPCHK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
         q->aux_stream = (void *)aux; q->ev_ready = (void *)e0; q->ev_done = (void *)e1;
