@@ -6,20 +6,26 @@
  * BASELINE config 5 scene.  Hit records do not depend on the tree (any conservative BVH + the bit-exact
  * fp64 triangle test reproduces the reference), so the traversal tree may be built by whatever is fastest:
  *
- *   1. per-primitive fp32-outward boxes and centroids from the fp64 triangles; scene box (atomic min / max);
- *   2. 63-bit Morton codes of the centroids, radix-sorted with the primitive ids (hipcub);
+ *   1. per-primitive fp32-outward boxes from the fp64 triangles; scene box (one atomic per wave and component);
+ *   2. 63-bit Morton codes of the centroids (one scale for the three axes: cubic cells), radix-sorted with the primitive
+ *      ids (hipcub);
  *   3. the binary radix tree over the sorted codes (Karras, "Maximizing Parallelism in the Construction of BVHs,
  *      Octrees, and k-d Trees", HPG 2012 -- the published algorithm, not code), ties between equal codes broken by
- *      position; boxes bottom-up with one atomic counter per inner node;
- *   4. the same 64-byte 4-wide 16-bit-grid nodes the host builder emits (lh_q4node_t): subtrees of <= 4 primitives become
- *      leaves (a contiguous range of the sorted order), the rest is collapsed level by level -- a 4-wide node takes its
- *      binary node's two children and opens the one with the largest area until it has four -- children of one node
- *      allocated adjacently; boxes quantised outward on the scene grid exactly as lh_bvh.c does (lo down, hi up, verified);
- *   5. the 48-byte triangle records (lh_tri32_t) in sorted = leaf order.
+ *      position;
+ *   4. node boxes as range queries over block tables of the sorted primitives' boxes (no bottom-up hand-over, no fences), and
+ *      in the same kernel the bottom-up SAH decision which subtrees of <= 4 primitives become ONE leaf;
+ *   5. binned SAH, on the host, over the roots of the subtrees of <= `cut` primitives (HLBVH: Pantaleoni & Luebke 2010,
+ *      Garanzha et al. 2011 -- the published idea): the top of a radix tree cuts through objects, the subtrees are fine;
+ *   6. the same 64-byte 4-wide 16-bit-grid nodes the host builder emits (lh_q4node_t), collapsed level by level -- a 4-wide
+ *      node takes its binary node's two children and opens the one with the largest area until it has four -- children of
+ *      one node allocated adjacently; boxes quantised outward on the scene grid exactly as lh_bvh.c does (lo down, hi up);
+ *   7. the LDS stack rows the walk needs on this tree, from its deepest path (instead of the 3 x depth + 5 of any tree);
+ *   8. the 48-byte triangle records (lh_tri32_t) in sorted = leaf order.
  *
  * Primitive numbering is the caller's (create_triangle_list order, bvh.c:1736-1826): ids ride along as payload.
- * The tree is shallower in quality than the binned-SAH host tree (more node visits per ray) and about three orders of
- * magnitude quicker to build; lh_api.hip chooses (LH_BUILD=device, lh_accel_commit's build_threads == LH_BUILD_ON_DEVICE).
+ * BASELINE config 5 (21.1 M triangles): 0.06 s for the tree, 0.2 s for the whole commit, frame within 3 % of the frame on
+ * the binned-SAH host tree; lh_commit.hip chooses (LH_BUILD=device, lh_accel_commit's build_threads ==
+ * LH_BUILD_ON_DEVICE).
  */
 #include <hip/hip_runtime.h>
 #include <time.h>
@@ -62,29 +68,38 @@ __device__ __forceinline__ float f_up(double d) { return __double2float_ru(d); }
 __device__ __forceinline__ uint32_t f2o(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float o2f(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
 
-__global__ void k_prim_boxes(uint32_t n, const double *__restrict__ tri64, float *__restrict__ plo, float *__restrict__ phi,
-                             uint32_t *__restrict__ scene /* 6 ordered uints: min xyz, max xyz */, int *__restrict__ bad)
+__global__ __launch_bounds__(256) void k_prim_boxes(uint32_t n, const double *__restrict__ tri64, float *__restrict__ plo, float *__restrict__ phi,
+                                                    uint32_t *__restrict__ scene /* 6 ordered uints: min xyz, max xyz */, int *__restrict__ bad)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t smin[4][3], smax[4][3];
     uint32_t omin[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, omax[3] = {0u, 0u, 0u};
-    if (p < n) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
         const double *t = tri64 + 9 * (size_t)p;
         for (int k = 0; k < 3; k++) {
             const double a = t[k], b = t[3 + k], c = t[6 + k];
             if (!(fabs(a) <= 1.0e30) || !(fabs(b) <= 1.0e30) || !(fabs(c) <= 1.0e30)) atomicExch(bad, 1);
             const float lo = f_down(fmin(a, fmin(b, c))), hi = f_up(fmax(a, fmax(b, c)));
             plo[3 * (size_t)p + k] = lo; phi[3 * (size_t)p + k] = hi;
-            omin[k] = f2o(lo); omax[k] = f2o(hi);
+            const uint32_t ol = f2o(lo), oh = f2o(hi);
+            omin[k] = ol < omin[k] ? ol : omin[k]; omax[k] = oh > omax[k] ? oh : omax[k];
         }
     }
-    /* scene bounds: one atomic per wave and component (one per THREAD was 126 M same-address atomics on a 21 M-triangle scene:
-     * 22 ms of a 170 ms build) */
+    /* scene bounds: six atomics per WORKGROUP of a grid that is a few thousand workgroups whatever n is.  Same-address
+     * device-scope atomics serialise at ~95 ns each: one per thread was 126 M of them on a 21 M-triangle scene, one per wave
+     * still 22 ms of a 60 ms build */
     for (int k = 0; k < 3; k++) {
         for (int off = 32; off >= 1; off >>= 1) {
             const uint32_t a = (uint32_t)__shfl_xor((int)omin[k], off), b = (uint32_t)__shfl_xor((int)omax[k], off);
             omin[k] = a < omin[k] ? a : omin[k]; omax[k] = b > omax[k] ? b : omax[k];
         }
-        if ((threadIdx.x & 63) == 0) { atomicMin(&scene[k], omin[k]); atomicMax(&scene[3 + k], omax[k]); }
+        if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6][k] = omin[k]; smax[threadIdx.x >> 6][k] = omax[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        uint32_t lo = smin[0][k], hi = smax[0][k];
+        for (int w = 1; w < 4; w++) { lo = smin[w][k] < lo ? smin[w][k] : lo; hi = smax[w][k] > hi ? smax[w][k] : hi; }
+        atomicMin(&scene[k], lo); atomicMax(&scene[3 + k], hi);
     }
 }
 
@@ -522,7 +537,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     BCHK(hipMalloc((void **)&scene, sizeof(uint32_t) * 8)); BCHK(hipMalloc((void **)&bad, sizeof(int)));
     BCHK(hipMemcpyAsync(scene, init_scene, sizeof(init_scene), hipMemcpyHostToDevice, s));
     BCHK(hipMemsetAsync(bad, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_prim_boxes, dim3(nb), dim3(256), 0, s, n, d_tri64, plo, phi, scene, bad);
+    hipLaunchKernelGGL(k_prim_boxes, dim3(nb < 2048u ? nb : 2048u), dim3(256), 0, s, n, d_tri64, plo, phi, scene, bad);
     BCHK(hipMemcpyAsync(h_scene, scene, sizeof(h_scene), hipMemcpyDeviceToHost, s));
     BCHK(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
     BCHK(hipStreamSynchronize(s));

@@ -8,12 +8,12 @@ cd /tmp; export TMPDIR=/tmp
 for LEG in $LEGS; do
   OUT=$R/gpurun_out/$TAG/$LEG; mkdir -p $OUT
   case $LEG in
-    main) CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu --no-ao --no-pt --no-hbm" ;;
+    main) CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu --no-ao --no-pt --no-hbm --no-config2" ;;
     *)    CMD="python $R/bench.py --only $LEG" ;;
   esac
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
-  timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1
-  timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1
   grep -h '"metric"' $OUT/trace.log | tail -1 > $OUT/bench_line.json
   # the raw counter CSVs are large: keep the rows of the ray-query kernels only
   for P in fetch write; do
