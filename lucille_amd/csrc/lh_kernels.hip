@@ -1059,7 +1059,7 @@ extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int n
     scl.stack_rows = rows4(*sc, &guard);
     scl.stack_guard = guard ? 1 : 0;
     const size_t lds_bytes = (size_t)scl.stack_rows * LH_BLOCK * sizeof(int);
-    if (scl.ray_chunk < 512) scl.ray_chunk = 512;      /* AO rays of a slot are coherent: longer ranges per wave (config 5: 92.9 -> 91.4 ms, tools/ao_sweep5.py) */
+    if (scl.ray_chunk < LH_TILE_CHUNK) scl.ray_chunk = LH_TILE_CHUNK;      /* AO rays of a slot are coherent: longer ranges per wave */
     clamp_chunk(scl, n, grid_blocks);
     AoSrc ao = {d_hitrec, d_slot_key, d_occ_count, seed, ntheta, nphi};
     FixQ fq = {(unsigned long long *)q->queue, q->qcount, q->qcap, (uint32_t)grid_blocks * (LH_BLOCK / 64), q->qcount + 4};

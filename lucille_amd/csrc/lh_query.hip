@@ -107,15 +107,16 @@ int lh_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, voi
     }
     /* ray dumps are incoherent by assumption: a wave's iterations serve 64 unrelated rays, a ray's age in iterations runs to
      * several times its own steps -- the tile pipelines' budget (128) would send half the batch to the cooperative walk */
-    const uint32_t budget_keep = a->dev.ray_budget;
+    const uint32_t budget_keep = a->dev.ray_budget, chunk_keep = a->dev.ray_chunk;
     if (dump) a->dev.ray_budget = a->dump_budget;
+    else if (a->dev.ray_chunk < LH_TILE_CHUNK) a->dev.ray_chunk = LH_TILE_CHUNK;       /* the tile pipelines' batches are coherent in batch order */
     const int qk = lh_aoq_slot(a, s);             /* the stream's fix-up queue (rays out of visit budget -> the cooperative walk) */
-    if (qk < 0) { a->dev.ray_budget = budget_keep; return -1; }
+    if (qk < 0) { a->dev.ray_budget = budget_keep; a->dev.ray_chunk = chunk_keep; return -1; }
     int rc = lh_launch_trace(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim,
                              (double *)d_t, (double *)d_u, (double *)d_v, mode == LH_MODE_ANY,
                              (uint8_t *)d_occ, d_counters, a->d_cursor + (size_t)LH_NPART * (a->cursor_next++ % LH_NCURSOR), variant, a->grid_blocks, a->min_active, a->tri_batch,
                              &a->aoq[qk].q, a->ncus, (void *)s);
-    a->dev.ray_budget = budget_keep;
+    a->dev.ray_budget = budget_keep; a->dev.ray_chunk = chunk_keep;
     if (rc != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     return 0;
 }
