@@ -474,7 +474,7 @@ static int device_upload(lh_accel_t *a)
     HIPCHK(hipSetDevice(a->device));
     double t0 = now_s();
     HIPCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
-    HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(unsigned long long) * LH_NPART * LH_NCURSOR));
+    HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(uint32_t) * LH_CURSOR_WORDS * LH_NCURSOR));
     HIPCHK(hipMalloc((void **)&a->d_counters, sizeof(unsigned long long) * LH_CNT_DEV));
     HIPCHK(hipMalloc((void **)&a->d_total, sizeof(unsigned long long) * 4));
     a->device_bytes = 0;
@@ -789,7 +789,7 @@ int lh_scene_image_alloc(lh_accel_t *a, const lh_scene_image_t *h)
     a->commit_failed = 1;
     HIPCHK(hipSetDevice(a->device));
     HIPCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
-    HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(unsigned long long) * LH_NPART * LH_NCURSOR));
+    HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(uint32_t) * LH_CURSOR_WORDS * LH_NCURSOR));
     HIPCHK(hipMalloc((void **)&a->d_counters, sizeof(unsigned long long) * LH_CNT_DEV));
     HIPCHK(hipMalloc((void **)&a->d_total, sizeof(unsigned long long) * 4));
     hs->received = 1; hs->device_built = 1;              /* no host tree: the walks over other node formats are not available */

@@ -67,6 +67,9 @@ enum {
                                          66 unchecked rows: 129 ms against 94 ms at 40 checked rows (r03) -- so deeper trees take the checked walk */
 #define LH_ROWS_CHECKED   40u          /* ... of the checked walk: four workgroups per CU */
 #define LH_NPART          8            /* cursor partitions of a persistent launch: one per XCD (each with its own L2) */
+#define LH_CURSOR_STRIDE  32           /* 32-bit words between two cursors: a 128-byte line each (device-scope atomics on one line serialise like atomics on
+                                         one address) */
+#define LH_CURSOR_WORDS   ((LH_NPART + 1) * LH_CURSOR_STRIDE)   /* the cursors + the drained-partition mask, per launch */
 #define LH_AO_QCAP        (1u << 22)   /* rays of one launch that may wait in the fix-up queue (8 B each): fragile AO hits, rays out of visit budget */
 #define LH_DUMP_BUDGET    2048u        /* ... of ray-dump launches (incoherent rays: ages run to several times the steps) */
 #define LH_TILE_CHUNK     1024u        /* rays per cursor atomic in the tile pipelines (camera rays, AO rays of a slot, path-tracing bounces: neighbours in the

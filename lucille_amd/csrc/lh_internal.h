@@ -74,7 +74,7 @@ struct lh_accel {
     void *d_nodes, *d_tri32, *d_tri64, *d_q4nodes, *d_q8nodes;
     int ncus;                          /* compute units of the device */
     int wide8;                         /* ray dumps walk the 8-wide nodes: -1 when the hot set exceeds the Infinity Cache (default), 0 never, 1 always */
-    unsigned long long *d_cursor, *d_counters;   /* d_cursor: LH_NCURSOR blocks of LH_NPART cursors, one block per launch in flight */
+    unsigned long long *d_cursor, *d_counters;   /* d_cursor: LH_NCURSOR blocks of LH_CURSOR_WORDS words (a line per cursor + the drained mask), one block per launch in flight */
     unsigned cursor_next;
     pthread_mutex_t mu;                /* serialises the entry points of ONE accelerator (recursive) */
     int stat_on;                       /* lh_accel_trace_statistics */

@@ -508,7 +508,7 @@ __device__ __forceinline__ void trace_persist_lane(
                     const uint32_t c = n / (gridDim.x * (LH_BLOCK / 64) * 4u);
                     chunk = c < 64u ? 64u : (c < chunk ? c : chunk);
                 }
-                /* A partition found handed out is published in cursor[LH_NPART] (a bit mask, zeroed with the cursors), and a wave
+                /* A partition found handed out is published in the word behind the cursors (a bit mask, zeroed with them), and a wave
                  * that runs dry reads that word before it probes further.  Without it every wave probed all LH_NPART cursors at
                  * the end of a launch: ~5000 waves x 8 device-scope atomics, serialised per address at ~95 ns each, were the
                  * ~0.5 ms "drain" of every launch -- an EMPTY launch of the path tracer's bounce chain took 0.49 ms
@@ -520,15 +520,15 @@ __device__ __forceinline__ void trace_persist_lane(
                     const uint32_t plen = p1 > p0 ? p1 - p0 : 0u;                              /* a small batch leaves the last partitions empty */
                     uint32_t b = plen;
                     if (plen) {
-                        if ((tid & 63) == 0) b = atomicAdd(cursor + part, chunk);              /* < 2^31 + waves * chunk: no wrap */
+                        if ((tid & 63) == 0) b = atomicAdd(cursor + part * LH_CURSOR_STRIDE, chunk);              /* < 2^31 + waves * chunk: no wrap */
                         b = (uint32_t)__shfl((int)b, 0);
                     }
                     if (b < plen) { b += p0; wbase = b; wend = (p1 - b > chunk) ? b + chunk : p1; break; }
                     drained |= 1u << part;
                     uint32_t seen = 0;
                     if ((tid & 63) == 0) {
-                        seen = __hip_atomic_load(cursor + LH_NPART, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((seen & drained) != drained) atomicOr(cursor + LH_NPART, drained);
+                        seen = __hip_atomic_load(cursor + LH_NPART * LH_CURSOR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((seen & drained) != drained) atomicOr(cursor + LH_NPART * LH_CURSOR_STRIDE, drained);
                     }
                     drained |= (uint32_t)__shfl((int)seen, 0);
                     part = (part + 1u) % LH_NPART;
@@ -933,7 +933,7 @@ int launch_one(const lh_dev_scene_t &sc, size_t n, const double *org, const doub
         hipLaunchKernelGGL((k_trace_direct<ANYHIT, COUNT>), dim3((unsigned)blocks), dim3(LH_BLOCK), lds_bytes, s,
                            sc, n, org, dir, prim, t, u, v, occ, counters);
     } else {
-        if (hipMemsetAsync(cursor, 0, sizeof(unsigned long long) * LH_NPART, s) != hipSuccess) return -1;
+        if (hipMemsetAsync(cursor, 0, sizeof(uint32_t) * LH_CURSOR_WORDS, s) != hipSuccess) return -1;
         if (sc.cam_src) {                    /* ray source 2: closest hit over the 4-wide nodes only (lh_launch_trace checks) */
             if (walk == 8)
                 LH_LAUNCH_PERSIST((k_trace_persist_lane<false, COUNT, 8, 2>), sc, (uint32_t)n, org, dir, prim, t, u, v, occ, counters, (uint32_t *)cursor, min_active, tri_batch, AoSrc{}, fq);
@@ -1063,7 +1063,7 @@ extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int n
     clamp_chunk(scl, n, grid_blocks);
     AoSrc ao = {d_hitrec, d_slot_key, d_occ_count, seed, ntheta, nphi};
     FixQ fq = {(unsigned long long *)q->queue, q->qcount, q->qcap, (uint32_t)grid_blocks * (LH_BLOCK / 64), q->qcount + 4};
-    if (hipMemsetAsync(d_cursor, 0, sizeof(unsigned long long) * LH_NPART, s) != hipSuccess) return -1;
+    if (hipMemsetAsync(d_cursor, 0, sizeof(uint32_t) * LH_CURSOR_WORDS, s) != hipSuccess) return -1;
     if (hipMemsetAsync(d_occ_count, 0, sizeof(unsigned int) * nslots, s) != hipSuccess) return -1;
     if (fixq_begin(q, s) != 0) return -1;
 #define LH_AO_LAUNCH(CNT, W) LH_LAUNCH_PERSIST((k_trace_persist_lane<true, CNT, W, 1>), \

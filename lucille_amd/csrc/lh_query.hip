@@ -114,7 +114,7 @@ int lh_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, voi
     if (qk < 0) { a->dev.ray_budget = budget_keep; a->dev.ray_chunk = chunk_keep; return -1; }
     int rc = lh_launch_trace(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim,
                              (double *)d_t, (double *)d_u, (double *)d_v, mode == LH_MODE_ANY,
-                             (uint8_t *)d_occ, d_counters, a->d_cursor + (size_t)LH_NPART * (a->cursor_next++ % LH_NCURSOR), variant, a->grid_blocks, a->min_active, a->tri_batch,
+                             (uint8_t *)d_occ, d_counters, (unsigned long long *)((uint32_t *)a->d_cursor + (size_t)LH_CURSOR_WORDS * (a->cursor_next++ % LH_NCURSOR)), variant, a->grid_blocks, a->min_active, a->tri_batch,
                              &a->aoq[qk].q, a->ncus, (void *)s);
     a->dev.ray_budget = budget_keep; a->dev.ray_chunk = chunk_keep;
     if (rc != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
