@@ -13,9 +13,11 @@
  * non-missing triangle in the reference's own traversal order and depends on which leaves
  * its plane tests let through, so this kernel walks the reference-order tree (lh_refbvh.c)
  * with the reference's fp64 arithmetic, operation order and comparisons (no FMA
- * contraction): one beam per lane, private stack, 128-byte fp64 nodes.  It is a
- * low-volume query (the reference's only caller issues (W/64)^2 root beams), bounded by
- * dependent 128-byte gathers like the ray kernel; there is nothing for MFMA here.
+ * contraction) -- but not its schedule: a beam is walked by 16 lanes, which test a node's
+ * eight planes or a leaf's up to 16 triangles at once and restore the reference's order with
+ * a ballot (k_beam_visibility).  It is a low-volume query (the reference's only caller issues
+ * (W/64)^2 root beams), bounded by dependent 128-byte gathers like the ray kernel; there is
+ * nothing for MFMA here.
  */
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -135,47 +137,77 @@ __device__ int beam_triangle(const double *tv, const Beam &b)
     return (mask == 0xf) ? 1 : 2;
 }
 
-__global__ __launch_bounds__(128) void k_beam_visibility(lh_dev_scene_t sc, size_t n, const double *__restrict__ org,
-                                                         const double *__restrict__ dirs, int32_t *__restrict__ result)
+/* One beam per group of 16 lanes (four beams per wave).  The reference walks one beam at a time and tests a leaf's triangles
+ * one after the other until one is not missed (bvh.c:2435-2542); here the SAME tests -- beam_aabb's four plane tests per child
+ * box, beam_triangle's four corner-ray tests per triangle, fp64, no contraction -- are spread over the group's lanes and the
+ * reference's order is put back with a ballot:
+ *   inner node: lane 4 c + i tests plane i of child c; a child is missed when one of its four lanes says so;
+ *   leaf:       lane q tests triangle q (leaves hold <= 16; longer ones in rounds of 16); the answer is the class of the
+ *               lowest lane that did not miss = the first non-missing triangle in the reference's order.
+ * Control flow is uniform inside a group (every lane holds the beam and computes the same next node); the stack of node
+ * indices -- BVH_MAXDEPTH + 1 entries (bvh.c:80,124-129) -- is one LDS column per group. */
+__global__ __launch_bounds__(64) void k_beam_visibility(lh_dev_scene_t sc, size_t n, const double *__restrict__ org,
+                                                        const double *__restrict__ dirs, int32_t *__restrict__ result)
 {
-    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
+    LH_NC
+    __shared__ int stack[4][104];
+    const int lane = threadIdx.x, g = lane >> 4, l = lane & 15;
+    const size_t r = (size_t)blockIdx.x * 4 + (size_t)g;
+    const bool live = r < n;
     Beam b;
-    if (beam_set(b, org + 3 * r, dirs + 12 * r) != 0) { result[r] = -1; return; }
-    if (sc.ref_empty) { result[r] = 0; return; }
-    {
-        const double sb[6] = {sc.ref_bmin[0], sc.ref_bmin[1], sc.ref_bmin[2], sc.ref_bmax[0], sc.ref_bmax[1], sc.ref_bmax[2]};
-        if (!beam_aabb(sb, b)) { result[r] = 0; return; }
+    int ret = 0;
+    bool walking = false;
+    if (live) {
+        if (beam_set(b, org + 3 * r, dirs + 12 * r) != 0) ret = -1;
+        else if (!sc.ref_empty) {
+            const double sb[6] = {sc.ref_bmin[0], sc.ref_bmin[1], sc.ref_bmin[2], sc.ref_bmax[0], sc.ref_bmax[1], sc.ref_bmax[2]};
+            walking = beam_aabb(sb, b) != 0;
+        }
     }
     const lh_refnode_t *nodes = (const lh_refnode_t *)sc.ref_nodes;
     const uint32_t *leaf_prims = (const uint32_t *)sc.ref_leaf_prims;
     const double *tri64 = (const double *)sc.tri64;
-    int stack[104];           /* BVH_MAXDEPTH + 1 (bvh.c:80,124-129) */
-    int depth = 0, node = 0, ret = 0;
-    for (;;) {
-        const lh_refnode_t *nd = &nodes[node];
-        if (nd->is_leaf) {
-            int cls = 0;
-            for (uint32_t q = 0; q < nd->count; q++) {
-                cls = beam_triangle(tri64 + 9 * (size_t)leaf_prims[nd->first + q], b);
-                if (cls != 0) break;
+    int depth = 0, node = 0;
+    while (__ballot(walking) != 0ull) {                       /* the wave goes on while one of its four beams does */
+        const lh_refnode_t *nd = &nodes[walking ? node : 0];
+        const bool leaf = walking && nd->is_leaf;
+        /* ---- leaf: one triangle per lane ---- */
+        int cls = 0;
+        if (leaf) {
+            for (uint32_t base = 0; base < nd->count && cls == 0; base += 16u) {
+                int mine = 0;
+                if (base + (uint32_t)l < nd->count) mine = beam_triangle(tri64 + 9 * (size_t)leaf_prims[nd->first + base + (uint32_t)l], b);
+                /* the group's lanes in order: the first that did not miss */
+                for (int q = 0; q < 16 && cls == 0; q++) { const int c = __shfl(mine, (g << 4) | q); if (c != 0) cls = c; }
             }
-            if (cls != 0) { ret = cls; break; }
-            if (depth < 1) { ret = 0; break; }
-            node = stack[--depth];
+        }
+        /* ---- inner node: one plane of one child per lane (lanes 0 .. 7 of the group) ---- */
+        bool miss_plane = false;
+        if (walking && !leaf && l < 8) {
+            const double *box = nd->box[l >> 2]; const int i = l & 3;
+            double no[3];
+            for (int k = 0; k < 3; k++) no[k] = ((b.normal[i][k] > 0.0) ? box[k] : box[3 + k]) - b.org[k];
+            miss_plane = dot3(no, b.normal[i]) > 0.0;
+        }
+        const uint32_t mp = (uint32_t)(__ballot(miss_plane) >> (16 * g)) & 0xFFu;
+        if (!walking) continue;
+        if (leaf) {
+            if (cls != 0) { ret = cls; walking = false; }
+            else if (depth < 1) { ret = 0; walking = false; }
+            else node = stack[g][--depth];
         } else {
-            const int hit = beam_aabb(nd->box[0], b) | (beam_aabb(nd->box[1], b) << 1);
-            if (hit == 0) { if (depth < 1) { ret = 0; break; } node = stack[--depth]; }
+            const int hit = ((mp & 0x0Fu) == 0u ? 1 : 0) | ((mp & 0xF0u) == 0u ? 2 : 0);
+            if (hit == 0) { if (depth < 1) { ret = 0; walking = false; } else node = stack[g][--depth]; }
             else if (hit == 1) node = nd->child[0];
             else if (hit == 2) node = nd->child[1];
             else {
                 const int order = b.dirsign[b.dominant_axis];
-                if (depth < 103) stack[depth++] = nd->child[1 - order];
+                if (depth < 103) { stack[g][depth] = nd->child[1 - order]; depth++; }       /* every lane of the group writes the same value */
                 node = nd->child[order];
             }
         }
     }
-    result[r] = ret;
+    if (live && l == 0) result[r] = ret;
 }
 
 } /* namespace */
@@ -184,7 +216,7 @@ extern "C" int lh_launch_beam_visibility(const lh_dev_scene_t *sc, size_t n, con
                                          int32_t *d_result, void *stream)
 {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_beam_visibility, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_beam_visibility, dim3((unsigned)((n + 3) / 4)), dim3(64), 0, (hipStream_t)stream,
                        *sc, n, d_org, d_dirs, d_result);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
