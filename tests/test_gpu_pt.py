@@ -205,3 +205,22 @@ def test_interleaved_bands_as_one_pass_equal_the_frame(ps):
     assert torch.equal(img.flip(0).reshape(H, W, 3), ref) and rays == st["rays"]
     with pytest.raises(la.LucilleHipError, match="inside the frame"):
         acc.render_pt_bands(cam, 4, 4, 12, nb // 3 + 1, 0, 8, 8)
+
+
+def test_empty_and_one_triangle_scenes():
+    """no geometry: every camera ray leaves the scene and returns the environment (the bounce chain's ray counts live on the
+    device: the launches after the first find zero rays); one triangle with a 2-vertex limit: hits end black"""
+    import torch
+    cam = la.Camera.make(64, 48, 2.0, np.eye(4).ravel(), 1)
+    acc = la.HipAccel(0); acc.commit()
+    img, st = acc.render_pt_tile(cam, 0, 0, 64, 48, 0, 4, 4, kd=0.8, env=(0.5, 0.25, 1.0), seed=1)
+    assert st == {"paths": 64 * 48 * 4, "rays": 64 * 48 * 4, "max_depth_reached": 1}
+    assert torch.equal(img, torch.tensor([0.5, 0.25, 1.0], device="cuda").expand(48, 64, 3))
+    out, st = acc.render_pt_bands(cam, 0, 4, 8, 6, 0, 4, 4, seed=1)           # the accelerator's default environment: white
+    assert out.shape == (6, 4, 64, 3) and float(out.min()) == 1.0 and st["rays"] == 6 * 4 * 64 * 4
+    acc.close()
+    P = np.array([[0, 0, -5], [1, 0, -5], [0, 1, -5]], float)
+    acc = la.HipAccel(0); acc.add_mesh(P, np.arange(3, dtype=np.uint32)); acc.commit()
+    img, st = acc.render_pt_tile(cam, 0, 0, 64, 48, 0, 4, 4, kd=0.8, env=(1, 1, 1), seed=1, max_vertices=2)
+    assert st["rays"] == st["paths"] and 0.9 < float(img.mean()) < 1.0 and float(img.min()) == 0.0
+    acc.close()
