@@ -558,7 +558,9 @@ static void dp4_emit(const lh_bvh_t *o, const dp4_t *dp, const float *lo, const 
     ch[*n].lo = lo; ch[*n].hi = hi; ch[*n].ref = ref; (*n)++;
 }
 
-static void build4(lh_bvh_t *o, const dp4_t *dp, uint32_t i2, uint32_t k4, uint32_t depth, uint32_t *next)
+/* above: the stack entries a ray can hold when it steps at this node = the sum over its ancestors of (children - 1); the
+ * largest such sum + 5 (sentinel, the step's own writes) is the LDS rows the walk needs on this tree (q4_stack) */
+static void build4(lh_bvh_t *o, const dp4_t *dp, uint32_t i2, uint32_t k4, uint32_t depth, uint32_t above, uint32_t *next)
 {
     child4_t ch[4]; int n = 2, c, k; uint32_t kid[4];
     const lh_node_t *nd = &o->nodes[i2];
@@ -585,6 +587,7 @@ static void build4(lh_bvh_t *o, const dp4_t *dp, uint32_t i2, uint32_t k4, uint3
         }
     }
     if (depth + 1 > o->q4_depth) o->q4_depth = depth + 1;
+    if (above + 5 > o->q4_stack) o->q4_stack = above + 5;
     for (c = 0; c < n; c++) if (ch[c].ref >= 0) kid[c] = (*next)++;     /* inner children adjacent */
     {
         lh_q4node_t *q = &o->q4nodes[k4];
@@ -600,7 +603,7 @@ static void build4(lh_bvh_t *o, const dp4_t *dp, uint32_t i2, uint32_t k4, uint3
             }
         }
     }
-    for (c = 0; c < n; c++) if (ch[c].ref >= 0) build4(o, dp, (uint32_t)ch[c].ref, kid[c], depth + 1, next);
+    for (c = 0; c < n; c++) if (ch[c].ref >= 0) build4(o, dp, (uint32_t)ch[c].ref, kid[c], depth + 1, above + (uint32_t)(n - 1), next);
 }
 
 static int collapse4(lh_bvh_t *o)
@@ -615,8 +618,8 @@ static int collapse4(lh_bvh_t *o)
         if (!dp) return -1;
         if (dp4_fill(o, dp, 4) != 0) { free(dp); dp = NULL; }      /* not a parent-first order: the greedy rule */
     }
-    o->q4_depth = 0;
-    build4(o, dp, 0, 0, 0, &next);
+    o->q4_depth = 0; o->q4_stack = 0;
+    build4(o, dp, 0, 0, 0, 0, &next);
     o->nq4nodes = next;
     free(dp);
     return 0;
