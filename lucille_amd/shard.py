@@ -74,10 +74,35 @@ def init_process_group(backend=None, device=None):
         tdist.all_gather_object(devs, dev)
         shared = len(set(devs)) < world                       # one node: equal ordinals = one GPU (tests on a one-GPU box)
         transport = binding.DIST_SHM if shared or os.environ.get("LH_DIST_TRANSPORT") == "shm" else binding.DIST_RCCL
-        ids = [binding.HipDist.unique_id() if (rank == 0 and transport == binding.DIST_RCCL) else (os.urandom(128) if rank == 0 else None)]
-        tdist.broadcast_object_list(ids, src=0)
         torch.cuda.set_device(dev)
-        _DIST = binding.HipDist(rank, world, dev, unique_id=ids[0], transport=transport)
+        if transport == binding.DIST_RCCL:
+            # RCCL first; if ANY rank cannot bring its communicator up (no librccl, a fabric problem) every rank falls back to the
+            # shared-memory transport of lh_dist_* (host staging: slower, same results) instead of dying -- said loudly
+            ok, err = 1.0, ""
+            ids = [None]
+            try:
+                ids = [binding.HipDist.unique_id() if rank == 0 else None]
+            except Exception as e:                                   # noqa: BLE001 -- whatever dlopen / ncclGetUniqueId raised
+                ok, err = 0.0, repr(e)
+            flag = torch.tensor([ok], dtype=torch.float64); tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+            if float(flag.item()) > 0.5:
+                tdist.broadcast_object_list(ids, src=0)
+                try:
+                    _DIST = binding.HipDist(rank, world, dev, unique_id=ids[0], transport=binding.DIST_RCCL)
+                except Exception as e:                               # noqa: BLE001
+                    ok, err = 0.0, repr(e)
+                flag = torch.tensor([ok], dtype=torch.float64); tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+            if float(flag.item()) < 0.5:
+                if _DIST is not None:
+                    _DIST.close(); _DIST = None
+                import sys
+                print("[lucille_amd] rank %d: RCCL transport unavailable%s -- falling back to the shared-memory transport of lh_dist_*"
+                      % (rank, (": " + err) if err else " on another rank"), file=sys.stderr, flush=True)
+                transport = binding.DIST_SHM
+        if _DIST is None:
+            ids = [os.urandom(128) if rank == 0 else None]
+            tdist.broadcast_object_list(ids, src=0)
+            _DIST = binding.HipDist(rank, world, dev, unique_id=ids[0], transport=transport)
     return rank, world, local
 
 
