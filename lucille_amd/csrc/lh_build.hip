@@ -40,6 +40,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "lh_bvh.h"
@@ -299,9 +300,11 @@ static float top_area(const float lo[3], const float hi[3])
     return dx * dy + dy * dz + dz * dx;
 }
 
-/* binned SAH (16 bins, the three axes, subtrees weighted by their primitive counts) over it[b .. e); nodes appended to `out`,
- * their global index = base + position.  Returns the reference of the subtree's root */
-static int top_build(CutRoot *it, int b, int e, std::vector<BNode> &out, int base)
+/* binned SAH (16 bins, the three axes, subtrees weighted by their primitive counts) over it[b .. e).  A subtree over m items
+ * has m - 1 nodes: it gets the slots out[nb .. nb + m - 2] (root first, then the left subtree's, then the right's), so the
+ * layout does not depend on who builds what and the large subtrees near the top are built by threads of their own.  A node's
+ * global index = base + slot.  Returns the reference of the subtree's root */
+static int top_build(CutRoot *it, int b, int e, BNode *out, int nb, int base, int par_depth)
 {
     if (e - b == 1) return it[b].ref;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -353,14 +356,21 @@ static int top_build(CutRoot *it, int b, int e, std::vector<BNode> &out, int bas
         mid = (int)(m - it);
     } else mid = b;
     if (mid <= b || mid >= e) mid = b + (e - b) / 2;                 /* equal centroids: split the list */
-    const int me = (int)out.size();
-    out.push_back(BNode());
-    const int l = top_build(it, b, mid, out, base), r = top_build(it, mid, e, out, base);
-    BNode &nd = out[(size_t)me];
+    const int nl = nb + 1, nr = nb + 1 + (mid - b - 1);              /* first slots of the two subtrees */
+    int l, r;
+    if (par_depth > 0 && e - b > 4096) {
+        std::thread th([&]() { l = top_build(it, b, mid, out, nl, base, par_depth - 1); });
+        r = top_build(it, mid, e, out, nr, base, par_depth - 1);
+        th.join();
+    } else {
+        l = top_build(it, b, mid, out, nl, base, 0);
+        r = top_build(it, mid, e, out, nr, base, 0);
+    }
+    BNode &nd = out[nb];
     memset(&nd, 0, sizeof(nd));
     nd.left = l; nd.right = r; nd.parent = -1;
     for (int k = 0; k < 3; k++) { nd.lo[k] = lo[k]; nd.hi[k] = hi[k]; }
-    return base + me;
+    return base + nb;
 }
 
 struct Child { float lo[3], hi[3]; int node; uint32_t first, count; };   /* node >= 0: inner binary node with > 4 primitives */
@@ -514,7 +524,8 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     const uint32_t init_scene[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     int h_bad = 0, leaf_max = LH_MAX_LEAF_TRIS;     /* leaves of up to 4 triangles WHERE THE SAH SAYS SO (k_refit): forced 4-triangle leaves cost S-soup-1M 37 % (tools/leaf_probe.py), the SAH keeps that soup at one per leaf */
     { const char *e = getenv("LH_DEVICE_LEAF"); if (e && atoi(e) >= 1 && atoi(e) <= LH_MAX_LEAF_TRIS) leaf_max = atoi(e); }
-    uint32_t cut = 1024;                            /* primitives per subtree below the SAH-built top (LH_DEVICE_CUT; 0: plain radix tree) */
+    uint32_t cut = 256;                             /* primitives per subtree below the SAH-built top (LH_DEVICE_CUT; 0: plain radix tree).  config 5:
+                                                       1024 -> 93.9 ms, 256 -> 92.7 ms when measured; the host's share of the build is threaded */
     { const char *e = getenv("LH_DEVICE_CUT"); if (e && atoi(e) >= 0) cut = (uint32_t)atoi(e); }
     const uint32_t cut_cap = cut ? (uint32_t)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(65536u, 16ull * n / cut)) : 0u;
     int root_ref = 0;
@@ -576,6 +587,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
             BCHK(hipMalloc((void **)&leaf_parent, sizeof(int) * (size_t)n));
             hipLaunchKernelGGL(k_radix_tree, dim3((n - 1 + 255) / 256), dim3(256), 0, s, (int)n, key, nodes, leaf_parent);
             mark("radix tree");
+            BoxTable T;
             {
                 /* boxes of the sorted primitives and of their blocks of 64 / 4096 / 262144, all in one allocation */
                 size_t cnt[LH_BOX_LEVELS], total = 0;
@@ -583,7 +595,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                 for (int l = 1; l < LH_BOX_LEVELS; l++) cnt[l] = (cnt[l - 1] + LH_BOX_RADIX - 1) / LH_BOX_RADIX;
                 for (int l = 0; l < LH_BOX_LEVELS; l++) total += cnt[l];
                 BCHK(hipMalloc((void **)&boxes, sizeof(float) * 6 * total));
-                BoxTable T; size_t off = 0;
+                size_t off = 0;
                 for (int l = 0; l < LH_BOX_LEVELS; l++) { T.lo[l] = boxes + 6 * off; T.hi[l] = boxes + 6 * off + 3 * cnt[l]; off += cnt[l]; }
                 hipLaunchKernelGGL(k_sorted_boxes, dim3(nb), dim3(256), 0, s, n, (const uint32_t *)sorted, (const float *)plo, (const float *)phi,
                                    (float *)T.lo[0], (float *)T.hi[0]);
@@ -592,58 +604,66 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                                        (float *)T.lo[l], (float *)T.hi[l]);
                 hipLaunchKernelGGL(k_node_boxes, dim3((n - 1 + 255) / 256), dim3(256), 0, s, (int)n, nodes, T, leaf_max);
                 mark("node boxes + SAH leaves");
-                if (cut > 0 && n > 4 * cut) {
+            }
+            BCHK(hipMalloc((void **)&work[0], sizeof(uint2) * (size_t)n)); BCHK(hipMalloc((void **)&work[1], sizeof(uint2) * (size_t)n));
+            BCHK(hipMalloc((void **)&counters, sizeof(uint32_t) * 2));
+            BCHK(hipMalloc((void **)&lay, sizeof(uint32_t) * ((size_t)n + 1)));
+            if (cut_cap) { BCHK(hipMalloc((void **)&cuts, sizeof(CutRoot) * (size_t)cut_cap)); BCHK(hipMalloc((void **)&ncut, sizeof(uint32_t))); }
+            /* top + collapse + the rows its deepest path needs.  A finer cut gives the better tree (config 5: 92.7 ms at 256 against
+             * 93.9 at 1024) unless it makes the tree one level too deep for the unchecked walk's 64 LDS rows (97.6 ms): then the next
+             * coarser cut is tried -- a second attempt costs ~25 ms of a 0.2 s commit */
+            for (int attempt = 0; ; attempt++) {
+                const uint32_t cc = attempt == 0 ? cut : (attempt == 1 ? cut * 4u : cut * 16u);
+                root_ref = 0;
+                if (cc > 0 && n > 4 * cc) {
                     uint32_t h_ncut = 0;
-                    BCHK(hipMalloc((void **)&cuts, sizeof(CutRoot) * (size_t)cut_cap)); BCHK(hipMalloc((void **)&ncut, sizeof(uint32_t)));
                     BCHK(hipMemsetAsync(ncut, 0, sizeof(uint32_t), s));
-                    hipLaunchKernelGGL(k_cut_roots, dim3((n - 1 + 255) / 256), dim3(256), 0, s, (int)n, (const BNode *)nodes, T, cut, cuts, cut_cap, ncut);
+                    hipLaunchKernelGGL(k_cut_roots, dim3((n - 1 + 255) / 256), dim3(256), 0, s, (int)n, (const BNode *)nodes, T, cc, cuts, cut_cap, ncut);
                     BCHK(hipMemcpyAsync(&h_ncut, ncut, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     BCHK(hipStreamSynchronize(s));
                     if (h_ncut >= 2 && h_ncut <= cut_cap) {                    /* (more roots than room: a degenerate tree, left as it is) */
-                        std::vector<CutRoot> items(h_ncut); std::vector<BNode> top; top.reserve(h_ncut);
+                        std::vector<CutRoot> items(h_ncut); std::vector<BNode> top(h_ncut - 1);
                         BCHK(hipMemcpy(items.data(), cuts, sizeof(CutRoot) * (size_t)h_ncut, hipMemcpyDeviceToHost));
                         std::sort(items.begin(), items.end(), [](const CutRoot &a, const CutRoot &b) { return a.ref < b.ref; });   /* the append order is not reproducible */
-                        root_ref = top_build(items.data(), 0, (int)h_ncut, top, (int)(n - 1));
+                        root_ref = top_build(items.data(), 0, (int)h_ncut, top.data(), 0, (int)(n - 1), 5);      /* up to 32 threads near the top */
                         BCHK(hipMemcpyAsync(nodes + (n - 1), top.data(), sizeof(BNode) * top.size(), hipMemcpyHostToDevice, s));
                         BCHK(hipStreamSynchronize(s));
                     }
                     mark("SAH over the subtree roots");
                 }
-            }
-            /* level-by-level collapse; every level's children are allocated adjacently */
-            BCHK(hipMalloc((void **)&work[0], sizeof(uint2) * (size_t)n)); BCHK(hipMalloc((void **)&work[1], sizeof(uint2) * (size_t)n));
-            BCHK(hipMalloc((void **)&counters, sizeof(uint32_t) * 2));
-            {
-                const uint2 root = make_uint2((uint32_t)root_ref, 0u);
-                BCHK(hipMemcpyAsync(work[0], &root, sizeof(root), hipMemcpyHostToDevice, s));
-            }
-            nwork = 1; nq = 1;
-            while (nwork > 0) {
-                h_cnt[0] = nq; h_cnt[1] = 0;
-                BCHK(hipMemcpyAsync(counters, h_cnt, sizeof(h_cnt), hipMemcpyHostToDevice, s));
-                hipLaunchKernelGGL(k_collapse_level, dim3((nwork + 127) / 128), dim3(128), 0, s, nwork, (const uint2 *)work[level & 1], work[(level + 1) & 1],
-                                   counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q4, leaf_max);
-                BCHK(hipMemcpyAsync(h_cnt, counters, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
-                BCHK(hipStreamSynchronize(s));
-                lvl_begin.push_back(nq);                                  /* first index of the level the kernel just filled */
-                nq = h_cnt[0]; nwork = h_cnt[1]; level++;
-                if (level > 200) { snprintf(err, errlen, "device build: runaway collapse"); goto fail; }
-            }
-            mark("collapse to 4-wide nodes");
-            if (nq > 1) {
-                /* level l = indices [lb[l], lb[l + 1]): lb = 0, 1, then what the iterations recorded */
-                std::vector<uint32_t> lb; lb.push_back(0);
-                for (size_t k = 0; k < lvl_begin.size(); k++) lb.push_back(lvl_begin[k]);
-                lb.push_back(nq);
-                while (lb.size() >= 2 && lb[lb.size() - 1] == lb[lb.size() - 2]) lb.pop_back();       /* the last iteration adds nothing */
-                const int nl = (int)lb.size() - 1;
-                BCHK(hipMalloc((void **)&lay, sizeof(uint32_t) * ((size_t)nq + 1)));
-                BCHK(hipMemsetAsync(lay + nq, 0, sizeof(uint32_t), s));
-                for (int l = 0; l < nl; l++)
-                    hipLaunchKernelGGL(k_stack_need, dim3((lb[l + 1] - lb[l] + 255) / 256), dim3(256), 0, s, lb[l], lb[l + 1], (const lh_q4node_t *)q4, lay, lay + nq);
-                BCHK(hipMemcpyAsync(&need_rows, lay + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                BCHK(hipStreamSynchronize(s));
-                mark("stack rows of the deepest path");
+                /* level-by-level collapse; every level's children are allocated adjacently */
+                {
+                    const uint2 root = make_uint2((uint32_t)root_ref, 0u);
+                    BCHK(hipMemcpyAsync(work[0], &root, sizeof(root), hipMemcpyHostToDevice, s));
+                }
+                nwork = 1; nq = 1; level = 0; lvl_begin.clear(); need_rows = 0;
+                while (nwork > 0) {
+                    h_cnt[0] = nq; h_cnt[1] = 0;
+                    BCHK(hipMemcpyAsync(counters, h_cnt, sizeof(h_cnt), hipMemcpyHostToDevice, s));
+                    hipLaunchKernelGGL(k_collapse_level, dim3((nwork + 127) / 128), dim3(128), 0, s, nwork, (const uint2 *)work[level & 1], work[(level + 1) & 1],
+                                       counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q4, leaf_max);
+                    BCHK(hipMemcpyAsync(h_cnt, counters, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
+                    BCHK(hipStreamSynchronize(s));
+                    lvl_begin.push_back(nq);                                  /* first index of the level the kernel just filled */
+                    nq = h_cnt[0]; nwork = h_cnt[1]; level++;
+                    if (level > 200) { snprintf(err, errlen, "device build: runaway collapse"); goto fail; }
+                }
+                mark("collapse to 4-wide nodes");
+                if (nq > 1) {
+                    /* level l = indices [lb[l], lb[l + 1]): lb = 0, 1, then what the iterations recorded */
+                    std::vector<uint32_t> lb; lb.push_back(0);
+                    for (size_t k = 0; k < lvl_begin.size(); k++) lb.push_back(lvl_begin[k]);
+                    lb.push_back(nq);
+                    while (lb.size() >= 2 && lb[lb.size() - 1] == lb[lb.size() - 2]) lb.pop_back();       /* the last iteration adds nothing */
+                    const int nl = (int)lb.size() - 1;
+                    BCHK(hipMemsetAsync(lay + nq, 0, sizeof(uint32_t), s));
+                    for (int l = 0; l < nl; l++)
+                        hipLaunchKernelGGL(k_stack_need, dim3((lb[l + 1] - lb[l] + 255) / 256), dim3(256), 0, s, lb[l], lb[l + 1], (const lh_q4node_t *)q4, lay, lay + nq);
+                    BCHK(hipMemcpyAsync(&need_rows, lay + nq, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                    BCHK(hipStreamSynchronize(s));
+                    mark("stack rows of the deepest path");
+                }
+                if (need_rows + 5u <= LH_ROWS_UNCHECKED || cut == 0 || attempt == 2 || n <= 4 * cc) break;
             }
         }
     }

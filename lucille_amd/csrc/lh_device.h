@@ -62,9 +62,10 @@ enum {
     LH_VARIANT_SPEC   = 4    /* the default: persistent waves, branch-free 4-wide (or 8-wide) node step, parked leaves */
 };
 
-#define LH_ROWS_UNCHECKED 64u          /* LDS stack rows (1 KiB each per 256-thread workgroup) up to which the walk runs unchecked (3 x depth + 5 rows:
-                                         depth <= 19).  Beyond 64 KiB per workgroup the frame collapses -- a 20-level device-built tree at
-                                         66 unchecked rows: 129 ms against 94 ms at 40 checked rows (r03) -- so deeper trees take the checked walk */
+#define LH_ROWS_UNCHECKED 64u          /* LDS stack rows (1 KiB each per 256-thread workgroup) up to which the walk runs unchecked (3 x depth + 5 rows, or the
+                                         builder's count of the deepest path).  A workgroup with more than 64 KiB of LDS halves what a CU holds -- a
+                                         21-level device-built tree at 66 rows, with the attribute set to 80 or to 78 KiB alike: 129-132 ms against
+                                         94 ms at 40 checked rows and 87 ms for a 20-level tree under 64 (r03) -- so deeper trees take the checked walk */
 #define LH_ROWS_CHECKED   40u          /* ... of the checked walk: four workgroups per CU */
 #define LH_NPART          8            /* cursor partitions of a persistent launch: one per XCD (each with its own L2) */
 #define LH_CURSOR_STRIDE  32           /* 32-bit words between two cursors: a 128-byte line each (device-scope atomics on one line serialise like atomics on
