@@ -12,12 +12,17 @@ resident in HBM.  Workload (BASELINE.json config 3, the one the north-star targe
 --rays incoherent rays (default 100 M) that continues the same stream.
 
 STRONG scaling: the dump is fixed.  Rank r owns the contiguous slice
-[n r / N, n (r+1) / N) (it jump-aheads the generator to its first ray), traces it against
-its replica of the BVH in a few chunks, and the hit records (prim u32 + t, u, v f64 =
-28 B/ray) are gathered to rank 0 -- the display / dump owner, as in lucille's "every rank
-renders, rank 0 owns the display" design (render.c:468-514) -- chunk by chunk, overlapped
-with the tracing of the next chunk, INSIDE the timed region.  value = n x steps / max-over-
-ranks time.  At N = 1 there is nothing to gather and the dump is one launch.
+[n r / N, n (r+1) / N) (it jump-aheads the generator to its first ray) and traces it against
+its replica of the BVH.  The hit records (prim u32 + t, u, v f64 = 28 B/ray) stay in the HBM
+of the rank that traced them: in lucille a rank's transport stage consumes the records of the
+rays it shot and only PIXELS travel to the display owner ("every rank renders, rank 0 owns
+the display", render.c:468-514, parallel.c:101-119) -- that exchange is the `ao_render` /
+`pt_render` legs' gather of tile slabs.  The path has no per-ray exchange step, so the
+headline has no data-path collective; what rank 0 collects is a digest per rank (hits,
+sum of t).  value = n x steps / max-over-ranks time.  `with_record_gather` (N > 1) reports
+the same dump with every record gathered to rank 0 chunk by chunk behind the tracing of the
+next chunk (RCCL, lh_dist_gather) -- what a dump service that returns records to ONE host
+would pay -- and `--gather-records` makes that the headline.
 
 One JSON line on rank 0, with
   roofline      the dominant kernel on the headline workload: algorithmic bytes / HIP-event
@@ -116,7 +121,8 @@ def main():
     ap.add_argument("--half-extent", type=float, default=0.005)
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--mode", choices=["closest", "any"], default="closest")
-    ap.add_argument("--chunks", type=int, default=4, help="N>1: trace/gather pipeline depth per rank")
+    ap.add_argument("--chunks", type=int, default=4, help="N>1: trace/gather pipeline depth per rank (with_record_gather)")
+    ap.add_argument("--gather-records", action="store_true", help="N>1: gather every hit record to rank 0 inside the headline's timed region")
     ap.add_argument("--cpu-rays", type=int, default=1_500_000, help="cpu_baseline sample size")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-hbm", action="store_true", help="skip the S-soup-10M HBM-roofline leg")
@@ -191,7 +197,7 @@ def main():
     sptr = C.c_void_p(stream.cuda_stream)
     evp = EventPairs(hip, (args.steps + args.warmup + 2) * nchunks)
 
-    def one_step(timed):
+    def one_step(timed, gather=True):
         for c in range(nchunks):
             (o, m) = outs_of(c)
             if m > 0:
@@ -202,10 +208,10 @@ def main():
                 acc.intersect_device(d_org[sl], d_dir[sl], out=full, mode=mode, variant=args.variant)
                 if timed:
                     evp.end(sptr)
-            if world > 1:
+            if world > 1 and gather:
                 gstream.wait_stream(stream)
                 shard.gather_bytes(bufs[c], gathered[c] if rank == 0 else None, stream=gstream)
-        if world > 1:
+        if world > 1 and gather:
             stream.wait_stream(gstream)
 
     def barrier():
@@ -224,26 +230,73 @@ def main():
     b_ray = B_IN + b_out + B_NODE[node_fmt] * n_nodes + B_TRI * n_tris
 
     # ---- timed region -------------------------------------------------------------
+    head_gather = bool(args.gather_records) or world == 1
+    whole = None
+    if not head_gather:
+        # no exchange step: a rank's slice is ONE launch into one record buffer (the chunks exist for the gather pipeline)
+        whole = torch.empty(max(n, 1) * rec_bytes, dtype=torch.uint8, device=dev)
+        whole_out = record_views(torch, whole, max(n, 1))[:4] if mode == la.MODE_CLOSEST else (whole[:max(n, 1)],)
+
+        def head_step(timed):
+            if n > 0:
+                if timed:
+                    evp.begin(sptr)
+                acc.intersect_device(d_org[:n], d_dir[:n], out=tuple(x[:n] for x in whole_out), mode=mode, variant=args.variant)
+                if timed:
+                    evp.end(sptr)
+        head_step(False)
+    else:
+        def head_step(timed):
+            one_step(timed, world > 1)
     for _ in range(args.warmup):
-        one_step(False)
+        head_step(False)
     barrier(); torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        one_step(True)
+        head_step(True)
     torch.cuda.synchronize(dev); barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    # N > 1: the same dump with every record gathered to rank 0 (secondary figure; also what fills `gathered` for the validation)
+    gather_elapsed = None
+    if world > 1:
+        gsteps = max(1, min(args.steps, 3))
+        one_step(False, True)
+        barrier(); torch.cuda.synchronize(dev)
+        tg = time.perf_counter()
+        for k in range(gsteps):
+            one_step(False, True)
+        torch.cuda.synchronize(dev); barrier()
+        gather_elapsed = shard.all_reduce_max((time.perf_counter() - tg) / gsteps)
     kms = evp.ms()
-    launches_per_step = sum(1 for c in range(nchunks) if cb[c][1] > cb[c][0])
+    launches_per_step = sum(1 for c in range(nchunks) if cb[c][1] > cb[c][0]) if head_gather else (1 if n > 0 else 0)
     kernel_ms = float(np.sum(kms)) / max(1, args.steps)            # per step, this rank's launches together
 
     if world > 1:
         elapsed = shard.all_reduce_max(elapsed)
 
+    # ---- the digest every rank sends instead of its records: hits and sum of t of its slice ------------------
+    digest = None
+    if mode == la.MODE_CLOSEST:
+        if whole is not None:
+            hp = whole_out[0][:n] != -1; ht = whole_out[1][:n]
+            lh_, lt_ = float(hp.sum().item()), float(ht[hp].sum().item())
+        else:
+            lh_ = lt_ = 0.0
+            for c in range(nchunks):
+                (o_, m_) = outs_of(c)
+                if m_ > 0:
+                    hp = o_[0][:m_] != -1
+                    lh_ += float(hp.sum().item()); lt_ += float(o_[1][:m_][hp].sum().item())
+        digest = {"hits": int(shard.all_reduce_sum(lh_)) if world > 1 else int(lh_), "sum_t": round(shard.all_reduce_sum(lt_) if world > 1 else lt_, 3)}
+
     # ---- validation of the timed launches (rank 0) --------------------------------
     validation = None
     if rank == 0:
-        validation = validate_dump(torch, la, args, mode, outs_of, cb, cnt_out, ns, gathered, world, per, n_total, bufs)
+        if whole is not None:       # the headline's own launch: one buffer; the gathered chunks are checked against the chunked pass's
+            validation = validate_dump(torch, la, args, mode, lambda c: (whole_out, n), [(0, n)], cnt_out, ns, gathered, world, per, n_total, bufs, nchunks)
+        else:
+            validation = validate_dump(torch, la, args, mode, outs_of, cb, cnt_out, ns, gathered, world, per, n_total, bufs, nchunks)
 
     # ---- context figures (rank 0, N = 1, untimed for `value`) ----------------------
     copy_gbps = host_path = None
@@ -293,9 +346,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "S-soup-1M ray dump (BASELINE config 3): %d random triangles, one dump of %d incoherent rays cut into %d "
                                    "contiguous slice(s), %s-hit%s" % (args.tris, n_total, world, args.mode,
-                                                                      "" if world == 1 else ", 28-B hit records gathered to rank 0 inside the timed region"),
+                                                                      "" if world == 1 else (", 28-B hit records gathered to rank 0 inside the timed region" if head_gather
+                                                                                             else ", hit records stay with the rank that traced them (digest to rank 0)")),
                        "rays": n_total, "rays_per_gpu": n, "triangles": args.tris, "mode": args.mode,
-                       "variant": args.variant, "parallelism": "replicated BVH, ray slices x%d%s" % (world, "" if world == 1 else ", %d-chunk trace/gather pipeline" % nchunks),
+                       "variant": args.variant, "parallelism": "replicated BVH, ray slices x%d%s" % (world, "" if world == 1 else (", %d-chunk trace/gather pipeline" % nchunks if args.gather_records else ", one launch per rank, no per-ray exchange")),
                        "scene_load": {"rank0_commit_s": round(commit_s, 3), "broadcast_s": round(bcast_s, 3) if world > 1 else None,
                                       "transport": None if world == 1 else ("rccl" if shard.dist().transport == la.DIST_RCCL else "shm (ranks share a device)"),
                                       "note": "one host build on rank 0, flattened arrays broadcast to every rank (lh_dist_broadcast_scene)"},
@@ -311,6 +365,14 @@ def main():
                          "nodes_per_ray": round(n_nodes, 3), "tris_per_ray": round(n_tris, 3)},
             "validation": validation,
         }
+        if digest is not None:
+            validation["digest_all_ranks"] = dict(digest, hit_rate=round(digest["hits"] / max(1, n_total), 4))
+            validation["ok"] = bool(validation["ok"]) and 0.5 < digest["hits"] / max(1, n_total) < 0.99
+        if gather_elapsed is not None:
+            res["with_record_gather"] = {"value": round(n_total / gather_elapsed / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(gather_elapsed * 1e3, 3),
+                                         "bytes_to_rank0_per_step": int(rec_bytes * (n_total - n)),
+                                         "note": "the same dump, every hit record gathered to rank 0 in %d chunks behind the tracing of the next chunk (lh_dist_gather: RCCL "
+                                                 "point-to-point, one xGMI link per peer)" % nchunks}
         if copy_gbps is not None:
             # the box's own device-to-device copy rate next to the 8 TB/s datasheet peak
             res["roofline"]["measured_copy_GBps"] = round(copy_gbps, 1)
@@ -338,7 +400,7 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def validate_dump(torch, la, args, mode, outs_of, cb, cnt_out, ns, gathered, world, per, n_total, bufs):
+def validate_dump(torch, la, args, mode, outs_of, cb, cnt_out, ns, gathered, world, per, n_total, bufs, nchunks):
     """the timed launches' own outputs: (1) bit-equal to the counted launch on the sample, (2) hits and
     sum(t) of the first 1 M / 2 M rays against the reference's check values for the canonical dump,
     (3) N > 1: the gathered records on rank 0 == the ranks' slices (own slice checked bit for bit,
@@ -364,7 +426,7 @@ def validate_dump(torch, la, args, mode, outs_of, cb, cnt_out, ns, gathered, wor
         v["timed_equals_counted_launch"] = bool(same); v["ok"] &= bool(same)
     if world > 1:
         ok = True
-        for c in range(len(cb)):
+        for c in range(nchunks):
             ok &= bool(torch.equal(gathered[c][0], bufs[c]))
             if mode == la.MODE_CLOSEST:
                 for r in range(world):
