@@ -40,6 +40,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -304,7 +305,7 @@ static float top_area(const float lo[3], const float hi[3])
  * has m - 1 nodes: it gets the slots out[nb .. nb + m - 2] (root first, then the left subtree's, then the right's), so the
  * layout does not depend on who builds what and the large subtrees near the top are built by threads of their own.  A node's
  * global index = base + slot.  Returns the reference of the subtree's root */
-static int top_build(CutRoot *it, int b, int e, BNode *out, int nb, int base, int par_depth)
+static int top_build(CutRoot *it, int b, int e, BNode *out, int nb, int base, int par_depth, int level = 0)
 {
     if (e - b == 1) return it[b].ref;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -346,7 +347,9 @@ static int top_build(CutRoot *it, int b, int e, BNode *out, int nb, int base, in
         }
     }
     int mid;
-    if (best_axis >= 0) {
+    /* (a distribution that lets the SAH peel a few items per level -- an exponentially spaced line -- would recurse as deep as
+     * it is long: beyond 48 levels the list is simply halved) */
+    if (best_axis >= 0 && level < 48) {
         const int k = best_axis; const float scale = (float)NB / (chi[k] - clo[k]);
         CutRoot *m = std::partition(it + b, it + e, [&](const CutRoot &r) {
             int j = (int)((0.5f * (r.lo[k] + r.hi[k]) - clo[k]) * scale);
@@ -358,13 +361,18 @@ static int top_build(CutRoot *it, int b, int e, BNode *out, int nb, int base, in
     if (mid <= b || mid >= e) mid = b + (e - b) / 2;                 /* equal centroids: split the list */
     const int nl = nb + 1, nr = nb + 1 + (mid - b - 1);              /* first slots of the two subtrees */
     int l, r;
+    bool forked = false;
     if (par_depth > 0 && e - b > 4096) {
-        std::thread th([&]() { l = top_build(it, b, mid, out, nl, base, par_depth - 1); });
-        r = top_build(it, mid, e, out, nr, base, par_depth - 1);
-        th.join();
-    } else {
-        l = top_build(it, b, mid, out, nl, base, 0);
-        r = top_build(it, mid, e, out, nr, base, 0);
+        try {
+            std::thread th([&]() { l = top_build(it, b, mid, out, nl, base, par_depth - 1, level + 1); });
+            forked = true;
+            r = top_build(it, mid, e, out, nr, base, par_depth - 1, level + 1);
+            th.join();
+        } catch (const std::system_error &) { forked = false; }         /* no thread to be had: this one does both halves */
+    }
+    if (!forked) {
+        l = top_build(it, b, mid, out, nl, base, 0, level + 1);
+        r = top_build(it, mid, e, out, nr, base, 0, level + 1);
     }
     BNode &nd = out[nb];
     memset(&nd, 0, sizeof(nd));

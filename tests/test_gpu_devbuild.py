@@ -163,3 +163,27 @@ def test_device_commit_does_not_leak_device_memory():
     free1, _ = torch.cuda.mem_get_info()
     # one commit's temporaries are ~120 B / triangle = 36 MB here: six leaked commits would be > 200 MB
     assert free0 - free1 < 16 << 20, "device memory shrank by %.1f MB over six device commits" % ((free0 - free1) / 1e6)
+
+
+def test_long_skewed_distribution_through_the_sah_top():
+    """150 000 small triangles whose spacing grows geometrically along a line, plus a uniform cloud: the SAH over the radix
+    tree's subtree roots peels a few items per level on such data (its recursion is bounded and falls back to halving), the
+    collapsed tree may need the checked walk or the host builder -- hit records stay the oracle's"""
+    rng = np.random.default_rng(21)
+    n = 150000
+    x = np.cumsum(1e-6 * 1.00008 ** np.arange(n))
+    c = np.stack([x, 1e-3 * rng.standard_normal(n), 1e-3 * rng.standard_normal(n)], 1)
+    c[::7] = rng.uniform(0, x[-1], (len(c[::7]), 3)) * np.array([1, 0.01, 0.01])
+    tri = c[:, None, :] + rng.uniform(-1, 1, (n, 3, 3)) * (2e-6 + 1e-4 * x[:, None, None] / x[-1])
+    P = tri.reshape(-1, 3); idx = np.arange(3 * n, dtype=np.uint32)
+    tgt = tri[rng.integers(0, n, 30000)].mean(axis=1)                            # a point inside a triangle
+    org = tgt + rng.normal(size=(30000, 3)) * np.array([0.05 * x[-1], 0.02, 0.02])
+    dr = tgt - org
+    ok = np.abs(dr[:, 1]) > 1e-14
+    org, dr = np.ascontiguousarray(org[ok]), np.ascontiguousarray(dr[ok])
+    acc, info = dev_accel(P, idx); acc.wait_exact()
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr, nthreads=8)
+    assert (exp[0] != po.MISS).mean() > 0.5
+    assert_hits_equal(acc.intersect_host(org, dr), exp, "skewed line, device-built")
+    acc.close()
