@@ -12,6 +12,7 @@
  *   3. the binary radix tree over the sorted codes (Karras, "Maximizing Parallelism in the Construction of BVHs,
  *      Octrees, and k-d Trees", HPG 2012 -- the published algorithm, not code), ties between equal codes broken by
  *      position;
+ *   3b. binned SAH inside every radix subtree of <= 512 primitives, one wave each, in LDS (k_sah_subtree);
  *   4. node boxes as range queries over block tables of the sorted primitives' boxes (no bottom-up hand-over, no fences), and
  *      in the same kernel the bottom-up SAH decision which subtrees of <= 4 primitives become ONE leaf;
  *   5. binned SAH, on the host, over the roots of the subtrees of <= `cut` primitives (HLBVH: Pantaleoni & Luebke 2010,
@@ -259,6 +260,143 @@ __global__ void k_node_boxes(int n, BNode *__restrict__ nodes, const BoxTable T,
     bool leaf = false; float cost = 0.0f;
     if (nd.last - nd.first + 1u <= (uint32_t)leaf_max) cost = subtree_cost<LH_MAX_LEAF_TRIS - 1>(nodes, T, i, leaf_max, &leaf);
     nd.cost = cost; nd.leaf = leaf ? 1 : 0;
+}
+
+/* ---- binned SAH inside the subtrees (the bottom of the HLBVH) -----------------------------------------------------
+ * The radix tree's subtrees of up to LH_SUB_MAX primitives are spatially compact, but inside them the cuts still fall where the
+ * Morton code says.  Each is rebuilt top-down by ONE wave with the binned SAH (16 bins, three axes) in LDS: the wave permutes
+ * the subtree's stretch of the sorted order and writes its nodes over the radix nodes of that stretch.  (A radix subtree over
+ * the sorted positions a .. b is rooted at inner node a or b and owns, besides its root, exactly the inner nodes a + 1 .. b - 1;
+ * the root keeps its index, so everything above still points at it.)  Boxes and leaf decisions come afterwards, from the same
+ * range queries as for every other node. */
+#define LH_SUB_MAX 512
+
+__global__ void k_sub_roots(int n, const BNode *__restrict__ nodes, uint32_t sub_max, uint32_t *__restrict__ out, uint32_t *__restrict__ nout)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const uint32_t size = nodes[i].last - nodes[i].first + 1u;
+    if (size > sub_max || size < 3u) return;
+    const int p = nodes[i].parent;
+    if (p >= 0 && nodes[p].last - nodes[p].first + 1u <= sub_max) return;        /* inside a subtree */
+    out[atomicAdd(nout, 1u)] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(64) void k_sah_subtree(uint32_t nroots, const uint32_t *__restrict__ roots, BNode *__restrict__ nodes,
+                                                    uint32_t *__restrict__ sorted, const float *__restrict__ plo, const float *__restrict__ phi)
+{
+    __shared__ uint32_t pid[LH_SUB_MAX];                 /* primitive id of local item k (its position when the wave started) */
+    __shared__ float blo[LH_SUB_MAX][3], bhi[LH_SUB_MAX][3];
+    __shared__ uint16_t perm[LH_SUB_MAX], tmp[LH_SUB_MAX];       /* the order being built, as local items */
+    __shared__ uint32_t bcnt[3][16], bmin[3][16][3], bmax[3][16][3];
+    __shared__ uint32_t stk_rng[LH_SUB_MAX], stk_node[LH_SUB_MAX];   /* ranges still to split: lo | hi << 16, and their node */
+    if (blockIdx.x >= nroots) return;
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t r = roots[blockIdx.x];
+    const uint32_t a = nodes[r].first, b = nodes[r].last, m = b - a + 1u;
+    for (uint32_t k = lane; k < m; k += 64) {
+        const uint32_t p = sorted[a + k];
+        pid[k] = p; perm[k] = (uint16_t)k;
+        for (int c = 0; c < 3; c++) { blo[k][c] = plo[3 * (size_t)p + c]; bhi[k][c] = phi[3 * (size_t)p + c]; }
+    }
+    if (lane == 0) { stk_rng[0] = 0u | (m << 16); stk_node[0] = r; }
+    uint32_t used = 0;                                   /* nodes handed out besides the root: a + 1, a + 2, ... */
+    int sp = 1;
+    __syncthreads();
+    while (sp > 0) {
+        sp--;
+        const uint32_t lo = stk_rng[sp] & 0xFFFFu, hi = stk_rng[sp] >> 16, node = stk_node[sp], cnt = hi - lo;
+        /* ranges of up to four items (three quarters of all splits) are halved as they stand: they mostly end up as ONE leaf anyway */
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY}, scale[3] = {0.0f, 0.0f, 0.0f};
+        int best = 0; float bc = INFINITY; uint32_t nleft = 0;
+        if (cnt > 4u) {
+        /* centroid bounds of the range */
+        for (uint32_t k = lo + lane; k < hi; k += 64) {
+            const uint32_t e = perm[k];
+            for (int c = 0; c < 3; c++) { const float cc = 0.5f * (blo[e][c] + bhi[e][c]); clo[c] = fminf(clo[c], cc); chi[c] = fmaxf(chi[c], cc); }
+        }
+        for (int c = 0; c < 3; c++)
+            for (int off = 32; off >= 1; off >>= 1) { clo[c] = fminf(clo[c], __shfl_xor(clo[c], off)); chi[c] = fmaxf(chi[c], __shfl_xor(chi[c], off)); }
+        if (lane < 48) {
+            bcnt[lane / 16][lane % 16] = 0u;
+            for (int c = 0; c < 3; c++) { bmin[lane / 16][lane % 16][c] = 0xffffffffu; bmax[lane / 16][lane % 16][c] = 0u; }
+        }
+        __syncthreads();
+        for (int c = 0; c < 3; c++) scale[c] = chi[c] > clo[c] ? 16.0f / (chi[c] - clo[c]) : 0.0f;
+        for (uint32_t k = lo + lane; k < hi; k += 64) {
+            const uint32_t e = perm[k];
+            for (int ax = 0; ax < 3; ax++) {
+                int j = (int)((0.5f * (blo[e][ax] + bhi[e][ax]) - clo[ax]) * scale[ax]);
+                j = j < 0 ? 0 : (j > 15 ? 15 : j);
+                atomicAdd(&bcnt[ax][j], 1u);
+                for (int c = 0; c < 3; c++) { atomicMin(&bmin[ax][j][c], f2o(blo[e][c])); atomicMax(&bmax[ax][j][c], f2o(bhi[e][c])); }
+            }
+        }
+        __syncthreads();
+        /* lane 15 ax + j: the split "bins 0 .. j | j + 1 .. 15" along ax */
+        float cost = INFINITY;
+        if (lane < 45) {
+            const int ax = lane / 15, j = lane % 15;
+            if (scale[ax] > 0.0f) {
+                float ll[3] = {INFINITY, INFINITY, INFINITY}, lh[3] = {-INFINITY, -INFINITY, -INFINITY}, rl[3] = {INFINITY, INFINITY, INFINITY}, rh[3] = {-INFINITY, -INFINITY, -INFINITY};
+                uint32_t nl = 0, nr = 0;
+                for (int q = 0; q < 16; q++) {
+                    const uint32_t cq = bcnt[ax][q];
+                    if (!cq) continue;
+                    if (q <= j) { nl += cq; for (int c = 0; c < 3; c++) { ll[c] = fminf(ll[c], o2f(bmin[ax][q][c])); lh[c] = fmaxf(lh[c], o2f(bmax[ax][q][c])); } }
+                    else { nr += cq; for (int c = 0; c < 3; c++) { rl[c] = fminf(rl[c], o2f(bmin[ax][q][c])); rh[c] = fmaxf(rh[c], o2f(bmax[ax][q][c])); } }
+                }
+                if (nl && nr) { cost = half_area(ll, lh) * (float)nl + half_area(rl, rh) * (float)nr; nleft = nl; }
+            }
+        }
+        best = lane; bc = cost;                           /* the cheapest split (ties: the lower lane) */
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float oc = __shfl_xor(bc, off); const int ob = __shfl_xor(best, off);
+            if (oc < bc || (oc == bc && ob < best)) { bc = oc; best = ob; }
+        }
+        }
+        uint32_t nl = (uint32_t)__shfl((int)nleft, best);
+        const int ax = best / 15, j = best % 15;
+        const bool sah = bc < INFINITY;
+        if (!sah) nl = cnt / 2;                          /* equal centroids: halve the list as it stands */
+        /* stable partition of perm[lo .. hi) into tmp, 64 items a round */
+        uint32_t lbase = lo, rbase = lo + nl;
+        for (uint32_t k0 = lo; k0 < hi; k0 += 64) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            const bool in = k < hi; bool left = false; uint32_t e = 0;
+            if (in) {
+                e = perm[k];
+                if (sah) {
+                    int q = (int)((0.5f * (blo[e][ax] + bhi[e][ax]) - clo[ax]) * scale[ax]);
+                    q = q < 0 ? 0 : (q > 15 ? 15 : q);
+                    left = q <= j;
+                } else left = (k - lo) < nl;
+            }
+            const unsigned long long ml = __ballot(in && left), mr = __ballot(in && !left);
+            if (in) tmp[left ? lbase + (uint32_t)__popcll(ml & lt) : rbase + (uint32_t)__popcll(mr & lt)] = (uint16_t)e;
+            lbase += (uint32_t)__popcll(ml); rbase += (uint32_t)__popcll(mr);
+        }
+        __syncthreads();
+        for (uint32_t k = lo + lane; k < hi; k += 64) perm[k] = tmp[k];
+        /* children: a single item is a leaf reference, a longer range gets a node and waits on the stack */
+        const uint32_t mid = lo + nl;
+        const bool push_l = mid - lo > 1u, push_r = hi - mid > 1u;
+        uint32_t slot_l = 0, slot_r = 0;
+        if (push_l) { slot_l = a + 1u + used; used++; }
+        if (push_r) { slot_r = a + 1u + used; used++; }
+        if (lane == 0) {
+            BNode &nd = nodes[node];
+            nd.first = a + lo; nd.last = a + hi - 1u;
+            nd.left = push_l ? (int)slot_l : ~(int)(a + lo);
+            nd.right = push_r ? (int)slot_r : ~(int)(a + mid);
+            if (push_l) { nodes[slot_l].parent = (int)node; stk_rng[sp] = lo | (mid << 16); stk_node[sp] = slot_l; }
+            if (push_r) { nodes[slot_r].parent = (int)node; stk_rng[sp + (push_l ? 1 : 0)] = mid | (hi << 16); stk_node[sp + (push_l ? 1 : 0)] = slot_r; }
+        }
+        sp += (push_l ? 1 : 0) + (push_r ? 1 : 0);
+        __syncthreads();
+    }
+    for (uint32_t k = lane; k < m; k += 64) sorted[a + k] = pid[perm[k]];
 }
 
 /* ---- SAH over the top of the tree (HLBVH) ----------------------------------------------------------------------
@@ -596,6 +734,16 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
             BCHK(hipMalloc((void **)&leaf_parent, sizeof(int) * (size_t)n));
             hipLaunchKernelGGL(k_radix_tree, dim3((n - 1 + 255) / 256), dim3(256), 0, s, (int)n, key, nodes, leaf_parent);
             mark("radix tree");
+            if (n > LH_SUB_MAX && !(getenv("LH_DEVICE_SUBSAH") && atoi(getenv("LH_DEVICE_SUBSAH")) == 0)) {
+                /* the roots of the subtrees of <= LH_SUB_MAX primitives (into val_in: free since the sort), then a wave per subtree */
+                uint32_t h_nsub = 0;
+                BCHK(hipMemsetAsync(bad, 0, sizeof(int), s));
+                hipLaunchKernelGGL(k_sub_roots, dim3((n - 1 + 255) / 256), dim3(256), 0, s, (int)n, (const BNode *)nodes, (uint32_t)LH_SUB_MAX, val_in, (uint32_t *)bad);
+                BCHK(hipMemcpyAsync(&h_nsub, bad, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                BCHK(hipStreamSynchronize(s));
+                if (h_nsub) hipLaunchKernelGGL(k_sah_subtree, dim3(h_nsub), dim3(64), 0, s, h_nsub, (const uint32_t *)val_in, nodes, sorted, (const float *)plo, (const float *)phi);
+                mark("binned SAH inside the subtrees");
+            }
             BoxTable T;
             {
                 /* boxes of the sorted primitives and of their blocks of 64 / 4096 / 262144, all in one allocation */
