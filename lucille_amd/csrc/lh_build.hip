@@ -599,6 +599,78 @@ __global__ void k_collapse_level(uint32_t nwork, const uint2 *__restrict__ work_
     q4[k4] = out;
 }
 
+/* one level of the 8-wide collapse (lh_q8node_t: one 128-byte record = one cache line, for ray dumps over scenes that do not
+ * fit the Infinity Cache): as k_collapse_level, opening the larger-area inner child until there are eight; children go to octant
+ * slots -- the walk visits slot s with priority s ^ (ray octant), so a child takes the free slot whose diagonal its centroid
+ * offset points along most (the host builder's rule, lh_bvh.c build8q) */
+__global__ void k_collapse8_level(uint32_t nwork, const uint2 *__restrict__ work_in, uint2 *__restrict__ work_out,
+                                  uint32_t *__restrict__ counters, const BNode *__restrict__ nodes, const uint32_t *__restrict__ sorted,
+                                  const float *__restrict__ plo, const float *__restrict__ phi, const float3 glo, const float3 gstep,
+                                  lh_q8node_t *__restrict__ q8, int leaf_max)
+{
+    const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= nwork) return;
+    const int b = (int)work_in[wi].x; const uint32_t k8 = work_in[wi].y;
+    Child ch[8]; int n = 2;
+    child_of(nodes, sorted, plo, phi, nodes[b].left, ch[0], leaf_max);
+    child_of(nodes, sorted, plo, phi, nodes[b].right, ch[1], leaf_max);
+    while (n < 8) {
+        int best = -1; float ba = -1.0f;
+        for (int c = 0; c < n; c++)
+            if (ch[c].node >= 0) {
+                const float dx = ch[c].hi[0] - ch[c].lo[0], dy = ch[c].hi[1] - ch[c].lo[1], dz = ch[c].hi[2] - ch[c].lo[2];
+                const float a = dx * dy + dy * dz + dz * dx;
+                if (a > ba) { ba = a; best = c; }
+            }
+        if (best < 0) break;
+        const int g = ch[best].node;
+        child_of(nodes, sorted, plo, phi, nodes[g].left, ch[best], leaf_max);
+        child_of(nodes, sorted, plo, phi, nodes[g].right, ch[n], leaf_max);
+        n++;
+    }
+    double cen[3];
+    for (int k = 0; k < 3; k++) {
+        float lo = ch[0].lo[k], hi = ch[0].hi[k];
+        for (int c = 1; c < n; c++) { lo = fminf(lo, ch[c].lo[k]); hi = fmaxf(hi, ch[c].hi[k]); }
+        cen[k] = 0.5 * ((double)lo + (double)hi);
+    }
+    int slot_of[8]; bool used[8];
+    for (int c = 0; c < 8; c++) { slot_of[c] = -1; used[c] = false; }
+    for (int k = 0; k < n; k++) {
+        int bc = -1, bs = -1; double bv = -1.0e300;
+        for (int c = 0; c < n; c++) {
+            if (slot_of[c] >= 0) continue;
+            double d[3];
+            for (int a = 0; a < 3; a++) d[a] = 0.5 * ((double)ch[c].lo[a] + (double)ch[c].hi[a]) - cen[a];
+            for (int sl = 0; sl < 8; sl++) {
+                if (used[sl]) continue;
+                const double v = ((sl & 1) ? d[0] : -d[0]) + ((sl & 2) ? d[1] : -d[1]) + ((sl & 4) ? d[2] : -d[2]);
+                if (v > bv) { bv = v; bc = c; bs = sl; }
+            }
+        }
+        slot_of[bc] = bs; used[bs] = true;
+    }
+    int ninner = 0;
+    for (int c = 0; c < n; c++) ninner += ch[c].node >= 0;
+    uint32_t base8 = 0, basew = 0;
+    if (ninner) { base8 = atomicAdd(&counters[0], (uint32_t)ninner); basew = atomicAdd(&counters[1], (uint32_t)ninner); }
+    lh_q8node_t out;
+    const double g[3] = {glo.x, glo.y, glo.z}, st[3] = {gstep.x, gstep.y, gstep.z};
+    for (int sl = 0; sl < 8; sl++) { for (int k = 0; k < 3; k++) out.w[sl][k] = 65535u; out.ref[sl] = LH_REF_EMPTY; }
+    int slot = 0;
+    for (int sl = 0; sl < 8; sl++)                        /* inner children adjacent, in slot order */
+        for (int c = 0; c < n; c++) {
+            if (slot_of[c] != sl) continue;
+            for (int k = 0; k < 3; k++) quant_axis(g[k], st[k], ch[c].lo[k], ch[c].hi[k], out.w[sl][k]);
+            if (ch[c].node >= 0) {
+                out.ref[sl] = (int32_t)(base8 + (uint32_t)slot);
+                work_out[basew + (uint32_t)slot] = make_uint2((uint32_t)ch[c].node, base8 + (uint32_t)slot);
+                slot++;
+            } else out.ref[sl] = ~(int32_t)((ch[c].first << 2) | (ch[c].count - 1u));
+        }
+    q8[k8] = out;
+}
+
 /* ---- how many LDS stack rows the walk really needs ------------------------------------------------------------------
  * A step at node X leaves at most (children of X) - 1 entries on the stack, so a ray that is about to step at X holds at most
  * the sum of that over X's ancestors.  The walk sizes its stack for the largest such sum (+ 5: sentinel and the step's own
@@ -657,6 +729,7 @@ static inline void dfree(void *p) { if (p) (void)hipFree(p); }
  * *nq4 used) and *d_tri32 (ntris + 2 records) are hipMalloc'ed here and owned by the caller; bmin / bmax / grid as lh_bvh_t.
  * Returns 0, -1 (err filled), or -2 for a NaN / infinite / > 1e30 coordinate. */
 extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q4nodes, uint32_t *nq4, uint32_t *q4_depth, uint32_t *q4_stack,
+                               int want_q8, void **d_q8nodes, uint32_t *nq8, uint32_t *q8_depth,
                                void **d_tri32, float bmin[3], float bmax[3], float grid_lo[3], float grid_step[3],
                                void *stream, char *err, size_t errlen)
 {
@@ -664,7 +737,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     const uint32_t n = ntris;
     float *plo = NULL, *phi = NULL; uint32_t *scene = NULL, *val_in = NULL, *sorted = NULL, *counters = NULL, *ncut = NULL; float *boxes = NULL; CutRoot *cuts = NULL;
     uint64_t *key_in = NULL, *key = NULL; int *leaf_parent = NULL, *bad = NULL; BNode *nodes = NULL; void *tmp = NULL; size_t tmp_bytes = 0;
-    uint2 *work[2] = {NULL, NULL}; lh_q4node_t *q4 = NULL; lh_tri32_t *t32 = NULL; uint32_t *lay = NULL, need_rows = 0; std::vector<uint32_t> lvl_begin;
+    uint2 *work[2] = {NULL, NULL}; lh_q4node_t *q4 = NULL; lh_q8node_t *q8 = NULL; lh_tri32_t *t32 = NULL; uint32_t *lay = NULL, need_rows = 0; std::vector<uint32_t> lvl_begin;
     const unsigned nb = (n + 255) / 256;
     uint32_t h_scene[6], h_cnt[2], level = 0, nwork = 0, nq = 1;
     const uint32_t init_scene[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
@@ -676,7 +749,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     { const char *e = getenv("LH_DEVICE_CUT"); if (e && atoi(e) >= 0) cut = (uint32_t)atoi(e); }
     const uint32_t cut_cap = cut ? (uint32_t)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(65536u, 16ull * n / cut)) : 0u;
     int root_ref = 0;
-    *d_q4nodes = NULL; *d_tri32 = NULL; *nq4 = 0; *q4_depth = 0; *q4_stack = 0;
+    *d_q4nodes = NULL; *d_tri32 = NULL; *nq4 = 0; *q4_depth = 0; *q4_stack = 0; *d_q8nodes = NULL; *nq8 = 0; *q8_depth = 0;
     if (n == 0) return 0;
     /* LH_BUILD_TIMING=1: phase times on stderr (each mark synchronises the stream: diagnostics only) */
     const bool timing = getenv("LH_BUILD_TIMING") != NULL;
@@ -822,13 +895,34 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                 }
                 if (need_rows + 5u <= LH_ROWS_UNCHECKED || cut == 0 || attempt == 2 || n <= 4 * cc) break;
             }
+            if (want_q8 && nq > 1) {
+                /* the same binary tree once more as 8-wide nodes (never more of them than 4-wide ones) */
+                uint32_t nw8 = 1, n8 = 1, lev8 = 0;
+                BCHK(hipMalloc((void **)&q8, sizeof(lh_q8node_t) * (size_t)nq));
+                {
+                    const uint2 root = make_uint2((uint32_t)root_ref, 0u);
+                    BCHK(hipMemcpyAsync(work[0], &root, sizeof(root), hipMemcpyHostToDevice, s));
+                }
+                while (nw8 > 0) {
+                    h_cnt[0] = n8; h_cnt[1] = 0;
+                    BCHK(hipMemcpyAsync(counters, h_cnt, sizeof(h_cnt), hipMemcpyHostToDevice, s));
+                    hipLaunchKernelGGL(k_collapse8_level, dim3((nw8 + 127) / 128), dim3(128), 0, s, nw8, (const uint2 *)work[lev8 & 1], work[(lev8 + 1) & 1],
+                                       counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q8, leaf_max);
+                    BCHK(hipMemcpyAsync(h_cnt, counters, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
+                    BCHK(hipStreamSynchronize(s));
+                    n8 = h_cnt[0]; nw8 = h_cnt[1]; lev8++;
+                    if (lev8 > 200 || n8 > nq) { snprintf(err, errlen, "device build: runaway 8-wide collapse"); goto fail; }
+                }
+                *nq8 = n8; *q8_depth = lev8;
+                mark("collapse to 8-wide nodes");
+            }
         }
     }
     hipLaunchKernelGGL(k_tri32, dim3(nb), dim3(256), 0, s, n, (const uint32_t *)sorted, d_tri64, t32);
     BCHK(hipGetLastError());
     BCHK(hipStreamSynchronize(s));
     mark("tri32 records");
-    *d_q4nodes = q4; *d_tri32 = t32; *nq4 = nq; *q4_depth = level; *q4_stack = nq > 1 ? need_rows + 5u : 0u;     /* LDS stack rows the walk needs (0: unknown, 3 x depth + 5) */
+    *d_q4nodes = q4; *d_q8nodes = q8; *d_tri32 = t32; *nq4 = nq; *q4_depth = level; *q4_stack = nq > 1 ? need_rows + 5u : 0u;     /* LDS stack rows the walk needs (0: unknown, 3 x depth + 5) */
     dfree(plo); dfree(phi); dfree(scene); dfree(bad); dfree(key_in); dfree(key); dfree(val_in); dfree(sorted);
     dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters);
     mark("free temporaries");
@@ -836,6 +930,6 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
 fail:
     dfree(plo); dfree(phi); dfree(scene); dfree(bad); dfree(key_in); dfree(key); dfree(val_in); dfree(sorted);
     dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters);
-    dfree(q4); dfree(t32);
+    dfree(q4); dfree(q8); dfree(t32);
     return -1;
 }

@@ -365,6 +365,7 @@ static int host_build(lh_accel_t *a, int build_threads, bool on_device, bool kee
 }
 
 extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q4nodes, uint32_t *nq4, uint32_t *q4_depth, uint32_t *q4_stack,
+                               int want_q8, void **d_q8nodes, uint32_t *nq8, uint32_t *q8_depth,
                                void **d_tri32, float bmin[3], float bmax[3], float grid_lo[3], float grid_step[3],
                                void *stream, char *err, size_t errlen);                /* lh_build.hip */
 
@@ -508,9 +509,12 @@ static int device_upload(lh_accel_t *a)
         if (hs->device_built) {
             /* the traversal tree is built here, on this device (lh_build.hip): LBVH -> the same 4-wide nodes */
             char berr[256] = "";
-            uint32_t nq4 = 0, d4 = 0, st4 = 0; float bmin[3], bmax[3], glo[3], gst[3];
+            uint32_t nq4 = 0, d4 = 0, st4 = 0, nq8 = 0, d8 = 0; float bmin[3], bmax[3], glo[3], gst[3];
+            /* a scene whose ray dumps will want the 8-wide nodes (hot set beyond the Infinity Cache, or "wide8" = 1) gets them now:
+             * the binary tree they are collapsed from does not outlive the build */
+            const int want_q8 = a->wide8 == 1 || (a->wide8 == -1 && (size_t)hs->bvh.ntris * (sizeof(lh_tri32_t) + 20) > ((size_t)256 << 20));
             const double tb = now_s();
-            const int rcb = lh_device_build(hs->bvh.ntris, (const double *)a->d_tri64, &a->d_q4nodes, &nq4, &d4, &st4, &a->d_tri32, bmin, bmax, glo, gst,
+            const int rcb = lh_device_build(hs->bvh.ntris, (const double *)a->d_tri64, &a->d_q4nodes, &nq4, &d4, &st4, want_q8, &a->d_q8nodes, &nq8, &d8, &a->d_tri32, bmin, bmax, glo, gst,
                                             (void *)a->stream, berr, sizeof(berr));
             if (rcb == -2) return fail("lh_accel_commit: a vertex coordinate is NaN, infinite or beyond 1e30");
             if (rcb != 0) return fail("device BVH build failed: %s", berr);
@@ -520,6 +524,7 @@ static int device_upload(lh_accel_t *a)
             pthread_mutex_unlock(&g_scene_mu);
             a->dev.q4nodes = a->d_q4nodes;
             a->device_bytes += sizeof(lh_q4node_t) * (size_t)nq4;
+            if (a->d_q8nodes) { a->dev.q8nodes = a->d_q8nodes; a->dev.nq8nodes = nq8; a->dev.q8_depth = d8; a->device_bytes += sizeof(lh_q8node_t) * (size_t)nq8; }
             if (3 * d4 + 5 > 264) return -3;          /* deeper than k_overflow_fix's private stack: the caller falls back to the host builder */
         } else {
             HIPCHK(hipMalloc(&a->d_tri32, t32 + 64));   /* the unified walk reads 16 B past a record */

@@ -187,3 +187,26 @@ def test_long_skewed_distribution_through_the_sah_top():
     assert (exp[0] != po.MISS).mean() > 0.5
     assert_hits_equal(acc.intersect_host(org, dr), exp, "skewed line, device-built")
     acc.close()
+
+
+@pytest.mark.parametrize("ntri,he,seed", [(1, 0.2, 1), (2, 0.2, 8), (9, 0.2, 2), (37, 0.1, 5), (3000, 0.05, 6), (200000, 0.008, 7)])
+def test_device_built_eight_wide_nodes(ntri, he, seed):
+    """set_param("wide8", 1) before a device commit: the builder also collapses its binary tree to the 8-wide one-cache-line
+    nodes (k_collapse8_level) and ray dumps walk those -- same records, bit for bit, and the dump record size says which
+    nodes were walked"""
+    P, idx, org, dr = po.soup(ntri, 60000, he, 2000 + seed)
+    acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.set_param("wide8", 1)
+    acc.commit(on_device=True)
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr, nthreads=8)
+    assert_hits_equal(acc.intersect_host(org, dr), exp, "device-built 8-wide %d (no wait)" % ntri)
+    acc.wait_exact()
+    assert_hits_equal(acc.intersect_host(org, dr), exp, "device-built 8-wide %d" % ntri)
+    assert np.array_equal(acc.intersect_host(org, dr, mode=la.MODE_ANY).astype(bool), exp[0] != po.MISS)
+    if ntri > 16:
+        assert acc.dump_node_bytes() == 128
+    # the same scene without the knob stays on the 4-wide nodes
+    ref = la.HipAccel(0); ref.add_mesh(P, idx); ref.set_param("wide8", 0); ref.commit(on_device=True)
+    assert ref.dump_node_bytes() == 64
+    assert_hits_equal(ref.intersect_host(org, dr), exp, "device-built 4-wide %d" % ntri)
+    acc.close(); ref.close()

@@ -1,4 +1,4 @@
-"""host vs device build of the traversal tree, and what the device-built tree costs in traversal: python tools/build_probe.py"""
+"""host vs device build of the traversal tree, and what the device-built tree costs in traversal: python tools/build_probe.py [--soups-only]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,6 +23,8 @@ for name, nt, he, nr in (("S-soup-1M", 1000000, 0.005, 30000000), ("S-soup-10M",
               % (name, "DEVICE" if on_dev else "host  ", tc, info["build_seconds"], info["ref_build_seconds"], " in the background" if on_dev else "",
                  info["nnodes_traversal"], info["max_depth"], rate(acc, o, d, 0), rate(acc, o, d, 1), cnt["nodes"] / 2e6, cnt["tris"] / 2e6), flush=True)
         acc.close()
+if "--soups-only" in sys.argv:
+    sys.exit(0)
 g = np.load(os.path.join(ROOT, "tests", "golden", "ao_c1.npz"))
 c = g["camera"]; cam = la.Camera.make(4096, 4096, c[16], c[:16], int(c[19]))
 for on_dev in (False, True):
