@@ -6,7 +6,7 @@
  * BASELINE config 5 scene.  Hit records do not depend on the tree (any conservative BVH + the bit-exact
  * fp64 triangle test reproduces the reference), so the traversal tree may be built by whatever is fastest:
  *
- *   1. per-primitive fp32-outward boxes from the fp64 triangles; scene box (one atomic per wave and component);
+ *   1. per-primitive fp32-outward boxes from the fp64 triangles; scene box (six atomics per workgroup);
  *   2. 63-bit Morton codes of the centroids (one scale for the three axes: cubic cells), radix-sorted with the primitive
  *      ids (hipcub);
  *   3. the binary radix tree over the sorted codes (Karras, "Maximizing Parallelism in the Construction of BVHs,
@@ -20,6 +20,7 @@
  *   6. the same 64-byte 4-wide 16-bit-grid nodes the host builder emits (lh_q4node_t), collapsed level by level -- a 4-wide
  *      node takes its binary node's two children and opens the one with the largest area until it has four -- children of
  *      one node allocated adjacently; boxes quantised outward on the scene grid exactly as lh_bvh.c does (lo down, hi up);
+ *   6b. for scenes whose ray dumps want them (lh_commit.hip), the same binary tree also as 128-byte 8-wide nodes (lh_q8node_t);
  *   7. the LDS stack rows the walk needs on this tree, from its deepest path (instead of the 3 x depth + 5 of any tree);
  *   8. the 48-byte triangle records (lh_tri32_t) in sorted = leaf order.
  *
@@ -55,7 +56,7 @@ struct BNode {              /* inner node of the binary radix tree */
     int parent;
     uint32_t first, last;   /* range of sorted positions it covers */
     float lo[3], hi[3];
-    float cost;             /* SAH cost of the cheapest way to finish this subtree (k_refit) */
+    float cost;             /* SAH cost of the cheapest way to finish this subtree (k_node_boxes) */
     int leaf;               /* 1: cheapest as ONE leaf of its <= 4 primitives */
 };
 
@@ -532,7 +533,7 @@ __device__ __forceinline__ void child_of(const BNode *__restrict__ nodes, const 
         const BNode &b = nodes[ref];
         for (int k = 0; k < 3; k++) { c.lo[k] = b.lo[k]; c.hi[k] = b.hi[k]; }
         c.first = b.first; c.count = b.last - b.first + 1;
-        c.node = b.leaf ? -1 : ref;            /* k_refit's SAH decision: one leaf of its <= leaf_max primitives, or an inner node */
+        c.node = b.leaf ? -1 : ref;            /* k_node_boxes' SAH decision: one leaf of its <= leaf_max primitives, or an inner node */
         (void)leaf_max;
     }
 }
@@ -628,6 +629,16 @@ __global__ void k_collapse8_level(uint32_t nwork, const uint2 *__restrict__ work
         child_of(nodes, sorted, plo, phi, nodes[g].right, ch[n], leaf_max);
         n++;
     }
+    int ninner = 0;
+    for (int c = 0; c < n; c++) ninner += ch[c].node >= 0;
+    uint32_t base8 = 0, basew = 0;
+    if (ninner) { base8 = atomicAdd(&counters[0], (uint32_t)ninner); basew = atomicAdd(&counters[1], (uint32_t)ninner); }
+    if (!q8) {                                            /* counting pass: only the work list of the next level */
+        int slot = 0;
+        for (int c = 0; c < n; c++)
+            if (ch[c].node >= 0) { work_out[basew + (uint32_t)slot] = make_uint2((uint32_t)ch[c].node, base8 + (uint32_t)slot); slot++; }
+        return;
+    }
     double cen[3];
     for (int k = 0; k < 3; k++) {
         float lo = ch[0].lo[k], hi = ch[0].hi[k];
@@ -650,10 +661,6 @@ __global__ void k_collapse8_level(uint32_t nwork, const uint2 *__restrict__ work
         }
         slot_of[bc] = bs; used[bs] = true;
     }
-    int ninner = 0;
-    for (int c = 0; c < n; c++) ninner += ch[c].node >= 0;
-    uint32_t base8 = 0, basew = 0;
-    if (ninner) { base8 = atomicAdd(&counters[0], (uint32_t)ninner); basew = atomicAdd(&counters[1], (uint32_t)ninner); }
     lh_q8node_t out;
     const double g[3] = {glo.x, glo.y, glo.z}, st[3] = {gstep.x, gstep.y, gstep.z};
     for (int sl = 0; sl < 8; sl++) { for (int k = 0; k < 3; k++) out.w[sl][k] = 65535u; out.ref[sl] = LH_REF_EMPTY; }
@@ -726,7 +733,8 @@ static inline void dfree(void *p) { if (p) (void)hipFree(p); }
 } /* namespace */
 
 /* d_tri64: ntris x 9 doubles (primitive-id order) on the current device.  On success *d_q4nodes (capacity ntris records,
- * *nq4 used) and *d_tri32 (ntris + 2 records) are hipMalloc'ed here and owned by the caller; bmin / bmax / grid as lh_bvh_t.
+ * *nq4 used), *d_tri32 (ntris + 2 records) and -- if want_q8 and the tree has more than one node -- *d_q8nodes (*nq8 records)
+ * are hipMalloc'ed here and owned by the caller; bmin / bmax / grid as lh_bvh_t.
  * Returns 0, -1 (err filled), or -2 for a NaN / infinite / > 1e30 coordinate. */
 extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q4nodes, uint32_t *nq4, uint32_t *q4_depth, uint32_t *q4_stack,
                                int want_q8, void **d_q8nodes, uint32_t *nq8, uint32_t *q8_depth,
@@ -741,7 +749,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     const unsigned nb = (n + 255) / 256;
     uint32_t h_scene[6], h_cnt[2], level = 0, nwork = 0, nq = 1;
     const uint32_t init_scene[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    int h_bad = 0, leaf_max = LH_MAX_LEAF_TRIS;     /* leaves of up to 4 triangles WHERE THE SAH SAYS SO (k_refit): forced 4-triangle leaves cost S-soup-1M 37 % (tools/leaf_probe.py), the SAH keeps that soup at one per leaf */
+    int h_bad = 0, leaf_max = LH_MAX_LEAF_TRIS;     /* leaves of up to 4 triangles WHERE THE SAH SAYS SO (k_node_boxes): forced 4-triangle leaves cost S-soup-1M 37 % (tools/leaf_probe.py), the SAH keeps that soup at one per leaf */
     { const char *e = getenv("LH_DEVICE_LEAF"); if (e && atoi(e) >= 1 && atoi(e) <= LH_MAX_LEAF_TRIS) leaf_max = atoi(e); }
     uint32_t cut = 512;                             /* primitives per subtree below the SAH-built top (LH_DEVICE_CUT; 0: plain radix tree).  config 5, frame /
                                                        tree time: 64 -> 86.9 ms / 0.125 s, 128 -> 87.3 / 0.058, 512 -> 87.6 / 0.029, 2048 -> 87.8 / 0.023; 256 makes
@@ -896,23 +904,29 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                 if (need_rows + 5u <= LH_ROWS_UNCHECKED || cut == 0 || attempt == 2 || n <= 4 * cc) break;
             }
             if (want_q8 && nq > 1) {
-                /* the same binary tree once more as 8-wide nodes (never more of them than 4-wide ones) */
-                uint32_t nw8 = 1, n8 = 1, lev8 = 0;
-                BCHK(hipMalloc((void **)&q8, sizeof(lh_q8node_t) * (size_t)nq));
-                {
-                    const uint2 root = make_uint2((uint32_t)root_ref, 0u);
-                    BCHK(hipMemcpyAsync(work[0], &root, sizeof(root), hipMemcpyHostToDevice, s));
+                /* the same binary tree once more as 8-wide nodes.  How many there will be is not bounded by the 4-wide count (a
+                 * node that opens eight small subtrees leaves eight nodes where the 4-wide collapse leaves four): the first
+                 * pass only counts, the second writes into an allocation of exactly that size */
+                uint32_t nw8 = 0, n8 = 0, lev8 = 0, n8_counted = 0;
+                for (int pass = 0; pass < 2; pass++) {
+                    if (pass == 1) { n8_counted = n8; BCHK(hipMalloc((void **)&q8, sizeof(lh_q8node_t) * (size_t)n8_counted)); }
+                    {
+                        const uint2 root = make_uint2((uint32_t)root_ref, 0u);
+                        BCHK(hipMemcpyAsync(work[0], &root, sizeof(root), hipMemcpyHostToDevice, s));
+                    }
+                    nw8 = 1; n8 = 1; lev8 = 0;
+                    while (nw8 > 0) {
+                        h_cnt[0] = n8; h_cnt[1] = 0;
+                        BCHK(hipMemcpyAsync(counters, h_cnt, sizeof(h_cnt), hipMemcpyHostToDevice, s));
+                        hipLaunchKernelGGL(k_collapse8_level, dim3((nw8 + 127) / 128), dim3(128), 0, s, nw8, (const uint2 *)work[lev8 & 1], work[(lev8 + 1) & 1],
+                                           counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q8, leaf_max);
+                        BCHK(hipMemcpyAsync(h_cnt, counters, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
+                        BCHK(hipStreamSynchronize(s));
+                        n8 = h_cnt[0]; nw8 = h_cnt[1]; lev8++;
+                        if (lev8 > 200 || n8 > n) { snprintf(err, errlen, "device build: runaway 8-wide collapse"); goto fail; }
+                    }
                 }
-                while (nw8 > 0) {
-                    h_cnt[0] = n8; h_cnt[1] = 0;
-                    BCHK(hipMemcpyAsync(counters, h_cnt, sizeof(h_cnt), hipMemcpyHostToDevice, s));
-                    hipLaunchKernelGGL(k_collapse8_level, dim3((nw8 + 127) / 128), dim3(128), 0, s, nw8, (const uint2 *)work[lev8 & 1], work[(lev8 + 1) & 1],
-                                       counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q8, leaf_max);
-                    BCHK(hipMemcpyAsync(h_cnt, counters, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
-                    BCHK(hipStreamSynchronize(s));
-                    n8 = h_cnt[0]; nw8 = h_cnt[1]; lev8++;
-                    if (lev8 > 200 || n8 > nq) { snprintf(err, errlen, "device build: runaway 8-wide collapse"); goto fail; }
-                }
+                if (n8 != n8_counted) { snprintf(err, errlen, "device build: the 8-wide collapse counted %u nodes and wrote %u", n8_counted, n8); goto fail; }
                 *nq8 = n8; *q8_depth = lev8;
                 mark("collapse to 8-wide nodes");
             }

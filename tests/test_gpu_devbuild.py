@@ -210,3 +210,34 @@ def test_device_built_eight_wide_nodes(ntri, he, seed):
     assert ref.dump_node_bytes() == 64
     assert_hits_equal(ref.intersect_host(org, dr), exp, "device-built 4-wide %d" % ntri)
     acc.close(); ref.close()
+
+
+def test_device_built_eight_wide_nodes_can_outnumber_the_four_wide_ones():
+    """eight far-apart pairs of triangles: the 4-wide collapse needs 5 nodes (root -> 4 x [2 pairs]), the 8-wide one 9
+    (root -> 8 pairs), so the 8-wide array cannot be sized by the 4-wide count"""
+    rng = np.random.default_rng(11)
+    tris = []
+    for cx in (0.0, 100.0):
+        for cy in (0.0, 100.0):
+            for cz in (0.0, 100.0):
+                for off in (0.0, 6.0):
+                    c = np.array([cx + off, cy + off, cz + off])
+                    tris.append(c + rng.uniform(-1.0, 1.0, (3, 3)))
+    P = np.ascontiguousarray(np.array(tris).reshape(-1, 3)); idx = np.arange(P.shape[0], dtype=np.uint32)
+    T = P.reshape(-1, 3, 3)
+    pick = rng.integers(0, T.shape[0], 20000)
+    w = rng.dirichlet((1.0, 1.0, 1.0), 20000)
+    tgt = (T[pick] * w[:, :, None]).sum(axis=1)
+    org = tgt + rng.normal(size=tgt.shape) * 150.0
+    dr = np.ascontiguousarray(tgt - org); org = np.ascontiguousarray(org)
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr, nthreads=8)
+    assert (exp[0] != po.MISS).mean() > 0.9
+    for wide8 in (1, 0):
+        acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.set_param("wide8", wide8)
+        info = acc.commit(on_device=True)
+        assert acc.dump_node_bytes() == (128 if wide8 else 64)
+        assert_hits_equal(acc.intersect_host(org, dr), exp, "pairs, wide8=%d" % wide8)
+        if not wide8:
+            assert info["nnodes_traversal"] == 5
+        acc.close()
