@@ -167,17 +167,17 @@ extern "C" int lh_dist_init(lh_dist_t **out, const void *id128, int rank, int wo
     d->rank = rank; d->world = world; d->device = device; d->transport = transport;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { free(d); return DFAIL("lh_dist_init: cannot use device %d", device); }
     if (transport == LH_DIST_RCCL) {
-        if (rccl_load() != 0) { free(d); return -1; }
+        if (rccl_load() != 0) { (void)hipStreamDestroy(d->stream); free(d); return -1; }
         ncclUniqueId id; memcpy(&id, id128, LH_DIST_ID_BYTES);
         ncclResult_t r = g_rccl.CommInitRank(&d->comm, world, id, rank);
-        if (r != ncclSuccess) { free(d); return DFAIL("ncclCommInitRank failed: %s (two ranks on one device? use LH_DIST_SHM)", g_rccl.GetErrorString(r)); }
+        if (r != ncclSuccess) { (void)hipStreamDestroy(d->stream); free(d); return DFAIL("ncclCommInitRank failed: %s (two ranks on one device? use LH_DIST_SHM)", g_rccl.GetErrorString(r)); }
     } else {
         name_from_id(id128, d->shm_name, sizeof(d->shm_name));
         int fd = shm_open(d->shm_name, O_CREAT | O_RDWR, 0600);       /* a fresh segment reads as zeros */
-        if (fd < 0 || ftruncate(fd, 4096) != 0) { if (fd >= 0) close(fd); free(d); return DFAIL("lh_dist (shm): cannot create %s: %s", d->shm_name, strerror(errno)); }
+        if (fd < 0 || ftruncate(fd, 4096) != 0) { if (fd >= 0) close(fd); (void)hipStreamDestroy(d->stream); free(d); return DFAIL("lh_dist (shm): cannot create %s: %s", d->shm_name, strerror(errno)); }
         d->ctl = (shm_ctl *)mmap(NULL, 4096, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0); close(fd);
-        if ((void *)d->ctl == MAP_FAILED) { free(d); return DFAIL("lh_dist (shm): mmap failed"); }
-        if (shm_barrier(d) != 0) { free(d); return -1; }
+        if ((void *)d->ctl == MAP_FAILED) { (void)hipStreamDestroy(d->stream); free(d); return DFAIL("lh_dist (shm): mmap failed"); }
+        if (shm_barrier(d) != 0) { munmap((void *)d->ctl, 4096); (void)hipStreamDestroy(d->stream); free(d); return -1; }
     }
     *out = d;
     return 0;
@@ -284,10 +284,13 @@ extern "C" int lh_dist_gather(lh_dist_t *d, const void *d_send, size_t bytes, vo
     if (bytes == 0) return 0;
     if (d->transport == LH_DIST_RCCL) {
         NCHK(g_rccl.GroupStart());
+        ncclResult_t rc = ncclSuccess;
         if (d->rank == 0) {
-            for (int r = 1; r < d->world; r++) NCHK(g_rccl.Recv((char *)d_recv + (size_t)r * bytes, bytes, ncclUint8, r, d->comm, s));
-        } else NCHK(g_rccl.Send(d_send, bytes, ncclUint8, 0, d->comm, s));
-        NCHK(g_rccl.GroupEnd());
+            for (int r = 1; r < d->world && rc == ncclSuccess; r++) rc = g_rccl.Recv((char *)d_recv + (size_t)r * bytes, bytes, ncclUint8, r, d->comm, s);
+        } else rc = g_rccl.Send(d_send, bytes, ncclUint8, 0, d->comm, s);
+        const ncclResult_t rce = g_rccl.GroupEnd();                     /* the group is closed whatever happened inside it */
+        if (rc != ncclSuccess) return DFAIL("lh_dist_gather: ncclSend / ncclRecv failed: %s", g_rccl.GetErrorString(rc));
+        if (rce != ncclSuccess) return DFAIL("lh_dist_gather: ncclGroupEnd failed: %s", g_rccl.GetErrorString(rce));
         if (d->rank == 0 && d_recv != d_send) HIPCHK(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, s));     /* the owner's own slab */
         return 0;
     }
