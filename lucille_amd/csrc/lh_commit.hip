@@ -369,9 +369,51 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                                void **d_tri32, float bmin[3], float bmax[3], float grid_lo[3], float grid_step[3],
                                void *stream, char *err, size_t errlen);                /* lh_build.hip */
 
+/* flag = 1 if the two word arrays differ anywhere */
+__global__ void k_words_differ(size_t nwords, const uint32_t *__restrict__ x, const uint32_t *__restrict__ y, int *__restrict__ flag)
+{
+    bool diff = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) diff |= x[i] != y[i];
+    if (__ballot(diff) != 0ull && (threadIdx.x & 63) == 0) atomicExch(flag, 1);
+}
+
+/* the 8-wide nodes of a scene whose tree was built on this device without them: the build is run once more (it is
+ * deterministic: stable sort, stable partitions, a layout of the top that does not depend on its threads) and only its 8-wide
+ * collapse is kept.  The leaves of those nodes index the resident triangle records, so the second run's records must be the
+ * resident ones word for word -- checked, not assumed */
+static int device_rebuild_q8(lh_accel_t *a)
+{
+    lh_host_scene *hs = a->hs;
+    char berr[256] = "";
+    void *q4 = NULL, *q8 = NULL, *t32 = NULL; int *flag = NULL, h_flag = 0;
+    uint32_t nq4 = 0, d4 = 0, st4 = 0, nq8 = 0, d8 = 0; float bmin[3], bmax[3], glo[3], gst[3];
+    const int rcb = lh_device_build(hs->bvh.ntris, (const double *)a->d_tri64, &q4, &nq4, &d4, &st4, 1, &q8, &nq8, &d8, &t32, bmin, bmax, glo, gst,
+                                    (void *)a->stream, berr, sizeof(berr));
+    if (rcb != 0) return fail("building the 8-wide nodes on the device failed: %s", berr);
+    int rc = 0;
+    if (q8) {
+        const size_t nwords = sizeof(lh_tri32_t) / 4 * (size_t)hs->bvh.ntris;
+        if (hipMalloc((void **)&flag, sizeof(int)) != hipSuccess || hipMemsetAsync(flag, 0, sizeof(int), a->stream) != hipSuccess) rc = fail("out of device memory");
+        if (rc == 0) {
+            hipLaunchKernelGGL(k_words_differ, dim3(2048), dim3(256), 0, a->stream, nwords, (const uint32_t *)t32, (const uint32_t *)a->d_tri32, flag);
+            if (hipMemcpyAsync(&h_flag, flag, sizeof(int), hipMemcpyDeviceToHost, a->stream) != hipSuccess || hipStreamSynchronize(a->stream) != hipSuccess)
+                rc = fail("comparing the rebuilt triangle order failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        if (rc == 0 && (h_flag || nq4 != hs->bvh.nq4nodes))
+            rc = fail("the device build did not repeat itself (%u nodes, then %u): the 8-wide nodes are not usable; set \"wide8\" = 1 before the commit", hs->bvh.nq4nodes, nq4);
+    }
+    if (flag) (void)hipFree(flag);
+    if (q4) (void)hipFree(q4);
+    if (t32) (void)hipFree(t32);
+    if (rc != 0) { if (q8) (void)hipFree(q8); return -1; }
+    if (q8) { a->d_q8nodes = q8; a->dev.q8nodes = q8; a->dev.nq8nodes = nq8; a->dev.q8_depth = d8; a->device_bytes += sizeof(lh_q8node_t) * (size_t)nq8; }
+    return 0;
+}
+
 int lh_ensure_formats(lh_accel_t *a, int mask)
 {
     const lh_bvh_t *b = &a->hs->bvh;
+    if ((mask & LH_FMT_Q8) && !a->d_q8nodes && a->hs->device_built && !a->hs->received && b->nq4nodes > 1 && device_rebuild_q8(a) != 0) return -1;
     if ((mask & LH_FMT_Q8) && !a->d_q8nodes && !a->hs->device_built) {
         /* the 8-wide 16-bit-grid nodes for ray dumps over scenes larger than the Infinity Cache: built on first use */
         pthread_mutex_lock(&g_scene_mu);
@@ -510,9 +552,10 @@ static int device_upload(lh_accel_t *a)
             /* the traversal tree is built here, on this device (lh_build.hip): LBVH -> the same 4-wide nodes */
             char berr[256] = "";
             uint32_t nq4 = 0, d4 = 0, st4 = 0, nq8 = 0, d8 = 0; float bmin[3], bmax[3], glo[3], gst[3];
-            /* a scene whose ray dumps will want the 8-wide nodes (hot set beyond the Infinity Cache, or "wide8" = 1) gets them now:
-             * the binary tree they are collapsed from does not outlive the build */
-            const int want_q8 = a->wide8 == 1 || (a->wide8 == -1 && (size_t)hs->bvh.ntris * (sizeof(lh_tri32_t) + 20) > ((size_t)256 << 20));
+            /* "wide8" = 1: the 8-wide nodes of ray dumps are collapsed from the same binary tree now.  Left to itself (-1) a scene
+             * gets them when its first dump asks (lh_ensure_formats: the build is run again, ~40 ms per 10 M triangles) -- a renderer
+             * that re-commits every frame and never dumps does not pay for them */
+            const int want_q8 = a->wide8 == 1;
             const double tb = now_s();
             const int rcb = lh_device_build(hs->bvh.ntris, (const double *)a->d_tri64, &a->d_q4nodes, &nq4, &d4, &st4, want_q8, &a->d_q8nodes, &nq8, &d8, &a->d_tri32, bmin, bmax, glo, gst,
                                             (void *)a->stream, berr, sizeof(berr));

@@ -67,6 +67,14 @@ static bool wide8_pays(const lh_accel_t *a)
     return sizeof(lh_q4node_t) * (size_t)b->nq4nodes + sizeof(lh_tri32_t) * (size_t)b->ntris > ((size_t)256 << 20);
 }
 
+/* the 8-wide nodes exist or can be made: always for a host-built tree (lh_bvh_ensure_q8), by a second run of the build for a
+ * tree built on this device (lh_ensure_formats), never for a scene received from another rank without them */
+static bool q8_available(const lh_accel_t *a)
+{
+    if (a->d_q8nodes || !a->hs->device_built) return true;
+    return !a->hs->received && a->hs->bvh.nq4nodes > 1;
+}
+
 int lh_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, void *d_prim,
               void *d_t, void *d_u, void *d_v, void *d_occ, int mode, int variant,
               unsigned long long *d_counters, hipStream_t s, bool dump)
@@ -101,7 +109,7 @@ int lh_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, voi
      * nodes: each record then costs a 128-byte line of HBM traffic whatever its size, and an 8-wide record uses all of it
      * (S-soup-10M: 57 -> 40 records per ray).  The tile pipelines' coherent rays stay on the 4-wide nodes. */
     a->dev.prefer_q8 = 0;
-    if (dump && variant == LH_VARIANT_SPEC && (!a->hs->device_built || a->d_q8nodes) && (a->wide8 == 1 || (a->wide8 == -1 && wide8_pays(a)))) {
+    if (dump && variant == LH_VARIANT_SPEC && q8_available(a) && (a->wide8 == 1 || (a->wide8 == -1 && wide8_pays(a)))) {
         if (lh_ensure_formats(a, LH_FMT_Q8) != 0) return -1;
         a->dev.prefer_q8 = 1;
     }
@@ -161,7 +169,7 @@ extern "C" int lh_accel_intersect_device_counted(lh_accel_t *a, size_t n, const 
 extern "C" int lh_accel_dump_node_bytes(const lh_accel_t *a)
 {
     if (!a || !a->committed || a->hs->bvh.ntris == 0) return 0;
-    if (a->default_variant == LH_VARIANT_SPEC && (!a->hs->device_built || a->d_q8nodes) &&
+    if (a->default_variant == LH_VARIANT_SPEC && q8_available(a) &&
         (a->wide8 == 1 || (a->wide8 == -1 && wide8_pays(a)))) return (int)sizeof(lh_q8node_t);
     return 64;
 }

@@ -209,6 +209,12 @@ def test_device_built_eight_wide_nodes(ntri, he, seed):
     ref = la.HipAccel(0); ref.add_mesh(P, idx); ref.set_param("wide8", 0); ref.commit(on_device=True)
     assert ref.dump_node_bytes() == 64
     assert_hits_equal(ref.intersect_host(org, dr), exp, "device-built 4-wide %d" % ntri)
+    # asked for only after the commit: the build is repeated for its 8-wide collapse when the first dump needs it
+    before = ref.info()["device_bytes"]
+    ref.set_param("wide8", 1)
+    assert_hits_equal(ref.intersect_host(org, dr), exp, "device-built, 8-wide nodes on first use %d" % ntri)
+    if ntri > 16:
+        assert ref.dump_node_bytes() == 128 and ref.info()["device_bytes"] > before
     acc.close(); ref.close()
 
 
