@@ -73,14 +73,19 @@ int  lh_accel_add_mesh(lh_accel_t *accel, uint32_t npositions, const double *pos
  * Every entry point taking an accelerator holds its lock: calls from several threads are safe and
  * serialised (lucille's render threads call accel->intersect concurrently, render.c:1043-1105). */
 int  lh_accel_commit(lh_accel_t *accel, int build_threads);
-/* build_threads == LH_BUILD_ON_DEVICE (or LH_BUILD=device in the environment): the traversal tree is built on the GPU
- * (LBVH -> the same 4-wide nodes; milliseconds instead of seconds: lucille re-builds its accelerator in every
- * ri_scene_setup, scene.c:84-98) and lucille's own tree -- needed only for exact-t tie winners, fragile hits and beams --
- * by a background host thread.  Queries are exact by default: the first one waits for that tree (lh_accel_wait_exact does
- * so explicitly).  lh_accel_set_param(accel, "fast_start", 1) (or LH_FAST_START=1) lets queries run before it is
- * attached; until then exact-t ties resolve to the larger primitive id.  Hit records are otherwise independent of the tree. */
+/* build_threads == LH_BUILD_ON_DEVICE (or LH_BUILD=device in the environment): both trees are built on the GPU -- the
+ * traversal tree (LBVH + SAH -> the same 4-wide nodes) and lucille's own tree (ri_bvh_build, bvh.c:276-379, restated level by
+ * level, bit for bit: exact-t tie winners, fragile hits and beams depend on it): a fraction of a second instead of seconds;
+ * lucille re-builds its accelerator in every ri_scene_setup (scene.c:84-98).  LH_REF_BUILD=host leaves lucille's own tree to
+ * a background host thread as in round 2: queries are exact by default (the first one waits for it, lh_accel_wait_exact does so
+ * explicitly); lh_accel_set_param(accel, "fast_start", 1) (or LH_FAST_START=1) lets them run before it is attached, exact-t
+ * ties resolving to the larger primitive id until then.  Hit records are otherwise independent of the trees. */
 #define LH_BUILD_ON_DEVICE (-2)
 int  lh_accel_wait_exact(lh_accel_t *accel);
+/* lucille's own tree as the kernels read it, for inspection (tests compare the device-built tree with the host-built one):
+ * *nnodes nodes of 128 bytes (lh_refbvh.h: two child boxes of 6 doubles, child[2], axis, is_leaf, first, count, parent, depth;
+ * root = 0) and the ntriangles primitive ids in leaf order.  Either pointer may be NULL.  Fails if the tree is not attached. */
+int  lh_accel_ref_tree(lh_accel_t *accel, uint32_t *nnodes, void *nodes_out, uint32_t *leaf_prims_out);
 void lh_accel_destroy(lh_accel_t *accel);
 int  lh_accel_info(const lh_accel_t *accel, lh_accel_info_t *out);
 

@@ -94,7 +94,7 @@ class TileStats(C.Structure):
 
 # every symbol include/lucille_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
-    "lh_device_count", "lh_last_error", "lh_accel_create", "lh_accel_add_mesh", "lh_accel_commit", "lh_accel_wait_exact",
+    "lh_device_count", "lh_last_error", "lh_accel_create", "lh_accel_add_mesh", "lh_accel_commit", "lh_accel_wait_exact", "lh_accel_ref_tree",
     "lh_accel_destroy", "lh_accel_info", "lh_accel_prim_lookup", "lh_accel_intersect1",
     "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted", "lh_accel_last_retraced", "lh_accel_dump_node_bytes",
     "lh_accel_set_grid", "lh_accel_set_param", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
@@ -136,6 +136,7 @@ def lib():
     L.lh_accel_add_mesh.argtypes = [vp, u32, vp, sz, u32, vp]
     L.lh_accel_commit.argtypes = [vp, i32]
     L.lh_accel_wait_exact.argtypes = [vp]
+    L.lh_accel_ref_tree.argtypes = [vp, C.POINTER(C.c_uint32), vp, vp]
     L.lh_accel_destroy.argtypes = [vp]
     L.lh_accel_destroy.restype = None
     L.lh_accel_info.argtypes = [vp, C.POINTER(AccelInfo)]
@@ -281,6 +282,18 @@ class HipAccel:
 
     def wait_exact(self):
         _check(self.L.lh_accel_wait_exact(self.h), "lh_accel_wait_exact")
+
+    REF_NODE = np.dtype([("box", "<f8", (2, 6)), ("child", "<i4", (2,)), ("axis", "<i4"), ("is_leaf", "<i4"), ("first", "<u4"),
+                         ("count", "<u4"), ("parent", "<i4"), ("depth", "<i4")])
+
+    def ref_tree(self):
+        """lucille's own tree as the kernels read it: (nodes [structured, 128 bytes each, root 0], leaf_prims)"""
+        nn = C.c_uint32()
+        _check(self.L.lh_accel_ref_tree(self.h, C.byref(nn), None, None), "lh_accel_ref_tree")
+        nodes = np.zeros(nn.value, dtype=self.REF_NODE)
+        prims = np.zeros(self.info()["ntriangles"], dtype=np.uint32)
+        _check(self.L.lh_accel_ref_tree(self.h, C.byref(nn), nodes.ctypes.data_as(C.c_void_p), prims.ctypes.data_as(C.c_void_p)), "lh_accel_ref_tree")
+        return nodes, prims
 
     def info(self):
         s = AccelInfo()

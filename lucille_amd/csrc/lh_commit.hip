@@ -220,6 +220,7 @@ static void *ref_thread_main(void *arg)
     lh_host_scene *hs = (lh_host_scene *)arg;
     const double t0 = now_s();
     free_trash(hs);
+    if (hs->ref_on_device) { __atomic_store_n(&hs->ref_state, 0, __ATOMIC_RELEASE); return NULL; }       /* only the mesh copies to return */
     const int rc = lh_refbvh_build(&hs->ref, hs->bvh.tri64, hs->bvh.ntris, hs->ref_threads);
     hs->ref_build_seconds = now_s() - t0;
     __atomic_store_n(&hs->ref_state, rc == 0 ? 2 : -1, __ATOMIC_RELEASE);
@@ -410,6 +411,36 @@ static int device_rebuild_q8(lh_accel_t *a)
     return 0;
 }
 
+extern "C" int lh_device_ref_build(uint32_t ntris, const double *d_tri64, void **d_nodes, uint32_t *nnodes, uint32_t *max_depth,
+                                   void **d_leaf_prims, void **d_lca, void **d_leafpos, double scene6[6], void *stream, char *err, size_t errlen);   /* lh_refbuild.hip */
+
+/* lucille's own tree of a device-built scene, on this device (LH_REF_BUILD=host: the background host thread instead).
+ * 0: attached; 1: not built here (the host thread will); -1: error */
+static int device_ref_tree(lh_accel_t *a)
+{
+    lh_host_scene *hs = a->hs;
+    const char *e = getenv("LH_REF_BUILD");
+    if (e && strcmp(e, "host") == 0 && !hs->ref_on_device) return 1;
+    char rerr[256] = ""; uint32_t rn = 0, rdepth = 0; double sc6[6];
+    const double t0 = now_s();
+    if (lh_device_ref_build(hs->bvh.ntris, (const double *)a->d_tri64, &a->d_ref_nodes, &rn, &rdepth, &a->d_ref_leaf_prims, &a->d_ref_lca,
+                            &a->d_prim_leafpos, sc6, (void *)a->stream, rerr, sizeof(rerr)) != 0) {
+        a->d_ref_nodes = a->d_ref_leaf_prims = a->d_ref_lca = a->d_prim_leafpos = NULL;
+        if (hs->ref_on_device) return fail("building lucille's own tree on the device failed: %s", rerr);       /* a replica: there is no host copy to fall back on */
+        if (getenv("LH_BUILD_TIMING")) fprintf(stderr, "[lucille_hip] commit: lucille's own tree not built on the device (%s): host thread\n", rerr);
+        return 1;
+    }
+    a->dev.ref_lca = a->d_ref_lca; a->dev.prim_leafpos = a->d_prim_leafpos;
+    a->dev.ref_nodes = a->d_ref_nodes; a->dev.ref_leaf_prims = a->d_ref_leaf_prims;
+    a->dev.ref_nnodes = rn; a->dev.ref_empty = 0;
+    for (int k = 0; k < 3; k++) { a->dev.ref_bmin[k] = sc6[k]; a->dev.ref_bmax[k] = sc6[3 + k]; }
+    a->device_bytes += sizeof(int) * 4 * (size_t)rn + sizeof(uint32_t) * 3 * (size_t)hs->bvh.ntris + sizeof(lh_refnode_t) * (size_t)rn;
+    pthread_mutex_lock(&g_scene_mu);
+    hs->ref_on_device = 1; hs->ref_build_seconds = now_s() - t0;
+    pthread_mutex_unlock(&g_scene_mu);
+    return 0;
+}
+
 int lh_ensure_formats(lh_accel_t *a, int mask)
 {
     const lh_bvh_t *b = &a->hs->bvh;
@@ -569,6 +600,7 @@ static int device_upload(lh_accel_t *a)
             a->device_bytes += sizeof(lh_q4node_t) * (size_t)nq4;
             if (a->d_q8nodes) { a->dev.q8nodes = a->d_q8nodes; a->dev.nq8nodes = nq8; a->dev.q8_depth = d8; a->device_bytes += sizeof(lh_q8node_t) * (size_t)nq8; }
             if (3 * d4 + 5 > 264) return -3;          /* deeper than k_overflow_fix's private stack: the caller falls back to the host builder */
+            if (hs->have_ref && (hs->ref_on_device || hs->ref_state == 1) && device_ref_tree(a) < 0) return -1;
         } else {
             HIPCHK(hipMalloc(&a->d_tri32, t32 + 64));   /* the unified walk reads 16 B past a record */
             HIPCHK(hipMemcpy(a->d_tri32, hs->bvh.tri32, t32, hipMemcpyHostToDevice));
@@ -636,7 +668,7 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
             pthread_mutex_unlock(&g_scene_mu);
             free(hs->nrm9); free(hs->attr9[0]); free(hs->attr9[1]); free(hs->attr9[2]); free(hs->st6); free(hs->inside);
             hs->nrm9 = NULL; hs->attr9[0] = hs->attr9[1] = hs->attr9[2] = NULL; hs->st6 = NULL; hs->inside = NULL;
-            lh_bvh_release(&hs->bvh); lh_refbvh_release(&hs->ref); hs->ref_state = 0;
+            lh_bvh_release(&hs->bvh); lh_refbvh_release(&hs->ref); hs->ref_state = 0; hs->ref_on_device = 0;
             on_device = false;
         } else {
             for (uint32_t g = 0; g < a->nmeshes; g++) {
@@ -683,6 +715,19 @@ extern "C" int lh_accel_commit_replica(lh_accel_t *dst, lh_accel_t *src)
         if (rc != 0) return -1;
     }
     dst->commit_failed = 0;
+    return 0;
+}
+
+extern "C" int lh_accel_ref_tree(lh_accel_t *a, uint32_t *nnodes, void *nodes_out, uint32_t *leaf_prims_out)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("lh_accel_ref_tree: accel not committed");
+    if (lh_sync_ref(a, true) != 0) return -1;
+    if (!a->d_ref_nodes) return fail("lh_accel_ref_tree: the reference-order tree is not attached (empty scene or LH_REFTREE=0)");
+    HIPCHK(hipSetDevice(a->device));
+    if (nnodes) *nnodes = a->dev.ref_nnodes;
+    if (nodes_out) HIPCHK(hipMemcpy(nodes_out, a->d_ref_nodes, sizeof(lh_refnode_t) * (size_t)a->dev.ref_nnodes, hipMemcpyDeviceToHost));
+    if (leaf_prims_out) HIPCHK(hipMemcpy(leaf_prims_out, a->d_ref_leaf_prims, sizeof(uint32_t) * (size_t)a->hs->bvh.ntris, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -56,6 +56,7 @@ struct lh_host_scene {
      * background thread and attached to the replicas when it is ready (ref_state: 0 none, 1 building, 2 ready, -1 failed) */
     int device_built;
     int received;             /* the scene arrived as an image from another rank (lh_dist.hip): device arrays only */
+    int ref_on_device;        /* lucille's own tree of a device-built scene was built on the device too (lh_refbuild.hip): no host copy */
     int ref_state; pthread_t ref_thread; int ref_thread_live; int ref_threads;
     void **trash; uint32_t ntrash;   /* host blocks the device-side commit no longer needs: freed by the background thread (unmapping 0.5 GB takes 0.1 s) */
 };
