@@ -623,10 +623,11 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
         for k in range(int(g["ngeoms"])):
             P_, I_ = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess); acc_d.add_mesh(P_, I_); del P_, I_
         t0 = time.perf_counter(); info_d = acc_d.commit(on_device=True); commit_dev_s = time.perf_counter() - t0
-        acc_d.wait_exact()
+        acc_d.wait_exact(); exact_s = time.perf_counter() - t0          # lucille's own tree attached: ties, fragile hits, beams follow the reference
         render.render_ao_frame(acc_d, cam, 1, nsamples, tile=tile); torch.cuda.synchronize(dev)
         t0 = time.perf_counter(); img_d, st_d = render.render_ao_frame(acc_d, cam, 1, nsamples, tile=tile); torch.cuda.synchronize(dev)
         devb = {"host_commit_s": round(commit_host_s, 3), "device_commit_s": round(commit_dev_s, 3), "device_tree_s": round(info_d["build_seconds"], 3),
+                "device_reference_tree_s": round(acc_d.info()["ref_build_seconds"], 3), "commit_to_exact_s": round(exact_s, 3),
                 "frame_ms_on_device_tree": round((time.perf_counter() - t0) * 1e3, 3),
                 "image_bit_equal": bool(torch.equal(img_d, img)) and dict(st_d) == stats[0]}
         ok = ok and devb["image_bit_equal"]

@@ -37,7 +37,7 @@ namespace {
 #define RB_EPS 1.0e-14          /* RI_EPS src/base/common.h:27 */
 #define RB_INF 1.0e38           /* RI_INFINITY include/ri.h:47 */
 #define RB_NONE 0xffffffffu
-#define RB_CHUNK 2048u          /* elements per workgroup of the histogram pass */
+#define RB_CHUNK 2048u          /* elements per workgroup of the histogram and the bounds pass */
 #define RB_HIST (2 * 3 * RB_BINS)
 
 struct RBox { double lo[3], hi[3]; };
@@ -124,31 +124,55 @@ __device__ __forceinline__ void bins_of(const RBox &b, const RSeg &s, uint32_t o
     }
 }
 
+/* Nodes are contiguous ranges of the element array.  LONG nodes (RB_LONG elements or more) are counted here: a workgroup
+ * walks the long runs of its chunk, each in LDS and then 384 atomics (same-address atomics serialise at ~95 ns: the root's
+ * 21 M elements would queue on 384 addresses otherwise).  Short nodes: k_rb_small, a wave each, no atomics in memory at all. */
+#define RB_LONG 1024u
 __global__ __launch_bounds__(256) void k_rb_bin(uint32_t n, const RBox *__restrict__ E, const uint32_t *__restrict__ seg, const RSeg *__restrict__ segs,
                                                 uint32_t *__restrict__ hist)
 {
     __shared__ uint32_t h[RB_HIST];
     __shared__ RSeg ss;
+    __shared__ uint32_t s_next, any_long;
     const uint32_t base = blockIdx.x * RB_CHUNK, end = (base + RB_CHUNK < n) ? base + RB_CHUNK : n;
-    const uint32_t s0 = seg[base], s1 = seg[end - 1];
-    if (s0 == s1 && s0 != RB_NONE) {
-        /* the whole chunk lies inside one node (nodes are contiguous ranges): count in LDS, 384 atomics for the chunk */
-        for (uint32_t t = threadIdx.x; t < RB_HIST; t += 256) h[t] = 0u;
-        if (threadIdx.x == 0) ss = segs[s0];
-        __syncthreads();
-        for (uint32_t i = base + threadIdx.x; i < end; i += 256) {
-            uint32_t b[6]; bins_of(E[i], ss, b);
-            for (int q = 0; q < 6; q++) atomicAdd(&h[b[q]], 1u);
-        }
-        __syncthreads();
-        for (uint32_t t = threadIdx.x; t < RB_HIST; t += 256) if (h[t]) atomicAdd(&hist[(size_t)s0 * RB_HIST + t], h[t]);
-        return;
-    }
+    if (threadIdx.x == 0) any_long = 0u;
+    __syncthreads();
+    bool saw_long = false;
     for (uint32_t i = base + threadIdx.x; i < end; i += 256) {
         const uint32_t s = seg[i];
-        if (s == RB_NONE) continue;
-        uint32_t b[6]; bins_of(E[i], segs[s], b);
-        for (int q = 0; q < 6; q++) atomicAdd(&hist[(size_t)s * RB_HIST + b[q]], 1u);
+        if (s != RB_NONE && segs[s].ir - segs[s].il >= RB_LONG) saw_long = true;
+    }
+    if (saw_long) any_long = 1u;
+    __syncthreads();
+    if (!any_long) return;
+    uint32_t pos = base;
+    while (pos < end) {
+        const uint32_t s = seg[pos];
+        if (s == RB_NONE) {
+            if (threadIdx.x == 0) s_next = 0xffffffffu;
+            __syncthreads();
+            const uint32_t i = pos + threadIdx.x;
+            if (i < end && seg[i] != RB_NONE) atomicMin(&s_next, i);
+            __syncthreads();
+            const uint32_t nx = s_next;
+            __syncthreads();
+            pos = (nx == 0xffffffffu) ? pos + 256u : nx;
+            continue;
+        }
+        if (threadIdx.x == 0) ss = segs[s];
+        for (uint32_t t = threadIdx.x; t < RB_HIST; t += 256) h[t] = 0u;
+        __syncthreads();
+        const uint32_t re = ss.ir < end ? ss.ir : end;
+        if (ss.ir - ss.il >= RB_LONG) {
+            for (uint32_t i = pos + threadIdx.x; i < re; i += 256) {
+                uint32_t b[6]; bins_of(E[i], ss, b);
+                for (int q = 0; q < 6; q++) atomicAdd(&h[b[q]], 1u);
+            }
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < RB_HIST; t += 256) if (h[t]) atomicAdd(&hist[(size_t)s * RB_HIST + t], h[t]);
+        }
+        __syncthreads();
+        pos = re;
     }
 }
 
@@ -166,29 +190,88 @@ __device__ __forceinline__ double sah_cost(int ns1, double a1, int ns2, double a
     return T;
 }
 
-/* find_cut_from_bin bvh.c:1230-1326 */
-__global__ void k_rb_cut(uint32_t S, RSeg *__restrict__ segs, const uint32_t *__restrict__ hist)
+/* find_cut_from_bin bvh.c:1230-1326.  The reference keeps the first candidate, in (axis, bin) order, whose cost is below
+ * everything before it: three threads take an axis each, the first-found minima are then compared in axis order */
+__global__ __launch_bounds__(192) void k_rb_cut(uint32_t S, RSeg *__restrict__ segs, const uint32_t *__restrict__ hist)
 {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    RSeg sg = segs[s];
-    const uint32_t *bin = hist + (size_t)s * RB_HIST;
-    const uint32_t n = sg.ir - sg.il;
-    double bstep[3], min_cost = RB_INF; const double sa_total = area_of(sg.bmin, sg.bmax);
-    double cut_pos = 0.0; int cut_axis = 0;
-    for (int k = 0; k < 3; k++) bstep[k] = (sg.bmax[k] - sg.bmin[k]) / (double)RB_BINS;
-    for (int j = 0; j < 3; j++) {
+    __shared__ double scost[192], spos[192];
+    const uint32_t s = blockIdx.x * 64u + threadIdx.x / 3u; const int j = (int)(threadIdx.x % 3u);
+    double best = RB_INF, best_pos = 0.0;
+    const bool mine = s < S && segs[s].ir - segs[s].il >= RB_LONG;        /* short nodes: k_rb_small */
+    if (mine) {
+        const RSeg sg = segs[s];
+        const uint32_t *bin = hist + (size_t)s * RB_HIST;
+        const uint32_t n = sg.ir - sg.il;
+        const double sa_total = area_of(sg.bmin, sg.bmax);
+        const double bstep = (sg.bmax[j] - sg.bmin[j]) / (double)RB_BINS;
         uint64_t left = 0, right = n; double lmin[3], lmax[3], rmin[3], rmax[3];
         for (int k = 0; k < 3; k++) { lmin[k] = rmin[k] = sg.bmin[k]; lmax[k] = rmax[k] = sg.bmax[k]; }
         for (int b = 0; b < RB_BINS - 1; b++) {
             left += bin[j * RB_BINS + b]; right -= bin[(3 + j) * RB_BINS + b];
-            const double pos = sg.bmin[j] + (b + 1) * bstep[j];
+            const double pos = sg.bmin[j] + (b + 1) * bstep;
             lmax[j] = pos; rmin[j] = pos;
             const double cost = sah_cost((int)left, area_of(lmin, lmax), (int)right, area_of(rmin, rmax), sa_total);
-            if (cost < min_cost) { min_cost = cost; cut_axis = j; cut_pos = pos; }
+            if (cost < best) { best = cost; best_pos = pos; }
         }
     }
-    segs[s].axis = cut_axis; segs[s].pos = cut_pos;
+    scost[threadIdx.x] = best; spos[threadIdx.x] = best_pos;
+    __syncthreads();
+    if (mine && j == 0) {
+        double min_cost = RB_INF, cut_pos = 0.0; int cut_axis = 0;
+        for (int a = 0; a < 3; a++) if (scost[threadIdx.x + a] < min_cost) { min_cost = scost[threadIdx.x + a]; cut_axis = a; cut_pos = spos[threadIdx.x + a]; }
+        segs[s].axis = cut_axis; segs[s].pos = cut_pos;
+    }
+}
+
+/* bins and cut of a SHORT node (fewer than RB_LONG elements), one wave per node: the 384 counters live in LDS, the 189
+ * candidates are spread over the lanes (lane b: the cut after bin b on each axis; left / right counts by a prefix sum across
+ * the lanes), and the reference's "first candidate below everything before it" is the minimum with ties to the lowest
+ * (axis, bin) */
+__global__ __launch_bounds__(256) void k_rb_small(uint32_t S, RSeg *__restrict__ segs, const RBox *__restrict__ E)
+{
+    __shared__ uint32_t hh[4][RB_HIST];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t s = blockIdx.x * 4u + (uint32_t)wv;
+    uint32_t *h = hh[wv];
+    RSeg sg; bool mine = false;
+    if (s < S) { sg = segs[s]; mine = sg.ir - sg.il < RB_LONG; }
+    for (int q = 0; q < 6; q++) h[q * 64 + lane] = 0u;
+    __syncthreads();
+    if (mine)
+        for (uint32_t i = sg.il + (uint32_t)lane; i < sg.ir; i += 64) {
+            uint32_t b[6]; bins_of(E[i], sg, b);
+            for (int q = 0; q < 6; q++) atomicAdd(&h[b[q]], 1u);
+        }
+    __syncthreads();
+    if (!mine) return;
+    const uint32_t n = sg.ir - sg.il;
+    const double sa_total = area_of(sg.bmin, sg.bmax);
+    double best = RB_INF, best_pos = 0.0; int best_key = 0;
+    for (int j = 0; j < 3; j++) {
+        uint32_t c0 = h[j * 64 + lane], c1 = h[(3 + j) * 64 + lane];
+        for (int off = 1; off < 64; off <<= 1) {                /* inclusive prefix sums across the lanes */
+            const uint32_t u0 = (uint32_t)__shfl_up((int)c0, off), u1 = (uint32_t)__shfl_up((int)c1, off);
+            if (lane >= off) { c0 += u0; c1 += u1; }
+        }
+        if (lane < RB_BINS - 1) {
+            const uint64_t left = c0, right = (uint64_t)n - (uint64_t)c1;
+            const double bstep = (sg.bmax[j] - sg.bmin[j]) / (double)RB_BINS;
+            double lmin[3], lmax[3], rmin[3], rmax[3];
+            for (int k = 0; k < 3; k++) { lmin[k] = rmin[k] = sg.bmin[k]; lmax[k] = rmax[k] = sg.bmax[k]; }
+            const double pos = sg.bmin[j] + (lane + 1) * bstep;
+            lmax[j] = pos; rmin[j] = pos;
+            const double cost = sah_cost((int)left, area_of(lmin, lmax), (int)right, area_of(rmin, rmax), sa_total);
+            if (cost < best) { best = cost; best_pos = pos; best_key = j * 64 + lane; }
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double oc = __shfl_xor(best, off), op = __shfl_xor(best_pos, off); const int ok = __shfl_xor(best_key, off);
+        if (oc < best || (oc == best && ok < best_key)) { best = oc; best_pos = op; best_key = ok; }
+    }
+    if (lane == 0) {
+        const bool found = best < RB_INF;
+        segs[s].axis = found ? best_key / 64 : 0; segs[s].pos = found ? best_pos : 0.0;
+    }
 }
 
 /* partition bvh.c:1437-1478, first half: who goes left */
@@ -241,29 +324,93 @@ __global__ void k_rb_scatter(uint32_t n, const RBox *__restrict__ E, const uint3
     cid[pos] = 2 * s + (pos < il + nl ? 0u : 1u);
 }
 
-/* bounds of the children (calc_bbox_of_triangles bvh.c:1872-1895): a wave whose 64 elements belong to one child reduces first */
-__global__ __launch_bounds__(256) void k_rb_child_bounds(uint32_t n, const RBox *__restrict__ E, const uint32_t *__restrict__ cid, unsigned long long *__restrict__ cb)
+/* an ordered-integer min / max that only goes to the atomic unit when it would change the value: after the first few
+ * elements of a node almost none does, and same-address atomics serialise at ~95 ns each.  (A stale read can only be LARGER
+ * than the current minimum / smaller than the current maximum: the test errs towards the atomic.) */
+__device__ __forceinline__ void bound_min(unsigned long long *p, unsigned long long v) { if (v < *(volatile unsigned long long *)p) atomicMin(p, v); }
+__device__ __forceinline__ void bound_max(unsigned long long *p, unsigned long long v) { if (v > *(volatile unsigned long long *)p) atomicMax(p, v); }
+
+/* bounds of the children (calc_bbox_of_triangles bvh.c:1872-1895).  LONG children (RB_LONG elements or more): a workgroup
+ * walks the long runs of its chunk, reduces each and updates the child's box with at most six atomics. */
+__global__ __launch_bounds__(256) void k_rb_child_bounds(uint32_t n, const RBox *__restrict__ E, const uint32_t *__restrict__ cid, const RSeg *__restrict__ segs,
+                                                         unsigned long long *__restrict__ cb)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t c = i < n ? cid[i] : RB_NONE;
-    const uint32_t c0 = (uint32_t)__shfl((int)c, 0);
-    const bool uniform = __ballot(c != c0) == 0ull;
-    if (uniform) {
-        if (c0 == RB_NONE) return;
-        const RBox b = E[i];
-        double lo[3] = {b.lo[0], b.lo[1], b.lo[2]}, hi[3] = {b.hi[0], b.hi[1], b.hi[2]};
-        for (int k = 0; k < 3; k++)
-            for (int off = 32; off >= 1; off >>= 1) { lo[k] = fmin(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmax(hi[k], __shfl_xor(hi[k], off)); }
-        if ((threadIdx.x & 63) == 0) {
-            unsigned long long *o = cb + (size_t)c0 * 6;
-            for (int k = 0; k < 3; k++) { atomicMin(&o[k], d2o(lo[k])); atomicMax(&o[3 + k], d2o(hi[k])); }
-        }
-        return;
+    __shared__ double smin[4][3], smax[4][3];
+    __shared__ uint32_t s_next, any_long;
+    const uint32_t base = blockIdx.x * RB_CHUNK, end = (base + RB_CHUNK < n) ? base + RB_CHUNK : n;
+    if (threadIdx.x == 0) any_long = 0u;
+    __syncthreads();
+    bool saw_long = false;
+    for (uint32_t i = base + threadIdx.x; i < end; i += 256) {
+        const uint32_t c = cid[i];
+        if (c == RB_NONE) continue;
+        const RSeg &sg = segs[c >> 1];
+        if (((c & 1u) ? (sg.ir - sg.il) - sg.nl : sg.nl) >= RB_LONG) saw_long = true;
     }
-    if (c == RB_NONE) return;
-    const RBox b = E[i];
-    unsigned long long *o = cb + (size_t)c * 6;
-    for (int k = 0; k < 3; k++) { atomicMin(&o[k], d2o(b.lo[k])); atomicMax(&o[3 + k], d2o(b.hi[k])); }
+    if (saw_long) any_long = 1u;
+    __syncthreads();
+    if (!any_long) return;
+    uint32_t pos = base;
+    while (pos < end) {
+        const uint32_t c = cid[pos];
+        if (c == RB_NONE) {
+            if (threadIdx.x == 0) s_next = 0xffffffffu;
+            __syncthreads();
+            const uint32_t i = pos + threadIdx.x;
+            if (i < end && cid[i] != RB_NONE) atomicMin(&s_next, i);
+            __syncthreads();
+            const uint32_t nx = s_next;
+            __syncthreads();
+            pos = (nx == 0xffffffffu) ? pos + 256u : nx;
+            continue;
+        }
+        const RSeg &sg = segs[c >> 1];
+        const uint32_t cbeg = (c & 1u) ? sg.il + sg.nl : sg.il, cend = (c & 1u) ? sg.ir : sg.il + sg.nl;
+        const uint32_t re = cend < end ? cend : end;
+        if (cend - cbeg >= RB_LONG) {
+            unsigned long long *o = cb + (size_t)c * 6;
+            double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (uint32_t i = pos + threadIdx.x; i < re; i += 256) {
+                const RBox b = E[i];
+                for (int k = 0; k < 3; k++) { lo[k] = fmin(lo[k], b.lo[k]); hi[k] = fmax(hi[k], b.hi[k]); }
+            }
+            for (int k = 0; k < 3; k++) {
+                for (int off = 32; off >= 1; off >>= 1) { lo[k] = fmin(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmax(hi[k], __shfl_xor(hi[k], off)); }
+                if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6][k] = lo[k]; smax[threadIdx.x >> 6][k] = hi[k]; }
+            }
+            __syncthreads();
+            if (threadIdx.x < 3) {
+                const int k = threadIdx.x;
+                double l = smin[0][k], h = smax[0][k];
+                for (int w = 1; w < 4; w++) { l = fmin(l, smin[w][k]); h = fmax(h, smax[w][k]); }
+                bound_min(&o[k], d2o(l)); bound_max(&o[3 + k], d2o(h));
+            }
+            __syncthreads();
+        }
+        pos = re;
+    }
+}
+
+/* short children: a wave each, the box written once */
+__global__ __launch_bounds__(256) void k_rb_child_small(uint32_t S, const RSeg *__restrict__ segs, const RBox *__restrict__ E, unsigned long long *__restrict__ cb)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (c >= 2 * S) return;
+    const RSeg &sg = segs[c >> 1];
+    const uint32_t cbeg = (c & 1u) ? sg.il + sg.nl : sg.il, cend = (c & 1u) ? sg.ir : sg.il + sg.nl;
+    if (cend - cbeg >= RB_LONG) return;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = cbeg + (uint32_t)lane; i < cend; i += 64) {
+        const RBox b = E[i];
+        for (int k = 0; k < 3; k++) { lo[k] = fmin(lo[k], b.lo[k]); hi[k] = fmax(hi[k], b.hi[k]); }
+    }
+    for (int k = 0; k < 3; k++)
+        for (int off = 32; off >= 1; off >>= 1) { lo[k] = fmin(lo[k], __shfl_xor(lo[k], off)); hi[k] = fmax(hi[k], __shfl_xor(hi[k], off)); }
+    if (lane == 0) {
+        unsigned long long *o = cb + (size_t)c * 6;
+        for (int k = 0; k < 3; k++) { o[k] = d2o(lo[k]); o[3 + k] = d2o(hi[k]); }
+    }
 }
 
 /* per child: its box with margin into the parent (bvh.c:1511-1548); a leaf (bvh.c:1345-1403) or a node of the next level */
@@ -430,13 +577,15 @@ extern "C" int lh_device_ref_build(uint32_t ntris, const double *d_tri64, void *
         const unsigned nbs = (S + 127) / 128, nbc = (2 * S + 1 + 127) / 128;
         RCHK(hipMemsetAsync(hist, 0, sizeof(uint32_t) * RB_HIST * (size_t)S, s));
         hipLaunchKernelGGL(k_rb_bin, dim3((n + RB_CHUNK - 1) / RB_CHUNK), dim3(256), 0, s, n, (const RBox *)E[cur], (const uint32_t *)seg[cur], (const RSeg *)segs[cur], hist);
-        hipLaunchKernelGGL(k_rb_cut, dim3(nbs), dim3(128), 0, s, S, segs[cur], (const uint32_t *)hist);
+        hipLaunchKernelGGL(k_rb_cut, dim3((S + 63) / 64), dim3(192), 0, s, S, segs[cur], (const uint32_t *)hist);
+        hipLaunchKernelGGL(k_rb_small, dim3((S + 3) / 4), dim3(256), 0, s, S, segs[cur], (const RBox *)E[cur]);
         hipLaunchKernelGGL(k_rb_flag, dim3((n + 1 + 255) / 256), dim3(256), 0, s, n, (const RBox *)E[cur], (const uint32_t *)seg[cur], (const RSeg *)segs[cur], F);
         { size_t b = tmp_cap; RCHK(hipcub::DeviceScan::ExclusiveSum(tmp, b, F, F, (int)((size_t)n + 1), s)); }
         hipLaunchKernelGGL(k_rb_split, dim3(nbs), dim3(128), 0, s, S, segs[cur], (const uint32_t *)F, nodes, node_count, (int)level, cb);
         hipLaunchKernelGGL(k_rb_scatter, dim3(nbe), dim3(256), 0, s, n, (const RBox *)E[cur], (const uint32_t *)idx[cur], (const uint32_t *)seg[cur],
                            (const RSeg *)segs[cur], (const uint32_t *)F, E[cur ^ 1], idx[cur ^ 1], seg[cur ^ 1]);
-        hipLaunchKernelGGL(k_rb_child_bounds, dim3(nbe), dim3(256), 0, s, n, (const RBox *)E[cur ^ 1], (const uint32_t *)seg[cur ^ 1], cb);
+        hipLaunchKernelGGL(k_rb_child_bounds, dim3((n + RB_CHUNK - 1) / RB_CHUNK), dim3(256), 0, s, n, (const RBox *)E[cur ^ 1], (const uint32_t *)seg[cur ^ 1], (const RSeg *)segs[cur], cb);
+        hipLaunchKernelGGL(k_rb_child_small, dim3((2 * S + 3) / 4), dim3(256), 0, s, S, (const RSeg *)segs[cur], (const RBox *)E[cur ^ 1], cb);
         hipLaunchKernelGGL(k_rb_children, dim3(nbc), dim3(128), 0, s, S, (const RSeg *)segs[cur], (const unsigned long long *)cb, nodes, node_count, A);
         { size_t b = tmp_cap; RCHK(hipcub::DeviceScan::ExclusiveSum(tmp, b, A, P, (int)(2 * (size_t)S + 1), s)); }
         hipLaunchKernelGGL(k_rb_next, dim3(nbc), dim3(128), 0, s, S, (const RSeg *)segs[cur], (const lh_refnode_t *)nodes, node_count, (const uint32_t *)A, (const uint32_t *)P, segs[cur ^ 1]);
