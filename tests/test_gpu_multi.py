@@ -80,3 +80,27 @@ def test_sharded_pt_frame_and_ray_dump_equal_unsharded():
         assert np.array_equal(x, y)
     assert np.array_equal(m2.intersect_host(org, dr, mode=la.MODE_ANY).astype(bool), exp[0] != po.MISS)
     m.close(); m2.close(); a.close()
+
+
+def test_replicas_of_a_device_built_scene_build_both_trees_themselves():
+    """lh_multi_commit(LH_BUILD_ON_DEVICE): replica 0 builds the traversal tree AND lucille's own tree on its device, the other
+    replicas do the same on theirs (there is no host copy to upload): frames, ray dumps with exact-t ties and the trees agree"""
+    import torch
+    from lucille_amd import scenes
+    from tests.test_gpu_refbuild import assert_same_tree
+    g = load_golden("ao_c1")
+    m = la.HipMulti([0, 0]); a = la.HipAccel(0)
+    meshes = [scenes.tessellate(g["pos%d" % k], g["idx%d" % k], 3) for k in range(int(g["ngeoms"]))]
+    for P, I in meshes:
+        m.add_mesh(P, I); a.add_mesh(P, I)
+    m.commit(-2); a.commit()
+    oc = po.Camera.from_ref(g["camera"])
+    cam = la.Camera.make(oc.width, oc.height, oc.flength, list(oc.cam2world), oc.rh)
+    rgb, st, _ = m.render_ao_frame(cam, 1, 16, seed=5, tile=64)
+    ref, st1 = render.render_ao_frame(a, cam, 1, 16, tile=cam.width, seed=5)
+    torch.cuda.synchronize()
+    assert np.array_equal(rgb, ref.cpu().numpy()) and st == st1
+    th = a.ref_tree()
+    for k in range(2):
+        assert_same_tree(th, m.accel(k).ref_tree(), "replica %d" % k)
+    m.close(); a.close()
