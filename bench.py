@@ -172,7 +172,7 @@ def main():
 
     # ONE host build (rank 0), then the flattened scene into every rank's HBM: ncclBroadcast
     acc = la.HipAccel(local)
-    info, commit_s, bcast_s = shard.commit_shared(acc, lambda a: a.add_mesh(P, idx), rank, world)
+    info, commit_s, bcast_s = shard.commit_shared(acc, lambda a: a.add_mesh(P, idx), rank, world, build="host")       # the timed trees are the host builder's, as in rounds 1-2 (the library's own choice from 1 M triangles on is the device: ao_render.device_build)
 
     mode = la.MODE_CLOSEST if args.mode == "closest" else la.MODE_ANY
     rec_bytes = 28 if mode == la.MODE_CLOSEST else 1
@@ -353,7 +353,8 @@ def main():
                        "scene_load": {"rank0_commit_s": round(commit_s, 3), "broadcast_s": round(bcast_s, 3) if world > 1 else None,
                                       "transport": None if world == 1 else ("rccl" if shard.dist().transport == la.DIST_RCCL else "shm (ranks share a device)"),
                                       "note": "one host build on rank 0, flattened arrays broadcast to every rank (lh_dist_broadcast_scene)"},
-                       "bvh": {"nodes": info["nnodes_traversal"], "depth": info["max_depth"], "device_bytes": info["device_bytes"],
+                       "bvh": {"builder": "host, asked for (rounds stay comparable); lh_accel_commit's own choice from 1 M triangles on is the device builders, see ao_render.device_build",
+                               "nodes": info["nnodes_traversal"], "depth": info["max_depth"], "device_bytes": info["device_bytes"],
                                "build_s": round(info["build_seconds"], 3), "ref_tree_build_s": round(info["ref_build_seconds"], 3)}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
@@ -481,7 +482,7 @@ def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
     P, idx, st = scenes.soup_triangles(args.hbm_tris, 0.002)
     n = args.hbm_rays
     d_org, d_dir, _ = upload_rays(scenes, torch, dev, st, n)
-    acc = la.HipAccel(local); acc.add_mesh(P, idx); info = acc.commit()
+    acc = la.HipAccel(local); acc.add_mesh(P, idx); info = acc.commit(build="host")
     del P, idx
     out = acc.intersect_device(d_org, d_dir); torch.cuda.synchronize(dev)
     ns = min(n, 4_000_000)
@@ -565,7 +566,7 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
             a.add_mesh(P_, I_)
             del P_, I_
     # ONE build (rank 0: tessellation + commit), then the broadcast of the flattened scene to every rank
-    t0c = time.perf_counter(); info, commit_s, bcast_s = shard.commit_shared(acc, add_meshes, rank, world); commit_host_s = time.perf_counter() - t0c
+    t0c = time.perf_counter(); info, commit_s, bcast_s = shard.commit_shared(acc, add_meshes, rank, world, build="host"); commit_host_s = time.perf_counter() - t0c
     c = g["camera"]
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
     # one GPU: the whole frame as one tile; sharded: full-width bands, ~16 per rank, band_id % world, ONE device batch per rank (render.bands_for / lh_render_ao_bands)
@@ -706,7 +707,7 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
             a.add_mesh(g["pos%d" % k], g["idx%d" % k])
             if ("nrm%d" % k) in g.files:
                 a.set_normals(k, g["nrm%d" % k], int(g["two_side%d" % k]))
-    shard.commit_shared(acc, add_meshes, rank, world)
+    shard.commit_shared(acc, add_meshes, rank, world, build="host")
     c = g["camera"]
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
     times = []; st = None; img = None; first = None; repeat = True

@@ -81,6 +81,13 @@ int  lh_accel_commit(lh_accel_t *accel, int build_threads);
  * explicitly); lh_accel_set_param(accel, "fast_start", 1) (or LH_FAST_START=1) lets them run before it is attached, exact-t
  * ties resolving to the larger primitive id until then.  Hit records are otherwise independent of the trees. */
 #define LH_BUILD_ON_DEVICE (-2)
+/* build_threads == LH_BUILD_ON_HOST (or LH_BUILD=host), or a thread count > 0: the host builders (binned SAH for traversal,
+ * lucille's own tree beside it on the same thread pool): the better traversal tree (frames ~2 % faster), seconds for tens of
+ * millions of triangles.  build_threads == 0 lets the library choose: the device builders from LH_AUTO_DEVICE_TRIANGLES
+ * triangles on (what `lsh_hip --build auto` always did: lucille sets its scene up in front of every frame), the host builders
+ * below; an automatic device build that cannot be done (memory, a degenerate tree) is redone on the host. */
+#define LH_BUILD_ON_HOST (-3)
+#define LH_AUTO_DEVICE_TRIANGLES 1000000ull
 int  lh_accel_wait_exact(lh_accel_t *accel);
 /* lucille's own tree as the kernels read it, for inspection (tests compare the device-built tree with the host-built one):
  * *nnodes nodes of 128 bytes (lh_refbvh.h: two child boxes of 6 doubles, child[2], axis, is_leaf, first, count, parent, depth;

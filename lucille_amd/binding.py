@@ -274,9 +274,13 @@ class HipAccel:
                                            (N.shape[1] * 8) if N is not None else 24, int(two_side)),
                "lh_accel_set_normals")
 
-    def commit(self, build_threads=0, on_device=False):
-        """on_device: the traversal tree is built on the GPU (LH_BUILD_ON_DEVICE), lucille's own tree in the background"""
-        _check(self.L.lh_accel_commit(self.h, -2 if on_device else int(build_threads)), "lh_accel_commit")
+    def commit(self, build_threads=0, on_device=False, build=None):
+        """build: "device" (= on_device: both trees on the GPU, LH_BUILD_ON_DEVICE), "host" (LH_BUILD_ON_HOST; a thread count
+        in build_threads also means the host), None / "auto": the library chooses by the size of the scene"""
+        if build not in (None, "auto", "host", "device"):
+            raise ValueError("build must be 'auto', 'host' or 'device'")
+        code = -2 if (on_device or build == "device") else (int(build_threads) if int(build_threads) > 0 else (-3 if build == "host" else 0))
+        _check(self.L.lh_accel_commit(self.h, code), "lh_accel_commit")
         self.committed = True
         return self.info()
 

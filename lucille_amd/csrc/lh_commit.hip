@@ -591,6 +591,10 @@ static int device_upload(lh_accel_t *a)
             const int rcb = lh_device_build(hs->bvh.ntris, (const double *)a->d_tri64, &a->d_q4nodes, &nq4, &d4, &st4, want_q8, &a->d_q8nodes, &nq8, &d8, &a->d_tri32, bmin, bmax, glo, gst,
                                             (void *)a->stream, berr, sizeof(berr));
             if (rcb == -2) return fail("lh_accel_commit: a vertex coordinate is NaN, infinite or beyond 1e30");
+            if (rcb != 0 && a->build_auto && !hs->ref_on_device) {
+                if (getenv("LH_BUILD_TIMING")) fprintf(stderr, "[lucille_hip] commit: device build failed (%s): host builders\n", berr);
+                return -3;                              /* nobody asked for the device: the caller builds on the host */
+            }
             if (rcb != 0) return fail("device BVH build failed: %s", berr);
             pthread_mutex_lock(&g_scene_mu);
             hs->bvh.nq4nodes = nq4; hs->bvh.q4_depth = d4; hs->bvh.q4_stack = st4; hs->bvh.nnodes = nq4; hs->bvh.max_depth = d4; hs->bvh.build_seconds = now_s() - tb;
@@ -630,8 +634,21 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
     if (a->committed) return fail("lh_accel_commit: already committed");
     if (a->commit_failed) return fail("lh_accel_commit: an earlier commit of this accelerator failed; create a new one");
     a->commit_failed = 1;                       /* cleared on success */
+    /* where the trees are built: said by the caller (LH_BUILD_ON_DEVICE, LH_BUILD_ON_HOST, or a thread count = the host), by
+     * LH_BUILD in the environment, or -- build_threads == 0 -- by the size of the scene: from LH_AUTO_DEVICE_TRIANGLES on the
+     * device builders (0.3 s instead of 4 s for 21 M triangles, frames ~2 % slower), below it the host builders
+     * (milliseconds either way, and the better tree).  An automatic device build that fails falls back to the host. */
     bool on_device = build_threads == LH_BUILD_ON_DEVICE;
-    { const char *e = getenv("LH_BUILD"); if (e && strcmp(e, "device") == 0) on_device = true; if (e && strcmp(e, "host") == 0) on_device = false; }
+    bool chosen = build_threads == LH_BUILD_ON_DEVICE || build_threads == LH_BUILD_ON_HOST || build_threads > 0;
+    { const char *e = getenv("LH_BUILD"); if (e && strcmp(e, "device") == 0) { on_device = true; chosen = true; } if (e && strcmp(e, "host") == 0) { on_device = false; chosen = true; } }
+    if (!chosen) {
+        unsigned long long ntri = 0;
+        for (uint32_t g = 0; g < a->nmeshes; g++) ntri += a->meshes[g].nidx / 3;
+        unsigned long long at = LH_AUTO_DEVICE_TRIANGLES;
+        { const char *e = getenv("LH_AUTO_DEVICE_TRIANGLES"); if (e && atoll(e) > 0) at = (unsigned long long)atoll(e); }
+        on_device = ntri >= at;
+    }
+    a->build_auto = !chosen;
     if (build_threads < 0) build_threads = 0;
     if (on_device) {
         const bool timing = getenv("LH_BUILD_TIMING") != NULL;

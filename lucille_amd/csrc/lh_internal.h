@@ -109,6 +109,7 @@ struct lh_accel {
     uint64_t last_retraced;            /* rays the last counted launch finished outside the main kernel */
     int ao_fused;                      /* AO rays generated inside the any-hit kernel (default); 0: materialised in HBM */
     uint32_t dump_budget;              /* visit budget of ray-dump launches (the tile pipelines': dev.ray_budget) */
+    int build_auto;                    /* the commit chose the builders by the size of the scene: a failing device build falls back to the host */
     int fast_start;                    /* device-built scenes: launch before lucille's own tree is attached (ties by primitive id until then) */
     lh_buf p_org2, p_dir2, p_path, p_path2, p_thr, p_thr2, p_rad, p_counts;   /* path tracer */
     unsigned long long *d_total;

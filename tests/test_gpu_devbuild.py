@@ -247,3 +247,28 @@ def test_device_built_eight_wide_nodes_can_outnumber_the_four_wide_ones():
         if not wide8:
             assert info["nnodes_traversal"] == 5
         acc.close()
+
+
+def test_commit_chooses_its_builders_by_the_size_of_the_scene(monkeypatch):
+    """build_threads == 0: the device builders from LH_AUTO_DEVICE_TRIANGLES (1 M; lowered here through the environment)
+    triangles on, the host builders below; LH_BUILD_ON_HOST / a thread count / LH_BUILD say otherwise; records never change"""
+    P, idx, org, dr = po.soup(5000, 20000, 0.05, 4242)
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr, nthreads=8)
+
+    def built_on_device(**kw):
+        acc = la.HipAccel(0); acc.add_mesh(P, idx); info = acc.commit(**kw)
+        assert_hits_equal(acc.intersect_host(org, dr), exp, "auto policy %r" % (kw,))
+        acc.close()
+        return info["nnodes"] == info["nnodes_traversal"]
+
+    assert not built_on_device()                                   # 5 000 triangles: host
+    monkeypatch.setenv("LH_AUTO_DEVICE_TRIANGLES", "5000")
+    assert built_on_device()                                       # at the threshold: device
+    assert not built_on_device(build="host") and not built_on_device(build_threads=4)
+    monkeypatch.setenv("LH_AUTO_DEVICE_TRIANGLES", "5001")
+    assert not built_on_device() and built_on_device(build="device")
+    monkeypatch.setenv("LH_BUILD", "device")
+    assert built_on_device() and built_on_device(build="host")     # the environment has the last word
+    monkeypatch.setenv("LH_BUILD", "host")
+    assert not built_on_device(build="device")

@@ -37,10 +37,10 @@ def gpu_any(acc, org, dr, variant):
     return out[0].cpu().numpy()
 
 
-def make_accel(P, idx):
+def make_accel(P, idx, build=None):
     acc = la.HipAccel(0)
     acc.add_mesh(P, idx)
-    acc.commit()
+    acc.commit(build=build)
     return acc
 
 
@@ -267,14 +267,19 @@ def test_counters_match_host_model():
     assert c4["nodes"] < 0.6 * cnt["nodes"]          # the 4-wide walk visits about half the records
 
 
-def test_full_size_properties_soup_1m():
+@pytest.mark.parametrize("build", ["host", "auto"])
+def test_full_size_properties_soup_1m(build):
     """BASELINE config 3 scale (1M triangles): properties that need no CPU reference:
     any-hit == (closest hit exists); variants agree bit for bit; t >= 0; the hit point
-    lies inside the hit triangle's box; first 200k rays bit-exact vs the oracle."""
+    lies inside the hit triangle's box; first 200k rays bit-exact vs the oracle.
+    build "auto": what lh_accel_commit chooses by itself at this size -- the device builders (there the textbook
+    variant runs as the default walk: the 2-wide fp32 nodes exist only in the host builder)"""
     import torch
     ntri, nrays = 1000000, 4000000
     P, idx, org, dr = po.soup(ntri, nrays)
-    acc = make_accel(P, idx)
+    acc = make_accel(P, idx, build)
+    info = acc.info()
+    assert (info["nnodes"] == info["nnodes_traversal"]) == (build == "auto")     # a device-built scene has no 2-wide nodes of its own
     o_, d_ = torch_rays(org, dr)
     res = {}
     for variant in VARIANTS:
@@ -306,7 +311,7 @@ def test_full_size_properties_soup_10m():
     import torch
     ntri, nrays = 10000000, 8000000
     P, idx, org, dr = po.soup(ntri, nrays, 0.002)
-    acc = make_accel(P, idx)
+    acc = make_accel(P, idx, "host")                            # (the 2-wide direct walk below needs the host builder's nodes)
     info = acc.info()
     assert info["ntriangles"] == ntri
     o_, d_ = torch_rays(org, dr)

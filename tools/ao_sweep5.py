@@ -10,7 +10,7 @@ c = g["camera"]; cam = la.Camera.make(4096, 4096, c[16], c[:16], int(c[19]))
 acc = la.HipAccel(0)
 for k in range(int(g["ngeoms"])):
     Pk, Ik = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], 8); acc.add_mesh(Pk, Ik)
-acc.commit()
+acc.commit(build="host")
 def frame():
     render.render_ao_frame(acc, cam, 1, 64, tile=4096); torch.cuda.synchronize(); best = 1e9
     for _ in range(2):

@@ -17,7 +17,7 @@ for name, nt, he, nr in (("S-soup-1M", 1000000, 0.005, 30000000), ("S-soup-10M",
     o = torch.from_numpy(ho).cuda(); d = torch.from_numpy(hd).cuda()
     for on_dev in (False, True):
         acc = la.HipAccel(0); acc.add_mesh(P, idx)
-        t0 = time.perf_counter(); info = acc.commit(on_device=on_dev); tc = time.perf_counter() - t0
+        t0 = time.perf_counter(); info = acc.commit(build="device" if on_dev else "host"); tc = time.perf_counter() - t0
         _, cnt = acc.intersect_device(o[:2000000], d[:2000000], counters=True)
         print("%s %s build: commit %.3f s (tree %.3f s, ref tree %.3f s%s), %d 4-wide nodes, depth %d; closest %.0f any %.0f Mrays/s; %.1f nodes + %.1f tris per ray"
               % (name, "DEVICE" if on_dev else "host  ", tc, info["build_seconds"], info["ref_build_seconds"], " in the background" if on_dev else "",
@@ -31,7 +31,7 @@ for on_dev in (False, True):
     acc = la.HipAccel(0)
     for k in range(int(g["ngeoms"])):
         Pk, Ik = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], 8); acc.add_mesh(Pk, Ik)
-    t0 = time.perf_counter(); info = acc.commit(on_device=on_dev); tc = time.perf_counter() - t0
+    t0 = time.perf_counter(); info = acc.commit(build="device" if on_dev else "host"); tc = time.perf_counter() - t0
     render.render_ao_frame(acc, cam, 1, 64, tile=4096); torch.cuda.synchronize()
     t0 = time.perf_counter(); img, st = render.render_ao_frame(acc, cam, 1, 64, tile=4096); torch.cuda.synchronize(); tf = time.perf_counter() - t0
     t0 = time.perf_counter(); acc.wait_exact(); tw = time.perf_counter() - t0

@@ -8,7 +8,7 @@ g = np.load(os.path.join(ROOT, "tests", "golden", "ao_c1.npz"))
 acc = la.HipAccel(0)
 for k in range(int(g["ngeoms"])):
     Pk, Ik = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], 8); acc.add_mesh(Pk, Ik)
-t0 = time.perf_counter(); info = acc.commit(); print("commit %.2f s, tree %.2f s, ref tree %.2f s, upload %.2f s" % (time.perf_counter() - t0, info["build_seconds"], info["ref_build_seconds"], info["upload_seconds"]))
+t0 = time.perf_counter(); info = acc.commit(build="host"); print("commit %.2f s, tree %.2f s, ref tree %.2f s, upload %.2f s" % (time.perf_counter() - t0, info["build_seconds"], info["ref_build_seconds"], info["upload_seconds"]))
 P, idx, st = scenes.soup_triangles(10000000, 0.002)
 acc2 = la.HipAccel(0); acc2.add_mesh(P, idx)
-t0 = time.perf_counter(); info = acc2.commit(); print("soup-10M commit %.2f s, tree %.2f s, ref tree %.2f s, upload %.2f s" % (time.perf_counter() - t0, info["build_seconds"], info["ref_build_seconds"], info["upload_seconds"]))
+t0 = time.perf_counter(); info = acc2.commit(build="host"); print("soup-10M commit %.2f s, tree %.2f s, ref tree %.2f s, upload %.2f s" % (time.perf_counter() - t0, info["build_seconds"], info["ref_build_seconds"], info["upload_seconds"]))

@@ -10,7 +10,7 @@ t0 = time.time()
 acc = la.HipAccel(0); ntri = 0
 for k in range(int(g["ngeoms"])):
     P, I = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess); acc.add_mesh(P, I); ntri += len(I) // 3
-t1 = time.time(); info = acc.commit(); t2 = time.time()
+t1 = time.time(); info = acc.commit(build="host"); t2 = time.time()
 print("tris", ntri, "tessellate s %.2f commit s %.2f" % (t1 - t0, t2 - t1), info, flush=True)
 c = g["camera"]; cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
 for it in range(3):

@@ -13,7 +13,7 @@ if os.environ.get("WITH_HOST_ACCEL"):                  # bench.py's situation: t
     keep = la.HipAccel(0)
     for k in range(int(g["ngeoms"])):
         P, I = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess); keep.add_mesh(P, I)
-    keep.commit()
+    keep.commit(build="host")
     for it in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter(); render.render_ao_frame(keep, cam, 1, 64, tile=size); torch.cuda.synchronize()
         print("host-tree frame %.1f ms" % ((time.perf_counter() - t0) * 1e3))

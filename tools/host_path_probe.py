@@ -6,7 +6,7 @@ import lucille_amd as la
 from oracle import pyoracle as po
 nr = int(sys.argv[1]) if len(sys.argv) > 1 else 20000000
 P, idx, org, dr = po.soup(1000000, nr)
-acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit()
+acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit(build="host")
 prim = np.zeros(nr, np.uint32); t = np.zeros(nr); u = np.zeros(nr); v = np.zeros(nr); occ = np.zeros(nr, np.uint8)
 L = acc.L
 for label, env in (("pipelined", None), ("simple", "1")):

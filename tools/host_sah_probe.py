@@ -14,7 +14,7 @@ meshes = [scenes.tessellate(g["pos%d" % k], g["idx%d" % k], 8) for k in range(in
 c = g["camera"]; cam = la.Camera.make(4096, 4096, c[16], c[:16], int(c[19]))
 for ct in sys.argv[1:] or ["1.0", "1.2", "1.5", "2.0"]:
     os.environ["LH_BVH_CT"] = ct
-    acc = la.HipAccel(0); acc.add_mesh(P, idx); info = acc.commit()
+    acc = la.HipAccel(0); acc.add_mesh(P, idx); info = acc.commit(build="host")
     out = acc.intersect_device(o, d); torch.cuda.synchronize(); ts = []
     for _ in range(3):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record(); acc.intersect_device(o, d, out=out); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
@@ -24,7 +24,7 @@ for ct in sys.argv[1:] or ["1.0", "1.2", "1.5", "2.0"]:
     acc = la.HipAccel(0)
     for Pk, Ik in meshes:
         acc.add_mesh(Pk, Ik)
-    info = acc.commit(); fr = []
+    info = acc.commit(build="host"); fr = []
     for _ in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter(); render.render_ao_frame(acc, cam, 1, 64, tile=4096); torch.cuda.synchronize(); fr.append((time.perf_counter() - t0) * 1e3)
     print("CT %s config 5: frame %.2f ms, %d nodes" % (ct, min(fr), info["nnodes_traversal"]), flush=True)

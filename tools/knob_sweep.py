@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 P, idx, st = scenes.soup_triangles(1000000, 0.005)
 ho, hd, _ = scenes.soup_rays(n, st)
 o = torch.from_numpy(ho).cuda(); d = torch.from_numpy(hd).cuda(); del ho, hd
-acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit()
+acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit(build="host")
 out = acc.intersect_device(o, d); torch.cuda.synchronize()
 def t():
     ts = []

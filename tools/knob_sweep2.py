@@ -8,7 +8,7 @@ n = 100_000_000
 P, idx, st = scenes.soup_triangles(1000000, 0.005)
 ho, hd, _ = scenes.soup_rays(n, st)
 o = torch.from_numpy(ho).cuda(); d = torch.from_numpy(hd).cuda(); del ho, hd
-acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit()
+acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit(build="host")
 out = acc.intersect_device(o, d); torch.cuda.synchronize()
 def t():
     ts = []
@@ -24,7 +24,7 @@ g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 acc = la.HipAccel(0)
 for k in range(int(g["ngeoms"])):
     Pk, Ik = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], 8); acc.add_mesh(Pk, Ik)
-acc.commit()
+acc.commit(build="host")
 c = g["camera"]; cam = la.Camera.make(4096, 4096, c[16], c[:16], int(c[19]))
 for tb in (8, 12):
     for ma in (32, 40):

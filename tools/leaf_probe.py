@@ -34,7 +34,7 @@ os.environ.pop("LH_DEVICE_LEAF")
 acc = la.HipAccel(0)
 for k in range(int(g["ngeoms"])):
     Pk, Ik = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], 6); acc.add_mesh(Pk, Ik)
-info = acc.commit()
+info = acc.commit(build="host")
 render.render_ao_frame(acc, cam, 1, 64, tile=2048); torch.cuda.synchronize()
 t0 = time.perf_counter(); img, stt = render.render_ao_frame(acc, cam, 1, 64, tile=2048); torch.cuda.synchronize(); tf = time.perf_counter() - t0
 print("   AO tess-6 HOST build: %d nodes depth %d build %.3f s; frame %.1f ms" % (info["nnodes_traversal"], info["max_depth"], info["build_seconds"], tf * 1e3))

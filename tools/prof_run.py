@@ -6,7 +6,7 @@ import lucille_amd as la
 from oracle import pyoracle as po
 nt = int(sys.argv[1]) if len(sys.argv) > 1 else 20000000
 P, idx, org, dr = po.soup(int(os.environ.get("NTRI", "1000000")), nt)
-acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit()
+acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit(build="host")
 o = torch.from_numpy(org).cuda(); d = torch.from_numpy(dr).cuda()
 for mode in (0, 1):
     out = acc.intersect_device(o, d, mode=mode)

@@ -11,7 +11,7 @@ for k in range(int(g["ngeoms"])):
     acc.add_mesh(g["pos%d" % k], g["idx%d" % k])
     if ("nrm%d" % k) in g.files:
         acc.set_normals(k, g["nrm%d" % k], int(g["two_side%d" % k]))
-acc.commit()
+acc.commit(build="host")
 c = g["camera"]; size = 2048; spp = 256
 cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
 ref = None

@@ -16,7 +16,7 @@ for k in range(int(g["ngeoms"])):
     acc.add_mesh(g["pos%d" % k], g["idx%d" % k])
     if ("nrm%d" % k) in g.files:
         acc.set_normals(k, g["nrm%d" % k], int(g["two_side%d" % k]))
-acc.commit()
+acc.commit(build="host")
 c = g["camera"]; cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
 ts = []
 for it in range(frames):

@@ -12,7 +12,7 @@ for k in range(int(g["ngeoms"])):
     acc.add_mesh(g["pos%d" % k], g["idx%d" % k])
     if ("nrm%d" % k) in g.files:
         acc.set_normals(k, g["nrm%d" % k], int(g["two_side%d" % k]))
-acc.commit()
+acc.commit(build="host")
 c = g["camera"]; cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
 out = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
 for it in range(3):

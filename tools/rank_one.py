@@ -13,7 +13,7 @@ g = np.load(os.path.join(ROOT, "tests", "golden", "ao_c1.npz"))
 acc = la.HipAccel(0)
 for k in range(int(g["ngeoms"])):
     P, I = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess); acc.add_mesh(P, I)
-acc.commit()
+acc.commit(build="host")
 c = g["camera"]; cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
 if world == 1:
     brow = size

@@ -18,7 +18,7 @@ for k in range(int(g["ngeoms"])):
     acc.add_mesh(g["pos%d" % k], g["idx%d" % k])
     if ("nrm%d" % k) in g.files:
         acc.set_normals(k, g["nrm%d" % k], int(g["two_side%d" % k]))
-info = acc.commit()
+info = acc.commit(build="host")
 c = g["camera"]; cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
 KW = dict(kd=0.8, env=(1.0, 1.0, 1.0), max_vertices=8, seed=7)
 def t_tile(x0, y0, w, h):

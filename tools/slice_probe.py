@@ -11,7 +11,7 @@ g = np.load(os.path.join(ROOT, "tests", "golden", "ao_c1.npz"))
 acc = la.HipAccel(0)
 for k in range(int(g["ngeoms"])):
     P, I = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess); acc.add_mesh(P, I)
-acc.commit()
+acc.commit(build="host")
 c = g["camera"]; cam = la.Camera.make(4096, 4096, c[16], c[:16], int(c[19]))
 org, dr = acc.primary_rays(cam, 0, 0, 4096, 4096, 1)
 n = org.shape[0]

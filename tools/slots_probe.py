@@ -10,7 +10,7 @@ P, idx, org, dr = po.soup(1000000, nr)
 o = torch.from_numpy(org).cuda(); d = torch.from_numpy(dr).cuda()
 for ma, tb, ch in ((32, 8, 64), (32, 8, 256), (32, 8, 512), (32, 8, 2048), (40, 8, 512), (48, 8, 512), (56, 8, 512), (40, 16, 512), (48, 4, 512)):
     os.environ["LH_MIN_ACTIVE"] = str(ma); os.environ["LH_TRI_BATCH"] = str(tb); os.environ["LH_RAY_CHUNK"] = str(ch)
-    acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit()
+    acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit(build="host")
     for mode in (0,):
         print("min_active", ma, "tri_batch", tb, "chunk", ch, flush=True)
         out, cnt = acc.intersect_device(o, d, mode=mode, counters=True)

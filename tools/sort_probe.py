@@ -10,7 +10,7 @@ bits = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 P, idx, st = scenes.soup_triangles(1000000, 0.005)
 ho, hd, _ = scenes.soup_rays(n, st)
 o = torch.from_numpy(ho).cuda(); d = torch.from_numpy(hd).cuda()
-acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit()
+acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit(build="host")
 def t(o, d):
     out = acc.intersect_device(o, d); torch.cuda.synchronize(); ts = []
     for _ in range(3):

@@ -23,7 +23,7 @@ def timeit(acc, mode, variant, reps=3, o=d_org, d=d_dir):
 
 def mk(env=None):
     for k, v in (env or {}).items(): os.environ[k] = str(v)
-    acc = la.HipAccel(0); acc.add_mesh(P, idx); info = acc.commit()
+    acc = la.HipAccel(0); acc.add_mesh(P, idx); info = acc.commit(build="host")
     for k in (env or {}): os.environ.pop(k, None)
     return acc, info
 

@@ -17,7 +17,7 @@ for on_device in (False, True):
     acc = la.HipAccel(0)
     for P, I in meshes:
         acc.add_mesh(P, I)
-    t0 = time.perf_counter(); info = acc.commit(on_device=on_device); tc = time.perf_counter() - t0
+    t0 = time.perf_counter(); info = acc.commit(build="device" if on_device else "host"); tc = time.perf_counter() - t0
     acc.wait_exact()
     if os.environ.get("LH_STACK_CAP"):
         acc.set_param("stack_cap", int(os.environ["LH_STACK_CAP"])); acc.set_param("grid", 256 * int(os.environ.get("LH_WG_PER_CU", "3")))

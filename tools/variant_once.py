@@ -9,7 +9,7 @@ v = int(sys.argv[1]); nr = int(sys.argv[2]) if len(sys.argv) > 2 else 20000000
 P, idx, st = scenes.soup_triangles(1000000, 0.005)
 ho, hd, _ = scenes.soup_rays(nr, st)
 o = torch.from_numpy(ho).cuda(); d = torch.from_numpy(hd).cuda()
-acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit()
+acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit(build="host")
 for kv in sys.argv[3:]:
     k, val = kv.split("="); acc.set_param(k, int(val))
 out = acc.intersect_device(o[:1000000], d[:1000000], variant=v); torch.cuda.synchronize()
