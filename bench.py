@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--half-extent", type=float, default=0.005)
     ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--build", choices=["auto", "host", "device"], default="auto",
+                    help="builders of the headline leg's scene: auto = lh_accel_commit's own choice (the device builders from 1 M triangles on)")
     ap.add_argument("--mode", choices=["closest", "any"], default="closest")
     ap.add_argument("--chunks", type=int, default=4, help="N>1: trace/gather pipeline depth per rank (with_record_gather)")
     ap.add_argument("--gather-records", action="store_true", help="N>1: gather every hit record to rank 0 inside the headline's timed region")
@@ -172,7 +174,8 @@ def main():
 
     # ONE host build (rank 0), then the flattened scene into every rank's HBM: ncclBroadcast
     acc = la.HipAccel(local)
-    info, commit_s, bcast_s = shard.commit_shared(acc, lambda a: a.add_mesh(P, idx), rank, world, build="host")       # the timed trees are the host builder's, as in rounds 1-2 (the library's own choice from 1 M triangles on is the device: ao_render.device_build)
+    info, commit_s, bcast_s = shard.commit_shared(acc, lambda a: a.add_mesh(P, idx), rank, world, build=args.build)     # auto: what lh_accel_commit(accel, 0) does by itself
+    device_built = info["nnodes"] == info["nnodes_traversal"]          # a device-built scene has no 2-wide nodes of its own
 
     mode = la.MODE_CLOSEST if args.mode == "closest" else la.MODE_ANY
     rec_bytes = 28 if mode == la.MODE_CLOSEST else 1
@@ -268,6 +271,24 @@ def main():
             one_step(False, True)
         torch.cuda.synchronize(dev); barrier()
         gather_elapsed = shard.all_reduce_max((time.perf_counter() - tg) / gsteps)
+    # the same dump on the OTHER builder's tree (N = 1; secondary figure: what the choice of builder costs or gains)
+    other = None
+    if world == 1 and args.build == "auto" and n > 0:
+        acc_o = la.HipAccel(local); acc_o.add_mesh(P, idx)
+        t0o = time.perf_counter(); info_o = acc_o.commit(build="host" if device_built else "device"); commit_o = time.perf_counter() - t0o
+        buf_o = torch.empty(max(n, 1) * rec_bytes, dtype=torch.uint8, device=dev)
+        out_o = record_views(torch, buf_o, max(n, 1))[:4] if mode == la.MODE_CLOSEST else (buf_o[:max(n, 1)],)
+        acc_o.intersect_device(d_org[:n], d_dir[:n], out=tuple(x[:n] for x in out_o), mode=mode, variant=args.variant); torch.cuda.synchronize(dev)
+        to = []
+        for _ in range(3):
+            t0o = time.perf_counter()
+            acc_o.intersect_device(d_org[:n], d_dir[:n], out=tuple(x[:n] for x in out_o), mode=mode, variant=args.variant); torch.cuda.synchronize(dev)
+            to.append(time.perf_counter() - t0o)
+        (o_m, m_m) = outs_of(0)
+        same = all(bool(torch.equal(a_[:min(n, m_m)], b_[:min(n, m_m)])) for a_, b_ in zip(out_o, o_m)) if (nchunks == 1 and m_m > 0) else None
+        other = {"builder": "host" if device_built else "device", "value": round(n / min(to) / 1e6, 2), "unit": "Mrays/s", "commit_s": round(commit_o, 3),
+                 "nodes": info_o["nnodes_traversal"], "depth": info_o["max_depth"], "records_bit_equal": same}
+        acc_o.close(); del buf_o, out_o
     kms = evp.ms()
     launches_per_step = sum(1 for c in range(nchunks) if cb[c][1] > cb[c][0]) if head_gather else (1 if n > 0 else 0)
     kernel_ms = float(np.sum(kms)) / max(1, args.steps)            # per step, this rank's launches together
@@ -352,8 +373,9 @@ def main():
                        "variant": args.variant, "parallelism": "replicated BVH, ray slices x%d%s" % (world, "" if world == 1 else (", %d-chunk trace/gather pipeline" % nchunks if args.gather_records else ", one launch per rank, no per-ray exchange")),
                        "scene_load": {"rank0_commit_s": round(commit_s, 3), "broadcast_s": round(bcast_s, 3) if world > 1 else None,
                                       "transport": None if world == 1 else ("rccl" if shard.dist().transport == la.DIST_RCCL else "shm (ranks share a device)"),
-                                      "note": "one host build on rank 0, flattened arrays broadcast to every rank (lh_dist_broadcast_scene)"},
-                       "bvh": {"builder": "host, asked for (rounds stay comparable); lh_accel_commit's own choice from 1 M triangles on is the device builders, see ao_render.device_build",
+                                      "note": "one build on rank 0, flattened arrays broadcast to every rank (lh_dist_broadcast_scene)"},
+                       "bvh": {"builder": ("device" if device_built else "host") + (": lh_accel_commit's own choice at this size (the device builders from 1 M triangles on)" if args.build == "auto" else ", asked for"),
+                               "other_builder": other,
                                "nodes": info["nnodes_traversal"], "depth": info["max_depth"], "device_bytes": info["device_bytes"],
                                "build_s": round(info["build_seconds"], 3), "ref_tree_build_s": round(info["ref_build_seconds"], 3)}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -369,6 +391,9 @@ def main():
         if digest is not None:
             validation["digest_all_ranks"] = dict(digest, hit_rate=round(digest["hits"] / max(1, n_total), 4))
             validation["ok"] = bool(validation["ok"]) and 0.5 < digest["hits"] / max(1, n_total) < 0.99
+        if validation is not None and other is not None and other["records_bit_equal"] is not None:
+            validation["records_equal_on_the_other_builders_tree"] = other["records_bit_equal"]       # hit records do not depend on the tree
+            validation["ok"] = bool(validation["ok"]) and bool(other["records_bit_equal"])
         if gather_elapsed is not None:
             res["with_record_gather"] = {"value": round(n_total / gather_elapsed / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(gather_elapsed * 1e3, 3),
                                          "bytes_to_rank0_per_step": int(rec_bytes * (n_total - n)),

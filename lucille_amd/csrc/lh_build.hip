@@ -551,20 +551,82 @@ __device__ __forceinline__ void quant_axis(double g, double st, float lo, float 
     w = (uint32_t)ql | ((uint32_t)qh << 16);
 }
 
+/* ---- which binary nodes become 4-wide nodes (the host builder's rule, lh_bvh.c dp4_fill) ------------------------------
+ * A ray pays one record per 4-wide node whose box it enters, so the expected cost of a collapse is the sum of the areas of the
+ * binary nodes kept as 4-wide nodes.  cost[k-1] of a binary node = the cheapest way to hang its subtree into k free child slots
+ * of a 4-wide parent: as one 4-wide node of its own (its area + the best split of ITS four slots over its two children), or
+ * dissolved into its two children with the k slots split i : k - i (split[k-1] = i; 0 = a node of its own; split[0] = how its
+ * own four slots are shared).  Children before parents: the binary tree's levels (k_bfs_level) in reverse.  The greedy rule
+ * of round 2 -- open the child of largest area until four slots are full -- is LH_DEVICE_COLLAPSE=greedy. */
+struct DP4 { double cost[4]; uint8_t split[4]; uint8_t pad[4]; };
+
+__device__ __forceinline__ bool is_inner(const BNode *__restrict__ nodes, int ref) { return ref >= 0 && !nodes[ref].leaf; }
+
+__global__ void k_bfs_level(uint32_t nin, const uint32_t *__restrict__ in, const BNode *__restrict__ nodes, uint32_t *__restrict__ out, uint32_t *__restrict__ cursor)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nin) return;
+    const BNode &b = nodes[in[i]];
+    if (is_inner(nodes, b.left)) out[atomicAdd(cursor, 1u)] = (uint32_t)b.left;
+    if (is_inner(nodes, b.right)) out[atomicAdd(cursor, 1u)] = (uint32_t)b.right;
+}
+
+__global__ void k_dp_level(uint32_t cnt, const uint32_t *__restrict__ list, const BNode *__restrict__ nodes, DP4 *__restrict__ dp)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cnt) return;
+    const uint32_t b = list[t];
+    const BNode &nd = nodes[b];
+    double cl[4] = {0.0, 0.0, 0.0, 0.0}, cr[4] = {0.0, 0.0, 0.0, 0.0};      /* [i]: the child's subtree into i slots */
+    if (is_inner(nodes, nd.left)) for (int i = 1; i <= 3; i++) cl[i] = dp[nd.left].cost[i - 1];
+    if (is_inner(nodes, nd.right)) for (int i = 1; i <= 3; i++) cr[i] = dp[nd.right].cost[i - 1];
+    double g[5]; uint8_t gi[5];
+    for (int k = 2; k <= 4; k++) {
+        g[k] = 1e300; gi[k] = 1;
+        for (int i = 1; i < k; i++) { const double c = cl[i] + cr[k - i]; if (c < g[k]) { g[k] = c; gi[k] = (uint8_t)i; } }
+    }
+    DP4 o;
+    o.cost[0] = (double)half_area(nd.lo, nd.hi) + g[4]; o.split[0] = gi[4];
+    for (int k = 2; k <= 4; k++) {
+        if (o.cost[0] <= g[k]) { o.cost[k - 1] = o.cost[0]; o.split[k - 1] = 0; }
+        else { o.cost[k - 1] = g[k]; o.split[k - 1] = gi[k]; }
+    }
+    for (int k = 0; k < 4; k++) o.pad[k] = 0;
+    dp[b] = o;
+}
+
 /* one level of the 4-wide collapse: work item = (binary node, index of its 4-wide node) */
 __global__ void k_collapse_level(uint32_t nwork, const uint2 *__restrict__ work_in, uint2 *__restrict__ work_out,
                                  uint32_t *__restrict__ counters /* [0] next 4-wide index, [1] work_out count */,
                                  const BNode *__restrict__ nodes, const uint32_t *__restrict__ sorted,
                                  const float *__restrict__ plo, const float *__restrict__ phi,
-                                 const float3 glo, const float3 gstep, lh_q4node_t *__restrict__ q4, int leaf_max)
+                                 const float3 glo, const float3 gstep, lh_q4node_t *__restrict__ q4, int leaf_max, const DP4 *__restrict__ dp)
 {
     const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
     if (wi >= nwork) return;
     const int b = (int)work_in[wi].x; const uint32_t k4 = work_in[wi].y;
     Child ch[4]; int n = 2;
+    if (dp) {
+        /* the four slots as the table says: (subtree, slots) pairs, a subtree dissolving into its children while its entry says so */
+        int sr[6], sk[6], sp = 0;
+        const int i0 = dp[b].split[0];
+        n = 0;
+        sr[sp] = nodes[b].right; sk[sp] = 4 - i0; sp++;
+        sr[sp] = nodes[b].left; sk[sp] = i0; sp++;
+        while (sp > 0) {
+            sp--;
+            const int ref = sr[sp], k = sk[sp];
+            const int i = (is_inner(nodes, ref) && k >= 2) ? (int)dp[ref].split[k - 1] : 0;
+            if (i != 0) {
+                sr[sp] = nodes[ref].right; sk[sp] = k - i; sp++;
+                sr[sp] = nodes[ref].left; sk[sp] = i; sp++;
+            } else child_of(nodes, sorted, plo, phi, ref, ch[n++], leaf_max);
+        }
+    } else {
     child_of(nodes, sorted, plo, phi, nodes[b].left, ch[0], leaf_max);
     child_of(nodes, sorted, plo, phi, nodes[b].right, ch[1], leaf_max);
-    while (n < 4) {
+    }
+    while (!dp && n < 4) {
         int best = -1; float ba = -1.0f;
         for (int c = 0; c < n; c++)
             if (ch[c].node >= 0) {
@@ -746,7 +808,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     const uint32_t n = ntris;
     float *plo = NULL, *phi = NULL; uint32_t *scene = NULL, *val_in = NULL, *sorted = NULL, *counters = NULL, *ncut = NULL; float *boxes = NULL; CutRoot *cuts = NULL;
     uint64_t *key_in = NULL, *key = NULL; int *leaf_parent = NULL, *bad = NULL; BNode *nodes = NULL; void *tmp = NULL; size_t tmp_bytes = 0;
-    uint2 *work[2] = {NULL, NULL}; lh_q4node_t *q4 = NULL; lh_q8node_t *q8 = NULL; lh_tri32_t *t32 = NULL; uint32_t *lay = NULL, need_rows = 0; std::vector<uint32_t> lvl_begin;
+    uint2 *work[2] = {NULL, NULL}; DP4 *dp = NULL; uint32_t *bfs = NULL; lh_q4node_t *q4 = NULL; lh_q8node_t *q8 = NULL; lh_tri32_t *t32 = NULL; uint32_t *lay = NULL, need_rows = 0; std::vector<uint32_t> lvl_begin;
     const unsigned nb = (n + 255) / 256;
     uint32_t h_scene[6], h_cnt[2], level = 0, nwork = 0, nq = 1;
     const uint32_t init_scene[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
@@ -758,6 +820,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     { const char *e = getenv("LH_DEVICE_CUT"); if (e && atoi(e) >= 0) cut = (uint32_t)atoi(e); }
     const uint32_t cut_cap = cut ? (uint32_t)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(65536u, 16ull * n / cut)) : 0u;
     int root_ref = 0;
+    const bool use_dp = !(getenv("LH_DEVICE_COLLAPSE") && strcmp(getenv("LH_DEVICE_COLLAPSE"), "greedy") == 0);
     *d_q4nodes = NULL; *d_tri32 = NULL; *nq4 = 0; *q4_depth = 0; *q4_stack = 0; *d_q8nodes = NULL; *nq8 = 0; *q8_depth = 0;
     if (n == 0) return 0;
     /* LH_BUILD_TIMING=1: phase times on stderr (each mark synchronises the stream: diagnostics only) */
@@ -848,6 +911,10 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
             BCHK(hipMalloc((void **)&counters, sizeof(uint32_t) * 2));
             BCHK(hipMalloc((void **)&lay, sizeof(uint32_t) * ((size_t)n + 1)));
             if (cut_cap) { BCHK(hipMalloc((void **)&cuts, sizeof(CutRoot) * (size_t)cut_cap)); BCHK(hipMalloc((void **)&ncut, sizeof(uint32_t))); }
+            if (use_dp) {
+                BCHK(hipMalloc((void **)&dp, sizeof(DP4) * ((size_t)(n - 1) + cut_cap)));
+                BCHK(hipMalloc((void **)&bfs, sizeof(uint32_t) * ((size_t)(n - 1) + cut_cap + 1)));
+            }
             /* top + collapse + the rows its deepest path needs.  A finer cut gives the better tree (config 5: 92.7 ms at 256 against
              * 93.9 at 1024) unless it makes the tree one level too deep for the unchecked walk's 64 LDS rows (97.6 ms): then the next
              * coarser cut is tried -- a second attempt costs ~25 ms of a 0.2 s commit */
@@ -870,6 +937,27 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                     }
                     mark("SAH over the subtree roots");
                 }
+                if (use_dp) {
+                    /* the binary tree's levels from the root, then the table from the deepest level up */
+                    std::vector<uint32_t> lb2; uint32_t tot = 1, h_c = 0;
+                    const uint32_t rr = (uint32_t)root_ref;
+                    BCHK(hipMemcpyAsync(bfs, &rr, sizeof(rr), hipMemcpyHostToDevice, s));
+                    lb2.push_back(0); lb2.push_back(1);
+                    while (lb2[lb2.size() - 1] > lb2[lb2.size() - 2]) {
+                        const uint32_t b0 = lb2[lb2.size() - 2], b1 = lb2[lb2.size() - 1];
+                        BCHK(hipMemsetAsync(counters, 0, sizeof(uint32_t), s));
+                        hipLaunchKernelGGL(k_bfs_level, dim3((b1 - b0 + 255) / 256), dim3(256), 0, s, b1 - b0, (const uint32_t *)(bfs + b0), (const BNode *)nodes, bfs + b1, counters);
+                        BCHK(hipMemcpyAsync(&h_c, counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                        BCHK(hipStreamSynchronize(s));
+                        tot += h_c; lb2.push_back(tot);
+                        if (lb2.size() > 4096) { snprintf(err, errlen, "device build: the binary tree is more than 4096 levels deep"); goto fail; }
+                    }
+                    for (size_t l = lb2.size() - 2; l-- > 0;) {
+                        const uint32_t b0 = lb2[l], b1 = lb2[l + 1];
+                        if (b1 > b0) hipLaunchKernelGGL(k_dp_level, dim3((b1 - b0 + 255) / 256), dim3(256), 0, s, b1 - b0, (const uint32_t *)(bfs + b0), (const BNode *)nodes, dp);
+                    }
+                    mark("slots table of the collapse");
+                }
                 /* level-by-level collapse; every level's children are allocated adjacently */
                 {
                     const uint2 root = make_uint2((uint32_t)root_ref, 0u);
@@ -880,7 +968,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                     h_cnt[0] = nq; h_cnt[1] = 0;
                     BCHK(hipMemcpyAsync(counters, h_cnt, sizeof(h_cnt), hipMemcpyHostToDevice, s));
                     hipLaunchKernelGGL(k_collapse_level, dim3((nwork + 127) / 128), dim3(128), 0, s, nwork, (const uint2 *)work[level & 1], work[(level + 1) & 1],
-                                       counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q4, leaf_max);
+                                       counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q4, leaf_max, (const DP4 *)dp);
                     BCHK(hipMemcpyAsync(h_cnt, counters, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
                     BCHK(hipStreamSynchronize(s));
                     lvl_begin.push_back(nq);                                  /* first index of the level the kernel just filled */
@@ -939,12 +1027,12 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     mark("tri32 records");
     *d_q4nodes = q4; *d_q8nodes = q8; *d_tri32 = t32; *nq4 = nq; *q4_depth = level; *q4_stack = nq > 1 ? need_rows + 5u : 0u;     /* LDS stack rows the walk needs (0: unknown, 3 x depth + 5) */
     dfree(plo); dfree(phi); dfree(scene); dfree(bad); dfree(key_in); dfree(key); dfree(val_in); dfree(sorted);
-    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters);
+    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters); dfree(dp); dfree(bfs);
     mark("free temporaries");
     return 0;
 fail:
     dfree(plo); dfree(phi); dfree(scene); dfree(bad); dfree(key_in); dfree(key); dfree(val_in); dfree(sorted);
-    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters);
+    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters); dfree(dp); dfree(bfs);
     dfree(q4); dfree(q8); dfree(t32);
     return -1;
 }

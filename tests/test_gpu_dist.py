@@ -55,7 +55,7 @@ d = la.HipDist(rank, world, 0, rendezvous=rdv)
 P, idx, org, dr = po.soup(40000, 60000, 0.01, 77)
 acc = la.HipAccel(0)
 if rank == 0:
-    acc.add_mesh(P, idx); acc.commit()
+    acc.add_mesh(P, idx); acc.commit(build=sys.argv[5])
 d.broadcast_scene(acc)
 info = acc.info()
 got = acc.intersect_host(org, dr)
@@ -72,13 +72,15 @@ d.close(); acc.close()
 """
 
 
-def test_scene_broadcast_gives_every_rank_the_same_records(tmp_path):
+@pytest.mark.parametrize("build", ["host", "device"])
+def test_scene_broadcast_gives_every_rank_the_same_records(tmp_path, build):
     """lh_dist_broadcast_scene: rank 1 never sees the meshes and never builds -- it receives rank 0's flattened arrays
-    (traversal nodes, triangle records, lucille's own tree, primitive lookup) and answers ray batches with the oracle's bits"""
+    (traversal nodes, triangle records, lucille's own tree, primitive lookup) and answers ray batches with the oracle's bits;
+    the same when rank 0 built both trees on its device (they exist in HBM only)"""
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT % {"root": ROOT})
     rdv = str(tmp_path / "rdv")
-    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", rdv, str(tmp_path / ("out%d.npz" % r))],
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", rdv, str(tmp_path / ("out%d.npz" % r)), build],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
     outs = [p.communicate(timeout=600) for p in procs]
     for p, (so, se) in zip(procs, outs):
