@@ -558,7 +558,9 @@ __device__ __forceinline__ void quant_axis(double g, double st, float lo, float 
  * dissolved into its two children with the k slots split i : k - i (split[k-1] = i; 0 = a node of its own; split[0] = how its
  * own four slots are shared).  Children before parents: the binary tree's levels (k_bfs_level) in reverse.  The greedy rule
  * of round 2 -- open the child of largest area until four slots are full -- is LH_DEVICE_COLLAPSE=greedy. */
-struct DP4 { double cost[4]; uint8_t split[4]; uint8_t pad[4]; };
+template <int W> struct DPW { double cost[W]; uint8_t split[W]; };
+typedef DPW<4> DP4;
+typedef DPW<8> DP8;
 
 __device__ __forceinline__ bool is_inner(const BNode *__restrict__ nodes, int ref) { return ref >= 0 && !nodes[ref].leaf; }
 
@@ -571,28 +573,51 @@ __global__ void k_bfs_level(uint32_t nin, const uint32_t *__restrict__ in, const
     if (is_inner(nodes, b.right)) out[atomicAdd(cursor, 1u)] = (uint32_t)b.right;
 }
 
-__global__ void k_dp_level(uint32_t cnt, const uint32_t *__restrict__ list, const BNode *__restrict__ nodes, DP4 *__restrict__ dp)
+template <int W>
+__global__ void k_dp_level(uint32_t cnt, const uint32_t *__restrict__ list, const BNode *__restrict__ nodes, DPW<W> *__restrict__ dp)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= cnt) return;
     const uint32_t b = list[t];
     const BNode &nd = nodes[b];
-    double cl[4] = {0.0, 0.0, 0.0, 0.0}, cr[4] = {0.0, 0.0, 0.0, 0.0};      /* [i]: the child's subtree into i slots */
-    if (is_inner(nodes, nd.left)) for (int i = 1; i <= 3; i++) cl[i] = dp[nd.left].cost[i - 1];
-    if (is_inner(nodes, nd.right)) for (int i = 1; i <= 3; i++) cr[i] = dp[nd.right].cost[i - 1];
-    double g[5]; uint8_t gi[5];
-    for (int k = 2; k <= 4; k++) {
+    double cl[W], cr[W];                                  /* [i]: the child's subtree into i slots */
+    for (int i = 0; i < W; i++) { cl[i] = 0.0; cr[i] = 0.0; }
+    if (is_inner(nodes, nd.left)) for (int i = 1; i < W; i++) cl[i] = dp[nd.left].cost[i - 1];
+    if (is_inner(nodes, nd.right)) for (int i = 1; i < W; i++) cr[i] = dp[nd.right].cost[i - 1];
+    double g[W + 1]; uint8_t gi[W + 1];
+    for (int k = 2; k <= W; k++) {
         g[k] = 1e300; gi[k] = 1;
         for (int i = 1; i < k; i++) { const double c = cl[i] + cr[k - i]; if (c < g[k]) { g[k] = c; gi[k] = (uint8_t)i; } }
     }
-    DP4 o;
-    o.cost[0] = (double)half_area(nd.lo, nd.hi) + g[4]; o.split[0] = gi[4];
-    for (int k = 2; k <= 4; k++) {
+    DPW<W> o;
+    o.cost[0] = (double)half_area(nd.lo, nd.hi) + g[W]; o.split[0] = gi[W];
+    for (int k = 2; k <= W; k++) {
         if (o.cost[0] <= g[k]) { o.cost[k - 1] = o.cost[0]; o.split[k - 1] = 0; }
         else { o.cost[k - 1] = g[k]; o.split[k - 1] = gi[k]; }
     }
-    for (int k = 0; k < 4; k++) o.pad[k] = 0;
     dp[b] = o;
+}
+
+/* the W slots of wide node b as the table says: (subtree, slots) pairs, a subtree dissolving into its children while its
+ * entry says so; children come out left to right */
+template <int W>
+__device__ __forceinline__ int slots_of(const BNode *__restrict__ nodes, const uint32_t *__restrict__ sorted, const float *__restrict__ plo,
+                                        const float *__restrict__ phi, const DPW<W> *__restrict__ dp, int b, Child *ch, int leaf_max)
+{
+    int sr[W + 2], sk[W + 2], sp = 0, n = 0;
+    const int i0 = dp[b].split[0];
+    sr[sp] = nodes[b].right; sk[sp] = W - i0; sp++;
+    sr[sp] = nodes[b].left; sk[sp] = i0; sp++;
+    while (sp > 0) {
+        sp--;
+        const int ref = sr[sp], k = sk[sp];
+        const int i = (is_inner(nodes, ref) && k >= 2) ? (int)dp[ref].split[k - 1] : 0;
+        if (i != 0) {
+            sr[sp] = nodes[ref].right; sk[sp] = k - i; sp++;
+            sr[sp] = nodes[ref].left; sk[sp] = i; sp++;
+        } else child_of(nodes, sorted, plo, phi, ref, ch[n++], leaf_max);
+    }
+    return n;
 }
 
 /* one level of the 4-wide collapse: work item = (binary node, index of its 4-wide node) */
@@ -607,21 +632,7 @@ __global__ void k_collapse_level(uint32_t nwork, const uint2 *__restrict__ work_
     const int b = (int)work_in[wi].x; const uint32_t k4 = work_in[wi].y;
     Child ch[4]; int n = 2;
     if (dp) {
-        /* the four slots as the table says: (subtree, slots) pairs, a subtree dissolving into its children while its entry says so */
-        int sr[6], sk[6], sp = 0;
-        const int i0 = dp[b].split[0];
-        n = 0;
-        sr[sp] = nodes[b].right; sk[sp] = 4 - i0; sp++;
-        sr[sp] = nodes[b].left; sk[sp] = i0; sp++;
-        while (sp > 0) {
-            sp--;
-            const int ref = sr[sp], k = sk[sp];
-            const int i = (is_inner(nodes, ref) && k >= 2) ? (int)dp[ref].split[k - 1] : 0;
-            if (i != 0) {
-                sr[sp] = nodes[ref].right; sk[sp] = k - i; sp++;
-                sr[sp] = nodes[ref].left; sk[sp] = i; sp++;
-            } else child_of(nodes, sorted, plo, phi, ref, ch[n++], leaf_max);
-        }
+        n = slots_of<4>(nodes, sorted, plo, phi, dp, b, ch, leaf_max);
     } else {
     child_of(nodes, sorted, plo, phi, nodes[b].left, ch[0], leaf_max);
     child_of(nodes, sorted, plo, phi, nodes[b].right, ch[1], leaf_max);
@@ -670,15 +681,18 @@ __global__ void k_collapse_level(uint32_t nwork, const uint2 *__restrict__ work_
 __global__ void k_collapse8_level(uint32_t nwork, const uint2 *__restrict__ work_in, uint2 *__restrict__ work_out,
                                   uint32_t *__restrict__ counters, const BNode *__restrict__ nodes, const uint32_t *__restrict__ sorted,
                                   const float *__restrict__ plo, const float *__restrict__ phi, const float3 glo, const float3 gstep,
-                                  lh_q8node_t *__restrict__ q8, int leaf_max)
+                                  lh_q8node_t *__restrict__ q8, int leaf_max, const DP8 *__restrict__ dp)
 {
     const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
     if (wi >= nwork) return;
     const int b = (int)work_in[wi].x; const uint32_t k8 = work_in[wi].y;
     Child ch[8]; int n = 2;
+    if (dp) n = slots_of<8>(nodes, sorted, plo, phi, dp, b, ch, leaf_max);
+    else {
     child_of(nodes, sorted, plo, phi, nodes[b].left, ch[0], leaf_max);
     child_of(nodes, sorted, plo, phi, nodes[b].right, ch[1], leaf_max);
-    while (n < 8) {
+    }
+    while (!dp && n < 8) {
         int best = -1; float ba = -1.0f;
         for (int c = 0; c < n; c++)
             if (ch[c].node >= 0) {
@@ -808,7 +822,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     const uint32_t n = ntris;
     float *plo = NULL, *phi = NULL; uint32_t *scene = NULL, *val_in = NULL, *sorted = NULL, *counters = NULL, *ncut = NULL; float *boxes = NULL; CutRoot *cuts = NULL;
     uint64_t *key_in = NULL, *key = NULL; int *leaf_parent = NULL, *bad = NULL; BNode *nodes = NULL; void *tmp = NULL; size_t tmp_bytes = 0;
-    uint2 *work[2] = {NULL, NULL}; DP4 *dp = NULL; uint32_t *bfs = NULL; lh_q4node_t *q4 = NULL; lh_q8node_t *q8 = NULL; lh_tri32_t *t32 = NULL; uint32_t *lay = NULL, need_rows = 0; std::vector<uint32_t> lvl_begin;
+    uint2 *work[2] = {NULL, NULL}; DP4 *dp = NULL; uint32_t *bfs = NULL; lh_q4node_t *q4 = NULL; lh_q8node_t *q8 = NULL; lh_tri32_t *t32 = NULL; uint32_t *lay = NULL, need_rows = 0; std::vector<uint32_t> lvl_begin, lb2; DP8 *dp8 = NULL;
     const unsigned nb = (n + 255) / 256;
     uint32_t h_scene[6], h_cnt[2], level = 0, nwork = 0, nq = 1;
     const uint32_t init_scene[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
@@ -939,7 +953,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                 }
                 if (use_dp) {
                     /* the binary tree's levels from the root, then the table from the deepest level up */
-                    std::vector<uint32_t> lb2; uint32_t tot = 1, h_c = 0;
+                    uint32_t tot = 1, h_c = 0; lb2.clear();
                     const uint32_t rr = (uint32_t)root_ref;
                     BCHK(hipMemcpyAsync(bfs, &rr, sizeof(rr), hipMemcpyHostToDevice, s));
                     lb2.push_back(0); lb2.push_back(1);
@@ -954,7 +968,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                     }
                     for (size_t l = lb2.size() - 2; l-- > 0;) {
                         const uint32_t b0 = lb2[l], b1 = lb2[l + 1];
-                        if (b1 > b0) hipLaunchKernelGGL(k_dp_level, dim3((b1 - b0 + 255) / 256), dim3(256), 0, s, b1 - b0, (const uint32_t *)(bfs + b0), (const BNode *)nodes, dp);
+                        if (b1 > b0) hipLaunchKernelGGL(k_dp_level<4>, dim3((b1 - b0 + 255) / 256), dim3(256), 0, s, b1 - b0, (const uint32_t *)(bfs + b0), (const BNode *)nodes, dp);
                     }
                     mark("slots table of the collapse");
                 }
@@ -997,6 +1011,14 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                  * node that opens eight small subtrees leaves eight nodes where the 4-wide collapse leaves four): the first
                  * pass only counts, the second writes into an allocation of exactly that size */
                 uint32_t nw8 = 0, n8 = 0, lev8 = 0, n8_counted = 0;
+                if (use_dp && lb2.size() >= 2) {
+                    /* the slot table for eight slots, over the same levels of the binary tree */
+                    BCHK(hipMalloc((void **)&dp8, sizeof(DP8) * ((size_t)(n - 1) + cut_cap)));
+                    for (size_t l = lb2.size() - 2; l-- > 0;) {
+                        const uint32_t b0 = lb2[l], b1 = lb2[l + 1];
+                        if (b1 > b0) hipLaunchKernelGGL(k_dp_level<8>, dim3((b1 - b0 + 255) / 256), dim3(256), 0, s, b1 - b0, (const uint32_t *)(bfs + b0), (const BNode *)nodes, dp8);
+                    }
+                }
                 for (int pass = 0; pass < 2; pass++) {
                     if (pass == 1) { n8_counted = n8; BCHK(hipMalloc((void **)&q8, sizeof(lh_q8node_t) * (size_t)n8_counted)); }
                     {
@@ -1008,7 +1030,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                         h_cnt[0] = n8; h_cnt[1] = 0;
                         BCHK(hipMemcpyAsync(counters, h_cnt, sizeof(h_cnt), hipMemcpyHostToDevice, s));
                         hipLaunchKernelGGL(k_collapse8_level, dim3((nw8 + 127) / 128), dim3(128), 0, s, nw8, (const uint2 *)work[lev8 & 1], work[(lev8 + 1) & 1],
-                                           counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q8, leaf_max);
+                                           counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q8, leaf_max, (const DP8 *)dp8);
                         BCHK(hipMemcpyAsync(h_cnt, counters, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
                         BCHK(hipStreamSynchronize(s));
                         n8 = h_cnt[0]; nw8 = h_cnt[1]; lev8++;
@@ -1027,12 +1049,12 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     mark("tri32 records");
     *d_q4nodes = q4; *d_q8nodes = q8; *d_tri32 = t32; *nq4 = nq; *q4_depth = level; *q4_stack = nq > 1 ? need_rows + 5u : 0u;     /* LDS stack rows the walk needs (0: unknown, 3 x depth + 5) */
     dfree(plo); dfree(phi); dfree(scene); dfree(bad); dfree(key_in); dfree(key); dfree(val_in); dfree(sorted);
-    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters); dfree(dp); dfree(bfs);
+    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters); dfree(dp); dfree(dp8); dfree(bfs);
     mark("free temporaries");
     return 0;
 fail:
     dfree(plo); dfree(phi); dfree(scene); dfree(bad); dfree(key_in); dfree(key); dfree(val_in); dfree(sorted);
-    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters); dfree(dp); dfree(bfs);
+    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters); dfree(dp); dfree(dp8); dfree(bfs);
     dfree(q4); dfree(q8); dfree(t32);
     return -1;
 }
