@@ -271,7 +271,9 @@ __global__ void k_node_boxes(int n, BNode *__restrict__ nodes, const BoxTable T,
  * the sorted positions a .. b is rooted at inner node a or b and owns, besides its root, exactly the inner nodes a + 1 .. b - 1;
  * the root keeps its index, so everything above still points at it.)  Boxes and leaf decisions come afterwards, from the same
  * range queries as for every other node. */
+#ifndef LH_SUB_MAX
 #define LH_SUB_MAX 512
+#endif
 
 __global__ void k_sub_roots(int n, const BNode *__restrict__ nodes, uint32_t sub_max, uint32_t *__restrict__ out, uint32_t *__restrict__ nout)
 {
