@@ -627,9 +627,12 @@ __global__ void k_collapse_level(uint32_t nwork, const uint2 *__restrict__ work_
                                  uint32_t *__restrict__ counters /* [0] next 4-wide index, [1] work_out count */,
                                  const BNode *__restrict__ nodes, const uint32_t *__restrict__ sorted,
                                  const float *__restrict__ plo, const float *__restrict__ phi,
-                                 const float3 glo, const float3 gstep, lh_q4node_t *__restrict__ q4, int leaf_max, const DP4 *__restrict__ dp)
+                                 const float3 glo, const float3 gstep, lh_q4node_t *__restrict__ q4, int leaf_max, const DP4 *__restrict__ dp,
+                                 uint32_t *__restrict__ cnt_out /* counting pass: inner children per work item, [nwork] = 0 */,
+                                 const uint32_t *__restrict__ offs /* emitting pass: their exclusive prefix sum */, uint32_t node_base)
 {
     const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cnt_out && wi == nwork) cnt_out[wi] = 0u;
     if (wi >= nwork) return;
     const int b = (int)work_in[wi].x; const uint32_t k4 = work_in[wi].y;
     Child ch[4]; int n = 2;
@@ -655,8 +658,13 @@ __global__ void k_collapse_level(uint32_t nwork, const uint2 *__restrict__ work_
     }
     int ninner = 0;
     for (int c = 0; c < n; c++) ninner += ch[c].node >= 0;
+    if (cnt_out) { cnt_out[wi] = (uint32_t)ninner; return; }
+    /* children are numbered in the order of their parents (a prefix sum over the level's work items, not an atomic counter whose
+     * order is whoever arrives first): neighbours in space stay neighbours in the array at every level, as in the host builder's
+     * level order */
     uint32_t base4 = 0, basew = 0;
-    if (ninner) { base4 = atomicAdd(&counters[0], (uint32_t)ninner); basew = atomicAdd(&counters[1], (uint32_t)ninner); }
+    if (offs) { base4 = node_base + offs[wi]; basew = offs[wi]; }
+    else if (ninner) { base4 = atomicAdd(&counters[0], (uint32_t)ninner); basew = atomicAdd(&counters[1], (uint32_t)ninner); }
     lh_q4node_t out;
     const double g[3] = {glo.x, glo.y, glo.z}, st[3] = {gstep.x, gstep.y, gstep.z};
     int slot = 0;
@@ -683,9 +691,11 @@ __global__ void k_collapse_level(uint32_t nwork, const uint2 *__restrict__ work_
 __global__ void k_collapse8_level(uint32_t nwork, const uint2 *__restrict__ work_in, uint2 *__restrict__ work_out,
                                   uint32_t *__restrict__ counters, const BNode *__restrict__ nodes, const uint32_t *__restrict__ sorted,
                                   const float *__restrict__ plo, const float *__restrict__ phi, const float3 glo, const float3 gstep,
-                                  lh_q8node_t *__restrict__ q8, int leaf_max, const DP8 *__restrict__ dp)
+                                  lh_q8node_t *__restrict__ q8, int leaf_max, const DP8 *__restrict__ dp,
+                                  uint32_t *__restrict__ cnt_out, const uint32_t *__restrict__ offs, uint32_t node_base)
 {
     const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cnt_out && wi == nwork) cnt_out[wi] = 0u;
     if (wi >= nwork) return;
     const int b = (int)work_in[wi].x; const uint32_t k8 = work_in[wi].y;
     Child ch[8]; int n = 2;
@@ -710,8 +720,10 @@ __global__ void k_collapse8_level(uint32_t nwork, const uint2 *__restrict__ work
     }
     int ninner = 0;
     for (int c = 0; c < n; c++) ninner += ch[c].node >= 0;
+    if (cnt_out) { cnt_out[wi] = (uint32_t)ninner; return; }
     uint32_t base8 = 0, basew = 0;
-    if (ninner) { base8 = atomicAdd(&counters[0], (uint32_t)ninner); basew = atomicAdd(&counters[1], (uint32_t)ninner); }
+    if (offs) { base8 = node_base + offs[wi]; basew = offs[wi]; }
+    else if (ninner) { base8 = atomicAdd(&counters[0], (uint32_t)ninner); basew = atomicAdd(&counters[1], (uint32_t)ninner); }
     if (!q8) {                                            /* counting pass: only the work list of the next level */
         int slot = 0;
         for (int c = 0; c < n; c++)
@@ -824,9 +836,9 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     const uint32_t n = ntris;
     float *plo = NULL, *phi = NULL; uint32_t *scene = NULL, *val_in = NULL, *sorted = NULL, *counters = NULL, *ncut = NULL; float *boxes = NULL; CutRoot *cuts = NULL;
     uint64_t *key_in = NULL, *key = NULL; int *leaf_parent = NULL, *bad = NULL; BNode *nodes = NULL; void *tmp = NULL; size_t tmp_bytes = 0;
-    uint2 *work[2] = {NULL, NULL}; DP4 *dp = NULL; uint32_t *bfs = NULL; lh_q4node_t *q4 = NULL; lh_q8node_t *q8 = NULL; lh_tri32_t *t32 = NULL; uint32_t *lay = NULL, need_rows = 0; std::vector<uint32_t> lvl_begin, lb2; DP8 *dp8 = NULL;
+    uint2 *work[2] = {NULL, NULL}; DP4 *dp = NULL; uint32_t *bfs = NULL; lh_q4node_t *q4 = NULL; lh_q8node_t *q8 = NULL; lh_tri32_t *t32 = NULL; uint32_t *lay = NULL, *offs = NULL, need_rows = 0; std::vector<uint32_t> lvl_begin, lb2; DP8 *dp8 = NULL;
     const unsigned nb = (n + 255) / 256;
-    uint32_t h_scene[6], h_cnt[2], level = 0, nwork = 0, nq = 1;
+    uint32_t h_scene[6], level = 0, nwork = 0, nq = 1;
     const uint32_t init_scene[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     int h_bad = 0, leaf_max = LH_MAX_LEAF_TRIS;     /* leaves of up to 4 triangles WHERE THE SAH SAYS SO (k_node_boxes): forced 4-triangle leaves cost S-soup-1M 37 % (tools/leaf_probe.py), the SAH keeps that soup at one per leaf */
     { const char *e = getenv("LH_DEVICE_LEAF"); if (e && atoi(e) >= 1 && atoi(e) <= LH_MAX_LEAF_TRIS) leaf_max = atoi(e); }
@@ -926,6 +938,12 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
             BCHK(hipMalloc((void **)&work[0], sizeof(uint2) * (size_t)n)); BCHK(hipMalloc((void **)&work[1], sizeof(uint2) * (size_t)n));
             BCHK(hipMalloc((void **)&counters, sizeof(uint32_t) * 2));
             BCHK(hipMalloc((void **)&lay, sizeof(uint32_t) * ((size_t)n + 1)));
+            BCHK(hipMalloc((void **)&offs, sizeof(uint32_t) * ((size_t)n + 1)));
+            {
+                size_t sb = 0;
+                BCHK(hipcub::DeviceScan::ExclusiveSum(NULL, sb, lay, offs, (int)n, s));
+                if (sb > tmp_bytes) { dfree(tmp); tmp = NULL; tmp_bytes = sb; BCHK(hipMalloc(&tmp, tmp_bytes)); }
+            }
             if (cut_cap) { BCHK(hipMalloc((void **)&cuts, sizeof(CutRoot) * (size_t)cut_cap)); BCHK(hipMalloc((void **)&ncut, sizeof(uint32_t))); }
             if (use_dp) {
                 BCHK(hipMalloc((void **)&dp, sizeof(DP4) * ((size_t)(n - 1) + cut_cap)));
@@ -981,14 +999,19 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                 }
                 nwork = 1; nq = 1; level = 0; lvl_begin.clear(); need_rows = 0;
                 while (nwork > 0) {
-                    h_cnt[0] = nq; h_cnt[1] = 0;
-                    BCHK(hipMemcpyAsync(counters, h_cnt, sizeof(h_cnt), hipMemcpyHostToDevice, s));
+                    /* count the level's inner children, prefix-sum them (children numbered in the order of their parents), emit */
+                    uint32_t total = 0;
+                    hipLaunchKernelGGL(k_collapse_level, dim3((nwork + 1 + 127) / 128), dim3(128), 0, s, nwork, (const uint2 *)work[level & 1], work[(level + 1) & 1],
+                                       counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q4, leaf_max, (const DP4 *)dp,
+                                       lay, (const uint32_t *)NULL, nq);
+                    { size_t tb = tmp_bytes; BCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, lay, offs, (int)(nwork + 1), s)); }
+                    BCHK(hipMemcpyAsync(&total, offs + nwork, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                     hipLaunchKernelGGL(k_collapse_level, dim3((nwork + 127) / 128), dim3(128), 0, s, nwork, (const uint2 *)work[level & 1], work[(level + 1) & 1],
-                                       counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q4, leaf_max, (const DP4 *)dp);
-                    BCHK(hipMemcpyAsync(h_cnt, counters, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
+                                       counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q4, leaf_max, (const DP4 *)dp,
+                                       (uint32_t *)NULL, (const uint32_t *)offs, nq);
                     BCHK(hipStreamSynchronize(s));
                     lvl_begin.push_back(nq);                                  /* first index of the level the kernel just filled */
-                    nq = h_cnt[0]; nwork = h_cnt[1]; level++;
+                    nq += total; nwork = total; level++;
                     if (level > 200) { snprintf(err, errlen, "device build: runaway collapse"); goto fail; }
                 }
                 mark("collapse to 4-wide nodes");
@@ -1029,13 +1052,17 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                     }
                     nw8 = 1; n8 = 1; lev8 = 0;
                     while (nw8 > 0) {
-                        h_cnt[0] = n8; h_cnt[1] = 0;
-                        BCHK(hipMemcpyAsync(counters, h_cnt, sizeof(h_cnt), hipMemcpyHostToDevice, s));
+                        uint32_t total = 0;
+                        hipLaunchKernelGGL(k_collapse8_level, dim3((nw8 + 1 + 127) / 128), dim3(128), 0, s, nw8, (const uint2 *)work[lev8 & 1], work[(lev8 + 1) & 1],
+                                           counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q8, leaf_max, (const DP8 *)dp8,
+                                           lay, (const uint32_t *)NULL, n8);
+                        { size_t tb = tmp_bytes; BCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, lay, offs, (int)(nw8 + 1), s)); }
+                        BCHK(hipMemcpyAsync(&total, offs + nw8, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                         hipLaunchKernelGGL(k_collapse8_level, dim3((nw8 + 127) / 128), dim3(128), 0, s, nw8, (const uint2 *)work[lev8 & 1], work[(lev8 + 1) & 1],
-                                           counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q8, leaf_max, (const DP8 *)dp8);
-                        BCHK(hipMemcpyAsync(h_cnt, counters, sizeof(h_cnt), hipMemcpyDeviceToHost, s));
+                                           counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q8, leaf_max, (const DP8 *)dp8,
+                                           (uint32_t *)NULL, (const uint32_t *)offs, n8);
                         BCHK(hipStreamSynchronize(s));
-                        n8 = h_cnt[0]; nw8 = h_cnt[1]; lev8++;
+                        n8 += total; nw8 = total; lev8++;
                         if (lev8 > 200 || n8 > n) { snprintf(err, errlen, "device build: runaway 8-wide collapse"); goto fail; }
                     }
                 }
@@ -1051,12 +1078,12 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     mark("tri32 records");
     *d_q4nodes = q4; *d_q8nodes = q8; *d_tri32 = t32; *nq4 = nq; *q4_depth = level; *q4_stack = nq > 1 ? need_rows + 5u : 0u;     /* LDS stack rows the walk needs (0: unknown, 3 x depth + 5) */
     dfree(plo); dfree(phi); dfree(scene); dfree(bad); dfree(key_in); dfree(key); dfree(val_in); dfree(sorted);
-    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters); dfree(dp); dfree(dp8); dfree(bfs);
+    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters); dfree(dp); dfree(dp8); dfree(bfs); dfree(offs);
     mark("free temporaries");
     return 0;
 fail:
     dfree(plo); dfree(phi); dfree(scene); dfree(bad); dfree(key_in); dfree(key); dfree(val_in); dfree(sorted);
-    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters); dfree(dp); dfree(dp8); dfree(bfs);
+    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters); dfree(dp); dfree(dp8); dfree(bfs); dfree(offs);
     dfree(q4); dfree(q8); dfree(t32);
     return -1;
 }
