@@ -560,6 +560,22 @@ __device__ __forceinline__ void quant_axis(double g, double st, float lo, float 
  * dissolved into its two children with the k slots split i : k - i (split[k-1] = i; 0 = a node of its own; split[0] = how its
  * own four slots are shared).  Children before parents: the binary tree's levels (k_bfs_level) in reverse.  The greedy rule
  * of round 2 -- open the child of largest area until four slots are full -- is LH_DEVICE_COLLAPSE=greedy. */
+/* node slots of a sibling group as a function of the parity of the index it starts at: a group of two or more inner children
+ * starts at an EVEN index (two 64-byte nodes share the 128-byte line the L2 fetches: a group of two costs one line instead of
+ * possibly two, a group of four two instead of possibly three), i.e. it takes one empty node first if it would start at an odd
+ * one; single children fill whatever comes.  The starts follow from a prefix "sum" over these pairs -- composition of the
+ * parity functions, associative -- so the numbering stays a scan (what the host builder does with a running index). */
+struct PL { uint32_t l0, l1; };        /* length if the start is even / odd */
+struct PLOp {
+    __host__ __device__ __forceinline__ PL operator()(const PL &a, const PL &b) const
+    {
+        PL r;
+        r.l0 = a.l0 + ((a.l0 & 1u) ? b.l1 : b.l0);
+        r.l1 = a.l1 + (((1u + a.l1) & 1u) ? b.l1 : b.l0);
+        return r;
+    }
+};
+
 template <int W> struct DPW { double cost[W]; uint8_t split[W]; };
 typedef DPW<4> DP4;
 typedef DPW<8> DP8;
@@ -628,12 +644,13 @@ __global__ void k_collapse_level(uint32_t nwork, const uint2 *__restrict__ work_
                                  const BNode *__restrict__ nodes, const uint32_t *__restrict__ sorted,
                                  const float *__restrict__ plo, const float *__restrict__ phi,
                                  const float3 glo, const float3 gstep, lh_q4node_t *__restrict__ q4, int leaf_max, const DP4 *__restrict__ dp,
-                                 uint32_t *__restrict__ cnt_out /* counting pass: inner children per work item, [nwork] = 0 */,
-                                 const uint32_t *__restrict__ offs /* emitting pass: their exclusive prefix sum */, uint32_t node_base)
+                                 PL *__restrict__ cnt_out /* counting pass: node slots per work item (by start parity), [nwork] = 0 */,
+                                 const PL *__restrict__ offs /* emitting pass: their exclusive prefix composition */, uint32_t node_base, int pair_align)
 {
     const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cnt_out && wi == nwork) cnt_out[wi] = 0u;
+    if (cnt_out && wi == nwork) { cnt_out[wi].l0 = 0u; cnt_out[wi].l1 = 0u; }
     if (wi >= nwork) return;
+    if (work_in[wi].x == 0xffffffffu) { if (cnt_out) { cnt_out[wi].l0 = 0u; cnt_out[wi].l1 = 0u; } return; }        /* a padding slot of the level above */
     const int b = (int)work_in[wi].x; const uint32_t k4 = work_in[wi].y;
     Child ch[4]; int n = 2;
     if (dp) {
@@ -658,13 +675,22 @@ __global__ void k_collapse_level(uint32_t nwork, const uint2 *__restrict__ work_
     }
     int ninner = 0;
     for (int c = 0; c < n; c++) ninner += ch[c].node >= 0;
-    if (cnt_out) { cnt_out[wi] = (uint32_t)ninner; return; }
-    /* children are numbered in the order of their parents (a prefix sum over the level's work items, not an atomic counter whose
+    if (cnt_out) { cnt_out[wi].l0 = (uint32_t)ninner; cnt_out[wi].l1 = (uint32_t)ninner + ((pair_align && ninner >= 2) ? 1u : 0u); return; }
+    /* children are numbered in the order of their parents (a prefix scan over the level's work items, not an atomic counter whose
      * order is whoever arrives first): neighbours in space stay neighbours in the array at every level, as in the host builder's
      * level order */
     uint32_t base4 = 0, basew = 0;
-    if (offs) { base4 = node_base + offs[wi]; basew = offs[wi]; }
-    else if (ninner) { base4 = atomicAdd(&counters[0], (uint32_t)ninner); basew = atomicAdd(&counters[1], (uint32_t)ninner); }
+    if (offs) {
+        const uint32_t off = (node_base & 1u) ? offs[wi].l1 : offs[wi].l0;
+        base4 = node_base + off; basew = off;
+        if (pair_align && ninner >= 2 && (base4 & 1u)) {          /* the group moves up to the next line: an empty node first */
+            lh_q4node_t pad;
+            for (int c = 0; c < 4; c++) { for (int k = 0; k < 3; k++) pad.w[c][k] = 65535u; pad.ref[c] = LH_REF_EMPTY; }
+            q4[base4] = pad;
+            work_out[basew] = make_uint2(0xffffffffu, base4);
+            base4++; basew++;
+        }
+    } else if (ninner) { base4 = atomicAdd(&counters[0], (uint32_t)ninner); basew = atomicAdd(&counters[1], (uint32_t)ninner); }
     lh_q4node_t out;
     const double g[3] = {glo.x, glo.y, glo.z}, st[3] = {gstep.x, gstep.y, gstep.z};
     int slot = 0;
@@ -779,10 +805,11 @@ __global__ void k_stack_need(uint32_t begin, uint32_t end, const lh_q4node_t *__
 {
     const uint32_t k = begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= end) return;
-    const uint32_t mine = k == 0 ? 0u : acc[k];
-    atomicMax(need_max, mine);
     uint32_t nch = 0;
     for (int c = 0; c < 4; c++) nch += q4[k].ref[c] != LH_REF_EMPTY;
+    if (nch == 0) return;                                   /* a padding node: nobody refers to it, nobody wrote acc[k] */
+    const uint32_t mine = k == 0 ? 0u : acc[k];
+    atomicMax(need_max, mine);
     for (int c = 0; c < 4; c++) { const int32_t r = q4[k].ref[c]; if (r >= 0) acc[r] = mine + (nch ? nch - 1u : 0u); }
 }
 
@@ -823,8 +850,7 @@ static inline void dfree(void *p) { if (p) (void)hipFree(p); }
 
 } /* namespace */
 
-/* d_tri64: ntris x 9 doubles (primitive-id order) on the current device.  On success *d_q4nodes (capacity ntris records,
- * *nq4 used), *d_tri32 (ntris + 2 records) and -- if want_q8 and the tree has more than one node -- *d_q8nodes (*nq8 records)
+/* d_tri64: ntris x 9 doubles (primitive-id order) on the current device.  On success *d_q4nodes (*nq4 records), *d_tri32 (ntris + 2 records) and -- if want_q8 and the tree has more than one node -- *d_q8nodes (*nq8 records)
  * are hipMalloc'ed here and owned by the caller; bmin / bmax / grid as lh_bvh_t.
  * Returns 0, -1 (err filled), or -2 for a NaN / infinite / > 1e30 coordinate. */
 extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q4nodes, uint32_t *nq4, uint32_t *q4_depth, uint32_t *q4_stack,
@@ -836,7 +862,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     const uint32_t n = ntris;
     float *plo = NULL, *phi = NULL; uint32_t *scene = NULL, *val_in = NULL, *sorted = NULL, *counters = NULL, *ncut = NULL; float *boxes = NULL; CutRoot *cuts = NULL;
     uint64_t *key_in = NULL, *key = NULL; int *leaf_parent = NULL, *bad = NULL; BNode *nodes = NULL; void *tmp = NULL; size_t tmp_bytes = 0;
-    uint2 *work[2] = {NULL, NULL}; DP4 *dp = NULL; uint32_t *bfs = NULL; lh_q4node_t *q4 = NULL; lh_q8node_t *q8 = NULL; lh_tri32_t *t32 = NULL; uint32_t *lay = NULL, *offs = NULL, need_rows = 0; std::vector<uint32_t> lvl_begin, lb2; DP8 *dp8 = NULL;
+    uint2 *work[2] = {NULL, NULL}; DP4 *dp = NULL; uint32_t *bfs = NULL; lh_q4node_t *q4 = NULL; lh_q8node_t *q8 = NULL; lh_tri32_t *t32 = NULL; uint32_t *lay = NULL, *offs = NULL, need_rows = 0; PL *pl_in = NULL, *pl_out = NULL; std::vector<uint32_t> lvl_begin, lb2; DP8 *dp8 = NULL;
     const unsigned nb = (n + 255) / 256;
     uint32_t h_scene[6], level = 0, nwork = 0, nq = 1;
     const uint32_t init_scene[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
@@ -848,6 +874,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     { const char *e = getenv("LH_DEVICE_CUT"); if (e && atoi(e) >= 0) cut = (uint32_t)atoi(e); }
     const uint32_t cut_cap = cut ? (uint32_t)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(65536u, 16ull * n / cut)) : 0u;
     int root_ref = 0;
+    const int pair_align = !(getenv("LH_Q4_PAIRS") && atoi(getenv("LH_Q4_PAIRS")) == 0);
     const bool use_dp = !(getenv("LH_DEVICE_COLLAPSE") && strcmp(getenv("LH_DEVICE_COLLAPSE"), "greedy") == 0);
     *d_q4nodes = NULL; *d_tri32 = NULL; *nq4 = 0; *q4_depth = 0; *q4_stack = 0; *d_q8nodes = NULL; *nq8 = 0; *q8_depth = 0;
     if (n == 0) return 0;
@@ -884,7 +911,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
         float fs = (float)st; if ((double)fs < st) fs = nextafterf(fs, INFINITY);
         grid_lo[k] = fl; grid_step[k] = fs;
     }
-    BCHK(hipMalloc((void **)&q4, sizeof(lh_q4node_t) * (size_t)(n > 1 ? n : 1)));
+    BCHK(hipMalloc((void **)&q4, sizeof(lh_q4node_t) * (2 * (size_t)n + 2)));      /* <= n - 1 nodes + at most one padding node per sibling group; cut to size at the end */
     BCHK(hipMalloc((void **)&t32, sizeof(lh_tri32_t) * ((size_t)n + 2)));
     BCHK(hipMalloc((void **)&sorted, sizeof(uint32_t) * (size_t)n));
     {
@@ -935,13 +962,16 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                 hipLaunchKernelGGL(k_node_boxes, dim3((n - 1 + 255) / 256), dim3(256), 0, s, (int)n, nodes, T, leaf_max);
                 mark("node boxes + SAH leaves");
             }
-            BCHK(hipMalloc((void **)&work[0], sizeof(uint2) * (size_t)n)); BCHK(hipMalloc((void **)&work[1], sizeof(uint2) * (size_t)n));
+            BCHK(hipMalloc((void **)&work[0], sizeof(uint2) * (2 * (size_t)n + 2))); BCHK(hipMalloc((void **)&work[1], sizeof(uint2) * (2 * (size_t)n + 2)));
             BCHK(hipMalloc((void **)&counters, sizeof(uint32_t) * 2));
             BCHK(hipMalloc((void **)&lay, sizeof(uint32_t) * ((size_t)n + 1)));
             BCHK(hipMalloc((void **)&offs, sizeof(uint32_t) * ((size_t)n + 1)));
+            BCHK(hipMalloc((void **)&pl_in, sizeof(PL) * (2 * (size_t)n + 2))); BCHK(hipMalloc((void **)&pl_out, sizeof(PL) * (2 * (size_t)n + 2)));
             {
-                size_t sb = 0;
+                size_t sb = 0, sb2 = 0; const PL zero = {0u, 0u};
                 BCHK(hipcub::DeviceScan::ExclusiveSum(NULL, sb, lay, offs, (int)n, s));
+                BCHK(hipcub::DeviceScan::ExclusiveScan(NULL, sb2, pl_in, pl_out, PLOp(), zero, (int)(2 * (size_t)n + 2), s));
+                if (sb2 > sb) sb = sb2;
                 if (sb > tmp_bytes) { dfree(tmp); tmp = NULL; tmp_bytes = sb; BCHK(hipMalloc(&tmp, tmp_bytes)); }
             }
             if (cut_cap) { BCHK(hipMalloc((void **)&cuts, sizeof(CutRoot) * (size_t)cut_cap)); BCHK(hipMalloc((void **)&ncut, sizeof(uint32_t))); }
@@ -1000,17 +1030,18 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                 nwork = 1; nq = 1; level = 0; lvl_begin.clear(); need_rows = 0;
                 while (nwork > 0) {
                     /* count the level's inner children, prefix-sum them (children numbered in the order of their parents), emit */
-                    uint32_t total = 0;
+                    PL tot = {0u, 0u}; uint32_t total = 0;
                     hipLaunchKernelGGL(k_collapse_level, dim3((nwork + 1 + 127) / 128), dim3(128), 0, s, nwork, (const uint2 *)work[level & 1], work[(level + 1) & 1],
                                        counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q4, leaf_max, (const DP4 *)dp,
-                                       lay, (const uint32_t *)NULL, nq);
-                    { size_t tb = tmp_bytes; BCHK(hipcub::DeviceScan::ExclusiveSum(tmp, tb, lay, offs, (int)(nwork + 1), s)); }
-                    BCHK(hipMemcpyAsync(&total, offs + nwork, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                                       pl_in, (const PL *)NULL, nq, pair_align);
+                    { size_t tb = tmp_bytes; const PL zero = {0u, 0u}; BCHK(hipcub::DeviceScan::ExclusiveScan(tmp, tb, pl_in, pl_out, PLOp(), zero, (int)(nwork + 1), s)); }
+                    BCHK(hipMemcpyAsync(&tot, pl_out + nwork, sizeof(PL), hipMemcpyDeviceToHost, s));
                     hipLaunchKernelGGL(k_collapse_level, dim3((nwork + 127) / 128), dim3(128), 0, s, nwork, (const uint2 *)work[level & 1], work[(level + 1) & 1],
                                        counters, (const BNode *)nodes, (const uint32_t *)sorted, (const float *)plo, (const float *)phi, glo, gst, q4, leaf_max, (const DP4 *)dp,
-                                       (uint32_t *)NULL, (const uint32_t *)offs, nq);
+                                       (PL *)NULL, (const PL *)pl_out, nq, pair_align);
                     BCHK(hipStreamSynchronize(s));
                     lvl_begin.push_back(nq);                                  /* first index of the level the kernel just filled */
+                    total = (nq & 1u) ? tot.l1 : tot.l0;
                     nq += total; nwork = total; level++;
                     if (level > 200) { snprintf(err, errlen, "device build: runaway collapse"); goto fail; }
                 }
@@ -1076,14 +1107,22 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     BCHK(hipGetLastError());
     BCHK(hipStreamSynchronize(s));
     mark("tri32 records");
+    {
+        /* the node array was sized for the worst case: keep what is used */
+        lh_q4node_t *fit = NULL;
+        if (hipMalloc((void **)&fit, sizeof(lh_q4node_t) * (size_t)nq) == hipSuccess) {
+            if (hipMemcpyAsync(fit, q4, sizeof(lh_q4node_t) * (size_t)nq, hipMemcpyDeviceToDevice, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess) { dfree(q4); q4 = fit; }
+            else dfree(fit);
+        }
+    }
     *d_q4nodes = q4; *d_q8nodes = q8; *d_tri32 = t32; *nq4 = nq; *q4_depth = level; *q4_stack = nq > 1 ? need_rows + 5u : 0u;     /* LDS stack rows the walk needs (0: unknown, 3 x depth + 5) */
     dfree(plo); dfree(phi); dfree(scene); dfree(bad); dfree(key_in); dfree(key); dfree(val_in); dfree(sorted);
-    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters); dfree(dp); dfree(dp8); dfree(bfs); dfree(offs);
+    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters); dfree(dp); dfree(dp8); dfree(bfs); dfree(offs); dfree(pl_in); dfree(pl_out);
     mark("free temporaries");
     return 0;
 fail:
     dfree(plo); dfree(phi); dfree(scene); dfree(bad); dfree(key_in); dfree(key); dfree(val_in); dfree(sorted);
-    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters); dfree(dp); dfree(dp8); dfree(bfs); dfree(offs);
+    dfree(nodes); dfree(leaf_parent); dfree(boxes); dfree(cuts); dfree(ncut); dfree(lay); dfree(tmp); dfree(work[0]); dfree(work[1]); dfree(counters); dfree(dp); dfree(dp8); dfree(bfs); dfree(offs); dfree(pl_in); dfree(pl_out);
     dfree(q4); dfree(q8); dfree(t32);
     return -1;
 }

@@ -132,7 +132,16 @@ def test_wide_collapses_cover_every_triangle_once(ntri, he):
     lo, step = m.grid()
     q4 = np.ascontiguousarray(m.q4nodes()).view(np.uint32).reshape(-1, 16); n4, d4 = m.q4info()
     seen, nv, md = _wide_walk(q4[:, :12], q4[:, 12:16].view(np.int32), 4, tri32, tri_dbl, lo, step)
-    assert sorted(seen) == list(range(ntri)) and nv == n4 and md == d4
+    # (a sibling group of two or more starts at an even index -- two 64-byte nodes to a 128-byte line; the skipped slots hold
+    # empty records nobody refers to)
+    refs4 = q4[:n4, 12:16].view(np.int32)
+    pads = np.nonzero((refs4 == EMPTY).all(axis=1))[0] if n4 > 1 else np.zeros(0, np.int64)
+    assert (q4[pads, :12] == 65535).all()
+    assert sorted(seen) == list(range(ntri)) and nv + len(pads) == n4 and md == d4
+    for k in range(n4):
+        kids = refs4[k][refs4[k] >= 0]
+        if len(kids) >= 2:
+            assert kids.min() % 2 == 0 and sorted(kids) == list(range(kids.min(), kids.min() + len(kids)))      # adjacent, starting on a line
     q8 = m.q8nodes(); n8, d8 = m.q8info()
     seen, nv, md = _wide_walk(q8[:, :24], q8[:, 24:32].view(np.int32), 8, tri32, tri_dbl, lo, step)
     assert sorted(seen) == list(range(ntri)) and nv == n8 and md == d8
