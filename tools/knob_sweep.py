@@ -16,7 +16,7 @@ def t():
     for _ in range(3):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record(); acc.intersect_device(o, d, out=out); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return n / min(ts) / 1e3
-DEF = {"min_active": 32, "tri_batch": 8, "ray_chunk": 256, "dump_budget": 2048}
+DEF = {"min_active": 32, "tri_batch": 12, "ray_chunk": 256, "dump_budget": 2048}
 print("defaults %.1f Mrays/s" % t(), flush=True)
 for name, vals in (("dump_budget", (512, 1024, 4096, 16384, 1 << 30)), ("min_active", (16, 24, 40, 48)), ("tri_batch", (4, 6, 12, 16, 24)),
                    ("ray_chunk", (64, 128, 512, 1024))):
