@@ -409,6 +409,9 @@ __global__ __launch_bounds__(64) void k_sah_subtree(uint32_t nroots, const uint3
  * compact patches and fine as they are.  So: the roots of those subtrees (k_cut_roots; ~3 n / cut of them) go to the host,
  * which builds a binned-SAH tree over their boxes in a few milliseconds (top_build) and hands it back as ordinary BNodes
  * behind the radix nodes; the collapse then starts at the new root. */
+#ifndef LH_TOP_BINS
+#define LH_TOP_BINS 32
+#endif
 struct CutRoot { int ref; uint32_t count; float lo[3], hi[3]; };
 
 __global__ void k_cut_roots(int n, const BNode *__restrict__ nodes, const BoxTable T, uint32_t cut, CutRoot *__restrict__ out, uint32_t cap,
@@ -443,10 +446,11 @@ static float top_area(const float lo[3], const float hi[3])
     return dx * dy + dy * dz + dz * dx;
 }
 
-/* binned SAH (16 bins, the three axes, subtrees weighted by their primitive counts) over it[b .. e).  A subtree over m items
+/* binned SAH (LH_TOP_BINS = 32 bins -- 16 until the end of round 3: config 5 86.1 -> 85.7 ms --, the three axes, subtrees weighted by their primitive counts) over it[b .. e).  A subtree over m items
  * has m - 1 nodes: it gets the slots out[nb .. nb + m - 2] (root first, then the left subtree's, then the right's), so the
  * layout does not depend on who builds what and the large subtrees near the top are built by threads of their own.  A node's
  * global index = base + slot.  Returns the reference of the subtree's root */
+static int g_top_bins = LH_TOP_BINS;        /* LH_DEVICE_TOP_BINS (2 .. LH_TOP_BINS) */
 static int top_build(CutRoot *it, int b, int e, BNode *out, int nb, int base, int par_depth, int level = 0)
 {
     if (e - b == 1) return it[b].ref;
@@ -457,12 +461,12 @@ static int top_build(CutRoot *it, int b, int e, BNode *out, int nb, int base, in
             const float c = 0.5f * (it[i].lo[k] + it[i].hi[k]);
             clo[k] = fminf(clo[k], c); chi[k] = fmaxf(chi[k], c);
         }
-    enum { NB = 16 };
+    const int NB = g_top_bins;
     int best_axis = -1, best_bin = 0; float best_cost = INFINITY;
     for (int k = 0; k < 3; k++) {
         const float ext = chi[k] - clo[k];
         if (!(ext > 0.0f)) continue;
-        float blo[NB][3], bhi[NB][3]; double bcnt[NB];
+        float blo[LH_TOP_BINS][3], bhi[LH_TOP_BINS][3]; double bcnt[LH_TOP_BINS];
         for (int j = 0; j < NB; j++) { bcnt[j] = 0.0; for (int a = 0; a < 3; a++) { blo[j][a] = INFINITY; bhi[j][a] = -INFINITY; } }
         const float scale = (float)NB / ext;
         for (int i = b; i < e; i++) {
@@ -471,7 +475,7 @@ static int top_build(CutRoot *it, int b, int e, BNode *out, int nb, int base, in
             bcnt[j] += it[i].count;
             for (int a = 0; a < 3; a++) { blo[j][a] = fminf(blo[j][a], it[i].lo[a]); bhi[j][a] = fmaxf(bhi[j][a], it[i].hi[a]); }
         }
-        float rarea[NB]; double rcnt[NB];
+        float rarea[LH_TOP_BINS]; double rcnt[LH_TOP_BINS];
         {
             float rl[3] = {INFINITY, INFINITY, INFINITY}, rh[3] = {-INFINITY, -INFINITY, -INFINITY}; double rc = 0.0;
             for (int j = NB - 1; j >= 1; j--) {
@@ -874,6 +878,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     { const char *e = getenv("LH_DEVICE_CUT"); if (e && atoi(e) >= 0) cut = (uint32_t)atoi(e); }
     const uint32_t cut_cap = cut ? (uint32_t)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(65536u, 16ull * n / cut)) : 0u;
     int root_ref = 0;
+    { const char *e = getenv("LH_DEVICE_TOP_BINS"); g_top_bins = (e && atoi(e) >= 2 && atoi(e) <= LH_TOP_BINS) ? atoi(e) : LH_TOP_BINS; }
     const int pair_align = !(getenv("LH_Q4_PAIRS") && atoi(getenv("LH_Q4_PAIRS")) == 0);
     const bool use_dp = !(getenv("LH_DEVICE_COLLAPSE") && strcmp(getenv("LH_DEVICE_COLLAPSE"), "greedy") == 0);
     *d_q4nodes = NULL; *d_tri32 = NULL; *nq4 = 0; *q4_depth = 0; *q4_stack = 0; *d_q8nodes = NULL; *nq8 = 0; *q8_depth = 0;
