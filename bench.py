@@ -562,6 +562,7 @@ def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
             "definitions": defs, "formula": "bytes_per_ray = 48 (ray in) + 28 (hit record out) + B_node x nodes_per_ray + 40 x tris_per_ray; "
                                             "achieved = bytes_per_ray x rays / kernel_ms; frac = achieved / peak",
             "residency": "hot set %.0f MB as 4-wide nodes + tri32 >> 256 MiB Infinity Cache: HBM" % (hot / 1e6),
+            "builder": "host, asked for (the better tree by 0.5-1 %; lh_accel_commit's own choice at this size is the device builders: 0.11 s instead of 5 s of commit, tools/build_probe.py)",
             "kernel": "k_trace_persist_lane<walk=spec8, q16x8 nodes: 128-byte 8-wide records, one cache line each>" if node_bytes == 128
                       else "k_trace_persist_lane<walk=spec,%s nodes>" % node_fmt,
             "node_bytes": node_bytes,
@@ -670,6 +671,7 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
                 len(render.bands_for(size, world)[1]), render.bands_for(size, world)[0], world),
             "device_bytes": info["device_bytes"], "build_s": round(info["build_seconds"], 3),
             "ref_tree_build_s": round(info["ref_build_seconds"], 3),
+            "builder": "host, asked for (the better tree by 1-2 % of the frame); lh_accel_commit's own choice at this size is the device builders: see device_build",
             "scene_load": {"rank0_commit_s": round(commit_s, 3), "broadcast_s": round(bcast_s, 3) if world > 1 else None},
             "rays_per_frame": int(rays_all), "frame_ms": round(t_all * 1e3, 3),
             "value": round(rays_all / t_all / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
