@@ -652,10 +652,13 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
         t0 = time.perf_counter(); info_d = acc_d.commit(on_device=True); commit_dev_s = time.perf_counter() - t0
         acc_d.wait_exact(); exact_s = time.perf_counter() - t0          # lucille's own tree attached: ties, fragile hits, beams follow the reference
         render.render_ao_frame(acc_d, cam, 1, nsamples, tile=tile); torch.cuda.synchronize(dev)
-        t0 = time.perf_counter(); img_d, st_d = render.render_ao_frame(acc_d, cam, 1, nsamples, tile=tile); torch.cuda.synchronize(dev)
+        tfd = []
+        for _ in range(max(1, min(steps, 3))):                  # as the host-tree frames above: the best of the timed frames
+            t0 = time.perf_counter(); img_d, st_d = render.render_ao_frame(acc_d, cam, 1, nsamples, tile=tile); torch.cuda.synchronize(dev)
+            tfd.append(time.perf_counter() - t0)
         devb = {"host_commit_s": round(commit_host_s, 3), "device_commit_s": round(commit_dev_s, 3), "device_tree_s": round(info_d["build_seconds"], 3),
                 "device_reference_tree_s": round(acc_d.info()["ref_build_seconds"], 3), "commit_to_exact_s": round(exact_s, 3),
-                "frame_ms_on_device_tree": round((time.perf_counter() - t0) * 1e3, 3),
+                "frame_ms_on_device_tree": round(min(tfd) * 1e3, 3),
                 "image_bit_equal": bool(torch.equal(img_d, img)) and dict(st_d) == stats[0]}
         ok = ok and devb["image_bit_equal"]
         acc_d.close(); del img_d
