@@ -274,6 +274,9 @@ __global__ void k_node_boxes(int n, BNode *__restrict__ nodes, const BoxTable T,
 #ifndef LH_SUB_MAX
 #define LH_SUB_MAX 512
 #endif
+#ifndef LH_SUB_BINS
+#define LH_SUB_BINS 16
+#endif
 
 __global__ void k_sub_roots(int n, const BNode *__restrict__ nodes, uint32_t sub_max, uint32_t *__restrict__ out, uint32_t *__restrict__ nout)
 {
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(64) void k_sah_subtree(uint32_t nroots, const uint3
     __shared__ uint32_t pid[LH_SUB_MAX];                 /* primitive id of local item k (its position when the wave started) */
     __shared__ float blo[LH_SUB_MAX][3], bhi[LH_SUB_MAX][3];
     __shared__ uint16_t perm[LH_SUB_MAX], tmp[LH_SUB_MAX];       /* the order being built, as local items */
-    __shared__ uint32_t bcnt[3][16], bmin[3][16][3], bmax[3][16][3];
+    __shared__ uint32_t bcnt[3][LH_SUB_BINS], bmin[3][LH_SUB_BINS][3], bmax[3][LH_SUB_BINS][3];
     __shared__ uint32_t stk_rng[LH_SUB_MAX], stk_node[LH_SUB_MAX];   /* ranges still to split: lo | hi << 16, and their node */
     if (blockIdx.x >= nroots) return;
     const int lane = threadIdx.x;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(64) void k_sah_subtree(uint32_t nroots, const uint3
         const uint32_t lo = stk_rng[sp] & 0xFFFFu, hi = stk_rng[sp] >> 16, node = stk_node[sp], cnt = hi - lo;
         /* ranges of up to four items (three quarters of all splits) are halved as they stand: they mostly end up as ONE leaf anyway */
         float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY}, scale[3] = {0.0f, 0.0f, 0.0f};
-        int best = 0; float bc = INFINITY; uint32_t nleft = 0;
+        int best = 0x7fffffff, owner = 0; float bc = INFINITY; uint32_t nleft = 0;
         if (cnt > 4u) {
         /* centroid bounds of the range */
         for (uint32_t k = lo + lane; k < hi; k += 64) {
@@ -322,46 +325,49 @@ __global__ __launch_bounds__(64) void k_sah_subtree(uint32_t nroots, const uint3
         }
         for (int c = 0; c < 3; c++)
             for (int off = 32; off >= 1; off >>= 1) { clo[c] = fminf(clo[c], __shfl_xor(clo[c], off)); chi[c] = fmaxf(chi[c], __shfl_xor(chi[c], off)); }
-        if (lane < 48) {
-            bcnt[lane / 16][lane % 16] = 0u;
-            for (int c = 0; c < 3; c++) { bmin[lane / 16][lane % 16][c] = 0xffffffffu; bmax[lane / 16][lane % 16][c] = 0u; }
+        for (int t = lane; t < 3 * LH_SUB_BINS; t += 64) {
+            bcnt[t / LH_SUB_BINS][t % LH_SUB_BINS] = 0u;
+            for (int c = 0; c < 3; c++) { bmin[t / LH_SUB_BINS][t % LH_SUB_BINS][c] = 0xffffffffu; bmax[t / LH_SUB_BINS][t % LH_SUB_BINS][c] = 0u; }
         }
         __syncthreads();
-        for (int c = 0; c < 3; c++) scale[c] = chi[c] > clo[c] ? 16.0f / (chi[c] - clo[c]) : 0.0f;
+        for (int c = 0; c < 3; c++) scale[c] = chi[c] > clo[c] ? (float)LH_SUB_BINS / (chi[c] - clo[c]) : 0.0f;
         for (uint32_t k = lo + lane; k < hi; k += 64) {
             const uint32_t e = perm[k];
             for (int ax = 0; ax < 3; ax++) {
                 int j = (int)((0.5f * (blo[e][ax] + bhi[e][ax]) - clo[ax]) * scale[ax]);
-                j = j < 0 ? 0 : (j > 15 ? 15 : j);
+                j = j < 0 ? 0 : (j > LH_SUB_BINS - 1 ? LH_SUB_BINS - 1 : j);
                 atomicAdd(&bcnt[ax][j], 1u);
                 for (int c = 0; c < 3; c++) { atomicMin(&bmin[ax][j][c], f2o(blo[e][c])); atomicMax(&bmax[ax][j][c], f2o(bhi[e][c])); }
             }
         }
         __syncthreads();
-        /* lane 15 ax + j: the split "bins 0 .. j | j + 1 .. 15" along ax */
-        float cost = INFINITY;
-        if (lane < 45) {
-            const int ax = lane / 15, j = lane % 15;
+        /* candidate (LH_SUB_BINS - 1) ax + j: the split "bins 0 .. j | j + 1 .." along ax; a lane takes candidates lane, lane + 64 */
+        bc = INFINITY; best = 0x7fffffff;
+        for (int cand = lane; cand < 3 * (LH_SUB_BINS - 1); cand += 64) {
+            const int ax = cand / (LH_SUB_BINS - 1), j = cand % (LH_SUB_BINS - 1);
             if (scale[ax] > 0.0f) {
                 float ll[3] = {INFINITY, INFINITY, INFINITY}, lh[3] = {-INFINITY, -INFINITY, -INFINITY}, rl[3] = {INFINITY, INFINITY, INFINITY}, rh[3] = {-INFINITY, -INFINITY, -INFINITY};
                 uint32_t nl = 0, nr = 0;
-                for (int q = 0; q < 16; q++) {
+                for (int q = 0; q < LH_SUB_BINS; q++) {
                     const uint32_t cq = bcnt[ax][q];
                     if (!cq) continue;
                     if (q <= j) { nl += cq; for (int c = 0; c < 3; c++) { ll[c] = fminf(ll[c], o2f(bmin[ax][q][c])); lh[c] = fmaxf(lh[c], o2f(bmax[ax][q][c])); } }
                     else { nr += cq; for (int c = 0; c < 3; c++) { rl[c] = fminf(rl[c], o2f(bmin[ax][q][c])); rh[c] = fmaxf(rh[c], o2f(bmax[ax][q][c])); } }
                 }
-                if (nl && nr) { cost = half_area(ll, lh) * (float)nl + half_area(rl, rh) * (float)nr; nleft = nl; }
+                if (nl && nr) {
+                    const float cost = half_area(ll, lh) * (float)nl + half_area(rl, rh) * (float)nr;
+                    if (cost < bc) { bc = cost; best = cand; nleft = nl; }          /* (candidates ascend: ties keep the lower) */
+                }
             }
         }
-        best = lane; bc = cost;                           /* the cheapest split (ties: the lower lane) */
+        owner = lane;                                     /* the cheapest split (ties: the lower candidate), and whose nleft it is */
         for (int off = 32; off >= 1; off >>= 1) {
-            const float oc = __shfl_xor(bc, off); const int ob = __shfl_xor(best, off);
-            if (oc < bc || (oc == bc && ob < best)) { bc = oc; best = ob; }
+            const float oc = __shfl_xor(bc, off); const int ob = __shfl_xor(best, off), oo = __shfl_xor(owner, off);
+            if (oc < bc || (oc == bc && ob < best)) { bc = oc; best = ob; owner = oo; }
         }
         }
-        uint32_t nl = (uint32_t)__shfl((int)nleft, best);
-        const int ax = best / 15, j = best % 15;
+        uint32_t nl = (uint32_t)__shfl((int)nleft, owner);
+        const int ax = best < 0x7fffffff ? best / (LH_SUB_BINS - 1) : 0, j = best < 0x7fffffff ? best % (LH_SUB_BINS - 1) : 0;
         const bool sah = bc < INFINITY;
         if (!sah) nl = cnt / 2;                          /* equal centroids: halve the list as it stands */
         /* stable partition of perm[lo .. hi) into tmp, 64 items a round */
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(64) void k_sah_subtree(uint32_t nroots, const uint3
                 e = perm[k];
                 if (sah) {
                     int q = (int)((0.5f * (blo[e][ax] + bhi[e][ax]) - clo[ax]) * scale[ax]);
-                    q = q < 0 ? 0 : (q > 15 ? 15 : q);
+                    q = q < 0 ? 0 : (q > LH_SUB_BINS - 1 ? LH_SUB_BINS - 1 : q);
                     left = q <= j;
                 } else left = (k - lo) < nl;
             }
