@@ -16,12 +16,12 @@ def frame():
     for _ in range(2):
         t0 = time.perf_counter(); img, st = render.render_ao_frame(acc, cam, 1, 64, tile=4096); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
     return best * 1e3, float(img.mean())
-print("defaults (min_active 32, tri_batch 8, ray_chunk 256): %.1f ms mean %.6f" % frame(), flush=True)
-for ma in (16, 24, 32, 40, 48):
-    for tb in (4, 8, 16):
+print("defaults (min_active 32, tri_batch 12): %.2f ms mean %.6f" % frame(), flush=True)
+for ma in (24, 32, 40):
+    for tb in (8, 12, 16, 24):
         acc.set_param("min_active", ma); acc.set_param("tri_batch", tb)
-        print("min_active %2d tri_batch %2d: %.1f ms" % ((ma, tb) + frame()[:1]), flush=True)
-acc.set_param("min_active", 32); acc.set_param("tri_batch", 8)
+        print("min_active %2d tri_batch %2d: %.2f ms" % ((ma, tb) + frame()[:1]), flush=True)
+acc.set_param("min_active", 32); acc.set_param("tri_batch", 12)
 for rc in (64, 128, 256, 512, 1024):
     acc.set_param("ray_chunk", rc)
     print("ray_chunk %4d: %.1f ms" % ((rc,) + frame()[:1]), flush=True)
