@@ -146,3 +146,24 @@ def test_wide_collapses_cover_every_triangle_once(ntri, he):
     seen, nv, md = _wide_walk(q8[:, :24], q8[:, 24:32].view(np.int32), 8, tri32, tri_dbl, lo, step)
     assert sorted(seen) == list(range(ntri)) and nv == n8 and md == d8
     assert n8 <= n4 and d8 <= d4
+
+
+@pytest.mark.parametrize("layout,pairs", [("dfs", "0"), ("level", "0"), ("level", "1")])
+def test_node_orders_hold_the_same_tree(layout, pairs, monkeypatch):
+    """LH_Q4_LAYOUT / LH_Q4_PAIRS only renumber the 4-wide nodes (depth-first as in rounds 1-2, level order, level order with
+    sibling groups on 128-byte lines): the same set of (boxes, leaf references) records, every triangle under one leaf"""
+    P, idx, _, _ = po.soup(3000, 1, 0.02, 123)
+    def records(layout_, pairs_):
+        monkeypatch.setenv("LH_Q4_LAYOUT", layout_); monkeypatch.setenv("LH_Q4_PAIRS", pairs_)
+        m = Model(P, idx)
+        q4 = np.ascontiguousarray(m.q4nodes()).view(np.uint32).reshape(-1, 16); n4, d4 = m.q4info()
+        tri32 = m.tri32(); lo, step = m.grid()
+        seen, nv, md = _wide_walk(q4[:, :12], q4[:, 12:16].view(np.int32), 4, tri32, P[idx].reshape(-1, 9), lo, step)
+        refs = q4[:n4, 12:16].view(np.int32)
+        real = ~(refs == EMPTY).all(axis=1)
+        # a record without its child numbering: boxes + leaf refs (inner refs -> a marker)
+        canon = np.concatenate([q4[:n4, :12], np.where(refs >= 0, 1, refs).view(np.uint32)], axis=1)[real]
+        return sorted(map(bytes, canon)), sorted(seen), nv, md
+    base = records("dfs", "0")
+    got = records(layout, pairs)
+    assert got[0] == base[0] and got[1] == base[1] == list(range(3000)) and got[2] == base[2] and got[3] == base[3]
