@@ -67,6 +67,9 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     if (env && atoi(env) > 0) a->dump_budget = (uint32_t)atoi(env);
     env = getenv("LH_RAY_BUDGET");
     if (env && atoi(env) > 0) a->dev.ray_budget = (uint32_t)atoi(env);
+    a->dev.top_nodes = LH_TOP_AUTO;
+    env = getenv("LH_TOP_NODES");
+    if (env && atoi(env) >= 0 && atoi(env) <= (int)LH_TOP_NODES_MAX) a->dev.top_nodes = (uint32_t)atoi(env);
     *out = a;
     return 0;
 }
@@ -819,6 +822,7 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
     else if (!strcmp(name, "ao_fused")) a->ao_fused = value != 0;
     else if (!strcmp(name, "fast_start")) a->fast_start = value != 0;
     else if (!strcmp(name, "wide8") && value >= -1 && value <= 1) a->wide8 = value;
+    else if (!strcmp(name, "top_nodes") && value >= -1 && value <= (int)LH_TOP_NODES_MAX) a->dev.top_nodes = value < 0 ? LH_TOP_AUTO : (uint32_t)value;
     else if (!strcmp(name, "stack_cap") && (value == 0 || (value >= 8 && value <= 64 && value % 2 == 0))) a->dev.stack_cap = (uint32_t)value;
     else return fail("lh_accel_set_param: unknown parameter or bad value: %s = %d", name, value);
     return 0;

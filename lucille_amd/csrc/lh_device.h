@@ -42,6 +42,7 @@ typedef struct lh_dev_scene {
     uint32_t    ray_budget;/* wave iterations after which a ray leaves the persistent walk for the cooperative one */
     int         stack_guard;    /* set by the launchers when the LDS rows do not cover the tree's worst case: the walks check before they push */
     uint32_t    stack_cap; /* 0: 64 LDS stack rows at most; 8..62: a lower cap (tests of the overflow path) */
+    uint32_t    top_nodes; /* the first top_nodes 4-wide nodes (level order: the top of the tree) are walked from a copy in the workgroup's LDS; 0: none */
     const void *cam_src;       /* NULL, or: ray source 2 -- the launch's rays are the camera rays of a path-traced pass (PtCamSrc, lh_pt.h), org / dir unused */
     const uint32_t *n_dev;     /* NULL, or: the launch's ray count lives on the device (the path tracer's bounce chain; the host passes an upper bound) */
     unsigned long long *diag_clock;   /* diagnostics (LH_STAGE_TIMING): [2][waves] start / exit wall clock of every persistent wave, or NULL */
@@ -66,6 +67,8 @@ enum {
                                          builder's count of the deepest path).  A workgroup with more than 64 KiB of LDS halves what a CU holds -- a
                                          21-level device-built tree at 66 rows, with the attribute set to 80 or to 78 KiB alike: 129-132 ms against
                                          94 ms at 40 checked rows and 87 ms for a 20-level tree under 64 (r03) -- so deeper trees take the checked walk */
+#define LH_TOP_AUTO       0xFFFFFFFFu  /* lh_dev_scene_t.top_nodes: as many as the CU's LDS leaves over beside the stack rows (the default) */
+#define LH_TOP_NODES_MAX  512u         /* 4-wide nodes a workgroup may keep in LDS behind its stack rows (32 KiB) */
 #define LH_ROWS_CHECKED   40u          /* ... of the checked walk: four workgroups per CU */
 #define LH_NPART          8            /* cursor partitions of a persistent launch: one per XCD (each with its own L2) */
 #define LH_CURSOR_STRIDE  32           /* 32-bit words between two cursors: a 128-byte line each (device-scope atomics on one line serialise like atomics on

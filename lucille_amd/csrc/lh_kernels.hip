@@ -134,11 +134,19 @@ constexpr uint32_t kRegroupMask = 63u;   /* the walk returns to the regroup poin
  * its stack drifts upwards without bound); the persistent kernel indexes rows directly */
 template <bool COUNT, int STRIDE, bool RING>
 __device__ __forceinline__ void node_step4(Lane &L, int &pend, const lh_dev_scene_t &sc, int (*stk)[STRIDE], const int tid, uint32_t &c_nodes,
-                                           const int ring_mask = 0)
+                                           const int ring_mask = 0, const uint4 *top = NULL, const uint32_t ntop = 0u)
 {
 #define LH_ROW(x) (RING ? ((x) & ring_mask) : (x))
-    const uint4 *p = (const uint4 *)sc.q4nodes + 4 * (size_t)L.cur;
-    const uint4 a = p[0], b = p[1], c = p[2], r = p[3];
+    /* the first ntop nodes (level order: the top of the tree, which every ray walks) are read from the workgroup's copy in LDS:
+     * no request leaves the CU for them */
+    uint4 a, b, c, r;
+    if (!RING && (uint32_t)L.cur < ntop) {
+        const uint4 *lp = top + 4 * (uint32_t)L.cur;
+        a = lp[0]; b = lp[1]; c = lp[2]; r = lp[3];
+    } else {
+        const uint4 *p = (const uint4 *)sc.q4nodes + 4 * (size_t)L.cur;
+        a = p[0]; b = p[1]; c = p[2]; r = p[3];
+    }
     if (COUNT) c_nodes++;
     float t0, t1, t2, t3;
     const bool h0 = slab_w(L, a.x, a.y, a.z, t0) & ((int)r.x != kDone);
@@ -204,13 +212,15 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
                                                uint32_t &c_nslots, uint32_t &c_tslots, uint32_t &it)
 {
     const int rows = (int)sc.stack_rows;
+    const uint4 *top = (const uint4 *)(&stk[rows][0]);        /* the workgroup's copy of the first sc.top_nodes nodes, behind the stack rows */
+    const uint32_t ntop = sc.top_nodes;
     for (;;) {
         if (COUNT) { if (__ballot(L.cur >= 0) != 0ull) c_nslots++; }
         /* the step below writes up to slot sp + 3.  rows = 3 * depth + 5 covers every ray of a tree that deep; a deeper
          * tree (an LBVH built on the device over a degenerate distribution) gets 64 rows and a ray that would overrun them
          * is finished by k_coop_walk -- same arithmetic, same answer */
         if (L.cur >= 0) {
-            node_step4<COUNT, LH_BLOCK, false>(L, pend, sc, stk, tid, c_nodes);
+            node_step4<COUNT, LH_BLOCK, false>(L, pend, sc, stk, tid, c_nodes, 0, top, ntop);
             if (GUARD) {          /* for the NEXT step (a fresh ray starts at sp = 1): one compare and a scalar branch per iteration */
                 const bool ov = (L.cur >= 0) & (L.sp + 4 > rows);
                 if (__builtin_expect(__ballot(ov) != 0ull, 0)) { if (ov) { L.over = true; L.cur = kDone; pend = kNoLeaf; } }
@@ -580,8 +590,14 @@ __global__ __launch_bounds__(LH_BLOCK, WALK == 7 ? 3 : 4) void k_trace_persist_l
     double *__restrict__ v, uint8_t *__restrict__ occ, unsigned long long *counters,
     uint32_t *cursor, int min_active, int tri_batch, const AoSrc ao, const FixQ fq)
 {
-    extern __shared__ int lh_stack_lds[];          /* [stack entries][LH_BLOCK], sized at launch */
+    extern __shared__ int lh_stack_lds[];          /* [stack entries][LH_BLOCK], sized at launch; then the top of the tree (sc.top_nodes x 64 bytes) */
     if (SRC != 1 && sc.n_dev) n = *sc.n_dev;       /* the path tracer's bounce chain: the count the previous shading pass left */
+    if (WALK != 7 && sc.top_nodes) {
+        uint4 *dst = (uint4 *)(lh_stack_lds + (size_t)sc.stack_rows * LH_BLOCK);
+        const uint4 *src = (const uint4 *)sc.q4nodes;
+        for (uint32_t k = threadIdx.x; k < sc.top_nodes * 4u; k += LH_BLOCK) dst[k] = src[k];
+        __syncthreads();
+    }
     trace_persist_lane<ANYHIT, COUNT, WALK, SRC>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, min_active, tri_batch, ao, fq, lh_stack_lds);
 }
 
@@ -912,7 +928,7 @@ static int allow_lds(const void *func, size_t bytes)
     for (int k = 0; k < ndone; k++) have = have || done[k] == func;
     int rc = 0;
     if (!have) {
-        rc = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LH_ROWS_UNCHECKED * LH_BLOCK * sizeof(int))) == hipSuccess ? 0 : -1;
+        rc = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LH_ROWS_UNCHECKED * LH_BLOCK * sizeof(int) + LH_TOP_NODES_MAX * 64u)) == hipSuccess ? 0 : -1;
         if (rc == 0 && ndone < 64) done[ndone++] = func;
     }
     pthread_mutex_unlock(&mu);
@@ -977,6 +993,26 @@ uint32_t rows4(const lh_dev_scene_t &sc, bool *guard)
     need = (need + 1u) & ~1u;
     if (need < 16 && !*guard) need = 16;
     return need;
+}
+
+/* nodes of the top of the tree a workgroup keeps in LDS behind its `rows` stack rows (node_step4): what the CU's 160 KiB leave
+ * over once the workgroups its stack rows allow are resident -- never a workgroup fewer for it.  Measured (tools/top_probe.py,
+ * r04): S-soup-1M 2 228 -> 2 249 Mrays/s on the host builder's tree, 2 212 -> 2 233 on the device builder's (144 nodes = 6.3 of a
+ * ray's 42.5 node visits), config-5 AO frame 86.8 -> 86.2 ms: the requests that leave the CU for the hot top levels are not what
+ * bounds the walk (profiles/README.md r04), so the gain is small; it is free.  sc.top_nodes: LH_TOP_AUTO, 0 (off), or a count. */
+uint32_t top_nodes_for(const lh_dev_scene_t &sc, uint32_t rows)
+{
+    uint32_t want = sc.top_nodes;
+    if (want == LH_TOP_AUTO) {
+        const uint32_t cu = 160u * 1024u, stack = rows * LH_BLOCK * (uint32_t)sizeof(int);
+        uint32_t wgs = cu / stack;
+        if (wgs > 4u) wgs = 4u;                     /* 128 VGPRs: four workgroups per CU at most */
+        if (wgs == 0u) return 0u;
+        const uint32_t spare = (cu / wgs - stack) / 64u;
+        want = spare < LH_TOP_NODES_MAX ? spare : LH_TOP_NODES_MAX;
+        want &= ~15u;
+    }
+    return want < sc.nq4nodes ? want : sc.nq4nodes;
 }
 
 /* the cooperative walk's ring of stack rows: a power of two covering the tree's worst case (3 per level + sentinel + the
@@ -1058,7 +1094,8 @@ extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int n
     bool guard = false;
     scl.stack_rows = rows4(*sc, &guard);
     scl.stack_guard = guard ? 1 : 0;
-    const size_t lds_bytes = (size_t)scl.stack_rows * LH_BLOCK * sizeof(int);
+    scl.top_nodes = top_nodes_for(*sc, scl.stack_rows);
+    const size_t lds_bytes = (size_t)scl.stack_rows * LH_BLOCK * sizeof(int) + (size_t)scl.top_nodes * 64u;
     if (scl.ray_chunk < LH_TILE_CHUNK) scl.ray_chunk = LH_TILE_CHUNK;      /* AO rays of a slot are coherent: longer ranges per wave */
     clamp_chunk(scl, n, grid_blocks);
     AoSrc ao = {d_hitrec, d_slot_key, d_occ_count, seed, ntheta, nphi};
@@ -1142,7 +1179,8 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
     }
     if (need > LH_ROWS_UNCHECKED) return -1;
     scl.stack_rows = need;
-    const size_t lds_bytes = (size_t)need * LH_BLOCK * sizeof(int);
+    scl.top_nodes = (walk == 0 || walk == 7) ? 0u : top_nodes_for(*sc, need);
+    const size_t lds_bytes = (size_t)need * LH_BLOCK * sizeof(int) + (size_t)scl.top_nodes * 64u;
     clamp_chunk(scl, n, grid_blocks);
     /* small batches (one synchronous ray, a bucket of lucille's renderer): no visit budget, no second stream -- a ray the walk
      * cannot finish (LDS rows) stays flagged for k_fixups */
