@@ -362,6 +362,37 @@ int  lh_accel_beam_visibility_host(lh_accel_t *accel, size_t n, const double *or
 int  lh_accel_beam_visibility_device(lh_accel_t *accel, size_t n, const void *d_org_xyz,
                                      const void *d_corner_dirs_xyz, void *d_result, void *stream);
 
+/* ---- the beam-raster path: ri_beam_set + ri_raster_plane_setup + ri_bvh_intersect_beam ----
+ * reference: src/render/bvh.c:544-609 (-> :2547-2643, :2315-2426, :2751-2820), src/render/beam.c:469-730,
+ * src/render/raster.c:42-147,166-435, src/render/triangle.c:8-68.  The reference never calls this path and left it
+ * unfinished; what it COMPUTES is reproduced bit for bit, quirks included (lh_beam.hip lists them): after the call the raster
+ * plane's t array holds, per pixel of the window, the ray parameter of the LAST rasterised triangle that covered the pixel
+ * in the reference's traversal order, 0.0 elsewhere (u, v, geom, index of ri_raster_plane_t are never written by the
+ * reference either).  Like beam visibility it runs on the reference-order tree.
+ *   plane:   the raster window shared by the batch -- width x height pixels, frame = du dv dw (raster.h:38), eye =
+ *            plane->org, fov in degrees;
+ *   corner:  n x 3, the lower-left corner of every beam's window (plane->corner; the testbed shifts it per beam,
+ *            simplerender.cpp:703-720);
+ *   t_out:   n x height x width doubles; written for status 0 only;
+ *   status:  0 traced; 1 nothing done (empty scene or the beam misses the scene box: the reference returns before it clears
+ *            the plane, bvh.c:560-563,586-593); LH_BEAM_INVALID where ri_beam_set refuses the beam;
+ *   flags:   n x 4 u64 or NULL -- what is UNDEFINED in the reference, reported instead of reproduced: [0] pixel tests outside
+ *            the window (the reference writes plane->t[t * width + s] unchecked, raster.c:300-316; here the box is cut to the
+ *            window), [1] / [2] the asserts of beam.c:142 / :626 would have fired, [3] triangles rasterised. */
+typedef struct lh_raster_plane {
+    int32_t width, height;
+    double  frame[9];
+    double  eye[3];
+    double  fov;
+} lh_raster_plane_t;
+
+int  lh_accel_beam_raster_host(lh_accel_t *accel, size_t n, const double *org_xyz, const double *corner_dirs_xyz,
+                               const double *corner_xyz, const lh_raster_plane_t *plane, double *t_out,
+                               int32_t *status, uint64_t *flags);
+int  lh_accel_beam_raster_device(lh_accel_t *accel, size_t n, const void *d_org_xyz, const void *d_corner_dirs_xyz,
+                                 const void *d_corner_xyz, const lh_raster_plane_t *plane, void *d_t_out,
+                                 void *d_status, void *d_flags, void *stream);
+
 /* whole AO frame into HOST memory: the tile loop of render_frame_controller + bucket_write
  * (src/render/render.c:1168-1207, 919-983) over lh_render_ao_tile.  rgb: height rows of width RGB
  * float triples, top row first (bucket_write's y flip applied) -- what the reference hands its

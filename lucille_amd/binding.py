@@ -46,6 +46,11 @@ class AccelInfo(C.Structure):
                 ("nnodes_traversal", C.c_uint32)]
 
 
+class RasterPlane(C.Structure):
+    """lh_raster_plane_t (include/lucille_hip.h)"""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("frame", C.c_double * 9), ("eye", C.c_double * 3), ("fov", C.c_double)]
+
+
 class Camera(C.Structure):
     """lh_camera_t: the members of ri_camera_t the ray generator reads (camera.c:248-318)"""
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("rh", C.c_int), ("ortho", C.c_int),
@@ -98,7 +103,7 @@ ABI_SYMBOLS = [
     "lh_accel_destroy", "lh_accel_info", "lh_accel_prim_lookup", "lh_accel_intersect1",
     "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted", "lh_accel_last_retraced", "lh_accel_dump_node_bytes",
     "lh_accel_set_grid", "lh_accel_set_param", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
-    "lh_render_ao_tile", "lh_render_ao_tile_host", "lh_render_ao_bands", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device", "lh_render_pt_tile",
+    "lh_render_ao_tile", "lh_render_ao_tile_host", "lh_render_ao_bands", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device", "lh_accel_beam_raster_host", "lh_accel_beam_raster_device", "lh_render_pt_tile",
     "lh_accel_trace_statistics", "lh_accel_statistics", "lh_accel_slot_statistics",
     "lh_render_ao_frame_host", "lh_rib_load", "lh_rib_free", "lh_rib_last_error", "lh_rib_info", "lh_rib_messages",
     "lh_rib_mesh", "lh_accel_add_rib_scene", "lh_hdr_write",
@@ -165,6 +170,8 @@ def lib():
                                     C.POINTER(C.c_float * 3), C.c_uint64, vp, C.POINTER(PtStats), vp]
     L.lh_accel_beam_visibility_host.argtypes = [vp, sz, vp, vp, vp]
     L.lh_accel_beam_visibility_device.argtypes = [vp, sz, vp, vp, vp, vp]
+    L.lh_accel_beam_raster_host.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp]
+    L.lh_accel_beam_raster_device.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, vp]
     L.lh_accel_set_material.argtypes = [vp, u32, C.POINTER(Material)]
     L.lh_accel_set_environment.argtypes = [vp, C.POINTER(Environment)]
     L.lh_render_pt_bands.argtypes = [vp, C.POINTER(Camera), i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(Material), C.c_uint64, vp,
@@ -396,6 +403,22 @@ class HipAccel:
     def dump_node_bytes(self):
         """64: ray dumps walk the 4-wide nodes; 128: the 8-wide nodes (scene larger than the Infinity Cache, or wide8 = 1)"""
         return int(self.L.lh_accel_dump_node_bytes(self.h))
+
+    def beam_raster(self, org, corner_dirs, corners, width, height, frame, eye, fov, t_init=None):
+        """ri_beam_set + ri_raster_plane_setup + ri_bvh_intersect_beam for n beams over one width x height raster window
+        (frame = du dv dw, eye = plane->org, fov in degrees; corners [n,3] = plane->corner per beam).
+        -> (t [n,height,width] float64, status int32 [n] (0 traced, 1 nothing done, -1 invalid beam), flags uint64 [n,4]);
+        planes that are not traced keep t_init (default zeros = a freshly set-up plane)"""
+        o = np.ascontiguousarray(org, np.float64).reshape(-1, 3); n = o.shape[0]
+        d = np.ascontiguousarray(corner_dirs, np.float64).reshape(n, 4, 3)
+        c = np.ascontiguousarray(corners, np.float64).reshape(n, 3)
+        pl = RasterPlane(int(width), int(height), (C.c_double * 9)(*np.asarray(frame, np.float64).reshape(-1)),
+                         (C.c_double * 3)(*np.asarray(eye, np.float64).reshape(-1)), float(fov))
+        t = np.zeros((n, height, width)) if t_init is None else np.ascontiguousarray(t_init, np.float64).reshape(n, height, width).copy()
+        st = np.empty(n, np.int32); fl = np.zeros((n, 4), np.uint64)
+        _check(self.L.lh_accel_beam_raster_host(self.h, n, o.ctypes.data, d.ctypes.data, c.ctypes.data, C.addressof(pl),
+                                                t.ctypes.data, st.ctypes.data, fl.ctypes.data), "lh_accel_beam_raster_host")
+        return t, st, fl
 
     def beam_visibility(self, org, corner_dirs):
         """ri_beam_set + ri_bvh_intersect_beam_visibility for n beams: org [n,3], corner_dirs [n,4,3]

@@ -405,3 +405,60 @@ extern "C" int lh_accel_beam_visibility_host(lh_accel_t *a, size_t n, const doub
     return 0;
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* the beam-raster path (ri_bvh_intersect_beam, bvh.c:544-609)               */
+/* ------------------------------------------------------------------------ */
+extern "C" int lh_launch_beam_raster(const lh_dev_scene_t *sc, size_t n, const double *d_org, const double *d_dirs, const double *d_corner,
+                                     const lh_raster_plane_t *plane, double ktan, double *d_t, int32_t *d_status, unsigned long long *d_flags,
+                                     void *stream);
+
+extern "C" int lh_accel_beam_raster_device(lh_accel_t *a, size_t n, const void *d_org, const void *d_dirs, const void *d_corner,
+                                           const lh_raster_plane_t *plane, void *d_t, void *d_status, void *d_flags, void *stream)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("beam_raster: accel not committed");
+    if (n == 0) return 0;
+    if (!d_org || !d_dirs || !d_corner || !plane || !d_t || !d_status) return fail("beam_raster: NULL argument");
+    if (plane->width <= 0 || plane->height <= 0) return fail("beam_raster: the raster window is %d x %d", plane->width, plane->height);
+    if (!a->hs->have_ref) return fail("beam_raster: the reference-order tree was disabled (LH_REFTREE=0)");
+    if (lh_sync_ref(a, true) != 0) return -1;
+    HIPCHK(hipSetDevice(a->device));
+    lh_dev_scene_t sc = a->dev;
+    if (a->hs->bvh.ntris == 0) { sc.ref_empty = 1; }
+    /* (1.0 / tan(0.5 * fov_rad)) exactly as raster.c:120,135-136 evaluates it, on the host */
+    const double fov_rad = plane->fov * M_PI / 180.0;
+    const double ktan = 1.0 / tan(0.5 * fov_rad);
+    if (lh_launch_beam_raster(&sc, n, (const double *)d_org, (const double *)d_dirs, (const double *)d_corner, plane, ktan, (double *)d_t,
+                              (int32_t *)d_status, (unsigned long long *)d_flags, stream) != 0)
+        return fail("beam raster kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
+extern "C" int lh_accel_beam_raster_host(lh_accel_t *a, size_t n, const double *org, const double *dirs, const double *corner,
+                                         const lh_raster_plane_t *plane, double *t_out, int32_t *status, uint64_t *flags)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("beam_raster: accel not committed");
+    if (n == 0) return 0;
+    if (!org || !dirs || !corner || !plane || !t_out || !status) return fail("beam_raster: NULL argument");
+    if (plane->width <= 0 || plane->height <= 0) return fail("beam_raster: the raster window is %d x %d", plane->width, plane->height);
+    HIPCHK(hipSetDevice(a->device));
+    const size_t px = (size_t)plane->width * (size_t)plane->height;
+    const size_t bo = sizeof(double) * 3 * n, bd = sizeof(double) * 12 * n, bt = sizeof(double) * px * n, bs = (sizeof(int32_t) * n + 7) & ~(size_t)7,
+                 bf = sizeof(uint64_t) * 4 * n;
+    if (lh_ensure_stage(a, 2 * bo + bd + bt + bs + bf + 64) != 0) return -1;
+    char *base = (char *)a->d_stage;
+    char *d_org = base, *d_dirs = base + bo, *d_corner = d_dirs + bd, *d_t = d_corner + bo, *d_st = d_t + bt, *d_fl = d_st + bs;
+    HIPCHK(hipMemcpyAsync(d_org, org, bo, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_dirs, dirs, bd, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_corner, corner, bo, hipMemcpyHostToDevice, a->stream));
+    /* planes that are not traced keep the caller's contents: the staging copy starts as the caller's */
+    HIPCHK(hipMemcpyAsync(d_t, t_out, bt, hipMemcpyHostToDevice, a->stream));
+    if (lh_accel_beam_raster_device(a, n, d_org, d_dirs, d_corner, plane, d_t, d_st, d_fl, a->stream) != 0) return -1;
+    HIPCHK(hipMemcpyAsync(t_out, d_t, bt, hipMemcpyDeviceToHost, a->stream));
+    HIPCHK(hipMemcpyAsync(status, d_st, sizeof(int32_t) * n, hipMemcpyDeviceToHost, a->stream));
+    if (flags) HIPCHK(hipMemcpyAsync(flags, d_fl, bf, hipMemcpyDeviceToHost, a->stream));
+    HIPCHK(hipStreamSynchronize(a->stream));
+    return 0;
+}

@@ -156,6 +156,14 @@ uint64_t lo_render_pt(const lo_scene_t *scene, const lo_camera_t *cam, int x0, i
 void lo_beam_visibility_batch(const lo_scene_t *scene, size_t n, const double *org_xyz,
                               const double *dirs_xyz, int32_t *result);
 
+/* The beam-raster path: ri_beam_set + ri_raster_plane_setup + ri_bvh_intersect_beam (bvh.c:544-609) for one beam, restated as
+ * the reference behaves (lucille_oracle_beam.c has the list of its quirks).  dirs: 4 x 3; frame9: du dv dw; t_out: width *
+ * height doubles.  -1: ri_beam_set refuses the beam.  flags_out[4] (may be NULL): pixel tests outside the raster window (heap
+ * corruption in the reference), assert(t >= 0) / assert(outer_len < 8) failures (aborts in the reference), triangles rasterised. */
+int lo_beam_raster(const lo_scene_t *scene, const double *org, const double *dirs, int width, int height,
+                   const double *frame9, const double *corner, const double *eye, double fov, double *t_out,
+                   uint64_t *flags_out);
+
 #ifdef __cplusplus
 }
 #endif

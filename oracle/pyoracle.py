@@ -101,6 +101,7 @@ def lib():
         L.lo_brute_force_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _u32p, _dp, _dp, _dp, C.c_int]
         L.lo_beam_visibility_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, C.POINTER(C.c_int32)]
         L.lo_scene_leaf_order.argtypes = [C.c_void_p, _u32p, _u32p]
+        L.lo_beam_raster.argtypes = [C.c_void_p, _dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _u64p]
         L.lo_count_equal_t_batch.argtypes = [C.c_void_p, C.c_size_t, _dp, _dp, _dp, _u32p]
         L.lo_scene_set_normals.argtypes = [C.c_void_p, C.c_uint32, _dp, C.c_int]
         L.lo_camera_ray.argtypes = [C.POINTER(Camera), C.c_double, C.c_double, _dp, _dp]
@@ -264,6 +265,15 @@ class Oracle:
         self.L.lo_beam_visibility_batch(self.h, org.shape[0], _p(org, _dp), _p(dirs, _dp), res.ctypes.data_as(C.POINTER(C.c_int32)))
         return res
 
+    def beam_raster(self, org, dirs, width, height, frame, corner, eye, fov):
+        """ri_beam_set + ri_raster_plane_setup + ri_bvh_intersect_beam for ONE beam -> (rc, t[height, width], flags[4]);
+        rc -1: ri_beam_set refuses; flags: lo_beam_raster (lucille_oracle.h)"""
+        a = [_c(x, np.float64).reshape(-1) for x in (org, dirs, frame, corner, eye)]
+        t = np.zeros((height, width)); fl = np.zeros(4, np.uint64)
+        rc = self.L.lo_beam_raster(self.h, _p(a[0], _dp), _p(a[1], _dp), int(width), int(height), _p(a[2], _dp), _p(a[3], _dp),
+                                   _p(a[4], _dp), float(fov), _p(t, _dp), _p(fl, _u64p))
+        return rc, t, fl
+
     def leaf_order(self):
         n = self.ntriangles
         lp = np.empty(n, np.uint32); pf = np.empty(n, np.uint32)
@@ -345,6 +355,17 @@ class RefLib:
         self.L.lref_beam_visibility_batch(org.shape[0], _p(org, _dp), _p(dirs, _dp), res.ctypes.data_as(C.POINTER(C.c_int32)))
         return res
 
+    def beam_raster(self, org, dirs, width, height, frame, corner, eye, fov, invalidate=True):
+        """the reference's own beam-raster path for ONE beam (ref_harness.c lref_beam_raster) -> (rc, t[height, width]).
+        NOT SAFE in-process: a beam whose footprint leaves the raster window makes the reference write outside plane->t and
+        its asserts abort -- use ref_beam_raster_child()."""
+        self.L.lref_beam_raster.argtypes = [_dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_int, _dp]
+        a = [_c(x, np.float64).reshape(-1) for x in (org, dirs, frame, corner, eye)]
+        t = np.zeros((height, width))
+        rc = self.L.lref_beam_raster(_p(a[0], _dp), _p(a[1], _dp), int(width), int(height), _p(a[2], _dp), _p(a[3], _dp),
+                                     _p(a[4], _dp), float(fov), 1 if invalidate else 0, _p(t, _dp))
+        return rc, t
+
     def intersect(self, org, dr, state=False, counters=False):
         org = _c(org, np.float64).reshape(-1, 3); dr = _c(dr, np.float64).reshape(-1, 3)
         n = org.shape[0]
@@ -362,3 +383,56 @@ class RefLib:
             self.L.lref_counters_get(_p(o, _u64p))
             out.append(dict(zip(("ninner", "nleaf", "ntested", "nhit", "nrays"), map(int, o))))
         return tuple(out)
+
+
+# ---- beam-raster helpers (test infrastructure) ---------------------------------------------------------------------
+def beam_camera(eye, lookat, up, width, height, fov):
+    """the testbed's camera set-up (src/testbed/simplerender.cpp:37-70): -> corner, du, dv, dw"""
+    eye = np.asarray(eye, np.float64); lookat = np.asarray(lookat, np.float64); up = np.asarray(up, np.float64)
+    flen = 0.5 * width / np.tan(0.5 * (fov * np.pi / 180.0))
+    dw = lookat - eye
+    du = np.cross(dw, up); du = du / np.linalg.norm(du)
+    dv = np.cross(dw, du); dv = dv / np.linalg.norm(dv)
+    dw = dw / np.linalg.norm(dw)
+    return flen * dw - 0.5 * (width * du + height * dv), du, dv, dw
+
+
+def beam_dirs(corner, du, dv, size, s, t):
+    """the four corner directions of the beam over pixels [s, s + size) x [t, t + size) (simplerender.cpp:88-120)"""
+    return np.array([corner + (s + a) * du + (t + b) * dv for a, b in ((0, 0), (size, 0), (size, size), (0, size))])
+
+
+def _ref_beam_child(meshes, beams, q):
+    ref = RefLib()
+    for P, idx in meshes:
+        ref.add_mesh(P, idx)
+    ref.build()
+    out = []
+    for b in beams:
+        out.append(ref.beam_raster(*b))
+        q.put((len(out) - 1, out[-1]))
+    q.put(None)
+
+
+def ref_beam_raster_child(meshes, beams, timeout=120):
+    """Run the compiled reference's beam-raster path in a CHILD process, one scene, a list of beams (argument tuples of
+    RefLib.beam_raster).  -> list of (rc, t) per beam, None from the first beam on that killed the child (assert, heap
+    corruption, hang)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=_ref_beam_child, args=(meshes, beams, q))
+    p.start()
+    res = [None] * len(beams)
+    try:
+        while True:
+            item = q.get(timeout=timeout)
+            if item is None:
+                break
+            res[item[0]] = item[1]
+    except Exception:
+        pass
+    p.join(5)
+    if p.is_alive():
+        p.kill(); p.join()
+    return res

@@ -37,6 +37,7 @@
 #include "ray.h"
 #include "intersection_state.h"
 #include "beam.h"
+#include "raster.h"
 #include "context.h"
 #include "option.h"
 #include "camera.h"
@@ -445,6 +446,41 @@ void lref_beam_visibility_batch(size_t n, const double *org, const double *dirs,
         if (i != 0) { result[r] = -1; continue; }
         result[r] = ri_bvh_intersect_beam_visibility(accel, &beam, NULL);
     }
+}
+
+/* the beam-raster path through the reference's own ri_beam_set (beam.c:331-465), ri_raster_plane_setup (raster.c:42-147),
+ * ri_bvh_invalidate_cache (bvh.c:420-428; the testbed's "MUST CALL", simplerender.cpp:693) and ri_bvh_intersect_beam
+ * (bvh.c:544-609 -> bvh_traverse_beam :2547-2643 -> bvh_intersect_leaf_node_beam :2315-2426 -> project_triangles :2751-2820,
+ * ri_beam_clip_by_triangle2d beam.c:469-730, ri_rasterize_beam raster.c:333-382).  The debug printf()s of that path go to
+ * /dev/null (stdout swapped for the call, the reference is not edited).  frame9: du dv dw; t_out: w * h doubles = plane->t.
+ * Returns -1 where ri_beam_set refuses the beam, else ri_bvh_intersect_beam's return value (always 0).
+ * The reference writes plane->t[t * width + s] without a bounds check (raster.c:300-316): a beam whose footprint leaves the
+ * raster window corrupts the heap -- callers run this in a child process and keep to beams inside the window. */
+int lref_beam_raster(const double *org, const double *dirs, int w, int h, const double *frame9, const double *corner,
+                     const double *eye, double fov, int invalidate, double *t_out)
+{
+    void *accel = ri_render_get()->scene->accel->data;
+    static ri_raster_plane_t *plane = NULL;
+    ri_beam_t beam; ri_vector_t o, d[4], fr[3], cn, ey; int i, k, rc;
+    FILE *saved_err = stderr, *saved_out = stdout, *nul = fopen("/dev/null", "w");
+    memset(&beam, 0, sizeof(beam));
+    for (k = 0; k < 3; k++) { o[k] = org[k]; cn[k] = corner[k]; ey[k] = eye[k]; }
+    o[3] = cn[3] = ey[3] = 0.0;
+    for (i = 0; i < 4; i++) { for (k = 0; k < 3; k++) d[i][k] = dirs[3 * i + k]; d[i][3] = 0.0; }
+    for (i = 0; i < 3; i++) { for (k = 0; k < 3; k++) fr[i][k] = frame9[3 * i + k]; fr[i][3] = 0.0; }
+    stderr = nul; stdout = nul;
+    rc = ri_beam_set(&beam, o, d);
+    if (rc == 0) {
+        if (!plane) plane = ri_raster_plane_new();
+        ri_raster_plane_setup(plane, w, h, fr, cn, ey, fov);
+        if (invalidate) ri_bvh_invalidate_cache(accel);
+        rc = ri_bvh_intersect_beam(accel, &beam, plane, NULL);
+        memcpy(t_out, plane->t, sizeof(double) * (size_t)w * (size_t)h);
+    } else rc = -1;
+    fflush(nul);
+    stderr = saved_err; stdout = saved_out;
+    fclose(nul);
+    return rc;
 }
 
 /* recorder control */

@@ -150,6 +150,24 @@ def beam_fixture(name, ntri, half_extent, seed, nbeams):
     print(name, {k: np.bincount(v + 1, minlength=4).tolist() for k, v in out.items()})
 
 
+def beam_raster_fixture(name="beam_raster"):
+    """ri_beam_set + ri_raster_plane_setup + ri_bvh_invalidate_cache + ri_bvh_intersect_beam of the compiled reference
+    (ref_harness.c lref_beam_raster, run in a child process: the path asserts and writes unchecked) on the seeded cases of
+    tests.helpers.raster_case: expected plane->t per beam.  Inputs are reproducible from CASES."""
+    from tests.helpers import raster_case, RASTER_GOLDEN_CASES
+    out = {}
+    for k, kw in enumerate(RASTER_GOLDEN_CASES):
+        c = raster_case(**kw)
+        beams = [(c["org"][i], c["dirs"][i], c["width"], c["height"], c["frame"], c["corners"][i], c["eye"], c["fov"])
+                 for i in range(c["org"].shape[0])]
+        res = po.ref_beam_raster_child([(c["P"], c["idx"])], beams)
+        assert all(r is not None for r in res), "the reference died on a beam of case %d" % k
+        out["rc%d" % k] = np.array([r[0] for r in res], np.int32)
+        out["t%d" % k] = np.stack([r[1] for r in res])
+        print(name, "case", k, kw, "pixels written", [int((r[1] != 0).sum()) for r in res])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), ncases=len(RASTER_GOLDEN_CASES), **out)
+
+
 def rib_fixture():
     """What the reference's RenderMan front end makes of the RIB files under tests/golden/rib/
     (its geoms after ingest, in order, and its camera), captured through its own Ri C API
@@ -201,6 +219,8 @@ if __name__ == "__main__":
         rib_fixture(); hdr_fixture(); sys.exit(0)
     if "--state" in sys.argv:
         state_fixture(); sys.exit(0)
+    if "--beam-raster" in sys.argv:
+        beam_raster_fixture(); sys.exit(0)
     if not po.ref_available(stat=True):
         po.build_ref()
     soup_fixture("soup_20k", 20000, 20000, 0.005)
@@ -215,5 +235,6 @@ if __name__ == "__main__":
     rib_fixture()
     hdr_fixture()
     state_fixture()
+    beam_raster_fixture()
     # check values of the full S-soup-1M are pinned in
     # tests/test_oracle_vs_ref.py against the live reference, not stored here.

@@ -226,3 +226,56 @@ def vertex_aimed_rays(rng, P, idx, n, spread=1.2):
     tgt[1::3] = 0.5 * (T[pick[1::3], 0] + T[pick[1::3], 1])
     tgt[2::5] = T[pick[2::5]].mean(axis=1)
     return org, tgt - org
+
+
+# ---- the beam-raster path (ri_bvh_intersect_beam): seeded cases ----------------------------------------------------
+def raster_camera(eye, lookat, up, width, height, fov):
+    """the testbed's camera (src/testbed/simplerender.cpp:37-70): -> corner, frame [du, dv, dw]"""
+    eye = np.asarray(eye, np.float64); lookat = np.asarray(lookat, np.float64); up = np.asarray(up, np.float64)
+    flen = 0.5 * width / np.tan(0.5 * (fov * np.pi / 180.0))
+    dw = lookat - eye
+    du = np.cross(dw, up); du = du / np.linalg.norm(du)
+    dv = np.cross(dw, du); dv = dv / np.linalg.norm(dv)
+    dw = dw / np.linalg.norm(dw)
+    return flen * dw - 0.5 * (width * du + height * dv), np.stack([du, dv, dw])
+
+
+def raster_beam_dirs(corner, frame, size, s, t):
+    """corner directions of the beam over pixels [s, s + size) x [t, t + size) (simplerender.cpp:88-120)"""
+    du, dv = frame[0], frame[1]
+    return np.array([corner + (s + a) * du + (t + b) * dv for a, b in ((0, 0), (size, 0), (size, size), (0, size))])
+
+
+def raster_case(seed, ntri, width, height, nbeams, eye=(0.0, 0.0, 0.0), fov=45.0, tri_size=0.6, inside=True):
+    """A seeded scene in front of a camera looking down +z and `nbeams` square beams, each inside ONE quadrant of the
+    window (ri_beam_set refuses beams whose corner directions differ in sign).  inside=False lets beams hang over the
+    window's edge (undefined in the reference: it writes outside plane->t).
+    -> dict(P, idx, eye, fov, width, height, frame, corner, org [n,3], dirs [n,4,3], corners [n,3])"""
+    rng = np.random.default_rng(seed)
+    c = np.stack([rng.uniform(-2, 2, ntri), rng.uniform(-2, 2, ntri), rng.uniform(4, 8, ntri)], 1)[:, None, :]
+    P = (c + rng.uniform(-tri_size, tri_size, (ntri, 3, 3))).reshape(-1, 3)
+    idx = np.arange(3 * ntri, dtype=np.uint32)
+    eye = np.asarray(eye, np.float64)
+    corner, frame = raster_camera(eye, eye + np.array([0.0, 0.0, 1.0]), [0.0, 1.0, 0.0], width, height, fov)
+    dirs = []
+    hw, hh = width // 2, height // 2
+    for _ in range(nbeams):
+        size = int(rng.integers(2, min(hw, hh) - 1))
+        qx, qy = (int(v) for v in rng.integers(0, 2, 2))
+        s = int(rng.integers(0, hw - size)) + qx * hw
+        t = int(rng.integers(0, hh - size)) + qy * hh
+        if not inside:                         # push the beam over the outer edge of its quadrant
+            s = (width - size // 2) if qx else -(size // 2)
+        dirs.append(raster_beam_dirs(corner, frame, size, s, t))
+    n = nbeams
+    return dict(P=P, idx=idx, eye=eye, fov=fov, width=width, height=height, frame=frame, corner=corner,
+                org=np.repeat(eye[None], n, 0), dirs=np.array(dirs), corners=np.repeat(corner[None], n, 0))
+
+
+# the cases tests/golden/beam_raster.npz holds the compiled reference's planes for (tests/golden/make_golden.py)
+RASTER_GOLDEN_CASES = (
+    dict(seed=7, ntri=200, width=64, height=64, nbeams=12, eye=(0.2, -0.1, 0.3)),      # eye off the origin: project_triangles' quirk shows
+    dict(seed=11, ntri=40, width=32, height=32, nbeams=8),
+    dict(seed=13, ntri=1500, width=48, height=48, nbeams=6, tri_size=0.25),
+    dict(seed=17, ntri=300, width=128, height=128, nbeams=6, eye=(-0.4, 0.3, -0.2), fov=60.0),   # two columns per lane on the device
+)
