@@ -191,8 +191,40 @@ int  ri_hipbvh_intersect_beam_visibility(void *accel, ri_beam_t *beam, void *use
 /* n beams in one launch; result[i] = RI_BEAM_* or -1 where ri_beam_set refuses the beam */
 int  ri_hipbvh_intersect_beam_visibility_batch(void *accel, size_t n, const double *org_xyz,
                                                const double *corner_dirs_xyz, int32_t *result);
+/* ---- the beam-raster path (raster.h:24-84, bvh.h:203-206) ----
+ * ri_raster_plane_t as raster.h:24-57 declares it; _new / _setup / _free as raster.c:24-160 (setup allocates and zeroes the
+ * five arrays and computes `offset`, the lower-left corner in NDC).  ri_hipbvh_intersect_beam = ri_bvh_intersect_beam
+ * (bvh.c:544-609): returns 0 like the reference; afterwards raster_out->t holds what the reference's path leaves there (its
+ * quirks included: lucille_hip.h "the beam-raster path"); u, v, geom, index are never written (the reference does not
+ * either); `user` is ignored.  Beams whose footprint leaves the window are cut to it (the reference writes out of bounds). */
+typedef struct _ri_raster_plane_t {
+    ri_float_t  *t, *u, *v;           /* [width * height] */
+    ri_geom_t  **geom;
+    uint32_t    *index;
+    int          width, height;
+    ri_vector_t  frame[3];            /* du dv dw */
+    ri_vector_t  corner;              /* lower-left of the raster plane in 3-D */
+    ri_vector_t  org;                 /* eye */
+    ri_float_t   fov;                 /* degrees */
+    ri_float_t   offset[2];
+    ri_float_t   scale[2];
+} ri_raster_plane_t;
+
+ri_raster_plane_t *ri_raster_plane_new(void);
+int  ri_raster_plane_setup(ri_raster_plane_t *plane, int width, int height, ri_vector_t frame[3], ri_vector_t corner,
+                           ri_vector_t org, ri_float_t fov);
+int  ri_raster_plane_free(ri_raster_plane_t *plane);
+int  ri_hipbvh_intersect_beam(void *accel, ri_beam_t *beam, ri_raster_plane_t *raster_out, void *user);
+/* n beams over windows of one size in one launch (plain arrays; lh_accel_beam_raster_host in lucille_hip.h has the details):
+ * corner_dirs n x 4 x 3, corners n x 3, frame9 = du dv dw, t_out n x height x width, status n (0 traced, 1 nothing done,
+ * -1 refused by ri_beam_set), flags n x 4 or NULL.  Returns 0 / -1. */
+int  ri_hipbvh_intersect_beam_batch(void *accel, size_t n, const double *org_xyz, const double *corner_dirs_xyz,
+                                    const double *corners_xyz, int width, int height, const double *frame9,
+                                    const double *eye_xyz, double fov, double *t_out, int32_t *status, uint64_t *flags);
+
 /* ri_bvh_invalidate_cache (bvh.c:389-428) frees the lazily built per-leaf 2-D triangle caches of
- * the beam-raster path; this accelerator has none: a no-op kept for source compatibility. */
+ * the beam-raster path; this accelerator keeps none (every beam projects with its own origin, i.e. it
+ * always behaves as the reference does right after this call): a no-op kept for source compatibility. */
 void ri_hipbvh_invalidate_cache(void *accel);
 
 /* ri_bvh_clear_stat_traversal / ri_bvh_report_stat_traversal (bvh.c:669-706).  The reference

@@ -424,6 +424,78 @@ int ri_hipbvh_intersect_beam_visibility(void *accel, ri_beam_t *beam, void *user
     return cls < 0 ? 0 : (int)cls;
 }
 
+/* ---------------------------------------------------------- beam raster ---- */
+
+/* ri_raster_plane_new / _setup / _free, src/render/raster.c:24-160 */
+ri_raster_plane_t *ri_raster_plane_new(void)
+{
+    return (ri_raster_plane_t *)calloc(1, sizeof(ri_raster_plane_t));
+}
+
+int ri_raster_plane_setup(ri_raster_plane_t *pl, int width, int height, ri_vector_t frame[3], ri_vector_t corner, ri_vector_t org,
+                          ri_float_t fov)
+{
+    size_t sz; double fov_rad, w[3], p[2];
+    if (!pl || width <= 0 || height <= 0) return -1;
+    sz = (size_t)width * (size_t)height;
+    free(pl->t); free(pl->u); free(pl->v); free(pl->geom); free(pl->index);
+    pl->width = width; pl->height = height;
+    pl->t = (ri_float_t *)calloc(sz, sizeof(ri_float_t)); pl->u = (ri_float_t *)calloc(sz, sizeof(ri_float_t));
+    pl->v = (ri_float_t *)calloc(sz, sizeof(ri_float_t)); pl->geom = (ri_geom_t **)calloc(sz, sizeof(ri_geom_t *));
+    pl->index = (uint32_t *)calloc(sz, sizeof(uint32_t));
+    if (!pl->t || !pl->u || !pl->v || !pl->geom || !pl->index) return -1;
+    memcpy(pl->frame, frame, sizeof(ri_vector_t) * 3);
+    memcpy(pl->corner, corner, sizeof(ri_vector_t)); memcpy(pl->org, org, sizeof(ri_vector_t));
+    pl->fov = fov;
+    /* the lower-left corner in NDC (raster.c:114-144) */
+    fov_rad = pl->fov * M_PI / 180.0;
+    w[0] =  pl->frame[0][0] * corner[0] + pl->frame[0][1] * corner[1] + pl->frame[0][2] * corner[2];
+    w[1] =  pl->frame[1][0] * corner[0] + pl->frame[1][1] * corner[1] + pl->frame[1][2] * corner[2];
+    w[2] = -pl->frame[2][0] * corner[0] - pl->frame[2][1] * corner[1] - pl->frame[2][2] * corner[2];
+    p[0] = (1.0 / tan(0.5 * fov_rad)) * w[0]; p[1] = (1.0 / tan(0.5 * fov_rad)) * w[1];
+    p[0] /= -w[2]; p[1] /= -w[2];
+    pl->offset[0] = p[0]; pl->offset[1] = p[1];
+    return 0;
+}
+
+int ri_raster_plane_free(ri_raster_plane_t *pl)
+{
+    if (pl == NULL) return -1;
+    free(pl->t); free(pl->u); free(pl->v); free(pl->geom); free(pl->index);
+    pl->t = pl->u = pl->v = NULL; pl->geom = NULL; pl->index = NULL;
+    return 0;
+}
+
+int ri_hipbvh_intersect_beam_batch(void *accel, size_t n, const double *org, const double *dirs, const double *corners, int width,
+                                   int height, const double *frame9, const double *eye, double fov, double *t_out, int32_t *status,
+                                   uint64_t *flags)
+{
+    hipbvh_t *h = (hipbvh_t *)accel; lh_raster_plane_t pl; int k;
+    if (!h || !frame9 || !eye) return -1;
+    pl.width = width; pl.height = height; pl.fov = fov;
+    for (k = 0; k < 9; k++) pl.frame[k] = frame9[k];
+    for (k = 0; k < 3; k++) pl.eye[k] = eye[k];
+    if (lh_accel_beam_raster_host(h->lh, n, org, dirs, corners, &pl, t_out, status, flags) != 0) {
+        fprintf(stderr, "[lucille_hip] ERROR : (HIPBVH) %s\n", lh_last_error());
+        return -1;
+    }
+    return 0;
+}
+
+/* ri_bvh_intersect_beam, bvh.c:544-609: the beam was accepted by ri_beam_set; always returns 0 */
+int ri_hipbvh_intersect_beam(void *accel, ri_beam_t *beam, ri_raster_plane_t *raster_out, void *user)
+{
+    double org[3], dirs[12], corner[3], frame9[9], eye[3]; int32_t st = 0; int i, k;
+    (void)user;
+    if (!accel || !beam || !raster_out || !raster_out->t) return 0;
+    for (k = 0; k < 3; k++) { org[k] = beam->org[k]; corner[k] = raster_out->corner[k]; eye[k] = raster_out->org[k]; }
+    for (i = 0; i < 4; i++) for (k = 0; k < 3; k++) dirs[3 * i + k] = beam->corner[i][k];
+    for (i = 0; i < 3; i++) for (k = 0; k < 3; k++) frame9[3 * i + k] = raster_out->frame[i][k];
+    ri_hipbvh_intersect_beam_batch(accel, 1, org, dirs, corner, raster_out->width, raster_out->height, frame9, eye, raster_out->fov,
+                                   raster_out->t, &st, NULL);
+    return 0;
+}
+
 void ri_hipbvh_invalidate_cache(void *accel) { (void)accel; }
 
 int ri_accel_prim_lookup(void *accel, uint32_t prim, ri_geom_t **geom, uint32_t *index)

@@ -12,7 +12,9 @@
  *      u32 nbeams; double borg[nbeams][3]; double bdir[nbeams][4][3]
  * out: per ray, single path then batch path: i32 hit, i32 geom ordinal, u32 index, double t,u,v,
  *      P[3], Ng[3], Ns[3], i32 inside; then per beam: i32 ri_beam_set rc, i32 class;
- *      then u64 stat[5]; then i32 bind_unknown_rc, i32 empty_scene_hit
+ *      then u64 stat[5]; then i32 bind_unknown_rc, i32 empty_scene_hit; then the 24 x 16 x 3 float tile;
+ *      then u32 nraster and, per raster beam (the last accepted beams, at most 8), i32 beam ordinal + the 16 x 16 doubles of
+ *      its raster plane's t (ri_raster_plane_setup + ri_hipbvh_intersect_beam)
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -145,6 +147,31 @@ int main(int argc, char **argv)
         CHECK(ri_render_tile_ao(scene->accel->data, &cam, 4, 8, 24, 16, 2, 16, 77ull, rgb) == 0);
         CHECK(ri_render_tile_ao(NULL, &cam, 4, 8, 24, 16, 2, 16, 77ull, rgb) == -1);
         fwrite(rgb, sizeof(float), 24 * 16 * 3, out);
+    }
+    /* 5. the beam-raster path (bvh.h:203-206): a 16 x 16 window per beam -- eye = the beam's origin, axis-aligned frame,
+     * lower-left corner = the beam's first corner direction, 45 degrees */
+    {
+        ri_raster_plane_t *plane = ri_raster_plane_new(); uint32_t nraster = 0, done = 0; long pos;
+        CHECK(plane != NULL);
+        pos = ftell(out); fwrite(&nraster, 4, 1, out);
+        uint32_t bi;
+        for (bi = nbeams; bi > 0 && done < 8; bi--) {         /* from the end: the wide beams */
+            ri_beam_t beam; ri_vector_t o, d[4], frame[3]; int32_t ord; int j;
+            i = bi - 1; ord = (int32_t)i;
+            memset(o, 0, sizeof(o)); memset(d, 0, sizeof(d)); memset(frame, 0, sizeof(frame));
+            for (k = 0; k < 3; k++) o[k] = borg[3 * i + k];
+            for (j = 0; j < 4; j++) for (k = 0; k < 3; k++) d[j][k] = bdir[12 * i + 3 * j + k];
+            if (ri_beam_set(&beam, o, d) != 0) continue;
+            frame[0][0] = 1.0; frame[1][1] = 1.0; frame[2][2] = 1.0;
+            CHECK(ri_raster_plane_setup(plane, 16, 16, frame, d[0], o, 45.0) == 0);
+            CHECK(ri_hipbvh_intersect_beam(scene->accel->data, &beam, plane, NULL) == 0);
+            fwrite(&ord, 4, 1, out); fwrite(plane->t, 8, 256, out);
+            done++;
+        }
+        nraster = done;
+        fseek(out, pos, SEEK_SET); fwrite(&nraster, 4, 1, out); fseek(out, 0, SEEK_END);
+        CHECK(ri_raster_plane_free(plane) == 0);
+        free(plane);
     }
     ri_hipbvh_report_stat_traversal();
 

@@ -85,7 +85,13 @@ def test_lucille_style_c_program_matches_the_oracle(tmp_path):
     beams = np.frombuffer(raw, "<i4", 2 * len(borg), off).reshape(-1, 2); off += 8 * len(borg)
     stat = np.frombuffer(raw, "<u8", 5, off); off += 40
     rc_unknown, empty_hit = np.frombuffer(raw, "<i4", 2, off); off += 8
-    tile_c = np.frombuffer(raw, "<f4", 24 * 16 * 3, off).reshape(16, 24, 3)
+    tile_c = np.frombuffer(raw, "<f4", 24 * 16 * 3, off).reshape(16, 24, 3); off += 4 * 24 * 16 * 3
+    nraster = int(np.frombuffer(raw, "<u4", 1, off)[0]); off += 4
+    raster = []
+    for _ in range(nraster):
+        ordn = int(np.frombuffer(raw, "<i4", 1, off)[0]); off += 4
+        raster.append((ordn, np.frombuffer(raw, "<f8", 256, off).reshape(16, 16))); off += 8 * 256
+    assert off == len(raw)
 
     assert rc_unknown == -1 and empty_hit == 0
     hit = prim != po.MISS
@@ -110,6 +116,15 @@ def test_lucille_style_c_program_matches_the_oracle(tmp_path):
     ok = exp_b >= 0
     assert np.array_equal(beams[ok, 1], exp_b[ok])
     assert ok.sum() > 50 and len(set(exp_b[ok].tolist())) >= 2
+
+    # the beam-raster path through the mirror (ri_raster_plane_setup + ri_hipbvh_intersect_beam): plane->t == the oracle's
+    assert nraster == 8
+    written = 0
+    for ordn, plane_t in raster:
+        rc, t_exp, fl = o.beam_raster(borg[ordn], bdir[ordn], 16, 16, np.eye(3), bdir[ordn][0], borg[ordn], 45.0)
+        assert rc == 0 and np.array_equal(plane_t, t_exp)
+        written += int((plane_t != 0).sum())
+    assert written > 0
 
     # statistics: both legs counted, hits agree with the oracle; work counters are plausible
     assert stat[0] == 2 * nrays and stat[4] == 2 * int(hit.sum())
