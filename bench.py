@@ -51,6 +51,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 B_IN, B_OUT, B_TRI = 32, 16, 40   # SURVEY.md 8(d) algorithmic bytes per ray / per triangle test
+B_NODE_SURVEY = 64                # a node visit is priced at 64 B whatever the record
 B_NODE = {"f32": 64, "q16": 32, "q16x4": 64}   # per node visit: SURVEY's 64-B fp32 2-wide node, 32-B 16-bit grid 2-wide, 64-B 16-bit grid 4-wide
 # check values of the canonical S-soup-1M dump on the UNMODIFIED reference
 SOUP1M_CHECK = {1_000_000: (821_596, 87998.6606), 2_000_000: (1_644_156, 176110.93)}
@@ -124,7 +125,8 @@ def main():
                     help="builders of the headline leg's scene: auto = lh_accel_commit's own choice (the device builders from 1 M triangles on)")
     ap.add_argument("--mode", choices=["closest", "any"], default="closest")
     ap.add_argument("--chunks", type=int, default=4, help="N>1: trace/gather pipeline depth per rank (with_record_gather)")
-    ap.add_argument("--gather-records", action="store_true", help="N>1: gather every hit record to rank 0 inside the headline's timed region")
+    ap.add_argument("--gather-records", action="store_true", help="accepted for compatibility: at N > 1 the gather of every hit record to rank 0 IS inside the headline's timed region (SURVEY 8e)")
+    ap.add_argument("--no-gather-records", action="store_true", help="N>1: headline = the records stay with the rank that traced them (a digest travels); the gathered figure moves to `with_record_gather`")
     ap.add_argument("--cpu-rays", type=int, default=1_500_000, help="cpu_baseline sample size")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-hbm", action="store_true", help="skip the S-soup-10M HBM-roofline leg")
@@ -233,24 +235,29 @@ def main():
     b_ray = B_IN + b_out + B_NODE[node_fmt] * n_nodes + B_TRI * n_tris
 
     # ---- timed region -------------------------------------------------------------
-    head_gather = bool(args.gather_records) or world == 1
-    whole = None
-    if not head_gather:
+    # ONE exchange step -- the hit-record slices gathered to GPU 0.  At N > 1 that gather is INSIDE the headline's timed
+    # region (chunk c on the links while chunk c + 1 is traced), as in rounds 1-2; `records_stay_with_rank` reports the other
+    # reading (a rank's transport stage consumes its own records, only a digest travels) beside it, --no-gather-records swaps them.
+    head_gather = world == 1 or not args.no_gather_records
+    whole = whole_out = None
+    if world > 1:
         # no exchange step: a rank's slice is ONE launch into one record buffer (the chunks exist for the gather pipeline)
         whole = torch.empty(max(n, 1) * rec_bytes, dtype=torch.uint8, device=dev)
         whole_out = record_views(torch, whole, max(n, 1))[:4] if mode == la.MODE_CLOSEST else (whole[:max(n, 1)],)
 
-        def head_step(timed):
-            if n > 0:
-                if timed:
-                    evp.begin(sptr)
-                acc.intersect_device(d_org[:n], d_dir[:n], out=tuple(x[:n] for x in whole_out), mode=mode, variant=args.variant)
-                if timed:
-                    evp.end(sptr)
-        head_step(False)
-    else:
-        def head_step(timed):
-            one_step(timed, world > 1)
+    def stay_step(timed):
+        if n > 0:
+            if timed:
+                evp.begin(sptr)
+            acc.intersect_device(d_org[:n], d_dir[:n], out=tuple(x[:n] for x in whole_out), mode=mode, variant=args.variant)
+            if timed:
+                evp.end(sptr)
+
+    def gather_step(timed):
+        one_step(timed, world > 1)
+    head_step = gather_step if head_gather else stay_step
+    other_step = None if world == 1 else (stay_step if head_gather else gather_step)
+    head_step(False)
     for _ in range(args.warmup):
         head_step(False)
     barrier(); torch.cuda.synchronize(dev)
@@ -260,17 +267,30 @@ def main():
     torch.cuda.synchronize(dev); barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    # N > 1: the same dump with every record gathered to rank 0 (secondary figure; also what fills `gathered` for the validation)
-    gather_elapsed = None
+    # N > 1: the other reading of the exchange step (secondary figure); the gathered pass also fills `gathered` for the validation
+    other_elapsed = None
+    gather_only_ms = None
     if world > 1:
         gsteps = max(1, min(args.steps, 3))
-        one_step(False, True)
+        other_step(False)
         barrier(); torch.cuda.synchronize(dev)
         tg = time.perf_counter()
         for k in range(gsteps):
-            one_step(False, True)
+            other_step(False)
         torch.cuda.synchronize(dev); barrier()
-        gather_elapsed = shard.all_reduce_max((time.perf_counter() - tg) / gsteps)
+        other_elapsed = shard.all_reduce_max((time.perf_counter() - tg) / gsteps)
+        if not head_gather:
+            pass
+        # this rank's share of the exchange alone (nothing traced): what the links cost when they are not hidden
+        barrier(); torch.cuda.synchronize(dev)
+        tg = time.perf_counter()
+        for c in range(nchunks):
+            shard.gather_bytes(bufs[c], gathered[c] if rank == 0 else None, stream=gstream)
+        gstream.synchronize()
+        gather_only_ms = (time.perf_counter() - tg) * 1e3
+        barrier()
+    gather_elapsed = None if world == 1 else (elapsed / args.steps if head_gather else other_elapsed)
+    stay_elapsed = None if world == 1 else (other_elapsed if head_gather else elapsed / args.steps)
     # the same dump on the OTHER builder's tree (N = 1; secondary figure: what the choice of builder costs or gains)
     other = None
     if world == 1 and args.build == "auto" and n > 0:
@@ -295,11 +315,24 @@ def main():
 
     if world > 1:
         elapsed = shard.all_reduce_max(elapsed)
+        if gather_elapsed is not None and head_gather:
+            gather_elapsed = elapsed / args.steps
+        if stay_elapsed is not None and not head_gather:
+            stay_elapsed = elapsed / args.steps
+    # ---- per-rank diagnostics (N > 1): every rank says what it did, on stderr and -- collected by rank 0 -- in the line ----
+    ranks = None
+    if world > 1:
+        d_ = shard.dist()
+        mine = {"rank": rank, "device": local, "transport": "rccl" if (d_ is not None and d_.transport == la.DIST_RCCL) else "shm",
+                "rccl_status": shard.rccl_status(), "rays": int(n), "launches_per_step": int(launches_per_step),
+                "kernel_ms_per_step": round(kernel_ms, 3), "gather_only_ms": None if gather_only_ms is None else round(gather_only_ms, 3)}
+        print("[bench rank %d] %s" % (rank, json.dumps(mine)), file=sys.stderr, flush=True)
+        ranks = shard.all_gather_object(mine)
 
     # ---- the digest every rank sends instead of its records: hits and sum of t of its slice ------------------
     digest = None
     if mode == la.MODE_CLOSEST:
-        if whole is not None:
+        if not head_gather:
             hp = whole_out[0][:n] != -1; ht = whole_out[1][:n]
             lh_, lt_ = float(hp.sum().item()), float(ht[hp].sum().item())
         else:
@@ -314,7 +347,7 @@ def main():
     # ---- validation of the timed launches (rank 0) --------------------------------
     validation = None
     if rank == 0:
-        if whole is not None:       # the headline's own launch: one buffer; the gathered chunks are checked against the chunked pass's
+        if not head_gather:         # the headline's own launch: one buffer; the gathered chunks are checked against the chunked pass's
             validation = validate_dump(torch, la, args, mode, lambda c: (whole_out, n), [(0, n)], cnt_out, ns, gathered, world, per, n_total, bufs, nchunks)
         else:
             validation = validate_dump(torch, la, args, mode, outs_of, cb, cnt_out, ns, gathered, world, per, n_total, bufs, nchunks)
@@ -370,7 +403,7 @@ def main():
                                                                       "" if world == 1 else (", 28-B hit records gathered to rank 0 inside the timed region" if head_gather
                                                                                              else ", hit records stay with the rank that traced them (digest to rank 0)")),
                        "rays": n_total, "rays_per_gpu": n, "triangles": args.tris, "mode": args.mode,
-                       "variant": args.variant, "parallelism": "replicated BVH, ray slices x%d%s" % (world, "" if world == 1 else (", %d-chunk trace/gather pipeline" % nchunks if args.gather_records else ", one launch per rank, no per-ray exchange")),
+                       "variant": args.variant, "parallelism": "replicated BVH, ray slices x%d%s" % (world, "" if world == 1 else (", %d-chunk trace/gather pipeline" % nchunks if head_gather else ", one launch per rank, no per-ray exchange")),
                        "scene_load": {"rank0_commit_s": round(commit_s, 3), "broadcast_s": round(bcast_s, 3) if world > 1 else None,
                                       "transport": None if world == 1 else ("rccl" if shard.dist().transport == la.DIST_RCCL else "shm (ranks share a device)"),
                                       "note": "one build on rank 0, flattened arrays broadcast to every rank (lh_dist_broadcast_scene)"},
@@ -378,8 +411,13 @@ def main():
                                "other_builder": other,
                                "nodes": info["nnodes_traversal"], "depth": info["max_depth"], "device_bytes": info["device_bytes"],
                                "build_s": round(info["build_seconds"], 3), "ref_tree_build_s": round(info["ref_build_seconds"], 3)}},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "l2+mall" if hot_mb < 256.0 else "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_over_algorithmic": None if traffic is None else round(traffic / (b_ray * n), 3),
+                         "peak_note": "peak = the 8 TB/s HBM datasheet figure, kept as the common denominator; this workload's hot set is cache-resident, "
+                                      "so `frac` is NOT a fraction of a bandwidth the data asked of HBM -- the HBM-bound figure is roofline_hbm.frac",
+                         "formula": "bytes_per_ray = %d + %d + %d x nodes_per_ray + %d x tris_per_ray (SURVEY 8d); achieved = bytes_per_ray x rays_per_launch / kernel_ms; "
+                                    "frac = achieved / peak" % (B_IN, b_out, B_NODE[node_fmt], B_TRI),
                          "residency": "hot set %.0f MB (4-wide nodes + tri32) < 256 MiB Infinity Cache: served by L2 + MALL, "
                                       "NOT an HBM measurement; see roofline_hbm" % hot_mb,
                          "kernel": "k_trace_persist_lane<walk=spec,%s nodes>" % node_fmt if args.variant in (-1, 4) else "k_trace_direct<%s nodes>" % node_fmt,
@@ -394,11 +432,23 @@ def main():
         if validation is not None and other is not None and other["records_bit_equal"] is not None:
             validation["records_equal_on_the_other_builders_tree"] = other["records_bit_equal"]       # hit records do not depend on the tree
             validation["ok"] = bool(validation["ok"]) and bool(other["records_bit_equal"])
-        if gather_elapsed is not None:
+        if world > 1:
+            res["exchange"] = {"headline_includes_record_gather": bool(head_gather),
+                               "definition": "SURVEY 8e: hit-record slices gathered to GPU 0 (one exchange step); the gather is inside the headline's timed region "
+                                             "unless --no-gather-records.  Rounds 1-2 timed it inside, round 3's headline did not: compare N > 1 values across rounds "
+                                             "through `with_record_gather` / `records_stay_with_rank`, which every round from 4 on emits side by side"}
             res["with_record_gather"] = {"value": round(n_total / gather_elapsed / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(gather_elapsed * 1e3, 3),
-                                         "bytes_to_rank0_per_step": int(rec_bytes * (n_total - n)),
-                                         "note": "the same dump, every hit record gathered to rank 0 in %d chunks behind the tracing of the next chunk (lh_dist_gather: RCCL "
+                                         "is_headline": bool(head_gather), "bytes_to_rank0_per_step": int(rec_bytes * (n_total - n)),
+                                         "note": "every hit record gathered to rank 0 in %d chunks behind the tracing of the next chunk (lh_dist_gather: RCCL "
                                                  "point-to-point, one xGMI link per peer)" % nchunks}
+            res["records_stay_with_rank"] = {"value": round(n_total / stay_elapsed / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(stay_elapsed * 1e3, 3),
+                                             "is_headline": not head_gather,
+                                             "note": "one launch per rank, the records stay in the HBM of the rank that traced them (its transport stage consumes them), "
+                                                     "rank 0 collects a digest per rank (hits, sum of t)"}
+            res["ranks"] = ranks
+            bad = [r_ for r_ in ranks if r_["transport"] != "rccl"]
+            distinct = len(set(r_["device"] for r_ in ranks)) == world
+            res["exchange"]["transport_ok"] = not (bad and distinct and os.environ.get("LH_DIST_TRANSPORT") != "shm")
         if copy_gbps is not None:
             # the box's own device-to-device copy rate next to the 8 TB/s datasheet peak
             res["roofline"]["measured_copy_GBps"] = round(copy_gbps, 1)
@@ -420,10 +470,21 @@ def main():
             res["cpu_baseline"] = cpu_baseline(P, idx, first[0], first[1])
         print(json.dumps(res), flush=True)
     acc.close()
+    rc = 0
     if world > 1:
+        # a rank that fell back to the shared-memory transport although every rank has its own device makes the scaling figure
+        # meaningless (host staging instead of xGMI): the run fails, loudly, on every rank
+        bad_local = 1.0 if (shard.dist().transport != la.DIST_RCCL and args.device_override is None
+                            and os.environ.get("LH_DIST_TRANSPORT") != "shm") else 0.0
+        if shard.all_reduce_max(bad_local) > 0.5:
+            print("[bench rank %d] FAILED: the RCCL transport did not come up on every rank (%s); the figures above were taken over the "
+                  "shared-memory fallback" % (rank, shard.rccl_status()), file=sys.stderr, flush=True)
+            rc = 3
         shard.barrier()
         shard.dist().close()
         torch.distributed.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 def validate_dump(torch, la, args, mode, outs_of, cb, cnt_out, ns, gathered, world, per, n_total, bufs, nchunks):
@@ -516,7 +577,10 @@ def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
     node_bytes = acc.dump_node_bytes()              # 128: the 8-wide nodes (hot set beyond the Infinity Cache), else the 4-wide node's 64
     if node_bytes == 128:
         node_fmt = "q16x8"
-    b_ray = B_IN + B_OUT + node_bytes * n_nodes + B_TRI * n_tris
+    # SURVEY 8d prices EVERY node visit at 64 B (B_node), whatever record the walk really fetches: that is `bytes_per_ray`,
+    # `achieved` and `frac` below.  The 8-wide walk fetches one 128-byte record per visit (and makes fewer visits); its record
+    # bytes are reported as a plain number (`record_bytes_per_ray`), not as a bandwidth -- part of them is served by caches.
+    b_ray = B_IN + B_OUT + B_NODE_SURVEY * n_nodes + B_TRI * n_tris
     # the same sample through the 4-wide walk: hit records do not depend on the tree
     cross = None
     if node_bytes == 128:
@@ -526,22 +590,18 @@ def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
         acc.set_param("wide8", -1)
         del alt
     steps = 3
-    evp = EventPairs(hip, steps)
-    acc.intersect_device(d_org, d_dir, out=out); torch.cuda.synchronize(dev)
-    for _ in range(steps):
-        evp.begin(sptr); acc.intersect_device(d_org, d_dir, out=out); evp.end(sptr)
-    torch.cuda.synchronize(dev)
-    ms = float(np.mean(evp.ms()))
+
+    def timed(a, o):
+        ev = EventPairs(hip, steps)
+        a.intersect_device(d_org, d_dir, out=o); torch.cuda.synchronize(dev)
+        for _ in range(steps):
+            ev.begin(sptr); a.intersect_device(d_org, d_dir, out=o); ev.end(sptr)
+        torch.cuda.synchronize(dev)
+        return float(np.mean(ev.ms()))
+    ms = timed(acc, out)
     ok = all(torch.equal(a[:ns], b) for a, b in zip(out, cnt_out))
     hit = float((out[0] != -1).float().mean().item())
     achieved = b_ray * n / (ms * 1e-3) / 1e9
-    # both definitions of the per-visit bytes: SURVEY 8d prices a node visit at 64 B (its 2-wide fp32 node); the 8-wide walk this
-    # scene runs fetches one 128-B record per visit (and makes fewer visits).  Same counted visits, same kernel time.
-    defs = {}
-    for name, nb in (("survey_8d_64B_per_node_visit", 64), ("record_bytes_%dB_per_node_visit" % node_bytes, node_bytes)):
-        br = B_IN + B_OUT + nb * n_nodes + B_TRI * n_tris
-        defs[name] = {"bytes_per_ray": round(br, 1), "achieved": round(br * n / (ms * 1e-3) / 1e9, 1),
-                      "frac": round(br * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
     traffic = traffic_source = None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest_hbm.json")
     if os.path.exists(pmc):
@@ -555,14 +615,43 @@ def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
     info = acc.info()
     hot = info["nnodes_traversal"] * 64 + info["ntriangles"] * 48
     acc.close()
+    # the twin on the tree lh_accel_commit builds by itself at this size (the device builders): same rays, same records
+    twin = None
+    try:
+        P2, idx2, _ = scenes.soup_triangles(args.hbm_tris, 0.002)
+        acc2 = la.HipAccel(local); acc2.add_mesh(P2, idx2)
+        t0 = time.perf_counter(); info2 = acc2.commit(build="device"); commit2 = time.perf_counter() - t0
+        del P2, idx2
+        out2 = acc2.intersect_device(d_org, d_dir); torch.cuda.synchronize(dev)
+        _, cnt2 = acc2.intersect_device(d_org[:ns], d_dir[:ns], counters=True)
+        ms2 = timed(acc2, out2)
+        same2 = all(bool(torch.equal(a, b)) for a, b in zip(out2, out))
+        nn2 = cnt2["nodes"] / ns; nt2 = cnt2["tris"] / ns
+        br2 = B_IN + B_OUT + B_NODE_SURVEY * nn2 + B_TRI * nt2
+        twin = {"builder": "device (lh_accel_commit's own choice at this size)", "commit_s": round(commit2, 3), "kernel_ms": round(ms2, 3),
+                "value": round(n / (ms2 * 1e-3) / 1e6, 1), "value_unit": "Mrays/s", "nodes_per_ray": round(nn2, 3), "tris_per_ray": round(nt2, 3),
+                "bytes_per_ray": round(br2, 1), "achieved": round(br2 * n / (ms2 * 1e-3) / 1e9, 1),
+                "frac": round(br2 * n / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "records_bit_equal_to_host_tree": same2,
+                "nodes": info2["nnodes_traversal"], "depth": info2["max_depth"]}
+        ok = ok and same2
+        acc2.close(); del out2
+    except Exception as e:                                  # noqa: BLE001 -- the twin is context, the leg stands without it
+        twin = {"error": repr(e)}
     return {"workload": "S-soup-10M ray dump: %d random triangles (half-extent 0.002), %d incoherent rays, closest-hit" % (args.hbm_tris, n),
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": traffic, "traffic_source": traffic_source,
             "traffic_frac_of_peak": None if traffic is None else round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-            "definitions": defs, "formula": "bytes_per_ray = 48 (ray in) + 28 (hit record out) + B_node x nodes_per_ray + 40 x tris_per_ray; "
-                                            "achieved = bytes_per_ray x rays / kernel_ms; frac = achieved / peak",
+            "traffic_over_algorithmic": None if traffic is None else round(traffic / (b_ray * n), 3),
+            "formula": "bytes_per_ray = %d (ray in) + %d (hit record out) + %d x nodes_per_ray + %d x tris_per_ray -- SURVEY 8d's constants "
+                       "(B_in, B_out, B_node, B_tri), whatever the walk really moves (this kernel reads 48 B of fp64 ray and writes a 28-B record per ray, "
+                       "and an 8-wide visit fetches a 128-B record); achieved = bytes_per_ray x rays / kernel_ms; frac = achieved / peak; "
+                       "traffic = 2 x FETCH_SIZE + WRITE_SIZE of the committed counter pass; traffic_over_algorithmic = traffic / (bytes_per_ray x rays)"
+                       % (B_IN, B_OUT, B_NODE_SURVEY, B_TRI),
+            "record_bytes_per_ray": round(B_IN + B_OUT + node_bytes * n_nodes + B_TRI * n_tris, 1),
+            "record_bytes_note": "what the walk's own records add up to per ray (%d-B node records): includes bytes served by L2 / the Infinity Cache -- a count, not a bandwidth" % node_bytes,
             "residency": "hot set %.0f MB as 4-wide nodes + tri32 >> 256 MiB Infinity Cache: HBM" % (hot / 1e6),
-            "builder": "host, asked for (the better tree by 0.5-1 %; lh_accel_commit's own choice at this size is the device builders: 0.11 s instead of 5 s of commit, tools/build_probe.py)",
+            "builder": "host, asked for (the better tree by 0.5-1 %; `device_tree` is the same dump on lh_accel_commit's own choice)",
+            "device_tree": twin,
             "kernel": "k_trace_persist_lane<walk=spec8, q16x8 nodes: 128-byte 8-wide records, one cache line each>" if node_bytes == 128
                       else "k_trace_persist_lane<walk=spec,%s nodes>" % node_fmt,
             "node_bytes": node_bytes,
@@ -664,6 +753,17 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
         acc_d.close(); del img_d
     rays_all = shard.all_reduce_sum(float(st["primary_rays"] + st["ao_rays"])) if world > 1 else float(st["primary_rays"] + st["ao_rays"])
     t_all = shard.all_reduce_max(min(times)) if world > 1 else min(times)
+    ranks = None
+    if world > 1:       # one more frame, untimed, with the device synchronised between a rank's batch and the gather: who did what
+        tm = {}
+        shard.barrier()
+        render.render_ao_frame_sharded(acc, cam, 1, nsamples, rank, world, timing=tm)
+        shard.barrier()
+        d_ = shard.dist()
+        tm.update(rank=rank, transport="rccl" if (d_ is not None and d_.transport == la.DIST_RCCL) else "shm", frame_ms_best=round(min(times) * 1e3, 3),
+                  rays=int(st["primary_rays"] + st["ao_rays"]))
+        print("[bench rank %d] ao_render %s" % (rank, json.dumps(tm)), file=sys.stderr, flush=True)
+        ranks = shard.all_gather_object(tm)
     ok_all = (shard.all_reduce_min(1.0 if ok else 0.0) if world > 1 else (1.0 if ok else 0.0)) > 0.5
     acc.close()
     if rank != 0:
@@ -678,7 +778,7 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
             "scene_load": {"rank0_commit_s": round(commit_s, 3), "broadcast_s": round(bcast_s, 3) if world > 1 else None},
             "rays_per_frame": int(rays_all), "frame_ms": round(t_all * 1e3, 3),
             "value": round(rays_all / t_all / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
-            "image_mean": float(img.mean().item()), "roofline": roof, "device_build": devb,
+            "image_mean": float(img.mean().item()), "roofline": roof, "device_build": devb, "ranks": ranks,
             "validation": {"frames_repeat": ok_all, "retiled_frame_bit_equal": bool(ok) if world == 1 else None,
                            "primary_hits": int(stats[0]["primary_hits"]) if world == 1 else None, "ok": ok_all}}
 
@@ -814,15 +914,40 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
                            "ok": repeat and retiled is not False and 0.0 < float(img.mean().item()) <= 1.0}}
 
 
+def host_cores():
+    """what this process may really use: os.cpu_count() is the box, the affinity mask and the cgroup CPU quota are the share"""
+    n_os = os.cpu_count() or 1
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:                                            # noqa: BLE001
+        aff = n_os
+    quota = None
+    try:                                                         # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:                                            # noqa: BLE001
+        try:                                                     # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:                                        # noqa: BLE001
+            quota = None
+    eff = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return {"os_cpu_count": n_os, "sched_affinity": aff, "cgroup_cpu_quota": None if quota is None else round(quota, 2), "effective": eff}
+
+
 def cpu_baseline(P, idx, org, dr):
     """The reference's CPU path on this box's host cores, bounded sample of the SAME
     workload (first rays of the dump).  kind "reference": the compiled reference
     itself (oracle/_ref, scalar double, single thread -- its own threading is a racy
     bucket queue that scales 1.36x on 8 cores); else kind "port": the
-    bit-identical oracle.  Also reports the port on all host cores.  The only place bench.py
+    bit-identical oracle.  Also reports the port on the cores this process may use (affinity mask and
+    cgroup quota, not os.cpu_count()) with the speed-up over one thread.  The only place bench.py
     touches oracle/: the checker timed as the CPU baseline."""
     from oracle import pyoracle as po
-    ncores = os.cpu_count() or 1
+    hc = host_cores()
+    ncores = hc["effective"]
     out = {}
     if po.ref_available():
         ref = po.RefLib()
@@ -831,15 +956,29 @@ def cpu_baseline(P, idx, org, dr):
         out = {"value": round(org.shape[0] / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "reference",
                "sample": "first %d rays of the same S-soup ray dump, ri_raytrace() per ray, %.1f s" % (org.shape[0], dt)}
     o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    sub = min(org.shape[0], 300_000)
+    t0 = time.perf_counter(); o.intersect(org[:sub], dr[:sub], nthreads=1); dt1 = time.perf_counter() - t0
+    one = sub / dt1 / 1e6
     if not out:
-        t0 = time.perf_counter(); o.intersect(org, dr, nthreads=1); dt = time.perf_counter() - t0
-        out = {"value": round(org.shape[0] / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
-               "sample": "first %d rays of the same S-soup ray dump, %.1f s" % (org.shape[0], dt)}
-    reps = max(1, min(8, ncores // 8))
-    big_o = np.concatenate([org] * reps); big_d = np.concatenate([dr] * reps)
-    t0 = time.perf_counter(); o.intersect(big_o, big_d, nthreads=ncores); dt = time.perf_counter() - t0
-    out["port_all_cores"] = {"value": round(big_o.shape[0] / dt / 1e6, 3), "unit": "Mrays/s", "cores": ncores,
-                             "sample": "%d rays, contiguous slices per thread, %.1f s" % (big_o.shape[0], dt)}
+        out = {"value": round(one, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
+               "sample": "first %d rays of the same S-soup ray dump, %.1f s" % (sub, dt1)}
+    out["host"] = hc
+    curve = []
+    for nt in sorted(set(t for t in (8, 32, ncores) if t <= ncores)):
+        reps = max(1, min(8, nt // 8))
+        big_o = np.concatenate([org] * reps); big_d = np.concatenate([dr] * reps)
+        t0 = time.perf_counter(); o.intersect(big_o, big_d, nthreads=nt); dt = time.perf_counter() - t0
+        curve.append({"threads": nt, "value": round(big_o.shape[0] / dt / 1e6, 3), "speedup_over_one_thread": round(big_o.shape[0] / dt / 1e6 / one, 1),
+                      "rays": int(big_o.shape[0]), "seconds": round(dt, 1)})
+    best = max(curve, key=lambda c: c["value"]) if curve else None
+    if best is not None:
+        out["port_all_cores"] = {"value": best["value"], "unit": "Mrays/s", "cores": best["threads"],
+                                 "speedup_over_one_thread": best["speedup_over_one_thread"], "port_one_thread": round(one, 4),
+                                 "thread_curve": curve,
+                                 "sample": "%d rays, contiguous slices per thread, %.1f s" % (best["rays"], best["seconds"]),
+                                 "note": "the port walks 240-byte pointer-linked nodes (the reference's layout): one dependent cache miss per step, so it scales with "
+                                         "memory-level parallelism, not with cores -- `cores` is the thread count of the best point of the curve, `host` what the "
+                                         "process is allowed to use"}
     return out
 
 

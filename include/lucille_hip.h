@@ -246,7 +246,7 @@ typedef struct lh_environment { float rgb[3]; const float *map_rgba; int width, 
 #define LH_PT_REFERENCE_WEIGHTS 1     /* throughput *= the reference's brdf() value (kd / pi, ks, kt) instead of the
                                          unbiased weight of the same sampling scheme */
 int  lh_accel_set_material(lh_accel_t *accel, uint32_t mesh /* or LH_ALL_MESHES */, const lh_material_t *material);
-int  lh_accel_set_environment(lh_accel_t *accel, const lh_environment_t *environment);   /* after commit; the map is copied */
+int  lh_accel_set_environment(lh_accel_t *accel, const lh_environment_t *environment);   /* after commit; the map is copied; NULL: back to the default (constant white) */
 /* as lh_render_pt_tile, with the accelerator's materials and environment */
 int  lh_render_pt_tile2(lh_accel_t *accel, const lh_camera_t *cam, int x0, int y0, int w, int h,
                         int spp_begin, int spp_count, int spp_total, int max_path_vertices, int flags,

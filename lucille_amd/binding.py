@@ -245,6 +245,7 @@ class HipAccel:
         self.device = int(device)
         self.committed = False
         self._npos = []            # vertex count per added mesh (set_normals validates against it)
+        self._env = None           # what set_environment was last given (render.render_pt_frame_sharded restores it)
         _live.add(self)
 
     def close(self):
@@ -530,8 +531,14 @@ class HipAccel:
     def set_material(self, mesh, material):
         _check(self.L.lh_accel_set_material(self.h, int(mesh), C.byref(material)), "lh_accel_set_material")
 
+    def reset_environment(self):
+        """back to the default environment of the path tracer (constant white)"""
+        _check(self.L.lh_accel_set_environment(self.h, None), "lh_accel_set_environment")
+        self._env = None
+
     def set_environment(self, rgb=(1.0, 1.0, 1.0), envmap=None):
-        """envmap: [H,W,4] float32 angular-map light probe or None (constant radiance rgb)"""
+        """envmap: [H,W,4] float32 angular-map light probe or None (constant radiance rgb).  An explicit (0, 0, 0) is black."""
+        self._env = (tuple(float(x) for x in rgb), envmap)
         e = Environment()
         for k in range(3):
             e.rgb[k] = float(rgb[k])
@@ -706,10 +713,19 @@ class HipDist:
         self.L.lh_dist_barrier.argtypes = [C.c_void_p]
         _check(self.L.lh_dist_barrier(self.h), "lh_dist_barrier")
 
+    @staticmethod
+    def _stream_of(tensor, stream):
+        """the stream a collective on `tensor` is enqueued on: the caller's, else torch's CURRENT stream of the tensor's device --
+        behind whatever torch op produced the tensor (the communicator's private stream has no such dependency)"""
+        import torch
+        if stream is None:
+            return C.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)
+        return C.c_void_p(stream.cuda_stream) if hasattr(stream, "cuda_stream") else C.c_void_p(stream)
+
     def broadcast(self, tensor, stream=None):
-        """in-place broadcast of a CUDA tensor from rank 0"""
+        """in-place broadcast of a CUDA tensor from rank 0 (stream: a torch.cuda.Stream or a raw handle; default: torch's current stream)"""
         self.L.lh_dist_broadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
-        _check(self.L.lh_dist_broadcast(self.h, tensor.data_ptr(), tensor.numel() * tensor.element_size(), stream), "lh_dist_broadcast")
+        _check(self.L.lh_dist_broadcast(self.h, tensor.data_ptr(), tensor.numel() * tensor.element_size(), self._stream_of(tensor, stream)), "lh_dist_broadcast")
         return tensor
 
     def gather(self, tensor, stream=None):
@@ -718,7 +734,7 @@ class HipDist:
         t = tensor.contiguous()
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device) if self.rank == 0 else None
         self.L.lh_dist_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
-        _check(self.L.lh_dist_gather(self.h, t.data_ptr(), t.numel() * t.element_size(), out.data_ptr() if out is not None else None, stream), "lh_dist_gather")
+        _check(self.L.lh_dist_gather(self.h, t.data_ptr(), t.numel() * t.element_size(), out.data_ptr() if out is not None else None, self._stream_of(t, stream)), "lh_dist_gather")
         torch.cuda.synchronize(t.device)
         return out
 

@@ -662,6 +662,8 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
         if (timing) fprintf(stderr, "[lucille_hip] commit: host side %.2f ms, device side %.2f ms\n", (tc1 - tc0) * 1e3, (now_s() - tc1) * 1e3);
         {
             lh_host_scene *hs = a->hs;
+            if (hs->ref_state == 1 && !hs->ref_thread_live && rc != 0) hs->ref_state = 0;      /* the device side failed (or the tree is too deep: -3): no background
+                                                                                                  * build of lucille's tree for a scene that is about to be rebuilt on the host, or dropped */
             if (hs->ref_state == 1 && !hs->ref_thread_live) {
                 if (rc == 0 && a->nmeshes) {
                     /* the mesh copies are no longer needed: the background thread returns them to the system */
@@ -848,6 +850,10 @@ int lh_scene_image_header(lh_accel_t *a, lh_scene_image_t *h)
 {
     if (!a || !a->committed) return fail("scene image: accel not committed");
     if (lh_sync_ref(a, true) != 0) return -1;           /* a device-built scene: lucille's own tree must be attached */
+    /* a scene whose ray dumps walk the 8-wide nodes (hot set beyond the Infinity Cache) is sent WITH them: rank 0 builds them
+     * lazily on its first dump, a receiver has no host tree to build them from and would walk the slower 4-wide nodes --
+     * and the slowest rank sets the time of a sharded dump */
+    if (lh_accel_dump_node_bytes(a) == (int)sizeof(lh_q8node_t) && !a->d_q8nodes && lh_ensure_formats(a, LH_FMT_Q8) != 0) return -1;
     const lh_host_scene *hs = a->hs;
     memset(h, 0, sizeof(*h));
     h->magic = 0x4C48494Du;

@@ -84,7 +84,7 @@ struct lh_dist {
     /* shm transport */
     char shm_name[96]; shm_ctl *ctl; unsigned op;
     /* frame assembly on rank 0 */
-    lh_buf slab, all, frame, bands;
+    lh_buf slab, all, frame, bands, agree;
 };
 
 static double now_sec(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -243,7 +243,7 @@ extern "C" void lh_dist_destroy(lh_dist_t *d)
 {
     if (!d) return;
     (void)hipSetDevice(d->device);
-    lh_free_buf(&d->slab); lh_free_buf(&d->all); lh_free_buf(&d->frame); lh_free_buf(&d->bands);
+    lh_free_buf(&d->slab); lh_free_buf(&d->all); lh_free_buf(&d->frame); lh_free_buf(&d->bands); lh_free_buf(&d->agree);
     if (d->transport == LH_DIST_RCCL && d->comm) (void)g_rccl.CommDestroy(d->comm);
     if (d->ctl) { (void)shm_barrier(d); munmap((void *)d->ctl, 4096); if (d->rank == 0) shm_unlink(d->shm_name); }
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -315,22 +315,65 @@ extern "C" int lh_dist_barrier(lh_dist_t *d)
     return 0;
 }
 
+/* Every rank contributes ok (1) or not (0); every rank learns whether ALL were ok: a 4-byte gather to rank 0 and a 4-byte
+ * broadcast back.  A collective of its own -- every rank must reach it -- placed BEFORE a payload moves, so that a rank that
+ * cannot go on (rank 0's commit failed, a receiver is out of memory) tells the others instead of leaving them blocked in the
+ * payload's collective: RCCL has no timeout.  -> 1 all ok, 0 somebody failed, -1 the exchange itself failed */
+static int dist_agree(lh_dist_t *d, int ok)
+{
+    if (d->world == 1) return ok ? 1 : 0;
+    if (lh_ensure_buf(&d->agree, 64 * (size_t)d->world + 128)) return -1;
+    unsigned int mine = ok ? 1u : 0u;
+    char *base = (char *)d->agree.p;
+    HIPCHK(hipMemcpyAsync(base, &mine, sizeof(mine), hipMemcpyHostToDevice, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    if (lh_dist_gather(d, base, 64, d->rank == 0 ? base + 64 : NULL, (void *)d->stream) != 0) return -1;
+    unsigned int all = 1u;
+    if (d->rank == 0) {
+        std::vector<unsigned int> w(16 * (size_t)d->world);
+        HIPCHK(hipMemcpyAsync(w.data(), base + 64, 64 * (size_t)d->world, hipMemcpyDeviceToHost, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+        for (int r = 0; r < d->world; r++) all &= (w[16 * (size_t)r] != 0u) ? 1u : 0u;
+        HIPCHK(hipMemcpyAsync(base, &all, sizeof(all), hipMemcpyHostToDevice, d->stream));
+        HIPCHK(hipStreamSynchronize(d->stream));
+    }
+    if (lh_dist_broadcast(d, base, 64, (void *)d->stream) != 0) return -1;
+    HIPCHK(hipMemcpyAsync(&all, base, sizeof(all), hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
+    return all ? 1 : 0;
+}
+
 /* ---- scene load: one build, one broadcast -------------------------------------------------------------- */
+/* EVERY rank calls this, rank 0 too when its commit failed (its accel is then not committed): the first thing that travels
+ * is a status word, and every rank returns -1 together instead of the receivers waiting in ncclBroadcast for a scene that
+ * never comes.  The same after the receivers have allocated: one that is out of memory says so before the arrays move. */
 extern "C" int lh_dist_broadcast_scene(lh_dist_t *d, lh_accel_t *accel)
 {
     if (!d || !accel) return DFAIL("lh_dist_broadcast_scene: NULL argument");
     HIPCHK(hipSetDevice(d->device));
     lh_scene_image_t h; memset(&h, 0, sizeof(h));
-    if (d->rank == 0 && lh_scene_image_header(accel, &h) != 0) return -1;
+    char why[512]; why[0] = 0;
+    int ok = 1;
+    if (d->rank == 0 && lh_scene_image_header(accel, &h) != 0) { ok = 0; snprintf(why, sizeof(why), "%s", lh_last_error()); }
+    int all = dist_agree(d, ok);
+    if (all < 0) return -1;
+    if (!all) return ok ? DFAIL("lh_dist_broadcast_scene: rank 0 has no committed scene to send (its commit failed); nothing was broadcast")
+                        : DFAIL("lh_dist_broadcast_scene: rank 0 cannot send its scene (%s); the other ranks were told", why);
     /* the header and the two host arrays travel through a device staging buffer */
     if (lh_ensure_buf(&d->bands, sizeof(h) > 256 ? sizeof(h) : 256)) return -1;
     if (d->rank == 0) HIPCHK(hipMemcpy(d->bands.p, &h, sizeof(h), hipMemcpyHostToDevice));
     if (lh_dist_broadcast(d, d->bands.p, sizeof(h), NULL) != 0) return -1;
     HIPCHK(hipStreamSynchronize(d->stream));
+    ok = 1;
     if (d->rank != 0) {
         HIPCHK(hipMemcpy(&h, d->bands.p, sizeof(h), hipMemcpyDeviceToHost));
-        if (lh_scene_image_alloc(accel, &h) != 0) return -1;
+        if (h.magic != 0x4C48494Du) { ok = 0; snprintf(why, sizeof(why), "the scene header arrived damaged"); }
+        else if (lh_scene_image_alloc(accel, &h) != 0) { ok = 0; snprintf(why, sizeof(why), "%s", lh_last_error()); }
     }
+    all = dist_agree(d, ok);
+    if (all < 0) return -1;
+    if (!all) return ok ? DFAIL("lh_dist_broadcast_scene: another rank could not allocate the scene; nothing was broadcast")
+                        : DFAIL("lh_dist_broadcast_scene: rank %d cannot receive the scene (%s)", d->rank, why);
     void *ptr[32]; size_t bytes[32];
     const int n = lh_scene_image_arrays(accel, &h, ptr, bytes, 32);
     if (n > 32) return DFAIL("lh_dist_broadcast_scene: image table overflow");
@@ -386,14 +429,22 @@ extern "C" int lh_dist_render_ao_frame_host(lh_dist_t *d, lh_accel_t *accel, con
     std::vector<int> y0;
     for (int b = d->rank; b < nbands; b += d->world) y0.push_back(b * band_rows);
     const size_t slab_bytes = (size_t)per * band_rows * W * 3 * sizeof(float);
-    if (lh_ensure_buf(&d->slab, slab_bytes)) return -1;
-    HIPCHK(hipMemsetAsync(d->slab.p, 0, slab_bytes, d->stream));
     lh_tile_stats_t st; memset(&st, 0, sizeof(st));
-    if (lh_render_ao_bands(accel, cam, (int)y0.size(), y0.data(), band_rows, pixel_samples, gather_nsamples, seed, d->slab.p, &st, (void *)d->stream) != 0) return -1;
-    if (d->rank == 0 && lh_ensure_buf(&d->all, slab_bytes * (size_t)d->world)) return -1;
+    /* a rank that cannot render its bands (or rank 0 without room for the slabs) says so before the gather: the others return
+     * with it instead of waiting in ncclRecv / ncclSend */
+    int ok = lh_ensure_buf(&d->slab, slab_bytes) == 0 && hipMemsetAsync(d->slab.p, 0, slab_bytes, d->stream) == hipSuccess;
+    if (!ok) lh_fail("lh_dist_render_ao_frame_host: no room for this rank's slab (%zu bytes)", slab_bytes);
+    if (ok) ok = lh_render_ao_bands(accel, cam, (int)y0.size(), y0.data(), band_rows, pixel_samples, gather_nsamples, seed, d->slab.p, &st, (void *)d->stream) == 0;
+    char why[512]; why[0] = 0;
+    if (!ok) snprintf(why, sizeof(why), "%s", lh_last_error());
+    if (ok && d->rank == 0 && lh_ensure_buf(&d->all, slab_bytes * (size_t)d->world)) { ok = 0; snprintf(why, sizeof(why), "%s", lh_last_error()); }
+    const int all_ok = dist_agree(d, ok);
+    if (all_ok < 0) return -1;
+    if (!all_ok) return ok ? DFAIL("lh_dist_render_ao_frame_host: another rank could not render its bands; no frame") : DFAIL("lh_dist_render_ao_frame_host: rank %d: %s", d->rank, why);
     if (lh_dist_gather(d, d->slab.p, slab_bytes, d->rank == 0 ? d->all.p : NULL, (void *)d->stream) != 0) return -1;
-    /* statistics: the sum over the ranks (four 64-bit counters through the same gather) */
-    if (stats) {
+    /* statistics: the sum over the ranks (four 64-bit counters through the same gather) -- ALWAYS, whether or not this rank's
+     * caller asked for them: a collective every rank must enter */
+    {
         if (lh_ensure_buf(&d->bands, 64 * (size_t)d->world + 64)) return -1;
         unsigned long long mine[4] = {st.primary_rays, st.primary_hits, st.ao_rays, st.ao_occluded};
         HIPCHK(hipMemcpyAsync(d->bands.p, mine, sizeof(mine), hipMemcpyHostToDevice, d->stream));
@@ -403,11 +454,13 @@ extern "C" int lh_dist_render_ao_frame_host(lh_dist_t *d, lh_accel_t *accel, con
             std::vector<unsigned long long> all(4 * (size_t)d->world);
             HIPCHK(hipMemcpyAsync(all.data(), (char *)d->bands.p + 64, 32 * (size_t)d->world, hipMemcpyDeviceToHost, d->stream));
             HIPCHK(hipStreamSynchronize(d->stream));
-            memset(stats, 0, sizeof(*stats));
-            for (int r = 0; r < d->world; r++) {
-                stats->primary_rays += all[4 * r]; stats->primary_hits += all[4 * r + 1]; stats->ao_rays += all[4 * r + 2]; stats->ao_occluded += all[4 * r + 3];
+            if (stats) {
+                memset(stats, 0, sizeof(*stats));
+                for (int r = 0; r < d->world; r++) {
+                    stats->primary_rays += all[4 * r]; stats->primary_hits += all[4 * r + 1]; stats->ao_rays += all[4 * r + 2]; stats->ao_occluded += all[4 * r + 3];
+                }
             }
-        } else *stats = st;
+        } else if (stats) *stats = st;
     }
     if (d->rank == 0) {
         const size_t fb = (size_t)W * H * 3 * sizeof(float);

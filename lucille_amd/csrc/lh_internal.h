@@ -99,7 +99,7 @@ struct lh_accel {
     void *d_attr9[3], *d_st6, *d_inside;            /* colour / tangent / binormal, st, inside flags (uploaded at commit if present) */
     void *d_prim_mesh;                 /* mesh ordinal per primitive (materials; uploaded on first use) */
     lh_material_t *materials; uint32_t nmaterials; void *d_materials; int materials_dirty;
-    lh_environment_t env; void *d_env_map;
+    lh_environment_t env; void *d_env_map; int env_set;      /* env_set: lh_accel_set_environment was called (else the path tracer's environment is constant white) */
     lh_buf r_state;                    /* lh_accel_state_build_host staging */
     lh_buf r_uni;                      /* lh_render_ao_tile_host: caller uniforms on the device */
     lh_buf r_diag;                     /* LH_STAGE_TIMING: wave start / exit clocks */

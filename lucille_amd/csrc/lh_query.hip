@@ -36,24 +36,33 @@ int lh_aoq_slot(lh_accel_t *a, hipStream_t s)
     }
     k = free_k;
     lh_fixq_t *q = &a->aoq[k].q;
-    if (!q->queue) {
-        HIPCHK(hipMalloc(&q->queue, (size_t)LH_AO_QCAP * sizeof(unsigned long long)));
-        HIPCHK(hipMalloc((void **)&q->qcount, (4 + 4096) * sizeof(uint32_t)));       /* counters + the consumer groups' heads (LH_Q_GROUPS) */
-        HIPCHK(hipMemset(q->queue, 0, (size_t)LH_AO_QCAP * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(q->qcount, 0, (4 + 4096) * sizeof(uint32_t)));
-        q->qcap = LH_AO_QCAP;
-        hipStream_t aux; hipEvent_t e0, e1;
+    if (!q->ev_done) {              /* ev_done is set last: a slot whose set-up failed half-way is not "ready" */
+        void *queue = NULL; uint32_t *qcount = NULL; hipStream_t aux = NULL; hipEvent_t e0 = NULL, e1 = NULL;
+        bool ok = hipMalloc(&queue, (size_t)LH_AO_QCAP * sizeof(unsigned long long)) == hipSuccess &&
+                  hipMalloc((void **)&qcount, (4 + 4096) * sizeof(uint32_t)) == hipSuccess &&       /* counters + the consumer groups' heads (LH_Q_GROUPS) */
+                  hipMemset(queue, 0, (size_t)LH_AO_QCAP * sizeof(unsigned long long)) == hipSuccess &&
+                  hipMemset(qcount, 0, (4 + 4096) * sizeof(uint32_t)) == hipSuccess;
         /* the consumer's stream gets the highest priority: streams of one priority share a handful of hardware queues round
          * robin (four by default), and a consumer that lands on its producer's queue runs BEHIND it instead of next to it
          * (bench.py's second accelerator: config-5 frame 89 -> 122 ms); priority streams have queues of their own */
-        {
+        if (ok) {
             int prio_lo = 0, prio_hi = 0;
             if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess || prio_hi == prio_lo ||
                 hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, prio_hi) != hipSuccess)
-                HIPCHK(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+                ok = hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) == hipSuccess;
         }
-        HIPCHK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        ok = ok && hipEventCreateWithFlags(&e0, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {                  /* nothing half-built stays behind */
+            const hipError_t e = hipGetLastError();
+            if (e1) (void)hipEventDestroy(e1);
+            if (e0) (void)hipEventDestroy(e0);
+            if (aux) (void)hipStreamDestroy(aux);
+            if (qcount) (void)hipFree(qcount);
+            if (queue) (void)hipFree(queue);
+            return fail("the fix-up queue of a launch stream could not be set up: %s", hipGetErrorString(e));
+        }
+        q->queue = queue; q->qcount = qcount; q->qcap = LH_AO_QCAP;
         q->aux_stream = (void *)aux; q->ev_ready = (void *)e0; q->ev_done = (void *)e1;
     }
     a->aoq[k].stream = s; a->aoq[k].used = 1;

@@ -337,12 +337,17 @@ extern "C" int lh_accel_set_material(lh_accel_t *a, uint32_t mesh, const lh_mate
 extern "C" int lh_accel_set_environment(lh_accel_t *a, const lh_environment_t *env)
 {
     lh_guard guard(a);
-    if (!a || !env) return fail("lh_accel_set_environment: NULL argument");
+    if (!a) return fail("lh_accel_set_environment: NULL argument");
     if (!a->committed) return fail("lh_accel_set_environment: accel not committed");
+    if (!env) {                  /* back to the default: constant white, no map */
+        if (a->d_env_map) { (void)hipFree(a->d_env_map); a->d_env_map = NULL; }
+        memset(&a->env, 0, sizeof(a->env)); a->env_set = 0;
+        return 0;
+    }
     if (env->map_rgba && (env->width < 1 || env->height < 1)) return fail("lh_accel_set_environment: bad map size");
     HIPCHK(hipSetDevice(a->device));
     if (a->d_env_map) { (void)hipFree(a->d_env_map); a->d_env_map = NULL; }
-    a->env = *env; a->env.map_rgba = NULL;
+    a->env = *env; a->env.map_rgba = NULL; a->env_set = 1;
     if (env->map_rgba) {
         const size_t b = sizeof(float) * 4 * (size_t)env->width * env->height;
         HIPCHK(hipMalloc(&a->d_env_map, b));
@@ -493,7 +498,7 @@ extern "C" int lh_render_pt_tile2(lh_accel_t *a, const lh_camera_t *cam, int x0,
     if (!a || !a->committed) return fail("lh_render_pt_tile2: accel not committed");
     if (!cam || !d_rgb) return fail("lh_render_pt_tile2: NULL argument");
     float one[3] = {1.0f, 1.0f, 1.0f};
-    const float *rgb = (a->env.rgb[0] != 0.0f || a->env.rgb[1] != 0.0f || a->env.rgb[2] != 0.0f || a->d_env_map) ? a->env.rgb : one;
+    const float *rgb = a->env_set ? a->env.rgb : one;          /* never set: constant white; an explicit black environment stays black */
     return pt_tile(a, cam, x0, y0, w, h, h, 0, s0, spp, spp_total, max_vertices, NULL, rgb, a->d_env_map, a->env.width, a->env.height, flags,
                    seed, d_rgb, stats, stream);
 }
@@ -512,7 +517,7 @@ extern "C" int lh_render_pt_bands(lh_accel_t *a, const lh_camera_t *cam, int y0_
         (long long)y0_first + (long long)(nbands - 1) * band_stride + band_rows > cam->height)
         return fail("lh_render_pt_bands: bands must be disjoint and inside the frame");
     float one[3] = {1.0f, 1.0f, 1.0f};
-    const float *rgb = (a->env.rgb[0] != 0.0f || a->env.rgb[1] != 0.0f || a->env.rgb[2] != 0.0f || a->d_env_map) ? a->env.rgb : one;
+    const float *rgb = a->env_set ? a->env.rgb : one;          /* never set: constant white; an explicit black environment stays black */
     return pt_tile(a, cam, 0, y0_first, cam->width, nbands * band_rows, band_rows, band_stride, s0, spp, spp_total, max_vertices, override_mat, rgb,
                    a->d_env_map, a->env.width, a->env.height, flags, seed, d_rgb, stats, stream);
 }

@@ -124,10 +124,15 @@ int main(int argc, char **argv)
     if (ndev_listed > 0) ngpus = ndev_listed;
     if (world > 0) {
         /* one process per GPU (lh_dist_*: SURVEY 8e): rank 0 builds, everybody receives the scene image */
-        if (lh_dist_init_file(&dist, rendezvous, rank, world, device) != 0 || lh_accel_create(&accel, device) != 0 ||
-            (rank == 0 && (lh_accel_add_rib_scene(accel, scene) != 0 || lh_accel_commit(accel, build_threads) != 0)) ||
-            lh_dist_broadcast_scene(dist, accel) != 0) {
+        if (lh_dist_init_file(&dist, rendezvous, rank, world, device) != 0 || lh_accel_create(&accel, device) != 0) {
             fprintf(stderr, "lsh_hip: rank %d: %s\n", rank, lh_last_error()); lh_rib_free(scene); return 1;
+        }
+        /* rank 0's commit may fail: it says why, and STILL enters the broadcast, whose first word tells the other ranks to give up
+         * (they would wait in ncclBroadcast for ever otherwise) */
+        if (rank == 0 && (lh_accel_add_rib_scene(accel, scene) != 0 || lh_accel_commit(accel, build_threads) != 0))
+            fprintf(stderr, "lsh_hip: rank 0: %s\n", lh_last_error());
+        if (lh_dist_broadcast_scene(dist, accel) != 0) {
+            fprintf(stderr, "lsh_hip: rank %d: %s\n", rank, lh_last_error()); lh_rib_free(scene); lh_dist_destroy(dist); return 1;
         }
     } else if (ngpus > 1 || ndev_listed > 0) {
         /* the G GPUs of this node from this one process (lh_multi_*: SURVEY 8b(4), 8e) */

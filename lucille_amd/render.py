@@ -45,10 +45,13 @@ def bands_for(height, world, rows=None):
     return rows, list(range(0, height, rows))
 
 
-def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, world, tile=None, seed=1, band_rows=None):
+def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, world, tile=None, seed=1, band_rows=None, timing=None):
     """Each rank renders its interleaved shards; ONE gather of equal-sized slabs assembles the frame on rank 0 (None
     elsewhere).  tile=None (default): full-width bands, all of a rank's bands in one device batch; an int: square tiles,
-    one batch each (the round-1 path, kept for comparison).  Returns (image|None, local stats)."""
+    one batch each (the round-1 path, kept for comparison).  Returns (image|None, local stats).
+    timing: a dict that receives this rank's bands / batch_ms / gather_ms (diagnostic frames only: it synchronises the device
+    between the two phases)."""
+    import time
     import torch
     W, H = cam.width, cam.height
     dev = torch.device("cuda", acc.device)
@@ -57,10 +60,18 @@ def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, worl
         mine = shard.tiles_of_rank(len(y0s), rank, world)
         per = (len(y0s) + world - 1) // world
         slab = torch.zeros((per, rows * W * 3), dtype=torch.float32, device=dev)
+        if timing is not None:
+            torch.cuda.synchronize(dev); t0 = time.perf_counter()
         _, tot = acc.render_ao_bands(cam, [y0s[b] for b in mine], rows, pixel_samples, gather_nsamples, seed=seed,
                                      out=slab[:len(mine)].view(len(mine), rows, W, 3))
+        if timing is not None:
+            torch.cuda.synchronize(dev); t1 = time.perf_counter()
         shards = [(0, y0, W, min(rows, H - y0)) for y0 in y0s]
-        return assemble_shards(slab, shards, W, H, rank, world, stride_rows=rows), tot
+        img = assemble_shards(slab, shards, W, H, rank, world, stride_rows=rows)
+        if timing is not None:
+            torch.cuda.synchronize(dev)
+            timing.update(bands=len(mine), band_rows=rows, batch_ms=round((t1 - t0) * 1e3, 3), gather_ms=round((time.perf_counter() - t1) * 1e3, 3))
+        return img, tot
     shards = shard.tile_grid(W, H, tile)
     mine = shard.tiles_of_rank(len(shards), rank, world)
     cap = max(w * h for (_, _, w, h) in shards) * 3
@@ -125,39 +136,54 @@ def assemble(slab, W, H, tile, rank, world):
 
 def render_pt_frame_sharded(acc, cam, spp, rank, world, tile=256, spp_chunk=16, band_rows=None, **kw):
     """Path-traced frame (BASELINE config 4), samples in passes of `spp_chunk` (bounded device memory), one gather of slabs.
-    world > 1 (or band_rows given): a rank's interleaved full-width bands (bands_for) are ONE pass per sample chunk
-    (lh_render_pt_bands: a pass costs a fixed ~3 ms of kernel ramps whatever its size, and fine bands spread sky / floor / sphere
-    evenly over the ranks); else square tiles `tile_id % world == rank`, one pass each.  kw: kd | material, env, max_vertices,
-    flags, seed.  Returns (image on rank 0 | None, local stats)."""
+    world > 1, band_rows given, or a material / flags asked for: a rank's interleaved full-width bands (bands_for) are ONE pass
+    per sample chunk (lh_render_pt_bands: a pass costs a fixed ~3 ms of kernel ramps whatever its size, and fine bands spread sky
+    / floor / sphere evenly over the ranks; a frame height the band rows do not divide, or fewer bands than ranks, falls back to
+    one-line bands -- never to another code path); else (one rank, kd / env only) square tiles, one pass each.
+    kw: kd | material, env, max_vertices, flags, seed -- the SAME meaning on both paths: env is this frame's constant
+    environment (default: the accelerator's own, white if never set; an explicit black stays black) and is restored afterwards.
+    Returns (image on rank 0 | None, local stats)."""
     import torch
     from . import binding
     W, H = cam.width, cam.height
     dev = torch.device("cuda", acc.device)
     tot = {"paths": 0, "rays": 0}
     rows = None
-    if world > 1 or band_rows is not None:
+    if world > 1 or band_rows is not None or kw.get("material") is not None or kw.get("flags"):
         rows, y0s = bands_for(H, max(world, 2) if band_rows is not None else world, band_rows)
         if H % rows != 0 or len(y0s) < world:
-            rows = None                                   # ragged last band: the tile path below
+            rows, y0s = 1, list(range(H))                 # one-line bands always tile the frame
     if rows is not None:
         mine = shard.tiles_of_rank(len(y0s), rank, world)
         per = (len(y0s) + world - 1) // world
         slab = torch.zeros((per, rows * W * 3), dtype=torch.float32, device=dev)
+        prev_env = getattr(acc, "_env", None)
         if "env" in kw:
             acc.set_environment(kw["env"], None)
         mat = kw.get("material")
         if mat is None and "kd" in kw:
             mat = binding.Material.make(kd=(kw["kd"],) * 3)
-        if mine:
-            out = slab[:len(mine)].view(len(mine), rows, W, 3)
-            for s0 in range(0, spp, spp_chunk):
-                _, st = acc.render_pt_bands(cam, y0s[mine[0]], rows, rows * world, len(mine), s0, min(spp_chunk, spp - s0), spp,
-                                            max_vertices=kw.get("max_vertices", 8), flags=kw.get("flags", 0), override=mat,
-                                            seed=kw.get("seed", 1), out=out)
-                tot["paths"] += st["paths"]; tot["rays"] += st["rays"]
+        try:
+            if mine:
+                out = slab[:len(mine)].view(len(mine), rows, W, 3)
+                for s0 in range(0, spp, spp_chunk):
+                    _, st = acc.render_pt_bands(cam, y0s[mine[0]], rows, rows * world, len(mine), s0, min(spp_chunk, spp - s0), spp,
+                                                max_vertices=kw.get("max_vertices", 8), flags=kw.get("flags", 0), override=mat,
+                                                seed=kw.get("seed", 1), out=out)
+                    tot["paths"] += st["paths"]; tot["rays"] += st["rays"]
+                torch.cuda.synchronize(dev)               # the passes read the environment: finished before it is put back
+        finally:
+            if "env" in kw:
+                if prev_env is None:
+                    acc.reset_environment()
+                else:
+                    acc.set_environment(*prev_env)
         shards = [(0, y0, W, rows) for y0 in y0s]
         return assemble_shards(slab, shards, W, H, rank, world, stride_rows=rows), tot
-    kw = {k: v for k, v in kw.items() if k not in ("material", "flags")}
+    # one rank, one diffuse reflectance, a constant environment: square tiles through lh_render_pt_tile (env passed per call)
+    tkw = {k: v for k, v in kw.items() if k in ("kd", "env", "max_vertices", "seed")}
+    if "env" not in tkw and getattr(acc, "_env", None) is not None and acc._env[1] is None:
+        tkw["env"] = acc._env[0]                         # the accelerator's own constant environment, as the band path uses it
     tiles = shard.tile_grid(W, H, tile)
     mine = shard.tiles_of_rank(len(tiles), rank, world)
     slab = torch.zeros((len(mine), tile * tile * 3), dtype=torch.float32, device=dev)
@@ -165,7 +191,7 @@ def render_pt_frame_sharded(acc, cam, spp, rank, world, tile=256, spp_chunk=16, 
         x0, y0, w, h = tiles[tid]
         out = torch.zeros((h, w, 3), dtype=torch.float32, device=dev)
         for s0 in range(0, spp, spp_chunk):
-            _, st = acc.render_pt_tile(cam, x0, y0, w, h, s0, min(spp_chunk, spp - s0), spp, out=out, **kw)
+            _, st = acc.render_pt_tile(cam, x0, y0, w, h, s0, min(spp_chunk, spp - s0), spp, out=out, **tkw)
             tot["paths"] += st["paths"]; tot["rays"] += st["rays"]
         t = torch.zeros((tile, tile, 3), dtype=torch.float32, device=dev)
         t[:h, :w] = out

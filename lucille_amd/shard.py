@@ -43,6 +43,12 @@ def tiles_of_rank(ntiles, rank, world):
 
 
 _DIST = None      # this process's lh_dist_t (binding.HipDist) when world > 1
+_RCCL_STATUS = "not tried (world 1)"
+
+
+def rccl_status():
+    """how this rank's communicator came up: 'ok', 'shm: ranks share a device', 'shm: asked for', or the error that forced the fallback"""
+    return _RCCL_STATUS
 
 
 def dist():
@@ -57,7 +63,7 @@ def init_process_group(backend=None, device=None):
     max-over-ranks of a timing).  Everything that moves device data -- the scene broadcast, the gather of hit records and
     tile slabs -- goes through lh_dist_* in the C ABI (ncclBroadcast / grouped ncclSend + ncclRecv), the same entry points
     `lsh_hip --rank R --world N` uses without Python.  `backend` is accepted for compatibility and ignored."""
-    global _DIST
+    global _DIST, _RCCL_STATUS
     import torch
     import torch.distributed as tdist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -74,6 +80,7 @@ def init_process_group(backend=None, device=None):
         tdist.all_gather_object(devs, dev)
         shared = len(set(devs)) < world                       # one node: equal ordinals = one GPU (tests on a one-GPU box)
         transport = binding.DIST_SHM if shared or os.environ.get("LH_DIST_TRANSPORT") == "shm" else binding.DIST_RCCL
+        _RCCL_STATUS = "ok" if transport == binding.DIST_RCCL else ("shm: ranks share a device" if shared else "shm: asked for (LH_DIST_TRANSPORT)")
         torch.cuda.set_device(dev)
         if transport == binding.DIST_RCCL:
             # RCCL first; if ANY rank cannot bring its communicator up (no librccl, a fabric problem) every rank falls back to the
@@ -99,6 +106,7 @@ def init_process_group(backend=None, device=None):
                 print("[lucille_amd] rank %d: RCCL transport unavailable%s -- falling back to the shared-memory transport of lh_dist_*"
                       % (rank, (": " + err) if err else " on another rank"), file=sys.stderr, flush=True)
                 transport = binding.DIST_SHM
+                _RCCL_STATUS = "shm: RCCL unavailable" + ((": " + err) if err else " on another rank")
         if _DIST is None:
             ids = [os.urandom(128) if rank == 0 else None]
             tdist.broadcast_object_list(ids, src=0)
@@ -111,12 +119,23 @@ def commit_shared(acc, add_meshes, rank, world, **commit_kw):
     rank's HBM (lh_dist_broadcast_scene).  -> (info dict, seconds spent in rank 0's commit, seconds in the broadcast)"""
     import time
     t0 = time.perf_counter()
+    err = None
     if rank == 0 or world == 1:
-        add_meshes(acc)
-        acc.commit(**commit_kw)
+        try:
+            add_meshes(acc)
+            acc.commit(**commit_kw)
+        except Exception as e:                  # noqa: BLE001 -- rank 0 still enters the broadcast: its first word tells the peers to give up
+            err = e
+            if world == 1:
+                raise
     t1 = time.perf_counter()
     if world > 1:
-        _DIST.broadcast_scene(acc)
+        try:
+            _DIST.broadcast_scene(acc)
+        except Exception:
+            if err is not None:
+                raise err
+            raise
     return acc.info(), t1 - t0, time.perf_counter() - t1
 
 
@@ -141,6 +160,16 @@ def all_reduce_sum(x):
         return x
     t = torch.tensor([x], dtype=torch.float64); tdist.all_reduce(t)
     return float(t.item())
+
+
+def all_gather_object(obj):
+    """every rank's small Python object, in rank order, on every rank (control plane)"""
+    import torch.distributed as tdist
+    if not (tdist.is_available() and tdist.is_initialized()):
+        return [obj]
+    out = [None] * tdist.get_world_size()
+    tdist.all_gather_object(out, obj)
+    return out
 
 
 def all_reduce_min(x):

@@ -207,6 +207,39 @@ def test_interleaved_bands_as_one_pass_equal_the_frame(ps):
         acc.render_pt_bands(cam, 4, 4, 12, nb // 3 + 1, 0, 8, 8)
 
 
+def test_sharded_frame_arguments_mean_the_same_on_every_path(ps):
+    """render.render_pt_frame_sharded at world 1: material / flags are honoured whatever path the frame takes (they used to be
+    dropped on the tile path), kd == a diffuse material of that reflectance, env is this frame's environment on both paths and
+    the accelerator's own environment is put back afterwards, an explicit black environment is black (it used to turn white)"""
+    import torch
+    from lucille_amd import render as R
+    acc, cam = ps["acc"], ps["cam"]
+    acc.set_environment((0.25, 0.5, 1.0), None)                                     # the accelerator's own: must survive
+    mat = la.Material.make(kd=(0.6,) * 3)
+    env = (1.0, 0.9, 0.8)
+    a, sa = R.render_pt_frame_sharded(acc, cam, 8, 0, 1, tile=48, spp_chunk=4, kd=0.6, env=env, max_vertices=5, seed=2)        # tiles
+    b, sb = R.render_pt_frame_sharded(acc, cam, 8, 0, 1, tile=48, spp_chunk=4, material=mat, env=env, max_vertices=5, seed=2)  # -> bands
+    c, sc = R.render_pt_frame_sharded(acc, cam, 8, 0, 1, spp_chunk=4, band_rows=4, kd=0.6, env=env, max_vertices=5, seed=2)     # bands asked for
+    assert torch.equal(a, b) and torch.equal(a, c) and sa == sb == sc
+    dark = la.Material.make(kd=(0.2,) * 3)
+    d, _ = R.render_pt_frame_sharded(acc, cam, 8, 0, 1, tile=48, spp_chunk=4, material=dark, env=env, max_vertices=5, seed=2)
+    assert float(d.mean()) < 0.8 * float(a.mean())                                  # the material was used, not a default kd
+    # the accelerator's own environment is back: a frame without env uses it, on both paths
+    e, _ = R.render_pt_frame_sharded(acc, cam, 4, 0, 1, tile=48, spp_chunk=4, kd=0.6, max_vertices=5, seed=2)
+    f, _ = R.render_pt_frame_sharded(acc, cam, 4, 0, 1, spp_chunk=4, band_rows=4, kd=0.6, max_vertices=5, seed=2)
+    g, _ = acc.render_pt_tile(cam, 0, 0, cam.width, cam.height, 0, 4, 4, kd=0.6, env=(0.25, 0.5, 1.0), max_vertices=5, seed=2)
+    assert torch.equal(e, f) and torch.equal(e, g)
+    # black is black
+    k, _ = R.render_pt_frame_sharded(acc, cam, 2, 0, 1, spp_chunk=2, band_rows=4, kd=0.6, env=(0.0, 0.0, 0.0), max_vertices=5, seed=2)
+    assert float(k.abs().max()) == 0.0
+    # a frame height the band rows do not divide: one-line bands, same frame
+    cam2 = la.Camera.make(cam.width, cam.height - 2, cam.flength, np.array(list(cam.cam2world)), cam.rh)
+    t1, _ = R.render_pt_frame_sharded(acc, cam2, 4, 0, 1, tile=64, spp_chunk=4, kd=0.6, env=env, max_vertices=5, seed=2)
+    t2, _ = R.render_pt_frame_sharded(acc, cam2, 4, 0, 1, spp_chunk=4, band_rows=4, material=mat, env=env, max_vertices=5, seed=2)
+    assert torch.equal(t1, t2)
+    acc.set_environment((1.0, 1.0, 1.0), None)
+
+
 def test_empty_and_one_triangle_scenes():
     """no geometry: every camera ray leaves the scene and returns the environment (the bounce chain's ray counts live on the
     device: the launches after the first find zero rays); one triangle with a 2-vertex limit: hits end black"""

@@ -106,3 +106,12 @@ def test_bench_n2_code_path_on_one_gpu():
     assert j["validation"]["ok"] and j["validation"]["gathered_records_ok"] and j["validation"]["timed_equals_counted_launch"]
     assert j["ao_render"]["validation"]["ok"] and j["ao_render"]["rays_per_frame"] > 0
     assert j["pt_render"]["rays_per_frame"] > 0 and j["value"] > 0
+    # at N > 1 the record gather is INSIDE the headline's timed region; both readings are emitted side by side
+    assert j["exchange"]["headline_includes_record_gather"] and j["with_record_gather"]["is_headline"]
+    assert abs(j["with_record_gather"]["value"] - j["value"]) <= 0.02 * j["value"] and j["records_stay_with_rank"]["value"] > 0
+    assert "28-B hit records gathered to rank 0 inside the timed region" in j["config"]["workload"]
+    # every rank reported what it did (transport, launches, kernel and gather time); two ranks on one device = the shm transport
+    assert [r_["rank"] for r_ in j["ranks"]] == [0, 1] and all(r_["transport"] == "shm" and "share a device" in r_["rccl_status"] for r_ in j["ranks"])
+    assert all(r_["kernel_ms_per_step"] > 0 and r_["gather_only_ms"] >= 0 for r_ in j["ranks"])
+    assert [r_["rank"] for r_ in j["ao_render"]["ranks"]] == [0, 1] and all(r_["bands"] > 0 and r_["batch_ms"] > 0 for r_ in j["ao_render"]["ranks"])
+    assert "[bench rank 1]" in r.stderr
