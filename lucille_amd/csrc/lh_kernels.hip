@@ -219,13 +219,15 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
         /* the step below writes up to slot sp + 3.  rows = 3 * depth + 5 covers every ray of a tree that deep; a deeper
          * tree (an LBVH built on the device over a degenerate distribution) gets 64 rows and a ray that would overrun them
          * is finished by k_coop_walk -- same arithmetic, same answer */
-        if (L.cur >= 0) {
-            node_step4<COUNT, LH_BLOCK, false>(L, pend, sc, stk, tid, c_nodes, 0, top, ntop);
-            if (GUARD) {          /* for the NEXT step (a fresh ray starts at sp = 1): one compare and a scalar branch per iteration */
-                const bool ov = (L.cur >= 0) & (L.sp + 4 > rows);
-                if (__builtin_expect(__ballot(ov) != 0ull, 0)) { if (ov) { L.over = true; L.cur = kDone; pend = kNoLeaf; } }
-            }
+        if (GUARD) {
+            /* BEFORE the step, not after it: a lane that came out of a step holding a leaf (no check: it was not going to step) pops
+             * an inner node in the triangle pass and steps with a stack pointer one below the one that was never checked -- the
+             * write landed one row past the stack (dropped by the LDS until round 4 put the top of the tree there).  One compare
+             * and a scalar branch per iteration */
+            const bool ov = (L.cur >= 0) & (L.sp + 4 > rows);
+            if (__builtin_expect(__ballot(ov) != 0ull, 0)) { if (ov) { L.over = true; L.cur = kDone; pend = kNoLeaf; } }
         }
+        if (L.cur >= 0) node_step4<COUNT, LH_BLOCK, false>(L, pend, sc, stk, tid, c_nodes, 0, top, ntop);
         const unsigned long long m_node = __ballot(L.cur >= 0);
         const unsigned long long m_pend = __ballot(pend != kNoLeaf);
         if (m_pend != 0ull && (__popcll(m_pend) >= tri_batch || m_node == 0ull)) {
@@ -995,6 +997,16 @@ uint32_t rows4(const lh_dev_scene_t &sc, bool *guard)
     return need;
 }
 
+/* the cooperative walk's ring of stack rows: a power of two covering the tree's worst case (3 per level + sentinel + the
+ * step's scratch slots); 0: the tree is deeper than any builder hands over */
+uint32_t coop_rows(const lh_dev_scene_t &sc)
+{
+    const uint32_t need = 3 * sc.q4_depth + 6;
+    uint32_t r = 16;
+    while (r < need) r <<= 1;
+    return r <= 512 ? r : 0;
+}
+
 /* nodes of the top of the tree a workgroup keeps in LDS behind its `rows` stack rows (node_step4): what the CU's 160 KiB leave
  * over once the workgroups its stack rows allow are resident -- never a workgroup fewer for it.  Measured (tools/top_probe.py,
  * r04): S-soup-1M 2 228 -> 2 249 Mrays/s on the host builder's tree, 2 212 -> 2 233 on the device builder's (144 nodes = 6.3 of a
@@ -1004,25 +1016,21 @@ uint32_t top_nodes_for(const lh_dev_scene_t &sc, uint32_t rows)
 {
     uint32_t want = sc.top_nodes;
     if (want == LH_TOP_AUTO) {
-        const uint32_t cu = 160u * 1024u, stack = rows * LH_BLOCK * (uint32_t)sizeof(int);
-        uint32_t wgs = cu / stack;
+        /* the CU's 160 KiB also hold the workgroup of the cooperative walk that runs NEXT TO this launch (k_coop_walk: one wave,
+         * a ring of coop_rows x 64 entries): its stream has the higher priority, so it is placed first -- a persistent workgroup
+         * that no longer fits beside it is one workgroup per CU fewer for the whole launch (r04: 2 240 -> 1 680 Mrays/s, the
+         * config-5 frame 85 -> 128 ms with every spare byte given to the top of the tree) */
+        const uint32_t crows = coop_rows(sc);
+        const uint32_t coop = crows ? (crows * 64u + 128u) * (uint32_t)sizeof(int) + 1024u : 0u;
+        const uint32_t cu = 160u * 1024u - coop, stack = rows * LH_BLOCK * (uint32_t)sizeof(int);
+        uint32_t wgs = (160u * 1024u) / stack;      /* what size_grid() launches per CU */
         if (wgs > 4u) wgs = 4u;                     /* 128 VGPRs: four workgroups per CU at most */
-        if (wgs == 0u) return 0u;
+        if (wgs == 0u || cu < wgs * stack) return 0u;
         const uint32_t spare = (cu / wgs - stack) / 64u;
         want = spare < LH_TOP_NODES_MAX ? spare : LH_TOP_NODES_MAX;
         want &= ~15u;
     }
     return want < sc.nq4nodes ? want : sc.nq4nodes;
-}
-
-/* the cooperative walk's ring of stack rows: a power of two covering the tree's worst case (3 per level + sentinel + the
- * step's scratch slots); 0: the tree is deeper than any builder hands over */
-uint32_t coop_rows(const lh_dev_scene_t &sc)
-{
-    const uint32_t need = 3 * sc.q4_depth + 6;
-    uint32_t r = 16;
-    while (r < need) r <<= 1;
-    return r <= 512 ? r : 0;
 }
 
 /* rays per cursor atomic: the scene's setting, but never so large that a wave gets fewer than

@@ -6,7 +6,7 @@ nr = sys.argv[1] if len(sys.argv) > 1 else "50000000"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 libs = sorted(glob.glob(os.path.join(ROOT, "gpurun_variants", "*.so")))
 code = ("import sys,os; sys.path.insert(0,%r); import numpy as np, torch; import lucille_amd as la; from oracle import pyoracle as po;"
-        "P,idx,org,dr=po.soup(1000000,%s); acc=la.HipAccel(0); acc.add_mesh(P,idx); acc.commit(build="host");"
+        "P,idx,org,dr=po.soup(1000000,%s); acc=la.HipAccel(0); acc.add_mesh(P,idx); acc.commit(build='host');"
         "o=torch.from_numpy(org).cuda(); d=torch.from_numpy(dr).cuda();\n"
         "def t(mode):\n"
         "    out=acc.intersect_device(o,d,mode=mode); torch.cuda.synchronize(); ts=[]\n"
