@@ -191,6 +191,15 @@ int  ri_hipbvh_intersect_beam_visibility(void *accel, ri_beam_t *beam, void *use
 /* n beams in one launch; result[i] = RI_BEAM_* or -1 where ri_beam_set refuses the beam */
 int  ri_hipbvh_intersect_beam_visibility_batch(void *accel, size_t n, const double *org_xyz,
                                                const double *corner_dirs_xyz, int32_t *result);
+/* ri_bvh_diag_t (bvh.h:103-110): what ri_bvh_intersect zeroes and fills through `user` (bvh.c:451-456).  ri_hipbvh_intersect
+ * fills it with the numbers of ITS walk over ITS tree for that ray: 4-wide node visits, leaf visits, and -- where the reference
+ * counts one "triangle isect" per leaf (bvh.c:827) -- the triangle records that went through the filter. */
+typedef struct _ri_bvh_diag_t {
+    uint32_t ninner_node_traversals;
+    uint32_t nleaf_node_traversals;
+    uint32_t ntriangle_isects;
+} ri_bvh_diag_t;
+
 /* ---- the beam-raster path (raster.h:24-84, bvh.h:203-206) ----
  * ri_raster_plane_t as raster.h:24-57 declares it; _new / _setup / _free as raster.c:24-160 (setup allocates and zeroes the
  * five arrays and computes `offset`, the lower-left corner in NDC).  ri_hipbvh_intersect_beam = ri_bvh_intersect_beam

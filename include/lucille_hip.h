@@ -113,6 +113,16 @@ int  lh_accel_prim_lookup(const lh_accel_t *accel, uint32_t prim, uint32_t *mesh
  * batch of one through the same kernel). Returns 1 hit / 0 miss / -1 error. */
 int  lh_accel_intersect1(lh_accel_t *accel, const double org[3], const double dir[3],
                          uint32_t *prim, double *t, double *u, double *v);
+/* Per-ray traversal diagnostics: what ri_bvh_intersect reports through its `user` argument (a ri_bvh_diag_t, bvh.h:103-110,
+ * bvh.c:451-456) for THIS build's tree.  diag: n x 4 u32 -- 4-wide node visits, leaf visits, triangle records through the fp32
+ * filter, fp64 tests -- of the sequential walk (nearest child first, as tests/cpu_model walks); records as every other path's.
+ * With lh_accel_trace_statistics on, the launch's totals are the sums of these rows. */
+int  lh_accel_intersect_diag_host(lh_accel_t *accel, size_t n, const double *org_xyz, const double *dir_xyz,
+                                  uint32_t *prim_id, double *t, double *u, double *v, uint32_t *diag);
+/* Concurrent lh_accel_intersect1 callers (lucille's render threads) are coalesced into one launch per batch of callers
+ * (lh_query.hip "flat combining"); set_param("combine", 0) / LH_COMBINE=0 restores one launch per call.
+ * out[0] = launches, out[1] = rays they carried since the last clear. */
+int  lh_accel_combine_statistics(lh_accel_t *accel, uint64_t out[2], int clear);
 
 /* host-resident batch: H2D, kernel, D2H on the accel's own stream */
 int  lh_accel_intersect_host(lh_accel_t *accel, size_t n, const double *org_xyz,

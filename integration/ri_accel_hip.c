@@ -22,6 +22,7 @@
 #include "list.h"
 #include "log.h"
 #include "intersection_state.h"
+#include "bvh.h"                 /* ri_bvh_diag_t: what `user` points at (bvh.h:103-110) */
 
 #include "lucille_hip.h"
 
@@ -129,9 +130,14 @@ int ri_hipbvh_intersect(void *accel, ri_ray_t *ray, ri_intersection_state_t *sta
     uint32_t prim, mesh, index;
     double t, u, v;
     int hit;
-    (void)user;
 
-    hit = lh_accel_intersect1(h->lh, ray->org, ray->dir, &prim, &t, &u, &v);
+    if (user) {          /* ri_bvh_diag_t (bvh.h:103-110): zeroed and filled as bvh.c:451-456 does, with this walk's numbers */
+        ri_bvh_diag_t *dg = (ri_bvh_diag_t *)user; uint32_t d4[4] = {0, 0, 0, 0};
+        memset(dg, 0, sizeof(*dg));
+        if (lh_accel_intersect_diag_host(h->lh, 1, ray->org, ray->dir, &prim, &t, &u, &v, d4) != 0) return 0;
+        dg->ninner_node_traversals = d4[0]; dg->nleaf_node_traversals = d4[1]; dg->ntriangle_isects = d4[2];
+        hit = prim != 0xFFFFFFFFu;
+    } else hit = lh_accel_intersect1(h->lh, ray->org, ray->dir, &prim, &t, &u, &v);
     if (hit <= 0) return 0;
 
     lh_accel_prim_lookup(h->lh, prim, &mesh, &index);

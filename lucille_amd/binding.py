@@ -100,7 +100,7 @@ class TileStats(C.Structure):
 # every symbol include/lucille_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "lh_device_count", "lh_last_error", "lh_accel_create", "lh_accel_add_mesh", "lh_accel_commit", "lh_accel_wait_exact", "lh_accel_ref_tree",
-    "lh_accel_destroy", "lh_accel_info", "lh_accel_prim_lookup", "lh_accel_intersect1",
+    "lh_accel_destroy", "lh_accel_info", "lh_accel_prim_lookup", "lh_accel_intersect1", "lh_accel_combine_statistics", "lh_accel_intersect_diag_host",
     "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted", "lh_accel_last_retraced", "lh_accel_dump_node_bytes",
     "lh_accel_set_grid", "lh_accel_set_param", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
     "lh_render_ao_tile", "lh_render_ao_tile_host", "lh_render_ao_bands", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device", "lh_accel_beam_raster_host", "lh_accel_beam_raster_device", "lh_render_pt_tile",
@@ -331,6 +331,23 @@ class HipAccel:
         return nodes, tri32
 
     # ---- queries ----------------------------------------------------------
+    def intersect_diag(self, org, dr):
+        """per-ray traversal diagnostics -> ((prim, t, u, v), diag uint32 [n, 4]: 4-wide node visits, leaf visits, triangle
+        records through the fp32 filter, fp64 tests) -- the sequential walk's numbers (ri_bvh_diag_t, bvh.h:103-110)"""
+        o = _np(org, np.float64).reshape(-1, 3); d = _np(dr, np.float64).reshape(-1, 3); n = o.shape[0]
+        prim = np.empty(n, np.uint32); t = np.empty(n); u = np.empty(n); v = np.empty(n); diag = np.zeros((n, 4), np.uint32)
+        self.L.lh_accel_intersect_diag_host.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 7
+        _check(self.L.lh_accel_intersect_diag_host(self.h, n, o.ctypes.data, d.ctypes.data, prim.ctypes.data, t.ctypes.data, u.ctypes.data,
+                                                   v.ctypes.data, diag.ctypes.data), "lh_accel_intersect_diag_host")
+        return (prim, t, u, v), diag
+
+    def combine_statistics(self, clear=False):
+        """(launches, rays) of the coalesced single-ray path since the last clear"""
+        o = (C.c_uint64 * 2)()
+        self.L.lh_accel_combine_statistics.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+        _check(self.L.lh_accel_combine_statistics(self.h, o, 1 if clear else 0), "lh_accel_combine_statistics")
+        return int(o[0]), int(o[1])
+
     def intersect1(self, org, dr):
         o = _np(org, np.float64).reshape(3); d = _np(dr, np.float64).reshape(3)
         p = C.c_uint32(); t = C.c_double(); u = C.c_double(); v = C.c_double()

@@ -46,6 +46,8 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
         pthread_mutex_init(&a->mu, &at); pthread_mutexattr_destroy(&at);
     }
     a->default_variant = LH_VARIANT_SPEC;
+    a->combine = 1;
+    { const char *e = getenv("LH_COMBINE"); if (e) a->combine = atoi(e) != 0; }
     a->ao_fused = 1;
     a->wide8 = -1;
     { const char *e = getenv("LH_WIDE8"); if (e) a->wide8 = atoi(e); }
@@ -756,7 +758,7 @@ extern "C" int lh_accel_ref_tree(lh_accel_t *a, uint32_t *nnodes, void *nodes_ou
 extern "C" void lh_accel_destroy(lh_accel_t *a)
 {
     if (!a) return;
-    if (a->committed || a->commit_failed) { (void)hipSetDevice(a->device); release_device(a); }
+    if (a->committed || a->commit_failed) { (void)hipSetDevice(a->device); lh_comb_destroy(a); release_device(a); }
     for (uint32_t g = 0; g < a->nmeshes; g++) {
         free(a->meshes[g].pos); free(a->meshes[g].idx); free(a->meshes[g].nrm);
         for (int k = 0; k < 5; k++) free(a->meshes[g].attr[k]);
@@ -822,6 +824,7 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
     else if (!strcmp(name, "ray_budget") && value > 0) { a->dev.ray_budget = (uint32_t)value; a->dump_budget = (uint32_t)value; }
     else if (!strcmp(name, "dump_budget") && value > 0) a->dump_budget = (uint32_t)value;
     else if (!strcmp(name, "ao_fused")) a->ao_fused = value != 0;
+    else if (!strcmp(name, "combine")) a->combine = value != 0;
     else if (!strcmp(name, "fast_start")) a->fast_start = value != 0;
     else if (!strcmp(name, "wide8") && value >= -1 && value <= 1) a->wide8 = value;
     else if (!strcmp(name, "top_nodes") && value >= -1 && value <= (int)LH_TOP_NODES_MAX) a->dev.top_nodes = value < 0 ? LH_TOP_AUTO : (uint32_t)value;

@@ -45,6 +45,8 @@ typedef struct lh_dev_scene {
     uint32_t    top_nodes; /* the first top_nodes 4-wide nodes (level order: the top of the tree) are walked from a copy in the workgroup's LDS; 0: none */
     const void *cam_src;       /* NULL, or: ray source 2 -- the launch's rays are the camera rays of a path-traced pass (PtCamSrc, lh_pt.h), org / dir unused */
     const uint32_t *n_dev;     /* NULL, or: the launch's ray count lives on the device (the path tracer's bounce chain; the host passes an upper bound) */
+    uint32_t   *diag_out;      /* NULL, or: four counts per ray of this launch (4-wide node visits, leaf visits, triangle records through the fp32
+                                  filter, fp64 tests): the per-ray diagnostics of ri_bvh_intersect's `user` argument (bvh.h:103-110, bvh.c:451-456) */
     unsigned long long *diag_clock;   /* diagnostics (LH_STAGE_TIMING): [2][waves] start / exit wall clock of every persistent wave, or NULL */
 } lh_dev_scene_t;
 

@@ -276,7 +276,6 @@ int ri_hipbvh_intersect(void *accel, ri_ray_t *ray, ri_intersection_state_t *sta
 {
     hipbvh_t *h = (hipbvh_t *)accel;
     uint32_t prim; double t, u, v; int hit, k;
-    (void)user;
     if (!h || !ray || !state) return 0;
     /* the scratch members the reference writes into the caller's ray (bvh.c:473-497) */
     for (k = 0; k < 3; k++) {
@@ -285,7 +284,12 @@ int ri_hipbvh_intersect(void *accel, ri_ray_t *ray, ri_intersection_state_t *sta
                                                        : ((ray->dir[k] < 0.0) ? -1.7976931348623157e308 : 1.7976931348623157e308);
     }
     stat_before(h);
-    hit = lh_accel_intersect1(h->lh, ray->org, ray->dir, &prim, &t, &u, &v);
+    if (user) {          /* a ri_bvh_diag_t (bvh.c:451-456): this ray's own numbers, from the sequential walk */
+        ri_bvh_diag_t *dg = (ri_bvh_diag_t *)user; uint32_t d4[4] = {0, 0, 0, 0};
+        memset(dg, 0, sizeof(*dg));
+        hit = lh_accel_intersect_diag_host(h->lh, 1, ray->org, ray->dir, &prim, &t, &u, &v, d4);
+        if (hit == 0) { hit = prim != 0xFFFFFFFFu; dg->ninner_node_traversals = d4[0]; dg->nleaf_node_traversals = d4[1]; dg->ntriangle_isects = d4[2]; }
+    } else hit = lh_accel_intersect1(h->lh, ray->org, ray->dir, &prim, &t, &u, &v);
     stat_after(h);
     if (hit < 0) { fprintf(stderr, "[lucille_hip] ERROR : (HIPBVH) %s\n", lh_last_error()); return 0; }
     /* bvh_traverse initialises these whether or not there is a hit (bvh.c:1111-1115) */

@@ -114,6 +114,8 @@ struct lh_accel {
     lh_buf p_org2, p_dir2, p_path, p_path2, p_thr, p_thr2, p_rad, p_counts;   /* path tracer */
     unsigned long long *d_total;
     size_t r_nsamples, r_nslots, r_nao;
+    struct lh_combiner *comb;          /* lh_accel_intersect1: concurrent single-ray callers coalesced into one launch (lh_query.hip) */
+    int combine;                       /* 1 (default): coalesce; 0: one launch per call, as in rounds 1-3 */
 };
 
 #define LH_NCURSOR 64
@@ -153,6 +155,7 @@ uint32_t *lh_scene_image_prim_index(lh_accel_t *a);
 int  lh_scene_image_alloc(lh_accel_t *a, const lh_scene_image_t *h);
 int  lh_scene_image_finish(lh_accel_t *a);
 /* lh_query.hip */
+void lh_comb_destroy(lh_accel_t *a);                 /* the single-ray combiner's pinned block and stream (lh_accel_destroy) */
 int  lh_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, void *d_prim, void *d_t, void *d_u, void *d_v,
                void *d_occ, int mode, int variant, unsigned long long *d_counters, hipStream_t s, bool dump);
 int  lh_aoq_slot(lh_accel_t *a, hipStream_t s);

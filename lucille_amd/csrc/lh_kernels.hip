@@ -843,16 +843,18 @@ __device__ __forceinline__ void flagged_ray(const lh_dev_scene_t &sc, size_t i, 
     }
 }
 
+/* cnt (or NULL): this ray's 4-wide node visits, leaf visits, triangle records through the fp32 filter, fp64 tests -- the walk
+ * is sequential (nearest child first, a leaf's triangles in order), so the counts are the host model's (tests/cpu_model) */
 template <bool ANYHIT>
 __device__ void overflow_walk(const lh_dev_scene_t &sc, size_t i, const double *__restrict__ org, const double *__restrict__ dir,
                               uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u, double *__restrict__ v,
-                              uint8_t *__restrict__ occ)
+                              uint8_t *__restrict__ occ, uint32_t *cnt = NULL)
 {
     double ox, oy, oz, dx, dy, dz;
     flagged_ray(sc, i, org, dir, ox, oy, oz, dx, dy, dz);
     const float4 *__restrict__ tris = (const float4 *)sc.tri32;
     Lane L; Best best = {LH_T_INF, 0.0, 0.0, LH_MISS_PRIM, 0u};
-    uint32_t ce = 0;
+    uint32_t ce = 0, cn = 0, cl = 0, ct = 0;
     int stack[LH_COOP_ROWS_MAX]; int sp = 0;
     lane_init(L, sc, ox, oy, oz, dx, dy, dz);
     int cur = 0;
@@ -861,14 +863,17 @@ __device__ void overflow_walk(const lh_dev_scene_t &sc, size_t i, const double *
             const uint4 *p = (const uint4 *)sc.q4nodes + 4 * (size_t)cur;
             const uint4 a = p[0], b = p[1], c = p[2], r = p[3];
             float tn[4]; bool h[4]; const int ref[4] = {(int)r.x, (int)r.y, (int)r.z, (int)r.w};
+            cn++;
             h[0] = slab_w(L, a.x, a.y, a.z, tn[0]) & (ref[0] != kDone);
             h[1] = slab_w(L, a.w, b.x, b.y, tn[1]) & (ref[1] != kDone);
             h[2] = slab_w(L, b.z, b.w, c.x, tn[2]) & (ref[2] != kDone);
             h[3] = slab_w(L, c.y, c.z, c.w, tn[3]) & (ref[3] != kDone);
-            int order[4], nh = 0;
+            /* nearest first, by the key of the default walk's node step (distance bits with the slot in the two low bits) */
+            int order[4], nh = 0; uint32_t key[4];
             for (int k = 0; k < 4; k++) if (h[k]) {
+                key[k] = (__float_as_uint(tn[k]) & ~3u) | (uint32_t)k;
                 int m = nh++;
-                while (m > 0 && tn[order[m - 1]] > tn[k]) { order[m] = order[m - 1]; m--; }
+                while (m > 0 && key[order[m - 1]] > key[k]) { order[m] = order[m - 1]; m--; }
                 order[m] = k;
             }
             for (int k = nh - 1; k >= 1; k--) if (sp < LH_COOP_ROWS_MAX) stack[sp++] = ref[order[k]];
@@ -876,21 +881,24 @@ __device__ void overflow_walk(const lh_dev_scene_t &sc, size_t i, const double *
             else if (sp) cur = stack[--sp];
             else break;
         } else {
-            const uint32_t x = ~(uint32_t)cur, first = x >> 2, cnt = (x & 3u) + 1u;
+            const uint32_t x = ~(uint32_t)cur, first = x >> 2, cnt_ = (x & 3u) + 1u;
             bool finished = false;
-            for (uint32_t k = 0; k < cnt && !finished; k++) {
+            cl++;
+            for (uint32_t k = 0; k < cnt_ && !finished; k++) {
                 const float4 *tp = tris + 3 * (size_t)(first + k);
                 const float4 ta = tp[0], tb_ = tp[1], tc = tp[2];
-                finished = tri_step<ANYHIT, false>(L, sc, ta.x, ta.y, ta.z, ta.w, tb_.x, tb_.y, tb_.z, tb_.w, tc.x, tc.z, tc.w,
-                                                   __float_as_uint(tc.y), ox, oy, oz, dx, dy, dz, best, ce);
+                ct++;
+                finished = tri_step<ANYHIT, true>(L, sc, ta.x, ta.y, ta.z, ta.w, tb_.x, tb_.y, tb_.z, tb_.w, tc.x, tc.z, tc.w,
+                                                  __float_as_uint(tc.y), ox, oy, oz, dx, dy, dz, best, ce);
             }
             if (finished || sp == 0) break;
             cur = stack[--sp];
         }
     }
     L.over = false;
-    finish<ANYHIT, false>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
+    finish<ANYHIT, true>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
     write_out<ANYHIT>(i, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL);
+    if (cnt) { cnt[0] = cn; cnt[1] = cl; cnt[2] = ct; cnt[3] = ce; }
 }
 
 __global__ __launch_bounds__(256) void k_fixups(lh_dev_scene_t sc, size_t n, const double *__restrict__ org,
@@ -917,6 +925,42 @@ __global__ __launch_bounds__(256) void k_fixups(lh_dev_scene_t sc, size_t n, con
         else { prim[i] = rh.prim; t[i] = rh.t; u[i] = rh.u; v[i] = rh.v; }
         if (counters) atomicAdd(&counters[LH_CNT_RETRACED], 1ull);
     }
+}
+
+/* ------------------------------------------------------------------------ */
+/* a handful of rays: one launch, one lane per ray                            */
+/* ------------------------------------------------------------------------ */
+/* lucille's synchronous accel->intersect (raytrace.c:31-69) reaches the device as batches of at most a few dozen rays (the
+ * render threads' concurrent calls, coalesced: lh_query.hip).  The persistent kernel is the wrong tool there -- a cursor reset,
+ * a fix-up queue reset, 768 workgroups that find nothing to do, a scan for flagged rays: four launches and ~100 us for
+ * microseconds of work.  Here every ray gets a wave of ONE small launch and walks the 4-wide nodes sequentially with a private
+ * stack (overflow_walk: the same filter, the same fp64 resolve, the same answer); a fragile hit goes through the
+ * reference's own walk in the same lane. */
+#define LH_SMALL_BATCH 64u
+/* PER_WAVE: one ray per wave (lane 0), else one per lane.  counters (or NULL): the launch's totals (LH_CNT_*); sc.diag_out (or
+ * NULL): four counts per ray -- ri_bvh_diag_t's numbers (bvh.h:103-110) for this build's tree */
+template <bool ANYHIT, bool PER_WAVE>
+__global__ __launch_bounds__(64) void k_trace_small(lh_dev_scene_t sc, uint32_t n, const double *__restrict__ org, const double *__restrict__ dir,
+                                                    uint32_t *__restrict__ prim, double *__restrict__ t, double *__restrict__ u,
+                                                    double *__restrict__ v, uint8_t *__restrict__ occ, unsigned long long *counters)
+{
+    /* ONE RAY PER WAVE: sixty-four unrelated rays in the lanes of one wave walk in lockstep through each other's branches
+     * (16 rays: 243 us against 49 us for one, r04); a wave per ray runs them side by side on as many CUs -- the batch takes
+     * as long as its longest ray.  63 idle lanes per wave are free here: the batch is tiny and the chip is empty. */
+    const uint32_t i = PER_WAVE ? blockIdx.x : blockIdx.x * 64u + threadIdx.x;
+    if (i >= n || (PER_WAVE && threadIdx.x != 0)) return;
+    uint32_t cnt[4] = {0u, 0u, 0u, 0u};
+    overflow_walk<ANYHIT>(sc, i, org, dir, prim, t, u, v, occ, cnt);
+    if (sc.diag_out) { uint32_t *d = sc.diag_out + 4 * (size_t)i; d[0] = cnt[0]; d[1] = cnt[1]; d[2] = cnt[2]; d[3] = cnt[3]; }
+    if (counters) add_counters(counters, cnt[0], cnt[2], cnt[3], 1);
+    if (sc.ref_nodes == NULL) return;
+    if (ANYHIT ? (occ[i] != LH_OCC_RETRACE) : (prim[i] != LH_PRIM_RETRACE)) return;
+    double ox, oy, oz, dx, dy, dz;
+    flagged_ray(sc, i, org, dir, ox, oy, oz, dx, dy, dz);
+    const RefHit rh = ref_trace_one(sc, ox, oy, oz, dx, dy, dz);
+    if (ANYHIT) occ[i] = rh.prim != LH_MISS_PRIM ? 1 : 0;
+    else { prim[i] = rh.prim; t[i] = rh.t; u[i] = rh.u; v[i] = rh.v; }
+    if (counters) atomicAdd(&counters[LH_CNT_RETRACED], 1ull);
 }
 
 /* a workgroup's LDS stack beyond 64 KiB (trees deeper than 19 four-wide levels: up to LH_ROWS_UNCHECKED rows) has to be
@@ -1162,7 +1206,20 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
     lh_dev_scene_t scl = *sc;
     uint32_t need; int walk; bool guard = false;
     if ((sc->cam_src || sc->n_dev) && (variant == LH_VARIANT_DIRECT || anyhit || q == NULL)) return -1;      /* the path tracer's chain: default walk, closest hit */
-    if (sc->cam_src) scl.prefer_q8 = 0;
+    if ((n <= LH_SMALL_BATCH || sc->diag_out) && variant != LH_VARIANT_DIRECT && !sc->cam_src && !sc->n_dev && !sc->stack_cap && sc->q4nodes) {
+        /* a handful of rays (the coalesced one-ray callers): one small launch, a wave per ray, no queue, no cursors.
+         * Per-ray diagnostics (diag_out): the same walk for a batch of any size, a lane per ray */
+        if (n <= LH_SMALL_BATCH) {
+            if (anyhit) hipLaunchKernelGGL((k_trace_small<true, true>), dim3((unsigned)n), dim3(64), 0, s, scl, (uint32_t)n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occluded, d_counters);
+            else hipLaunchKernelGGL((k_trace_small<false, true>), dim3((unsigned)n), dim3(64), 0, s, scl, (uint32_t)n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occluded, d_counters);
+        } else {
+            const unsigned blocks = (unsigned)((n + 63) / 64);
+            if (anyhit) hipLaunchKernelGGL((k_trace_small<true, false>), dim3(blocks), dim3(64), 0, s, scl, (uint32_t)n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occluded, d_counters);
+            else hipLaunchKernelGGL((k_trace_small<false, false>), dim3(blocks), dim3(64), 0, s, scl, (uint32_t)n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occluded, d_counters);
+        }
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    if (sc->diag_out) return -1;                 /* per-ray diagnostics exist for the default walk's nodes only */
     if (variant == LH_VARIANT_DIRECT) {
         if (!sc->nodes) return -1;
         need = sc->max_depth + 2; walk = 0;          /* 2-wide: one push per level + the sentinel */

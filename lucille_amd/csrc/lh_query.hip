@@ -353,12 +353,165 @@ extern "C" int lh_accel_slot_statistics(lh_accel_t *a, uint64_t slots[3], int cl
     return 0;
 }
 
+/* ------------------------------------------------------------------------ */
+/* one synchronous ray: accel_intersect_func as lucille calls it              */
+/* ------------------------------------------------------------------------ */
+/* lucille calls accel->intersect(accel, ray, state, user) for ONE ray from up to 16 render threads at once (raytrace.c:31-69,
+ * render.c:1043-1105; 18 call sites in whitted.c, shader.c, ibl.c).  A launch per call is ~100 us of copies, launch and
+ * synchronisation for ~1 us of work, and the calls serialise on the accelerator's lock: ~10 000 rays/s whatever the thread
+ * count (rounds 1-3).  Here concurrent callers are COALESCED (flat combining): a caller writes its ray into the open batch --
+ * a slot of a pinned, device-visible block -- and either finds a batch in flight (it sleeps until its own batch is done) or
+ * becomes the leader: it waits a few microseconds for the other render threads (which come back from their previous ray
+ * at about the same time), closes the batch, launches it straight out of the pinned block (no copies: the kernel reads the
+ * rays and writes the records over the link), and wakes the batch's owners.  While a batch runs the next one fills (two
+ * blocks).  Records are the batch path's, bit for bit.  set_param("combine", 0) restores one launch per call. */
+#define LH_COMB_CAP 64
+struct lh_combiner {
+    pthread_mutex_t mu; pthread_cond_t cv;
+    unsigned long long open_gen, done_gen;      /* the batch that accepts rays; batches finished (done_gen > g: batch g is done) */
+    int leader_active;
+    volatile int n_pending;                     /* rays in the open batch */
+    int readers_left[2], rc[2], expect;
+    char err[2][256];
+    void *block; double *org[2], *dir[2], *t[2], *u[2], *v[2]; uint32_t *prim[2];       /* pinned host memory the device reads / writes */
+    void *d_block; double *d_org[2], *d_dir[2], *d_t[2], *d_u[2], *d_v[2]; uint32_t *d_prim[2];
+    hipStream_t stream;
+    unsigned long long batches, rays;
+};
+
+static int comb_create(lh_accel_t *a)
+{
+    lh_combiner *c = (lh_combiner *)calloc(1, sizeof(*c));
+    if (!c) return fail("out of memory");
+    const size_t per = sizeof(double) * (3 + 3 + 1 + 1 + 1) * LH_COMB_CAP + sizeof(uint32_t) * LH_COMB_CAP;
+    if (hipHostMalloc(&c->block, 2 * per, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&c->d_block, c->block, 0) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        const hipError_t e = hipGetLastError();
+        if (c->block) (void)hipHostFree(c->block);
+        free(c);
+        return fail("lh_accel_intersect1: the pinned block of the combiner could not be set up: %s", hipGetErrorString(e));
+    }
+    for (int b = 0; b < 2; b++) {
+        char *h = (char *)c->block + (size_t)b * per, *d = (char *)c->d_block + (size_t)b * per;
+        c->org[b] = (double *)h; c->dir[b] = c->org[b] + 3 * LH_COMB_CAP; c->t[b] = c->dir[b] + 3 * LH_COMB_CAP; c->u[b] = c->t[b] + LH_COMB_CAP;
+        c->v[b] = c->u[b] + LH_COMB_CAP; c->prim[b] = (uint32_t *)(c->v[b] + LH_COMB_CAP);
+        c->d_org[b] = (double *)d; c->d_dir[b] = c->d_org[b] + 3 * LH_COMB_CAP; c->d_t[b] = c->d_dir[b] + 3 * LH_COMB_CAP; c->d_u[b] = c->d_t[b] + LH_COMB_CAP;
+        c->d_v[b] = c->d_u[b] + LH_COMB_CAP; c->d_prim[b] = (uint32_t *)(c->d_v[b] + LH_COMB_CAP);
+    }
+    pthread_mutex_init(&c->mu, NULL); pthread_cond_init(&c->cv, NULL);
+    c->expect = 1;
+    a->comb = c;
+    return 0;
+}
+
+void lh_comb_destroy(lh_accel_t *a)
+{
+    lh_combiner *c = a->comb;
+    if (!c) return;
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->block) (void)hipHostFree(c->block);
+    pthread_mutex_destroy(&c->mu); pthread_cond_destroy(&c->cv);
+    free(c); a->comb = NULL;
+}
+
+static int comb_run(lh_accel_t *a, lh_combiner *c, int b, int n)
+{
+    lh_guard guard(a);                       /* the accelerator's device state: one launch at a time */
+    HIPCHK(hipSetDevice(a->device));
+    if (lh_launch(a, (size_t)n, c->d_org[b], c->d_dir[b], c->d_prim[b], c->d_t[b], c->d_u[b], c->d_v[b], NULL, LH_MODE_CLOSEST,
+                  LH_VARIANT_DEFAULT, NULL, c->stream, true) != 0) return -1;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int lh_accel_combine_statistics(lh_accel_t *a, uint64_t out[2], int clear)
+{
+    if (!a || !out) return fail("lh_accel_combine_statistics: NULL argument");
+    out[0] = out[1] = 0;
+    lh_combiner *c = a->comb;
+    if (!c) return 0;
+    pthread_mutex_lock(&c->mu);
+    out[0] = c->batches; out[1] = c->rays;
+    if (clear) c->batches = c->rays = 0;
+    pthread_mutex_unlock(&c->mu);
+    return 0;
+}
+
 extern "C" int lh_accel_intersect1(lh_accel_t *a, const double org[3], const double dir[3],
                                    uint32_t *prim, double *t, double *u, double *v)
 {
     uint32_t p = LH_MISS_PRIM; double tt = LH_T_INF, uu = 0.0, vv = 0.0;
+    if (!a || !a->committed) return fail("lh_accel_intersect1: accel not committed");
     if (!org || !dir) return fail("lh_accel_intersect1: NULL ray");
-    if (lh_accel_intersect_host(a, 1, org, dir, &p, &tt, &uu, &vv, NULL, LH_MODE_CLOSEST) != 0) return -1;
+    if (!a->combine || a->stat_on) {         /* statistics are per launch: counted launches stay one ray each */
+        if (lh_accel_intersect_host(a, 1, org, dir, &p, &tt, &uu, &vv, NULL, LH_MODE_CLOSEST) != 0) return -1;
+    } else {
+        if (!a->comb) {
+            lh_guard guard(a);
+            if (!a->comb) { HIPCHK(hipSetDevice(a->device)); if (comb_create(a) != 0) return -1; }
+        }
+        lh_combiner *c = a->comb;
+        int rc = 0;
+        pthread_mutex_lock(&c->mu);
+        while (c->n_pending >= LH_COMB_CAP) pthread_cond_wait(&c->cv, &c->mu);
+        const unsigned long long g = c->open_gen;
+        const int b = (int)(g & 1ull), slot = c->n_pending;
+        for (int k = 0; k < 3; k++) { c->org[b][3 * slot + k] = org[k]; c->dir[b][3 * slot + k] = dir[k]; }
+        __atomic_store_n(&c->n_pending, slot + 1, __ATOMIC_RELEASE);
+        for (;;) {
+            if (__atomic_load_n(&c->done_gen, __ATOMIC_ACQUIRE) > g) break;      /* somebody ran my batch */
+            if (!c->leader_active && c->open_gen == g) {
+                if (c->readers_left[b] != 0) { pthread_cond_wait(&c->cv, &c->mu); continue; }     /* owners of batch g - 2 still copy their records out of this block */
+                c->leader_active = 1;
+                /* the other render threads come back from their previous ray about now: wait for as many as the last batches
+                 * held, a few microseconds at most */
+                static const double gather_us = getenv("LH_COMB_GATHER_US") ? atof(getenv("LH_COMB_GATHER_US")) : 50.0;
+                if (gather_us > 0.0 && c->expect > 1 && c->n_pending < c->expect) {
+                    pthread_mutex_unlock(&c->mu);
+                    const double t0 = lh_now_s();
+                    while (__atomic_load_n(&c->n_pending, __ATOMIC_ACQUIRE) < c->expect && lh_now_s() - t0 < gather_us * 1e-6) { }
+                    pthread_mutex_lock(&c->mu);
+                }
+                const int n = c->n_pending;
+                c->n_pending = 0; c->open_gen = g + 1;                   /* closed: arrivals fill the other block */
+                pthread_cond_broadcast(&c->cv);                           /* callers waiting for room */
+                pthread_mutex_unlock(&c->mu);
+                const int r = comb_run(a, c, b, n);
+                pthread_mutex_lock(&c->mu);
+                c->rc[b] = r;
+                if (r != 0) { snprintf(c->err[b], sizeof(c->err[b]), "%s", lh_last_error()); }
+                c->readers_left[b] = n; c->leader_active = 0;
+                __atomic_store_n(&c->done_gen, g + 1, __ATOMIC_RELEASE);
+                c->batches++; c->rays += (unsigned long long)n;
+                c->expect = n > c->expect ? n : (n + 3 * c->expect) / 4;     /* follows the callers' concurrency, decays slowly */
+                if (c->expect < 1) c->expect = 1;
+                pthread_cond_broadcast(&c->cv);
+                break;
+            }
+            /* a batch is ~100 us away at most: watch for it without the mutex for a while (a condition variable's wake-up costs
+             * tens of microseconds and sixteen owners take the mutex one after the other), then sleep */
+            pthread_mutex_unlock(&c->mu);
+            {
+                static const double spin_us = getenv("LH_COMB_SPIN_US") ? atof(getenv("LH_COMB_SPIN_US")) : 300.0;
+                const double t0 = lh_now_s(); int spins = 0;
+                if (spin_us > 0.0) while (__atomic_load_n(&c->done_gen, __ATOMIC_ACQUIRE) <= g && !(__atomic_load_n(&c->leader_active, __ATOMIC_RELAXED) == 0 && __atomic_load_n(&c->open_gen, __ATOMIC_RELAXED) == g)) {
+                    __builtin_ia32_pause();
+                    if ((++spins & 255) == 0 && lh_now_s() - t0 > spin_us * 1e-6) break;
+                }
+            }
+            pthread_mutex_lock(&c->mu);
+            if (__atomic_load_n(&c->done_gen, __ATOMIC_ACQUIRE) > g) break;
+            if (!c->leader_active && c->open_gen == g) continue;          /* the leader's seat is free: take it */
+            pthread_cond_wait(&c->cv, &c->mu);
+        }
+        rc = c->rc[b];
+        if (rc == 0) { p = c->prim[b][slot]; tt = c->t[b][slot]; uu = c->u[b][slot]; vv = c->v[b][slot]; }
+        else lh_fail("%s", c->err[b]);
+        if (--c->readers_left[b] == 0) pthread_cond_broadcast(&c->cv);
+        pthread_mutex_unlock(&c->mu);
+        if (rc != 0) return -1;
+    }
     if (prim) *prim = p;
     if (t) *t = tt;
     if (u) *u = uu;
@@ -366,6 +519,61 @@ extern "C" int lh_accel_intersect1(lh_accel_t *a, const double org[3], const dou
     return p != LH_MISS_PRIM;
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* per-ray traversal diagnostics (ri_bvh_diag_t, bvh.h:103-110)               */
+/* ------------------------------------------------------------------------ */
+/* ri_bvh_intersect zeroes and (built with RI_BVH_ENABLE_DIAGNOSTICS) fills a caller-supplied ri_bvh_diag_t through `user`
+ * (bvh.c:451-456,1127,1146,827): inner-node visits, leaf visits, leaf tests of THAT ray -- the testbed's heat maps
+ * (simplerender.cpp:202-218).  Here: the same three numbers for THIS build's tree, per ray, from the sequential walk
+ * (k_trace_small; the numbers of a speculative walk would depend on its wave-mates): diag = n x 4 u32 -- 4-wide node visits,
+ * leaf visits, triangle records through the fp32 filter, fp64 tests.  Records are the batch path's.  A diagnostic path: a
+ * lane per ray, no regrouping. */
+extern "C" int lh_accel_intersect_diag_host(lh_accel_t *a, size_t n, const double *org, const double *dir, uint32_t *prim,
+                                            double *t, double *u, double *v, uint32_t *diag)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("intersect_diag: accel not committed");
+    if (n == 0) return 0;
+    if (!org || !dir || !diag) return fail("intersect_diag: NULL argument");
+    if (n > 0x7fffffffull) return fail("intersect_diag: more than 2^31 rays");
+    HIPCHK(hipSetDevice(a->device));
+    if (a->hs->bvh.ntris == 0) {
+        memset(diag, 0, sizeof(uint32_t) * 4 * n);
+        for (size_t i = 0; i < n; i++) { if (prim) prim[i] = LH_MISS_PRIM; if (t) t[i] = LH_T_INF; if (u) u[i] = 0.0; if (v) v[i] = 0.0; }
+        return 0;
+    }
+    const size_t b_ray = sizeof(double) * 3 * n, b_d = sizeof(double) * n;
+    const size_t total = 2 * b_ray + 3 * b_d + sizeof(uint32_t) * n + sizeof(uint32_t) * 4 * n + 64;
+    if (lh_ensure_stage(a, total) != 0) return -1;
+    char *base = (char *)a->d_stage;
+    double *d_org = (double *)base, *d_dir = (double *)(base + b_ray);
+    double *d_t = (double *)(base + 2 * b_ray), *d_u = d_t + n, *d_v = d_u + n;
+    uint32_t *d_prim = (uint32_t *)(d_v + n), *d_diag = d_prim + n;
+    HIPCHK(hipMemcpyAsync(d_org, org, b_ray, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_dir, dir, b_ray, hipMemcpyHostToDevice, a->stream));
+    if (a->stat_on) HIPCHK(hipMemsetAsync(a->d_counters, 0, sizeof(unsigned long long) * LH_CNT_DEV, a->stream));
+    a->dev.diag_out = d_diag;
+    const int rc = lh_launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, NULL, LH_MODE_CLOSEST, LH_VARIANT_SPEC, a->stat_on ? a->d_counters : NULL, a->stream, true);
+    a->dev.diag_out = NULL;
+    if (rc != 0) return rc;
+    HIPCHK(hipMemcpyAsync(diag, d_diag, sizeof(uint32_t) * 4 * n, hipMemcpyDeviceToHost, a->stream));
+    std::vector<uint32_t> hp;
+    if (a->stat_on || prim) { hp.resize(n); HIPCHK(hipMemcpyAsync(hp.data(), d_prim, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, a->stream)); }
+    if (t) HIPCHK(hipMemcpyAsync(t, d_t, b_d, hipMemcpyDeviceToHost, a->stream));
+    if (u) HIPCHK(hipMemcpyAsync(u, d_u, b_d, hipMemcpyDeviceToHost, a->stream));
+    if (v) HIPCHK(hipMemcpyAsync(v, d_v, b_d, hipMemcpyDeviceToHost, a->stream));
+    unsigned long long h[LH_CNT_N] = {0, 0, 0, 0};
+    if (a->stat_on) HIPCHK(hipMemcpyAsync(h, a->d_counters, sizeof(h), hipMemcpyDeviceToHost, a->stream));
+    HIPCHK(hipStreamSynchronize(a->stream));
+    if (prim) memcpy(prim, hp.data(), sizeof(uint32_t) * n);
+    if (a->stat_on) {
+        unsigned long long nh = 0;
+        for (size_t i = 0; i < n; i++) nh += hp[i] != LH_MISS_PRIM;
+        a->stat[0] += h[LH_CNT_NODES]; a->stat[1] += h[LH_CNT_TRIS]; a->stat[2] += h[LH_CNT_EXACT]; a->stat[3] += n; a->stat[4] += nh;
+    }
+    return 0;
+}
 
 /* ------------------------------------------------------------------------ */
 /* beam visibility                                                          */

@@ -49,6 +49,7 @@ typedef struct {
     const lh_bvh_t *b; size_t begin, end; const double *org, *dir;
     uint32_t *prim; double *t, *u, *v; uint8_t *occ; int anyhit; int qnodes;
     uint64_t c[4];
+    uint32_t *diag;            /* NULL, or n x 4: this ray's node visits, leaf visits, triangle records through the filter, fp64 tests */
 } job_t;
 
 static void trace_one(job_t *j, size_t i)
@@ -57,6 +58,7 @@ static void trace_one(job_t *j, size_t i)
     const double *o = &j->org[3 * i], *d = &j->dir[3 * i];
     best_t best = { T_INF, 0.0, 0.0, MISS, 0u };
     int certain = 0;
+    const uint64_t c0 = j->c[0], c1 = j->c[1], c2 = j->c[2]; uint32_t leaves = 0;
     j->c[3]++;
     if (b->ntris) {
         lh_ray32_t r; float tb = 1.0e38f, scene_r = 0.0f;
@@ -113,6 +115,7 @@ static void trace_one(job_t *j, size_t i)
             if (cur == DONE) break;
             {
                 uint32_t x = ~(uint32_t)cur, first = x >> 2, cnt = (x & 3u) + 1u, q; int finished = 0;
+                leaves++;
                 for (q = 0; q < cnt; q++) {
                     const lh_tri32_t *T = &b->tri32[first + q]; float t_hi; int cls;
                     j->c[1]++;
@@ -139,6 +142,7 @@ static void trace_one(job_t *j, size_t i)
             j->c[2] += (uint64_t)np;
         }
     }
+    if (j->diag) { uint32_t *dg = j->diag + 4 * i; dg[0] = (uint32_t)(j->c[0] - c0); dg[1] = leaves; dg[2] = (uint32_t)(j->c[1] - c1); dg[3] = (uint32_t)(j->c[2] - c2); }
     if (g_ref && best.prim != MISS && best.frag != 0u && !(j->anyhit && certain)) {
         /* the kernel's retrace pass (k_ref_retrace): the reference's own walk decides */
         uint32_t p; double tt, uu, vv;
@@ -155,6 +159,9 @@ static void trace_one(job_t *j, size_t i)
 
 static void *run(void *arg) { job_t *j = (job_t *)arg; size_t i; for (i = j->begin; i < j->end; i++) trace_one(j, i); return NULL; }
 
+static uint32_t *g_diag = NULL;      /* per-ray counts of the next lhm_trace call (lhm_set_diag) */
+void lhm_set_diag(uint32_t *diag) { g_diag = diag; }
+
 int lhm_trace(const lh_bvh_t *b, size_t n, const double *org, const double *dir, uint32_t *prim,
               double *t, double *u, double *v, uint8_t *occ, int anyhit, uint64_t counters[4], int nthreads)
 {
@@ -164,7 +171,7 @@ int lhm_trace(const lh_bvh_t *b, size_t n, const double *org, const double *dir,
     for (i = 0; i < nthreads; i++) {
         jobs[i].b = b; jobs[i].begin = n * (size_t)i / (size_t)nthreads; jobs[i].end = n * (size_t)(i + 1) / (size_t)nthreads;
         jobs[i].org = org; jobs[i].dir = dir; jobs[i].prim = prim; jobs[i].t = t; jobs[i].u = u; jobs[i].v = v;
-        jobs[i].occ = occ; jobs[i].anyhit = anyhit & 1; jobs[i].qnodes = (anyhit >> 1) & 7;
+        jobs[i].occ = occ; jobs[i].anyhit = anyhit & 1; jobs[i].qnodes = (anyhit >> 1) & 7; jobs[i].diag = g_diag;
     }
     if (nthreads == 1) run(&jobs[0]);
     else { for (i = 0; i < nthreads; i++) pthread_create(&th[i], NULL, run, &jobs[i]); for (i = 0; i < nthreads; i++) pthread_join(th[i], NULL); }

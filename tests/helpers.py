@@ -157,6 +157,19 @@ class Model:
                              t.ctypes.data_as(_dp), u.ctypes.data_as(_dp), v.ctypes.data_as(_dp), None, qnodes << 1, cp, nthreads)
         return (prim, t, u, v), dict(zip(("nodes", "tris", "exact", "rays"), map(int, cnt)))
 
+    def trace_diag(self, org, dr, qnodes=2):
+        """closest-hit walk with PER-RAY counts -> ((prim, t, u, v), uint32 [n, 4]: node visits, leaf visits, triangle records
+        through the fp32 filter, fp64 tests)"""
+        org = np.ascontiguousarray(org, np.float64).reshape(-1, 3); n = org.shape[0]
+        diag = np.zeros((n, 4), np.uint32)
+        L = self.lib(); L.lhm_set_diag.argtypes = [C.c_void_p]
+        L.lhm_set_diag(diag.ctypes.data)
+        try:
+            out, _ = self.trace(org, dr, nthreads=1, qnodes=qnodes)
+        finally:
+            L.lhm_set_diag(None)
+        return out, diag
+
 
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
