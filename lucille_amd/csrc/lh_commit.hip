@@ -70,6 +70,9 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     env = getenv("LH_RAY_BUDGET");
     if (env && atoi(env) > 0) a->dev.ray_budget = (uint32_t)atoi(env);
     a->dev.top_nodes = LH_TOP_AUTO;
+    a->dev.ao_group = 0;            /* measured: the grouped order is SLOWER on the config-5 frame (84.6 -> 95.1 ms, tools/ao_group_probe.py): a slot's own rays share their first levels */
+    env = getenv("LH_AO_GROUP");
+    if (env && atoi(env) >= 0 && atoi(env) <= 4096) a->dev.ao_group = (uint32_t)atoi(env);
     env = getenv("LH_TOP_NODES");
     if (env && atoi(env) >= 0 && atoi(env) <= (int)LH_TOP_NODES_MAX) a->dev.top_nodes = (uint32_t)atoi(env);
     *out = a;
@@ -542,7 +545,7 @@ static int size_grid(lh_accel_t *a)
     if (per_cu < 1) per_cu = 1;
     a->grid_blocks = prop.multiProcessorCount * per_cu; a->ncus = prop.multiProcessorCount;
     const char *env = getenv("LH_GRID_BLOCKS");
-    if (env && atoi(env) > 0) a->grid_blocks = atoi(env);
+    if (env && atoi(env) > 0) { a->grid_blocks = atoi(env); a->grid_user = 1; }
     return 0;
 }
 
@@ -816,7 +819,7 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
 {
     lh_guard guard(a);
     if (!a || !name) return fail("lh_accel_set_param: NULL argument");
-    if (!strcmp(name, "grid") && value > 0) a->grid_blocks = value;
+    if (!strcmp(name, "grid") && value > 0) { a->grid_blocks = value; a->grid_user = 1; }
     else if (!strcmp(name, "min_active") && value > 0 && value <= 64) a->min_active = value;
     else if (!strcmp(name, "tri_batch") && value > 0 && value <= 64) a->tri_batch = value;
     else if (!strcmp(name, "ray_chunk") && value > 0 && value <= (1 << 20)) { a->ray_chunk = (uint32_t)value; a->dev.ray_chunk = (uint32_t)value; }
@@ -825,6 +828,7 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
     else if (!strcmp(name, "dump_budget") && value > 0) a->dump_budget = (uint32_t)value;
     else if (!strcmp(name, "ao_fused")) a->ao_fused = value != 0;
     else if (!strcmp(name, "combine")) a->combine = value != 0;
+    else if (!strcmp(name, "ao_group") && value >= 0 && value <= 4096) a->dev.ao_group = (uint32_t)value;
     else if (!strcmp(name, "fast_start")) a->fast_start = value != 0;
     else if (!strcmp(name, "wide8") && value >= -1 && value <= 1) a->wide8 = value;
     else if (!strcmp(name, "top_nodes") && value >= -1 && value <= (int)LH_TOP_NODES_MAX) a->dev.top_nodes = value < 0 ? LH_TOP_AUTO : (uint32_t)value;

@@ -85,6 +85,7 @@ struct lh_accel {
     uint64_t device_bytes;
     double upload_seconds;
     int grid_blocks;
+    int grid_user;                     /* the persistent grid was set by the caller (set_param "grid", LH_GRID_BLOCKS): launches do not resize it */
     int min_active;
     uint32_t ray_chunk;                /* rays reserved per cursor atomic (LH_RAY_CHUNK) */
     int tri_batch;

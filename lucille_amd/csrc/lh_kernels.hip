@@ -46,6 +46,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 #include <pthread.h>
 
 #include "../../include/lucille_hip.h"
@@ -418,7 +419,23 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_direct(
 struct AoSrc {
     const double *hitrec; const unsigned long long *slot_key; unsigned int *occ_count;
     unsigned long long seed; int ntheta, nphi;
+    uint32_t nslots; int group;           /* group: 64 = items ordered (64 slots) x (sample) x (slot in group), 0 = (slot) x (sample) */
 };
+
+/* Work item i of a fused AO stage -> (hit slot, sample).  The plain order -- a slot's N samples side by side -- puts the N
+ * directions of ONE hemisphere into the lanes of a wave: one origin, sixty-four directions, and one address for their
+ * sixty-four occlusion atomics.  The grouped order (round 4) takes the slots 64 at a time and runs the SAME sample index of
+ * the group's 64 slots side by side: neighbouring pixels' hits, the same stratum of the hemisphere (calculate_occlusion's
+ * (i, j), ambientocclusion.c:65-117) -- nearby origins, nearly parallel directions, the same nodes and leaves; the atomics of
+ * a wave go to 64 different counters.  The rays are the same rays (keyed by absolute pixel and sample), so is the frame. */
+__device__ __forceinline__ void ao_item(const AoSrc &ao, uint32_t i, uint32_t &slot, uint32_t &r)
+{
+    const uint32_t N = (uint32_t)(ao.ntheta * ao.nphi);
+    if (ao.group == 0) { slot = i / N; r = i - slot * N; return; }
+    const uint32_t G = (uint32_t)ao.group, per = G * N, blk = i / per, q = i - blk * per;
+    const uint32_t left = ao.nslots - blk * G, m = left < G ? left : G;      /* the last group may be short */
+    r = q / m; slot = blk * G + (q - r * m);
+}
 
 /* ray `i` of the launch.  SRC 0: from the arrays; 1: the AO ray (slot i / N, sample i % N) regenerated from the hit record
  * (selfp: the triangle it starts on, when that cannot occlude it); 2: the camera ray of path i of a path-traced pass */
@@ -430,10 +447,10 @@ __device__ __forceinline__ void src_ray(const lh_dev_scene_t &sc, uint32_t i, co
         ox = org[3 * (size_t)i]; oy = org[3 * (size_t)i + 1]; oz = org[3 * (size_t)i + 2];
         dx = dir[3 * (size_t)i]; dy = dir[3 * (size_t)i + 1]; dz = dir[3 * (size_t)i + 2];
     } else if (SRC == 1) {
-        const uint32_t N = (uint32_t)(ao.ntheta * ao.nphi), slot = i / N;
+        uint32_t slot, r;
+        ao_item(ao, i, slot, r);
         const unsigned long long key = ao.slot_key[slot];
-        lh_ao_ray_builtin(ao.hitrec + LH_HITREC_DOUBLES * (size_t)slot, key, ao.seed, ao.ntheta, ao.nphi,
-                          (int)(i - slot * N), ox, oy, oz, dx, dy, dz);
+        lh_ao_ray_builtin(ao.hitrec + LH_HITREC_DOUBLES * (size_t)slot, key, ao.seed, ao.ntheta, ao.nphi, (int)r, ox, oy, oz, dx, dy, dz);
         selfp = lh_slot_selfprim(key);            /* LH_SLOT_NOSELF matches no primitive id (ids < 2^29) */
     } else {
         double o[3], d[3];
@@ -493,7 +510,7 @@ __device__ __forceinline__ void trace_persist_lane(
             bool queued = false;
             if (__builtin_expect(L.over | fragile, 0)) queued = fixq_push(fq, my, L.over ? LH_Q_COOP : LH_Q_REF);
             if (SRC != 1) { if (__builtin_expect(!queued, 1)) write_out<ANYHIT>(my, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL); }
-            else if (!L.over && !fragile && (L.certain || best.prim != LH_MISS_PRIM)) atomicAdd(&ao.occ_count[my / (uint32_t)(ao.ntheta * ao.nphi)], 1u);
+            else if (!L.over && !fragile && (L.certain || best.prim != LH_MISS_PRIM)) { uint32_t sl, rr; ao_item(ao, my, sl, rr); atomicAdd(&ao.occ_count[sl], 1u); }
             if (COUNT) {
                 cr++;
                 /* rays by node visits: every ray of 64 visits or more, one in 256 of the shorter ones (weighted 256: the
@@ -726,7 +743,7 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
                 }
                 if (SRC == 1 && (lane & 15) == 0) {
                     if (need_ref) hit = ref_trace_one(sc, ox, oy, oz, dx, dy, dz).prim != LH_MISS_PRIM;
-                    if (hit) atomicAdd(&ao.occ_count[(uint32_t)i / (uint32_t)(ao.ntheta * ao.nphi)], 1u);
+                    if (hit) { uint32_t sl, rr; ao_item(ao, (uint32_t)i, sl, rr); atomicAdd(&ao.occ_count[sl], 1u); }
                 }
                 if (counters && (lane & 15) == 0) atomicAdd(&counters[LH_CNT_RETRACED], 1ull);
                 have = false;
@@ -750,7 +767,7 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
                     if ((lane & 15) == 0) {
                         const RefHit rh = ref_trace_one(sc, ox, oy, oz, dx, dy, dz);
                         if (counters) atomicAdd(&counters[LH_CNT_RETRACED], 1ull);
-                        if (SRC == 1) { if (rh.prim != LH_MISS_PRIM) atomicAdd(&ao.occ_count[(uint32_t)i / (uint32_t)(ao.ntheta * ao.nphi)], 1u); }
+                        if (SRC == 1) { if (rh.prim != LH_MISS_PRIM) { uint32_t sl, rr; ao_item(ao, (uint32_t)i, sl, rr); atomicAdd(&ao.occ_count[sl], 1u); } }
                         else if (ANYHIT) occ[i] = rh.prim != LH_MISS_PRIM ? 1 : 0;
                         else { prim[i] = rh.prim; t[i] = rh.t; u[i] = rh.u; v[i] = rh.v; }
                     }
@@ -1150,7 +1167,7 @@ extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int n
     const size_t lds_bytes = (size_t)scl.stack_rows * LH_BLOCK * sizeof(int) + (size_t)scl.top_nodes * 64u;
     if (scl.ray_chunk < LH_TILE_CHUNK) scl.ray_chunk = LH_TILE_CHUNK;      /* AO rays of a slot are coherent: longer ranges per wave */
     clamp_chunk(scl, n, grid_blocks);
-    AoSrc ao = {d_hitrec, d_slot_key, d_occ_count, seed, ntheta, nphi};
+    AoSrc ao = {d_hitrec, d_slot_key, d_occ_count, seed, ntheta, nphi, (uint32_t)nslots, (int)sc->ao_group};
     FixQ fq = {(unsigned long long *)q->queue, q->qcount, q->qcap, (uint32_t)grid_blocks * (LH_BLOCK / 64), q->qcount + 4};
     if (hipMemsetAsync(d_cursor, 0, sizeof(uint32_t) * LH_CURSOR_WORDS, s) != hipSuccess) return -1;
     if (hipMemsetAsync(d_occ_count, 0, sizeof(unsigned int) * nslots, s) != hipSuccess) return -1;
@@ -1206,7 +1223,8 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
     lh_dev_scene_t scl = *sc;
     uint32_t need; int walk; bool guard = false;
     if ((sc->cam_src || sc->n_dev) && (variant == LH_VARIANT_DIRECT || anyhit || q == NULL)) return -1;      /* the path tracer's chain: default walk, closest hit */
-    if ((n <= LH_SMALL_BATCH || sc->diag_out) && variant != LH_VARIANT_DIRECT && !sc->cam_src && !sc->n_dev && !sc->stack_cap && sc->q4nodes) {
+    static const bool small_ok = !(getenv("LH_SMALL_BATCH") && atoi(getenv("LH_SMALL_BATCH")) == 0);      /* LH_SMALL_BATCH=0: rounds 1-3's path for a handful of rays (A/B) */
+    if (((n <= LH_SMALL_BATCH && small_ok) || sc->diag_out) && variant != LH_VARIANT_DIRECT && !sc->cam_src && !sc->n_dev && !sc->stack_cap && sc->q4nodes) {
         /* a handful of rays (the coalesced one-ray callers): one small launch, a wave per ray, no queue, no cursors.
          * Per-ray diagnostics (diag_out): the same walk for a batch of any size, a lane per ray */
         if (n <= LH_SMALL_BATCH) {
