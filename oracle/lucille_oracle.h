@@ -150,6 +150,14 @@ uint64_t lo_render_pt(const lo_scene_t *scene, const lo_camera_t *cam, int x0, i
                       const float env_rgb[3], const float *env_map, int env_w, int env_h, int ref_weights, uint64_t seed,
                       float *rgb, uint16_t *path_rays, uint64_t *max_rays_on_a_path);
 
+/* src/transport/pathtrace.c AS WRITTEN (lucille_oracle_ptref.c: restated from the reference's text alone, its own MT19937 in
+ * the text's call order, the connect step, BRDF values without cosine / pdf, no roulette compensation): the tile (x0, y0, w, h)
+ * of the frame, nsamples paths per pixel, rgb[h][w][3] floats top row first.  Transport parity-UNPINNED (the file is dead code);
+ * exists so that the product's departures from the text are numbers in tests/test_oracle_ptref.py.  Returns the rays traced. */
+uint64_t lo_render_ptref(const lo_scene_t *scene, const lo_camera_t *cam, int x0, int y0, int w, int h, int nsamples,
+                         int max_vertices, const uint32_t *prim_mesh, const float *materials10, const float *override10,
+                         const float env_rgb[3], const float *env_map, int env_w, int env_h, unsigned long mt_seed, float *rgb);
+
 /* beam (frustum) visibility: ri_beam_set + ri_bvh_intersect_beam_visibility
  * (lucille_oracle_beam.c).  dirs_xyz: n x 4 corner directions.  result: 0 miss, 1 hit
  * completely, 2 hit partially (beam.h:27-29), -1 where ri_beam_set returns -1 */

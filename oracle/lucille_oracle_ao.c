@@ -75,6 +75,11 @@ static double mt_next(lo_mt_t *m)
 }
 
 /* exported for tests: the first n numbers of thread 0's stream */
+/* randomMT / seedMT (random.c:80-90,116-153: the same generator as randomMT2 with one global state) for the other oracle files */
+void *lo_priv_mt_new(unsigned long seed) { lo_mt_t *m = (lo_mt_t *)malloc(sizeof(*m)); if (m) { mt_seed(m, seed); m->mti = MT_N; } return m; }
+double lo_priv_mt_next(void *m) { return mt_next((lo_mt_t *)m); }
+void lo_priv_mt_free(void *m) { free(m); }
+
 void lo_mt_stream(unsigned long seed, size_t n, double *out)
 {
     lo_mt_t m; size_t i;

@@ -224,6 +224,26 @@ class Oracle:
                                    rgb.ctypes.data_as(fp), per.ctypes.data_as(C.POINTER(C.c_uint16)), C.byref(longest))
         return rgb, {"paths": w * h * spp, "rays": int(rays), "max_depth_reached": int(longest.value)}, per
 
+    def render_ptref(self, cam, x0, y0, w, h, nsamples, max_vertices=0, materials=None, override=None, env_rgb=(1.0, 1.0, 1.0),
+                     env_map=None, mt_seed=4357):
+        """lo_render_ptref (lucille_oracle_ptref.c): src/transport/pathtrace.c AS WRITTEN -> (rgb [h, w, 3] float32, rays traced)"""
+        fp = C.POINTER(C.c_float)
+        rgb = np.zeros((h, w, 3), np.float32)
+        _, g, _ = self.triangles()
+        g = _c(g, np.uint32)
+        mats = None if materials is None else _c(materials, np.float32).reshape(-1, 10)
+        ov = None if override is None else _c(override, np.float32).reshape(10)
+        assert (mats is None) != (ov is None)
+        env = _c(env_rgb, np.float32).reshape(3)
+        em = None if env_map is None else _c(env_map, np.float32)
+        self.L.lo_render_ptref.restype = C.c_uint64
+        self.L.lo_render_ptref.argtypes = [C.c_void_p, C.POINTER(Camera)] + [C.c_int] * 6 + [_u32p, fp, fp, fp, fp, C.c_int, C.c_int, C.c_ulong, fp]
+        rays = self.L.lo_render_ptref(self.h, C.byref(cam), x0, y0, w, h, int(nsamples), int(max_vertices), _p(g, _u32p),
+                                      None if mats is None else mats.ctypes.data_as(fp), None if ov is None else ov.ctypes.data_as(fp),
+                                      env.ctypes.data_as(fp), None if em is None else em.ctypes.data_as(fp),
+                                      0 if em is None else em.shape[1], 0 if em is None else em.shape[0], int(mt_seed), rgb.ctypes.data_as(fp))
+        return rgb, int(rays)
+
     @property
     def ntriangles(self):
         return int(self.L.lo_scene_ntriangles(self.h))
