@@ -844,7 +844,7 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
     pt_tile = size if world == 1 else max(128, size // 4)
     # paths per pass (decided once: the first frame's buffers stay allocated): as many as 70 % of the free HBM holds (176 B of
     # path state each; a 2048^2 x 256 spp frame is 2^30 paths = 189 GB of the 288): every pass costs one kernel ramp + drain per
-    # bounce, so fewer, larger wavefronts are faster (tools/pt_frames.py: 166.3 / 154.7 / 148.6 ms per frame as 4 / 2 / 1 passes;
+    # bounce, so fewer, larger wavefronts are faster (tools/experiments/pt_frames.py: 166.3 / 154.7 / 148.6 ms per frame as 4 / 2 / 1 passes;
     # the image does not change by a bit)
     torch.cuda.empty_cache()
     free_b = torch.cuda.mem_get_info(dev)[0]

@@ -338,6 +338,9 @@ int  lh_dist_rank(const lh_dist_t *dist);
 int  lh_dist_world(const lh_dist_t *dist);
 int  lh_dist_transport(const lh_dist_t *dist);
 int  lh_dist_barrier(lh_dist_t *dist);
+/* the ranks of ONE node meet in shared memory (microseconds; host only -- synchronise the device first): what brackets a timed
+ * frame.  lh_dist_barrier goes through the transport (RCCL: a one-byte gather and broadcast) and works across nodes. */
+int  lh_dist_host_barrier(lh_dist_t *dist);
 /* device buffers; stream NULL: the communicator's own.  gather: d_recv (rank 0 only) holds world * bytes */
 int  lh_dist_broadcast(lh_dist_t *dist, void *d_buf, size_t bytes, void *stream);
 int  lh_dist_gather(lh_dist_t *dist, const void *d_send, size_t bytes, void *d_recv, void *stream);

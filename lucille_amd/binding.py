@@ -114,7 +114,7 @@ ABI_SYMBOLS = [
     "lh_multi_render_ao_frame_host", "lh_multi_render_pt_frame_host",
     "lh_synth_soup_triangles", "lh_synth_soup_rays", "lh_synth_tessellate", "lh_synth_skip",
     "lh_dist_unique_id", "lh_dist_init", "lh_dist_init_file", "lh_dist_destroy", "lh_dist_rank", "lh_dist_world", "lh_dist_transport",
-    "lh_dist_barrier", "lh_dist_broadcast", "lh_dist_gather", "lh_dist_broadcast_scene", "lh_dist_render_ao_frame_host",
+    "lh_dist_barrier", "lh_dist_host_barrier", "lh_dist_broadcast", "lh_dist_gather", "lh_dist_broadcast_scene", "lh_dist_render_ao_frame_host",
 ]
 
 _lib = None
@@ -729,6 +729,11 @@ class HipDist:
     def barrier(self):
         self.L.lh_dist_barrier.argtypes = [C.c_void_p]
         _check(self.L.lh_dist_barrier(self.h), "lh_dist_barrier")
+
+    def host_barrier(self):
+        """the ranks of one node meet in shared memory (microseconds): the barrier around a timed frame"""
+        self.L.lh_dist_host_barrier.argtypes = [C.c_void_p]
+        _check(self.L.lh_dist_host_barrier(self.h), "lh_dist_host_barrier")
 
     @staticmethod
     def _stream_of(tensor, stream):

@@ -876,7 +876,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     const unsigned nb = (n + 255) / 256;
     uint32_t h_scene[6], level = 0, nwork = 0, nq = 1;
     const uint32_t init_scene[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    int h_bad = 0, leaf_max = LH_MAX_LEAF_TRIS;     /* leaves of up to 4 triangles WHERE THE SAH SAYS SO (k_node_boxes): forced 4-triangle leaves cost S-soup-1M 37 % (tools/leaf_probe.py), the SAH keeps that soup at one per leaf */
+    int h_bad = 0, leaf_max = LH_MAX_LEAF_TRIS;     /* leaves of up to 4 triangles WHERE THE SAH SAYS SO (k_node_boxes): forced 4-triangle leaves cost S-soup-1M 37 % (tools/experiments/leaf_probe.py), the SAH keeps that soup at one per leaf */
     { const char *e = getenv("LH_DEVICE_LEAF"); if (e && atoi(e) >= 1 && atoi(e) <= LH_MAX_LEAF_TRIS) leaf_max = atoi(e); }
     uint32_t cut = 512;                             /* primitives per subtree below the SAH-built top (LH_DEVICE_CUT; 0: plain radix tree).  config 5, frame /
                                                        tree time: 64 -> 86.9 ms / 0.125 s, 128 -> 87.3 / 0.058, 512 -> 87.6 / 0.029, 2048 -> 87.8 / 0.023; 256 makes

@@ -862,7 +862,7 @@ int lh_bvh_build_hook(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmes
 
     if (after_flatten) after_flatten(hook_arg);
 
-    b.ci = 1.0f; b.ct = 1.3f;          /* a triangle step against a node step (tools/host_sah_probe.py, r03: S-soup-1M 2110 -> 2132 Mrays/s with 4.6 instead of
+    b.ci = 1.0f; b.ct = 1.3f;          /* a triangle step against a node step (tools/experiments/host_sah_probe.py, r03: S-soup-1M 2110 -> 2132 Mrays/s with 4.6 instead of
                                           5.1 triangle tests per ray; config 5 unchanged) */
     if ((env = getenv("LH_BVH_CI")) != NULL) b.ci = (float)atof(env);
     if ((env = getenv("LH_BVH_CT")) != NULL) b.ct = (float)atof(env);

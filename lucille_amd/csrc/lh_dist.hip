@@ -98,8 +98,12 @@ static int shm_barrier(lh_dist_t *d)
         __atomic_store_n(&c->generation, gen + 1u, __ATOMIC_RELEASE);
         return 0;
     }
+    /* the others are microseconds away when the ranks run in step (the two barriers around a frame): watch the word for a while
+     * before sleeping in 50 us slices -- a sleeping waiter leaves the barrier up to a slice late, and that spread is time a
+     * sharded frame pays (tools/skew_probe.py) */
     const double t0 = now_sec();
-    while (__atomic_load_n(&c->generation, __ATOMIC_ACQUIRE) == gen) {
+    for (int spins = 0; __atomic_load_n(&c->generation, __ATOMIC_ACQUIRE) == gen; spins++) {
+        if (spins < 20000) { __builtin_ia32_pause(); continue; }
         usleep(50);
         if (now_sec() - t0 > 120.0) return DFAIL("lh_dist (shm): a rank did not reach the barrier within 120 s");
     }
@@ -171,7 +175,9 @@ extern "C" int lh_dist_init(lh_dist_t **out, const void *id128, int rank, int wo
         ncclUniqueId id; memcpy(&id, id128, LH_DIST_ID_BYTES);
         ncclResult_t r = g_rccl.CommInitRank(&d->comm, world, id, rank);
         if (r != ncclSuccess) { (void)hipStreamDestroy(d->stream); free(d); return DFAIL("ncclCommInitRank failed: %s (two ranks on one device? use LH_DIST_SHM)", g_rccl.GetErrorString(r)); }
-    } else {
+    }
+    {   /* the job's control block in shared memory: the shm transport's barrier -- and, for BOTH transports, the host barrier of
+         * the ranks of one node (lh_dist_host_barrier: what brackets a timed frame) */
         name_from_id(id128, d->shm_name, sizeof(d->shm_name));
         int fd = shm_open(d->shm_name, O_CREAT | O_RDWR, 0600);       /* a fresh segment reads as zeros */
         if (fd < 0 || ftruncate(fd, 4096) != 0) { if (fd >= 0) close(fd); (void)hipStreamDestroy(d->stream); free(d); return DFAIL("lh_dist (shm): cannot create %s: %s", d->shm_name, strerror(errno)); }
@@ -300,6 +306,16 @@ extern "C" int lh_dist_gather(lh_dist_t *d, const void *d_send, size_t bytes, vo
     if (shm_barrier(d) != 0) return -1;
     if (d->rank == 0) { HIPCHK(hipMemcpyAsync(d_recv, seg, bytes * (size_t)d->world, hipMemcpyHostToDevice, s)); HIPCHK(hipStreamSynchronize(s)); }
     return shm_release(d, seg, bytes * (size_t)d->world);
+}
+
+/* the ranks of ONE node (the contract of bench.py --gpus N and of lsh_hip --world N) meet in shared memory: microseconds, where a
+ * gloo barrier between eight processes costs 1.3 ms and lets them out up to 0.4 ms apart (tools/skew_probe.py) -- a tenth of a
+ * rank's 12 ms share of the config-5 frame.  Host only: the caller synchronises its device first. */
+extern "C" int lh_dist_host_barrier(lh_dist_t *d)
+{
+    if (!d) return DFAIL("lh_dist_host_barrier: NULL");
+    if (!d->ctl) return DFAIL("lh_dist_host_barrier: no shared control block");
+    return shm_barrier(d);
 }
 
 extern "C" int lh_dist_barrier(lh_dist_t *d)

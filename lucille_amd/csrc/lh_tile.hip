@@ -64,7 +64,7 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
     /* lh_accel_trace_statistics: the counting instantiations of the same kernels, accumulated over the batch */
     unsigned long long *cnt = (a->stat_on && a->hs->bvh.ntris) ? a->d_counters : NULL;
     if (cnt) HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * LH_CNT_DEV, s));
-    /* LH_STAGE_TIMING=1: HIP events between the stages of the batch, printed to stderr (tools/rank_breakdown.py) */
+    /* LH_STAGE_TIMING=1: HIP events between the stages of the batch, printed to stderr (tools/experiments/rank_breakdown.py) */
     const bool stage_timing = getenv("LH_STAGE_TIMING") != NULL;
     hipEvent_t ev[6] = {NULL, NULL, NULL, NULL, NULL, NULL};
     if (stage_timing) { for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&ev[k])); HIPCHK(hipEventRecord(ev[0], s)); }

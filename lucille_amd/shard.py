@@ -140,6 +140,12 @@ def commit_shared(acc, add_meshes, rank, world, **commit_kw):
 
 
 def barrier():
+    """all ranks meet.  With a communicator: in shared memory (lh_dist_host_barrier: the ranks of one node, microseconds -- a gloo
+    barrier between eight processes costs ~1.3 ms and releases them up to ~0.4 ms apart, tools/skew_probe.py: a tenth of a rank's
+    share of a sharded frame); LH_SHARD_BARRIER=gloo or no communicator (the CPU tests): torch.distributed's."""
+    if _DIST is not None and os.environ.get("LH_SHARD_BARRIER") != "gloo":
+        _DIST.host_barrier()
+        return
     import torch.distributed as tdist
     if tdist.is_available() and tdist.is_initialized():
         tdist.barrier()

@@ -1,6 +1,6 @@
 """bench.py's AO leg alone: python tools/ao_leg_probe.py"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import lucille_amd as la
 import bench

@@ -1,6 +1,6 @@
 """AO leg alone (for rocprofv3 --kernel-trace --stats): python tools/ao_probe.py [size] [samples] [tess]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import lucille_amd as la
 import bench

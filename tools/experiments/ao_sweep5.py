@@ -1,6 +1,6 @@
 """config-5 AO frame against the kernel's regroup / triangle-batch / range thresholds (one scene build): python tools/ao_sweep5.py"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lucille_amd as la

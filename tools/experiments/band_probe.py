@@ -1,7 +1,7 @@
 """config 5 frame as one batch, then as full-width bands of `rows` rows (for rocprofv3 --kernel-trace):
 python tools/band_probe.py [rows ...]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lucille_amd as la

@@ -1,6 +1,6 @@
 """host vs device build of the traversal tree, and what the device-built tree costs in traversal: python tools/build_probe.py [--soups-only]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lucille_amd as la

@@ -1,11 +1,11 @@
 """BASELINE config 5 probe: example scene tessellated 4^n, big AO frame on 1 GPU."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import lucille_amd as la
 from lucille_amd import render, scenes
 tess = int(sys.argv[1]); size = int(sys.argv[2]); ns = int(sys.argv[3]); tile = int(sys.argv[4])
-g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ao_c1.npz"))
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "ao_c1.npz"))
 t0 = time.time()
 acc = la.HipAccel(0); ntri = 0
 for k in range(int(g["ngeoms"])):

@@ -1,12 +1,12 @@
 """config-5 frame on the device-built tree: python tools/devtree_frame.py [tess] [size]   (env LH_DEVICE_CUT, LH_DEVICE_LEAF, LH_BUILD_TIMING)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import lucille_amd as la
 from lucille_amd import render, scenes
 tess = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ao_c1.npz"))
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "ao_c1.npz"))
 c = g["camera"]; cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
 keep = None
 if os.environ.get("WITH_HOST_ACCEL"):                  # bench.py's situation: the host-built accelerator of the same scene stays alive

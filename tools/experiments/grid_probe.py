@@ -1,6 +1,6 @@
 """S-soup-1M closest-hit dump on both builders' trees at several persistent-grid sizes: python tools/grid_probe.py [nrays]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import lucille_amd as la
 from lucille_amd import scenes

@@ -1,6 +1,6 @@
 """host-array path (lh_accel_intersect_host) throughput with caller-owned, already-touched buffers"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import lucille_amd as la
 from oracle import pyoracle as po

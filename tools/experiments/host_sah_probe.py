@@ -1,7 +1,7 @@
 """the host builder's SAH constants (LH_BVH_CT: a triangle test against a node step, LH_BVH_CI) on the soup and on config 5:
 python tools/host_sah_probe.py"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import lucille_amd as la
 from lucille_amd import scenes, render
@@ -9,7 +9,7 @@ n = 50_000_000
 P, idx, st = scenes.soup_triangles(1000000, 0.005)
 ho, hd, _ = scenes.soup_rays(n, st)
 o = torch.from_numpy(ho).cuda(); d = torch.from_numpy(hd).cuda(); del ho, hd
-g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ao_c1.npz"))
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "ao_c1.npz"))
 meshes = [scenes.tessellate(g["pos%d" % k], g["idx%d" % k], 8) for k in range(int(g["ngeoms"]))]
 c = g["camera"]; cam = la.Camera.make(4096, 4096, c[16], c[:16], int(c[19]))
 for ct in sys.argv[1:] or ["1.0", "1.2", "1.5", "2.0"]:

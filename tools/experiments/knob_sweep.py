@@ -1,7 +1,7 @@
 """S-soup-1M closest-hit dump: one knob at a time around the defaults (set_param), 3 timed launches each, best of 3.
 python tools/knob_sweep.py [nrays]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import lucille_amd as la
 from lucille_amd import scenes

@@ -1,6 +1,6 @@
 """tri_batch x min_active around the defaults: S-soup-1M closest-hit dump, then the config-5 AO frame (python tools/knob_sweep2.py)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import lucille_amd as la
 from lucille_amd import scenes, render
@@ -20,7 +20,7 @@ for tb in (8, 10, 12, 14):
         acc.set_param("tri_batch", tb); acc.set_param("min_active", ma)
         print("soup tri_batch %2d min_active %2d  %.1f Mrays/s" % (tb, ma, t()), flush=True)
 acc.close(); del o, d, out
-g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ao_c1.npz"))
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "ao_c1.npz"))
 acc = la.HipAccel(0)
 for k in range(int(g["ngeoms"])):
     Pk, Ik = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], 8); acc.add_mesh(Pk, Ik)

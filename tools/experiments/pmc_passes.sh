@@ -5,11 +5,11 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  timeout 120 rocprofv3 --pmc $line --output-format csv -d $OUT/p$i -- python $R/tools/prof_run.py 20000000 > $OUT/p$i.log 2>&1
+  timeout 120 rocprofv3 --pmc $line --output-format csv -d $OUT/p$i -- python $R/tools/experiments/prof_run.py 20000000 > $OUT/p$i.log 2>&1
 done <<'PASSES'
 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM
 SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA
 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
 PASSES
 cd $R
-python $R/tools/pmc_summarize.py $OUT
+python $R/tools/experiments/pmc_summarize.py $OUT

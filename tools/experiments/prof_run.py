@@ -1,6 +1,6 @@
 """One small traced workload for PMC passes: S-soup-1M, N rays, variant 2 closest + any."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import lucille_amd as la
 from oracle import pyoracle as po

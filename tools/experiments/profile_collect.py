@@ -1,7 +1,7 @@
 """Copy the summaries of gpurun_out/<tag>/ (tools/profile_round.sh) into profiles/ and refresh
 profiles/pmc_latest.json.  python tools/profile_collect.py <tag> <round-name>"""
 import csv, glob, json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tag, rnd = sys.argv[1], sys.argv[2]
 src = os.path.join(ROOT, "gpurun_out", tag)
 ks = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]

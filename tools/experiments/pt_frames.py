@@ -2,7 +2,7 @@
 (for rocprofv3 --kernel-trace --stats: every kernel total / frames = its share of one frame; the first frame is warm-up
 but counted by the profiler, so use frames >= 4 and the printed wall time of the later ones)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import lucille_amd as la
 from lucille_amd import render
@@ -10,7 +10,7 @@ size = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 frames = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ao_ps.npz"))
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "ao_ps.npz"))
 acc = la.HipAccel(0)
 for k in range(int(g["ngeoms"])):
     acc.add_mesh(g["pos%d" % k], g["idx%d" % k])

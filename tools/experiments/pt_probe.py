@@ -1,6 +1,6 @@
 """PT leg alone (for rocprofv3 --kernel-trace --stats): python tools/pt_probe.py [size] [spp]"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import lucille_amd as la
 import bench

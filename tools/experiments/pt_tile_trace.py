@@ -1,12 +1,12 @@
 """one path-traced tile, three times (for a rocprofv3 --kernel-trace timeline): python tools/pt_tile_trace.py x0 y0 w h [spp] [size]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import lucille_amd as la
 x0, y0, w, h = [int(v) for v in sys.argv[1:5]]
 spp = int(sys.argv[5]) if len(sys.argv) > 5 else 256
 size = int(sys.argv[6]) if len(sys.argv) > 6 else 2048
-g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ao_ps.npz"))
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "ao_ps.npz"))
 acc = la.HipAccel(0)
 for k in range(int(g["ngeoms"])):
     acc.add_mesh(g["pos%d" % k], g["idx%d" % k])

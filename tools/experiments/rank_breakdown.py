@@ -3,7 +3,7 @@ of the whole frame and of every rank's batch at world = 8 under three shard layo
 contiguous strips, interleaved 64-line bands -- plus the histogram of node visits per AO ray (COUNT build) of the whole frame.
   LH_STAGE_TIMING=1 python tools/rank_breakdown.py [size] [tess] [samples] 2> gpurun_out/rank_breakdown.log"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lucille_amd as la

@@ -2,7 +2,7 @@
 rocprofv3 --kernel-trace --stats / --pmc when looking at what a rank's batch costs per kernel.
   python tools/rank_one.py [world] [rank] [band_rows] [repeats] [size] [tess] [samples]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lucille_amd as la

@@ -1,12 +1,12 @@
 """commit of the config-5 scene with both trees on the device, phase by phase: python tools/refbuild_timing.py [tess]   (LH_REF_BUILD=host for the round-2 path)"""
 import os, sys, time
 os.environ["LH_BUILD_TIMING"] = "1"
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import lucille_amd as la
 from lucille_amd import scenes
 tess = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ao_c1.npz"))
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "ao_c1.npz"))
 meshes = [scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess) for k in range(int(g["ngeoms"]))]
 for it in range(3):
     acc = la.HipAccel(0)

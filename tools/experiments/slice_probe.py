@@ -1,7 +1,7 @@
 """does the traversal kernel lose efficiency on smaller launches?  config 5 scene, the frame's 16.8 M camera rays and
 the any-hit version of the same rays, traced in 1 / 4 / 16 / 64 / 256 slices (no host sync in between)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lucille_amd as la

@@ -1,6 +1,6 @@
 """lane-slot diagnostics of the COUNT build: python tools/slots_probe.py [nrays]  (LH_MIN_ACTIVE / LH_TRI_BATCH sweepable)"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["LH_DEBUG_COUNTERS"] = "1"
 import numpy as np, torch
 import lucille_amd as la

@@ -1,7 +1,7 @@
 """would sorting an incoherent ray dump pay?  S-soup-1M, n rays: trace time in dump order against the same rays ordered by
 (origin cell Morton code, direction octant) with torch: python tools/sort_probe.py [nrays] [bits]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import lucille_amd as la
 from lucille_amd import scenes

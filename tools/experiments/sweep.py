@@ -1,7 +1,7 @@
 """Within-process A/B sweeps of the trace kernel on S-soup (interleaved rounds).
 python tools/sweep.py <what> [nrays]     what in: grid, minact, bvh, sort """
 import sys, os, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import lucille_amd as la
 from oracle import pyoracle as po

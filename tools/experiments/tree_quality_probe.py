@@ -1,7 +1,7 @@
 """host-built vs device-built traversal tree on the BASELINE config-5 scene: commit time, frame time, node visits / triangle
 tests per ray (COUNT build).  python tools/tree_quality_probe.py [size] [tess] [samples]   (LH_DEVICE_* env knobs apply)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import lucille_amd as la
