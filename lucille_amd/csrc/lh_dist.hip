@@ -103,9 +103,11 @@ static int shm_barrier(lh_dist_t *d)
      * sharded frame pays (tools/skew_probe.py) */
     const double t0 = now_sec();
     for (int spins = 0; __atomic_load_n(&c->generation, __ATOMIC_ACQUIRE) == gen; spins++) {
-        if (spins < 20000) { __builtin_ia32_pause(); continue; }
-        usleep(50);
-        if (now_sec() - t0 > 120.0) return DFAIL("lh_dist (shm): a rank did not reach the barrier within 120 s");
+        if ((spins & 255) != 255) { __builtin_ia32_pause(); continue; }
+        const double dt = now_sec() - t0;
+        if (dt < 3.0e-3) continue;                    /* 3 ms of watching: ranks that render shares of one frame arrive within that */
+        usleep(20);
+        if (dt > 120.0) return DFAIL("lh_dist (shm): a rank did not reach the barrier within 120 s");
     }
     return 0;
 }

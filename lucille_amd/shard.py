@@ -80,6 +80,8 @@ def init_process_group(backend=None, device=None):
         tdist.all_gather_object(devs, dev)
         shared = len(set(devs)) < world                       # one node: equal ordinals = one GPU (tests on a one-GPU box)
         transport = binding.DIST_SHM if shared or os.environ.get("LH_DIST_TRANSPORT") == "shm" else binding.DIST_RCCL
+        if shared and os.environ.get("LH_DIST_TRANSPORT") == "rccl" and os.environ.get("LH_RCCL_LIBRARY"):
+            transport = binding.DIST_RCCL      # a stand-in library that accepts ranks on one device (tests/mock_rccl): the RCCL branch with peers on a one-GPU box
         _RCCL_STATUS = "ok" if transport == binding.DIST_RCCL else ("shm: ranks share a device" if shared else "shm: asked for (LH_DIST_TRANSPORT)")
         torch.cuda.set_device(dev)
         if transport == binding.DIST_RCCL:

@@ -115,3 +115,21 @@ def test_bench_n2_code_path_on_one_gpu():
     assert all(r_["kernel_ms_per_step"] > 0 and r_["gather_only_ms"] >= 0 for r_ in j["ranks"])
     assert [r_["rank"] for r_ in j["ao_render"]["ranks"]] == [0, 1] and all(r_["bands"] > 0 and r_["batch_ms"] > 0 for r_ in j["ao_render"]["ranks"])
     assert "[bench rank 1]" in r.stderr
+
+
+def test_bench_n2_over_the_rccl_branch_with_a_mock_library():
+    """the same launch with LH_DIST_TRANSPORT=rccl and tests/mock_rccl as the library: bench.py's own N = 2 path -- the id from
+    rank 0 through gloo, ncclCommInitRank on every rank, the scene through ncclBroadcast, the record and band-slab gathers through
+    grouped ncclSend / ncclRecv -- with a real peer, on the one-GPU box; the line says transport rccl and validates"""
+    from tests.test_gpu_dist_mock import build_mock
+    env = dict(os.environ, LH_DIST_TRANSPORT="rccl", LH_RCCL_LIBRARY=build_mock(), MOCK_RCCL_TIMEOUT="120")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--device-override", "0", "--rays", "2000001", "--tris", "100000", "--half-extent", "0.01",
+           "--no-cpu", "--no-hbm", "--no-pt", "--ao-size", "192", "--ao-tess", "2", "--ao-samples", "16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l][-1])
+    assert j["n_gpus"] == 2 and j["validation"]["ok"] and j["validation"]["gathered_records_ok"]
+    assert j["config"]["scene_load"]["transport"] == "rccl" and all(r_["transport"] == "rccl" and r_["rccl_status"] == "ok" for r_ in j["ranks"])
+    assert j["exchange"]["transport_ok"] and j["ao_render"]["validation"]["ok"] and all(r_["transport"] == "rccl" for r_ in j["ao_render"]["ranks"])
