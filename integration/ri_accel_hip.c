@@ -23,6 +23,8 @@
 #include "log.h"
 #include "intersection_state.h"
 #include "bvh.h"                 /* ri_bvh_diag_t: what `user` points at (bvh.h:103-110) */
+#include "beam.h"
+#include "raster.h"
 
 #include "lucille_hip.h"
 
@@ -155,5 +157,25 @@ int ri_accel_bind_hip(ri_accel_t *accel)
     accel->build     = ri_hipbvh_build;
     accel->free      = ri_hipbvh_free;
     accel->intersect = ri_hipbvh_intersect;
+    return 0;
+}
+
+/* ri_bvh_intersect_beam (bvh.h:203-206, bvh.c:544-609) on the device: after the call raster_out->t holds what the reference's own
+ * path leaves there for this beam (as right after ri_bvh_invalidate_cache: the leaf caches of projected triangles are per beam
+ * here).  corner_dirs = the four directions ri_beam_set was GIVEN: it stores scaled copies in beam->dir and the device repeats
+ * ri_beam_set from the originals -- in lucille proper, a `ri_vector_t corner[4]` member of ri_beam_t that ri_beam_set fills
+ * (beam.c:331) makes this argument unnecessary.  Returns 0 like the reference; `user` is ignored. */
+int ri_hipbvh_intersect_beam(void *accel, ri_beam_t *beam, ri_vector_t corner_dirs[4], ri_raster_plane_t *raster_out, void *user)
+{
+    ri_hipbvh_t *h = (ri_hipbvh_t *)accel;
+    lh_raster_plane_t lp; double org[3], dirs[12], corner[3]; int32_t status = 0; int i, k;
+    (void)user;
+    if (!h || h->magic != RI_HIPBVH_MAGIC || !beam || !raster_out || !raster_out->t) return 0;
+    lp.width = raster_out->width; lp.height = raster_out->height; lp.fov = raster_out->fov;
+    for (i = 0; i < 3; i++) for (k = 0; k < 3; k++) lp.frame[3 * i + k] = raster_out->frame[i][k];
+    for (k = 0; k < 3; k++) { lp.eye[k] = raster_out->org[k]; org[k] = beam->org[k]; corner[k] = raster_out->corner[k]; }
+    for (i = 0; i < 4; i++) for (k = 0; k < 3; k++) dirs[3 * i + k] = corner_dirs[i][k];
+    if (lh_accel_beam_raster_host(h->lh, 1, org, dirs, corner, &lp, raster_out->t, &status, NULL) != 0)
+        ri_log(LOG_ERROR, "(HIPBVH) %s", lh_last_error());
     return 0;
 }

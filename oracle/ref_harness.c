@@ -49,6 +49,7 @@
 
 #ifdef LREF_WITH_HIP
 extern int ri_accel_bind_hip(ri_accel_t *accel);   /* integration/ri_accel_hip.c */
+extern int ri_hipbvh_intersect_beam(void *accel, ri_beam_t *beam, ri_vector_t corner_dirs[4], ri_raster_plane_t *raster_out, void *user);
 #endif
 
 /* ---------------------------------------------------------------------- */
@@ -482,6 +483,44 @@ int lref_beam_raster(const double *org, const double *dirs, int w, int h, const 
     fclose(nul);
     return rc;
 }
+
+#ifdef LREF_WITH_HIP
+/* the scene built with the reference's CPU BVH (method 1) or through the RI_ACCEL_HIP glue (method 2) */
+int lref_scene_build_with(int method)
+{
+    ri_scene_t *scene = ri_render_get()->scene;
+    if (ri_accel_bind(scene->accel, method) != 0) return -1;
+    return ri_scene_build_accel(scene);
+}
+
+/* lref_beam_raster with the scene's accelerator bound to RI_ACCEL_HIP: the reference's own ri_beam_set and
+ * ri_raster_plane_setup, then the glue's ri_hipbvh_intersect_beam in place of ri_bvh_intersect_beam */
+int lref_beam_raster_hip(const double *org, const double *dirs, int w, int h, const double *frame9, const double *corner,
+                         const double *eye, double fov, double *t_out)
+{
+    void *accel = ri_render_get()->scene->accel->data;
+    static ri_raster_plane_t *plane = NULL;
+    ri_beam_t beam; ri_vector_t o, d[4], fr[3], cn, ey; int i, k, rc;
+    FILE *saved_err = stderr, *saved_out = stdout, *nul = fopen("/dev/null", "w");
+    memset(&beam, 0, sizeof(beam));
+    for (k = 0; k < 3; k++) { o[k] = org[k]; cn[k] = corner[k]; ey[k] = eye[k]; }
+    o[3] = cn[3] = ey[3] = 0.0;
+    for (i = 0; i < 4; i++) { for (k = 0; k < 3; k++) d[i][k] = dirs[3 * i + k]; d[i][3] = 0.0; }
+    for (i = 0; i < 3; i++) { for (k = 0; k < 3; k++) fr[i][k] = frame9[3 * i + k]; fr[i][3] = 0.0; }
+    stderr = nul; stdout = nul;
+    rc = ri_beam_set(&beam, o, d);
+    if (rc == 0) {
+        if (!plane) plane = ri_raster_plane_new();
+        ri_raster_plane_setup(plane, w, h, fr, cn, ey, fov);
+        rc = ri_hipbvh_intersect_beam(accel, &beam, d, plane, NULL);
+        memcpy(t_out, plane->t, sizeof(double) * (size_t)w * (size_t)h);
+    } else rc = -1;
+    fflush(nul);
+    stderr = saved_err; stdout = saved_out;
+    fclose(nul);
+    return rc;
+}
+#endif
 
 /* recorder control */
 void   lref_record_start(void) { g_rec_n = 0; g_rec_on = 1; }

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle as po
-from tests.helpers import load_golden
+from tests.helpers import ROOT, load_golden
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not os.path.exists(os.path.join(po.HERE, "_ref", "liblucille_ref_hip.so")),
@@ -104,3 +104,54 @@ def test_reference_renderer_batched_frame_loop(tmp_path):
     # the default mode is the batched one
     dflt = ref_rib.render_scene_subprocess(sp, str(tmp_path / "default.npz"), accel_method=2, record=False, **kw)
     assert np.array_equal(dflt["image"], img)
+
+
+_BEAM_SCRIPT = r"""
+import sys, ctypes as C
+sys.path.insert(0, %(root)r)
+import numpy as np
+from tests.helpers import raster_case
+_dp = C.POINTER(C.c_double); _u32p = C.POINTER(C.c_uint32)
+L = C.CDLL(%(lib)r)
+L.lref_scene_add_mesh.argtypes = [C.c_uint32, _dp, C.c_uint32, _u32p]
+L.lref_beam_raster.argtypes = [_dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, C.c_int, _dp]
+L.lref_beam_raster_hip.argtypes = [_dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp, C.c_double, _dp]
+L.lref_init(); L.lref_scene_reset()
+c = raster_case(seed=31, ntri=400, width=64, height=64, nbeams=10, eye=(0.1, -0.2, 0.3))
+P = np.ascontiguousarray(c["P"]); I = np.ascontiguousarray(c["idx"])
+L.lref_scene_add_mesh(P.shape[0], P.ctypes.data_as(_dp), I.shape[0], I.ctypes.data_as(_u32p))
+p = lambda a: np.ascontiguousarray(a, np.float64).ctypes.data_as(_dp)
+out = {}
+for tag, method in (("cpu", 1), ("hip", 2)):
+    assert L.lref_scene_build_with(method) == 0
+    planes = []
+    for i in range(c["org"].shape[0]):
+        t = np.zeros((c["height"], c["width"]))
+        a = [np.ascontiguousarray(x, np.float64) for x in (c["org"][i], c["dirs"][i], c["frame"], c["corners"][i], c["eye"])]
+        if method == 1:
+            rc = L.lref_beam_raster(p(a[0]), p(a[1]), c["width"], c["height"], p(a[2]), p(a[3]), p(a[4]), c["fov"], 1, t.ctypes.data_as(_dp))
+        else:
+            rc = L.lref_beam_raster_hip(p(a[0]), p(a[1]), c["width"], c["height"], p(a[2]), p(a[3]), p(a[4]), c["fov"], t.ctypes.data_as(_dp))
+        assert rc == 0
+        planes.append(t)
+    out[tag] = np.stack(planes)
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_reference_process_beam_raster_through_the_hip_glue(tmp_path):
+    """row f4 as a drop-in: in ONE process of the compiled reference, ri_beam_set + ri_raster_plane_setup are the reference's own;
+    ri_bvh_intersect_beam on its CPU BVH and ri_hipbvh_intersect_beam (integration/ri_accel_hip.c) on the accelerator bound as
+    RI_ACCEL_HIP leave the same plane->t behind, double for double"""
+    import subprocess, sys
+    lib = os.path.join(ROOT, "oracle", "_ref", "liblucille_ref_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("oracle/_ref/liblucille_ref_hip.so not built")
+    script = tmp_path / "beam.py"
+    script.write_text(_BEAM_SCRIPT % {"root": ROOT, "lib": lib})
+    out = str(tmp_path / "planes.npz")
+    r = subprocess.run([sys.executable, str(script), out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    z = np.load(out)
+    assert z["cpu"].shape == (10, 64, 64) and int((z["cpu"] != 0).sum()) > 2000
+    assert np.array_equal(z["cpu"], z["hip"])
