@@ -14,7 +14,7 @@ acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit(build="host")
 ref = [x.clone() for x in acc.intersect_device(o, d)]; torch.cuda.synchronize()
 out = acc.intersect_device(o, d); torch.cuda.synchronize()
 ncu = torch.cuda.get_device_properties(0).multi_processor_count
-for per_cu, cap in ((3, 0), (2, 0), (4, 40), (4, 36), (3, 40), (3, 0)):
+for per_cu, cap in ((3, 0), (4, 40), (4, 36), (4, 34), (4, 32), (4, 28), (5, 28), (3, 0)):
     acc.set_param("grid", ncu * per_cu); acc.set_param("stack_cap", cap); acc.set_param("top_nodes", 0)
     ts = []
     for _ in range(3):
