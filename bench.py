@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--half-extent", type=float, default=0.005)
     ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--leg-build", choices=["auto", "host", "device"], default="auto",
+                    help="builders of the roofline_hbm and ao_render legs' scenes (auto = lh_accel_commit's own choice; the other builder's tree is timed beside it at N = 1)")
+    ap.add_argument("--no-other-builder", action="store_true", help="skip the launches on the other builder's tree (profiling runs: one tree per process)")
     ap.add_argument("--build", choices=["auto", "host", "device"], default="auto",
                     help="builders of the headline leg's scene: auto = lh_accel_commit's own choice (the device builders from 1 M triangles on)")
     ap.add_argument("--mode", choices=["closest", "any"], default="closest")
@@ -293,7 +296,7 @@ def main():
     stay_elapsed = None if world == 1 else (other_elapsed if head_gather else elapsed / args.steps)
     # the same dump on the OTHER builder's tree (N = 1; secondary figure: what the choice of builder costs or gains)
     other = None
-    if world == 1 and args.build == "auto" and n > 0:
+    if world == 1 and args.build == "auto" and n > 0 and not args.no_other_builder:
         acc_o = la.HipAccel(local); acc_o.add_mesh(P, idx)
         t0o = time.perf_counter(); info_o = acc_o.commit(build="host" if device_built else "device"); commit_o = time.perf_counter() - t0o
         buf_o = torch.empty(max(n, 1) * rec_bytes, dtype=torch.uint8, device=dev)
@@ -367,7 +370,7 @@ def main():
     ao = None
     if not args.no_ao:
         ao = ao_frame_leg(la, acc_device=local, rank=rank, world=world, size=args.ao_size, nsamples=args.ao_samples,
-                          steps=max(2, args.steps), dev=dev, tess=args.ao_tess)
+                          steps=max(2, args.steps), dev=dev, tess=args.ao_tess, build=args.leg_build, twin=not args.no_other_builder)
 
     c2 = None
     if rank == 0 and world == 1 and not args.no_config2:
@@ -568,7 +571,10 @@ def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
     P, idx, st = scenes.soup_triangles(args.hbm_tris, 0.002)
     n = args.hbm_rays
     d_org, d_dir, _ = upload_rays(scenes, torch, dev, st, n)
-    acc = la.HipAccel(local); acc.add_mesh(P, idx); info = acc.commit(build="host")
+    acc = la.HipAccel(local); acc.add_mesh(P, idx)
+    t0 = time.perf_counter(); info = acc.commit(build=args.leg_build); commit1 = time.perf_counter() - t0
+    dev_built = info["nnodes"] == info["nnodes_traversal"]          # a device-built scene has no 2-wide nodes of its own
+    other_b = "host" if dev_built else "device"
     del P, idx
     out = acc.intersect_device(d_org, d_dir); torch.cuda.synchronize(dev)
     ns = min(n, 4_000_000)
@@ -615,12 +621,14 @@ def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
     info = acc.info()
     hot = info["nnodes_traversal"] * 64 + info["ntriangles"] * 48
     acc.close()
-    # the twin on the tree lh_accel_commit builds by itself at this size (the device builders): same rays, same records
+    # the twin on the OTHER builder's tree: same rays, same records
     twin = None
     try:
+        if args.no_other_builder:
+            raise RuntimeError("skipped (--no-other-builder)")
         P2, idx2, _ = scenes.soup_triangles(args.hbm_tris, 0.002)
         acc2 = la.HipAccel(local); acc2.add_mesh(P2, idx2)
-        t0 = time.perf_counter(); info2 = acc2.commit(build="device"); commit2 = time.perf_counter() - t0
+        t0 = time.perf_counter(); info2 = acc2.commit(build=other_b); commit2 = time.perf_counter() - t0
         del P2, idx2
         out2 = acc2.intersect_device(d_org, d_dir); torch.cuda.synchronize(dev)
         _, cnt2 = acc2.intersect_device(d_org[:ns], d_dir[:ns], counters=True)
@@ -628,10 +636,10 @@ def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
         same2 = all(bool(torch.equal(a, b)) for a, b in zip(out2, out))
         nn2 = cnt2["nodes"] / ns; nt2 = cnt2["tris"] / ns
         br2 = B_IN + B_OUT + B_NODE_SURVEY * nn2 + B_TRI * nt2
-        twin = {"builder": "device (lh_accel_commit's own choice at this size)", "commit_s": round(commit2, 3), "kernel_ms": round(ms2, 3),
+        twin = {"builder": other_b, "commit_s": round(commit2, 3), "kernel_ms": round(ms2, 3),
                 "value": round(n / (ms2 * 1e-3) / 1e6, 1), "value_unit": "Mrays/s", "nodes_per_ray": round(nn2, 3), "tris_per_ray": round(nt2, 3),
                 "bytes_per_ray": round(br2, 1), "achieved": round(br2 * n / (ms2 * 1e-3) / 1e9, 1),
-                "frac": round(br2 * n / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "records_bit_equal_to_host_tree": same2,
+                "frac": round(br2 * n / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "records_bit_equal": same2,
                 "nodes": info2["nnodes_traversal"], "depth": info2["max_depth"]}
         ok = ok and same2
         acc2.close(); del out2
@@ -650,8 +658,9 @@ def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
             "record_bytes_per_ray": round(B_IN + B_OUT + node_bytes * n_nodes + B_TRI * n_tris, 1),
             "record_bytes_note": "what the walk's own records add up to per ray (%d-B node records): includes bytes served by L2 / the Infinity Cache -- a count, not a bandwidth" % node_bytes,
             "residency": "hot set %.0f MB as 4-wide nodes + tri32 >> 256 MiB Infinity Cache: HBM" % (hot / 1e6),
-            "builder": "host, asked for (the better tree by 0.5-1 %; `device_tree` is the same dump on lh_accel_commit's own choice)",
-            "device_tree": twin,
+            "builder": ("device" if dev_built else "host") + (": lh_accel_commit's own choice at this size" if args.leg_build == "auto" else ", asked for")
+                       + "; `other_builder` is the same dump on the other builder's tree",
+            "commit_s": round(commit1, 3), "other_builder": twin,
             "kernel": "k_trace_persist_lane<walk=spec8, q16x8 nodes: 128-byte 8-wide records, one cache line each>" if node_bytes == 128
                       else "k_trace_persist_lane<walk=spec,%s nodes>" % node_fmt,
             "node_bytes": node_bytes,
@@ -663,7 +672,7 @@ def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
                            "ok": bool(ok) and cross is not False and 0.5 < hit < 0.999}}
 
 
-def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
+def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess, build="auto", twin=True):
     """Secondary leg = BASELINE config 5 as stated (4096 x 4096, 64 AO samples, the AO example scene -- the
     322 triangles the reference's own RIB ingest produced, tests/golden/ao_c1.npz -- midpoint-tessellated
     `tess` = 8 times: 21.1 M triangles >= 10 M); --ao-size 1024 --ao-tess 0 is config 2.  Whole pipeline on
@@ -681,7 +690,8 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
             a.add_mesh(P_, I_)
             del P_, I_
     # ONE build (rank 0: tessellation + commit), then the broadcast of the flattened scene to every rank
-    t0c = time.perf_counter(); info, commit_s, bcast_s = shard.commit_shared(acc, add_meshes, rank, world, build="host"); commit_host_s = time.perf_counter() - t0c
+    t0c = time.perf_counter(); info, commit_s, bcast_s = shard.commit_shared(acc, add_meshes, rank, world, build=build); commit_main_s = time.perf_counter() - t0c
+    dev_built = info["nnodes"] == info["nnodes_traversal"]; other_b = "host" if dev_built else "device"
     c = g["camera"]
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
     # one GPU: the whole frame as one tile; sharded: full-width bands, ~16 per rank, band_id % world, ONE device batch per rank (render.bands_for / lh_render_ao_bands)
@@ -731,23 +741,23 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
                 "lane_use_node_steps": round(c["nodes"] / max(1, sl["node_slots"]), 3),
                 "lane_use_triangle_passes": round(c["tris"] / max(1, sl["tri_slots"]), 3),
                 "rays_counted": c["rays"]}
-    # the same scene with the traversal tree built on the device (lh_build.hip; what lsh_hip does from 1 M triangles on): commit
-    # time, frame time on that tree, and the image -- which must not change by a bit
+    # the same scene through the OTHER builder (the device builders of lh_build.hip are lh_accel_commit's own choice from 1 M
+    # triangles on, the host builder below that): commit time, frame time on that tree, and the image -- which must not change by a bit
     devb = None
-    if world == 1 and commit_host_s is not None:
+    if world == 1 and twin:
         acc_d = la.HipAccel(acc_device)
         for k in range(int(g["ngeoms"])):
             P_, I_ = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess); acc_d.add_mesh(P_, I_); del P_, I_
-        t0 = time.perf_counter(); info_d = acc_d.commit(on_device=True); commit_dev_s = time.perf_counter() - t0
+        t0 = time.perf_counter(); info_d = acc_d.commit(build=other_b); commit_other_s = time.perf_counter() - t0
         acc_d.wait_exact(); exact_s = time.perf_counter() - t0          # lucille's own tree attached: ties, fragile hits, beams follow the reference
         render.render_ao_frame(acc_d, cam, 1, nsamples, tile=tile); torch.cuda.synchronize(dev)
         tfd = []
-        for _ in range(max(1, min(steps, 3))):                  # as the host-tree frames above: the best of the timed frames
+        for _ in range(max(1, min(steps, 3))):                  # as the frames above: the best of the timed frames
             t0 = time.perf_counter(); img_d, st_d = render.render_ao_frame(acc_d, cam, 1, nsamples, tile=tile); torch.cuda.synchronize(dev)
             tfd.append(time.perf_counter() - t0)
-        devb = {"host_commit_s": round(commit_host_s, 3), "device_commit_s": round(commit_dev_s, 3), "device_tree_s": round(info_d["build_seconds"], 3),
-                "device_reference_tree_s": round(acc_d.info()["ref_build_seconds"], 3), "commit_to_exact_s": round(exact_s, 3),
-                "frame_ms_on_device_tree": round(min(tfd) * 1e3, 3),
+        devb = {"builder": other_b, "commit_s": round(commit_other_s, 3), "tree_s": round(info_d["build_seconds"], 3),
+                "reference_tree_s": round(acc_d.info()["ref_build_seconds"], 3), "commit_to_exact_s": round(exact_s, 3),
+                "frame_ms": round(min(tfd) * 1e3, 3),
                 "image_bit_equal": bool(torch.equal(img_d, img)) and dict(st_d) == stats[0]}
         ok = ok and devb["image_bit_equal"]
         acc_d.close(); del img_d
@@ -774,11 +784,12 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess):
                 len(render.bands_for(size, world)[1]), render.bands_for(size, world)[0], world),
             "device_bytes": info["device_bytes"], "build_s": round(info["build_seconds"], 3),
             "ref_tree_build_s": round(info["ref_build_seconds"], 3),
-            "builder": "host, asked for (the better tree by 1-2 % of the frame); lh_accel_commit's own choice at this size is the device builders: see device_build",
-            "scene_load": {"rank0_commit_s": round(commit_s, 3), "broadcast_s": round(bcast_s, 3) if world > 1 else None},
+            "builder": ("device" if dev_built else "host") + (": lh_accel_commit's own choice at this size" if build == "auto" else ", asked for")
+                       + "; `other_builder` is the same frame on the other builder's tree",
+            "scene_load": {"rank0_tessellate_and_commit_s": round(commit_main_s, 3), "rank0_commit_s": round(commit_s, 3), "broadcast_s": round(bcast_s, 3) if world > 1 else None},
             "rays_per_frame": int(rays_all), "frame_ms": round(t_all * 1e3, 3),
             "value": round(rays_all / t_all / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
-            "image_mean": float(img.mean().item()), "roofline": roof, "device_build": devb, "ranks": ranks,
+            "image_mean": float(img.mean().item()), "roofline": roof, "other_builder": devb, "ranks": ranks,
             "validation": {"frames_repeat": ok_all, "retiled_frame_bit_equal": bool(ok) if world == 1 else None,
                            "primary_hits": int(stats[0]["primary_hits"]) if world == 1 else None, "ok": ok_all}}
 

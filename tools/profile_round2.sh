@@ -8,8 +8,8 @@ cd /tmp; export TMPDIR=/tmp
 for LEG in $LEGS; do
   OUT=$R/gpurun_out/$TAG/$LEG; mkdir -p $OUT
   case $LEG in
-    main) CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu --no-ao --no-pt --no-hbm --no-config2 --build device" ;;   # the headline's tree (what --build auto picks at 1 M triangles) without the other-builder comparison launches
-    *)    CMD="python $R/bench.py --only $LEG" ;;
+    main) CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu --no-ao --no-pt --no-hbm --no-config2 --no-other-builder" ;;   # lh_accel_commit's own choice of builder, without the other-builder comparison launches
+    *)    CMD="python $R/bench.py --only $LEG --no-other-builder" ;;
   esac
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1
