@@ -65,6 +65,9 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     if (env && atoi(env) > 0 && atoi(env) <= (1 << 20)) a->ray_chunk = (uint32_t)atoi(env);
     a->dev.ray_chunk = a->ray_chunk;
     a->dev.ray_budget = LH_RAY_BUDGET; a->dump_budget = LH_DUMP_BUDGET;
+    a->ao_budget = LH_AO_BUDGET;
+    env = getenv("LH_AO_BUDGET");
+    if (env && atoi(env) > 0) a->ao_budget = (uint32_t)atoi(env);
     env = getenv("LH_DUMP_BUDGET");
     if (env && atoi(env) > 0) a->dump_budget = (uint32_t)atoi(env);
     env = getenv("LH_RAY_BUDGET");
@@ -534,14 +537,14 @@ int lh_sync_ref(lh_accel_t *a, bool wait)
     return attach_ref(a);
 }
 
-/* persistent workgroups per launch: as many as the LDS stack rows of this scene let a CU hold (at most 5) */
+/* persistent workgroups per launch: as many as the LDS stack rows of this scene let a CU hold -- at most 4: the walk's 128 VGPRs */
 static int size_grid(lh_accel_t *a)
 {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, a->device));
     const uint32_t stack = (uint32_t)lh_trace_rows(&a->dev);
     int per_cu = (int)(160u / stack);                     /* LDS: stack KiB per 256-thread workgroup */
-    if (per_cu > 5) per_cu = 5;
+    if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
     a->grid_blocks = prop.multiProcessorCount * per_cu; a->ncus = prop.multiProcessorCount;
     const char *env = getenv("LH_GRID_BLOCKS");
@@ -824,8 +827,9 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
     else if (!strcmp(name, "tri_batch") && value > 0 && value <= 64) a->tri_batch = value;
     else if (!strcmp(name, "ray_chunk") && value > 0 && value <= (1 << 20)) { a->ray_chunk = (uint32_t)value; a->dev.ray_chunk = (uint32_t)value; }
     else if (!strcmp(name, "variant") && (value == LH_VARIANT_DIRECT || value == LH_VARIANT_SPEC)) a->default_variant = value;
-    else if (!strcmp(name, "ray_budget") && value > 0) { a->dev.ray_budget = (uint32_t)value; a->dump_budget = (uint32_t)value; }
+    else if (!strcmp(name, "ray_budget") && value > 0) { a->dev.ray_budget = (uint32_t)value; a->dump_budget = (uint32_t)value; a->ao_budget = (uint32_t)value; }
     else if (!strcmp(name, "dump_budget") && value > 0) a->dump_budget = (uint32_t)value;
+    else if (!strcmp(name, "ao_budget") && value >= 0) a->ao_budget = (uint32_t)value;
     else if (!strcmp(name, "ao_fused")) a->ao_fused = value != 0;
     else if (!strcmp(name, "combine")) a->combine = value != 0;
     else if (!strcmp(name, "ao_group") && value >= 0 && value <= 4096) a->dev.ao_group = (uint32_t)value;

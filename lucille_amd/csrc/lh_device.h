@@ -72,7 +72,8 @@ enum {
                                          94 ms at 40 checked rows and 87 ms for a 20-level tree under 64 (r03) -- so deeper trees take the checked walk */
 #define LH_TOP_AUTO       0xFFFFFFFFu  /* lh_dev_scene_t.top_nodes: as many as the CU's LDS leaves over beside the stack rows (the default) */
 #define LH_TOP_NODES_MAX  512u         /* 4-wide nodes a workgroup may keep in LDS behind its stack rows (32 KiB) */
-#define LH_ROWS_CHECKED   40u          /* ... of the checked walk: four workgroups per CU */
+#define LH_ROWS_CHECKED   34u          /* ... of the checked walk: four workgroups per CU (4 x 34 KiB) and the cooperative walk's 17 KiB beside them; what every
+                                         launch of 65536 rays or more walks when its tree asks for more (rows4 in lh_kernels.hip) */
 #define LH_NPART          8            /* cursor partitions of a persistent launch: one per XCD (each with its own L2) */
 #define LH_CURSOR_STRIDE  32           /* 32-bit words between two cursors: a 128-byte line each (device-scope atomics on one line serialise like atomics on
                                          one address) */
@@ -81,6 +82,10 @@ enum {
 #define LH_DUMP_BUDGET    2048u        /* ... of ray-dump launches (incoherent rays: ages run to several times the steps) */
 #define LH_TILE_CHUNK     1024u        /* rays per cursor atomic in the tile pipelines (camera rays, AO rays of a slot, path-tracing bounces: neighbours in the
                                          batch are neighbours in space; ray dumps keep "ray_chunk" = 256): config 4 frame 148 -> 134 ms, config 5 87.0 -> 85.5 */
+#define LH_AO_BUDGET      384u         /* ... of the fused AO stage: one ray in 800 leaves the surface it starts on at so low an angle that it threads the boxes of
+                                         hundreds of triangles; past 128 iterations 0.12 % of a config-5 frame's AO rays are still walking, past 384 0.02 %.
+                                         Each of them restarts in the cooperative walk (16 lanes a ray), so the lower budget trades the launch's tail for a
+                                         queue: whole frame 61.9 ms at 128, 59.4 at 384, 58.3 at 512; an eighth of it 10.4 / 10.4 / 11.2 (tools/ao_budget_probe.py) */
 #define LH_RAY_BUDGET     128u         /* default visit budget of the persistent walk (set_param "ray_budget") */
 #define LH_PRIM_OVERFLOW  0xFFFFFFFDu  /* the LDS stack column was too short for this ray: k_overflow_fix */
 #define LH_OCC_OVERFLOW   4u

@@ -109,6 +109,7 @@ struct lh_accel {
     lh_buf r_org, r_dir, r_prim, r_t, r_u, r_v, r_slot, r_hitrec, r_aorg, r_adir, r_occ, r_blocks, r_key, r_frame, r_occcount;
     uint64_t last_retraced;            /* rays the last counted launch finished outside the main kernel */
     int ao_fused;                      /* AO rays generated inside the any-hit kernel (default); 0: materialised in HBM */
+    uint32_t ao_budget;                /* visit budget of the fused AO stage (0: dev.ray_budget) */
     uint32_t dump_budget;              /* visit budget of ray-dump launches (the tile pipelines': dev.ray_budget) */
     int build_auto;                    /* the commit chose the builders by the size of the scene: a failing device build falls back to the host */
     int fast_start;                    /* device-built scenes: launch before lucille's own tree is attached (ties by primitive id until then) */

@@ -800,6 +800,10 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
             left = (uint32_t)__shfl((int)left, 0); cnt = (uint32_t)__shfl((int)cnt, 0);
             known = cnt < fq.qcap ? cnt : fq.qcap;
             if (left >= fq.nprod) {                                /* every producer wave has left (acquire): the count is final */
+                /* the pass next to the producer takes no new entry from here on: its few waves had the CUs' spare room while the
+                 * producer ran; now the chip is empty, and the sweep behind the producer -- sixteen times the waves -- takes the
+                 * backlog from heads[] on (a producer with three workgroups per CU outruns this pass by a third of the launch) */
+                if (owner_groups == 0u) gdone = true;
                 if (!prod_done) { prod_done = true; progress = wall_clock64(); continue; }      /* one more look at the count, now final */
                 if (e >= known) gdone = true;
             }
@@ -1041,16 +1045,20 @@ int launch_walk(const lh_dev_scene_t &sc, size_t n, const double *org, const dou
     return launch_one<false, false>(sc, n, org, dir, prim, t, u, v, occ, counters, cursor, walk, grid_blocks, min_active, tri_batch, lds_bytes, fq, s);
 }
 
-/* LDS stack rows of a 4-wide walk over this scene.  3 * depth + 5 covers every ray: up to 64 rows the walk runs unchecked (the
- * config-5 host tree needs 56-64: two workgroups per CU, 87 ms; checked at 40 rows / four per CU it is 91 ms -- the check costs
- * what the occupancy gives).  A deeper tree (an LBVH built on the device is: BASELINE config 5's needs 65) gets 40 rows -- FOUR
- * workgroups per CU: the walk is bound by rays in flight (140 ms at 64 rows / 2 workgroups, 113 at 48 / 3, 100 at 40 / 4) --
- * checks after every push, and the rare ray that would overrun its column goes to the cooperative walk.  "stack_cap" (tests)
- * forces a lower cap. */
-uint32_t rows4(const lh_dev_scene_t &sc, bool *guard)
+/* LDS stack rows of a 4-wide walk over this scene.  3 * depth + 5 (or the builder's count of the deepest path) covers every
+ * ray, but a launch that fills the chip is bound by rays in flight, and 128 VGPRs allow FOUR workgroups per CU: so a big launch
+ * (`dense`) walks at most LH_ROWS_CHECKED rows -- four workgroups and the cooperative walk's in a CU's 160 KiB -- with a check
+ * before every push, and the rare ray that would overrun its column goes to the cooperative walk.  Config-5 frame (the tree
+ * asks for 59 rows: two workgroups per CU): 85.6 ms unchecked, 61.9 at 34 checked rows; S-soup-1M dump (44 rows: three) 2 234 ->
+ * 2 278 Mrays/s.  (Rounds 2-3 measured the opposite for the frame -- 91 against 87 ms -- because the cooperative pass beside
+ * the launch, which cannot be resident next to four 128-VGPR workgroups, kept its share of the queue after the launch had ended:
+ * k_coop_walk.)  Small batches keep unchecked rows (up to 64): a handful of waves fills nothing, and without a queue an
+ * overrunning ray would be left to k_fixups' sequential walk.  "stack_cap" forces a cap (8 .. 64). */
+uint32_t rows4(const lh_dev_scene_t &sc, bool *guard, bool dense = true)
 {
     uint32_t need = sc.q4_stack ? sc.q4_stack : 3 * sc.q4_depth + 5;      /* the builder's own count of the deepest path, or the bound of any tree that deep */
-    const uint32_t cap = (sc.stack_cap >= 8 && sc.stack_cap < LH_ROWS_UNCHECKED) ? sc.stack_cap : (need <= LH_ROWS_UNCHECKED ? LH_ROWS_UNCHECKED : LH_ROWS_CHECKED);
+    const uint32_t cap = (sc.stack_cap >= 8 && sc.stack_cap <= LH_ROWS_UNCHECKED) ? sc.stack_cap
+                       : ((dense || need > LH_ROWS_UNCHECKED) ? LH_ROWS_CHECKED : LH_ROWS_UNCHECKED);
     *guard = need > cap;
     if (need > cap) need = cap;
     need = (need + 1u) & ~1u;
@@ -1125,11 +1133,15 @@ int launch_coop(const lh_dev_scene_t &sc, const double *org, const double *dir, 
     hipStream_t aux = (hipStream_t)q->aux_stream;
     int grid = ncus > 0 ? ncus : 256;                      /* one wave per workgroup and CU, 4 rays per wave */
     if (grid * 4 > (int)LH_Q_GROUPS) grid = (int)LH_Q_GROUPS / 4;
-    if (hipStreamWaitEvent(aux, (hipEvent_t)q->ev_ready, 0) != hipSuccess) return -1;
-    hipLaunchKernelGGL((k_coop_walk<ANYHIT, SRC>), dim3(grid), dim3(64), lds, aux, scl, org, dir, prim, t, u, v, occ, ao, fq, counters, 0u);
-    if (hipGetLastError() != hipSuccess) return -1;
-    if (hipEventRecord((hipEvent_t)q->ev_done, aux) != hipSuccess) return -1;
-    if (hipStreamWaitEvent(s, (hipEvent_t)q->ev_done, 0) != hipSuccess) return -1;
+    static int concurrent = -1;
+    if (concurrent < 0) { const char *e = getenv("LH_COOP_CONCURRENT"); concurrent = (e && atoi(e) == 0) ? 0 : 1; }
+    if (concurrent) {
+        if (hipStreamWaitEvent(aux, (hipEvent_t)q->ev_ready, 0) != hipSuccess) return -1;
+        hipLaunchKernelGGL((k_coop_walk<ANYHIT, SRC>), dim3(grid), dim3(64), lds, aux, scl, org, dir, prim, t, u, v, occ, ao, fq, counters, 0u);
+        if (hipGetLastError() != hipSuccess) return -1;
+        if (hipEventRecord((hipEvent_t)q->ev_done, aux) != hipSuccess) return -1;
+        if (hipStreamWaitEvent(s, (hipEvent_t)q->ev_done, 0) != hipSuccess) return -1;
+    }
     /* the sweep: the same kernel behind the producer, on its stream, sixteen waves per CU -- whatever the concurrent pass did not
      * take (nothing, when it ran next to the producer: the waves read a few words and leave) */
     hipLaunchKernelGGL((k_coop_walk<ANYHIT, SRC>), dim3(grid * 16), dim3(64), lds, s, scl, org, dir, prim, t, u, v, occ, ao, fq, counters, (uint32_t)grid * 4u);
@@ -1161,7 +1173,7 @@ extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int n
     if (n >= ((size_t)1 << 31)) return -1;
     lh_dev_scene_t scl = *sc;
     bool guard = false;
-    scl.stack_rows = rows4(*sc, &guard);
+    scl.stack_rows = rows4(*sc, &guard, n >= 65536);
     scl.stack_guard = guard ? 1 : 0;
     scl.top_nodes = top_nodes_for(*sc, scl.stack_rows);
     const size_t lds_bytes = (size_t)scl.stack_rows * LH_BLOCK * sizeof(int) + (size_t)scl.top_nodes * 64u;
@@ -1253,11 +1265,11 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
         if (need < 16 && !guard) need = 16;
         scl.stack_guard = guard ? 1 : 0;
     } else {
-        /* a very deep tree (chains of nested geometry, an LBVH over a degenerate distribution): the 4-wide walk's worst case
-         * does not fit the 64-row LDS stack; a ray that would overrun it (none in practice: the bound is three pushes on
-         * every level) is finished by the cooperative walk */
+        /* a launch that fills the chip walks at most LH_ROWS_CHECKED rows (four workgroups per CU), a ray that would overrun
+         * them is finished by the cooperative walk; so does a very deep tree (chains of nested geometry, an LBVH over a
+         * degenerate distribution) whose worst case does not fit 64 rows -- rows4 */
         scl.prefer_q8 = 0;
-        need = rows4(*sc, &guard); walk = guard ? 8 : 3;
+        need = rows4(*sc, &guard, n >= 65536 || sc->n_dev != NULL); walk = guard ? 8 : 3;
         scl.stack_guard = guard ? 1 : 0;
     }
     if (need > LH_ROWS_UNCHECKED) return -1;

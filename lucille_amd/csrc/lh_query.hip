@@ -127,16 +127,7 @@ int lh_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, voi
     const uint32_t budget_keep = a->dev.ray_budget, chunk_keep = a->dev.ray_chunk;
     if (dump) a->dev.ray_budget = a->dump_budget;
     else if (a->dev.ray_chunk < LH_TILE_CHUNK) a->dev.ray_chunk = LH_TILE_CHUNK;       /* the tile pipelines' batches are coherent in batch order */
-    /* A big incoherent dump over the 4-wide nodes is bound by rays in flight: a fourth workgroup per CU (128 VGPRs allow four) is
-     * worth 3 %, the stack check that makes room for it costs 1 % (tools/occupancy_probe.py, r04: S-soup-1M 2 234 -> 2 278
-     * Mrays/s; two per CU: 1 681).  So a tree that needs 41 .. 64 unchecked rows walks 40 checked ones here -- the rare ray that
-     * would overrun them is finished by the cooperative walk.  (The tile pipelines' coherent rays lose with the same trade:
-     * config 5 91 ms against 87, r03 -- they keep their rows.) */
-    const uint32_t cap_keep = a->dev.stack_cap; int grid = a->grid_blocks;
-    if (dump && n >= 65536 && variant == LH_VARIANT_SPEC && !a->dev.prefer_q8 && a->dev.stack_cap == 0 && !a->grid_user) {
-        const uint32_t rows = (uint32_t)lh_trace_rows(&a->dev);
-        if (rows > LH_ROWS_CHECKED && rows <= LH_ROWS_UNCHECKED) { a->dev.stack_cap = LH_ROWS_CHECKED; grid = a->ncus * 4; }
-    }
+    const uint32_t cap_keep = a->dev.stack_cap; const int grid = a->grid_blocks;
     const int qk = lh_aoq_slot(a, s);             /* the stream's fix-up queue (rays out of visit budget -> the cooperative walk) */
     if (qk < 0) { a->dev.ray_budget = budget_keep; a->dev.ray_chunk = chunk_keep; a->dev.stack_cap = cap_keep; return -1; }
     int rc = lh_launch_trace(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim,

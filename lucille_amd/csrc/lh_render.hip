@@ -255,12 +255,12 @@ __global__ void k_ao_resolve(int w, int h, int band_rows, int xs, int ys, int N,
 {
     LH_NC
     const size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= (size_t)w * h) return;
+    const bool inside = pix < (size_t)w * h;
     /* h = all lines of the batch (nbands * band_rows); every band is flipped within itself, as a tile is */
     const int lx = (int)(pix % w), line = (int)(pix / w), band = line / band_rows, ly = line % band_rows;
     double accum = 0.0;
     unsigned int nocc = 0;
-    const int S = xs * ys;
+    const int S = inside ? xs * ys : 0;
     for (int s = 0; s < S; s++) {
         const uint32_t slot = slot_of_sample[pix * S + s];
         double rad = 0.0;
@@ -278,12 +278,18 @@ __global__ void k_ao_resolve(int w, int h, int band_rows, int xs, int ys, int N,
         }
         accum = accum + rad;
     }
-    const double val = accum * ((double)1.0 / (xs * ys));
-    float f = (float)val;
-    if (f < 0.0f) f = 0.0f;
-    float *o = rgb + 3 * ((size_t)(band * band_rows + (band_rows - 1 - ly)) * w + lx);
-    o[0] = f; o[1] = f; o[2] = f;
-    if (occ_total && nocc) atomicAdd(occ_total, (unsigned long long)nocc);
+    if (inside) {
+        const double val = accum * ((double)1.0 / (xs * ys));
+        float f = (float)val;
+        if (f < 0.0f) f = 0.0f;
+        float *o = rgb + 3 * ((size_t)(band * band_rows + (band_rows - 1 - ly)) * w + lx);
+        o[0] = f; o[1] = f; o[2] = f;
+    }
+    if (occ_total) {
+        /* one atomic per wave, not per pixel: 6.9 M same-address atomics were 1.2 of the 1.35 ms this kernel took on a 4096^2 frame */
+        for (int off = 32; off > 0; off >>= 1) nocc += (unsigned int)__shfl_xor((int)nocc, off);
+        if ((threadIdx.x & 63) == 0 && nocc) atomicAdd(occ_total, (unsigned long long)nocc);
+    }
 }
 
 

@@ -108,10 +108,13 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
         if (ensure_buf(&a->r_occcount, (size_t)nhit * sizeof(unsigned int))) return -1;
         const int k = lh_aoq_slot(a, s);
         if (k < 0) return -1;
-        if (lh_launch_trace_ao(&a->dev, (size_t)nhit, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const unsigned long long *)a->r_key.p,
+        const uint32_t budget_keep = a->dev.ray_budget;
+        if (a->ao_budget) a->dev.ray_budget = a->ao_budget;
+        const int rc_ao = lh_launch_trace_ao(&a->dev, (size_t)nhit, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const unsigned long long *)a->r_key.p,
                                (unsigned int *)a->r_occcount.p, cnt, (unsigned long long *)((uint32_t *)a->d_cursor + (size_t)LH_CURSOR_WORDS * (a->cursor_next++ % LH_NCURSOR)), a->grid_blocks,
-                               a->min_active, a->tri_batch, &a->aoq[k].q, a->ncus, (void *)s) != 0)
-            return fail("fused AO launch failed: %s", hipGetErrorString(hipGetLastError()));
+                               a->min_active, a->tri_batch, &a->aoq[k].q, a->ncus, (void *)s);
+        a->dev.ray_budget = budget_keep;
+        if (rc_ao != 0) return fail("fused AO launch failed: %s", hipGetErrorString(hipGetLastError()));
         uint32_t qc[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(qc, a->aoq[k].q.qcount, sizeof(qc), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
