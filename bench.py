@@ -52,6 +52,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 B_IN, B_OUT, B_TRI = 32, 16, 40   # SURVEY.md 8(d) algorithmic bytes per ray / per triangle test
 B_NODE_SURVEY = 64                # a node visit is priced at 64 B whatever the record
+VALU_NODE_STEP, VALU_TRI_STEP = 136, 75      # VALU instructions of one 4-wide node step / one triangle record through the fp32 filter (lh_walk.h, lh_filter.h: counted in the disassembly)
+VALU_PEAK_TLANEOPS = 256 * 64 * 2.4e9 / 1e12   # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane operations per second (one wave64 VALU instruction per SIMD every 4 cycles)
 B_NODE = {"f32": 64, "q16": 32, "q16x4": 64}   # per node visit: SURVEY's 64-B fp32 2-wide node, 32-B 16-bit grid 2-wide, 64-B 16-bit grid 4-wide
 # check values of the canonical S-soup-1M dump on the UNMODIFIED reference
 SOUP1M_CHECK = {1_000_000: (821_596, 87998.6606), 2_000_000: (1_644_156, 176110.93)}
@@ -722,21 +724,26 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess, 
         render.render_ao_frame(acc, cam, 1, nsamples, tile=tile); torch.cuda.synchronize(dev)
         c = acc.statistics(clear=True); sl = acc.slot_statistics(clear=True); acc.trace_statistics(False)
         nr = max(1, c["rays"])
-        # The frame is NOT bandwidth-bound (coherent rays: 0.06 KB of fabric traffic per ray).  What bounds it is how fast the CUs
-        # issue the walk: every node / triangle record is one dependent 64 / 48-byte fetch followed by ~150 VALU instructions, and
-        # the walk's fetch rate sits at 3/4 of what the same chip reaches on a pure gather of such records
-        # (tools/ubench/gather: 129 G records/s with 2048 waves resident).  `achieved` / `peak` are record fetches per second;
-        # the algorithmic-bytes figure (64 B per node visit, 40 B per triangle test, 76 B per camera ray, 4 B per hit slot) is
-        # kept beside it without a fraction.
+        # The frame is NOT bandwidth-bound (coherent rays: 0.15 KB of fabric traffic per ray).  With four workgroups per CU (round 4) the
+        # fused any-hit kernel is bound by VALU ISSUE: profiles/r04_pmc_ao_dense.txt -- SQ_INSTS_VALU 2.96e10 wave instructions x 4
+        # cycles / 1024 SIMDs = 1.16e8 of the launch's 1.21e8 cycles: the vector pipes are busy 96 % of the time, at 74 % lane use.
+        # `achieved` / `peak` are therefore VALU lane operations per second: what the walk's own steps need -- 136 per node step
+        # (lh_walk.h slab_w: the disassembly's count), 75 per triangle record through the fp32 filter (lh_filter.h) -- x the counted
+        # steps of the frame, against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.  What `frac` leaves out is what the counters show the
+        # pipes are busy WITH besides: idle lanes (26 %), the refill of finished lanes (ray generation + set-up, ~300 instructions a
+        # regroup), the fp64 resolves.  The record rate is kept beside it (`records_per_s`): round 1's gather microbenchmark
+        # (129 G random 64-B records/s) is no ceiling for these rays -- the 64 rays of a hemisphere share their first ten levels.
         recs = c["nodes"] + c["tris"]
         b_frame = 64.0 * c["nodes"] + 40.0 * c["tris"] + (48.0 + 28.0) * st["primary_rays"] + 4.0 * st["primary_hits"]
-        sq = {"source": "profiles/r03_pmc_ao_config5_sq_tcc.txt (tools/pmc_cmd.sh: separate SQ / TCC passes of this frame, the fused any-hit launch)",
-              "valu_busy": 0.59, "valu_lane_use": 0.73, "wave_cycles_waiting": 0.55, "l2_hit_rate": 0.53,
-              "fabric_read_bytes_per_frame": 59.3e9}
-        roof = {"bound": "issue", "achieved": round(recs / min(times) / 1e9, 1), "peak": 129.0, "unit": "G records/s",
-                "frac": round(recs / min(times) / 1e9 / 129.0, 4), "traffic": sq["fabric_read_bytes_per_frame"],
-                "peak_source": "tools/ubench/gather (profiles/r01_ubench_gather.log): dependent 64-B record gathers, 2048 resident waves",
-                "counters": sq, "algorithmic_GBps": round(b_frame / min(times) / 1e9, 1),
+        lane_ops = VALU_NODE_STEP * c["nodes"] + VALU_TRI_STEP * c["tris"]
+        sq = {"source": "profiles/r04_pmc_ao_dense.txt (tools/pmc_cmd.sh: separate SQ / TCC passes of this frame, the fused any-hit launch)",
+              "valu_busy": 0.96, "valu_lane_use": 0.74, "wave_cycles_waiting": 0.49, "l2_hit_rate": 0.52,
+              "valu_wave_instructions_per_ray": 66.8, "fabric_read_bytes_per_frame": 68.6e9}
+        roof = {"bound": "valu issue", "achieved": round(lane_ops / min(times) / 1e12, 2), "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
+                "frac": round(lane_ops / min(times) / 1e12 / VALU_PEAK_TLANEOPS, 4), "traffic": sq["fabric_read_bytes_per_frame"],
+                "formula": "achieved = (%d x node steps + %d x triangle records of the counted frame) / frame time; peak = 256 CUs x 64 lanes x 2.4 GHz"
+                           % (VALU_NODE_STEP, VALU_TRI_STEP),
+                "counters": sq, "records_per_s": round(recs / min(times) / 1e9, 1), "algorithmic_GBps": round(b_frame / min(times) / 1e9, 1),
                 "nodes_per_ray": round(c["nodes"] / nr, 2), "tris_per_ray": round(c["tris"] / nr, 2), "exact_per_ray": round(c["exact"] / nr, 4),
                 "lane_use_node_steps": round(c["nodes"] / max(1, sl["node_slots"]), 3),
                 "lane_use_triangle_passes": round(c["tris"] / max(1, sl["tri_slots"]), 3),
