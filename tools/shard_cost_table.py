@@ -17,7 +17,7 @@ g = np.load(os.path.join(ROOT, "tests", "golden", "ao_c1.npz"))
 acc = la.HipAccel(0); ntri = 0
 for k in range(int(g["ngeoms"])):
     P, I = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess); acc.add_mesh(P, I); ntri += I.shape[0] // 3
-info = acc.commit(build="host")
+info = acc.commit()          # lh_accel_commit's own choice of builder (the device builders at this size)
 c = g["camera"]; cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
 def t_of(x0, y0, w, h, out):
     best = 1e9
@@ -29,7 +29,7 @@ def t_of(x0, y0, w, h, out):
 full = torch.empty((size, size, 3), dtype=torch.float32, device="cuda")
 t1 = t_of(0, 0, size, size, full)
 print("# Shard cost table: BASELINE config 5 AO frame (%d triangles, %dx%d, %d AO samples), one MI355X\n" % (ntri, size, size, ns))
-print("Whole frame as ONE device batch: **%.2f ms** (host build %.2f s + reference-order tree %.2f s, once per scene).\n" % (t1 * 1e3, info["build_seconds"], info["ref_build_seconds"]))
+print("Whole frame as ONE device batch: **%.2f ms** (tree %.2f s + reference-order tree %.2f s, once per scene: lh_accel_commit's own choice of builder).\n" % (t1 * 1e3, info["build_seconds"], info["ref_build_seconds"]))
 print("Shards = `render.bands_for(H, world)`: full-width bands of a few lines (column 3), `band_id %% world == rank`; a rank's bands are ONE "
       "`lh_render_ao_bands` call (one device batch).  Times are best-of-3 wall times of every rank's batch, run one after the other on one "
       "GPU.  Prediction for N ranks = max over ranks of its batch + gather, where the gather moves "
@@ -57,7 +57,7 @@ for world, want_rows in ((1, None), (2, None), (4, None), (8, None), (8, 1), (8,
           100.0 * (max(per) / (sum(per) / world) - 1.0), gather * 1e3, pred * 1e3, rows[1][1] / pred))
 print("\nPer-rank batch time at 8 ranks (ms): " + " ".join("%.2f" % (x * 1e3) for x in rows[8][0]))
 print("\nReading: a rank renders ALL of its bands as one device batch (`lh_render_ao_bands`), so the per-launch drain of the persistent "
-      "traversal kernel (as long as its slowest ray: ~1.7 ms on this scene, where a few grazing AO rays walk thousands of floor boxes) is paid "
+      "traversal kernel (as long as its slowest ray: bounded by the visit budget since round 3) is paid "
       "once per rank and frame.  The sum over ranks exceeds the one-batch frame by (ranks - 1) drains plus what the finer interleave costs in "
       "coherence; the imbalance column is the busiest rank against the mean (the extra 8-rank rows show other band heights: the "
       "default is the first).  Rendering the same bands one launch at a time costs +1.7 ms per band "
