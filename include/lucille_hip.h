@@ -167,7 +167,12 @@ int  lh_accel_slot_statistics(lh_accel_t *accel, uint64_t slots[3], int clear);
 /* number of persistent workgroups the persistent variants launch */
 int  lh_accel_set_grid(lh_accel_t *accel, int blocks);
 /* knobs by name: "grid", "min_active", "tri_batch", "ray_chunk" (sweeps), "variant" (0: the textbook reference walk, 4: the
- * default), "ao_fused", "wide8" (-1 auto / 0 / 1), "fast_start", "stack_cap" (tests of the overflow path) */
+ * default), "ao_fused", "wide8" (-1 auto / 0 / 1), "fast_start", "combine", "top_nodes", "ao_group";
+ * "stack_cap": LDS stack rows of the default walk -- 0 (default): a launch of 65 536 rays or more walks at most 34 CHECKED rows
+ * (four workgroups per CU; a ray that would overrun them is finished by the cooperative walk), smaller launches up to 64
+ * unchecked; 8 .. 64: that many at most (64 = rounds 1-3's unchecked rows; small values: tests of the overflow path);
+ * "ray_budget" (wave iterations after which a ray leaves the persistent walk for the cooperative one; sets "dump_budget" and
+ * "ao_budget" with it), "dump_budget" (ray dumps: 2048), "ao_budget" (the fused AO stage: 384; 0: "ray_budget") */
 int  lh_accel_set_param(lh_accel_t *accel, const char *name, int value);
 
 /* ---- tile rendering: the callers on either side of the query, on the device ----
