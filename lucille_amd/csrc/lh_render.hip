@@ -286,9 +286,16 @@ __global__ void k_ao_resolve(int w, int h, int band_rows, int xs, int ys, int N,
         o[0] = f; o[1] = f; o[2] = f;
     }
     if (occ_total) {
-        /* one atomic per wave, not per pixel: 6.9 M same-address atomics were 1.2 of the 1.35 ms this kernel took on a 4096^2 frame */
+        /* one atomic per WORKGROUP on one of 64 counters: atomics on one address are served one after the other (~5 ns each) --
+         * one per wave, 262 144 of them on a 4096^2 frame, were 1.2 of the 1.35 ms this kernel took */
+        __shared__ unsigned int wsum[4];
         for (int off = 32; off > 0; off >>= 1) nocc += (unsigned int)__shfl_xor((int)nocc, off);
-        if ((threadIdx.x & 63) == 0 && nocc) atomicAdd(occ_total, (unsigned long long)nocc);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = nocc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (tot) atomicAdd(occ_total + (blockIdx.x & 63u), (unsigned long long)tot);
+        }
     }
 }
 

@@ -134,13 +134,15 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
     }
     if (stage_timing) HIPCHK(hipEventRecord(ev[4], s));
     /* 6. radiance */
-    HIPCHK(hipMemsetAsync(a->d_total, 0, sizeof(unsigned long long), s));
+    HIPCHK(hipMemsetAsync(a->d_total, 0, sizeof(unsigned long long) * 64, s));
     if (lh_render_launch_resolve(w, h, band_rows, ps, ps, N, (const uint32_t *)a->r_slot.p, (const uint8_t *)a->r_occ.p,
                                  fused ? (const unsigned int *)a->r_occcount.p : NULL, (float *)d_rgb, a->d_total, s) != 0)
         return fail("resolve kernel launch failed");
-    HIPCHK(hipMemcpyAsync(&nocc, a->d_total, sizeof(nocc), hipMemcpyDeviceToHost, s));
+    unsigned long long nocc64[64];
+    HIPCHK(hipMemcpyAsync(nocc64, a->d_total, sizeof(nocc64), hipMemcpyDeviceToHost, s));
     if (stage_timing) HIPCHK(hipEventRecord(ev[5], s));
     HIPCHK(hipStreamSynchronize(s));
+    for (int k = 0; k < 64; k++) nocc += nocc64[k];
     if (stage_timing) {
         float ms[5] = {0, 0, 0, 0, 0};
         for (int k = 0; k < 5; k++) (void)hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]);
