@@ -48,13 +48,15 @@ struct Region {
     const int *band_y0;
 };
 
-__device__ __forceinline__ void region_pixel(const Region &rg, size_t pix, int &px, int &py)
+/* 32-bit index arithmetic: a batch holds fewer than 2^32 samples (checked by the callers); the 64-bit divisions by run-time values
+ * that stood here cost ~100 instructions each, five per thread of k_primary_rays and k_ao_setup */
+__device__ __forceinline__ void region_pixel(const Region &rg, uint32_t pix, int &px, int &py)
 {
-    const size_t per = (size_t)rg.w * rg.band_rows;
-    const int band = (int)(pix / per);
-    const size_t within = pix % per;
-    px = rg.x0 + (int)(within % (size_t)rg.w);
-    py = (rg.band_y0 ? rg.band_y0[band] : rg.y0) + (int)(within / (size_t)rg.w);
+    const uint32_t per = (uint32_t)rg.w * (uint32_t)rg.band_rows;
+    const uint32_t band = pix / per, within = pix - band * per;
+    const uint32_t line = within / (uint32_t)rg.w;
+    px = rg.x0 + (int)(within - line * (uint32_t)rg.w);
+    py = (rg.band_y0 ? rg.band_y0[band] : rg.y0) + (int)line;
 }
 
 /* radical inverse permutation of init_sigma (render.c:870-917) */
@@ -73,8 +75,8 @@ __global__ void k_primary_rays(DevCamera cam, Region rg, int xs, int ys,
     const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)rg.w * rg.band_rows * rg.nbands * xs * ys;
     if (id >= total) return;
-    const int sx = (int)(id % xs), sy = (int)((id / xs) % ys);
-    const size_t pix = id / ((size_t)xs * ys);
+    const uint32_t id32 = (uint32_t)id, pix = id32 / (uint32_t)(xs * ys), sub = id32 - pix * (uint32_t)(xs * ys);
+    const int sy = (int)(sub / (uint32_t)xs), sx = (int)(sub - (uint32_t)sy * (uint32_t)xs);
     int px, py;
     region_pixel(rg, pix, px, py);
     if (py >= rg.height) {          /* below the frame (ragged last band): a ray that misses everything */
@@ -172,9 +174,10 @@ __global__ void k_ao_setup(size_t n, const lh_dev_scene_t sc, const double *__re
     {   /* absolute sample key (frame position, not tile position): keeps the built-in
          * RNG independent of how the frame is tiled or sharded */
         int ipx, ipy;
-        region_pixel(rg, i / (size_t)spp, ipx, ipy);
+        const uint32_t i32 = (uint32_t)i, ipix = i32 / (uint32_t)spp;
+        region_pixel(rg, ipix, ipx, ipy);
         const unsigned long long px = (unsigned long long)ipx, py = (unsigned long long)ipy;
-        slot_key[slot] = (py * (unsigned long long)full_width + px) * (unsigned long long)spp + (i % (size_t)spp);      /* < 2^34: checked by the caller */
+        slot_key[slot] = (py * (unsigned long long)full_width + px) * (unsigned long long)spp + (i32 - ipix * (uint32_t)spp);      /* < 2^34: checked by the caller */
     }
 
     /* ri_intersection_state_build (intersection_state.c:99-248): P, Ng, Ns */
@@ -513,10 +516,21 @@ __global__ __launch_bounds__(256) void k_pt_resolve(int w, int h, int band_rows,
     float sr = 0.0f, sg = 0.0f, sb = 0.0f;
     for (int s0 = 0; s0 < spp; s0 += LH_RESOLVE_SLICE) {
         const int ns = (spp - s0 < LH_RESOLVE_SLICE) ? spp - s0 : LH_RESOLVE_SLICE;
-        const size_t nfl = npb * (size_t)(3 * ns);                     /* floats of this slice, pixel-major */
-        for (size_t k = threadIdx.x; k < nfl; k += 256) {
-            const size_t p = k / (size_t)(3 * ns), c = k % (size_t)(3 * ns);
-            stage[p * (3 * LH_RESOLVE_SLICE + 1) + c] = radiance[3 * ((pix0 + p) * (size_t)spp + (size_t)s0) + c];
+        const uint32_t nfl = (uint32_t)npb * (uint32_t)(3 * ns);       /* floats of this slice, pixel-major: at most 256 x 48 */
+        const float *src = radiance + 3 * (pix0 * (size_t)spp + (size_t)s0);
+        /* (p, c) of element k by 32-bit division -- by a CONSTANT for a full slice: the 64-bit division by a run-time value that stood
+         * here was most of this kernel's 6.2 ms on a 2048^2 x 256 pass */
+        if (ns == LH_RESOLVE_SLICE) {
+            for (uint32_t k = threadIdx.x; k < nfl; k += 256u) {
+                const uint32_t p = k / (3u * LH_RESOLVE_SLICE), c = k - p * (3u * LH_RESOLVE_SLICE);
+                stage[p * (3 * LH_RESOLVE_SLICE + 1) + c] = src[(size_t)p * (size_t)(3 * spp) + c];
+            }
+        } else {
+            const uint32_t per = (uint32_t)(3 * ns);
+            for (uint32_t k = threadIdx.x; k < nfl; k += 256u) {
+                const uint32_t p = k / per, c = k - p * per;
+                stage[p * (3 * LH_RESOLVE_SLICE + 1) + c] = src[(size_t)p * (size_t)(3 * spp) + c];
+            }
         }
         __syncthreads();
         if (pix < npix) {

@@ -57,6 +57,7 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
     const size_t S = (size_t)w * h * ps * ps;
     if ((unsigned long long)cam->width * (unsigned long long)cam->height * (unsigned long long)(ps * ps) >= (1ull << 34))
         return fail("AO pipeline: more than 2^34 samples in the frame (slot keys carry 34 bits)");
+    if (S >= ((size_t)1 << 31)) return fail("AO pipeline: more than 2^31 samples in one batch; render the frame in tiles");     /* 32-bit sample indices on the device */
     const unsigned nb = (unsigned)((S + 255) / 256);
     if (ensure_buf(&a->r_org, S * 24) || ensure_buf(&a->r_dir, S * 24) || ensure_buf(&a->r_prim, S * 4) ||
         ensure_buf(&a->r_t, S * 8) || ensure_buf(&a->r_u, S * 8) || ensure_buf(&a->r_v, S * 8) ||
