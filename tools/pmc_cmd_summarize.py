@@ -6,7 +6,7 @@ for f in sorted(glob.glob(d + "/p*/**/*counter_collection.csv", recursive=True))
     per = collections.defaultdict(dict)   # (kernel, dispatch) -> counter -> value
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if not any(s in k for s in ("k_trace", "k_resolve", "k_quad")):
+        if not any(s in k for s in ("k_trace", "k_resolve", "k_quad", "k_pt_shade", "k_pt_resolve", "k_ao_setup")):
             continue
         per[(k, r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
     # largest dispatch per kernel = the one with the largest first counter
