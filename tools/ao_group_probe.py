@@ -11,7 +11,7 @@ for tess, size in ((8, 4096), (0, 1024)):
     acc = la.HipAccel(0)
     for k in range(int(g["ngeoms"])):
         Pk, Ik = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], tess); acc.add_mesh(Pk, Ik)
-    acc.commit(build="host")
+    acc.commit()
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
     base = None
     for grp in (0, 64, 16, 256, 1024, 64, 0):
