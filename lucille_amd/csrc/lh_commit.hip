@@ -67,7 +67,7 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     a->dev.ray_budget = LH_RAY_BUDGET; a->dump_budget = LH_DUMP_BUDGET;
     a->ao_budget = LH_AO_BUDGET;
     env = getenv("LH_AO_BUDGET");
-    if (env && atoi(env) > 0) a->ao_budget = (uint32_t)atoi(env);
+    if (env && atoi(env) > 0) { a->ao_budget = (uint32_t)atoi(env); a->ao_budget_user = 1; }
     env = getenv("LH_DUMP_BUDGET");
     if (env && atoi(env) > 0) a->dump_budget = (uint32_t)atoi(env);
     env = getenv("LH_RAY_BUDGET");
@@ -827,9 +827,9 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
     else if (!strcmp(name, "tri_batch") && value > 0 && value <= 64) a->tri_batch = value;
     else if (!strcmp(name, "ray_chunk") && value > 0 && value <= (1 << 20)) { a->ray_chunk = (uint32_t)value; a->dev.ray_chunk = (uint32_t)value; }
     else if (!strcmp(name, "variant") && (value == LH_VARIANT_DIRECT || value == LH_VARIANT_SPEC)) a->default_variant = value;
-    else if (!strcmp(name, "ray_budget") && value > 0) { a->dev.ray_budget = (uint32_t)value; a->dump_budget = (uint32_t)value; a->ao_budget = (uint32_t)value; }
+    else if (!strcmp(name, "ray_budget") && value > 0) { a->dev.ray_budget = (uint32_t)value; a->dump_budget = (uint32_t)value; a->ao_budget = (uint32_t)value; a->ao_budget_user = 1; }
     else if (!strcmp(name, "dump_budget") && value > 0) a->dump_budget = (uint32_t)value;
-    else if (!strcmp(name, "ao_budget") && value >= 0) a->ao_budget = (uint32_t)value;
+    else if (!strcmp(name, "ao_budget") && value >= 0) { a->ao_budget = (uint32_t)value; a->ao_budget_user = 1; }
     else if (!strcmp(name, "ao_fused")) a->ao_fused = value != 0;
     else if (!strcmp(name, "combine")) a->combine = value != 0;
     else if (!strcmp(name, "ao_group") && value >= 0 && value <= 4096) a->dev.ao_group = (uint32_t)value;

@@ -85,7 +85,8 @@ enum {
 #define LH_AO_BUDGET      384u         /* ... of the fused AO stage: one ray in 800 leaves the surface it starts on at so low an angle that it threads the boxes of
                                          hundreds of triangles; past 128 iterations 0.12 % of a config-5 frame's AO rays are still walking, past 384 0.02 %.
                                          Each of them restarts in the cooperative walk (16 lanes a ray), so the lower budget trades the launch's tail for a
-                                         queue: whole frame 61.9 ms at 128, 59.4 at 384, 58.3 at 512; an eighth of it 10.4 / 10.4 / 11.2 (tools/ao_budget_probe.py) */
+                                         queue: whole frame 61.9 ms at 128, 59.4 at 384, 58.3 at 512; an eighth of it 10.4 / 10.4 / 11.2 (tools/ao_budget_probe.py).  A launch of 2^27 rays
+                                         or more takes twice this (lh_tile.hip) unless the caller set a budget */
 #define LH_RAY_BUDGET     128u         /* default visit budget of the persistent walk (set_param "ray_budget") */
 #define LH_PRIM_OVERFLOW  0xFFFFFFFDu  /* the LDS stack column was too short for this ray: k_overflow_fix */
 #define LH_OCC_OVERFLOW   4u

@@ -110,6 +110,7 @@ struct lh_accel {
     uint64_t last_retraced;            /* rays the last counted launch finished outside the main kernel */
     int ao_fused;                      /* AO rays generated inside the any-hit kernel (default); 0: materialised in HBM */
     uint32_t ao_budget;                /* visit budget of the fused AO stage (0: dev.ray_budget) */
+    int ao_budget_user;                /* set by the caller (set_param / LH_AO_BUDGET / "ray_budget"): taken as it is, whatever the launch's size */
     uint32_t dump_budget;              /* visit budget of ray-dump launches (the tile pipelines': dev.ray_budget) */
     int build_auto;                    /* the commit chose the builders by the size of the scene: a failing device build falls back to the host */
     int fast_start;                    /* device-built scenes: launch before lucille's own tree is attached (ties by primitive id until then) */

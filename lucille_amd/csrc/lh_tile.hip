@@ -111,6 +111,10 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
         if (k < 0) return -1;
         const uint32_t budget_keep = a->dev.ray_budget;
         if (a->ao_budget) a->dev.ray_budget = a->ao_budget;
+        /* the tail a budget costs a launch is fixed, the queue a low budget sends to the sweep grows with the launch: a launch of
+         * 2^27 rays or more doubles the default (config 5: whole frame 57.6 -> 56.7 ms, half of it 30.8 -> 29.9; a quarter and an
+         * eighth are best at 384 -- tools/ao_budget_probe.py) */
+        if (a->ao_budget && !a->ao_budget_user && nao >= ((size_t)1 << 27)) a->dev.ray_budget = 2u * a->ao_budget;
         const int rc_ao = lh_launch_trace_ao(&a->dev, (size_t)nhit, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const unsigned long long *)a->r_key.p,
                                (unsigned int *)a->r_occcount.p, cnt, (unsigned long long *)((uint32_t *)a->d_cursor + (size_t)LH_CURSOR_WORDS * (a->cursor_next++ % LH_NCURSOR)), a->grid_blocks,
                                a->min_active, a->tri_batch, &a->aoq[k].q, a->ncus, (void *)s);
