@@ -48,6 +48,9 @@ typedef struct lh_accel_info {
     double   ref_build_seconds;      /* host build of the reference-order tree (lucille's own tree,
                                         kept for ties / fragile hits / beams): part of every commit */
     uint32_t nnodes_traversal;       /* 4-wide nodes the default kernel walks  */
+    uint32_t ntriangles_in_tree;     /* ntriangles minus the zero-area triangles the reference can never report (two equal
+                                        vertices: its determinant test, bvh.c:754, rejects them for every ray): those keep their
+                                        primitive ids and stay in lucille's own tree, but no leaf of the traversal tree holds them */
 } lh_accel_info_t;
 
 /* ---- runtime ----------------------------------------------------------- */
@@ -119,6 +122,9 @@ int  lh_accel_intersect1(lh_accel_t *accel, const double org[3], const double di
  * With lh_accel_trace_statistics on, the launch's totals are the sums of these rows. */
 int  lh_accel_intersect_diag_host(lh_accel_t *accel, size_t n, const double *org_xyz, const double *dir_xyz,
                                   uint32_t *prim_id, double *t, double *u, double *v, uint32_t *diag);
+/* ... for rays resident on the device, closest- or any-hit (mode: LH_MODE_*); d_diag: n x 4 u32 on the device, hit records dropped */
+int  lh_accel_intersect_diag_device(lh_accel_t *accel, size_t n, const void *d_org_xyz, const void *d_dir_xyz, int mode,
+                                    void *d_diag, void *stream);
 /* Concurrent lh_accel_intersect1 callers (lucille's render threads) are coalesced into one launch per batch of callers
  * (lh_query.hip "flat combining"); set_param("combine", 0) / LH_COMBINE=0 restores one launch per call.
  * out[0] = launches, out[1] = rays they carried since the last clear. */

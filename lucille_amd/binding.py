@@ -43,7 +43,7 @@ class AccelInfo(C.Structure):
     _fields_ = [("ntriangles", C.c_uint32), ("nnodes", C.c_uint32), ("nleaves", C.c_uint32),
                 ("max_depth", C.c_uint32), ("device_bytes", C.c_uint64), ("build_seconds", C.c_double),
                 ("upload_seconds", C.c_double), ("device", C.c_int), ("ref_build_seconds", C.c_double),
-                ("nnodes_traversal", C.c_uint32)]
+                ("nnodes_traversal", C.c_uint32), ("ntriangles_in_tree", C.c_uint32)]
 
 
 class RasterPlane(C.Structure):
@@ -100,7 +100,7 @@ class TileStats(C.Structure):
 # every symbol include/lucille_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "lh_device_count", "lh_last_error", "lh_accel_create", "lh_accel_add_mesh", "lh_accel_commit", "lh_accel_wait_exact", "lh_accel_ref_tree",
-    "lh_accel_destroy", "lh_accel_info", "lh_accel_prim_lookup", "lh_accel_intersect1", "lh_accel_combine_statistics", "lh_accel_intersect_diag_host",
+    "lh_accel_destroy", "lh_accel_info", "lh_accel_prim_lookup", "lh_accel_intersect1", "lh_accel_combine_statistics", "lh_accel_intersect_diag_host", "lh_accel_intersect_diag_device",
     "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted", "lh_accel_last_retraced", "lh_accel_dump_node_bytes",
     "lh_accel_set_grid", "lh_accel_set_param", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
     "lh_render_ao_tile", "lh_render_ao_tile_host", "lh_render_ao_bands", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device", "lh_accel_beam_raster_host", "lh_accel_beam_raster_device", "lh_render_pt_tile",
@@ -340,6 +340,16 @@ class HipAccel:
         _check(self.L.lh_accel_intersect_diag_host(self.h, n, o.ctypes.data, d.ctypes.data, prim.ctypes.data, t.ctypes.data, u.ctypes.data,
                                                    v.ctypes.data, diag.ctypes.data), "lh_accel_intersect_diag_host")
         return (prim, t, u, v), diag
+
+    def intersect_diag_device(self, org, dr, mode=MODE_CLOSEST):
+        """CUDA float64 [n,3] rays -> uint32 [n,4] CUDA tensor of the sequential walk's per-ray counts (closest- or any-hit)"""
+        import torch
+        n = org.shape[0]
+        diag = torch.zeros((n, 4), dtype=torch.int32, device=org.device)
+        self.L.lh_accel_intersect_diag_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _check(self.L.lh_accel_intersect_diag_device(self.h, n, _dptr(org), _dptr(dr), int(mode), _dptr(diag),
+                                                     C.c_void_p(torch.cuda.current_stream(org.device).cuda_stream)), "lh_accel_intersect_diag_device")
+        return diag
 
     def combine_statistics(self, clear=False):
         """(launches, rays) of the coalesced single-ray path since the last clear"""
@@ -741,7 +751,12 @@ class HipDist:
         behind whatever torch op produced the tensor (the communicator's private stream has no such dependency)"""
         import torch
         if stream is None:
-            return C.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)
+            cur = torch.cuda.current_stream(tensor.device)
+            if cur.cuda_stream == 0:
+                # torch's default stream has handle 0, which lh_dist_* reads as "the communicator's own stream" -- a non-blocking
+                # stream with no dependency on the legacy default stream: finish the producer first (ADVICE r04)
+                cur.synchronize()
+            return C.c_void_p(cur.cuda_stream)
         return C.c_void_p(stream.cuda_stream) if hasattr(stream, "cuda_stream") else C.c_void_p(stream)
 
     def broadcast(self, tensor, stream=None):

@@ -73,11 +73,17 @@ __device__ __forceinline__ float f_up(double d) { return __double2float_ru(d); }
 __device__ __forceinline__ uint32_t f2o(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float o2f(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o); }
 
+/* bad[0]: a coordinate that is NaN / infinite / beyond 1e30; bad[1]: primitives the reference can never report (lh_bvh.c
+ * tri_dead_class: two equal vertices -- they stay out of the traversal tree, marked by a NaN in plo[3 p]); bad[2]: some of them are
+ * of class 2 (v1 == v2: rejected for rays whose direction components stay below LH_DEG_DCAP).  drop = 0: nothing is marked */
+#define LH_DEG_DCAP  1024.0
+#define LH_DEG_S2CAP (1.0e-14 / (1.0e-15 * LH_DEG_DCAP))
 __global__ __launch_bounds__(256) void k_prim_boxes(uint32_t n, const double *__restrict__ tri64, float *__restrict__ plo, float *__restrict__ phi,
-                                                    uint32_t *__restrict__ scene /* 6 ordered uints: min xyz, max xyz */, int *__restrict__ bad)
+                                                    uint32_t *__restrict__ scene /* 6 ordered uints: min xyz, max xyz */, int *__restrict__ bad, int drop)
 {
     __shared__ uint32_t smin[4][3], smax[4][3];
     uint32_t omin[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, omax[3] = {0u, 0u, 0u};
+    uint32_t ndead = 0, noise = 0;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
         const double *t = tri64 + 9 * (size_t)p;
         for (int k = 0; k < 3; k++) {
@@ -88,6 +94,19 @@ __global__ __launch_bounds__(256) void k_prim_boxes(uint32_t n, const double *__
             const uint32_t ol = f2o(lo), oh = f2o(hi);
             omin[k] = ol < omin[k] ? ol : omin[k]; omax[k] = oh > omax[k] ? oh : omax[k];
         }
+        if (drop) {
+            int cls = 0;
+            if ((t[0] == t[3] && t[1] == t[4] && t[2] == t[5]) || (t[0] == t[6] && t[1] == t[7] && t[2] == t[8])) cls = 1;
+            else if (t[3] == t[6] && t[4] == t[7] && t[5] == t[8]) {
+                const double sN = fabs(t[3] - t[0]) + fabs(t[4] - t[1]) + fabs(t[5] - t[2]);
+                if (sN * sN * (1.0 + 1e-9) <= LH_DEG_S2CAP) cls = 2;
+            }
+            if (cls) { plo[3 * (size_t)p] = __uint_as_float(0x7fc00000u); ndead++; noise |= (uint32_t)(cls == 2); }
+        }
+    }
+    if (drop) {
+        for (int off = 32; off >= 1; off >>= 1) { ndead += (uint32_t)__shfl_xor((int)ndead, off); noise |= (uint32_t)__shfl_xor((int)noise, off); }
+        if ((threadIdx.x & 63) == 0 && ndead) { atomicAdd(&bad[1], (int)ndead); if (noise) atomicExch(&bad[2], 1); }
     }
     /* scene bounds: six atomics per WORKGROUP of a grid that is a few thousand workgroups whatever n is.  Same-address
      * device-scope atomics serialise at ~95 ns each: one per thread was 126 M of them on a 21 M-triangle scene, one per wave
@@ -124,6 +143,7 @@ __global__ void k_morton(uint32_t n, const float *__restrict__ plo, const float 
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
+    if (plo[3 * (size_t)p] != plo[3 * (size_t)p]) { key[p] = ~0ull; val[p] = p; return; }      /* marked by k_prim_boxes: behind every 63-bit code, outside the tree */
     uint64_t code = 0;
     /* one scale for the three axes (the largest extent): cubic cells.  A scale per axis makes the cells of a flat scene -- a
      * floor with objects on it -- slabs, and every third split of the radix tree a cut across the thin direction */
@@ -866,29 +886,32 @@ static inline void dfree(void *p) { if (p) (void)hipFree(p); }
 extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q4nodes, uint32_t *nq4, uint32_t *q4_depth, uint32_t *q4_stack,
                                int want_q8, void **d_q8nodes, uint32_t *nq8, uint32_t *q8_depth,
                                void **d_tri32, float bmin[3], float bmax[3], float grid_lo[3], float grid_step[3],
-                               void *stream, char *err, size_t errlen)
+                               uint32_t *nlive, double *deg_dcap, void *stream, char *err, size_t errlen)
 {
     hipStream_t s = (hipStream_t)stream;
-    const uint32_t n = ntris;
+    const uint32_t ntot = ntris;         /* every primitive: tri32 records, the sort */
+    uint32_t n = ntris;                  /* the primitives in the tree: ntot minus what the reference can never report (k_prim_boxes) */
     float *plo = NULL, *phi = NULL; uint32_t *scene = NULL, *val_in = NULL, *sorted = NULL, *counters = NULL, *ncut = NULL; float *boxes = NULL; CutRoot *cuts = NULL;
     uint64_t *key_in = NULL, *key = NULL; int *leaf_parent = NULL, *bad = NULL; BNode *nodes = NULL; void *tmp = NULL; size_t tmp_bytes = 0;
     uint2 *work[2] = {NULL, NULL}; DP4 *dp = NULL; uint32_t *bfs = NULL; lh_q4node_t *q4 = NULL; lh_q8node_t *q8 = NULL; lh_tri32_t *t32 = NULL; uint32_t *lay = NULL, *offs = NULL, need_rows = 0; PL *pl_in = NULL, *pl_out = NULL; std::vector<uint32_t> lvl_begin, lb2; DP8 *dp8 = NULL;
-    const unsigned nb = (n + 255) / 256;
+    const unsigned nb = (ntot + 255) / 256;
     uint32_t h_scene[6], level = 0, nwork = 0, nq = 1;
     const uint32_t init_scene[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    int h_bad = 0, leaf_max = LH_MAX_LEAF_TRIS;     /* leaves of up to 4 triangles WHERE THE SAH SAYS SO (k_node_boxes): forced 4-triangle leaves cost S-soup-1M 37 % (tools/experiments/leaf_probe.py), the SAH keeps that soup at one per leaf */
+    int h_bad[3] = {0, 0, 0}, leaf_max = LH_MAX_LEAF_TRIS;     /* leaves of up to 4 triangles WHERE THE SAH SAYS SO (k_node_boxes): forced 4-triangle leaves cost S-soup-1M 37 % (tools/experiments/leaf_probe.py), the SAH keeps that soup at one per leaf */
     { const char *e = getenv("LH_DEVICE_LEAF"); if (e && atoi(e) >= 1 && atoi(e) <= LH_MAX_LEAF_TRIS) leaf_max = atoi(e); }
     uint32_t cut = 512;                             /* primitives per subtree below the SAH-built top (LH_DEVICE_CUT; 0: plain radix tree).  config 5, frame /
                                                        tree time: 64 -> 86.9 ms / 0.125 s, 128 -> 87.3 / 0.058, 512 -> 87.6 / 0.029, 2048 -> 87.8 / 0.023; 256 makes
                                                        that tree one level too deep for the unchecked walk (97.6 ms) and is retried coarser (below) */
     { const char *e = getenv("LH_DEVICE_CUT"); if (e && atoi(e) >= 0) cut = (uint32_t)atoi(e); }
-    const uint32_t cut_cap = cut ? (uint32_t)std::min<uint64_t>((uint64_t)n, std::max<uint64_t>(65536u, 16ull * n / cut)) : 0u;
+    const uint32_t cut_cap = cut ? (uint32_t)std::min<uint64_t>((uint64_t)ntot, std::max<uint64_t>(65536u, 16ull * ntot / cut)) : 0u;
     int root_ref = 0;
     { const char *e = getenv("LH_DEVICE_TOP_BINS"); g_top_bins = (e && atoi(e) >= 2 && atoi(e) <= LH_TOP_BINS) ? atoi(e) : LH_TOP_BINS; }
     const int pair_align = !(getenv("LH_Q4_PAIRS") && atoi(getenv("LH_Q4_PAIRS")) == 0);
     const bool use_dp = !(getenv("LH_DEVICE_COLLAPSE") && strcmp(getenv("LH_DEVICE_COLLAPSE"), "greedy") == 0);
     *d_q4nodes = NULL; *d_tri32 = NULL; *nq4 = 0; *q4_depth = 0; *q4_stack = 0; *d_q8nodes = NULL; *nq8 = 0; *q8_depth = 0;
-    if (n == 0) return 0;
+    if (nlive) *nlive = ntot;
+    if (deg_dcap) *deg_dcap = INFINITY;
+    if (ntot == 0) return 0;
     /* LH_BUILD_TIMING=1: phase times on stderr (each mark synchronises the stream: diagnostics only) */
     const bool timing = getenv("LH_BUILD_TIMING") != NULL;
     double tmark = 0.0;
@@ -902,15 +925,23 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     };
     mark(NULL);
 
-    BCHK(hipMalloc((void **)&plo, sizeof(float) * 3 * (size_t)n)); BCHK(hipMalloc((void **)&phi, sizeof(float) * 3 * (size_t)n));
-    BCHK(hipMalloc((void **)&scene, sizeof(uint32_t) * 8)); BCHK(hipMalloc((void **)&bad, sizeof(int)));
-    BCHK(hipMemcpyAsync(scene, init_scene, sizeof(init_scene), hipMemcpyHostToDevice, s));
-    BCHK(hipMemsetAsync(bad, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_prim_boxes, dim3(nb < 2048u ? nb : 2048u), dim3(256), 0, s, n, d_tri64, plo, phi, scene, bad);
-    BCHK(hipMemcpyAsync(h_scene, scene, sizeof(h_scene), hipMemcpyDeviceToHost, s));
-    BCHK(hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, s));
-    BCHK(hipStreamSynchronize(s));
-    if (h_bad) { dfree(plo); dfree(phi); dfree(scene); dfree(bad); return -2; }
+    BCHK(hipMalloc((void **)&plo, sizeof(float) * 3 * (size_t)ntot)); BCHK(hipMalloc((void **)&phi, sizeof(float) * 3 * (size_t)ntot));
+    BCHK(hipMalloc((void **)&scene, sizeof(uint32_t) * 8)); BCHK(hipMalloc((void **)&bad, sizeof(int) * 4));
+    /* triangles the reference can never report stay out of the tree (lh_bvh.c tri_dead_class; LH_DROP_DEGENERATE=0: all stay);
+     * a scene of nothing else, or of a single leaf, is built as it was handed over */
+    for (int drop = (ntot > LH_MAX_LEAF_TRIS && !(getenv("LH_DROP_DEGENERATE") && atoi(getenv("LH_DROP_DEGENERATE")) == 0)) ? 1 : 0; ; drop = 0) {
+        BCHK(hipMemcpyAsync(scene, init_scene, sizeof(init_scene), hipMemcpyHostToDevice, s));
+        BCHK(hipMemsetAsync(bad, 0, sizeof(int) * 4, s));
+        hipLaunchKernelGGL(k_prim_boxes, dim3(nb < 2048u ? nb : 2048u), dim3(256), 0, s, ntot, d_tri64, plo, phi, scene, bad, drop);
+        BCHK(hipMemcpyAsync(h_scene, scene, sizeof(h_scene), hipMemcpyDeviceToHost, s));
+        BCHK(hipMemcpyAsync(h_bad, bad, sizeof(h_bad), hipMemcpyDeviceToHost, s));
+        BCHK(hipStreamSynchronize(s));
+        if (h_bad[0]) { dfree(plo); dfree(phi); dfree(scene); dfree(bad); return -2; }
+        if (!drop || (uint32_t)h_bad[1] < ntot) break;
+    }
+    n = ntot - (uint32_t)h_bad[1];
+    if (nlive) *nlive = n;
+    if (deg_dcap && h_bad[2]) *deg_dcap = LH_DEG_DCAP;
     mark("boxes + scene bounds");
     for (int k = 0; k < 3; k++) {
         uint32_t lo = h_scene[k], hi = h_scene[3 + k]; float fl, fh;
@@ -923,24 +954,30 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
         grid_lo[k] = fl; grid_step[k] = fs;
     }
     BCHK(hipMalloc((void **)&q4, sizeof(lh_q4node_t) * (2 * (size_t)n + 2)));      /* <= n - 1 nodes + at most one padding node per sibling group; cut to size at the end */
-    BCHK(hipMalloc((void **)&t32, sizeof(lh_tri32_t) * ((size_t)n + 2)));
-    BCHK(hipMalloc((void **)&sorted, sizeof(uint32_t) * (size_t)n));
+    BCHK(hipMalloc((void **)&t32, sizeof(lh_tri32_t) * ((size_t)ntot + 2)));
+    BCHK(hipMalloc((void **)&sorted, sizeof(uint32_t) * (size_t)ntot));
     {
         const float3 glo = make_float3(grid_lo[0], grid_lo[1], grid_lo[2]), gst = make_float3(grid_step[0], grid_step[1], grid_step[2]);
-        if (n <= LH_MAX_LEAF_TRIS) {
+        if (ntot <= LH_MAX_LEAF_TRIS) {
             /* identity order, one leaf (the only place a device-built leaf holds more than leaf_max triangles) */
             uint32_t ids[LH_MAX_LEAF_TRIS]; for (uint32_t i = 0; i < n; i++) ids[i] = i;
             BCHK(hipMemcpyAsync(sorted, ids, sizeof(uint32_t) * n, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_single_leaf, dim3(1), dim3(64), 0, s, n, scene, glo, gst, q4);
             nq = 1; level = 1;
         } else {
-            BCHK(hipMalloc((void **)&key_in, sizeof(uint64_t) * (size_t)n)); BCHK(hipMalloc((void **)&key, sizeof(uint64_t) * (size_t)n));
-            BCHK(hipMalloc((void **)&val_in, sizeof(uint32_t) * (size_t)n));
-            hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, s, n, plo, phi, scene, key_in, val_in);
-            BCHK(hipcub::DeviceRadixSort::SortPairs(NULL, tmp_bytes, key_in, key, val_in, sorted, (int)n, 0, 63, s));
+            /* every primitive is sorted (the dropped ones carry the key ~0: behind every 63-bit Morton code -- hence all 64 bits);
+             * the tree is built over the first n sorted positions */
+            BCHK(hipMalloc((void **)&key_in, sizeof(uint64_t) * (size_t)ntot)); BCHK(hipMalloc((void **)&key, sizeof(uint64_t) * (size_t)ntot));
+            BCHK(hipMalloc((void **)&val_in, sizeof(uint32_t) * (size_t)ntot));
+            hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, s, ntot, plo, phi, scene, key_in, val_in);
+            BCHK(hipcub::DeviceRadixSort::SortPairs(NULL, tmp_bytes, key_in, key, val_in, sorted, (int)ntot, 0, 64, s));
             BCHK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-            BCHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key_in, key, val_in, sorted, (int)n, 0, 63, s));
+            BCHK(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key_in, key, val_in, sorted, (int)ntot, 0, 64, s));
             mark("morton + radix sort");
+          if (n <= LH_MAX_LEAF_TRIS) {          /* a handful of live triangles among the dropped ones: one leaf over sorted[0 .. n) */
+            hipLaunchKernelGGL(k_single_leaf, dim3(1), dim3(64), 0, s, n, scene, glo, gst, q4);
+            nq = 1; level = 1;
+          } else {
             BCHK(hipMalloc((void **)&nodes, sizeof(BNode) * ((size_t)(n - 1) + cut_cap)));
             BCHK(hipMalloc((void **)&leaf_parent, sizeof(int) * (size_t)n));
             hipLaunchKernelGGL(k_radix_tree, dim3((n - 1 + 255) / 256), dim3(256), 0, s, (int)n, key, nodes, leaf_parent);
@@ -1112,9 +1149,10 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
                 *nq8 = n8; *q8_depth = lev8;
                 mark("collapse to 8-wide nodes");
             }
+          }
         }
     }
-    hipLaunchKernelGGL(k_tri32, dim3(nb), dim3(256), 0, s, n, (const uint32_t *)sorted, d_tri64, t32);
+    hipLaunchKernelGGL(k_tri32, dim3(nb), dim3(256), 0, s, ntot, (const uint32_t *)sorted, d_tri64, t32);
     BCHK(hipGetLastError());
     BCHK(hipStreamSynchronize(s));
     mark("tri32 records");

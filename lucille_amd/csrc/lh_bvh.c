@@ -77,6 +77,7 @@ typedef struct {
     int collecting;
     lh_tpool_t *pool;      /* the top of the tree (ranges of >= LH_PAR_MIN primitives while tasks are collected) runs its passes on it */
     uint32_t *tmp;          /* [n]: scratch of the parallel partition */
+    int drop_dead;          /* triangles the reference can never report stay out of the tree (tri_dead_class) */
 } build_ctx_t;
 
 static inline float down32(double d) { float f = (float)d; if ((double)f > d) f = nextafterf(f, -INFINITY); return f; }
@@ -397,25 +398,29 @@ typedef struct {
     int defer;               /* the serial pass over the top of the tree: subtree tasks are only given their place */
 } flat_t;
 
+/* the 48-byte filter record of primitive p */
+static void make_tri32(lh_tri32_t *o, const lh_tri64_t *t, uint32_t p)
+{
+    double e1[3], e2[3], n1, n2; int k;
+    for (k = 0; k < 3; k++) {
+        e1[k] = t->v[1][k] - t->v[0][k]; e2[k] = t->v[2][k] - t->v[0][k];
+        o->v0[k] = (float)t->v[0][k];
+    }
+    o->e1x = (float)e1[0]; o->e1y = (float)e1[1]; o->e1z = (float)e1[2];
+    o->e2x = (float)e2[0]; o->e2y = (float)e2[1]; o->e2z = (float)e2[2];
+    n1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    n2 = sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+    o->prim = p;
+    o->ne1 = up32(n1 * (1.0 + 1e-6));
+    o->ne2 = up32(n2 * (1.0 + 1e-6));
+}
+
 static int32_t emit_leaf(flat_t *f, const tnode_t *n)
 {
-    uint32_t first = f->next_tri, i; int k;
+    uint32_t first = f->next_tri, i;
     for (i = 0; i < n->count; i++) {
         uint32_t p = f->b->order[n->first + i];
-        const lh_tri64_t *t = &f->tri64[p];
-        lh_tri32_t *o = &f->out->tri32[f->next_tri++];
-        double e1[3], e2[3], n1, n2;
-        for (k = 0; k < 3; k++) {
-            e1[k] = t->v[1][k] - t->v[0][k]; e2[k] = t->v[2][k] - t->v[0][k];
-            o->v0[k] = (float)t->v[0][k];
-        }
-        o->e1x = (float)e1[0]; o->e1y = (float)e1[1]; o->e1z = (float)e1[2];
-        o->e2x = (float)e2[0]; o->e2y = (float)e2[1]; o->e2z = (float)e2[2];
-        n1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
-        n2 = sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
-        o->prim = p;
-        o->ne1 = up32(n1 * (1.0 + 1e-6));
-        o->ne2 = up32(n2 * (1.0 + 1e-6));
+        make_tri32(&f->out->tri32[f->next_tri++], &f->tri64[p], p);
     }
     f->nleaves++;
     return ~(int32_t)((first << 2) | (n->count - 1));
@@ -768,7 +773,35 @@ int lh_bvh_ensure_q8(lh_bvh_t *o)
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
-typedef struct { const lh_mesh_view_t *m; uint32_t g, p0; lh_bvh_t *out; build_ctx_t *b; volatile int err; } prep_job_t;
+typedef struct { const lh_mesh_view_t *m; uint32_t g, p0; lh_bvh_t *out; build_ctx_t *b; volatile int err; volatile int dead, dead_noise; } prep_job_t;
+
+/* Triangles the reference can NEVER report (triangle_isect, bvh.c:730-791: `if (fabs(a) > 1e-14) ... else return 0`, with
+ * a = e1 . (dir x e2) in fp64, no FMA), decided from the vertices alone -- they stay out of the TRAVERSAL tree (lucille's own tree,
+ * lh_refbvh.c, keeps them: its shape depends on them).  Why it matters: midpoint-tessellating a mesh with a collapsed edge (the ten
+ * apex "quads" of the example scene's cone) leaves 65 536 zero-area triangles along ONE segment per source triangle -- coincident
+ * boxes, hundreds of records per ray that comes near, and every one of them through the fp64 test, because an fp32 determinant
+ * of zero decides nothing (round 5: 2 000 pixels of the config-5 frame cost 100-1200 triangle records per AO ray, against 2.8).
+ *   class 1  v0 == v1 (e1 = 0): a = 0 * px + 0 * py + 0 * pz = 0 (or NaN if p overflowed): never > 1e-14.  Any ray.
+ *            v0 == v2 (e2 = 0): p = dir x 0 = 0 (NaN for an infinite dir), a = e1 . 0 = 0: never > 1e-14.  Any ray.
+ *   class 2  v1 == v2 (e1 == e2 =: e): a is rounding noise around the exact e . (dir x e) = 0.  With u = 2^-53, D = max |dir_k|,
+ *            S = |ex| + |ey| + |ez|: every component of the computed p is off by <= 2u(1+u) D S, so e . p_computed is off by
+ *            <= 2u(1+u) D S^2, and the three-term dot product adds <= 3u/(1-3u) (1+u)^2 D S^2: |a| < 5.01 u D S^2.  Dropped when
+ *            S^2 <= LH_DEG_S2CAP, so that |a| <= 1e-15 D S^2 <= 1e-14 for every ray with D <= LH_DEG_DCAP = 1024; a ray with a
+ *            larger direction component (unnormalised directions are legal, ray.h:22-68) is decided by the reference's own walk
+ *            on its own tree (lh_dev_scene_t.deg_dcap; lh_kernels.hip).
+ * Equality is numeric (== on doubles): +0 and -0 give differences of +-0, which the argument covers. */
+#define LH_DEG_DCAP  1024.0
+#define LH_DEG_S2CAP (1.0e-14 / (1.0e-15 * LH_DEG_DCAP))
+static int tri_dead_class(const lh_tri64_t *t)
+{
+    const double *a = t->v[0], *b = t->v[1], *c = t->v[2];
+    if ((a[0] == b[0] && a[1] == b[1] && a[2] == b[2]) || (a[0] == c[0] && a[1] == c[1] && a[2] == c[2])) return 1;
+    if (b[0] == c[0] && b[1] == c[1] && b[2] == c[2]) {
+        const double s = fabs(b[0] - a[0]) + fabs(b[1] - a[1]) + fabs(b[2] - a[2]);
+        if (s * s * (1.0 + 1e-9) <= LH_DEG_S2CAP) return 2;
+    }
+    return 0;
+}
 
 /* triangles [a0, a1) of one mesh: fp64 vertices, primitive -> (geom, index), fp32 outward box, centroid */
 static void prep_part(void *j_, int t, int nt)
@@ -801,6 +834,10 @@ static void prep_part(void *j_, int t, int nt)
             b->cen[3 * (size_t)p + k] = (float)(0.5 * (lo + hi));
         }
         b->order[p] = p;
+        if (b->drop_dead) {
+            const int dc = tri_dead_class(tr);
+            if (dc) { b->order[p] = 0xFFFFFFFFu; j->dead = 1; if (dc == 2) j->dead_noise = 1; }
+        }
     }
 }
 
@@ -820,6 +857,7 @@ int lh_bvh_build_hook(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmes
     const char *env;
 
     memset(out, 0, sizeof(*out));
+    out->deg_dcap = INFINITY;
     for (g = 0; g < nmeshes; g++) {
         const lh_mesh_view_t *m = &meshes[g];
         if (m->nindices && (!m->indices || !m->positions)) return -1;
@@ -848,15 +886,28 @@ int lh_bvh_build_hook(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmes
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 64) nthreads = 64;
     if (nthreads > 1 && n > 100000) b.pool = tpool_new(nthreads);
+    b.drop_dead = !((env = getenv("LH_DROP_DEGENERATE")) != NULL && atoi(env) == 0);
+    out->nlive = n; out->deg_dcap = INFINITY;
     {
-        uint32_t p = 0;
+        uint32_t p = 0; int any_dead = 0, any_noise = 0;
         for (g = 0; g < nmeshes; g++) {
             prep_job_t pj;
-            pj.m = &meshes[g]; pj.g = g; pj.p0 = p; pj.out = out; pj.b = &b; pj.err = 0;
+            pj.m = &meshes[g]; pj.g = g; pj.p0 = p; pj.out = out; pj.b = &b; pj.err = 0; pj.dead = 0; pj.dead_noise = 0;
             if (b.pool && pj.m->nindices / 3 >= LH_PAR_MIN) tpool_run(b.pool, prep_part, &pj);
             else prep_part(&pj, 0, 1);
             if (pj.err) { tpool_free(b.pool); free(b.plo); free(b.phi); free(b.cen); free(b.order); lh_bvh_release(out); return pj.err; }
             p += pj.m->nindices / 3;
+            any_dead |= pj.dead; any_noise |= pj.dead_noise;
+        }
+        if (any_dead) {
+            /* the tree is built over the live primitives: order[0 .. nlive); the dead ones keep their ids, their tri64 records
+             * (lucille's own tree and the reference walk read those) and the unreferenced tail of tri32 */
+            uint32_t m = 0, q;
+            for (q = 0; q < n; q++) if (b.order[q] != 0xFFFFFFFFu) b.order[m++] = q;
+            if (m == 0) { for (q = 0; q < n; q++) b.order[q] = q; m = n; any_noise = 0; }      /* nothing but zero-area triangles: as handed over */
+            else { uint32_t w = m; for (q = 0; q < n; q++) if (tri_dead_class(&out->tri64[q])) b.order[w++] = q; }
+            out->nlive = m; b.n = m;
+            if (any_noise) out->deg_dcap = LH_DEG_DCAP;
         }
     }
 
@@ -871,13 +922,13 @@ int lh_bvh_build_hook(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmes
     if (nthreads > 1 && n > 100000) {
         b.tmp = (uint32_t *)malloc(sizeof(uint32_t) * n);       /* NULL: the top of the tree partitions serially */
         b.collecting = 1;
-        b.task_threshold = n / (uint32_t)(nthreads * 8);
+        b.task_threshold = out->nlive / (uint32_t)(nthreads * 8);
         if (b.task_threshold < 4096) b.task_threshold = 4096;
         /* every range above the threshold is processed by the pool: no serial pass over more than LH_PAR_MIN primitives */
         if (b.pool && b.task_threshold < LH_PAR_MIN && n / LH_PAR_MIN >= (uint32_t)(2 * nthreads)) b.task_threshold = LH_PAR_MIN;
     }
     double t_prep = now_s();
-    build_range(&b, &main_arena, root, 0, n, 0);
+    build_range(&b, &main_arena, root, 0, out->nlive, 0);
     b.collecting = 0;
     tpool_free(b.pool); b.pool = NULL; free(b.tmp); b.tmp = NULL;
     double t_top = now_s();
@@ -936,6 +987,7 @@ int lh_bvh_build_hook(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmes
         free(w); free(th);
     }
     arena_free(&main_arena);
+    { uint32_t q; for (q = out->nlive; q < n; q++) make_tri32(&out->tri32[q], &out->tri64[b.order[q]], b.order[q]); }     /* the dropped triangles: records no leaf refers to */
     free(b.tasks); free(b.plo); free(b.phi); free(b.cen); free(b.order);
     {
         double t1 = now_s(), t2, t3;
@@ -986,13 +1038,14 @@ int lh_bvh_flatten(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmeshes
     uint64_t n64 = 0; uint32_t g, *first_prim; int t, nt, rc = 0;
     soup_job_t *jobs; pthread_t *th;
     memset(out, 0, sizeof(*out));
+    out->deg_dcap = INFINITY;
     for (g = 0; g < nmeshes; g++) {
         const lh_mesh_view_t *m = &meshes[g];
         if (m->nindices && (!m->indices || !m->positions)) return -1;
         n64 += m->nindices / 3;
     }
     if (n64 >= (1u << 29)) return -1;
-    out->ntris = (uint32_t)n64;
+    out->ntris = (uint32_t)n64; out->nlive = (uint32_t)n64;
     if (n64 == 0) return 0;
     out->tri64 = (lh_tri64_t *)malloc(sizeof(lh_tri64_t) * (size_t)n64);
     out->prim_geom = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n64);

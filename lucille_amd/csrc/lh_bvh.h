@@ -87,6 +87,8 @@ typedef struct lh_bvh {
     uint32_t    nq8nodes, q8_depth;
     float       grid_lo[3], grid_step[3];   /* the 16-bit grid of q4nodes / q8nodes */
     double      build_seconds;
+    uint32_t    nlive;         /* primitives in the leaves of the traversal tree: ntris minus the triangles the reference can never report (lh_bvh.c tri_dead_class) */
+    double      deg_dcap;      /* rays with a direction component beyond this are decided by the reference's own walk (INFINITY: no such limit) */
 } lh_bvh_t;
 
 typedef struct lh_mesh_view {

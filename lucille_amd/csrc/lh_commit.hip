@@ -73,6 +73,7 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     env = getenv("LH_RAY_BUDGET");
     if (env && atoi(env) > 0) a->dev.ray_budget = (uint32_t)atoi(env);
     a->dev.top_nodes = LH_TOP_AUTO;
+    a->dev.deg_dcap = INFINITY;
     a->dev.ao_group = 0;            /* measured: the grouped order is SLOWER on the config-5 frame (84.6 -> 95.1 ms, tools/ao_group_probe.py): a slot's own rays share their first levels */
     env = getenv("LH_AO_GROUP");
     if (env && atoi(env) >= 0 && atoi(env) <= 4096) a->dev.ao_group = (uint32_t)atoi(env);
@@ -379,7 +380,7 @@ static int host_build(lh_accel_t *a, int build_threads, bool on_device, bool kee
 extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q4nodes, uint32_t *nq4, uint32_t *q4_depth, uint32_t *q4_stack,
                                int want_q8, void **d_q8nodes, uint32_t *nq8, uint32_t *q8_depth,
                                void **d_tri32, float bmin[3], float bmax[3], float grid_lo[3], float grid_step[3],
-                               void *stream, char *err, size_t errlen);                /* lh_build.hip */
+                               uint32_t *nlive, double *deg_dcap, void *stream, char *err, size_t errlen);                /* lh_build.hip */
 
 /* flag = 1 if the two word arrays differ anywhere */
 __global__ void k_words_differ(size_t nwords, const uint32_t *__restrict__ x, const uint32_t *__restrict__ y, int *__restrict__ flag)
@@ -400,7 +401,7 @@ static int device_rebuild_q8(lh_accel_t *a)
     void *q4 = NULL, *q8 = NULL, *t32 = NULL; int *flag = NULL, h_flag = 0;
     uint32_t nq4 = 0, d4 = 0, st4 = 0, nq8 = 0, d8 = 0; float bmin[3], bmax[3], glo[3], gst[3];
     const int rcb = lh_device_build(hs->bvh.ntris, (const double *)a->d_tri64, &q4, &nq4, &d4, &st4, 1, &q8, &nq8, &d8, &t32, bmin, bmax, glo, gst,
-                                    (void *)a->stream, berr, sizeof(berr));
+                                    NULL, NULL, (void *)a->stream, berr, sizeof(berr));
     if (rcb != 0) return fail("building the 8-wide nodes on the device failed: %s", berr);
     int rc = 0;
     if (q8) {
@@ -599,8 +600,9 @@ static int device_upload(lh_accel_t *a)
              * that re-commits every frame and never dumps does not pay for them */
             const int want_q8 = a->wide8 == 1;
             const double tb = now_s();
+            uint32_t nlive = hs->bvh.ntris; double dcap = INFINITY;
             const int rcb = lh_device_build(hs->bvh.ntris, (const double *)a->d_tri64, &a->d_q4nodes, &nq4, &d4, &st4, want_q8, &a->d_q8nodes, &nq8, &d8, &a->d_tri32, bmin, bmax, glo, gst,
-                                            (void *)a->stream, berr, sizeof(berr));
+                                            &nlive, &dcap, (void *)a->stream, berr, sizeof(berr));
             if (rcb == -2) return fail("lh_accel_commit: a vertex coordinate is NaN, infinite or beyond 1e30");
             if (rcb != 0 && a->build_auto && !hs->ref_on_device) {
                 if (getenv("LH_BUILD_TIMING")) fprintf(stderr, "[lucille_hip] commit: device build failed (%s): host builders\n", berr);
@@ -609,6 +611,7 @@ static int device_upload(lh_accel_t *a)
             if (rcb != 0) return fail("device BVH build failed: %s", berr);
             pthread_mutex_lock(&g_scene_mu);
             hs->bvh.nq4nodes = nq4; hs->bvh.q4_depth = d4; hs->bvh.q4_stack = st4; hs->bvh.nnodes = nq4; hs->bvh.max_depth = d4; hs->bvh.build_seconds = now_s() - tb;
+            hs->bvh.nlive = nlive; hs->bvh.deg_dcap = dcap;
             for (int k = 0; k < 3; k++) { hs->bvh.bmin[k] = bmin[k]; hs->bvh.bmax[k] = bmax[k]; hs->bvh.grid_lo[k] = glo[k]; hs->bvh.grid_step[k] = gst[k]; }
             pthread_mutex_unlock(&g_scene_mu);
             a->dev.q4nodes = a->d_q4nodes;
@@ -626,6 +629,7 @@ static int device_upload(lh_accel_t *a)
         a->dev.tri32 = a->d_tri32; a->dev.tri64 = a->d_tri64;
         a->dev.ntris = hs->bvh.ntris; a->dev.nnodes = hs->bvh.nnodes;
         a->dev.max_depth = hs->bvh.max_depth; a->dev.scene_r = r; a->dev.ray_chunk = a->ray_chunk;
+        a->dev.deg_dcap = hs->bvh.deg_dcap < 3.0e38 ? (float)hs->bvh.deg_dcap : INFINITY;
         for (int k = 0; k < 3; k++) { a->dev.grid_lo[k] = hs->bvh.grid_lo[k]; a->dev.grid_step[k] = hs->bvh.grid_step[k]; }
         if (hs->have_ref && __atomic_load_n(&hs->ref_state, __ATOMIC_ACQUIRE) == 2 && attach_ref(a) != 0) return -1;
         a->dev.nq4nodes = hs->bvh.nq4nodes; a->dev.q4_depth = hs->bvh.q4_depth; a->dev.q4_stack = hs->bvh.q4_stack;
@@ -795,6 +799,7 @@ extern "C" int lh_accel_info(const lh_accel_t *a, lh_accel_info_t *o)
     o->device = a->device;
     o->ref_build_seconds = a->hs->ref_build_seconds;
     o->nnodes_traversal = a->hs->bvh.nq4nodes;
+    o->ntriangles_in_tree = a->hs->bvh.ntris ? a->hs->bvh.nlive : 0u;
     return 0;
 }
 
@@ -880,6 +885,7 @@ int lh_scene_image_header(lh_accel_t *a, lh_scene_image_t *h)
         h->ref_bmin[k] = a->dev.ref_bmin[k]; h->ref_bmax[k] = a->dev.ref_bmax[k];
     }
     h->build_seconds = hs->bvh.build_seconds; h->ref_build_seconds = hs->ref_build_seconds;
+    h->nlive = hs->bvh.nlive; h->deg_dcap = hs->bvh.deg_dcap;
     return 0;
 }
 
@@ -927,6 +933,8 @@ int lh_scene_image_alloc(lh_accel_t *a, const lh_scene_image_t *h)
     hs->bvh.ntris = h->ntris; hs->bvh.nnodes = h->nnodes; hs->bvh.max_depth = h->max_depth; hs->bvh.nleaves = h->nleaves;
     hs->bvh.nq4nodes = h->nq4; hs->bvh.q4_depth = h->q4_depth; hs->bvh.q4_stack = h->q4_stack; hs->nmeshes = h->nmeshes;
     hs->bvh.build_seconds = h->build_seconds; hs->ref_build_seconds = h->ref_build_seconds;
+    hs->bvh.nlive = h->nlive; hs->bvh.deg_dcap = h->deg_dcap;
+    a->dev.deg_dcap = h->deg_dcap < 3.0e38 ? (float)h->deg_dcap : INFINITY;
     hs->have_ref = h->have_ref; hs->ref_state = h->have_ref ? 2 : 0;
     float r = 0.0f;
     for (int k = 0; k < 3; k++) {

@@ -38,6 +38,9 @@ typedef struct lh_dev_scene {
     uint32_t    nnodes;
     uint32_t    max_depth;
     float       scene_r;   /* max |coordinate| of the scene box              */
+    float       deg_dcap;  /* a ray with a direction component beyond this is decided by the reference's own walk: the traversal tree leaves out
+                              zero-area triangles whose fp64 determinant is provably below the reference's 1e-14 only up to there (lh_bvh.c
+                              tri_dead_class); INFINITY: no such triangle in this scene */
     uint32_t    ray_chunk; /* rays a persistent wave reserves per atomic on the global cursor */
     uint32_t    ray_budget;/* wave iterations after which a ray leaves the persistent walk for the cooperative one */
     int         stack_guard;    /* set by the launchers when the LDS rows do not cover the tree's worst case: the walks check before they push */

@@ -41,6 +41,7 @@
 
 #define DFAIL(...) lh_fail(__VA_ARGS__)
 
+
 struct rccl_api {
     void *lib;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *);
@@ -103,7 +104,7 @@ static int shm_barrier(lh_dist_t *d)
      * sharded frame pays (tools/skew_probe.py) */
     const double t0 = now_sec();
     for (int spins = 0; __atomic_load_n(&c->generation, __ATOMIC_ACQUIRE) == gen; spins++) {
-        if ((spins & 255) != 255) { __builtin_ia32_pause(); continue; }
+        if ((spins & 255) != 255) { LH_CPU_RELAX(); continue; }
         const double dt = now_sec() - t0;
         if (dt < 3.0e-3) continue;                    /* 3 ms of watching: ranks that render shares of one frame arrive within that */
         usleep(20);
@@ -162,6 +163,27 @@ static void name_from_id(const void *id128, char *out, size_t n)
     snprintf(out, n, "/lh_dist_%016llx", h);
 }
 
+/* an id of the host this process runs on: ranks with the same id can meet in one POSIX shared-memory segment */
+static unsigned long long host_id(void)
+{
+    char buf[320]; memset(buf, 0, sizeof(buf));
+    (void)gethostname(buf, 255);
+    FILE *f = fopen("/proc/sys/kernel/random/boot_id", "r");          /* two containers may share a hostname, never a boot id + hostname + /dev/shm */
+    if (f) { if (!fgets(buf + 256, 63, f)) buf[256] = 0; fclose(f); }
+    unsigned long long h = 1469598103934665603ull;
+    for (size_t k = 0; k < sizeof(buf); k++) { h ^= (unsigned char)buf[k]; h *= 1099511628211ull; }
+    return h ? h : 1ull;
+}
+
+static void dist_teardown(lh_dist_t *d)
+{
+    if (d->ctl) munmap((void *)d->ctl, 4096);
+    if (d->transport == LH_DIST_RCCL && d->comm) (void)g_rccl.CommDestroy(d->comm);
+    lh_free_buf(&d->agree);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    free(d);
+}
+
 extern "C" int lh_dist_init(lh_dist_t **out, const void *id128, int rank, int world, int device, int transport)
 {
     if (!out || !id128) return DFAIL("lh_dist_init: NULL argument");
@@ -171,21 +193,41 @@ extern "C" int lh_dist_init(lh_dist_t **out, const void *id128, int rank, int wo
     lh_dist_t *d = (lh_dist_t *)calloc(1, sizeof(*d));
     if (!d) return DFAIL("out of memory");
     d->rank = rank; d->world = world; d->device = device; d->transport = transport;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { free(d); return DFAIL("lh_dist_init: cannot use device %d", device); }
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) { d->stream = NULL; dist_teardown(d); return DFAIL("lh_dist_init: cannot use device %d", device); }
+    bool one_host = true;                /* the shared-memory transport is one host by construction */
     if (transport == LH_DIST_RCCL) {
-        if (rccl_load() != 0) { (void)hipStreamDestroy(d->stream); free(d); return -1; }
+        if (rccl_load() != 0) { dist_teardown(d); return -1; }
         ncclUniqueId id; memcpy(&id, id128, LH_DIST_ID_BYTES);
         ncclResult_t r = g_rccl.CommInitRank(&d->comm, world, id, rank);
-        if (r != ncclSuccess) { (void)hipStreamDestroy(d->stream); free(d); return DFAIL("ncclCommInitRank failed: %s (two ranks on one device? use LH_DIST_SHM)", g_rccl.GetErrorString(r)); }
+        if (r != ncclSuccess) { d->comm = NULL; dist_teardown(d); return DFAIL("ncclCommInitRank failed: %s (two ranks on one device? use LH_DIST_SHM)", g_rccl.GetErrorString(r)); }
+        /* do all ranks run on ONE host?  (RCCL itself spans nodes; the shared control block below does not: ranks of a second node
+         * would wait in its barrier for arrivals that never come.)  Every rank's host id to rank 0 and the table back, over the
+         * communicator that has just come up */
+        if (world > 1) {
+            const size_t tb = sizeof(unsigned long long) * (size_t)world;
+            std::vector<unsigned long long> ids((size_t)world, 0ull);
+            const unsigned long long mine = host_id();
+            int rc = lh_ensure_buf(&d->agree, 2 * tb + 64);
+            char *base = (char *)d->agree.p;
+            if (rc == 0) rc = hipMemcpyAsync(base, &mine, sizeof(mine), hipMemcpyHostToDevice, d->stream) == hipSuccess ? 0 : -1;
+            if (rc == 0) rc = lh_dist_gather(d, base, sizeof(mine), base + 64, (void *)d->stream);
+            if (rc == 0) rc = lh_dist_broadcast(d, base + 64, tb, (void *)d->stream);
+            if (rc == 0) rc = hipMemcpyAsync(ids.data(), base + 64, tb, hipMemcpyDeviceToHost, d->stream) == hipSuccess ? 0 : -1;
+            if (rc == 0) rc = hipStreamSynchronize(d->stream) == hipSuccess ? 0 : -1;
+            if (rc != 0) { dist_teardown(d); return DFAIL("lh_dist_init: the ranks could not exchange their host ids over RCCL"); }
+            for (int r2 = 0; r2 < world; r2++) if (ids[(size_t)r2] != mine) one_host = false;
+        }
     }
-    {   /* the job's control block in shared memory: the shm transport's barrier -- and, for BOTH transports, the host barrier of
-         * the ranks of one node (lh_dist_host_barrier: what brackets a timed frame) */
+    if (one_host) {
+        /* the job's control block in shared memory: the shm transport's barrier -- and, for BOTH transports, the host barrier of
+         * the ranks of one node (lh_dist_host_barrier: what brackets a timed frame).  Ranks on more than one host (RCCL only) have
+         * none: lh_dist_host_barrier falls back to the transport's own barrier there */
         name_from_id(id128, d->shm_name, sizeof(d->shm_name));
         int fd = shm_open(d->shm_name, O_CREAT | O_RDWR, 0600);       /* a fresh segment reads as zeros */
-        if (fd < 0 || ftruncate(fd, 4096) != 0) { if (fd >= 0) close(fd); (void)hipStreamDestroy(d->stream); free(d); return DFAIL("lh_dist (shm): cannot create %s: %s", d->shm_name, strerror(errno)); }
+        if (fd < 0 || ftruncate(fd, 4096) != 0) { if (fd >= 0) close(fd); dist_teardown(d); return DFAIL("lh_dist (shm): cannot create %s: %s", d->shm_name, strerror(errno)); }
         d->ctl = (shm_ctl *)mmap(NULL, 4096, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0); close(fd);
-        if ((void *)d->ctl == MAP_FAILED) { (void)hipStreamDestroy(d->stream); free(d); return DFAIL("lh_dist (shm): mmap failed"); }
-        if (shm_barrier(d) != 0) { munmap((void *)d->ctl, 4096); (void)hipStreamDestroy(d->stream); free(d); return -1; }
+        if ((void *)d->ctl == MAP_FAILED) { d->ctl = NULL; dist_teardown(d); return DFAIL("lh_dist (shm): mmap failed"); }
+        if (shm_barrier(d) != 0) { dist_teardown(d); return -1; }
     }
     *out = d;
     return 0;
@@ -316,7 +358,7 @@ extern "C" int lh_dist_gather(lh_dist_t *d, const void *d_send, size_t bytes, vo
 extern "C" int lh_dist_host_barrier(lh_dist_t *d)
 {
     if (!d) return DFAIL("lh_dist_host_barrier: NULL");
-    if (!d->ctl) return DFAIL("lh_dist_host_barrier: no shared control block");
+    if (!d->ctl) return lh_dist_barrier(d);          /* RCCL ranks on more than one host: the transport's own barrier */
     return shm_barrier(d);
 }
 

@@ -132,6 +132,15 @@ struct lh_guard {
 };
 
 
+/* a spin-wait hint that is not x86-only */
+#if defined(__x86_64__) || defined(__i386__)
+#define LH_CPU_RELAX() __builtin_ia32_pause()
+#elif defined(__aarch64__)
+#define LH_CPU_RELAX() __asm__ __volatile__("yield")
+#else
+#define LH_CPU_RELAX() ((void)0)
+#endif
+
 static inline double lh_now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 #define now_s lh_now_s
 
@@ -150,6 +159,7 @@ typedef struct lh_scene_image {
     int      have_ref, ref_empty, has_nrm, has_attr[3], has_st, has_inside;
     float    bmin[3], bmax[3], grid_lo[3], grid_step[3];
     double   ref_bmin[3], ref_bmax[3], build_seconds, ref_build_seconds;
+    double   deg_dcap; uint32_t nlive, pad_;        /* lh_bvh_t: the triangles outside the traversal tree and the rays that need the reference walk for them */
 } lh_scene_image_t;
 int  lh_scene_image_header(lh_accel_t *a, lh_scene_image_t *h);
 int  lh_scene_image_arrays(lh_accel_t *a, const lh_scene_image_t *h, void **ptr, size_t *bytes, int cap);

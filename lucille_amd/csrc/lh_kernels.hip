@@ -400,6 +400,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_direct(
     uint32_t cn = 0, ct = 0, ce = 0;
     lane_init(L, sc, ox, oy, oz, dx, dy, dz);
     stk[0][tid] = kDone;
+    if (__builtin_expect(ray_needs_ref_walk(sc, dx, dy, dz), 0)) LH_FORCE_REF_WALK(L, best);
     traverse<ANYHIT, COUNT>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce);
     finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
     write_out<ANYHIT>(i, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL);
@@ -574,6 +575,7 @@ __device__ __forceinline__ void trace_persist_lane(
                 lane_init(L, sc, ox, oy, oz, dx, dy, dz);
                 best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM; best.frag = 0u;
                 stk[0][tid] = kDone;
+                if (SRC == 0 && __builtin_expect(ray_needs_ref_walk(sc, dx, dy, dz), 0)) LH_FORCE_REF_WALK(L, best);      /* camera and AO rays are unit vectors */
                 it0 = it;
             }
             wbase += take;
@@ -879,7 +881,9 @@ __device__ void overflow_walk(const lh_dev_scene_t &sc, size_t i, const double *
     int stack[LH_COOP_ROWS_MAX]; int sp = 0;
     lane_init(L, sc, ox, oy, oz, dx, dy, dz);
     int cur = 0;
-    for (;;) {
+    const bool refw = ray_needs_ref_walk(sc, dx, dy, dz);          /* the reference's own walk decides (lh_walk.h) */
+    if (refw) { best.prim = 0u; best.frag = 1u; }
+    else for (;;) {
         if (cur >= 0) {
             const uint4 *p = (const uint4 *)sc.q4nodes + 4 * (size_t)cur;
             const uint4 a = p[0], b = p[1], c = p[2], r = p[3];
@@ -1084,21 +1088,25 @@ uint32_t coop_rows(const lh_dev_scene_t &sc)
 uint32_t top_nodes_for(const lh_dev_scene_t &sc, uint32_t rows)
 {
     uint32_t want = sc.top_nodes;
-    if (want == LH_TOP_AUTO) {
-        /* the CU's 160 KiB also hold the workgroup of the cooperative walk that runs NEXT TO this launch (k_coop_walk: one wave,
-         * a ring of coop_rows x 64 entries): its stream has the higher priority, so it is placed first -- a persistent workgroup
-         * that no longer fits beside it is one workgroup per CU fewer for the whole launch (r04: 2 240 -> 1 680 Mrays/s, the
-         * config-5 frame 85 -> 128 ms with every spare byte given to the top of the tree) */
-        const uint32_t crows = coop_rows(sc);
-        const uint32_t coop = crows ? (crows * 64u + 128u) * (uint32_t)sizeof(int) + 1024u : 0u;
-        const uint32_t cu = 160u * 1024u - coop, stack = rows * LH_BLOCK * (uint32_t)sizeof(int);
-        uint32_t wgs = (160u * 1024u) / stack;      /* what size_grid() launches per CU */
-        if (wgs > 4u) wgs = 4u;                     /* 128 VGPRs: four workgroups per CU at most */
-        if (wgs == 0u || cu < wgs * stack) return 0u;
-        const uint32_t spare = (cu / wgs - stack) / 64u;
-        want = spare < LH_TOP_NODES_MAX ? spare : LH_TOP_NODES_MAX;
-        want &= ~15u;
-    }
+    if (want == 0u) return 0u;
+    /* the CU's 160 KiB also hold the workgroup of the cooperative walk that runs NEXT TO this launch (k_coop_walk: one wave,
+     * a ring of coop_rows x 64 entries): its stream has the higher priority, so it is placed first -- a persistent workgroup
+     * that no longer fits beside it is one workgroup per CU fewer for the whole launch (r04: 2 240 -> 1 680 Mrays/s, the
+     * config-5 frame 85 -> 128 ms with every spare byte given to the top of the tree).  A count set by the caller is held to
+     * the same room (512 nodes beside 34 dense rows made 4 x 43 KiB and silently dropped a workgroup per CU) */
+    const uint32_t crows = coop_rows(sc);
+    const uint32_t coop = crows ? (crows * 64u + 128u) * (uint32_t)sizeof(int) + 1024u : 0u;
+    const uint32_t cu = 160u * 1024u - coop, stack = rows * LH_BLOCK * (uint32_t)sizeof(int);
+    uint32_t wgs = (160u * 1024u) / stack;      /* what size_grid() launches per CU */
+    if (wgs > 4u) wgs = 4u;                     /* 128 VGPRs: four workgroups per CU at most */
+    if (wgs == 0u || cu < wgs * stack) return 0u;
+    uint32_t spare = (cu / wgs - stack) / 64u;
+    /* a workgroup above 64 KiB of LDS halves what a CU holds (lh_device.h): the copy never takes a launch across that line (the
+     * small launches' up to 64 unchecked rows are 64 KiB by themselves: no copy there) */
+    if (stack <= 64u * 1024u) { const uint32_t room = (64u * 1024u - stack) / 64u; if (spare > room) spare = room; }
+    if (spare > LH_TOP_NODES_MAX) spare = LH_TOP_NODES_MAX;
+    if (want == LH_TOP_AUTO || want > spare) want = spare;
+    want &= ~15u;
     return want < sc.nq4nodes ? want : sc.nq4nodes;
 }
 
@@ -1236,7 +1244,7 @@ extern "C" int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double 
     uint32_t need; int walk; bool guard = false;
     if ((sc->cam_src || sc->n_dev) && (variant == LH_VARIANT_DIRECT || anyhit || q == NULL)) return -1;      /* the path tracer's chain: default walk, closest hit */
     static const bool small_ok = !(getenv("LH_SMALL_BATCH") && atoi(getenv("LH_SMALL_BATCH")) == 0);      /* LH_SMALL_BATCH=0: rounds 1-3's path for a handful of rays (A/B) */
-    if (((n <= LH_SMALL_BATCH && small_ok) || sc->diag_out) && variant != LH_VARIANT_DIRECT && !sc->cam_src && !sc->n_dev && !sc->stack_cap && sc->q4nodes) {
+    if (((n <= LH_SMALL_BATCH && small_ok) || sc->diag_out) && variant != LH_VARIANT_DIRECT && !sc->cam_src && !sc->n_dev && (sc->diag_out || !sc->stack_cap) && sc->q4nodes) {      /* the sequential walk has a private stack: a capped LDS stack (tests) does not concern per-ray diagnostics */
         /* a handful of rays (the coalesced one-ray callers): one small launch, a wave per ray, no queue, no cursors.
          * Per-ray diagnostics (diag_out): the same walk for a batch of any size, a lane per ray */
         if (n <= LH_SMALL_BATCH) {

@@ -402,7 +402,7 @@ static int comb_create(lh_accel_t *a)
     }
     pthread_mutex_init(&c->mu, NULL); pthread_cond_init(&c->cv, NULL);
     c->expect = 1;
-    a->comb = c;
+    __atomic_store_n(&a->comb, c, __ATOMIC_RELEASE);          /* published last: a caller that sees the pointer (acquire) sees the mutex and the block pointers */
     return 0;
 }
 
@@ -445,14 +445,15 @@ extern "C" int lh_accel_intersect1(lh_accel_t *a, const double org[3], const dou
     uint32_t p = LH_MISS_PRIM; double tt = LH_T_INF, uu = 0.0, vv = 0.0;
     if (!a || !a->committed) return fail("lh_accel_intersect1: accel not committed");
     if (!org || !dir) return fail("lh_accel_intersect1: NULL ray");
-    if (!a->combine || a->stat_on) {         /* statistics are per launch: counted launches stay one ray each */
+    if (!__atomic_load_n(&a->combine, __ATOMIC_RELAXED) || __atomic_load_n(&a->stat_on, __ATOMIC_RELAXED)) {         /* statistics are per launch: counted launches stay one ray each */
         if (lh_accel_intersect_host(a, 1, org, dir, &p, &tt, &uu, &vv, NULL, LH_MODE_CLOSEST) != 0) return -1;
     } else {
-        if (!a->comb) {
+        lh_combiner *c = __atomic_load_n(&a->comb, __ATOMIC_ACQUIRE);
+        if (!c) {
             lh_guard guard(a);
             if (!a->comb) { HIPCHK(hipSetDevice(a->device)); if (comb_create(a) != 0) return -1; }
+            c = a->comb;
         }
-        lh_combiner *c = a->comb;
         int rc = 0;
         pthread_mutex_lock(&c->mu);
         while (c->n_pending >= LH_COMB_CAP) pthread_cond_wait(&c->cv, &c->mu);
@@ -497,7 +498,7 @@ extern "C" int lh_accel_intersect1(lh_accel_t *a, const double org[3], const dou
                 static const double spin_us = getenv("LH_COMB_SPIN_US") ? atof(getenv("LH_COMB_SPIN_US")) : 300.0;
                 const double t0 = lh_now_s(); int spins = 0;
                 if (spin_us > 0.0) while (__atomic_load_n(&c->done_gen, __ATOMIC_ACQUIRE) <= g && !(__atomic_load_n(&c->leader_active, __ATOMIC_RELAXED) == 0 && __atomic_load_n(&c->open_gen, __ATOMIC_RELAXED) == g)) {
-                    __builtin_ia32_pause();
+                    LH_CPU_RELAX();
                     if ((++spins & 255) == 0 && lh_now_s() - t0 > spin_us * 1e-6) break;
                 }
             }
@@ -574,6 +575,29 @@ extern "C" int lh_accel_intersect_diag_host(lh_accel_t *a, size_t n, const doubl
         a->stat[0] += h[LH_CNT_NODES]; a->stat[1] += h[LH_CNT_TRIS]; a->stat[2] += h[LH_CNT_EXACT]; a->stat[3] += n; a->stat[4] += nh;
     }
     return 0;
+}
+
+/* the same for rays resident on the device, closest- or any-hit: d_diag n x 4 u32 (see lh_accel_intersect_diag_host); the hit
+ * records go to the accelerator's staging block and are dropped.  What a cost map of a frame is made of (tools/ao_cost_map.py). */
+extern "C" int lh_accel_intersect_diag_device(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, int mode, void *d_diag, void *stream)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("intersect_diag_device: accel not committed");
+    if (n == 0) return 0;
+    if (!d_org || !d_dir || !d_diag) return fail("intersect_diag_device: NULL argument");
+    if (mode != LH_MODE_CLOSEST && mode != LH_MODE_ANY) return fail("intersect_diag_device: unknown mode %d", mode);
+    if (n > 0x7fffffffull) return fail("intersect_diag_device: more than 2^31 rays");
+    HIPCHK(hipSetDevice(a->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (a->hs->bvh.ntris == 0) { HIPCHK(hipMemsetAsync(d_diag, 0, sizeof(uint32_t) * 4 * n, s)); return 0; }
+    const size_t b_d = sizeof(double) * n;
+    if (lh_ensure_stage(a, 3 * b_d + sizeof(uint32_t) * n + n + 64) != 0) return -1;
+    double *d_t = (double *)a->d_stage, *d_u = d_t + n, *d_v = d_u + n;
+    uint32_t *d_prim = (uint32_t *)(d_v + n); uint8_t *d_occ = (uint8_t *)(d_prim + n);
+    a->dev.diag_out = (uint32_t *)d_diag;
+    const int rc = lh_launch(a, n, d_org, d_dir, d_prim, d_t, d_u, d_v, d_occ, mode, LH_VARIANT_SPEC, NULL, s, true);
+    a->dev.diag_out = NULL;
+    return rc;
 }
 
 /* ------------------------------------------------------------------------ */

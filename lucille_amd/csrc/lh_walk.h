@@ -83,6 +83,17 @@ __device__ __forceinline__ void lane_init(Lane &L, const lh_dev_scene_t &sc,
 }
 
 
+/* A ray the traversal tree cannot answer by itself: the tree leaves out zero-area triangles of class 2 (v1 == v2; lh_bvh.c
+ * tri_dead_class), whose fp64 determinant in the reference is provably below its 1e-14 only while every direction component
+ * stays below sc.deg_dcap.  Beyond that (unnormalised directions are legal, ray.h:22-68) the reference's own walk on its own
+ * tree -- which holds every triangle -- decides: the callers mark the ray as a fragile hit before it takes a step, and the
+ * fix-up machinery (LH_Q_REF / LH_PRIM_RETRACE) does the rest.  deg_dcap is INFINITY for scenes without such triangles. */
+__device__ __forceinline__ bool ray_needs_ref_walk(const lh_dev_scene_t &sc, double dx, double dy, double dz)
+{
+    return (fmax(fabs(dx), fmax(fabs(dy), fabs(dz))) > (double)sc.deg_dcap) & (sc.ref_nodes != NULL);
+}
+#define LH_FORCE_REF_WALK(L, best) do { (L).cur = kDone; (best).prim = 0u; (best).frag = 1u; } while (0)
+
 /* lh_slab_w (lh_filter.h) written for the VALU: per axis one rotate (v_alignbit_b32 by 0 or 16)
  * puts (near, far) into the (low, high) halves, two SDWA converts, two FMAs: 136 VALU ops per
  * 4-wide node step instead of 161 with per-plane selects.  Measured (A/B, 50 M rays): +1.5 %;

@@ -75,7 +75,54 @@ def test_coincident_and_degenerate_triangles():
     idx = np.arange(P.shape[0], dtype=np.uint32)
     m = Model(P, idx)
     seen, maxd = walk(m.nodes(), m.tri32(), P[idx].reshape(-1, 9))
-    assert sorted(seen) == list(range(360)) and m.max_depth <= 60
+    # round 5: a triangle with two EQUAL vertices can never be reported by the reference (triangle_isect, bvh.c:754: its
+    # determinant is exactly zero) and stays out of the traversal tree (lh_bvh.c tri_dead_class); a zero-area triangle with
+    # three different vertices stays in
+    assert sorted(seen) == list(range(300)) + list(range(350, 360)) and m.max_depth <= 60
+    # ... their records are still there (unreferenced, behind the live ones): every primitive has one
+    assert sorted(m.tri32()[:, 9].view(np.uint32).tolist()) == list(range(360))
+
+
+def test_zero_area_triangles_outside_the_tree_do_not_change_a_record():
+    """the example scene's cone has ten collapsed "quads" at its apex (v0 == v1); tessellated, each leaves hundreds of zero-area
+    triangles along one segment.  With them outside the tree every record is still the oracle's, bit for bit -- also for rays
+    aimed at those segments -- and the tree is smaller"""
+    import os
+    from tests.helpers import load_golden
+    from lucille_amd import scenes
+    g = load_golden("ao_c1")
+    P, idx = scenes.tessellate(g["pos0"], g["idx0"], 3)          # geom 0 = the cone: 20 triangles -> 1280, half of them zero-area
+    T = P[idx].reshape(-1, 3, 3)
+    zero = ((T[:, 0] == T[:, 1]).all(1) | (T[:, 0] == T[:, 2]).all(1) | (T[:, 1] == T[:, 2]).all(1))
+    assert zero.sum() == 640
+    # v0 == v1 or v0 == v2: the reference's determinant is exactly 0 for any ray; v1 == v2: rounding noise, provably below its
+    # 1e-14 for |dir| components <= 1024 only if (|ex| + |ey| + |ez|)^2 <= 10 / 1024 (lh_bvh.c tri_dead_class) -- at three
+    # levels of subdivision only some of those edges are that short
+    s1 = np.abs(T[:, 1] - T[:, 0]).sum(1)
+    dead = (T[:, 0] == T[:, 1]).all(1) | (T[:, 0] == T[:, 2]).all(1) | ((T[:, 1] == T[:, 2]).all(1) & (s1 * s1 * (1 + 1e-9) <= 10.0 / 1024.0))
+    assert 300 < dead.sum() <= 640
+    m = Model(P, idx)
+    seen, _ = walk(m.nodes(), m.tri32(), P[idx].reshape(-1, 9))
+    assert sorted(seen) == np.nonzero(~dead)[0].tolist()
+    rng = np.random.default_rng(7)
+    n = 4000
+    # rays from outside aimed at points ON the degenerate segments (apex -> base vertices), and random ones
+    seg = T[zero][rng.integers(0, zero.sum(), n)]
+    target = seg[:, 0] + (seg[:, 2] - seg[:, 0]) * rng.random((n, 1)) + (seg[:, 1] - seg[:, 0]) * rng.random((n, 1))
+    org = target + rng.normal(size=(n, 3)) * 3.0
+    dr = target - org
+    dr[n // 2:] += rng.normal(size=(n - n // 2, 3)) * 0.05
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr)
+    m.ref_build()            # the segments are edges of live triangles too: exact-t ties follow lucille's own tree (which keeps every triangle)
+    try:
+        got, _ = m.trace(org, dr)
+    finally:
+        Model.ref_off()
+    assert np.array_equal(got[0], exp[0])
+    for k in (1, 2, 3):
+        assert np.array_equal(got[k], exp[k])
+    assert (exp[0] != po.MISS).sum() > 100
 
 
 def test_indexed_mesh_shared_vertices():

@@ -1,0 +1,94 @@
+"""Zero-area triangles with two EQUAL vertices stay out of the traversal tree (round 5; lh_bvh.c tri_dead_class, lh_build.hip
+k_prim_boxes): the reference's determinant test (triangle_isect, bvh.c:754) rejects them for every ray -- exactly for v0 == v1
+and v0 == v2, provably up to direction components of 1024 for v1 == v2 with short edges, and beyond that the reference's own
+walk on its own tree decides (lh_walk.h ray_needs_ref_walk).  Hit records must not change by a bit, on either builder."""
+import os
+
+import numpy as np
+import pytest
+
+import lucille_amd as la
+from lucille_amd import scenes
+from oracle import pyoracle as po
+from tests.helpers import assert_hits_equal, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def cone(levels):
+    g = load_golden("ao_c1")
+    P, I = scenes.tessellate(g["pos0"], g["idx0"], levels)        # the example scene's cone: ten collapsed apex "quads" (v0 == v1)
+    T = P[I.astype(np.int64)].reshape(-1, 3, 3)
+    s1 = np.abs(T[:, 1] - T[:, 0]).sum(1)
+    zero = (T[:, 0] == T[:, 1]).all(1) | (T[:, 0] == T[:, 2]).all(1) | (T[:, 1] == T[:, 2]).all(1)
+    dead = (T[:, 0] == T[:, 1]).all(1) | (T[:, 0] == T[:, 2]).all(1) | ((T[:, 1] == T[:, 2]).all(1) & (s1 * s1 * (1 + 1e-9) <= 10.0 / 1024.0))
+    return P, I, T, zero, dead
+
+
+def rays_at_segments(T, zero, n, seed):
+    rng = np.random.default_rng(seed)
+    seg = T[zero][rng.integers(0, zero.sum(), n)]
+    target = seg[:, 0] + (seg[:, 2] - seg[:, 0]) * rng.random((n, 1)) + (seg[:, 1] - seg[:, 0]) * rng.random((n, 1))
+    org = target + rng.normal(size=(n, 3)) * 3.0
+    dr = target - org
+    dr[n // 2:] += rng.normal(size=(n - n // 2, 3)) * 0.02          # half exactly at a segment (a shared edge: exact-t ties), half near it
+    ok = np.abs(dr[:, 1]) > 1e-14
+    return np.ascontiguousarray(org[ok]), np.ascontiguousarray(dr[ok])
+
+
+@pytest.mark.parametrize("build", ["host", "device"])
+def test_dropped_triangles_change_no_record(build):
+    import torch
+    P, I, T, zero, dead = cone(6)
+    assert zero.sum() == 10 * 4 ** 6 and dead.sum() == zero.sum()          # at this level every v1 == v2 edge is short enough
+    acc = la.HipAccel(0); acc.add_mesh(P, I)
+    info = acc.commit(build=build)
+    acc.wait_exact()
+    assert info["ntriangles"] == T.shape[0] and acc.info()["ntriangles_in_tree"] == T.shape[0] - int(dead.sum())
+    o = po.Oracle(); o.add_mesh(P, I); o.build()
+    org, dr = rays_at_segments(T, zero, 60000, 11)
+    exp = o.intersect(org, dr, nthreads=8)
+    assert (exp[0] != po.MISS).sum() > 10000
+    assert_hits_equal(acc.intersect_host(org, dr), exp, "%s tree, rays at the degenerate segments" % build)
+    assert np.array_equal(acc.intersect_host(org, dr, mode=la.MODE_ANY).astype(bool), exp[0] != po.MISS)
+    # the batch paths on the device: the default walk, the textbook walk, a handful of rays (k_trace_small)
+    d_o = torch.from_numpy(org).cuda(); d_d = torch.from_numpy(dr).cuda()
+    for variant in (la.VARIANT_DEFAULT, la.VARIANT_DIRECT):
+        out = acc.intersect_device(d_o, d_d, variant=variant); torch.cuda.synchronize()
+        assert_hits_equal(tuple(x.cpu().numpy() for x in out), exp, "%s tree, variant %d" % (build, variant))
+    assert_hits_equal(acc.intersect_host(org[:40], dr[:40]), tuple(x[:40] for x in exp), "%s tree, small batch" % build)
+    # unnormalised directions beyond 1024 per component: the traversal tree alone cannot vouch for the v1 == v2 triangles there,
+    # the reference's own walk decides -- the records are the reference's (t scales with 1 / |dir|)
+    big = dr * 4096.0
+    assert (np.abs(big).max(1) > 1024.0).mean() > 0.9
+    expb = o.intersect(org, big, nthreads=8)
+    assert_hits_equal(acc.intersect_host(org, big), expb, "%s tree, direction components beyond 1024" % build)
+    assert np.array_equal(acc.intersect_host(org, big, mode=la.MODE_ANY).astype(bool), expb[0] != po.MISS)
+    outb = acc.intersect_device(torch.from_numpy(org).cuda(), torch.from_numpy(big).cuda(), variant=la.VARIANT_DIRECT); torch.cuda.synchronize()
+    assert_hits_equal(tuple(x.cpu().numpy() for x in outb), expb, "%s tree, textbook walk, big directions" % build)
+    assert_hits_equal(acc.intersect_host(org[:33], big[:33]), tuple(x[:33] for x in expb), "%s tree, small batch, big directions" % build)
+    acc.close()
+
+
+def test_switch_keeps_every_triangle_in_the_tree_and_the_frame():
+    """LH_DROP_DEGENERATE=0 builds the tree of rounds 1-4; the AO frame of the tessellated example scene is the same frame"""
+    import torch
+    from lucille_amd import render
+    g = load_golden("ao_c1")
+    c = g["camera"]; cam = la.Camera.make(192, 192, c[16], c[:16], int(c[19]))
+    frames = []; in_tree = []
+    for sw in ("1", "0"):
+        os.environ["LH_DROP_DEGENERATE"] = sw
+        try:
+            acc = la.HipAccel(0)
+            for k in range(int(g["ngeoms"])):
+                P, I = scenes.tessellate(g["pos%d" % k], g["idx%d" % k], 4); acc.add_mesh(P, I)
+            acc.commit(build="device" if sw == "1" else "host")
+            acc.wait_exact()
+            in_tree.append(acc.info()["ntriangles_in_tree"])
+            img, st = render.render_ao_frame(acc, cam, 1, 16, tile=192, seed=5)
+            frames.append((img.cpu(), st)); acc.close()
+        finally:
+            del os.environ["LH_DROP_DEGENERATE"]
+    assert in_tree[1] == 322 * 256 and in_tree[0] < in_tree[1]
+    assert torch.equal(frames[0][0], frames[1][0]) and frames[0][1] == frames[1][1]
