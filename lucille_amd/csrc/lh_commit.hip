@@ -184,6 +184,7 @@ static void release_device(lh_accel_t *a)
     if (a->d_env_map) (void)hipFree(a->d_env_map);
     a->d_st6 = a->d_inside = a->d_prim_mesh = a->d_materials = a->d_env_map = NULL;
     free_buf(&a->r_state); free_buf(&a->r_uni); free_buf(&a->r_bands); free_buf(&a->r_diag);
+    if (a->h_read) { (void)hipHostFree(a->h_read); a->h_read = NULL; }
     a->d_total = NULL; a->d_nrm9 = NULL;
     if (a->d_nodes) (void)hipFree(a->d_nodes);
     if (a->d_tri32) (void)hipFree(a->d_tri32);
@@ -562,7 +563,7 @@ static int device_upload(lh_accel_t *a)
     HIPCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(uint32_t) * LH_CURSOR_WORDS * LH_NCURSOR));
     HIPCHK(hipMalloc((void **)&a->d_counters, sizeof(unsigned long long) * LH_CNT_DEV));
-    HIPCHK(hipMalloc((void **)&a->d_total, sizeof(unsigned long long) * 64));      /* the hit count of a batch; then k_ao_resolve's 64 occlusion counters */
+    HIPCHK(hipMalloc((void **)&a->d_total, sizeof(unsigned long long) * 72));      /* the hit count of a batch; then k_ao_resolve's 64 occlusion counters; [64]: the hit count kept for the fused AO stage and the batch's one read-back */
     a->device_bytes = 0;
     if (hs->nrm9) {
         HIPCHK(hipMalloc(&a->d_nrm9, sizeof(double) * 9 * (size_t)hs->bvh.ntris));
@@ -928,7 +929,7 @@ int lh_scene_image_alloc(lh_accel_t *a, const lh_scene_image_t *h)
     HIPCHK(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void **)&a->d_cursor, sizeof(uint32_t) * LH_CURSOR_WORDS * LH_NCURSOR));
     HIPCHK(hipMalloc((void **)&a->d_counters, sizeof(unsigned long long) * LH_CNT_DEV));
-    HIPCHK(hipMalloc((void **)&a->d_total, sizeof(unsigned long long) * 64));      /* the hit count of a batch; then k_ao_resolve's 64 occlusion counters */
+    HIPCHK(hipMalloc((void **)&a->d_total, sizeof(unsigned long long) * 72));      /* the hit count of a batch; then k_ao_resolve's 64 occlusion counters; [64]: the hit count kept for the fused AO stage and the batch's one read-back */
     hs->received = 1; hs->device_built = 1;              /* no host tree: the walks over other node formats are not available */
     hs->bvh.ntris = h->ntris; hs->bvh.nnodes = h->nnodes; hs->bvh.max_depth = h->max_depth; hs->bvh.nleaves = h->nleaves;
     hs->bvh.nq4nodes = h->nq4; hs->bvh.q4_depth = h->q4_depth; hs->bvh.q4_stack = h->q4_stack; hs->nmeshes = h->nmeshes;

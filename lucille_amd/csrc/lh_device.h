@@ -119,7 +119,7 @@ int lh_launch_trace(const lh_dev_scene_t *sc, size_t n, const double *d_org,
 int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int ntheta, int nphi, unsigned long long seed,
                        const double *d_hitrec, const unsigned long long *d_slot_key, unsigned int *d_occ_count,
                        unsigned long long *d_counters, unsigned long long *d_cursor, int grid_blocks, int min_active,
-                       int tri_batch, const lh_fixq_t *q, int ncus, void *stream);
+                       int tri_batch, const lh_fixq_t *q, int ncus, const unsigned long long *d_nslots, uint32_t budget_big, void *stream);
 int lh_trace_formats_needed(const lh_dev_scene_t *sc, int variant);
 int lh_trace_rows(const lh_dev_scene_t *sc);        /* LDS stack rows the default walk launches with on this scene */
 

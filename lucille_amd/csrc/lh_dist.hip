@@ -40,6 +40,7 @@
 #include "lh_internal.h"
 
 #define DFAIL(...) lh_fail(__VA_ARGS__)
+#define LH_DIST_BAND_ROWS 32         /* lines per band of a sharded AO frame unless the caller says (render.py DEFAULT_BAND_ROWS; profiles/r05_shard_cost_table.md) */
 
 
 struct rccl_api {
@@ -458,14 +459,18 @@ extern "C" int lh_dist_broadcast_scene(lh_dist_t *d, lh_accel_t *accel)
 }
 
 /* ---- frames: every rank renders its bands, rank 0 owns the display (render.c:468-514) ----------------------------- */
-/* slabs [world][per][rows][W][3] (band k of rank r = frame band r + k * world, image orientation inside) -> frame [H][W][3],
- * top row first: band b covers frame lines b * rows ... from the BOTTOM of the image (bucket_write's y flip, render.c:962-964) */
+/* slabs [world][per][rows][W][3] (image orientation inside) -> frame [H][W][3], top row first: band b covers frame lines
+ * b * rows ... from the BOTTOM of the image (bucket_write's y flip, render.c:962-964).  The bands are dealt out in SERPENTINE order:
+ * groups of `world`, even groups in rank order, odd groups in reverse -- band g * world + pos is the g-th band of rank pos (g even)
+ * or world - 1 - pos (g odd).  Plain interleaving hands the last rank the lower band of EVERY group: where the cost of a line
+ * changes steadily down the image that rank carries the whole slope (config 5, 64-line bands: 7 %); the serpentine cancels a linear
+ * slope exactly, so the bands can be tall -- and coherent.  Same rule: lucille_amd/shard.py bands_of_rank */
 __global__ void k_place_bands(const float *__restrict__ slabs, float *__restrict__ frame, int world, int per, int rows, int W, int H)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)W * H) return;
     const int x = (int)(i % W), row = (int)(i / W);            /* row 0 = top of the image = frame line H - 1 */
-    const int line = H - 1 - row, band = line / rows, r = band % world, k = band / world;
+    const int line = H - 1 - row, band = line / rows, k = band / world, pos = band % world, r = (k & 1) ? world - 1 - pos : pos;
     const int y0 = band * rows, h = (y0 + rows <= H) ? rows : H - y0;
     /* inside a band slab the first frame line of the band is the LAST of its h lines; a clipped band keeps them at the bottom */
     const int srow = (rows - h) + (h - 1 - (line - y0));
@@ -482,12 +487,15 @@ extern "C" int lh_dist_render_ao_frame_host(lh_dist_t *d, lh_accel_t *accel, con
     const int W = cam->width, H = cam->height;
     if (W <= 0 || H <= 0) return DFAIL("lh_dist_render_ao_frame_host: bad resolution");
     HIPCHK(hipSetDevice(d->device));
-    if (band_rows <= 0) band_rows = 4;
+    if (band_rows <= 0) band_rows = LH_DIST_BAND_ROWS;
     if (d->world == 1) band_rows = H;
     if (band_rows > H) band_rows = H;
     const int nbands = (H + band_rows - 1) / band_rows, per = (nbands + d->world - 1) / d->world;
     std::vector<int> y0;
-    for (int b = d->rank; b < nbands; b += d->world) y0.push_back(b * band_rows);
+    for (int k = 0; k < per; k++) {             /* this rank's band of every group (k_place_bands) */
+        const int b = k * d->world + ((k & 1) ? d->world - 1 - d->rank : d->rank);
+        if (b < nbands) y0.push_back(b * band_rows);
+    }
     const size_t slab_bytes = (size_t)per * band_rows * W * 3 * sizeof(float);
     lh_tile_stats_t st; memset(&st, 0, sizeof(st));
     /* a rank that cannot render its bands (or rank 0 without room for the slabs) says so before the gather: the others return

@@ -105,6 +105,7 @@ struct lh_accel {
     lh_buf r_uni;                      /* lh_render_ao_tile_host: caller uniforms on the device */
     lh_buf r_diag;                     /* LH_STAGE_TIMING: wave start / exit clocks */
     lh_buf r_bands;                    /* lh_render_ao_bands: first line of every band */
+    void *h_read;                      /* 1 KiB of pinned host memory: the read-backs at the end of an AO batch (occlusion totals, hit count, queue flags) */
     /* tile-render scratch (lh_render_ao_tile) */
     lh_buf r_org, r_dir, r_prim, r_t, r_u, r_v, r_slot, r_hitrec, r_aorg, r_adir, r_occ, r_blocks, r_key, r_frame, r_occcount;
     uint64_t last_retraced;            /* rays the last counted launch finished outside the main kernel */

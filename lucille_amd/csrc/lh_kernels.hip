@@ -421,6 +421,9 @@ struct AoSrc {
     const double *hitrec; const unsigned long long *slot_key; unsigned int *occ_count;
     unsigned long long seed; int ntheta, nphi;
     uint32_t nslots; int group;           /* group: 64 = items ordered (64 slots) x (sample) x (slot in group), 0 = (slot) x (sample) */
+    const unsigned long long *nslots_dev; /* NULL, or: the slot count lives on the device (the compaction's total: the host launches this stage without reading
+                                             it back; nslots is then its upper bound) */
+    uint32_t budget_big;                  /* 0, or: the visit budget of a launch that turns out to hold 2^27 rays or more (lh_tile.hip) */
 };
 
 /* Work item i of a fused AO stage -> (hit slot, sample).  The plain order -- a slot's N samples side by side -- puts the N
@@ -481,6 +484,7 @@ __device__ __forceinline__ void trace_persist_lane(
 #ifdef LH_DIAG_CLOCK      /* wave start / exit clocks (LH_STAGE_TIMING); off in the product: two SGPRs live across the whole kernel */
     if (sc.diag_clock && (tid & 63) == 0) sc.diag_clock[(size_t)blockIdx.x * (LH_BLOCK / 64) + (tid >> 6)] = wall_clock64();
 #endif
+    const uint32_t budget = (SRC == 1 && ao.budget_big && n >= (1u << 27)) ? ao.budget_big : sc.ray_budget;
     bool exhausted = false;          /* wave-uniform: every partition's cursor ran past its end */
     uint32_t wbase = 0, wend = 0;    /* wave-uniform: this wave's reserved ray range */
     uint32_t part, drained = 0;      /* wave-uniform: the partition this wave draws from, bit mask of the partitions known to be handed out */
@@ -498,7 +502,7 @@ __device__ __forceinline__ void trace_persist_lane(
     for (;;) {
         /* ---- regroup: retire finished lanes, refill them ----------------- */
         /* out of budget: the ray leaves the persistent walk here and is finished cooperatively (its partial results are dropped) */
-        if (__builtin_expect(my != kNoRay && it - it0 > sc.ray_budget && ((L.cur != kDone) | (pend != 0)), 0)) { L.over = true; L.cur = kDone; pend = 0; }
+        if (__builtin_expect(my != kNoRay && it - it0 > budget && ((L.cur != kDone) | (pend != 0)), 0)) { L.over = true; L.cur = kDone; pend = 0; }
         const bool idle = (L.cur == kDone) && (pend == 0);
         if (COUNT) crs++;
         if (idle && my != kNoRay) {
@@ -534,7 +538,7 @@ __device__ __forceinline__ void trace_persist_lane(
             if (__builtin_expect(wbase == wend, 0)) {
                 const uint32_t per = (n + LH_NPART - 1) / LH_NPART;
                 uint32_t chunk = sc.ray_chunk;
-                if (SRC != 1 && sc.n_dev) {                   /* the host sized the chunk for its upper bound of n */
+                if ((SRC != 1 && sc.n_dev) || (SRC == 1 && ao.nslots_dev)) {                   /* the host sized the chunk for its upper bound of n */
                     const uint32_t c = n / (gridDim.x * (LH_BLOCK / 64) * 4u);
                     chunk = c < 64u ? 64u : (c < chunk ? c : chunk);
                 }
@@ -581,7 +585,12 @@ __device__ __forceinline__ void trace_persist_lane(
             wbase += take;
         }
         const unsigned long long work = __ballot((L.cur != kDone) | (pend != 0));
-        if (work == 0ull) break;
+        if (work == 0ull) {
+            /* nothing to walk: the end -- unless the refill handed out rays that are finished before their first step (forced to
+             * the reference walk: ray_needs_ref_walk): they are retired at the top of the loop */
+            if (SRC != 0 || __ballot(my != kNoRay) == 0ull) break;
+            continue;
+        }
         /* ---- walk until too few lanes remain active ---------------------- */
         const int thresh = exhausted ? 1 : min_active;
         if (WALK == 3)
@@ -613,6 +622,7 @@ __global__ __launch_bounds__(LH_BLOCK, WALK == 7 ? 3 : 4) void k_trace_persist_l
 {
     extern __shared__ int lh_stack_lds[];          /* [stack entries][LH_BLOCK], sized at launch; then the top of the tree (sc.top_nodes x 64 bytes) */
     if (SRC != 1 && sc.n_dev) n = *sc.n_dev;       /* the path tracer's bounce chain: the count the previous shading pass left */
+    if (SRC == 1 && ao.nslots_dev) n = (uint32_t)*ao.nslots_dev * (uint32_t)(ao.ntheta * ao.nphi);      /* the fused AO stage behind a compaction nobody read back (<= the host's bound < 2^31) */
     if (WALK != 7 && sc.top_nodes) {
         uint4 *dst = (uint4 *)(lh_stack_lds + (size_t)sc.stack_rows * LH_BLOCK);
         const uint4 *src = (const uint4 *)sc.q4nodes;
@@ -1173,8 +1183,10 @@ int fixq_begin(const lh_fixq_t *q, hipStream_t s)
 extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int ntheta, int nphi, unsigned long long seed,
                                   const double *d_hitrec, const unsigned long long *d_slot_key, unsigned int *d_occ_count,
                                   unsigned long long *d_counters, unsigned long long *d_cursor, int grid_blocks, int min_active,
-                                  int tri_batch, const lh_fixq_t *q, int ncus, void *stream)
+                                  int tri_batch, const lh_fixq_t *q, int ncus, const unsigned long long *d_nslots, uint32_t budget_big, void *stream)
 {
+    /* d_nslots (or NULL): the slot count on the device -- nslots is then its upper bound (the samples of the batch), the buffers
+     * are sized for it and the kernels read the count themselves: no host round trip between the compaction and this stage */
     hipStream_t s = (hipStream_t)stream;
     const size_t n = nslots * (size_t)(ntheta * nphi);
     if (n == 0) return 0;
@@ -1187,7 +1199,8 @@ extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int n
     const size_t lds_bytes = (size_t)scl.stack_rows * LH_BLOCK * sizeof(int) + (size_t)scl.top_nodes * 64u;
     if (scl.ray_chunk < LH_TILE_CHUNK) scl.ray_chunk = LH_TILE_CHUNK;      /* AO rays of a slot are coherent: longer ranges per wave */
     clamp_chunk(scl, n, grid_blocks);
-    AoSrc ao = {d_hitrec, d_slot_key, d_occ_count, seed, ntheta, nphi, (uint32_t)nslots, (int)sc->ao_group};
+    AoSrc ao = {d_hitrec, d_slot_key, d_occ_count, seed, ntheta, nphi, (uint32_t)nslots, (int)sc->ao_group, d_nslots, budget_big};
+    if (d_nslots && sc->ao_group) return -1;            /* the grouped order needs the exact count on the host */
     FixQ fq = {(unsigned long long *)q->queue, q->qcount, q->qcap, (uint32_t)grid_blocks * (LH_BLOCK / 64), q->qcount + 4};
     if (hipMemsetAsync(d_cursor, 0, sizeof(uint32_t) * LH_CURSOR_WORDS, s) != hipSuccess) return -1;
     if (hipMemsetAsync(d_occ_count, 0, sizeof(unsigned int) * nslots, s) != hipSuccess) return -1;

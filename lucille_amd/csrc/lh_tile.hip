@@ -82,8 +82,16 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
     if (lh_launch(a, S, a->r_org.p, a->r_dir.p, a->r_prim.p, a->r_t.p, a->r_u.p, a->r_v.p, NULL, LH_MODE_CLOSEST,
                LH_VARIANT_DEFAULT, cnt, s, false) != 0) return -1;
     if (stage_timing) { HIPCHK(hipEventRecord(ev[2], s)); a->dev.diag_clock = (unsigned long long *)a->r_diag.p + 2 * nwaves; }
-    /* 3. count hits (deterministic compaction needs the total before sizing the AO batch) */
-    unsigned long long nhit = 0;
+    /* 3. compaction (deterministic: hits in sample order).  The fused AO stage does not need the total on the host: its buffers are
+     * sized for the worst case (every sample hits) and its kernels read the count where the compaction left it -- a batch costs ONE
+     * host round trip, at its end (round 5: the two in the middle were ~0.25 ms of a rank's 8.9 ms share of the config-5 frame).
+     * The materialised stage (caller uniforms: the parity replay; LH_AO_FUSED=0; a fix-up queue that overflowed) sizes its ray
+     * arrays from the count and reads it first. */
+    unsigned long long nhit = 0, nocc = 0;
+    unsigned long long *d_nhit = a->d_total + 64;          /* the compaction's total, kept clear of k_ao_resolve's 64 counters */
+    const size_t nao_max = S * (size_t)N;
+    bool fused = a->ao_fused && !d_uniforms && a->hs->bvh.ntris;
+    const bool late_count = fused && nao_max < ((size_t)1 << 31) && !a->dev.ao_group && !getenv("LH_AO_SYNC");      /* the persistent kernel's 32-bit ray index covers the worst case */
     if (a->hs->bvh.ntris) {
         if (ensure_buf(&a->r_hitrec, S * 96) || ensure_buf(&a->r_key, S * 8)) return -1;   /* worst case: every sample hits */
         if (lh_render_launch_compact(&a->dev, (const double *)a->d_nrm9, S, (const double *)a->r_org.p,
@@ -92,62 +100,96 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
                                      (uint32_t *)a->r_slot.p, (double *)a->r_hitrec.p, (unsigned long long *)a->r_key.p,
                                      x0, w, nbands, band_rows, d_band_y0, y0, ps * ps, cam->width, a->d_total, s) != 0)
             return fail("compaction kernels failed: %s", hipGetErrorString(hipGetLastError()));
-        HIPCHK(hipMemcpyAsync(&nhit, a->d_total, sizeof(nhit), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMemcpyAsync(d_nhit, a->d_total, sizeof(nhit), hipMemcpyDeviceToDevice, s));
+        if (!late_count) {
+            HIPCHK(hipMemcpyAsync(&nhit, d_nhit, sizeof(nhit), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (nhit * (unsigned long long)N >= (1ull << 31)) fused = false;
+        }
     } else {
         HIPCHK(hipMemsetAsync(a->r_slot.p, 0xFF, S * 4, s));
+        HIPCHK(hipMemsetAsync(d_nhit, 0, sizeof(nhit), s));
     }
-    const size_t nao = (size_t)nhit * N;
-    unsigned long long nocc = 0;
     if (stage_timing) HIPCHK(hipEventRecord(ev[3], s));
     /* AO stage.  Fused (default): the any-hit kernel generates ray (slot, r) in its refill (lh_ao.h) and counts
      * the occluded rays per slot -- nothing per AO ray goes through HBM.  Materialised: caller uniforms (the parity
-     * replay), LH_AO_FUSED=0, a scene the lean walk cannot take, or a pending-queue overflow of the fused launch. */
-    bool fused = a->ao_fused && !d_uniforms && nao && nao < ((size_t)1 << 31);      /* the persistent kernel's 32-bit ray index */
+     * replay), LH_AO_FUSED=0, or a fix-up queue overflow of the fused launch. */
+    if (fused && !late_count && nhit == 0) fused = false;          /* nothing was hit: nothing to trace, the resolve sees misses only */
     const bool fused_tried = fused;
-    if (fused) {
-        if (ensure_buf(&a->r_occcount, (size_t)nhit * sizeof(unsigned int))) return -1;
-        const int k = lh_aoq_slot(a, s);
-        if (k < 0) return -1;
+    int qslot = -1;
+    /* the batch's read-backs land in pinned memory: three small copies behind the last kernel, one wait */
+    if (!a->h_read) HIPCHK(hipHostMalloc(&a->h_read, 1024, hipHostMallocDefault));
+    unsigned long long *h_nocc64 = (unsigned long long *)a->h_read, *h_nhit = h_nocc64 + 64; uint32_t *h_qc = (uint32_t *)(h_nocc64 + 65);
+    h_qc[0] = h_qc[1] = 0u;
+    if (fused && (late_count || nhit)) {
+        const size_t nslots = late_count ? S : (size_t)nhit;
+        if (ensure_buf(&a->r_occcount, nslots * sizeof(unsigned int))) return -1;
+        qslot = lh_aoq_slot(a, s);
+        if (qslot < 0) return -1;
         const uint32_t budget_keep = a->dev.ray_budget;
         if (a->ao_budget) a->dev.ray_budget = a->ao_budget;
         /* the tail a budget costs a launch is fixed, the queue a low budget sends to the sweep grows with the launch: a launch of
          * 2^27 rays or more doubles the default (config 5: whole frame 57.6 -> 56.7 ms, half of it 30.8 -> 29.9; a quarter and an
-         * eighth are best at 384 -- tools/ao_budget_probe.py) */
-        if (a->ao_budget && !a->ao_budget_user && nao >= ((size_t)1 << 27)) a->dev.ray_budget = 2u * a->ao_budget;
-        const int rc_ao = lh_launch_trace_ao(&a->dev, (size_t)nhit, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const unsigned long long *)a->r_key.p,
+         * eighth are best at 384 -- tools/ao_budget_probe.py).  With the count on the device the kernel picks between the two */
+        const uint32_t big = (a->ao_budget && !a->ao_budget_user) ? 2u * a->ao_budget : 0u;
+        if (!late_count && big && nhit * (unsigned long long)N >= (1ull << 27)) a->dev.ray_budget = big;
+        const int rc_ao = lh_launch_trace_ao(&a->dev, nslots, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const unsigned long long *)a->r_key.p,
                                (unsigned int *)a->r_occcount.p, cnt, (unsigned long long *)((uint32_t *)a->d_cursor + (size_t)LH_CURSOR_WORDS * (a->cursor_next++ % LH_NCURSOR)), a->grid_blocks,
-                               a->min_active, a->tri_batch, &a->aoq[k].q, a->ncus, (void *)s);
+                               a->min_active, a->tri_batch, &a->aoq[qslot].q, a->ncus, late_count ? d_nhit : NULL, late_count ? big : 0u, (void *)s);
         a->dev.ray_budget = budget_keep;
         if (rc_ao != 0) return fail("fused AO launch failed: %s", hipGetErrorString(hipGetLastError()));
-        uint32_t qc[2] = {0, 0};
-        HIPCHK(hipMemcpyAsync(qc, a->aoq[k].q.qcount, sizeof(qc), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        if (qc[1] != 0) fused = false;             /* more than LH_AO_QCAP uncertain AO rays: redo the stage materialised */
-        if (stage_timing) fprintf(stderr, "[lucille_hip]   fused AO stage: %u rays through the fix-up queue (budget %u)\n", qc[0], a->dev.ray_budget);
+        if (!late_count) {
+            uint32_t qc[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(qc, a->aoq[qslot].q.qcount, sizeof(qc), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (qc[1] != 0) fused = false;             /* more than LH_AO_QCAP uncertain AO rays: redo the stage materialised */
+            if (stage_timing) fprintf(stderr, "[lucille_hip]   fused AO stage: %u rays through the fix-up queue (budget %u)\n", qc[0], a->dev.ray_budget);
+        }
     }
-    if (nao && !fused) {
-        if (ensure_buf(&a->r_aorg, nao * 24) || ensure_buf(&a->r_adir, nao * 24) || ensure_buf(&a->r_occ, nao)) return -1;
-        /* 4. AO rays */
-        if (lh_render_launch_ao_rays(nhit, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const double *)d_uniforms,
-                                     (const unsigned long long *)a->r_key.p, (double *)a->r_aorg.p, (double *)a->r_adir.p, s) != 0)
-            return fail("AO ray kernel launch failed");
-        /* 5. any-hit */
-        if (cnt && fused_tried) HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * LH_CNT_DEV, s));   /* the abandoned fused pass is not counted (nor are the camera rays then) */
-        if (lh_launch(a, nao, a->r_aorg.p, a->r_adir.p, NULL, NULL, NULL, NULL, a->r_occ.p, LH_MODE_ANY,
-                   LH_VARIANT_DEFAULT, cnt, s, false) != 0) return -1;
-    }
+    /* stages 4-6 with the AO rays in HBM; also the second try of a batch whose fused launch overflowed its queue */
+    auto materialised = [&]() -> int {
+        const size_t nao_m = (size_t)nhit * N;
+        if (nao_m) {
+            if (ensure_buf(&a->r_aorg, nao_m * 24) || ensure_buf(&a->r_adir, nao_m * 24) || ensure_buf(&a->r_occ, nao_m)) return -1;
+            /* 4. AO rays */
+            if (lh_render_launch_ao_rays(nhit, ntheta, nphi, seed, (const double *)a->r_hitrec.p, (const double *)d_uniforms,
+                                         (const unsigned long long *)a->r_key.p, (double *)a->r_aorg.p, (double *)a->r_adir.p, s) != 0)
+                return fail("AO ray kernel launch failed");
+            /* 5. any-hit */
+            if (cnt && fused_tried) HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * LH_CNT_DEV, s));   /* the abandoned fused pass is not counted (nor are the camera rays then) */
+            if (lh_launch(a, nao_m, a->r_aorg.p, a->r_adir.p, NULL, NULL, NULL, NULL, a->r_occ.p, LH_MODE_ANY,
+                       LH_VARIANT_DEFAULT, cnt, s, false) != 0) return -1;
+        }
+        return 0;
+    };
+    auto resolve = [&](bool from_counts) -> int {
+        /* 6. radiance */
+        HIPCHK(hipMemsetAsync(a->d_total, 0, sizeof(unsigned long long) * 64, s));
+        if (lh_render_launch_resolve(w, h, band_rows, ps, ps, N, (const uint32_t *)a->r_slot.p, (const uint8_t *)a->r_occ.p,
+                                     from_counts ? (const unsigned int *)a->r_occcount.p : NULL, (float *)d_rgb, a->d_total, s) != 0)
+            return fail("resolve kernel launch failed");
+        HIPCHK(hipMemcpyAsync(h_nocc64, a->d_total, sizeof(unsigned long long) * 64, hipMemcpyDeviceToHost, s));
+        return 0;
+    };
+    if (!fused && materialised() != 0) return -1;
     if (stage_timing) HIPCHK(hipEventRecord(ev[4], s));
-    /* 6. radiance */
-    HIPCHK(hipMemsetAsync(a->d_total, 0, sizeof(unsigned long long) * 64, s));
-    if (lh_render_launch_resolve(w, h, band_rows, ps, ps, N, (const uint32_t *)a->r_slot.p, (const uint8_t *)a->r_occ.p,
-                                 fused ? (const unsigned int *)a->r_occcount.p : NULL, (float *)d_rgb, a->d_total, s) != 0)
-        return fail("resolve kernel launch failed");
-    unsigned long long nocc64[64];
-    HIPCHK(hipMemcpyAsync(nocc64, a->d_total, sizeof(nocc64), hipMemcpyDeviceToHost, s));
+    if (resolve(fused) != 0) return -1;
     if (stage_timing) HIPCHK(hipEventRecord(ev[5], s));
-    HIPCHK(hipStreamSynchronize(s));
-    for (int k = 0; k < 64; k++) nocc += nocc64[k];
+    if (late_count) {
+        /* the batch's one round trip: hit count, occlusion totals, the queue's overflow flag */
+        HIPCHK(hipMemcpyAsync(h_nhit, d_nhit, sizeof(nhit), hipMemcpyDeviceToHost, s));
+        if (qslot >= 0) HIPCHK(hipMemcpyAsync(h_qc, a->aoq[qslot].q.qcount, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        nhit = *h_nhit;
+        if (stage_timing) fprintf(stderr, "[lucille_hip]   fused AO stage: %u rays through the fix-up queue (budget %u)\n", h_qc[0], a->ao_budget ? a->ao_budget : a->dev.ray_budget);
+        if (h_qc[1] != 0) {                           /* more than LH_AO_QCAP uncertain AO rays: the stage once more, materialised */
+            fused = false;
+            if (materialised() != 0 || resolve(false) != 0) return -1;
+            HIPCHK(hipStreamSynchronize(s));
+        }
+    } else HIPCHK(hipStreamSynchronize(s));
+    const size_t nao = (size_t)nhit * N;
+    for (int k = 0; k < 64; k++) nocc += h_nocc64[k];
     if (stage_timing) {
         float ms[5] = {0, 0, 0, 0, 0};
         for (int k = 0; k < 5; k++) (void)hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]);

@@ -31,14 +31,19 @@ def render_ao_frame(acc, cam, pixel_samples, gather_nsamples, tile=256, seed=1, 
     return img, tot
 
 
+DEFAULT_BAND_ROWS = 32
+
+
 def bands_for(height, world, rows=None):
-    """image-space shards for `world` ranks: full-width bands of `rows` lines (default 4; LH_BAND_ROWS overrides),
-    interleaved band_id % world == rank.  A rank renders ALL of its bands as ONE device batch (lh_render_ao_bands), so fine
-    bands cost nothing per band and spread sky / floor / silhouettes evenly over the ranks (profiles/r02_shard_cost_table.md:
-    32-line bands leave the busiest of 8 ranks 28 % above the mean).  -> (band_rows, [first line of every band])"""
+    """image-space shards for `world` ranks: full-width bands of `rows` lines (default DEFAULT_BAND_ROWS; LH_BAND_ROWS overrides).
+    AO frames deal them out in serpentine order (shard.bands_of_rank), path-traced frames interleaved (band_id % world: their
+    bands are one pass with a fixed stride).  A rank renders ALL of its bands as ONE device batch (lh_render_ao_bands), so a band
+    costs nothing by itself; what its height trades is coherence (tall: a wave's neighbours in the batch are neighbours in the
+    image) against balance (fine: sky / floor / silhouettes spread evenly) -- profiles/r05_shard_cost_table.md.
+    -> (band_rows, [first line of every band])"""
     import os
     if rows is None:
-        rows = int(os.environ.get("LH_BAND_ROWS", "4"))
+        rows = int(os.environ.get("LH_BAND_ROWS", str(DEFAULT_BAND_ROWS)))
     if world <= 1:
         rows = height                      # one rank: the frame is one band
     rows = max(1, min(rows, height))
@@ -57,7 +62,7 @@ def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, worl
     dev = torch.device("cuda", acc.device)
     if tile is None:
         rows, y0s = bands_for(H, world, band_rows)
-        mine = shard.tiles_of_rank(len(y0s), rank, world)
+        mine = shard.bands_of_rank(len(y0s), rank, world)
         per = (len(y0s) + world - 1) // world
         slab = torch.zeros((per, rows * W * 3), dtype=torch.float32, device=dev)
         if timing is not None:
@@ -67,7 +72,7 @@ def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, worl
         if timing is not None:
             torch.cuda.synchronize(dev); t1 = time.perf_counter()
         shards = [(0, y0, W, min(rows, H - y0)) for y0 in y0s]
-        img = assemble_shards(slab, shards, W, H, rank, world, stride_rows=rows)
+        img = assemble_shards(slab, shards, W, H, rank, world, stride_rows=rows, serpentine=True)
         if timing is not None:
             torch.cuda.synchronize(dev)
             timing.update(bands=len(mine), band_rows=rows, batch_ms=round((t1 - t0) * 1e3, 3), gather_ms=round((time.perf_counter() - t1) * 1e3, 3))
@@ -87,26 +92,29 @@ def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, worl
     return assemble_shards(slab, shards, W, H, rank, world), tot
 
 
-def assemble_shards(slab, shards, W, H, rank, world, stride_rows=None):
+def assemble_shards(slab, shards, W, H, rank, world, stride_rows=None, serpentine=False):
     """the exchange step (one gather of [per_rank, cap] slabs to rank 0) + placement with the reference's y flip
     (bucket_write, render.c:962-964).  stride_rows: the slab of a shard holds that many rows (bands of a batch: a clipped
-    last band keeps its lines at the BOTTOM of its slab, the clipped lines being below the frame); None: h rows."""
+    last band keeps its lines at the BOTTOM of its slab, the clipped lines being below the frame); None: h rows.
+    serpentine: the shards were dealt out by shard.bands_of_rank (AO bands), else by shard.tiles_of_rank."""
     import torch
     out = shard.gather_slabs(slab, rank, world)
     if rank != 0:
         return None
+    of_rank = shard.bands_of_rank if serpentine else shard.tiles_of_rank
     if stride_rows is not None and H % stride_rows == 0:
-        # regular bands: one strided copy per rank, then one flip -- band 0 is the BOTTOM of the image, every band is
+        # regular bands: one indexed copy per rank, then one flip -- band 0 is the BOTTOM of the image, every band is
         # already top-line-first inside (thousands of bands per frame: no Python loop over them)
         nb = H // stride_rows
         bands = torch.empty((nb, stride_rows, W, 3), dtype=slab.dtype, device=slab.device)
         for r in range(world):
-            cnt = len(range(r, nb, world))
-            bands[r::world] = out[r][:cnt].view(cnt, stride_rows, W, 3)
+            ids = of_rank(nb, r, world)
+            if ids:
+                bands[torch.tensor(ids, device=slab.device)] = out[r][:len(ids)].view(len(ids), stride_rows, W, 3)
         return bands.flip(0).reshape(H, W, 3)
     img = torch.zeros((H, W, 3), dtype=slab.dtype, device=slab.device)
     for r in range(world):
-        for k, tid in enumerate(shard.tiles_of_rank(len(shards), r, world)):
+        for k, tid in enumerate(of_rank(len(shards), r, world)):
             x0, y0, w, h = shards[tid]
             if stride_rows is None:
                 img[H - (y0 + h):H - y0, x0:x0 + w] = out[r][k, :w * h * 3].view(h, w, 3)

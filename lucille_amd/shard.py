@@ -42,6 +42,27 @@ def tiles_of_rank(ntiles, rank, world):
     return list(range(rank, ntiles, world))
 
 
+def bands_of_rank(nbands, rank, world):
+    """full-width bands of an AO frame, SERPENTINE: the bands are dealt out in groups of `world`, even groups in rank order, odd
+    groups in reverse -- band b = g * world + pos belongs to rank pos (g even) or world - 1 - pos (g odd) and is that rank's g-th.
+    Plain interleaving (b % world) hands rank r the band r lines-worth below rank 0's in EVERY group: where the cost of a line
+    changes steadily down the image (sky, objects, floor) the last rank carries all of that slope (config 5, 64-line bands: rank 7
+    7 % above rank 0); the serpentine cancels a linear slope exactly, so bands can be tall -- and tall bands are coherent
+    (lh_dist.hip k_place_bands has the same rule)."""
+    out = []
+    for g in range((nbands + world - 1) // world):
+        b = g * world + (rank if g % 2 == 0 else world - 1 - rank)
+        if b < nbands:
+            out.append(b)
+    return out
+
+
+def band_owner(b, world):
+    """(rank, index among that rank's bands) of band b under bands_of_rank's rule"""
+    g, pos = divmod(b, world)
+    return (pos if g % 2 == 0 else world - 1 - pos), g
+
+
 _DIST = None      # this process's lh_dist_t (binding.HipDist) when world > 1
 _RCCL_STATUS = "not tried (world 1)"
 

@@ -139,9 +139,10 @@ def test_a_failed_commit_on_rank_0_releases_the_peers(tmp_path, transport):
 
 
 def test_a_failing_send_is_an_error_on_both_ends(tmp_path):
-    """the third ncclSend of rank 1 fails (injected; the first two carry the status words of the scene broadcast): rank 1's
-    gather raises with the library's message, rank 0's receive gives up (the mock's timeout) and raises too"""
-    procs, outs = run_ranks(tmp_path, 2, "send_fails", {"MOCK_RCCL_FAIL": "send:1:2", "MOCK_RCCL_TIMEOUT": "4"}, timeout=120)
+    """the fourth ncclSend of rank 1 fails (injected; the first carries its host id at lh_dist_init -- are all ranks on one host?
+    --, the next two the status words of the scene broadcast): rank 1's gather raises with the library's message, rank 0's
+    receive gives up (the mock's timeout) and raises too"""
+    procs, outs = run_ranks(tmp_path, 2, "send_fails", {"MOCK_RCCL_FAIL": "send:1:3", "MOCK_RCCL_TIMEOUT": "4"}, timeout=120)
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, (so, se[-2000:])
     assert "ncclGroupEnd failed" in open(tmp_path / "out1.txt").read()          # a grouped send is issued -- and fails -- at ncclGroupEnd

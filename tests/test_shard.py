@@ -129,3 +129,62 @@ def test_ray_dump_gather_world2_gloo(n, nchunks):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert np.array_equal(out, np.arange(n) * 3 + 1)
+
+
+def test_serpentine_bands_cover_once_and_cancel_a_slope():
+    """shard.bands_of_rank: every band exactly once, band_owner is its inverse, and a cost that changes linearly down the image
+    is shared out evenly (plain interleaving leaves the last rank the whole slope)"""
+    for nbands, world in ((128, 8), (64, 8), (37, 8), (5, 8), (1024, 3), (16, 1), (7, 2)):
+        got = [shard.bands_of_rank(nbands, r, world) for r in range(world)]
+        assert sorted(sum(got, [])) == list(range(nbands))
+        for r in range(world):
+            assert got[r] == sorted(got[r]) and len(got[r]) <= (nbands + world - 1) // world
+            for k, b in enumerate(got[r]):
+                assert shard.band_owner(b, world) == (r, b // world) and (len(got[r]) <= k or got[r][k] == b)
+    cost = np.arange(128, dtype=np.float64) + 50.0                  # a steady slope down the image
+    serp = [cost[shard.bands_of_rank(128, r, 8)].sum() for r in range(8)]
+    plain = [cost[shard.tiles_of_rank(128, r, 8)].sum() for r in range(8)]
+    assert max(serp) == min(serp) and max(plain) - min(plain) == 7 * 16
+
+
+def _band_worker(rank, world, port, W, H, rows, q):
+    """the AO frame's exchange step on gloo: every rank fills the slabs of ITS serpentine bands with a function of the frame
+    position, one gather, rank 0 places them (render.assemble_shards: the regular fast path and the clipped-last-band path)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    shard.init_process_group(backend="gloo")
+    _, y0s = render.bands_for(H, world, rows)
+    mine = shard.bands_of_rank(len(y0s), rank, world)
+    per = (len(y0s) + world - 1) // world
+    slab = torch.zeros((per, rows * W * 3))
+    for k, b in enumerate(mine):
+        y0 = y0s[b]; h = min(rows, H - y0)
+        t = torch.zeros((rows, W, 3))
+        for ly in range(h):                          # a clipped band keeps its lines at the BOTTOM of its slab
+            line = y0 + (h - 1 - ly)
+            t[rows - h + ly, :, 0] = torch.arange(W, dtype=torch.float32); t[rows - h + ly, :, 1] = float(line); t[rows - h + ly, :, 2] = float(rank)
+        slab[k] = t.view(-1)
+    shards = [(0, y0, W, min(rows, H - y0)) for y0 in y0s]
+    img = render.assemble_shards(slab, shards, W, H, rank, world, stride_rows=rows, serpentine=True)
+    if rank == 0:
+        q.put(img.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("W,H,rows,world", [(24, 64, 4, 2), (24, 70, 8, 2), (16, 96, 4, 3)])
+def test_serpentine_band_gather_gloo(W, H, rows, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_band_worker, args=(r, world, port, W, H, rows, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    img = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    assert np.array_equal(img[..., 0], xs)
+    assert np.array_equal(img[..., 1], H - 1 - ys)          # image row r shows frame line H - 1 - r (bucket_write's flip)
+    owner = np.array([shard.band_owner((H - 1 - r) // rows, world)[0] for r in range(H)], np.float32)
+    assert np.array_equal(img[..., 2], np.repeat(owner[:, None], W, 1))

@@ -19,7 +19,7 @@ cap = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 if per_cu: acc.set_param("grid", ncu * per_cu); acc.set_param("stack_cap", cap)
 for world in (1, 2, 4):
     brow, y0s = render.bands_for(size, world, None)
-    mine = [y0s[b] for b in shard.tiles_of_rank(len(y0s), 0, world)]
+    mine = [y0s[b] for b in shard.bands_of_rank(len(y0s), 0, world)]
     out = torch.zeros((len(mine), brow, size, 3), dtype=torch.float32, device="cuda")
     for rb, ab in ((128, 384), (128, 512), (128, 768), (128, 1024), (128, 384)):
         acc.set_param("ray_budget", rb); acc.set_param("ao_budget", ab)   # "ray_budget" sets both: the AO stage's after it

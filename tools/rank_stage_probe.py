@@ -22,7 +22,7 @@ if per_cu > 0:
 c = g["camera"]; cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
 brow, y0s = render.bands_for(size, world, want)
 for r in (0, world - 1):
-    mine = [y0s[b] for b in shard.tiles_of_rank(len(y0s), r, world)]
+    mine = [y0s[b] for b in shard.bands_of_rank(len(y0s), r, world)]
     out = torch.zeros((len(mine), brow, size, 3), dtype=torch.float32, device="cuda")
     ts = []
     for _ in range(5):

@@ -1,6 +1,6 @@
 """Per-shard cost table of the BASELINE config 5 AO frame from a ONE-GPU run, and the max-over-ranks frame time it
-predicts for 2 / 4 / 8 GPUs under the shard assignment bench.py uses (render.bands_for: full-width bands, 8 per rank,
-band_id % world) -- SURVEY 8e / VERDICT r01 item 2c.  No multi-GPU hardware is involved: the prediction is
+predicts for 2 / 4 / 8 GPUs under the shard assignment bench.py uses (render.bands_for + shard.bands_of_rank: full-width bands
+dealt out in serpentine order) -- SURVEY 8e / VERDICT r01 item 2c, r04 item 1.  No multi-GPU hardware is involved: the prediction is
 sum-of-my-bands + the gather of the other ranks' slabs at a stated link rate.
   python tools/shard_cost_table.py [size] [tess] [samples] > profiles/<round>_shard_cost_table.md"""
 import os, sys, time
@@ -30,19 +30,21 @@ full = torch.empty((size, size, 3), dtype=torch.float32, device="cuda")
 t1 = t_of(0, 0, size, size, full)
 print("# Shard cost table: BASELINE config 5 AO frame (%d triangles, %dx%d, %d AO samples), one MI355X\n" % (ntri, size, size, ns))
 print("Whole frame as ONE device batch: **%.2f ms** (tree %.2f s + reference-order tree %.2f s, once per scene: lh_accel_commit's own choice of builder).\n" % (t1 * 1e3, info["build_seconds"], info["ref_build_seconds"]))
-print("Shards = `render.bands_for(H, world)`: full-width bands of a few lines (column 3), `band_id %% world == rank`; a rank's bands are ONE "
+SKEW_MS = {1: 0.0, 2: 0.10, 4: 0.16, 8: 0.17}      # what a frame's two barriers cost between real processes (profiles/r04_skew.txt, lh_dist_host_barrier, p50)
+print("Shards = `render.bands_for(H, world)`: full-width bands (column 3: lines per band; the default first), dealt out in serpentine order (`shard.bands_of_rank`: groups of `world` bands, even groups in rank order, odd groups reversed); a rank's bands are ONE "
       "`lh_render_ao_bands` call (one device batch).  Times are best-of-3 wall times of every rank's batch, run one after the other on one "
       "GPU.  Prediction for N ranks = max over ranks of its batch + gather, where the gather moves "
-      "(N-1)/N of the frame (%d MB fp32 RGB) to rank 0 over N-1 xGMI links in parallel at %.0f GB/s per link.\n" % (size * size * 12 // 1000000, LINK_GBPS))
-print("| ranks | bands | band rows | sum over ranks (ms) | busiest rank (ms) | least busy (ms) | imbalance | gather (ms) | predicted frame (ms) | predicted speed-up |")
-print("|---|---|---|---|---|---|---|---|---|---|")
+      "(N-1)/N of the frame (%d MB fp32 RGB) to rank 0 over N-1 xGMI links in parallel at %.0f GB/s per link; the last column adds what the two barriers "
+      "around a timed frame cost between real processes (p50: %s ms at 2 / 4 / 8 ranks, profiles/r04_skew.txt).\n" % (size * size * 12 // 1000000, LINK_GBPS, " / ".join("%.2f" % SKEW_MS[k] for k in (2, 4, 8))))
+print("| ranks | bands | band rows | sum over ranks (ms) | busiest rank (ms) | least busy (ms) | imbalance | gather (ms) | predicted frame (ms) | predicted speed-up | with the barriers' skew |")
+print("|---|---|---|---|---|---|---|---|---|---|---|")
 rows = {}
 slab = torch.zeros(size * size * 3 + 64 * size * 3, dtype=torch.float32, device="cuda")
-for world, want_rows in ((1, None), (2, None), (4, None), (8, None), (8, 1), (8, 16), (8, 64)):
+for world, want_rows in ((1, None), (2, None), (4, None), (8, None), (8, 4), (8, 16), (8, 64), (8, 128)):
     brow, y0s = render.bands_for(size, world, want_rows)
     per = []
     for r in range(world):
-        mine = [y0s[b] for b in shard.tiles_of_rank(len(y0s), r, world)]
+        mine = [y0s[b] for b in shard.bands_of_rank(len(y0s), r, world)]
         out = slab[:len(mine) * brow * size * 3].view(len(mine), brow, size, 3)
         best = 1e9
         for _ in range(3):
@@ -53,9 +55,9 @@ for world, want_rows in ((1, None), (2, None), (4, None), (8, None), (8, 1), (8,
     gather = 0.0 if world == 1 else (size * size * 12 / world) / (LINK_GBPS * 1e9)       # each peer sends its 1/N of the frame over its own link
     pred = max(per) + gather
     rows.setdefault(world, (per, pred))
-    print("| %d | %d | %d | %.2f | %.2f | %.2f | %.1f %% | %.2f | %.2f | %.2fx |" % (world, len(y0s), brow, sum(per) * 1e3, max(per) * 1e3, min(per) * 1e3,
-          100.0 * (max(per) / (sum(per) / world) - 1.0), gather * 1e3, pred * 1e3, rows[1][1] / pred))
-print("\nPer-rank batch time at 8 ranks (ms): " + " ".join("%.2f" % (x * 1e3) for x in rows[8][0]))
+    print("| %d | %d | %d | %.2f | %.2f | %.2f | %.1f %% | %.2f | %.2f | %.2fx | %.2fx |" % (world, len(y0s), brow, sum(per) * 1e3, max(per) * 1e3, min(per) * 1e3,
+          100.0 * (max(per) / (sum(per) / world) - 1.0), gather * 1e3, pred * 1e3, rows[1][1] / pred, rows[1][1] / (pred + SKEW_MS[world] * 1e-3)))
+print("\nPer-rank batch time at 8 ranks, default bands (ms): " + " ".join("%.2f" % (x * 1e3) for x in rows[8][0]))
 print("\nReading: a rank renders ALL of its bands as one device batch (`lh_render_ao_bands`), so the per-launch drain of the persistent "
       "traversal kernel (as long as its slowest ray: bounded by the visit budget since round 3) is paid "
       "once per rank and frame.  The sum over ranks exceeds the one-batch frame by (ranks - 1) drains plus what the finer interleave costs in "
