@@ -585,12 +585,7 @@ __device__ __forceinline__ void trace_persist_lane(
             wbase += take;
         }
         const unsigned long long work = __ballot((L.cur != kDone) | (pend != 0));
-        if (work == 0ull) {
-            /* nothing to walk: the end -- unless the refill handed out rays that are finished before their first step (forced to
-             * the reference walk: ray_needs_ref_walk): they are retired at the top of the loop */
-            if (SRC != 0 || __ballot(my != kNoRay) == 0ull) break;
-            continue;
-        }
+        if (work == 0ull) break;
         /* ---- walk until too few lanes remain active ---------------------- */
         const int thresh = exhausted ? 1 : min_active;
         if (WALK == 3)
@@ -687,7 +682,10 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
      * share a hardware queue this kernel only starts when the producer has finished: it then leaves at once, and the sweep --
      * owner_groups = that pass's group count, launched behind the producer on its own stream with a grid that fills the chip --
      * takes every entry no owner has taken (e >= heads[e mod owner_groups]).  (A serialised small pass over the 475 000 queued
-     * rays of a BASELINE config-5 frame took 30 ms: bench.py's device-tree frame, 89 -> 122 ms, until r03.) */
+     * rays of a BASELINE config-5 frame took 30 ms: bench.py's device-tree frame, 89 -> 122 ms, until r03.)
+     * Round 5 tried ONE consumer instead -- the sweep's grid on the second stream, working the queue off to its end, nothing
+     * launched afterwards (a sweep costs 65-73 us even with nothing to do) -- and lost: a rank's share of the config-5 frame
+     * 8.43 -> 8.65 ms, the path-traced frame 128.8 -> 130.1 ms, S-soup-1M 2 247 -> 2 236 Mrays/s (profiles/README.md r05). */
     extern __shared__ int lh_stack_lds[];          /* [rows][64] stack + 2 x 64 exchange words */
     const int rows = (int)sc.stack_rows, rmask = rows - 1;          /* rows: a power of two (ring of stack positions) */
     int (*stk)[64] = (int (*)[64])lh_stack_lds;

@@ -92,7 +92,10 @@ __device__ __forceinline__ bool ray_needs_ref_walk(const lh_dev_scene_t &sc, dou
 {
     return (fmax(fabs(dx), fmax(fabs(dy), fabs(dz))) > (double)sc.deg_dcap) & (sc.ref_nodes != NULL);
 }
-#define LH_FORCE_REF_WALK(L, best) do { (L).cur = kDone; (best).prim = 0u; (best).frag = 1u; } while (0)
+/* a negative culling bound: the root's children are all missed (slab_w: 0 <= tn <= tf <= tb fails), the ray is finished after one
+ * node step like any other -- no special case in the walks' control flow (a ray that is idle before its first step cost the
+ * dump kernel 80 bytes of scratch per lane) -- and retires as a fragile hit */
+#define LH_FORCE_REF_WALK(L, best) do { (L).tb = -1.0f; (best).prim = 0u; (best).frag = 1u; } while (0)
 
 /* lh_slab_w (lh_filter.h) written for the VALU: per axis one rotate (v_alignbit_b32 by 0 or 16)
  * puts (near, far) into the (low, high) halves, two SDWA converts, two FMAs: 136 VALU ops per

@@ -21,7 +21,8 @@ if per_cu > 0:
     acc.set_param("grid", int(torch.cuda.get_device_properties(0).multi_processor_count * per_cu)); acc.set_param("stack_cap", cap)
 c = g["camera"]; cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
 brow, y0s = render.bands_for(size, world, want)
-for r in (0, world - 1):
+ranks = [int(x) for x in os.environ["LH_PROBE_RANKS"].split(",")] if os.environ.get("LH_PROBE_RANKS") else (0, world - 1)
+for r in ranks:
     mine = [y0s[b] for b in shard.bands_of_rank(len(y0s), r, world)]
     out = torch.zeros((len(mine), brow, size, 3), dtype=torch.float32, device="cuda")
     ts = []

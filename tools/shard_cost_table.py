@@ -38,7 +38,7 @@ print("Shards = `render.bands_for(H, world)`: full-width bands (column 3: lines 
       "around a timed frame cost between real processes (p50: %s ms at 2 / 4 / 8 ranks, profiles/r04_skew.txt).\n" % (size * size * 12 // 1000000, LINK_GBPS, " / ".join("%.2f" % SKEW_MS[k] for k in (2, 4, 8))))
 print("| ranks | bands | band rows | sum over ranks (ms) | busiest rank (ms) | least busy (ms) | imbalance | gather (ms) | predicted frame (ms) | predicted speed-up | with the barriers' skew |")
 print("|---|---|---|---|---|---|---|---|---|---|---|")
-rows = {}
+rows = {}; hits_of = {}; per_of = {}
 slab = torch.zeros(size * size * 3 + 64 * size * 3, dtype=torch.float32, device="cuda")
 for world, want_rows in ((1, None), (2, None), (4, None), (8, None), (8, 4), (8, 16), (8, 64), (8, 128)):
     brow, y0s = render.bands_for(size, world, want_rows)
@@ -49,15 +49,19 @@ for world, want_rows in ((1, None), (2, None), (4, None), (8, None), (8, 4), (8,
         best = 1e9
         for _ in range(3):
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            acc.render_ao_bands(cam, mine, brow, 1, ns, seed=1, out=out); torch.cuda.synchronize()
+            _, st_ = acc.render_ao_bands(cam, mine, brow, 1, ns, seed=1, out=out); torch.cuda.synchronize()
             best = min(best, time.perf_counter() - t0)
-        per.append(best)
+        per.append(best); hits_of.setdefault((world, brow), []).append(st_["primary_hits"])
     gather = 0.0 if world == 1 else (size * size * 12 / world) / (LINK_GBPS * 1e9)       # each peer sends its 1/N of the frame over its own link
     pred = max(per) + gather
-    rows.setdefault(world, (per, pred))
+    rows.setdefault(world, (per, pred)); per_of[(world, brow)] = per
     print("| %d | %d | %d | %.2f | %.2f | %.2f | %.1f %% | %.2f | %.2f | %.2fx | %.2fx |" % (world, len(y0s), brow, sum(per) * 1e3, max(per) * 1e3, min(per) * 1e3,
           100.0 * (max(per) / (sum(per) / world) - 1.0), gather * 1e3, pred * 1e3, rows[1][1] / pred, rows[1][1] / (pred + SKEW_MS[world] * 1e-3)))
 print("\nPer-rank batch time at 8 ranks, default bands (ms): " + " ".join("%.2f" % (x * 1e3) for x in rows[8][0]))
+print("\nPer rank, 8 ranks, by band height -- batch ms (camera-ray hits of the rank, thousands):\n")
+for (w_, b_), per in per_of.items():
+    if w_ == 8:
+        print("* %d lines: " % b_ + "  ".join("%.2f (%d)" % (x * 1e3, h // 1000) for x, h in zip(per, hits_of[(w_, b_)])))
 print("\nReading: a rank renders ALL of its bands as one device batch (`lh_render_ao_bands`), so the per-launch drain of the persistent "
       "traversal kernel (as long as its slowest ray: bounded by the visit budget since round 3) is paid "
       "once per rank and frame.  The sum over ranks exceeds the one-batch frame by (ranks - 1) drains plus what the finer interleave costs in "
