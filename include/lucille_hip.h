@@ -358,7 +358,7 @@ int  lh_dist_gather(lh_dist_t *dist, const void *d_send, size_t bytes, void *d_r
 /* rank 0: a committed accelerator; the others: a fresh one (lh_accel_create), committed on return -- no build, no host
  * copy of the tree on those ranks (lh_accel_export and replicas of it are refused) */
 int  lh_dist_broadcast_scene(lh_dist_t *dist, lh_accel_t *accel);
-/* the AO frame sharded over the ranks: bands of band_rows lines (<= 0: 32), dealt out in serpentine order (groups of `world`
+/* the AO frame sharded over the ranks: bands of band_rows lines (<= 0: 16), dealt out in serpentine order (groups of `world`
  * bands, even groups in rank order, odd groups reversed: a steady change of cost down the image cancels); rgb (rank 0 only): height
  * rows of width RGB floats, top row first; stats: the frame's totals on rank 0, the rank's own elsewhere */
 int  lh_dist_render_ao_frame_host(lh_dist_t *dist, lh_accel_t *accel, const lh_camera_t *cam, int pixel_samples,

@@ -40,7 +40,7 @@
 #include "lh_internal.h"
 
 #define DFAIL(...) lh_fail(__VA_ARGS__)
-#define LH_DIST_BAND_ROWS 32         /* lines per band of a sharded AO frame unless the caller says (render.py DEFAULT_BAND_ROWS; profiles/r05_shard_cost_table.md) */
+#define LH_DIST_BAND_ROWS 16         /* lines per band of a sharded AO frame unless the caller says (render.py DEFAULT_BAND_ROWS; profiles/r05_shard_cost_table.md) */
 
 
 struct rccl_api {
@@ -86,7 +86,7 @@ struct lh_dist {
     /* shm transport */
     char shm_name[96]; shm_ctl *ctl; unsigned op;
     /* frame assembly on rank 0 */
-    lh_buf slab, all, frame, bands, agree;
+    lh_buf slab, mono, all, frame, bands, agree;
 };
 
 static double now_sec(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
@@ -294,7 +294,7 @@ extern "C" void lh_dist_destroy(lh_dist_t *d)
 {
     if (!d) return;
     (void)hipSetDevice(d->device);
-    lh_free_buf(&d->slab); lh_free_buf(&d->all); lh_free_buf(&d->frame); lh_free_buf(&d->bands); lh_free_buf(&d->agree);
+    lh_free_buf(&d->slab); lh_free_buf(&d->mono); lh_free_buf(&d->all); lh_free_buf(&d->frame); lh_free_buf(&d->bands); lh_free_buf(&d->agree);
     if (d->transport == LH_DIST_RCCL && d->comm) (void)g_rccl.CommDestroy(d->comm);
     if (d->ctl) { (void)shm_barrier(d); munmap((void *)d->ctl, 4096); if (d->rank == 0) shm_unlink(d->shm_name); }
     if (d->stream) (void)hipStreamDestroy(d->stream);
@@ -465,7 +465,15 @@ extern "C" int lh_dist_broadcast_scene(lh_dist_t *d, lh_accel_t *accel)
  * or world - 1 - pos (g odd).  Plain interleaving hands the last rank the lower band of EVERY group: where the cost of a line
  * changes steadily down the image that rank carries the whole slope (config 5, 64-line bands: 7 %); the serpentine cancels a linear
  * slope exactly, so the bands can be tall -- and coherent.  Same rule: lucille_amd/shard.py bands_of_rank */
-__global__ void k_place_bands(const float *__restrict__ slabs, float *__restrict__ frame, int world, int per, int rows, int W, int H)
+/* ch: floats per pixel of the slabs -- 3 (RGB), or 1: an AO frame is grey (Lo = (N - occluded) / N in every channel,
+ * ambientocclusion.c:383-401), so the exchange step moves ONE float per pixel and the owner of the display writes it three times */
+__global__ void k_take_channel0(size_t npix, const float *__restrict__ rgb, float *__restrict__ mono)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < npix) mono[i] = rgb[3 * i];
+}
+
+__global__ void k_place_bands(const float *__restrict__ slabs, float *__restrict__ frame, int world, int per, int rows, int W, int H, int ch)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)W * H) return;
@@ -474,9 +482,9 @@ __global__ void k_place_bands(const float *__restrict__ slabs, float *__restrict
     const int y0 = band * rows, h = (y0 + rows <= H) ? rows : H - y0;
     /* inside a band slab the first frame line of the band is the LAST of its h lines; a clipped band keeps them at the bottom */
     const int srow = (rows - h) + (h - 1 - (line - y0));
-    const float *src = slabs + ((((size_t)r * per + k) * rows + srow) * W + x) * 3;
+    const float *src = slabs + ((((size_t)r * per + k) * rows + srow) * W + x) * (size_t)ch;
     float *dst = frame + i * 3;
-    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    dst[0] = src[0]; dst[1] = ch == 3 ? src[1] : src[0]; dst[2] = ch == 3 ? src[2] : src[0];
 }
 
 extern "C" int lh_dist_render_ao_frame_host(lh_dist_t *d, lh_accel_t *accel, const lh_camera_t *cam, int pixel_samples,
@@ -505,11 +513,18 @@ extern "C" int lh_dist_render_ao_frame_host(lh_dist_t *d, lh_accel_t *accel, con
     if (ok) ok = lh_render_ao_bands(accel, cam, (int)y0.size(), y0.data(), band_rows, pixel_samples, gather_nsamples, seed, d->slab.p, &st, (void *)d->stream) == 0;
     char why[512]; why[0] = 0;
     if (!ok) snprintf(why, sizeof(why), "%s", lh_last_error());
-    if (ok && d->rank == 0 && lh_ensure_buf(&d->all, slab_bytes * (size_t)d->world)) { ok = 0; snprintf(why, sizeof(why), "%s", lh_last_error()); }
+    /* what travels: one float per pixel (k_take_channel0) */
+    const size_t slab_px = (size_t)per * band_rows * W, mono_bytes = slab_px * sizeof(float);
+    if (ok && lh_ensure_buf(&d->mono, mono_bytes)) { ok = 0; snprintf(why, sizeof(why), "%s", lh_last_error()); }
+    if (ok) {
+        hipLaunchKernelGGL(k_take_channel0, dim3((unsigned)((slab_px + 255) / 256)), dim3(256), 0, d->stream, slab_px, (const float *)d->slab.p, (float *)d->mono.p);
+        if (hipGetLastError() != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "k_take_channel0 launch failed"); }
+    }
+    if (ok && d->rank == 0 && lh_ensure_buf(&d->all, mono_bytes * (size_t)d->world)) { ok = 0; snprintf(why, sizeof(why), "%s", lh_last_error()); }
     const int all_ok = dist_agree(d, ok);
     if (all_ok < 0) return -1;
     if (!all_ok) return ok ? DFAIL("lh_dist_render_ao_frame_host: another rank could not render its bands; no frame") : DFAIL("lh_dist_render_ao_frame_host: rank %d: %s", d->rank, why);
-    if (lh_dist_gather(d, d->slab.p, slab_bytes, d->rank == 0 ? d->all.p : NULL, (void *)d->stream) != 0) return -1;
+    if (lh_dist_gather(d, d->mono.p, mono_bytes, d->rank == 0 ? d->all.p : NULL, (void *)d->stream) != 0) return -1;
     /* statistics: the sum over the ranks (four 64-bit counters through the same gather) -- ALWAYS, whether or not this rank's
      * caller asked for them: a collective every rank must enter */
     {
@@ -535,7 +550,7 @@ extern "C" int lh_dist_render_ao_frame_host(lh_dist_t *d, lh_accel_t *accel, con
         if (lh_ensure_buf(&d->frame, fb)) return -1;
         const size_t px = (size_t)W * H;
         hipLaunchKernelGGL(k_place_bands, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, d->stream, (const float *)d->all.p, (float *)d->frame.p,
-                           d->world, per, band_rows, W, H);
+                           d->world, per, band_rows, W, H, 1);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(rgb, d->frame.p, fb, hipMemcpyDeviceToHost, d->stream));
     }

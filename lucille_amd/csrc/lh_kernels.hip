@@ -548,7 +548,13 @@ __device__ __forceinline__ void trace_persist_lane(
                  * ~0.5 ms "drain" of every launch -- an EMPTY launch of the path tracer's bounce chain took 0.49 ms
                  * (profiles/r03_pt_sky_timeline.csv) */
                 for (;;) {
-                    if (drained == (1u << LH_NPART) - 1u) { exhausted = true; break; }       /* every partition has been handed out */
+                    if (drained == (1u << LH_NPART) - 1u) {       /* every partition has been handed out */
+                        exhausted = true;
+#ifdef LH_DIAG_CLOCK
+                        if (sc.diag_clock && (tid & 63) == 0) sc.diag_clock[(size_t)(2 * gridDim.x + blockIdx.x) * (LH_BLOCK / 64) + (tid >> 6)] = wall_clock64();
+#endif
+                        break;
+                    }
                     if (drained & (1u << part)) { part = (part + 1u) % LH_NPART; continue; }
                     const uint32_t p0 = per * part, p1 = (p0 + per < n) ? p0 + per : n;      /* per * LH_NPART < 2^31 + 8 */
                     const uint32_t plen = p1 > p0 ? p1 - p0 : 0u;                              /* a small batch leaves the last partitions empty */

@@ -71,7 +71,7 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
     if (stage_timing) { for (int k = 0; k < 6; k++) HIPCHK(hipEventCreate(&ev[k])); HIPCHK(hipEventRecord(ev[0], s)); }
     /* ... and the wall clock at which every persistent wave starts and leaves (two launches: closest, AO) */
     const size_t nwaves = (size_t)a->grid_blocks * (LH_BLOCK / 64);
-    if (stage_timing) { if (ensure_buf(&a->r_diag, sizeof(unsigned long long) * 4 * nwaves)) return -1; HIPCHK(hipMemsetAsync(a->r_diag.p, 0, sizeof(unsigned long long) * 4 * nwaves, s)); }
+    if (stage_timing) { if (ensure_buf(&a->r_diag, sizeof(unsigned long long) * 6 * nwaves)) return -1; HIPCHK(hipMemsetAsync(a->r_diag.p, 0, sizeof(unsigned long long) * 6 * nwaves, s)); }
     a->dev.diag_clock = stage_timing ? (unsigned long long *)a->r_diag.p : NULL;
     /* 1. camera rays */
     if (lh_render_launch_primary_region(cam, x0, w, nbands, band_rows, d_band_y0, y0, cam->height, ps, ps,
@@ -81,7 +81,7 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
     /* 2. closest hit */
     if (lh_launch(a, S, a->r_org.p, a->r_dir.p, a->r_prim.p, a->r_t.p, a->r_u.p, a->r_v.p, NULL, LH_MODE_CLOSEST,
                LH_VARIANT_DEFAULT, cnt, s, false) != 0) return -1;
-    if (stage_timing) { HIPCHK(hipEventRecord(ev[2], s)); a->dev.diag_clock = (unsigned long long *)a->r_diag.p + 2 * nwaves; }
+    if (stage_timing) { HIPCHK(hipEventRecord(ev[2], s)); a->dev.diag_clock = (unsigned long long *)a->r_diag.p + 3 * nwaves; }
     /* 3. compaction (deterministic: hits in sample order).  The fused AO stage does not need the total on the host: its buffers are
      * sized for the worst case (every sample hits) and its kernels read the count where the compaction left it -- a batch costs ONE
      * host round trip, at its end (round 5: the two in the middle were ~0.25 ms of a rank's 8.9 ms share of the config-5 frame).
@@ -196,10 +196,10 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
         fprintf(stderr, "[lucille_hip] AO batch stages (ms): primary %.3f closest %.3f compact %.3f ao %.3f resolve %.3f | samples %zu hits %llu ao rays %zu\n",
                 ms[0], ms[1], ms[2], ms[3], ms[4], S, nhit, nao);
         for (int k = 0; k < 6; k++) (void)hipEventDestroy(ev[k]);
-        std::vector<unsigned long long> clk(4 * nwaves);
-        HIPCHK(hipMemcpy(clk.data(), a->r_diag.p, sizeof(unsigned long long) * 4 * nwaves, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> clk(6 * nwaves);
+        HIPCHK(hipMemcpy(clk.data(), a->r_diag.p, sizeof(unsigned long long) * 6 * nwaves, hipMemcpyDeviceToHost));
         for (int launch = 0; launch < 2; launch++) {
-            const unsigned long long *st = clk.data() + 2 * nwaves * launch, *ex = st + nwaves;
+            const unsigned long long *st = clk.data() + 3 * nwaves * launch, *ex = st + nwaves, *dry = ex + nwaves;
             unsigned long long t0 = ~0ull; std::vector<double> e;
             for (size_t w = 0; w < nwaves; w++) if (st[w] && st[w] < t0) t0 = st[w];
             for (size_t w = 0; w < nwaves; w++) if (ex[w]) e.push_back((double)(ex[w] - t0) * 1e-5);        /* 100 MHz -> ms */
@@ -209,6 +209,15 @@ static int ao_region(lh_accel_t *a, const lh_camera_t *cam, int x0, int w, int n
             double last_start = 0; for (size_t w = 0; w < nwaves; w++) if (st[w]) last_start = fmax(last_start, (double)(st[w] - t0) * 1e-5);
             fprintf(stderr, "[lucille_hip]   %s kernel: %zu waves, last start %.3f ms; exits (ms) min %.3f p10 %.3f p50 %.3f p90 %.3f p99 %.3f max %.3f\n",
                     launch ? "AO" : "closest", e.size(), last_start, e.front(), q(0.10), q(0.50), q(0.90), q(0.99), e.back());
+            /* when a wave found every cursor dry, and how long it went on after that (its last range and its slowest last rays) */
+            std::vector<double> d, g;
+            for (size_t w = 0; w < nwaves; w++) if (dry[w] && ex[w]) { d.push_back((double)(dry[w] - t0) * 1e-5); g.push_back((double)(ex[w] - dry[w]) * 1e-5); }
+            if (!d.empty()) {
+                std::sort(d.begin(), d.end()); std::sort(g.begin(), g.end());
+                auto qq = [&](std::vector<double> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+                fprintf(stderr, "[lucille_hip]     cursors found dry at (ms) min %.3f p50 %.3f p90 %.3f max %.3f; exit - dry (ms) min %.3f p10 %.3f p50 %.3f p90 %.3f p99 %.3f max %.3f (%zu waves)\n",
+                        d.front(), qq(d, 0.5), qq(d, 0.9), d.back(), g.front(), qq(g, 0.1), qq(g, 0.5), qq(g, 0.9), qq(g, 0.99), g.back(), d.size());
+            }
         }
         a->dev.diag_clock = NULL;
     }

@@ -31,7 +31,7 @@ def render_ao_frame(acc, cam, pixel_samples, gather_nsamples, tile=256, seed=1, 
     return img, tot
 
 
-DEFAULT_BAND_ROWS = 32
+DEFAULT_BAND_ROWS = 16
 
 
 def bands_for(height, world, rows=None):
@@ -72,7 +72,10 @@ def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, worl
         if timing is not None:
             torch.cuda.synchronize(dev); t1 = time.perf_counter()
         shards = [(0, y0, W, min(rows, H - y0)) for y0 in y0s]
-        img = assemble_shards(slab, shards, W, H, rank, world, stride_rows=rows, serpentine=True)
+        # an AO frame is grey (Lo = (N - occluded) / N in every channel, ambientocclusion.c:383-401): ONE float per pixel travels,
+        # rank 0 writes it three times (lh_dist.hip k_take_channel0 / k_place_bands do the same for a C caller)
+        mono = slab.view(per, rows * W, 3)[:, :, 0].contiguous()
+        img = assemble_shards(mono, shards, W, H, rank, world, stride_rows=rows, serpentine=True, channels=1)
         if timing is not None:
             torch.cuda.synchronize(dev)
             timing.update(bands=len(mine), band_rows=rows, batch_ms=round((t1 - t0) * 1e3, 3), gather_ms=round((time.perf_counter() - t1) * 1e3, 3))
@@ -92,15 +95,18 @@ def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, worl
     return assemble_shards(slab, shards, W, H, rank, world), tot
 
 
-def assemble_shards(slab, shards, W, H, rank, world, stride_rows=None, serpentine=False):
+def assemble_shards(slab, shards, W, H, rank, world, stride_rows=None, serpentine=False, channels=3):
     """the exchange step (one gather of [per_rank, cap] slabs to rank 0) + placement with the reference's y flip
     (bucket_write, render.c:962-964).  stride_rows: the slab of a shard holds that many rows (bands of a batch: a clipped
     last band keeps its lines at the BOTTOM of its slab, the clipped lines being below the frame); None: h rows.
-    serpentine: the shards were dealt out by shard.bands_of_rank (AO bands), else by shard.tiles_of_rank."""
+    serpentine: the shards were dealt out by shard.bands_of_rank (AO bands), else by shard.tiles_of_rank.
+    channels: floats per pixel in the slabs (1: a grey frame, expanded to RGB here)."""
     import torch
     out = shard.gather_slabs(slab, rank, world)
     if rank != 0:
         return None
+    if channels == 1:
+        out = [o.view(o.shape[0], -1, 1).expand(-1, -1, 3).reshape(o.shape[0], -1) for o in out]
     of_rank = shard.bands_of_rank if serpentine else shard.tiles_of_rank
     if stride_rows is not None and H % stride_rows == 0:
         # regular bands: one indexed copy per rank, then one flip -- band 0 is the BOTTOM of the image, every band is

@@ -165,7 +165,11 @@ def _band_worker(rank, world, port, W, H, rows, q):
         slab[k] = t.view(-1)
     shards = [(0, y0, W, min(rows, H - y0)) for y0 in y0s]
     img = render.assemble_shards(slab, shards, W, H, rank, world, stride_rows=rows, serpentine=True)
+    # a grey frame travels as ONE float per pixel (channel 1 here: the frame line) and comes back as three
+    mono = slab.view(per, rows * W, 3)[:, :, 1].contiguous()
+    img1 = render.assemble_shards(mono, shards, W, H, rank, world, stride_rows=rows, serpentine=True, channels=1)
     if rank == 0:
+        assert img1.shape == (H, W, 3) and bool((img1 == img[..., 1:2]).all())
         q.put(img.numpy())
     dist.barrier()
     dist.destroy_process_group()

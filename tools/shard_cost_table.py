@@ -34,8 +34,8 @@ SKEW_MS = {1: 0.0, 2: 0.10, 4: 0.16, 8: 0.17}      # what a frame's two barriers
 print("Shards = `render.bands_for(H, world)`: full-width bands (column 3: lines per band; the default first), dealt out in serpentine order (`shard.bands_of_rank`: groups of `world` bands, even groups in rank order, odd groups reversed); a rank's bands are ONE "
       "`lh_render_ao_bands` call (one device batch).  Times are best-of-3 wall times of every rank's batch, run one after the other on one "
       "GPU.  Prediction for N ranks = max over ranks of its batch + gather, where the gather moves "
-      "(N-1)/N of the frame (%d MB fp32 RGB) to rank 0 over N-1 xGMI links in parallel at %.0f GB/s per link; the last column adds what the two barriers "
-      "around a timed frame cost between real processes (p50: %s ms at 2 / 4 / 8 ranks, profiles/r04_skew.txt).\n" % (size * size * 12 // 1000000, LINK_GBPS, " / ".join("%.2f" % SKEW_MS[k] for k in (2, 4, 8))))
+      "(N-1)/N of the frame (%d MB: one fp32 per pixel -- an AO frame is grey, rank 0 writes the value three times) to rank 0 over N-1 xGMI links in parallel at %.0f GB/s per link; the last column adds what the two barriers "
+      "around a timed frame cost between real processes (p50: %s ms at 2 / 4 / 8 ranks, profiles/r04_skew.txt).\n" % (size * size * 4 // 1000000, LINK_GBPS, " / ".join("%.2f" % SKEW_MS[k] for k in (2, 4, 8))))
 print("| ranks | bands | band rows | sum over ranks (ms) | busiest rank (ms) | least busy (ms) | imbalance | gather (ms) | predicted frame (ms) | predicted speed-up | with the barriers' skew |")
 print("|---|---|---|---|---|---|---|---|---|---|---|")
 rows = {}; hits_of = {}; per_of = {}
@@ -52,7 +52,7 @@ for world, want_rows in ((1, None), (2, None), (4, None), (8, None), (8, 4), (8,
             _, st_ = acc.render_ao_bands(cam, mine, brow, 1, ns, seed=1, out=out); torch.cuda.synchronize()
             best = min(best, time.perf_counter() - t0)
         per.append(best); hits_of.setdefault((world, brow), []).append(st_["primary_hits"])
-    gather = 0.0 if world == 1 else (size * size * 12 / world) / (LINK_GBPS * 1e9)       # each peer sends its 1/N of the frame over its own link
+    gather = 0.0 if world == 1 else (size * size * 4 / world) / (LINK_GBPS * 1e9)       # each peer sends its 1/N of the frame over its own link: ONE float per pixel (an AO frame is grey: render.py / lh_dist.hip k_take_channel0)
     pred = max(per) + gather
     rows.setdefault(world, (per, pred)); per_of[(world, brow)] = per
     print("| %d | %d | %d | %.2f | %.2f | %.2f | %.1f %% | %.2f | %.2f | %.2fx | %.2fx |" % (world, len(y0s), brow, sum(per) * 1e3, max(per) * 1e3, min(per) * 1e3,
