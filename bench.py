@@ -696,7 +696,7 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess, 
     dev_built = info["nnodes"] == info["nnodes_traversal"]; other_b = "host" if dev_built else "device"
     c = g["camera"]
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
-    # one GPU: the whole frame as one tile; sharded: full-width bands, ~16 per rank, band_id % world, ONE device batch per rank (render.bands_for / lh_render_ao_bands)
+    # one GPU: the whole frame as one tile; sharded: full-width bands in serpentine order, ONE device batch per rank (render.bands_for / shard.bands_of_rank / lh_render_ao_bands)
     tile = None if world > 1 else min(size, 4096)
     times = []; st = None; img = None; stats = []
     for it in range(steps + 1):
@@ -781,13 +781,20 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess, 
                   rays=int(st["primary_rays"] + st["ao_rays"]))
         print("[bench rank %d] ao_render %s" % (rank, json.dumps(tm)), file=sys.stderr, flush=True)
         ranks = shard.all_gather_object(tm)
+    # N > 1: the gathered frame against the SAME frame rendered as one batch on rank 0's own replica (untimed): bit for bit
+    # (the sample stream is keyed by absolute pixel and sample, so sharding must not move a bit)
+    sharded_equal = None
+    if world > 1 and rank == 0:
+        one, st_one = render.render_ao_frame(acc, cam, 1, nsamples, tile=min(size, 4096)); torch.cuda.synchronize(dev)
+        sharded_equal = bool(torch.equal(one, img)) and int(st_one["primary_rays"] + st_one["ao_rays"]) == int(rays_all)
+        ok = ok and sharded_equal; del one
     ok_all = (shard.all_reduce_min(1.0 if ok else 0.0) if world > 1 else (1.0 if ok else 0.0)) > 0.5
     acc.close()
     if rank != 0:
         return None
     return {"workload": "BASELINE config 5: examples/ambient_occlusion scene tessellated to %d tris, %dx%d, %d AO samples, frame wall incl. ray gen + tile gather"
                         % (ntri, size, size, nsamples), "triangles": ntri,
-            "tile": tile if tile is not None else "%d full-width bands of %d rows, band_id %% %d, one device batch per rank" % (
+            "tile": tile if tile is not None else "%d full-width bands of %d rows dealt out to %d ranks in serpentine order (shard.bands_of_rank), one device batch per rank, one float per pixel gathered" % (
                 len(render.bands_for(size, world)[1]), render.bands_for(size, world)[0], world),
             "device_bytes": info["device_bytes"], "build_s": round(info["build_seconds"], 3),
             "ref_tree_build_s": round(info["ref_build_seconds"], 3),
@@ -797,7 +804,7 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess, 
             "rays_per_frame": int(rays_all), "frame_ms": round(t_all * 1e3, 3),
             "value": round(rays_all / t_all / 1e6, 1), "unit": "Mrays/s", "scaling": "strong",
             "image_mean": float(img.mean().item()), "roofline": roof, "other_builder": devb, "ranks": ranks,
-            "validation": {"frames_repeat": ok_all, "retiled_frame_bit_equal": bool(ok) if world == 1 else None,
+            "validation": {"frames_repeat": ok_all, "retiled_frame_bit_equal": bool(ok) if world == 1 else None, "sharded_frame_equals_one_batch": sharded_equal,
                            "primary_hits": int(stats[0]["primary_hits"]) if world == 1 else None, "ok": ok_all}}
 
 

@@ -23,10 +23,12 @@ def _lsh_async(args, cwd):
     return subprocess.Popen([rib.lsh_hip_path()] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_lsh_hip_ranks_write_the_single_gpu_frame(tmp_path, world):
     """`lsh_hip --rank R --world N` -- N processes, rank 0 builds and broadcasts the scene, every rank
-    renders its interleaved bands as one batch, rank 0 gathers and writes the .hdr: byte-equal to the single-process file"""
+    renders its bands (serpentine order) as one batch, rank 0 gathers and writes the .hdr: byte-equal to the single-process file.
+    world = 8: 138 lines in 16-line bands are 9 bands -- per = ceil(9 / 8) = 2 slabs per rank, seven ranks with
+    one band and an empty second slab, the last band clipped: the slab padding and the seven-receive group of the driver's launch"""
     rib_path = os.path.join(RIB, "ambient_occlusion.rib")
     common = ["--resolution", "200x138", "--gather", "16", "--pixelsamples", "2", "--seed", "5"]
     one = subprocess.run([rib.lsh_hip_path()] + common + ["--output", "one.hdr", rib_path], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)

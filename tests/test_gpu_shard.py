@@ -133,3 +133,44 @@ def test_bench_n2_over_the_rccl_branch_with_a_mock_library():
     assert j["n_gpus"] == 2 and j["validation"]["ok"] and j["validation"]["gathered_records_ok"]
     assert j["config"]["scene_load"]["transport"] == "rccl" and all(r_["transport"] == "rccl" and r_["rccl_status"] == "ok" for r_ in j["ranks"])
     assert j["exchange"]["transport_ok"] and j["ao_render"]["validation"]["ok"] and all(r_["transport"] == "rccl" for r_ in j["ao_render"]["ranks"])
+
+
+def _bench_n8(extra_env, extra_args=()):
+    env = dict(os.environ); env.update(extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--device-override", "0", "--rays", "1600003", "--tris", "60000", "--half-extent", "0.012",
+           "--no-cpu", "--no-hbm", "--ao-size", "200", "--ao-tess", "2", "--ao-samples", "16", "--pt-size", "96", "--pt-spp", "4"] + list(extra_args)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1500)
+    return r, (json.loads([l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l][-1]) if r.returncode == 0 else None)
+
+
+def _check_n8(j, transport):
+    assert j["n_gpus"] == 8 and j["scaling"] == "strong" and j["config"]["rays"] == 1600003
+    assert j["validation"]["ok"] and j["validation"]["gathered_records_ok"] and j["validation"]["timed_equals_counted_launch"]
+    assert [r_["rank"] for r_ in j["ranks"]] == list(range(8)) and all(r_["transport"] == transport for r_ in j["ranks"])
+    assert sum(r_["rays"] for r_ in j["ranks"]) == 1600003
+    ao = j["ao_render"]
+    # 200 lines in 16-line bands: 13 bands on 8 ranks -- per = 2 slabs, three ranks hold an empty second slab, the last band is clipped
+    assert ao["validation"]["ok"] and ao["validation"]["sharded_frame_equals_one_batch"] is True
+    assert [r_["rank"] for r_ in ao["ranks"]] == list(range(8)) and sorted(r_["bands"] for r_ in ao["ranks"]) == [1, 1, 1, 2, 2, 2, 2, 2]
+    assert all(r_["transport"] == transport for r_ in ao["ranks"]) and j["pt_render"]["rays_per_frame"] > 0
+
+
+def test_bench_n8_code_path_on_one_gpu():
+    """bench.py exactly as the driver launches it for N = 8 -- eight processes, all on device 0 (shared-memory
+    transport): eight `ranks` entries, the gathered records and the gathered AO frame equal to what one rank produces alone"""
+    r, j = _bench_n8({})
+    assert r.returncode == 0, r.stderr[-3000:]
+    _check_n8(j, "shm")
+    assert all("share a device" in r_["rccl_status"] for r_ in j["ranks"])
+
+
+def test_bench_n8_over_the_rccl_branch_with_a_mock_library():
+    """... and over lh_dist_*'s RCCL branch (tests/mock_rccl): ncclCommInitRank with eight ranks, the scene through ncclBroadcast,
+    the seven-receive group of every gather on rank 0, the status words agreed by eight ranks"""
+    from tests.test_gpu_dist_mock import build_mock
+    r, j = _bench_n8({"LH_DIST_TRANSPORT": "rccl", "LH_RCCL_LIBRARY": build_mock(), "MOCK_RCCL_TIMEOUT": "240"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    _check_n8(j, "rccl")
+    assert j["config"]["scene_load"]["transport"] == "rccl" and j["exchange"]["transport_ok"] and all(r_["rccl_status"] == "ok" for r_ in j["ranks"])
