@@ -40,6 +40,7 @@ Every timed launch is validated in-run (`validation`).
 import argparse
 import ctypes as C
 import json
+import subprocess
 import os
 import sys
 import time
@@ -135,6 +136,7 @@ def main():
     ap.add_argument("--cpu-rays", type=int, default=1_500_000, help="cpu_baseline sample size")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-hbm", action="store_true", help="skip the S-soup-10M HBM-roofline leg")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the gather microbenchmark (roofline.gather_ceiling)")
     ap.add_argument("--hbm-tris", type=int, default=10_000_000)
     ap.add_argument("--hbm-rays", type=int, default=50_000_000)
     ap.add_argument("--no-ao", action="store_true", help="skip the secondary AO-frame leg")
@@ -385,14 +387,14 @@ def main():
     if rank == 0:
         value = n_total * args.steps / elapsed / 1e6
         achieved = b_ray * n / (kernel_ms * 1e-3) / 1e9
-        traffic = traffic_source = None
+        traffic = traffic_source = traffic_ms = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc) and world == 1:
             try:
                 j = json.load(open(pmc))
                 if j.get("rays_per_launch") == n and j.get("mode") == args.mode and j.get("kernel_tag") == node_fmt \
                         and args.variant in (-1, 4):
-                    traffic = j.get("hbm_bytes_per_launch")
+                    traffic = j.get("hbm_bytes_per_launch"); traffic_ms = j.get("kernel_avg_ms_rocprof")
                     traffic_source = pmc_source("profiles/pmc_latest.json", j)
             except Exception:
                 traffic = traffic_source = None
@@ -419,6 +421,7 @@ def main():
             "roofline": {"bound": "l2+mall" if hot_mb < 256.0 else "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_over_algorithmic": None if traffic is None else round(traffic / (b_ray * n), 3),
+                         "traffic_frac_of_peak": None if traffic is None or not traffic_ms else round(traffic / (traffic_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                          "peak_note": "peak = the 8 TB/s HBM datasheet figure, kept as the common denominator; this workload's hot set is cache-resident, "
                                       "so `frac` is NOT a fraction of a bandwidth the data asked of HBM -- the HBM-bound figure is roofline_hbm.frac",
                          "formula": "bytes_per_ray = %d + %d + %d x nodes_per_ray + %d x tris_per_ray (SURVEY 8d); achieved = bytes_per_ray x rays_per_launch / kernel_ms; "
@@ -454,6 +457,15 @@ def main():
             bad = [r_ for r_ in ranks if r_["transport"] != "rccl"]
             distinct = len(set(r_["device"] for r_ in ranks)) == world
             res["exchange"]["transport_ok"] = not (bad and distinct and os.environ.get("LH_DIST_TRANSPORT") != "shm")
+        if world == 1 and not args.no_ceiling:
+            # the ceiling that actually binds a cache-resident incoherent walk, measured now: random dependent 64-byte records at
+            # this scene's footprint, four workgroups per CU like the walk; `frac_of_gather_ceiling` = the walk's records per second
+            # (node visits + triangle records, both one request each) over it
+            gc = gather_ceiling(max(16.0, hot_mb), 0)
+            res["roofline"]["gather_ceiling"] = gc
+            rec_s = (n_nodes + n_tris) * n / (kernel_ms * 1e-3)
+            res["roofline"]["records_per_s"] = round(rec_s, 0)
+            res["roofline"]["frac_of_gather_ceiling"] = round(rec_s / gc["records_per_s"], 4) if "records_per_s" in gc else None
         if copy_gbps is not None:
             # the box's own device-to-device copy rate next to the 8 TB/s datasheet peak
             res["roofline"]["measured_copy_GBps"] = round(copy_gbps, 1)
@@ -473,6 +485,11 @@ def main():
             res["config2"] = c2
         if not args.no_cpu and world == 1:            # rank 0 at N = 1 only (the contract)
             res["cpu_baseline"] = cpu_baseline(P, idx, first[0], first[1])
+            if not res["cpu_baseline"]["kind_ok"]:
+                res["validation"]["cpu_baseline_is_the_compiled_reference"] = False
+                res["validation"]["ok"] = False
+                print("[bench] FAILED: cpu_baseline fell back to the port: oracle/_ref/liblucille_ref.so did not travel with the snapshot "
+                      "(__graft_entry__.build() builds it where /root/reference exists; LH_ALLOW_PORT_BASELINE=1 accepts the port)", file=sys.stderr, flush=True)
         print(json.dumps(res), flush=True)
     acc.close()
     rc = 0
@@ -558,6 +575,25 @@ def host_path_leg(acc, d_org, d_dir, n):
                       "streams, 48 B/ray up + 28 B/ray down over PCIe; never the headline value" % nh}
 
 
+def gather_ceiling(mb, mode, lds=40000, steps=200):
+    """SURVEY 8d / VERDICT r04 item 4: what binds the incoherent walk is not the HBM datasheet figure but the memory system's rate
+    for DEPENDENT random records -- tools/ubench/gather (one chain per lane, every link perturbed by the chain's own running
+    sum), run here, on this box, at this leg's footprint and occupancy: mode 0 = 64-byte records (a 4-wide node), mode 5 =
+    128-byte records (an 8-wide node).  -> {"records_per_s": G/s, ...} or {"error": ...}"""
+    exe = os.path.join(ROOT, "tools", "ubench", "gather")
+    cmd = [exe, str(int(mb)), str(steps), "4096", str(mode)]
+    try:
+        env = dict(os.environ, GATHER_LDS=str(lds))
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=env).stdout
+        line = [l for l in out.splitlines() if l.startswith("array") and ("mode %d:" % mode) in l][-1]
+        g = float(line.split("ms")[1].split("G chain-steps/s")[0])
+        return {"records_per_s": round(g * 1e9, 0), "record_bytes": 64 if mode == 0 else 128, "footprint_MB": int(mb), "blocks_per_cu": int(160 * 1024 // lds),
+                "cmd": "GATHER_LDS=%d tools/ubench/gather %d %d 4096 %d" % (lds, int(mb), steps, mode), "raw": line.strip(),
+                "what": "dependent random gather, one chain per lane, 256 CUs x %d workgroups; the incoherent walk's binding ceiling (DESIGN 3.3)" % int(160 * 1024 // lds)}
+    except Exception as e:                                  # noqa: BLE001 -- context, the leg stands without it
+        return {"error": repr(e), "cmd": " ".join(cmd)}
+
+
 def pmc_source(path, j):
     """where a `traffic` figure comes from: it is NOT measured inside this run (rocprofv3 counter passes re-run the whole
     command: tools/profile_round2.sh), it is the committed summary of the same command's last counter passes"""
@@ -610,19 +646,23 @@ def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
     ok = all(torch.equal(a[:ns], b) for a, b in zip(out, cnt_out))
     hit = float((out[0] != -1).float().mean().item())
     achieved = b_ray * n / (ms * 1e-3) / 1e9
-    traffic = traffic_source = None
+    traffic = traffic_source = traffic_ms = None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest_hbm.json")
     if os.path.exists(pmc):
         try:
             j = json.load(open(pmc))
             if j.get("rays_per_launch") == n and j.get("triangles") == args.hbm_tris and j.get("kernel_tag") == node_fmt:
-                traffic = j.get("hbm_bytes_per_launch")
+                traffic = j.get("hbm_bytes_per_launch"); traffic_ms = j.get("kernel_avg_ms_rocprof")
                 traffic_source = pmc_source("profiles/pmc_latest_hbm.json", j)
         except Exception:
             traffic = traffic_source = None
     info = acc.info()
     hot = info["nnodes_traversal"] * 64 + info["ntriangles"] * 48
+    hot8 = (info["nnodes_traversal"] * 128 * 3 // 7 if node_bytes == 128 else info["nnodes_traversal"] * 64) + info["ntriangles"] * 48       # an 8-wide tree has ~3/7 of the 4-wide tree's nodes
     acc.close()
+    # the ceiling of THIS leg's access pattern, measured now: dependent random records of the size the walk fetches, at the
+    # scene's footprint (HBM-resident), at the walk's occupancy (three workgroups per CU for the 8-wide walk, four for the 4-wide)
+    gc = None if args.no_ceiling else gather_ceiling(min(4096.0, hot8 / 1e6), 5 if node_bytes == 128 else 0, lds=53000 if node_bytes == 128 else 40000)
     # the twin on the OTHER builder's tree: same rays, same records
     twin = None
     try:
@@ -650,7 +690,10 @@ def hbm_leg(la, scenes, torch, dev, local, args, hip, sptr, node_fmt):
     return {"workload": "S-soup-10M ray dump: %d random triangles (half-extent 0.002), %d incoherent rays, closest-hit" % (args.hbm_tris, n),
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": traffic, "traffic_source": traffic_source,
-            "traffic_frac_of_peak": None if traffic is None else round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "traffic_frac_of_peak": None if traffic is None else round(traffic / ((traffic_ms or ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "traffic_frac_note": "bytes AND time of the same profiled run (%s ms per launch under the counters; this run: %.3f ms)" % (traffic_ms, ms),
+            "gather_ceiling": gc, "records_per_s": round((n_nodes + n_tris) * n / (ms * 1e-3), 0),
+            "frac_of_gather_ceiling": None if not gc or "records_per_s" not in gc else round((n_nodes + n_tris) * n / (ms * 1e-3) / gc["records_per_s"], 4),
             "traffic_over_algorithmic": None if traffic is None else round(traffic / (b_ray * n), 3),
             "formula": "bytes_per_ray = %d (ray in) + %d (hit record out) + %d x nodes_per_ray + %d x tris_per_ray -- SURVEY 8d's constants "
                        "(B_in, B_out, B_node, B_tri), whatever the walk really moves (this kernel reads 48 B of fp64 ray and writes a 28-B record per ray, "
@@ -980,9 +1023,16 @@ def cpu_baseline(P, idx, org, dr):
     if po.ref_available():
         ref = po.RefLib()
         ref.add_mesh(P, idx); ref.build()
-        t0 = time.perf_counter(); ref.intersect(org, dr); dt = time.perf_counter() - t0
-        out = {"value": round(org.shape[0] / dt / 1e6, 4), "unit": "Mrays/s", "cores": 1, "kind": "reference",
-               "sample": "first %d rays of the same S-soup ray dump, ri_raytrace() per ray, %.1f s" % (org.shape[0], dt)}
+        # three thirds of the sample, timed one after the other: the median, and the spread between them (r04: one un-repeated
+        # sample read 0.128 and 0.156 Mrays/s on two boxes)
+        m = org.shape[0] // 3; rates = []; dt = 0.0
+        for k in range(3):
+            t0 = time.perf_counter(); ref.intersect(org[k * m:(k + 1) * m], dr[k * m:(k + 1) * m]); d_ = time.perf_counter() - t0
+            rates.append(m / d_ / 1e6); dt += d_
+        rates.sort()
+        out = {"value": round(rates[1], 4), "unit": "Mrays/s", "cores": 1, "kind": "reference",
+               "repeats": [round(r_, 4) for r_ in rates], "spread": round((rates[2] - rates[0]) / rates[1], 3),
+               "sample": "the first %d rays of the same S-soup ray dump in three parts of %d, ri_raytrace() per ray, %.1f s; value = the median part" % (3 * m, m, dt)}
     o = po.Oracle(); o.add_mesh(P, idx); o.build()
     sub = min(org.shape[0], 300_000)
     t0 = time.perf_counter(); o.intersect(org[:sub], dr[:sub], nthreads=1); dt1 = time.perf_counter() - t0
@@ -991,6 +1041,10 @@ def cpu_baseline(P, idx, org, dr):
         out = {"value": round(one, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
                "sample": "first %d rays of the same S-soup ray dump, %.1f s" % (sub, dt1)}
     out["host"] = hc
+    # the compiled reference (oracle/_ref: built by __graft_entry__.build() where /root/reference exists, shipped to the GPU box with
+    # the snapshot) is what this leg is expected to time: a run that silently fell back to the port says so and turns the line red
+    out["expected_kind"] = "port" if os.environ.get("LH_ALLOW_PORT_BASELINE") == "1" else "reference"
+    out["kind_ok"] = out["kind"] == out["expected_kind"] or out["kind"] == "reference"
     curve = []
     for nt in sorted(set(t for t in (8, 32, ncores) if t <= ncores)):
         reps = max(1, min(8, nt // 8))
