@@ -13,7 +13,7 @@
 #include <vector>
 #include <cstdint>
 
-#define LAUNCH(M, ...) do { if (perturb) hipLaunchKernelGGL((k_gather<M, true>), __VA_ARGS__); else hipLaunchKernelGGL((k_gather<M, false>), __VA_ARGS__); } while (0)
+#define LAUNCH(M, ...) do { if (perturb) hipLaunchKernelGGL((k_gather<M, true>), __VA_ARGS__, alu); else hipLaunchKernelGGL((k_gather<M, false>), __VA_ARGS__, alu); } while (0)
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 // PERTURB: modes 1, 3 and 6 originally followed the link unmodified -- a pure functional graph, on which the chains of a
@@ -21,16 +21,23 @@
 // (181-193 G/s) overstate the quad-cooperative ceiling.  GATHER_PERTURB=1 (default now) xors the chain's own running sum into
 // the link, as modes 0, 2, 4, 5, 7, 8 always did.
 template <int MODE, bool PERTURB>
-__global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ nodes, uint32_t nnodes, int steps, uint32_t *out)
+__global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ nodes, uint32_t nnodes, int steps, uint32_t *out, int alu)
 {
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
     uint32_t acc = 0;
+    /* GATHER_ALU=N (round 5): N fp32 FMAs per step on the loaded data, eight independent chains, their result folded into the next
+     * link -- what a node step's arithmetic does to the gather rate (the 4-wide step: ~136 VALU ops, an 8-wide step: ~250) */
+#define ALU_PAD(V) do { if (alu > 0) { float c0 = __uint_as_float(((V).x & 0x7fffffu) | 0x3f800000u), c1 = c0 + 1.f, c2 = c0 + 2.f, c3 = c0 + 3.f, c4 = c0 + 4.f, c5 = c0 + 5.f, c6 = c0 + 6.f, c7 = c0 + 7.f; \
+        for (int k = 0; k < alu; k += 8) { c0 = fmaf(c0, 0.9999f, 0.25f); c1 = fmaf(c1, 0.9999f, 0.25f); c2 = fmaf(c2, 0.9999f, 0.25f); c3 = fmaf(c3, 0.9999f, 0.25f); \
+                                            c4 = fmaf(c4, 0.9999f, 0.25f); c5 = fmaf(c5, 0.9999f, 0.25f); c6 = fmaf(c6, 0.9999f, 0.25f); c7 = fmaf(c7, 0.9999f, 0.25f); } \
+        acc += __float_as_uint(c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7) >> 31; } } while (0)
     if (MODE == 0) {
         uint32_t cur = (gid * 2654435761u) % nnodes;
         for (int s = 0; s < steps; s++) {
             const uint4 *p = nodes + 4 * (size_t)cur;
             uint4 a = p[0], b = p[1], c = p[2], d = p[3];
             acc += a.y + b.y + c.y + d.y;
+            ALU_PAD(b);
             cur = (a.x ^ (acc & 1)) % nnodes;
         }
     } else if (MODE == 1) {
@@ -66,6 +73,7 @@ __global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ nodes,
             const uint4 *p = nodes + 8 * (size_t)cur;
             uint4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], g = p[6], h = p[7];
             acc += a.y + b.y + c.y + d.y + e.y + f.y + g.y + h.y;
+            ALU_PAD(b);
             cur = (a.x ^ (acc & 1)) % (nnodes / 2);
         }
     } else if (MODE == 6) {          /* 128-byte nodes, one chain per QUAD, 2 x dwordx4 per lane */
@@ -140,6 +148,8 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     const bool perturb = !(getenv("GATHER_PERTURB") && atoi(getenv("GATHER_PERTURB")) == 0);
     const size_t lds = getenv("GATHER_LDS") ? (size_t)atol(getenv("GATHER_LDS")) : 0;
+    const int alu = getenv("GATHER_ALU") ? atoi(getenv("GATHER_ALU")) : 0;
+    if (alu) printf("%d FMAs per step between the load and the next link\n", alu);
     if (lds) printf("dynamic LDS %zu bytes per block: at most %zu blocks (%zu waves per SIMD) per CU\n", lds, (size_t)(160 * 1024) / lds, (size_t)(160 * 1024) / lds);
     for (int a = 4; a < argc; a++) {
         const int mode = atoi(argv[a]);
