@@ -48,6 +48,8 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     a->default_variant = LH_VARIANT_SPEC;
     a->combine = 1;
     { const char *e = getenv("LH_COMBINE"); if (e) a->combine = atoi(e) != 0; }
+    a->host_walk = 1;
+    { const char *e = getenv("LH_HOST_WALK"); if (e) a->host_walk = atoi(e) != 0; }
     a->ao_fused = 1;
     a->wide8 = -1;
     { const char *e = getenv("LH_WIDE8"); if (e) a->wide8 = atoi(e); }
@@ -838,6 +840,7 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
     else if (!strcmp(name, "ao_budget") && value >= 0) { a->ao_budget = (uint32_t)value; a->ao_budget_user = 1; }
     else if (!strcmp(name, "ao_fused")) a->ao_fused = value != 0;
     else if (!strcmp(name, "combine")) a->combine = value != 0;
+    else if (!strcmp(name, "host_walk")) { a->host_walk = value != 0; a->hw_gpu_left = 0; a->hw_ns = 0.0; }
     else if (!strcmp(name, "ao_group") && value >= 0 && value <= 4096) a->dev.ao_group = (uint32_t)value;
     else if (!strcmp(name, "fast_start")) a->fast_start = value != 0;
     else if (!strcmp(name, "wide8") && value >= -1 && value <= 1) a->wide8 = value;

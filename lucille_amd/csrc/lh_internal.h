@@ -120,6 +120,11 @@ struct lh_accel {
     size_t r_nsamples, r_nslots, r_nao;
     struct lh_combiner *comb;          /* lh_accel_intersect1: concurrent single-ray callers coalesced into one launch (lh_query.hip) */
     int combine;                       /* 1 (default): coalesce; 0: one launch per call, as in rounds 1-3 */
+    /* lh_accel_intersect1 on the calling thread, over the host copy of the trees (lh_hostwalk.c): host_walk 1 (default) / 0;
+     * hw_ns: what a host walk costs on this scene (ns, running mean of timed samples); hw_calls: calls answered there; hw_gpu_left:
+     * calls still to send to the device before the host is probed again (a scene whose walks are long: S-soup-1M's incoherent rays
+     * cost 5-10 us of cache misses each on the host, the coalesced device path amortises to about that) */
+    int host_walk; unsigned long long hw_calls; double hw_ns; int hw_gpu_left;
 };
 
 #define LH_NCURSOR 64
@@ -168,6 +173,8 @@ uint32_t *lh_scene_image_prim_geom(lh_accel_t *a);
 uint32_t *lh_scene_image_prim_index(lh_accel_t *a);
 int  lh_scene_image_alloc(lh_accel_t *a, const lh_scene_image_t *h);
 int  lh_scene_image_finish(lh_accel_t *a);
+/* lh_hostwalk.c */
+extern "C" int lh_host_walk_closest(const lh_bvh_t *b, const lh_refbvh_t *ref, const double o[3], const double d[3], uint32_t *prim, double *t, double *u, double *v);
 /* lh_query.hip */
 void lh_comb_destroy(lh_accel_t *a);                 /* the single-ray combiner's pinned block and stream (lh_accel_destroy) */
 int  lh_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, void *d_prim, void *d_t, void *d_u, void *d_v,

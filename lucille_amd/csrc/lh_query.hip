@@ -445,6 +445,37 @@ extern "C" int lh_accel_intersect1(lh_accel_t *a, const double org[3], const dou
     uint32_t p = LH_MISS_PRIM; double tt = LH_T_INF, uu = 0.0, vv = 0.0;
     if (!a || !a->committed) return fail("lh_accel_intersect1: accel not committed");
     if (!org || !dir) return fail("lh_accel_intersect1: NULL ray");
+    /* One ray, on the calling thread, over the host copy of the trees (lh_hostwalk.c): a device answers a
+     * single ray in ~20 us whatever its kernel does, the host walks lucille's example scenes in 0.2-0.3 us -- and sixteen render
+     * threads walk side by side instead of queueing for one launch.  Same filter, same fp64 test, same tie and fragile-hit rules:
+     * the same record.  For scenes whose trees live on the host (host-built commits; a device-built or received scene has none),
+     * while a walk stays cheaper than the device's amortised answer (LH_HOST_WALK_MAX_NS, 8 us: the incoherent rays of a
+     * million-triangle soup cost the host 5-10 us of cache misses each); statistics and per-ray diagnostics stay on the device. */
+    if (__atomic_load_n(&a->host_walk, __ATOMIC_RELAXED) && !__atomic_load_n(&a->stat_on, __ATOMIC_RELAXED)) {
+        const lh_host_scene *hs = a->hs;
+        const bool trees_here = !hs->device_built && !hs->received && hs->bvh.q4nodes && hs->bvh.tri32 && hs->bvh.tri64 &&
+                                (!hs->have_ref || (!hs->ref_on_device && __atomic_load_n(&hs->ref_state, __ATOMIC_ACQUIRE) == 2 && hs->ref.nodes));
+        static const bool cpu_fma = __builtin_cpu_supports("fma");          /* lh_hostwalk.o is compiled with -mfma */
+        if (trees_here && cpu_fma && (hs->bvh.ntris == 0 || __atomic_load_n(&a->hw_gpu_left, __ATOMIC_RELAXED) <= 0)) {
+            static const double max_ns = getenv("LH_HOST_WALK_MAX_NS") ? atof(getenv("LH_HOST_WALK_MAX_NS")) : 8000.0;
+            const unsigned long long k = __atomic_fetch_add(&a->hw_calls, 1ull, __ATOMIC_RELAXED);
+            const bool timed = (k & 63ull) == 0ull;          /* one call in 64 is timed */
+            const double t0 = timed ? lh_now_s() : 0.0;
+            const int hit = lh_host_walk_closest(&hs->bvh, hs->have_ref ? &hs->ref : NULL, org, dir, &p, &tt, &uu, &vv);
+            if (timed) {
+                const double ns = (lh_now_s() - t0) * 1e9, old = a->hw_ns;
+                const double mean = old > 0.0 ? 0.75 * old + 0.25 * ns : ns;
+                a->hw_ns = mean;                              /* racy by design: a statistic */
+                if (mean > max_ns) __atomic_store_n(&a->hw_gpu_left, 65536, __ATOMIC_RELAXED);       /* long walks: the device for a while, then another look */
+            }
+            if (prim) *prim = p;
+            if (t) *t = tt;
+            if (u) *u = uu;
+            if (v) *v = vv;
+            return hit;
+        }
+        if (trees_here) __atomic_fetch_sub(&a->hw_gpu_left, 1, __ATOMIC_RELAXED);
+    }
     if (!__atomic_load_n(&a->combine, __ATOMIC_RELAXED) || __atomic_load_n(&a->stat_on, __ATOMIC_RELAXED)) {         /* statistics are per launch: counted launches stay one ray each */
         if (lh_accel_intersect_host(a, 1, org, dir, &p, &tt, &uu, &vv, NULL, LH_MODE_CLOSEST) != 0) return -1;
     } else {

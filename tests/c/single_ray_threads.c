@@ -3,7 +3,7 @@
  * accel->intersect for ONE ray at a time (raytrace.c:31-69 -> ri_hipbvh_intersect -> lh_accel_intersect1) over its share of a
  * ray file.  Test infrastructure: writes every record it got back and prints the rays/s, with the coalescing path on and off.
  *
- * usage: single_ray_threads <in.bin> <out.bin> <threads> <combine 0|1>
+ * usage: single_ray_threads <in.bin> <out.bin> <threads> <combine 0|1> [host_walk 0|1 (default 0: the device path)]
  * in : u32 npos; double pos[npos][3]; u32 nidx; u32 idx[nidx]; u32 nrays; double org[nrays][3]; double dir[nrays][3]
  * out: u32 prim[nrays]; double t[nrays], u[nrays], v[nrays]; then double seconds; u64 launches, rays (combine statistics)
  */
@@ -30,7 +30,7 @@ static void *worker(void *arg)
 int main(int argc, char **argv)
 {
     FILE *in, *out; uint32_t npos, nidx; double *pos; uint32_t *idx; pthread_t th[64]; struct timespec a, b; double secs; uint64_t st[2]; int k;
-    if (argc != 5) return 1;
+    if (argc != 5 && argc != 6) return 1;
     nthreads = atoi(argv[3]); if (nthreads < 1 || nthreads > 64) return 1;
     CHECK((in = fopen(argv[1], "rb")) != NULL);
     CHECK(fread(&npos, 4, 1, in) == 1); pos = (double *)malloc(24 * (size_t)npos); CHECK(fread(pos, 24, npos, in) == npos);
@@ -43,6 +43,7 @@ int main(int argc, char **argv)
     CHECK(lh_accel_add_mesh(acc, npos, pos, 24, nidx, idx) == 0);
     CHECK(lh_accel_commit(acc, 0) == 0);
     CHECK(lh_accel_set_param(acc, "combine", atoi(argv[4])) == 0);
+    CHECK(lh_accel_set_param(acc, "host_walk", argc == 6 ? atoi(argv[5]) : 0) == 0);        /* lh_hostwalk.c: one ray on the calling thread */
     { uint32_t p; double tt, uu, vv; CHECK(lh_accel_intersect1(acc, org, dir, &p, &tt, &uu, &vv) >= 0); }      /* first-launch costs outside the timing */
     CHECK(lh_accel_combine_statistics(acc, st, 1) == 0);
     clock_gettime(CLOCK_MONOTONIC, &a);
@@ -54,7 +55,7 @@ int main(int argc, char **argv)
     CHECK((out = fopen(argv[2], "wb")) != NULL);
     fwrite(prim, 4, nrays, out); fwrite(t, 8, nrays, out); fwrite(u, 8, nrays, out); fwrite(v, 8, nrays, out);
     fwrite(&secs, 8, 1, out); fwrite(st, 8, 2, out); fclose(out);
-    printf("%d threads, combine %s: %u rays in %.3f s = %.0f rays/s; %llu launches (%.2f rays each)\n", nthreads, argv[4], nrays, secs, nrays / secs,
+    printf("%d threads, combine %s, host walk %s: %u rays in %.3f s = %.0f rays/s; %llu launches (%.2f rays each)\n", nthreads, argv[4], argc == 6 ? argv[5] : "0", nrays, secs, nrays / secs,
            (unsigned long long)st[0], st[0] ? (double)st[1] / (double)st[0] : 0.0);
     lh_accel_destroy(acc);
     return 0;

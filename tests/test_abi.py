@@ -55,3 +55,8 @@ def test_product_does_not_import_the_oracle():
                 if re.search(r"(import|from)\s+oracle|pyoracle|liblucille_oracle|lucille_oracle\.h|liblucille_ref|liblh_model", txt):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+    # bench.py: only the cpu_baseline leg may touch oracle/ (the checker timed as the CPU baseline, never the thing measured)
+    for f in ["bench.py"] + [os.path.join("benchlegs", x) for x in sorted(os.listdir(os.path.join(ROOT, "benchlegs"))) if x.endswith(".py")]:
+        txt = open(os.path.join(ROOT, f)).read()
+        uses = re.search(r"(import|from)\s+oracle|pyoracle|CDLL\([^)]*oracle", txt) is not None
+        assert uses == (f == os.path.join("benchlegs", "cpu.py")), f
