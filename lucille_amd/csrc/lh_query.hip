@@ -459,14 +459,14 @@ extern "C" int lh_accel_intersect1(lh_accel_t *a, const double org[3], const dou
         if (trees_here && cpu_fma && (hs->bvh.ntris == 0 || __atomic_load_n(&a->hw_gpu_left, __ATOMIC_RELAXED) <= 0)) {
             static const double max_ns = getenv("LH_HOST_WALK_MAX_NS") ? atof(getenv("LH_HOST_WALK_MAX_NS")) : 8000.0;
             const unsigned long long k = __atomic_fetch_add(&a->hw_calls, 1ull, __ATOMIC_RELAXED);
-            const bool timed = (k & 63ull) == 0ull;          /* one call in 64 is timed */
+            const bool timed = (k & 63ull) == 63ull;         /* one call in 64 is timed (never the first: cold caches, page faults) */
             const double t0 = timed ? lh_now_s() : 0.0;
             const int hit = lh_host_walk_closest(&hs->bvh, hs->have_ref ? &hs->ref : NULL, org, dir, &p, &tt, &uu, &vv);
             if (timed) {
                 const double ns = (lh_now_s() - t0) * 1e9, old = a->hw_ns;
                 const double mean = old > 0.0 ? 0.75 * old + 0.25 * ns : ns;
                 a->hw_ns = mean;                              /* racy by design: a statistic */
-                if (mean > max_ns) __atomic_store_n(&a->hw_gpu_left, 65536, __ATOMIC_RELAXED);       /* long walks: the device for a while, then another look */
+                if (mean > max_ns && k >= 255ull) __atomic_store_n(&a->hw_gpu_left, 65536, __ATOMIC_RELAXED);       /* long walks (four samples or more agree): the device for a while, then another look */
             }
             if (prim) *prim = p;
             if (t) *t = tt;
