@@ -24,8 +24,58 @@
 
 #include "lh_bvh.h"
 #include "lh_refbvh.h"
+
+/* fmaxf / fminf with their IEEE meaning (a NaN operand is ignored), inline: without -ffinite-math-only gcc calls libm for each of
+ * the eight in a slab test -- 200 calls per ray, two thirds of this file's time -- and that switch would let the compiler drop the
+ * NaN-safe comparisons lh_filter.h relies on */
+static inline float hw_maxf(float a, float b) { return (a >= b || b != b) ? a : b; }
+static inline float hw_minf(float a, float b) { return (a <= b || b != b) ? a : b; }
+#define fmaxf(a, b) hw_maxf((a), (b))
+#define fminf(a, b) hw_minf((a), (b))
 #include "lh_filter.h"
 #include "lh_reftrace.h"
+
+#if defined(__SSE2__) && defined(__FMA__)
+#include <immintrin.h>
+/* the four slab tests of a 4-wide node at once: lh_slab_w's arithmetic, operation for operation (the same converts, the same FMAs,
+ * the same nesting of max / min), one child per SSE lane.  _mm_max_ps / _mm_min_ps treat a NaN operand differently from fmaxf /
+ * fminf, so a node with an unordered lane (coordinates near 1e30 times a reciprocal of 1e30) is redone by the scalar test.
+ * Returns the hit mask (bit c: child c), entry distances in tn[4]. */
+static inline int hw_node4(const lh_ray32_t *r, const lh_q4node_t *n, float tb, float tn_out[4])
+{
+    const __m128i m16 = _mm_set1_epi32(0xffff);
+    const __m128i wx = _mm_setr_epi32((int)n->w[0][0], (int)n->w[1][0], (int)n->w[2][0], (int)n->w[3][0]);
+    const __m128i wy = _mm_setr_epi32((int)n->w[0][1], (int)n->w[1][1], (int)n->w[2][1], (int)n->w[3][1]);
+    const __m128i wz = _mm_setr_epi32((int)n->w[0][2], (int)n->w[1][2], (int)n->w[2][2], (int)n->w[3][2]);
+    const __m128i lx = _mm_and_si128(wx, m16), hx = _mm_srli_epi32(wx, 16);
+    const __m128i ly = _mm_and_si128(wy, m16), hy = _mm_srli_epi32(wy, 16);
+    const __m128i lz = _mm_and_si128(wz, m16), hz = _mm_srli_epi32(wz, 16);
+    const __m128 nx = _mm_cvtepi32_ps(r->ngx ? hx : lx), fx = _mm_cvtepi32_ps(r->ngx ? lx : hx);
+    const __m128 ny = _mm_cvtepi32_ps(r->ngy ? hy : ly), fy = _mm_cvtepi32_ps(r->ngy ? ly : hy);
+    const __m128 nz = _mm_cvtepi32_ps(r->ngz ? hz : lz), fz = _mm_cvtepi32_ps(r->ngz ? lz : hz);
+    const __m128 tn = _mm_max_ps(_mm_max_ps(_mm_fmadd_ps(nx, _mm_set1_ps(r->qax), _mm_set1_ps(r->qbnx)), _mm_fmadd_ps(ny, _mm_set1_ps(r->qay), _mm_set1_ps(r->qbny))),
+                                 _mm_max_ps(_mm_fmadd_ps(nz, _mm_set1_ps(r->qaz), _mm_set1_ps(r->qbnz)), _mm_setzero_ps()));
+    const __m128 tf = _mm_min_ps(_mm_min_ps(_mm_fmadd_ps(fx, _mm_set1_ps(r->qax), _mm_set1_ps(r->qbfx)), _mm_fmadd_ps(fy, _mm_set1_ps(r->qay), _mm_set1_ps(r->qbfy))),
+                                 _mm_min_ps(_mm_fmadd_ps(fz, _mm_set1_ps(r->qaz), _mm_set1_ps(r->qbfz)), _mm_set1_ps(tb)));
+    int c, mask;
+    if (__builtin_expect(_mm_movemask_ps(_mm_cmpunord_ps(tn, tf)) != 0 || tb != tb, 0)) {
+        mask = 0;
+        for (c = 0; c < 4; c++) if (lh_slab_w(r, n->w[c][0], n->w[c][1], n->w[c][2], tb, &tn_out[c])) mask |= 1 << c;
+    } else {
+        _mm_storeu_ps(tn_out, tn);
+        mask = _mm_movemask_ps(_mm_cmple_ps(tn, tf));
+    }
+    for (c = 0; c < 4; c++) if (n->ref[c] == LH_REF_EMPTY) mask &= ~(1 << c);
+    return mask;
+}
+#else
+static inline int hw_node4(const lh_ray32_t *r, const lh_q4node_t *n, float tb, float tn_out[4])
+{
+    int c, mask = 0;
+    for (c = 0; c < 4; c++) if (n->ref[c] != LH_REF_EMPTY && lh_slab_w(r, n->w[c][0], n->w[c][1], n->w[c][2], tb, &tn_out[c])) mask |= 1 << c;
+    return mask;
+}
+#endif
 
 #define HW_MISS   0xFFFFFFFFu
 #define HW_T_INF  1.0e38
@@ -71,11 +121,12 @@ int lh_host_walk_closest(const lh_bvh_t *b, const lh_refbvh_t *ref, const double
         for (;;) {
             if (cur >= 0) {
                 const lh_q4node_t *n = &b->q4nodes[cur];
-                uint32_t key[4]; int slot[4], nh = 0, c, m;
+                uint32_t key[4]; int slot[4], nh = 0, c, m; float tn4[4];
+                const int hitmask = hw_node4(&r, n, tb, tn4);
                 for (c = 0; c < 4; c++) {
-                    float tn; union { float f; uint32_t w; } cv;
-                    if (n->ref[c] == LH_REF_EMPTY || !lh_slab_w(&r, n->w[c][0], n->w[c][1], n->w[c][2], tb, &tn)) continue;
-                    cv.f = tn;                                         /* entry distances are >= 0: their bits order like integers */
+                    union { float f; uint32_t w; } cv;
+                    if (!(hitmask >> c & 1)) continue;
+                    cv.f = tn4[c];                                     /* entry distances are >= 0: their bits order like integers */
                     const uint32_t kc = (cv.w & ~3u) | (uint32_t)c;    /* the kernels' key: distance bits, slot in the two low bits */
                     for (m = nh; m > 0 && key[m - 1] > kc; m--) { key[m] = key[m - 1]; slot[m] = slot[m - 1]; }
                     key[m] = kc; slot[m] = c; nh++;

@@ -458,8 +458,10 @@ extern "C" int lh_accel_intersect1(lh_accel_t *a, const double org[3], const dou
         static const bool cpu_fma = __builtin_cpu_supports("fma");          /* lh_hostwalk.o is compiled with -mfma */
         if (trees_here && cpu_fma && (hs->bvh.ntris == 0 || __atomic_load_n(&a->hw_gpu_left, __ATOMIC_RELAXED) <= 0)) {
             static const double max_ns = getenv("LH_HOST_WALK_MAX_NS") ? atof(getenv("LH_HOST_WALK_MAX_NS")) : 8000.0;
-            const unsigned long long k = __atomic_fetch_add(&a->hw_calls, 1ull, __ATOMIC_RELAXED);
+            static thread_local unsigned long long tl_calls = 0;          /* per thread: sixteen render threads must not share a counter's cache line */
+            const unsigned long long k = tl_calls++;
             const bool timed = (k & 63ull) == 63ull;         /* one call in 64 is timed (never the first: cold caches, page faults) */
+            if (timed) __atomic_fetch_add(&a->hw_calls, 64ull, __ATOMIC_RELAXED);
             const double t0 = timed ? lh_now_s() : 0.0;
             const int hit = lh_host_walk_closest(&hs->bvh, hs->have_ref ? &hs->ref : NULL, org, dir, &p, &tt, &uu, &vv);
             if (timed) {

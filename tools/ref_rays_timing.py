@@ -1,5 +1,5 @@
 """BASELINE config 1 (the AO example scene, 256 x 256, 16 AO samples) through the REFERENCE's own renderer and render threads,
-every ray through ri_raytrace -> accel->intersect (RI_HIP_RENDER=rays): the coalesced one-ray path against one launch per call
+every ray through ri_raytrace -> accel->intersect (RI_HIP_RENDER=rays): round 5's host walk (lh_hostwalk.c), the coalesced one-ray device path (LH_HOST_WALK=0) against one launch per call
 (LH_COMBINE=0), against rounds 1-3's path (LH_COMBINE=0 LH_SMALL_BATCH=0) and against the reference's CPU BVH.  GPU box.
   python tools/ref_rays_timing.py [threads] [size] [gather]"""
 import os, sys, tempfile, time
@@ -27,11 +27,16 @@ def run(tag, method, env, **over):
     dt = time.time() - t0
     print("%-58s %7.2f s wall (process start, Ri ingest, build, frame; image mean %.4f)" % (tag, dt, float(o["image"].mean())), flush=True)
     return dt, o
-t_new, o_new = run("hip accel, %d threads, coalesced (default)" % threads, 2, {})
-t_one, _ = run("hip accel, 1 thread, coalesced (batches of one)", 2, {}, nthreads=1)
+DEV = {"LH_HOST_WALK": "0"}          # the device paths of rounds 1-4; round 5's default answers one ray on the calling thread (lh_hostwalk.c)
+t_hw, o_hw = run("hip accel, %d threads, host walk (round 5 default)" % threads, 2, {})
+t_hw1, _ = run("hip accel, 1 thread, host walk (round 5 default)", 2, {}, nthreads=1)
 t_cpu, _ = run("reference CPU BVH, %d threads" % threads, 1, {})
+t_cpu1, _ = run("reference CPU BVH, 1 thread", 1, {}, nthreads=1)
+t_new, o_new = run("hip accel, %d threads, device, coalesced (round 4 default)" % threads, 2, DEV)
+t_one, _ = run("hip accel, 1 thread, device, coalesced (batches of one)", 2, DEV, nthreads=1)
 small = dict(width=size // 4, height=size // 4)           # 1/16 of the frame: these paths are slow
-t_nc, _ = run("hip accel, %d threads, LH_COMBINE=0, 1/16 frame" % threads, 2, {"LH_COMBINE": "0"}, **small)
-t_r3, _ = run("hip accel, %d threads, rounds 1-3 path, 1/16 frame" % threads, 2, {"LH_COMBINE": "0", "LH_SMALL_BATCH": "0"}, **small)
-t_ns, _ = run("hip accel, %d threads, coalesced, 1/16 frame" % threads, 2, {}, **small)
+t_nc, _ = run("hip accel, %d threads, device, LH_COMBINE=0, 1/16 frame" % threads, 2, dict(DEV, LH_COMBINE="0"), **small)
+t_r3, _ = run("hip accel, %d threads, device, rounds 1-3 path, 1/16 frame" % threads, 2, dict(DEV, LH_COMBINE="0", LH_SMALL_BATCH="0"), **small)
+t_ns, _ = run("hip accel, %d threads, device, coalesced, 1/16 frame" % threads, 2, DEV, **small)
 print("coalesced vs rounds 1-3 (1/16 frame, same process overheads): %.1fx; vs one launch per call: %.1fx" % (t_r3 / t_ns, t_nc / t_ns))
+print("frames: host walk == device path: %s" % bool(np.array_equal(o_hw["image"], o_new["image"])))
