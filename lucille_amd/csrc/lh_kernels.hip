@@ -133,7 +133,13 @@ constexpr uint32_t kRegroupMask = 63u;   /* the walk returns to the regroup poin
 
 /* RING: stack positions are taken modulo ring_mask + 1 rows (k_coop_walk: a lane that gives entries away from the bottom of
  * its stack drifts upwards without bound); the persistent kernel indexes rows directly */
-template <bool COUNT, int STRIDE, bool RING>
+/* SORTED = false (an occlusion query over its own rays: the fused AO stage): the hit children go onto the stack in SLOT order, no
+ * ranking by entry distance -- any hit ends the ray, the culling bound never moves, so the order only decides how soon an occluded
+ * ray meets its occluder, and the step loses its six key comparisons and rank sums (~27 of 136 VALU operations).  LH_AO_UNSORTED */
+#ifndef LH_AO_UNSORTED
+#define LH_AO_UNSORTED 1
+#endif
+template <bool COUNT, int STRIDE, bool RING, bool SORTED = true>
 __device__ __forceinline__ void node_step4(Lane &L, int &pend, const lh_dev_scene_t &sc, int (*stk)[STRIDE], const int tid, uint32_t &c_nodes,
                                            const int ring_mask = 0, const uint4 *top = NULL, const uint32_t ntop = 0u)
 {
@@ -154,20 +160,29 @@ __device__ __forceinline__ void node_step4(Lane &L, int &pend, const lh_dev_scen
     const bool h1 = slab_w(L, a.w, b.x, b.y, t1) & ((int)r.y != kDone);
     const bool h2 = slab_w(L, b.z, b.w, c.x, t2) & ((int)r.z != kDone);
     const bool h3 = slab_w(L, c.y, c.z, c.w, t3) & ((int)r.w != kDone);
-    /* entry distances are >= 0, so their bit patterns order like unsigned integers */
-    const uint32_t k0 = h0 ? ((__float_as_uint(t0) & ~3u) | 0u) : 0xFFFFFFFCu;
-    const uint32_t k1 = h1 ? ((__float_as_uint(t1) & ~3u) | 1u) : 0xFFFFFFFDu;
-    const uint32_t k2 = h2 ? ((__float_as_uint(t2) & ~3u) | 2u) : 0xFFFFFFFEu;
-    const uint32_t k3 = h3 ? ((__float_as_uint(t3) & ~3u) | 3u) : 0xFFFFFFFFu;
-    const int b10 = k1 < k0, b20 = k2 < k0, b30 = k3 < k0, b21 = k2 < k1, b31 = k3 < k1, b32 = k3 < k2;
-    const int rk0 = b10 + b20 + b30, rk1 = (1 - b10) + b21 + b31;
-    const int rk2 = (2 - b20 - b21) + b32, rk3 = 3 - b30 - b31 - b32;
     const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
     const int base = L.sp + nh - 1;
-    stk[LH_ROW(h0 ? base - rk0 : L.sp + rk0)][tid] = (int)r.x;
-    stk[LH_ROW(h1 ? base - rk1 : L.sp + rk1)][tid] = (int)r.y;
-    stk[LH_ROW(h2 ? base - rk2 : L.sp + rk2)][tid] = (int)r.z;
-    stk[LH_ROW(h3 ? base - rk3 : L.sp + rk3)][tid] = (int)r.w;
+    if (SORTED) {
+        /* entry distances are >= 0, so their bit patterns order like unsigned integers */
+        const uint32_t k0 = h0 ? ((__float_as_uint(t0) & ~3u) | 0u) : 0xFFFFFFFCu;
+        const uint32_t k1 = h1 ? ((__float_as_uint(t1) & ~3u) | 1u) : 0xFFFFFFFDu;
+        const uint32_t k2 = h2 ? ((__float_as_uint(t2) & ~3u) | 2u) : 0xFFFFFFFEu;
+        const uint32_t k3 = h3 ? ((__float_as_uint(t3) & ~3u) | 3u) : 0xFFFFFFFFu;
+        const int b10 = k1 < k0, b20 = k2 < k0, b30 = k3 < k0, b21 = k2 < k1, b31 = k3 < k1, b32 = k3 < k2;
+        const int rk0 = b10 + b20 + b30, rk1 = (1 - b10) + b21 + b31;
+        const int rk2 = (2 - b20 - b21) + b32, rk3 = 3 - b30 - b31 - b32;
+        stk[LH_ROW(h0 ? base - rk0 : L.sp + rk0)][tid] = (int)r.x;
+        stk[LH_ROW(h1 ? base - rk1 : L.sp + rk1)][tid] = (int)r.y;
+        stk[LH_ROW(h2 ? base - rk2 : L.sp + rk2)][tid] = (int)r.z;
+        stk[LH_ROW(h3 ? base - rk3 : L.sp + rk3)][tid] = (int)r.w;
+    } else {
+        /* hit c sits below the hits before it (slot 0 ends on top); every miss goes to the row above the new top: free space */
+        const int a1 = (int)h0, a2 = a1 + (int)h1, a3 = a2 + (int)h2;
+        stk[LH_ROW(h0 ? base : base + 1)][tid] = (int)r.x;
+        stk[LH_ROW(h1 ? base - a1 : base + 1)][tid] = (int)r.y;
+        stk[LH_ROW(h2 ? base - a2 : base + 1)][tid] = (int)r.z;
+        stk[LH_ROW(h3 ? base - a3 : base + 1)][tid] = (int)r.w;
+    }
     L.sp = base;
     const int nxt = stk[LH_ROW(base)][tid];
     const int popped2 = stk[LH_ROW(L.sp - 1)][tid];
@@ -203,7 +218,7 @@ __device__ __forceinline__ void tri_pass(Lane &L, int &pend, const lh_dev_scene_
 #undef LH_ROW
 }
 
-template <bool ANYHIT, bool COUNT, bool GUARD>
+template <bool ANYHIT, bool COUNT, bool GUARD, bool SORTED = true>
 __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_scene_t &sc,
                                                int (*stk)[LH_BLOCK], const int tid,
                                                double ox, double oy, double oz,
@@ -228,7 +243,7 @@ __device__ __forceinline__ void traverse_spec4(Lane &L, int &pend, const lh_dev_
             const bool ov = (L.cur >= 0) & (L.sp + 4 > rows);
             if (__builtin_expect(__ballot(ov) != 0ull, 0)) { if (ov) { L.over = true; L.cur = kDone; pend = kNoLeaf; } }
         }
-        if (L.cur >= 0) node_step4<COUNT, LH_BLOCK, false>(L, pend, sc, stk, tid, c_nodes, 0, top, ntop);
+        if (L.cur >= 0) node_step4<COUNT, LH_BLOCK, false, SORTED>(L, pend, sc, stk, tid, c_nodes, 0, top, ntop);
         const unsigned long long m_node = __ballot(L.cur >= 0);
         const unsigned long long m_pend = __ballot(pend != kNoLeaf);
         if (m_pend != 0ull && (__popcll(m_pend) >= tri_batch || m_node == 0ull)) {
@@ -595,9 +610,9 @@ __device__ __forceinline__ void trace_persist_lane(
         /* ---- walk until too few lanes remain active ---------------------- */
         const int thresh = exhausted ? 1 : min_active;
         if (WALK == 3)
-            traverse_spec4<ANYHIT, COUNT, false>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, it);
+            traverse_spec4<ANYHIT, COUNT, false, !(SRC == 1 && LH_AO_UNSORTED)>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, it);
         else if (WALK == 8)          /* the same with the stack check: trees whose worst case the LDS rows do not cover */
-            traverse_spec4<ANYHIT, COUNT, true>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, it);
+            traverse_spec4<ANYHIT, COUNT, true, !(SRC == 1 && LH_AO_UNSORTED)>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, it);
         else
             traverse_spec8<ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, it);
     }
@@ -1201,7 +1216,9 @@ extern "C" int lh_launch_trace_ao(const lh_dev_scene_t *sc, size_t nslots, int n
     scl.stack_guard = guard ? 1 : 0;
     scl.top_nodes = top_nodes_for(*sc, scl.stack_rows);
     const size_t lds_bytes = (size_t)scl.stack_rows * LH_BLOCK * sizeof(int) + (size_t)scl.top_nodes * 64u;
-    if (scl.ray_chunk < LH_TILE_CHUNK) scl.ray_chunk = LH_TILE_CHUNK;      /* AO rays of a slot are coherent: longer ranges per wave */
+    static uint32_t ao_chunk = 0;
+    if (!ao_chunk) { const char *e = getenv("LH_AO_CHUNK"); ao_chunk = (e && atoi(e) >= 64 && atoi(e) <= 65536) ? (uint32_t)atoi(e) : LH_TILE_CHUNK; }
+    scl.ray_chunk = ao_chunk;                                               /* AO rays of a slot are coherent: longer ranges per wave (LH_AO_CHUNK) */
     clamp_chunk(scl, n, grid_blocks);
     AoSrc ao = {d_hitrec, d_slot_key, d_occ_count, seed, ntheta, nphi, (uint32_t)nslots, (int)sc->ao_group, d_nslots, budget_big};
     if (d_nslots && sc->ao_group) return -1;            /* the grouped order needs the exact count on the host */

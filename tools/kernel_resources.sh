@@ -7,4 +7,4 @@ cd "$(dirname "$0")/../lucille_amd/csrc" || exit 1
 f=${1:-lh_kernels.hip}
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Rpass-analysis=kernel-resource-usage -c "$f" -o /tmp/kres.o 2>&1 \
   | grep -E "Function Name|VGPRs:|ScratchSize|Occupancy" | sed 's/.*remark: *//; s/ \[-Rpass.*//' | paste - - - - \
-  | sed 's/Function Name: //; s/_ZN12_GLOBAL__N_1[0-9]*//; s/EEEv12lh_dev_scene.*\t/>\t/; s/ILb/</; s/ELb/,/g; s/ELi/,/g; s/EEv.*\t/>\t/' | sort
+  | sed 's/Function Name: _ZN12_GLOBAL__N_1[0-9]*//; s/EEEv12lh_dev_scene[A-Za-z0-9_]*//; s/ILb/</; s/ELb/,/g; s/ELi/,/g; s/EEv[A-Za-z0-9_]*//' | sort

@@ -40,7 +40,7 @@ print("| ranks | bands | band rows | sum over ranks (ms) | busiest rank (ms) | l
 print("|---|---|---|---|---|---|---|---|---|---|---|")
 rows = {}; hits_of = {}; per_of = {}
 slab = torch.zeros(size * size * 3 + 64 * size * 3, dtype=torch.float32, device="cuda")
-for world, want_rows in ((1, None), (2, None), (4, None), (8, None), (8, 4), (8, 16), (8, 64), (8, 128)):
+for world, want_rows in ((1, None), (2, None), (4, None), (8, None), (8, 4), (8, 8), (8, 32), (8, 64)):
     brow, y0s = render.bands_for(size, world, want_rows)
     per = []
     for r in range(world):
