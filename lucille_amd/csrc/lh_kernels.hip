@@ -610,9 +610,9 @@ __device__ __forceinline__ void trace_persist_lane(
         /* ---- walk until too few lanes remain active ---------------------- */
         const int thresh = exhausted ? 1 : min_active;
         if (WALK == 3)
-            traverse_spec4<ANYHIT, COUNT, false, !(SRC == 1 && LH_AO_UNSORTED)>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, it);
+            traverse_spec4<ANYHIT, COUNT, false, !(ANYHIT && LH_AO_UNSORTED)>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, it);
         else if (WALK == 8)          /* the same with the stack check: trees whose worst case the LDS rows do not cover */
-            traverse_spec4<ANYHIT, COUNT, true, !(SRC == 1 && LH_AO_UNSORTED)>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, it);
+            traverse_spec4<ANYHIT, COUNT, true, !(ANYHIT && LH_AO_UNSORTED)>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, it);
         else
             traverse_spec8<ANYHIT, COUNT>(L, pend, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce, thresh, tri_batch, cns, cts, it);
     }
