@@ -460,11 +460,25 @@ extern "C" int lh_dist_broadcast_scene(lh_dist_t *d, lh_accel_t *accel)
 
 /* ---- frames: every rank renders its bands, rank 0 owns the display (render.c:468-514) ----------------------------- */
 /* slabs [world][per][rows][W][3] (image orientation inside) -> frame [H][W][3], top row first: band b covers frame lines
- * b * rows ... from the BOTTOM of the image (bucket_write's y flip, render.c:962-964).  The bands are dealt out in SERPENTINE order:
- * groups of `world`, even groups in rank order, odd groups in reverse -- band g * world + pos is the g-th band of rank pos (g even)
- * or world - 1 - pos (g odd).  Plain interleaving hands the last rank the lower band of EVERY group: where the cost of a line
- * changes steadily down the image that rank carries the whole slope (config 5, 64-line bands: 7 %); the serpentine cancels a linear
- * slope exactly, so the bands can be tall -- and coherent.  Same rule: lucille_amd/shard.py bands_of_rank */
+ * b * rows ... from the BOTTOM of the image (bucket_write's y flip, render.c:962-964).  The bands are dealt out in groups of
+ * `world`; band g * world + pos is the g-th band of the rank whose position in group g is pos (band_pos: rank order, reversed,
+ * shifted, shifted and reversed).  Plain interleaving hands the last rank the lower band of EVERY group: where the cost of a
+ * line changes steadily down the image that rank carries the whole slope (config 5, 64-line bands: 7 %); this order cancels a
+ * linear slope exactly and most of the curvature, so the bands can be tall -- and coherent.  Same rule: lucille_amd/shard.py */
+/* the position of rank r's band inside group g, and its inverse: rank order, reversed, shifted by half the world, shifted and
+ * reversed, and again (lucille_amd/shard.py _band_pos: rank order + reversed cancel a steady change of cost down the image,
+ * the shifted pair most of its curvature) */
+__host__ __device__ static inline int band_pos(int g, int r, int world)
+{
+    const int s = (r + world / 2) % world;
+    switch (g & 3) { case 0: return r; case 1: return world - 1 - r; case 2: return s; default: return world - 1 - s; }
+}
+__host__ __device__ static inline int band_rank(int g, int pos, int world)
+{
+    const int q = (g & 1) ? world - 1 - pos : pos;                 /* undo the reversal */
+    return (g & 2) ? (q + world - world / 2) % world : q;          /* undo the shift */
+}
+
 /* ch: floats per pixel of the slabs -- 3 (RGB), or 1: an AO frame is grey (Lo = (N - occluded) / N in every channel,
  * ambientocclusion.c:383-401), so the exchange step moves ONE float per pixel and the owner of the display writes it three times */
 __global__ void k_take_channel0(size_t npix, const float *__restrict__ rgb, float *__restrict__ mono)
@@ -478,7 +492,7 @@ __global__ void k_place_bands(const float *__restrict__ slabs, float *__restrict
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)W * H) return;
     const int x = (int)(i % W), row = (int)(i / W);            /* row 0 = top of the image = frame line H - 1 */
-    const int line = H - 1 - row, band = line / rows, k = band / world, pos = band % world, r = (k & 1) ? world - 1 - pos : pos;
+    const int line = H - 1 - row, band = line / rows, k = band / world, pos = band % world, r = band_rank(k, pos, world);
     const int y0 = band * rows, h = (y0 + rows <= H) ? rows : H - y0;
     /* inside a band slab the first frame line of the band is the LAST of its h lines; a clipped band keeps them at the bottom */
     const int srow = (rows - h) + (h - 1 - (line - y0));
@@ -501,7 +515,7 @@ extern "C" int lh_dist_render_ao_frame_host(lh_dist_t *d, lh_accel_t *accel, con
     const int nbands = (H + band_rows - 1) / band_rows, per = (nbands + d->world - 1) / d->world;
     std::vector<int> y0;
     for (int k = 0; k < per; k++) {             /* this rank's band of every group (k_place_bands) */
-        const int b = k * d->world + ((k & 1) ? d->world - 1 - d->rank : d->rank);
+        const int b = k * d->world + band_pos(k, d->rank, d->world);
         if (b < nbands) y0.push_back(b * band_rows);
     }
     const size_t slab_bytes = (size_t)per * band_rows * W * 3 * sizeof(float);

@@ -145,6 +145,11 @@ def test_serpentine_bands_cover_once_and_cancel_a_slope():
     serp = [cost[shard.bands_of_rank(128, r, 8)].sum() for r in range(8)]
     plain = [cost[shard.tiles_of_rank(128, r, 8)].sum() for r in range(8)]
     assert max(serp) == min(serp) and max(plain) - min(plain) == 7 * 16
+    # ... and most of a curvature: the shifted groups (rank order, reversed, shifted by half the world, shifted and reversed)
+    quad = (np.arange(128, dtype=np.float64) - 40.0) ** 2
+    q4 = [quad[shard.bands_of_rank(128, r, 8)].sum() for r in range(8)]
+    q2 = [quad[[g * 8 + (r if g % 2 == 0 else 7 - r) for g in range(16)]].sum() for r in range(8)]      # the plain serpentine
+    assert (max(q4) - min(q4)) * 2 < max(q2) - min(q2)
 
 
 def _band_worker(rank, world, port, W, H, rows, q):

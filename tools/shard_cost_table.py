@@ -32,7 +32,7 @@ print("# Shard cost table: BASELINE config 5 AO frame (%d triangles, %dx%d, %d A
 print("Whole frame as ONE device batch: **%.2f ms** (tree %.2f s + reference-order tree %.2f s, once per scene: lh_accel_commit's own choice of builder).\n" % (t1 * 1e3, info["build_seconds"], info["ref_build_seconds"]))
 SKEW_MS = {1: 0.0, 2: 0.10, 4: 0.16, 8: 0.17}      # what a frame's two barriers cost between real processes (profiles/r04_skew.txt, lh_dist_host_barrier, p50)
 print("Shards = `render.bands_for(H, world)`: full-width bands (column 3: lines per band; the default first), dealt out in serpentine order (`shard.bands_of_rank`: groups of `world` bands, even groups in rank order, odd groups reversed); a rank's bands are ONE "
-      "`lh_render_ao_bands` call (one device batch).  Times are best-of-3 wall times of every rank's batch, run one after the other on one "
+      "`lh_render_ao_bands` call (one device batch).  Times are best-of-4 wall times of every rank's batch (after one untimed pass over all ranks), run one after the other on one "
       "GPU.  Prediction for N ranks = max over ranks of its batch + gather, where the gather moves "
       "(N-1)/N of the frame (%d MB: one fp32 per pixel -- an AO frame is grey, rank 0 writes the value three times) to rank 0 over N-1 xGMI links in parallel at %.0f GB/s per link; the last column adds what the two barriers "
       "around a timed frame cost between real processes (p50: %s ms at 2 / 4 / 8 ranks, profiles/r04_skew.txt).\n" % (size * size * 4 // 1000000, LINK_GBPS, " / ".join("%.2f" % SKEW_MS[k] for k in (2, 4, 8))))
@@ -40,14 +40,20 @@ print("| ranks | bands | band rows | sum over ranks (ms) | busiest rank (ms) | l
 print("|---|---|---|---|---|---|---|---|---|---|---|")
 rows = {}; hits_of = {}; per_of = {}
 slab = torch.zeros(size * size * 3 + 64 * size * 3, dtype=torch.float32, device="cuda")
-for world, want_rows in ((1, None), (2, None), (4, None), (8, None), (8, 4), (8, 8), (8, 32), (8, 64)):
+for world, want_rows in ((1, None), (2, None), (4, None), (8, None), (8, 4), (8, 8), (8, 12), (8, 32), (8, 64)):
     brow, y0s = render.bands_for(size, world, want_rows)
     per = []
+    # one untimed pass over every rank's batch first: the first batches after a change of band layout run 0.3-0.8 ms slow for several
+    # repetitions (scratch buffers re-grown, clocks), which best-of-3 of the FIRST rank alone did not shake off (r05: rank 0 read
+    # 7.68 ms where rank 1, with the same number of hits, read 7.28)
+    for r in range(world if world > 1 else 0):
+        mine = [y0s[b] for b in shard.bands_of_rank(len(y0s), r, world)]
+        acc.render_ao_bands(cam, mine, brow, 1, ns, seed=1, out=slab[:len(mine) * brow * size * 3].view(len(mine), brow, size, 3)); torch.cuda.synchronize()
     for r in range(world):
         mine = [y0s[b] for b in shard.bands_of_rank(len(y0s), r, world)]
         out = slab[:len(mine) * brow * size * 3].view(len(mine), brow, size, 3)
         best = 1e9
-        for _ in range(3):
+        for _ in range(4):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             _, st_ = acc.render_ao_bands(cam, mine, brow, 1, ns, seed=1, out=out); torch.cuda.synchronize()
             best = min(best, time.perf_counter() - t0)
