@@ -97,7 +97,7 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
             "image_mean": float(img.mean().item()), "roofline": roof,
             "parity": "every bounce's closest-hit records are the pinned kernel's (bit-equal to the compiled reference on the same rays); the TRANSPORT "
                       "arithmetic (roulette, lobe choice, weights) is parity-UNPINNED: the reference's pathtrace.c is dead code that does not compile, "
-                      "there is nothing to run it against (SURVEY 8f-3; DESIGN.md 11 lists the departures from its text)",
+                      "there is nothing to run it against (SURVEY 8f-3; HISTORY.md 11 lists the departures from its text)",
             # white furnace with albedo 0.8 under a unit environment: every pixel's radiance lies in (0, 1]
             "validation": {"frames_repeat": repeat, "retiled_frame_bit_equal": retiled,
                            "radiance_in_0_1": bool(float(img.min().item()) >= 0.0 and float(img.max().item()) <= 1.0 + 1e-6),

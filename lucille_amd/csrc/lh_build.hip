@@ -26,7 +26,7 @@
  *
  * Primitive numbering is the caller's (create_triangle_list order, bvh.c:1736-1826): ids ride along as payload.
  * BASELINE config 5 (21.1 M triangles): 0.06 s for the tree, 0.2 s for the whole commit, frame within 3 % of the frame on
- * the binned-SAH host tree; lh_commit.hip chooses (LH_BUILD=device, lh_accel_commit's build_threads ==
+ * the binned-SAH host tree (HISTORY.md 15); lh_commit.hip chooses (LH_BUILD=device, lh_accel_commit's build_threads ==
  * LH_BUILD_ON_DEVICE).  lucille's OWN tree, which exact-t ties, fragile hits and beams depend on, is built next to this one by
  * lh_refbuild.hip.
  */

@@ -654,7 +654,7 @@ extern "C" int lh_accel_commit(lh_accel_t *a, int build_threads)
     a->commit_failed = 1;                       /* cleared on success */
     /* where the trees are built: said by the caller (LH_BUILD_ON_DEVICE, LH_BUILD_ON_HOST, or a thread count = the host), by
      * LH_BUILD in the environment, or -- build_threads == 0 -- by the size of the scene: from LH_AUTO_DEVICE_TRIANGLES on the
-     * device builders (0.3 s instead of 4 s for 21 M triangles, frames ~2 % slower), below it the host builders
+     * device builders (0.3 s instead of 4 s for 21 M triangles, frames ~2 % slower, HISTORY.md 15), below it the host builders
      * (milliseconds either way, and the better tree).  An automatic device build that fails falls back to the host. */
     bool on_device = build_threads == LH_BUILD_ON_DEVICE;
     bool chosen = build_threads == LH_BUILD_ON_DEVICE || build_threads == LH_BUILD_ON_HOST || build_threads > 0;

@@ -4,7 +4,7 @@
  * Why it exists: lucille calls accel->intersect for one ray at a time from its
  * shaders (src/render/raytrace.c:31-69; 18 compiled call sites in shader.c, ibl.c, whitted.c).  A GPU answers one ray in
  * ~20 us -- launch, walk, synchronise -- whatever the kernel does: 50 k rays/s per thread, 200 k coalesced over sixteen
- * (DESIGN 16), where the reference's CPU BVH gives 5 M per thread on the same scene.  The batched entry points are where
+ * (DESIGN 11), where the reference's CPU BVH gives 5 M per thread on the same scene.  The batched entry points are where
  * the GPU is; a caller that insists on one ray gets the SAME answer faster from the host copy of the tree the commit built
  * anyway (lh_bvh.c: the 4-wide 16-bit-grid nodes the kernels walk, the fp32 triangle records, the fp64 triangles) --
  * nothing under oracle/, nothing the device path does not also do:

@@ -5,7 +5,7 @@
  * Why a second path-tracing checker: lucille_oracle_pt.c restates the PRODUCT's wavefront transport (lh_pt.h) and so can only
  * tell whether the device and the host agree with each other.  This file is written from the reference's file, function by
  * function, without looking at the product, so that every place where the product departs from pathtrace.c is a number in a
- * test (tests/test_oracle_ptref.py) and a line in DESIGN.md 11 instead of a sentence:
+ * test (tests/test_oracle_ptref.py) and a line in HISTORY.md 11 instead of a sentence:
  *
  *   ri_transport_pathtrace   pathtrace.c:128-186   pixel loop (x outer, y from the top), nsamples paths per pixel, mean
  *   trace_pixel              pathtrace.c:189-243   camera ray; miss -> ri_texture_ibl_fetch; else trace_path, then the CONNECT

@@ -5,7 +5,7 @@ not compile), so nothing can be RUN to pin the transport: f3 stays parity-unpinn
 from its text alone (oracle/lucille_oracle_ptref.c -- recursive, its own MT19937 in the text's call order, the connect step,
 BRDF values without cosine or pdf, no roulette compensation) and to measure, on scenes with a closed-form answer, where the
 product's wavefront transport (restated on the host by oracle/lucille_oracle_pt.c, which the GPU tests pin the device to ray for
-ray) gives a DIFFERENT number -- each departure is one the design chose and DESIGN.md 11 lists, with these numbers."""
+ray) gives a DIFFERENT number -- each departure is one the design chose and HISTORY.md 11 lists, with these numbers."""
 import numpy as np
 
 from oracle import pyoracle as po
