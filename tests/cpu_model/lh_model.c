@@ -221,3 +221,13 @@ void lhm_ref_leaf_order(const lh_refbvh_t *r, uint32_t *leaf_prims, uint32_t *pr
     for (i = 0; i < r->ntris; i++) prim_leaf_first[i] = r->nodes[r->prim_leaf[i]].first;
 }
 void lhm_ref_bbox(const lh_refbvh_t *r, double out[6]) { int k; for (k = 0; k < 3; k++) { out[k] = r->bmin[k]; out[3 + k] = r->bmax[k]; } }
+
+/* the PRODUCT's one-ray host walk (lucille_amd/csrc/lh_hostwalk.c, linked into this test library as it is): n rays, one after the
+ * other, over this model's trees -- so that the not-gpu suite pins its records on the oracle without a device */
+int lh_host_walk_closest(const lh_bvh_t *b, const lh_refbvh_t *ref, const double o[3], const double d[3], uint32_t *prim, double *t, double *u, double *v);
+int lhm_hostwalk(const lh_bvh_t *b, const lh_refbvh_t *ref, size_t n, const double *org, const double *dir, uint32_t *prim, double *t, double *u, double *v)
+{
+    size_t i; int hits = 0;
+    for (i = 0; i < n; i++) hits += lh_host_walk_closest(b, ref, org + 3 * i, dir + 3 * i, prim + i, t + i, u + i, v + i);
+    return hits;
+}

@@ -26,11 +26,12 @@ def build_model():
     the product's own BVH builder (lh_bvh.c) and arithmetic (lh_filter.h)."""
     so = os.path.join(MODEL_DIR, "liblh_model.so")
     srcs = [os.path.join(MODEL_DIR, "lh_model.c"), os.path.join(CSRC, "lh_bvh.c"), os.path.join(CSRC, "lh_refbvh.c"),
+            os.path.join(CSRC, "lh_hostwalk.c"),           # the product's one-ray host walk, as it is (lhm_hostwalk)
             os.path.join(CSRC, "lh_bvh.h"), os.path.join(CSRC, "lh_filter.h"), os.path.join(CSRC, "lh_refbvh.h"),
             os.path.join(CSRC, "lh_reftrace.h")]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-shared"] + _fma_flag() +
-                              ["-I" + CSRC, srcs[0], srcs[1], srcs[2], "-o", so, "-lm", "-lpthread"])
+                              ["-I" + CSRC, srcs[0], srcs[1], srcs[2], srcs[3], "-o", so, "-lm", "-lpthread"])
     return so
 
 
@@ -156,6 +157,18 @@ class Model:
         self.lib().lhm_trace(self.h, n, org.ctypes.data_as(_dp), dr.ctypes.data_as(_dp), prim.ctypes.data_as(_u32p),
                              t.ctypes.data_as(_dp), u.ctypes.data_as(_dp), v.ctypes.data_as(_dp), None, qnodes << 1, cp, nthreads)
         return (prim, t, u, v), dict(zip(("nodes", "tris", "exact", "rays"), map(int, cnt)))
+
+    def hostwalk(self, org, dr, use_ref=True):
+        """the PRODUCT's one-ray host walk (lh_hostwalk.c) over this model's trees, ray by ray -> (prim, t, u, v).
+        use_ref: with lucille's own tree (ref_build() first), as lh_accel_intersect1 calls it"""
+        org = np.ascontiguousarray(org, np.float64).reshape(-1, 3); dr = np.ascontiguousarray(dr, np.float64).reshape(-1, 3)
+        n = org.shape[0]
+        prim = np.empty(n, np.uint32); t = np.empty(n); u = np.empty(n); v = np.empty(n)
+        L = self.lib()
+        L.lhm_hostwalk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, _dp, _dp, _u32p, _dp, _dp, _dp]
+        L.lhm_hostwalk(self.h, self.ref if (use_ref and getattr(self, "ref", None)) else None, n, org.ctypes.data_as(_dp), dr.ctypes.data_as(_dp),
+                       prim.ctypes.data_as(_u32p), t.ctypes.data_as(_dp), u.ctypes.data_as(_dp), v.ctypes.data_as(_dp))
+        return prim, t, u, v
 
     def trace_diag(self, org, dr, qnodes=2):
         """closest-hit walk with PER-RAY counts -> ((prim, t, u, v), uint32 [n, 4]: node visits, leaf visits, triangle records
