@@ -144,9 +144,8 @@ __device__ __forceinline__ uint64_t pt_key(unsigned long long seed, uint32_t pat
 }
 
 /* a path vertex that hit something: does the path go on?  (vertex limit; Russian roulette on d + s + t, pathtrace.c:407-430) */
-__device__ __forceinline__ bool pt_survives(const DevMaterial &M, uint64_t key, int depth, int max_depth)
+__device__ __forceinline__ bool pt_survives(const double ksum /* DevMaterial.asum9: (kd0 + kd1 + kd2 + ks0 + ... + kt2) / 3 */, uint64_t key, int depth, int max_depth)
 {
-    const double ksum = M.asum9;        /* (kd0 + kd1 + kd2 + ks0 + ... + kt2) / 3 */
     return !(depth + 2 >= max_depth || !(ksum > 0.0) || rnd01(key) > ksum);
 }
 
@@ -162,16 +161,17 @@ __device__ __forceinline__ void pt_scatter(const lh_dev_scene_t &sc, const doubl
     /* ri_intersection_state_build subset: P, Ng, Ns, colour */
     const double *tv = (const double *)sc.tri64 + 9 * (size_t)p;
     const double wgt = 1.0 - uu - vv;
-    double P[3], Ng[3], Ns[3], v01[3], v02[3];
+    double P[3], Ng[3], Ns[3];
     for (int k = 0; k < 3; k++) P[k] = org[k] + D[k] * tt;
-    for (int k = 0; k < 3; k++) { v01[k] = tv[3 + k] - tv[k]; v02[k] = tv[6 + k] - tv[k]; }
     bool has_n = false;
     if (nrm9) { const double n0x = nrm9[9 * (size_t)p]; has_n = (n0x == n0x); }
     if (has_n) {
         const double *nn = nrm9 + 9 * (size_t)p;
         for (int k = 0; k < 3; k++) { const double a = nn[k] * wgt, b = nn[3 + k] * uu, c = nn[6 + k] * vv; Ns[k] = (a + b) + c; }
         vnormalize(Ns);
-    } else {                                    /* flat shaded: the geometric normal (only then is it needed at all) */
+    } else {                                    /* flat shaded: the geometric normal (only then is it needed at all -- and the triangle's corners) */
+        double v01[3], v02[3];
+        for (int k = 0; k < 3; k++) { v01[k] = tv[3 + k] - tv[k]; v02[k] = tv[6 + k] - tv[k]; }
         vcross(Ng, v01, v02); vnormalize(Ng);
         Ns[0] = Ng[0]; Ns[1] = Ng[1]; Ns[2] = Ng[2];
     }
@@ -208,11 +208,9 @@ __device__ __forceinline__ void pt_scatter(const lh_dev_scene_t &sc, const doubl
         const double dn = D[0] * N[0] + D[1] * N[1] + D[2] * N[2];
         for (int k = 0; k < 3; k++) O[k] = D[k] - 2.0 * dn * N[k];
     } else if (type == 0) {                     /* sample_cosweight (pathtrace.c:500-531) about the facing normal */
-        double b0[3], b1[3] = {0.0, 0.0, 0.0};
-        int ax = 3;
-        for (int k = 0; k < 3; k++) if (N[k] < 0.6 && N[k] > -0.6) { ax = k; break; }
-        if (ax >= 3) ax = 0;
-        b1[ax] = 1.0;
+        /* the first axis the normal is not close to (selects, not an indexed store: an array indexed at run time lives in scratch) */
+        const int ax = (N[0] < 0.6 && N[0] > -0.6) ? 0 : ((N[1] < 0.6 && N[1] > -0.6) ? 1 : ((N[2] < 0.6 && N[2] > -0.6) ? 2 : 0));
+        double b0[3], b1[3] = {ax == 0 ? 1.0 : 0.0, ax == 1 ? 1.0 : 0.0, ax == 2 ? 1.0 : 0.0};
         vcross(b0, b1, N); vnormalize(b0);
         vcross(b1, N, b0); vnormalize(b1);
         /* the local direction in single precision, as the reference holds it (v.f[] = (float)(...), pathtrace.c:519-521),
@@ -222,8 +220,13 @@ __device__ __forceinline__ void pt_scatter(const lh_dev_scene_t &sc, const doubl
         for (int k = 0; k < 3; k++) O[k] = (double)d0 * b0[k] + (double)d1 * b1[k] + (double)d2 * N[k];
     }
     /* throughput (brdf, pathtrace.c:533-565) */
-    const float *kk = type == 0 ? M.kd : (type == 1 ? M.ks : M.kt);
-    const float wsel = ref_weights ? (type == 0 ? 0.318309886f : 1.0f) : (type == 0 ? M.wd : (type == 1 ? M.ws : M.wt));     /* unbiased: 1 / (P(type) x survival) = (float)(1 / ave) */
+    /* the chosen lobe's reflectance and weight by bit masks: written as selects of the record's fields the compiler turns them into
+     * loads at a run-time offset, which pins the record in scratch */
+    const uint32_t m0 = type == 0 ? 0xFFFFFFFFu : 0u, m1 = type == 1 ? 0xFFFFFFFFu : 0u, m2 = type == 2 ? 0xFFFFFFFFu : 0u;
+#define LH_PICK(a, b, c) __uint_as_float((__float_as_uint(a) & m0) | (__float_as_uint(b) & m1) | (__float_as_uint(c) & m2))
+    const float kk[3] = {LH_PICK(M.kd[0], M.ks[0], M.kt[0]), LH_PICK(M.kd[1], M.ks[1], M.kt[1]), LH_PICK(M.kd[2], M.ks[2], M.kt[2])};
+    const float wsel = ref_weights ? (type == 0 ? 0.318309886f : 1.0f) : LH_PICK(M.wd, M.ws, M.wt);     /* unbiased: 1 / (P(type) x survival) = (float)(1 / ave) */
+#undef LH_PICK
     for (int k = 0; k < 3; k++) {
         G2[k] = G[k] * kk[k] * col[k] * wsel;
         org2[k] = P[k] + side * N[k] * 1.0e-6;

@@ -388,12 +388,20 @@ __global__ void k_state_build(size_t n, const lh_dev_scene_t sc, const double *_
 /* ri_raytrace level (every bounce goes through the closest-hit kernel and fp64 resolve).   */
 /* ------------------------------------------------------------------------------------ */
 
-/* After the closest-hit launch of bounce `depth`: ONE pass over the live paths.  Round 2 ran decide -> flag count -> scan ->
- * emit with the survivor count read back by the host before the next launch (110 dependent launches and 28 host round trips
- * per 64-sample pass; the decide pass alone re-read 44 bytes per path vertex).  Here a workgroup takes LH_PT_ITEMS x 256
- * consecutive paths, decides them all (miss -> radiance = throughput x environment, the path ends; hit -> vertex limit and
- * Russian roulette on d + s + t, pathtrace.c:407-430 -> ends with radiance 0, or goes on), reserves the survivors' slots with
- * one atomic on counts[depth + 1], and writes each survivor's next ray ONCE into its slot, in path order within the workgroup.
+/* After the closest-hit launch of bounce `depth`: the live paths are DECIDED (k_pt_decide) and the survivors SCATTERED
+ * (k_pt_scatter).  Round 2 ran decide -> flag count -> scan -> emit with the survivor count read back by the host before the
+ * next launch (110 dependent launches and 28 host round trips per 64-sample pass); rounds 3-4 ran ONE kernel per bounce, a
+ * workgroup deciding 2048 consecutive paths, listing its survivors in LDS and scattering them -- at the scatter's 136-146
+ * VGPRs and 96 bytes of scratch: three waves per SIMD, every one of them waiting on its loads 61-74 % of the time, the decision
+ * loop one dependent load chain per item (profiles/r05_pmc_pt_summary.txt: 31 ms for a 2^30-path pass's first bounce with the
+ * vector pipes 37 % busy).  Round 5 splits the two halves at the place where their needs differ:
+ *   k_pt_decide  -- a streaming pass at eight waves per SIMD: a workgroup takes LH_PT_ITEMS x 256 consecutive paths, loads their
+ *     hit words (and, for the misses, throughputs) in one batch, decides them (miss -> radiance = throughput x environment, the
+ *     path ends; hit -> vertex limit and Russian roulette on d + s + t, pathtrace.c:407-430 -> ends with radiance 0, or goes
+ *     on), reserves the survivors' slots with one atomic on counts[depth + 1] and writes each survivor's SOURCE INDEX into its
+ *     slot of the next bounce's path-word array, in path order within the workgroup;
+ *   k_pt_scatter -- one thread per survivor slot j: source index i = path_of2[j], hit epilogue, lobe, next ray, throughput,
+ *     written once into slot j (the path word over the source index it has just read).
  * The launch's own path count is counts[depth], left there by the previous bounce: nothing comes back to the host inside a
  * pass.  Every path writes its radiance exactly once (where it ends), so the buffer needs no clearing.  Slot order across
  * workgroups depends on scheduling; a path's arithmetic does not (keys are (pixel, sample, bounce)): the frame is the same. */
@@ -405,47 +413,58 @@ struct PtPass {
     int use_override, ref_weights, depth, max_depth, s0, spp, x0, y0, w, band_rows, band_stride, full_width;
 };
 
-template <bool FIRST>
-__global__ __launch_bounds__(256) void k_pt_shade(const PtPass ps, const lh_dev_scene_t sc, const double *__restrict__ nrm9,
-                                                  const double *__restrict__ col9, const uint32_t *__restrict__ prim_mesh,
-                                                  const DevMaterial *__restrict__ materials, uint32_t *__restrict__ counts,
-                                                  const double *__restrict__ org, const double *__restrict__ dir,
-                                                  const uint32_t *__restrict__ prim, const double *__restrict__ t,
-                                                  const double *__restrict__ u, const double *__restrict__ v,
-                                                  const uint32_t *__restrict__ path_of, const float *__restrict__ thr,
-                                                  float *__restrict__ radiance, double *__restrict__ org2, double *__restrict__ dir2,
-                                                  uint32_t *__restrict__ path_of2, float *__restrict__ thr2)
+/* PROBE: the environment is a light probe (a miss evaluates it in the path's direction: fp64 acos / sqrt / divisions, kept out of the
+ * constant-environment instantiation, whose decision loop is unrolled over its batch) */
+template <bool FIRST, bool PROBE>
+__global__ __launch_bounds__(256) void k_pt_decide(const PtPass ps, const uint32_t *__restrict__ prim_mesh, const DevMaterial *__restrict__ materials,
+                                                   uint32_t *__restrict__ counts, const double *__restrict__ dir, const uint32_t *__restrict__ prim,
+                                                   const uint32_t *__restrict__ path_of, const float *__restrict__ thr, float *__restrict__ radiance,
+                                                   uint32_t *__restrict__ src_of)
 {
     LH_NC
     __shared__ unsigned long long sbal[LH_PT_ITEMS][4];
     __shared__ uint32_t soff[LH_PT_ITEMS][4];
-    __shared__ uint32_t gbase, stotal;
-    __shared__ uint16_t slist[256 * LH_PT_ITEMS];
+    __shared__ uint32_t gbase;
     const uint32_t n = counts[ps.depth];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t span = 256u * LH_PT_ITEMS;
     for (uint32_t base = blockIdx.x * span; base < n; base += gridDim.x * span) {      /* n < 2^31: no wrap */
-#pragma unroll 1
+        /* the batch's loads first, all of them in flight together: hit words, path words, the misses' throughputs */
+        uint32_t pr[LH_PT_ITEMS], pw[LH_PT_ITEMS];
+        float g0[LH_PT_ITEMS], g1[LH_PT_ITEMS], g2[LH_PT_ITEMS];
+#pragma unroll
+        for (int k = 0; k < LH_PT_ITEMS; k++) {
+            const uint32_t i = base + (uint32_t)k * 256u + threadIdx.x;
+            pr[k] = i < n ? prim[i] : 0u;
+            pw[k] = FIRST ? i : (i < n ? path_of[i] : 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < LH_PT_ITEMS; k++) {
+            const uint32_t i = base + (uint32_t)k * 256u + threadIdx.x;
+            g0[k] = 1.0f; g1[k] = 1.0f; g2[k] = 1.0f;
+            if (!FIRST && i < n && pr[k] == LH_MISS_PRIM) { g0[k] = thr[3 * (size_t)i]; g1[k] = thr[3 * (size_t)i + 1]; g2[k] = thr[3 * (size_t)i + 2]; }
+        }
+#pragma unroll
         for (int k = 0; k < LH_PT_ITEMS; k++) {
             const uint32_t i = base + (uint32_t)k * 256u + threadIdx.x;
             bool go = false;
             if (i < n) {
-                const uint32_t p = prim[i];
-                const uint32_t path = FIRST ? i : (path_of[i] & ~LH_PT_INTERIOR);
+                const uint32_t p = pr[k];
+                const uint32_t path = pw[k] & ~LH_PT_INTERIOR;
                 float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
                 if (p == LH_MISS_PRIM) {
                     float e[3];
-                    if (ps.env.map) {
+                    if (PROBE) {
                         double o[3], d[3];
                         if (FIRST) pt_camera_ray(ps.cam, i, o, d);
                         else { d[0] = dir[3 * (size_t)i]; d[1] = dir[3 * (size_t)i + 1]; d[2] = dir[3 * (size_t)i + 2]; }
                         env_fetch(ps.env, d[0], d[1], d[2], e);
                     } else { e[0] = ps.env.rgb[0]; e[1] = ps.env.rgb[1]; e[2] = ps.env.rgb[2]; }
                     if (FIRST) { r0 = e[0]; r1 = e[1]; r2 = e[2]; }
-                    else { r0 = thr[3 * (size_t)i] * e[0]; r1 = thr[3 * (size_t)i + 1] * e[1]; r2 = thr[3 * (size_t)i + 2] * e[2]; }
+                    else { r0 = g0[k] * e[0]; r1 = g1[k] * e[1]; r2 = g2[k] * e[2]; }
                 } else {
-                    const DevMaterial M = ps.use_override ? ps.override_mat : materials[prim_mesh[p]];
-                    go = pt_survives(M, pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.band_rows, ps.band_stride, ps.full_width, ps.depth), ps.depth, ps.max_depth);
+                    const double ksum = ps.use_override ? ps.override_mat.asum9 : materials[prim_mesh[p]].asum9;
+                    go = pt_survives(ksum, pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.band_rows, ps.band_stride, ps.full_width, ps.depth), ps.depth, ps.max_depth);
                 }
                 if (!go) { radiance[3 * (size_t)path] = r0; radiance[3 * (size_t)path + 1] = r1; radiance[3 * (size_t)path + 2] = r2; }
             }
@@ -457,42 +476,68 @@ __global__ __launch_bounds__(256) void k_pt_shade(const PtPass ps, const lh_dev_
             uint32_t run = 0;
             for (int k = 0; k < LH_PT_ITEMS; k++) for (int w = 0; w < 4; w++) { const uint32_t c = soff[k][w]; soff[k][w] = run; run += c; }
             gbase = run ? atomicAdd(&counts[ps.depth + 1], run) : 0u;
-            stotal = run;
         }
         __syncthreads();
         const uint32_t g = gbase;
-        /* the survivors' item numbers, in slot order: the expensive part below (hit epilogue, fp64 sincos / sqrt / divisions) then
-         * runs with every lane busy instead of the ~half that survive (depth 0) or fewer (later bounces) */
-#pragma unroll 1
+#pragma unroll
         for (int k = 0; k < LH_PT_ITEMS; k++) {
             const unsigned long long m = sbal[k][wv];
-            if ((m >> lane) & 1ull) slist[soff[k][wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(k * 256 + (int)threadIdx.x);
+            if ((m >> lane) & 1ull) src_of[g + soff[k][wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = base + (uint32_t)k * 256u + threadIdx.x;
         }
         __syncthreads();
-        const uint32_t nlive = stotal;
+    }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_pt_scatter(const PtPass ps, const lh_dev_scene_t sc, const double *__restrict__ nrm9,
+                                                    const double *__restrict__ col9, const uint32_t *__restrict__ prim_mesh,
+                                                    const DevMaterial *__restrict__ materials, const uint32_t *__restrict__ counts,
+                                                    const double *__restrict__ org, const double *__restrict__ dir,
+                                                    const uint32_t *__restrict__ prim, const double *__restrict__ t,
+                                                    const double *__restrict__ u, const double *__restrict__ v,
+                                                    const uint32_t *__restrict__ path_of, const float *__restrict__ thr,
+                                                    double *__restrict__ org2, double *__restrict__ dir2,
+                                                    uint32_t *path_of2 /* in: the survivor's source index; out: its path word */, float *__restrict__ thr2)
+{
+    LH_NC
+    const uint32_t n2 = counts[ps.depth + 1];
 #pragma unroll 1
-        for (uint32_t q = threadIdx.x; q < nlive; q += 256u) {
-            const uint32_t i = base + (uint32_t)slist[q];
-            const size_t j = (size_t)g + q;
-            const uint32_t pword = FIRST ? i : path_of[i];
-            const uint32_t path = pword & ~LH_PT_INTERIOR;
-            const uint32_t p = prim[i];
-            float G[3] = {1.0f, 1.0f, 1.0f};
-            if (!FIRST) { G[0] = thr[3 * (size_t)i]; G[1] = thr[3 * (size_t)i + 1]; G[2] = thr[3 * (size_t)i + 2]; }
-            double Or[3], D[3];
-            if (FIRST) pt_camera_ray(ps.cam, i, Or, D);
-            else {
-                Or[0] = org[3 * (size_t)i]; Or[1] = org[3 * (size_t)i + 1]; Or[2] = org[3 * (size_t)i + 2];
-                D[0] = dir[3 * (size_t)i]; D[1] = dir[3 * (size_t)i + 1]; D[2] = dir[3 * (size_t)i + 2];
-            }
-            const uint64_t key = pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.band_rows, ps.band_stride, ps.full_width, ps.depth);
-            const DevMaterial M = ps.use_override ? ps.override_mat : materials[prim_mesh[p]];
-            double o2[3], O[3]; float G2[3]; uint32_t pw2;
-            pt_scatter(sc, nrm9, col9, M, ps.ref_weights, key, p, pword, Or, D, t[i], u[i], v[i], G, o2, O, G2, pw2);
-            for (int c = 0; c < 3; c++) { thr2[3 * j + c] = G2[c]; org2[3 * j + c] = o2[c]; dir2[3 * j + c] = O[c]; }
-            path_of2[j] = pw2;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n2; j += gridDim.x * 256u) {
+        const uint32_t i = path_of2[j];
+        const uint32_t pword = FIRST ? i : path_of[i];
+        const uint32_t path = pword & ~LH_PT_INTERIOR;
+        const uint32_t p = prim[i];
+        const double tt = t[i], uu = u[i], vv = v[i];
+        float G[3] = {1.0f, 1.0f, 1.0f};
+        if (!FIRST) { G[0] = thr[3 * (size_t)i]; G[1] = thr[3 * (size_t)i + 1]; G[2] = thr[3 * (size_t)i + 2]; }
+        double Or[3], D[3];
+        if (FIRST) pt_camera_ray(ps.cam, i, Or, D);
+        else {
+            Or[0] = org[3 * (size_t)i]; Or[1] = org[3 * (size_t)i + 1]; Or[2] = org[3 * (size_t)i + 2];
+            D[0] = dir[3 * (size_t)i]; D[1] = dir[3 * (size_t)i + 1]; D[2] = dir[3 * (size_t)i + 2];
         }
-        __syncthreads();
+        const uint64_t key = pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.band_rows, ps.band_stride, ps.full_width, ps.depth);
+        /* field by field: a whole-struct copy from one of two places keeps the record in scratch (96 bytes a lane, and the lobe's
+         * reflectance then read from it by a run-time offset) */
+        DevMaterial M;
+#define LH_MFIELDS LH_MF(kd[0]) LH_MF(kd[1]) LH_MF(kd[2]) LH_MF(ks[0]) LH_MF(ks[1]) LH_MF(ks[2]) LH_MF(kt[0]) LH_MF(kt[1]) LH_MF(kt[2]) LH_MF(ior) \
+                   LH_MF(ad) LH_MF(as) LH_MF(at) LH_MF(asum9) LH_MF(wd) LH_MF(ws) LH_MF(wt)
+        M.pad = 0.0f;
+        if (ps.use_override) {
+#define LH_MF(x) M.x = ps.override_mat.x;
+            LH_MFIELDS
+#undef LH_MF
+        } else {
+            const DevMaterial *mp = materials + prim_mesh[p];
+#define LH_MF(x) M.x = mp->x;
+            LH_MFIELDS
+#undef LH_MF
+        }
+#undef LH_MFIELDS
+        double o2[3], O[3]; float G2[3]; uint32_t pw2;
+        pt_scatter(sc, nrm9, col9, M, ps.ref_weights, key, p, pword, Or, D, tt, uu, vv, G, o2, O, G2, pw2);
+        for (int c = 0; c < 3; c++) { thr2[3 * (size_t)j + c] = G2[c]; org2[3 * (size_t)j + c] = o2[c]; dir2[3 * (size_t)j + c] = O[c]; }
+        path_of2[j] = pw2;
     }
 }
 
@@ -669,14 +714,29 @@ extern "C" int lh_pt_launch_shade(size_t n_max, const lh_dev_scene_t *sc, const 
     ps.seed = seed; ps.use_override = override_mat != NULL; ps.ref_weights = ref_weights; ps.depth = depth; ps.max_depth = max_depth;
     ps.s0 = s0; ps.spp = spp; ps.x0 = x0; ps.y0 = y0; ps.w = w; ps.band_rows = band_rows; ps.band_stride = band_stride; ps.full_width = full_width;
     const size_t spans = (n_max + 256 * LH_PT_ITEMS - 1) / (256 * LH_PT_ITEMS);
-    const size_t cap = (size_t)(ncus > 0 ? ncus : 256) * 8;
-    const unsigned nb = (unsigned)(spans < cap ? spans : cap);
-    if (depth == 0)
-        hipLaunchKernelGGL((k_pt_shade<true>), dim3(nb), dim3(256), 0, s, ps, *sc, d_nrm9, d_col9, d_prim_mesh, (const DevMaterial *)d_materials,
-                           d_counts, d_org, d_dir, d_prim, d_t, d_u, d_v, d_path_of, d_thr, d_radiance, d_org2, d_dir2, d_path_of2, d_thr2);
-    else
-        hipLaunchKernelGGL((k_pt_shade<false>), dim3(nb), dim3(256), 0, s, ps, *sc, d_nrm9, d_col9, d_prim_mesh, (const DevMaterial *)d_materials,
-                           d_counts, d_org, d_dir, d_prim, d_t, d_u, d_v, d_path_of, d_thr, d_radiance, d_org2, d_dir2, d_path_of2, d_thr2);
+    const size_t cus = (size_t)(ncus > 0 ? ncus : 256);
+    const unsigned nb = (unsigned)(spans < cus * 16 ? spans : cus * 16);                    /* decide: 2 x the eight resident workgroups of a CU */
+    const size_t blocks = (n_max + 255) / 256;
+    const unsigned ns = (unsigned)(blocks < cus * 16 ? blocks : cus * 16);                  /* scatter: grid-stride over the survivors counted by then */
+    if (depth == 0) {
+        if (d_env_map)
+            hipLaunchKernelGGL((k_pt_decide<true, true>), dim3(nb), dim3(256), 0, s, ps, d_prim_mesh, (const DevMaterial *)d_materials, d_counts, d_dir, d_prim,
+                               d_path_of, d_thr, d_radiance, d_path_of2);
+        else
+            hipLaunchKernelGGL((k_pt_decide<true, false>), dim3(nb), dim3(256), 0, s, ps, d_prim_mesh, (const DevMaterial *)d_materials, d_counts, d_dir, d_prim,
+                               d_path_of, d_thr, d_radiance, d_path_of2);
+        hipLaunchKernelGGL((k_pt_scatter<true>), dim3(ns), dim3(256), 0, s, ps, *sc, d_nrm9, d_col9, d_prim_mesh, (const DevMaterial *)d_materials,
+                           (const uint32_t *)d_counts, d_org, d_dir, d_prim, d_t, d_u, d_v, d_path_of, d_thr, d_org2, d_dir2, d_path_of2, d_thr2);
+    } else {
+        if (d_env_map)
+            hipLaunchKernelGGL((k_pt_decide<false, true>), dim3(nb), dim3(256), 0, s, ps, d_prim_mesh, (const DevMaterial *)d_materials, d_counts, d_dir, d_prim,
+                               d_path_of, d_thr, d_radiance, d_path_of2);
+        else
+            hipLaunchKernelGGL((k_pt_decide<false, false>), dim3(nb), dim3(256), 0, s, ps, d_prim_mesh, (const DevMaterial *)d_materials, d_counts, d_dir, d_prim,
+                               d_path_of, d_thr, d_radiance, d_path_of2);
+        hipLaunchKernelGGL((k_pt_scatter<false>), dim3(ns), dim3(256), 0, s, ps, *sc, d_nrm9, d_col9, d_prim_mesh, (const DevMaterial *)d_materials,
+                           (const uint32_t *)d_counts, d_org, d_dir, d_prim, d_t, d_u, d_v, d_path_of, d_thr, d_org2, d_dir2, d_path_of2, d_thr2);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
