@@ -414,7 +414,11 @@ struct PtPass {
 };
 
 /* PROBE: the environment is a light probe (a miss evaluates it in the path's direction: fp64 acos / sqrt / divisions, kept out of the
- * constant-environment instantiation, whose decision loop is unrolled over its batch) */
+ * constant-environment instantiation, whose decision loop is unrolled over its batch).
+ * A workgroup's span is LH_PT_ROUNDS batches of LH_PT_ITEMS x 256 paths behind ONE atomic on the survivor count: every workgroup of
+ * every launch adds to the same word, and same-address atomics retire one every ~20 ns -- at 2048 paths an atomic a 2^30-path
+ * pass's first decision took 6.0 ms for its 13 GB; at 8192 the atomics are a quarter of that. */
+#define LH_PT_ROUNDS 4
 template <bool FIRST, bool PROBE>
 __global__ __launch_bounds__(256) void k_pt_decide(const PtPass ps, const uint32_t *__restrict__ prim_mesh, const DevMaterial *__restrict__ materials,
                                                    uint32_t *__restrict__ counts, const double *__restrict__ dir, const uint32_t *__restrict__ prim,
@@ -422,67 +426,76 @@ __global__ __launch_bounds__(256) void k_pt_decide(const PtPass ps, const uint32
                                                    uint32_t *__restrict__ src_of)
 {
     LH_NC
-    __shared__ unsigned long long sbal[LH_PT_ITEMS][4];
-    __shared__ uint32_t soff[LH_PT_ITEMS][4];
+    constexpr int NB = LH_PT_ROUNDS * LH_PT_ITEMS * 4;             /* ballots of a span: (round, item, wave) */
+    __shared__ unsigned long long sbal[NB];
+    __shared__ uint32_t soff[NB];
     __shared__ uint32_t gbase;
     const uint32_t n = counts[ps.depth];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t span = 256u * LH_PT_ITEMS;
+    const uint32_t batch = 256u * LH_PT_ITEMS, span = batch * LH_PT_ROUNDS;
     for (uint32_t base = blockIdx.x * span; base < n; base += gridDim.x * span) {      /* n < 2^31: no wrap */
-        /* the batch's loads first, all of them in flight together: hit words, path words, the misses' throughputs */
-        uint32_t pr[LH_PT_ITEMS], pw[LH_PT_ITEMS];
-        float g0[LH_PT_ITEMS], g1[LH_PT_ITEMS], g2[LH_PT_ITEMS];
+#pragma unroll 1
+        for (int r = 0; r < LH_PT_ROUNDS; r++) {
+            const uint32_t b0 = base + (uint32_t)r * batch;
+            /* the batch's loads first, all of them in flight together: hit words, path words, the misses' throughputs */
+            uint32_t pr[LH_PT_ITEMS], pw[LH_PT_ITEMS];
+            float g0[LH_PT_ITEMS], g1[LH_PT_ITEMS], g2[LH_PT_ITEMS];
 #pragma unroll
-        for (int k = 0; k < LH_PT_ITEMS; k++) {
-            const uint32_t i = base + (uint32_t)k * 256u + threadIdx.x;
-            pr[k] = i < n ? prim[i] : 0u;
-            pw[k] = FIRST ? i : (i < n ? path_of[i] : 0u);
-        }
-#pragma unroll
-        for (int k = 0; k < LH_PT_ITEMS; k++) {
-            const uint32_t i = base + (uint32_t)k * 256u + threadIdx.x;
-            g0[k] = 1.0f; g1[k] = 1.0f; g2[k] = 1.0f;
-            if (!FIRST && i < n && pr[k] == LH_MISS_PRIM) { g0[k] = thr[3 * (size_t)i]; g1[k] = thr[3 * (size_t)i + 1]; g2[k] = thr[3 * (size_t)i + 2]; }
-        }
-#pragma unroll
-        for (int k = 0; k < LH_PT_ITEMS; k++) {
-            const uint32_t i = base + (uint32_t)k * 256u + threadIdx.x;
-            bool go = false;
-            if (i < n) {
-                const uint32_t p = pr[k];
-                const uint32_t path = pw[k] & ~LH_PT_INTERIOR;
-                float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
-                if (p == LH_MISS_PRIM) {
-                    float e[3];
-                    if (PROBE) {
-                        double o[3], d[3];
-                        if (FIRST) pt_camera_ray(ps.cam, i, o, d);
-                        else { d[0] = dir[3 * (size_t)i]; d[1] = dir[3 * (size_t)i + 1]; d[2] = dir[3 * (size_t)i + 2]; }
-                        env_fetch(ps.env, d[0], d[1], d[2], e);
-                    } else { e[0] = ps.env.rgb[0]; e[1] = ps.env.rgb[1]; e[2] = ps.env.rgb[2]; }
-                    if (FIRST) { r0 = e[0]; r1 = e[1]; r2 = e[2]; }
-                    else { r0 = g0[k] * e[0]; r1 = g1[k] * e[1]; r2 = g2[k] * e[2]; }
-                } else {
-                    const double ksum = ps.use_override ? ps.override_mat.asum9 : materials[prim_mesh[p]].asum9;
-                    go = pt_survives(ksum, pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.band_rows, ps.band_stride, ps.full_width, ps.depth), ps.depth, ps.max_depth);
-                }
-                if (!go) { radiance[3 * (size_t)path] = r0; radiance[3 * (size_t)path + 1] = r1; radiance[3 * (size_t)path + 2] = r2; }
+            for (int k = 0; k < LH_PT_ITEMS; k++) {
+                const uint32_t i = b0 + (uint32_t)k * 256u + threadIdx.x;
+                pr[k] = i < n ? prim[i] : 0u;
+                pw[k] = FIRST ? i : (i < n ? path_of[i] : 0u);
             }
-            const unsigned long long m = __ballot(go);
-            if (lane == 0) { sbal[k][wv] = m; soff[k][wv] = (uint32_t)__popcll(m); }
+#pragma unroll
+            for (int k = 0; k < LH_PT_ITEMS; k++) {
+                const uint32_t i = b0 + (uint32_t)k * 256u + threadIdx.x;
+                g0[k] = 1.0f; g1[k] = 1.0f; g2[k] = 1.0f;
+                if (!FIRST && i < n && pr[k] == LH_MISS_PRIM) { g0[k] = thr[3 * (size_t)i]; g1[k] = thr[3 * (size_t)i + 1]; g2[k] = thr[3 * (size_t)i + 2]; }
+            }
+#pragma unroll
+            for (int k = 0; k < LH_PT_ITEMS; k++) {
+                const uint32_t i = b0 + (uint32_t)k * 256u + threadIdx.x;
+                bool go = false;
+                if (i < n) {
+                    const uint32_t p = pr[k];
+                    const uint32_t path = pw[k] & ~LH_PT_INTERIOR;
+                    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+                    if (p == LH_MISS_PRIM) {
+                        float e[3];
+                        if (PROBE) {
+                            double o[3], d[3];
+                            if (FIRST) pt_camera_ray(ps.cam, i, o, d);
+                            else { d[0] = dir[3 * (size_t)i]; d[1] = dir[3 * (size_t)i + 1]; d[2] = dir[3 * (size_t)i + 2]; }
+                            env_fetch(ps.env, d[0], d[1], d[2], e);
+                        } else { e[0] = ps.env.rgb[0]; e[1] = ps.env.rgb[1]; e[2] = ps.env.rgb[2]; }
+                        if (FIRST) { r0 = e[0]; r1 = e[1]; r2 = e[2]; }
+                        else { r0 = g0[k] * e[0]; r1 = g1[k] * e[1]; r2 = g2[k] * e[2]; }
+                    } else {
+                        const double ksum = ps.use_override ? ps.override_mat.asum9 : materials[prim_mesh[p]].asum9;
+                        go = pt_survives(ksum, pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.band_rows, ps.band_stride, ps.full_width, ps.depth), ps.depth, ps.max_depth);
+                    }
+                    if (!go) { radiance[3 * (size_t)path] = r0; radiance[3 * (size_t)path + 1] = r1; radiance[3 * (size_t)path + 2] = r2; }
+                }
+                const unsigned long long m = __ballot(go);
+                if (lane == 0) sbal[(r * LH_PT_ITEMS + k) * 4 + wv] = m;
+            }
         }
         __syncthreads();
-        if (threadIdx.x == 0) {                      /* 32 counts -> exclusive offsets in path order (item-major, then wave) */
-            uint32_t run = 0;
-            for (int k = 0; k < LH_PT_ITEMS; k++) for (int w = 0; w < 4; w++) { const uint32_t c = soff[k][w]; soff[k][w] = run; run += c; }
-            gbase = run ? atomicAdd(&counts[ps.depth + 1], run) : 0u;
+        /* NB counts -> exclusive offsets in path order (round, item, wave), by the first wave: two entries a lane */
+        if (wv == 0) {
+            static_assert(NB == 128, "two ballots a lane");
+            const uint32_t c0 = (uint32_t)__popcll(sbal[2 * lane]), c1 = (uint32_t)__popcll(sbal[2 * lane + 1]);
+            uint32_t incl = c0 + c1;
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)incl, off); if (lane >= off) incl += up; }
+            soff[2 * lane] = incl - c0 - c1; soff[2 * lane + 1] = incl - c1;
+            if (lane == 63) gbase = incl ? atomicAdd(&counts[ps.depth + 1], incl) : 0u;
         }
         __syncthreads();
         const uint32_t g = gbase;
-#pragma unroll
-        for (int k = 0; k < LH_PT_ITEMS; k++) {
-            const unsigned long long m = sbal[k][wv];
-            if ((m >> lane) & 1ull) src_of[g + soff[k][wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = base + (uint32_t)k * 256u + threadIdx.x;
+#pragma unroll 4
+        for (int q = 0; q < LH_PT_ROUNDS * LH_PT_ITEMS; q++) {
+            const unsigned long long m = sbal[q * 4 + wv];
+            if ((m >> lane) & 1ull) src_of[g + soff[q * 4 + wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = base + (uint32_t)q * 256u + threadIdx.x;
         }
         __syncthreads();
     }
@@ -713,7 +726,7 @@ extern "C" int lh_pt_launch_shade(size_t n_max, const lh_dev_scene_t *sc, const 
     ps.cam = (const PtCamSrc *)d_cam;
     ps.seed = seed; ps.use_override = override_mat != NULL; ps.ref_weights = ref_weights; ps.depth = depth; ps.max_depth = max_depth;
     ps.s0 = s0; ps.spp = spp; ps.x0 = x0; ps.y0 = y0; ps.w = w; ps.band_rows = band_rows; ps.band_stride = band_stride; ps.full_width = full_width;
-    const size_t spans = (n_max + 256 * LH_PT_ITEMS - 1) / (256 * LH_PT_ITEMS);
+    const size_t spans = (n_max + 256 * LH_PT_ITEMS * LH_PT_ROUNDS - 1) / (256 * LH_PT_ITEMS * LH_PT_ROUNDS);
     const size_t cus = (size_t)(ncus > 0 ? ncus : 256);
     const unsigned nb = (unsigned)(spans < cus * 16 ? spans : cus * 16);                    /* decide: 2 x the eight resident workgroups of a CU */
     const size_t blocks = (n_max + 255) / 256;

@@ -52,6 +52,10 @@ __device__ __forceinline__ void resolve(const lh_dev_scene_t &sc, uint32_t prim,
         /* almost-equal t of two triangles: which one the reference keeps can hinge on one box test */
         if (b.prim != LH_MISS_PRIM && prim != b.prim && t != b.t && fabs(t - b.t) <= LH_FRAGILE_REL * fabs(t)) b.frag |= 2u;
         if (take && t < LH_T_INF) {
+            /* the fragility bit is evaluated HERE, for every hit that is taken, although only the last one's counts: evaluating it
+             * once in finish() (70 of this function's 175 instructions, per candidate slot any lane of the wave had filled) needs the
+             * kept triangle's corners again -- one more dependent load at the end of every regroup -- and lost on the same box:
+             * S-soup-1M 2 245 -> 2 219 Mrays/s, the path-traced config-4 frame 116.9 -> 118.9 ms (r05, tools/experiments/ab_frames.py) */
             b.t = t; b.u = u; b.v = v; b.prim = prim;
             b.frag = (b.frag & 2u) | (uint32_t)lh_hit_fragile(tv, ox, oy, oz, dx, dy, dz, t);
         }
