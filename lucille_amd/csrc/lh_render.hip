@@ -419,10 +419,51 @@ struct PtPass {
  * every launch adds to the same word, and same-address atomics retire one every ~20 ns -- at 2048 paths an atomic a 2^30-path
  * pass's first decision took 6.0 ms for its 13 GB; at 8192 the atomics are a quarter of that. */
 #define LH_PT_ROUNDS 4
+
+/* A path's radiance goes into its pixel's accumulator where the path ends -- three 64-bit FIXED-POINT sums per pixel of the pass
+ * (32 fraction bits; a sample clamped to +-2^19: the 2^12 samples of a pixel that lh_tile.hip allows in one pass cannot overflow) -- instead of into a 12-byte record per path that a resolve pass sums afterwards (rounds 2-4): those records
+ * were written where the paths ended, a few of every 128-byte line per bounce (6.7 + 5.6 + ... GB of partial-line writes and
+ * 12.9 GB read back per 2^30-path pass, 12.9 GB of HBM held).  Integer sums do not depend on the order of their terms: a pixel
+ * is the same whatever the slot order, tiling or sharding, bit for bit, as before.  Lanes of a wave hold consecutive slots,
+ * i.e. runs of paths of the same pixel: the runs are summed across the wave first (a segmented scan over run numbers), one
+ * atomic per run and channel. */
+#define LH_PT_FIX_CLAMP 524288.0f
+__device__ __forceinline__ unsigned long long pt_fix(float r)
+{
+    r = fminf(fmaxf(r, -LH_PT_FIX_CLAMP), LH_PT_FIX_CLAMP);          /* (a NaN never gets here: pt_accumulate drops it) */
+    const float fl = floorf(r);
+    const uint32_t lo = (uint32_t)((r - fl) * 4294967296.0f);          /* the fraction is exact in fp32, below 1 - 2^-24: no carry */
+    return ((unsigned long long)(long long)(int)fl << 32) | (unsigned long long)lo;
+}
+
+__device__ __forceinline__ void pt_accumulate(unsigned long long *__restrict__ accum, uint32_t pix, bool ends, float r0, float r1, float r2, int lane)
+{
+    const bool mine = ends && r0 == r0 && r1 == r1 && r2 == r2 && (r0 != 0.0f || r1 != 0.0f || r2 != 0.0f);
+    if (__ballot(mine) == 0ull) return;                                /* wave-uniform: nothing ends here with light */
+    unsigned long long a = mine ? pt_fix(r0) : 0ull, b = mine ? pt_fix(r1) : 0ull, c = mine ? pt_fix(r2) : 0ull;
+    /* run number: the pixel may come back later in the wave (two workgroups' survivors of one pixel with a third's between) */
+    const uint32_t before = (uint32_t)__shfl_up((int)pix, 1);
+    const unsigned long long heads = __ballot(lane == 0 || before != pix);
+    const uint32_t run = (uint32_t)__popcll(heads & ((2ull << lane) - 1ull));
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t ru = (uint32_t)__shfl_up((int)run, off);
+        const unsigned long long au = __shfl_up(a, off), bu = __shfl_up(b, off), cu = __shfl_up(c, off);
+        if (lane >= off && ru == run) { a += au; b += bu; c += cu; }
+    }
+    const bool last = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    if (last && (a | b | c) != 0ull) {
+        unsigned long long *o = accum + 3 * (size_t)pix;
+        if (a) atomicAdd(o, a);
+        if (b) atomicAdd(o + 1, b);
+        if (c) atomicAdd(o + 2, c);
+    }
+}
+
 template <bool FIRST, bool PROBE>
 __global__ __launch_bounds__(256) void k_pt_decide(const PtPass ps, const uint32_t *__restrict__ prim_mesh, const DevMaterial *__restrict__ materials,
                                                    uint32_t *__restrict__ counts, const double *__restrict__ dir, const uint32_t *__restrict__ prim,
-                                                   const uint32_t *__restrict__ path_of, const float *__restrict__ thr, float *__restrict__ radiance,
+                                                   const uint32_t *__restrict__ path_of, const float *__restrict__ thr, unsigned long long *__restrict__ accum,
                                                    uint32_t *__restrict__ src_of)
 {
     LH_NC
@@ -456,10 +497,10 @@ __global__ __launch_bounds__(256) void k_pt_decide(const PtPass ps, const uint32
             for (int k = 0; k < LH_PT_ITEMS; k++) {
                 const uint32_t i = b0 + (uint32_t)k * 256u + threadIdx.x;
                 bool go = false;
+                const uint32_t path = pw[k] & ~LH_PT_INTERIOR;
+                float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
                 if (i < n) {
                     const uint32_t p = pr[k];
-                    const uint32_t path = pw[k] & ~LH_PT_INTERIOR;
-                    float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
                     if (p == LH_MISS_PRIM) {
                         float e[3];
                         if (PROBE) {
@@ -474,8 +515,8 @@ __global__ __launch_bounds__(256) void k_pt_decide(const PtPass ps, const uint32
                         const double ksum = ps.use_override ? ps.override_mat.asum9 : materials[prim_mesh[p]].asum9;
                         go = pt_survives(ksum, pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.band_rows, ps.band_stride, ps.full_width, ps.depth), ps.depth, ps.max_depth);
                     }
-                    if (!go) { radiance[3 * (size_t)path] = r0; radiance[3 * (size_t)path + 1] = r1; radiance[3 * (size_t)path + 2] = r2; }
                 }
+                pt_accumulate(accum, path / (uint32_t)ps.spp, i < n && !go, r0, r1, r2, lane);          /* a path the roulette ended adds nothing */
                 const unsigned long long m = __ballot(go);
                 if (lane == 0) sbal[(r * LH_PT_ITEMS + k) * 4 + wv] = m;
             }
@@ -561,47 +602,23 @@ __global__ void k_pt_begin(uint32_t *counts, uint32_t paths, int nentries, const
     if (threadIdx.x == 0) *dst = src;
 }
 
-/* per pixel: add the mean of this pass's samples (in sample order).  A workgroup's 256 pixels are one contiguous run of
- * 256 x spp x 3 floats: staged through LDS in coalesced 16-sample slices (one thread per pixel reading its own samples straight
- * from HBM touched 64 different lines per load instruction: 1.15 ms per 2048^2 x 16 pass instead of 0.25) */
-#define LH_RESOLVE_SLICE 16
-__global__ __launch_bounds__(256) void k_pt_resolve(int w, int h, int band_rows, int spp, float inv_total_spp, const float *__restrict__ radiance, float *__restrict__ rgb)
+/* per pixel: add the mean of this pass's samples -- the pixel's three fixed-point sums (pt_accumulate) as floats x 1 / spp_total --
+ * and leave the sums zero for the next pass.  (Rounds 2-4 summed 12-byte per-path records here, staged through LDS: 3.3 ms of a
+ * 2^30-path pass.) */
+__global__ __launch_bounds__(256) void k_pt_resolve(int w, int h, int band_rows, float inv_total_spp, unsigned long long *__restrict__ accum, float *__restrict__ rgb)
 {
-    __shared__ float stage[256 * (3 * LH_RESOLVE_SLICE + 1)];        /* +1: odd row stride, conflict-free column reads */
-    const size_t npix = (size_t)w * h;
-    const size_t pix0 = (size_t)blockIdx.x * 256, pix = pix0 + threadIdx.x;
-    const size_t npb = (npix - pix0 < 256) ? npix - pix0 : 256;       /* pixels of this workgroup */
-    float sr = 0.0f, sg = 0.0f, sb = 0.0f;
-    for (int s0 = 0; s0 < spp; s0 += LH_RESOLVE_SLICE) {
-        const int ns = (spp - s0 < LH_RESOLVE_SLICE) ? spp - s0 : LH_RESOLVE_SLICE;
-        const uint32_t nfl = (uint32_t)npb * (uint32_t)(3 * ns);       /* floats of this slice, pixel-major: at most 256 x 48 */
-        const float *src = radiance + 3 * (pix0 * (size_t)spp + (size_t)s0);
-        /* (p, c) of element k by 32-bit division -- by a CONSTANT for a full slice: the 64-bit division by a run-time value that stood
-         * here was most of this kernel's 6.2 ms on a 2048^2 x 256 pass */
-        if (ns == LH_RESOLVE_SLICE) {
-            for (uint32_t k = threadIdx.x; k < nfl; k += 256u) {
-                const uint32_t p = k / (3u * LH_RESOLVE_SLICE), c = k - p * (3u * LH_RESOLVE_SLICE);
-                stage[p * (3 * LH_RESOLVE_SLICE + 1) + c] = src[(size_t)p * (size_t)(3 * spp) + c];
-            }
-        } else {
-            const uint32_t per = (uint32_t)(3 * ns);
-            for (uint32_t k = threadIdx.x; k < nfl; k += 256u) {
-                const uint32_t p = k / per, c = k - p * per;
-                stage[p * (3 * LH_RESOLVE_SLICE + 1) + c] = src[(size_t)p * (size_t)(3 * spp) + c];
-            }
-        }
-        __syncthreads();
-        if (pix < npix) {
-            const float *r = stage + (size_t)threadIdx.x * (3 * LH_RESOLVE_SLICE + 1);
-            for (int s = 0; s < ns; s++) { sr += r[3 * s]; sg += r[3 * s + 1]; sb += r[3 * s + 2]; }
-        }
-        __syncthreads();
-    }
+    const size_t npix = (size_t)w * h, pix = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (pix >= npix) return;
+    float sum[3];
+    for (int c = 0; c < 3; c++) {
+        const long long v = (long long)accum[3 * pix + c];
+        accum[3 * pix + c] = 0ull;
+        sum[c] = (float)((double)v * 2.3283064365386963e-10);
+    }
     /* every band is written in image orientation (its first frame line last); a tile is one band */
     const int lx = (int)(pix % w), ly = (int)(pix / w), band = ly / band_rows;
     float *o = rgb + 3 * ((size_t)(band * band_rows + (band_rows - 1 - (ly - band * band_rows))) * w + lx);
-    o[0] += sr * inv_total_spp; o[1] += sg * inv_total_spp; o[2] += sb * inv_total_spp;
+    o[0] += sum[0] * inv_total_spp; o[1] += sum[1] * inv_total_spp; o[2] += sum[2] * inv_total_spp;
 }
 
 } /* namespace */
@@ -713,7 +730,7 @@ extern "C" int lh_pt_launch_shade(size_t n_max, const lh_dev_scene_t *sc, const 
                                   int depth, int max_depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w,
                                   int band_rows, int band_stride, int full_width, const void *d_cam, uint32_t *d_counts, const double *d_org, const double *d_dir, const uint32_t *d_prim,
                                   const double *d_t, const double *d_u, const double *d_v, const uint32_t *d_path_of,
-                                  const float *d_thr, float *d_radiance, double *d_org2, double *d_dir2, uint32_t *d_path_of2,
+                                  const float *d_thr, unsigned long long *d_accum, double *d_org2, double *d_dir2, uint32_t *d_path_of2,
                                   float *d_thr2, int ncus, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;
@@ -734,31 +751,31 @@ extern "C" int lh_pt_launch_shade(size_t n_max, const lh_dev_scene_t *sc, const 
     if (depth == 0) {
         if (d_env_map)
             hipLaunchKernelGGL((k_pt_decide<true, true>), dim3(nb), dim3(256), 0, s, ps, d_prim_mesh, (const DevMaterial *)d_materials, d_counts, d_dir, d_prim,
-                               d_path_of, d_thr, d_radiance, d_path_of2);
+                               d_path_of, d_thr, d_accum, d_path_of2);
         else
             hipLaunchKernelGGL((k_pt_decide<true, false>), dim3(nb), dim3(256), 0, s, ps, d_prim_mesh, (const DevMaterial *)d_materials, d_counts, d_dir, d_prim,
-                               d_path_of, d_thr, d_radiance, d_path_of2);
+                               d_path_of, d_thr, d_accum, d_path_of2);
         hipLaunchKernelGGL((k_pt_scatter<true>), dim3(ns), dim3(256), 0, s, ps, *sc, d_nrm9, d_col9, d_prim_mesh, (const DevMaterial *)d_materials,
                            (const uint32_t *)d_counts, d_org, d_dir, d_prim, d_t, d_u, d_v, d_path_of, d_thr, d_org2, d_dir2, d_path_of2, d_thr2);
     } else {
         if (d_env_map)
             hipLaunchKernelGGL((k_pt_decide<false, true>), dim3(nb), dim3(256), 0, s, ps, d_prim_mesh, (const DevMaterial *)d_materials, d_counts, d_dir, d_prim,
-                               d_path_of, d_thr, d_radiance, d_path_of2);
+                               d_path_of, d_thr, d_accum, d_path_of2);
         else
             hipLaunchKernelGGL((k_pt_decide<false, false>), dim3(nb), dim3(256), 0, s, ps, d_prim_mesh, (const DevMaterial *)d_materials, d_counts, d_dir, d_prim,
-                               d_path_of, d_thr, d_radiance, d_path_of2);
+                               d_path_of, d_thr, d_accum, d_path_of2);
         hipLaunchKernelGGL((k_pt_scatter<false>), dim3(ns), dim3(256), 0, s, ps, *sc, d_nrm9, d_col9, d_prim_mesh, (const DevMaterial *)d_materials,
                            (const uint32_t *)d_counts, d_org, d_dir, d_prim, d_t, d_u, d_v, d_path_of, d_thr, d_org2, d_dir2, d_path_of2, d_thr2);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-extern "C" int lh_pt_launch_resolve(int w, int h, int band_rows, int spp, float inv_total_spp, const float *d_radiance, float *d_rgb, void *stream)
+extern "C" int lh_pt_launch_resolve(int w, int h, int band_rows, float inv_total_spp, unsigned long long *d_accum, float *d_rgb, void *stream)
 {
     const size_t total = (size_t)w * h;
     if (total == 0) return 0;
     hipLaunchKernelGGL(k_pt_resolve, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       w, h, band_rows, spp, inv_total_spp, d_radiance, d_rgb);
+                       w, h, band_rows, inv_total_spp, d_accum, d_rgb);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -458,9 +458,9 @@ extern "C" int lh_pt_launch_shade(size_t n_max, const lh_dev_scene_t *sc, const 
                                   int depth, int max_depth, unsigned long long seed, int s0, int spp, int x0, int y0, int w,
                                   int band_rows, int band_stride, int full_width, const void *d_cam, uint32_t *d_counts, const double *d_org, const double *d_dir, const uint32_t *d_prim,
                                   const double *d_t, const double *d_u, const double *d_v, const uint32_t *d_path_of,
-                                  const float *d_thr, float *d_radiance, double *d_org2, double *d_dir2, uint32_t *d_path_of2,
+                                  const float *d_thr, unsigned long long *d_accum, double *d_org2, double *d_dir2, uint32_t *d_path_of2,
                                   float *d_thr2, int ncus, void *stream);
-extern "C" int lh_pt_launch_resolve(int w, int h, int band_rows, int spp, float inv_total_spp, const float *d_radiance, float *d_rgb, void *stream);
+extern "C" int lh_pt_launch_resolve(int w, int h, int band_rows, float inv_total_spp, unsigned long long *d_accum, float *d_rgb, void *stream);
 
 /* the pass over a w-wide region of h lines = full bands of band_rows lines, band k starting at frame line y0 + k * band_stride
  * (an ordinary tile: band_rows = h) */
@@ -475,6 +475,7 @@ static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w,
     hipStream_t s = (hipStream_t)stream;
     const size_t S = (size_t)w * h * spp;
     if (S > ((size_t)1 << 30)) return fail("lh_render_pt_tile: more than 2^30 paths in one pass; lower spp_count or the tile size");
+    if (spp > 4096) return fail("lh_render_pt_tile: more than 4096 samples of a pixel in one pass (the pixels' fixed-point sums); lower spp_count");
     unsigned long long *cnt = (a->stat_on && a->hs->bvh.ntris) ? a->d_counters : NULL;      /* lh_accel_trace_statistics */
     if (cnt) HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * LH_CNT_DEV, s));
     const int nbounce = max_vertices - 1;                  /* bounce d traces the ray to path vertex d + 2; the last vertex scatters nothing */
@@ -482,7 +483,7 @@ static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w,
         ensure_buf(&a->p_dir2, S * 24) || ensure_buf(&a->r_prim, S * 4) || ensure_buf(&a->r_t, S * 8) ||
         ensure_buf(&a->r_u, S * 8) || ensure_buf(&a->r_v, S * 8) || ensure_buf(&a->p_path, S * 4) ||
         ensure_buf(&a->p_path2, S * 4) || ensure_buf(&a->p_thr, S * 12) || ensure_buf(&a->p_thr2, S * 12) ||
-        ensure_buf(&a->p_rad, S * 12) || ensure_buf(&a->p_counts, ((size_t)nbounce + 2) * 4 + 64 + lh_pt_cam_bytes())) return -1;
+        ensure_buf(&a->p_rad, (size_t)w * h * 24) || ensure_buf(&a->p_counts, ((size_t)nbounce + 2) * 4 + 64 + lh_pt_cam_bytes())) return -1;
     /* the chain's ray / path-word / throughput records alternate between two sets; bounce 0 reads none (its rays are the camera
      * rays, generated inside the closest-hit kernel and again by the shading pass for the paths that go on) */
     double *org = NULL, *dir = NULL, *org2 = (double *)a->r_org.p, *dir2 = (double *)a->r_dir.p;
@@ -492,6 +493,9 @@ static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w,
     /* counts[d] = rays of bounce d: [0] = S here, [d + 1] accumulated by bounce d's shading pass.  The host never reads a count
      * inside the chain (every launch gets S as its upper bound and the count's address) -- except every 8th bounce of a long
      * chain (a furnace test's 400 vertices), to stop once every path has ended */
+    /* the pixels' radiance sums (three 64-bit fixed-point words each, lh_render.hip pt_accumulate): the resolve leaves them zero, but
+     * the buffer may be new, grown, or left by a pass that failed */
+    HIPCHK(hipMemsetAsync(a->p_rad.p, 0, (size_t)w * h * 24, s));
     if (lh_pt_launch_begin(cam, x0, y0, w, h, band_rows, band_stride, spp, s0, seed, d_cam, counts, nbounce + 2, s) != 0) return fail("pt begin launch failed");
     int rc = 0;
     for (int depth = 0; depth < nbounce && rc == 0; depth++) {
@@ -502,7 +506,7 @@ static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w,
         if (lh_pt_launch_shade(S, &a->dev, (const double *)a->d_nrm9, (const double *)a->d_attr9[0], (const uint32_t *)a->d_prim_mesh,
                                a->d_materials, override_mat, env_rgb, d_env_map, env_w, env_h, (flags & LH_PT_REFERENCE_WEIGHTS) != 0,
                                depth, max_vertices, seed, s0, spp, x0, y0, w, band_rows, band_stride, cam->width, d_cam, counts, org, dir, (const uint32_t *)a->r_prim.p,
-                               (const double *)a->r_t.p, (const double *)a->r_u.p, (const double *)a->r_v.p, path, thr, (float *)a->p_rad.p,
+                               (const double *)a->r_t.p, (const double *)a->r_u.p, (const double *)a->r_v.p, path, thr, (unsigned long long *)a->p_rad.p,
                                org2, dir2, path2, thr2, a->ncus, s) != 0)
             return fail("pt shade launch failed: %s", hipGetErrorString(hipGetLastError()));
         if (depth == 0) {
@@ -520,7 +524,7 @@ static int pt_tile(lh_accel_t *a, const lh_camera_t *cam, int x0, int y0, int w,
         }
     }
     if (rc != 0) return -1;
-    if (lh_pt_launch_resolve(w, h, band_rows, spp, 1.0f / (float)spp_total, (const float *)a->p_rad.p, (float *)d_rgb, s) != 0)
+    if (lh_pt_launch_resolve(w, h, band_rows, 1.0f / (float)spp_total, (unsigned long long *)a->p_rad.p, (float *)d_rgb, s) != 0)
         return fail("pt resolve launch failed");
     std::vector<uint32_t> hcounts((size_t)nbounce + 1);
     HIPCHK(hipMemcpyAsync(hcounts.data(), counts, hcounts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
