@@ -29,13 +29,13 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
     cam = la.Camera.make(size, size, c[16], c[:16], int(c[19]))
     times = []; st = None; img = None; first = None; repeat = True
     pt_tile = size if world == 1 else max(128, size // 4)
-    # paths per pass (decided once: the first frame's buffers stay allocated): as many as 70 % of the free HBM holds (176 B of
-    # path state each; a 2048^2 x 256 spp frame is 2^30 paths = 189 GB of the 288): every pass costs one kernel ramp + drain per
+    # paths per pass (decided once: the first frame's buffers stay allocated): as many as 70 % of the free HBM holds (164 B of
+    # path state each; a 2048^2 x 256 spp frame is 2^30 paths = 176 GB of the 288): every pass costs one kernel ramp + drain per
     # bounce, so fewer, larger wavefronts are faster (tools/experiments/pt_frames.py: 166.3 / 154.7 / 148.6 ms per frame as 4 / 2 / 1 passes;
     # the image does not change by a bit)
     torch.cuda.empty_cache()
     free_b = torch.cuda.mem_get_info(dev)[0]
-    per_pass = max(64 << 20, min(1 << 30, int(free_b * 7 // 10 // 176)))
+    per_pass = max(64 << 20, min(1 << 30, int(free_b * 7 // 10 // 164)))
     # sharded: a rank's interleaved 4-line bands (1 / world of the frame) are one pass per sample chunk (render_pt_frame_sharded)
     area = pt_tile * pt_tile if world == 1 else max(1, size * size // world)
     chunk = max(1, min(spp, per_pass // area))
@@ -81,8 +81,9 @@ def pt_frame_leg(la, acc_device, rank, world, size, spp, dev):
                 "nodes_per_ray": round(c["nodes"] / nr, 2), "tris_per_ray": round(c["tris"] / nr, 2), "exact_per_ray": round(c["exact"] / nr, 4),
                 "rays_counted": c["rays"],
                 "note": "1 986 triangles: the tree is L2-resident.  Per pass: closest hit with the camera rays generated in the kernel, then per "
-                        "bounce one shading pass (decide + compact + scatter, ray counts stay on the device) and one closest-hit launch: 15 "
-                        "launches, no host round trip; kernel time = frame time, closest-hit kernels 67 % of it (profiles/r03_pt_kernel_stats.csv)"}
+                        "bounce a decision kernel (streaming: miss / roulette, radiance into per-pixel 64-bit fixed-point sums, survivors compacted), "
+                        "a scatter kernel over the survivors (hit epilogue, lobe, next ray) and one closest-hit launch: 22 launches, no host round "
+                        "trip; kernel time = frame time, closest-hit kernels 71 % of it (profiles/r05_pt_timeline.txt)"}
     rays_all = shard.all_reduce_sum(float(st["rays"])) if world > 1 else float(st["rays"])
     t_all = shard.all_reduce_max(min(times)) if world > 1 else min(times)
     acc.close()

@@ -1,6 +1,6 @@
 /*
  * lh_pt.h -- the path tracer's per-vertex arithmetic, for the two places that run it on the device: the shading pass of
- * lh_render.hip (k_pt_shade: one launch per bounce; decides, compacts and scatters the live paths) and the closest-hit walk
+ * lh_render.hip (k_pt_decide + k_pt_scatter per bounce: decides and compacts the live paths, scatters the survivors) and the closest-hit walk
  * of lh_kernels.hip, whose ray source 2 generates the camera rays of a pass in its refill (pt_camera_ray) instead of reading
  * them from HBM.  Counter-based keys (pixel, sample, bounce): a frame does not depend on tiling, sharding or slot order.
  *
@@ -14,6 +14,26 @@
 
 #define LH_NC _Pragma("clang fp contract(off)")
 #define LH_PT_INTERIOR 0x80000000u
+
+/* path id -> (pixel, sample) -> (line, band): three divisions by the pass's spp, width and band height per key, ~25 instructions each
+ * as run-time 32-bit divisions.  n / d for n < 2^30 as a multiplication: with l = ceil(log2 d), k = max(32, 30 + l) and
+ * m = floor(2^k / d) + 1 (below 2^32 for d >= 2), m d = 2^k + e with 0 < e <= d <= 2^l, so n m / 2^k = n / d + n e / (d 2^k) and
+ * n e < 2^(30 + l) <= 2^k keeps the excess below 1 / d: the quotient is floor(n / d) exactly.  (Packed on the host, lh_div_make.) */
+struct LhDiv { uint32_t m, sh, one, pad; };
+struct PtDivs { LhDiv spp, w, rows; };
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t lh_div(uint32_t n, const LhDiv d) { return d.one ? n : (__umulhi(n, d.m) >> d.sh); }
+#endif
+static inline LhDiv lh_div_make(uint32_t d)
+{
+    LhDiv r; r.pad = 0; r.one = d <= 1u; r.m = 0; r.sh = 0;
+    if (d > 1u) {
+        uint32_t l = 0; while ((1ull << l) < (unsigned long long)d) l++;
+        const uint32_t k = 30u + l > 32u ? 30u + l : 32u;
+        r.m = (uint32_t)(((unsigned long long)1 << k) / d + 1ull); r.sh = k - 32u;
+    }
+    return r;
+}
 
 struct DevCamera {
     double c2w[16];
@@ -91,22 +111,22 @@ __device__ __forceinline__ void env_fetch(const DevEnv &e, double dx, double dy,
 /* path id -> frame pixel.  The pass covers a w-wide region whose lines are those of full bands: line `row` of the pass is
  * line y0 + (row / band_rows) * band_stride + row % band_rows of the frame (an ordinary tile: band_rows = its height; a rank's
  * interleaved bands of a sharded frame: band_stride = world x band_rows) */
-__device__ __forceinline__ void pt_pixel(uint32_t pix, int x0, int y0, int w, int band_rows, int band_stride, int &px, int &py)
+__device__ __forceinline__ void pt_pixel(uint32_t pix, int x0, int y0, int w, int band_rows, int band_stride, const PtDivs dv, int &px, int &py)
 {
-    const uint32_t row = pix / (uint32_t)w, band = row / (uint32_t)band_rows;
+    const uint32_t row = lh_div(pix, dv.w), band = lh_div(row, dv.rows);
     px = x0 + (int)(pix - row * (uint32_t)w);
     py = y0 + (int)band * band_stride + (int)(row - band * (uint32_t)band_rows);
 }
 
 __device__ __forceinline__ void pt_primary_ray(const DevCamera &cam, int x0, int y0, int w, int band_rows, int band_stride, int spp, int s0,
-                                               unsigned long long seed, size_t id, double pos3[3], double d[3])
+                                               const PtDivs dv, unsigned long long seed, size_t id, double pos3[3], double d[3])
 {
     LH_NC
-    /* 32-bit divisions: a pass holds fewer than 2^30 paths (64-bit ones cost ~4x the instructions, four per key) */
-    const uint32_t id32 = (uint32_t)id, pix = id32 / (uint32_t)spp;
+    /* a pass holds at most 2^30 paths: 32-bit ids, divisions by multiplication (LhDiv) */
+    const uint32_t id32 = (uint32_t)id, pix = lh_div(id32, dv.spp);
     const int s = (int)(id32 - pix * (uint32_t)spp);
     int px, py;
-    pt_pixel(pix, x0, y0, w, band_rows, band_stride, px, py);
+    pt_pixel(pix, x0, y0, w, band_rows, band_stride, dv, px, py);
     const uint64_t key = (seed * 0x9E3779B97F4A7C15ULL) ^ ((((uint64_t)py * (uint64_t)cam.width + (uint64_t)px) << 20) + (uint64_t)(s0 + s)) * 64ull;
     const double x = (double)px + rnd01(key), y = (double)py + rnd01(key + 1);
     const double W = cam.width, H = cam.height;
@@ -125,19 +145,19 @@ __device__ __forceinline__ void pt_primary_ray(const DevCamera &cam, int x0, int
 
 /* the camera rays of one pass as a ray SOURCE (lh_kernels.hip, ray source 2; the first bounce's shading pass): path id ->
  * ray, nothing materialised.  Lives in device memory (written by k_pt_begin), read with scalar loads. */
-struct PtCamSrc { DevCamera cam; unsigned long long seed; int x0, y0, w, spp, s0, band_rows, band_stride, pad; };
+struct PtCamSrc { DevCamera cam; unsigned long long seed; int x0, y0, w, spp, s0, band_rows, band_stride, pad; PtDivs dv; };
 
 __device__ __forceinline__ void pt_camera_ray(const PtCamSrc *__restrict__ c, uint32_t id, double pos3[3], double d[3])
 {
-    pt_primary_ray(c->cam, c->x0, c->y0, c->w, c->band_rows, c->band_stride, c->spp, c->s0, c->seed, (size_t)id, pos3, d);
+    pt_primary_ray(c->cam, c->x0, c->y0, c->w, c->band_rows, c->band_stride, c->spp, c->s0, c->dv, c->seed, (size_t)id, pos3, d);
 }
 
 __device__ __forceinline__ uint64_t pt_key(unsigned long long seed, uint32_t path, int spp, int s0, int x0, int y0, int w, int band_rows, int band_stride,
-                                           int full_width, int depth)
+                                           const PtDivs dv, int full_width, int depth)
 {
-    const uint32_t pix = path / (uint32_t)spp;
+    const uint32_t pix = lh_div(path, dv.spp);
     int px, py;
-    pt_pixel(pix, x0, y0, w, band_rows, band_stride, px, py);
+    pt_pixel(pix, x0, y0, w, band_rows, band_stride, dv, px, py);
     const uint64_t gx = (uint64_t)px, gy = (uint64_t)py;
     return ((seed * 0x9E3779B97F4A7C15ULL) ^ (((gy * (uint64_t)full_width + gx) << 20) + (uint64_t)(s0 + (int)(path - pix * (uint32_t)spp))) * 64ull)
            + 4ull * (uint64_t)(depth + 1);

@@ -411,6 +411,7 @@ struct PtPass {
     const PtCamSrc *cam;                 /* bounce 0: the pass's rays are the camera rays, regenerated from the path id */
     unsigned long long seed;
     int use_override, ref_weights, depth, max_depth, s0, spp, x0, y0, w, band_rows, band_stride, full_width;
+    PtDivs dv;                           /* divisions by spp, w, band_rows as multiplications (lh_pt.h) */
 };
 
 /* PROBE: the environment is a light probe (a miss evaluates it in the path's direction: fp64 acos / sqrt / divisions, kept out of the
@@ -438,9 +439,9 @@ __device__ __forceinline__ unsigned long long pt_fix(float r)
 
 __device__ __forceinline__ void pt_accumulate(unsigned long long *__restrict__ accum, uint32_t pix, bool ends, float r0, float r1, float r2, int lane)
 {
-    const bool mine = ends && r0 == r0 && r1 == r1 && r2 == r2 && (r0 != 0.0f || r1 != 0.0f || r2 != 0.0f);
-    if (__ballot(mine) == 0ull) return;                                /* wave-uniform: nothing ends here with light */
-    unsigned long long a = mine ? pt_fix(r0) : 0ull, b = mine ? pt_fix(r1) : 0ull, c = mine ? pt_fix(r2) : 0ull;
+    const bool v0 = ends && r0 == r0 && r0 != 0.0f, v1 = ends && r1 == r1 && r1 != 0.0f, v2 = ends && r2 == r2 && r2 != 0.0f;      /* a NaN channel adds nothing */
+    if (__ballot(v0 | v1 | v2) == 0ull) return;                        /* wave-uniform: nothing ends here with light */
+    unsigned long long a = v0 ? pt_fix(r0) : 0ull, b = v1 ? pt_fix(r1) : 0ull, c = v2 ? pt_fix(r2) : 0ull;
     /* run number: the pixel may come back later in the wave (two workgroups' survivors of one pixel with a third's between) */
     const uint32_t before = (uint32_t)__shfl_up((int)pix, 1);
     const unsigned long long heads = __ballot(lane == 0 || before != pix);
@@ -513,10 +514,10 @@ __global__ __launch_bounds__(256) void k_pt_decide(const PtPass ps, const uint32
                         else { r0 = g0[k] * e[0]; r1 = g1[k] * e[1]; r2 = g2[k] * e[2]; }
                     } else {
                         const double ksum = ps.use_override ? ps.override_mat.asum9 : materials[prim_mesh[p]].asum9;
-                        go = pt_survives(ksum, pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.band_rows, ps.band_stride, ps.full_width, ps.depth), ps.depth, ps.max_depth);
+                        go = pt_survives(ksum, pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.band_rows, ps.band_stride, ps.dv, ps.full_width, ps.depth), ps.depth, ps.max_depth);
                     }
                 }
-                pt_accumulate(accum, path / (uint32_t)ps.spp, i < n && !go, r0, r1, r2, lane);          /* a path the roulette ended adds nothing */
+                pt_accumulate(accum, lh_div(path, ps.dv.spp), i < n && !go, r0, r1, r2, lane);          /* a path the roulette ended adds nothing */
                 const unsigned long long m = __ballot(go);
                 if (lane == 0) sbal[(r * LH_PT_ITEMS + k) * 4 + wv] = m;
             }
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(256) void k_pt_decide(const PtPass ps, const uint32
 }
 
 template <bool FIRST>
-__global__ __launch_bounds__(256) void k_pt_scatter(const PtPass ps, const lh_dev_scene_t sc, const double *__restrict__ nrm9,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_pt_scatter(const PtPass ps, const lh_dev_scene_t sc, const double *__restrict__ nrm9,
                                                     const double *__restrict__ col9, const uint32_t *__restrict__ prim_mesh,
                                                     const DevMaterial *__restrict__ materials, const uint32_t *__restrict__ counts,
                                                     const double *__restrict__ org, const double *__restrict__ dir,
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(256) void k_pt_scatter(const PtPass ps, const lh_de
             Or[0] = org[3 * (size_t)i]; Or[1] = org[3 * (size_t)i + 1]; Or[2] = org[3 * (size_t)i + 2];
             D[0] = dir[3 * (size_t)i]; D[1] = dir[3 * (size_t)i + 1]; D[2] = dir[3 * (size_t)i + 2];
         }
-        const uint64_t key = pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.band_rows, ps.band_stride, ps.full_width, ps.depth);
+        const uint64_t key = pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.band_rows, ps.band_stride, ps.dv, ps.full_width, ps.depth);
         /* field by field: a whole-struct copy from one of two places keeps the record in scratch (96 bytes a lane, and the lobe's
          * reflectance then read from it by a run-time offset) */
         DevMaterial M;
@@ -716,6 +717,7 @@ extern "C" int lh_pt_launch_begin(const lh_camera_t *cam, int x0, int y0, int w,
     for (int i = 0; i < 16; i++) c.cam.c2w[i] = cam->cam2world[i];
     c.cam.flength = cam->flength; c.cam.width = cam->width; c.cam.height = cam->height; c.cam.rh = cam->rh; c.cam.ortho = cam->ortho;
     c.seed = seed; c.x0 = x0; c.y0 = y0; c.w = w; c.spp = spp; c.s0 = s0; c.band_rows = band_rows; c.band_stride = band_stride;
+    c.dv.spp = lh_div_make((uint32_t)spp); c.dv.w = lh_div_make((uint32_t)w); c.dv.rows = lh_div_make((uint32_t)band_rows);
     const size_t total = (size_t)w * h * spp;
     hipLaunchKernelGGL(k_pt_begin, dim3(1), dim3(256), 0, (hipStream_t)stream, d_counts, (uint32_t)total, ncounts, c, (PtCamSrc *)d_cam);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -743,6 +745,7 @@ extern "C" int lh_pt_launch_shade(size_t n_max, const lh_dev_scene_t *sc, const 
     ps.cam = (const PtCamSrc *)d_cam;
     ps.seed = seed; ps.use_override = override_mat != NULL; ps.ref_weights = ref_weights; ps.depth = depth; ps.max_depth = max_depth;
     ps.s0 = s0; ps.spp = spp; ps.x0 = x0; ps.y0 = y0; ps.w = w; ps.band_rows = band_rows; ps.band_stride = band_stride; ps.full_width = full_width;
+    ps.dv.spp = lh_div_make((uint32_t)spp); ps.dv.w = lh_div_make((uint32_t)w); ps.dv.rows = lh_div_make((uint32_t)band_rows);
     const size_t spans = (n_max + 256 * LH_PT_ITEMS * LH_PT_ROUNDS - 1) / (256 * LH_PT_ITEMS * LH_PT_ROUNDS);
     const size_t cus = (size_t)(ncus > 0 ? ncus : 256);
     const unsigned nb = (unsigned)(spans < cus * 16 ? spans : cus * 16);                    /* decide: 2 x the eight resident workgroups of a CU */

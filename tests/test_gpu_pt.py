@@ -257,3 +257,30 @@ def test_empty_and_one_triangle_scenes():
     img, st = acc.render_pt_tile(cam, 0, 0, 64, 48, 0, 4, 4, kd=0.8, env=(1, 1, 1), seed=1, max_vertices=2)
     assert st["rays"] == st["paths"] and 0.9 < float(img.mean()) < 1.0 and float(img.min()) == 0.0
     acc.close()
+
+
+def test_pixel_sums_are_fixed_point(ps):
+    """a path's radiance goes into its pixel's three 64-bit fixed-point sums (32 fraction bits) where the path ends: integer sums do
+    not depend on the order of their terms -- a pixel does not depend on slot order, tiling or how the samples are cut into
+    passes beyond the one float addition per pass -- a sample is clamped to +-2^19, a NaN is dropped, and one pass holds at most
+    4096 samples of a pixel"""
+    import torch
+    cam = la.Camera.make(32, 16, 2.0, np.eye(4).ravel(), 1)
+    acc = la.HipAccel(0); acc.commit()                       # no geometry: every sample is the environment, exactly
+    env = (0.3, 1.0e-7, 3.0)                                 # not dyadic: 0.3f = 10066330 x 2^-25 is a 32-fraction-bit number all the same
+    img, _ = acc.render_pt_tile(cam, 0, 0, 32, 16, 0, 64, 64, kd=0.8, env=env, seed=1)
+    # 64 equal samples summed exactly, converted to fp32 once, times 1 / 64 (exact): the environment itself -- the 1e-7 channel to
+    # the 2^-32 of its quantum (floor)
+    got = img.cpu().numpy()
+    assert (got[..., 0] == np.float32(0.3)).all() and (got[..., 2] == np.float32(3.0)).all()
+    q = np.floor(np.float64(np.float32(1.0e-7)) * 2.0 ** 32) / 2.0 ** 32
+    assert np.allclose(got[..., 1], q, rtol=1e-6, atol=0)
+    # the clamp and the NaN rule
+    big, _ = acc.render_pt_tile(cam, 0, 0, 32, 16, 0, 4, 4, kd=0.8, env=(1.0e9, -1.0e9, float("nan")), seed=1)
+    big = big.cpu().numpy()
+    assert (big[..., 0] == 524288.0).all() and (big[..., 1] == -524288.0).all() and (big[..., 2] == 0.0).all()
+    with pytest.raises(Exception, match="4096 samples"):
+        acc.render_pt_tile(cam, 0, 0, 4, 4, 0, 4097, 4097, kd=0.8, env=(1, 1, 1), seed=1)
+    out, _ = acc.render_pt_tile(cam, 0, 0, 4, 4, 0, 4096, 4096, kd=0.8, env=(0.5, 0.25, 1.0), seed=1)      # the largest pass: no overflow
+    assert torch.equal(out, torch.tensor([0.5, 0.25, 1.0], device="cuda").expand(4, 4, 3))
+    acc.close()

@@ -1,12 +1,12 @@
 """per kernel (ray-query kernels only): the counters of its largest dispatch in each pass of tools/pmc_cmd.sh"""
-import csv, glob, sys, collections
+import csv, glob, re, sys, collections
 d = sys.argv[1]
 best = collections.OrderedDict()          # kernel -> counter -> value of the dispatch with the largest SQ_WAVES-independent proxy
 for f in sorted(glob.glob(d + "/p*/**/*counter_collection.csv", recursive=True)):
     per = collections.defaultdict(dict)   # (kernel, dispatch) -> counter -> value
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if not any(s in k for s in ("k_trace", "k_resolve", "k_quad", "k_pt_shade", "k_pt_resolve", "k_ao_setup")):
+        if not any(s in k for s in ("k_trace", "k_resolve", "k_quad", "k_pt_decide", "k_pt_scatter", "k_pt_resolve", "k_ao_setup")):
             continue
         per[(k, r["Dispatch_Id"])][r["Counter_Name"]] = float(r["Counter_Value"])
     # largest dispatch per kernel = the one with the largest first counter
@@ -17,7 +17,8 @@ for f in sorted(glob.glob(d + "/p*/**/*counter_collection.csv", recursive=True))
         top = max(lst, key=lambda c: max(c.values()))
         best.setdefault(k, {}).update(top)
 for k, c in best.items():
-    print("==", k.split("(")[0][-90:])
+    nm = re.search(r"(k_\w+(?:<[^>]*>)?)", k)
+    print("==", nm.group(1) if nm else k[:90])
     for name, v in c.items():
         print("   %-28s %.6g" % (name, v))
     g = c.get
