@@ -164,6 +164,10 @@ __device__ __forceinline__ bool tri_step(Lane &L, const lh_dev_scene_t &sc, floa
                                      best, c_exact);
 }
 
+/* (Round 5 also tried ONE candidate per regroup in the persistent walk -- a lane with more stays idle, unretired, and takes its next
+ * one at the next regroup beside the other lanes' first, so the second to fourth test never run for a lane or two: the same
+ * records, S-soup-1M and the config-5 AO frame unchanged, the path-traced config-4 frame 111.2 -> 113.1 ms: the idle lanes
+ * cost more than the tests saved.  tools/experiments/ab_frames.py.) */
 /* the end of a ray's walk: its unresolved candidates through the fp64 test (bvh.c:730-791 order).  skip: a primitive that
  * is known not to be hit (the triangle a flat-shaded AO ray starts on, lh_ao.h), or LH_MISS_PRIM */
 template <bool ANYHIT, bool COUNT>

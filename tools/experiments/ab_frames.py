@@ -1,5 +1,5 @@
 """A/B of differently built liblucille_hip.so files (gpurun_variants/*.so) on the same box, one subprocess per library, interleaved
-rounds: S-soup-1M closest-hit dump (Mrays/s), the path-traced config-4 frame (ms).   python tools/experiments/ab_frames.py [rounds]"""
+rounds: S-soup-1M closest-hit dump (Mrays/s), the path-traced config-4 frame and the config-5 AO frame (ms).   python tools/experiments/ab_frames.py [rounds]"""
 import glob, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
@@ -26,8 +26,21 @@ for it in range(5):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     img, st = render.render_pt_frame_sharded(acc, cam, 256, 0, 1, tile=2048, spp_chunk=256, kd=0.8, env=(1.0, 1.0, 1.0), max_vertices=8, seed=7)
     torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
-print("soup %%.1f Mrays/s   pt frame %%.2f ms   image mean %%.9f" %% (soup, min(ts[1:]), float(img.mean())))
-''' % (ROOT, ROOT)
+pt = min(ts[1:]); ptmean = float(img.mean()); acc.close(); del img
+from lucille_amd import scenes
+g = np.load(os.path.join(%r, "tests", "golden", "ao_c1.npz"))
+acc = la.HipAccel(0)
+for k in range(int(g["ngeoms"])):
+    P_, I_ = scenes.tessellate(g["pos%%d" %% k], g["idx%%d" %% k], 8); acc.add_mesh(P_, I_); del P_, I_
+acc.commit()
+c = g["camera"]; cam = la.Camera.make(4096, 4096, c[16], c[:16], int(c[19]))
+ts = []
+for it in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    img, st = render.render_ao_frame(acc, cam, 1, 64, tile=4096)
+    torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+print("soup %%.1f Mrays/s   pt frame %%.2f ms (mean %%.9f)   ao frame %%.2f ms (mean %%.9f)" %% (soup, pt, ptmean, min(ts[1:]), float(img.mean())))
+''' % (ROOT, ROOT, ROOT)
 for r in range(rounds):
     for l in libs:
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LH_LIBRARY=l), capture_output=True, text=True)
