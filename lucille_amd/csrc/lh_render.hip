@@ -422,13 +422,13 @@ struct PtPass {
 #define LH_PT_ROUNDS 4
 
 /* A path's radiance goes into its pixel's accumulator where the path ends -- three 64-bit FIXED-POINT sums per pixel of the pass
- * (32 fraction bits; a sample clamped to +-2^19: the 2^12 samples of a pixel that lh_tile.hip allows in one pass cannot overflow) -- instead of into a 12-byte record per path that a resolve pass sums afterwards (rounds 2-4): those records
+ * (32 fraction bits; a sample clamped to +-2^18: the 2^12 samples of a pixel that lh_tile.hip allows in one pass stay below 2^62) -- instead of into a 12-byte record per path that a resolve pass sums afterwards (rounds 2-4): those records
  * were written where the paths ended, a few of every 128-byte line per bounce (6.7 + 5.6 + ... GB of partial-line writes and
  * 12.9 GB read back per 2^30-path pass, 12.9 GB of HBM held).  Integer sums do not depend on the order of their terms: a pixel
  * is the same whatever the slot order, tiling or sharding, bit for bit, as before.  Lanes of a wave hold consecutive slots,
  * i.e. runs of paths of the same pixel: the runs are summed across the wave first (a segmented scan over run numbers), one
  * atomic per run and channel. */
-#define LH_PT_FIX_CLAMP 524288.0f
+#define LH_PT_FIX_CLAMP 262144.0f
 __device__ __forceinline__ unsigned long long pt_fix(float r)
 {
     r = fminf(fmaxf(r, -LH_PT_FIX_CLAMP), LH_PT_FIX_CLAMP);          /* (a NaN never gets here: pt_accumulate drops it) */

@@ -262,7 +262,7 @@ def test_empty_and_one_triangle_scenes():
 def test_pixel_sums_are_fixed_point(ps):
     """a path's radiance goes into its pixel's three 64-bit fixed-point sums (32 fraction bits) where the path ends: integer sums do
     not depend on the order of their terms -- a pixel does not depend on slot order, tiling or how the samples are cut into
-    passes beyond the one float addition per pass -- a sample is clamped to +-2^19, a NaN is dropped, and one pass holds at most
+    passes beyond the one float addition per pass -- a sample is clamped to +-2^18, a NaN is dropped, and one pass holds at most
     4096 samples of a pixel"""
     import torch
     cam = la.Camera.make(32, 16, 2.0, np.eye(4).ravel(), 1)
@@ -278,9 +278,9 @@ def test_pixel_sums_are_fixed_point(ps):
     # the clamp and the NaN rule
     big, _ = acc.render_pt_tile(cam, 0, 0, 32, 16, 0, 4, 4, kd=0.8, env=(1.0e9, -1.0e9, float("nan")), seed=1)
     big = big.cpu().numpy()
-    assert (big[..., 0] == 524288.0).all() and (big[..., 1] == -524288.0).all() and (big[..., 2] == 0.0).all()
+    assert (big[..., 0] == 262144.0).all() and (big[..., 1] == -262144.0).all() and (big[..., 2] == 0.0).all()
     with pytest.raises(Exception, match="4096 samples"):
         acc.render_pt_tile(cam, 0, 0, 4, 4, 0, 4097, 4097, kd=0.8, env=(1, 1, 1), seed=1)
-    out, _ = acc.render_pt_tile(cam, 0, 0, 4, 4, 0, 4096, 4096, kd=0.8, env=(0.5, 0.25, 1.0), seed=1)      # the largest pass: no overflow
-    assert torch.equal(out, torch.tensor([0.5, 0.25, 1.0], device="cuda").expand(4, 4, 3))
+    out, _ = acc.render_pt_tile(cam, 0, 0, 4, 4, 0, 4096, 4096, kd=0.8, env=(0.5, 1.0e9, -1.0e9), seed=1)      # the largest pass at the clamp: no overflow
+    assert torch.equal(out, torch.tensor([0.5, 262144.0, -262144.0], device="cuda").expand(4, 4, 3))
     acc.close()

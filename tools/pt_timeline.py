@@ -1,5 +1,5 @@
 """round 4: the kernel timeline of one path-traced config-4 frame (2048^2 x 256 spp as one pass) from a rocprofv3 --kernel-trace csv:
-rocprofv3 --kernel-trace --output-format csv -d DIR -- python tools/pt_timeline.py run ; python tools/pt_timeline.py show DIR/.../kernel_trace.csv"""
+rocprofv3 --kernel-trace --output-format csv -d DIR -- python tools/pt_timeline.py run [world] ; python tools/pt_timeline.py show DIR/.../kernel_trace.csv"""
 import os, sys, csv, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,7 +17,13 @@ if sys.argv[1] == "run":
     import time
     for it in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        img, st = render.render_pt_frame_sharded(acc, cam, 256, 0, 1, tile=2048, spp_chunk=256, kd=0.8, env=(1.0, 1.0, 1.0), max_vertices=8, seed=7)
+        world = int(sys.argv[2]) if len(sys.argv) > 2 else 1        # > 1: rank 0's share of the frame (its interleaved 4-line bands as one pass)
+        if world == 1:
+            img, st = render.render_pt_frame_sharded(acc, cam, 256, 0, 1, tile=2048, spp_chunk=256, kd=0.8, env=(1.0, 1.0, 1.0), max_vertices=8, seed=7)
+        else:
+            acc.set_environment((1.0, 1.0, 1.0), None)
+            out = torch.zeros((2048 // 4 // world, 4, 2048, 3), dtype=torch.float32, device="cuda")
+            acc.render_pt_bands(cam, 0, 4, 4 * world, 2048 // 4 // world, 0, 256, 256, max_vertices=8, override=la.Material.make(kd=(0.8,) * 3), seed=7, out=out)
         torch.cuda.synchronize(); print("frame ms %.2f" % ((time.perf_counter() - t0) * 1e3), flush=True)
 else:
     rows = sorted(csv.DictReader(open(sys.argv[2])), key=lambda r: int(r["Start_Timestamp"]))
