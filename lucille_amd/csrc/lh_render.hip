@@ -461,6 +461,26 @@ __device__ __forceinline__ void pt_accumulate(unsigned long long *__restrict__ a
     }
 }
 
+/* the same when every path that ends here with light carries the SAME radiance (camera rays that leave the scene under a constant
+ * environment -- half of a frame's paths): a run's sum is its count x that value, counted from the wave's ballots, no scan */
+__device__ __forceinline__ void pt_accumulate_uniform(unsigned long long *__restrict__ accum, uint32_t pix, bool ends, const float e[3], int lane)
+{
+    const unsigned long long mm = __ballot(ends);
+    if (mm == 0ull) return;
+    const uint32_t before = (uint32_t)__shfl_up((int)pix, 1);
+    const unsigned long long heads = __ballot(lane == 0 || before != pix);
+    const bool last = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    if (last) {
+        const unsigned long long upto = (2ull << lane) - 1ull;
+        const int start = 63 - __clzll((long long)(heads & upto));                    /* bit `lane`'s run begins at its nearest head below */
+        const unsigned long long cnt = (unsigned long long)__popcll(mm & upto & ~((1ull << start) - 1ull));
+        if (cnt) {
+            unsigned long long *o = accum + 3 * (size_t)pix;
+            for (int c = 0; c < 3; c++) if (e[c] == e[c] && e[c] != 0.0f) atomicAdd(o + c, cnt * pt_fix(e[c]));
+        }
+    }
+}
+
 template <bool FIRST, bool PROBE>
 __global__ __launch_bounds__(256) void k_pt_decide(const PtPass ps, const uint32_t *__restrict__ prim_mesh, const DevMaterial *__restrict__ materials,
                                                    uint32_t *__restrict__ counts, const double *__restrict__ dir, const uint32_t *__restrict__ prim,
@@ -517,7 +537,9 @@ __global__ __launch_bounds__(256) void k_pt_decide(const PtPass ps, const uint32
                         go = pt_survives(ksum, pt_key(ps.seed, path, ps.spp, ps.s0, ps.x0, ps.y0, ps.w, ps.band_rows, ps.band_stride, ps.dv, ps.full_width, ps.depth), ps.depth, ps.max_depth);
                     }
                 }
-                pt_accumulate(accum, lh_div(path, ps.dv.spp), i < n && !go, r0, r1, r2, lane);          /* a path the roulette ended adds nothing */
+                /* a path the roulette ended adds nothing */
+                if (FIRST && !PROBE) pt_accumulate_uniform(accum, lh_div(path, ps.dv.spp), i < n && pr[k] == LH_MISS_PRIM, ps.env.rgb, lane);
+                else pt_accumulate(accum, lh_div(path, ps.dv.spp), i < n && !go, r0, r1, r2, lane);
                 const unsigned long long m = __ballot(go);
                 if (lane == 0) sbal[(r * LH_PT_ITEMS + k) * 4 + wv] = m;
             }
