@@ -247,7 +247,10 @@ int  lh_render_ao_tile_host(lh_accel_t *accel, const lh_camera_t *cam, int x0, i
  * as closest-hit batches, every bounce through the same kernel as ri_raytrace).  Adds
  * spp_count samples (numbered spp_begin...) of spp_total to d_rgb (float[h][w][3], image
  * orientation; the caller zeroes it before the first pass).  kd: diffuse reflectance in (0,1];
- * env_rgb: constant environment radiance.  stats: rays traced / paths. */
+ * env_rgb: constant environment radiance.  stats: rays traced / paths.
+ * One pass holds at most 2^30 paths (w x h x spp_count) and at most 4096 samples of a pixel: a path's radiance goes into
+ * its pixel's 64-bit fixed-point sums (32 fraction bits, a sample clamped to +-2^18, a NaN channel dropped), so a pixel
+ * does not depend on the order its paths end in -- tiling, sharding and slot order leave the image bit for bit the same. */
 typedef struct lh_pt_stats { uint64_t paths, rays, max_depth_reached; } lh_pt_stats_t;
 
 int  lh_render_pt_tile(lh_accel_t *accel, const lh_camera_t *cam, int x0, int y0, int w, int h,

@@ -323,6 +323,7 @@ extern "C" int lh_multi_render_pt_frame_host(lh_multi_t *m, const lh_camera_t *c
     if (!cam || !rgb) return mfail("lh_multi_render_pt_frame_host: NULL argument");
     if (spp < 1) return mfail("lh_multi_render_pt_frame_host: bad sample count");
     if (spp_chunk < 1 || spp_chunk > spp) spp_chunk = spp;
+    if (spp_chunk > 4096) spp_chunk = 4096;          /* samples of a pixel in one pass (lh_render_pt_tile) */
     std::vector<lh_pt_stats_t> part((size_t)m->n, lh_pt_stats_t{0, 0, 0});
     const int rc = frame_loop(m, cam->width, cam->height, tile, rgb, device_seconds,
         [&](int k, const Tile &T, float *d_slab, hipStream_t s) {
