@@ -75,7 +75,9 @@ __device__ __forceinline__ float o2f(uint32_t o) { return __uint_as_float((o & 0
 
 /* bad[0]: a coordinate that is NaN / infinite / beyond 1e30; bad[1]: primitives the reference can never report (lh_bvh.c
  * tri_dead_class: two equal vertices -- they stay out of the traversal tree, marked by a NaN in plo[3 p]); bad[2]: some of them are
- * of class 2 (v1 == v2: rejected for rays whose direction components stay below LH_DEG_DCAP).  drop = 0: nothing is marked */
+ * of class 2 (v1 == v2: rejected for rays whose direction components stay below LH_DEG_DCAP); bad[3]: the float bits of the largest
+ * s2 of a zero-area triangle that STAYS in the tree (lh_bvh.c tri_zero_area_s2: rays beyond 1 / s2 go through the reference's own
+ * walk).  drop = 0: nothing is marked */
 #define LH_DEG_DCAP  1024.0
 #define LH_DEG_S2CAP (1.0e-14 / (1.0e-15 * LH_DEG_DCAP))
 __global__ __launch_bounds__(256) void k_prim_boxes(uint32_t n, const double *__restrict__ tri64, float *__restrict__ plo, float *__restrict__ phi,
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256) void k_prim_boxes(uint32_t n, const double *__
     __shared__ uint32_t smin[4][3], smax[4][3];
     uint32_t omin[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, omax[3] = {0u, 0u, 0u};
     uint32_t ndead = 0, noise = 0;
+    float s2keep = 0.0f;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
         const double *t = tri64 + 9 * (size_t)p;
         for (int k = 0; k < 3; k++) {
@@ -94,8 +97,8 @@ __global__ __launch_bounds__(256) void k_prim_boxes(uint32_t n, const double *__
             const uint32_t ol = f2o(lo), oh = f2o(hi);
             omin[k] = ol < omin[k] ? ol : omin[k]; omax[k] = oh > omax[k] ? oh : omax[k];
         }
+        int cls = 0;
         if (drop) {
-            int cls = 0;
             if ((t[0] == t[3] && t[1] == t[4] && t[2] == t[5]) || (t[0] == t[6] && t[1] == t[7] && t[2] == t[8])) cls = 1;
             else if (t[3] == t[6] && t[4] == t[7] && t[5] == t[8]) {
                 const double sN = fabs(t[3] - t[0]) + fabs(t[4] - t[1]) + fabs(t[5] - t[2]);
@@ -103,7 +106,15 @@ __global__ __launch_bounds__(256) void k_prim_boxes(uint32_t n, const double *__
             }
             if (cls) { plo[3 * (size_t)p] = __uint_as_float(0x7fc00000u); ndead++; noise |= (uint32_t)(cls == 2); }
         }
+        if (!cls) {                                  /* tri_zero_area_s2 (lh_bvh.c), operation for operation */
+            const double e1x = t[3] - t[0], e1y = t[4] - t[1], e1z = t[5] - t[2], e2x = t[6] - t[0], e2y = t[7] - t[1], e2z = t[8] - t[2];
+            const double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+            const double s2 = (fabs(e1x) + fabs(e1y) + fabs(e1z)) * (fabs(e2x) + fabs(e2y) + fabs(e2z));
+            if (fmax(fabs(nx), fmax(fabs(ny), fabs(nz))) <= 8.9e-16 * s2) s2keep = fmaxf(s2keep, f_up(s2));
+        }
     }
+    for (int off = 32; off >= 1; off >>= 1) s2keep = fmaxf(s2keep, __shfl_xor(s2keep, off));
+    if ((threadIdx.x & 63) == 0 && s2keep > 0.0f) atomicMax((unsigned int *)&bad[3], __float_as_uint(s2keep));      /* positive floats order like their bits */
     if (drop) {
         for (int off = 32; off >= 1; off >>= 1) { ndead += (uint32_t)__shfl_xor((int)ndead, off); noise |= (uint32_t)__shfl_xor((int)noise, off); }
         if ((threadIdx.x & 63) == 0 && ndead) { atomicAdd(&bad[1], (int)ndead); if (noise) atomicExch(&bad[2], 1); }
@@ -897,7 +908,7 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     const unsigned nb = (ntot + 255) / 256;
     uint32_t h_scene[6], level = 0, nwork = 0, nq = 1;
     const uint32_t init_scene[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    int h_bad[3] = {0, 0, 0}, leaf_max = LH_MAX_LEAF_TRIS;     /* leaves of up to 4 triangles WHERE THE SAH SAYS SO (k_node_boxes): forced 4-triangle leaves cost S-soup-1M 37 % (tools/experiments/leaf_probe.py), the SAH keeps that soup at one per leaf */
+    int h_bad[4] = {0, 0, 0, 0}, leaf_max = LH_MAX_LEAF_TRIS;     /* leaves of up to 4 triangles WHERE THE SAH SAYS SO (k_node_boxes): forced 4-triangle leaves cost S-soup-1M 37 % (tools/experiments/leaf_probe.py), the SAH keeps that soup at one per leaf */
     { const char *e = getenv("LH_DEVICE_LEAF"); if (e && atoi(e) >= 1 && atoi(e) <= LH_MAX_LEAF_TRIS) leaf_max = atoi(e); }
     uint32_t cut = 512;                             /* primitives per subtree below the SAH-built top (LH_DEVICE_CUT; 0: plain radix tree).  config 5, frame /
                                                        tree time: 64 -> 86.9 ms / 0.125 s, 128 -> 87.3 / 0.058, 512 -> 87.6 / 0.029, 2048 -> 87.8 / 0.023; 256 makes
@@ -942,6 +953,10 @@ extern "C" int lh_device_build(uint32_t ntris, const double *d_tri64, void **d_q
     n = ntot - (uint32_t)h_bad[1];
     if (nlive) *nlive = n;
     if (deg_dcap && h_bad[2]) *deg_dcap = LH_DEG_DCAP;
+    if (deg_dcap && h_bad[3]) {                  /* zero-area triangles in the tree: rays beyond 1 / s2 are the reference's own walk's */
+        float s2; memcpy(&s2, &h_bad[3], sizeof(s2));
+        if (s2 > 0.0f && 1.0 / (double)s2 < *deg_dcap) *deg_dcap = 1.0 / (double)s2;
+    }
     mark("boxes + scene bounds");
     for (int k = 0; k < 3; k++) {
         uint32_t lo = h_scene[k], hi = h_scene[3 + k]; float fl, fh;

@@ -773,7 +773,8 @@ int lh_bvh_ensure_q8(lh_bvh_t *o)
 
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
-typedef struct { const lh_mesh_view_t *m; uint32_t g, p0; lh_bvh_t *out; build_ctx_t *b; volatile int err; volatile int dead, dead_noise; } prep_job_t;
+typedef struct { const lh_mesh_view_t *m; uint32_t g, p0; lh_bvh_t *out; build_ctx_t *b; volatile int err; volatile int dead, dead_noise;
+                 double s2keep[LH_POOL_MAX]; } prep_job_t;          /* s2keep[t]: thread t's largest zero-area triangle that stays in the tree (tri_zero_area_s2) */
 
 /* Triangles the reference can NEVER report (triangle_isect, bvh.c:730-791: `if (fabs(a) > 1e-14) ... else return 0`, with
  * a = e1 . (dir x e2) in fp64, no FMA), decided from the vertices alone -- they stay out of the TRAVERSAL tree (lucille's own tree,
@@ -801,6 +802,25 @@ static int tri_dead_class(const lh_tri64_t *t)
         if (s * s * (1.0 + 1e-9) <= LH_DEG_S2CAP) return 2;
     }
     return 0;
+}
+
+/* A zero-area triangle that STAYS in the tree (v1 == v2 beyond LH_DEG_S2CAP; three different points on one line; builds with
+ * LH_DROP_DEGENERATE=0): the reference's determinant for it is rounding noise, and that noise clears 1e-14 once D S^2 is large
+ * enough -- for ANY ray that reaches the triangle's leaf in lucille's own tree, whether it comes near the triangle or not (its
+ * leaves hold several triangles; the traversal tree's boxes would never lead there).  Found by tools/fuzz_parity.py: a scene of
+ * scale 28 with zero-area triangles of 17 units, directions of 1e5: 174 of 52 000 rays "hit" one at t = +-0.  So such triangles
+ * bound deg_dcap too.  Numerically zero-area: the computed normal n = e1 x e2 is no larger than its own rounding error,
+ * max |n_k| <= 8u s2 with s2 = |e1|_1 |e2|_1 (the exact normal is then below ~12u s2); the reference's
+ * a = e1 . (dir x e2) = dir . n is below 3 D 12u s2 exact + ~15u D s2 of evaluation noise < 6e-15 D s2: never above 1e-14 while
+ * D <= 1 / s2.  Returns s2 (0: the triangle has area, or an edge of length zero -- class 1, exactly a = 0). */
+static double tri_zero_area_s2(const lh_tri64_t *t)
+{
+    const double *a = t->v[0], *b = t->v[1], *c = t->v[2];
+    const double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+    const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+    const double s2 = (fabs(e1[0]) + fabs(e1[1]) + fabs(e1[2])) * (fabs(e2[0]) + fabs(e2[1]) + fabs(e2[2]));
+    const double m = fmax(fabs(nx), fmax(fabs(ny), fabs(nz)));
+    return (m <= 8.9e-16 * s2) ? s2 : 0.0;
 }
 
 /* triangles [a0, a1) of one mesh: fp64 vertices, primitive -> (geom, index), fp32 outward box, centroid */
@@ -834,9 +854,10 @@ static void prep_part(void *j_, int t, int nt)
             b->cen[3 * (size_t)p + k] = (float)(0.5 * (lo + hi));
         }
         b->order[p] = p;
-        if (b->drop_dead) {
-            const int dc = tri_dead_class(tr);
+        {
+            const int dc = b->drop_dead ? tri_dead_class(tr) : 0;
             if (dc) { b->order[p] = 0xFFFFFFFFu; j->dead = 1; if (dc == 2) j->dead_noise = 1; }
+            else { const double s2 = tri_zero_area_s2(tr); if (s2 > j->s2keep[t]) j->s2keep[t] = s2; }
         }
     }
 }
@@ -889,26 +910,33 @@ int lh_bvh_build_hook(lh_bvh_t *out, const lh_mesh_view_t *meshes, uint32_t nmes
     b.drop_dead = !((env = getenv("LH_DROP_DEGENERATE")) != NULL && atoi(env) == 0);
     out->nlive = n; out->deg_dcap = INFINITY;
     {
-        uint32_t p = 0; int any_dead = 0, any_noise = 0;
+        uint32_t p = 0; int any_dead = 0, any_noise = 0; double s2keep = 0.0;
         for (g = 0; g < nmeshes; g++) {
-            prep_job_t pj;
+            prep_job_t pj; int tk;
             pj.m = &meshes[g]; pj.g = g; pj.p0 = p; pj.out = out; pj.b = &b; pj.err = 0; pj.dead = 0; pj.dead_noise = 0;
+            for (tk = 0; tk < LH_POOL_MAX; tk++) pj.s2keep[tk] = 0.0;
             if (b.pool && pj.m->nindices / 3 >= LH_PAR_MIN) tpool_run(b.pool, prep_part, &pj);
             else prep_part(&pj, 0, 1);
             if (pj.err) { tpool_free(b.pool); free(b.plo); free(b.phi); free(b.cen); free(b.order); lh_bvh_release(out); return pj.err; }
             p += pj.m->nindices / 3;
             any_dead |= pj.dead; any_noise |= pj.dead_noise;
+            for (tk = 0; tk < LH_POOL_MAX; tk++) if (pj.s2keep[tk] > s2keep) s2keep = pj.s2keep[tk];
         }
         if (any_dead) {
             /* the tree is built over the live primitives: order[0 .. nlive); the dead ones keep their ids, their tri64 records
              * (lucille's own tree and the reference walk read those) and the unreferenced tail of tri32 */
             uint32_t m = 0, q;
             for (q = 0; q < n; q++) if (b.order[q] != 0xFFFFFFFFu) b.order[m++] = q;
-            if (m == 0) { for (q = 0; q < n; q++) b.order[q] = q; m = n; any_noise = 0; }      /* nothing but zero-area triangles: as handed over */
+            if (m == 0) {                                                                       /* nothing but zero-area triangles: as handed over */
+                for (q = 0; q < n; q++) { const double s2 = tri_zero_area_s2(&out->tri64[q]); b.order[q] = q; if (s2 > s2keep) s2keep = s2; }
+                m = n; any_noise = 0;
+            }
             else { uint32_t w = m; for (q = 0; q < n; q++) if (tri_dead_class(&out->tri64[q])) b.order[w++] = q; }
             out->nlive = m; b.n = m;
             if (any_noise) out->deg_dcap = LH_DEG_DCAP;
         }
+        /* zero-area triangles in the tree: rays beyond 1 / s2 are decided by the reference's own walk (tri_zero_area_s2) */
+        if (s2keep > 0.0 && 1.0 / s2keep < out->deg_dcap) out->deg_dcap = 1.0 / s2keep;
     }
 
     if (after_flatten) after_flatten(hook_arg);

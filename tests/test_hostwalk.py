@@ -75,3 +75,29 @@ def test_empty_scene_always_misses():
     m = Model(np.zeros((0, 3)), np.zeros(0, np.uint32))
     prim, t, u, v = m.hostwalk(np.zeros((5, 3)), np.ones((5, 3)), use_ref=False)
     assert (prim == po.MISS).all() and (t == 1.0e38).all() and (u == 0).all() and (v == 0).all()
+
+
+def test_zero_area_triangles_that_stay_in_the_tree():
+    """zero-area triangles too large to be left out (v1 == v2 at 15 units; three different points on one line): the reference reports
+    them by its determinant's rounding noise for rays that reach their leaf in ITS tree with large direction components -- rays
+    beyond deg_dcap = 1 / (|e1|_1 |e2|_1) are its own walk's (lh_bvh.c tri_zero_area_s2; found by tools/fuzz_parity.py)"""
+    rng = np.random.default_rng(3)
+    c = rng.uniform(0, 1, (60, 1, 3)); T = (c + rng.normal(size=(60, 3, 3)) * 0.3) * 28.0
+    T[::3, 2] = T[::3, 1]
+    T[1::5, 2] = T[1::5, 0] + 2.0 * (T[1::5, 1] - T[1::5, 0])
+    P = T.reshape(-1, 3).copy(); idx = np.arange(180, dtype=np.uint32)
+    n = 40000; pick = rng.integers(0, 60, n)
+    w = rng.random((n, 3)); w /= w.sum(1, keepdims=True); tgt = (T[pick] * w[:, :, None]).sum(1)
+    org = tgt + rng.normal(size=(n, 3)) * 28.0 * 30.0
+    dr = (tgt - org) * rng.uniform(0.001, 1000.0, (n, 1))
+    dr[-n // 4:] /= np.abs(dr[-n // 4:]).max(1, keepdims=True) * rng.uniform(1.0, 400.0, (n // 4, 1))
+    ok = np.abs(dr[:, 1]) > 1e-14 * np.abs(dr).max(1)
+    org, dr = np.ascontiguousarray(org[ok]), np.ascontiguousarray(dr[ok])
+    exp = oracle_of(P, idx, org, dr)
+    za = np.zeros(60, bool); za[::3] = True; za[1::5] = True
+    assert ((exp[0] != po.MISS) & za[np.minimum(exp[0], 59)]).sum() > 10
+    m = Model(P, idx); m.ref_build()
+    try:
+        assert_hits_equal(m.hostwalk(org, dr), exp, "zero-area triangles in the tree")
+    finally:
+        Model.ref_off()

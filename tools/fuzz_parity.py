@@ -1,0 +1,55 @@
+"""Randomised parity sweep on the GPU box: many small random scenes (soups of varying triangle size, scaled / translated boxes, meshes
+with shared vertices, sliver and zero-area triangles) x rays aimed at random points, at vertices, along edges and with unnormalised
+directions; closest-hit records and any-hit flags of the device (both builders) against the oracle, bit for bit.
+python tools/fuzz_parity.py [rounds] [seed]   -> one line per scene, a total, exit code 1 on the first mismatch."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import lucille_amd as la
+from oracle import pyoracle as po
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+total = 0
+for r in range(rounds):
+    kind = r % 5
+    ntri = int(rng.choice([1, 2, 7, 60, 900, 12000, 150000]))
+    scale = float(10.0 ** rng.uniform(-3, 3)); shift = rng.uniform(-1, 1, 3) * scale * float(rng.choice([0.0, 1.0, 100.0]))
+    he = float(10.0 ** rng.uniform(-3, -0.5))
+    c = rng.uniform(0, 1, (ntri, 1, 3)); T = c + rng.normal(size=(ntri, 3, 3)) * he
+    if kind == 1:                                   # a strip mesh: shared vertices, shared edges (exact-t ties)
+        g = int(max(2, np.sqrt(ntri))); xs, ys = np.meshgrid(np.linspace(0, 1, g + 1), np.linspace(0, 1, g + 1))
+        V = np.stack([xs.ravel(), ys.ravel(), 0.3 + 0.2 * np.sin(5 * xs.ravel()) * np.cos(3 * ys.ravel())], 1)
+        q = np.array([[i * (g + 1) + j, i * (g + 1) + j + 1, (i + 1) * (g + 1) + j, i * (g + 1) + j + 1, (i + 1) * (g + 1) + j + 1, (i + 1) * (g + 1) + j] for i in range(g) for j in range(g)]).reshape(-1, 3)
+        T = V[q]
+    if kind == 2: T[:, :, 2] = np.round(T[:, :, 2] * 4) / 4                     # axis-aligned sheets
+    if kind == 3: T[::3, 2] = T[::3, 1]                                          # zero-area triangles among the others
+    if kind == 4: T[:, 2] = T[:, 0] + (T[:, 1] - T[:, 0]) * 1.0000001 + rng.normal(size=(T.shape[0], 3)) * 1e-9     # slivers
+    P = (T.reshape(-1, 3) * scale + shift).astype(np.float64); idx = np.arange(P.shape[0], dtype=np.uint32)
+    n = 60000
+    tri = P.reshape(-1, 3, 3); pick = rng.integers(0, tri.shape[0], n)
+    w = rng.random((n, 3)); w /= w.sum(1, keepdims=True); tgt = (tri[pick] * w[:, :, None]).sum(1)
+    tgt[:n // 4] = tri[pick[:n // 4], rng.integers(0, 3, n // 4)]               # exactly a vertex
+    tgt[n // 4:n // 2] = 0.5 * (tri[pick[n // 4:n // 2], 0] + tri[pick[n // 4:n // 2], 1])          # on an edge
+    org = tgt + rng.normal(size=(n, 3)) * scale * float(rng.choice([0.1, 1.0, 30.0]))
+    dr = (tgt - org) * rng.uniform(0.001, 1000.0, (n, 1))
+    dr[-n // 8:] = rng.normal(size=(n // 8, 3))                                  # anywhere
+    ok = np.abs(dr[:, 1]) > 1e-14 * np.abs(dr).max(1)                            # the reference's |dir.y| <= 1e-14 branch is outside the contract
+    org, dr = np.ascontiguousarray(org[ok]), np.ascontiguousarray(dr[ok])
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr, nthreads=16); occ = exp[0] != po.MISS            # the reference's any-hit answer: is there a closest hit
+    for build in ("host", "device"):
+        acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit(build=build)
+        got = acc.intersect_host(org, dr); gocc = acc.intersect_host(org, dr, mode=la.MODE_ANY)
+        for k, name in enumerate(("prim", "t", "u", "v")):
+            g = np.asarray(got[k]); g = g.view(np.uint32) if g.dtype == np.int32 else g
+            bad = np.nonzero(g != np.asarray(exp[k]))[0]
+            if bad.size:
+                print("MISMATCH round %d kind %d build %s: %s at %d rays, first %s" % (r, kind, build, name, bad.size, bad[:5])); sys.exit(1)
+        if gocc is not None and not np.array_equal(np.asarray(gocc).astype(bool), np.asarray(occ).astype(bool)):
+            print("MISMATCH round %d kind %d build %s: any-hit flags" % (r, kind, build)); sys.exit(1)
+        acc.close()
+    total += org.shape[0]
+    print("round %2d kind %d: %6d triangles, scale %.1e, %d rays, hits %.2f: equal on both builders" % (r, kind, tri.shape[0], scale, org.shape[0], float((exp[0] != po.MISS).mean())), flush=True)
+print("%d rays over %d scenes x 2 builders: closest-hit records and any-hit flags equal to the oracle" % (total, rounds))
