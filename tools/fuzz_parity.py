@@ -1,6 +1,6 @@
 """Randomised parity sweep on the GPU box: many small random scenes (soups of varying triangle size, scaled / translated boxes, meshes
 with shared vertices, sliver and zero-area triangles) x rays aimed at random points, at vertices, along edges and with unnormalised
-directions; closest-hit records and any-hit flags of the device (both builders) against the oracle, bit for bit.
+directions, in coordinate planes, along an axis, starting on a vertex; closest-hit records and any-hit flags of the device (both builders) against the oracle, bit for bit.
 python tools/fuzz_parity.py [rounds] [seed]   -> one line per scene, a total, exit code 1 on the first mismatch."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,11 +11,12 @@ from oracle import pyoracle as po
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"        # big: 0.3 .. 1.5 M triangles, 400 k rays as ONE device batch (fix-up queue, cooperative walk, device builders' large paths)
 total = 0
 for r in range(rounds):
     kind = r % 5
-    ntri = int(rng.choice([1, 2, 7, 60, 900, 12000, 150000]))
-    scale = float(10.0 ** rng.uniform(-3, 3)); shift = rng.uniform(-1, 1, 3) * scale * float(rng.choice([0.0, 1.0, 100.0]))
+    ntri = int(rng.choice([300000, 700000, 1500000])) if BIG else int(rng.choice([1, 2, 7, 60, 900, 12000, 150000]))
+    scale = float(10.0 ** rng.uniform(-6, 6)); shift = rng.uniform(-1, 1, 3) * scale * float(rng.choice([0.0, 1.0, 100.0]))
     he = float(10.0 ** rng.uniform(-3, -0.5))
     c = rng.uniform(0, 1, (ntri, 1, 3)); T = c + rng.normal(size=(ntri, 3, 3)) * he
     if kind == 1:                                   # a strip mesh: shared vertices, shared edges (exact-t ties)
@@ -27,7 +28,7 @@ for r in range(rounds):
     if kind == 3: T[::3, 2] = T[::3, 1]                                          # zero-area triangles among the others
     if kind == 4: T[:, 2] = T[:, 0] + (T[:, 1] - T[:, 0]) * 1.0000001 + rng.normal(size=(T.shape[0], 3)) * 1e-9     # slivers
     P = (T.reshape(-1, 3) * scale + shift).astype(np.float64); idx = np.arange(P.shape[0], dtype=np.uint32)
-    n = 60000
+    n = 400000 if BIG else 60000
     tri = P.reshape(-1, 3, 3); pick = rng.integers(0, tri.shape[0], n)
     w = rng.random((n, 3)); w /= w.sum(1, keepdims=True); tgt = (tri[pick] * w[:, :, None]).sum(1)
     tgt[:n // 4] = tri[pick[:n // 4], rng.integers(0, 3, n // 4)]               # exactly a vertex
@@ -35,13 +36,23 @@ for r in range(rounds):
     org = tgt + rng.normal(size=(n, 3)) * scale * float(rng.choice([0.1, 1.0, 30.0]))
     dr = (tgt - org) * rng.uniform(0.001, 1000.0, (n, 1))
     dr[-n // 8:] = rng.normal(size=(n // 8, 3))                                  # anywhere
+    k8 = n // 8
+    dr[k8:2 * k8, 0] = 0.0                                                        # in a coordinate plane (dir.y stays: the reference's |dir.y| <= 1e-14 branch is outside the contract)
+    dr[2 * k8:3 * k8, 2] = 0.0; dr[2 * k8:2 * k8 + k8 // 2, 0] = 0.0               # ... along the y axis
+    org[3 * k8:3 * k8 + k8 // 2] = tri[pick[3 * k8:3 * k8 + k8 // 2], 0]           # starting exactly on a vertex
+    dr[3 * k8:3 * k8 + k8 // 2] = rng.normal(size=(k8 // 2, 3))
     ok = np.abs(dr[:, 1]) > 1e-14 * np.abs(dr).max(1)                            # the reference's |dir.y| <= 1e-14 branch is outside the contract
     org, dr = np.ascontiguousarray(org[ok]), np.ascontiguousarray(dr[ok])
     o = po.Oracle(); o.add_mesh(P, idx); o.build()
     exp = o.intersect(org, dr, nthreads=16); occ = exp[0] != po.MISS            # the reference's any-hit answer: is there a closest hit
     for build in ("host", "device"):
         acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit(build=build)
-        got = acc.intersect_host(org, dr); gocc = acc.intersect_host(org, dr, mode=la.MODE_ANY)
+        if BIG:
+            import torch
+            d_o = torch.from_numpy(org).cuda(); d_d = torch.from_numpy(dr).cuda()
+            got = tuple(x.cpu().numpy() for x in acc.intersect_device(d_o, d_d)); gocc = acc.intersect_device(d_o, d_d, mode=la.MODE_ANY)[0].cpu().numpy()
+        else:
+            got = acc.intersect_host(org, dr); gocc = acc.intersect_host(org, dr, mode=la.MODE_ANY)
         for k, name in enumerate(("prim", "t", "u", "v")):
             g = np.asarray(got[k]); g = g.view(np.uint32) if g.dtype == np.int32 else g
             bad = np.nonzero(g != np.asarray(exp[k]))[0]
