@@ -14,7 +14,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"        # big: 0.3 .. 1.5 M triangles, 400 k rays as ONE device batch (fix-up queue, cooperative walk, device builders' large paths)
 total = 0
 for r in range(rounds):
-    kind = r % 5
+    kind = r % 9
     ntri = int(rng.choice([300000, 700000, 1500000])) if BIG else int(rng.choice([1, 2, 7, 60, 900, 12000, 150000]))
     scale = float(10.0 ** rng.uniform(-6, 6)); shift = rng.uniform(-1, 1, 3) * scale * float(rng.choice([0.0, 1.0, 100.0]))
     he = float(10.0 ** rng.uniform(-3, -0.5))
@@ -25,7 +25,11 @@ for r in range(rounds):
         q = np.array([[i * (g + 1) + j, i * (g + 1) + j + 1, (i + 1) * (g + 1) + j, i * (g + 1) + j + 1, (i + 1) * (g + 1) + j + 1, (i + 1) * (g + 1) + j] for i in range(g) for j in range(g)]).reshape(-1, 3)
         T = V[q]
     if kind == 2: T[:, :, 2] = np.round(T[:, :, 2] * 4) / 4                     # axis-aligned sheets
-    if kind == 3: T[::3, 2] = T[::3, 1]                                          # zero-area triangles among the others
+    if kind == 3: T[::3, 2] = T[::3, 1]; T[1::7, 2] = T[1::7, 0] + 2.0 * (T[1::7, 1] - T[1::7, 0])      # zero-area triangles among the others: two equal vertices; three points on a line
+    if kind == 5: T = np.concatenate([T, T[: max(1, ntri // 2)], T[: max(1, ntri // 3)][:, ::-1]])        # the same triangle two and three times (one of them wound the other way): ties everywhere
+    if kind == 6: T[:, 1] = T[:, 0] + (T[:, 1] - T[:, 0]) * 200.0                # needles, 200 times as long as wide
+    if kind == 7: T[:, 0] = T[0, 0]                                              # a fan: every triangle shares one vertex
+    if kind == 8: T[0] = np.array([[-40.0, -40.0, 0.5], [80.0, -40.0, 0.5], [-40.0, 80.0, 0.5]]); T[1:] = 0.5 + (T[1:] - 0.5) * 1e-3      # one huge triangle over a speck of tiny ones
     if kind == 4: T[:, 2] = T[:, 0] + (T[:, 1] - T[:, 0]) * 1.0000001 + rng.normal(size=(T.shape[0], 3)) * 1e-9     # slivers
     P = (T.reshape(-1, 3) * scale + shift).astype(np.float64); idx = np.arange(P.shape[0], dtype=np.uint32)
     n = 400000 if BIG else 60000
