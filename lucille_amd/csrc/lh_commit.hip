@@ -76,6 +76,7 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     if (env && atoi(env) > 0) a->dev.ray_budget = (uint32_t)atoi(env);
     a->dev.top_nodes = LH_TOP_AUTO;
     a->dev.deg_dcap = INFINITY;
+    a->dev.coop_patience = 0;
     a->dev.ao_group = 0;            /* measured: the grouped order is SLOWER on the config-5 frame (84.6 -> 95.1 ms, tools/ao_group_probe.py): a slot's own rays share their first levels */
     env = getenv("LH_AO_GROUP");
     if (env && atoi(env) >= 0 && atoi(env) <= 4096) a->dev.ao_group = (uint32_t)atoi(env);
@@ -825,7 +826,8 @@ extern "C" int lh_accel_set_grid(lh_accel_t *a, int blocks)
 
 /* tuning knobs of the traversal kernel (sweeps, tools/): "grid" persistent workgroups, "min_active" regroup threshold,
  * "tri_batch" parked leaves per triangle pass, "ray_chunk" rays per cursor atomic, "variant" default kernel variant,
- * "ao_fused", "wide8" (-1 auto / 0 / 1), "stack_cap" (tests of the overflow path) */
+ * "ao_fused", "wide8" (-1 auto / 0 / 1), "stack_cap" (tests of the overflow path),
+ * "coop_patience" (10 ns ticks the pass beside a launch waits for progress; 0: half a second) */
 extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
 {
     lh_guard guard(a);
@@ -838,6 +840,7 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
     else if (!strcmp(name, "ray_budget") && value > 0) { a->dev.ray_budget = (uint32_t)value; a->dump_budget = (uint32_t)value; a->ao_budget = (uint32_t)value; a->ao_budget_user = 1; }
     else if (!strcmp(name, "dump_budget") && value > 0) a->dump_budget = (uint32_t)value;
     else if (!strcmp(name, "ao_budget") && value >= 0) { a->ao_budget = (uint32_t)value; a->ao_budget_user = 1; }
+    else if (!strcmp(name, "coop_patience") && value >= 0) a->dev.coop_patience = (uint32_t)value;
     else if (!strcmp(name, "ao_fused")) a->ao_fused = value != 0;
     else if (!strcmp(name, "combine")) a->combine = value != 0;
     else if (!strcmp(name, "host_walk")) { a->host_walk = value != 0; a->hw_gpu_left = 0; a->hw_ns = 0.0; }

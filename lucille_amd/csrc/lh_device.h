@@ -45,6 +45,7 @@ typedef struct lh_dev_scene {
     uint32_t    ray_budget;/* wave iterations after which a ray leaves the persistent walk for the cooperative one */
     int         stack_guard;    /* set by the launchers when the LDS rows do not cover the tree's worst case: the walks check before they push */
     uint32_t    stack_cap; /* 0: 64 LDS stack rows at most; 8..62: a lower cap (tests of the overflow path) */
+    uint32_t    coop_patience; /* 0 (half a second), or: wall-clock ticks of 10 ns the pass beside a producer waits without progress before it leaves the queue to the sweep (tests) */
     uint32_t    ao_group;  /* fused AO stage: work items in groups of this many hit slots, a group's slots side by side per sample; 0 (the default): a slot's samples side by side */
     uint32_t    top_nodes; /* the first top_nodes 4-wide nodes (level order: the top of the tree) are walked from a copy in the workgroup's LDS; 0: none */
     const void *cam_src;       /* NULL, or: ray source 2 -- the launch's rays are the camera rays of a path-traced pass (PtCamSrc, lh_pt.h), org / dir unused */

@@ -819,7 +819,11 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
                 /* never wait for ever: if the producer makes no progress for half a second (it may not be running at all: two
                  * streams can share a hardware queue, and then this kernel runs in front of it) leave -- the sweep launched
                  * behind the producer takes what is left */
-                if (__ballot(wall_clock64() - progress <= 50000000ull) == 0ull) break;          /* wave-uniform: no group has seen anything for 0.5 s */
+                /* (only the pass beside the producer: the sweep works the queue off to its end however long an entry takes -- a
+                 * reference walk through 300 000 triangles that share a vertex runs for longer than this in ONE lane, and a sweep that
+                 * gave up after it left 110 000 of 157 000 queued any-hit rays of such a scene without an answer: tools/fuzz_parity.py,
+                 * big scenes, seed 41 round 7) */
+                if (owner_groups == 0u && __ballot(wall_clock64() - progress <= (sc.coop_patience ? (unsigned long long)sc.coop_patience : 50000000ull)) == 0ull) break;          /* wave-uniform: no group has seen anything for 0.5 s */
                 if (__ballot(!gdone && e < known) != 0ull) { __builtin_amdgcn_s_sleep(16); continue; }     /* a slot below the known count: being written, or skipped above */
                 for (int k = 0; k < 8; k++) __builtin_amdgcn_s_sleep(127);
             }

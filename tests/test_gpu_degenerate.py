@@ -132,3 +132,36 @@ def test_zero_area_triangles_that_stay_in_the_tree(build):
     assert_hits_equal(tuple(x.cpu().numpy() for x in out), exp, "%s tree, device batch" % build)
     assert_hits_equal(acc.intersect_host(org[:40], dr[:40]), tuple(x[:40] for x in exp), "%s tree, small batch" % build)
     acc.close()
+
+
+def test_every_queued_any_hit_ray_gets_its_answer():
+    """a fan of triangles about ONE vertex, far from the origin: half of an any-hit dump's rays leave the persistent walk (stack rows, or
+    a first hit the reference may not reach) and the reference's own walk on such a scene runs for a long time in one lane.  The sweep
+    behind the launch used to give up after half a second without progress -- the answer slots of the rays it left were never
+    written (tools/fuzz_parity.py big, seed 41 round 7: 110 000 of 400 000).  The output is filled with a sentinel first."""
+    import torch
+    rng = np.random.default_rng(41)
+    ntri, n = 60000, 100000
+    c = rng.uniform(0, 1, (ntri, 1, 3)); T = c + rng.normal(size=(ntri, 3, 3)) * 0.03; T[:, 0] = T[0, 0]
+    T = T * 1.5 + np.array([-57.4, -105.4, 104.0])
+    P = T.reshape(-1, 3).copy(); idx = np.arange(3 * ntri, dtype=np.uint32)
+    pick = rng.integers(0, ntri, n); w = rng.random((n, 3)); w /= w.sum(1, keepdims=True); tgt = (T[pick] * w[:, :, None]).sum(1)
+    tgt[:n // 4] = T[pick[:n // 4], rng.integers(0, 3, n // 4)]
+    org = tgt + rng.normal(size=(n, 3)) * 1.5; dr = (tgt - org) * rng.uniform(0.001, 1000.0, (n, 1))
+    ok = np.abs(dr[:, 1]) > 1e-14 * np.abs(dr).max(1); org, dr = np.ascontiguousarray(org[ok]), np.ascontiguousarray(dr[ok]); n = org.shape[0]
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr, nthreads=16)
+    acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit(build="host"); acc.wait_exact()
+    d_o = torch.from_numpy(org).cuda(); d_d = torch.from_numpy(dr).cuda()
+    # patience of one tick: the pass beside the launch leaves at once, the sweep behind it (which had the same time limit) takes the queue
+    for patience in (0, 1):
+        acc.set_param("coop_patience", patience)
+        out = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
+        acc.intersect_device(d_o, d_d, out=(out,), mode=la.MODE_ANY); torch.cuda.synchronize()
+        g = out.cpu().numpy()
+        assert int((g == 7).sum()) == 0, "%d any-hit answers were never written (patience %d)" % (int((g == 7).sum()), patience)
+        assert np.array_equal(g.astype(bool), exp[0] != po.MISS)
+    pr = torch.full((n,), 0x77777777, dtype=torch.int32, device="cuda"); tt = torch.zeros(n, dtype=torch.float64, device="cuda"); uu = torch.zeros_like(tt); vv = torch.zeros_like(tt)
+    acc.intersect_device(d_o, d_d, out=(pr, tt, uu, vv)); torch.cuda.synchronize()
+    assert_hits_equal((pr.cpu().numpy(), tt.cpu().numpy(), uu.cpu().numpy(), vv.cpu().numpy()), exp, "the fan, closest hit")
+    acc.close()

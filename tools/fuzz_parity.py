@@ -11,6 +11,7 @@ from oracle import pyoracle as po
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+ONLY = int(sys.argv[4]) if len(sys.argv) > 4 else -1       # replay: generate every round (the same random stream), trace only this one
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"        # big: 0.3 .. 1.5 M triangles, 400 k rays as ONE device batch (fix-up queue, cooperative walk, device builders' large paths)
 total = 0
 for r in range(rounds):
@@ -47,6 +48,8 @@ for r in range(rounds):
     dr[3 * k8:3 * k8 + k8 // 2] = rng.normal(size=(k8 // 2, 3))
     ok = np.abs(dr[:, 1]) > 1e-14 * np.abs(dr).max(1)                            # the reference's |dir.y| <= 1e-14 branch is outside the contract
     org, dr = np.ascontiguousarray(org[ok]), np.ascontiguousarray(dr[ok])
+    if ONLY >= 0 and r != ONLY: continue
+    if os.environ.get("FUZZ_SAVE"): np.savez(os.environ["FUZZ_SAVE"], P=P, idx=idx, org=org, dr=dr); print("saved round", r, "kind", kind, "scale", scale, "shift", shift, "he", he); sys.exit(0)
     o = po.Oracle(); o.add_mesh(P, idx); o.build()
     exp = o.intersect(org, dr, nthreads=16); occ = exp[0] != po.MISS            # the reference's any-hit answer: is there a closest hit
     for build in ("host", "device"):
