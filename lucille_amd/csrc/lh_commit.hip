@@ -55,6 +55,7 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     { const char *e = getenv("LH_WIDE8"); if (e) a->wide8 = atoi(e); }
     { const char *e = getenv("LH_AO_FUSED"); if (e) a->ao_fused = atoi(e) != 0; }
     { const char *e = getenv("LH_FAST_START"); if (e) a->fast_start = atoi(e) != 0; }
+    { const char *e = getenv("LH_POISON_OUTPUTS"); a->poison_outputs = e && atoi(e) != 0; }
     const char *env;
     a->min_active = 32;
     a->tri_batch = 12;          /* parked leaves a triangle pass waits for (tools/experiments/knob_sweep2.py, r03: S-soup-1M 2119 -> 2142 Mrays/s, config-5 AO frame 87.0 -> 85.8 ms against 8) */

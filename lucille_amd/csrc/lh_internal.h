@@ -114,6 +114,8 @@ struct lh_accel {
     int ao_budget_user;                /* set by the caller (set_param / LH_AO_BUDGET / "ray_budget"): taken as it is, whatever the launch's size */
     uint32_t dump_budget;              /* visit budget of ray-dump launches (the tile pipelines': dev.ray_budget) */
     int build_auto;                    /* the commit chose the builders by the size of the scene: a failing device build falls back to the host */
+    int poison_outputs;                /* LH_POISON_OUTPUTS=1 (tests, tools/fuzz_*): a ray dump's output arrays are filled with 0x77 before the launch -- an answer slot that nobody
+                                          writes shows up as a wrong record instead of as whatever the buffer held (the lost any-hit rays of r05 hid behind recycled buffers) */
     int fast_start;                    /* device-built scenes: launch before lucille's own tree is attached (ties by primitive id until then) */
     lh_buf p_org2, p_dir2, p_path, p_path2, p_thr, p_thr2, p_rad, p_counts;   /* path tracer */
     unsigned long long *d_total;

@@ -104,6 +104,12 @@ int lh_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, voi
         HIPCHK(hipGetLastError());
         return 0;
     }
+    if (dump && a->poison_outputs) {          /* LH_POISON_OUTPUTS: every answer slot must be written by the launch */
+        if (mode == LH_MODE_CLOSEST) {
+            HIPCHK(hipMemsetAsync(d_prim, 0x77, n * sizeof(uint32_t), s)); HIPCHK(hipMemsetAsync(d_t, 0x77, n * sizeof(double), s));
+            HIPCHK(hipMemsetAsync(d_u, 0x77, n * sizeof(double), s)); HIPCHK(hipMemsetAsync(d_v, 0x77, n * sizeof(double), s));
+        } else HIPCHK(hipMemsetAsync(d_occ, 0x77, n, s));
+    }
     /* a device-built scene: lucille's own tree (exact-t tie winners, fragile hits) is built by a background host thread.
      * Queries are exact by default -- the first launch waits for it; set_param("fast_start", 1) / LH_FAST_START=1 launches
      * at once and attaches the tree when it is ready (until then ties resolve to the larger primitive id) */

@@ -3,6 +3,7 @@ camera's view; the fused stage (rays generated inside the any-hit kernel) agains
 equal -- and the materialised AO rays' occlusion against the oracle's closest-hit answer for the same rays; both builders.
 python tools/fuzz_ao.py [seed] [rounds]"""
 import os, sys
+os.environ.setdefault("LH_POISON_OUTPUTS", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch

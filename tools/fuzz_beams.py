@@ -2,6 +2,7 @@
 spreads, beam raster (ri_bvh_intersect_beam) over tests/test_beam_raster.py's case generator with other seeds, both builders.
 python tools/fuzz_beams.py [seed] [rounds]"""
 import os, sys
+os.environ.setdefault("LH_POISON_OUTPUTS", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

@@ -3,6 +3,7 @@ with shared vertices, sliver and zero-area triangles) x rays aimed at random poi
 directions, in coordinate planes, along an axis, starting on a vertex; closest-hit records and any-hit flags of the device (both builders) against the oracle, bit for bit.
 python tools/fuzz_parity.py [rounds] [seed]   -> one line per scene, a total, exit code 1 on the first mismatch."""
 import os, sys
+os.environ.setdefault("LH_POISON_OUTPUTS", "1")          # an answer slot nobody writes must show up as a mismatch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
@@ -65,7 +66,7 @@ for r in range(rounds):
             bad = np.nonzero(g != np.asarray(exp[k]))[0]
             if bad.size:
                 print("MISMATCH round %d kind %d build %s: %s at %d rays, first %s" % (r, kind, build, name, bad.size, bad[:5])); sys.exit(1)
-        if gocc is not None and not np.array_equal(np.asarray(gocc).astype(bool), np.asarray(occ).astype(bool)):
+        if gocc is not None and not np.array_equal(np.asarray(gocc).astype(np.uint8), np.asarray(occ).astype(np.uint8)):          # raw: 0 or 1, nothing else
             print("MISMATCH round %d kind %d build %s: any-hit flags" % (r, kind, build)); sys.exit(1)
         acc.close()
     total += org.shape[0]

@@ -3,6 +3,7 @@ example scenes, random per-mesh materials (diffuse / mirror / glass mixes), cons
 random tiles, sample ranges, vertex limits and seeds: rays traced, paths and longest path equal, the frame within 1e-6.
 python tools/fuzz_pt.py [seed] [rounds]"""
 import os, sys
+os.environ.setdefault("LH_POISON_OUTPUTS", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

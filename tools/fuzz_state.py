@@ -2,6 +2,7 @@
 oracle's ri_intersection_state_build, bit for bit, on the test fixtures' scene generator with other seeds.
 python tools/fuzz_state.py [first seed] [count]"""
 import os, sys
+os.environ.setdefault("LH_POISON_OUTPUTS", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
