@@ -30,8 +30,10 @@ def build_model():
             os.path.join(CSRC, "lh_bvh.h"), os.path.join(CSRC, "lh_filter.h"), os.path.join(CSRC, "lh_refbvh.h"),
             os.path.join(CSRC, "lh_reftrace.h")]
     if (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        tmp = "%s.%d.tmp" % (so, os.getpid())              # pytest-xdist workers build at once: link aside, rename whole
         subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-ffp-contract=off", "-fPIC", "-shared"] + _fma_flag() +
-                              ["-I" + CSRC, srcs[0], srcs[1], srcs[2], srcs[3], "-o", so, "-lm", "-lpthread"])
+                              ["-I" + CSRC, srcs[0], srcs[1], srcs[2], srcs[3], "-o", tmp, "-lm", "-lpthread"])
+        os.replace(tmp, so)
     return so
 
 
