@@ -60,9 +60,9 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     a->min_active = 32;
     a->tri_batch = 12;          /* parked leaves a triangle pass waits for (tools/experiments/knob_sweep2.py, r03: S-soup-1M 2119 -> 2142 Mrays/s, config-5 AO frame 87.0 -> 85.8 ms against 8) */
     env = getenv("LH_TRI_BATCH");
-    if (env && atoi(env) > 0 && atoi(env) <= 64) a->tri_batch = atoi(env);
+    if (env && atoi(env) > 0 && atoi(env) <= 64) { a->tri_batch = atoi(env); a->knobs_user = 1; }
     env = getenv("LH_MIN_ACTIVE");
-    if (env && atoi(env) > 0 && atoi(env) <= 64) a->min_active = atoi(env);
+    if (env && atoi(env) > 0 && atoi(env) <= 64) { a->min_active = atoi(env); a->knobs_user = 1; }
     a->ray_chunk = 256;
     env = getenv("LH_RAY_CHUNK");
     if (env && atoi(env) > 0 && atoi(env) <= (1 << 20)) a->ray_chunk = (uint32_t)atoi(env);
@@ -834,8 +834,8 @@ extern "C" int lh_accel_set_param(lh_accel_t *a, const char *name, int value)
     lh_guard guard(a);
     if (!a || !name) return fail("lh_accel_set_param: NULL argument");
     if (!strcmp(name, "grid") && value > 0) { a->grid_blocks = value; a->grid_user = 1; }
-    else if (!strcmp(name, "min_active") && value > 0 && value <= 64) a->min_active = value;
-    else if (!strcmp(name, "tri_batch") && value > 0 && value <= 64) a->tri_batch = value;
+    else if (!strcmp(name, "min_active") && value > 0 && value <= 64) { a->min_active = value; a->knobs_user = 1; }
+    else if (!strcmp(name, "tri_batch") && value > 0 && value <= 64) { a->tri_batch = value; a->knobs_user = 1; }
     else if (!strcmp(name, "ray_chunk") && value > 0 && value <= (1 << 20)) { a->ray_chunk = (uint32_t)value; a->dev.ray_chunk = (uint32_t)value; }
     else if (!strcmp(name, "variant") && (value == LH_VARIANT_DIRECT || value == LH_VARIANT_SPEC)) a->default_variant = value;
     else if (!strcmp(name, "ray_budget") && value > 0) { a->dev.ray_budget = (uint32_t)value; a->dump_budget = (uint32_t)value; a->ao_budget = (uint32_t)value; a->ao_budget_user = 1; }

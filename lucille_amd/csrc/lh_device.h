@@ -84,6 +84,8 @@ enum {
 #define LH_CURSOR_WORDS   ((LH_NPART + 1) * LH_CURSOR_STRIDE)   /* the cursors + the drained-partition mask, per launch */
 #define LH_AO_QCAP        (1u << 22)   /* rays of one launch that may wait in the fix-up queue (8 B each): fragile AO hits, rays out of visit budget */
 #define LH_DUMP_BUDGET    2048u        /* ... of ray-dump launches (incoherent rays: ages run to several times the steps) */
+#define LH_DUMP_MIN_ACTIVE 24           /* ray dumps over the 4-wide nodes: regroup below this many working lanes ... */
+#define LH_DUMP_TRI_BATCH  8            /* ... and pass over the parked leaves once this many lanes hold one (lh_query.hip lh_launch) */
 #define LH_TILE_CHUNK     1024u        /* rays per cursor atomic in the tile pipelines (camera rays, AO rays of a slot, path-tracing bounces: neighbours in the
                                          batch are neighbours in space; ray dumps keep "ray_chunk" = 256): config 4 frame 148 -> 134 ms, config 5 87.0 -> 85.5 */
 #define LH_AO_BUDGET      384u         /* ... of the fused AO stage: one ray in 800 leaves the surface it starts on at so low an angle that it threads the boxes of

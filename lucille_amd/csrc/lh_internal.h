@@ -89,6 +89,7 @@ struct lh_accel {
     int min_active;
     uint32_t ray_chunk;                /* rays reserved per cursor atomic (LH_RAY_CHUNK) */
     int tri_batch;
+    int knobs_user;                    /* min_active / tri_batch were set by the caller (set_param, LH_MIN_ACTIVE, LH_TRI_BATCH): ray dumps do not pick their own */
     int default_variant;
     /* per-stream fix-up queues of the persistent launches (rays out of visit budget / stack rows, fragile AO hits) */
     struct { hipStream_t stream; int used; lh_fixq_t q; } aoq[LH_AOQ_SLOTS];
