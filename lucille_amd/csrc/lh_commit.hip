@@ -57,7 +57,7 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     { const char *e = getenv("LH_FAST_START"); if (e) a->fast_start = atoi(e) != 0; }
     { const char *e = getenv("LH_POISON_OUTPUTS"); a->poison_outputs = e && atoi(e) != 0; }
     const char *env;
-    a->min_active = 32;
+    a->min_active = 24;         /* the tile pipelines' regroup threshold (tools/experiments/knob_sweep6.py, r05: config 4 108.9 -> 107.4 ms, config 5 47.95 -> 47.67 ms against 32); ray dumps: LH_DUMP*_MIN_ACTIVE */
     a->tri_batch = 12;          /* parked leaves a triangle pass waits for (tools/experiments/knob_sweep2.py, r03: S-soup-1M 2119 -> 2142 Mrays/s, config-5 AO frame 87.0 -> 85.8 ms against 8) */
     env = getenv("LH_TRI_BATCH");
     if (env && atoi(env) > 0 && atoi(env) <= 64) { a->tri_batch = atoi(env); a->knobs_user = 1; }

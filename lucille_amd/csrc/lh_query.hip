@@ -140,10 +140,11 @@ int lh_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dir, voi
      * pipelines' coherent batches want (tools/experiments/knob_sweep3.py / knob_sweep4.py, r05: S-soup-1M 2 233 -> 2 266 Mrays/s
      * closest hit, 2 735 -> 2 772 any hit; the 8-wide walk and the AO stage are best where they are) */
     const bool dump4 = dump && !a->dev.prefer_q8 && !a->knobs_user;
+    const bool dump8 = dump && a->dev.prefer_q8 && !a->knobs_user;
     int rc = lh_launch_trace(&a->dev, n, (const double *)d_org, (const double *)d_dir, (uint32_t *)d_prim,
                              (double *)d_t, (double *)d_u, (double *)d_v, mode == LH_MODE_ANY,
                              (uint8_t *)d_occ, d_counters, (unsigned long long *)((uint32_t *)a->d_cursor + (size_t)LH_CURSOR_WORDS * (a->cursor_next++ % LH_NCURSOR)), variant, grid,
-                             dump4 ? LH_DUMP_MIN_ACTIVE : a->min_active, dump4 ? LH_DUMP_TRI_BATCH : a->tri_batch,
+                             dump4 ? LH_DUMP_MIN_ACTIVE : dump8 ? LH_DUMP8_MIN_ACTIVE : a->min_active, dump4 ? LH_DUMP_TRI_BATCH : dump8 ? LH_DUMP8_TRI_BATCH : a->tri_batch,
                              &a->aoq[qk].q, a->ncus, (void *)s);
     a->dev.ray_budget = budget_keep; a->dev.ray_chunk = chunk_keep; a->dev.stack_cap = cap_keep;
     if (rc != 0) return fail("kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
