@@ -178,7 +178,7 @@ int  lh_accel_set_grid(lh_accel_t *accel, int blocks);
  * (four workgroups per CU; a ray that would overrun them is finished by the cooperative walk), smaller launches up to 64
  * unchecked; 8 .. 64: that many at most (64 = rounds 1-3's unchecked rows; small values: tests of the overflow path);
  * "min_active" / "tri_batch": working lanes below which a wave regroups / lanes holding a parked leaf from which it runs a triangle
- * pass -- 24 / 12 for the tile pipelines; left alone, ray dumps use 24 / 8 over the 4-wide nodes and 32 / 12 over the 8-wide ones,
+ * pass -- 24 / 12 for the tile pipelines; left alone, ray dumps use 24 / 8 over the 4-wide nodes and 40 / 20 over the 8-wide ones,
  * once either is set here (or by LH_MIN_ACTIVE / LH_TRI_BATCH) every launch uses the caller's pair;
  * "ray_budget" (wave iterations after which a ray leaves the persistent walk for the cooperative one; sets "dump_budget" and
  * "ao_budget" with it), "dump_budget" (ray dumps: 2048), "ao_budget" (the fused AO stage: 384; 0: "ray_budget") */

@@ -86,8 +86,9 @@ enum {
 #define LH_DUMP_BUDGET    2048u        /* ... of ray-dump launches (incoherent rays: ages run to several times the steps) */
 #define LH_DUMP_MIN_ACTIVE 24           /* ray dumps over the 4-wide nodes: regroup below this many working lanes ... */
 #define LH_DUMP_TRI_BATCH  8            /* ... and pass over the parked leaves once this many lanes hold one (lh_query.hip lh_launch) */
-#define LH_DUMP8_MIN_ACTIVE 32          /* ray dumps over the 8-wide nodes (scenes beyond the Infinity Cache) keep the older pair: S-soup-10M 1 676 Mrays/s at 24 / 8, 1 693 at 24 / 12, 1 708 here */
-#define LH_DUMP8_TRI_BATCH  12
+#define LH_DUMP8_MIN_ACTIVE 40          /* ray dumps over the 8-wide nodes (scenes beyond the Infinity Cache): S-soup-10M, 50 M rays, 1 787 -> 1 821 Mrays/s closest hit, 2 796 -> 2 875 any hit
+                                         * against 32 / 12 (tools/experiments/knob_sweep7.py, r05); 24 / 8, the 4-wide dumps' pair, loses 2 % here */
+#define LH_DUMP8_TRI_BATCH  20
 #define LH_TILE_CHUNK     1024u        /* rays per cursor atomic in the tile pipelines (camera rays, AO rays of a slot, path-tracing bounces: neighbours in the
                                          batch are neighbours in space; ray dumps keep "ray_chunk" = 256): config 4 frame 148 -> 134 ms, config 5 87.0 -> 85.5 */
 #define LH_AO_BUDGET      384u         /* ... of the fused AO stage: one ray in 800 leaves the surface it starts on at so low an angle that it threads the boxes of
