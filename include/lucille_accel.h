@@ -165,22 +165,27 @@ int ri_render_tile_ao(void *accel, const ri_tile_camera_t *camera, int x0, int y
 
 /* ---- BVH extras of the boundary (bvh.h:194-227) ---------------------------- */
 
-/* beam = frustum of 4 corner rays with a common origin (beam.h:45-84).  Only the members the
- * visibility query reads are kept; `corner` remembers the caller's un-normalised directions,
- * which is what the device query (which repeats ri_beam_set in fp64) is fed with. */
+/* beam = frustum of 4 corner rays with a common origin: ri_beam_t member for member as beam.h:45-84 declares it.
+ * ri_beam_set fills what the reference's fills (beam.c:331-465); the device queries read org, dir, normal,
+ * dominant_axis and dirsign of the beam they are handed (lh_beam_set_t, lucille_hip.h) -- nothing is recomputed
+ * from the caller's un-normalised directions. */
 #define RI_BEAM_MISS_COMPLETELY 0     /* beam.h:27-29 */
 #define RI_BEAM_HIT_COMPLETELY  1
 #define RI_BEAM_HIT_PARTIALLY   2
 
 typedef struct _ri_beam_t {
     ri_vector_t org;
-    ri_vector_t dir[4];               /* scaled onto the axis plane at distance d (beam.c:417-440) */
-    ri_float_t  d, t_max;
+    ri_vector_t dir[4];               /* P[i] - org, P[i] on the axis-aligned plane at distance d (beam.c:412-432) */
+    ri_vector_t length;               /* side length (xyz); never set by ri_beam_set */
+    ri_float_t  d;                    /* distance to the axis-aligned plane: 1024 */
+    ri_float_t  t_max;                /* RI_INFINITY */
+    int         is_tetrahedron;
     ri_vector_t invdir[4];
     int         dominant_axis;
     int         dirsign[3];
     ri_vector_t normal[4];
-    ri_vector_t corner[4];            /* as given to ri_beam_set */
+    struct _ri_beam_t *children;      /* beam.h:76-80: subdivided beams; unused by the compiled reference */
+    int         nchildren;
 } ri_beam_t;
 
 /* 0, or -1 when the corner directions straddle an octant (beam.c:352-376) */

@@ -393,6 +393,23 @@ int  lh_accel_beam_visibility_host(lh_accel_t *accel, size_t n, const double *or
 int  lh_accel_beam_visibility_device(lh_accel_t *accel, size_t n, const void *d_org_xyz,
                                      const void *d_corner_dirs_xyz, void *d_result, void *stream);
 
+/* The same queries for beams the CALLER has already set up with lucille's own ri_beam_set: what
+ * ri_bvh_intersect_beam_visibility(accel, ri_beam_t *, user) / ri_bvh_intersect_beam(accel, ri_beam_t *, plane, user) are
+ * handed (src/render/bvh.h:203-221).  lh_beam_set_t = the members of ri_beam_t (src/render/beam.h:45-84) those two walks read:
+ * org, the four directions SCALED onto the plane at d = 1024 (beam.c:412-432), their cross products (beam.c:446-452), the
+ * dominant axis and the direction signs (beam.c:381-403) -- taken as they are, nothing recomputed, so the answer is the
+ * reference's for the beam it holds (integration/ri_accel_hip.c copies them out of the ri_beam_t).  invdir, d, t_max,
+ * is_tetrahedron and the child beams are not read by either walk (t_max stays RI_INFINITY, beam.c:344). */
+typedef struct lh_beam_set {
+    double  org[3];
+    double  dir[4][3];
+    double  normal[4][3];
+    int32_t dominant_axis;
+    int32_t dirsign[3];
+} lh_beam_set_t;
+
+int  lh_accel_beam_visibility_set_host(lh_accel_t *accel, size_t n, const lh_beam_set_t *beams, int32_t *result);
+
 /* ---- the beam-raster path: ri_beam_set + ri_raster_plane_setup + ri_bvh_intersect_beam ----
  * reference: src/render/bvh.c:544-609 (-> :2547-2643, :2315-2426, :2751-2820), src/render/beam.c:469-730,
  * src/render/raster.c:42-147,166-435, src/render/triangle.c:8-68.  The reference never calls this path and left it
@@ -423,6 +440,9 @@ int  lh_accel_beam_raster_host(lh_accel_t *accel, size_t n, const double *org_xy
 int  lh_accel_beam_raster_device(lh_accel_t *accel, size_t n, const void *d_org_xyz, const void *d_corner_dirs_xyz,
                                  const void *d_corner_xyz, const lh_raster_plane_t *plane, void *d_t_out,
                                  void *d_status, void *d_flags, void *stream);
+/* ... for beams already set up by the caller's ri_beam_set (lh_beam_set_t above); status is never LH_BEAM_INVALID */
+int  lh_accel_beam_raster_set_host(lh_accel_t *accel, size_t n, const lh_beam_set_t *beams, const double *corner_xyz,
+                                   const lh_raster_plane_t *plane, double *t_out, int32_t *status, uint64_t *flags);
 
 /* whole AO frame into HOST memory: the tile loop of render_frame_controller + bucket_write
  * (src/render/render.c:1168-1207, 919-983) over lh_render_ao_tile.  rgb: height rows of width RGB

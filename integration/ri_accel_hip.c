@@ -44,6 +44,19 @@ typedef struct {
 static int g_ri_hip_device = 0;
 void ri_hipbvh_set_device(int device) { g_ri_hip_device = device; }
 
+/* RI_HIP_STATS_FILE=<path> (diagnostics, tests/test_gpu_dropin.py): how the one-ray calls of this accelerator were answered --
+ * "<device batches> <rays in them>" of the coalesced device path (lh_accel_combine_statistics); 0 0 = every ray was answered by
+ * the host walk.  Written when the accelerator is freed, or at exit if the renderer never frees it. */
+static ri_hipbvh_t *g_ri_hip_last = NULL;
+static void ri_hipbvh_dump_stats(void)
+{
+    const char *path = getenv("RI_HIP_STATS_FILE"); uint64_t st[2] = {0, 0}; FILE *f;
+    if (!path || !g_ri_hip_last) return;
+    if (lh_accel_combine_statistics(g_ri_hip_last->lh, st, 0) != 0) return;
+    f = fopen(path, "w");
+    if (f) { fprintf(f, "%llu %llu\n", (unsigned long long)st[0], (unsigned long long)st[1]); fclose(f); }
+}
+
 /* accel_build_func: walks scene->geom_list exactly like create_triangle_list
  * (bvh.c:1758-1821) so primitive ids match the CPU BVH's numbering */
 void *ri_hipbvh_build(const void *data)
@@ -104,6 +117,11 @@ void *ri_hipbvh_build(const void *data)
         lh_accel_destroy(h->lh); free(h->geoms); free(h);
         return NULL;
     }
+    if (getenv("RI_HIP_STATS_FILE")) {
+        static int registered = 0;
+        if (!registered) { registered = 1; atexit(ri_hipbvh_dump_stats); }
+        g_ri_hip_last = h;
+    }
     return h;
 }
 
@@ -119,6 +137,7 @@ void ri_hipbvh_free(void *accel)
 {
     ri_hipbvh_t *h = (ri_hipbvh_t *)accel;
     if (!h) return;
+    if (h == g_ri_hip_last) { ri_hipbvh_dump_stats(); g_ri_hip_last = NULL; }
     lh_accel_destroy(h->lh);
     free(h->geoms);
     free(h);
@@ -160,22 +179,63 @@ int ri_accel_bind_hip(ri_accel_t *accel)
     return 0;
 }
 
-/* ri_bvh_intersect_beam (bvh.h:203-206, bvh.c:544-609) on the device: after the call raster_out->t holds what the reference's own
- * path leaves there for this beam (as right after ri_bvh_invalidate_cache: the leaf caches of projected triangles are per beam
- * here).  corner_dirs = the four directions ri_beam_set was GIVEN: it stores scaled copies in beam->dir and the device repeats
- * ri_beam_set from the originals -- in lucille proper, a `ri_vector_t corner[4]` member of ri_beam_t that ri_beam_set fills
- * (beam.c:331) makes this argument unnecessary.  Returns 0 like the reference; `user` is ignored. */
-int ri_hipbvh_intersect_beam(void *accel, ri_beam_t *beam, ri_vector_t corner_dirs[4], ri_raster_plane_t *raster_out, void *user)
+/* the members of the reference's own ri_beam_t (beam.h:45-84) that its two beam walks read, as ri_beam_set (beam.c:331-465) left
+ * them: the device takes the beam as it is (lh_beam_set_t, lucille_hip.h) -- no member added to ri_beam_t, nothing recomputed */
+static void hipbvh_beam_fields(lh_beam_set_t *o, const ri_beam_t *beam)
+{
+    int i, k;
+    for (k = 0; k < 3; k++) { o->org[k] = beam->org[k]; o->dirsign[k] = beam->dirsign[k]; }
+    for (i = 0; i < 4; i++) for (k = 0; k < 3; k++) { o->dir[i][k] = beam->dir[i][k]; o->normal[i][k] = beam->normal[i][k]; }
+    o->dominant_axis = beam->dominant_axis;
+}
+
+/* ri_bvh_intersect_beam (bvh.h:203-206, bvh.c:544-609) on the device, the reference's signature: after the call raster_out->t
+ * holds what the reference's own path leaves there for this beam (as right after ri_bvh_invalidate_cache: the leaf caches of
+ * projected triangles are per beam here).  Returns 0 like the reference; `user` is ignored. */
+int ri_hipbvh_intersect_beam(void *accel, ri_beam_t *beam, ri_raster_plane_t *raster_out, void *user)
 {
     ri_hipbvh_t *h = (ri_hipbvh_t *)accel;
-    lh_raster_plane_t lp; double org[3], dirs[12], corner[3]; int32_t status = 0; int i, k;
+    lh_raster_plane_t lp; lh_beam_set_t b; double corner[3]; int32_t status = 0; int i, k;
     (void)user;
     if (!h || h->magic != RI_HIPBVH_MAGIC || !beam || !raster_out || !raster_out->t) return 0;
+    hipbvh_beam_fields(&b, beam);
     lp.width = raster_out->width; lp.height = raster_out->height; lp.fov = raster_out->fov;
     for (i = 0; i < 3; i++) for (k = 0; k < 3; k++) lp.frame[3 * i + k] = raster_out->frame[i][k];
-    for (k = 0; k < 3; k++) { lp.eye[k] = raster_out->org[k]; org[k] = beam->org[k]; corner[k] = raster_out->corner[k]; }
-    for (i = 0; i < 4; i++) for (k = 0; k < 3; k++) dirs[3 * i + k] = corner_dirs[i][k];
-    if (lh_accel_beam_raster_host(h->lh, 1, org, dirs, corner, &lp, raster_out->t, &status, NULL) != 0)
+    for (k = 0; k < 3; k++) { lp.eye[k] = raster_out->org[k]; corner[k] = raster_out->corner[k]; }
+    if (lh_accel_beam_raster_set_host(h->lh, 1, &b, corner, &lp, raster_out->t, &status, NULL) != 0)
         ri_log(LOG_ERROR, "(HIPBVH) %s", lh_last_error());
     return 0;
+}
+
+/* ri_bvh_intersect_beam_visibility (bvh.h:208-221, bvh.c:612-667) on the device, the reference's signature on the reference's
+ * ri_beam_t: RI_BEAM_MISS_COMPLETELY / _HIT_COMPLETELY / _HIT_PARTIALLY (beam.h:27-29) exactly as the CPU BVH classifies the
+ * beam (the walk runs on the bit-faithful rebuild of ITS tree); `user` is ignored as the reference ignores it. */
+int ri_hipbvh_intersect_beam_visibility(void *accel, ri_beam_t *beam, void *user)
+{
+    ri_hipbvh_t *h = (ri_hipbvh_t *)accel;
+    lh_beam_set_t b; int32_t cls = RI_BEAM_MISS_COMPLETELY;
+    (void)user;
+    if (!h || h->magic != RI_HIPBVH_MAGIC || !beam) return RI_BEAM_MISS_COMPLETELY;
+    hipbvh_beam_fields(&b, beam);
+    if (lh_accel_beam_visibility_set_host(h->lh, 1, &b, &cls) != 0) {
+        ri_log(LOG_ERROR, "(HIPBVH) %s", lh_last_error());
+        return RI_BEAM_MISS_COMPLETELY;
+    }
+    return (int)cls;
+}
+
+/* the same for n beams in one launch (a testbed-style caller that sets up a grid of beams first: simplerender.cpp:640-720) */
+int ri_hipbvh_intersect_beam_visibility_n(void *accel, size_t n, ri_beam_t *beams, int *result)
+{
+    ri_hipbvh_t *h = (ri_hipbvh_t *)accel;
+    lh_beam_set_t *b; int32_t *cls; size_t i; int rc = 0;
+    if (!h || h->magic != RI_HIPBVH_MAGIC || !beams || !result) return -1;
+    if (n == 0) return 0;
+    b = (lh_beam_set_t *)malloc(n * sizeof(*b)); cls = (int32_t *)malloc(n * sizeof(*cls));
+    if (!b || !cls) { free(b); free(cls); return -1; }
+    for (i = 0; i < n; i++) hipbvh_beam_fields(&b[i], &beams[i]);
+    if (lh_accel_beam_visibility_set_host(h->lh, n, b, cls) != 0) { ri_log(LOG_ERROR, "(HIPBVH) %s", lh_last_error()); rc = -1; }
+    else for (i = 0; i < n; i++) result[i] = (int)cls[i];
+    free(b); free(cls);
+    return rc;
 }

@@ -97,13 +97,17 @@ class TileStats(C.Structure):
                 ("ao_occluded", C.c_uint64)]
 
 
+# lh_beam_set_t (include/lucille_hip.h): a beam as lucille's ri_beam_set leaves it -- 232 bytes
+BEAM_SET_DTYPE = np.dtype([("org", np.float64, (3,)), ("dir", np.float64, (4, 3)), ("normal", np.float64, (4, 3)),
+                           ("dominant_axis", np.int32), ("dirsign", np.int32, (3,))])
+
 # every symbol include/lucille_hip.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "lh_device_count", "lh_last_error", "lh_accel_create", "lh_accel_add_mesh", "lh_accel_commit", "lh_accel_wait_exact", "lh_accel_ref_tree",
     "lh_accel_destroy", "lh_accel_info", "lh_accel_prim_lookup", "lh_accel_intersect1", "lh_accel_combine_statistics", "lh_accel_intersect_diag_host", "lh_accel_intersect_diag_device",
     "lh_accel_intersect_host", "lh_accel_intersect_device", "lh_accel_intersect_device_counted", "lh_accel_last_retraced", "lh_accel_dump_node_bytes",
     "lh_accel_set_grid", "lh_accel_set_param", "lh_accel_export", "lh_accel_set_normals", "lh_render_primary_rays",
-    "lh_render_ao_tile", "lh_render_ao_tile_host", "lh_render_ao_bands", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device", "lh_accel_beam_raster_host", "lh_accel_beam_raster_device", "lh_render_pt_tile",
+    "lh_render_ao_tile", "lh_render_ao_tile_host", "lh_render_ao_bands", "lh_render_scratch", "lh_accel_beam_visibility_host", "lh_accel_beam_visibility_device", "lh_accel_beam_visibility_set_host", "lh_accel_beam_raster_host", "lh_accel_beam_raster_device", "lh_accel_beam_raster_set_host", "lh_render_pt_tile",
     "lh_accel_trace_statistics", "lh_accel_statistics", "lh_accel_slot_statistics",
     "lh_render_ao_frame_host", "lh_rib_load", "lh_rib_free", "lh_rib_last_error", "lh_rib_info", "lh_rib_messages",
     "lh_rib_mesh", "lh_accel_add_rib_scene", "lh_hdr_write",
@@ -455,6 +459,15 @@ class HipAccel:
         res = np.empty(o.shape[0], np.int32)
         _check(self.L.lh_accel_beam_visibility_host(self.h, o.shape[0], o.ctypes.data, d.ctypes.data, res.ctypes.data),
                "lh_accel_beam_visibility_host")
+        return res
+
+    def beam_visibility_set(self, beams):
+        """ri_bvh_intersect_beam_visibility for n beams a caller's ri_beam_set has ALREADY set up: beams = a structured array of
+        BEAM_SET_DTYPE (lh_beam_set_t: org, dir[4], normal[4], dominant_axis, dirsign[3]) -> int32 [n]"""
+        b = np.ascontiguousarray(beams, BEAM_SET_DTYPE).reshape(-1)
+        res = np.empty(b.shape[0], np.int32)
+        self.L.lh_accel_beam_visibility_set_host.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        _check(self.L.lh_accel_beam_visibility_set_host(self.h, b.shape[0], b.ctypes.data, res.ctypes.data), "lh_accel_beam_visibility_set_host")
         return res
 
     # ---- tile rendering (device-resident pipeline) ---------------------------

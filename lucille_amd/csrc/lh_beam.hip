@@ -82,6 +82,15 @@ __device__ int beam_set(Beam &b, const double *org, const double *dir /* 4x3 */)
     return 0;
 }
 
+/* a beam the CALLER's ri_beam_set has set up (lh_beam_set_t, include/lucille_hip.h: the fields of lucille's own ri_beam_t the
+ * beam queries read -- beam.h:45-84 org, dir[4], normal[4], dominant_axis, dirsign[3]): taken as it is, nothing recomputed */
+__device__ __forceinline__ void beam_load(Beam &b, const lh_beam_set_t *s)
+{
+    for (int k = 0; k < 3; k++) { b.org[k] = s->org[k]; b.dirsign[k] = s->dirsign[k]; }
+    for (int i = 0; i < 4; i++) for (int k = 0; k < 3; k++) { b.dir[i][k] = s->dir[i][k]; b.normal[i][k] = s->normal[i][k]; }
+    b.dominant_axis = s->dominant_axis;
+}
+
 /* test_beam_aabb (bvh.c:2053-2089): 1 = the box may be hit.  The "cull by t" block at the top of the reference function
  * (bvh.c:2065-2074, beam->t_max against the box's near side) sits inside `#if 0`: it is not part of the compiled reference, and
  * ri_beam_set leaves t_max = RI_INFINITY (beam.c:344), so there is nothing to restate -- the plane test below is the whole
@@ -147,7 +156,8 @@ __device__ int beam_triangle(const double *tv, const Beam &b)
  * Control flow is uniform inside a group (every lane holds the beam and computes the same next node); the stack of node
  * indices -- BVH_MAXDEPTH + 1 entries (bvh.c:80,124-129) -- is one LDS column per group. */
 __global__ __launch_bounds__(64) void k_beam_visibility(lh_dev_scene_t sc, size_t n, const double *__restrict__ org,
-                                                        const double *__restrict__ dirs, int32_t *__restrict__ result)
+                                                        const double *__restrict__ dirs, int32_t *__restrict__ result,
+                                                        const lh_beam_set_t *__restrict__ preset)
 {
     LH_NC
     __shared__ int stack[4][104];
@@ -158,7 +168,9 @@ __global__ __launch_bounds__(64) void k_beam_visibility(lh_dev_scene_t sc, size_
     int ret = 0;
     bool walking = false;
     if (live) {
-        if (beam_set(b, org + 3 * r, dirs + 12 * r) != 0) ret = -1;
+        int bad = 0;
+        if (preset) beam_load(b, preset + r); else bad = beam_set(b, org + 3 * r, dirs + 12 * r);
+        if (bad != 0) ret = -1;
         else if (!sc.ref_empty) {
             const double sb[6] = {sc.ref_bmin[0], sc.ref_bmin[1], sc.ref_bmin[2], sc.ref_bmax[0], sc.ref_bmax[1], sc.ref_bmax[2]};
             walking = beam_aabb(sb, b) != 0;
@@ -403,7 +415,8 @@ __device__ void rb_rasterize_subbeam(const RPlane &pl, const Beam &b, double (*p
  * box: the reference returns before it clears the plane, bvh.c:560-563,586-593), -1 ri_beam_set refuses the beam */
 __global__ __launch_bounds__(64) void k_beam_raster(lh_dev_scene_t sc, size_t n, const double *__restrict__ org, const double *__restrict__ dirs,
                                                     const double *__restrict__ corner, lh_raster_plane_t rp, double ktan, double *__restrict__ t_out,
-                                                    int32_t *__restrict__ status, unsigned long long *__restrict__ flags_out)
+                                                    int32_t *__restrict__ status, unsigned long long *__restrict__ flags_out,
+                                                    const lh_beam_set_t *__restrict__ preset)
 {
     LH_NC
     __shared__ int stack[104];
@@ -413,7 +426,9 @@ __global__ __launch_bounds__(64) void k_beam_raster(lh_dev_scene_t sc, size_t n,
     if (r >= n) return;
     unsigned long long flags[4] = {0ull, 0ull, 0ull, 0ull};
     Beam b;
-    if (beam_set(b, org + 3 * r, dirs + 12 * r) != 0) { if (lane == 0) { status[r] = -1; if (flags_out) for (int k = 0; k < 4; k++) flags_out[4 * r + k] = 0ull; } return; }
+    int bad = 0;
+    if (preset) beam_load(b, preset + r); else bad = beam_set(b, org + 3 * r, dirs + 12 * r);
+    if (bad != 0) { if (lane == 0) { status[r] = -1; if (flags_out) for (int k = 0; k < 4; k++) flags_out[4 * r + k] = 0ull; } return; }
     RPlane pl;
     pl.width = rp.width; pl.height = rp.height; pl.ktan = ktan;
     pl.t = t_out + r * (size_t)rp.width * (size_t)rp.height;
@@ -502,11 +517,11 @@ __global__ __launch_bounds__(64) void k_beam_raster(lh_dev_scene_t sc, size_t n,
 } /* namespace */
 
 extern "C" int lh_launch_beam_visibility(const lh_dev_scene_t *sc, size_t n, const double *d_org, const double *d_dirs,
-                                         int32_t *d_result, void *stream)
+                                         int32_t *d_result, void *stream, const lh_beam_set_t *d_preset)
 {
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_beam_visibility, dim3((unsigned)((n + 3) / 4)), dim3(64), 0, (hipStream_t)stream,
-                       *sc, n, d_org, d_dirs, d_result);
+                       *sc, n, d_org, d_dirs, d_result, d_preset);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -514,11 +529,11 @@ extern "C" int lh_launch_beam_visibility(const lh_dev_scene_t *sc, size_t n, con
  * the device never evaluates tan() */
 extern "C" int lh_launch_beam_raster(const lh_dev_scene_t *sc, size_t n, const double *d_org, const double *d_dirs, const double *d_corner,
                                      const lh_raster_plane_t *plane, double ktan, double *d_t, int32_t *d_status, unsigned long long *d_flags,
-                                     void *stream)
+                                     void *stream, const lh_beam_set_t *d_preset)
 {
     if (n == 0) return 0;
     if (n > 0x7fffffffull) return -1;
     hipLaunchKernelGGL(k_beam_raster, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, *sc, n, d_org, d_dirs, d_corner, *plane, ktan,
-                       d_t, d_status, d_flags);
+                       d_t, d_status, d_flags, d_preset);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -382,7 +382,6 @@ int ri_beam_set(ri_beam_t *beam, ri_vector_t org, ri_vector_t dir[4])
             return -1;
         }
     }
-    for (j = 0; j < 4; j++) memcpy(beam->corner[j], dir[j], sizeof(ri_vector_t));
     memcpy(beam->org, org, sizeof(ri_vector_t));
     maxval = fabs(dir[0][0]); dom = 0;
     if (maxval < fabs(dir[0][1])) { maxval = fabs(dir[0][0]); dom = 1; }
@@ -402,6 +401,7 @@ int ri_beam_set(ri_beam_t *beam, ri_vector_t org, ri_vector_t dir[4])
     vcross(beam->normal[1], beam->dir[2], beam->dir[1]);
     vcross(beam->normal[2], beam->dir[3], beam->dir[2]);
     vcross(beam->normal[3], beam->dir[0], beam->dir[3]);
+    beam->is_tetrahedron = 0;
     return 0;
 }
 
@@ -416,15 +416,26 @@ int ri_hipbvh_intersect_beam_visibility_batch(void *accel, size_t n, const doubl
     return 0;
 }
 
+/* the members of a set-up ri_beam_t the beam walks read (lh_beam_set_t, lucille_hip.h) */
+static void beam_fields(lh_beam_set_t *o, const ri_beam_t *beam)
+{
+    int i, k;
+    for (k = 0; k < 3; k++) { o->org[k] = beam->org[k]; o->dirsign[k] = beam->dirsign[k]; }
+    for (i = 0; i < 4; i++) for (k = 0; k < 3; k++) { o->dir[i][k] = beam->dir[i][k]; o->normal[i][k] = beam->normal[i][k]; }
+    o->dominant_axis = beam->dominant_axis;
+}
+
 /* ri_bvh_intersect_beam_visibility, bvh.c:612-667: the beam was accepted by ri_beam_set */
 int ri_hipbvh_intersect_beam_visibility(void *accel, ri_beam_t *beam, void *user)
 {
-    double org[3], dirs[12]; int32_t cls = 0; int i, k;
+    hipbvh_t *h = (hipbvh_t *)accel; lh_beam_set_t b; int32_t cls = 0;
     (void)user;
-    if (!accel || !beam) return 0;
-    for (k = 0; k < 3; k++) org[k] = beam->org[k];
-    for (i = 0; i < 4; i++) for (k = 0; k < 3; k++) dirs[3 * i + k] = beam->corner[i][k];
-    if (ri_hipbvh_intersect_beam_visibility_batch(accel, 1, org, dirs, &cls) != 0) return 0;
+    if (!h || !beam) return 0;
+    beam_fields(&b, beam);
+    if (lh_accel_beam_visibility_set_host(h->lh, 1, &b, &cls) != 0) {
+        fprintf(stderr, "[lucille_hip] ERROR : (HIPBVH) %s\n", lh_last_error());
+        return 0;
+    }
     return cls < 0 ? 0 : (int)cls;
 }
 
@@ -489,14 +500,15 @@ int ri_hipbvh_intersect_beam_batch(void *accel, size_t n, const double *org, con
 /* ri_bvh_intersect_beam, bvh.c:544-609: the beam was accepted by ri_beam_set; always returns 0 */
 int ri_hipbvh_intersect_beam(void *accel, ri_beam_t *beam, ri_raster_plane_t *raster_out, void *user)
 {
-    double org[3], dirs[12], corner[3], frame9[9], eye[3]; int32_t st = 0; int i, k;
+    hipbvh_t *h = (hipbvh_t *)accel; lh_beam_set_t b; lh_raster_plane_t pl; double corner[3]; int32_t st = 0; int i, k;
     (void)user;
-    if (!accel || !beam || !raster_out || !raster_out->t) return 0;
-    for (k = 0; k < 3; k++) { org[k] = beam->org[k]; corner[k] = raster_out->corner[k]; eye[k] = raster_out->org[k]; }
-    for (i = 0; i < 4; i++) for (k = 0; k < 3; k++) dirs[3 * i + k] = beam->corner[i][k];
-    for (i = 0; i < 3; i++) for (k = 0; k < 3; k++) frame9[3 * i + k] = raster_out->frame[i][k];
-    ri_hipbvh_intersect_beam_batch(accel, 1, org, dirs, corner, raster_out->width, raster_out->height, frame9, eye, raster_out->fov,
-                                   raster_out->t, &st, NULL);
+    if (!h || !beam || !raster_out || !raster_out->t) return 0;
+    beam_fields(&b, beam);
+    pl.width = raster_out->width; pl.height = raster_out->height; pl.fov = raster_out->fov;
+    for (i = 0; i < 3; i++) for (k = 0; k < 3; k++) pl.frame[3 * i + k] = raster_out->frame[i][k];
+    for (k = 0; k < 3; k++) { corner[k] = raster_out->corner[k]; pl.eye[k] = raster_out->org[k]; }
+    if (lh_accel_beam_raster_set_host(h->lh, 1, &b, corner, &pl, raster_out->t, &st, NULL) != 0)
+        fprintf(stderr, "[lucille_hip] ERROR : (HIPBVH) %s\n", lh_last_error());
     return 0;
 }
 

@@ -53,12 +53,17 @@ static inline int hw_node4(const lh_ray32_t *r, const lh_q4node_t *n, float tb, 
     const __m128 nx = _mm_cvtepi32_ps(r->ngx ? hx : lx), fx = _mm_cvtepi32_ps(r->ngx ? lx : hx);
     const __m128 ny = _mm_cvtepi32_ps(r->ngy ? hy : ly), fy = _mm_cvtepi32_ps(r->ngy ? ly : hy);
     const __m128 nz = _mm_cvtepi32_ps(r->ngz ? hz : lz), fz = _mm_cvtepi32_ps(r->ngz ? lz : hz);
-    const __m128 tn = _mm_max_ps(_mm_max_ps(_mm_fmadd_ps(nx, _mm_set1_ps(r->qax), _mm_set1_ps(r->qbnx)), _mm_fmadd_ps(ny, _mm_set1_ps(r->qay), _mm_set1_ps(r->qbny))),
-                                 _mm_max_ps(_mm_fmadd_ps(nz, _mm_set1_ps(r->qaz), _mm_set1_ps(r->qbnz)), _mm_setzero_ps()));
-    const __m128 tf = _mm_min_ps(_mm_min_ps(_mm_fmadd_ps(fx, _mm_set1_ps(r->qax), _mm_set1_ps(r->qbfx)), _mm_fmadd_ps(fy, _mm_set1_ps(r->qay), _mm_set1_ps(r->qbfy))),
-                                 _mm_min_ps(_mm_fmadd_ps(fz, _mm_set1_ps(r->qaz), _mm_set1_ps(r->qbfz)), _mm_set1_ps(tb)));
+    const __m128 anx = _mm_fmadd_ps(nx, _mm_set1_ps(r->qax), _mm_set1_ps(r->qbnx)), any_ = _mm_fmadd_ps(ny, _mm_set1_ps(r->qay), _mm_set1_ps(r->qbny)),
+                 anz = _mm_fmadd_ps(nz, _mm_set1_ps(r->qaz), _mm_set1_ps(r->qbnz));
+    const __m128 afx = _mm_fmadd_ps(fx, _mm_set1_ps(r->qax), _mm_set1_ps(r->qbfx)), afy = _mm_fmadd_ps(fy, _mm_set1_ps(r->qay), _mm_set1_ps(r->qbfy)),
+                 afz = _mm_fmadd_ps(fz, _mm_set1_ps(r->qaz), _mm_set1_ps(r->qbfz));
+    const __m128 tn = _mm_max_ps(_mm_max_ps(anx, any_), _mm_max_ps(anz, _mm_setzero_ps()));
+    const __m128 tf = _mm_min_ps(_mm_min_ps(afx, afy), _mm_min_ps(afz, _mm_set1_ps(tb)));
+    /* an unordered plane distance in ANY of the six products: _mm_max_ps / _mm_min_ps return their second operand when one is a NaN,
+     * so a NaN in a FIRST operand would be dropped before tn / tf are looked at */
+    const __m128 unord = _mm_or_ps(_mm_or_ps(_mm_cmpunord_ps(anx, any_), _mm_cmpunord_ps(anz, afx)), _mm_cmpunord_ps(afy, afz));
     int c, mask;
-    if (__builtin_expect(_mm_movemask_ps(_mm_cmpunord_ps(tn, tf)) != 0 || tb != tb, 0)) {
+    if (__builtin_expect(_mm_movemask_ps(unord) != 0 || tb != tb, 0)) {
         mask = 0;
         for (c = 0; c < 4; c++) if (lh_slab_w(r, n->w[c][0], n->w[c][1], n->w[c][2], tb, &tn_out[c])) mask |= 1 << c;
     } else {
@@ -101,7 +106,8 @@ static void hw_resolve(const lh_bvh_t *b, const lh_refbvh_t *ref, uint32_t prim,
     }
 }
 
-/* closest hit of one ray.  ref: lucille's own tree (or NULL).  Returns 1 on a hit, 0 on a miss; outputs always written. */
+/* closest hit of one ray.  ref: lucille's own tree (or NULL).  Returns 1 on a hit, 0 on a miss (outputs written), -2 when the walk could
+ * not be finished here (stack rows) and there is no reference tree to ask. */
 int lh_host_walk_closest(const lh_bvh_t *b, const lh_refbvh_t *ref, const double o[3], const double d[3],
                          uint32_t *prim, double *t, double *u, double *v)
 {
@@ -114,7 +120,7 @@ int lh_host_walk_closest(const lh_bvh_t *b, const lh_refbvh_t *ref, const double
     if (!refw) {
         lh_ray32_t r; float tb = 1.0e38f, scene_r = 0.0f;
         int32_t stack[HW_STACK]; int sp = 0, k; int32_t cur = 0;
-        uint32_t pend[4]; int np = 0;
+        uint32_t pend[4]; int np = 0, ovf = 0;
         for (k = 0; k < 3; k++) { scene_r = fmaxf(scene_r, fabsf(b->bmin[k])); scene_r = fmaxf(scene_r, fabsf(b->bmax[k])); }
         lh_ray_setup(&r, o[0], o[1], o[2], d[0], d[1], d[2], scene_r);
         lh_ray_setup_grid(&r, b->grid_lo, b->grid_step, scene_r);
@@ -131,7 +137,7 @@ int lh_host_walk_closest(const lh_bvh_t *b, const lh_refbvh_t *ref, const double
                     for (m = nh; m > 0 && key[m - 1] > kc; m--) { key[m] = key[m - 1]; slot[m] = slot[m - 1]; }
                     key[m] = kc; slot[m] = c; nh++;
                 }
-                for (m = nh - 1; m >= 1; m--) if (sp < HW_STACK) stack[sp++] = n->ref[slot[m]];
+                for (m = nh - 1; m >= 1; m--) { if (sp < HW_STACK) stack[sp++] = n->ref[slot[m]]; else ovf = 1; }
                 if (nh) cur = n->ref[slot[0]];
                 else if (sp) cur = stack[--sp];
                 else break;
@@ -151,6 +157,10 @@ int lh_host_walk_closest(const lh_bvh_t *b, const lh_refbvh_t *ref, const double
         }
         for (k = 0; k < np; k++) hw_resolve(b, ref, pend[k], o, d, &best);
         refw = ref && best.prim != HW_MISS && best.frag != 0u;           /* a hit the reference may not reach: its own walk decides */
+        /* the private stack was full and children were left out (a tree deeper than HW_STACK covers: no builder of this library makes
+         * one today): the walk's answer is not to be trusted -- the reference's own walk decides, or, without its tree, the caller
+         * takes the device path (-2), whose cooperative walk has no such limit */
+        if (ovf) { if (ref) refw = 1; else return -2; }
     }
     if (refw) {
         uint32_t p; double tt, uu, vv;

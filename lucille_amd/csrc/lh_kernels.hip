@@ -133,9 +133,12 @@ constexpr uint32_t kRegroupMask = 63u;   /* the walk returns to the regroup poin
 
 /* RING: stack positions are taken modulo ring_mask + 1 rows (k_coop_walk: a lane that gives entries away from the bottom of
  * its stack drifts upwards without bound); the persistent kernel indexes rows directly */
-/* SORTED = false (an occlusion query over its own rays: the fused AO stage): the hit children go onto the stack in SLOT order, no
- * ranking by entry distance -- any hit ends the ray, the culling bound never moves, so the order only decides how soon an occluded
- * ray meets its occluder, and the step loses its six key comparisons and rank sums (~27 of 136 VALU operations).  LH_AO_UNSORTED */
+/* SORTED = false (EVERY any-hit walk over the 4-wide nodes: the fused AO stage, SRC 1, and any-hit ray dumps, SRC 0 -- the macro's
+ * name dates from the first of the two): the hit children go onto the stack in SLOT order, no ranking by entry distance -- any hit
+ * ends the ray, the culling bound never moves, so the order only decides how soon an occluded ray meets its occluder, and the step
+ * loses its six key comparisons and rank sums (~27 of 136 VALU operations).  Answers do not depend on it; visit counts do (r05,
+ * profiles/README.md: config-5 AO frame 14.76 -> 14.07 node visits per ray, S-soup-1M any-hit dump 38.85 -> 38.45 and 2 677 -> 2 784
+ * Mrays/s), and with them how many rays run past ray_budget into the cooperative walk.  LH_AO_UNSORTED=0 restores the ranking. */
 #ifndef LH_AO_UNSORTED
 #define LH_AO_UNSORTED 1
 #endif
@@ -600,7 +603,9 @@ __device__ __forceinline__ void trace_persist_lane(
                 lane_init(L, sc, ox, oy, oz, dx, dy, dz);
                 best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM; best.frag = 0u;
                 stk[0][tid] = kDone;
-                if (SRC == 0 && __builtin_expect(ray_needs_ref_walk(sc, dx, dy, dz), 0)) LH_FORCE_REF_WALK(L, best);      /* camera and AO rays are unit vectors */
+                /* camera and AO rays are unit vectors: beyond deg_dcap only where a zero-area triangle of |e1|_1 |e2|_1 > 1 stayed in the tree
+                 * (lh_bvh.c tri_zero_area_s2: deg_dcap = 1 / s2 < 1) -- then every source takes the test (wave-uniform) */
+                if ((SRC == 0 || sc.deg_dcap < 1.0f) && __builtin_expect(ray_needs_ref_walk(sc, dx, dy, dz), 0)) LH_FORCE_REF_WALK(L, best);
                 it0 = it;
             }
             wbase += take;

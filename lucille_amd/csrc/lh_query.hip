@@ -482,11 +482,14 @@ extern "C" int lh_accel_intersect1(lh_accel_t *a, const double org[3], const dou
                 a->hw_ns = mean;                              /* racy by design: a statistic */
                 if (mean > max_ns && k >= 255ull) __atomic_store_n(&a->hw_gpu_left, 65536, __ATOMIC_RELAXED);       /* long walks (four samples or more agree): the device for a while, then another look */
             }
-            if (prim) *prim = p;
-            if (t) *t = tt;
-            if (u) *u = uu;
-            if (v) *v = vv;
-            return hit;
+            if (hit != -2) {
+                if (prim) *prim = p;
+                if (t) *t = tt;
+                if (u) *u = uu;
+                if (v) *v = vv;
+                return hit;
+            }
+            p = LH_MISS_PRIM; tt = LH_T_INF; uu = vv = 0.0;          /* the host walk ran out of stack rows: this ray through the device */
         }
         if (trees_here) __atomic_fetch_sub(&a->hw_gpu_left, 1, __ATOMIC_RELAXED);
     }
@@ -649,7 +652,7 @@ extern "C" int lh_accel_intersect_diag_device(lh_accel_t *a, size_t n, const voi
 /* beam visibility                                                          */
 /* ------------------------------------------------------------------------ */
 extern "C" int lh_launch_beam_visibility(const lh_dev_scene_t *sc, size_t n, const double *d_org, const double *d_dirs,
-                                         int32_t *d_result, void *stream);
+                                         int32_t *d_result, void *stream, const lh_beam_set_t *d_preset);
 
 __global__ void k_fill_i32(size_t n, int32_t *p, int32_t v)
 {
@@ -657,19 +660,26 @@ __global__ void k_fill_i32(size_t n, int32_t *p, int32_t v)
     if (i < n) p[i] = v;
 }
 
+static int beam_visibility_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dirs, void *d_result, void *stream, const lh_beam_set_t *d_preset);
+
 extern "C" int lh_accel_beam_visibility_device(lh_accel_t *a, size_t n, const void *d_org, const void *d_dirs,
                                                void *d_result, void *stream)
+{
+    return beam_visibility_launch(a, n, d_org, d_dirs, d_result, stream, NULL);
+}
+
+static int beam_visibility_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dirs, void *d_result, void *stream, const lh_beam_set_t *d_preset)
 {
     lh_guard guard(a);
     if (!a || !a->committed) return fail("beam_visibility: accel not committed");
     if (n == 0) return 0;
-    if (!d_org || !d_dirs || !d_result) return fail("beam_visibility: NULL argument");
+    if ((!d_preset && (!d_org || !d_dirs)) || !d_result) return fail("beam_visibility: NULL argument");
     if (!a->hs->have_ref) return fail("beam_visibility: the reference-order tree was disabled (LH_REFTREE=0)");
     if (lh_sync_ref(a, true) != 0) return -1;
     HIPCHK(hipSetDevice(a->device));
     lh_dev_scene_t sc = a->dev;
     if (a->hs->bvh.ntris == 0) { sc.ref_empty = 1; }
-    if (lh_launch_beam_visibility(&sc, n, (const double *)d_org, (const double *)d_dirs, (int32_t *)d_result, stream) != 0)
+    if (lh_launch_beam_visibility(&sc, n, (const double *)d_org, (const double *)d_dirs, (int32_t *)d_result, stream, d_preset) != 0)
         return fail("beam kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     return 0;
 }
@@ -692,21 +702,47 @@ extern "C" int lh_accel_beam_visibility_host(lh_accel_t *a, size_t n, const doub
     return 0;
 }
 
+/* beams the caller's own ri_beam_set has set up (lh_beam_set_t: ri_bvh_intersect_beam_visibility's argument, bvh.h:208-221) */
+extern "C" int lh_accel_beam_visibility_set_host(lh_accel_t *a, size_t n, const lh_beam_set_t *beams, int32_t *result)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("beam_visibility: accel not committed");
+    if (n == 0) return 0;
+    if (!beams || !result) return fail("beam_visibility: NULL argument");
+    HIPCHK(hipSetDevice(a->device));
+    const size_t bb = sizeof(lh_beam_set_t) * n, br = sizeof(int32_t) * n;
+    if (lh_ensure_stage(a, bb + br + 64) != 0) return -1;
+    char *base = (char *)a->d_stage;
+    HIPCHK(hipMemcpyAsync(base, beams, bb, hipMemcpyHostToDevice, a->stream));
+    if (beam_visibility_launch(a, n, NULL, NULL, base + bb, a->stream, (const lh_beam_set_t *)base) != 0) return -1;
+    HIPCHK(hipMemcpyAsync(result, base + bb, br, hipMemcpyDeviceToHost, a->stream));
+    HIPCHK(hipStreamSynchronize(a->stream));
+    return 0;
+}
 
 /* ------------------------------------------------------------------------ */
 /* the beam-raster path (ri_bvh_intersect_beam, bvh.c:544-609)               */
 /* ------------------------------------------------------------------------ */
 extern "C" int lh_launch_beam_raster(const lh_dev_scene_t *sc, size_t n, const double *d_org, const double *d_dirs, const double *d_corner,
                                      const lh_raster_plane_t *plane, double ktan, double *d_t, int32_t *d_status, unsigned long long *d_flags,
-                                     void *stream);
+                                     void *stream, const lh_beam_set_t *d_preset);
+
+static int beam_raster_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dirs, const void *d_corner, const lh_raster_plane_t *plane,
+                              void *d_t, void *d_status, void *d_flags, void *stream, const lh_beam_set_t *d_preset);
 
 extern "C" int lh_accel_beam_raster_device(lh_accel_t *a, size_t n, const void *d_org, const void *d_dirs, const void *d_corner,
                                            const lh_raster_plane_t *plane, void *d_t, void *d_status, void *d_flags, void *stream)
 {
+    return beam_raster_launch(a, n, d_org, d_dirs, d_corner, plane, d_t, d_status, d_flags, stream, NULL);
+}
+
+static int beam_raster_launch(lh_accel_t *a, size_t n, const void *d_org, const void *d_dirs, const void *d_corner, const lh_raster_plane_t *plane,
+                              void *d_t, void *d_status, void *d_flags, void *stream, const lh_beam_set_t *d_preset)
+{
     lh_guard guard(a);
     if (!a || !a->committed) return fail("beam_raster: accel not committed");
     if (n == 0) return 0;
-    if (!d_org || !d_dirs || !d_corner || !plane || !d_t || !d_status) return fail("beam_raster: NULL argument");
+    if ((!d_preset && (!d_org || !d_dirs)) || !d_corner || !plane || !d_t || !d_status) return fail("beam_raster: NULL argument");
     if (plane->width <= 0 || plane->height <= 0) return fail("beam_raster: the raster window is %d x %d", plane->width, plane->height);
     if (!a->hs->have_ref) return fail("beam_raster: the reference-order tree was disabled (LH_REFTREE=0)");
     if (lh_sync_ref(a, true) != 0) return -1;
@@ -717,7 +753,7 @@ extern "C" int lh_accel_beam_raster_device(lh_accel_t *a, size_t n, const void *
     const double fov_rad = plane->fov * M_PI / 180.0;
     const double ktan = 1.0 / tan(0.5 * fov_rad);
     if (lh_launch_beam_raster(&sc, n, (const double *)d_org, (const double *)d_dirs, (const double *)d_corner, plane, ktan, (double *)d_t,
-                              (int32_t *)d_status, (unsigned long long *)d_flags, stream) != 0)
+                              (int32_t *)d_status, (unsigned long long *)d_flags, stream, d_preset) != 0)
         return fail("beam raster kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
     return 0;
 }
@@ -743,6 +779,32 @@ extern "C" int lh_accel_beam_raster_host(lh_accel_t *a, size_t n, const double *
     /* planes that are not traced keep the caller's contents: the staging copy starts as the caller's */
     HIPCHK(hipMemcpyAsync(d_t, t_out, bt, hipMemcpyHostToDevice, a->stream));
     if (lh_accel_beam_raster_device(a, n, d_org, d_dirs, d_corner, plane, d_t, d_st, d_fl, a->stream) != 0) return -1;
+    HIPCHK(hipMemcpyAsync(t_out, d_t, bt, hipMemcpyDeviceToHost, a->stream));
+    HIPCHK(hipMemcpyAsync(status, d_st, sizeof(int32_t) * n, hipMemcpyDeviceToHost, a->stream));
+    if (flags) HIPCHK(hipMemcpyAsync(flags, d_fl, bf, hipMemcpyDeviceToHost, a->stream));
+    HIPCHK(hipStreamSynchronize(a->stream));
+    return 0;
+}
+
+extern "C" int lh_accel_beam_raster_set_host(lh_accel_t *a, size_t n, const lh_beam_set_t *beams, const double *corner,
+                                             const lh_raster_plane_t *plane, double *t_out, int32_t *status, uint64_t *flags)
+{
+    lh_guard guard(a);
+    if (!a || !a->committed) return fail("beam_raster: accel not committed");
+    if (n == 0) return 0;
+    if (!beams || !corner || !plane || !t_out || !status) return fail("beam_raster: NULL argument");
+    if (plane->width <= 0 || plane->height <= 0) return fail("beam_raster: the raster window is %d x %d", plane->width, plane->height);
+    HIPCHK(hipSetDevice(a->device));
+    const size_t px = (size_t)plane->width * (size_t)plane->height;
+    const size_t bb = (sizeof(lh_beam_set_t) * n + 15) & ~(size_t)15, bo = sizeof(double) * 3 * n, bt = sizeof(double) * px * n,
+                 bs = (sizeof(int32_t) * n + 7) & ~(size_t)7, bf = sizeof(uint64_t) * 4 * n;
+    if (lh_ensure_stage(a, bb + bo + bt + bs + bf + 64) != 0) return -1;
+    char *base = (char *)a->d_stage;
+    char *d_beams = base, *d_corner = base + bb, *d_t = d_corner + bo, *d_st = d_t + bt, *d_fl = d_st + bs;
+    HIPCHK(hipMemcpyAsync(d_beams, beams, sizeof(lh_beam_set_t) * n, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_corner, corner, bo, hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemcpyAsync(d_t, t_out, bt, hipMemcpyHostToDevice, a->stream));         /* planes that are not traced keep the caller's contents */
+    if (beam_raster_launch(a, n, NULL, NULL, d_corner, plane, d_t, d_st, d_fl, a->stream, (const lh_beam_set_t *)d_beams) != 0) return -1;
     HIPCHK(hipMemcpyAsync(t_out, d_t, bt, hipMemcpyDeviceToHost, a->stream));
     HIPCHK(hipMemcpyAsync(status, d_st, sizeof(int32_t) * n, hipMemcpyDeviceToHost, a->stream));
     if (flags) HIPCHK(hipMemcpyAsync(flags, d_fl, bf, hipMemcpyDeviceToHost, a->stream));

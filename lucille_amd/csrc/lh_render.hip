@@ -432,8 +432,9 @@ struct PtPass {
 __device__ __forceinline__ unsigned long long pt_fix(float r)
 {
     r = fminf(fmaxf(r, -LH_PT_FIX_CLAMP), LH_PT_FIX_CLAMP);          /* (a NaN never gets here: pt_accumulate drops it) */
-    const float fl = floorf(r);
-    const uint32_t lo = (uint32_t)((r - fl) * 4294967296.0f);          /* the fraction is exact in fp32, below 1 - 2^-24: no carry */
+    float fl = floorf(r), fr = r - fl;          /* fr is exact in fp32 -- except for a tiny negative r (-1e-10: floor -1, r + 1 rounds to 1.0f) */
+    if (fr >= 1.0f) { fr = 0.0f; fl += 1.0f; }  /* ... which is the carry: without it (uint32_t)(1.0f * 2^32) is out of range */
+    const uint32_t lo = (uint32_t)(fr * 4294967296.0f);
     return ((unsigned long long)(long long)(int)fl << 32) | (unsigned long long)lo;
 }
 

@@ -49,7 +49,9 @@
 
 #ifdef LREF_WITH_HIP
 extern int ri_accel_bind_hip(ri_accel_t *accel);   /* integration/ri_accel_hip.c */
-extern int ri_hipbvh_intersect_beam(void *accel, ri_beam_t *beam, ri_vector_t corner_dirs[4], ri_raster_plane_t *raster_out, void *user);
+extern int ri_hipbvh_intersect_beam(void *accel, ri_beam_t *beam, ri_raster_plane_t *raster_out, void *user);
+extern int ri_hipbvh_intersect_beam_visibility(void *accel, ri_beam_t *beam, void *user);
+extern int ri_hipbvh_intersect_beam_visibility_n(void *accel, size_t n, ri_beam_t *beams, int *result);
 #endif
 
 /* ---------------------------------------------------------------------- */
@@ -512,13 +514,43 @@ int lref_beam_raster_hip(const double *org, const double *dirs, int w, int h, co
     if (rc == 0) {
         if (!plane) plane = ri_raster_plane_new();
         ri_raster_plane_setup(plane, w, h, fr, cn, ey, fov);
-        rc = ri_hipbvh_intersect_beam(accel, &beam, d, plane, NULL);
+        rc = ri_hipbvh_intersect_beam(accel, &beam, plane, NULL);
         memcpy(t_out, plane->t, sizeof(double) * (size_t)w * (size_t)h);
     } else rc = -1;
     fflush(nul);
     stderr = saved_err; stdout = saved_out;
     fclose(nul);
     return rc;
+}
+
+/* lref_beam_visibility_batch with the scene's accelerator bound to RI_ACCEL_HIP: the reference's own ri_beam_set on the
+ * reference's own ri_beam_t, then the glue's ri_hipbvh_intersect_beam_visibility (integration/ri_accel_hip.c) in place of
+ * ri_bvh_intersect_beam_visibility -- one call per beam (together 0) or every accepted beam in one launch (together 1) */
+void lref_beam_visibility_hip_batch(size_t n, const double *org, const double *dirs, int32_t *result, int together)
+{
+    size_t r, m = 0; void *accel = ri_render_get()->scene->accel->data;
+    FILE *saved = stderr;
+    ri_beam_t *beams = (ri_beam_t *)calloc(n ? n : 1, sizeof(ri_beam_t)); size_t *slot = (size_t *)calloc(n ? n : 1, sizeof(size_t));
+    for (r = 0; r < n; r++) {
+        ri_beam_t *beam = &beams[m]; ri_vector_t o, d[4]; int i, k;
+        memset(beam, 0, sizeof(*beam));
+        for (k = 0; k < 3; k++) o[k] = org[3 * r + k];
+        o[3] = 0.0;
+        for (i = 0; i < 4; i++) { for (k = 0; k < 3; k++) d[i][k] = dirs[12 * r + 3 * i + k]; d[i][3] = 0.0; }
+        stderr = fopen("/dev/null", "w");
+        i = ri_beam_set(beam, o, d);
+        fclose(stderr); stderr = saved;
+        if (i != 0) { result[r] = -1; continue; }
+        if (!together) result[r] = ri_hipbvh_intersect_beam_visibility(accel, beam, NULL);
+        else slot[m++] = r;
+    }
+    if (together && m) {
+        int *cls = (int *)calloc(m, sizeof(int));
+        if (ri_hipbvh_intersect_beam_visibility_n(accel, m, beams, cls) != 0) for (r = 0; r < m; r++) cls[r] = -2;
+        for (r = 0; r < m; r++) result[slot[r]] = cls[r];
+        free(cls);
+    }
+    free(beams); free(slot);
 }
 #endif
 

@@ -228,6 +228,6 @@ int lh_host_walk_closest(const lh_bvh_t *b, const lh_refbvh_t *ref, const double
 int lhm_hostwalk(const lh_bvh_t *b, const lh_refbvh_t *ref, size_t n, const double *org, const double *dir, uint32_t *prim, double *t, double *u, double *v)
 {
     size_t i; int hits = 0;
-    for (i = 0; i < n; i++) hits += lh_host_walk_closest(b, ref, org + 3 * i, dir + 3 * i, prim + i, t + i, u + i, v + i);
+    for (i = 0; i < n; i++) hits += lh_host_walk_closest(b, ref, org + 3 * i, dir + 3 * i, prim + i, t + i, u + i, v + i) > 0;
     return hits;
 }

@@ -165,3 +165,45 @@ def test_every_queued_any_hit_ray_gets_its_answer():
     acc.intersect_device(d_o, d_d, out=(pr, tt, uu, vv)); torch.cuda.synchronize()
     assert_hits_equal((pr.cpu().numpy(), tt.cpu().numpy(), uu.cpu().numpy(), vv.cpu().numpy()), exp, "the fan, closest hit")
     acc.close()
+
+
+@pytest.mark.parametrize("build", ["host", "device"])
+def test_one_large_collinear_triangle_sends_every_ray_source_through_the_reference_walk(build):
+    """a numerically collinear triangle with |e1|_1 |e2|_1 > 1 that stays in the tree pulls deg_dcap = 1 / s2
+    below 1 -- below 0.577 EVERY unit-length ray has a component beyond it and belongs to the reference's own walk.  The ray dumps
+    (rays from arrays) applied that rule, the fused AO stage (rays generated in the refill) skipped it "because AO rays are unit
+    vectors": the tile pipeline and the dump path answered the same ray by different rules.  Now every source takes the test:
+    the fused stage's rays take ONE node step each (the root, under a negative culling bound) and go to the reference walk,
+    the frame equals the materialised stage's (dump path) bit for bit and the AO rays' occlusion equals the oracle's."""
+    import torch
+    g = load_golden("ao_c1")
+    allp = np.concatenate([g["pos%d" % k][:, :3] for k in range(int(g["ngeoms"]))]); lo, hi = allp.min(0), allp.max(0)
+    rng = np.random.default_rng(77)
+    ntri = 600
+    ctr = rng.uniform(0, 1, (ntri, 1, 3)); T = (ctr + rng.normal(size=(ntri, 3, 3)) * 0.08) * (hi - lo) + lo
+    a = 0.5 * (lo + hi); d = np.array([0.6, 0.1, 0.79]); d /= np.linalg.norm(d)
+    Z = np.stack([a - 4.0 * d, a + 5.0 * d, a - 4.0 * d + 1.75 * (9.0 * d)])[None]          # three different points on one line, 9 and 15.75 units
+    P = np.concatenate([T, Z]).reshape(-1, 3).copy(); idx = np.arange(P.shape[0], dtype=np.uint32)
+    c = g["camera"]; W, H, ns = 64, 48, 16
+    cam = la.Camera.make(W, H, c[16], c[:16], int(c[19]))
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit(build=build); acc.wait_exact()
+    assert acc.info()["ntriangles_in_tree"] == ntri + 1              # too large for class 2, no two equal vertices: it stays
+    acc.set_param("ao_fused", 1)
+    img_f, st_f = acc.render_ao_tile(cam, 0, 0, W, H, 1, ns, seed=9)
+    acc.set_param("ao_fused", 0)
+    img_m, st_m = acc.render_ao_tile(cam, 0, 0, W, H, 1, ns, seed=9)
+    aorg = acc.scratch(8, np.float64, 3); adir = acc.scratch(9, np.float64, 3); occ = acc.scratch(10, np.uint8, 1)
+    torch.cuda.synchronize()
+    assert st_f == st_m and st_f["ao_rays"] > 5000 and torch.equal(img_f, img_m)
+    ok = np.abs(adir[:, 1]) > 1e-14
+    exp = o.intersect(aorg[ok], adir[ok], nthreads=8)
+    assert np.array_equal(occ[ok].astype(bool).ravel(), exp[0] != po.MISS)
+    # the fused stage by itself, counted: one node step per ray (camera rays and AO rays alike), everything else by the reference walk
+    acc.set_param("ao_fused", 1)
+    acc.trace_statistics(True); acc.statistics(clear=True)
+    acc.render_ao_tile(cam, 0, 0, W, H, 1, ns, seed=9); torch.cuda.synchronize()
+    cnt = acc.statistics(clear=True); acc.trace_statistics(False)
+    assert cnt["rays"] == st_f["primary_rays"] + st_f["ao_rays"]
+    assert 0 < cnt["nodes"] <= cnt["rays"] and cnt["tris"] == 0, cnt
+    acc.close()

@@ -1,8 +1,8 @@
 """Randomised sweep of the AO tile pipeline: random soups (some with zero-area triangles, some with vertex normals) in the example
 camera's view; the fused stage (rays generated inside the any-hit kernel) against the materialised one -- frames bit-equal, counts
 equal -- and the materialised AO rays' occlusion against the oracle's closest-hit answer for the same rays; both builders.
-python tools/fuzz_ao.py [seed] [rounds]"""
-import os, sys
+python tools/fuzz_ao.py [seed] [rounds]          (FUZZ_BUDGET_S=<seconds>: no new round after that long)"""
+import os, sys, time
 os.environ.setdefault("LH_POISON_OUTPUTS", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,8 +15,9 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1; rounds = int(sys.argv[2]) i
 rng = np.random.default_rng(seed)
 g = load_golden("ao_c1")
 allp = np.concatenate([g["pos%d" % k][:, :3] for k in range(int(g["ngeoms"]))]); lo, hi = allp.min(0), allp.max(0)
-c = g["camera"]; nrays = 0
+c = g["camera"]; nrays = 0; done = 0; T0 = time.time(); BUDGET = float(os.environ.get("FUZZ_BUDGET_S", "0"))
 for r in range(rounds):
+    if BUDGET > 0 and time.time() - T0 > BUDGET: break
     ntri = int(rng.choice([1, 6, 50, 800, 20000, 200000])); he = float(10.0 ** rng.uniform(-2.5, -0.3))
     ctr = rng.uniform(0, 1, (ntri, 1, 3)); T = (ctr + rng.normal(size=(ntri, 3, 3)) * he) * (hi - lo) + lo
     if r % 3 == 1: T[::4, 2] = T[::4, 1]
@@ -47,4 +48,5 @@ for r in range(rounds):
                 print("MISMATCH round %d build %s: occlusion of %d AO rays" % (r, build, int((occ[ok].astype(bool).ravel() != (exp[0] != po.MISS)).sum()))); sys.exit(1)
             nrays += int(ok.sum())
         acc.close()
-print("%d AO rays over %d frames x 2 builders: fused == materialised bit for bit, occlusion equal to the oracle" % (nrays, rounds))
+    done += 1
+print("%d AO rays over %d frames x 2 builders: fused == materialised bit for bit, occlusion equal to the oracle" % (nrays, done))

@@ -21,7 +21,8 @@
 // (181-193 G/s) overstate the quad-cooperative ceiling.  GATHER_PERTURB=1 (default now) xors the chain's own running sum into
 // the link, as modes 0, 2, 4, 5, 7, 8 always did.
 template <int MODE, bool PERTURB>
-__global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ nodes, uint32_t nnodes, int steps, uint32_t *out, int alu)
+__global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ nodes, uint32_t nnodes, int steps, uint32_t *out, int alu,
+                                                const uint4 *__restrict__ tris = nullptr, uint32_t ntris = 0, int node_steps = 8)
 {
     const uint32_t gid = blockIdx.x * 256 + threadIdx.x;
     uint32_t acc = 0;
@@ -85,6 +86,32 @@ __global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ nodes,
             acc += a.y + b.y;
             uint32_t nx = __shfl(a.x, (threadIdx.x & 63) & ~3);
             cur = (nx ^ (PERTURB ? (__shfl(acc, (threadIdx.x & 63) & ~3) & 1) : 0)) % (nnodes / 2);
+        }
+    } else if (MODE == 10 || MODE == 11) {
+        /* TWO arrays (round 6): `node_steps` dependent node records (64 B: mode 10, 128 B: mode 11) out of
+         * `nodes`, then one 48-byte triangle record out of `tris`, and again -- the 8-wide walk's mix on S-soup-10M
+         * (39.7 node + 5.1 triangle records per ray).  nnodes counts records of the mode's own size. */
+        uint32_t cur = (gid * 2654435761u) % nnodes;
+        int k = (int)(gid % (uint32_t)(node_steps + 1));              /* chains out of phase: the mix is the same at every instant */
+        for (int s = 0; s < steps; s++) {
+            uint32_t link;
+            if (k == node_steps) {
+                const uint4 *p = tris + 3 * (size_t)((cur * 40503u + acc) % ntris);
+                uint4 a = p[0], b = p[1], c = p[2];
+                acc += a.y + b.y + c.y; link = a.x; k = 0;
+                ALU_PAD(b);
+            } else if (MODE == 10) {
+                const uint4 *p = nodes + 4 * (size_t)cur;
+                uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+                acc += a.y + b.y + c.y + d.y; link = a.x; k++;
+                ALU_PAD(b);
+            } else {
+                const uint4 *p = nodes + 8 * (size_t)cur;
+                uint4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], g = p[6], h = p[7];
+                acc += a.y + b.y + c.y + d.y + e.y + f.y + g.y + h.y; link = a.x; k++;
+                ALU_PAD(b);
+            }
+            cur = (link ^ (acc & 1)) % nnodes;
         }
     } else if (MODE == 7) {          /* 256-byte nodes (2 lines), one chain per lane, first 5 x dwordx4 (80 B used) */
         uint32_t cur = (gid * 2654435761u) % (nnodes / 4);
@@ -151,9 +178,34 @@ int main(int argc, char **argv)
     const int alu = getenv("GATHER_ALU") ? atoi(getenv("GATHER_ALU")) : 0;
     if (alu) printf("%d FMAs per step between the load and the next link\n", alu);
     if (lds) printf("dynamic LDS %zu bytes per block: at most %zu blocks (%zu waves per SIMD) per CU\n", lds, (size_t)(160 * 1024) / lds, (size_t)(160 * 1024) / lds);
+    /* GATHER_NODE_MB / GATHER_TRI_MB (modes 10, 11): node records and triangle records in arrays of their own */
+    const size_t node_mb = getenv("GATHER_NODE_MB") ? (size_t)atol(getenv("GATHER_NODE_MB")) : 0, tri_mb = getenv("GATHER_TRI_MB") ? (size_t)atol(getenv("GATHER_TRI_MB")) : 0;
+    const int node_steps = getenv("GATHER_NODE_STEPS") ? atoi(getenv("GATHER_NODE_STEPS")) : 8;
+    uint4 *dn = nullptr, *dt = nullptr;
+    if (node_mb && tri_mb) {
+        std::vector<uint32_t> hh((node_mb > tri_mb ? node_mb : tri_mb) * 1024 * 1024 / 4);
+        for (size_t i = 0; i < hh.size(); i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; hh[i] = (uint32_t)(x >> 20); }
+        CHK(hipMalloc(&dn, node_mb << 20)); CHK(hipMalloc(&dt, tri_mb << 20));
+        CHK(hipMemcpy(dn, hh.data(), node_mb << 20, hipMemcpyHostToDevice)); CHK(hipMemcpy(dt, hh.data(), tri_mb << 20, hipMemcpyHostToDevice));
+    }
     for (int a = 4; a < argc; a++) {
         const int mode = atoi(argv[a]);
         float best = 1e30f;
+        if (mode == 10 || mode == 11) {
+            if (!dn) { printf("modes 10 / 11 need GATHER_NODE_MB and GATHER_TRI_MB\n"); return 1; }
+            const uint32_t nrec = (uint32_t)((node_mb << 20) / (mode == 10 ? 64 : 128)), ntri = (uint32_t)((tri_mb << 20) / 48);
+            for (int rep = 0; rep < 4; rep++) {
+                CHK(hipEventRecord(e0));
+                if (mode == 10) hipLaunchKernelGGL((k_gather<10, true>), dim3(blocks), dim3(256), lds, 0, dn, nrec, steps, out, alu, dt, ntri, node_steps);
+                else            hipLaunchKernelGGL((k_gather<11, true>), dim3(blocks), dim3(256), lds, 0, dn, nrec, steps, out, alu, dt, ntri, node_steps);
+                CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1)); if (rep > 0 && ms < best) best = ms;
+            }
+            const double g = (double)blocks * 256 * steps / (best * 1e-3) / 1e9;
+            printf("nodes %4zu MB of %3d-byte records, triangles %4zu MB of 48-byte records, %d node steps per triangle step, blocks %5d mode %d: %.3f ms  %.2f G records/s\n",
+                   node_mb, mode == 10 ? 64 : 128, tri_mb, node_steps, blocks, mode, best, g);
+            continue;
+        }
         for (int rep = 0; rep < 4; rep++) {
             CHK(hipEventRecord(e0));
             switch (mode) {
