@@ -13,16 +13,20 @@ resident in HBM.  Workload (BASELINE.json config 3, the one the north-star targe
 
 STRONG scaling: the dump is fixed.  Rank r owns the contiguous slice
 [n r / N, n (r+1) / N) (it jump-aheads the generator to its first ray) and traces it against
-its replica of the BVH.  The hit records (prim u32 + t, u, v f64 = 28 B/ray) stay in the HBM
-of the rank that traced them: in lucille a rank's transport stage consumes the records of the
-rays it shot and only PIXELS travel to the display owner ("every rank renders, rank 0 owns
-the display", render.c:468-514, parallel.c:101-119) -- that exchange is the `ao_render` /
-`pt_render` legs' gather of tile slabs.  The path has no per-ray exchange step, so the
-headline has no data-path collective; what rank 0 collects is a digest per rank (hits,
-sum of t).  value = n x steps / max-over-ranks time.  `with_record_gather` (N > 1) reports
-the same dump with every record gathered to rank 0 chunk by chunk behind the tracing of the
-next chunk (RCCL, lh_dist_gather) -- what a dump service that returns records to ONE host
-would pay -- and `--gather-records` makes that the headline.
+its replica of the BVH.  The path has no per-ray exchange; its ONE exchange step is
+the gather of the hit records to rank 0 (lh_dist_gather: RCCL point-to-point, one xGMI link per
+peer), and at N > 1 that gather IS INSIDE the headline's timed region: a rank's slice is traced
+in --chunks chunks, chunk c travels while chunk c + 1 is traced.  On the wire a record is 16
+bytes (--record-bytes 16, the default: prim u32 + t, u, v rounded to fp32 from the fp64 bits --
+6e-8 relative, north_star allows 1e-5; lh_dist_pack_records16); the fp64 records (28 bytes:
+prim u32 + t, u, v f64) stay in the HBM of the rank that traced them -- in lucille a rank's
+transport stage consumes the records of the rays it shot and only PIXELS travel to the display
+owner ("every rank renders, rank 0 owns the display", render.c:468-514, parallel.c:101-119).
+At 28 bytes a ray eight ranks are bound by rank 0's links (350 MB per peer against 5.4 ms of
+tracing: profiles/r06_dump_cost_table.md); `record_gather_fp64` reports that reading beside
+the headline, `records_stay_with_rank` the one with no record exchange at all (a digest per rank
+travels: hits, sum of t), and --no-gather-records makes the latter the headline.
+value = n x steps / max-over-ranks time.
 
 One JSON line on rank 0, with
   roofline      the dominant kernel on the headline workload: algorithmic bytes / HIP-event
@@ -52,7 +56,7 @@ sys.path.insert(0, ROOT)
 
 from benchlegs.common import *  # noqa: E402,F401,F403 -- constants (HBM_PEAK_GBPS, B_IN ...), hip_events, EventPairs, upload_rays, record_views
 from benchlegs.common import gather_ceiling, pmc_source, copy_rate, host_cores  # noqa: E402
-from benchlegs.dump import validate_dump  # noqa: E402
+from benchlegs.dump import validate_dump, gathered_vs_world1  # noqa: E402
 from benchlegs.hostpath import host_path_leg  # noqa: E402
 from benchlegs.hbm import hbm_leg  # noqa: E402
 from benchlegs.ao import ao_frame_leg  # noqa: E402
@@ -76,7 +80,9 @@ def main():
     ap.add_argument("--build", choices=["auto", "host", "device"], default="auto",
                     help="builders of the headline leg's scene: auto = lh_accel_commit's own choice (the device builders from 1 M triangles on)")
     ap.add_argument("--mode", choices=["closest", "any"], default="closest")
-    ap.add_argument("--chunks", type=int, default=4, help="N>1: trace/gather pipeline depth per rank (with_record_gather)")
+    ap.add_argument("--chunks", type=int, default=8, help="N>1: trace/gather pipeline depth per rank (with_record_gather)")
+    ap.add_argument("--record-bytes", type=int, choices=[16, 28], default=16,
+                    help="N>1: bytes of a hit record on the wire -- 16: prim u32 + t, u, v fp32 (rounded from the fp64 records, which stay with the rank that traced them); 28: the fp64 records themselves")
     ap.add_argument("--gather-records", action="store_true", help="accepted for compatibility: at N > 1 the gather of every hit record to rank 0 IS inside the headline's timed region (SURVEY 8e)")
     ap.add_argument("--no-gather-records", action="store_true", help="N>1: headline = the records stay with the rank that traced them (a digest travels); the gathered figure moves to `with_record_gather`")
     ap.add_argument("--cpu-rays", type=int, default=1_500_000, help="cpu_baseline sample size")
@@ -105,7 +111,7 @@ def main():
 
     import torch
     import lucille_amd as la
-    from lucille_amd import scenes, shard
+    from lucille_amd import binding, scenes, shard
 
     if args.device_override is not None:
         os.environ["LH_DEVICE_OVERRIDE"] = str(args.device_override)
@@ -145,9 +151,13 @@ def main():
         m = cb[c][1] - cb[c][0]
         return record_views(torch, bufs[c], per)[:4] if mode == la.MODE_CLOSEST else (bufs[c][:per],), max(m, 0)
 
+    # what travels: the fp64 records themselves (28 B), or 16-byte wire records packed behind every chunk's launch (closest hit only)
+    wire16 = world > 1 and mode == la.MODE_CLOSEST and args.record_bytes == 16
+    wire_bytes = 16 if wire16 else rec_bytes
+    wire = [torch.empty(per * 16, dtype=torch.uint8, device=dev) for _ in range(nchunks)] if wire16 else bufs
     gathered = None
     if world > 1 and rank == 0:
-        gathered = [torch.empty((world, per * rec_bytes), dtype=torch.uint8, device=dev) for _ in range(nchunks)]
+        gathered = [torch.empty((world, per * wire_bytes), dtype=torch.uint8, device=dev) for _ in range(nchunks)]
     gstream = torch.cuda.Stream(device=dev) if world > 1 else None       # the exchange step's own stream: chunk c on the links while chunk c + 1 is traced
 
     hip = hip_events()
@@ -155,7 +165,8 @@ def main():
     sptr = C.c_void_p(stream.cuda_stream)
     evp = EventPairs(hip, (args.steps + args.warmup + 2) * nchunks)
 
-    def one_step(timed, gather=True):
+    def one_step(timed, gather=True, wire_=None, dst_=None):
+        wire_ = wire if wire_ is None else wire_; dst_ = gathered if dst_ is None else dst_
         for c in range(nchunks):
             (o, m) = outs_of(c)
             if m > 0:
@@ -167,8 +178,10 @@ def main():
                 if timed:
                     evp.end(sptr)
             if world > 1 and gather:
+                if wire_ is not bufs:              # the chunk's wire records, behind its launch on the tracing stream (every slot: equal sizes on every rank)
+                    binding.pack_records16(o[0], o[1], o[2], o[3], wire_[c], n=per, stream=stream)
                 gstream.wait_stream(stream)
-                shard.gather_bytes(bufs[c], gathered[c] if rank == 0 else None, stream=gstream)
+                shard.gather_bytes(wire_[c], dst_[c] if rank == 0 else None, stream=gstream)
         if world > 1 and gather:
             stream.wait_stream(gstream)
 
@@ -232,13 +245,25 @@ def main():
             other_step(False)
         torch.cuda.synchronize(dev); barrier()
         other_elapsed = shard.all_reduce_max((time.perf_counter() - tg) / gsteps)
-        if not head_gather:
-            pass
+        # the exchange with the fp64 records themselves on the wire (28 B a ray): the reading of rounds 1-5
+        fp64_elapsed = None
+        if wire16:
+            g28 = [torch.empty((world, per * rec_bytes), dtype=torch.uint8, device=dev) for _ in range(nchunks)] if rank == 0 else None
+            one_step(False, True, bufs, g28)
+            barrier(); torch.cuda.synchronize(dev)
+            tg = time.perf_counter()
+            for k in range(gsteps):
+                one_step(False, True, bufs, g28)
+            torch.cuda.synchronize(dev); barrier()
+            fp64_elapsed = shard.all_reduce_max((time.perf_counter() - tg) / gsteps)
+            if rank == 0:
+                fp64_gather_ok = all(bool(torch.equal(g28[c][0], bufs[c])) for c in range(nchunks))
+            del g28
         # this rank's share of the exchange alone (nothing traced): what the links cost when they are not hidden
         barrier(); torch.cuda.synchronize(dev)
         tg = time.perf_counter()
         for c in range(nchunks):
-            shard.gather_bytes(bufs[c], gathered[c] if rank == 0 else None, stream=gstream)
+            shard.gather_bytes(wire[c], gathered[c] if rank == 0 else None, stream=gstream)
         gstream.synchronize()
         gather_only_ms = (time.perf_counter() - tg) * 1e3
         barrier()
@@ -301,9 +326,15 @@ def main():
     validation = None
     if rank == 0:
         if not head_gather:         # the headline's own launch: one buffer; the gathered chunks are checked against the chunked pass's
-            validation = validate_dump(torch, la, args, mode, lambda c: (whole_out, n), [(0, n)], cnt_out, ns, gathered, world, per, n_total, bufs, nchunks)
+            validation = validate_dump(torch, la, args, mode, lambda c: (whole_out, n), [(0, n)], cnt_out, ns, gathered, world, per, n_total, bufs, nchunks, wire_bytes)
         else:
-            validation = validate_dump(torch, la, args, mode, outs_of, cb, cnt_out, ns, gathered, world, per, n_total, bufs, nchunks)
+            validation = validate_dump(torch, la, args, mode, outs_of, cb, cnt_out, ns, gathered, world, per, n_total, bufs, nchunks, wire_bytes)
+        if world > 1:
+            # every gathered slice against rank 0's OWN trace of that slice's rays (world-1 records), when the dump is small enough to repeat here
+            validation.update(gathered_vs_world1(torch, la, scenes, shard, acc, args, mode, gathered, wire_bytes, per, nchunks, world, n_total, st_after_tris, dev))
+            validation["ok"] = bool(validation["ok"]) and validation.get("gathered_equals_world1_records") is not False
+            if wire16:
+                validation["fp64_records_gathered_ok"] = bool(fp64_gather_ok); validation["ok"] = bool(validation["ok"]) and bool(fp64_gather_ok)
 
     # ---- context figures (rank 0, N = 1, untimed for `value`) ----------------------
     copy_gbps = host_path = None
@@ -353,7 +384,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "S-soup-1M ray dump (BASELINE config 3): %d random triangles, one dump of %d incoherent rays cut into %d "
                                    "contiguous slice(s), %s-hit%s" % (args.tris, n_total, world, args.mode,
-                                                                      "" if world == 1 else (", 28-B hit records gathered to rank 0 inside the timed region" if head_gather
+                                                                      "" if world == 1 else (", %d-B hit records gathered to rank 0 inside the timed region" % wire_bytes if head_gather
                                                                                              else ", hit records stay with the rank that traced them (digest to rank 0)")),
                        "rays": n_total, "rays_per_gpu": n, "triangles": args.tris, "mode": args.mode,
                        "variant": args.variant, "parallelism": "replicated BVH, ray slices x%d%s" % (world, "" if world == 1 else (", %d-chunk trace/gather pipeline" % nchunks if head_gather else ", one launch per rank, no per-ray exchange")),
@@ -392,9 +423,14 @@ def main():
                                              "unless --no-gather-records.  Rounds 1-2 timed it inside, round 3's headline did not: compare N > 1 values across rounds "
                                              "through `with_record_gather` / `records_stay_with_rank`, which every round from 4 on emits side by side"}
             res["with_record_gather"] = {"value": round(n_total / gather_elapsed / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(gather_elapsed * 1e3, 3),
-                                         "is_headline": bool(head_gather), "bytes_to_rank0_per_step": int(rec_bytes * (n_total - n)),
+                                         "is_headline": bool(head_gather), "record_bytes_on_the_wire": wire_bytes, "bytes_to_rank0_per_step": int(wire_bytes * (n_total - n)),
                                          "note": "every hit record gathered to rank 0 in %d chunks behind the tracing of the next chunk (lh_dist_gather: RCCL "
-                                                 "point-to-point, one xGMI link per peer)" % nchunks}
+                                                 "point-to-point, one xGMI link per peer)%s" % (nchunks, "; on the wire: prim u32 + t, u, v fp32 rounded from the fp64 records, "
+                                                 "which stay with the rank that traced them (lh_dist_pack_records16)" if wire16 else "")}
+            if wire16 and fp64_elapsed is not None:
+                res["record_gather_fp64"] = {"value": round(n_total / fp64_elapsed / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(fp64_elapsed * 1e3, 3),
+                                             "record_bytes_on_the_wire": rec_bytes, "bytes_to_rank0_per_step": int(rec_bytes * (n_total - n)),
+                                             "note": "the same pipeline with the 28-byte fp64 records themselves on the wire (rounds 1-5's exchange): link-bound at 8 ranks"}
             res["records_stay_with_rank"] = {"value": round(n_total / stay_elapsed / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(stay_elapsed * 1e3, 3),
                                              "is_headline": not head_gather,
                                              "note": "one launch per rank, the records stay in the HBM of the rank that traced them (its transport stage consumes them), "

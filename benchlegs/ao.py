@@ -7,7 +7,7 @@ import time
 import numpy as np
 
 from .common import *  # noqa: F401,F403 -- the constants and helpers every leg shares
-from .common import ROOT, gather_ceiling, pmc_source, host_cores
+from .common import ROOT, gather_ceiling, pmc_source, host_cores, newest_pmc_summary, VALU_NODE_STEP_ANYHIT
 
 
 def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess, build="auto", twin=True):
@@ -60,25 +60,34 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess, 
         render.render_ao_frame(acc, cam, 1, nsamples, tile=tile); torch.cuda.synchronize(dev)
         c = acc.statistics(clear=True); sl = acc.slot_statistics(clear=True); acc.trace_statistics(False)
         nr = max(1, c["rays"])
-        # The frame is NOT bandwidth-bound (coherent rays: 0.15 KB of fabric traffic per ray).  With four workgroups per CU (round 4) the
-        # fused any-hit kernel is bound by VALU ISSUE: profiles/r04_pmc_ao_dense.txt -- SQ_INSTS_VALU 2.96e10 wave instructions x 4
-        # cycles / 1024 SIMDs = 1.16e8 of the launch's 1.21e8 cycles: the vector pipes are busy 96 % of the time, at 74 % lane use.
-        # `achieved` / `peak` are therefore VALU lane operations per second: what the walk's own steps need -- 136 per node step
-        # (lh_walk.h slab_w: the disassembly's count), 75 per triangle record through the fp32 filter (lh_filter.h) -- x the counted
-        # steps of the frame, against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.  What `frac` leaves out is what the counters show the
-        # pipes are busy WITH besides: idle lanes (26 %), the refill of finished lanes (ray generation + set-up, ~300 instructions a
-        # regroup), the fp64 resolves.  The record rate is kept beside it (`records_per_s`): round 1's gather microbenchmark
-        # (129 G random 64-B records/s) is no ceiling for these rays -- the 64 rays of a hemisphere share their first ten levels.
+        # The frame is NOT bandwidth-bound (coherent rays: 0.15 KB of fabric traffic per ray).  With four workgroups per CU the fused
+        # any-hit kernel is bound by VALU ISSUE: the newest profiles/r*_pmc_ao_dense.txt (tools/pmc_cmd.sh: separate SQ / TCC passes of
+        # this frame; its last block is the fused AO launch) -- SQ_INSTS_VALU wave instructions x 4 cycles / 1024 SIMDs against the
+        # launch's cycles (GRBM_GUI_ACTIVE summed over the 8 XCDs / 8).  `achieved` / `peak` are VALU lane operations per second: what
+        # the walk's own steps need -- an ANY-HIT node step does not rank its children: VALU_NODE_STEP_ANYHIT (109; the ranked step's
+        # 136 is the closest-hit walk's), 75 per triangle record through the fp32 filter (profiles/step_costs.json) -- x the counted
+        # steps of the frame, against 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.  The camera rays' closest-hit steps (4 % of the frame's
+        # rays) are priced like the rest.  What `frac` leaves out is what the counters show the pipes are busy WITH besides: idle
+        # lanes, the refill of finished lanes (ray generation + set-up, ~300 instructions a regroup), the fp64 resolves.
         recs = c["nodes"] + c["tris"]
         b_frame = 64.0 * c["nodes"] + 40.0 * c["tris"] + (48.0 + 28.0) * st["primary_rays"] + 4.0 * st["primary_hits"]
-        lane_ops = VALU_NODE_STEP * c["nodes"] + VALU_TRI_STEP * c["tris"]
-        sq = {"source": "profiles/r04_pmc_ao_dense.txt (tools/pmc_cmd.sh: separate SQ / TCC passes of this frame, the fused any-hit launch)",
-              "valu_busy": 0.96, "valu_lane_use": 0.74, "wave_cycles_waiting": 0.49, "l2_hit_rate": 0.52,
-              "valu_wave_instructions_per_ray": 66.8, "fabric_read_bytes_per_frame": 68.6e9}
+        lane_ops = VALU_NODE_STEP_ANYHIT * c["nodes"] + VALU_TRI_STEP * c["tris"]
+        src, k = newest_pmc_summary("pmc_ao_dense.txt")
+        sq = None
+        if k is not None and k.get("SQ_INSTS_VALU") and k.get("GRBM_GUI_ACTIVE"):
+            g = k.get
+            sq = {"source": "%s (tools/pmc_cmd.sh: separate SQ / TCC passes of this frame; the fused any-hit launch)" % src,
+                  "valu_busy": round(g("SQ_INSTS_VALU") * 4.0 / 1024.0 / (g("GRBM_GUI_ACTIVE") / 8.0), 3),
+                  "valu_lane_use": round(g("SQ_THREAD_CYCLES_VALU", 0.0) / max(1.0, g("SQ_ACTIVE_INST_VALU", 0.0) * 64.0), 3),
+                  "wave_cycles_waiting": round(g("SQ_WAIT_ANY", 0.0) / max(1.0, g("SQ_WAVE_CYCLES", 0.0)), 3),
+                  "l2_hit_rate": round(g("TCC_HIT_sum", 0.0) / max(1.0, g("TCC_HIT_sum", 0.0) + g("TCC_MISS_sum", 0.0)), 3),
+                  "valu_wave_instructions_per_ray": round(g("SQ_INSTS_VALU") / max(1, st["ao_rays"]), 1),
+                  "fabric_read_bytes_per_frame": g("TCC_EA0_RDREQ_sum", 0.0) * 128.0}
         roof = {"bound": "valu issue", "achieved": round(lane_ops / min(times) / 1e12, 2), "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
-                "frac": round(lane_ops / min(times) / 1e12 / VALU_PEAK_TLANEOPS, 4), "traffic": sq["fabric_read_bytes_per_frame"],
-                "formula": "achieved = (%d x node steps + %d x triangle records of the counted frame) / frame time; peak = 256 CUs x 64 lanes x 2.4 GHz"
-                           % (VALU_NODE_STEP, VALU_TRI_STEP),
+                "frac": round(lane_ops / min(times) / 1e12 / VALU_PEAK_TLANEOPS, 4), "traffic": sq["fabric_read_bytes_per_frame"] if sq else None,
+                "formula": "achieved = (%d x node steps [the any-hit step: no ranking] + %d x triangle records of the counted frame) / frame time; peak = 256 CUs x 64 lanes x 2.4 GHz"
+                           % (VALU_NODE_STEP_ANYHIT, VALU_TRI_STEP),
+                "node_steps": int(c["nodes"]), "triangle_records": int(c["tris"]),
                 "counters": sq, "records_per_s": round(recs / min(times) / 1e9, 1), "algorithmic_GBps": round(b_frame / min(times) / 1e9, 1),
                 "nodes_per_ray": round(c["nodes"] / nr, 2), "tris_per_ray": round(c["tris"] / nr, 2), "exact_per_ray": round(c["exact"] / nr, 4),
                 "lane_use_node_steps": round(c["nodes"] / max(1, sl["node_slots"]), 3),

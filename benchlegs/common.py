@@ -15,7 +15,17 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 B_IN, B_OUT, B_TRI = 32, 16, 40   # SURVEY.md 8(d) algorithmic bytes per ray / per triangle test
 B_NODE_SURVEY = 64                # a node visit is priced at 64 B whatever the record
-VALU_NODE_STEP, VALU_TRI_STEP = 136, 75      # VALU instructions of one 4-wide node step / one triangle record through the fp32 filter (lh_walk.h, lh_filter.h: counted in the disassembly)
+def _step_costs():
+    """VALU instructions of one 4-wide node step (ranked: closest hit; unranked: any hit) / one triangle record through the fp32 filter:
+    profiles/step_costs.json (tools/step_costs.py; lh_walk.h, lh_filter.h: counted in the disassembly)"""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "step_costs.json")))
+        return int(j["node_step4_sorted"]), int(j["node_step4_unsorted"]), int(j["tri_filter"])
+    except (OSError, ValueError, KeyError):
+        return 136, 109, 75
+
+
+VALU_NODE_STEP, VALU_NODE_STEP_ANYHIT, VALU_TRI_STEP = _step_costs()
 VALU_PEAK_TLANEOPS = 256 * 64 * 2.4e9 / 1e12   # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane operations per second (one wave64 VALU instruction per SIMD every 4 cycles)
 B_NODE = {"f32": 64, "q16": 32, "q16x4": 64}   # per node visit: SURVEY's 64-B fp32 2-wide node, 32-B 16-bit grid 2-wide, 64-B 16-bit grid 4-wide
 # check values of the canonical S-soup-1M dump on the UNMODIFIED reference (SURVEY.md Appendix C)
@@ -137,3 +147,27 @@ def host_cores():
             quota = None
     eff = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
     return {"os_cpu_count": n_os, "sched_affinity": aff, "cgroup_cpu_quota": None if quota is None else round(quota, 2), "effective": eff}
+
+
+def newest_pmc_summary(suffix, kernel_marker=None):
+    """the counters of the newest profiles/r<NN>_<suffix> (a tools/pmc_cmd.sh summary): the LAST block whose header holds
+    `kernel_marker` (None: the last block) -> (path relative to the repo, {counter: value}) or (None, None)"""
+    import glob, re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_" + suffix)):
+        m = re.match(r"r(\d+)_", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        return None, None
+    blocks = []; cur = None
+    for line in open(best[1]):
+        if line.startswith("=="):
+            cur = {"_header": line.strip()}; blocks.append(cur)
+        elif cur is not None:
+            m = re.match(r"\s+([A-Za-z0-9_]+)\s+([0-9.eE+-]+)\s*$", line)
+            if m:
+                cur[m.group(1)] = float(m.group(2))
+    if kernel_marker is not None:
+        blocks = [b for b in blocks if kernel_marker in b["_header"]] or blocks
+    return (os.path.relpath(best[1], ROOT), blocks[-1]) if blocks else (None, None)

@@ -118,7 +118,7 @@ ABI_SYMBOLS = [
     "lh_multi_render_ao_frame_host", "lh_multi_render_pt_frame_host",
     "lh_synth_soup_triangles", "lh_synth_soup_rays", "lh_synth_tessellate", "lh_synth_skip",
     "lh_dist_unique_id", "lh_dist_init", "lh_dist_init_file", "lh_dist_destroy", "lh_dist_rank", "lh_dist_world", "lh_dist_transport",
-    "lh_dist_barrier", "lh_dist_host_barrier", "lh_dist_broadcast", "lh_dist_gather", "lh_dist_broadcast_scene", "lh_dist_render_ao_frame_host",
+    "lh_dist_barrier", "lh_dist_host_barrier", "lh_dist_broadcast", "lh_dist_gather", "lh_dist_pack_records16", "lh_dist_broadcast_scene", "lh_dist_render_ao_frame_host",
 ]
 
 _lib = None
@@ -712,6 +712,19 @@ class HipMulti:
 
 
 DIST_RCCL, DIST_SHM = 0, 1
+
+
+def pack_records16(prim, t, u, v, out, n=None, stream=None):
+    """lh_dist_pack_records16: the first n hit records (prim i32/u32, t, u, v f64 CUDA tensors) -> n 16-byte wire records
+    {prim u32, t, u, v f32} in `out` (a CUDA uint8 tensor of >= 16 n bytes)"""
+    import torch
+    n = int(prim.shape[0]) if n is None else int(n)
+    L = lib()
+    L.lh_dist_pack_records16.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    s = stream if stream is not None else torch.cuda.current_stream(prim.device)
+    _check(L.lh_dist_pack_records16(n, prim.data_ptr(), t.data_ptr(), u.data_ptr(), v.data_ptr(), out.data_ptr(), C.c_void_p(s.cuda_stream)),
+           "lh_dist_pack_records16")
+    return out
 
 
 class HipDist:

@@ -353,6 +353,28 @@ extern "C" int lh_dist_gather(lh_dist_t *d, const void *d_send, size_t bytes, vo
     return shm_release(d, seg, bytes * (size_t)d->world);
 }
 
+/* hit records for the wire (lucille_hip.h): one 16-byte store per ray */
+__global__ __launch_bounds__(256) void k_pack_records16(size_t n, const uint32_t *__restrict__ prim, const double *__restrict__ t,
+                                                        const double *__restrict__ u, const double *__restrict__ v, uint4 *__restrict__ rec)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint4 r;
+    r.x = prim[i]; r.y = __float_as_uint((float)t[i]); r.z = __float_as_uint((float)u[i]); r.w = __float_as_uint((float)v[i]);
+    rec[i] = r;
+}
+
+extern "C" int lh_dist_pack_records16(size_t n, const void *d_prim, const void *d_t, const void *d_u, const void *d_v, void *d_rec16, void *stream)
+{
+    if (n == 0) return 0;
+    if (!d_prim || !d_t || !d_u || !d_v || !d_rec16) return DFAIL("lh_dist_pack_records16: NULL argument");
+    if (((uintptr_t)d_rec16 & 15u) != 0) return DFAIL("lh_dist_pack_records16: the record buffer is not 16-byte aligned");
+    hipLaunchKernelGGL(k_pack_records16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, (const uint32_t *)d_prim,
+                       (const double *)d_t, (const double *)d_u, (const double *)d_v, (uint4 *)d_rec16);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 /* the ranks of ONE node (the contract of bench.py --gpus N and of lsh_hip --world N) meet in shared memory: microseconds, where a
  * gloo barrier between eight processes costs 1.3 ms and lets them out up to 0.4 ms apart (tools/skew_probe.py) -- a tenth of a
  * rank's 12 ms share of the config-5 frame.  Host only: the caller synchronises its device first. */

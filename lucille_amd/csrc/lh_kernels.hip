@@ -576,6 +576,10 @@ __device__ __forceinline__ void trace_persist_lane(
                     if (drained & (1u << part)) { part = (part + 1u) % LH_NPART; continue; }
                     const uint32_t p0 = per * part, p1 = (p0 + per < n) ? p0 + per : n;      /* per * LH_NPART < 2^31 + 8 */
                     const uint32_t plen = p1 > p0 ? p1 - p0 : 0u;                              /* a small batch leaves the last partitions empty */
+                    /* (Round 6 tried GUIDED ranges here -- a look at the cursor, then min(chunk, what is left / (the partition's waves x k)) rays,
+                     * never fewer than 64 -- to shrink the spread of the waves' exits: a rank's share of the config-5 frame 7.35 / 7.80 ms
+                     * (rank 0 / 7) -> 7.96 / 8.16 (k = 1), 8.13 / 8.42 (k = 2), 8.57 / 8.60 (k = 4): the short ranges of the tail are
+                     * thousands of atomics on ONE address, serialised at ~95 ns each.  profiles/r06_share_probe.txt.) */
                     uint32_t b = plen;
                     if (plen) {
                         if ((tid & 63) == 0) b = atomicAdd(cursor + part * LH_CURSOR_STRIDE, chunk);              /* < 2^31 + waves * chunk: no wrap */
@@ -1190,6 +1194,7 @@ int launch_coop(const lh_dev_scene_t &sc, const double *org, const double *dir, 
     }
     /* the sweep: the same kernel behind the producer, on its stream, sixteen waves per CU -- whatever the concurrent pass did not
      * take (nothing, when it ran next to the producer: the waves read a few words and leave) */
+    /* (a sweep of grid x 4 or x 2 workgroups instead of x 16: a rank's share of the config-5 frame 7.35 / 7.80 -> 7.35 / 7.79 and 7.31 / 7.73 ms: nothing.  r06_share_probe.txt) */
     hipLaunchKernelGGL((k_coop_walk<ANYHIT, SRC>), dim3(grid * 16), dim3(64), lds, s, scl, org, dir, prim, t, u, v, occ, ao, fq, counters, (uint32_t)grid * 4u);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

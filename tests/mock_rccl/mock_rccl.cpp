@@ -14,6 +14,16 @@
  *   MOCK_RCCL_LOG=prefix         every call is appended to prefix.rank<R> ("GroupStart", "Send 0 1024", ...)
  *   MOCK_RCCL_FAIL=op:rank:n     the (n+1)-th call of op (send | recv | broadcast) on that rank returns ncclSystemError
  *   MOCK_RCCL_TIMEOUT=seconds    a receive / broadcast whose peer never shows up fails after this long (default 30)
+ *
+ * Link model (round 6; tools/predict8.py): the bytes really move through host shared memory, far slower than xGMI, so wall time
+ * here says nothing about a node.  Instead every rank keeps a MODEL CLOCK of what its calls would cost on one:
+ *   MOCK_RCCL_LATENCY_US=us      per call that reaches the library's proxy: an ungrouped ncclSend / ncclRecv / ncclBroadcast, or
+ *                                one ncclGroupEnd that closes a non-empty group
+ *   MOCK_RCCL_GBPS=rate          per peer and direction (xGMI is point-to-point: the N - 1 receives of a gather cross N - 1 links
+ *                                at once) -- a call costs latency + the LARGEST of its transfers / rate; a broadcast of B bytes
+ *                                costs latency + B / rate (a pipelined ring moves every byte over every link once)
+ * mock_rccl_model_seconds() / _calls() / _bytes() read this process's clock, mock_rccl_model_reset() zeroes it.  Nothing sleeps:
+ * the clock is a count, read by the tool that adds it to kernel times measured on the GPU.
  */
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -48,6 +58,18 @@ struct ncclComm {
     FILE *log; double timeout;
     int fail_op, fail_rank; long fail_after; long calls[3];
 };
+
+static double g_model_s = 0.0, g_lat_s = 0.0, g_rate = 0.0;          /* this process's model clock; seconds per call; bytes per second per link (0: free) */
+static unsigned long long g_model_calls = 0, g_model_bytes = 0;
+static void model_call(size_t largest_bytes, size_t all_bytes)
+{
+    g_model_s += g_lat_s + (g_rate > 0.0 ? (double)largest_bytes / g_rate : 0.0);
+    g_model_calls++; g_model_bytes += all_bytes;
+}
+extern "C" double mock_rccl_model_seconds(void) { return g_model_s; }
+extern "C" unsigned long long mock_rccl_model_calls(void) { return g_model_calls; }
+extern "C" unsigned long long mock_rccl_model_bytes(void) { return g_model_bytes; }
+extern "C" void mock_rccl_model_reset(void) { g_model_s = 0.0; g_model_calls = 0; g_model_bytes = 0; }
 
 static thread_local int g_depth = 0;
 static thread_local std::vector<std::pair<ncclComm *, op_t>> g_ops;
@@ -102,6 +124,8 @@ extern "C" ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqu
     snprintf(c->name, sizeof(c->name), "/mock_rccl_%016llx", h);
     c->rank = rank; c->nranks = nranks; c->timeout = 30.0; c->fail_op = -1;
     if (const char *e = getenv("MOCK_RCCL_TIMEOUT")) c->timeout = atof(e);
+    if (const char *e = getenv("MOCK_RCCL_LATENCY_US")) g_lat_s = atof(e) * 1e-6;
+    if (const char *e = getenv("MOCK_RCCL_GBPS")) g_rate = atof(e) * 1e9;
     if (const char *e = getenv("MOCK_RCCL_LOG")) { char p[1200]; snprintf(p, sizeof(p), "%s.rank%d", e, rank); c->log = fopen(p, "a"); }
     if (const char *e = getenv("MOCK_RCCL_FAIL")) {
         char op[32] = ""; int r = -1; long n = 0;
@@ -197,7 +221,12 @@ extern "C" ncclResult_t ncclGroupEnd(void)
     /* buffered sends first, then the receives in posting order: no pattern of grouped operations can deadlock */
     for (auto &p : g_ops) if (p.second.kind == 0 && rc == ncclSuccess) rc = do_send(p.first, p.second);
     for (auto &p : g_ops) if (p.second.kind == 1 && rc == ncclSuccess) rc = do_recv(p.first, p.second);
-    if (!g_ops.empty()) logf_(g_ops[0].first, "GroupEnd %zu", g_ops.size());
+    if (!g_ops.empty()) {
+        size_t largest = 0, all = 0;
+        for (auto &p : g_ops) { if (p.second.bytes > largest) largest = p.second.bytes; all += p.second.bytes; }
+        model_call(largest, all);
+        logf_(g_ops[0].first, "GroupEnd %zu", g_ops.size());
+    }
     g_ops.clear();
     return rc;
 }
@@ -207,6 +236,7 @@ extern "C" ncclResult_t ncclSend(const void *buf, size_t count, ncclDataType_t t
     if (!c || peer < 0 || peer >= c->nranks || peer == c->rank) return ncclInvalidArgument;
     op_t o = {0, (void *)buf, count * type_size(t), peer, s};
     if (g_depth > 0) { g_ops.push_back({c, o}); return ncclSuccess; }
+    model_call(o.bytes, o.bytes);
     return do_send(c, o);
 }
 
@@ -215,6 +245,7 @@ extern "C" ncclResult_t ncclRecv(void *buf, size_t count, ncclDataType_t t, int 
     if (!c || peer < 0 || peer >= c->nranks || peer == c->rank) return ncclInvalidArgument;
     op_t o = {1, buf, count * type_size(t), peer, s};
     if (g_depth > 0) { g_ops.push_back({c, o}); return ncclSuccess; }
+    model_call(o.bytes, o.bytes);
     return do_recv(c, o);
 }
 
@@ -226,6 +257,7 @@ extern "C" ncclResult_t ncclBroadcast(const void *sendbuf, void *recvbuf, size_t
     if (fails(c, 2)) { logf_(c, "Broadcast %zu FAILED (injected)", bytes); return ncclSystemError; }
     char name[160]; seg_name(c, name, sizeof(name), "bc", root, 0, seq);
     if (c->nranks == 1) { logf_(c, "Broadcast %zu", bytes); return ncclSuccess; }
+    model_call(bytes, bytes);
     if (c->rank == root) {
         ncclResult_t rc = put(c, name, sendbuf, bytes, s);
         if (rc != ncclSuccess) return rc;

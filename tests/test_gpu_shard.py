@@ -109,7 +109,8 @@ def test_bench_n2_code_path_on_one_gpu():
     # at N > 1 the record gather is INSIDE the headline's timed region; both readings are emitted side by side
     assert j["exchange"]["headline_includes_record_gather"] and j["with_record_gather"]["is_headline"]
     assert abs(j["with_record_gather"]["value"] - j["value"]) <= 0.02 * j["value"] and j["records_stay_with_rank"]["value"] > 0
-    assert "28-B hit records gathered to rank 0 inside the timed region" in j["config"]["workload"]
+    assert "16-B hit records gathered to rank 0 inside the timed region" in j["config"]["workload"]
+    assert j["validation"]["gathered_equals_world1_records"] is True and j["validation"]["gathered_records_checked"] == 3000001
     # every rank reported what it did (transport, launches, kernel and gather time); two ranks on one device = the shm transport
     assert [r_["rank"] for r_ in j["ranks"]] == [0, 1] and all(r_["transport"] == "shm" and "share a device" in r_["rccl_status"] for r_ in j["ranks"])
     assert all(r_["kernel_ms_per_step"] > 0 and r_["gather_only_ms"] >= 0 for r_ in j["ranks"])
@@ -125,12 +126,15 @@ def test_bench_n2_over_the_rccl_branch_with_a_mock_library():
     env = dict(os.environ, LH_DIST_TRANSPORT="rccl", LH_RCCL_LIBRARY=build_mock(), MOCK_RCCL_TIMEOUT="120")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--device-override", "0", "--rays", "2000001", "--tris", "100000", "--half-extent", "0.01",
+           "--device-override", "0", "--rays", "2000001", "--tris", "100000", "--half-extent", "0.01", "--record-bytes", "28",
            "--no-cpu", "--no-hbm", "--no-pt", "--ao-size", "192", "--ao-tess", "2", "--ao-samples", "16"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l][-1])
     assert j["n_gpus"] == 2 and j["validation"]["ok"] and j["validation"]["gathered_records_ok"]
+    # the fp64 records themselves on the wire (28 B): every gathered slice == this rank's own trace of that slice's rays, bit for bit
+    assert j["with_record_gather"]["record_bytes_on_the_wire"] == 28 and j["validation"]["gathered_equals_world1_records"] is True
+    assert j["validation"]["gathered_records_checked"] == 2000001
     assert j["config"]["scene_load"]["transport"] == "rccl" and all(r_["transport"] == "rccl" and r_["rccl_status"] == "ok" for r_ in j["ranks"])
     assert j["exchange"]["transport_ok"] and j["ao_render"]["validation"]["ok"] and all(r_["transport"] == "rccl" for r_ in j["ao_render"]["ranks"])
 
@@ -148,6 +152,11 @@ def _bench_n8(extra_env, extra_args=()):
 def _check_n8(j, transport):
     assert j["n_gpus"] == 8 and j["scaling"] == "strong" and j["config"]["rays"] == 1600003
     assert j["validation"]["ok"] and j["validation"]["gathered_records_ok"] and j["validation"]["timed_equals_counted_launch"]
+    # 16-byte wire records (the default): every rank's gathered slice == rank 0's own trace of that slice (prim equal, t / u / v the fp64
+    # values rounded to fp32), and the fp64 records gathered beside them (`record_gather_fp64`) arrive bit for bit
+    assert j["with_record_gather"]["record_bytes_on_the_wire"] == 16 and j["validation"]["gathered_equals_world1_records"] is True
+    assert j["validation"]["gathered_records_checked"] == 1600003 and j["validation"]["fp64_records_gathered_ok"] is True
+    assert j["record_gather_fp64"]["record_bytes_on_the_wire"] == 28
     assert [r_["rank"] for r_ in j["ranks"]] == list(range(8)) and all(r_["transport"] == transport for r_ in j["ranks"])
     assert sum(r_["rays"] for r_ in j["ranks"]) == 1600003
     ao = j["ao_render"]
