@@ -80,7 +80,8 @@ def main():
     ap.add_argument("--build", choices=["auto", "host", "device"], default="auto",
                     help="builders of the headline leg's scene: auto = lh_accel_commit's own choice (the device builders from 1 M triangles on)")
     ap.add_argument("--mode", choices=["closest", "any"], default="closest")
-    ap.add_argument("--chunks", type=int, default=8, help="N>1: trace/gather pipeline depth per rank (with_record_gather)")
+    ap.add_argument("--chunks", type=int, default=0, help="N>1: trace/gather pipeline depth per rank (with_record_gather); 0 = 16 // N (8 / 4 / 2 chunks at 2 / 4 / 8 ranks: "
+                    "a chunk costs its launch's ramp and drain, ~0.6 ms for incoherent rays, profiles/r06_dump_cost_table.md)")
     ap.add_argument("--record-bytes", type=int, choices=[16, 28], default=16,
                     help="N>1: bytes of a hit record on the wire -- 16: prim u32 + t, u, v fp32 (rounded from the fp64 records, which stay with the rank that traced them); 28: the fp64 records themselves")
     ap.add_argument("--gather-records", action="store_true", help="accepted for compatibility: at N > 1 the gather of every hit record to rank 0 IS inside the headline's timed region (SURVEY 8e)")
@@ -142,7 +143,7 @@ def main():
     rec_bytes = 28 if mode == la.MODE_CLOSEST else 1
 
     # chunks of this rank's slice (N = 1: one launch); record buffers; rank 0's gather destination
-    nchunks = 1 if world == 1 else max(1, args.chunks)
+    nchunks = 1 if world == 1 else (max(1, args.chunks) if args.chunks > 0 else max(1, 16 // world))
     per = shard.chunk_capacity(n_total, world, nchunks)     # equal chunk capacity on every rank
     cb = [(c * per, min(n, (c + 1) * per)) for c in range(nchunks)]
     bufs = [torch.empty(per * rec_bytes, dtype=torch.uint8, device=dev) for _ in range(nchunks)]
@@ -165,22 +166,30 @@ def main():
     sptr = C.c_void_p(stream.cuda_stream)
     evp = EventPairs(hip, (args.steps + args.warmup + 2) * nchunks)
 
+    # N > 1: the chunks of a slice are launched one behind the other on ONE stream.  (Round 6 alternated them between two trace streams, the
+    # first of higher priority, so that chunk c + 1's workgroups would take the CUs chunk c's last waves leave -- a persistent launch ends as
+    # slowly as its last rays walk, ~0.6 ms per 1.5 M-ray chunk.  The two launches ran side by side instead and lost: a 12.5 M-ray slice in
+    # 2 / 4 chunks 6.7 / 8.1 ms on one stream, 7.8 / 9.3 on two; a 50 M-ray slice in 2 chunks 23.2 -> 27.8 ms.  profiles/r06_dump_cost_table.md)
+    tstreams = [stream, stream] if world > 1 else None
+
     def one_step(timed, gather=True, wire_=None, dst_=None):
         wire_ = wire if wire_ is None else wire_; dst_ = gathered if dst_ is None else dst_
         for c in range(nchunks):
             (o, m) = outs_of(c)
+            ts = tstreams[c % 2] if world > 1 else stream
+            tp = C.c_void_p(ts.cuda_stream)
             if m > 0:
                 if timed:
-                    evp.begin(sptr)
+                    evp.begin(tp)
                 sl = slice(cb[c][0], cb[c][1])
                 full = tuple(x[:m] for x in o)
-                acc.intersect_device(d_org[sl], d_dir[sl], out=full, mode=mode, variant=args.variant)
+                acc.intersect_device(d_org[sl], d_dir[sl], out=full, mode=mode, variant=args.variant, stream=ts.cuda_stream)
                 if timed:
-                    evp.end(sptr)
+                    evp.end(tp)
             if world > 1 and gather:
-                if wire_ is not bufs:              # the chunk's wire records, behind its launch on the tracing stream (every slot: equal sizes on every rank)
-                    binding.pack_records16(o[0], o[1], o[2], o[3], wire_[c], n=per, stream=stream)
-                gstream.wait_stream(stream)
+                if wire_ is not bufs:              # the chunk's wire records, behind its launch on its trace stream (every slot: equal sizes on every rank)
+                    binding.pack_records16(o[0], o[1], o[2], o[3], wire_[c], n=per, stream=ts)
+                gstream.wait_stream(ts)
                 shard.gather_bytes(wire_[c], dst_[c] if rank == 0 else None, stream=gstream)
         if world > 1 and gather:
             stream.wait_stream(gstream)

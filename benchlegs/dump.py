@@ -48,7 +48,7 @@ def validate_dump(torch, la, args, mode, outs_of, cb, cnt_out, ns, gathered, wor
                 ok &= bool(torch.equal(gathered[c][0], bufs[c]))
             if mode == la.MODE_CLOSEST:
                 for r in range(world):
-                    p = gathered[c][r].view(torch.int32).view(per, 4)[:, 0] if wire_bytes == 16 else gathered[c][r][24 * per:28 * per].view(torch.int32)
+                    p = gathered[c][r].view(torch.int32).view(per, 4)[:, 0] if wire_bytes == 16 else gathered[c][r][24 * per:28 * per].clone().view(torch.int32)
                     frac = float((p != -1).float().mean().item())
                     ok &= (0.5 < frac < 0.99) or n_total < 100_000
         v["gathered_records_ok"] = ok; v["ok"] &= ok
@@ -78,7 +78,7 @@ def gathered_vs_world1(torch, la, scenes, shard, acc, args, mode, gathered, wire
                 for k in (1, 2, 3):
                     ok &= bool(torch.equal(rec[:, k].view(torch.float32), ref[k][lo:hi].to(torch.float32)))
             else:
-                g = gathered[c][r]
+                g = gathered[c][r].clone()          # a row of the [world, per * 28] slab starts at r * per * 28 bytes: not 8-byte aligned in general
                 ok &= bool(torch.equal(g[24 * per:28 * per].view(torch.int32)[:hi - lo], ref[0][lo:hi]))
                 for k in (1, 2, 3):
                     ok &= bool(torch.equal(g[8 * (k - 1) * per:8 * k * per].view(torch.float64)[:hi - lo], ref[k][lo:hi]))

@@ -578,8 +578,11 @@ __device__ __forceinline__ void trace_persist_lane(
                     const uint32_t plen = p1 > p0 ? p1 - p0 : 0u;                              /* a small batch leaves the last partitions empty */
                     /* (Round 6 tried GUIDED ranges here -- a look at the cursor, then min(chunk, what is left / (the partition's waves x k)) rays,
                      * never fewer than 64 -- to shrink the spread of the waves' exits: a rank's share of the config-5 frame 7.35 / 7.80 ms
-                     * (rank 0 / 7) -> 7.96 / 8.16 (k = 1), 8.13 / 8.42 (k = 2), 8.57 / 8.60 (k = 4): the short ranges of the tail are
-                     * thousands of atomics on ONE address, serialised at ~95 ns each.  profiles/r06_share_probe.txt.) */
+                     * (rank 0 / 7) -> 7.96 / 8.16 (k = 1), 8.13 / 8.42 (k = 2), 8.57 / 8.60 (k = 4).  Not the atomics of the short ranges on ONE
+                     * address: with 64 cursors, eight per XCD, the same rule costs the same (7.27 / 7.71 / 7.71 ms for ranks 0 / 3 / 7 ->
+                     * 7.81 / 8.00 / 8.09 at k = 1; 64 cursors by themselves 7.54 / 7.73 / 7.93, the whole frame 48.3 -> 48.6 ms, S-soup-1M
+                     * 2 266 -> 2 253 Mrays/s) -- short ranges at the end of a launch lose more in the walk than its exits gain.
+                     * profiles/r06_share_probe.txt, r06_ab_cursors_guided.txt; tools/experiments/cursors_guided.patch.) */
                     uint32_t b = plen;
                     if (plen) {
                         if ((tid & 63) == 0) b = atomicAdd(cursor + part * LH_CURSOR_STRIDE, chunk);              /* < 2^31 + waves * chunk: no wrap */

@@ -158,12 +158,14 @@ static void seg_name(ncclComm *c, char *out, size_t n, const char *kind, int a, 
     snprintf(out, n, "%s_%s_%d_%d_%llu", c->name, kind, a, b, seq);
 }
 
+#define MOCK_WHY(c, ...) do { fprintf(stderr, "[mock_rccl rank %d] ", (c)->rank); fprintf(stderr, __VA_ARGS__); fprintf(stderr, " (errno %d: %s)\n", errno, strerror(errno)); } while (0)
+
 static ncclResult_t put(ncclComm *c, const char *name, const void *dbuf, size_t bytes, hipStream_t s)
 {
     int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
-    if (fd < 0 || ftruncate(fd, (off_t)(bytes ? bytes : 1)) != 0) { if (fd >= 0) close(fd); return ncclSystemError; }
+    if (fd < 0 || ftruncate(fd, (off_t)(bytes ? bytes : 1)) != 0) { MOCK_WHY(c, "put %s: shm_open / ftruncate of %zu bytes failed", name, bytes); if (fd >= 0) close(fd); return ncclSystemError; }
     void *seg = mmap(NULL, bytes ? bytes : 1, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0); close(fd);
-    if (seg == MAP_FAILED) return ncclSystemError;
+    if (seg == MAP_FAILED) { MOCK_WHY(c, "put %s: mmap of %zu bytes failed", name, bytes); return ncclSystemError; }
     if (hipStreamSynchronize(s) != hipSuccess || (bytes && hipMemcpy(seg, dbuf, bytes, hipMemcpyDeviceToHost) != hipSuccess)) { munmap(seg, bytes ? bytes : 1); return ncclUnhandledCudaError; }
     munmap(seg, bytes ? bytes : 1);
     return ncclSuccess;
@@ -172,10 +174,10 @@ static ncclResult_t put(ncclComm *c, const char *name, const void *dbuf, size_t 
 static ncclResult_t take(ncclComm *c, const char *name, void *dbuf, size_t bytes, hipStream_t s, bool unlink_it)
 {
     int fd = shm_open(name, O_RDWR, 0600);
-    if (fd < 0) return ncclSystemError;
-    struct stat st; if (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes) { close(fd); return ncclInvalidArgument; }      /* size mismatch between the peers */
+    if (fd < 0) { MOCK_WHY(c, "take %s: shm_open failed", name); return ncclSystemError; }
+    struct stat st; if (fstat(fd, &st) != 0 || (size_t)st.st_size < bytes) { MOCK_WHY(c, "take %s: the segment holds %lld bytes, %zu wanted", name, (long long)st.st_size, bytes); close(fd); return ncclInvalidArgument; }      /* size mismatch between the peers */
     void *seg = mmap(NULL, bytes ? bytes : 1, PROT_READ, MAP_SHARED, fd, 0); close(fd);
-    if (seg == MAP_FAILED) return ncclSystemError;
+    if (seg == MAP_FAILED) { MOCK_WHY(c, "take %s: mmap of %zu bytes failed", name, bytes); return ncclSystemError; }
     ncclResult_t rc = ncclSuccess;
     if (hipStreamSynchronize(s) != hipSuccess || (bytes && hipMemcpy(dbuf, seg, bytes, hipMemcpyHostToDevice) != hipSuccess)) rc = ncclUnhandledCudaError;
     munmap(seg, bytes ? bytes : 1);
@@ -202,7 +204,7 @@ static ncclResult_t do_recv(ncclComm *c, const op_t &o)
     const double t0 = now_sec();
     while (__atomic_load_n(&c->ctl->sent[o.peer][c->rank], __ATOMIC_ACQUIRE) <= seq) {
         usleep(50);
-        if (now_sec() - t0 > c->timeout) { logf_(c, "Recv %d %zu TIMEOUT", o.peer, o.bytes); return ncclSystemError; }
+        if (now_sec() - t0 > c->timeout) { MOCK_WHY(c, "recv of %zu bytes from %d: nothing after %.0f s", o.bytes, o.peer, c->timeout); logf_(c, "Recv %d %zu TIMEOUT", o.peer, o.bytes); return ncclSystemError; }
     }
     char name[160]; seg_name(c, name, sizeof(name), "p2p", o.peer, c->rank, seq);
     ncclResult_t rc = take(c, name, o.buf, o.bytes, o.stream, true);
@@ -265,14 +267,14 @@ extern "C" ncclResult_t ncclBroadcast(const void *sendbuf, void *recvbuf, size_t
         const double t0 = now_sec();
         while (__atomic_load_n(&c->ctl->bcast_taken, __ATOMIC_ACQUIRE) < (seq + 1) * (unsigned long long)(c->nranks - 1)) {
             usleep(50);
-            if (now_sec() - t0 > c->timeout) { shm_unlink(name); logf_(c, "Broadcast %zu TIMEOUT", bytes); return ncclSystemError; }
+            if (now_sec() - t0 > c->timeout) { MOCK_WHY(c, "broadcast %llu of %zu bytes: %llu of %llu copies taken after %.0f s", seq, bytes, (unsigned long long)c->ctl->bcast_taken, (seq + 1) * (unsigned long long)(c->nranks - 1), c->timeout); shm_unlink(name); logf_(c, "Broadcast %zu TIMEOUT", bytes); return ncclSystemError; }
         }
         shm_unlink(name);
     } else {
         const double t0 = now_sec();
         while (__atomic_load_n(&c->ctl->bcast_pub, __ATOMIC_ACQUIRE) <= seq) {
             usleep(50);
-            if (now_sec() - t0 > c->timeout) { logf_(c, "Broadcast %zu TIMEOUT", bytes); return ncclSystemError; }
+            if (now_sec() - t0 > c->timeout) { MOCK_WHY(c, "broadcast %llu of %zu bytes: the root published %llu after %.0f s", seq, bytes, (unsigned long long)c->ctl->bcast_pub, c->timeout); logf_(c, "Broadcast %zu TIMEOUT", bytes); return ncclSystemError; }
         }
         ncclResult_t rc = take(c, name, recvbuf, bytes, s, false);
         __atomic_add_fetch(&c->ctl->bcast_taken, 1ull, __ATOMIC_ACQ_REL);
