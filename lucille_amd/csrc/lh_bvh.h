@@ -89,7 +89,16 @@ typedef struct lh_bvh {
     double      build_seconds;
     uint32_t    nlive;         /* primitives in the leaves of the traversal tree: ntris minus the triangles the reference can never report (lh_bvh.c tri_dead_class) */
     double      deg_dcap;      /* rays with a direction component beyond this are decided by the reference's own walk (INFINITY: no such limit) */
+    /* ... unless (round 6) the cap comes from zero-area triangles that STAY in the tree (deg_dcap < LH_DEG_DCAP_ALL) and the ray misses
+     * the box of every leaf of lucille's own tree that holds one: the reference can only "hit" such a triangle -- by the noise of its
+     * determinant -- on rays that reach its leaf.  ndanger >= 1 boxes (bmin xyz, bmax xyz: the child box in the leaf's parent), or
+     * LH_DANGER_ALL (0): more than LH_DANGER_MAX such leaves, or not computed (yet): every ray beyond deg_dcap takes the reference walk */
+    uint32_t    ndanger;
+    double      danger[16][6];
 } lh_bvh_t;
+#define LH_DANGER_MAX   16u
+#define LH_DANGER_ALL   0u             /* zero-initialised state = the safe one */
+#define LH_DEG_DCAP_ALL 1024.0         /* = lh_bvh.c LH_DEG_DCAP: beyond it the triangles LEFT OUT of the tree (v1 == v2, short) are no longer provably missed */
 
 typedef struct lh_mesh_view {
     uint32_t        npositions;

@@ -76,7 +76,7 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     env = getenv("LH_RAY_BUDGET");
     if (env && atoi(env) > 0) a->dev.ray_budget = (uint32_t)atoi(env);
     a->dev.top_nodes = LH_TOP_AUTO;
-    a->dev.deg_dcap = INFINITY;
+    a->dev.deg_dcap = INFINITY; a->dev.ndanger = LH_DANGER_ALL;
     a->dev.coop_patience = 0;
     a->dev.ao_group = 0;            /* measured: the grouped order is SLOWER on the config-5 frame (84.6 -> 95.1 ms, tools/ao_group_probe.py): a slot's own rays share their first levels */
     env = getenv("LH_AO_GROUP");
@@ -201,6 +201,8 @@ static void release_device(lh_accel_t *a)
     if (a->d_ref_nodes) (void)hipFree(a->d_ref_nodes);
     if (a->d_ref_leaf_prims) (void)hipFree(a->d_ref_leaf_prims);
     a->d_ref_lca = a->d_prim_leafpos = a->d_ref_nodes = a->d_ref_leaf_prims = NULL;
+    if (a->d_danger) (void)hipFree(a->d_danger);
+    a->d_danger = NULL; a->dev.ndanger = LH_DANGER_ALL;
     if (a->d_cursor) (void)hipFree(a->d_cursor);
     if (a->d_counters) (void)hipFree(a->d_counters);
     for (int k = 0; k < LH_AOQ_SLOTS; k++) {
@@ -433,6 +435,78 @@ extern "C" int lh_device_ref_build(uint32_t ntris, const double *d_tri64, void *
 
 /* lucille's own tree of a device-built scene, on this device (LH_REF_BUILD=host: the background host thread instead).
  * 0: attached; 1: not built here (the host thread will); -1: error */
+/* ---- the leaves of lucille's own tree that hold a zero-area triangle (round 6; lh_bvh.h ndanger / danger, lh_walk.h danger_hit) ----
+ * A numerically collinear triangle that stays in the traversal tree caps the directions the tree can vouch for at 1 / s2 (lh_bvh.c
+ * tri_zero_area_s2) -- below 1 as soon as |e1|_1 |e2|_1 > 1, i.e. for ANY such sliver in a scene modelled in small units -- and every
+ * ray beyond the cap used to take the single-lane reference walk: correct, and a hundred times slower.  The reference
+ * can "hit" such a triangle only on rays that reach its leaf, so once lucille's own tree is on the device this scan lists the
+ * boxes of those leaves (the child box the leaf's parent holds: what test_ray_node tests, bvh.c:938-1083); rays that miss them all
+ * walk the traversal tree like any other.  More than LH_DANGER_MAX of them: every ray, as before. */
+__global__ __launch_bounds__(256) void k_danger_scan(uint32_t n, const double *__restrict__ tri64, const uint2 *__restrict__ leafpos, const int4 *__restrict__ lca,
+                                                     const lh_refnode_t *__restrict__ nodes, double s0, double s1, double s2_, double s3, double s4, double s5,
+                                                     unsigned long long *__restrict__ count, double *__restrict__ boxes)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const double *t = tri64 + 9 * (size_t)p;
+    /* tri_dead_class (lh_bvh.c): out of the traversal tree, never reported below LH_DEG_DCAP_ALL */
+    if ((t[0] == t[3] && t[1] == t[4] && t[2] == t[5]) || (t[0] == t[6] && t[1] == t[7] && t[2] == t[8])) return;
+    if (t[3] == t[6] && t[4] == t[7] && t[5] == t[8]) {
+        const double sN = fabs(t[3] - t[0]) + fabs(t[4] - t[1]) + fabs(t[5] - t[2]);
+        if (sN * sN * (1.0 + 1e-9) <= 1.0e-14 / (1.0e-15 * LH_DEG_DCAP_ALL)) return;
+    }
+    /* tri_zero_area_s2 (lh_bvh.c), operation for operation */
+    const double e1x = t[3] - t[0], e1y = t[4] - t[1], e1z = t[5] - t[2], e2x = t[6] - t[0], e2y = t[7] - t[1], e2z = t[8] - t[2];
+    const double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+    const double s2 = (fabs(e1x) + fabs(e1y) + fabs(e1z)) * (fabs(e2x) + fabs(e2y) + fabs(e2z));
+    if (!(fmax(fabs(nx), fmax(fabs(ny), fabs(nz))) <= 8.9e-16 * s2)) return;
+    const unsigned long long slot = atomicAdd(count, 1ull);
+    if (slot >= LH_DANGER_MAX) return;
+    const int leaf = (int)leafpos[p].x, parent = lca[leaf].x;
+    double *o = boxes + 6 * slot;
+    if (parent < 0) { o[0] = s0; o[1] = s1; o[2] = s2_; o[3] = s3; o[4] = s4; o[5] = s5; return; }       /* the root is the leaf: the scene box (bvh.c:325-340) */
+    const int k = (lca[parent].w == leaf) ? 0 : 1;          /* children are allocated adjacently: child[1] = child[0] + 1 */
+    for (int q = 0; q < 6; q++) o[q] = nodes[parent].box[k][q];
+}
+
+static int lh_danger_scan(lh_accel_t *a)
+{
+    lh_host_scene *hs = a->hs;
+    a->dev.ndanger = LH_DANGER_ALL;
+    if (!a->d_ref_nodes || !a->d_tri64 || hs->bvh.ntris == 0) return 0;
+    if (!(hs->bvh.deg_dcap < LH_DEG_DCAP_ALL)) return 0;              /* no zero-area triangle in the tree caps the directions: nothing to list */
+    if (getenv("LH_DANGER_BOXES") && atoi(getenv("LH_DANGER_BOXES")) == 0) return 0;       /* A/B: round 5's rule (every ray beyond the cap) */
+    HIPCHK(hipSetDevice(a->device));
+    if (!a->d_danger) HIPCHK(hipMalloc(&a->d_danger, sizeof(double) * (8 + 6 * LH_DANGER_MAX)));
+    HIPCHK(hipMemsetAsync(a->d_danger, 0, sizeof(double) * (8 + 6 * LH_DANGER_MAX), a->stream));
+    const uint32_t n = hs->bvh.ntris;
+    hipLaunchKernelGGL(k_danger_scan, dim3((n + 255u) / 256u), dim3(256), 0, a->stream, n, (const double *)a->d_tri64, (const uint2 *)a->d_prim_leafpos,
+                       (const int4 *)a->d_ref_lca, (const lh_refnode_t *)a->d_ref_nodes, a->dev.ref_bmin[0], a->dev.ref_bmin[1], a->dev.ref_bmin[2],
+                       a->dev.ref_bmax[0], a->dev.ref_bmax[1], a->dev.ref_bmax[2], (unsigned long long *)a->d_danger, (double *)a->d_danger + 8);
+    HIPCHK(hipGetLastError());
+    double h[8 + 6 * LH_DANGER_MAX];
+    HIPCHK(hipMemcpyAsync(h, a->d_danger, sizeof(h), hipMemcpyDeviceToHost, a->stream));
+    HIPCHK(hipStreamSynchronize(a->stream));
+    unsigned long long cnt; memcpy(&cnt, h, sizeof(cnt));
+    if (cnt == 0 || cnt > LH_DANGER_MAX) return 0;                      /* none found (the cap came from somewhere else: keep round 5's rule) or too many */
+    pthread_mutex_lock(&g_scene_mu);
+    memcpy(hs->bvh.danger, h + 8, sizeof(double) * 6 * (size_t)cnt);
+    __atomic_store_n(&hs->bvh.ndanger, (uint32_t)cnt, __ATOMIC_RELEASE);      /* the one-ray host walk reads it (lh_hostwalk.c) */
+    pthread_mutex_unlock(&g_scene_mu);
+    {   /* the union of the listed boxes, rounded outward to fp32 and widened by a part in a million of the scene: lh_slab's slack is sized
+         * for boxes inside the scene box, and the reference's leaf boxes carry its own margin beyond that */
+        double u[6] = {1.0e308, 1.0e308, 1.0e308, -1.0e308, -1.0e308, -1.0e308};
+        for (unsigned long long i = 0; i < cnt; i++)
+            for (int k = 0; k < 3; k++) { u[k] = fmin(u[k], h[8 + 6 * i + k]); u[3 + k] = fmax(u[3 + k], h[8 + 6 * i + 3 + k]); }
+        const double pad = 1.0e-6 * (double)a->dev.scene_r;
+        for (int k = 0; k < 3; k++) {
+            a->dev.danger[k] = nextafterf((float)(u[k] - pad), -INFINITY); a->dev.danger[3 + k] = nextafterf((float)(u[3 + k] + pad), INFINITY);
+        }
+    }
+    a->dev.ndanger = (uint32_t)cnt;
+    return 0;
+}
+
 static int device_ref_tree(lh_accel_t *a)
 {
     lh_host_scene *hs = a->hs;
@@ -455,7 +529,7 @@ static int device_ref_tree(lh_accel_t *a)
     pthread_mutex_lock(&g_scene_mu);
     hs->ref_on_device = 1; hs->ref_build_seconds = now_s() - t0;
     pthread_mutex_unlock(&g_scene_mu);
-    return 0;
+    return lh_danger_scan(a);
 }
 
 int lh_ensure_formats(lh_accel_t *a, int mask)
@@ -523,7 +597,7 @@ static int attach_ref(lh_accel_t *a)
         for (int k = 0; k < 3; k++) { a->dev.ref_bmin[k] = hs->ref.bmin[k]; a->dev.ref_bmax[k] = hs->ref.bmax[k]; }
         a->device_bytes += sizeof(int) * 4 * (size_t)rn + sizeof(uint32_t) * 3 * (size_t)hs->bvh.ntris + sizeof(lh_refnode_t) * (size_t)rn;
     }
-    return 0;
+    return lh_danger_scan(a);
 }
 
 /* the background build of the reference-order tree: attach it if it has finished (wait: block until it has) */
@@ -988,6 +1062,7 @@ int lh_scene_image_finish(lh_accel_t *a)
     if (!a || !a->hs->received || a->committed) return fail("scene image: not a receiving accelerator");
     HIPCHK(hipSetDevice(a->device));
     if (size_grid(a) != 0) return -1;
+    if (lh_danger_scan(a) != 0) return -1;          /* the arrays have arrived: this replica lists its own boxes */
     a->upload_seconds = 0.0;
     a->committed = 1; a->commit_failed = 0;
     return 0;

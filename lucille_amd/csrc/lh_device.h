@@ -41,6 +41,9 @@ typedef struct lh_dev_scene {
     float       deg_dcap;  /* a ray with a direction component beyond this is decided by the reference's own walk: the traversal tree leaves out
                               zero-area triangles whose fp64 determinant is provably below the reference's 1e-14 only up to there (lh_bvh.c
                               tri_dead_class); INFINITY: no such triangle in this scene */
+    uint32_t    ndanger;   /* deg_dcap < LH_DEG_DCAP_ALL: LH_DANGER_ALL (0) = every ray beyond deg_dcap takes the reference walk; else only rays that hit ... */
+    float       danger[6]; /* ... this box (bmin xyz rounded down, bmax xyz rounded up): the union of the boxes of the leaves of lucille's own tree that hold a
+                              zero-area triangle (lh_bvh.h), through the conservative fp32 slab test every box of the walk goes through (lh_slab) */
     uint32_t    ray_chunk; /* rays a persistent wave reserves per atomic on the global cursor */
     uint32_t    ray_budget;/* wave iterations after which a ray leaves the persistent walk for the cooperative one */
     int         stack_guard;    /* set by the launchers when the LDS rows do not cover the tree's worst case: the walks check before they push */

@@ -106,6 +106,24 @@ static void hw_resolve(const lh_bvh_t *b, const lh_refbvh_t *ref, uint32_t prim,
     }
 }
 
+/* lh_walk.h danger_hit on the host: test_ray_aabb (bvh.c:869-936) against the listed leaf boxes, the same fp64 expressions */
+static int hw_danger_hit(const lh_bvh_t *b, uint32_t nd, const double o[3], const double d[3])
+{
+    uint32_t i; int k;
+    for (i = 0; i < nd; i++) {
+        const double *bx = b->danger[i];
+        double tmin = -1.0e308, tmax = 1.0e308;
+        for (k = 0; k < 3; k++) {
+            if (!(fabs(d[k]) > 1.0e-14)) continue;
+            const double inv = 1.0 / d[k];
+            const double lo = ((d[k] < 0.0 ? bx[3 + k] : bx[k]) - o[k]) * inv, hi = ((d[k] < 0.0 ? bx[k] : bx[3 + k]) - o[k]) * inv;
+            tmin = (tmin > lo) ? tmin : lo; tmax = (tmax < hi) ? tmax : hi;
+        }
+        if ((tmax > 0.0) && (tmin <= tmax)) return 1;
+    }
+    return 0;
+}
+
 /* closest hit of one ray.  ref: lucille's own tree (or NULL).  Returns 1 on a hit, 0 on a miss (outputs written), -2 when the walk could
  * not be finished here (stack rows) and there is no reference tree to ask. */
 int lh_host_walk_closest(const lh_bvh_t *b, const lh_refbvh_t *ref, const double o[3], const double d[3],
@@ -115,8 +133,16 @@ int lh_host_walk_closest(const lh_bvh_t *b, const lh_refbvh_t *ref, const double
     *prim = HW_MISS; *t = HW_T_INF; *u = 0.0; *v = 0.0;
     if (b->ntris == 0) return 0;
     /* a direction component beyond deg_dcap: the traversal tree leaves out zero-area triangles it can vouch for only below it
-     * (lh_bvh.c tri_dead_class) -- the reference's own walk decides */
-    int refw = ref && (fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2]))) > b->deg_dcap);
+     * (lh_bvh.c tri_dead_class) -- the reference's own walk decides; where the cap comes from zero-area triangles that stay in the
+     * tree, only for rays that hit the box of one of their leaves in lucille's own tree (lh_bvh.h danger, lh_walk.h danger_hit) */
+    int refw = 0;
+    if (ref) {
+        const double D = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
+        if (D > b->deg_dcap) {
+            const uint32_t nd = __atomic_load_n(&b->ndanger, __ATOMIC_ACQUIRE);
+            refw = (nd == LH_DANGER_ALL || D > LH_DEG_DCAP_ALL) ? 1 : hw_danger_hit(b, nd, o, d);
+        }
+    }
     if (!refw) {
         lh_ray32_t r; float tb = 1.0e38f, scene_r = 0.0f;
         int32_t stack[HW_STACK]; int sp = 0, k; int32_t cur = 0;

@@ -70,6 +70,7 @@ struct lh_accel {
     lh_mesh_copy *meshes; uint32_t nmeshes;
     lh_host_scene *hs;        /* never NULL after create */
     void *d_ref_lca, *d_prim_leafpos, *d_ref_nodes, *d_ref_leaf_prims;
+    void *d_danger;                    /* 8 + LH_DANGER_MAX x 6 doubles: the count, then the boxes of lh_dev_scene_t.danger (lh_commit.hip lh_danger_scan) */
     /* device */
     lh_dev_scene_t dev;
     void *d_nodes, *d_tri32, *d_tri64, *d_q4nodes, *d_q8nodes;

@@ -418,7 +418,7 @@ __global__ __launch_bounds__(LH_BLOCK) void k_trace_direct(
     uint32_t cn = 0, ct = 0, ce = 0;
     lane_init(L, sc, ox, oy, oz, dx, dy, dz);
     stk[0][tid] = kDone;
-    if (__builtin_expect(ray_needs_ref_walk(sc, dx, dy, dz), 0)) LH_FORCE_REF_WALK(L, best);
+    if (__builtin_expect(ray_needs_ref_walk(sc, L, dx, dy, dz), 0)) LH_FORCE_REF_WALK(L, best);
     traverse<ANYHIT, COUNT>(L, sc, stk, tid, ox, oy, oz, dx, dy, dz, best, cn, ct, ce);
     finish<ANYHIT, COUNT>(L, sc, ox, oy, oz, dx, dy, dz, best, ce);
     write_out<ANYHIT>(i, L, best, prim, t, u, v, occ, sc.ref_nodes != NULL);
@@ -612,7 +612,7 @@ __device__ __forceinline__ void trace_persist_lane(
                 stk[0][tid] = kDone;
                 /* camera and AO rays are unit vectors: beyond deg_dcap only where a zero-area triangle of |e1|_1 |e2|_1 > 1 stayed in the tree
                  * (lh_bvh.c tri_zero_area_s2: deg_dcap = 1 / s2 < 1) -- then every source takes the test (wave-uniform) */
-                if ((SRC == 0 || sc.deg_dcap < 1.0f) && __builtin_expect(ray_needs_ref_walk(sc, dx, dy, dz), 0)) LH_FORCE_REF_WALK(L, best);
+                if ((SRC == 0 || sc.deg_dcap < 1.0f) && __builtin_expect(ray_needs_ref_walk(sc, L, dx, dy, dz), 0)) LH_FORCE_REF_WALK(L, best);
                 it0 = it;
             }
             wbase += take;
@@ -926,7 +926,7 @@ __device__ void overflow_walk(const lh_dev_scene_t &sc, size_t i, const double *
     int stack[LH_COOP_ROWS_MAX]; int sp = 0;
     lane_init(L, sc, ox, oy, oz, dx, dy, dz);
     int cur = 0;
-    const bool refw = ray_needs_ref_walk(sc, dx, dy, dz);          /* the reference's own walk decides (lh_walk.h) */
+    const bool refw = ray_needs_ref_walk(sc, L, dx, dy, dz);          /* the reference's own walk decides (lh_walk.h) */
     if (refw) { best.prim = 0u; best.frag = 1u; }
     else for (;;) {
         if (cur >= 0) {

@@ -199,11 +199,66 @@ def test_one_large_collinear_triangle_sends_every_ray_source_through_the_referen
     ok = np.abs(adir[:, 1]) > 1e-14
     exp = o.intersect(aorg[ok], adir[ok], nthreads=8)
     assert np.array_equal(occ[ok].astype(bool).ravel(), exp[0] != po.MISS)
-    # the fused stage by itself, counted: one node step per ray (camera rays and AO rays alike), everything else by the reference walk
-    acc.set_param("ao_fused", 1)
-    acc.trace_statistics(True); acc.statistics(clear=True)
-    acc.render_ao_tile(cam, 0, 0, W, H, 1, ns, seed=9); torch.cuda.synchronize()
-    cnt = acc.statistics(clear=True); acc.trace_statistics(False)
+    # the fused stage by itself, counted, under round 5's rule (LH_DANGER_BOXES=0 at commit: EVERY ray beyond the cap, whatever its
+    # source): one node step per ray (camera rays and AO rays alike), everything else by the reference walk -- and the same frame.
+    # (Round 6's default asks the box of the sliver's leaf first: rays that miss it walk the traversal tree -- the frame above.)
+    os.environ["LH_DANGER_BOXES"] = "0"
+    try:
+        acc5 = la.HipAccel(0); acc5.add_mesh(P, idx); acc5.commit(build=build); acc5.wait_exact()
+    finally:
+        del os.environ["LH_DANGER_BOXES"]
+    acc5.set_param("ao_fused", 1)
+    acc5.trace_statistics(True); acc5.statistics(clear=True)
+    img_5, st_5 = acc5.render_ao_tile(cam, 0, 0, W, H, 1, ns, seed=9); torch.cuda.synchronize()
+    cnt = acc5.statistics(clear=True); acc5.trace_statistics(False)
+    assert st_5 == st_f and torch.equal(img_5, img_f)
     assert cnt["rays"] == st_f["primary_rays"] + st_f["ao_rays"]
     assert 0 < cnt["nodes"] <= cnt["rays"] and cnt["tris"] == 0, cnt
-    acc.close()
+    acc.close(); acc5.close()
+
+
+@pytest.mark.parametrize("build", ["host", "device"])
+def test_one_sliver_no_longer_sends_the_whole_dump_through_the_reference_walk(build):
+    """Round 6 (second half): the cap 1 / s2 of a zero-area triangle that stays in the tree concerns only rays that can
+    reach it in the reference's walk -- rays that hit the box of its leaf in lucille's own tree (lh_commit.hip lh_danger_scan,
+    lh_walk.h ray_needs_ref_walk).  A soup in a box of 2 000 units (a scene in millimetres) with ONE collinear triangle of 30 x 50
+    units in a corner: s2 = 1 500 and more, so the cap is far below every unit direction -- round 5 sent all 60 000 rays through the
+    single-lane reference walk; now only the rays that pass that corner go, and the records still equal the oracle's bit for bit."""
+    import torch
+    rng = np.random.default_rng(91)
+    ntri, n = 40000, 60000
+    c = rng.uniform(0, 1, (ntri, 1, 3)); T = (c + rng.normal(size=(ntri, 3, 3)) * 0.004) * 2000.0
+    a = np.array([60.0, 80.0, 40.0]); u = np.array([0.6, 0.1, 0.79]); u /= np.linalg.norm(u)
+    Z = np.stack([a, a + 30.0 * u, a + 1.6 * 30.0 * u])[None]                  # three different points on one line: it stays in the tree
+    P = np.concatenate([T, Z]).reshape(-1, 3).copy(); idx = np.arange(P.shape[0], dtype=np.uint32)
+    pick = rng.integers(0, ntri + 1, n); w = rng.random((n, 3)); w /= w.sum(1, keepdims=True)
+    tri = P.reshape(-1, 3, 3); tgt = (tri[pick] * w[:, :, None]).sum(1)
+    tgt[:2000] = Z[0, 0] + (Z[0, 2] - Z[0, 0]) * rng.random((2000, 1))      # 2 000 rays aimed AT the sliver's line (the reference's noise determinant decides)
+    org = tgt + rng.normal(size=(n, 3)) * 300.0
+    dr = tgt - org; dr /= np.linalg.norm(dr, axis=1, keepdims=True)            # unit directions: every one beyond the cap
+    ok = np.abs(dr[:, 1]) > 1e-14
+    org, dr = np.ascontiguousarray(org[ok]), np.ascontiguousarray(dr[ok]); n = org.shape[0]
+    o = po.Oracle(); o.add_mesh(P, idx); o.build()
+    exp = o.intersect(org, dr, nthreads=8)
+    acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit(build=build); acc.wait_exact()
+    assert acc.info()["ntriangles_in_tree"] == ntri + 1
+    d_o = torch.from_numpy(org).cuda(); d_d = torch.from_numpy(dr).cuda()
+    out, cnt = acc.intersect_device(d_o, d_d, counters=True); torch.cuda.synchronize()
+    assert_hits_equal(tuple(x.cpu().numpy() for x in out), exp, "%s tree, device batch" % build)
+    assert 1500 < cnt["retraced"] < n // 4, "rays through the reference walk: %d of %d" % (cnt["retraced"], n)
+    occ = acc.intersect_device(d_o, d_d, mode=la.MODE_ANY)[0]; torch.cuda.synchronize()
+    assert np.array_equal(occ.cpu().numpy().astype(bool), exp[0] != po.MISS)
+    assert_hits_equal(acc.intersect_host(org[:3000], dr[:3000]), tuple(x[:3000] for x in exp), "%s tree, host batch" % build)
+    for k in range(0, 400, 7):                                                  # ray by ray: the host walk (host-built trees) / the coalesced device path
+        hit, p_, t_, u_, v_ = acc.intersect1(org[k], dr[k])
+        assert p_ == int(exp[0][k]) and (p_ == po.MISS or (t_, u_, v_) == (exp[1][k], exp[2][k], exp[3][k])), k
+    # round 5's rule (LH_DANGER_BOXES=0 at commit): every ray takes the reference walk -- and gives the same records
+    os.environ["LH_DANGER_BOXES"] = "0"
+    try:
+        acc2 = la.HipAccel(0); acc2.add_mesh(P, idx); acc2.commit(build=build); acc2.wait_exact()
+        out2, cnt2 = acc2.intersect_device(d_o, d_d, counters=True); torch.cuda.synchronize()
+    finally:
+        del os.environ["LH_DANGER_BOXES"]
+    assert cnt2["retraced"] >= n - 10
+    assert all(torch.equal(x, y) for x, y in zip(out, out2))
+    acc.close(); acc2.close()

@@ -18,7 +18,7 @@ BIG = len(sys.argv) > 3 and sys.argv[3] == "big"        # big: 0.3 .. 1.5 M tria
 total = 0; done = 0; T0 = time.time(); BUDGET = float(os.environ.get("FUZZ_BUDGET_S", "0"))
 for r in range(rounds):
     if BUDGET > 0 and time.time() - T0 > BUDGET: break
-    kind = r % 9
+    kind = r % 10
     ntri = int(rng.choice([300000, 700000, 1500000])) if BIG else int(rng.choice([1, 2, 7, 60, 900, 12000, 150000]))
     scale = float(10.0 ** rng.uniform(-6, 6)); shift = rng.uniform(-1, 1, 3) * scale * float(rng.choice([0.0, 1.0, 100.0]))
     he = float(10.0 ** rng.uniform(-3, -0.5))
@@ -34,6 +34,9 @@ for r in range(rounds):
     if kind == 6: T[:, 1] = T[:, 0] + (T[:, 1] - T[:, 0]) * 200.0                # needles, 200 times as long as wide
     if kind == 7: T[:, 0] = T[0, 0]                                              # a fan: every triangle shares one vertex
     if kind == 8: T[0] = np.array([[-40.0, -40.0, 0.5], [80.0, -40.0, 0.5], [-40.0, 80.0, 0.5]]); T[1:] = 0.5 + (T[1:] - 0.5) * 1e-3      # one huge triangle over a speck of tiny ones
+    if kind == 9:                                                                # ONE to three zero-area triangles among ordinary ones (three different points on a line, any size): they stay in
+        for q in rng.integers(0, T.shape[0], int(rng.integers(1, 4))):           # the tree, and only rays that reach the box of their leaf in lucille's own tree take the reference walk (round 6)
+            T[q, 2] = T[q, 0] + float(rng.uniform(0.2, 3.0)) * (T[q, 1] - T[q, 0])
     if kind == 4: T[:, 2] = T[:, 0] + (T[:, 1] - T[:, 0]) * 1.0000001 + rng.normal(size=(T.shape[0], 3)) * 1e-9     # slivers
     P = (T.reshape(-1, 3) * scale + shift).astype(np.float64); idx = np.arange(P.shape[0], dtype=np.uint32)
     n = 400000 if BIG else 60000
