@@ -723,6 +723,8 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
     const int rows = (int)sc.stack_rows, rmask = rows - 1;          /* rows: a power of two (ring of stack positions) */
     int (*stk)[64] = (int (*)[64])lh_stack_lds;
     int *xref = lh_stack_lds + (size_t)rows * 64; float *xtb = (float *)(xref + 64);
+    uint32_t *stash = (uint32_t *)(xref + 128) + 16 * (threadIdx.x >> 4);          /* this group's stashed LH_Q_REF entries (below) */
+    int ns = 0;                                                                       /* group-uniform: how many */
     const int lane = threadIdx.x, g = lane >> 4;
     const unsigned long long gmask = 0xFFFFull << (16 * g), lt_mask = (1ull << lane) - 1ull;
     const uint32_t ngroups = gridDim.x * 4u;
@@ -804,23 +806,38 @@ __global__ __launch_bounds__(64) void k_coop_walk(lh_dev_scene_t sc, const doubl
                 if (owner_groups) while (e < fq.qcap && e < fq.heads[e % owner_groups]) e += ngroups;
                 if (e >= fq.qcap || (owner_groups && e >= known)) gdone = true;
                 progress = wall_clock64();
-                src_ray<SRC>(sc, (uint32_t)i, org, dir, ao, ox, oy, oz, dx, dy, dz, selfp);
                 if (reason == LH_Q_REF) {
-                    /* a fragile hit: the reference's own walk on its own tree decides, no cooperative walk */
-                    if ((lane & 15) == 0) {
-                        const RefHit rh = ref_trace_one(sc, ox, oy, oz, dx, dy, dz);
-                        if (counters) atomicAdd(&counters[LH_CNT_RETRACED], 1ull);
-                        if (SRC == 1) { if (rh.prim != LH_MISS_PRIM) { uint32_t sl, rr; ao_item(ao, (uint32_t)i, sl, rr); atomicAdd(&ao.occ_count[sl], 1u); } }
-                        else if (ANYHIT) occ[i] = rh.prim != LH_MISS_PRIM ? 1 : 0;
-                        else { prim[i] = rh.prim; t[i] = rh.t; u[i] = rh.u; v[i] = rh.v; }
-                    }
+                    /* a fragile hit, or a ray beyond deg_dcap: the reference's own walk on its own tree decides, no cooperative walk.
+                     * The entry is STASHED: the group walks its stashed rays sixteen at a time, one per lane (below) -- until round 6
+                     * the group's first lane walked every such ray by itself while fifteen watched: 8 M rays/s for a launch whose
+                     * rays all came this way (a zero-area triangle through the scene: profiles/r06_degenerate_cliff.txt) */
+                    if ((lane & 15) == 0) stash[ns] = (uint32_t)i;
+                    ns++;
                 } else {
+                    src_ray<SRC>(sc, (uint32_t)i, org, dir, ao, ox, oy, oz, dx, dy, dz, selfp);
                     lane_init(L, sc, ox, oy, oz, dx, dy, dz);
                     best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM; best.frag = 0u;
                     pend = kNoLeaf; floor_ = 1; stk[0][lane] = kDone;
                     L.cur = (lane & 15) == 0 ? 0 : kDone;
                     have = true;
                 }
+            }
+            /* the stashed reference walks: when sixteen have come together, when the queue has nothing for this group right now, or when it
+             * has just ended for it (the wave leaves the loop once every group has seen the end: nothing may stay stashed) */
+            if (ns == 16 || (ns > 0 && (ent == 0ull || gdone || have))) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if ((lane & 15) < ns) {
+                    const uint32_t ri = stash[lane & 15];
+                    double rox, roy, roz, rdx, rdy, rdz; uint32_t rself = LH_MISS_PRIM;
+                    src_ray<SRC>(sc, ri, org, dir, ao, rox, roy, roz, rdx, rdy, rdz, rself);
+                    const RefHit rh = ref_trace_one(sc, rox, roy, roz, rdx, rdy, rdz);
+                    if (counters) atomicAdd(&counters[LH_CNT_RETRACED], 1ull);
+                    if (SRC == 1) { if (rh.prim != LH_MISS_PRIM) { uint32_t sl, rr; ao_item(ao, ri, sl, rr); atomicAdd(&ao.occ_count[sl], 1u); } }
+                    else if (ANYHIT) occ[ri] = rh.prim != LH_MISS_PRIM ? 1 : 0;
+                    else { prim[ri] = rh.prim; t[ri] = rh.t; u[ri] = rh.u; v[ri] = rh.v; }
+                }
+                ns = 0;
+                progress = wall_clock64();
             }
         }
         /* a look at the queue's counters: when the whole wave is idle (after a nap of ~25 us), else every 128 iterations */
@@ -1177,7 +1194,7 @@ int launch_coop(const lh_dev_scene_t &sc, const double *org, const double *dir, 
     lh_dev_scene_t scl = sc;
     scl.stack_rows = coop_rows(sc);
     if (scl.stack_rows == 0) return -1;
-    const size_t lds = ((size_t)scl.stack_rows * 64 + 128) * sizeof(int);
+    const size_t lds = ((size_t)scl.stack_rows * 64 + 128 + 64) * sizeof(int);          /* the stack ring, 2 x 64 exchange words, 4 x 16 stashed reference-walk entries */
     static bool attr_set[2][3] = {{false, false, false}, {false, false, false}};
     if (lds > 64 * 1024 && !attr_set[ANYHIT][SRC]) {
         if (hipFuncSetAttribute((const void *)k_coop_walk<ANYHIT, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
