@@ -75,14 +75,14 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess, 
         src, k = newest_pmc_summary("pmc_ao_dense.txt")
         sq = None
         if k is not None and k.get("SQ_INSTS_VALU") and k.get("GRBM_GUI_ACTIVE"):
-            g = k.get
+            gv = k.get
             sq = {"source": "%s (tools/pmc_cmd.sh: separate SQ / TCC passes of this frame; the fused any-hit launch)" % src,
-                  "valu_busy": round(g("SQ_INSTS_VALU") * 4.0 / 1024.0 / (g("GRBM_GUI_ACTIVE") / 8.0), 3),
-                  "valu_lane_use": round(g("SQ_THREAD_CYCLES_VALU", 0.0) / max(1.0, g("SQ_ACTIVE_INST_VALU", 0.0) * 64.0), 3),
-                  "wave_cycles_waiting": round(g("SQ_WAIT_ANY", 0.0) / max(1.0, g("SQ_WAVE_CYCLES", 0.0)), 3),
-                  "l2_hit_rate": round(g("TCC_HIT_sum", 0.0) / max(1.0, g("TCC_HIT_sum", 0.0) + g("TCC_MISS_sum", 0.0)), 3),
-                  "valu_wave_instructions_per_ray": round(g("SQ_INSTS_VALU") / max(1, st["ao_rays"]), 1),
-                  "fabric_read_bytes_per_frame": g("TCC_EA0_RDREQ_sum", 0.0) * 128.0}
+                  "valu_busy": round(gv("SQ_INSTS_VALU") * 4.0 / 1024.0 / (gv("GRBM_GUI_ACTIVE") / 8.0), 3),
+                  "valu_lane_use": round(gv("SQ_THREAD_CYCLES_VALU", 0.0) / max(1.0, gv("SQ_ACTIVE_INST_VALU", 0.0) * 64.0), 3),
+                  "wave_cycles_waiting": round(gv("SQ_WAIT_ANY", 0.0) / max(1.0, gv("SQ_WAVE_CYCLES", 0.0)), 3),
+                  "l2_hit_rate": round(gv("TCC_HIT_sum", 0.0) / max(1.0, gv("TCC_HIT_sum", 0.0) + gv("TCC_MISS_sum", 0.0)), 3),
+                  "valu_wave_instructions_per_ray": round(gv("SQ_INSTS_VALU") / max(1, st["ao_rays"]), 1),
+                  "fabric_read_bytes_per_frame": gv("TCC_EA0_RDREQ_sum", 0.0) * 128.0}
         roof = {"bound": "valu issue", "achieved": round(lane_ops / min(times) / 1e12, 2), "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
                 "frac": round(lane_ops / min(times) / 1e12 / VALU_PEAK_TLANEOPS, 4), "traffic": sq["fabric_read_bytes_per_frame"] if sq else None,
                 "formula": "achieved = (%d x node steps [the any-hit step: no ranking] + %d x triangle records of the counted frame) / frame time; peak = 256 CUs x 64 lanes x 2.4 GHz"
