@@ -76,7 +76,7 @@ extern "C" int lh_accel_create(lh_accel_t **out, int device)
     env = getenv("LH_RAY_BUDGET");
     if (env && atoi(env) > 0) a->dev.ray_budget = (uint32_t)atoi(env);
     a->dev.top_nodes = LH_TOP_AUTO;
-    a->dev.deg_dcap = INFINITY; a->dev.ndanger = LH_DANGER_ALL;
+    a->dev.deg_dcap = INFINITY; a->dev.cap_srcs = 0u; a->dev.ndanger = LH_DANGER_ALL;
     a->dev.coop_patience = 0;
     a->dev.ao_group = 0;            /* measured: the grouped order is SLOWER on the config-5 frame (84.6 -> 95.1 ms, tools/ao_group_probe.py): a slot's own rays share their first levels */
     env = getenv("LH_AO_GROUP");
@@ -493,15 +493,21 @@ static int lh_danger_scan(lh_accel_t *a)
     memcpy(hs->bvh.danger, h + 8, sizeof(double) * 6 * (size_t)cnt);
     __atomic_store_n(&hs->bvh.ndanger, (uint32_t)cnt, __ATOMIC_RELEASE);      /* the one-ray host walk reads it (lh_hostwalk.c) */
     pthread_mutex_unlock(&g_scene_mu);
-    {   /* the union of the listed boxes, rounded outward to fp32 and widened by a part in a million of the scene: lh_slab's slack is sized
-         * for boxes inside the scene box, and the reference's leaf boxes carry its own margin beyond that */
+    {   /* the union of the listed boxes on the scene's 16-bit grid, a cell wider on every side (the nodes' own boxes are rounded outward
+         * the same way: lh_bvh.c).  A union that leaves the grid (a leaf that also holds a triangle outside the traversal tree's bounds):
+         * round 5's rule */
         double u[6] = {1.0e308, 1.0e308, 1.0e308, -1.0e308, -1.0e308, -1.0e308};
         for (unsigned long long i = 0; i < cnt; i++)
             for (int k = 0; k < 3; k++) { u[k] = fmin(u[k], h[8 + 6 * i + k]); u[3 + k] = fmax(u[3 + k], h[8 + 6 * i + 3 + k]); }
-        const double pad = 1.0e-6 * (double)a->dev.scene_r;
+        uint32_t w[3];
         for (int k = 0; k < 3; k++) {
-            a->dev.danger[k] = nextafterf((float)(u[k] - pad), -INFINITY); a->dev.danger[3 + k] = nextafterf((float)(u[3 + k] + pad), INFINITY);
+            const double g0 = (double)hs->bvh.grid_lo[k], st = (double)hs->bvh.grid_step[k];          /* the host scene's: a->dev's copy is set later in a device-built commit */
+            const double qlo = floor((u[k] - g0) / st) - 1.0, qhi = ceil((u[3 + k] - g0) / st) + 1.0;
+            if (!(st > 0.0) || !(qlo >= -2.0) || !(qhi <= 65537.0)) return 0;          /* (also a NaN) */
+            const uint32_t lo = qlo < 0.0 ? 0u : (uint32_t)qlo, hi = qhi > 65535.0 ? 65535u : (uint32_t)qhi;
+            w[k] = lo | hi << 16;
         }
+        for (int k = 0; k < 3; k++) a->dev.danger[k] = w[k];
     }
     a->dev.ndanger = (uint32_t)cnt;
     return 0;
@@ -709,6 +715,7 @@ static int device_upload(lh_accel_t *a)
         a->dev.ntris = hs->bvh.ntris; a->dev.nnodes = hs->bvh.nnodes;
         a->dev.max_depth = hs->bvh.max_depth; a->dev.scene_r = r; a->dev.ray_chunk = a->ray_chunk;
         a->dev.deg_dcap = hs->bvh.deg_dcap < 3.0e38 ? (float)hs->bvh.deg_dcap : INFINITY;
+        a->dev.cap_srcs = (a->dev.deg_dcap < 3.0e38f ? 1u : 0u) | (a->dev.deg_dcap < 1.0f ? 6u : 0u);
         for (int k = 0; k < 3; k++) { a->dev.grid_lo[k] = hs->bvh.grid_lo[k]; a->dev.grid_step[k] = hs->bvh.grid_step[k]; }
         if (hs->have_ref && __atomic_load_n(&hs->ref_state, __ATOMIC_ACQUIRE) == 2 && attach_ref(a) != 0) return -1;
         a->dev.nq4nodes = hs->bvh.nq4nodes; a->dev.q4_depth = hs->bvh.q4_depth; a->dev.q4_stack = hs->bvh.q4_stack;
@@ -1017,6 +1024,7 @@ int lh_scene_image_alloc(lh_accel_t *a, const lh_scene_image_t *h)
     hs->bvh.build_seconds = h->build_seconds; hs->ref_build_seconds = h->ref_build_seconds;
     hs->bvh.nlive = h->nlive; hs->bvh.deg_dcap = h->deg_dcap;
     a->dev.deg_dcap = h->deg_dcap < 3.0e38 ? (float)h->deg_dcap : INFINITY;
+    a->dev.cap_srcs = (a->dev.deg_dcap < 3.0e38f ? 1u : 0u) | (a->dev.deg_dcap < 1.0f ? 6u : 0u);
     hs->have_ref = h->have_ref; hs->ref_state = h->have_ref ? 2 : 0;
     float r = 0.0f;
     for (int k = 0; k < 3; k++) {

@@ -41,9 +41,12 @@ typedef struct lh_dev_scene {
     float       deg_dcap;  /* a ray with a direction component beyond this is decided by the reference's own walk: the traversal tree leaves out
                               zero-area triangles whose fp64 determinant is provably below the reference's 1e-14 only up to there (lh_bvh.c
                               tri_dead_class); INFINITY: no such triangle in this scene */
+    uint32_t    cap_srcs;  /* bit s: rays of source s (0 arrays, 1 AO rays of the refill, 2 camera rays of a path-traced pass) can exceed deg_dcap at all -- bit 0: it is
+                              finite; bits 1, 2: it is below 1 (those rays are unit vectors).  0 for every scene without such triangles: the persistent walk's
+                              refill then skips the test whole (one scalar branch) */
     uint32_t    ndanger;   /* deg_dcap < LH_DEG_DCAP_ALL: LH_DANGER_ALL (0) = every ray beyond deg_dcap takes the reference walk; else only rays that hit ... */
-    float       danger[6]; /* ... this box (bmin xyz rounded down, bmax xyz rounded up): the union of the boxes of the leaves of lucille's own tree that hold a
-                              zero-area triangle (lh_bvh.h), through the conservative fp32 slab test every box of the walk goes through (lh_slab) */
+    uint32_t    danger[3]; /* ... this box, on the scene's 16-bit grid in the nodes' packing (lo | hi << 16 per axis, rounded outward): the union of the boxes of the
+                              leaves of lucille's own tree that hold a zero-area triangle (lh_bvh.h), asked through slab_w like any node's box */
     uint32_t    ray_chunk; /* rays a persistent wave reserves per atomic on the global cursor */
     uint32_t    ray_budget;/* wave iterations after which a ray leaves the persistent walk for the cooperative one */
     int         stack_guard;    /* set by the launchers when the LDS rows do not cover the tree's worst case: the walks check before they push */

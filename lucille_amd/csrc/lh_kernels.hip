@@ -610,9 +610,10 @@ __device__ __forceinline__ void trace_persist_lane(
                 lane_init(L, sc, ox, oy, oz, dx, dy, dz);
                 best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM; best.frag = 0u;
                 stk[0][tid] = kDone;
-                /* camera and AO rays are unit vectors: beyond deg_dcap only where a zero-area triangle of |e1|_1 |e2|_1 > 1 stayed in the tree
-                 * (lh_bvh.c tri_zero_area_s2: deg_dcap = 1 / s2 < 1) -- then every source takes the test (wave-uniform) */
-                if ((SRC == 0 || sc.deg_dcap < 1.0f) && __builtin_expect(ray_needs_ref_walk(sc, L, dx, dy, dz), 0)) LH_FORCE_REF_WALK(L, best);
+                /* rays beyond deg_dcap are the reference walk's (lh_walk.h).  cap_srcs (host-set, scalar): can a ray of THIS source exceed it at all --
+                 * dumps whenever it is finite; camera and AO rays (unit vectors) only where a zero-area triangle of |e1|_1 |e2|_1 > 1 stayed in the
+                 * tree.  Every other scene skips the test whole */
+                if ((SRC == 0 ? (sc.cap_srcs & 1u) != 0u : sc.deg_dcap < 1.0f) && __builtin_expect(ray_needs_ref_walk(sc, L, dx, dy, dz), 0)) LH_FORCE_REF_WALK(L, best);
                 it0 = it;
             }
             wbase += take;

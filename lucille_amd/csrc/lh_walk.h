@@ -96,18 +96,21 @@ __device__ __forceinline__ void lane_init(Lane &L, const lh_dev_scene_t &sc,
  * collinear triangle with |e1|_1 |e2|_1 = s2; in a scene modelled in millimetres ANY such sliver pulls the cap below 1, and then
  * every unit-length ray would take the single-lane reference walk: ADVICE r05) concerns only rays that can REACH such a triangle in
  * the reference's walk, i.e. that hit the box of its leaf in lucille's own tree (the child box its parent holds: what
- * test_ray_node tests, bvh.c:938-1083).  The kernels ask ONE box -- the union of the listed leaves' boxes, rounded outward to
- * fp32 (lh_commit.hip lh_danger_scan) -- through lh_slab, the conservative fp32 form of test_ray_aabb every box of the textbook
- * walk goes through (outward box, per-ray slack, NaN-safe): a superset of the rays that reach one of those leaves (the leaves'
- * ancestors are not asked).  `L` is the lane right after lane_init.  (The same test in fp64, or over the list behind a call,
- * cost the persistent walk 16 bytes of scratch per lane in every instantiation: tools/kernel_resources.sh.) */
+ * test_ray_node tests, bvh.c:938-1083).  The kernels ask ONE box -- the union of the listed leaves' boxes, rounded outward onto
+ * the scene's 16-bit grid (lh_commit.hip lh_danger_scan) -- through slab_w, the conservative test every node's box goes through
+ * (outward box, per-ray slack): a superset of the rays that reach one of those leaves (the leaves' ancestors are not asked).
+ * `L` is the lane right after lane_init.  Why the grid form: it reads only what the walk keeps alive anyway (the lane's q*
+ * constants).  The same test in fp64, or over the list behind a call, cost the persistent walk 16 bytes of scratch per lane in
+ * every instantiation; through lh_slab (the fp32 box form) it kept nine of lane_init's values alive that the 4-wide walk
+ * otherwise never computes: config 4 and 5 +1 % (profiles/r06_ab_variants.txt). */
+__device__ __forceinline__ bool slab_w(const Lane &L, uint32_t wx, uint32_t wy, uint32_t wz, float &tn_out);
 __device__ __forceinline__ bool ray_needs_ref_walk(const lh_dev_scene_t &sc, const Lane &L, double dx, double dy, double dz)
 {
     const double D = fmax(fabs(dx), fmax(fabs(dy), fabs(dz)));
     if (!((D > (double)sc.deg_dcap) & (sc.ref_nodes != NULL))) return false;
     if (sc.ndanger == LH_DANGER_ALL || D > LH_DEG_DCAP_ALL) return true;
     float tn;
-    return lh_slab(&L.r, sc.danger[0], sc.danger[1], sc.danger[2], sc.danger[3], sc.danger[4], sc.danger[5], 1.0e38f, &tn) != 0;
+    return slab_w(L, sc.danger[0], sc.danger[1], sc.danger[2], tn);
 }
 /* a negative culling bound: the root's children are all missed (slab_w: 0 <= tn <= tf <= tb fails), the ray is finished after one
  * node step like any other -- no special case in the walks' control flow (a ray that is idle before its first step cost the
