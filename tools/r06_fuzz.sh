@@ -1,14 +1,15 @@
-# tools/r06_fuzz.sh (GPU box): round 6's randomised sweeps, fresh seeds, every output poisoned (LH_POISON_OUTPUTS=1 is the tools' default)
+# tools/r06_fuzz.sh (GPU box): round 6's randomised sweeps at the round's final kernels, fresh seeds, every output poisoned (LH_POISON_OUTPUTS=1 is the
+# tools' default); fuzz_parity's kind 9 = a few collinear triangles among ordinary ones (the leaf-box rule of DESIGN 4.5)
 cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/r06_fuzz.txt; : > $OUT
-run() { echo "== $*" >> $OUT; ( timeout ${T:-400} "$@" 2>&1 | grep -v amdgpu | tail -2 ) >> $OUT; }
-FUZZ_BUDGET_S=150 run python tools/fuzz_parity.py 2000 601
-FUZZ_BUDGET_S=150 run python tools/fuzz_parity.py 2000 602
-FUZZ_BUDGET_S=120 run python tools/fuzz_parity.py 40 603 big
-FUZZ_BUDGET_S=100 run python tools/fuzz_ao.py 61 400
-FUZZ_BUDGET_S=100 run python tools/fuzz_ao.py 62 400
-T=200 run python tools/fuzz_beams.py 61
-T=200 run python tools/fuzz_state.py 3000
-T=300 run python tools/fuzz_pt.py 61
-T=200 run python tools/fuzz_hostpath.py 61
+OUT=gpurun_out/r06_fuzz_final.txt; : > $OUT
+run() { echo "== $*" >> $OUT; ( timeout -k 5 ${T:-500} "$@" 2>&1 | grep -v amdgpu | tail -1 ) >> $OUT; }
+FUZZ_BUDGET_S=300 run python tools/fuzz_parity.py 4000 621
+FUZZ_BUDGET_S=300 run python tools/fuzz_parity.py 4000 622
+FUZZ_BUDGET_S=200 run python tools/fuzz_parity.py 60 623 big
+FUZZ_BUDGET_S=150 run python tools/fuzz_ao.py 64 600
+FUZZ_BUDGET_S=150 run python tools/fuzz_ao.py 65 600
+T=300 run python tools/fuzz_beams.py 62 60
+T=300 run python tools/fuzz_state.py 4000 150
+T=400 run python tools/fuzz_pt.py 62 40
+T=300 run python tools/fuzz_hostpath.py 62 30
 cat $OUT
