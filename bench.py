@@ -82,6 +82,10 @@ def main():
     ap.add_argument("--mode", choices=["closest", "any"], default="closest")
     ap.add_argument("--chunks", type=int, default=0, help="N>1: trace/gather pipeline depth per rank (with_record_gather); 0 = 16 // N (8 / 4 / 2 chunks at 2 / 4 / 8 ranks: "
                     "a chunk costs its launch's ramp and drain, ~0.6 ms for incoherent rays, profiles/r06_dump_cost_table.md)")
+    ap.add_argument("--comm-wgs", type=int, default=32,
+                    help="N>1: persistent workgroups the headline's launches leave out of their grid (of CUs x 4) so that the exchange's RCCL kernels find room "
+                         "beside them: a persistent launch holds every wave slot of the chip until its cursors run dry, and a send / receive kernel that cannot "
+                         "start until then would put the gather of chunk c BEHIND the tracing of chunk c + 1 instead of beside it")
     ap.add_argument("--record-bytes", type=int, choices=[16, 28], default=16,
                     help="N>1: bytes of a hit record on the wire -- 16: prim u32 + t, u, v fp32 (rounded from the fp64 records, which stay with the rank that traced them); 28: the fp64 records themselves")
     ap.add_argument("--gather-records", action="store_true", help="accepted for compatibility: at N > 1 the gather of every hit record to rank 0 IS inside the headline's timed region (SURVEY 8e)")
@@ -139,6 +143,9 @@ def main():
     info, commit_s, bcast_s = shard.commit_shared(acc, lambda a: a.add_mesh(P, idx), rank, world, build=args.build)     # auto: what lh_accel_commit(accel, 0) does by itself
     device_built = info["nnodes"] == info["nnodes_traversal"]          # a device-built scene has no 2-wide nodes of its own
 
+    if world > 1 and args.comm_wgs > 0:
+        full_grid = torch.cuda.get_device_properties(dev).multi_processor_count * 4
+        acc.set_param("grid", max(full_grid // 2, full_grid - args.comm_wgs))
     mode = la.MODE_CLOSEST if args.mode == "closest" else la.MODE_ANY
     rec_bytes = 28 if mode == la.MODE_CLOSEST else 1
 
@@ -396,7 +403,7 @@ def main():
                                                                       "" if world == 1 else (", %d-B hit records gathered to rank 0 inside the timed region" % wire_bytes if head_gather
                                                                                              else ", hit records stay with the rank that traced them (digest to rank 0)")),
                        "rays": n_total, "rays_per_gpu": n, "triangles": args.tris, "mode": args.mode,
-                       "variant": args.variant, "parallelism": "replicated BVH, ray slices x%d%s" % (world, "" if world == 1 else (", %d-chunk trace/gather pipeline" % nchunks if head_gather else ", one launch per rank, no per-ray exchange")),
+                       "variant": args.variant, "parallelism": "replicated BVH, ray slices x%d%s" % (world, "" if world == 1 else ((", %d-chunk trace/gather pipeline, %d workgroup slots left to the exchange's kernels" % (nchunks, args.comm_wgs)) if head_gather else ", one launch per rank, no per-ray exchange")),
                        "scene_load": {"rank0_commit_s": round(commit_s, 3), "broadcast_s": round(bcast_s, 3) if world > 1 else None,
                                       "transport": None if world == 1 else ("rccl" if shard.dist().transport == la.DIST_RCCL else "shm (ranks share a device)"),
                                       "note": "one build on rank 0, flattened arrays broadcast to every rank (lh_dist_broadcast_scene)"},

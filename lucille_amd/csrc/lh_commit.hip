@@ -490,8 +490,10 @@ static int lh_danger_scan(lh_accel_t *a)
     unsigned long long cnt; memcpy(&cnt, h, sizeof(cnt));
     if (cnt == 0 || cnt > LH_DANGER_MAX) return 0;                      /* none found (the cap came from somewhere else: keep round 5's rule) or too many */
     pthread_mutex_lock(&g_scene_mu);
-    memcpy(hs->bvh.danger, h + 8, sizeof(double) * 6 * (size_t)cnt);
-    __atomic_store_n(&hs->bvh.ndanger, (uint32_t)cnt, __ATOMIC_RELEASE);      /* the one-ray host walk reads it (lh_hostwalk.c) */
+    if (hs->bvh.ndanger == LH_DANGER_ALL) {            /* the first replica of a shared host scene writes the list; the others found the same one */
+        memcpy(hs->bvh.danger, h + 8, sizeof(double) * 6 * (size_t)cnt);
+        __atomic_store_n(&hs->bvh.ndanger, (uint32_t)cnt, __ATOMIC_RELEASE);      /* the one-ray host walk reads it (lh_hostwalk.c) */
+    }
     pthread_mutex_unlock(&g_scene_mu);
     {   /* the union of the listed boxes on the scene's 16-bit grid, a cell wider on every side (the nodes' own boxes are rounded outward
          * the same way: lh_bvh.c).  A union that leaves the grid (a leaf that also holds a triangle outside the traversal tree's bounds):
