@@ -482,6 +482,9 @@ __device__ __forceinline__ void src_ray(const lh_dev_scene_t &sc, uint32_t i, co
 }
 
 constexpr uint32_t kNoRay = 0xFFFFFFFFu;
+#ifndef LH_REFILL_PASSES
+#define LH_REFILL_PASSES 2          /* ranges a refill may draw from (1: rounds 1-5: the lanes a range's end did not fill wait for the next regroup) */
+#endif
 
 template <bool ANYHIT, bool COUNT, int WALK, int SRC>
 __device__ __forceinline__ void trace_persist_lane(
@@ -552,71 +555,86 @@ __device__ __forceinline__ void trace_persist_lane(
          * XCD-aware: the batch is cut into LH_NPART contiguous partitions with a cursor each; a wave draws from the partition
          * of the XCD it runs on (each XCD has its own 4 MiB L2: the rays of one image region -- and the nodes and triangles
          * they touch -- stay in ONE L2 instead of all eight), and moves on to the next partition when its own is drained. */
+        uint32_t newray = kNoRay;           /* the ray this lane starts now */
         if (idle_mask != 0ull && !exhausted) {
-            if (__builtin_expect(wbase == wend, 0)) {
-                const uint32_t per = (n + LH_NPART - 1) / LH_NPART;
-                uint32_t chunk = sc.ray_chunk;
-                if ((SRC != 1 && sc.n_dev) || (SRC == 1 && ao.nslots_dev)) {                   /* the host sized the chunk for its upper bound of n */
-                    const uint32_t c = n / (gridDim.x * (LH_BLOCK / 64) * 4u);
-                    chunk = c < 64u ? 64u : (c < chunk ? c : chunk);
-                }
-                /* A partition found handed out is published in the word behind the cursors (a bit mask, zeroed with them), and a wave
-                 * that runs dry reads that word before it probes further.  Without it every wave probed all LH_NPART cursors at
-                 * the end of a launch: ~5000 waves x 8 device-scope atomics, serialised per address at ~95 ns each, were the
-                 * ~0.5 ms "drain" of every launch -- an EMPTY launch of the path tracer's bounce chain took 0.49 ms
-                 * (profiles/r03_pt_sky_timeline.csv) */
-                for (;;) {
-                    if (drained == (1u << LH_NPART) - 1u) {       /* every partition has been handed out */
-                        exhausted = true;
-#ifdef LH_DIAG_CLOCK
-                        if (sc.diag_clock && (tid & 63) == 0) sc.diag_clock[(size_t)(2 * gridDim.x + blockIdx.x) * (LH_BLOCK / 64) + (tid >> 6)] = wall_clock64();
-#endif
-                        break;
-                    }
-                    if (drained & (1u << part)) { part = (part + 1u) % LH_NPART; continue; }
-                    const uint32_t p0 = per * part, p1 = (p0 + per < n) ? p0 + per : n;      /* per * LH_NPART < 2^31 + 8 */
-                    const uint32_t plen = p1 > p0 ? p1 - p0 : 0u;                              /* a small batch leaves the last partitions empty */
-                    /* (Round 6 tried GUIDED ranges here -- a look at the cursor, then min(chunk, what is left / (the partition's waves x k)) rays,
-                     * never fewer than 64 -- to shrink the spread of the waves' exits: a rank's share of the config-5 frame 7.35 / 7.80 ms
-                     * (rank 0 / 7) -> 7.96 / 8.16 (k = 1), 8.13 / 8.42 (k = 2), 8.57 / 8.60 (k = 4).  Not the atomics of the short ranges on ONE
-                     * address: with 64 cursors, eight per XCD, the same rule costs the same (7.27 / 7.71 / 7.71 ms for ranks 0 / 3 / 7 ->
-                     * 7.81 / 8.00 / 8.09 at k = 1; 64 cursors by themselves 7.54 / 7.73 / 7.93, the whole frame 48.3 -> 48.6 ms, S-soup-1M
-                     * 2 266 -> 2 253 Mrays/s) -- short ranges at the end of a launch lose more in the walk than its exits gain.
-                     * profiles/r06_share_probe.txt, r06_ab_cursors_guided.txt; tools/experiments/cursors_guided.patch.) */
-                    uint32_t b = plen;
-                    if (plen) {
-                        if ((tid & 63) == 0) b = atomicAdd(cursor + part * LH_CURSOR_STRIDE, chunk);              /* < 2^31 + waves * chunk: no wrap */
-                        b = (uint32_t)__shfl((int)b, 0);
-                    }
-                    if (b < plen) { b += p0; wbase = b; wend = (p1 - b > chunk) ? b + chunk : p1; break; }
-                    drained |= 1u << part;
-                    uint32_t seen = 0;
-                    if ((tid & 63) == 0) {
-                        seen = __hip_atomic_load(cursor + LH_NPART * LH_CURSOR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((seen & drained) != drained) atomicOr(cursor + LH_NPART * LH_CURSOR_STRIDE, drained);
-                    }
-                    drained |= (uint32_t)__shfl((int)seen, 0);
-                    part = (part + 1u) % LH_NPART;
-                }
-            }
+            /* Idle lanes take the next rays of the wave's range -- and, when the range ends short of them, go on into the NEXT range in the
+             * same regroup (round 6).  Until then the lanes a range's last rays did not fill stayed idle until the following regroup: once
+             * per range -- every sixteenth refill of a tile pipeline's 1 024-ray ranges, every sixth of a dump's 256.  Two passes cover every
+             * case but a range clipped at its partition's end.  Config 4 108.1 -> 107.5 ms, config 5 48.2 -> 47.9 ms, S-soup-1M 2 263 -> 2 269
+             * Mrays/s (profiles/r06_ab_refill.txt; LH_REFILL_PASSES=1: rounds 1-5).  It is NOT what makes short ranges at the end of a
+             * launch lose: guided ranges lose as much with it (shares 7.23 / 7.60 / 7.67 -> 7.73 / 8.02 / 8.09 ms, and S-soup-1M -2 %:
+             * the look at the cursor before the atomic is a second dependent trip to L2 per range). */
             const int need = __popcll(idle_mask);
-            const uint32_t avail = wend - wbase;
-            const int take = avail < (uint32_t)need ? (int)avail : need;
             const int rank = __popcll(idle_mask & ((1ull << (tid & 63)) - 1ull));
-            if (idle && rank < take) {
-                const uint32_t i = wbase + (uint32_t)rank;
-                my = i;
-                src_ray<SRC>(sc, i, org, dir, ao, ox, oy, oz, dx, dy, dz, selfp);
-                lane_init(L, sc, ox, oy, oz, dx, dy, dz);
-                best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM; best.frag = 0u;
-                stk[0][tid] = kDone;
-                /* rays beyond deg_dcap are the reference walk's (lh_walk.h).  cap_srcs (host-set, scalar): can a ray of THIS source exceed it at all --
-                 * dumps whenever it is finite; camera and AO rays (unit vectors) only where a zero-area triangle of |e1|_1 |e2|_1 > 1 stayed in the
-                 * tree.  Every other scene skips the test whole */
-                if ((SRC == 0 ? (sc.cap_srcs & 1u) != 0u : sc.deg_dcap < 1.0f) && __builtin_expect(ray_needs_ref_walk(sc, L, dx, dy, dz), 0)) LH_FORCE_REF_WALK(L, best);
-                it0 = it;
+            int filled = 0;
+#pragma nounroll
+            for (int pass = 0; pass < LH_REFILL_PASSES && filled < need && !exhausted; pass++) {
+                if (__builtin_expect(wbase == wend, 0)) {
+                    const uint32_t per = (n + LH_NPART - 1) / LH_NPART;
+                    uint32_t chunk = sc.ray_chunk;
+                    if ((SRC != 1 && sc.n_dev) || (SRC == 1 && ao.nslots_dev)) {                   /* the host sized the chunk for its upper bound of n */
+                        const uint32_t c = n / (gridDim.x * (LH_BLOCK / 64) * 4u);
+                        chunk = c < 64u ? 64u : (c < chunk ? c : chunk);
+                    }
+                    /* A partition found handed out is published in the word behind the cursors (a bit mask, zeroed with them), and a wave
+                     * that runs dry reads that word before it probes further.  Without it every wave probed all LH_NPART cursors at
+                     * the end of a launch: ~5000 waves x 8 device-scope atomics, serialised per address at ~95 ns each, were the
+                     * ~0.5 ms "drain" of every launch -- an EMPTY launch of the path tracer's bounce chain took 0.49 ms
+                     * (profiles/r03_pt_sky_timeline.csv) */
+                    for (;;) {
+                        if (drained == (1u << LH_NPART) - 1u) {       /* every partition has been handed out */
+                            exhausted = true;
+    #ifdef LH_DIAG_CLOCK
+                            if (sc.diag_clock && (tid & 63) == 0) sc.diag_clock[(size_t)(2 * gridDim.x + blockIdx.x) * (LH_BLOCK / 64) + (tid >> 6)] = wall_clock64();
+    #endif
+                            break;
+                        }
+                        if (drained & (1u << part)) { part = (part + 1u) % LH_NPART; continue; }
+                        const uint32_t p0 = per * part, p1 = (p0 + per < n) ? p0 + per : n;      /* per * LH_NPART < 2^31 + 8 */
+                        const uint32_t plen = p1 > p0 ? p1 - p0 : 0u;                              /* a small batch leaves the last partitions empty */
+                        /* (Round 6 tried GUIDED ranges here -- a look at the cursor, then min(chunk, what is left / (the partition's waves x k)) rays,
+                         * never fewer than 64 -- to shrink the spread of the waves' exits: a rank's share of the config-5 frame 7.35 / 7.80 ms
+                         * (rank 0 / 7) -> 7.96 / 8.16 (k = 1), 8.13 / 8.42 (k = 2), 8.57 / 8.60 (k = 4).  Not the atomics of the short ranges on ONE
+                         * address: with 64 cursors, eight per XCD, the same rule costs the same (7.27 / 7.71 / 7.71 ms for ranks 0 / 3 / 7 ->
+                         * 7.81 / 8.00 / 8.09 at k = 1; 64 cursors by themselves 7.54 / 7.73 / 7.93, the whole frame 48.3 -> 48.6 ms, S-soup-1M
+                         * 2 266 -> 2 253 Mrays/s) -- short ranges at the end of a launch lose more in the walk than its exits gain.
+                         * profiles/r06_share_probe.txt, r06_ab_cursors_guided.txt; tools/experiments/cursors_guided.patch.) */
+                        uint32_t b = plen;
+                        if (plen) {
+                            if ((tid & 63) == 0) b = atomicAdd(cursor + part * LH_CURSOR_STRIDE, chunk);              /* < 2^31 + waves * chunk: no wrap */
+                            b = (uint32_t)__shfl((int)b, 0);
+                        }
+                        if (b < plen) { b += p0; wbase = b; wend = (p1 - b > chunk) ? b + chunk : p1; break; }
+                        drained |= 1u << part;
+                        uint32_t seen = 0;
+                        if ((tid & 63) == 0) {
+                            seen = __hip_atomic_load(cursor + LH_NPART * LH_CURSOR_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((seen & drained) != drained) atomicOr(cursor + LH_NPART * LH_CURSOR_STRIDE, drained);
+                        }
+                        drained |= (uint32_t)__shfl((int)seen, 0);
+                        part = (part + 1u) % LH_NPART;
+                    }
+                }
+                if (!exhausted) {
+                    const uint32_t avail = wend - wbase;
+                    const int take = avail < (uint32_t)(need - filled) ? (int)avail : need - filled;
+                    if (idle && rank >= filled && rank < filled + take) newray = wbase + (uint32_t)(rank - filled);
+                    wbase += (uint32_t)take; filled += take;
+                }
             }
-            wbase += take;
+        }
+        if (newray != kNoRay) {
+            const uint32_t i = newray;
+            my = i;
+            src_ray<SRC>(sc, i, org, dir, ao, ox, oy, oz, dx, dy, dz, selfp);
+            lane_init(L, sc, ox, oy, oz, dx, dy, dz);
+            best.t = LH_T_INF; best.u = 0.0; best.v = 0.0; best.prim = LH_MISS_PRIM; best.frag = 0u;
+            stk[0][tid] = kDone;
+            /* rays beyond deg_dcap are the reference walk's (lh_walk.h).  cap_srcs (host-set, scalar): can a ray of THIS source exceed it at all --
+             * dumps whenever it is finite; camera and AO rays (unit vectors) only where a zero-area triangle of |e1|_1 |e2|_1 > 1 stayed in the
+             * tree.  Every other scene skips the test whole */
+            if ((SRC == 0 ? (sc.cap_srcs & 1u) != 0u : sc.deg_dcap < 1.0f) && __builtin_expect(ray_needs_ref_walk(sc, L, dx, dy, dz), 0)) LH_FORCE_REF_WALK(L, best);
+            it0 = it;
         }
         const unsigned long long work = __ballot((L.cur != kDone) | (pend != 0));
         if (work == 0ull) break;

@@ -121,3 +121,28 @@ def test_rccl_transport_with_a_world_of_one():
     x = torch.arange(12, device="cuda", dtype=torch.float32).reshape(3, 4)
     assert torch.equal(d.gather(x)[0], x)
     d.barrier(); d.close(); acc.close()
+
+
+def test_wire_records_are_the_fp64_records_rounded_to_nearest():
+    """lh_dist_pack_records16 (the exchange's 16-byte record: prim u32 + t, u, v fp32): against numpy's rounding of the fp64 records of a
+    real launch -- hits, misses (prim 0xFFFFFFFF, t = 1e38), an odd count, and the refusals (a misaligned buffer, a NULL array)"""
+    import torch
+    from lucille_amd import binding
+    P, idx, org, dr = po.soup(20000, 100003, 0.01, 77)
+    acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit()
+    out = acc.intersect_device(torch.from_numpy(org).cuda(), torch.from_numpy(dr).cuda()); torch.cuda.synchronize()
+    n = org.shape[0]
+    rec = torch.full((16 * n + 16,), 0x55, dtype=torch.uint8, device="cuda")
+    binding.pack_records16(out[0], out[1], out[2], out[3], rec, n=n); torch.cuda.synchronize()
+    r = rec[:16 * n].cpu().numpy().view(np.uint32).reshape(n, 4)
+    prim = out[0].cpu().numpy().view(np.uint32)
+    assert np.array_equal(r[:, 0], prim) and 0 < int((prim == po.MISS).sum()) < n
+    for k in (1, 2, 3):
+        assert np.array_equal(r[:, k].view(np.float32), out[k].cpu().numpy().astype(np.float32))
+    assert np.all(rec[16 * n:].cpu().numpy() == 0x55)                      # nothing behind the n-th record
+    hit = prim != po.MISS
+    t64 = out[1].cpu().numpy()[hit]
+    assert np.max(np.abs(r[hit, 1].view(np.float32).astype(np.float64) - t64) / t64) < 6.1e-8       # north_star: 1e-5
+    with pytest.raises(la.LucilleHipError):
+        binding.pack_records16(out[0], out[1], out[2], out[3], rec[4:], n=n)
+    acc.close()
