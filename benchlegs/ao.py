@@ -139,7 +139,7 @@ def ao_frame_leg(la, acc_device, rank, world, size, nsamples, steps, dev, tess, 
         return None
     return {"workload": "BASELINE config 5: examples/ambient_occlusion scene tessellated to %d tris, %dx%d, %d AO samples, frame wall incl. ray gen + tile gather"
                         % (ntri, size, size, nsamples), "triangles": ntri,
-            "tile": tile if tile is not None else "%d full-width bands of %d rows dealt out to %d ranks in serpentine order (shard.bands_of_rank), one device batch per rank, one float per pixel gathered" % (
+            "tile": tile if tile is not None else "%d full-width bands of %d rows dealt out to %d ranks in serpentine order (shard.bands_of_rank), one device batch per rank, one byte per pixel gathered (the count of unoccluded rays; a float when samples per pixel > 1 or AO rays > 255)" % (
                 len(render.bands_for(size, world)[1]), render.bands_for(size, world)[0], world),
             "device_bytes": info["device_bytes"], "build_s": round(info["build_seconds"], 3),
             "ref_tree_build_s": round(info["ref_build_seconds"], 3),

@@ -502,14 +502,26 @@ __host__ __device__ static inline int band_rank(int g, int pos, int world)
 }
 
 /* ch: floats per pixel of the slabs -- 3 (RGB), or 1: an AO frame is grey (Lo = (N - occluded) / N in every channel,
- * ambientocclusion.c:383-401), so the exchange step moves ONE float per pixel and the owner of the display writes it three times */
+ * ambientocclusion.c:383-401), so the exchange step moves ONE float per pixel and the owner of the display writes it three times (k_take_count8 below: one BYTE
+ * when the frame has one sample per pixel) */
 __global__ void k_take_channel0(size_t npix, const float *__restrict__ rgb, float *__restrict__ mono)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < npix) mono[i] = rgb[3 * i];
 }
 
-__global__ void k_place_bands(const float *__restrict__ slabs, float *__restrict__ frame, int world, int per, int rows, int W, int H, int ch)
+/* ... and with ONE sample per pixel that float is (N - occluded) / N for an integer N - occluded <= N (k_ao_resolve, lh_render.hip:
+ * `(float)(1.0 * (ns - occlusion) / ns)`, 0 for a miss): ONE BYTE per pixel travels when N <= 255 -- the count, recovered exactly from the float
+ * (it is within 1e-7 N of an integer) -- and the owner of the display evaluates the same expression on it: the same bits (round 6:
+ * the exchange of a 4096^2 frame at 8 ranks 58.7 -> 14.7 MB into rank 0) */
+__global__ void k_take_count8(size_t npix, const float *__restrict__ rgb, uint8_t *__restrict__ cnt, float N)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < npix) cnt[i] = (uint8_t)(int)(rgb[3 * i] * N + 0.5f);
+}
+
+/* ch: floats per pixel of the slabs (3, 1), or 0: one byte per pixel, the count of k_take_count8 over N = nsamp */
+__global__ void k_place_bands(const float *__restrict__ slabs, float *__restrict__ frame, int world, int per, int rows, int W, int H, int ch, int nsamp = 0)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)W * H) return;
@@ -518,8 +530,15 @@ __global__ void k_place_bands(const float *__restrict__ slabs, float *__restrict
     const int y0 = band * rows, h = (y0 + rows <= H) ? rows : H - y0;
     /* inside a band slab the first frame line of the band is the LAST of its h lines; a clipped band keeps them at the bottom */
     const int srow = (rows - h) + (h - 1 - (line - y0));
-    const float *src = slabs + ((((size_t)r * per + k) * rows + srow) * W + x) * (size_t)ch;
     float *dst = frame + i * 3;
+    if (ch == 0) {
+        const uint8_t c = ((const uint8_t *)slabs)[(((size_t)r * per + k) * rows + srow) * W + x];
+        const double ns = (double)(uint32_t)nsamp;
+        const float f = (float)(1.0 * (double)c / ns);                 /* k_ao_resolve's expression for ns - occlusion = c */
+        dst[0] = f; dst[1] = f; dst[2] = f;
+        return;
+    }
+    const float *src = slabs + ((((size_t)r * per + k) * rows + srow) * W + x) * (size_t)ch;
     dst[0] = src[0]; dst[1] = ch == 3 ? src[1] : src[0]; dst[2] = ch == 3 ? src[2] : src[0];
 }
 
@@ -549,12 +568,17 @@ extern "C" int lh_dist_render_ao_frame_host(lh_dist_t *d, lh_accel_t *accel, con
     if (ok) ok = lh_render_ao_bands(accel, cam, (int)y0.size(), y0.data(), band_rows, pixel_samples, gather_nsamples, seed, d->slab.p, &st, (void *)d->stream) == 0;
     char why[512]; why[0] = 0;
     if (!ok) snprintf(why, sizeof(why), "%s", lh_last_error());
-    /* what travels: one float per pixel (k_take_channel0) */
-    const size_t slab_px = (size_t)per * band_rows * W, mono_bytes = slab_px * sizeof(float);
+    /* what travels: one float per pixel (k_take_channel0) -- or, with one sample per pixel and at most 255 AO rays per hit, one BYTE: the
+     * number of unoccluded rays (k_take_count8); LH_DIST_AO_BYTES=4 keeps the float */
+    const int nphi_ = (int)sqrt((double)gather_nsamples), nsamp = nphi_ * nphi_;          /* lh_tile.hip ao_region, ambientocclusion.c:378-380 */
+    static const bool want8 = !(getenv("LH_DIST_AO_BYTES") && atoi(getenv("LH_DIST_AO_BYTES")) == 4);
+    const bool count8 = want8 && pixel_samples == 1 && nsamp >= 1 && nsamp <= 255;
+    const size_t slab_px = (size_t)per * band_rows * W, mono_bytes = slab_px * (count8 ? 1 : sizeof(float));
     if (ok && lh_ensure_buf(&d->mono, mono_bytes)) { ok = 0; snprintf(why, sizeof(why), "%s", lh_last_error()); }
     if (ok) {
-        hipLaunchKernelGGL(k_take_channel0, dim3((unsigned)((slab_px + 255) / 256)), dim3(256), 0, d->stream, slab_px, (const float *)d->slab.p, (float *)d->mono.p);
-        if (hipGetLastError() != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "k_take_channel0 launch failed"); }
+        if (count8) hipLaunchKernelGGL(k_take_count8, dim3((unsigned)((slab_px + 255) / 256)), dim3(256), 0, d->stream, slab_px, (const float *)d->slab.p, (uint8_t *)d->mono.p, (float)nsamp);
+        else hipLaunchKernelGGL(k_take_channel0, dim3((unsigned)((slab_px + 255) / 256)), dim3(256), 0, d->stream, slab_px, (const float *)d->slab.p, (float *)d->mono.p);
+        if (hipGetLastError() != hipSuccess) { ok = 0; snprintf(why, sizeof(why), "k_take_channel0 / k_take_count8 launch failed"); }
     }
     if (ok && d->rank == 0 && lh_ensure_buf(&d->all, mono_bytes * (size_t)d->world)) { ok = 0; snprintf(why, sizeof(why), "%s", lh_last_error()); }
     const int all_ok = dist_agree(d, ok);
@@ -586,7 +610,7 @@ extern "C" int lh_dist_render_ao_frame_host(lh_dist_t *d, lh_accel_t *accel, con
         if (lh_ensure_buf(&d->frame, fb)) return -1;
         const size_t px = (size_t)W * H;
         hipLaunchKernelGGL(k_place_bands, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, d->stream, (const float *)d->all.p, (float *)d->frame.p,
-                           d->world, per, band_rows, W, H, 1);
+                           d->world, per, band_rows, W, H, count8 ? 0 : 1, nsamp);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(rgb, d->frame.p, fb, hipMemcpyDeviceToHost, d->stream));
     }

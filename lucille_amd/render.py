@@ -56,6 +56,7 @@ def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, worl
     one batch each (the round-1 path, kept for comparison).  Returns (image|None, local stats).
     timing: a dict that receives this rank's bands / batch_ms / gather_ms (diagnostic frames only: it synchronises the device
     between the two phases)."""
+    import os
     import time
     import torch
     W, H = cam.width, cam.height
@@ -74,8 +75,17 @@ def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, worl
         shards = [(0, y0, W, min(rows, H - y0)) for y0 in y0s]
         # an AO frame is grey (Lo = (N - occluded) / N in every channel, ambientocclusion.c:383-401): ONE float per pixel travels,
         # rank 0 writes it three times (lh_dist.hip k_take_channel0 / k_place_bands do the same for a C caller)
-        mono = slab.view(per, rows * W, 3)[:, :, 0].contiguous()
-        img = assemble_shards(mono, shards, W, H, rank, world, stride_rows=rows, serpentine=True, channels=1)
+        mono = slab.view(per, rows * W, 3)[:, :, 0]
+        # ... and with one sample per pixel that float is (N - occluded) / N for an integer numerator (lh_render.hip k_ao_resolve):
+        # for N <= 255 ONE BYTE per pixel travels, the numerator -- read back exactly from the float, which is within 1e-7 N of
+        # it -- and rank 0 evaluates the same fp64 quotient on it: the same bits (lh_dist.hip k_take_count8 does the same for a C
+        # caller; LH_DIST_AO_BYTES=4 keeps the float)
+        nsamp = ao_ray_count(gather_nsamples)
+        if pixel_samples == 1 and 1 <= nsamp <= 255 and world > 1 and os.environ.get("LH_DIST_AO_BYTES", "1") != "4":
+            mono = (mono * float(nsamp) + 0.5).to(torch.uint8)
+            img = assemble_shards(mono, shards, W, H, rank, world, stride_rows=rows, serpentine=True, channels=1, count_of=nsamp)
+        else:
+            img = assemble_shards(mono.contiguous(), shards, W, H, rank, world, stride_rows=rows, serpentine=True, channels=1)
         if timing is not None:
             torch.cuda.synchronize(dev)
             timing.update(bands=len(mine), band_rows=rows, batch_ms=round((t1 - t0) * 1e3, 3), gather_ms=round((time.perf_counter() - t1) * 1e3, 3))
@@ -95,16 +105,28 @@ def render_ao_frame_sharded(acc, cam, pixel_samples, gather_nsamples, rank, worl
     return assemble_shards(slab, shards, W, H, rank, world), tot
 
 
-def assemble_shards(slab, shards, W, H, rank, world, stride_rows=None, serpentine=False, channels=3):
+def ao_ray_count(gather_nsamples):
+    """AO rays per hit point: nphi = ntheta = (int)sqrt(nsamples) (ambientocclusion.c:378-380; lh_tile.hip ao_region)"""
+    import math
+    nphi = int(math.sqrt(float(gather_nsamples)))
+    return nphi * nphi
+
+
+def assemble_shards(slab, shards, W, H, rank, world, stride_rows=None, serpentine=False, channels=3, count_of=None):
     """the exchange step (one gather of [per_rank, cap] slabs to rank 0) + placement with the reference's y flip
     (bucket_write, render.c:962-964).  stride_rows: the slab of a shard holds that many rows (bands of a batch: a clipped
     last band keeps its lines at the BOTTOM of its slab, the clipped lines being below the frame); None: h rows.
     serpentine: the shards were dealt out by shard.bands_of_rank (AO bands), else by shard.tiles_of_rank.
-    channels: floats per pixel in the slabs (1: a grey frame, expanded to RGB here)."""
+    channels: floats per pixel in the slabs (1: a grey frame, expanded to RGB here).  count_of: the slabs hold uint8 numerators
+    over that denominator (a one-sample AO frame) instead of floats."""
     import torch
     out = shard.gather_slabs(slab, rank, world)
     if rank != 0:
         return None
+    odt = slab.dtype
+    if count_of is not None:
+        out = [(o.to(torch.float64) / float(count_of)).to(torch.float32) for o in out]
+        odt = torch.float32
     if channels == 1:
         out = [o.view(o.shape[0], -1, 1).expand(-1, -1, 3).reshape(o.shape[0], -1) for o in out]
     of_rank = shard.bands_of_rank if serpentine else shard.tiles_of_rank
@@ -112,13 +134,13 @@ def assemble_shards(slab, shards, W, H, rank, world, stride_rows=None, serpentin
         # regular bands: one indexed copy per rank, then one flip -- band 0 is the BOTTOM of the image, every band is
         # already top-line-first inside (thousands of bands per frame: no Python loop over them)
         nb = H // stride_rows
-        bands = torch.empty((nb, stride_rows, W, 3), dtype=slab.dtype, device=slab.device)
+        bands = torch.empty((nb, stride_rows, W, 3), dtype=odt, device=slab.device)
         for r in range(world):
             ids = of_rank(nb, r, world)
             if ids:
                 bands[torch.tensor(ids, device=slab.device)] = out[r][:len(ids)].view(len(ids), stride_rows, W, 3)
         return bands.flip(0).reshape(H, W, 3)
-    img = torch.zeros((H, W, 3), dtype=slab.dtype, device=slab.device)
+    img = torch.zeros((H, W, 3), dtype=odt, device=slab.device)
     for r in range(world):
         for k, tid in enumerate(of_rank(len(shards), r, world)):
             x0, y0, w, h = shards[tid]

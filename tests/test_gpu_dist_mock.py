@@ -69,7 +69,12 @@ d.broadcast(b)
 d.barrier()
 c = g["camera"]; cam = la.Camera.make(96, 70, c[16], c[:16], int(c[19]))
 img, st = d.render_ao_frame(acc, cam, 2, 9, seed=3, band_rows=4)
-np.savez(out, prim=got[0], t=got[1], u=got[2], v=got[3], gathered=(gat.cpu().numpy() if gat is not None else np.zeros(0)), bcast=b.cpu().numpy(),
+# one sample per pixel, 9 and 16 AO rays: ONE BYTE per pixel travels (k_take_count8); 289 rays: the float again
+img1 = {}
+for ns in (9, 16, 289):
+    im, _ = d.render_ao_frame(acc, cam, 1, ns, seed=5, band_rows=4)
+    img1["img1_%%d" %% ns] = im if im is not None else np.zeros(0)
+np.savez(out, **img1, prim=got[0], t=got[1], u=got[2], v=got[3], gathered=(gat.cpu().numpy() if gat is not None else np.zeros(0)), bcast=b.cpu().numpy(),
          transport=d.transport, img=(img if img is not None else np.zeros(0)), stats=np.array([st[k] for k in ("primary_rays", "primary_hits", "ao_rays", "ao_occluded")]))
 d.close(); acc.close()
 """
@@ -102,6 +107,7 @@ def test_rccl_branch_with_peers(tmp_path, world):
     exp = acc.intersect_host(org, dr)
     c = g["camera"]; cam = la.Camera.make(96, 70, c[16], c[:16], int(c[19]))
     ref, st_ref = acc.render_ao_frame_host(cam, 2, 9, seed=3)
+    ref1 = {ns: acc.render_ao_frame_host(cam, 1, ns, seed=5)[0] for ns in (9, 16, 289)}
     acc.close()
     assert (exp[0] != po.MISS).sum() > 500
     for r in range(world):
@@ -115,6 +121,13 @@ def test_rccl_branch_with_peers(tmp_path, world):
     for r in range(world):                                      # every peer's slab landed in ITS slot of rank 0's buffer
         assert np.array_equal(gat[r], np.arange(15, dtype=np.float32).reshape(5, 3) + 100.0 * r)
     assert np.array_equal(z0["img"], ref)                       # bands of `world` ranks, gathered and placed == the one-process frame
+    for ns in (9, 16, 289):                                     # ... and so are the one-sample frames, whose pixels travel as counts of unoccluded rays
+        assert np.array_equal(z0["img1_%d" % ns], ref1[ns]), ns
+        assert len(np.unique(ref1[ns])) > min(ns, 16) // 2
+    # what rank 0 received for them: width x lines-of-a-rank bytes for 9 and 16 rays, floats for 289 (17 x 17 > 255)
+    nbands = (70 + 3) // 4; per = (nbands + world - 1) // world * 4 * 96
+    sizes = [int(l.split()[2]) for l in open(str(tmp_path / "calls") + ".rank1").read().splitlines() if l.startswith("Send 0 ")]
+    assert sizes.count(per) == 2 and sizes.count(4 * per) == 2, (per, sizes)
     assert z0["stats"].tolist() == [st_ref[k] for k in ("primary_rays", "primary_hits", "ao_rays", "ao_occluded")]
     # the call pattern of the exchange step: rank 0 posts world - 1 receives in ONE group, every peer one send in one group
     log0 = open(str(tmp_path / "calls") + ".rank0").read().splitlines()

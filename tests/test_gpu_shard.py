@@ -44,6 +44,14 @@ def _worker(rank, world, port, q):
     c = g["camera"]
     cam = la.Camera.make(200, 150, c[16], c[:16], int(c[19]))        # 150 lines: the last band is clipped
     out = {}
+    # one sample per pixel: the bands travel as one byte per pixel (the count of unoccluded rays), LH_DIST_AO_BYTES=4: as floats
+    for name, env4 in (("bands_bytes", "1"), ("bands_floats", "4")):
+        os.environ["LH_DIST_AO_BYTES"] = env4
+        img, _ = render.render_ao_frame_sharded(acc, cam, 1, 16, rank, world, seed=4)
+        if rank == 0:
+            ref, _ = render.render_ao_frame(acc, cam, 1, 16, tile=200, seed=4)
+            out[name] = bool(torch.equal(img, ref)) and int(torch.unique(ref).numel()) > 8
+    os.environ.pop("LH_DIST_AO_BYTES")
     for name, kw in (("bands", {}), ("tiles", {"tile": 64})):
         img, st = render.render_ao_frame_sharded(acc, cam, 2, 16, rank, world, seed=3, **kw)
         stt = torch.tensor([st["primary_rays"], st["primary_hits"], st["ao_rays"], st["ao_occluded"]], dtype=torch.int64)
@@ -87,7 +95,7 @@ def test_two_ranks_on_one_gpu_equal_the_unsharded_frames():
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0
-    assert out == {"bands": True, "tiles": True, "pt": True, "pt_bands": True}, out
+    assert out == {"bands_bytes": True, "bands_floats": True, "bands": True, "tiles": True, "pt": True, "pt_bands": True}, out
 
 
 def test_bench_n2_code_path_on_one_gpu():

@@ -173,8 +173,13 @@ def _band_worker(rank, world, port, W, H, rows, q):
     # a grey frame travels as ONE float per pixel (channel 1 here: the frame line) and comes back as three
     mono = slab.view(per, rows * W, 3)[:, :, 1].contiguous()
     img1 = render.assemble_shards(mono, shards, W, H, rank, world, stride_rows=rows, serpentine=True, channels=1)
+    # ... and a one-sample AO frame as ONE BYTE per pixel, the numerator of (N - occluded) / N (here: line % 17 over 16)
+    cnt = (mono.to(torch.int64) % 17).to(torch.uint8)
+    img8 = render.assemble_shards(cnt, shards, W, H, rank, world, stride_rows=rows, serpentine=True, channels=1, count_of=16)
     if rank == 0:
         assert img1.shape == (H, W, 3) and bool((img1 == img[..., 1:2]).all())
+        want = ((img[..., 1:2].to(torch.int64) % 17).to(torch.float64) / 16.0).to(torch.float32)
+        assert img8.dtype == torch.float32 and img8.shape == (H, W, 3) and bool((img8 == want).all())
         q.put(img.numpy())
     dist.barrier()
     dist.destroy_process_group()
