@@ -24,5 +24,6 @@ def host_path_leg(acc, d_org, d_dir, n):
         assert rc == 0
         best = th if best is None else min(best, th)
     return {"value": round(nh / best / 1e6, 1), "unit": "Mrays/s", "link_GBps": round(nh * 76 / best / 1e9, 1),
-            "sample": "%d rays through lh_accel_intersect_host: pageable host arrays -> pinned staging in 2 M-ray chunks on two "
-                      "streams, 48 B/ray up + 28 B/ray down over PCIe; never the headline value" % nh}
+            "sample": "%d rays through lh_accel_intersect_host: pageable host arrays -> a ring of three pinned 2 M-ray blocks, rays up on one "
+                      "stream, trace + records down alternating between two more, 48 B/ray up + 28 B/ray down over PCIe "
+                      "(profiles/r06_hostpath.txt); never the headline value" % nh}

@@ -214,11 +214,12 @@ static void release_device(lh_accel_t *a)
         memset(q, 0, sizeof(*q)); a->aoq[k].used = 0;
     }
     if (a->pipe.ready) {
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < a->pipe.depth; b++) {
             (void)hipHostFree(a->pipe.h_in[b]); (void)hipHostFree(a->pipe.h_out[b]);
             (void)hipFree(a->pipe.d_in[b]); (void)hipFree(a->pipe.d_out[b]);
-            (void)hipStreamDestroy(a->pipe.s[b]); (void)hipEventDestroy(a->pipe.done[b]);
+            (void)hipEventDestroy(a->pipe.in_done[b]); (void)hipEventDestroy(a->pipe.done[b]);
         }
+        for (int b = 0; b < 3; b++) (void)hipStreamDestroy(a->pipe.s[b]);
         a->pipe.ready = 0;
     }
     if (a->d_stage) (void)hipFree(a->d_stage);

@@ -38,6 +38,7 @@ struct lh_mesh_copy { uint32_t npos, nidx; double *pos; uint32_t *idx; double *n
 
 struct lh_buf { void *p; size_t cap; };
 #define LH_AOQ_SLOTS 4
+#define LH_PIPE_DEPTH_MAX 8   /* staging blocks of a pipelined host batch (lh_query.hip) */
 
 /* the host side of a committed scene: ONE build, any number of device replicas (lh_multi.hip
  * uploads it to every GPU of the node; SURVEY.md 8e "replicated BVH") */
@@ -96,8 +97,9 @@ struct lh_accel {
     struct { hipStream_t stream; int used; lh_fixq_t q; } aoq[LH_AOQ_SLOTS];
     /* staging for host batches */
     void *d_stage; size_t stage_bytes;
-    /* pipelined host batches: two pinned in/out staging pairs, two device pairs, two streams */
-    struct { void *h_in[2], *h_out[2], *d_in[2], *d_out[2]; hipStream_t s[2]; hipEvent_t done[2]; size_t cap; int ready; } pipe;
+    /* pipelined host batches: a ring of pinned in/out staging blocks and their device twins; rays up on s[0]; trace + records down alternate between s[1] and s[2] */
+    struct { void *h_in[LH_PIPE_DEPTH_MAX], *h_out[LH_PIPE_DEPTH_MAX], *d_in[LH_PIPE_DEPTH_MAX], *d_out[LH_PIPE_DEPTH_MAX]; hipStream_t s[3];
+             hipEvent_t in_done[LH_PIPE_DEPTH_MAX], done[LH_PIPE_DEPTH_MAX]; size_t cap; int depth, ready; } pipe;
     void *d_nrm9;                      /* hs->nrm9 on the device */
     void *d_attr9[3], *d_st6, *d_inside;            /* colour / tangent / binormal, st, inside flags (uploaded at commit if present) */
     void *d_prim_mesh;                 /* mesh ordinal per primitive (materials; uploaded on first use) */

@@ -3,6 +3,11 @@
  * and pipelined host batches, one synchronous ray, traversal statistics (src/render/bvh.c:669-706) and beam visibility
  * (ri_bvh_intersect_beam_visibility, bvh.c:612-667).  The kernels are in lh_kernels.hip / lh_beam.hip.
  */
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -208,41 +213,118 @@ int lh_ensure_stage(lh_accel_t *a, size_t bytes)
 }
 
 /* ---- large host batches: chunks pipelined through pinned staging -----------------------------------
- * A pageable hipMemcpy moves ~12 GB/s; the link does ~50.  Rays are cut into chunks of LH_PIPE_CHUNK;
- * chunk k is copied into pinned memory by a few host threads, sent, traced and brought back on stream
- * k & 1 while the host stages chunk k+1 and un-stages chunk k-1. */
-#define LH_PIPE_CHUNK ((size_t)1 << 21)
+ * A pageable hipMemcpy moves ~12 GB/s; the link does ~50.  Rays are cut into chunks of `cap` rays; chunk k is copied into pinned
+ * block k % depth by a pool of host threads, sent, traced and brought back on stream k & 1 while the host stages the next chunks
+ * and un-stages the finished ones.
+ *
+ * Rounds 2-5: two blocks of 2 M rays, whole chunks on two alternating streams, eight threads spawned per copy: 520 Mrays/s closest hit,
+ * 640 any hit (S-soup-1M, 20 M rays) where the link alone does 57 GB/s each way = 1 190 Mrays/s of 48-byte rays.  Round 6 looked at the
+ * timeline (profiles/r06_hostpath.txt): the host's copies were NOT the bound (3 .. 12 threads, memcpy or streaming stores: the same) --
+ * the two streams ran in step, and streams that share one of the runtime's four hardware queues run one after the other.  Now: a stream
+ * per direction of the link, a ring of `depth` blocks, the pipeline's streams on hardware queues of their own (the high-priority pool),
+ * a pool of copy threads that lives with the process (stage + un-stage of an iteration as one set of slices): 845 / 1 030 Mrays/s.
+ * LH_PIPE_CHUNK (rays), LH_PIPE_DEPTH (2 .. 8), LH_COPY_THREADS, LH_PIPE_NORMAL_PRIORITY, LH_PIPE_DIAG=1 (the calling thread's time). */
+#define LH_PIPE_CHUNK_DEFAULT ((size_t)1 << 21)
+#define LH_PIPE_DEPTH_DEFAULT 3
 #define LH_PIPE_MIN   ((size_t)1 << 20)
+#define LH_COPY_SLICE ((size_t)1 << 20)
 
-static void par_copy(void *dst, const void *src, size_t bytes)
+namespace {
+struct CopyJob { char *dst; const char *src; size_t bytes; std::atomic<size_t> *left; };
+struct CopyPool {
+    std::mutex mu; std::condition_variable cv;
+    std::deque<CopyJob> q;
+    int nthreads;
+};
+CopyPool *g_pool;
+std::once_flag g_pool_once;
+
+bool pool_take(CopyPool *P, CopyJob &j, bool wait)
 {
-    const unsigned hw = std::thread::hardware_concurrency();
-    const size_t nt = bytes < ((size_t)8 << 20) ? 1 : (hw >= 16 ? 8 : (hw >= 4 ? 4 : 1));
-    if (nt == 1) { memcpy(dst, src, bytes); return; }
-    std::vector<std::thread> th;
-    const size_t per = ((bytes / nt) + 4095) & ~(size_t)4095;
-    for (size_t k = 0; k < nt; k++) {
-        const size_t b = k * per; if (b >= bytes) break;
-        const size_t e = (b + per < bytes) ? b + per : bytes;
-        th.emplace_back([=] { memcpy((char *)dst + b, (const char *)src + b, e - b); });
-    }
-    for (auto &t : th) t.join();
+    std::unique_lock<std::mutex> lk(P->mu);
+    if (wait) P->cv.wait(lk, [&] { return !P->q.empty(); });
+    if (P->q.empty()) return false;
+    j = P->q.front(); P->q.pop_front();
+    return true;
 }
+
+void pool_worker(CopyPool *P)
+{
+    for (;;) {
+        CopyJob j;
+        pool_take(P, j, true);
+        memcpy(j.dst, j.src, j.bytes);
+        j.left->fetch_sub(1, std::memory_order_release);
+    }
+}
+
+/* the pool lives as long as the process: its threads sleep on the queue and are never joined (a library that may be dlclose()d
+ * at exit must not run thread joins from a static destructor) */
+CopyPool *copy_pool()
+{
+    std::call_once(g_pool_once, [] {
+        CopyPool *P = new CopyPool();
+        const unsigned hw = std::thread::hardware_concurrency();
+        int nt = hw >= 16 ? 8 : (hw >= 4 ? 3 : 0);             /* + the calling thread */
+        const char *e = getenv("LH_COPY_THREADS");
+        if (e && atoi(e) >= 0 && atoi(e) <= 64) nt = atoi(e);
+        P->nthreads = nt;
+        for (int k = 0; k < nt; k++) std::thread(pool_worker, P).detach();
+        g_pool = P;
+    });
+    return g_pool;
+}
+
+struct CopySet {                      /* copies submitted together; run() returns when all of them are done */
+    std::vector<CopyJob> jobs;
+    std::atomic<size_t> left{0};
+    void add(void *dst, const void *src, size_t bytes)
+    {
+        for (size_t b = 0; b < bytes; b += LH_COPY_SLICE)
+            jobs.push_back({(char *)dst + b, (const char *)src + b, bytes - b < LH_COPY_SLICE ? bytes - b : LH_COPY_SLICE, &left});
+    }
+    void run()
+    {
+        if (jobs.empty()) return;
+        CopyPool *P = copy_pool();
+        left.store(jobs.size(), std::memory_order_relaxed);
+        if (P->nthreads == 0) { for (auto &j : jobs) memcpy(j.dst, j.src, j.bytes); jobs.clear(); return; }
+        { std::lock_guard<std::mutex> lk(P->mu); for (auto &j : jobs) P->q.push_back(j); }
+        P->cv.notify_all();
+        CopyJob j;                    /* the caller copies too (any set's slices), then waits for its own set's stragglers */
+        while (left.load(std::memory_order_acquire) != 0 && pool_take(P, j, false)) { memcpy(j.dst, j.src, j.bytes); j.left->fetch_sub(1, std::memory_order_release); }
+        while (left.load(std::memory_order_acquire) != 0) LH_CPU_RELAX();
+        jobs.clear();
+    }
+};
+}  // namespace
 
 static int pipe_init(lh_accel_t *a)
 {
     if (a->pipe.ready) return 0;
-    const size_t C = LH_PIPE_CHUNK;
+    size_t C = LH_PIPE_CHUNK_DEFAULT; int depth = LH_PIPE_DEPTH_DEFAULT;
+    const char *e = getenv("LH_PIPE_CHUNK");
+    if (e && atoll(e) >= (1 << 16) && atoll(e) <= (1 << 24)) C = (size_t)atoll(e);
+    e = getenv("LH_PIPE_DEPTH");
+    if (e && atoi(e) >= 2 && atoi(e) <= LH_PIPE_DEPTH_MAX) depth = atoi(e);
     const size_t in_b = sizeof(double) * 6 * C, out_b = (sizeof(double) * 3 + sizeof(uint32_t)) * C;
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < depth; b++) {
         HIPCHK(hipHostMalloc(&a->pipe.h_in[b], in_b, hipHostMallocDefault));
         HIPCHK(hipHostMalloc(&a->pipe.h_out[b], out_b, hipHostMallocDefault));
         HIPCHK(hipMalloc(&a->pipe.d_in[b], in_b));
         HIPCHK(hipMalloc(&a->pipe.d_out[b], out_b));
-        HIPCHK(hipStreamCreateWithFlags(&a->pipe.s[b], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&a->pipe.in_done[b], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&a->pipe.done[b], hipEventDisableTiming));
     }
-    a->pipe.cap = C; a->pipe.ready = 1;
+    /* the three streams come from the HIGH-priority pool of hardware queues: the runtime maps the streams of one priority onto four
+     * hardware queues (GPU_MAX_HW_QUEUES), and this process has more than four at normal priority by now (the caller's, the accelerator's,
+     * one per fix-up queue) -- two of the pipeline's stages on ONE in-order hardware queue run one after the other whatever the streams
+     * say (closest hit 665 Mrays/s; with the stages on queues of their own 850: profiles/r06_hostpath.txt) */
+    int prio_least = 0, prio_greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    static const bool normal_prio = getenv("LH_PIPE_NORMAL_PRIORITY") != NULL;
+    for (int b = 0; b < 3; b++) HIPCHK(hipStreamCreateWithPriority(&a->pipe.s[b], hipStreamNonBlocking, normal_prio ? 0 : prio_greatest));
+    a->pipe.cap = C; a->pipe.depth = depth; a->pipe.ready = 1;
     return 0;
 }
 
@@ -250,41 +332,66 @@ static int intersect_host_pipelined(lh_accel_t *a, size_t n, const double *org, 
                                     uint32_t *prim, double *t, double *u, double *v, uint8_t *occ, int mode)
 {
     if (pipe_init(a) != 0) return -1;
-    const size_t C = a->pipe.cap, nchunks = (n + C - 1) / C;
+    const size_t C = a->pipe.cap, nchunks = (n + C - 1) / C, D = (size_t)a->pipe.depth;
+    CopySet cs;
     auto unstage = [&](size_t k) {
-        const int b = (int)(k & 1); const size_t first = k * C, m = (first + C <= n) ? C : n - first;
+        const size_t b = k % D, first = k * C, m = (first + C <= n) ? C : n - first;
         const char *ho = (const char *)a->pipe.h_out[b];
         if (mode == LH_MODE_CLOSEST) {
-            if (t) par_copy(t + first, ho, sizeof(double) * m);
-            if (u) par_copy(u + first, ho + sizeof(double) * C, sizeof(double) * m);
-            if (v) par_copy(v + first, ho + 2 * sizeof(double) * C, sizeof(double) * m);
-            if (prim) par_copy(prim + first, ho + 3 * sizeof(double) * C, sizeof(uint32_t) * m);
-        } else if (occ) par_copy(occ + first, ho, m);
+            if (t) cs.add(t + first, ho, sizeof(double) * m);
+            if (u) cs.add(u + first, ho + sizeof(double) * C, sizeof(double) * m);
+            if (v) cs.add(v + first, ho + 2 * sizeof(double) * C, sizeof(double) * m);
+            if (prim) cs.add(prim + first, ho + 3 * sizeof(double) * C, sizeof(uint32_t) * m);
+        } else if (occ) cs.add(occ + first, ho, m);
     };
+    size_t unstaged = 0;              /* chunks [0, unstaged) are back in the caller's arrays */
+    static const bool diag = getenv("LH_PIPE_DIAG") != NULL;          /* where the calling thread's time goes: waits / copies / enqueues, ms */
+    double t_wait = 0, t_copy = 0, t_enq = 0;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (size_t k = 0; k < nchunks; k++) {
-        const int b = (int)(k & 1); const size_t first = k * C, m = (first + C <= n) ? C : n - first;
-        if (k >= 2) { HIPCHK(hipEventSynchronize(a->pipe.done[b])); unstage(k - 2); }
+        const size_t b = k % D, first = k * C, m = (first + C <= n) ? C : n - first;
+        /* block b is free once chunk k - depth has been un-staged: wait for that one; take along every later chunk that has come back */
+        double c0 = diag ? now() : 0;
+        if (k >= D) { HIPCHK(hipEventSynchronize(a->pipe.done[b])); }
+        double c1 = diag ? now() : 0; t_wait += c1 - c0;
+        while (unstaged < k && (unstaged + D <= k || hipEventQuery(a->pipe.done[unstaged % D]) == hipSuccess)) unstage(unstaged++);
+        (void)hipGetLastError();          /* a query that says "not ready" must not be the next launch check's last error */
         char *hi = (char *)a->pipe.h_in[b], *di = (char *)a->pipe.d_in[b], *dout = (char *)a->pipe.d_out[b];
-        par_copy(hi, org + 3 * first, sizeof(double) * 3 * m);
-        par_copy(hi + sizeof(double) * 3 * C, dir + 3 * first, sizeof(double) * 3 * m);
-        hipStream_t s = a->pipe.s[b];
-        HIPCHK(hipMemcpyAsync(di, hi, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(di + sizeof(double) * 3 * C, hi + sizeof(double) * 3 * C, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s));
+        cs.add(hi, org + 3 * first, sizeof(double) * 3 * m);
+        cs.add(hi + sizeof(double) * 3 * C, dir + 3 * first, sizeof(double) * 3 * m);
+        cs.run();
+        double c2 = diag ? now() : 0; t_copy += c2 - c1;
+        /* the rays go up on a stream of their own; trace + records down alternate between two more: chunk k + 1's rays cross the link while
+         * chunk k is traced, and its launch may start while chunk k's records go back (the runtime moves those with a copy KERNEL, which
+         * shares the chip with the launch).  Rounds 2-5 ran whole chunks -- up, trace, down -- on two alternating streams: both fell into
+         * step (two uploads sharing the link, then two launches sharing the chip, then two downloads) and nothing overlapped:
+         * profiles/r06_hostpath.txt */
+        hipStream_t s_in = a->pipe.s[0], s_tr = a->pipe.s[1 + (k & 1)];
+        if (m == C) HIPCHK(hipMemcpyAsync(di, hi, sizeof(double) * 6 * C, hipMemcpyHostToDevice, s_in));
+        else {
+            HIPCHK(hipMemcpyAsync(di, hi, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s_in));
+            HIPCHK(hipMemcpyAsync(di + sizeof(double) * 3 * C, hi + sizeof(double) * 3 * C, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s_in));
+        }
+        HIPCHK(hipEventRecord(a->pipe.in_done[b], s_in));
+        HIPCHK(hipStreamWaitEvent(s_tr, a->pipe.in_done[b], 0));
         double *d_t = (double *)dout, *d_u = d_t + C, *d_v = d_u + C; uint32_t *d_prim = (uint32_t *)(d_v + C);
-        const int rc = lh_launch(a, m, di, di + sizeof(double) * 3 * C, d_prim, d_t, d_u, d_v, (uint8_t *)dout, mode, LH_VARIANT_DEFAULT, NULL, s, true);
+        const int rc = lh_launch(a, m, di, di + sizeof(double) * 3 * C, d_prim, d_t, d_u, d_v, (uint8_t *)dout, mode, LH_VARIANT_DEFAULT, NULL, s_tr, true);
         if (rc != 0) return rc;
         char *ho = (char *)a->pipe.h_out[b];
         if (mode == LH_MODE_CLOSEST) {
-            if (t) HIPCHK(hipMemcpyAsync(ho, d_t, sizeof(double) * m, hipMemcpyDeviceToHost, s));
-            if (u) HIPCHK(hipMemcpyAsync(ho + sizeof(double) * C, d_u, sizeof(double) * m, hipMemcpyDeviceToHost, s));
-            if (v) HIPCHK(hipMemcpyAsync(ho + 2 * sizeof(double) * C, d_v, sizeof(double) * m, hipMemcpyDeviceToHost, s));
-            if (prim) HIPCHK(hipMemcpyAsync(ho + 3 * sizeof(double) * C, d_prim, sizeof(uint32_t) * m, hipMemcpyDeviceToHost, s));
-        } else if (occ) HIPCHK(hipMemcpyAsync(ho, dout, m, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipEventRecord(a->pipe.done[b], s));
+            if (t) HIPCHK(hipMemcpyAsync(ho, d_t, sizeof(double) * m, hipMemcpyDeviceToHost, s_tr));
+            if (u) HIPCHK(hipMemcpyAsync(ho + sizeof(double) * C, d_u, sizeof(double) * m, hipMemcpyDeviceToHost, s_tr));
+            if (v) HIPCHK(hipMemcpyAsync(ho + 2 * sizeof(double) * C, d_v, sizeof(double) * m, hipMemcpyDeviceToHost, s_tr));
+            if (prim) HIPCHK(hipMemcpyAsync(ho + 3 * sizeof(double) * C, d_prim, sizeof(uint32_t) * m, hipMemcpyDeviceToHost, s_tr));
+        } else if (occ) HIPCHK(hipMemcpyAsync(ho, dout, m, hipMemcpyDeviceToHost, s_tr));
+        HIPCHK(hipEventRecord(a->pipe.done[b], s_tr));
+        if (diag) t_enq += now() - c2;
     }
-    for (size_t k = (nchunks >= 2 ? nchunks - 2 : 0); k < nchunks; k++) {
-        HIPCHK(hipEventSynchronize(a->pipe.done[k & 1])); unstage(k);
+    const double c3 = diag ? now() : 0;
+    for (; unstaged < nchunks; unstaged++) {
+        HIPCHK(hipEventSynchronize(a->pipe.done[unstaged % D])); unstage(unstaged); cs.run();
     }
+    if (diag) fprintf(stderr, "[lucille_hip] pipelined host batch: %zu chunks of %zu rays, ring of %zu: waits %.2f ms, copies %.2f, enqueues %.2f, tail %.2f\n", nchunks, C, D, t_wait, t_copy, t_enq, now() - c3);
     return 0;
 }
 

@@ -145,6 +145,25 @@ def test_large_host_batches_are_pipelined_in_chunks():
     assert_hits_equal(tuple(g[:100000] for g in got), ex.intersect(org[:100000], dr[:100000], nthreads=16), "pipelined host path prefix")
 
 
+@pytest.mark.parametrize("chunk,depth,threads", [(131072, 2, 3), (196608, 3, 0), (65536, 8, 8)])
+def test_pipelined_host_batches_reuse_their_ring_of_staging_blocks(monkeypatch, chunk, depth, threads):
+    """the same path with small chunks: 1.3 M rays are 7 .. 20 chunks through a ring of 2 / 3 / 8 staging blocks (every block is
+    reused, the last chunk is ragged), copied by the pool's threads or by the caller alone; two such calls on one accelerator"""
+    import torch
+    monkeypatch.setenv("LH_PIPE_CHUNK", str(chunk)); monkeypatch.setenv("LH_PIPE_DEPTH", str(depth)); monkeypatch.setenv("LH_COPY_THREADS", str(threads))
+    P, idx, org, dr = po.soup(60000, (1 << 20) + 250001, 0.01, 21)
+    acc = make_accel(P, idx)
+    o_, d_ = torch_rays(org, dr)
+    dev = acc.intersect_device(o_, d_); occ_dev = acc.intersect_device(o_, d_, mode=la.MODE_ANY)[0]
+    torch.cuda.synchronize()
+    for _ in range(2):
+        got = acc.intersect_host(org, dr)
+        assert np.array_equal(got[0], dev[0].cpu().numpy().view(np.uint32))
+        for k in (1, 2, 3):
+            assert np.array_equal(got[k], dev[k].cpu().numpy())
+        assert np.array_equal(acc.intersect_host(org, dr, mode=la.MODE_ANY), occ_dev.cpu().numpy())
+
+
 def test_concurrent_host_threads_like_the_reference_render_threads():
     """lucille calls accel->intersect from up to 16 pthreads at once (render.c:1043-1105): batches of
     different sizes and single rays from 12 threads through ONE accelerator, every record exact"""
