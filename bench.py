@@ -166,7 +166,10 @@ def main():
     gathered = None
     if world > 1 and rank == 0:
         gathered = [torch.empty((world, per * wire_bytes), dtype=torch.uint8, device=dev) for _ in range(nchunks)]
-    gstream = torch.cuda.Stream(device=dev) if world > 1 else None       # the exchange step's own stream: chunk c on the links while chunk c + 1 is traced
+    # the exchange step's own stream: chunk c on the links while chunk c + 1 is traced.  HIGH priority = a hardware queue from another pool than
+    # the trace stream's: the runtime maps the streams of one priority onto four in-order hardware queues, and two streams on one queue run one
+    # after the other whatever the events say (seen on the host batch path: profiles/r06_hostpath.txt)
+    gstream = torch.cuda.Stream(device=dev, priority=-1) if world > 1 else None
 
     hip = hip_events()
     stream = torch.cuda.current_stream(dev)

@@ -221,9 +221,9 @@ int lh_ensure_stage(lh_accel_t *a, size_t bytes)
  * 640 any hit (S-soup-1M, 20 M rays) where the link alone does 57 GB/s each way = 1 190 Mrays/s of 48-byte rays.  Round 6 looked at the
  * timeline (profiles/r06_hostpath.txt): the host's copies were NOT the bound (3 .. 12 threads, memcpy or streaming stores: the same) --
  * the two streams ran in step, and streams that share one of the runtime's four hardware queues run one after the other.  Now: a stream
- * per direction of the link, a ring of `depth` blocks, the pipeline's streams on hardware queues of their own (the high-priority pool),
+ * per direction of the link, a ring of `depth` blocks, the pipeline's streams on hardware queues of their own (the low-priority pool),
  * a pool of copy threads that lives with the process (stage + un-stage of an iteration as one set of slices): 845 / 1 030 Mrays/s.
- * LH_PIPE_CHUNK (rays), LH_PIPE_DEPTH (2 .. 8), LH_COPY_THREADS, LH_PIPE_NORMAL_PRIORITY, LH_PIPE_DIAG=1 (the calling thread's time). */
+ * LH_PIPE_CHUNK (rays), LH_PIPE_DEPTH (2 .. 8), LH_COPY_THREADS, LH_PIPE_PRIORITY, LH_PIPE_DIAG=1 (the calling thread's time). */
 #define LH_PIPE_CHUNK_DEFAULT ((size_t)1 << 21)
 #define LH_PIPE_DEPTH_DEFAULT 3
 #define LH_PIPE_MIN   ((size_t)1 << 20)
@@ -316,14 +316,17 @@ static int pipe_init(lh_accel_t *a)
         HIPCHK(hipEventCreateWithFlags(&a->pipe.in_done[b], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&a->pipe.done[b], hipEventDisableTiming));
     }
-    /* the three streams come from the HIGH-priority pool of hardware queues: the runtime maps the streams of one priority onto four
-     * hardware queues (GPU_MAX_HW_QUEUES), and this process has more than four at normal priority by now (the caller's, the accelerator's,
-     * one per fix-up queue) -- two of the pipeline's stages on ONE in-order hardware queue run one after the other whatever the streams
-     * say (closest hit 665 Mrays/s; with the stages on queues of their own 850: profiles/r06_hostpath.txt) */
+    /* the three streams come from the LOW-priority pool of hardware queues: the runtime maps the streams of one priority onto four
+     * hardware queues (GPU_MAX_HW_QUEUES), this process has more than four at normal priority by now (the caller's, the accelerator's,
+     * other accelerators') and the fix-up queues' consumer streams fill the high-priority pool (lh_aoq_slot) -- two of the pipeline's
+     * stages on ONE in-order hardware queue run one after the other whatever the streams say (closest hit 660 Mrays/s; with the stages
+     * on queues of their own 850: profiles/r06_hostpath.txt).  LH_PIPE_PRIORITY = -1 / 0 / 1: high / normal / low */
     int prio_least = 0, prio_greatest = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    static const bool normal_prio = getenv("LH_PIPE_NORMAL_PRIORITY") != NULL;
-    for (int b = 0; b < 3; b++) HIPCHK(hipStreamCreateWithPriority(&a->pipe.s[b], hipStreamNonBlocking, normal_prio ? 0 : prio_greatest));
+    int prio = prio_least;
+    e = getenv("LH_PIPE_PRIORITY");
+    if (e) prio = atoi(e) < 0 ? prio_greatest : (atoi(e) > 0 ? prio_least : 0);
+    for (int b = 0; b < 3; b++) HIPCHK(hipStreamCreateWithPriority(&a->pipe.s[b], hipStreamNonBlocking, prio));
     a->pipe.cap = C; a->pipe.depth = depth; a->pipe.ready = 1;
     return 0;
 }
