@@ -226,7 +226,7 @@ int lh_ensure_stage(lh_accel_t *a, size_t bytes)
  * LH_PIPE_CHUNK (rays), LH_PIPE_DEPTH (2 .. 8), LH_COPY_THREADS, LH_PIPE_PRIORITY, LH_PIPE_DIAG=1 (the calling thread's time). */
 #define LH_PIPE_CHUNK_DEFAULT ((size_t)1 << 21)
 #define LH_PIPE_DEPTH_DEFAULT 3
-#define LH_PIPE_MIN   ((size_t)1 << 20)
+#define LH_PIPE_MIN   ((size_t)1 << 21)   /* below it the plain path (pageable copies, one launch) is as fast or faster: profiles/r06_hostpath.txt 7 */
 #define LH_COPY_SLICE ((size_t)1 << 20)
 
 namespace {
@@ -335,16 +335,21 @@ static int intersect_host_pipelined(lh_accel_t *a, size_t n, const double *org, 
                                     uint32_t *prim, double *t, double *u, double *v, uint8_t *occ, int mode)
 {
     if (pipe_init(a) != 0) return -1;
-    const size_t C = a->pipe.cap, nchunks = (n + C - 1) / C, D = (size_t)a->pipe.depth;
+    /* CAP: rays a staging block holds (the arrays inside it are CAP apart); C: rays per chunk of THIS batch -- a batch of less than four
+     * blocks is cut in four, so that its upload, launch and download overlap too (2 / 3 / 6 pieces: no better, tools/hostpath_sizes.py) */
+    const size_t CAP = a->pipe.cap, D = (size_t)a->pipe.depth;
+    size_t C = CAP;
+    if (n < 4 * CAP) { C = ((n + 3) / 4 + 4095) & ~(size_t)4095; if (C < ((size_t)1 << 16)) C = (size_t)1 << 16; if (C > CAP) C = CAP; }
+    const size_t nchunks = (n + C - 1) / C;
     CopySet cs;
     auto unstage = [&](size_t k) {
         const size_t b = k % D, first = k * C, m = (first + C <= n) ? C : n - first;
         const char *ho = (const char *)a->pipe.h_out[b];
         if (mode == LH_MODE_CLOSEST) {
             if (t) cs.add(t + first, ho, sizeof(double) * m);
-            if (u) cs.add(u + first, ho + sizeof(double) * C, sizeof(double) * m);
-            if (v) cs.add(v + first, ho + 2 * sizeof(double) * C, sizeof(double) * m);
-            if (prim) cs.add(prim + first, ho + 3 * sizeof(double) * C, sizeof(uint32_t) * m);
+            if (u) cs.add(u + first, ho + sizeof(double) * CAP, sizeof(double) * m);
+            if (v) cs.add(v + first, ho + 2 * sizeof(double) * CAP, sizeof(double) * m);
+            if (prim) cs.add(prim + first, ho + 3 * sizeof(double) * CAP, sizeof(uint32_t) * m);
         } else if (occ) cs.add(occ + first, ho, m);
     };
     size_t unstaged = 0;              /* chunks [0, unstaged) are back in the caller's arrays */
@@ -361,7 +366,7 @@ static int intersect_host_pipelined(lh_accel_t *a, size_t n, const double *org, 
         (void)hipGetLastError();          /* a query that says "not ready" must not be the next launch check's last error */
         char *hi = (char *)a->pipe.h_in[b], *di = (char *)a->pipe.d_in[b], *dout = (char *)a->pipe.d_out[b];
         cs.add(hi, org + 3 * first, sizeof(double) * 3 * m);
-        cs.add(hi + sizeof(double) * 3 * C, dir + 3 * first, sizeof(double) * 3 * m);
+        cs.add(hi + sizeof(double) * 3 * CAP, dir + 3 * first, sizeof(double) * 3 * m);
         cs.run();
         double c2 = diag ? now() : 0; t_copy += c2 - c1;
         /* the rays go up on a stream of their own; trace + records down alternate between two more: chunk k + 1's rays cross the link while
@@ -370,22 +375,22 @@ static int intersect_host_pipelined(lh_accel_t *a, size_t n, const double *org, 
          * step (two uploads sharing the link, then two launches sharing the chip, then two downloads) and nothing overlapped:
          * profiles/r06_hostpath.txt */
         hipStream_t s_in = a->pipe.s[0], s_tr = a->pipe.s[1 + (k & 1)];
-        if (m == C) HIPCHK(hipMemcpyAsync(di, hi, sizeof(double) * 6 * C, hipMemcpyHostToDevice, s_in));
+        if (m == CAP) HIPCHK(hipMemcpyAsync(di, hi, sizeof(double) * 6 * CAP, hipMemcpyHostToDevice, s_in));
         else {
             HIPCHK(hipMemcpyAsync(di, hi, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s_in));
-            HIPCHK(hipMemcpyAsync(di + sizeof(double) * 3 * C, hi + sizeof(double) * 3 * C, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s_in));
+            HIPCHK(hipMemcpyAsync(di + sizeof(double) * 3 * CAP, hi + sizeof(double) * 3 * CAP, sizeof(double) * 3 * m, hipMemcpyHostToDevice, s_in));
         }
         HIPCHK(hipEventRecord(a->pipe.in_done[b], s_in));
         HIPCHK(hipStreamWaitEvent(s_tr, a->pipe.in_done[b], 0));
-        double *d_t = (double *)dout, *d_u = d_t + C, *d_v = d_u + C; uint32_t *d_prim = (uint32_t *)(d_v + C);
-        const int rc = lh_launch(a, m, di, di + sizeof(double) * 3 * C, d_prim, d_t, d_u, d_v, (uint8_t *)dout, mode, LH_VARIANT_DEFAULT, NULL, s_tr, true);
+        double *d_t = (double *)dout, *d_u = d_t + CAP, *d_v = d_u + CAP; uint32_t *d_prim = (uint32_t *)(d_v + CAP);
+        const int rc = lh_launch(a, m, di, di + sizeof(double) * 3 * CAP, d_prim, d_t, d_u, d_v, (uint8_t *)dout, mode, LH_VARIANT_DEFAULT, NULL, s_tr, true);
         if (rc != 0) return rc;
         char *ho = (char *)a->pipe.h_out[b];
         if (mode == LH_MODE_CLOSEST) {
             if (t) HIPCHK(hipMemcpyAsync(ho, d_t, sizeof(double) * m, hipMemcpyDeviceToHost, s_tr));
-            if (u) HIPCHK(hipMemcpyAsync(ho + sizeof(double) * C, d_u, sizeof(double) * m, hipMemcpyDeviceToHost, s_tr));
-            if (v) HIPCHK(hipMemcpyAsync(ho + 2 * sizeof(double) * C, d_v, sizeof(double) * m, hipMemcpyDeviceToHost, s_tr));
-            if (prim) HIPCHK(hipMemcpyAsync(ho + 3 * sizeof(double) * C, d_prim, sizeof(uint32_t) * m, hipMemcpyDeviceToHost, s_tr));
+            if (u) HIPCHK(hipMemcpyAsync(ho + sizeof(double) * CAP, d_u, sizeof(double) * m, hipMemcpyDeviceToHost, s_tr));
+            if (v) HIPCHK(hipMemcpyAsync(ho + 2 * sizeof(double) * CAP, d_v, sizeof(double) * m, hipMemcpyDeviceToHost, s_tr));
+            if (prim) HIPCHK(hipMemcpyAsync(ho + 3 * sizeof(double) * CAP, d_prim, sizeof(uint32_t) * m, hipMemcpyDeviceToHost, s_tr));
         } else if (occ) HIPCHK(hipMemcpyAsync(ho, dout, m, hipMemcpyDeviceToHost, s_tr));
         HIPCHK(hipEventRecord(a->pipe.done[b], s_tr));
         if (diag) t_enq += now() - c2;
@@ -407,7 +412,8 @@ extern "C" int lh_accel_intersect_host(lh_accel_t *a, size_t n, const double *or
     if (!org || !dir) return fail("intersect: NULL ray arrays");
     if (mode != LH_MODE_CLOSEST && mode != LH_MODE_ANY) return fail("intersect: unknown mode %d", mode);
     HIPCHK(hipSetDevice(a->device));
-    if (n >= LH_PIPE_MIN && !a->stat_on && !getenv("LH_HOST_SIMPLE"))
+    static const size_t pipe_min = getenv("LH_PIPE_MIN") && atoll(getenv("LH_PIPE_MIN")) > 0 ? (size_t)atoll(getenv("LH_PIPE_MIN")) : LH_PIPE_MIN;
+    if (n >= pipe_min && !a->stat_on && !getenv("LH_HOST_SIMPLE"))
         return intersect_host_pipelined(a, n, org, dir, prim, t, u, v, occ, mode);
     /* layout of the staging block: org | dir | t | u | v | prim | occ */
     const size_t b_ray = sizeof(double) * 3 * n, b_d = sizeof(double) * n;

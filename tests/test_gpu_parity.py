@@ -125,7 +125,7 @@ def test_host_batch_and_single_ray_entry_points():
 
 
 def test_large_host_batches_are_pipelined_in_chunks():
-    """>= 1 M rays from host arrays go through pinned staging in 2 M-ray chunks on two streams: same records
+    """>= 2 M rays from host arrays go through a ring of pinned staging blocks (a batch of less than four blocks in four chunks): same records
     as the device path, ragged last chunk, both modes, optional outputs left out"""
     import torch
     P, idx, org, dr = po.soup(200000, 5 * (1 << 20) + 12345, 0.005, 4)
@@ -147,11 +147,11 @@ def test_large_host_batches_are_pipelined_in_chunks():
 
 @pytest.mark.parametrize("chunk,depth,threads", [(131072, 2, 3), (196608, 3, 0), (65536, 8, 8)])
 def test_pipelined_host_batches_reuse_their_ring_of_staging_blocks(monkeypatch, chunk, depth, threads):
-    """the same path with small chunks: 1.3 M rays are 7 .. 20 chunks through a ring of 2 / 3 / 8 staging blocks (every block is
+    """the same path with small chunks: 2.3 M rays are 12 .. 36 chunks through a ring of 2 / 3 / 8 staging blocks (every block is
     reused, the last chunk is ragged), copied by the pool's threads or by the caller alone; two such calls on one accelerator"""
     import torch
     monkeypatch.setenv("LH_PIPE_CHUNK", str(chunk)); monkeypatch.setenv("LH_PIPE_DEPTH", str(depth)); monkeypatch.setenv("LH_COPY_THREADS", str(threads))
-    P, idx, org, dr = po.soup(60000, (1 << 20) + 250001, 0.01, 21)
+    P, idx, org, dr = po.soup(60000, (1 << 21) + 250001, 0.01, 21)
     acc = make_accel(P, idx)
     o_, d_ = torch_rays(org, dr)
     dev = acc.intersect_device(o_, d_); occ_dev = acc.intersect_device(o_, d_, mode=la.MODE_ANY)[0]
