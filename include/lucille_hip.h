@@ -130,7 +130,10 @@ int  lh_accel_intersect_diag_device(lh_accel_t *accel, size_t n, const void *d_o
  * out[0] = launches, out[1] = rays they carried since the last clear. */
 int  lh_accel_combine_statistics(lh_accel_t *accel, uint64_t out[2], int clear);
 
-/* host-resident batch: H2D, kernel, D2H on the accel's own stream */
+/* host-resident batch (the batch form of accel_intersect_func, accel.h:30-34: rays and records in the caller's arrays).  Below 2 M rays:
+ * copy up, one launch, copy down on the accel's own stream.  From 2 M rays: chunks through a ring of pinned staging blocks -- the rays of
+ * chunk k + 1 cross the link while chunk k is traced and chunk k - 1's records go back (lh_query.hip; 860 Mrays/s closest hit over PCIe,
+ * profiles/r06_hostpath.txt).  Outputs the caller does not need may be NULL.  Synchronous: the arrays are complete on return */
 int  lh_accel_intersect_host(lh_accel_t *accel, size_t n, const double *org_xyz,
                              const double *dir_xyz, uint32_t *prim, double *t, double *u,
                              double *v, uint8_t *occluded, int mode);
