@@ -106,11 +106,9 @@ __global__ __launch_bounds__(256) void k_prim_boxes(uint32_t n, const double *__
             }
             if (cls) { plo[3 * (size_t)p] = __uint_as_float(0x7fc00000u); ndead++; noise |= (uint32_t)(cls == 2); }
         }
-        if (!cls) {                                  /* tri_zero_area_s2 (lh_bvh.c), operation for operation */
-            const double e1x = t[3] - t[0], e1y = t[4] - t[1], e1z = t[5] - t[2], e2x = t[6] - t[0], e2y = t[7] - t[1], e2z = t[8] - t[2];
-            const double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
-            const double s2 = (fabs(e1x) + fabs(e1y) + fabs(e1z)) * (fabs(e2x) + fabs(e2y) + fabs(e2z));
-            if (fmax(fabs(nx), fmax(fabs(ny), fabs(nz))) <= 8.9e-16 * s2) s2keep = fmaxf(s2keep, f_up(s2));
+        if (!cls) {                                  /* lh_bvh.h lh_zero_area_weight: what lh_bvh.c tri_zero_area_s2 calls */
+            const double w = lh_zero_area_weight(t, t + 3, t + 6);
+            if (w > 0.0) s2keep = fmaxf(s2keep, f_up(w));
         }
     }
     for (int off = 32; off >= 1; off >>= 1) s2keep = fmaxf(s2keep, __shfl_xor(s2keep, off));

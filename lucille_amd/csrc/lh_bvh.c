@@ -815,12 +815,7 @@ static int tri_dead_class(const lh_tri64_t *t)
  * D <= 1 / s2.  Returns s2 (0: the triangle has area, or an edge of length zero -- class 1, exactly a = 0). */
 static double tri_zero_area_s2(const lh_tri64_t *t)
 {
-    const double *a = t->v[0], *b = t->v[1], *c = t->v[2];
-    const double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
-    const double nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
-    const double s2 = (fabs(e1[0]) + fabs(e1[1]) + fabs(e1[2])) * (fabs(e2[0]) + fabs(e2[1]) + fabs(e2[2]));
-    const double m = fmax(fabs(nx), fmax(fabs(ny), fabs(nz)));
-    return (m <= 8.9e-16 * s2) ? s2 : 0.0;
+    return lh_zero_area_weight(t->v[0], t->v[1], t->v[2]);          /* round 6: lh_bvh.h -- also near-collinear triangles, with the bound that fits them */
 }
 
 /* triangles [a0, a1) of one mesh: fp64 vertices, primitive -> (geom, index), fp32 outward box, centroid */

@@ -13,6 +13,7 @@
 #ifndef LH_BVH_H
 #define LH_BVH_H
 
+#include <math.h>
 #include <stdint.h>
 #include <stddef.h>
 
@@ -99,6 +100,37 @@ typedef struct lh_bvh {
 #define LH_DANGER_MAX   16u
 #define LH_DANGER_ALL   0u             /* zero-initialised state = the safe one */
 #define LH_DEG_DCAP_ALL 1024.0         /* = lh_bvh.c LH_DEG_DCAP: beyond it the triangles LEFT OUT of the tree (v1 == v2, short) are no longer provably missed */
+
+/* ---- triangles whose determinant is the reference's rounding noise (lh_bvh.c prep_part, lh_build.hip k_prim_boxes, lh_commit.hip k_danger_scan) ----
+ * The reference's a = e1 . (dir x e2) = dir . n is computed in fp64 with ~15 u D s2 of evaluation noise (u = 2^-53, D = max |dir_k|,
+ * s2 = |e1|_1 |e2|_1).  For a triangle whose normal is no larger than that noise by many orders -- three points on a line, exactly or up to
+ * the rounding of their coordinates (|n| ~ u s2 |P| / |e|: a collinear triangle far from the origin), a sliver of aspect below 1e-9 -- u, v
+ * and t are then noise as well: the reference reports "hits" on rays that merely reach the triangle's leaf in ITS tree, at a t that need
+ * not lie inside the triangle's box.  Such a triangle is vouched for by the traversal tree only for rays the reference cannot accept on it:
+ * |a| <= D (|n_computed|_1 + 6 u s2) + 15 u D s2 < D (|n|_1 + 3e-15 s2) stays below the reference's 1e-14 (bvh.c:754) while
+ * D <= 0.9e-14 / (|n|_1 + 3e-15 s2).  Returns the reciprocal of that bound -- never less than s2, rounds 5-6's bound for max |n_k| <= 8.9e-16 s2,
+ * which the formula would relax to 1.6 / s2 -- or 0: the triangle's determinant carries at least nine digits.
+ * Round 5: max |n_k| <= 8.9e-16 s2 only.  Round 6's fourth fuzz campaign (tools/fuzz_parity.py seeds 661 / 662, kind 9): collinear triangles
+ * of |n| = 3e-15 s2 (coordinates of 8 and 9 600 units, edges of 0.1 and 100) were hit by the reference 5e-6 in t BEFORE their box, behind
+ * a nearer triangle's hit: 3 of 60 000 and 1 of 60 000 rays.  1e-9: the sliver scenes of the same fuzzer (|n| >= 2e-9 s2) have always been equal. */
+#define LH_ZERO_AREA_REL 1.0e-9
+#if defined(__HIPCC__)
+__host__ __device__ __forceinline__
+#else
+static inline
+#endif
+double lh_zero_area_weight(const double *a, const double *b, const double *c)
+{
+    const double e1x = b[0] - a[0], e1y = b[1] - a[1], e1z = b[2] - a[2], e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
+    const double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
+    const double s2 = (fabs(e1x) + fabs(e1y) + fabs(e1z)) * (fabs(e2x) + fabs(e2y) + fabs(e2z));
+    const double m = fmax(fabs(nx), fmax(fabs(ny), fabs(nz)));
+    if (!(m <= LH_ZERO_AREA_REL * s2)) return 0.0;
+    {
+        const double w = ((fabs(nx) + fabs(ny) + fabs(nz)) + 3.0e-15 * s2) / 0.9e-14;
+        return w > s2 ? w : s2;
+    }
+}
 
 typedef struct lh_mesh_view {
     uint32_t        npositions;

@@ -456,11 +456,7 @@ __global__ __launch_bounds__(256) void k_danger_scan(uint32_t n, const double *_
         const double sN = fabs(t[3] - t[0]) + fabs(t[4] - t[1]) + fabs(t[5] - t[2]);
         if (sN * sN * (1.0 + 1e-9) <= 1.0e-14 / (1.0e-15 * LH_DEG_DCAP_ALL)) return;
     }
-    /* tri_zero_area_s2 (lh_bvh.c), operation for operation */
-    const double e1x = t[3] - t[0], e1y = t[4] - t[1], e1z = t[5] - t[2], e2x = t[6] - t[0], e2y = t[7] - t[1], e2z = t[8] - t[2];
-    const double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
-    const double s2 = (fabs(e1x) + fabs(e1y) + fabs(e1z)) * (fabs(e2x) + fabs(e2y) + fabs(e2z));
-    if (!(fmax(fabs(nx), fmax(fabs(ny), fabs(nz))) <= 8.9e-16 * s2)) return;
+    if (!(lh_zero_area_weight(t, t + 3, t + 6) > 0.0)) return;          /* lh_bvh.h: the triangles lh_bvh.c tri_zero_area_s2 / lh_build.hip k_prim_boxes bound deg_dcap with */
     const unsigned long long slot = atomicAdd(count, 1ull);
     if (slot >= LH_DANGER_MAX) return;
     const int leaf = (int)leafpos[p].x, parent = lca[leaf].x;

@@ -101,3 +101,22 @@ def test_zero_area_triangles_that_stay_in_the_tree():
         assert_hits_equal(m.hostwalk(org, dr), exp, "zero-area triangles in the tree")
     finally:
         Model.ref_off()
+
+
+@pytest.mark.parametrize("name,rays,prim", [("fuzz_r06_f662_99", (1156, 6023, 6936), 29), ("fuzz_r06_f661_359", (), None)])
+def test_near_collinear_triangles_of_round_6_fuzz(name, rays, prim):
+    """two scenes of tools/fuzz_parity.py's kind 9 (seeds 662 / 661, rounds 99 / 359; saved with FUZZ_SAVE=..., the first 8000 / 4000 rays):
+    triangles whose three points were PUT on a line and then scaled and shifted -- collinear up to the rounding of coordinates of 8 and
+    9 600 units, max |n_k| = 3e-15 |e1|_1 |e2|_1, beyond round 5's 8.9e-16.  The reference reports them by its determinant's noise at a t
+    BEFORE their box, behind a nearer triangle's hit (rays 1156, 6023, 6936 of the first scene: three rays aimed at a vertex and an edge
+    of triangle 29).  lh_bvh.h lh_zero_area_weight now counts them among the triangles that bound deg_dcap"""
+    z = load_golden(name); P, idx, org, dr = z["P"], z["idx"], z["org"], z["dr"]
+    exp = oracle_of(P, idx, org, dr)
+    for r in rays:
+        assert exp[0][r] == prim
+    m = Model(P, idx); m.ref_build()
+    try:
+        assert_hits_equal(m.hostwalk(org, dr), exp, name)
+    finally:
+        Model.ref_off()
+

@@ -2,7 +2,8 @@
 with shared vertices, sliver and zero-area triangles) x rays aimed at random points, at vertices, along edges and with unnormalised
 directions, in coordinate planes, along an axis, starting on a vertex; closest-hit records and any-hit flags of the device (both builders) against the oracle, bit for bit.
 python tools/fuzz_parity.py [rounds] [seed]   -> one line per scene, a total, exit code 1 on the first mismatch.
-FUZZ_BUDGET_S=<seconds> in the environment: no new round is started after that long (tests/test_gpu_fuzz.py)."""
+FUZZ_BUDGET_S=<seconds> in the environment: no new round is started after that long (tests/test_gpu_fuzz.py).
+FUZZ_KIND=<0..9>: every round is of that kind;  FUZZ_SAVE=<file.npz> with a fifth argument (the round to replay): the scene and rays of that round, no tracing."""
 import os, sys, time
 os.environ.setdefault("LH_POISON_OUTPUTS", "1")          # an answer slot nobody writes must show up as a mismatch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,10 +16,11 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 ONLY = int(sys.argv[4]) if len(sys.argv) > 4 else -1       # replay: generate every round (the same random stream), trace only this one
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"        # big: 0.3 .. 1.5 M triangles, 400 k rays as ONE device batch (fix-up queue, cooperative walk, device builders' large paths)
+KIND = int(os.environ.get("FUZZ_KIND", "-1"))      # every round of this kind (the random stream is then another one than without it)
 total = 0; done = 0; T0 = time.time(); BUDGET = float(os.environ.get("FUZZ_BUDGET_S", "0"))
 for r in range(rounds):
     if BUDGET > 0 and time.time() - T0 > BUDGET: break
-    kind = r % 10
+    kind = r % 10 if KIND < 0 else KIND
     ntri = int(rng.choice([300000, 700000, 1500000])) if BIG else int(rng.choice([1, 2, 7, 60, 900, 12000, 150000]))
     scale = float(10.0 ** rng.uniform(-6, 6)); shift = rng.uniform(-1, 1, 3) * scale * float(rng.choice([0.0, 1.0, 100.0]))
     he = float(10.0 ** rng.uniform(-3, -0.5))
