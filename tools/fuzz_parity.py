@@ -3,13 +3,18 @@ with shared vertices, sliver and zero-area triangles) x rays aimed at random poi
 directions, in coordinate planes, along an axis, starting on a vertex; closest-hit records and any-hit flags of the device (both builders) against the oracle, bit for bit.
 python tools/fuzz_parity.py [rounds] [seed]   -> one line per scene, a total, exit code 1 on the first mismatch.
 FUZZ_BUDGET_S=<seconds> in the environment: no new round is started after that long (tests/test_gpu_fuzz.py).
+FUZZ_CPU=1: without a device -- the one-ray host walk on the host-built trees (tests/helpers.Model) against the oracle.
 FUZZ_KIND=<0..9>: every round is of that kind;  FUZZ_SAVE=<file.npz> with a fifth argument (the round to replay): the scene and rays of that round, no tracing."""
 import os, sys, time
 os.environ.setdefault("LH_POISON_OUTPUTS", "1")          # an answer slot nobody writes must show up as a mismatch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-import lucille_amd as la
+CPU = os.environ.get("FUZZ_CPU") == "1"      # no device: the product's one-ray host walk (lh_hostwalk.c through tests/helpers.Model) on the host-built trees
+if CPU:
+    from tests.helpers import Model
+else:
+    import lucille_amd as la
 from oracle import pyoracle as po
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -60,9 +65,16 @@ for r in range(rounds):
     if os.environ.get("FUZZ_SAVE"): np.savez(os.environ["FUZZ_SAVE"], P=P, idx=idx, org=org, dr=dr); print("saved round", r, "kind", kind, "scale", scale, "shift", shift, "he", he); sys.exit(0)
     o = po.Oracle(); o.add_mesh(P, idx); o.build()
     exp = o.intersect(org, dr, nthreads=16); occ = exp[0] != po.MISS            # the reference's any-hit answer: is there a closest hit
-    for build in ("host", "device"):
-        acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit(build=build)
-        if BIG:
+    for build in (("hostwalk",) if CPU else ("host", "device")):
+        if CPU:
+            m = Model(P, idx); m.ref_build()
+            try: got = m.hostwalk(org, dr)
+            finally: Model.ref_off()
+            gocc = None; acc = None
+        else:
+            acc = la.HipAccel(0); acc.add_mesh(P, idx); acc.commit(build=build)
+        if CPU: pass
+        elif BIG:
             import torch
             d_o = torch.from_numpy(org).cuda(); d_d = torch.from_numpy(dr).cuda()
             got = tuple(x.cpu().numpy() for x in acc.intersect_device(d_o, d_d)); gocc = acc.intersect_device(d_o, d_d, mode=la.MODE_ANY)[0].cpu().numpy()
@@ -75,7 +87,7 @@ for r in range(rounds):
                 print("MISMATCH round %d kind %d build %s: %s at %d rays, first %s" % (r, kind, build, name, bad.size, bad[:5])); sys.exit(1)
         if gocc is not None and not np.array_equal(np.asarray(gocc).astype(np.uint8), np.asarray(occ).astype(np.uint8)):          # raw: 0 or 1, nothing else
             print("MISMATCH round %d kind %d build %s: any-hit flags" % (r, kind, build)); sys.exit(1)
-        acc.close()
+        if acc is not None: acc.close()
     total += org.shape[0]; done += 1
     print("round %2d kind %d: %6d triangles, scale %.1e, %d rays, hits %.2f: equal on both builders" % (r, kind, tri.shape[0], scale, org.shape[0], float((exp[0] != po.MISS).mean())), flush=True)
 print("%d rays over %d scenes x 2 builders: closest-hit records and any-hit flags equal to the oracle" % (total, done))
