@@ -89,5 +89,5 @@ for r in range(rounds):
             print("MISMATCH round %d kind %d build %s: any-hit flags" % (r, kind, build)); sys.exit(1)
         if acc is not None: acc.close()
     total += org.shape[0]; done += 1
-    print("round %2d kind %d: %6d triangles, scale %.1e, %d rays, hits %.2f: equal on both builders" % (r, kind, tri.shape[0], scale, org.shape[0], float((exp[0] != po.MISS).mean())), flush=True)
-print("%d rays over %d scenes x 2 builders: closest-hit records and any-hit flags equal to the oracle" % (total, done))
+    print("round %2d kind %d: %6d triangles, scale %.1e, %d rays, hits %.2f: equal %s" % (r, kind, tri.shape[0], scale, org.shape[0], float((exp[0] != po.MISS).mean()), "(host walk)" if CPU else "on both builders"), flush=True)
+print(("%d rays over %d scenes: the one-ray host walk's closest-hit records equal to the oracle" if CPU else "%d rays over %d scenes x 2 builders: closest-hit records and any-hit flags equal to the oracle") % (total, done))
